@@ -1,0 +1,287 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding for oracle/liboracle.so (the CPU restatement of the reference step loop) and, when
+built, oracle/_ref/libedynref.so (the EnTT-free reference translation units compiled as they lie).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (edyn_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+POINT_DTYPE = np.dtype([
+    ("pivotA", np.float32, 3), ("pivotB", np.float32, 3), ("normal", np.float32, 3),
+    ("local_normal", np.float32, 3), ("distance", np.float32), ("friction", np.float32),
+    ("restitution", np.float32), ("attachment", np.int32), ("lifetime", np.uint32),
+    ("normal_impulse", np.float32), ("friction_impulse", np.float32, 2)])
+MANIFOLD_DTYPE = np.dtype([
+    ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
+
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
+KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
+JOINT_POINT, JOINT_HINGE = 0, 1
+ORDER_SEQUENTIAL, ORDER_COLOURED = 0, 1
+
+
+def build(ref=True):
+    """Compile liboracle.so (and _ref/libedynref.so when /root/reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if ref and os.path.isdir("/root/reference/src/edyn"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(x, n=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        L.orc_world_create.restype = C.c_void_p
+        L.orc_world_create.argtypes = [C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
+        L.orc_world_destroy.argtypes = [C.c_void_p]
+        L.orc_add_body.restype = C.c_uint32
+        L.orc_add_body.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_float)] * 4 + [
+            C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int,
+            C.c_uint64, C.c_uint64, C.POINTER(C.c_float)]
+        L.orc_add_joint.restype = C.c_uint32
+        L.orc_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_float)] * 4
+        L.orc_step.argtypes = [C.c_void_p, C.c_int]
+        L.orc_run_stage.argtypes = [C.c_void_p, C.c_int]
+        L.orc_num_bodies.restype = C.c_uint32
+        L.orc_num_bodies.argtypes = [C.c_void_p]
+        L.orc_get_state.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
+        L.orc_set_state.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
+        L.orc_get_derived.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_num_manifolds.restype = C.c_uint32
+        L.orc_num_manifolds.argtypes = [C.c_void_p]
+        L.orc_get_manifolds.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_manifolds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_get_joint_impulses.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_time_steps.restype = C.c_double
+        L.orc_time_steps.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sizeof_manifold_rec.restype = C.c_uint32
+        assert L.orc_sizeof_manifold_rec() == MANIFOLD_DTYPE.itemsize
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The real reference leaf functions (None if oracle/_ref was not built)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libedynref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+    return _ref
+
+
+class _Leaf:
+    """Leaf functions exported under a prefix ('orc_' restatement, 'ref_' real reference)."""
+
+    def __init__(self, L, prefix):
+        self.L, self.p = L, prefix
+
+    def _f(self, name):
+        return getattr(self.L, self.p + name)
+
+    def intersect_line_aabb(self, p0, p1, bmin, bmax):
+        s = np.zeros(2, np.float32)
+        f = self._f("intersect_line_aabb"); f.restype = C.c_int
+        n = f(_fp(_f32(p0, 2)), _fp(_f32(p1, 2)), _fp(_f32(bmin, 2)), _fp(_f32(bmax, 2)), _fp(s))
+        return n, s
+
+    def plane_space(self, n):
+        p = np.zeros(3, np.float32); q = np.zeros(3, np.float32)
+        self._f("plane_space")(_fp(_f32(n, 3)), _fp(p), _fp(q))
+        return p, q
+
+    def integrate(self, q, w, dt):
+        out = np.zeros(4, np.float32)
+        f = self._f("integrate"); f.argtypes = [C.POINTER(C.c_float)] * 2 + [C.c_float, C.POINTER(C.c_float)]
+        f(_fp(_f32(q, 4)), _fp(_f32(w, 3)), dt, _fp(out))
+        return out
+
+    def rotate(self, q, v):
+        out = np.zeros(3, np.float32)
+        self._f("rotate")(_fp(_f32(q, 4)), _fp(_f32(v, 3)), _fp(out))
+        return out
+
+    def insertion_point_index(self, pts, num_points, new_point):
+        n = C.c_int(num_points)
+        f = self._f("insertion_point_index"); f.restype = C.c_int
+        r = f(_fp(_f32(pts, 12)), C.byref(n), _fp(_f32(new_point, 3)))
+        return r & 0xFF, r >> 8, n.value
+
+    def closest_segment_segment(self, p1, q1, p2, q2):
+        st = np.zeros(4, np.float32); c = np.zeros(12, np.float32); num = C.c_int(0)
+        f = self._f("closest_segment_segment"); f.restype = C.c_float
+        d = f(_fp(_f32(p1, 3)), _fp(_f32(q1, 3)), _fp(_f32(p2, 3)), _fp(_f32(q2, 3)), _fp(st), _fp(c), C.byref(num))
+        return np.float32(d), st, c, num.value
+
+    def box_support_feature(self, h, direction, threshold):
+        feat = C.c_int(); idx = C.c_int(); proj = C.c_float()
+        f = self._f("box_support_feature")
+        f.argtypes = [C.POINTER(C.c_float)] * 2 + [C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        f(_fp(_f32(h, 3)), _fp(_f32(direction, 3)), threshold, C.byref(feat), C.byref(idx), C.byref(proj))
+        return feat.value, idx.value, np.float32(proj.value)
+
+    def box_support_projection(self, h, pos, orn, direction):
+        f = self._f("box_support_projection"); f.restype = C.c_float
+        return np.float32(f(_fp(_f32(h, 3)), _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), _fp(_f32(direction, 3))))
+
+    def row_prepare_solve(self, rowdata, vel, delta):
+        d = _f32(delta, 12).copy(); out = np.zeros(4, np.float32)
+        self._f("row_prepare_solve")(_fp(_f32(rowdata, 38)), _fp(_f32(vel, 12)), _fp(d), _fp(out))
+        return out, d
+
+
+def leaf():
+    return _Leaf(lib(), "orc_")
+
+
+def ref_leaf():
+    r = ref()
+    return _Leaf(r, "ref_") if r is not None else None
+
+
+def collide(typeA, paramA, posA, ornA, typeB, paramB, posB, ornB, threshold):
+    out = np.zeros(44, np.float32)
+    f = lib().orc_collide
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] + [C.POINTER(C.c_float)] * 3 + [C.c_int] + [C.POINTER(C.c_float)] * 3 + [C.c_float, C.POINTER(C.c_float)]
+    n = f(typeA, _fp(_f32(paramA, 4)), _fp(_f32(posA, 3)), _fp(_f32(ornA, 4)), typeB, _fp(_f32(paramB, 4)),
+          _fp(_f32(posB, 3)), _fp(_f32(ornB, 4)), threshold, _fp(out))
+    return out.reshape(4, 11)[:n].copy()
+
+
+def should_collide(groupA, maskA, groupB, maskB):
+    f = lib().orc_should_collide
+    f.argtypes = [C.c_uint64] * 4
+    f.restype = C.c_int
+    return bool(f(groupA, maskA, groupB, maskB))
+
+
+class World:
+    """Mirror of edyn_amd.World's interface over the CPU oracle."""
+
+    def __init__(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3, gravity=(0, -9.8, 0), order=ORDER_SEQUENTIAL):
+        g = _f32(gravity, 3)
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc_world_create(dt, vel_iters, pos_iters, _fp(g), order))
+        self.n_joints = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_world_destroy(self.h)
+            self.h = None
+
+    def add_body(self, kind=KIND_DYNAMIC, pos=(0, 0, 0), orn=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0),
+                 mass=1.0, shape_type=SHAPE_NONE, shape_param=(0, 0, 0, 0), inertia=None, friction=0.5,
+                 restitution=0.0, has_material=True, group=2**64 - 1, mask=2**64 - 1, gravity=None):
+        I = _fp(_f32(inertia, 9)) if inertia is not None else None
+        g = _fp(_f32(gravity, 3)) if gravity is not None else None
+        return self.L.orc_add_body(self.h, kind, _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), _fp(_f32(linvel, 3)),
+                                   _fp(_f32(angvel, 3)), mass, shape_type, _fp(_f32(shape_param, 4)), I,
+                                   friction, restitution, int(has_material), group, mask, g)
+
+    def add_bodies(self, scene):
+        """scene: dict of arrays as produced by edyn_amd.scenes (kind,pos,orn,linvel,angvel,mass,shape_type,shape_param,...)."""
+        n = len(scene["kind"])
+        inertia = scene.get("inertia")
+        has_inertia = scene.get("has_inertia")
+        for i in range(n):
+            I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
+            self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
+                          scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
+                          scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
+                          True, int(scene["group"][i]), int(scene["mask"][i]))
+        joints = scene.get("joints")
+        if joints is not None:
+            for j in joints:
+                self.add_joint(*j)
+
+    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0)):
+        self.n_joints += 1
+        return self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
+                                    _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+
+    def step(self, n=1):
+        self.L.orc_step(self.h, n)
+
+    def run_stage(self, stage):
+        self.L.orc_run_stage(self.h, stage)
+
+    def time_steps(self, n):
+        return self.L.orc_time_steps(self.h, n)
+
+    @property
+    def num_bodies(self):
+        return self.L.orc_num_bodies(self.h)
+
+    def get_state(self):
+        n = self.num_bodies
+        pos = np.zeros((n, 3), np.float32); orn = np.zeros((n, 4), np.float32)
+        lv = np.zeros((n, 3), np.float32); av = np.zeros((n, 3), np.float32)
+        self.L.orc_get_state(self.h, _fp(pos), _fp(orn), _fp(lv), _fp(av))
+        return pos, orn, lv, av
+
+    def set_state(self, pos, orn, lv, av):
+        n = self.num_bodies
+        self.L.orc_set_state(self.h, _fp(_f32(pos, 3 * n)), _fp(_f32(orn, 4 * n)), _fp(_f32(lv, 3 * n)), _fp(_f32(av, 3 * n)))
+
+    def get_derived(self):
+        n = self.num_bodies
+        aabb = np.zeros((n, 6), np.float32); iw = np.zeros((n, 9), np.float32); isl = np.zeros(n, np.uint32)
+        self.L.orc_get_derived(self.h, _fp(aabb), _fp(iw), isl.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return aabb, iw, isl
+
+    def get_manifolds(self):
+        m = self.L.orc_num_manifolds(self.h)
+        out = np.zeros(m, MANIFOLD_DTYPE)
+        if m:
+            self.L.orc_get_manifolds(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def set_manifolds(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=MANIFOLD_DTYPE)
+        self.L.orc_set_manifolds(self.h, recs.ctypes.data_as(C.c_void_p), len(recs))
+
+    def get_pairs(self):
+        """Canonical (hi, lo) pairs sorted ascending — the representation bit-exact parity is checked on."""
+        m = self.get_manifolds()
+        b = m["body"].astype(np.uint64)
+        hi = np.maximum(b[:, 0], b[:, 1]); lo = np.minimum(b[:, 0], b[:, 1])
+        return np.sort((hi << np.uint64(32)) | lo)
+
+    def get_joint_impulses(self):
+        out = np.zeros((self.n_joints, 5), np.float32)
+        if self.n_joints:
+            self.L.orc_get_joint_impulses(self.h, _fp(out))
+        return out
+
+    def get_stats(self):
+        s = np.zeros(7, np.uint32)
+        self.L.orc_get_stats(self.h, s.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return dict(zip(["num_manifolds", "num_points", "num_rows", "num_islands", "num_colours",
+                         "num_joint_colours", "colour_rounds"], [int(x) for x in s]))

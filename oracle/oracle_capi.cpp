@@ -1,0 +1,221 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.hpp header).
+// C ABI over the CPU restatement so that tests/ (ctypes) and bench.py's cpu_baseline leg can drive it.
+// The record layouts mirror include/edynhip.h so the same numpy dtypes describe both sides.
+#include "oworld.hpp"
+#include <chrono>
+#include <thread>
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_point_rec {
+    float pivotA[3], pivotB[3], normal[3], local_normal[3];
+    float distance, friction, restitution;
+    int32_t attachment;
+    uint32_t lifetime;
+    float normal_impulse, friction_impulse[2];
+};
+struct orc_manifold_rec {
+    uint32_t body[2];
+    uint32_t num_points;
+    uint32_t colour;
+    orc_point_rec pt[4];
+};
+
+static vec3 v3(const float *p) { return {p[0], p[1], p[2]}; }
+static void put3(float *d, vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+void *orc_world_create(float dt, int vel_iters, int pos_iters, const float *g, int order) {
+    World *w = new World();
+    w->dt = dt; w->vel_iters = vel_iters; w->pos_iters = pos_iters; w->gravity = v3(g); w->order = order;
+    return w;
+}
+void orc_world_destroy(void *h) { delete (World *)h; }
+
+static shape make_shape(int type, const float *p) {
+    shape s;
+    s.type = type;
+    if (type == SHAPE_BOX) s.half_extents = v3(p);
+    else if (type == SHAPE_SPHERE) s.radius = p[0];
+    else if (type == SHAPE_PLANE) { s.normal = v3(p); s.constant = p[3]; }
+    return s;
+}
+
+uint32_t orc_add_body(void *h, int kind, const float *pos, const float *orn, const float *linvel, const float *angvel,
+                      float mass, int shape_type, const float *shape_param, const float *inertia9, float friction,
+                      float restitution, int has_material, uint64_t group, uint64_t mask, const float *grav) {
+    World *w = (World *)h;
+    mat3 I;
+    if (inertia9) I = {{{inertia9[0], inertia9[1], inertia9[2]}, {inertia9[3], inertia9[4], inertia9[5]}, {inertia9[6], inertia9[7], inertia9[8]}}};
+    vec3 g = grav ? v3(grav) : w->gravity;
+    return w->add_body(kind, v3(pos), quat{orn[0], orn[1], orn[2], orn[3]}, v3(linvel), v3(angvel), mass,
+                       make_shape(shape_type, shape_param), inertia9 ? &I : nullptr, friction, restitution,
+                       has_material != 0, group, mask, &g);
+}
+uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
+                       const float *axisA, const float *axisB) {
+    return ((World *)h)->add_joint(type, a, b, v3(pivotA), v3(pivotB), v3(axisA), v3(axisB));
+}
+void orc_step(void *h, int n) { World *w = (World *)h; for (int i = 0; i < n; ++i) w->step(); }
+void orc_run_stage(void *h, int stage) {
+    World *w = (World *)h;
+    switch (stage) {
+    case 0: w->broadphase(); break;
+    case 1: w->narrowphase(); break;
+    case 2: w->update_islands(); break;
+    case 3: w->solve(); break;
+    }
+}
+uint32_t orc_num_bodies(void *h) { return (uint32_t)((World *)h)->bodies.size(); }
+void orc_get_state(void *h, float *pos, float *orn, float *linvel, float *angvel) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        const Body &b = w->bodies[i];
+        put3(pos + 3 * i, b.pos);
+        orn[4 * i] = b.orn.x; orn[4 * i + 1] = b.orn.y; orn[4 * i + 2] = b.orn.z; orn[4 * i + 3] = b.orn.w;
+        put3(linvel + 3 * i, b.linvel); put3(angvel + 3 * i, b.angvel);
+    }
+}
+void orc_set_state(void *h, const float *pos, const float *orn, const float *linvel, const float *angvel) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        Body &b = w->bodies[i];
+        b.pos = v3(pos + 3 * i);
+        b.orn = {orn[4 * i], orn[4 * i + 1], orn[4 * i + 2], orn[4 * i + 3]};
+        b.linvel = v3(linvel + 3 * i); b.angvel = v3(angvel + 3 * i);
+    }
+}
+void orc_get_derived(void *h, float *aabb6, float *inertia_world9, uint32_t *island) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        const Body &b = w->bodies[i];
+        if (aabb6) { put3(aabb6 + 6 * i, b.box.min); put3(aabb6 + 6 * i + 3, b.box.max); }
+        if (inertia_world9) for (int r = 0; r < 3; ++r) put3(inertia_world9 + 9 * i + 3 * r, b.I_inv_world.row[r]);
+        if (island) island[i] = i < w->island_label.size() ? w->island_label[i] : (uint32_t)i;
+    }
+}
+uint32_t orc_num_manifolds(void *h) { return (uint32_t)((World *)h)->manifolds.size(); }
+void orc_get_manifolds(void *h, orc_manifold_rec *out) {
+    World *w = (World *)h;
+    size_t k = 0;
+    for (auto &kv : w->manifolds) {
+        const Manifold &m = kv.second;
+        orc_manifold_rec &r = out[k++];
+        std::memset(&r, 0, sizeof(r));
+        r.body[0] = m.body[0]; r.body[1] = m.body[1]; r.num_points = (uint32_t)m.num_points; r.colour = m.colour;
+        for (int i = 0; i < m.num_points; ++i) {
+            const ContactPoint &c = m.pt[i];
+            orc_point_rec &p = r.pt[i];
+            put3(p.pivotA, c.pivotA); put3(p.pivotB, c.pivotB); put3(p.normal, c.normal); put3(p.local_normal, c.local_normal);
+            p.distance = c.distance; p.friction = c.friction; p.restitution = c.restitution;
+            p.attachment = c.attachment; p.lifetime = c.lifetime;
+            p.normal_impulse = c.normal_impulse; p.friction_impulse[0] = c.friction_impulse[0]; p.friction_impulse[1] = c.friction_impulse[1];
+        }
+    }
+}
+void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
+    World *w = (World *)h;
+    w->manifolds.clear();
+    for (uint32_t k = 0; k < n; ++k) {
+        const orc_manifold_rec &r = in[k];
+        Manifold m;
+        m.body[0] = r.body[0]; m.body[1] = r.body[1]; m.num_points = (int)r.num_points; m.colour = r.colour;
+        for (int i = 0; i < m.num_points; ++i) {
+            ContactPoint &c = m.pt[i];
+            const orc_point_rec &p = r.pt[i];
+            c.pivotA = v3(p.pivotA); c.pivotB = v3(p.pivotB); c.normal = v3(p.normal); c.local_normal = v3(p.local_normal);
+            c.distance = p.distance; c.friction = p.friction; c.restitution = p.restitution;
+            c.attachment = p.attachment; c.lifetime = p.lifetime;
+            c.normal_impulse = p.normal_impulse; c.friction_impulse[0] = p.friction_impulse[0]; c.friction_impulse[1] = p.friction_impulse[1];
+        }
+        w->manifolds.emplace(pair_key(m.body[0], m.body[1]), m);
+    }
+}
+void orc_get_joint_impulses(void *h, float *imp5) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->joints.size(); ++i) for (int k = 0; k < 5; ++k) imp5[5 * i + k] = w->joints[i].impulse[k];
+}
+void orc_get_stats(void *h, uint32_t *out7) {
+    const StepStats &s = ((World *)h)->stats;
+    out7[0] = s.num_manifolds; out7[1] = s.num_points; out7[2] = s.num_rows; out7[3] = s.num_islands;
+    out7[4] = s.num_colours; out7[5] = s.num_joint_colours; out7[6] = s.colour_rounds;
+}
+// Wall-clock seconds for `n` steps (single thread) — used by bench.py's cpu_baseline leg.
+double orc_time_steps(void *h, int n) {
+    World *w = (World *)h;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) w->step();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------- leaf functions for golden-vector and cross-check tests ----------------
+// out points: per point 11 floats (pivotA3, pivotB3, normal3, distance, attachment)
+int orc_collide(int typeA, const float *paramA, const float *posA, const float *ornA, int typeB, const float *paramB,
+                const float *posB, const float *ornB, float threshold, float *out) {
+    coll_ctx ctx{v3(posA), {ornA[0], ornA[1], ornA[2], ornA[3]}, v3(posB), {ornB[0], ornB[1], ornB[2], ornB[3]}, threshold};
+    coll_result r;
+    collide(make_shape(typeA, paramA), make_shape(typeB, paramB), ctx, r);
+    for (size_t i = 0; i < r.num_points; ++i) {
+        float *o = out + 11 * i;
+        put3(o, r.point[i].pivotA); put3(o + 3, r.point[i].pivotB); put3(o + 6, r.point[i].normal);
+        o[9] = r.point[i].distance; o[10] = (float)r.point[i].attachment;
+    }
+    return (int)r.num_points;
+}
+int orc_intersect_line_aabb(const float *p0, const float *p1, const float *bmin, const float *bmax, float *s) {
+    return (int)intersect_line_aabb({p0[0], p0[1]}, {p1[0], p1[1]}, {bmin[0], bmin[1]}, {bmax[0], bmax[1]}, s[0], s[1]);
+}
+void orc_plane_space(const float *n, float *p, float *q) { vec3 a, b; plane_space(v3(n), a, b); put3(p, a); put3(q, b); }
+void orc_integrate(const float *q, const float *w, float dt, float *out) {
+    quat r = integrate({q[0], q[1], q[2], q[3]}, v3(w), dt);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void orc_rotate(const float *q, const float *v, float *out) { put3(out, rotate({q[0], q[1], q[2], q[3]}, v3(v))); }
+// returns type | index<<8 ; num_points updated in place
+int orc_insertion_point_index(const float *pts, int *num_points, const float *np) {
+    vec3 p[4];
+    for (int i = 0; i < 4; ++i) p[i] = v3(pts + 3 * i);
+    size_t n = (size_t)*num_points;
+    insert_result r = insertion_point_index(p, 4, n, v3(np));
+    *num_points = (int)n;
+    return (int)r.type | ((int)(r.index & 0xFF) << 8);
+}
+float orc_closest_segment_segment(const float *p1, const float *q1, const float *p2, const float *q2, float *st,
+                                  float *c, int *num) {
+    float s, t, sp = 0, tp = 0; vec3 c1, c2, c1p{0, 0, 0}, c2p{0, 0, 0}; size_t n = 0;
+    float d = closest_point_segment_segment(v3(p1), v3(q1), v3(p2), v3(q2), s, t, c1, c2, &n, &sp, &tp, &c1p, &c2p);
+    st[0] = s; st[1] = t; st[2] = sp; st[3] = tp;
+    put3(c, c1); put3(c + 3, c2); put3(c + 6, c1p); put3(c + 9, c2p);
+    *num = (int)n;
+    return d;
+}
+void orc_box_support_feature(const float *h, const float *dir, float threshold, int *feature, int *index, float *proj) {
+    box_support_feature_local(v3(h), v3(dir), *feature, *index, *proj, threshold);
+}
+float orc_box_support_projection(const float *h, const float *pos, const float *orn, const float *dir) {
+    return box_support_projection(v3(h), v3(pos), {orn[0], orn[1], orn[2], orn[3]}, v3(dir));
+}
+// rowdata: J[12], inv_mA, inv_mB, inv_IA[9], inv_IB[9], error, erp, restitution, lower, upper, impulse  (38 floats)
+// vel: vA,wA,vB,wB (12) ; delta in/out: dvA,dwA,dvB,dwB (12). out: eff_mass, rhs, new impulse, delta_impulse
+void orc_row_prepare_solve(const float *rd, const float *vel, float *delta, float *out) {
+    Row r;
+    for (int i = 0; i < 4; ++i) r.J[i] = v3(rd + 3 * i);
+    r.inv_mA = rd[12]; r.inv_mB = rd[13];
+    for (int k = 0; k < 3; ++k) { r.inv_IA.row[k] = v3(rd + 14 + 3 * k); r.inv_IB.row[k] = v3(rd + 23 + 3 * k); }
+    RowOptions o; o.error = rd[32]; o.erp = rd[33]; o.restitution = rd[34];
+    r.lower = rd[35]; r.upper = rd[36]; r.impulse = rd[37];
+    vec3 d[4] = {v3(delta), v3(delta + 3), v3(delta + 6), v3(delta + 9)};
+    r.dvA = &d[0]; r.dwA = &d[1]; r.dvB = &d[2]; r.dwB = &d[3];
+    prepare_row(r, o, v3(vel), v3(vel + 3), v3(vel + 6), v3(vel + 9));
+    float di = solve_row(r);
+    apply_row_impulse(di, r);
+    out[0] = r.eff_mass; out[1] = r.rhs; out[2] = r.impulse; out[3] = di;
+    for (int i = 0; i < 4; ++i) put3(delta + 3 * i, d[i]);
+}
+int orc_should_collide(uint64_t groupA, uint64_t maskA, uint64_t groupB, uint64_t maskB) {
+    return ((groupA & maskB) != 0 && (groupB & maskA) != 0) ? 1 : 0;
+}
+uint32_t orc_sizeof_manifold_rec() { return (uint32_t)sizeof(orc_manifold_rec); }
+
+}  // extern "C"

@@ -1,0 +1,833 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.hpp header). Parity status: see oracle/README.md.
+//
+// CPU restatement of the reference's per-step loop over plain arrays (no EnTT):
+//   /root/reference/src/edyn/simulation/stepper_sequential.cpp:71-102,121-147   step order
+//   /root/reference/src/edyn/collision/broadphase.cpp:99-195                    pair maintenance
+//   /root/reference/src/edyn/collision/narrowphase.cpp:21-40                    narrowphase driver
+//   /root/reference/include/edyn/util/collision_util.hpp:104-276                process_collision
+//   /root/reference/src/edyn/util/collision_util.cpp:28-45,205-280,319-475      distances, merge, nearest, create, remove, detect
+//   /root/reference/src/edyn/dynamics/solver.cpp:83-215,387-468                 row prep + solver::update
+//   /root/reference/src/edyn/constraints/contact_constraint.cpp:15-98           contact rows / position solve
+//   /root/reference/src/edyn/constraints/point_constraint.cpp:9-58              point rows
+//   /root/reference/src/edyn/constraints/hinge_constraint.cpp:26-213            hinge rows / position solve (no limits/springs)
+//   /root/reference/src/edyn/constraints/constraint_row.cpp:6-57                prepare_row / solve / apply
+//   /root/reference/src/edyn/constraints/constraint_row_friction.cpp:11-66      friction circle
+//   /root/reference/src/edyn/dynamics/island_solver.cpp:76-111,357-376,513-543  warm start, iterations, integrate
+//   /root/reference/include/edyn/dynamics/position_solver.hpp:16-51             position correction
+//   /root/reference/src/edyn/sys/update_aabbs.cpp:53-78, update_inertias.cpp:12-24
+//
+// Two solver orders are provided over identical row arithmetic:
+//   ORDER_SEQUENTIAL — the reference's order: per island, type-major rows (hinge, point, contact),
+//                      all rows then all friction rows per iteration, per-island position iterations.
+//                      Manifold order = ascending canonical pair key, point order = the reference's
+//                      contact list order (newest first). EnTT pool order itself is not reproducible.
+//   ORDER_COLOURED   — the order the GPU uses: deterministic edge colouring (see colour_edges), colours
+//                      ascending, joints before contacts, normals of all colours before frictions.
+#pragma once
+#include <map>
+#include <vector>
+#include <array>
+#include <cstring>
+#include "ocollide.hpp"
+#include "otree.hpp"
+
+namespace orc {
+
+enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1 };
+enum solver_order : int { ORDER_SEQUENTIAL = 0, ORDER_COLOURED = 1 };
+constexpr uint32_t kNoColour = 0xFFu;
+constexpr uint32_t kMaxColours = 64;
+
+struct Body {
+    int kind = KIND_DYNAMIC;
+    vec3 pos{0, 0, 0};
+    quat orn{0, 0, 0, 1};
+    vec3 linvel{0, 0, 0}, angvel{0, 0, 0};
+    float mass_inv = 0;
+    mat3 I_inv = kMat3Zero, I_inv_world = kMat3Zero;
+    vec3 gravity{0, 0, 0};
+    shape sh{};
+    bool has_material = true;
+    float friction = 0.5f, restitution = 0.0f;
+    uint64_t group = ~0ull, mask = ~0ull;
+    aabb box{};
+    vec3 dv{0, 0, 0}, dw{0, 0, 0};
+    uint32_t leaf = DynTree::NIL;
+    bool procedural() const { return kind == KIND_DYNAMIC; }
+    bool rolling() const { return kind == KIND_DYNAMIC && sh.type == SHAPE_SPHERE; }
+};
+
+struct ContactPoint {
+    vec3 pivotA, pivotB, normal, local_normal;
+    int attachment;
+    float distance;
+    float friction, restitution;
+    uint32_t lifetime;
+    float normal_impulse;
+    float friction_impulse[2];
+};
+
+struct Manifold {
+    uint32_t body[2];
+    int num_points = 0;
+    ContactPoint pt[kMaxContacts];   // list order: newest first
+    uint32_t colour = kNoColour;
+};
+
+struct Joint {
+    int type = JOINT_POINT;
+    uint32_t body[2];
+    vec3 pivot[2];
+    mat3 frame[2] = {kMat3Identity, kMat3Identity};   // hinge: column 0 = axis
+    float impulse[5] = {0, 0, 0, 0, 0};
+    uint32_t colour = kNoColour;
+};
+
+struct Row {
+    vec3 J[4];
+    float eff_mass, rhs, lower, upper, impulse;
+    float inv_mA, inv_mB;
+    mat3 inv_IA, inv_IB;
+    vec3 *dvA, *dwA, *dvB, *dwB;
+};
+struct FrictionRow {
+    struct { vec3 J[4]; float eff_mass, rhs, impulse; } row[2];
+    float mu;
+    uint32_t normal_row;
+};
+struct RowOptions { float error = 0, erp = 0.2f, restitution = 0; };
+
+inline uint64_t pair_key(uint32_t a, uint32_t b) {
+    uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    return ((uint64_t)hi << 32) | lo;
+}
+inline uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+// --- row arithmetic (constraint_row.cpp, constraint_row_friction.cpp, constraint_util.cpp:137-158) ---
+inline float effective_mass(const vec3 J[4], float imA, const mat3 &iIA, float imB, const mat3 &iIB) {
+    float s = dot(J[0], J[0]) * imA + dot(iIA * J[1], J[1]) + dot(J[2], J[2]) * imB + dot(iIB * J[3], J[3]);
+    return 1.0f / s;
+}
+inline float relative_speed(const vec3 J[4], vec3 vA, vec3 wA, vec3 vB, vec3 wB) {
+    return dot(J[0], vA) + dot(J[1], wA) + dot(J[2], vB) + dot(J[3], wB);
+}
+inline void prepare_row(Row &r, const RowOptions &o, vec3 vA, vec3 wA, vec3 vB, vec3 wB) {
+    r.eff_mass = effective_mass(r.J, r.inv_mA, r.inv_IA, r.inv_mB, r.inv_IB);
+    float relvel = relative_speed(r.J, vA, wA, vB, wB);
+    r.rhs = -(o.error * o.erp + relvel * (1 + o.restitution));
+}
+inline void apply_row_impulse(float imp, Row &r) {
+    *r.dvA += r.inv_mA * r.J[0] * imp;
+    *r.dvB += r.inv_mB * r.J[2] * imp;
+    *r.dwA += r.inv_IA * r.J[1] * imp;
+    *r.dwB += r.inv_IB * r.J[3] * imp;
+}
+inline float solve_row(Row &r) {
+    float drel = relative_speed(r.J, *r.dvA, *r.dwA, *r.dvB, *r.dwB);
+    float dimp = (r.rhs - drel) * r.eff_mass;
+    float imp = r.impulse + dimp;
+    if (imp < r.lower) { dimp = r.lower - r.impulse; r.impulse = r.lower; }
+    else if (imp > r.upper) { dimp = r.upper - r.impulse; r.impulse = r.upper; }
+    else r.impulse = imp;
+    return dimp;
+}
+inline void solve_friction(FrictionRow &f, Row &n) {
+    float dimp[2], imp[2];
+    for (int i = 0; i < 2; ++i) {
+        float drel = relative_speed(f.row[i].J, *n.dvA, *n.dwA, *n.dvB, *n.dwB);
+        dimp[i] = (f.row[i].rhs - drel) * f.row[i].eff_mass;
+        imp[i] = f.row[i].impulse + dimp[i];
+    }
+    float len2 = imp[0] * imp[0] + imp[1] * imp[1];
+    float max_len = f.mu * n.impulse;
+    if (len2 > square(max_len)) {
+        float len = std::sqrt(len2);
+        if (len > kEps) { imp[0] = imp[0] / len * max_len; imp[1] = imp[1] / len * max_len; }
+        else { imp[0] = 0; imp[1] = 0; }
+        for (int i = 0; i < 2; ++i) dimp[i] = imp[i] - f.row[i].impulse;
+    }
+    for (int i = 0; i < 2; ++i) {
+        f.row[i].impulse = imp[i];
+        *n.dvA += n.inv_mA * f.row[i].J[0] * dimp[i];
+        *n.dwA += n.inv_IA * f.row[i].J[1] * dimp[i];
+        *n.dvB += n.inv_mB * f.row[i].J[2] * dimp[i];
+        *n.dwB += n.inv_IB * f.row[i].J[3] * dimp[i];
+    }
+}
+inline void warm_start_friction(FrictionRow &f, Row &n) {
+    for (int i = 0; i < 2; ++i) {
+        *n.dvA += n.inv_mA * f.row[i].J[0] * f.row[i].impulse;
+        *n.dwA += n.inv_IA * f.row[i].J[1] * f.row[i].impulse;
+        *n.dvB += n.inv_mB * f.row[i].J[2] * f.row[i].impulse;
+        *n.dwB += n.inv_IB * f.row[i].J[3] * f.row[i].impulse;
+    }
+}
+
+struct StepStats {
+    uint32_t num_manifolds = 0, num_points = 0, num_rows = 0, num_islands = 0, num_colours = 0,
+             num_joint_colours = 0, colour_rounds = 0;
+};
+
+class World {
+public:
+    float dt = 1.0f / 60.0f;
+    int vel_iters = 8, pos_iters = 3;   // context/settings.hpp:22-30 defaults
+    vec3 gravity{0, -9.8f, 0};
+    int order = ORDER_SEQUENTIAL;
+    std::vector<Body> bodies;
+    std::vector<Joint> joints;
+    std::map<uint64_t, Manifold> manifolds;
+    std::vector<uint32_t> island_label;   // per body; valid for procedural bodies after update_islands()
+    StepStats stats;
+
+    // rigidbody.cpp:47-191 (make_rigidbody), restricted to the components on the hot path.
+    uint32_t add_body(int kind, vec3 pos, quat orn, vec3 linvel, vec3 angvel, float mass, const shape &sh,
+                      const mat3 *inertia, float friction, float restitution, bool has_material, uint64_t group,
+                      uint64_t mask, const vec3 *grav) {
+        Body b;
+        b.kind = kind; b.pos = pos; b.orn = orn; b.sh = sh;
+        if (kind == KIND_DYNAMIC) {
+            b.mass_inv = 1.0f / mass;
+            mat3 I = inertia ? *inertia : moment_of_inertia(sh, mass);
+            b.I_inv = inverse_symmetric(I);
+            mat3 basis = to_mat3(orn);
+            b.I_inv_world = basis * b.I_inv * transpose(basis);
+        }
+        if (kind != KIND_STATIC) { b.linvel = linvel; b.angvel = angvel; }
+        vec3 g = grav ? *grav : gravity;
+        if (kind == KIND_DYNAMIC) b.gravity = g;
+        b.has_material = has_material; b.friction = friction; b.restitution = restitution;
+        b.group = group; b.mask = mask;
+        if (sh.type != SHAPE_NONE) b.box = shape_aabb(sh, pos, orn);
+        uint32_t id = (uint32_t)bodies.size();
+        bodies.push_back(b);
+        if (sh.type != SHAPE_NONE) {   // broadphase.cpp:75-97 init_new_aabb_entities
+            DynTree &t = bodies[id].procedural() ? tree_ : np_tree_;
+            bodies[id].leaf = t.create(bodies[id].box, id);
+        }
+        return id;
+    }
+    uint32_t add_joint(int type, uint32_t a, uint32_t b, vec3 pivotA, vec3 pivotB, vec3 axisA, vec3 axisB) {
+        Joint j;
+        j.type = type; j.body[0] = a; j.body[1] = b; j.pivot[0] = pivotA; j.pivot[1] = pivotB;
+        if (type == JOINT_HINGE) {   // hinge_constraint.cpp:11-17 set_axes
+            vec3 p, q;
+            plane_space(axisA, p, q); j.frame[0] = mat3_columns(axisA, p, q);
+            plane_space(axisB, p, q); j.frame[1] = mat3_columns(axisB, p, q);
+        }
+        joints.push_back(j);
+        joints_coloured_ = false;
+        return (uint32_t)joints.size() - 1;
+    }
+
+    // One fixed-dt step (stepper_sequential.cpp:121-147 step_simulation order).
+    void step() {
+        broadphase();
+        narrowphase();
+        update_islands();
+        solve();
+    }
+
+    // ---------------- broadphase ----------------
+    bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:23-57 (no exclusion lists)
+        if (a == b) return false;
+        const Body &A = bodies[a], &B = bodies[b];
+        if ((A.group & B.mask) == 0 || (B.group & A.mask) == 0) return false;
+        return true;
+    }
+    void broadphase() {
+        const float sep = kContactBreakingThreshold * 1.3f;   // broadphase.hpp:18
+        const vec3 sep_off = vec3{1, 1, 1} * -sep;
+        const vec3 q_off = vec3{1, 1, 1} * -kContactBreakingThreshold;   // broadphase.hpp:15
+        for (auto it = manifolds.begin(); it != manifolds.end();) {   // destroy_separated_manifolds
+            const aabb &b0 = bodies[it->second.body[0]].box, &b1 = bodies[it->second.body[1]].box;
+            if (!intersect(b0.inset(sep_off), b1)) it = manifolds.erase(it);
+            else ++it;
+        }
+        for (auto &b : bodies) {   // move_aabbs
+            if (b.sh.type == SHAPE_NONE) continue;
+            if (b.procedural()) tree_.move(b.leaf, b.box);
+            else if (b.kind == KIND_KINEMATIC) np_tree_.move(b.leaf, b.box);
+        }
+        // EnTT views iterate a pool back to front, i.e. most recently created body first.
+        for (uint32_t k = (uint32_t)bodies.size(); k-- > 0;) {
+            const Body &b = bodies[k];
+            if (!b.procedural() || b.sh.type == SHAPE_NONE) continue;
+            const aabb q = b.box.inset(q_off);
+            auto visit_tree = [&](const DynTree &t) {
+                t.query(q, [&](uint32_t leaf) {
+                    uint32_t other = t.payload(leaf);
+                    if (!should_collide(k, other)) return;
+                    uint64_t key = pair_key(k, other);
+                    if (manifolds.count(key)) return;
+                    if (!intersect(q, bodies[other].box)) return;
+                    Manifold m; m.body[0] = k; m.body[1] = other;   // constraint_util.cpp:60-102
+                    manifolds.emplace(key, m);
+                });
+            };
+            visit_tree(tree_);
+            visit_tree(np_tree_);
+        }
+    }
+
+    // ---------------- narrowphase ----------------
+    void detect(const Manifold &m, coll_result &res) const {   // collision_util.cpp:440-475
+        const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        const vec3 off = vec3{1, 1, 1} * -kContactBreakingThreshold;
+        res.num_points = 0;
+        if (!intersect(A.box.inset(off), B.box)) return;
+        coll_ctx ctx{A.pos, A.orn, B.pos, B.orn, kCollisionThreshold};
+        collide(A.sh, B.sh, ctx, res);
+    }
+    static size_t find_nearest(const ContactPoint &cp, const coll_result &res) {   // collision_util.cpp:233-255
+        float best = square(kContactCachingThreshold);
+        size_t idx = res.num_points;
+        for (size_t i = 0; i < res.num_points; ++i) {
+            float dA = length_sqr(res.point[i].pivotA - cp.pivotA);
+            float dB = length_sqr(res.point[i].pivotB - cp.pivotB);
+            if (dA < best) { best = dA; idx = i; }
+            if (dB < best) { best = dB; idx = i; }
+        }
+        return idx;
+    }
+    // collision_util.cpp:257-280. Note: compares against the result's pivotA for BOTH bodies, as the reference does.
+    size_t find_nearest_rolling(const coll_result &res, vec3 cp_pivot, vec3 origin, quat orn, vec3 angvel) const {
+        size_t idx = res.num_points;
+        quat prev_orn = integrate(orn, angvel, -dt);
+        vec3 prev_pivot = to_world(cp_pivot, origin, prev_orn);
+        float best = square(kContactCachingThreshold);
+        for (size_t i = 0; i < res.num_points; ++i) {
+            vec3 pA = to_world(res.point[i].pivotA, origin, orn);
+            float d2 = distance_sqr(pA, prev_pivot);
+            if (d2 < best) { best = d2; idx = i; }
+        }
+        return idx;
+    }
+    void set_local_normal(const Manifold &m, ContactPoint &cp) const {
+        if (cp.attachment != NA_NONE) {
+            const quat orn = bodies[m.body[cp.attachment == NA_ON_A ? 0 : 1]].orn;
+            cp.local_normal = rotate(conjugate(orn), cp.normal);
+        } else cp.local_normal = {0, 0, 0};
+    }
+    void merge_point(const Manifold &m, const coll_point &rp, ContactPoint &cp) const {   // collision_util.cpp:205-231
+        cp.pivotA = rp.pivotA; cp.pivotB = rp.pivotB; cp.normal = rp.normal;
+        cp.distance = rp.distance; cp.attachment = rp.attachment;
+        set_local_normal(m, cp);
+    }
+    ContactPoint make_point(const Manifold &m, const coll_point &rp) const {   // collision_util.cpp:319-395
+        ContactPoint cp{};
+        cp.pivotA = rp.pivotA; cp.pivotB = rp.pivotB; cp.normal = rp.normal;
+        cp.attachment = rp.attachment; cp.distance = rp.distance;
+        set_local_normal(m, cp);
+        const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        cp.friction = std::sqrt(A.friction * B.friction);            // material_mixing.hpp:16-18
+        cp.restitution = std::min(A.restitution, B.restitution);     // :12-14
+        return cp;
+    }
+    bool should_remove(const ContactPoint &cp, const Body &A, const Body &B) const {   // collision_util.cpp:397-413
+        const float thr = kContactBreakingThreshold, thr2 = thr * thr;
+        vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+        vec3 d = pA - pB;
+        float nd = dot(d, cp.normal);
+        vec3 td = d - nd * cp.normal;
+        return nd > thr || length_sqr(td) > thr2;
+    }
+    void process_collision(Manifold &m, const coll_result &res) const {   // collision_util.hpp:104-276
+        const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        const size_t R = res.num_points;
+        bool merged[kMaxContacts] = {false, false, false, false};
+        bool removed[kMaxContacts] = {false, false, false, false};
+        const int n_old = m.num_points;
+        size_t num_points = (size_t)n_old;
+        for (int i = 0; i < n_old; ++i) {
+            ContactPoint &cp = m.pt[i];
+            ++cp.lifetime;
+            size_t nearest = find_nearest(cp, res);
+            if (nearest == R && A.rolling()) nearest = find_nearest_rolling(res, cp.pivotA, A.pos, A.orn, A.angvel);
+            if (nearest == R && B.rolling()) nearest = find_nearest_rolling(res, cp.pivotB, B.pos, B.orn, B.angvel);
+            if (nearest < R && !merged[nearest]) {
+                merge_point(m, res.point[nearest], cp);
+                merged[nearest] = true;
+            } else if (should_remove(cp, A, B)) {
+                removed[i] = true;
+                --num_points;
+            }
+        }
+        bool all_merged = true;
+        for (size_t r = 0; r < R; ++r) all_merged &= merged[r];
+
+        struct Local { coll_point point; int old_index = -1; insert_type type = insert_type::none; };
+        Local local[kMaxContacts];
+        if (!all_merged) {
+            if (num_points > 0) {
+                int k = 0;
+                for (int i = 0; i < n_old; ++i) {
+                    if (removed[i]) continue;
+                    local[k].point = {m.pt[i].pivotA, m.pt[i].pivotB, m.pt[i].normal, m.pt[i].distance, NA_NONE};
+                    local[k].old_index = i;
+                    ++k;
+                }
+            } else {
+                ++num_points;
+                local[0].point = res.point[0];
+                local[0].type = insert_type::append;
+                merged[0] = true;
+            }
+            for (size_t r = 0; r < R; ++r) {
+                if (merged[r]) continue;
+                const coll_point &rp = res.point[r];
+                vec3 piv[kMaxContacts];
+                for (size_t i = 0; i < num_points; ++i) piv[i] = local[i].point.pivotA;
+                insert_result ir = insertion_point_index(piv, kMaxContacts, num_points, rp.pivotA);
+                if (ir.type == insert_type::none) {
+                    for (size_t i = 0; i < num_points; ++i) piv[i] = local[i].point.pivotB;
+                    ir = insertion_point_index(piv, kMaxContacts, num_points, rp.pivotB);
+                }
+                if (ir.type != insert_type::none) { local[ir.index].point = rp; local[ir.index].type = ir.type; }
+            }
+        }
+        // Resolve: destroyed old points leave the list, new points are pushed at the head in creation order.
+        bool dead[kMaxContacts];
+        for (int i = 0; i < n_old; ++i) dead[i] = removed[i];
+        ContactPoint created[kMaxContacts];
+        int n_created = 0;
+        if (!all_merged) {
+            for (size_t i = 0; i < num_points; ++i) {
+                Local &lp = local[i];
+                switch (lp.type) {
+                case insert_type::none: break;
+                case insert_type::append: created[n_created++] = make_point(m, lp.point); break;
+                case insert_type::similar:
+                    if (lp.old_index < 0) created[n_created++] = make_point(m, lp.point);
+                    else merge_point(m, lp.point, m.pt[lp.old_index]);
+                    break;
+                case insert_type::replace:
+                    if (lp.old_index >= 0) dead[lp.old_index] = true;
+                    created[n_created++] = make_point(m, lp.point);
+                    break;
+                }
+            }
+        }
+        ContactPoint out[kMaxContacts];
+        int n_out = 0;
+        for (int i = n_created - 1; i >= 0; --i) out[n_out++] = created[i];
+        for (int i = 0; i < n_old; ++i) if (!dead[i]) out[n_out++] = m.pt[i];
+        m.num_points = n_out;
+        for (int i = 0; i < n_out; ++i) m.pt[i] = out[i];
+    }
+    void narrowphase() {
+        for (auto &kv : manifolds) {   // update_contact_distances, collision_util.cpp:28-45
+            Manifold &m = kv.second;
+            const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+            for (int i = 0; i < m.num_points; ++i) {
+                vec3 pA = to_world(m.pt[i].pivotA, A.pos, A.orn), pB = to_world(m.pt[i].pivotB, B.pos, B.orn);
+                m.pt[i].distance = dot(m.pt[i].normal, pA - pB);
+            }
+        }
+        for (auto &kv : manifolds) {
+            coll_result res;
+            detect(kv.second, res);
+            process_collision(kv.second, res);
+        }
+    }
+
+    // ---------------- islands (connected components over procedural bodies) ----------------
+    void update_islands() {
+        const uint32_t n = (uint32_t)bodies.size();
+        island_label.resize(n);
+        for (uint32_t i = 0; i < n; ++i) island_label[i] = i;
+        auto find = [&](uint32_t x) {
+            while (island_label[x] != x) { island_label[x] = island_label[island_label[x]]; x = island_label[x]; }
+            return x;
+        };
+        auto unite = [&](uint32_t a, uint32_t b) {
+            if (!bodies[a].procedural() || !bodies[b].procedural()) return;   // static/kinematic nodes do not connect
+            uint32_t ra = find(a), rb = find(b);
+            if (ra == rb) return;
+            if (ra < rb) island_label[rb] = ra; else island_label[ra] = rb;
+        };
+        for (auto &kv : manifolds) unite(kv.second.body[0], kv.second.body[1]);   // every manifold is a graph edge
+        for (auto &j : joints) unite(j.body[0], j.body[1]);
+        uint32_t count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            island_label[i] = find(i);
+            if (bodies[i].procedural() && island_label[i] == i) ++count;
+        }
+        stats.num_islands = count;
+    }
+
+    // ---------------- colouring (shared spec with the GPU; see DESIGN.md "Colouring") ----------------
+    // Edges = constraints between two bodies; only procedural endpoints constrain the colour. Each round every
+    // uncoloured edge whose priority is the maximum among the uncoloured edges at all of its procedural endpoints
+    // takes the lowest colour free at those endpoints. Decisions in a round depend only on the state before it.
+    template <typename EdgeAt>
+    uint32_t colour_edges(uint32_t num_edges, EdgeAt &&edge, std::vector<uint64_t> &used) {
+        std::vector<uint64_t> best(bodies.size(), 0);
+        uint32_t rounds = 0;
+        for (;;) {
+            bool any = false;
+            for (uint32_t e = 0; e < num_edges; ++e) {
+                uint32_t a, b; uint32_t *col;
+                edge(e, a, b, col);
+                if (!col || *col != kNoColour) continue;
+                any = true;
+                uint64_t pr = ((uint64_t)mix32(e + 1) << 32) | (e + 1);
+                if (bodies[a].procedural()) best[a] = std::max(best[a], pr);
+                if (bodies[b].procedural()) best[b] = std::max(best[b], pr);
+            }
+            if (!any) break;
+            ++rounds;
+            std::vector<std::pair<uint32_t, uint32_t>> chosen;
+            for (uint32_t e = 0; e < num_edges; ++e) {
+                uint32_t a, b; uint32_t *col;
+                edge(e, a, b, col);
+                if (!col || *col != kNoColour) continue;
+                uint64_t pr = ((uint64_t)mix32(e + 1) << 32) | (e + 1);
+                bool pa = bodies[a].procedural(), pb = bodies[b].procedural();
+                if ((pa && best[a] != pr) || (pb && best[b] != pr)) continue;
+                uint64_t busy = (pa ? used[a] : 0) | (pb ? used[b] : 0);
+                uint32_t c = 0;
+                while (c < kMaxColours && (busy >> c & 1)) ++c;
+                if (c >= kMaxColours) { colour_overflow_ = true; c = kMaxColours - 1; }
+                *col = c;
+                if (pa) used[a] |= 1ull << c;
+                if (pb) used[b] |= 1ull << c;
+            }
+            std::fill(best.begin(), best.end(), 0);
+        }
+        return rounds;
+    }
+    void colour_contacts() {
+        std::vector<Manifold *> ms;
+        ms.reserve(manifolds.size());
+        for (auto &kv : manifolds) ms.push_back(&kv.second);
+        std::vector<uint64_t> used(bodies.size(), 0);
+        for (Manifold *m : ms) {
+            if (m->num_points == 0) { m->colour = kNoColour; continue; }   // inactive edges hold no colour
+            if (m->colour != kNoColour) {
+                for (int s = 0; s < 2; ++s) if (bodies[m->body[s]].procedural()) used[m->body[s]] |= 1ull << m->colour;
+            }
+        }
+        stats.colour_rounds = colour_edges((uint32_t)ms.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
+            a = ms[e]->body[0]; b = ms[e]->body[1];
+            col = ms[e]->num_points > 0 ? &ms[e]->colour : nullptr;
+        }, used);
+        uint32_t nc = 0;
+        for (Manifold *m : ms) if (m->colour != kNoColour) nc = std::max(nc, m->colour + 1);
+        stats.num_colours = nc;
+    }
+    void colour_joints() {
+        if (joints_coloured_) return;
+        for (auto &j : joints) j.colour = kNoColour;
+        std::vector<uint64_t> used(bodies.size(), 0);
+        colour_edges((uint32_t)joints.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
+            a = joints[e].body[0]; b = joints[e].body[1]; col = &joints[e].colour;
+        }, used);
+        uint32_t nc = 0;
+        for (auto &j : joints) nc = std::max(nc, j.colour + 1);
+        stats.num_joint_colours = nc;
+        joints_coloured_ = true;
+    }
+
+    // ---------------- solver ----------------
+    struct BodyRef {   // solver.cpp:83-147: static => zero velocity; non-procedural => zero inverse mass, dummy deltas
+        vec3 pos; quat orn; vec3 linvel, angvel; float inv_m; mat3 inv_I; vec3 *dv, *dw;
+    };
+    BodyRef body_ref(uint32_t i) {
+        Body &b = bodies[i];
+        BodyRef r;
+        r.pos = b.pos; r.orn = b.orn;
+        if (b.procedural()) { r.inv_m = b.mass_inv; r.inv_I = b.I_inv_world; r.dv = &b.dv; r.dw = &b.dw; }
+        else { r.inv_m = 0; r.inv_I = kMat3Zero; r.dv = &dummy_dv_; r.dw = &dummy_dw_; }
+        if (b.kind == KIND_STATIC) { r.linvel = {0, 0, 0}; r.angvel = {0, 0, 0}; }
+        else { r.linvel = b.linvel; r.angvel = b.angvel; }
+        return r;
+    }
+    static void finish_row(Row &r, const RowOptions &o, const BodyRef &A, const BodyRef &B) {
+        r.inv_mA = A.inv_m; r.inv_IA = A.inv_I; r.inv_mB = B.inv_m; r.inv_IB = B.inv_I;
+        r.dvA = A.dv; r.dwA = A.dw; r.dvB = B.dv; r.dwB = B.dw;
+        prepare_row(r, o, A.linvel, A.angvel, B.linvel, B.angvel);
+    }
+    // contact_constraint.cpp:15-56
+    void prepare_contact(const ContactPoint &cp, const BodyRef &A, const BodyRef &B, Row &nr, FrictionRow &fr) {
+        vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
+        vec3 rA = pAw - A.pos, rB = pBw - B.pos;
+        const vec3 n = cp.normal;
+        nr.J[0] = n; nr.J[1] = cross(rA, n); nr.J[2] = -n; nr.J[3] = -cross(rB, n);
+        nr.impulse = cp.normal_impulse;
+        nr.lower = 0; nr.upper = kLarge;
+        RowOptions o;
+        o.restitution = 0;   // solver.cpp:282-283: restitution solver enabled => rows carry zero restitution
+        if (cp.distance > 0) o.error = cp.distance / dt;
+        finish_row(nr, o, A, B);
+        fr.mu = cp.friction;
+        vec3 t[2];
+        plane_space(n, t[0], t[1]);
+        for (int i = 0; i < 2; ++i) {
+            auto &ri = fr.row[i];
+            ri.J[0] = t[i]; ri.J[1] = cross(rA, t[i]); ri.J[2] = -t[i]; ri.J[3] = -cross(rB, t[i]);
+            ri.impulse = cp.friction_impulse[i];
+            ri.eff_mass = effective_mass(ri.J, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+            ri.rhs = -relative_speed(ri.J, A.linvel, A.angvel, B.linvel, B.angvel);
+        }
+    }
+    // point_constraint.cpp:9-46 (friction_torque == 0) / hinge_constraint.cpp:26-67 (no limit/spring/torque rows)
+    int prepare_joint(const Joint &j, const BodyRef &A, const BodyRef &B, Row *rows) {
+        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 rA = pA - A.pos, rB = pB - B.pos;
+        mat3 sA = skew(rA), sB = skew(rB);
+        int n = 0;
+        for (int i = 0; i < 3; ++i) {
+            Row &r = rows[n];
+            r.J[0] = kMat3Identity.row[i]; r.J[1] = -sA.row[i]; r.J[2] = -kMat3Identity.row[i]; r.J[3] = sB.row[i];
+            r.lower = -kScalarMax; r.upper = kScalarMax;
+            r.impulse = j.impulse[n];
+            RowOptions o;
+            if (j.type == JOINT_POINT) o.error = (pA[i] - pB[i]) / dt;
+            finish_row(r, o, A, B);
+            ++n;
+        }
+        if (j.type == JOINT_HINGE) {
+            vec3 p = rotate(A.orn, j.frame[0].column(1)), q = rotate(A.orn, j.frame[0].column(2));
+            const vec3 ax[2] = {p, q};
+            for (int i = 0; i < 2; ++i) {
+                Row &r = rows[n];
+                r.J[0] = {0, 0, 0}; r.J[1] = ax[i]; r.J[2] = {0, 0, 0}; r.J[3] = -ax[i];
+                r.lower = -kScalarMax; r.upper = kScalarMax;
+                r.impulse = j.impulse[n];
+                finish_row(r, RowOptions{}, A, B);
+                ++n;
+            }
+        }
+        return n;
+    }
+
+    // position_solver.hpp:16-51. Transforms of non-procedural bodies are left untouched (the reference
+    // re-normalises a static body's quaternion here, a no-op for unit quaternions up to 1 ulp).
+    struct PosSolver {
+        Body *A, *B;
+        float inv_mA, inv_mB;
+        mat3 inv_IA, inv_IB;
+        float max_error = 0;
+        void bind(Body &a, Body &b) {
+            A = &a; B = &b;
+            inv_mA = a.procedural() ? a.mass_inv : 0; inv_IA = a.procedural() ? a.I_inv_world : kMat3Zero;
+            inv_mB = b.procedural() ? b.mass_inv : 0; inv_IB = b.procedural() ? b.I_inv_world : kMat3Zero;
+        }
+        void solve(const vec3 J[4], float error) {
+            float em = effective_mass(J, inv_mA, inv_IA, inv_mB, inv_IB);
+            float corr = error * kContactPositionCorrectionRate * em;
+            if (A->procedural()) apply(*A, inv_mA, inv_IA, J[0], J[1], corr);
+            if (B->procedural()) apply(*B, inv_mB, inv_IB, J[2], J[3], corr);
+            max_error = std::max(std::fabs(error), max_error);
+        }
+        static void apply(Body &b, float inv_m, mat3 &inv_I, vec3 Jl, vec3 Ja, float corr) {
+            b.pos += inv_m * Jl * corr;
+            vec3 ang = inv_I * Ja * corr;
+            b.orn = b.orn + quaternion_derivative(b.orn, ang);
+            b.orn = normalize(b.orn);
+            mat3 basis = to_mat3(b.orn);
+            inv_I = basis * b.I_inv * transpose(basis);
+            b.I_inv_world = inv_I;
+        }
+    };
+    void contact_solve_position(Manifold &m, ContactPoint &cp, PosSolver &ps) {   // contact_constraint.cpp:58-90
+        Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        ps.bind(A, B);
+        vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
+        if (cp.attachment == NA_ON_A) cp.normal = rotate(A.orn, cp.local_normal);
+        else if (cp.attachment == NA_ON_B) cp.normal = rotate(B.orn, cp.local_normal);
+        cp.distance = dot(pAw - pBw, cp.normal);
+        vec3 rA = pAw - A.pos, rB = pBw - B.pos;
+        if (cp.distance > -kEps) return;
+        float error = -cp.distance;
+        vec3 J[4] = {cp.normal, cross(rA, cp.normal), -cp.normal, -cross(rB, cp.normal)};
+        ps.solve(J, error);
+    }
+    void hinge_solve_position(Joint &j, PosSolver &ps) {   // hinge_constraint.cpp:180-213
+        Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        ps.bind(A, B);
+        vec3 axisA = rotate(A.orn, j.frame[0].column(0)), axisB = rotate(B.orn, j.frame[1].column(0));
+        vec3 p, q;
+        plane_space(axisA, p, q);
+        vec3 u = cross(axisA, axisB);
+        float e = dot(u, p);
+        if (std::fabs(e) > kEps) { vec3 J[4] = {{0, 0, 0}, p, {0, 0, 0}, -p}; ps.solve(J, e); }
+        e = dot(u, q);
+        if (std::fabs(e) > kEps) { vec3 J[4] = {{0, 0, 0}, q, {0, 0, 0}, -q}; ps.solve(J, e); }
+        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 dir = pA - pB;
+        float err = length(dir);
+        if (err > kEps) {
+            dir /= err;
+            vec3 rA = pA - A.pos, rB = pB - B.pos;
+            vec3 J[4] = {dir, cross(rA, dir), -dir, -cross(rB, dir)};
+            ps.solve(J, -err);
+        }
+    }
+
+    void integrate_body(Body &b) {   // island_solver.cpp:357-376
+        b.linvel += b.dv; b.angvel += b.dw;
+        b.pos += b.linvel * dt;
+        b.orn = integrate(b.orn, b.angvel, dt);
+        b.dv = {0, 0, 0}; b.dw = {0, 0, 0};
+    }
+
+    void solve() {
+        dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
+        // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
+        for (auto &b : bodies)   // apply_gravity.hpp:12-17
+            if (b.kind == KIND_DYNAMIC && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
+        if (order == ORDER_SEQUENTIAL) solve_sequential(); else solve_coloured();
+        for (auto &b : bodies) {   // update_aabbs (dynamic + kinematic), update_inertias (dynamic)
+            if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.pos, b.orn);
+            if (b.kind == KIND_DYNAMIC) {
+                mat3 basis = to_mat3(b.orn);
+                b.I_inv_world = basis * b.I_inv * transpose(basis);
+            }
+        }
+        uint32_t np = 0;
+        for (auto &kv : manifolds) np += kv.second.num_points;
+        stats.num_manifolds = (uint32_t)manifolds.size();
+        stats.num_points = np;
+    }
+
+    // Reference order (island_solver.cpp:513-543 per island).
+    void solve_sequential() {
+        std::map<uint32_t, std::vector<Manifold *>> isl_m;
+        std::map<uint32_t, std::vector<Joint *>> isl_j;
+        std::map<uint32_t, std::vector<uint32_t>> isl_b;
+        auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
+        for (uint32_t i = 0; i < bodies.size(); ++i) if (bodies[i].procedural()) isl_b[island_label[i]].push_back(i);
+        for (auto &kv : manifolds) isl_m[label_of(kv.second.body[0], kv.second.body[1])].push_back(&kv.second);
+        for (auto &j : joints) isl_j[label_of(j.body[0], j.body[1])].push_back(&j);
+        stats.num_rows = 0;
+        for (auto &ib : isl_b) {
+            const uint32_t label = ib.first;
+            std::vector<Row> rows;
+            std::vector<FrictionRow> fric;
+            std::vector<std::pair<Joint *, int>> jrows;       // joint, first row
+            std::vector<std::pair<ContactPoint *, uint32_t>> crows;   // point, normal row index
+            auto &js = isl_j[label];
+            for (int type : {JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: hinge ... point, contact
+                for (Joint *j : js) {
+                    if (j->type != type) continue;
+                    Row tmp[5];
+                    int n = prepare_joint(*j, body_ref(j->body[0]), body_ref(j->body[1]), tmp);
+                    jrows.push_back({j, (int)rows.size()});
+                    for (int i = 0; i < n; ++i) rows.push_back(tmp[i]);
+                }
+            for (Manifold *m : isl_m[label]) {
+                BodyRef A = body_ref(m->body[0]), B = body_ref(m->body[1]);
+                for (int i = 0; i < m->num_points; ++i) {
+                    Row nr; FrictionRow fr;
+                    prepare_contact(m->pt[i], A, B, nr, fr);
+                    fr.normal_row = (uint32_t)rows.size();
+                    crows.push_back({&m->pt[i], fr.normal_row});
+                    rows.push_back(nr);
+                    fric.push_back(fr);
+                }
+            }
+            stats.num_rows += (uint32_t)rows.size();
+            for (auto &r : rows) apply_row_impulse(r.impulse, r);                 // warm start
+            for (auto &f : fric) warm_start_friction(f, rows[f.normal_row]);
+            for (int it = 0; it < vel_iters; ++it) {
+                for (auto &r : rows) { float d = solve_row(r); apply_row_impulse(d, r); }
+                for (auto &f : fric) solve_friction(f, rows[f.normal_row]);
+            }
+            for (uint32_t b : ib.second) integrate_body(bodies[b]);
+            for (auto &jr : jrows) {                                               // assign_applied_impulses
+                int n = jr.first->type == JOINT_HINGE ? 5 : 3;
+                for (int i = 0; i < n; ++i) jr.first->impulse[i] = rows[jr.second + i].impulse;
+            }
+            for (size_t k = 0; k < crows.size(); ++k) {
+                crows[k].first->normal_impulse = rows[crows[k].second].impulse;
+                crows[k].first->friction_impulse[0] = fric[k].row[0].impulse;
+                crows[k].first->friction_impulse[1] = fric[k].row[1].impulse;
+            }
+            for (int it = 0; it < pos_iters; ++it) {
+                PosSolver hs, cs;
+                for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
+                for (Manifold *m : isl_m[label]) for (int i = 0; i < m->num_points; ++i) contact_solve_position(*m, m->pt[i], cs);
+                if (std::max(hs.max_error, cs.max_error) < 0.005f) break;
+            }
+        }
+    }
+
+    // GPU order. Rows live per constraint; deltas live on the bodies, exactly as above.
+    void solve_coloured() {
+        colour_joints();
+        colour_contacts();
+        struct CRows { Manifold *m; Row nr[kMaxContacts]; FrictionRow fr[kMaxContacts]; };
+        struct JRows { Joint *j; int n; Row r[5]; };
+        std::vector<std::vector<CRows>> cc(stats.num_colours);
+        std::vector<std::vector<JRows>> jc(stats.num_joint_colours);
+        stats.num_rows = 0;
+        for (auto &j : joints) {
+            JRows jr; jr.j = &j;
+            jr.n = prepare_joint(j, body_ref(j.body[0]), body_ref(j.body[1]), jr.r);
+            stats.num_rows += jr.n;
+            jc[j.colour].push_back(jr);
+        }
+        for (auto &kv : manifolds) {
+            Manifold &m = kv.second;
+            if (m.num_points == 0) continue;
+            CRows cr; cr.m = &m;
+            BodyRef A = body_ref(m.body[0]), B = body_ref(m.body[1]);
+            for (int i = 0; i < m.num_points; ++i) prepare_contact(m.pt[i], A, B, cr.nr[i], cr.fr[i]);
+            stats.num_rows += m.num_points;
+            cc[m.colour].push_back(cr);
+        }
+        for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) apply_row_impulse(jr.r[i].impulse, jr.r[i]);
+        for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
+        for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+        for (int it = 0; it < vel_iters; ++it) {
+            for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) { float d = solve_row(jr.r[i]); apply_row_impulse(d, jr.r[i]); }
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+        }
+        for (auto &b : bodies) if (b.kind == KIND_DYNAMIC) integrate_body(b);
+        for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) jr.j->impulse[i] = jr.r[i].impulse;
+        for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) {
+            cr.m->pt[i].normal_impulse = cr.nr[i].impulse;
+            cr.m->pt[i].friction_impulse[0] = cr.fr[i].row[0].impulse;
+            cr.m->pt[i].friction_impulse[1] = cr.fr[i].row[1].impulse;
+        }
+        // Position iterations: per-island early-out, islands keyed by label.
+        std::vector<uint8_t> done(bodies.size(), 0);
+        std::vector<float> err(bodies.size(), 0.0f);
+        auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
+        for (int it = 0; it < pos_iters; ++it) {
+            std::fill(err.begin(), err.end(), 0.0f);
+            for (auto &col : jc) for (auto &jr : col) {
+                if (jr.j->type != JOINT_HINGE) continue;
+                uint32_t l = label_of(jr.j->body[0], jr.j->body[1]);
+                if (done[l]) continue;
+                PosSolver ps; hinge_solve_position(*jr.j, ps);
+                err[l] = std::max(err[l], ps.max_error);
+            }
+            for (auto &col : cc) for (auto &cr : col) {
+                uint32_t l = label_of(cr.m->body[0], cr.m->body[1]);
+                if (done[l]) continue;
+                PosSolver ps;
+                for (int i = 0; i < cr.m->num_points; ++i) contact_solve_position(*cr.m, cr.m->pt[i], ps);
+                err[l] = std::max(err[l], ps.max_error);
+            }
+            for (size_t l = 0; l < done.size(); ++l) if (err[l] < 0.005f) done[l] = 1;
+        }
+    }
+
+    bool colour_overflow() const { return colour_overflow_; }
+
+private:
+    DynTree tree_, np_tree_;
+    vec3 dummy_dv_{0, 0, 0}, dummy_dw_{0, 0, 0};
+    bool joints_coloured_ = false;
+    bool colour_overflow_ = false;
+};
+
+}  // namespace orc
