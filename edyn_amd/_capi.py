@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI in include/edynhip.h (libedynhip.so, built in-tree by csrc/Makefile).
+
+The library is the product: there is no Python or CPU fallback. Importing this module without the
+built library raises ImportError; creating a context without a usable GPU raises EdynHipError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libedynhip.so")
+
+
+class EdynHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"edynhip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_bodies", C.c_uint32), ("max_manifolds", C.c_uint32),
+                ("max_joints", C.c_uint32), ("fixed_dt", C.c_float), ("num_velocity_iterations", C.c_uint32),
+                ("num_position_iterations", C.c_uint32), ("gravity", C.c_float * 3), ("flags", C.c_uint32)]
+
+
+class Bodies(C.Structure):
+    _fields_ = [("kind", C.c_void_p), ("pos", C.c_void_p), ("orn", C.c_void_p), ("linvel", C.c_void_p),
+                ("angvel", C.c_void_p), ("mass", C.c_void_p), ("inertia", C.c_void_p), ("has_inertia", C.c_void_p),
+                ("shape_type", C.c_void_p), ("shape_param", C.c_void_p), ("friction", C.c_void_p),
+                ("restitution", C.c_void_p), ("group", C.c_void_p), ("mask", C.c_void_p), ("gravity", C.c_void_p)]
+
+
+class Joints(C.Structure):
+    _fields_ = [("type", C.c_void_p), ("body", C.c_void_p), ("pivot", C.c_void_p), ("axis", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("broadphase_ms", "narrowphase_ms", "islands_ms", "colouring_ms", "prepare_ms",
+                                         "solve_velocity_ms", "integrate_ms", "solve_position_ms", "finish_ms", "step_ms")] + \
+               [("solve_velocity_launches", C.c_uint32), ("steps", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("num_bodies", "num_manifolds", "num_points", "num_active_manifolds",
+                                          "num_islands", "num_colours", "num_joint_colours", "colour_rounds",
+                                          "num_joints", "num_joint_rows")]
+
+
+POINT_DTYPE = np.dtype([
+    ("pivotA", np.float32, 3), ("pivotB", np.float32, 3), ("normal", np.float32, 3),
+    ("local_normal", np.float32, 3), ("distance", np.float32), ("friction", np.float32),
+    ("restitution", np.float32), ("attachment", np.int32), ("lifetime", np.uint32),
+    ("normal_impulse", np.float32), ("friction_impulse", np.float32, 2)])
+MANIFOLD_DTYPE = np.dtype([
+    ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
+
+FLAG_TIMING, FLAG_NO_GRAPH = 1, 2
+STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
+
+# every symbol include/edynhip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_set_stream", "edynhip_set_bodies",
+           "edynhip_set_joints", "edynhip_step", "edynhip_run_stages", "edynhip_synchronize", "edynhip_get_state",
+           "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
+           "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
+           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing - build it with __graft_entry__.build() (make -C edyn_amd/csrc); "
+                              "there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.edynhip_create.restype = C.c_void_p
+        L.edynhip_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int)]
+        L.edynhip_destroy.argtypes = [C.c_void_p]
+        L.edynhip_last_error.restype = C.c_char_p
+        L.edynhip_last_error.argtypes = [C.c_void_p]
+        L.edynhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.edynhip_set_bodies.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Bodies)]
+        L.edynhip_set_joints.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Joints)]
+        L.edynhip_step.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_run_stages.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_synchronize.argtypes = [C.c_void_p]
+        L.edynhip_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.edynhip_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.edynhip_pack_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.edynhip_get_derived.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+        L.edynhip_num_manifolds.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.edynhip_get_manifolds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_set_manifolds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.edynhip_get_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_get_joint_impulses.argtypes = [C.c_void_p, C.c_void_p]
+        L.edynhip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+        L.edynhip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.edynhip_abi_version.restype = C.c_uint32
+        _lib = L
+    return _lib

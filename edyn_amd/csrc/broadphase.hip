@@ -1,0 +1,312 @@
+// Broadphase on the GPU: the reference keeps three incrementally-updated dynamic AABB trees on the
+// CPU (src/edyn/collision/broadphase.cpp:99-195, dynamic_tree.cpp); here the tree over the
+// procedural bodies is REBUILT every step as a linear BVH (Morton sort + Karras radix-tree
+// construction + bottom-up refit), every procedural body queries it in parallel, and the shaped
+// non-procedural bodies (static planes etc.) are tested by brute force. Because the reference's
+// final predicates use the true AABBs (broadphase.cpp:119-155), the manifold set
+//     S_t = { p in S_{t-1} : intersect(box0 grown 0.026, box1) }  U  { p : should_collide, intersect(query grown 0.02, other) }
+// does not depend on the tree, and is reproduced bit-exactly including pair orientation.
+// The pair list is emitted, radix-sorted by canonical key and becomes this step's manifold array;
+// contact points persist by a binary search of the previous step's sorted array.
+#include "ctx.hpp"
+#include "dmath.hpp"
+
+namespace eh {
+using namespace dm;
+
+constexpr float kQueryGrow = 0.03f;              // conservative candidate margin (> 0.026)
+constexpr float kBreaking = 0.02f;               // broadphase.hpp:15 (m_aabb_offset)
+// broadphase.hpp:18: contact_breaking_threshold * scalar(1.3), evaluated in fp32 like the reference
+__device__ __forceinline__ float separation_threshold() { return 0.02f * 1.3f; }
+
+DI int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+DI float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_step_reset(Counters *cnt) {
+    int t = threadIdx.x;
+    if (t == 0) {
+        cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
+        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->num_islands = 0; cnt->colour_rounds = 0;
+    }
+    if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
+    if (t < (int)kMaxColours) { cnt->colour_start[t] = 0; cnt->colour_end[t] = 0; }
+}
+
+__global__ void k_bp_bounds(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin,
+                            const float4 *__restrict__ amax, Counters *cnt) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (t < np) {
+        uint32_t b = proc[t];
+        float4 a = amin[b], c = amax[b];
+        lo[0] = hi[0] = (a.x + c.x) * 0.5f; lo[1] = hi[1] = (a.y + c.y) * 0.5f; lo[2] = hi[2] = (a.z + c.z) * 0.5f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && lo[0] <= hi[0]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&cnt->bounds_min[k], f2ord(lo[k]));
+            atomicMax(&cnt->bounds_max[k], f2ord(hi[k]));
+        }
+    }
+}
+
+DI uint32_t expand10(uint32_t v) {
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void k_bp_morton(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin,
+                            const float4 *__restrict__ amax, const Counters *__restrict__ cnt, uint64_t *keys) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= np) return;
+    uint32_t b = proc[t];
+    float4 a = amin[b], c = amax[b];
+    float ctr[3] = {(a.x + c.x) * 0.5f, (a.y + c.y) * 0.5f, (a.z + c.z) * 0.5f};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float lo = ord2f(cnt->bounds_min[k]), hi = ord2f(cnt->bounds_max[k]);
+        float ext = hi - lo;
+        float u = ext > 0.0f ? (ctr[k] - lo) / ext : 0.0f;
+        int qi = (int)(u * 1023.0f);
+        q[k] = (uint32_t)min(max(qi, 0), 1023);
+    }
+    uint32_t code = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    keys[t] = ((uint64_t)code << 32) | b;
+}
+
+// Karras 2012 radix tree over unique 64-bit keys. Node ids: internal i in [0,n-2], leaf k -> n-1+k.
+DI int delta(const uint64_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+__global__ void k_bp_build(const uint64_t *__restrict__ keys, int n, uint32_t *parent, uint32_t *left, uint32_t *right,
+                           uint32_t *visit) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    visit[i] = 0;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    uint32_t lc = (min(i, j) == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+    uint32_t rc = (max(i, j) == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    left[i] = lc; right[i] = rc;
+    parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
+    if (i == 0) parent[0] = 0xFFFFFFFFu;
+}
+
+// Node boxes are exchanged between workgroups inside this launch, so they travel as 8-byte
+// agent-scope atomics on both sides (per-CU L1s and per-XCD L2s are not coherent for plain accesses).
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+DI unsigned long long pack2(float a, float b) { return ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a); }
+DI void store_box(float4 *nmin, float4 *nmax, uint32_t node, f3 mn, f3 mx) {
+    unsigned long long *p0 = (unsigned long long *)&nmin[node];
+    unsigned long long *p1 = (unsigned long long *)&nmax[node];
+    __hip_atomic_store(p0, pack2(mn.x, mn.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p0 + 1, pack2(mn.z, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p1, pack2(mx.x, mx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p1 + 1, pack2(mx.z, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DI void load_box(const float4 *nmin, const float4 *nmax, uint32_t node, f3 &mn, f3 &mx) {
+    unsigned long long *p0 = (unsigned long long *)&nmin[node];
+    unsigned long long *p1 = (unsigned long long *)&nmax[node];
+    unsigned long long a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long b = __hip_atomic_load(p0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long c = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long d = __hip_atomic_load(p1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mn = {__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b)};
+    mx = {__uint_as_float((uint32_t)c), __uint_as_float((uint32_t)(c >> 32)), __uint_as_float((uint32_t)d)};
+}
+
+__global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ parent,
+                           const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                           const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
+                           uint32_t *visit) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+    f3 mn = from4(amin[body]), mx = from4(amax[body]);
+    uint32_t node = (uint32_t)(n - 1 + k);
+    store_box(nmin, nmax, node, mn, mx);
+    if (n == 1) return;
+    uint32_t p = parent[node];
+    while (p != 0xFFFFFFFFu) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box stores drained before the arrival ticket
+        uint32_t old = atomicAdd(&visit[p], 1u);
+        if (old == 0) return;                              // first arriver leaves; the second one continues
+        uint32_t sib = left[p] == node ? right[p] : left[p];
+        f3 smn, smx;
+        load_box(nmin, nmax, sib, smn, smx);
+        mn = {fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z)};
+        mx = {fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z)};
+        store_box(nmin, nmax, p, mn, mx);
+        node = p;
+        p = parent[p];
+    }
+}
+
+DI box3 body_box(const float4 *amin, const float4 *amax, uint32_t b) { return {from4(amin[b]), from4(amax[b])}; }
+DI bool filter_ok(const uint64_t *group, const uint64_t *mask, uint32_t a, uint32_t b) {   // should_collide.cpp:23-57
+    return (group[a] & mask[b]) != 0 && (group[b] & mask[a]) != 0;
+}
+// lower_bound over the previous step's sorted skeys for canonical key `key`; returns index or ~0u.
+DI uint32_t find_prev(const uint64_t *__restrict__ pskey, uint32_t pm, uint64_t key) {
+    uint32_t lo = 0, hi = pm;
+    const uint64_t target = key << 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pskey[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    if (lo < pm && (pskey[lo] >> 1) == key) return lo;
+    return 0xFFFFFFFFu;
+}
+DI void emit_pair(uint64_t skey, uint64_t *out, uint32_t cap, Counters *cnt) {
+    uint32_t idx = atomicAdd(&cnt->num_pairs, 1u);
+    if (idx < cap) out[idx] = skey; else cnt->pair_overflow = 1;
+}
+// Decide whether the unordered pair {i (procedural, the querying body), j} is in this step's set.
+DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
+                      const uint64_t *mask, bool j_procedural, const uint64_t *pskey, uint32_t pm, uint64_t *out, uint32_t cap,
+                      Counters *cnt) {
+    const uint32_t hi = i > j ? i : j, lo = i > j ? j : i;
+    const uint64_t key = ((uint64_t)hi << 32) | lo;
+    const box3 bj = body_box(amin, amax, j);
+    uint32_t prev = find_prev(pskey, pm, key);
+    if (prev != 0xFFFFFFFFu) {   // destroy_separated_manifolds, broadphase.cpp:119-134
+        const uint64_t ps = pskey[prev];
+        const bool swapped = ps & 1;
+        const uint32_t b0 = swapped ? lo : hi;
+        const box3 &x0 = b0 == i ? bi : bj, &x1 = b0 == i ? bj : bi;
+        if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, out, cap, cnt);
+        return;
+    }
+    if (!filter_ok(group, mask, i, j)) return;
+    // collide_tree, broadphase.cpp:136-155: querying body's box grown by 0.02 vs the other's true box.
+    // Bodies are visited in descending index order, so the higher index gets to create the pair first.
+    const box3 &bh = hi == i ? bi : bj, &bl = hi == i ? bj : bi;
+    if (j_procedural) {
+        if (intersect(inset(bh, -kBreaking), bl)) emit_pair(key << 1, out, cap, cnt);
+        else if (intersect(inset(bl, -kBreaking), bh)) emit_pair((key << 1) | 1, out, cap, cnt);
+    } else {
+        if (intersect(inset(bi, -kBreaking), bj)) emit_pair((key << 1) | (i == lo ? 1u : 0u), out, cap, cnt);
+    }
+}
+
+__global__ void __launch_bounds__(128)
+k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+           const float4 *__restrict__ nmin, const float4 *__restrict__ nmax, const float4 *__restrict__ amin,
+           const float4 *__restrict__ amax, const uint64_t *__restrict__ group, const uint64_t *__restrict__ mask,
+           const uint32_t *__restrict__ np_list, uint32_t num_np, const uint64_t *__restrict__ pskey, uint32_t pm,
+           uint64_t *out, uint32_t cap, Counters *cnt) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+    const box3 bi = body_box(amin, amax, i);
+    const box3 q = inset(bi, -kQueryGrow);
+    if (n > 1) {
+        uint32_t stack[64];
+        int sp = 0;
+        stack[sp++] = 0;
+        while (sp > 0) {
+            uint32_t node = stack[--sp];
+            box3 nb{from4(nmin[node]), from4(nmax[node])};
+            if (!intersect(nb, q)) continue;
+            if (node >= (uint32_t)(n - 1)) {
+                uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
+                if (j < i) consider_pair(i, j, bi, amin, amax, group, mask, true, pskey, pm, out, cap, cnt);
+            } else if (sp <= 62) {
+                stack[sp++] = left[node];
+                stack[sp++] = right[node];
+            }
+        }
+    }
+    for (uint32_t t = 0; t < num_np; ++t) {
+        uint32_t j = np_list[t];
+        box3 bj = body_box(amin, amax, j);
+        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, pskey, pm, out, cap, cnt);
+    }
+}
+
+// New manifold array from the sorted pair keys; contact points persist from the previous array.
+__global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint64_t sk = skeys[m];
+    const uint64_t key = sk >> 1;
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const bool swapped = sk & 1;
+    cur.skey[m] = sk;
+    cur.bodyA[m] = swapped ? lo : hi;
+    cur.bodyB[m] = swapped ? hi : lo;
+    uint32_t p = find_prev(prev.skey, pm, key);
+    uint32_t info = kNoColour << 8;
+    if (p != 0xFFFFFFFFu) {
+        info = prev.info[p];
+        const uint32_t np = info & 0xFF;
+        for (uint32_t k = 0; k < np; ++k) {
+            const size_t s = (size_t)k * prev.cap + p, d = (size_t)k * cur.cap + m;
+            cur.pA[d] = prev.pA[s]; cur.pB[d] = prev.pB[s]; cur.nrm[d] = prev.nrm[s];
+            cur.lnrm[d] = prev.lnrm[s]; cur.imp[d] = prev.imp[s];
+        }
+    }
+    cur.info[m] = info;
+}
+
+static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
+
+int broadphase(edynhip_ctx *c) {
+    hipStream_t s = c->stream;
+    const uint32_t np = c->bvh.num_proc;
+    Manifolds &prev = c->m[c->cur], &cur = c->m[c->cur ^ 1];
+    const uint32_t pm = c->num_manifolds;
+    hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
+    uint32_t M = 0;
+    if (np > 0) {
+        hipLaunchKernelGGL(k_bp_bounds, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt);
+        hipLaunchKernelGGL(k_bp_morton, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt, c->bvh.keys);
+        EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 62));
+        if (np > 1)
+            hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
+        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.left, c->bvh.right, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev.skey, pm, c->pair_keys, cur.cap, c->cnt);
+        // pair count is needed on the host to size the sort and the manifold kernels
+        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        EH_HIP(c, hipStreamSynchronize(s));
+        if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, "broadphase: pair capacity (max_manifolds) exceeded");
+        M = c->cnt_host->num_pairs;
+        EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 64));
+        if (M > 0)
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm);
+    }
+    c->cur ^= 1;
+    c->num_manifolds = M;
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
+}
+
+}  // namespace eh

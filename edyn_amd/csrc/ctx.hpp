@@ -1,0 +1,171 @@
+// Device-resident mirror of the EnTT component pools used by the step loop, and the per-step
+// scratch. One context per GPU. All per-body / per-manifold data are "SoA of float4": one array per
+// component (like an EnTT pool), 16 B elements, so body-parallel kernels stream coalesced and the
+// solver's by-index gathers fetch a whole component in one transaction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/edynhip.h"
+
+namespace eh {
+
+constexpr uint32_t kNoColour = 0xFFu;
+constexpr uint32_t kMaxColours = 64;
+constexpr int kMaxPts = 4;
+
+// body flags
+constexpr uint32_t BF_KIND_MASK = 0x3u;        // EDYNHIP_KIND_*
+constexpr uint32_t BF_SHAPE_SHIFT = 4;         // EDYNHIP_SHAPE_* in bits 4..7
+constexpr uint32_t BF_SHAPE_MASK = 0xF0u;
+
+struct Bodies {
+    uint32_t n = 0, cap = 0;
+    float4 *pos = nullptr;      // xyz, w = mass_inv (dynamic) or 0
+    float4 *orn = nullptr;      // xyzw
+    float4 *linvel = nullptr;   // xyz
+    float4 *angvel = nullptr;   // xyz
+    float4 *dv = nullptr;       // delta_linvel xyz, w = effective inv mass (0 for non-procedural)
+    float4 *dw = nullptr;       // delta_angvel xyz
+    float4 *iw = nullptr;       // inertia_world_inv, 3 rows per body [3*i + r]
+    float4 *il = nullptr;       // inertia_inv (local), 3 rows per body
+    float4 *amin = nullptr;     // AABB min
+    float4 *amax = nullptr;     // AABB max
+    float4 *shape = nullptr;    // box half extents | sphere radius | plane normal+constant
+    float4 *grav = nullptr;     // per-body gravity
+    float2 *mat = nullptr;      // friction, restitution
+    uint32_t *flags = nullptr;  // kind | shape << 4
+    uint64_t *group = nullptr, *mask = nullptr;
+    uint32_t *island = nullptr; // connected-component label (min body index)
+};
+
+// Contact manifolds, rebuilt every step in ascending canonical key order (double buffered).
+struct Manifolds {
+    uint32_t cap = 0;
+    uint64_t *skey = nullptr;     // (hi<<32|lo)<<1 | swapped   (swapped: body[0] == lo)
+    uint32_t *bodyA = nullptr, *bodyB = nullptr;
+    uint32_t *info = nullptr;     // num_points | colour << 8
+    // per point slot k (list order, newest first): index k*cap + m
+    float4 *pA = nullptr;         // pivotA xyz, w = distance
+    float4 *pB = nullptr;         // pivotB xyz, w = friction
+    float4 *nrm = nullptr;        // normal xyz, w = bitcast(attachment)
+    float4 *lnrm = nullptr;       // local_normal xyz, w = restitution
+    float4 *imp = nullptr;        // normal_impulse, friction_impulse[0], [1], bitcast(lifetime)
+};
+
+struct Joints {
+    uint32_t n = 0, cap = 0, num_colours = 0, rows = 0;
+    // definitions, in colour-sorted order (static); orig[] maps back to the caller's index
+    uint32_t *orig = nullptr;
+    uint32_t *type = nullptr, *bodyA = nullptr, *bodyB = nullptr;
+    float4 *pivA = nullptr, *pivB = nullptr;       // object-space pivots
+    float4 *axA = nullptr;                          // frame[0] column 0 (hinge axis on A)
+    float4 *pA = nullptr, *qA = nullptr;            // frame[0] columns 1, 2
+    float4 *axB = nullptr;                          // frame[1] column 0
+    float *impulse = nullptr;                       // [5][cap]
+    // rows (per step)
+    float4 *rA = nullptr, *rB = nullptr;            // lever arms
+    float4 *wp = nullptr, *wq = nullptr;            // world hinge p, q
+    float *eff = nullptr, *rhs = nullptr;           // [5][cap]
+    uint32_t colour_start[kMaxColours + 1] = {0};   // host copy
+};
+
+// Solver rows in colour-sorted order p. Jacobians are stored compressed: normal n and lever arms
+// rA, rB; the friction tangents and all angular parts are recomputed from them (same arithmetic as
+// prep, hence bit-identical to stored Jacobians).
+struct Rows {
+    uint32_t *order = nullptr;    // p -> manifold index
+    uint32_t *bA = nullptr, *bB = nullptr, *np = nullptr;
+    // per point slot k: index k*cap + p
+    float4 *r0 = nullptr;         // n.xyz, eff_mass_n
+    float4 *r1 = nullptr;         // rA.xyz, rhs_n
+    float4 *r2 = nullptr;         // rB.xyz, impulse_n
+    float4 *r3 = nullptr;         // eff_t0, eff_t1, rhs_t0, rhs_t1
+    float4 *r4 = nullptr;         // impulse_t0, impulse_t1, mu, 0
+};
+
+struct LBVH {
+    uint64_t *keys = nullptr, *keys_sorted = nullptr;   // morton<<32 | body
+    uint32_t *parent = nullptr;     // [2n-1]: internal 0..n-2, leaves n-1..2n-2
+    uint32_t *left = nullptr, *right = nullptr;   // internal nodes
+    float4 *nmin = nullptr, *nmax = nullptr;      // node boxes [2n-1]
+    uint32_t *visit = nullptr;      // refit counters
+    uint32_t *np_list = nullptr;    // shaped non-procedural bodies
+    uint32_t num_proc = 0, num_np = 0;
+};
+
+// Device counters / flags block, mirrored to pinned host memory once or twice per step.
+struct Counters {
+    uint32_t num_pairs;          // pairs emitted this step
+    uint32_t pair_overflow;
+    uint32_t num_points;
+    uint32_t num_active;         // manifolds with points
+    uint32_t uncoloured;         // edges still lacking a colour
+    uint32_t colour_overflow;
+    uint32_t num_islands;
+    uint32_t colour_rounds;
+    int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
+    uint32_t colour_start[kMaxColours], colour_end[kMaxColours];
+};
+
+struct StageTimer { hipEvent_t e[12]; bool made = false; };
+
+}  // namespace eh
+
+struct edynhip_ctx {
+    edynhip_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    eh::Bodies b;
+    eh::Manifolds m[2];
+    int cur = 0;                   // index of the current manifold buffer
+    uint32_t num_manifolds = 0;    // in m[cur]
+    eh::Joints j;
+    eh::Rows rows;
+    eh::LBVH bvh;
+    uint64_t *pair_keys = nullptr, *pair_keys_sorted = nullptr;
+    uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr, *col_vals = nullptr;   // colour sort
+    uint64_t *used = nullptr;      // per body: colours in use
+    uint64_t *best[2] = {nullptr, nullptr};
+    float *isl_err = nullptr;      // per island label: max position error (as uint bits)
+    uint32_t *isl_done = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    eh::Counters *cnt = nullptr;   // device
+    eh::Counters *cnt_host = nullptr;   // pinned
+    eh::StageTimer timer;
+    edynhip_timings timings{};
+    edynhip_stats stats{};
+    uint32_t num_colours = 0;
+    uint32_t colour_start[eh::kMaxColours] = {0}, colour_end[eh::kMaxColours] = {0};
+    uint32_t num_active = 0;
+    std::vector<void *> allocs;
+    bool joints_dirty = false;
+};
+
+namespace eh {
+// stage entry points (each .hip file implements its own)
+int broadphase(edynhip_ctx *c);
+int narrowphase(edynhip_ctx *c);
+int islands(edynhip_ctx *c);
+int solve(edynhip_ctx *c);
+// sort helpers (sort.hip)
+size_t sort_temp_bytes(uint32_t max_items);
+int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int end_bit);
+int sort_pairs_u32(edynhip_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n, int end_bit);
+int set_error(edynhip_ctx *c, int code, const char *what, hipError_t e = hipSuccess);
+}  // namespace eh
+
+#define EH_HIP(c, call)                                                          \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) return eh::set_error((c), EDYNHIP_ERR_HIP, #call, e__); \
+    } while (0)
+#define EH_TRY(expr)                    \
+    do {                                \
+        int r__ = (expr);               \
+        if (r__ != EDYNHIP_OK) return r__; \
+    } while (0)

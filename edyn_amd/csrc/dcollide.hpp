@@ -1,0 +1,528 @@
+// Device-side closest-feature collision for the shape pairs on the hot path and the ≤4-point
+// manifold maintenance, executed one manifold per lane by k_narrowphase (narrowphase.hip).
+// Behaviour follows the reference routines named at each function; arithmetic order is kept so that
+// results are bit-identical to a scalar fp32 evaluation.
+#pragma once
+#include "dmath.hpp"
+
+namespace dc {
+using namespace dm;
+
+constexpr int kMaxContacts = 4;                     // config/constants.hpp:9
+constexpr float kCollisionThreshold = 0.01f;        // :15
+constexpr float kBreakingThreshold = 0.02f;         // :21
+constexpr float kMergingThreshold = 0.01f;          // :27
+constexpr float kCachingThreshold = 0.04f;          // :34
+constexpr float kSupportTolerance = 0.005f;         // :56
+
+enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3 };
+enum { BF_VERTEX = 0, BF_EDGE = 1, BF_FACE = 2 };
+enum { NA_NONE = 0, NA_ON_A = 1, NA_ON_B = 2 };
+enum { INS_NONE = 0, INS_APPEND = 1, INS_SIMILAR = 2, INS_REPLACE = 3 };
+
+// include/edyn/shapes/box_shape.hpp:22-47 and src/edyn/shapes/box_shape.cpp:115-168 (feature tables)
+__device__ static const signed char kVertSign[8][3] = {{1, 1, 1}, {1, -1, 1}, {1, -1, -1}, {1, 1, -1},
+                                                        {-1, 1, 1}, {-1, 1, -1}, {-1, -1, -1}, {-1, -1, 1}};
+__device__ static const unsigned char kEdgeIdx[24] = {0, 1, 1, 2, 2, 3, 3, 0, 4, 5, 5, 6, 6, 7, 7, 4, 0, 4, 1, 7, 2, 6, 3, 5};
+__device__ static const unsigned char kFaceIdx[24] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 3, 5, 4, 1, 7, 6, 2, 0, 4, 7, 1, 3, 2, 6, 5};
+__device__ static const signed char kFaceNormal[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+__device__ static const signed char kFaceTangent[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+
+DI f3 box_vertex(f3 h, int i) {
+    return h * mk3((float)kVertSign[i][0], (float)kVertSign[i][1], (float)kVertSign[i][2]);
+}
+DI f3 face_normal(int f) { return mk3((float)kFaceNormal[f][0], (float)kFaceNormal[f][1], (float)kFaceNormal[f][2]); }
+DI f3 face_tangent(int f) { return mk3((float)kFaceTangent[f][0], (float)kFaceTangent[f][1], (float)kFaceTangent[f][2]); }
+DI f3 support_point_box(f3 h, f3 d) { return {d.x > 0 ? h.x : -h.x, d.y > 0 ? h.y : -h.y, d.z > 0 ? h.z : -h.z}; }
+DI float box_support_projection(f3 h, f3 pos, q4 orn, f3 dir) {   // box_shape.cpp:24-28
+    f3 ld = rotate(conjugate(orn), dir);
+    f3 pt = support_point_box(h, ld);
+    return dot(pos, dir) + dot(pt, ld);
+}
+DI int support_face_index(f3 d) {   // box_shape.cpp:227-235 via max_index_abs
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    float m = ax; int i = 0;
+    if (ay > m) { m = ay; i = 1; }
+    if (az > m) { i = 2; }
+    return comp(d, i) < 0 ? i * 2 + 1 : i * 2;
+}
+DI int edge_index(int v0, int v1) {
+    for (int i = 0; i < 12; ++i) {
+        int a = kEdgeIdx[i * 2], b = kEdgeIdx[i * 2 + 1];
+        if ((a == v0 && b == v1) || (b == v0 && a == v1)) return i;
+    }
+    return 0;
+}
+// box_shape.cpp:30-96, object-space direction
+DI void support_feature_local(f3 h, f3 dir, int &feature, int &findex, float &projection, float threshold) {
+    const int face = support_face_index(dir);
+    float proj[4]; int vidx[4]; int idx[4] = {0, 0, 0, 0};
+    int count = 1, maxi = 0;
+    projection = -kScalarMax;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int vi = kFaceIdx[face * 4 + i];
+        vidx[i] = vi;
+        float p = dot(box_vertex(h, vi), dir);
+        proj[i] = p;
+        if (p > projection) { projection = p; idx[0] = i; maxi = i; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i != maxi && proj[i] > projection - threshold) idx[count++] = i;
+    if (count == 1) { feature = BF_VERTEX; findex = vidx[idx[0]]; }
+    else if (count == 2) { feature = BF_EDGE; findex = edge_index(vidx[idx[0]], vidx[idx[1]]); }
+    else if (count == 3) {
+        feature = BF_EDGE;
+        float p0 = proj[idx[0]], p1 = proj[idx[1]], p2 = proj[idx[2]];
+        if (p0 <= p1 && p0 <= p2) findex = edge_index(vidx[idx[1]], vidx[idx[2]]);
+        else if (p1 <= p0 && p1 <= p2) findex = edge_index(vidx[idx[0]], vidx[idx[2]]);
+        else findex = edge_index(vidx[idx[0]], vidx[idx[1]]);
+    } else { feature = BF_FACE; findex = face; }
+}
+DI void support_feature(f3 h, f3 pos, q4 orn, f3 axis_pos, f3 axis_dir, int &feature, int &findex, float &projection,
+                        float threshold) {
+    f3 ld = rotate(conjugate(orn), axis_dir);
+    support_feature_local(h, ld, feature, findex, projection, threshold);
+    projection += dot(pos - axis_pos, axis_dir);
+}
+DI void face_world(f3 h, int f, f3 pos, q4 orn, f3 out[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = to_world(box_vertex(h, kFaceIdx[f * 4 + i]), pos, orn);
+}
+DI void edge_world(f3 h, int e, f3 pos, q4 orn, f3 out[2]) {
+    out[0] = to_world(box_vertex(h, kEdgeIdx[e * 2]), pos, orn);
+    out[1] = to_world(box_vertex(h, kEdgeIdx[e * 2 + 1]), pos, orn);
+}
+DI f3 face_normal_world(int f, q4 orn) { return rotate(orn, face_normal(f)); }
+DI f3 face_center(f3 h, int f, f3 pos, q4 orn) { return pos + face_normal_world(f, orn) * comp(h, f / 2); }
+DI m3 face_basis(int f, q4 orn) {
+    f3 y = face_normal(f), x = face_tangent(f), z = cross(x, y);
+    return m3_columns(rotate(orn, x), rotate(orn, y), rotate(orn, z));
+}
+DI f2 face_half_extents(f3 h, int f) {
+    if (f == 0 || f == 1) return {h.z, h.y};
+    if (f == 2 || f == 3) return {h.x, h.z};
+    return {h.y, h.x};
+}
+
+// include/edyn/math/geom.hpp:331-348 (N = 4)
+DI bool point_in_quad_prism(const f3 v[4], f3 normal, f3 point) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int j = (i + 1) & 3;
+        f3 t = cross(v[j] - v[i], normal);
+        if (dot(point - v[i], t) > kEps) return false;
+    }
+    return true;
+}
+DI bool point_in_triangle(f3 v0, f3 v1, f3 v2, f3 normal, f3 p) {   // src/edyn/math/triangle.cpp:7-26
+    f3 e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+    f3 q0 = p - v0, q1 = p - v1, q2 = p - v2;
+    float d0 = dot(cross(e0, normal), q0), d1 = dot(cross(e1, normal), q1), d2 = dot(cross(e2, normal), q2);
+    return (d0 > -kEps && d1 > -kEps && d2 > -kEps) || (d0 < kEps && d1 < kEps && d2 < kEps);
+}
+// src/edyn/math/geom.cpp:1044-1138
+DI int intersect_line_aabb(f2 p0, f2 p1, f2 bmin, f2 bmax, float &s0, float &s1) {
+    int n = 0;
+    f2 d = p1 - p0, e = bmin - p0, f = bmax - p0;
+    if (fabsf(d.x) < kEps) {
+        if (e.x <= 0 && f.x >= 0) { s0 = e.y / d.y; s1 = f.y / d.y; n = 2; }
+        return n;
+    }
+    if (fabsf(d.y) < kEps) {
+        if (e.y <= 0 && f.y >= 0) { s0 = e.x / d.x; s1 = f.x / d.x; n = 2; }
+        return n;
+    }
+    { float t = e.x / d.x, qy = p0.y + d.y * t;
+      if (qy >= bmin.y && qy < bmax.y) { s0 = t; ++n; } }
+    { float t = f.x / d.x, qy = p0.y + d.y * t;
+      if (qy > bmin.y && qy <= bmax.y) {
+          if (n == 0) { s0 = t; ++n; } else if (fabsf(t - s0) > kEps) { s1 = t; ++n; } } }
+    if (n == 2) return n;
+    { float t = e.y / d.y, qx = p0.x + d.x * t;
+      if (qx >= bmin.x && qx < bmax.x) {
+          if (n == 0) { s0 = t; ++n; } else if (fabsf(t - s0) > kEps) { s1 = t; ++n; } } }
+    if (n == 2) return n;
+    { float t = f.y / d.y, qx = p0.x + d.x * t;
+      if (qx > bmin.x && qx <= bmax.x) {
+          if (n == 0) { s0 = t; ++n; } else if (fabsf(t - s0) > kEps) { s1 = t; ++n; } } }
+    return n;
+}
+// src/edyn/math/geom.cpp:73-170 (always called with num_points != nullptr on this path)
+DI void closest_segment_segment(f3 p1, f3 q1, f3 p2, f3 q2, f3 &c1, f3 &c2, int &num, f3 &c1p, f3 &c2p) {
+    const f3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    float s, t;
+    if (a <= kEps && e <= kEps) { c1 = p1; c2 = p2; return; }
+    if (a <= kEps) {
+        s = 0; t = f / e; t = clamp_unit(t);
+    } else {
+        float c = dot(d1, r);
+        if (e <= kEps) {
+            t = 0; s = clamp_unit(-c / a);
+        } else {
+            const float b = dot(d1, d2);
+            const float denom = a * e - b * b;
+            if (denom > kEps) {
+                s = clamp_unit((b * f - c * e) / denom);
+                num = 1;
+            } else {
+                f3 r1 = p1 - q2;
+                float f1 = dot(d1, r1);
+                float a_inv = 1 / a;
+                s = clamp_unit(fminf(-c * a_inv, -f1 * a_inv));
+                float sp = clamp_unit(fmaxf(-c * a_inv, -f1 * a_inv));
+                f3 r2 = p2 - q1;
+                float f2v = dot(d2, r2);
+                float e_inv = 1 / e;
+                t = clamp_unit(fminf(-f * e_inv, -f2v * e_inv));
+                float tp = clamp_unit(fmaxf(-f * e_inv, -f2v * e_inv));
+                if (fabsf(s - sp) > kEps) { num = 2; c1p = p1 + d1 * sp; c2p = p2 + d2 * tp; }
+                else num = 1;
+            }
+            const float tnom = b * s + f;
+            if (tnom < 0) { t = 0; s = clamp_unit(-c / a); }
+            else if (tnom > e) { t = 1; s = clamp_unit((b - c) / a); }
+            else t = tnom / e;
+        }
+    }
+    c1 = p1 + d1 * s;
+    c2 = p2 + d2 * t;
+}
+DI f3 closest_point_box_outside(f3 h, f3 p) {
+    f3 c = p;
+    c.x = fminf(h.x, c.x); c.x = fmaxf(-h.x, c.x);
+    c.y = fminf(h.y, c.y); c.y = fmaxf(-h.y, c.y);
+    c.z = fminf(h.z, c.z); c.z = fmaxf(-h.z, c.z);
+    return c;
+}
+DI float closest_point_box_inside(f3 h, f3 p, f3 &closest, f3 &normal) {   // geom.cpp:998-1042 (returns last dist)
+    float dist = h.x - p.x, md = dist;
+    closest = {h.x, p.y, p.z}; normal = {1, 0, 0};
+    dist = h.x + p.x; if (dist < md) { md = dist; closest = {-h.x, p.y, p.z}; normal = {-1, 0, 0}; }
+    dist = h.y - p.y; if (dist < md) { md = dist; closest = {p.x, h.y, p.z}; normal = {0, 1, 0}; }
+    dist = h.y + p.y; if (dist < md) { md = dist; closest = {p.x, -h.y, p.z}; normal = {0, -1, 0}; }
+    dist = h.z - p.z; if (dist < md) { md = dist; closest = {p.x, p.y, h.z}; normal = {0, 0, 1}; }
+    dist = h.z + p.z; if (dist < md) { md = dist; closest = {p.x, p.y, -h.z}; normal = {0, 0, -1}; }
+    return dist;
+}
+DI float manifold_score(f3 p0, f3 p1, f3 p2, f3 p3) {   // geom.cpp:846-855
+    f3 c0 = cross(p0 - p1, p0 - p2), c1 = cross(p0 - p2, p0 - p3), c2 = cross(p0 - p3, p0 - p1), c3 = cross(p1 - p2, p2 - p3);
+    return length_sqr(c0) + length_sqr(c1) + length_sqr(c2) + length_sqr(c3);
+}
+// geom.cpp:857-985. Returns type | index << 8; increments num_points on append.
+DI int insertion_point_index(const f3 p[4], int &num_points, f3 np) {
+    const float sim2 = kMergingThreshold * kMergingThreshold;
+    if (num_points == 0) { int i = num_points++; return INS_APPEND | i << 8; }
+    if (num_points == 1) {
+        if (distance_sqr(np, p[0]) > sim2) { int i = num_points++; return INS_APPEND | i << 8; }
+        return INS_SIMILAR;
+    }
+    if (num_points == 2) {
+        if (length_sqr(cross(np - p[0], np - p[1])) > kEps) { int i = num_points++; return INS_APPEND | i << 8; }
+        float d0 = distance_sqr(np, p[0]), d1 = distance_sqr(np, p[1]), cur = distance_sqr(p[0], p[1]);
+        if (d0 > cur && d0 > d1) return (d1 < sim2 ? INS_SIMILAR : INS_REPLACE) | 1 << 8;
+        if (d1 > cur && d1 > d0) return (d0 < sim2 ? INS_SIMILAR : INS_REPLACE) | 0 << 8;
+        return INS_NONE;
+    }
+    if (num_points == 3) {
+        f3 normal = cross(p[0] - p[1], p[1] - p[2]);
+        if (try_normalize(normal)) {
+            if (fabsf(dot(np - p[0], normal)) < kEps && point_in_triangle(p[0], p[1], p[2], normal, np)) return INS_NONE;
+            int i = num_points++;
+            return INS_APPEND | i << 8;
+        }
+        float d0 = dot(p[1] - p[0], p[2] - p[0]);
+        if (d0 > 0 && d0 < 1) return INS_REPLACE | 1 << 8;
+        float d1 = dot(p[0] - p[1], p[2] - p[1]);
+        if (d1 > 0 && d1 < 1) return INS_REPLACE | 0 << 8;
+        float d2 = dot(p[2] - p[0], p[1] - p[0]);
+        if (d2 > 0 && d2 < 1) return INS_REPLACE | 2 << 8;
+        float ds0 = distance_sqr(p[0], p[1]), ds1 = distance_sqr(p[1], p[2]), ds2 = distance_sqr(p[2], p[0]);
+        int mi = 0xFF; float md = kScalarMax;
+        if (ds0 < md) { md = ds0; mi = 0; }
+        if (ds1 < md) { md = ds1; mi = 1; }
+        if (ds2 < md) { md = ds2; mi = 2; }
+        return INS_REPLACE | mi << 8;
+    }
+    float s0 = manifold_score(np, p[1], p[2], p[3]);
+    float s1 = manifold_score(np, p[0], p[2], p[3]);
+    float s2 = manifold_score(np, p[0], p[1], p[3]);
+    float s3 = manifold_score(np, p[0], p[1], p[2]);
+    float best = manifold_score(p[0], p[1], p[2], p[3]);
+    int bi = -1;
+    if (s0 > best) { best = s0; bi = 0; }
+    if (s1 > best) { best = s1; bi = 1; }
+    if (s2 > best) { best = s2; bi = 2; }
+    if (s3 > best) { best = s3; bi = 3; }
+    if (bi >= 0) {
+        f3 pb = bi == 0 ? p[0] : (bi == 1 ? p[1] : (bi == 2 ? p[2] : p[3]));
+        return (distance_sqr(pb, np) < sim2 ? INS_SIMILAR : INS_REPLACE) | bi << 8;
+    }
+    return INS_NONE;
+}
+
+struct CPoint { f3 pivotA, pivotB, normal; float distance; int attachment; };
+struct CResult {
+    int num;
+    CPoint pt[kMaxContacts];
+};
+DI void cp_swap(CPoint &p) {   // collision_result.hpp:23-35
+    f3 t = p.pivotA; p.pivotA = p.pivotB; p.pivotB = t;
+    p.normal *= -1.0f;
+    if (p.attachment == NA_ON_A) p.attachment = NA_ON_B;
+    else if (p.attachment == NA_ON_B) p.attachment = NA_ON_A;
+}
+DI void res_add(CResult &r, const CPoint &p) { r.pt[r.num++] = p; }
+DI void res_maybe_add(CResult &r, const CPoint &np) {   // collision_result.cpp:12-33
+    f3 piv[kMaxContacts];
+#pragma unroll
+    for (int i = 0; i < kMaxContacts; ++i) piv[i] = r.pt[i].pivotA;
+    int res = insertion_point_index(piv, r.num, np.pivotA);
+    if ((res & 0xFF) == INS_NONE) {
+#pragma unroll
+        for (int i = 0; i < kMaxContacts; ++i) piv[i] = r.pt[i].pivotB;
+        res = insertion_point_index(piv, r.num, np.pivotB);
+    }
+    if ((res & 0xFF) != INS_NONE) r.pt[res >> 8] = np;
+}
+
+struct Ctx { f3 posA; q4 ornA; f3 posB; q4 ornB; float threshold; };
+
+// src/edyn/collision/collide/collide_box_box.cpp:14-266
+DI void collide_box_box(f3 hA, f3 hB, const Ctx &c, CResult &result) {
+    const f3 posA = c.posA, posB = c.posB;
+    const q4 ornA = c.ornA, ornB = c.ornB;
+    f3 axA[3] = {rotate(ornA, mk3(1, 0, 0)), rotate(ornA, mk3(0, 1, 0)), rotate(ornA, mk3(0, 0, 1))};
+    f3 axB[3] = {rotate(ornB, mk3(1, 0, 0)), rotate(ornB, mk3(0, 1, 0)), rotate(ornB, mk3(0, 0, 1))};
+    float distance = -kScalarMax;
+    f3 sep = mk3(0, 0, 0);
+    const f3 dAB = posA - posB;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f3 dir = axA[i];
+        if (dot(dAB, dir) < 0) dir = -dir;
+        float projA = dot(posA, dir) - comp(hA, i);
+        float projB = box_support_projection(hB, posB, ornB, dir);
+        float dist = projA - projB;
+        if (dist > distance) { distance = dist; sep = dir; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f3 dir = axB[i];
+        if (dot(dAB, dir) < 0) dir = -dir;
+        float projA = -box_support_projection(hA, posA, ornA, -dir);
+        float projB = dot(posB, dir) + comp(hB, i);
+        float dist = projA - projB;
+        if (dist > distance) { distance = dist; sep = dir; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f3 dir = cross(axA[i], axB[j]);
+            float l2 = length_sqr(dir);
+            if (!(l2 > kEps)) continue;
+            dir = div_recip(dir, sqrtf(l2));
+            if (dot(dAB, dir) < 0) dir *= -1.0f;
+            float projA = -box_support_projection(hA, posA, ornA, -dir);
+            float projB = box_support_projection(hB, posB, ornB, dir);
+            float dist = projA - projB;
+            if (dist > distance) { distance = dist; sep = dir; }
+        }
+    if (distance > c.threshold) return;
+
+    int featA, featB, idxA, idxB;
+    float prA, prB;
+    support_feature(hA, posA, ornA, mk3(0, 0, 0), -sep, featA, idxA, prA, kSupportTolerance);
+    support_feature(hB, posB, ornB, mk3(0, 0, 0), sep, featB, idxB, prB, kSupportTolerance);
+
+    CPoint point;
+    point.normal = sep; point.distance = distance; point.attachment = NA_NONE;
+    point.pivotA = mk3(0, 0, 0); point.pivotB = mk3(0, 0, 0);
+
+    if (featA == BF_FACE && featB == BF_FACE) {
+        f3 fvA[4], fvB[4];
+        face_world(hA, idxA, posA, ornA, fvA);
+        f3 fnA = face_normal_world(idxA, ornA);
+        face_world(hB, idxB, posB, ornB, fvB);
+        f3 fnB = face_normal_world(idxB, ornB);
+        point.attachment = NA_ON_B;
+        for (int i = 0; i < 4; ++i)
+            if (point_in_quad_prism(fvA, fnA, fvB[i])) {
+                f3 pf = project_plane(fvB[i], fvA[0], fnA);
+                point.pivotA = to_object(pf, posA, ornA);
+                point.pivotB = to_object(fvB[i], posB, ornB);
+                res_maybe_add(result, point);
+            }
+        for (int i = 0; i < 4; ++i)
+            if (point_in_quad_prism(fvB, fnB, fvA[i])) {
+                f3 pf = project_plane(fvA[i], fvB[0], fnB);
+                point.pivotA = to_object(fvA[i], posA, ornA);
+                point.pivotB = to_object(pf, posB, ornB);
+                res_maybe_add(result, point);
+            }
+        if (result.num < 4) {
+            f3 fc = face_center(hA, idxA, posA, ornA);
+            m3 fb = face_basis(idxA, ornA);
+            f2 he = face_half_extents(hA, idxA);
+            for (int j = 0; j < 4; ++j) {
+                f3 b0w = fvB[j], b1w = fvB[(j + 1) & 3];
+                f3 b0 = to_object(b0w, fc, fb), b1 = to_object(b1w, fc, fb);
+                float s[2];
+                int n = intersect_line_aabb({b0.x, b0.z}, {b1.x, b1.z}, -he, he, s[0], s[1]);
+                for (int k = 0; k < n; ++k) {
+                    if (s[k] < 0 || s[k] > 1) continue;
+                    f3 q1 = lerp(b0w, b1w, s[k]);
+                    f3 q0 = project_plane(q1, fc, fnA);
+                    point.pivotA = to_object(q0, posA, ornA);
+                    point.pivotB = to_object(q1, posB, ornB);
+                    res_maybe_add(result, point);
+                }
+            }
+        }
+    } else if ((featA == BF_FACE && featB == BF_EDGE) || (featB == BF_FACE && featA == BF_EDGE)) {
+        const bool fA = featA == BF_FACE;
+        f3 fn = fA ? face_normal_world(idxA, ornA) : face_normal_world(idxB, ornB);
+        f3 fv[4], ev[2];
+        if (fA) { face_world(hA, idxA, posA, ornA, fv); edge_world(hB, idxB, posB, ornB, ev); }
+        else { face_world(hB, idxB, posB, ornB, fv); edge_world(hA, idxA, posA, ornA, ev); }
+        point.attachment = fA ? NA_ON_A : NA_ON_B;
+        for (int i = 0; i < 2; ++i)
+            if (point_in_quad_prism(fv, fn, ev[i])) {
+                f3 pf = project_plane(ev[i], fv[0], fn);
+                point.pivotA = fA ? to_object(pf, posA, ornA) : to_object(ev[i], posA, ornA);
+                point.pivotB = fA ? to_object(ev[i], posB, ornB) : to_object(pf, posB, ornB);
+                res_add(result, point);
+            }
+        if (result.num < 2) {
+            f3 fc = fA ? face_center(hA, idxA, posA, ornA) : face_center(hB, idxB, posB, ornB);
+            m3 fb = fA ? face_basis(idxA, ornA) : face_basis(idxB, ornB);
+            f2 he = fA ? face_half_extents(hA, idxA) : face_half_extents(hB, idxB);
+            f3 e0 = to_object(ev[0], fc, fb), e1 = to_object(ev[1], fc, fb);
+            float s[2];
+            int n = intersect_line_aabb({e0.x, e0.z}, {e1.x, e1.z}, -he, he, s[0], s[1]);
+            for (int i = 0; i < n; ++i) {
+                if (s[i] < 0 || s[i] > 1) continue;
+                f3 ep = lerp(ev[0], ev[1], s[i]);
+                f3 fp = project_plane(ep, fc, sep);
+                point.pivotA = to_object(fA ? fp : ep, posA, ornA);
+                point.pivotB = to_object(fA ? ep : fp, posB, ornB);
+                res_add(result, point);
+            }
+        }
+    } else if (featA == BF_EDGE && featB == BF_EDGE) {
+        f3 eA[2], eB[2], c1, c2, c1p = mk3(0, 0, 0), c2p = mk3(0, 0, 0);
+        int n = 0;
+        edge_world(hA, idxA, posA, ornA, eA);
+        edge_world(hB, idxB, posB, ornB, eB);
+        closest_segment_segment(eA[0], eA[1], eB[0], eB[1], c1, c2, n, c1p, c2p);
+        point.attachment = NA_NONE;
+        if (n >= 1) { point.pivotA = to_object(c1, posA, ornA); point.pivotB = to_object(c2, posB, ornB); res_add(result, point); }
+        if (n >= 2) { point.pivotA = to_object(c1p, posA, ornA); point.pivotB = to_object(c2p, posB, ornB); res_add(result, point); }
+    } else if (featA == BF_FACE && featB == BF_VERTEX) {
+        point.pivotB = box_vertex(hB, idxB);
+        point.pivotA = to_world(point.pivotB, posB, ornB) + sep * distance;
+        point.pivotA = to_object(point.pivotA, posA, ornA);
+        point.attachment = NA_ON_A;
+        res_add(result, point);
+    } else if (featB == BF_FACE && featA == BF_VERTEX) {
+        point.pivotA = box_vertex(hA, idxA);
+        point.pivotB = to_world(point.pivotA, posA, ornA) - sep * distance;
+        point.pivotB = to_object(point.pivotB, posB, ornB);
+        point.attachment = NA_ON_B;
+        res_add(result, point);
+    }
+}
+
+// collide_box_plane.cpp:7-56
+DI void collide_box_plane(f3 hA, f3 pn, float pc, const Ctx &c, CResult &result) {
+    f3 center = pn * pc;
+    int featA, idxA; float prA;
+    support_feature(hA, c.posA, c.ornA, center, -pn, featA, idxA, prA, kSupportTolerance);
+    float distance = -prA;
+    if (distance > c.threshold) return;
+    f3 verts[4]; int nv;
+    if (featA == BF_VERTEX) { verts[0] = box_vertex(hA, idxA); nv = 1; }
+    else if (featA == BF_EDGE) { verts[0] = box_vertex(hA, kEdgeIdx[idxA * 2]); verts[1] = box_vertex(hA, kEdgeIdx[idxA * 2 + 1]); nv = 2; }
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) verts[i] = box_vertex(hA, kFaceIdx[idxA * 4 + i]);
+        nv = 4;
+    }
+    CPoint point;
+    point.normal = pn; point.attachment = NA_ON_B;
+    for (int i = 0; i < nv; ++i) {
+        point.pivotA = verts[i];
+        f3 pAw = to_world(point.pivotA, c.posA, c.ornA);
+        f3 pBw = project_plane(pAw, center, pn);
+        point.pivotB = to_object(pBw, c.posB, c.ornB);
+        point.distance = dot(pAw - pBw, pn);
+        res_add(result, point);
+    }
+}
+// collide_sphere_sphere.cpp:5-27
+DI void collide_sphere_sphere(float ra, float rb, const Ctx &c, CResult &result) {
+    f3 d = c.posA - c.posB;
+    float d2 = length_sqr(d);
+    float r = ra + rb + c.threshold;
+    if (d2 > r * r) return;
+    float dist = sqrtf(d2);
+    f3 dn = dist > kEps ? d / dist : mk3(1, 0, 0);
+    f3 rA = rotate(conjugate(c.ornA), -dn * ra);
+    f3 rB = rotate(conjugate(c.ornB), dn * rb);
+    res_add(result, CPoint{rA, rB, dn, dist - ra - rb, NA_NONE});
+}
+// collide_sphere_plane.cpp:5-20
+DI void collide_sphere_plane(float radius, f3 pn, float pc, const Ctx &c, CResult &result) {
+    f3 center = pn * pc;
+    f3 d = c.posA - center;
+    float l = dot(pn, d);
+    if (l > radius) return;
+    f3 pivotA = rotate(conjugate(c.ornA), -pn * radius);
+    f3 pivotB = rotate(conjugate(c.ornB), d - pn * l - center);
+    res_add(result, CPoint{pivotA, pivotB, pn, l - radius, NA_ON_B});
+}
+// collide_sphere_box.cpp:7-55
+DI void collide_sphere_box(float radius, f3 hB, const Ctx &c, CResult &result) {
+    const q4 ornBc = conjugate(c.ornB);
+    const f3 pAB = rotate(ornBc, c.posA - c.posB);
+    const q4 oAB = ornBc * c.ornA;
+    f3 closest = closest_point_box_outside(hB, pAB);
+    f3 nB = pAB - closest;
+    float d2 = length_sqr(nB);
+    float min_dist = radius + c.threshold;
+    if (d2 > min_dist * min_dist) return;
+    float cd; int attach = NA_NONE;
+    if (d2 <= kEps) {
+        cd = -closest_point_box_inside(hB, pAB, closest, nB);
+        attach = NA_ON_B;
+    } else {
+        cd = sqrtf(d2);
+        nB = div_recip(nB, cd);
+        if (fabsf(nB.x) > 1.0f - kEps || fabsf(nB.y) > 1.0f - kEps || fabsf(nB.z) > 1.0f - kEps) attach = NA_ON_B;
+    }
+    f3 pivotA_in_B = pAB - nB * radius;
+    f3 pivotA = to_object(pivotA_in_B, pAB, oAB);
+    res_add(result, CPoint{pivotA, closest, rotate(c.ornB, nB), cd - radius, attach});
+}
+
+// Shape pair dispatch incl. swap_collide (include/edyn/collision/collide.hpp:369-374).
+// shape param float4: box = half extents xyz; sphere = radius in x; plane = normal xyz, constant w.
+DI void collide(int tA, float4 sA, int tB, float4 sB, const Ctx &c, CResult &r) {
+    r.num = 0;
+    const Ctx sw{c.posB, c.ornB, c.posA, c.ornA, c.threshold};
+    bool swapped = false;
+    if (tA == SHAPE_BOX && tB == SHAPE_BOX) collide_box_box(from4(sA), from4(sB), c, r);
+    else if (tA == SHAPE_BOX && tB == SHAPE_PLANE) collide_box_plane(from4(sA), from4(sB), sB.w, c, r);
+    else if (tA == SHAPE_PLANE && tB == SHAPE_BOX) { collide_box_plane(from4(sB), from4(sA), sA.w, sw, r); swapped = true; }
+    else if (tA == SHAPE_SPHERE && tB == SHAPE_SPHERE) collide_sphere_sphere(sA.x, sB.x, c, r);
+    else if (tA == SHAPE_SPHERE && tB == SHAPE_PLANE) collide_sphere_plane(sA.x, from4(sB), sB.w, c, r);
+    else if (tA == SHAPE_PLANE && tB == SHAPE_SPHERE) { collide_sphere_plane(sB.x, from4(sA), sA.w, sw, r); swapped = true; }
+    else if (tA == SHAPE_SPHERE && tB == SHAPE_BOX) collide_sphere_box(sA.x, from4(sB), c, r);
+    else if (tA == SHAPE_BOX && tB == SHAPE_SPHERE) { collide_sphere_box(sB.x, from4(sA), sw, r); swapped = true; }
+    if (swapped) for (int i = 0; i < r.num; ++i) cp_swap(r.pt[i]);
+}
+
+}  // namespace dc

@@ -1,0 +1,216 @@
+// Narrowphase on the GPU, one contact manifold per lane:
+//   update_contact_distances   src/edyn/util/collision_util.cpp:28-45
+//   detect_collision           src/edyn/util/collision_util.cpp:440-475 (+ collide/*.cpp via dcollide.hpp)
+//   process_collision          include/edyn/util/collision_util.hpp:104-276
+//   find_nearest_contact[_rolling], merge_point, create_contact_point, should_remove_point
+//                              src/edyn/util/collision_util.cpp:205-280,319-413
+// The reference keeps every contact point as an EnTT entity in a linked list (newest first); here a
+// manifold owns four fixed slots kept in that same list order, so creation/destruction is a register
+// shuffle instead of entity churn.
+#include "ctx.hpp"
+#include "dcollide.hpp"
+
+namespace eh {
+using namespace dc;
+
+struct Pt {
+    f3 pivotA, pivotB, normal, lnormal;
+    float distance, friction, restitution;
+    int attachment;
+    uint32_t lifetime;
+    float ni, f0, f1;
+};
+
+struct BodyIn { f3 pos; q4 orn; f3 angvel; float friction, restitution; bool rolling; };
+
+DI void set_local_normal(Pt &p, const BodyIn &A, const BodyIn &B) {
+    if (p.attachment != NA_NONE) p.lnormal = rotate(conjugate(p.attachment == NA_ON_A ? A.orn : B.orn), p.normal);
+    else p.lnormal = mk3(0, 0, 0);
+}
+DI void merge_point(Pt &p, const CPoint &rp, const BodyIn &A, const BodyIn &B) {
+    p.pivotA = rp.pivotA; p.pivotB = rp.pivotB; p.normal = rp.normal;
+    p.distance = rp.distance; p.attachment = rp.attachment;
+    set_local_normal(p, A, B);
+}
+DI Pt make_point(const CPoint &rp, const BodyIn &A, const BodyIn &B) {
+    Pt p;
+    p.pivotA = rp.pivotA; p.pivotB = rp.pivotB; p.normal = rp.normal;
+    p.attachment = rp.attachment; p.distance = rp.distance;
+    set_local_normal(p, A, B);
+    p.friction = sqrtf(A.friction * B.friction);          // material_mixing.hpp:16-18
+    p.restitution = fminf(A.restitution, B.restitution);  // :12-14
+    p.lifetime = 0; p.ni = 0; p.f0 = 0; p.f1 = 0;
+    return p;
+}
+DI int find_nearest(const Pt &cp, const CResult &res) {
+    float best = square(kCachingThreshold);
+    int idx = res.num;
+    for (int i = 0; i < res.num; ++i) {
+        float dA = length_sqr(res.pt[i].pivotA - cp.pivotA);
+        float dB = length_sqr(res.pt[i].pivotB - cp.pivotB);
+        if (dA < best) { best = dA; idx = i; }
+        if (dB < best) { best = dB; idx = i; }
+    }
+    return idx;
+}
+DI int find_nearest_rolling(const CResult &res, f3 cp_pivot, f3 origin, q4 orn, f3 angvel, float dt) {
+    int idx = res.num;
+    q4 prev_orn = integrate(orn, angvel, -dt);
+    f3 prev_pivot = to_world(cp_pivot, origin, prev_orn);
+    float best = square(kCachingThreshold);
+    for (int i = 0; i < res.num; ++i) {
+        f3 pA = to_world(res.pt[i].pivotA, origin, orn);   // pivotA for both bodies, as the reference does
+        float d2 = distance_sqr(pA, prev_pivot);
+        if (d2 < best) { best = d2; idx = i; }
+    }
+    return idx;
+}
+DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
+    const float thr = kBreakingThreshold, thr2 = thr * thr;
+    f3 d = to_world(cp.pivotA, A.pos, A.orn) - to_world(cp.pivotB, B.pos, B.orn);
+    float nd = dot(d, cp.normal);
+    f3 td = d - nd * cp.normal;
+    return nd > thr || length_sqr(td) > thr2;
+}
+
+__global__ void __launch_bounds__(64)
+k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, Counters *cnt) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t my_points = 0, my_active = 0;
+    if (m < M) {
+        const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+        const uint32_t info = mf.info[m];
+        const int n_old = (int)(info & 0xFF);
+        const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+        const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+        BodyIn A, B;
+        { float4 p = b.pos[ia]; A.pos = from4(p); A.orn = q_from4(b.orn[ia]); A.angvel = from4(b.angvel[ia]);
+          float2 mt = b.mat[ia]; A.friction = mt.x; A.restitution = mt.y;
+          A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tA == SHAPE_SPHERE; }
+        { float4 p = b.pos[ib]; B.pos = from4(p); B.orn = q_from4(b.orn[ib]); B.angvel = from4(b.angvel[ib]);
+          float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
+          B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tB == SHAPE_SPHERE; }
+
+        Pt pts[kMaxPts];
+        for (int k = 0; k < n_old; ++k) {
+            const size_t s = (size_t)k * mf.cap + m;
+            float4 a = mf.pA[s], bb = mf.pB[s], n = mf.nrm[s], l = mf.lnrm[s], im = mf.imp[s];
+            Pt &p = pts[k];
+            p.pivotA = from4(a); p.pivotB = from4(bb); p.normal = from4(n); p.lnormal = from4(l);
+            p.friction = bb.w; p.attachment = __float_as_int(n.w); p.restitution = l.w;
+            p.ni = im.x; p.f0 = im.y; p.f1 = im.z; p.lifetime = __float_as_uint(im.w);
+            // update_contact_distances
+            p.distance = dot(p.normal, to_world(p.pivotA, A.pos, A.orn) - to_world(p.pivotB, B.pos, B.orn));
+        }
+
+        CResult res;
+        res.num = 0;
+        {
+            box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
+            if (intersect(inset(ba, -kBreakingThreshold), bbx)) {
+                Ctx ctx{A.pos, A.orn, B.pos, B.orn, kCollisionThreshold};
+                collide(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
+            }
+        }
+
+        // ---- process_collision ----
+        const int R = res.num;
+        bool merged[kMaxPts] = {false, false, false, false};
+        bool dead[kMaxPts] = {false, false, false, false};
+        int num_points = n_old;
+        for (int i = 0; i < n_old; ++i) {
+            Pt &cp = pts[i];
+            ++cp.lifetime;
+            int nearest = find_nearest(cp, res);
+            if (nearest == R && A.rolling) nearest = find_nearest_rolling(res, cp.pivotA, A.pos, A.orn, A.angvel, dt);
+            if (nearest == R && B.rolling) nearest = find_nearest_rolling(res, cp.pivotB, B.pos, B.orn, B.angvel, dt);
+            if (nearest < R && !merged[nearest]) { merge_point(cp, res.pt[nearest], A, B); merged[nearest] = true; }
+            else if (should_remove(cp, A, B)) { dead[i] = true; --num_points; }
+        }
+        bool all_merged = true;
+        for (int r = 0; r < R; ++r) all_merged = all_merged && merged[r];
+
+        Pt created[kMaxPts];
+        int n_created = 0;
+        if (!all_merged) {
+            CPoint lp[kMaxPts];
+            int lold[kMaxPts] = {-1, -1, -1, -1};
+            int ltype[kMaxPts] = {INS_NONE, INS_NONE, INS_NONE, INS_NONE};
+            if (num_points > 0) {
+                int k = 0;
+                for (int i = 0; i < n_old; ++i) {
+                    if (dead[i]) continue;
+                    lp[k] = CPoint{pts[i].pivotA, pts[i].pivotB, pts[i].normal, pts[i].distance, NA_NONE};
+                    lold[k] = i;
+                    ++k;
+                }
+            } else {
+                num_points = 1;
+                lp[0] = res.pt[0];
+                ltype[0] = INS_APPEND;
+                merged[0] = true;
+            }
+            for (int r = 0; r < R; ++r) {
+                if (merged[r]) continue;
+                const CPoint rp = res.pt[r];
+                f3 piv[kMaxPts];
+                for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotA;
+                int ir = insertion_point_index(piv, num_points, rp.pivotA);
+                if ((ir & 0xFF) == INS_NONE) {
+                    for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotB;
+                    ir = insertion_point_index(piv, num_points, rp.pivotB);
+                }
+                if ((ir & 0xFF) != INS_NONE) { lp[ir >> 8] = rp; ltype[ir >> 8] = ir & 0xFF; }
+            }
+            for (int i = 0; i < num_points; ++i) {
+                switch (ltype[i]) {
+                case INS_APPEND: created[n_created++] = make_point(lp[i], A, B); break;
+                case INS_SIMILAR:
+                    if (lold[i] < 0) created[n_created++] = make_point(lp[i], A, B);
+                    else merge_point(pts[lold[i]], lp[i], A, B);
+                    break;
+                case INS_REPLACE:
+                    if (lold[i] >= 0) dead[lold[i]] = true;
+                    created[n_created++] = make_point(lp[i], A, B);
+                    break;
+                default: break;
+                }
+            }
+        }
+        // new points go to the head of the list in creation order; survivors keep their order
+        int n_out = 0;
+        auto store = [&](const Pt &p) {
+            const size_t d = (size_t)n_out * mf.cap + m;
+            mf.pA[d] = to4(p.pivotA, p.distance);
+            mf.pB[d] = to4(p.pivotB, p.friction);
+            mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
+            mf.lnrm[d] = to4(p.lnormal, p.restitution);
+            mf.imp[d] = make_float4(p.ni, p.f0, p.f1, __uint_as_float(p.lifetime));
+            ++n_out;
+        };
+        for (int i = n_created - 1; i >= 0; --i) store(created[i]);
+        for (int i = 0; i < n_old; ++i) if (!dead[i]) store(pts[i]);
+        uint32_t colour = info >> 8;
+        if (n_out == 0) colour = kNoColour;   // inactive pairs hold no solver colour
+        mf.info[m] = (uint32_t)n_out | (colour << 8);
+        my_points = (uint32_t)n_out;
+        my_active = n_out > 0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        my_points += __shfl_xor(my_points, off);
+        my_active += __shfl_xor(my_active, off);
+    }
+    if ((threadIdx.x & 63) == 0 && my_points) { atomicAdd(&cnt->num_points, my_points); atomicAdd(&cnt->num_active, my_active); }
+}
+
+int narrowphase(edynhip_ctx *c) {
+    const uint32_t M = c->num_manifolds;
+    EH_HIP(c, hipMemsetAsync(&c->cnt->num_points, 0, 2 * sizeof(uint32_t), c->stream));   // num_points, num_active
+    if (M == 0) return EDYNHIP_OK;
+    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->cnt);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
+}
+
+}  // namespace eh

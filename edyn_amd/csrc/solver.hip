@@ -1,0 +1,705 @@
+// Islands, graph colouring, constraint-row preparation, the sequential-impulse (PGS) velocity solver,
+// integration, the position solver and the post-step derived state, as gfx950 kernels.
+//
+// Reference functions reproduced (arithmetic order kept):
+//   island labelling            src/edyn/simulation/island_manager.cpp:117-350 (connected components; static nodes do not connect)
+//   apply_gravity               include/edyn/sys/apply_gravity.hpp:12-17
+//   contact rows                src/edyn/constraints/contact_constraint.cpp:15-56
+//   point / hinge rows          src/edyn/constraints/point_constraint.cpp:9-46, hinge_constraint.cpp:26-67
+//   prepare_row                 src/edyn/constraints/constraint_row.cpp:6-22
+//   warm start / solve / apply  src/edyn/constraints/constraint_row.cpp:24-57, island_solver.cpp:76-111
+//   friction circle             src/edyn/constraints/constraint_row_friction.cpp:11-66
+//   integrate_velocities        src/edyn/dynamics/island_solver.cpp:357-376, src/edyn/math/quaternion.cpp:7-22
+//   position solver             include/edyn/dynamics/position_solver.hpp:16-51, contact_constraint.cpp:58-90,
+//                               hinge_constraint.cpp:180-213, island_solver.cpp:350-353,538-542
+//   update_aabbs / inertias     src/edyn/util/aabb_util.cpp:42-70, src/edyn/sys/update_inertias.cpp:12-24
+//
+// What is NOT in the reference: within an island the reference sweeps rows strictly sequentially
+// (Gauss-Seidel). Here the contact graph is edge-coloured so that the manifolds of one colour share no
+// procedural body; each colour is one launch with one manifold per lane (its <=4 points in sequence).
+// Per iteration: joints by colour, then the normal rows of every colour, then the friction rows of every
+// colour - the reference's "all rows, then all friction rows" structure.
+#include "ctx.hpp"
+#include "dcollide.hpp"
+
+namespace eh {
+using namespace dm;
+
+static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
+
+DI bool is_dynamic(uint32_t flags) { return (flags & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC; }
+DI uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+DI uint64_t edge_prio(uint32_t e) { return ((uint64_t)mix32(e + 1) << 32) | (e + 1); }
+
+// ------------------------------------------------------------------ islands (lock-free union-find)
+DI uint32_t cc_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DI uint32_t cc_find(uint32_t *parent, uint32_t x) {
+    uint32_t p = cc_load(&parent[x]);
+    while (p != x) { x = p; p = cc_load(&parent[x]); }
+    return x;
+}
+DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        uint32_t ra = cc_find(parent, a), rb = cc_find(parent, b);
+        if (ra == rb) return;
+        if (ra < rb) { uint32_t t = ra; ra = rb; rb = t; }   // hook the larger root under the smaller
+        if (atomicCAS(&parent[ra], ra, rb) == ra) return;
+    }
+}
+__global__ void k_cc_init(uint32_t n, uint32_t *island) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) island[i] = i;
+}
+__global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                          const uint32_t *__restrict__ flags, uint32_t *island) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M) return;
+    uint32_t a = bA[e], b = bB[e];
+    if (is_dynamic(flags[a]) && is_dynamic(flags[b])) cc_union(island, a, b);
+}
+__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t root = 0;
+    if (i < n) {
+        uint32_t r = cc_find(island, i);
+        label[i] = r;
+        root = (r == i && is_dynamic(flags[i])) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) root += __shfl_xor(root, off);
+    if ((threadIdx.x & 63) == 0 && root) atomicAdd(&cnt->num_islands, root);
+}
+
+// ------------------------------------------------------------------ colouring
+__global__ void k_col_prepare(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
+                              const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
+                              uint64_t *best0, uint64_t *best1, Counters *cnt) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t unc = 0;
+    if (m < M) {
+        uint32_t in = info[m];
+        uint32_t np = in & 0xFF, col = in >> 8;
+        if (np > 0) {
+            uint32_t a = bA[m], b = bB[m];
+            bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
+            if (col != kNoColour) {
+                if (da) atomicOr((unsigned long long *)&used[a], 1ull << col);
+                if (db) atomicOr((unsigned long long *)&used[b], 1ull << col);
+            } else {
+                unc = 1;
+                if (da) { best0[a] = 0; best1[a] = 0; }
+                if (db) { best0[b] = 0; best1[b] = 0; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) unc += __shfl_xor(unc, off);
+    if ((threadIdx.x & 63) == 0 && unc) atomicAdd(&cnt->uncoloured, unc);
+}
+__global__ void k_col_best(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
+                           const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *best_cur,
+                           uint64_t *best_next, const Counters *cnt) {
+    if (cnt->uncoloured == 0) return;
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    uint32_t in = info[m];
+    if ((in & 0xFF) == 0 || (in >> 8) != kNoColour) return;
+    uint32_t a = bA[m], b = bB[m];
+    uint64_t pr = edge_prio(m);
+    if (is_dynamic(flags[a])) { atomicMax((unsigned long long *)&best_cur[a], pr); best_next[a] = 0; }
+    if (is_dynamic(flags[b])) { atomicMax((unsigned long long *)&best_cur[b], pr); best_next[b] = 0; }
+}
+__global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                             const uint32_t *__restrict__ flags, const uint64_t *__restrict__ best_cur, uint64_t *used,
+                             Counters *cnt) {
+    if (cnt->uncoloured == 0) return;
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t done = 0;
+    if (m < M) {
+        uint32_t in = info[m];
+        if ((in & 0xFF) != 0 && (in >> 8) == kNoColour) {
+            uint32_t a = bA[m], b = bB[m];
+            bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
+            uint64_t pr = edge_prio(m);
+            if (!(da && best_cur[a] != pr) && !(db && best_cur[b] != pr)) {
+                uint64_t busy = (da ? used[a] : 0ull) | (db ? used[b] : 0ull);
+                uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
+                if (c >= kMaxColours) { cnt->colour_overflow = 1; c = kMaxColours - 1; }
+                info[m] = (in & 0xFF) | (c << 8);
+                if (da) used[a] |= 1ull << c;
+                if (db) used[b] |= 1ull << c;
+                done = 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicSub(&cnt->uncoloured, done);
+}
+__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, uint32_t *vals) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    uint32_t in = info[m];
+    keys[m] = (in & 0xFF) ? (in >> 8) : 0xFFu;
+    vals[m] = m;
+}
+__global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sorted, Counters *cnt) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    uint32_t c = keys_sorted[p];
+    if (c >= kMaxColours) return;
+    if (p == 0 || keys_sorted[p - 1] != c) cnt->colour_start[c] = p;
+    if (p == M - 1 || keys_sorted[p + 1] != c) cnt->colour_end[c] = p + 1;
+}
+
+// ------------------------------------------------------------------ row math shared by prep / solve
+struct BRef { f3 pos; q4 orn; f3 v, w; float inv_m; m3 inv_I; };
+DI BRef load_bref(const Bodies &b, uint32_t i) {
+    BRef r;
+    float4 p = b.pos[i];
+    uint32_t fl = b.flags[i];
+    r.pos = from4(p); r.orn = q_from4(b.orn[i]);
+    if (is_dynamic(fl)) {
+        r.inv_m = p.w;
+        r.inv_I = {from4(b.iw[3 * i]), from4(b.iw[3 * i + 1]), from4(b.iw[3 * i + 2])};
+    } else { r.inv_m = 0; r.inv_I = m3_zero(); }
+    if ((fl & BF_KIND_MASK) == EDYNHIP_KIND_STATIC) { r.v = mk3(0, 0, 0); r.w = mk3(0, 0, 0); }
+    else { r.v = from4(b.linvel[i]); r.w = from4(b.angvel[i]); }
+    return r;
+}
+DI float eff_mass(f3 J0, f3 J1, f3 J2, f3 J3, float imA, const m3 &iA, float imB, const m3 &iB) {
+    float s = dot(J0, J0) * imA + dot(mul(iA, J1), J1) + dot(J2, J2) * imB + dot(mul(iB, J3), J3);
+    return 1.0f / s;
+}
+DI float rel_speed(f3 J0, f3 J1, f3 J2, f3 J3, f3 vA, f3 wA, f3 vB, f3 wB) {
+    return dot(J0, vA) + dot(J1, wA) + dot(J2, vB) + dot(J3, wB);
+}
+
+__global__ void k_solve_begin(uint32_t n, Bodies b, float dt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t fl = b.flags[i];
+    float inv_m = 0;
+    if (is_dynamic(fl)) {
+        inv_m = b.pos[i].w;
+        f3 g = from4(b.grav[i]);
+        if (!(g.x == 0 && g.y == 0 && g.z == 0)) {
+            f3 v = from4(b.linvel[i]);
+            v += g * dt;
+            b.linvel[i] = to4(v, 0);
+        }
+    }
+    b.dv[i] = make_float4(0, 0, 0, inv_m);
+    b.dw[i] = make_float4(0, 0, 0, 0);
+}
+
+__global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_active) return;
+    const uint32_t m = rows.order[p];
+    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+    const uint32_t np = mf.info[m] & 0xFF;
+    rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
+    const BRef A = load_bref(b, ia), B = load_bref(b, ib);
+    for (uint32_t k = 0; k < np; ++k) {
+        const size_t s = (size_t)k * mf.cap + m, d = (size_t)k * rcap + p;
+        const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
+        const f3 n = from4(n4);
+        const float distance = a4.w, mu = b4.w;
+        const f3 pAw = to_world(from4(a4), A.pos, A.orn), pBw = to_world(from4(b4), B.pos, B.orn);
+        const f3 rA = pAw - A.pos, rB = pBw - B.pos;
+        // normal row
+        const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
+        const float effn = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
+        const float error = distance > 0 ? distance / dt : 0.0f;
+        const float rhsn = -(error * 0.2f + relvel * (1 + 0.0f));   // erp 0.2, zero restitution (restitution solver path)
+        // friction rows
+        f3 t0, t1;
+        plane_space(n, t0, t1);
+        const f3 K1 = cross(rA, t0), K3 = -cross(rB, t0);
+        const f3 L1 = cross(rA, t1), L3 = -cross(rB, t1);
+        const float eff0 = eff_mass(t0, K1, -t0, K3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        const float eff1 = eff_mass(t1, L1, -t1, L3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        const float rhs0 = -rel_speed(t0, K1, -t0, K3, A.v, A.w, B.v, B.w);
+        const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
+        rows.r0[d] = to4(n, effn);
+        rows.r1[d] = to4(rA, rhsn);
+        rows.r2[d] = to4(rB, im.x);
+        rows.r3[d] = make_float4(eff0, eff1, rhs0, rhs1);
+        rows.r4[d] = make_float4(im.y, im.z, mu, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------ velocity solve: contacts
+struct Delta { f3 dvA, dwA, dvB, dwB; float imA, imB; m3 iA, iB; };
+DI void load_delta(const Bodies &b, uint32_t ia, uint32_t ib, Delta &d) {
+    float4 va = b.dv[ia], vb = b.dv[ib];
+    d.dvA = from4(va); d.imA = va.w; d.dwA = from4(b.dw[ia]);
+    d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(b.dw[ib]);
+    d.iA = {from4(b.iw[3 * ia]), from4(b.iw[3 * ia + 1]), from4(b.iw[3 * ia + 2])};
+    d.iB = {from4(b.iw[3 * ib]), from4(b.iw[3 * ib + 1]), from4(b.iw[3 * ib + 2])};
+}
+DI void store_delta(const Bodies &b, uint32_t ia, uint32_t ib, const Delta &d) {
+    if (d.imA != 0) { b.dv[ia] = to4(d.dvA, d.imA); b.dw[ia] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { b.dv[ib] = to4(d.dvB, d.imB); b.dw[ib] = to4(d.dwB, 0); }
+}
+DI void apply_impulse(Delta &d, f3 J0, f3 J1, f3 J2, f3 J3, float imp) {   // apply_row_impulse
+    d.dvA += d.imA * J0 * imp;
+    d.dvB += d.imB * J2 * imp;
+    d.dwA += mul(d.iA, J1) * imp;
+    d.dwB += mul(d.iB, J3) * imp;
+}
+
+template <bool WARM>
+__global__ void __launch_bounds__(256)
+k_contact_normal(uint32_t start, uint32_t end, Rows rows, uint32_t rcap, Bodies b) {
+    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
+    Delta d;
+    load_delta(b, ia, ib, d);
+    for (uint32_t k = 0; k < np; ++k) {
+        const size_t s = (size_t)k * rcap + p;
+        const float4 q0 = rows.r0[s], q1 = rows.r1[s];
+        float4 q2 = rows.r2[s];
+        const f3 n = from4(q0), rA = from4(q1), rB = from4(q2);
+        const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
+        if (WARM) {
+            apply_impulse(d, J0, J1, J2, J3, q2.w);
+        } else {
+            float drel = rel_speed(J0, J1, J2, J3, d.dvA, d.dwA, d.dvB, d.dwB);
+            float dimp = (q1.w - drel) * q0.w;
+            float imp = q2.w + dimp;
+            if (imp < 0.0f) { dimp = 0.0f - q2.w; q2.w = 0.0f; }
+            else if (imp > kLarge) { dimp = kLarge - q2.w; q2.w = kLarge; }
+            else q2.w = imp;
+            apply_impulse(d, J0, J1, J2, J3, dimp);
+            rows.r2[s] = q2;
+        }
+    }
+    store_delta(b, ia, ib, d);
+}
+
+template <bool WARM>
+__global__ void __launch_bounds__(256)
+k_contact_friction(uint32_t start, uint32_t end, Rows rows, uint32_t rcap, Bodies b) {
+    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
+    Delta d;
+    load_delta(b, ia, ib, d);
+    for (uint32_t k = 0; k < np; ++k) {
+        const size_t s = (size_t)k * rcap + p;
+        const float4 q0 = rows.r0[s], q1 = rows.r1[s], q2 = rows.r2[s], q3 = rows.r3[s];
+        float4 q4v = rows.r4[s];
+        const f3 n = from4(q0), rA = from4(q1), rB = from4(q2);
+        f3 t0, t1;
+        plane_space(n, t0, t1);
+        const f3 K1 = cross(rA, t0), K3 = -cross(rB, t0), L1 = cross(rA, t1), L3 = -cross(rB, t1);
+        if (WARM) {   // warm_start(constraint_row_friction&): dvA, dwA, dvB, dwB per tangent
+            d.dvA += d.imA * t0 * q4v.x; d.dwA += mul(d.iA, K1) * q4v.x; d.dvB += d.imB * (-t0) * q4v.x; d.dwB += mul(d.iB, K3) * q4v.x;
+            d.dvA += d.imA * t1 * q4v.y; d.dwA += mul(d.iA, L1) * q4v.y; d.dvB += d.imB * (-t1) * q4v.y; d.dwB += mul(d.iB, L3) * q4v.y;
+        } else {
+            float dr0 = rel_speed(t0, K1, -t0, K3, d.dvA, d.dwA, d.dvB, d.dwB);
+            float di0 = (q3.z - dr0) * q3.x;
+            float i0 = q4v.x + di0;
+            float dr1 = rel_speed(t1, L1, -t1, L3, d.dvA, d.dwA, d.dvB, d.dwB);
+            float di1 = (q3.w - dr1) * q3.y;
+            float i1 = q4v.y + di1;
+            float len2 = i0 * i0 + i1 * i1;
+            float max_len = q4v.z * q2.w;   // mu * current normal impulse
+            if (len2 > square(max_len)) {
+                float len = sqrtf(len2);
+                if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+                else { i0 = 0; i1 = 0; }
+                di0 = i0 - q4v.x; di1 = i1 - q4v.y;
+            }
+            q4v.x = i0; q4v.y = i1;
+            d.dvA += d.imA * t0 * di0; d.dwA += mul(d.iA, K1) * di0; d.dvB += d.imB * (-t0) * di0; d.dwB += mul(d.iB, K3) * di0;
+            d.dvA += d.imA * t1 * di1; d.dwA += mul(d.iA, L1) * di1; d.dvB += d.imB * (-t1) * di1; d.dwB += mul(d.iB, L3) * di1;
+            rows.r4[s] = q4v;
+        }
+    }
+    store_delta(b, ia, ib, d);
+}
+
+__global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_active) return;
+    const uint32_t m = rows.order[p], np = rows.np[p];
+    for (uint32_t k = 0; k < np; ++k) {
+        const size_t s = (size_t)k * rcap + p, d = (size_t)k * mf.cap + m;
+        float4 im = mf.imp[d];
+        float4 f = rows.r4[s];
+        im.x = rows.r2[s].w; im.y = f.x; im.z = f.y;
+        mf.imp[d] = im;
+    }
+}
+
+// ------------------------------------------------------------------ joints (point, hinge)
+DI void joint_rowJ(int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
+    if (r < 3) {
+        // J = {I.row[i], -skew(rA).row[i], -I.row[i], skew(rB).row[i]}
+        f3 e = r == 0 ? mk3(1, 0, 0) : (r == 1 ? mk3(0, 1, 0) : mk3(0, 0, 1));
+        f3 sa = r == 0 ? mk3(0, -rA.z, rA.y) : (r == 1 ? mk3(rA.z, 0, -rA.x) : mk3(-rA.y, rA.x, 0));
+        f3 sb = r == 0 ? mk3(0, -rB.z, rB.y) : (r == 1 ? mk3(rB.z, 0, -rB.x) : mk3(-rB.y, rB.x, 0));
+        J0 = e; J1 = -sa; J2 = -e; J3 = sb;
+    } else {
+        f3 ax = r == 3 ? wp : wq;
+        J0 = mk3(0, 0, 0); J1 = ax; J2 = mk3(0, 0, 0); J3 = -ax;
+    }
+}
+__global__ void k_prep_joints(Joints j, Bodies b, float dt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n) return;
+    const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    const BRef A = load_bref(b, ia), B = load_bref(b, ib);
+    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    const f3 rA = pA - A.pos, rB = pB - B.pos;
+    const bool hinge = j.type[i] == EDYNHIP_JOINT_HINGE;
+    f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0);
+    if (hinge) { wp = rotate(A.orn, from4(j.pA[i])); wq = rotate(A.orn, from4(j.qA[i])); }
+    j.rA[i] = to4(rA, 0); j.rB[i] = to4(rB, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0);
+    const int nr = hinge ? 5 : 3;
+    for (int r = 0; r < nr; ++r) {
+        f3 J0, J1, J2, J3;
+        joint_rowJ(r, rA, rB, wp, wq, J0, J1, J2, J3);
+        float error = 0;
+        if (!hinge) error = (comp(pA, r) - comp(pB, r)) / dt;
+        float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
+        j.eff[(size_t)r * j.cap + i] = em;
+        j.rhs[(size_t)r * j.cap + i] = -(error * 0.2f + relvel * (1 + 0.0f));
+    }
+}
+template <bool WARM>
+__global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) {
+    uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    Delta d;
+    load_delta(b, ia, ib, d);
+    const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]);
+    const int nr = j.type[i] == EDYNHIP_JOINT_HINGE ? 5 : 3;
+    for (int r = 0; r < nr; ++r) {
+        f3 J0, J1, J2, J3;
+        joint_rowJ(r, rA, rB, wp, wq, J0, J1, J2, J3);
+        const size_t s = (size_t)r * j.cap + i;
+        float imp = j.impulse[s];
+        if (WARM) {
+            apply_impulse(d, J0, J1, J2, J3, imp);
+        } else {
+            float drel = rel_speed(J0, J1, J2, J3, d.dvA, d.dwA, d.dvB, d.dwB);
+            float dimp = (j.rhs[s] - drel) * j.eff[s];
+            float ni = imp + dimp;
+            if (ni < -kScalarMax) { dimp = -kScalarMax - imp; ni = -kScalarMax; }
+            else if (ni > kScalarMax) { dimp = kScalarMax - imp; ni = kScalarMax; }
+            j.impulse[s] = ni;
+            apply_impulse(d, J0, J1, J2, J3, dimp);
+        }
+    }
+    store_delta(b, ia, ib, d);
+}
+
+// ------------------------------------------------------------------ integration
+__global__ void k_integrate(uint32_t n, Bodies b, float dt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!is_dynamic(b.flags[i])) return;
+    float4 p4 = b.pos[i];
+    f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
+    v += from4(b.dv[i]);
+    w += from4(b.dw[i]);
+    f3 pos = from4(p4);
+    pos += v * dt;
+    q4 orn = integrate(q_from4(b.orn[i]), w, dt);
+    b.linvel[i] = to4(v, 0); b.angvel[i] = to4(w, 0);
+    b.pos[i] = to4(pos, p4.w); b.orn[i] = to4(orn);
+}
+
+// ------------------------------------------------------------------ position solver
+struct PBody { f3 pos; q4 orn; float inv_m; m3 iw, il; bool proc; };
+DI PBody load_pbody(const Bodies &b, uint32_t i) {
+    PBody r;
+    float4 p = b.pos[i];
+    r.pos = from4(p); r.orn = q_from4(b.orn[i]);
+    r.proc = is_dynamic(b.flags[i]);
+    if (r.proc) {
+        r.inv_m = p.w;
+        r.iw = {from4(b.iw[3 * i]), from4(b.iw[3 * i + 1]), from4(b.iw[3 * i + 2])};
+        r.il = {from4(b.il[3 * i]), from4(b.il[3 * i + 1]), from4(b.il[3 * i + 2])};
+    } else { r.inv_m = 0; r.iw = m3_zero(); r.il = m3_zero(); }
+    return r;
+}
+DI void store_pbody(const Bodies &b, uint32_t i, const PBody &r) {
+    if (!r.proc) return;
+    b.pos[i] = to4(r.pos, r.inv_m); b.orn[i] = to4(r.orn);
+    b.iw[3 * i] = to4(r.iw.r0, 0); b.iw[3 * i + 1] = to4(r.iw.r1, 0); b.iw[3 * i + 2] = to4(r.iw.r2, 0);
+}
+DI void pos_apply(PBody &x, f3 Jl, f3 Ja, float corr) {
+    if (!x.proc) return;
+    x.pos += x.inv_m * Jl * corr;
+    f3 ang = mul(x.iw, Ja) * corr;
+    x.orn = x.orn + quaternion_derivative(x.orn, ang);
+    x.orn = normalize(x.orn);
+    m3 basis = to_m3(x.orn);
+    x.iw = mul(mul(basis, x.il), transpose(basis));
+}
+DI void pos_solve(PBody &A, PBody &B, f3 J0, f3 J1, f3 J2, f3 J3, float error, float &max_err) {
+    float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.iw, B.inv_m, B.iw);
+    float corr = error * 0.2f * em;   // contact_position_correction_rate / error_correction_rate
+    pos_apply(A, J0, J1, corr);
+    pos_apply(B, J2, J3, corr);
+    max_err = fmaxf(fabsf(error), max_err);
+}
+DI void publish_error(float max_err, uint32_t label, float *isl_err) {
+    if (max_err > 0) atomicMax((unsigned int *)&isl_err[label], __float_as_uint(max_err));
+}
+
+__global__ void __launch_bounds__(256)
+k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
+    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const uint32_t m = rows.order[p];
+    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
+    PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
+    const uint32_t label = b.island[A.proc ? ia : ib];
+    if (isl_done[label]) return;
+    float max_err = 0;
+    for (uint32_t k = 0; k < np; ++k) {
+        const size_t s = (size_t)k * mf.cap + m;
+        float4 a4 = mf.pA[s];
+        const float4 b4 = mf.pB[s], l4 = mf.lnrm[s];
+        float4 n4 = mf.nrm[s];
+        const int attach = __float_as_int(n4.w);
+        const f3 pAw = to_world(from4(a4), A.pos, A.orn), pBw = to_world(from4(b4), B.pos, B.orn);
+        f3 n = from4(n4);
+        if (attach == dc::NA_ON_A) n = rotate(A.orn, from4(l4));
+        else if (attach == dc::NA_ON_B) n = rotate(B.orn, from4(l4));
+        const float distance = dot(pAw - pBw, n);
+        const f3 rA = pAw - A.pos, rB = pBw - B.pos;
+        a4.w = distance;
+        mf.pA[s] = a4;
+        mf.nrm[s] = to4(n, n4.w);
+        if (distance > -kEps) continue;
+        pos_solve(A, B, n, cross(rA, n), -n, -cross(rB, n), -distance, max_err);
+    }
+    store_pbody(b, ia, A);
+    store_pbody(b, ib, B);
+    publish_error(max_err, label, isl_err);
+}
+__global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
+    uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    if (j.type[i] != EDYNHIP_JOINT_HINGE) return;   // point_constraint has no solve_position (island_solver.cpp:252-260)
+    const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
+    const uint32_t label = b.island[A.proc ? ia : ib];
+    if (isl_done[label]) return;
+    float max_err = 0;
+    const f3 axisA = rotate(A.orn, from4(j.axA[i])), axisB = rotate(B.orn, from4(j.axB[i]));
+    f3 pp, qq;
+    plane_space(axisA, pp, qq);
+    const f3 u = cross(axisA, axisB);
+    float e = dot(u, pp);
+    if (fabsf(e) > kEps) pos_solve(A, B, mk3(0, 0, 0), pp, mk3(0, 0, 0), -pp, e, max_err);
+    e = dot(u, qq);
+    if (fabsf(e) > kEps) pos_solve(A, B, mk3(0, 0, 0), qq, mk3(0, 0, 0), -qq, e, max_err);
+    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    f3 dir = pA - pB;
+    const float err = length(dir);
+    if (err > kEps) {
+        dir = div_recip(dir, err);
+        const f3 rA = pA - A.pos, rB = pB - B.pos;
+        pos_solve(A, B, dir, cross(rA, dir), -dir, -cross(rB, dir), -err, max_err);
+    }
+    store_pbody(b, ia, A);
+    store_pbody(b, ib, B);
+    publish_error(max_err, label, isl_err);
+}
+__global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (isl_err[i] < 0.005f) isl_done[i] = 1;
+    isl_err[i] = 0;
+}
+
+// ------------------------------------------------------------------ derived state
+__global__ void k_finish(uint32_t n, Bodies b) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t fl = b.flags[i];
+    const uint32_t kind = fl & BF_KIND_MASK;
+    if (kind == EDYNHIP_KIND_STATIC) return;
+    const int st = (int)((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+    const f3 pos = from4(b.pos[i]);
+    const q4 orn = q_from4(b.orn[i]);
+    const m3 basis = to_m3(orn);
+    if (st == dc::SHAPE_BOX) {   // aabb_util.cpp:42-63
+        const f3 h = from4(b.shape[i]);
+        float mn[3] = {pos.x, pos.y, pos.z}, mx[3] = {pos.x, pos.y, pos.z};
+        const f3 rws[3] = {basis.r0, basis.r1, basis.r2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx) {
+                float e = comp(rws[r], cidx) * -comp(h, cidx);
+                float f = -e;
+                if (e < f) { mn[r] += e; mx[r] += f; } else { mn[r] += f; mx[r] += e; }
+            }
+        b.amin[i] = make_float4(mn[0], mn[1], mn[2], 0);
+        b.amax[i] = make_float4(mx[0], mx[1], mx[2], 0);
+    } else if (st == dc::SHAPE_SPHERE) {   // aabb_util.cpp:65-70
+        const float r = b.shape[i].x;
+        b.amin[i] = make_float4(pos.x - r, pos.y - r, pos.z - r, 0);
+        b.amax[i] = make_float4(pos.x + r, pos.y + r, pos.z + r, 0);
+    }
+    if (kind == EDYNHIP_KIND_DYNAMIC) {   // update_inertias.cpp:12-24
+        const m3 il = {from4(b.il[3 * i]), from4(b.il[3 * i + 1]), from4(b.il[3 * i + 2])};
+        const m3 iw = mul(mul(basis, il), transpose(basis));
+        b.iw[3 * i] = to4(iw.r0, 0); b.iw[3 * i + 1] = to4(iw.r1, 0); b.iw[3 * i + 2] = to4(iw.r2, 0);
+    }
+}
+
+// ------------------------------------------------------------------ host orchestration
+static void rec(edynhip_ctx *c, int idx) {
+    if (c->cfg.flags & EDYNHIP_FLAG_TIMING) (void)hipEventRecord(c->timer.e[idx], c->stream);
+}
+
+int islands(edynhip_ctx *c) {
+    hipStream_t s = c->stream;
+    const uint32_t n = c->b.n, M = c->num_manifolds;
+    if (n == 0) return EDYNHIP_OK;
+    const Manifolds &mf = c->m[c->cur];
+    // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
+    uint32_t *forest = c->isl_done;
+    EH_HIP(c, hipMemsetAsync(&c->cnt->num_islands, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest);
+    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest);
+    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
+}
+
+static int colour_contacts(edynhip_ctx *c) {
+    hipStream_t s = c->stream;
+    const uint32_t M = c->num_manifolds, n = c->b.n;
+    Manifolds &mf = c->m[c->cur];
+    c->num_colours = 0; c->num_active = 0;
+    if (M == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
+    EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
+    EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 2 * kMaxColours * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt);
+    uint32_t round = 0, total_rounds = 0;
+    uint32_t batch = 2;
+    for (;;) {
+        for (uint32_t r = 0; r < batch; ++r, ++round) {
+            uint64_t *bc = c->best[round & 1], *bn = c->best[(round + 1) & 1];
+            hipLaunchKernelGGL(k_col_best, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, bc, bn, c->cnt);
+            hipLaunchKernelGGL(k_col_assign, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, bc, c->used, c->cnt);
+        }
+        total_rounds += batch;
+        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals);
+        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
+        hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
+        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        EH_HIP(c, hipStreamSynchronize(s));
+        if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 64 colours");
+        if (c->cnt_host->uncoloured == 0) break;
+        batch = 8;
+        if (total_rounds > 4096) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
+    }
+    c->stats.colour_rounds = total_rounds;
+    uint32_t nc = 0, na = 0;
+    for (uint32_t k = 0; k < kMaxColours; ++k) {
+        c->colour_start[k] = c->cnt_host->colour_start[k];
+        c->colour_end[k] = c->cnt_host->colour_end[k];
+        if (c->colour_end[k] > c->colour_start[k]) { nc = k + 1; na = c->colour_end[k] > na ? c->colour_end[k] : na; }
+    }
+    c->num_colours = nc;
+    c->num_active = na;
+    return EDYNHIP_OK;
+}
+
+int solve(edynhip_ctx *c) {
+    hipStream_t s = c->stream;
+    const uint32_t n = c->b.n;
+    if (n == 0) return EDYNHIP_OK;
+    Manifolds &mf = c->m[c->cur];
+    const float dt = c->cfg.fixed_dt;
+    const uint32_t rcap = mf.cap;
+    rec(c, 3);
+    EH_TRY(colour_contacts(c));
+    rec(c, 4);
+    const uint32_t na = c->num_active, nc = c->num_colours;
+    const Joints &j = c->j;
+    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt);
+    if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
+    if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt);
+    rec(c, 5);
+    uint32_t launches = 0;
+    auto joints_pass = [&](bool warm) {
+        for (uint32_t k = 0; k < j.num_colours; ++k) {
+            uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
+            if (e <= a) continue;
+            if (warm) hipLaunchKernelGGL(k_joint_solve<true>, dim3(blocks(e - a, 128)), dim3(128), 0, s, a, e, j, c->b);
+            else hipLaunchKernelGGL(k_joint_solve<false>, dim3(blocks(e - a, 128)), dim3(128), 0, s, a, e, j, c->b);
+            ++launches;
+        }
+    };
+    auto contacts_pass = [&](bool warm) {
+        for (uint32_t k = 0; k < nc; ++k) {
+            uint32_t a = c->colour_start[k], e = c->colour_end[k];
+            if (e <= a) continue;
+            if (warm) hipLaunchKernelGGL(k_contact_normal<true>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+            else hipLaunchKernelGGL(k_contact_normal<false>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+            ++launches;
+        }
+        for (uint32_t k = 0; k < nc; ++k) {
+            uint32_t a = c->colour_start[k], e = c->colour_end[k];
+            if (e <= a) continue;
+            if (warm) hipLaunchKernelGGL(k_contact_friction<true>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+            else hipLaunchKernelGGL(k_contact_friction<false>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+            ++launches;
+        }
+    };
+    joints_pass(true);
+    contacts_pass(true);
+    for (uint32_t it = 0; it < c->cfg.num_velocity_iterations; ++it) {
+        joints_pass(false);
+        contacts_pass(false);
+    }
+    c->timings.solve_velocity_launches += launches;
+    rec(c, 6);
+    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt);
+    if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
+    rec(c, 7);
+    if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
+        EH_HIP(c, hipMemsetAsync(c->isl_done, 0, (size_t)n * sizeof(uint32_t), s));
+        EH_HIP(c, hipMemsetAsync(c->isl_err, 0, (size_t)n * sizeof(float), s));
+        for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
+            for (uint32_t k = 0; k < j.num_colours; ++k) {
+                uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
+                if (e > a) hipLaunchKernelGGL(k_pos_joints, dim3(blocks(e - a, 128)), dim3(128), 0, s, a, e, j, c->b, c->isl_err, c->isl_done);
+            }
+            for (uint32_t k = 0; k < nc; ++k) {
+                uint32_t a = c->colour_start[k], e = c->colour_end[k];
+                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
+            }
+            hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
+        }
+    }
+    rec(c, 8);
+    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b);
+    rec(c, 9);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
+}
+
+}  // namespace eh

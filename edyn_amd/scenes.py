@@ -1,0 +1,227 @@
+"""Synthetic benchmark scenes (BASELINE.json configs).
+
+Every generator returns a dict of packed numpy arrays in the layout include/edynhip.h's
+edynhip_bodies expects (body 0 is the static ground plane where there is one), plus an optional
+"joints" list. Jitter comes from SplitMix64 with seed 0x9E3779B97F4A7C15 so every run, and the
+CPU oracle, see identical inputs.
+"""
+import math
+import numpy as np
+
+KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
+JOINT_POINT, JOINT_HINGE = 0, 1
+ALL = np.uint64(2**64 - 1)
+SEED = 0x9E3779B97F4A7C15
+
+
+def splitmix64_uniform(count, seed=SEED, stream=0):
+    """count uniform floats in [0,1) from SplitMix64 (counter mode: state_i = seed + (i+1)*gamma)."""
+    gamma = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, count + 1, dtype=np.uint64) + np.uint64(stream) * np.uint64(0x100000000)
+        z = np.uint64(seed) + idx * gamma
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+def _empty(n):
+    s = {
+        "kind": np.zeros(n, np.int32),
+        "pos": np.zeros((n, 3), np.float32),
+        "orn": np.tile(np.array([0, 0, 0, 1], np.float32), (n, 1)),
+        "linvel": np.zeros((n, 3), np.float32),
+        "angvel": np.zeros((n, 3), np.float32),
+        "mass": np.ones(n, np.float32),
+        "shape_type": np.zeros(n, np.int32),
+        "shape_param": np.zeros((n, 4), np.float32),
+        "friction": np.full(n, 0.5, np.float32),
+        "restitution": np.zeros(n, np.float32),
+        "group": np.full(n, ALL, np.uint64),
+        "mask": np.full(n, ALL, np.uint64),
+        "inertia": np.zeros((n, 9), np.float32),
+        "has_inertia": np.zeros(n, np.uint8),
+        "joints": [],
+    }
+    return s
+
+
+def _add_plane(s, i=0):
+    s["kind"][i] = KIND_STATIC
+    s["shape_type"][i] = SHAPE_PLANE
+    s["shape_param"][i] = (0, 1, 0, 0)   # plane_shape{normal (0,1,0), constant 0}
+
+
+def _yaw_quat(yaw):
+    h = (yaw * np.float32(0.5)).astype(np.float32)
+    q = np.zeros((len(yaw), 4), np.float32)
+    q[:, 1] = np.sin(h)
+    q[:, 3] = np.cos(h)
+    return q
+
+
+def _jitter(s, first, count, stream=0):
+    u = splitmix64_uniform(3 * count, stream=stream).reshape(count, 3)
+    s["pos"][first:first + count, 0] += (u[:, 0] * 2 - 1) * np.float32(0.005)
+    s["pos"][first:first + count, 2] += (u[:, 1] * 2 - 1) * np.float32(0.005)
+    s["orn"][first:first + count] = _yaw_quat((u[:, 2] * 2 - 1) * np.float32(0.02))
+
+
+def _lattice(nx, ny, nz, origin=(0.0, 0.0, 0.0), pitch_h=1.02, pitch_v=1.005, y0=0.505, brick=True):
+    k, i, j = np.meshgrid(np.arange(ny), np.arange(nx), np.arange(nz), indexing="ij")
+    k = k.reshape(-1); i = i.reshape(-1); j = j.reshape(-1)
+    off = 0.5 * (k & 1) if brick else 0.0
+    x = origin[0] + (i - (nx - 1) / 2.0) * pitch_h + off
+    z = origin[2] + (j - (nz - 1) / 2.0) * pitch_h + off
+    y = origin[1] + y0 + k * pitch_v
+    return np.stack([x, y, z], 1).astype(np.float32), (i + j + k)
+
+
+def box_pile(nx, ny, nz, mixed=False):
+    """Brick-offset lattice of unit boxes on a static plane (configs C2 / C3 / headline).
+    mixed=True alternates boxes and radius-0.5 spheres by (i+j+k) parity (C3)."""
+    n = nx * ny * nz + 1
+    s = _empty(n)
+    _add_plane(s)
+    pos, parity = _lattice(nx, ny, nz)
+    s["pos"][1:] = pos
+    s["shape_type"][1:] = SHAPE_BOX
+    s["shape_param"][1:, :3] = 0.5
+    if mixed:
+        sph = (parity & 1) == 1
+        st = s["shape_type"][1:]
+        st[sph] = SHAPE_SPHERE
+        sp = s["shape_param"][1:]
+        sp[sph] = (0.5, 0, 0, 0)
+    _jitter(s, 1, n - 1)
+    return s
+
+
+def c1_columns():
+    """C1: 10x10x10 straight columns, pitch 1.05, lowest centre y=0.55 -> 100 independent islands."""
+    n = 1001
+    s = _empty(n)
+    _add_plane(s)
+    pos, _ = _lattice(10, 10, 10, pitch_h=1.05, pitch_v=1.05, y0=0.55, brick=False)
+    s["pos"][1:] = pos
+    s["shape_type"][1:] = SHAPE_BOX
+    s["shape_param"][1:, :3] = 0.5
+    _jitter(s, 1, n - 1)
+    return s
+
+
+def c2_pile():
+    return box_pile(20, 20, 20)
+
+
+def c3_mixed():
+    return box_pile(32, 32, 32, mixed=True)
+
+
+def headline_pile():
+    """32k-box pile (32x32x32), the configuration BASELINE.json's metric is quoted on."""
+    return box_pile(32, 32, 32)
+
+
+def mini_piles(sites_x, sites_z, site_pitch=8.0, first_site=0, num_sites=None):
+    """C4 building block: independent 4x4x4 brick-offset mini-piles on a grid of sites `site_pitch` apart.
+    Returns the sites [first_site, first_site+num_sites) in row-major site order (for sharding across ranks)."""
+    total = sites_x * sites_z
+    if num_sites is None:
+        num_sites = total - first_site
+    n = 64 * num_sites + 1
+    s = _empty(n)
+    _add_plane(s)
+    base, _ = _lattice(4, 4, 4)
+    for t in range(num_sites):
+        site = first_site + t
+        sx, sz = site % sites_x, site // sites_x
+        o = np.array([(sx - (sites_x - 1) / 2.0) * site_pitch, 0, (sz - (sites_z - 1) / 2.0) * site_pitch], np.float32)
+        s["pos"][1 + 64 * t:1 + 64 * (t + 1)] = base + o
+    s["shape_type"][1:] = SHAPE_BOX
+    s["shape_param"][1:, :3] = 0.5
+    # jitter is keyed by the GLOBAL body slot so a shard sees the same values as the full scene
+    u = splitmix64_uniform(3 * 64 * total).reshape(64 * total, 3)[64 * first_site:64 * (first_site + num_sites)]
+    s["pos"][1:, 0] += (u[:, 0] * 2 - 1) * np.float32(0.005)
+    s["pos"][1:, 2] += (u[:, 1] * 2 - 1) * np.float32(0.005)
+    s["orn"][1:] = _yaw_quat((u[:, 2] * 2 - 1) * np.float32(0.02))
+    return s
+
+
+def c4_islands(first_site=0, num_sites=None):
+    """C4: 262 144 bodies = 4096 mini-piles on a 64x64 grid of sites."""
+    return mini_piles(64, 64, first_site=first_site, num_sites=num_sites)
+
+
+def c5_chains(num_chains=1024, links=16):
+    """C5: amorphous bodies with inertia diag(0.01) in chains; joint k alternates hinge (axis z) / point;
+    link 0 hangs from a static anchor by a point constraint."""
+    nb = num_chains * (links + 1)
+    s = _empty(nb)
+    u = splitmix64_uniform(num_chains)
+    side = int(math.ceil(math.sqrt(num_chains)))
+    joints = []
+    I = np.diag([0.01, 0.01, 0.01]).astype(np.float32).reshape(9)
+    for c in range(num_chains):
+        base = c * (links + 1)
+        ax, az = (c % side) * 2.0, (c // side) * 2.0
+        yaw = (float(u[c]) * 2 - 1) * 0.02
+        s["kind"][base] = KIND_STATIC
+        s["pos"][base] = (ax, 10.0, az)
+        for k in range(links):
+            b = base + 1 + k
+            # chain laid out sideways (+x) from the anchor so that it swings down
+            s["pos"][b] = (ax + 0.5 * (k + 0.5) * math.cos(yaw), 10.0, az + 0.5 * (k + 0.5) * math.sin(yaw))
+            s["inertia"][b] = I
+            s["has_inertia"][b] = 1
+            prev = base + k
+            pa = (0.0, 0.0, 0.0) if k == 0 else (0.25, 0.0, 0.0)
+            pb = (-0.25, 0.0, 0.0)
+            jt = JOINT_POINT if (k == 0 or k % 2 == 0) else JOINT_HINGE
+            joints.append((jt, prev, b, pa, pb, (0.0, 0.0, 1.0), (0.0, 0.0, 1.0)))
+    s["joints"] = joints
+    return s
+
+
+def scene_from_defs(defs, joints):
+    """Pack a list of edyn_amd.rigidbody_def (+ joint tuples) into the array layout."""
+    n = len(defs)
+    s = _empty(n)
+    grav = np.zeros((n, 3), np.float32)
+    any_grav = False
+    for i, d in enumerate(defs):
+        s["kind"][i] = d.kind
+        s["pos"][i] = d.position
+        s["orn"][i] = d.orientation
+        s["linvel"][i] = d.linvel
+        s["angvel"][i] = d.angvel
+        s["mass"][i] = d.mass
+        s["shape_type"][i] = d.shape_type
+        s["shape_param"][i] = d.shape_param
+        s["friction"][i] = d.friction
+        s["restitution"][i] = d.restitution
+        s["group"][i] = np.uint64(d.collision_group)
+        s["mask"][i] = np.uint64(d.collision_mask)
+        if d.inertia is not None:
+            s["inertia"][i] = np.asarray(d.inertia, np.float32).reshape(9)
+            s["has_inertia"][i] = 1
+        if d.gravity is not None:
+            any_grav = True
+            grav[i] = d.gravity
+    if any_grav:
+        raise NotImplementedError("per-body gravity via rigidbody_def: pass a full 'gravity' array with set_scene")
+    s["joints"] = list(joints)
+    return s
+
+
+def subset(scene, idx):
+    """Bodies `idx` (array of body ids, ascending) as a new scene; joints are dropped."""
+    out = {}
+    for k, v in scene.items():
+        if k == "joints":
+            out[k] = []
+        else:
+            out[k] = np.ascontiguousarray(v[idx])
+    return out

@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference's public stepping API over the C-ABI.
+
+Names and argument meaning follow include/edyn/edyn.hpp:66-150 (attach / detach / update /
+step_simulation / set_paused / get_fixed_dt ...), include/edyn/util/rigidbody.hpp:29-93
+(rigidbody_def, make_rigidbody) and include/edyn/util/constraint_util.hpp:38-54 (make_constraint).
+The EnTT registry itself is a C++ construct: the C++ drop-in shim lives in include/edyn/edyn.hpp of
+this repo; this Python mirror exists so the parity tests and the bench read like the reference's
+own integration tests (attach -> make_rigidbody -> update -> read components).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+import numpy as np
+from . import _capi
+from ._capi import EdynHipError, MANIFOLD_DTYPE
+
+KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2          # rigidbody_kind
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
+JOINT_POINT, JOINT_HINGE = 0, 1
+ALL_GROUPS = 2**64 - 1                                       # collision_filter::all_groups
+
+
+@dataclass
+class init_config:
+    """edyn::init_config + the settings fields on the hot path (context/settings.hpp:21-57)."""
+    fixed_dt: float = 1.0 / 60.0
+    num_solver_velocity_iterations: int = 8
+    num_solver_position_iterations: int = 3
+    max_steps_per_update: int = 10
+    gravity: Sequence[float] = (0.0, -9.8, 0.0)
+    device: int = 0
+    max_bodies: int = 0          # 0 = size from the first scene upload
+    max_manifolds: int = 0
+    max_joints: int = 0
+    timing: bool = False
+
+
+@dataclass
+class rigidbody_def:
+    """edyn::rigidbody_def (include/edyn/util/rigidbody.hpp:29-81), hot-path fields."""
+    kind: int = KIND_DYNAMIC
+    position: Sequence[float] = (0.0, 0.0, 0.0)
+    orientation: Sequence[float] = (0.0, 0.0, 0.0, 1.0)
+    mass: float = 1.0
+    inertia: Optional[Sequence[float]] = None    # 3x3, row-major
+    linvel: Sequence[float] = (0.0, 0.0, 0.0)
+    angvel: Sequence[float] = (0.0, 0.0, 0.0)
+    gravity: Optional[Sequence[float]] = None
+    shape_type: int = SHAPE_NONE
+    shape_param: Sequence[float] = (0.0, 0.0, 0.0, 0.0)
+    friction: float = 0.5
+    restitution: float = 0.0
+    collision_group: int = ALL_GROUPS
+    collision_mask: int = ALL_GROUPS
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class World:
+    """One attached simulation: the analogue of a registry with edyn attached."""
+
+    def __init__(self, config: Optional[init_config] = None):
+        self.cfg = config or init_config()
+        self._h = None
+        self._defs = []
+        self._joints = []
+        self._dirty = True
+        self._paused = False
+        self._accum = 0.0
+        self._last_time = 0.0
+        self.n = 0
+        self.nj = 0
+        self._L = _capi.lib()
+
+    # ---- edyn::attach / detach
+    def attach(self, max_bodies, max_joints=0):
+        self.detach()
+        cfg = _capi.Config()
+        cfg.device = self.cfg.device
+        cfg.max_bodies = max(int(max_bodies), 1)
+        cfg.max_manifolds = int(self.cfg.max_manifolds)
+        cfg.max_joints = max(int(max_joints), 0)
+        cfg.fixed_dt = self.cfg.fixed_dt
+        cfg.num_velocity_iterations = self.cfg.num_solver_velocity_iterations
+        cfg.num_position_iterations = self.cfg.num_solver_position_iterations
+        cfg.gravity = (C.c_float * 3)(*[float(x) for x in self.cfg.gravity])
+        cfg.flags = _capi.FLAG_TIMING if self.cfg.timing else 0
+        st = C.c_int(0)
+        h = self._L.edynhip_create(C.byref(cfg), C.byref(st))
+        if not h:
+            raise EdynHipError(st.value, self._L.edynhip_last_error(None).decode())
+        self._h = C.c_void_p(h)
+
+    def detach(self):
+        if self._h:
+            self._L.edynhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.detach()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EdynHipError(rc, self._L.edynhip_last_error(self._h).decode())
+
+    # ---- edyn::make_rigidbody / make_constraint (deferred: uploaded on the next update)
+    def make_rigidbody(self, d: rigidbody_def) -> int:
+        self._defs.append(d)
+        self._dirty = True
+        return len(self._defs) - 1
+
+    def make_constraint(self, jtype, body0, body1, pivot0, pivot1, axis0=(1, 0, 0), axis1=(1, 0, 0)) -> int:
+        self._joints.append((jtype, body0, body1, tuple(pivot0), tuple(pivot1), tuple(axis0), tuple(axis1)))
+        self._dirty = True
+        return len(self._joints) - 1
+
+    def set_scene(self, scene):
+        """Bulk scene upload from a dict of arrays (see edyn_amd.scenes)."""
+        n = len(scene["kind"])
+        joints = scene.get("joints") or []
+        if self._h is None:
+            self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
+        a = {}
+        a["kind"] = np.ascontiguousarray(scene["kind"], np.int32)
+        for k, w in (("pos", 3), ("orn", 4), ("linvel", 3), ("angvel", 3), ("shape_param", 4)):
+            a[k] = np.ascontiguousarray(scene[k], np.float32).reshape(n, w)
+        for k in ("mass", "friction", "restitution"):
+            a[k] = np.ascontiguousarray(scene[k], np.float32)
+        a["shape_type"] = np.ascontiguousarray(scene["shape_type"], np.int32)
+        a["group"] = np.ascontiguousarray(scene["group"], np.uint64)
+        a["mask"] = np.ascontiguousarray(scene["mask"], np.uint64)
+        inertia = scene.get("inertia")
+        has_inertia = scene.get("has_inertia")
+        if inertia is not None and has_inertia is not None:
+            a["inertia"] = np.ascontiguousarray(inertia, np.float32).reshape(n, 9)
+            a["has_inertia"] = np.ascontiguousarray(has_inertia, np.uint8)
+        grav = scene.get("gravity")
+        if grav is not None:
+            a["gravity"] = np.ascontiguousarray(grav, np.float32).reshape(n, 3)
+        b = _capi.Bodies()
+        for f, _ in _capi.Bodies._fields_:
+            setattr(b, f, _ptr(a.get(f)))
+        self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
+        self.n = n
+        self.nj = len(joints)
+        if joints:
+            jt = np.array([j[0] for j in joints], np.int32)
+            jb = np.array([[j[1], j[2]] for j in joints], np.uint32)
+            jp = np.array([[j[3], j[4]] for j in joints], np.float32).reshape(-1, 6)
+            ja = np.array([[j[5], j[6]] for j in joints], np.float32).reshape(-1, 6)
+            js = _capi.Joints(_ptr(jt), _ptr(jb), _ptr(jp), _ptr(ja))
+            self._check(self._L.edynhip_set_joints(self._h, len(joints), C.byref(js)))
+        else:
+            self._check(self._L.edynhip_set_joints(self._h, 0, None))
+        self._dirty = False
+
+    def _flush_defs(self):
+        if not self._dirty:
+            return
+        from .scenes import scene_from_defs
+        self.set_scene(scene_from_defs(self._defs, self._joints))
+
+    # ---- stepping (stepper_sequential.cpp:28-147)
+    def get_fixed_dt(self):
+        return self.cfg.fixed_dt
+
+    def set_paused(self, paused):
+        self._paused = paused
+        self._accum = 0.0
+
+    def is_paused(self):
+        return self._paused
+
+    def update(self, time: float):
+        """edyn::update(registry, time): fixed-dt accumulator with the max_steps_per_update clamp."""
+        self._flush_defs()
+        if self._paused:
+            return 0
+        elapsed = max(time - self._last_time, 0.0)
+        self._accum += elapsed
+        dt = float(np.float32(self.cfg.fixed_dt))
+        num_steps = int(math.floor(self._accum / dt))
+        self._accum -= num_steps * dt
+        steps = min(num_steps, self.cfg.max_steps_per_update)
+        if steps:
+            self._check(self._L.edynhip_step(self._h, steps))
+        self._last_time = time
+        return steps
+
+    def step_simulation(self, n=1):
+        """edyn::step_simulation: exactly one fixed step per call (n calls)."""
+        self._flush_defs()
+        self._check(self._L.edynhip_step(self._h, n))
+
+    def run_stages(self, mask):
+        self._flush_defs()
+        self._check(self._L.edynhip_run_stages(self._h, mask))
+
+    def synchronize(self):
+        self._check(self._L.edynhip_synchronize(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._L.edynhip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- component read-back
+    def get_state(self):
+        n = self.n
+        pos = np.zeros((n, 3), np.float32); orn = np.zeros((n, 4), np.float32)
+        lv = np.zeros((n, 3), np.float32); av = np.zeros((n, 3), np.float32)
+        self._check(self._L.edynhip_get_state(self._h, _ptr(pos), _ptr(orn), _ptr(lv), _ptr(av)))
+        return pos, orn, lv, av
+
+    def set_state(self, pos, orn, lv, av):
+        n = self.n
+        arrs = [np.ascontiguousarray(x, np.float32).reshape(n, w) for x, w in ((pos, 3), (orn, 4), (lv, 3), (av, 3))]
+        self._check(self._L.edynhip_set_state(self._h, *[_ptr(x) for x in arrs]))
+
+    def pack_state_device(self, dst_ptr, first=0, count=None):
+        self._check(self._L.edynhip_pack_state_device(self._h, C.c_void_p(dst_ptr), first, self.n if count is None else count))
+
+    def get_derived(self):
+        n = self.n
+        aabb = np.zeros((n, 6), np.float32); iw = np.zeros((n, 9), np.float32); isl = np.zeros(n, np.uint32)
+        self._check(self._L.edynhip_get_derived(self._h, _ptr(aabb), _ptr(iw), _ptr(isl)))
+        return aabb, iw, isl
+
+    def get_manifolds(self):
+        m = C.c_uint32(0)
+        self._check(self._L.edynhip_num_manifolds(self._h, C.byref(m)))
+        out = np.zeros(m.value, MANIFOLD_DTYPE)
+        if m.value:
+            self._check(self._L.edynhip_get_manifolds(self._h, _ptr(out), m.value, C.byref(m)))
+        return out
+
+    def set_manifolds(self, recs):
+        recs = np.ascontiguousarray(recs, MANIFOLD_DTYPE)
+        self._check(self._L.edynhip_set_manifolds(self._h, _ptr(recs), len(recs)))
+
+    def get_pairs(self):
+        m = C.c_uint32(0)
+        self._check(self._L.edynhip_num_manifolds(self._h, C.byref(m)))
+        keys = np.zeros(m.value, np.uint64)
+        if m.value:
+            self._check(self._L.edynhip_get_pairs(self._h, _ptr(keys), m.value, C.byref(m)))
+        return keys
+
+    def get_joint_impulses(self):
+        out = np.zeros((self.nj, 5), np.float32)
+        if self.nj:
+            self._check(self._L.edynhip_get_joint_impulses(self._h, _ptr(out)))
+        return out
+
+    def get_timings(self):
+        t = _capi.Timings()
+        self._check(self._L.edynhip_get_timings(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _capi.Timings._fields_}
+
+    def get_stats(self):
+        s = _capi.Stats()
+        self._check(self._L.edynhip_get_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in _capi.Stats._fields_}
+
+
+# Free functions with the reference's names.
+def attach(world: World, max_bodies, max_joints=0):
+    world.attach(max_bodies, max_joints)
+
+
+def detach(world: World):
+    world.detach()
+
+
+def make_rigidbody(world: World, d: rigidbody_def) -> int:
+    return world.make_rigidbody(d)
+
+
+def update(world: World, time: float):
+    return world.update(time)
+
+
+def step_simulation(world: World):
+    world.step_simulation(1)

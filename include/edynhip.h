@@ -1,0 +1,176 @@
+/* edynhip.h — C-ABI of the MI355X-native stepper that replaces Edyn's per-step simulation loop.
+ *
+ * The reference (xissburg/edyn v1.3.1) has no FFI layer: its seam is the C++ API over a caller-owned
+ * entt::registry. This C-ABI sits UNDER a header-only C++ shim (include/edyn/edyn.hpp in this repo)
+ * that keeps edyn::attach / edyn::update / edyn::make_rigidbody, so each entry point below cites the
+ * reference interface it stands in for:
+ *
+ *   edynhip_create / edynhip_destroy   <- edyn::attach / edyn::detach            include/edyn/edyn.hpp:66-77, src/edyn/edyn.cpp:73-197
+ *                                         + settings{fixed_dt, iterations, gravity} include/edyn/context/settings.hpp:21-57
+ *   edynhip_set_bodies                 <- edyn::make_rigidbody(registry, def)     include/edyn/util/rigidbody.hpp:29-93, src/edyn/util/rigidbody.cpp:47-191
+ *   edynhip_set_joints                 <- edyn::make_constraint<point|hinge>      include/edyn/util/constraint_util.hpp:38-54
+ *   edynhip_step                       <- edyn::step_simulation / one fixed step of edyn::update
+ *                                                                                 src/edyn/simulation/stepper_sequential.cpp:71-102,121-147
+ *   edynhip_get_state / set_state      <- reading/patching position, orientation, linvel, angvel pools
+ *                                                                                 include/edyn/comp/{position,orientation,linvel,angvel}.hpp
+ *   edynhip_get_manifolds / set_       <- contact_manifold + contact_point* components
+ *                                                                                 include/edyn/collision/contact_manifold.hpp:14-22, contact_point.hpp:17-58
+ *   edynhip_get_timings / get_stats    <- profile_timers / profile_counters       include/edyn/context/profile.hpp:8-27
+ *
+ * Conventions: plain pointers and sizes, host arrays are borrowed for the duration of the call only,
+ * every function returns 0 on success or a negative edynhip_status; nothing throws across the boundary.
+ * A context is bound to one GPU and is single-threaded, like the reference's sequential stepper.
+ * There is NO CPU fallback: if no gfx950 device is usable, edynhip_create fails with EDYNHIP_ERR_NO_DEVICE.
+ */
+#ifndef EDYNHIP_H
+#define EDYNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct edynhip_ctx edynhip_ctx;
+
+typedef enum {
+    EDYNHIP_OK = 0,
+    EDYNHIP_ERR_INVALID = -1,       /* bad argument */
+    EDYNHIP_ERR_NO_DEVICE = -2,     /* no usable HIP device */
+    EDYNHIP_ERR_HIP = -3,           /* a HIP runtime call failed (see edynhip_last_error) */
+    EDYNHIP_ERR_CAPACITY = -4,      /* pair / manifold capacity exceeded */
+    EDYNHIP_ERR_COLOURS = -5,       /* a body has more simultaneous contact partners than colours (64) */
+    EDYNHIP_ERR_UNSUPPORTED = -6    /* feature outside the hot-path scope */
+} edynhip_status;
+
+/* rigidbody_kind (include/edyn/util/rigidbody.hpp:22-27) */
+enum { EDYNHIP_KIND_DYNAMIC = 0, EDYNHIP_KIND_KINEMATIC = 1, EDYNHIP_KIND_STATIC = 2 };
+/* shapes on the hot path; NONE = amorphous body */
+enum { EDYNHIP_SHAPE_NONE = 0, EDYNHIP_SHAPE_BOX = 1, EDYNHIP_SHAPE_SPHERE = 2, EDYNHIP_SHAPE_PLANE = 3 };
+enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1 };
+/* contact_normal_attachment (include/edyn/collision/contact_normal_attachment.hpp:17-21) */
+enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2 };
+
+typedef struct {
+    int32_t device;                  /* HIP device ordinal */
+    uint32_t max_bodies;
+    uint32_t max_manifolds;          /* 0 = 8 * max_bodies */
+    uint32_t max_joints;
+    float fixed_dt;                  /* settings.fixed_dt, default 1/60 */
+    uint32_t num_velocity_iterations;/* settings.num_solver_velocity_iterations, default 8 */
+    uint32_t num_position_iterations;/* settings.num_solver_position_iterations, default 3 */
+    float gravity[3];                /* settings.gravity, default (0,-9.8,0) */
+    uint32_t flags;                  /* EDYNHIP_FLAG_* */
+} edynhip_config;
+
+enum {
+    EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings) */
+    EDYNHIP_FLAG_NO_GRAPH = 2u       /* launch the solver eagerly instead of replaying captured hipGraphs */
+};
+
+/* Scene description, one entry per body, index = body id. Arrays are packed row-major
+ * (pos[n][3], orn[n][4] xyzw, ...), i.e. the memory layout of the corresponding EnTT pools. */
+typedef struct {
+    const int32_t *kind;             /* EDYNHIP_KIND_* */
+    const float *pos;                /* [n][3] */
+    const float *orn;                /* [n][4] */
+    const float *linvel;             /* [n][3] */
+    const float *angvel;             /* [n][3] */
+    const float *mass;               /* [n]   (dynamic only) */
+    const float *inertia;            /* [n][9] local inertia tensor, used where has_inertia[i] != 0; may be NULL */
+    const uint8_t *has_inertia;      /* [n] or NULL: 0 = derive from mass and shape (moment_of_inertia.cpp) */
+    const int32_t *shape_type;       /* EDYNHIP_SHAPE_* */
+    const float *shape_param;        /* [n][4]: box half_extents xyz | sphere radius | plane normal xyz + constant */
+    const float *friction;           /* [n] material.friction */
+    const float *restitution;        /* [n] material.restitution (must be 0: restitution solver is out of scope) */
+    const uint64_t *group;           /* [n] collision_filter.group (all ones = default) */
+    const uint64_t *mask;            /* [n] collision_filter.mask */
+    const float *gravity;            /* [n][3] per-body gravity or NULL = config gravity */
+} edynhip_bodies;
+
+typedef struct {
+    const int32_t *type;             /* EDYNHIP_JOINT_* */
+    const uint32_t *body;            /* [n][2] */
+    const float *pivot;              /* [n][2][3] object-space pivots */
+    const float *axis;               /* [n][2][3] hinge axes in object space (ignored for point joints) */
+} edynhip_joints;
+
+/* One contact point; mirrors contact_point + contact_point_geometry + _material + _impulse. */
+typedef struct {
+    float pivotA[3], pivotB[3], normal[3], local_normal[3];
+    float distance, friction, restitution;
+    int32_t attachment;
+    uint32_t lifetime;
+    float normal_impulse, friction_impulse[2];
+} edynhip_point;
+
+/* One contact manifold (body pair) with its <= 4 points in the reference's list order (newest first). */
+typedef struct {
+    uint32_t body[2];
+    uint32_t num_points;
+    uint32_t colour;                 /* solver colour of this pair (0xFF = none) */
+    edynhip_point pt[4];
+} edynhip_manifold;
+
+/* Stage selector for edynhip_run_stages: the reference's stage names (profile.hpp:8-18). */
+enum {
+    EDYNHIP_STAGE_BROADPHASE = 1u,
+    EDYNHIP_STAGE_NARROWPHASE = 2u,
+    EDYNHIP_STAGE_ISLANDS = 4u,
+    EDYNHIP_STAGE_SOLVE = 8u,
+    EDYNHIP_STAGE_ALL = 15u
+};
+
+typedef struct {
+    /* milliseconds, accumulated over the steps of the last edynhip_step call (EDYNHIP_FLAG_TIMING) */
+    float broadphase_ms, narrowphase_ms, islands_ms, colouring_ms, prepare_ms, solve_velocity_ms,
+          integrate_ms, solve_position_ms, finish_ms, step_ms;
+    uint32_t solve_velocity_launches;  /* kernel launches inside solve_velocity_ms */
+    uint32_t steps;
+} edynhip_timings;
+
+typedef struct {
+    uint32_t num_bodies, num_manifolds, num_points, num_active_manifolds, num_islands, num_colours,
+             num_joint_colours, colour_rounds, num_joints, num_joint_rows;
+} edynhip_stats;
+
+edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out);
+void edynhip_destroy(edynhip_ctx *ctx);
+const char *edynhip_last_error(const edynhip_ctx *ctx);   /* ctx may be NULL: error of the last failed create */
+
+/* Optional: run on a caller-owned hipStream_t (e.g. torch's current stream). NULL = the ctx's own stream. */
+int edynhip_set_stream(edynhip_ctx *ctx, void *hip_stream);
+
+int edynhip_set_bodies(edynhip_ctx *ctx, uint32_t n, const edynhip_bodies *bodies);
+int edynhip_set_joints(edynhip_ctx *ctx, uint32_t n, const edynhip_joints *joints);
+
+/* Advance `nsteps` fixed-dt steps. Returns after the work is enqueued and error flags were checked. */
+int edynhip_step(edynhip_ctx *ctx, uint32_t nsteps);
+/* Run a subset of one step's stages (parity tests). */
+int edynhip_run_stages(edynhip_ctx *ctx, uint32_t stage_mask);
+/* Block until all enqueued work of this ctx has finished. */
+int edynhip_synchronize(edynhip_ctx *ctx);
+
+int edynhip_get_state(edynhip_ctx *ctx, float *pos, float *orn, float *linvel, float *angvel);
+int edynhip_set_state(edynhip_ctx *ctx, const float *pos, const float *orn, const float *linvel, const float *angvel);
+/* Pack (pos3, orn4, linvel3, angvel3) = 13 floats per body into DEVICE memory `dst` (for RCCL gathers). */
+int edynhip_pack_state_device(edynhip_ctx *ctx, void *dst_device, uint32_t first_body, uint32_t count);
+/* Derived per-body state: aabb[n][6] (min,max), inertia_world_inv[n][9], island label[n]; any may be NULL. */
+int edynhip_get_derived(edynhip_ctx *ctx, float *aabb, float *inertia_world_inv, uint32_t *island);
+
+int edynhip_num_manifolds(edynhip_ctx *ctx, uint32_t *n);
+int edynhip_get_manifolds(edynhip_ctx *ctx, edynhip_manifold *out, uint32_t capacity, uint32_t *n);
+int edynhip_set_manifolds(edynhip_ctx *ctx, const edynhip_manifold *in, uint32_t n);
+/* Canonical broadphase pairs: keys[i] = (max(body)<<32 | min(body)), ascending. */
+int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint32_t *n);
+int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses5);
+
+int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
+int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);
+uint32_t edynhip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDYNHIP_H */
