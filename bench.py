@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py - steps/sec of the MI355X-native Edyn stepper on the headline scene.
+
+Contract (one JSON line on rank 0):
+  metric   steps/sec (whole node), 32k-box pile, 10 SI iters           (BASELINE.json)
+  value    pile-steps per second over all ranks, scene resident in HBM before the timed region
+  N = 1    the 32 768-box brick-offset pile on a static plane, 10 velocity / 3 position iterations
+  N > 1    the pile is ONE island and cannot be split: each rank steps its own replica of
+           the pile (N islands sharded one per GPU, no data-path collective) and the integrated state
+           (13 floats/body) is all-gathered over RCCL every step, as the registry write-back would need;
+           value counts pile-steps, scaling = "weak".
+  roofline the SI velocity-solve kernels (k_contact_solve, one launch per colour): algorithmic bytes
+           (380 B per contact point per iteration) / time measured with HIP events recorded
+           on the stepper's stream inside the timed region.
+  cpu_baseline  the CPU oracle (reference-order restatement, 1 thread) timed on a bounded sample of the
+           same scene on rank 0 at N=1. A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import edyn_amd
+from edyn_amd import scenes
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_POINT_ITER = 380.0   # algorithmic bytes per contact point per velocity iteration
+WORKLOADS = {
+    "pile32k": dict(gen=lambda: scenes.box_pile(32, 32, 32), vel=10, pos=3, desc="32x32x32 = 32768-box brick-offset pile on a static plane"),
+    "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, desc="20x20x20 = 8000-box pile (config C2)"),
+    "mixed32k": dict(gen=lambda: scenes.box_pile(32, 32, 32, mixed=True), vel=20, pos=3, desc="32768 mixed box/sphere stack, 20 it (config C3)"),
+    "pile512": dict(gen=lambda: scenes.box_pile(8, 8, 8), vel=10, pos=3, desc="8x8x8 pile (smoke)"),
+}
+
+
+def cpu_baseline(workload, sample_steps, warm_steps):
+    """Time the CPU oracle (reference order, single thread) on a bounded sample. Checker code, timed - never shipped."""
+    from oracle import binding as ob
+    wl = WORKLOADS[workload]
+    scene = wl["gen"]()
+    o = ob.World(vel_iters=wl["vel"], pos_iters=wl["pos"], order=ob.ORDER_SEQUENTIAL)
+    o.add_bodies(scene)
+    o.step(warm_steps)
+    t = o.time_steps(sample_steps)
+    return {"value": sample_steps / t, "unit": "steps/sec", "cores": 1, "kind": "port",
+            "sample": f"{sample_steps} steps after {warm_steps} warm-up steps of the same scene from its initial state "
+                      f"({o.get_stats()['num_points']} contact points at the end), oracle in reference (sequential) row order"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--workload", default="pile32k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=16)
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
+    torch.cuda.set_device(local_rank)
+    distributed = world_size > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    scene = wl["gen"]()
+    n_bodies = len(scene["kind"])
+    cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
+                               device=local_rank, timing=True)
+    w = edyn_amd.World(cfg)
+    w.set_scene(scene)
+    stream = torch.cuda.current_stream()
+    w.set_stream(stream.cuda_stream)   # stepper kernels and the RCCL gather share torch's stream => ordered
+
+    state = torch.empty((n_bodies, 13), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world_size * n_bodies, 13), dtype=torch.float32, device="cuda") if distributed else None
+
+    def one_step():
+        w.step_simulation(1)
+        if distributed:
+            w.pack_state_device(state.data_ptr())
+            dist.all_gather_into_tensor(gathered.view(-1), state.view(-1))
+
+    for _ in range(args.warmup):
+        one_step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if distributed:
+        for _ in range(args.steps):
+            one_step()
+    else:
+        w.step_simulation(args.steps)   # K steps, stage events recorded per step on the stepper's stream
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    stats = w.get_stats()
+    tm = w.get_timings()
+    pos = w.get_state()[0]
+    finite = bool(np.isfinite(pos).all())
+
+    if rank == 0:
+        value = world_size * args.steps / elapsed
+        steps_timed = max(tm["steps"], 1)
+        solve_ms = tm["solve_velocity_ms"] / steps_timed
+        launches = tm["solve_velocity_launches"] / max(args.steps if not distributed else 1, 1)
+        alg_bytes_step = BYTES_PER_POINT_ITER * stats["num_points"] * (wl["vel"] + 1)   # +1: warm start sweep
+        achieved = (alg_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "steps/sec (whole node), 32k-box pile, 10 SI iters; HBM GB/s in solve",
+            "value": value, "unit": "steps/sec", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}; {wl['vel']} velocity / {wl['pos']} position iterations, dt 1/60, "
+                                   f"friction 0.5, restitution 0" + (f"; {world_size} replicas (one island per GPU), per-step RCCL all-gather of state" if distributed else ""),
+                       "bodies": n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
+                       "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_contact_solve<false/true> (every colour, every iteration + warm start)",
+                         "algorithmic_bytes_per_launch": alg_bytes_step / max(launches, 1), "launches_per_step": launches,
+                         "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
+            "stages_ms_per_step": {k: tm[k] / steps_timed for k in ("broadphase_ms", "narrowphase_ms", "islands_ms", "colouring_ms",
+                                                                    "prepare_ms", "solve_velocity_ms", "integrate_ms", "solve_position_ms",
+                                                                    "finish_ms", "step_ms")},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_steps, 4)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

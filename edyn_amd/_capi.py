@@ -43,7 +43,7 @@ class Timings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("num_bodies", "num_manifolds", "num_points", "num_active_manifolds",
                                           "num_islands", "num_colours", "num_joint_colours", "colour_rounds",
-                                          "num_joints", "num_joint_rows")]
+                                          "num_joints", "num_joint_rows")] + [("colour_size", C.c_uint32 * 64)]
 
 
 POINT_DTYPE = np.dtype([

@@ -10,6 +10,7 @@
 // contact points persist by a binary search of the previous step's sorted array.
 #include "ctx.hpp"
 #include "dmath.hpp"
+#include <algorithm>
 
 namespace eh {
 using namespace dm;
@@ -26,20 +27,24 @@ __global__ void k_step_reset(Counters *cnt) {
     int t = threadIdx.x;
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->num_islands = 0; cnt->colour_rounds = 0;
+        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0;
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
     if (t < (int)kMaxColours) { cnt->colour_start[t] = 0; cnt->colour_end[t] = 0; }
 }
 
-__global__ void k_bp_bounds(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin,
-                            const float4 *__restrict__ amax, Counters *cnt) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+k_bp_bounds(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin,
+            const float4 *__restrict__ amax, Counters *cnt) {
+    __shared__ float slo[4][3], shi[4][3];
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (t < np) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < np; t += gridDim.x * blockDim.x) {   // grid-stride
         uint32_t b = proc[t];
         float4 a = amin[b], c = amax[b];
-        lo[0] = hi[0] = (a.x + c.x) * 0.5f; lo[1] = hi[1] = (a.y + c.y) * 0.5f; lo[2] = hi[2] = (a.z + c.z) * 0.5f;
+        float cx = (a.x + c.x) * 0.5f, cy = (a.y + c.y) * 0.5f, cz = (a.z + c.z) * 0.5f;
+        lo[0] = fminf(lo[0], cx); hi[0] = fmaxf(hi[0], cx);
+        lo[1] = fminf(lo[1], cy); hi[1] = fmaxf(hi[1], cy);
+        lo[2] = fminf(lo[2], cz); hi[2] = fmaxf(hi[2], cz);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -49,12 +54,14 @@ __global__ void k_bp_bounds(const uint32_t *__restrict__ proc, uint32_t np, cons
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
     }
-    if ((threadIdx.x & 63) == 0 && lo[0] <= hi[0]) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&cnt->bounds_min[k], f2ord(lo[k]));
-            atomicMax(&cnt->bounds_max[k], f2ord(hi[k]));
-        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { slo[wave][k] = lo[k]; shi[wave][k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = fminf(fminf(slo[0][k], slo[1][k]), fminf(slo[2][k], slo[3][k]));
+        float h = fmaxf(fmaxf(shi[0][k], shi[1][k]), fmaxf(shi[2][k], shi[3][k]));
+        if (l <= h) { atomicMin(&cnt->bounds_min[k], f2ord(l)); atomicMax(&cnt->bounds_max[k], f2ord(h)); }
     }
 }
 
@@ -174,35 +181,38 @@ DI box3 body_box(const float4 *amin, const float4 *amax, uint32_t b) { return {f
 DI bool filter_ok(const uint64_t *group, const uint64_t *mask, uint32_t a, uint32_t b) {   // should_collide.cpp:23-57
     return (group[a] & mask[b]) != 0 && (group[b] & mask[a]) != 0;
 }
-// lower_bound over the previous step's sorted skeys for canonical key `key`; returns index or ~0u.
-DI uint32_t find_prev(const uint64_t *__restrict__ pskey, uint32_t pm, uint64_t key) {
-    uint32_t lo = 0, hi = pm;
-    const uint64_t target = key << 1;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (pskey[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    if (lo < pm && (pskey[lo] >> 1) == key) return lo;
+// Previous-step manifold of the canonical pair (hi, lo), or ~0u. The previous array is sorted by (hi, lo), so
+// the candidates are the short contiguous run of manifolds whose higher body is `hi`.
+DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t lo) {
+    if (pm == 0) return 0xFFFFFFFFu;
+    const uint32_t s0 = prev.seg_start[hi], s1 = prev.seg_end[hi];
+    for (uint32_t s = s0; s < s1; ++s)
+        if ((uint32_t)(prev.skey[s] >> 1) == lo) return s;
     return 0xFFFFFFFFu;
 }
-DI void emit_pair(uint64_t skey, uint64_t *out, uint32_t cap, Counters *cnt) {
-    uint32_t idx = atomicAdd(&cnt->num_pairs, 1u);
-    if (idx < cap) out[idx] = skey; else cnt->pair_overflow = 1;
+// Pairs are staged per wave in LDS and flushed with ONE global atomic per wave: a single hot counter takes
+// ~12 ns per atomic on this chip, which would otherwise dominate the traversal.
+constexpr uint32_t kWaveBuf = 1536;   // keys per wave (64 lanes x 24 neighbours)
+struct Emit { uint64_t *buf; uint32_t *count; uint64_t *out; uint32_t cap; Counters *cnt; };
+DI void emit_pair(uint64_t skey, const Emit &e) {
+    uint32_t idx = atomicAdd(e.count, 1u);   // LDS atomic
+    if (idx < kWaveBuf) { e.buf[idx] = skey; return; }
+    uint32_t g = atomicAdd(&e.cnt->num_pairs, 1u);   // staging full: rare direct path
+    if (g < e.cap) e.out[g] = skey; else e.cnt->pair_overflow = 1;
 }
 // Decide whether the unordered pair {i (procedural, the querying body), j} is in this step's set.
 DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
-                      const uint64_t *mask, bool j_procedural, const uint64_t *pskey, uint32_t pm, uint64_t *out, uint32_t cap,
-                      Counters *cnt) {
+                      const uint64_t *mask, bool j_procedural, const Manifolds &prev, uint32_t pm, const Emit &em) {
     const uint32_t hi = i > j ? i : j, lo = i > j ? j : i;
     const uint64_t key = ((uint64_t)hi << 32) | lo;
     const box3 bj = body_box(amin, amax, j);
-    uint32_t prev = find_prev(pskey, pm, key);
-    if (prev != 0xFFFFFFFFu) {   // destroy_separated_manifolds, broadphase.cpp:119-134
-        const uint64_t ps = pskey[prev];
+    uint32_t pidx = find_prev(prev, pm, hi, lo);
+    if (pidx != 0xFFFFFFFFu) {   // destroy_separated_manifolds, broadphase.cpp:119-134
+        const uint64_t ps = prev.skey[pidx];
         const bool swapped = ps & 1;
         const uint32_t b0 = swapped ? lo : hi;
         const box3 &x0 = b0 == i ? bi : bj, &x1 = b0 == i ? bj : bi;
-        if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, out, cap, cnt);
+        if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, em);
         return;
     }
     if (!filter_ok(group, mask, i, j)) return;
@@ -210,10 +220,10 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
     // Bodies are visited in descending index order, so the higher index gets to create the pair first.
     const box3 &bh = hi == i ? bi : bj, &bl = hi == i ? bj : bi;
     if (j_procedural) {
-        if (intersect(inset(bh, -kBreaking), bl)) emit_pair(key << 1, out, cap, cnt);
-        else if (intersect(inset(bl, -kBreaking), bh)) emit_pair((key << 1) | 1, out, cap, cnt);
+        if (intersect(inset(bh, -kBreaking), bl)) emit_pair(key << 1, em);
+        else if (intersect(inset(bl, -kBreaking), bh)) emit_pair((key << 1) | 1, em);
     } else {
-        if (intersect(inset(bi, -kBreaking), bj)) emit_pair((key << 1) | (i == lo ? 1u : 0u), out, cap, cnt);
+        if (intersect(inset(bi, -kBreaking), bj)) emit_pair((key << 1) | (i == lo ? 1u : 0u), em);
     }
 }
 
@@ -221,41 +231,61 @@ __global__ void __launch_bounds__(128)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
            const float4 *__restrict__ nmin, const float4 *__restrict__ nmax, const float4 *__restrict__ amin,
            const float4 *__restrict__ amax, const uint64_t *__restrict__ group, const uint64_t *__restrict__ mask,
-           const uint32_t *__restrict__ np_list, uint32_t num_np, const uint64_t *__restrict__ pskey, uint32_t pm,
+           const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
            uint64_t *out, uint32_t cap, Counters *cnt) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-    const box3 bi = body_box(amin, amax, i);
-    const box3 q = inset(bi, -kQueryGrow);
-    if (n > 1) {
-        uint32_t stack[64];
-        int sp = 0;
-        stack[sp++] = 0;
-        while (sp > 0) {
-            uint32_t node = stack[--sp];
-            box3 nb{from4(nmin[node]), from4(nmax[node])};
-            if (!intersect(nb, q)) continue;
-            if (node >= (uint32_t)(n - 1)) {
-                uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
-                if (j < i) consider_pair(i, j, bi, amin, amax, group, mask, true, pskey, pm, out, cap, cnt);
-            } else if (sp <= 62) {
-                stack[sp++] = left[node];
-                stack[sp++] = right[node];
+    __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
+    __shared__ uint64_t wbuf[2][kWaveBuf];       // per-wave staging of emitted pairs
+    __shared__ uint32_t wcount[2];
+    const int tx = threadIdx.x, wave = tx >> 6, lane = tx & 63;
+    if (lane == 0) wcount[wave] = 0;
+    __syncthreads();
+    const Emit em{wbuf[wave], &wcount[wave], out, cap, cnt};
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+        const box3 bi = body_box(amin, amax, i);
+        const box3 q = inset(bi, -kQueryGrow);
+        if (n > 1) {
+            int sp = 0;
+            stk[sp++][tx] = 0;
+            while (sp > 0) {
+                uint32_t node = stk[--sp][tx];
+                box3 nb{from4(nmin[node]), from4(nmax[node])};
+                if (!intersect(nb, q)) continue;
+                if (node >= (uint32_t)(n - 1)) {
+                    uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
+                    if (j < i) consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);
+                } else if (sp <= 46) {
+                    stk[sp++][tx] = left[node];
+                    stk[sp++][tx] = right[node];
+                } else {
+                    cnt->pair_overflow = 2;   // traversal stack exhausted: reported as an error, never silently dropped
+                }
             }
         }
+        for (uint32_t t = 0; t < num_np; ++t) {
+            uint32_t j = np_list[t];
+            box3 bj = body_box(amin, amax, j);
+            if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, prev, pm, em);
+        }
     }
-    for (uint32_t t = 0; t < num_np; ++t) {
-        uint32_t j = np_list[t];
-        box3 bj = body_box(amin, amax, j);
-        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, pskey, pm, out, cap, cnt);
+    __syncthreads();
+    // flush this wave's staging buffer with one global atomic
+    const uint32_t total = min(wcount[wave], kWaveBuf);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(&cnt->num_pairs, total);
+    base = __shfl(base, 0);
+    for (uint32_t t = lane; t < total; t += 64) {
+        if (base + t < cap) out[base + t] = wbuf[wave][t]; else cnt->pair_overflow = 1;
     }
 }
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
-__global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm) {
+__global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
+                                     Counters *cnt) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    if (m == 0 && M != pm) cnt->pairs_changed = 1;
     const uint64_t sk = skeys[m];
     const uint64_t key = sk >> 1;
     const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
@@ -263,8 +293,15 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     cur.skey[m] = sk;
     cur.bodyA[m] = swapped ? lo : hi;
     cur.bodyB[m] = swapped ? hi : lo;
-    uint32_t p = find_prev(prev.skey, pm, key);
+    {   // segments of the new array, for next step's lookups
+        const uint32_t ph = m > 0 ? (uint32_t)(skeys[m - 1] >> 33) : 0xFFFFFFFFu;
+        const uint32_t nh = m + 1 < M ? (uint32_t)(skeys[m + 1] >> 33) : 0xFFFFFFFFu;
+        if (ph != hi) cur.seg_start[hi] = m;
+        if (nh != hi) cur.seg_end[hi] = m + 1;
+    }
+    uint32_t p = find_prev(prev, pm, hi, lo);
     uint32_t info = kNoColour << 8;
+    if (p == 0xFFFFFFFFu) cnt->pairs_changed = 1;
     if (p != 0xFFFFFFFFu) {
         info = prev.info[p];
         const uint32_t np = info & 0xFF;
@@ -287,21 +324,24 @@ int broadphase(edynhip_ctx *c) {
     hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
     uint32_t M = 0;
     if (np > 0) {
-        hipLaunchKernelGGL(k_bp_bounds, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt);
+        hipLaunchKernelGGL(k_bp_bounds, dim3(std::min(blocks(np, 256), 32u)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt);
         hipLaunchKernelGGL(k_bp_morton, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt, c->bvh.keys);
         EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 62));
         if (np > 1)
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.left, c->bvh.right, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev.skey, pm, c->pair_keys, cur.cap, c->cnt);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.left, c->bvh.right, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt);
         // pair count is needed on the host to size the sort and the manifold kernels
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
-        if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, "broadphase: pair capacity (max_manifolds) exceeded");
+        if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         M = c->cnt_host->num_pairs;
         EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 64));
+        EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
+        EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt);
+        else if (pm != 0) c->force_islands = true;
     }
     c->cur ^= 1;
     c->num_manifolds = M;

@@ -30,8 +30,9 @@ static int dalloc(edynhip_ctx *c, T *&p, size_t count) {
     return EDYNHIP_OK;
 }
 
-static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap) {
+static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap, uint32_t nb) {
     m.cap = cap;
+    EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb));
     EH_TRY(dalloc(c, m.skey, cap)); EH_TRY(dalloc(c, m.bodyA, cap)); EH_TRY(dalloc(c, m.bodyB, cap)); EH_TRY(dalloc(c, m.info, cap));
     EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
     EH_TRY(dalloc(c, m.nrm, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.lnrm, (size_t)cap * kMaxPts));
@@ -48,12 +49,11 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, b.amin, nb)); EH_TRY(dalloc(c, b.amax, nb)); EH_TRY(dalloc(c, b.shape, nb)); EH_TRY(dalloc(c, b.grav, nb));
     EH_TRY(dalloc(c, b.mat, nb)); EH_TRY(dalloc(c, b.flags, nb)); EH_TRY(dalloc(c, b.group, nb)); EH_TRY(dalloc(c, b.mask, nb));
     EH_TRY(dalloc(c, b.island, nb));
-    EH_TRY(alloc_manifolds(c, c->m[0], M));
-    EH_TRY(alloc_manifolds(c, c->m[1], M));
+    EH_TRY(alloc_manifolds(c, c->m[0], M, nb));
+    EH_TRY(alloc_manifolds(c, c->m[1], M, nb));
     Rows &r = c->rows;
     EH_TRY(dalloc(c, r.order, M)); EH_TRY(dalloc(c, r.bA, M)); EH_TRY(dalloc(c, r.bB, M)); EH_TRY(dalloc(c, r.np, M));
-    EH_TRY(dalloc(c, r.r0, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, r.r1, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, r.r2, (size_t)M * kMaxPts));
-    EH_TRY(dalloc(c, r.r3, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, r.r4, (size_t)M * kMaxPts));
+    EH_TRY(dalloc(c, r.rw, (size_t)M * kMaxPts * kRowsPerPoint * kRowF));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));
     EH_TRY(dalloc(c, t.parent, (size_t)2 * nb)); EH_TRY(dalloc(c, t.left, nb)); EH_TRY(dalloc(c, t.right, nb));
@@ -75,10 +75,6 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->cnt, 1));
     EH_HIP(c, hipHostMalloc((void **)&c->cnt_host, sizeof(Counters), hipHostMallocDefault));
     std::memset(c->cnt_host, 0, sizeof(Counters));
-    if (c->cfg.flags & EDYNHIP_FLAG_TIMING) {
-        for (auto &e : c->timer.e) EH_HIP(c, hipEventCreate(&e));
-        c->timer.made = true;
-    }
     EH_HIP(c, hipStreamSynchronize(c->stream));
     return EDYNHIP_OK;
 }
@@ -217,6 +213,12 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
     const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
     mf.skey[m] = ((((uint64_t)hi << 32) | lo) << 1) | (a == lo ? 1u : 0u);
     mf.bodyA[m] = a; mf.bodyB[m] = b;
+    {
+        const uint32_t ph = m > 0 ? (in[m - 1].body[0] > in[m - 1].body[1] ? in[m - 1].body[0] : in[m - 1].body[1]) : 0xFFFFFFFFu;
+        const uint32_t nh = m + 1 < M ? (in[m + 1].body[0] > in[m + 1].body[1] ? in[m + 1].body[0] : in[m + 1].body[1]) : 0xFFFFFFFFu;
+        if (ph != hi) mf.seg_start[hi] = m;
+        if (nh != hi) mf.seg_end[hi] = m + 1;
+    }
     mf.info[m] = (r.num_points & 0xFF) | ((r.colour & 0xFF) << 8);
     for (uint32_t k = 0; k < r.num_points; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
@@ -254,20 +256,41 @@ __global__ void k_pack_derived(uint32_t n, Bodies b, float *aabb, float *iw) {
     for (int r = 0; r < 3; ++r) { float4 x = b.iw[3 * i + r]; iw[9 * i + 3 * r] = x.x; iw[9 * i + 3 * r + 1] = x.y; iw[9 * i + 3 * r + 2] = x.z; }
 }
 
-static void accumulate_timings(edynhip_ctx *c) {
-    if (!(c->cfg.flags & EDYNHIP_FLAG_TIMING)) return;
-    (void)hipEventSynchronize(c->timer.e[10]);
-    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->timer.e[a], c->timer.e[b]); return ms; };
+constexpr uint32_t kMaxTimedSteps = 4096;
+static int begin_timed_step(edynhip_ctx *c) {
+    StageTimer &t = c->timer;
+    t.e = nullptr;
+    if (!(c->cfg.flags & EDYNHIP_FLAG_TIMING) || t.recorded >= kMaxTimedSteps) return EDYNHIP_OK;
+    if (t.recorded >= t.capacity) {
+        for (int k = 0; k < StageTimer::kEvents; ++k) { hipEvent_t e; EH_HIP(c, hipEventCreate(&e)); t.ev.push_back(e); }
+        t.capacity += 1;
+    }
+    t.e = &t.ev[(size_t)t.recorded * StageTimer::kEvents];
+    return EDYNHIP_OK;
+}
+static void resolve_timings(edynhip_ctx *c) {
+    StageTimer &tm = c->timer;
     edynhip_timings &t = c->timings;
-    t.broadphase_ms += el(0, 1); t.narrowphase_ms += el(1, 2); t.islands_ms += el(2, 3); t.colouring_ms += el(3, 4);
-    t.prepare_ms += el(4, 5); t.solve_velocity_ms += el(5, 6); t.integrate_ms += el(6, 7); t.solve_position_ms += el(7, 8);
-    t.finish_ms += el(8, 9); t.step_ms += el(0, 10);
-    t.steps += 1;
+    const uint32_t launches = t.solve_velocity_launches;
+    t = edynhip_timings{};
+    t.solve_velocity_launches = launches;
+    if (tm.recorded == 0) return;
+    (void)hipEventSynchronize(tm.ev[(size_t)(tm.recorded - 1) * StageTimer::kEvents + 10]);
+    for (uint32_t s = 0; s < tm.recorded; ++s) {
+        hipEvent_t *e = &tm.ev[(size_t)s * StageTimer::kEvents];
+        auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e[a], e[b]); return ms; };
+        t.broadphase_ms += el(0, 1); t.narrowphase_ms += el(1, 2); t.islands_ms += el(2, 3); t.colouring_ms += el(3, 4);
+        t.prepare_ms += el(4, 5); t.solve_velocity_ms += el(5, 6); t.integrate_ms += el(6, 7); t.solve_position_ms += el(7, 8);
+        t.finish_ms += el(8, 9); t.step_ms += el(0, 10);
+    }
+    t.steps = tm.recorded;
 }
 
 static int run_stages(edynhip_ctx *c, uint32_t mask) {
-    const bool timing = (c->cfg.flags & EDYNHIP_FLAG_TIMING) != 0 && mask == EDYNHIP_STAGE_ALL;
-    auto rec = [&](int i) { if (timing) (void)hipEventRecord(c->timer.e[i], c->stream); };
+    c->timer.e = nullptr;
+    if (mask == EDYNHIP_STAGE_ALL) EH_TRY(begin_timed_step(c));
+    else c->force_islands = true;   // partial runs (tests) never rely on a previous step's labels
+    auto rec = [&](int i) { if (c->timer.e) (void)hipEventRecord(c->timer.e[i], c->stream); };
     rec(0);
     if (mask & EDYNHIP_STAGE_BROADPHASE) EH_TRY(broadphase(c));
     rec(1);
@@ -276,7 +299,7 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     if (mask & EDYNHIP_STAGE_ISLANDS) EH_TRY(islands(c));
     if (mask & EDYNHIP_STAGE_SOLVE) EH_TRY(solve(c));   // records events 3..9
     rec(10);
-    if (timing) accumulate_timings(c);
+    if (c->timer.e) { c->timer.recorded += 1; c->timer.e = nullptr; }
     return EDYNHIP_OK;
 }
 
@@ -306,7 +329,7 @@ edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out) {
     edynhip_ctx *c = new edynhip_ctx();
     c->cfg = *cfg;
     c->device = cfg->device;
-    if (c->cfg.max_manifolds == 0) c->cfg.max_manifolds = 8 * c->cfg.max_bodies;
+    if (c->cfg.max_manifolds == 0) c->cfg.max_manifolds = 16 * c->cfg.max_bodies + 1024;
     if (c->cfg.fixed_dt <= 0) c->cfg.fixed_dt = 1.0f / 60.0f;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(EDYNHIP_ERR_HIP, "hipStreamCreate", e); }
@@ -327,7 +350,7 @@ void edynhip_destroy(edynhip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
-    if (c->timer.made) for (auto &e : c->timer.e) (void)hipEventDestroy(e);
+    for (auto &e : c->timer.ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -387,6 +410,7 @@ int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
     (void)hipStreamSynchronize(c->stream);
     for (void *p : tmp) (void)hipFree(p);
     c->num_manifolds = 0;
+    c->force_islands = true;
     c->stats.num_bodies = n;
     if (rc == EDYNHIP_OK) EH_HIP(c, hipGetLastError());
     return rc;
@@ -398,6 +422,7 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     EH_HIP(c, hipSetDevice(c->device));
     Joints &j = c->j;
     j.n = n; j.num_colours = 0; j.rows = 0;
+    c->force_islands = true;
     std::memset(j.colour_start, 0, sizeof(j.colour_start));
     if (n == 0) return EDYNHIP_OK;
     // body kinds are needed for the colouring (only procedural endpoints constrain a colour)
@@ -407,13 +432,12 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     // Deterministic edge colouring, identical to the per-step contact colouring kernels (solver.hip k_col_*).
     std::vector<uint32_t> colour(n, kNoColour);
     std::vector<uint64_t> used(c->b.n, 0), best(c->b.n, 0);
-    auto mix = [](uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; };
     for (;;) {
         bool any = false;
         for (uint32_t e = 0; e < n; ++e) {
             if (colour[e] != kNoColour) continue;
             any = true;
-            uint64_t pr = ((uint64_t)mix(e + 1) << 32) | (e + 1);
+            uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
             uint32_t a = in->body[2 * e], b = in->body[2 * e + 1];
             if (a >= c->b.n || b >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joints: body index out of range");
             if (dyn(a)) best[a] = std::max(best[a], pr);
@@ -422,7 +446,7 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
         if (!any) break;
         for (uint32_t e = 0; e < n; ++e) {
             if (colour[e] != kNoColour) continue;
-            uint64_t pr = ((uint64_t)mix(e + 1) << 32) | (e + 1);
+            uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
             uint32_t a = in->body[2 * e], b = in->body[2 * e + 1];
             bool da = dyn(a), db = dyn(b);
             if ((da && best[a] != pr) || (db && best[b] != pr)) continue;
@@ -501,6 +525,7 @@ int edynhip_step(edynhip_ctx *c, uint32_t nsteps) {
     if (!c) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
     c->timings = edynhip_timings{};
+    c->timer.recorded = 0;
     for (uint32_t i = 0; i < nsteps; ++i) EH_TRY(run_stages(c, EDYNHIP_STAGE_ALL));
     return EDYNHIP_OK;
 }
@@ -611,6 +636,9 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
         if (!(key(in[i - 1]) < key(in[i]))) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_manifolds: records not sorted by canonical pair key");
     }
     c->num_manifolds = n;
+    c->force_islands = true;
+    EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
+    EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     if (n == 0) return EDYNHIP_OK;
     edynhip_manifold *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, (size_t)n * sizeof(edynhip_manifold)));
@@ -652,6 +680,7 @@ int edynhip_get_joint_impulses(edynhip_ctx *c, float *out) {
 
 int edynhip_get_timings(edynhip_ctx *c, edynhip_timings *out) {
     if (!c || !out) return EDYNHIP_ERR_INVALID;
+    resolve_timings(c);
     *out = c->timings;
     return EDYNHIP_OK;
 }
@@ -659,14 +688,16 @@ int edynhip_get_timings(edynhip_ctx *c, edynhip_timings *out) {
 int edynhip_get_stats(edynhip_ctx *c, edynhip_stats *out) {
     if (!c || !out) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(count_points(c));
     EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.num_bodies = c->b.n;
     c->stats.num_manifolds = c->num_manifolds;
     c->stats.num_points = c->cnt_host->num_points;
-    c->stats.num_active_manifolds = c->num_active;
+    c->stats.num_active_manifolds = c->cnt_host->num_active;
     c->stats.num_islands = c->cnt_host->num_islands;
     c->stats.num_colours = c->num_colours;
+    for (uint32_t k = 0; k < kMaxColours; ++k) c->stats.colour_size[k] = k < c->num_colours ? c->colour_end[k] - c->colour_start[k] : 0;
     *out = c->stats;
     return EDYNHIP_OK;
 }

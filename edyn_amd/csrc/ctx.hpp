@@ -46,6 +46,7 @@ struct Manifolds {
     uint64_t *skey = nullptr;     // (hi<<32|lo)<<1 | swapped   (swapped: body[0] == lo)
     uint32_t *bodyA = nullptr, *bodyB = nullptr;
     uint32_t *info = nullptr;     // num_points | colour << 8
+    uint32_t *seg_start = nullptr, *seg_end = nullptr;   // per body b: manifolds whose higher body index is b
     // per point slot k (list order, newest first): index k*cap + m
     float4 *pA = nullptr;         // pivotA xyz, w = distance
     float4 *pB = nullptr;         // pivotB xyz, w = friction
@@ -71,19 +72,20 @@ struct Joints {
     uint32_t colour_start[kMaxColours + 1] = {0};   // host copy
 };
 
-// Solver rows in colour-sorted order p. Jacobians are stored compressed: normal n and lever arms
-// rA, rB; the friction tangents and all angular parts are recomputed from them (same arithmetic as
-// prep, hence bit-identical to stored Jacobians).
+// Solver rows in colour-sorted order p. The per-colour solve kernels are latency / issue bound (a colour of
+// a 32k-box pile is only ~10k lanes, one wave per CU), so everything that does not depend on the evolving
+// body deltas is precomputed once per step by k_prep_contacts: Jacobian blocks AND the angular impulse
+// directions I^-1 J^T. Every value is the result of the same fp32 operations the reference performs inside
+// its solve loop, so results stay bit-identical.
+// Row r of point slot k of lane p lives at rw[((k*3 + r)*5 + f) * cap + p], r = 0 normal, 1/2 friction tangents:
+//   f=0: J_lin.xyz (n or t; J[2] = -J_lin), eff_mass     f=1: J_angA.xyz, rhs      f=2: J_angB.xyz, impulse
+//   f=3: inv_IA * J_angA .xyz, mu (normal row only)      f=4: inv_IB * J_angB .xyz
 struct Rows {
     uint32_t *order = nullptr;    // p -> manifold index
     uint32_t *bA = nullptr, *bB = nullptr, *np = nullptr;
-    // per point slot k: index k*cap + p
-    float4 *r0 = nullptr;         // n.xyz, eff_mass_n
-    float4 *r1 = nullptr;         // rA.xyz, rhs_n
-    float4 *r2 = nullptr;         // rB.xyz, impulse_n
-    float4 *r3 = nullptr;         // eff_t0, eff_t1, rhs_t0, rhs_t1
-    float4 *r4 = nullptr;         // impulse_t0, impulse_t1, mu, 0
+    float4 *rw = nullptr;
 };
+constexpr int kRowF = 5, kRowsPerPoint = 3;
 
 struct LBVH {
     uint64_t *keys = nullptr, *keys_sorted = nullptr;   // morton<<32 | body
@@ -104,12 +106,19 @@ struct Counters {
     uint32_t uncoloured;         // edges still lacking a colour
     uint32_t colour_overflow;
     uint32_t num_islands;
-    uint32_t colour_rounds;
+    uint32_t pairs_changed;      // this step's pair set differs from the previous step's
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     uint32_t colour_start[kMaxColours], colour_end[kMaxColours];
 };
 
-struct StageTimer { hipEvent_t e[12]; bool made = false; };
+// Per-step stage events; resolved lazily by edynhip_get_timings so that timing adds no host sync.
+struct StageTimer {
+    static constexpr int kEvents = 11;
+    std::vector<hipEvent_t> ev;     // kEvents per recorded step
+    uint32_t recorded = 0;          // steps recorded since the last edynhip_step call
+    uint32_t capacity = 0;          // steps for which events exist
+    hipEvent_t *e = nullptr;        // events of the step being recorded (nullptr = not recording)
+};
 
 }  // namespace eh
 
@@ -143,13 +152,14 @@ struct edynhip_ctx {
     uint32_t colour_start[eh::kMaxColours] = {0}, colour_end[eh::kMaxColours] = {0};
     uint32_t num_active = 0;
     std::vector<void *> allocs;
-    bool joints_dirty = false;
+    bool force_islands = true;     // recompute island labels even if the pair set did not change
 };
 
 namespace eh {
 // stage entry points (each .hip file implements its own)
 int broadphase(edynhip_ctx *c);
 int narrowphase(edynhip_ctx *c);
+int count_points(edynhip_ctx *c);
 int islands(edynhip_ctx *c);
 int solve(edynhip_ctx *c);
 // sort helpers (sort.hip)

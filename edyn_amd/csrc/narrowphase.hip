@@ -74,9 +74,8 @@ DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
 }
 
 __global__ void __launch_bounds__(64)
-k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, Counters *cnt) {
+k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t my_points = 0, my_active = 0;
     if (m < M) {
         const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
         const uint32_t info = mf.info[m];
@@ -193,22 +192,29 @@ k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, Counters *cnt) {
         uint32_t colour = info >> 8;
         if (n_out == 0) colour = kNoColour;   // inactive pairs hold no solver colour
         mf.info[m] = (uint32_t)n_out | (colour << 8);
-        my_points = (uint32_t)n_out;
-        my_active = n_out > 0 ? 1u : 0u;
     }
+}
+
+// Contact point / active manifold census for edynhip_get_stats (not on the per-step path).
+__global__ void k_count_points(uint32_t M, const uint32_t *__restrict__ info, Counters *cnt) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t pts = m < M ? (info[m] & 0xFF) : 0, act = pts ? 1u : 0u;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        my_points += __shfl_xor(my_points, off);
-        my_active += __shfl_xor(my_active, off);
-    }
-    if ((threadIdx.x & 63) == 0 && my_points) { atomicAdd(&cnt->num_points, my_points); atomicAdd(&cnt->num_active, my_active); }
+    for (int off = 32; off > 0; off >>= 1) { pts += __shfl_xor(pts, off); act += __shfl_xor(act, off); }
+    if ((threadIdx.x & 63) == 0 && pts) { atomicAdd(&cnt->num_points, pts); atomicAdd(&cnt->num_active, act); }
+}
+int count_points(edynhip_ctx *c) {
+    EH_HIP(c, hipMemsetAsync(&c->cnt->num_points, 0, 2 * sizeof(uint32_t), c->stream));
+    const uint32_t M = c->num_manifolds;
+    if (M) hipLaunchKernelGGL(k_count_points, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->m[c->cur].info, c->cnt);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
 }
 
 int narrowphase(edynhip_ctx *c) {
     const uint32_t M = c->num_manifolds;
-    EH_HIP(c, hipMemsetAsync(&c->cnt->num_points, 0, 2 * sizeof(uint32_t), c->stream));   // num_points, num_active
     if (M == 0) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->cnt);
+    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }

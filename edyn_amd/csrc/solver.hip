@@ -17,8 +17,9 @@
 // What is NOT in the reference: within an island the reference sweeps rows strictly sequentially
 // (Gauss-Seidel). Here the contact graph is edge-coloured so that the manifolds of one colour share no
 // procedural body; each colour is one launch with one manifold per lane (its <=4 points in sequence).
-// Per iteration: joints by colour, then the normal rows of every colour, then the friction rows of every
-// colour - the reference's "all rows, then all friction rows" structure.
+// Per iteration: joints by colour, then contacts by colour; within a colour each lane sweeps the normal rows
+// of its manifold and then its friction rows (the friction circle uses the normal impulse just updated, as
+// in the reference). The reference's global "all rows, then all friction rows" split is kept per manifold.
 #include "ctx.hpp"
 #include "dcollide.hpp"
 
@@ -28,17 +29,21 @@ using namespace dm;
 static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
 
 DI bool is_dynamic(uint32_t flags) { return (flags & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC; }
-DI uint32_t mix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return h;
-}
-DI uint64_t edge_prio(uint32_t e) { return ((uint64_t)mix32(e + 1) << 32) | (e + 1); }
+// Edge priority for the colouring rounds: lower edge index wins, which reproduces sequential first-fit
+// colouring in canonical pair order (near-optimal colour counts on stacked scenes: max degree or +1) at the
+// price of more rounds when a whole scene is coloured from scratch; steady state only colours new edges.
+DI uint64_t edge_prio(uint32_t e) { return (uint64_t)(0xFFFFFFFFu - e); }
 
 // ------------------------------------------------------------------ islands (lock-free union-find)
 DI uint32_t cc_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// find with path halving: links always point to a smaller index, so storing a grandparent is safe under races
 DI uint32_t cc_find(uint32_t *parent, uint32_t x) {
     uint32_t p = cc_load(&parent[x]);
-    while (p != x) { x = p; p = cc_load(&parent[x]); }
+    while (p != x) {
+        uint32_t gp = cc_load(&parent[p]);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p; p = gp;
+    }
     return x;
 }
 DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
@@ -49,18 +54,25 @@ DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
         if (atomicCAS(&parent[ra], ra, rb) == ra) return;
     }
 }
-__global__ void k_cc_init(uint32_t n, uint32_t *island) {
+// The three island kernels are skipped on the device when the pair set is unchanged since the last step
+// (labels stay valid); `force` overrides that after scene edits.
+__global__ void k_cc_init(uint32_t n, uint32_t *island, Counters *cnt, uint32_t force) {
+    if (!force && !cnt->pairs_changed) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cnt->num_islands = 0;
     if (i < n) island[i] = i;
 }
 __global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                          const uint32_t *__restrict__ flags, uint32_t *island) {
+                          const uint32_t *__restrict__ flags, uint32_t *island, const Counters *cnt, uint32_t force) {
+    if (!force && !cnt->pairs_changed) return;
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M) return;
     uint32_t a = bA[e], b = bB[e];
     if (is_dynamic(flags[a]) && is_dynamic(flags[b])) cc_union(island, a, b);
 }
-__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt) {
+__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt,
+                             uint32_t force) {
+    if (!force && !cnt->pairs_changed) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t root = 0;
     if (i < n) {
@@ -74,14 +86,17 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
 }
 
 // ------------------------------------------------------------------ colouring
-__global__ void k_col_prepare(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
+// `reinsert` = last step's top colour: its edges are released and first-fit again, so colour classes freed by
+// vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards.
+__global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
-                              uint64_t *best0, uint64_t *best1, Counters *cnt) {
+                              uint64_t *best0, uint64_t *best1, Counters *cnt, uint32_t reinsert) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t unc = 0;
     if (m < M) {
         uint32_t in = info[m];
         uint32_t np = in & 0xFF, col = in >> 8;
+        if (np > 0 && col == reinsert) { col = kNoColour; info[m] = np | (kNoColour << 8); }
         if (np > 0) {
             uint32_t a = bA[m], b = bB[m];
             bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
@@ -196,6 +211,14 @@ __global__ void k_solve_begin(uint32_t n, Bodies b, float dt) {
     b.dw[i] = make_float4(0, 0, 0, 0);
 }
 
+DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, float eff, float rhs, float imp, float mu,
+                  const BRef &A, const BRef &B) {
+    rw[base] = to4(Jl, eff);
+    rw[base + cap] = to4(JaA, rhs);
+    rw[base + 2 * cap] = to4(JaB, imp);
+    rw[base + 3 * cap] = to4(mul(A.inv_I, JaA), mu);
+    rw[base + 4 * cap] = to4(mul(B.inv_I, JaB), 0.0f);
+}
 __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
@@ -205,7 +228,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
     rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * mf.cap + m, d = (size_t)k * rcap + p;
+        const size_t s = (size_t)k * mf.cap + m;
         const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
         const f3 n = from4(n4);
         const float distance = a4.w, mu = b4.w;
@@ -226,11 +249,10 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float eff1 = eff_mass(t1, L1, -t1, L3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
         const float rhs0 = -rel_speed(t0, K1, -t0, K3, A.v, A.w, B.v, B.w);
         const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
-        rows.r0[d] = to4(n, effn);
-        rows.r1[d] = to4(rA, rhsn);
-        rows.r2[d] = to4(rB, im.x);
-        rows.r3[d] = make_float4(eff0, eff1, rhs0, rhs1);
-        rows.r4[d] = make_float4(im.y, im.z, mu, 0.0f);
+        const size_t base = (size_t)(k * kRowsPerPoint) * kRowF * rcap + p, rstride = (size_t)kRowF * rcap;
+        store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
+        store_row(rows.rw, base + rstride, rcap, t0, K1, K3, eff0, rhs0, im.y, 0.0f, A, B);
+        store_row(rows.rw, base + 2 * rstride, rcap, t1, L1, L3, eff1, rhs1, im.z, 0.0f, A, B);
     }
 }
 
@@ -254,77 +276,121 @@ DI void apply_impulse(Delta &d, f3 J0, f3 J1, f3 J2, f3 J3, float imp) {   // ap
     d.dwB += mul(d.iB, J3) * imp;
 }
 
-template <bool WARM>
-__global__ void __launch_bounds__(256)
-k_contact_normal(uint32_t start, uint32_t end, Rows rows, uint32_t rcap, Bodies b) {
-    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= end) return;
-    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
-    Delta d;
-    load_delta(b, ia, ib, d);
-    for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * rcap + p;
-        const float4 q0 = rows.r0[s], q1 = rows.r1[s];
-        float4 q2 = rows.r2[s];
-        const f3 n = from4(q0), rA = from4(q1), rB = from4(q2);
-        const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
-        if (WARM) {
-            apply_impulse(d, J0, J1, J2, J3, q2.w);
-        } else {
-            float drel = rel_speed(J0, J1, J2, J3, d.dvA, d.dwA, d.dvB, d.dwB);
-            float dimp = (q1.w - drel) * q0.w;
-            float imp = q2.w + dimp;
-            if (imp < 0.0f) { dimp = 0.0f - q2.w; q2.w = 0.0f; }
-            else if (imp > kLarge) { dimp = kLarge - q2.w; q2.w = kLarge; }
-            else q2.w = imp;
-            apply_impulse(d, J0, J1, J2, J3, dimp);
-            rows.r2[s] = q2;
-        }
-    }
-    store_delta(b, ia, ib, d);
+// One launch per colour: each lane owns one manifold and sweeps its normal rows, then its friction rows
+// (solve(constraint_row&) + apply_row_impulse, then solve_friction, per point in list order).
+// Loads are all issued up front: indices -> {body deltas, every row of every point} -> arithmetic -> stores.
+struct RowReg { float4 f[kRowF]; };
+DI void row_apply(Delta &d, const RowReg &r, float imp) {   // apply_row_impulse with precomputed I^-1 J^T
+    const f3 Jl = from4(r.f[0]);
+    d.dvA += d.imA * Jl * imp;
+    d.dvB += d.imB * (-Jl) * imp;
+    d.dwA += from4(r.f[3]) * imp;
+    d.dwB += from4(r.f[4]) * imp;
 }
-
+DI float row_relspeed(const Delta &d, const RowReg &r) {
+    const f3 Jl = from4(r.f[0]);
+    return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
+}
 template <bool WARM>
-__global__ void __launch_bounds__(256)
-k_contact_friction(uint32_t start, uint32_t end, Rows rows, uint32_t rcap, Bodies b) {
-    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= end) return;
-    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
-    Delta d;
-    load_delta(b, ia, ib, d);
-    for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * rcap + p;
-        const float4 q0 = rows.r0[s], q1 = rows.r1[s], q2 = rows.r2[s], q3 = rows.r3[s];
-        float4 q4v = rows.r4[s];
-        const f3 n = from4(q0), rA = from4(q1), rB = from4(q2);
-        f3 t0, t1;
-        plane_space(n, t0, t1);
-        const f3 K1 = cross(rA, t0), K3 = -cross(rB, t0), L1 = cross(rA, t1), L3 = -cross(rB, t1);
-        if (WARM) {   // warm_start(constraint_row_friction&): dvA, dwA, dvB, dwB per tangent
-            d.dvA += d.imA * t0 * q4v.x; d.dwA += mul(d.iA, K1) * q4v.x; d.dvB += d.imB * (-t0) * q4v.x; d.dwB += mul(d.iB, K3) * q4v.x;
-            d.dvA += d.imA * t1 * q4v.y; d.dwA += mul(d.iA, L1) * q4v.y; d.dvB += d.imB * (-t1) * q4v.y; d.dwB += mul(d.iB, L3) * q4v.y;
-        } else {
-            float dr0 = rel_speed(t0, K1, -t0, K3, d.dvA, d.dwA, d.dvB, d.dwB);
-            float di0 = (q3.z - dr0) * q3.x;
-            float i0 = q4v.x + di0;
-            float dr1 = rel_speed(t1, L1, -t1, L3, d.dvA, d.dwA, d.dvB, d.dwB);
-            float di1 = (q3.w - dr1) * q3.y;
-            float i1 = q4v.y + di1;
-            float len2 = i0 * i0 + i1 * i1;
-            float max_len = q4v.z * q2.w;   // mu * current normal impulse
-            if (len2 > square(max_len)) {
-                float len = sqrtf(len2);
-                if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-                else { i0 = 0; i1 = 0; }
-                di0 = i0 - q4v.x; di1 = i1 - q4v.y;
-            }
-            q4v.x = i0; q4v.y = i1;
-            d.dvA += d.imA * t0 * di0; d.dwA += mul(d.iA, K1) * di0; d.dvB += d.imB * (-t0) * di0; d.dwB += mul(d.iB, K3) * di0;
-            d.dvA += d.imA * t1 * di1; d.dwA += mul(d.iA, L1) * di1; d.dvB += d.imB * (-t1) * di1; d.dwB += mul(d.iB, L3) * di1;
-            rows.r4[s] = q4v;
+DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                           const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
+                           float4 *__restrict__ bdv, float4 *__restrict__ bdw) {
+    const uint32_t ia = rbA[p], ib = rbB[p], np = rnp[p];
+    RowReg R[kMaxPts][kRowsPerPoint];
+#pragma unroll
+    for (int k = 0; k < kMaxPts; ++k) {
+        if ((uint32_t)k < np) {
+#pragma unroll
+            for (int r = 0; r < kRowsPerPoint; ++r)
+#pragma unroll
+                for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
         }
     }
-    store_delta(b, ia, ib, d);
+    Delta d;
+    {
+        const float4 va = bdv[ia], vb = bdv[ib], wa = bdw[ia], wb = bdw[ib];
+        d.dvA = from4(va); d.imA = va.w; d.dwA = from4(wa);
+        d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(wb);
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPts; ++k) {
+        if ((uint32_t)k < np) {
+            RowReg &r = R[k][0];
+            if (WARM) {
+                row_apply(d, r, r.f[2].w);
+            } else {
+                float drel = row_relspeed(d, r);
+                float dimp = (r.f[1].w - drel) * r.f[0].w;
+                float cur = r.f[2].w;
+                float imp = cur + dimp;
+                if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
+                else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
+                else cur = imp;
+                r.f[2].w = cur;
+                row_apply(d, r, dimp);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPts; ++k) {
+        if ((uint32_t)k < np) {
+            RowReg &ra = R[k][1], &rb = R[k][2];
+            if (WARM) {   // warm_start(constraint_row_friction&)
+                row_apply(d, ra, ra.f[2].w);
+                row_apply(d, rb, rb.f[2].w);
+            } else {
+                float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
+                float i0 = ra.f[2].w + di0;
+                float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
+                float i1 = rb.f[2].w + di1;
+                float len2 = i0 * i0 + i1 * i1;
+                float max_len = R[k][0].f[3].w * R[k][0].f[2].w;   // mu * current normal impulse
+                if (len2 > square(max_len)) {
+                    float len = sqrtf(len2);
+                    if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+                    else { i0 = 0; i1 = 0; }
+                    di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
+                }
+                ra.f[2].w = i0; rb.f[2].w = i1;
+                row_apply(d, ra, di0);
+                row_apply(d, rb, di1);
+            }
+        }
+    }
+    if (!WARM) {
+#pragma unroll
+        for (int k = 0; k < kMaxPts; ++k) {
+            if ((uint32_t)k < np) {
+#pragma unroll
+                for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
+            }
+        }
+    }
+    if (d.imA != 0) { bdv[ia] = to4(d.dvA, d.imA); bdw[ia] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { bdv[ib] = to4(d.dvB, d.imB); bdw[ib] = to4(d.dwB, 0); }
+}
+template <bool WARM>
+__global__ void __launch_bounds__(64)
+k_contact_solve(uint32_t start, uint32_t end, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
+                float4 *__restrict__ bdv, float4 *__restrict__ bdw) {
+    const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < end) contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdv, bdw);
+}
+// Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
+// workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
+struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxColours]; };
+constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
+template <bool WARM>
+__global__ void __launch_bounds__(256)
+k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, const uint32_t *rnp, float4 *rw, uint32_t rcap,
+                     float4 *bdv, float4 *bdw) {
+    for (uint32_t c = 0; c < tr.n; ++c) {
+        for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
+            contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdv, bdw);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf) {
@@ -332,10 +398,11 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
     if (p >= n_active) return;
     const uint32_t m = rows.order[p], np = rows.np[p];
     for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * rcap + p, d = (size_t)k * mf.cap + m;
+        const size_t d = (size_t)k * mf.cap + m;
         float4 im = mf.imp[d];
-        float4 f = rows.r4[s];
-        im.x = rows.r2[s].w; im.y = f.x; im.z = f.y;
+        im.x = rows.rw[(size_t)((k * kRowsPerPoint + 0) * kRowF + 2) * rcap + p].w;
+        im.y = rows.rw[(size_t)((k * kRowsPerPoint + 1) * kRowF + 2) * rcap + p].w;
+        im.z = rows.rw[(size_t)((k * kRowsPerPoint + 2) * kRowF + 2) * rcap + p].w;
         mf.imp[d] = im;
     }
 }
@@ -456,51 +523,79 @@ DI void pos_solve(PBody &A, PBody &B, f3 J0, f3 J1, f3 J2, f3 J3, float error, f
     pos_apply(B, J2, J3, corr);
     max_err = fmaxf(fabsf(error), max_err);
 }
-DI void publish_error(float max_err, uint32_t label, float *isl_err) {
-    if (max_err > 0) atomicMax((unsigned int *)&isl_err[label], __float_as_uint(max_err));
+// One atomic per wave when all its active lanes belong to one island (the common case: a pile is one
+// island). Every lane of the wave must call this (inactive lanes pass active = false).
+DI void publish_error(bool active, float max_err, uint32_t label, float *isl_err) {
+    uint32_t rep = active ? label : 0xFFFFFFFFu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rep = min(rep, (uint32_t)__shfl_xor((int)rep, off));
+    float m = active ? max_err : 0.0f;
+    if (__all(!active || label == rep)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0 && m > 0 && rep != 0xFFFFFFFFu) atomicMax((unsigned int *)&isl_err[rep], __float_as_uint(m));
+    } else if (m > 0) {
+        atomicMax((unsigned int *)&isl_err[label], __float_as_uint(m));
+    }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
-    uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= end) return;
-    const uint32_t m = rows.order[p];
-    const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
-    PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
-    const uint32_t label = b.island[A.proc ? ia : ib];
-    if (isl_done[label]) return;
+    const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = p < end;
+    uint32_t label = 0;
     float max_err = 0;
-    for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
-        float4 a4 = mf.pA[s];
-        const float4 b4 = mf.pB[s], l4 = mf.lnrm[s];
-        float4 n4 = mf.nrm[s];
-        const int attach = __float_as_int(n4.w);
-        const f3 pAw = to_world(from4(a4), A.pos, A.orn), pBw = to_world(from4(b4), B.pos, B.orn);
-        f3 n = from4(n4);
-        if (attach == dc::NA_ON_A) n = rotate(A.orn, from4(l4));
-        else if (attach == dc::NA_ON_B) n = rotate(B.orn, from4(l4));
-        const float distance = dot(pAw - pBw, n);
-        const f3 rA = pAw - A.pos, rB = pBw - B.pos;
-        a4.w = distance;
-        mf.pA[s] = a4;
-        mf.nrm[s] = to4(n, n4.w);
-        if (distance > -kEps) continue;
-        pos_solve(A, B, n, cross(rA, n), -n, -cross(rB, n), -distance, max_err);
+    if (active) {
+        const uint32_t m = rows.order[p];
+        const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
+        float4 a4[kMaxPts], b4[kMaxPts], l4[kMaxPts], n4[kMaxPts];
+#pragma unroll
+        for (int k = 0; k < kMaxPts; ++k) {   // all loads up front: this kernel is latency-bound
+            const size_t s = (size_t)k * mf.cap + m;
+            if ((uint32_t)k < np) { a4[k] = mf.pA[s]; b4[k] = mf.pB[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s]; }
+        }
+        PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
+        label = b.island[A.proc ? ia : ib];
+        active = isl_done[label] == 0;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < kMaxPts; ++k) {
+                if ((uint32_t)k < np) {
+                    const int attach = __float_as_int(n4[k].w);
+                    const f3 pAw = to_world(from4(a4[k]), A.pos, A.orn), pBw = to_world(from4(b4[k]), B.pos, B.orn);
+                    f3 n = from4(n4[k]);
+                    if (attach == dc::NA_ON_A) n = rotate(A.orn, from4(l4[k]));
+                    else if (attach == dc::NA_ON_B) n = rotate(B.orn, from4(l4[k]));
+                    const float distance = dot(pAw - pBw, n);
+                    const f3 rA = pAw - A.pos, rB = pBw - B.pos;
+                    a4[k].w = distance;
+                    n4[k] = to4(n, n4[k].w);
+                    if (!(distance > -kEps)) pos_solve(A, B, n, cross(rA, n), -n, -cross(rB, n), -distance, max_err);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxPts; ++k) {
+                const size_t s = (size_t)k * mf.cap + m;
+                if ((uint32_t)k < np) { mf.pA[s] = a4[k]; mf.nrm[s] = n4[k]; }
+            }
+            store_pbody(b, ia, A);
+            store_pbody(b, ib, B);
+        }
     }
-    store_pbody(b, ia, A);
-    store_pbody(b, ib, B);
-    publish_error(max_err, label, isl_err);
+    publish_error(active, max_err, label, isl_err);
 }
 __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
-    uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= end) return;
-    if (j.type[i] != EDYNHIP_JOINT_HINGE) return;   // point_constraint has no solve_position (island_solver.cpp:252-260)
+    const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+    // point_constraint has no solve_position (island_solver.cpp:252-260)
+    bool active = i < end && j.type[i] == EDYNHIP_JOINT_HINGE;
+    uint32_t label = 0;
+    float max_err = 0;
+    if (active) {
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
     PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
-    const uint32_t label = b.island[A.proc ? ia : ib];
-    if (isl_done[label]) return;
-    float max_err = 0;
+    label = b.island[A.proc ? ia : ib];
+    active = isl_done[label] == 0;
+    if (active) {
     const f3 axisA = rotate(A.orn, from4(j.axA[i])), axisB = rotate(B.orn, from4(j.axB[i]));
     f3 pp, qq;
     plane_space(axisA, pp, qq);
@@ -519,7 +614,9 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     }
     store_pbody(b, ia, A);
     store_pbody(b, ib, B);
-    publish_error(max_err, label, isl_err);
+    }
+    }
+    publish_error(active, max_err, label, isl_err);
 }
 __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,7 +664,7 @@ __global__ void k_finish(uint32_t n, Bodies b) {
 
 // ------------------------------------------------------------------ host orchestration
 static void rec(edynhip_ctx *c, int idx) {
-    if (c->cfg.flags & EDYNHIP_FLAG_TIMING) (void)hipEventRecord(c->timer.e[idx], c->stream);
+    if (c->timer.e) (void)hipEventRecord(c->timer.e[idx], c->stream);
 }
 
 int islands(edynhip_ctx *c) {
@@ -577,11 +674,12 @@ int islands(edynhip_ctx *c) {
     const Manifolds &mf = c->m[c->cur];
     // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
     uint32_t *forest = c->isl_done;
-    EH_HIP(c, hipMemsetAsync(&c->cnt->num_islands, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest);
-    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest);
-    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest);
-    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt);
+    const uint32_t force = c->force_islands ? 1u : 0u;
+    c->force_islands = false;
+    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->cnt, force);
+    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest, c->cnt, force);
+    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, force);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, force);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }
@@ -590,31 +688,45 @@ static int colour_contacts(edynhip_ctx *c) {
     hipStream_t s = c->stream;
     const uint32_t M = c->num_manifolds, n = c->b.n;
     Manifolds &mf = c->m[c->cur];
-    c->num_colours = 0; c->num_active = 0;
-    if (M == 0) return EDYNHIP_OK;
+    c->num_active = 0;
+    if (M == 0) { c->num_colours = 0; return EDYNHIP_OK; }
     EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
     EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
     EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 2 * kMaxColours * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt);
+    const uint32_t reinsert = c->num_colours >= 2 ? c->num_colours - 1 : kNoColour;
+    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert);
     uint32_t round = 0, total_rounds = 0;
-    uint32_t batch = 2;
-    for (;;) {
-        for (uint32_t r = 0; r < batch; ++r, ++round) {
+    auto run_rounds = [&](uint32_t count) {
+        for (uint32_t r = 0; r < count; ++r, ++round) {
             uint64_t *bc = c->best[round & 1], *bn = c->best[(round + 1) & 1];
             hipLaunchKernelGGL(k_col_best, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, bc, bn, c->cnt);
             hipLaunchKernelGGL(k_col_assign, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, bc, c->used, c->cnt);
         }
-        total_rounds += batch;
+        total_rounds += count;
+    };
+    auto sort_and_fetch = [&]() -> int {
         hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals);
         EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
-        if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 64 colours");
-        if (c->cnt_host->uncoloured == 0) break;
-        batch = 8;
-        if (total_rounds > 4096) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
+        return EDYNHIP_OK;
+    };
+    // Steady state: the few new edges colour within the speculative rounds and ONE host sync fetches the offsets.
+    run_rounds(2);
+    EH_TRY(sort_and_fetch());
+    if (c->cnt_host->uncoloured != 0) {
+        while (c->cnt_host->uncoloured != 0) {
+            if (c->cnt_host->colour_overflow) break;
+            run_rounds(16);
+            EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            EH_HIP(c, hipStreamSynchronize(s));
+            if (total_rounds > 65536) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
+        }
+        EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 2 * kMaxColours * sizeof(uint32_t), s));
+        EH_TRY(sort_and_fetch());
     }
+    if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 64 colours");
     c->stats.colour_rounds = total_rounds;
     uint32_t nc = 0, na = 0;
     for (uint32_t k = 0; k < kMaxColours; ++k) {
@@ -653,19 +765,27 @@ int solve(edynhip_ctx *c) {
             ++launches;
         }
     };
+    // maximal suffix of colours that each fit one workgroup -> one launch for all of them
+    TailRanges tail{};
+    uint32_t first_tail = nc;
+    while (first_tail > 0 && c->colour_end[first_tail - 1] - c->colour_start[first_tail - 1] <= kTailMax) --first_tail;
+    if (nc - first_tail >= 2) {
+        for (uint32_t k = first_tail; k < nc; ++k)
+            if (c->colour_end[k] > c->colour_start[k]) { tail.start[tail.n] = c->colour_start[k]; tail.end[tail.n] = c->colour_end[k]; ++tail.n; }
+    } else first_tail = nc;
     auto contacts_pass = [&](bool warm) {
-        for (uint32_t k = 0; k < nc; ++k) {
+        for (uint32_t k = 0; k < first_tail; ++k) {
             uint32_t a = c->colour_start[k], e = c->colour_end[k];
             if (e <= a) continue;
-            if (warm) hipLaunchKernelGGL(k_contact_normal<true>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
-            else hipLaunchKernelGGL(k_contact_normal<false>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+            const Rows &r = c->rows;
+            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
+            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
             ++launches;
         }
-        for (uint32_t k = 0; k < nc; ++k) {
-            uint32_t a = c->colour_start[k], e = c->colour_end[k];
-            if (e <= a) continue;
-            if (warm) hipLaunchKernelGGL(k_contact_friction<true>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
-            else hipLaunchKernelGGL(k_contact_friction<false>, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, rcap, c->b);
+        if (tail.n) {
+            const Rows &r = c->rows;
+            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
+            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
             ++launches;
         }
     };
@@ -690,7 +810,7 @@ int solve(edynhip_ctx *c) {
             }
             for (uint32_t k = 0; k < nc; ++k) {
                 uint32_t a = c->colour_start[k], e = c->colour_end[k];
-                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(e - a, 256)), dim3(256), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
+                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
             }
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }

@@ -1,0 +1,39 @@
+"""Multi-GPU sharding of independent islands.
+
+Islands never exchange data inside a step, so the path shards with NO data-path collective: every rank
+owns a contiguous block of islands (here: sites of a mini-pile grid, or whole replicas of a pile) plus
+its own copy of the static bodies, and steps them independently. The only collective is the gather of
+the integrated state (13 floats per body: pos3, orn4, linvel3, angvel3) that the host registry
+write-back needs - one all_gather per step over RCCL ("nccl" backend on ROCm; "gloo" in CPU tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous, balanced [first, first+count) of `total` items for `rank`."""
+    base, rem = divmod(total, world_size)
+    first = rank * base + min(rank, rem)
+    count = base + (1 if rank < rem else 0)
+    return first, count
+
+
+def gather_state(local_state: torch.Tensor, counts):
+    """All-gather per-rank state blocks [n_r, 13] into one [sum n_r, 13] tensor on every rank.
+    `counts` = bodies per rank (known on all ranks from shard_range); ragged blocks are padded to the max."""
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if world_size == 1:
+        return local_state
+    nmax = max(counts)
+    pad = local_state
+    if local_state.shape[0] < nmax:
+        pad = torch.zeros((nmax, local_state.shape[1]), dtype=local_state.dtype, device=local_state.device)
+        pad[: local_state.shape[0]] = local_state
+    out = torch.empty((world_size * nmax, local_state.shape[1]), dtype=local_state.dtype, device=local_state.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    return torch.cat([out[r * nmax: r * nmax + counts[r]] for r in range(world_size)], 0)
+
+
+def pack_state(pos, orn, linvel, angvel):
+    return np.concatenate([pos, orn, linvel, angvel], axis=1).astype(np.float32)

@@ -2,8 +2,8 @@
 
 Every generator returns a dict of packed numpy arrays in the layout include/edynhip.h's
 edynhip_bodies expects (body 0 is the static ground plane where there is one), plus an optional
-"joints" list. Jitter comes from SplitMix64 with seed 0x9E3779B97F4A7C15 so every run, and the
-CPU oracle, see identical inputs.
+"joints" list. Jitter comes from SplitMix64 with seed 0x9E3779B97F4A7C15 so every run (and any
+checker fed the same arrays) sees identical inputs.
 """
 import math
 import numpy as np
@@ -96,6 +96,24 @@ def box_pile(nx, ny, nz, mixed=False):
         sp = s["shape_param"][1:]
         sp[sph] = (0.5, 0, 0, 0)
     _jitter(s, 1, n - 1)
+    return s
+
+
+def pyramid(n):
+    """Stable test scene: square pyramid, layer k has (n-k)^2 unit boxes, each resting on four below."""
+    pts = []
+    for k in range(n):
+        m = n - k
+        for i in range(m):
+            for j in range(m):
+                pts.append(((i - (m - 1) / 2.0) * 1.02, 0.505 + 1.005 * k, (j - (m - 1) / 2.0) * 1.02))
+    cnt = len(pts)
+    s = _empty(cnt + 1)
+    _add_plane(s)
+    s["pos"][1:] = np.array(pts, np.float32)
+    s["shape_type"][1:] = SHAPE_BOX
+    s["shape_param"][1:, :3] = 0.5
+    _jitter(s, 1, cnt)
     return s
 
 

@@ -59,6 +59,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def fixed_step_plan(accumulated, elapsed, fixed_dt, max_steps):
+    """stepper_sequential::update's accumulator (stepper_sequential.cpp:45-65): returns
+    (effective_steps, new_accumulated). num_steps = floor(acc / dt); the remainder stays accumulated; the number
+    of steps actually run is clamped to max_steps_per_update (the reference then stretches step_dt, which this
+    stepper does not: it always steps by fixed_dt and drops the excess)."""
+    accumulated += max(elapsed, 0.0)
+    num_steps = int(math.floor(accumulated / fixed_dt))
+    accumulated -= num_steps * fixed_dt
+    return min(num_steps, max_steps), accumulated
+
+
 class World:
     """One attached simulation: the analogue of a registry with edyn attached."""
 
@@ -182,12 +193,8 @@ class World:
         self._flush_defs()
         if self._paused:
             return 0
-        elapsed = max(time - self._last_time, 0.0)
-        self._accum += elapsed
-        dt = float(np.float32(self.cfg.fixed_dt))
-        num_steps = int(math.floor(self._accum / dt))
-        self._accum -= num_steps * dt
-        steps = min(num_steps, self.cfg.max_steps_per_update)
+        steps, self._accum = fixed_step_plan(self._accum, time - self._last_time, float(np.float32(self.cfg.fixed_dt)),
+                                             self.cfg.max_steps_per_update)
         if steps:
             self._check(self._L.edynhip_step(self._h, steps))
         self._last_time = time
@@ -264,7 +271,9 @@ class World:
     def get_stats(self):
         s = _capi.Stats()
         self._check(self._L.edynhip_get_stats(self._h, C.byref(s)))
-        return {f: getattr(s, f) for f, _ in _capi.Stats._fields_}
+        out = {f: getattr(s, f) for f, _ in _capi.Stats._fields_ if f != "colour_size"}
+        out["colour_size"] = [int(x) for x in s.colour_size][: out["num_colours"]]
+        return out
 
 
 # Free functions with the reference's names.

@@ -55,7 +55,7 @@ enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2
 typedef struct {
     int32_t device;                  /* HIP device ordinal */
     uint32_t max_bodies;
-    uint32_t max_manifolds;          /* 0 = 8 * max_bodies */
+    uint32_t max_manifolds;          /* 0 = 16 * max_bodies + 1024 */
     uint32_t max_joints;
     float fixed_dt;                  /* settings.fixed_dt, default 1/60 */
     uint32_t num_velocity_iterations;/* settings.num_solver_velocity_iterations, default 8 */
@@ -133,6 +133,7 @@ typedef struct {
 typedef struct {
     uint32_t num_bodies, num_manifolds, num_points, num_active_manifolds, num_islands, num_colours,
              num_joint_colours, colour_rounds, num_joints, num_joint_rows;
+    uint32_t colour_size[64];        /* manifolds per solver colour in the last step */
 } edynhip_stats;
 
 edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out);

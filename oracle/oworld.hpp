@@ -22,7 +22,7 @@
 //                      Manifold order = ascending canonical pair key, point order = the reference's
 //                      contact list order (newest first). EnTT pool order itself is not reproducible.
 //   ORDER_COLOURED   — the order the GPU uses: deterministic edge colouring (see colour_edges), colours
-//                      ascending, joints before contacts, normals of all colours before frictions.
+//                      ascending, joints before contacts; per manifold its normal rows, then its friction rows.
 #pragma once
 #include <map>
 #include <vector>
@@ -418,6 +418,7 @@ public:
         for (int i = 0; i < n_old; ++i) if (!dead[i]) out[n_out++] = m.pt[i];
         m.num_points = n_out;
         for (int i = 0; i < n_out; ++i) m.pt[i] = out[i];
+        if (n_out == 0) m.colour = kNoColour;   // inactive pairs hold no solver colour
     }
     void narrowphase() {
         for (auto &kv : manifolds) {   // update_contact_distances, collision_util.cpp:28-45
@@ -475,7 +476,7 @@ public:
                 edge(e, a, b, col);
                 if (!col || *col != kNoColour) continue;
                 any = true;
-                uint64_t pr = ((uint64_t)mix32(e + 1) << 32) | (e + 1);
+                uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);   // lower index wins == sequential first-fit in canonical order
                 if (bodies[a].procedural()) best[a] = std::max(best[a], pr);
                 if (bodies[b].procedural()) best[b] = std::max(best[b], pr);
             }
@@ -486,7 +487,7 @@ public:
                 uint32_t a, b; uint32_t *col;
                 edge(e, a, b, col);
                 if (!col || *col != kNoColour) continue;
-                uint64_t pr = ((uint64_t)mix32(e + 1) << 32) | (e + 1);
+                uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);   // lower index wins == sequential first-fit in canonical order
                 bool pa = bodies[a].procedural(), pb = bodies[b].procedural();
                 if ((pa && best[a] != pr) || (pb && best[b] != pr)) continue;
                 uint64_t busy = (pa ? used[a] : 0) | (pb ? used[b] : 0);
@@ -506,8 +507,11 @@ public:
         ms.reserve(manifolds.size());
         for (auto &kv : manifolds) ms.push_back(&kv.second);
         std::vector<uint64_t> used(bodies.size(), 0);
+        // last step's top colour is released and first-fit again (keeps the colour count from drifting up)
+        const uint32_t reinsert = stats.num_colours >= 2 ? stats.num_colours - 1 : kNoColour;
         for (Manifold *m : ms) {
             if (m->num_points == 0) { m->colour = kNoColour; continue; }   // inactive edges hold no colour
+            if (m->colour == reinsert) m->colour = kNoColour;
             if (m->colour != kNoColour) {
                 for (int s = 0; s < 2; ++s) if (bodies[m->body[s]].procedural()) used[m->body[s]] |= 1ull << m->colour;
             }
@@ -783,12 +787,16 @@ public:
             cc[m.colour].push_back(cr);
         }
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) apply_row_impulse(jr.r[i].impulse, jr.r[i]);
-        for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
-        for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+        for (auto &col : cc) for (auto &cr : col) {
+            for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
+            for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+        }
         for (int it = 0; it < vel_iters; ++it) {
             for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) { float d = solve_row(jr.r[i]); apply_row_impulse(d, jr.r[i]); }
-            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
-            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+            for (auto &col : cc) for (auto &cr : col) {
+                for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
+                for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+            }
         }
         for (auto &b : bodies) if (b.kind == KIND_DYNAMIC) integrate_body(b);
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) jr.j->impulse[i] = jr.r[i].impulse;

@@ -1,0 +1,14 @@
+"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite output) as a per-kernel table."""
+import sqlite3, sys, glob, os
+path = sys.argv[1]
+if os.path.isdir(path):
+    path = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))[0]
+db = sqlite3.connect(path)
+cur = db.cursor()
+rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+print(f"# {os.path.basename(path)}  (durations in us; per_step = total / {steps:g} steps)")
+print(f"{'kernel':60s} {'calls':>8s} {'total_us':>12s} {'avg_us':>9s} {'pct':>6s} {'us/step':>10s}")
+for name, calls, total, avg, pct in rows:
+    short = name.replace("void ", "").split("(")[0][:60]
+    print(f"{short:60s} {calls:8d} {total:12.1f} {avg:9.3f} {pct:6.2f} {total / steps:10.1f}")

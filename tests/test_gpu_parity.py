@@ -1,0 +1,267 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the committed golden fixtures.
+
+Bars (stated per check):
+  * broadphase pair sets: bit-exact every step (canonical sorted (hi,lo) keys);
+  * contact manifolds (body order, point count, list order, pivots, normals, impulses), island labels, colours:
+    bit-exact vs the oracle run in the same (coloured) row order;
+  * positions / orientations / velocities vs the oracle in the same order: bit-exact for shape scenes whose
+    angular speeds stay in integrate()'s Taylor branch; 1e-4 abs (pos, orn) / 2e-3 (velocities) after N steps for
+    scenes with fast rotation (chains, spheres), where device sinf/cosf differ from glibc by <= 2 ulp;
+  * vs the reference (sequential) order: physical invariants only (see test_oracle_physics.py).
+"""
+import os
+import numpy as np
+import pytest
+
+import edyn_amd
+from edyn_amd import scenes
+from edyn_amd._capi import STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POINT_FIELDS = ("pivotA", "pivotB", "normal", "local_normal", "distance", "friction", "attachment", "lifetime",
+                "normal_impulse", "friction_impulse")
+
+
+def gpu_world(scene, vel=10, pos=3, **kw):
+    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=vel, num_solver_position_iterations=pos, **kw))
+    w.set_scene(scene)
+    return w
+
+
+def oracle_world(scene, vel=10, pos=3, order=ob.ORDER_COLOURED):
+    o = ob.World(vel_iters=vel, pos_iters=pos, order=order)
+    o.add_bodies(scene)
+    return o
+
+
+def assert_manifolds_equal(g, o, tol=0.0, what=""):
+    assert len(g) == len(o), what
+    for f in ("body", "num_points", "colour"):
+        assert np.array_equal(g[f], o[f]), (what, f)
+    for k in range(4):
+        sel = g["num_points"] > k
+        for f in POINT_FIELDS:
+            a, b = g["pt"][f][sel, k], o["pt"][f][sel, k]
+            if tol == 0.0 or a.dtype.kind in "iu":
+                assert np.array_equal(a, b), (what, k, f)
+            else:
+                assert np.allclose(a, b, rtol=0, atol=tol), (what, k, f, float(np.abs(a - b).max()))
+
+
+def shaped(scene):
+    return scene["shape_type"] != scenes.SHAPE_NONE
+
+
+# ------------------------------------------------------------------ stage-by-stage parity
+@pytest.mark.parametrize("name,gen,steps", [
+    ("pile4", lambda: scenes.box_pile(4, 4, 4), 12),
+    ("pyramid4", lambda: scenes.pyramid(4), 12),
+    ("mixed5", lambda: scenes.box_pile(5, 5, 5, mixed=True), 16),
+    ("columns", lambda: scenes.c1_columns(), 4),
+])
+def test_every_stage_bit_exact_vs_oracle(name, gen, steps):
+    scene = gen()
+    w, o = gpu_world(scene), oracle_world(scene)
+    for s in range(steps):
+        w.run_stages(STAGE_BROADPHASE); o.run_stage(0)
+        assert np.array_equal(w.get_pairs(), o.get_pairs()), f"{name} step {s}: broadphase pair set"
+        w.run_stages(STAGE_NARROWPHASE); o.run_stage(1)
+        assert_manifolds_equal(w.get_manifolds(), o.get_manifolds(), what=f"{name} step {s} narrowphase")
+        w.run_stages(STAGE_ISLANDS); o.run_stage(2)
+        assert np.array_equal(w.get_derived()[2], o.get_derived()[2]), f"{name} step {s}: island labels"
+        w.run_stages(STAGE_SOLVE); o.run_stage(3)
+        assert_manifolds_equal(w.get_manifolds(), o.get_manifolds(), what=f"{name} step {s} solve")
+        for a, b, f in zip(w.get_state(), o.get_state(), ("pos", "orn", "linvel", "angvel")):
+            assert np.array_equal(a, b), f"{name} step {s}: {f}"
+        ga, oa = w.get_derived(), o.get_derived()
+        sh = shaped(scene)
+        assert np.array_equal(ga[0][sh], oa[0][sh]) and np.array_equal(ga[1], oa[1]), f"{name} step {s}: aabb / inertia"
+    assert w.get_stats()["num_islands"] == o.get_stats()["num_islands"]
+    assert w.get_stats()["num_colours"] == o.get_stats()["num_colours"]
+
+
+def test_single_stage_from_injected_oracle_state():
+    """Feed the oracle's state + manifolds into the GPU and run ONE stage: isolates each kernel family."""
+    scene = scenes.box_pile(5, 5, 5)
+    o = oracle_world(scene)
+    o.step(20)
+    w = gpu_world(scene)
+    w.step_simulation(1)                      # allocate / warm
+    w.set_state(*o.get_state())
+    w.set_manifolds(o.get_manifolds())
+    # derived state (aabb, world inertia) is rebuilt by one solve-less pass: re-run finish via a zero-work trick is not
+    # exposed, so compare stages that read only transforms + manifolds:
+    o2 = oracle_world(scene); o2.set_state(*o.get_state()); o2.set_manifolds(o.get_manifolds())
+    # narrowphase reads AABBs: bring both sides' derived state to the same point by one full identical step first
+    w.step_simulation(1); o.step(1)
+    assert_manifolds_equal(w.get_manifolds(), o.get_manifolds(), tol=1e-5, what="after injected step")
+
+
+# ------------------------------------------------------------------ N-step trajectories
+def test_trajectory_pile_60_steps():
+    scene = scenes.box_pile(6, 6, 6)
+    w, o = gpu_world(scene), oracle_world(scene)
+    w.step_simulation(60); o.step(60)
+    assert np.array_equal(w.get_pairs(), o.get_pairs())
+    for a, b, tol in zip(w.get_state(), o.get_state(), (1e-4, 1e-4, 1e-3, 1e-3)):
+        assert np.abs(a - b).max() <= tol
+
+
+def test_trajectory_chains_tolerance():
+    scene = scenes.c5_chains(8, 8)
+    w, o = gpu_world(scene), oracle_world(scene)
+    w.step_simulation(40); o.step(40)
+    gp, gq, gv, gw = w.get_state(); op, oq, ov, ow = o.get_state()
+    assert np.abs(gp - op).max() <= 1e-4                      # positions, metres
+    assert (1 - np.abs((gq * oq).sum(1))).max() <= 1e-4       # orientations, 1 - |q.q'|
+    assert np.abs(gv - ov).max() <= 2e-3 and np.abs(gw - ow).max() <= 2e-3
+    assert np.abs(w.get_joint_impulses() - o.get_joint_impulses()).max() <= 1e-3
+
+
+# ------------------------------------------------------------------ committed golden fixtures (no oracle at run time)
+@pytest.mark.parametrize("name,gen", [
+    ("pile4", lambda: scenes.box_pile(4, 4, 4)),
+    ("mixed5", lambda: scenes.box_pile(5, 5, 5, mixed=True)),
+    ("pyramid5", lambda: scenes.pyramid(5)),
+    ("chains", lambda: scenes.c5_chains(4, 6)),
+])
+def test_golden_fixture(name, gen):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    scene = gen()
+    w = gpu_world(scene, vel=int(g["vel_iters"]))
+    counts, xors = [], []
+    for _ in range(int(g["steps"])):
+        w.step_simulation(1)
+        p = w.get_pairs()
+        counts.append(len(p)); xors.append(np.bitwise_xor.reduce(p) if len(p) else np.uint64(0))
+    assert np.array_equal(np.array(counts), g["pair_counts"]) and np.array_equal(np.array(xors, np.uint64), g["pairs_xor"])
+    assert np.array_equal(w.get_pairs(), g["pairs_last"])
+    pos, orn, lv, av = w.get_state()
+    tol = 1e-4 if name in ("chains", "mixed5") else 0.0
+    for a, key, t in ((pos, "pos", tol), (orn, "orn", tol), (lv, "linvel", 20 * tol), (av, "angvel", 20 * tol)):
+        assert np.abs(a - g[key]).max() <= t, (name, key, float(np.abs(a - g[key]).max()))
+    assert np.array_equal(w.get_derived()[2], g["island"])
+    assert_manifolds_equal(w.get_manifolds(), g["manifolds"], tol=tol * 10, what=name)
+
+
+def test_golden_columns_fixture():
+    g = np.load(os.path.join(GOLDEN, "columns.npz"))
+    s = scenes._empty(46)
+    scenes._add_plane(s)
+    pos, _ = scenes._lattice(3, 5, 3, pitch_h=1.05, pitch_v=1.05, y0=0.55, brick=False)
+    s["pos"][1:] = pos; s["shape_type"][1:] = scenes.SHAPE_BOX; s["shape_param"][1:, :3] = 0.5
+    scenes._jitter(s, 1, 45)
+    w = gpu_world(s, vel=int(g["vel_iters"]))
+    w.step_simulation(int(g["steps"]))
+    assert np.array_equal(w.get_pairs(), g["pairs_last"])
+    assert np.array_equal(w.get_state()[0], g["pos"]) and np.array_equal(w.get_derived()[2], g["island"])
+    assert w.get_stats()["num_islands"] == 9
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_single_body_worlds():
+    s = scenes._empty(1)
+    s["inertia"][0] = np.eye(3).reshape(9); s["has_inertia"][0] = 1
+    w = gpu_world(s)
+    w.step_simulation(10)
+    pos, _, v, _ = w.get_state()
+    dt = np.float32(1 / 60); vy = np.float32(0); y = np.float32(0)
+    for _ in range(10):
+        vy = vy + np.float32(-9.8) * dt; y = y + vy * dt
+    assert pos[0, 1] == y and v[0, 1] == vy            # free fall, bit-exact semi-implicit Euler
+    assert len(w.get_pairs()) == 0 and w.get_stats()["num_points"] == 0
+    only_plane = scenes._empty(1); scenes._add_plane(only_plane)
+    w2 = gpu_world(only_plane)
+    w2.step_simulation(3)
+    assert np.array_equal(w2.get_state()[0], np.zeros((1, 3), np.float32))
+
+
+def test_collision_filter_and_sensor_free_pairs():
+    s = scenes._empty(4)
+    scenes._add_plane(s)
+    for i, x in enumerate((0.0, 0.9, 1.8)):
+        s["pos"][1 + i] = (x, 0.5, 0); s["shape_type"][1 + i] = scenes.SHAPE_BOX; s["shape_param"][1 + i, :3] = 0.5
+    ALL = 2**64 - 1
+    s["group"][1] = 0x1; s["mask"][1] = ALL & ~0x2      # test_broadphase.cpp:4-34 truth table
+    s["group"][2] = 0x2; s["mask"][2] = ALL & ~0x1
+    w, o = gpu_world(s), oracle_world(s)
+    w.step_simulation(2); o.step(2)
+    keys = w.get_pairs()
+    assert np.array_equal(keys, o.get_pairs())
+    pairs = {(int(k >> np.uint64(32)), int(k & np.uint64(0xFFFFFFFF))) for k in keys}
+    assert (2, 1) not in pairs and (3, 2) in pairs and (1, 0) in pairs
+
+
+def test_ragged_scene_mixed_kinds():
+    """Amorphous bodies, a kinematic body and spheres in one world; ragged manifold point counts."""
+    s = scenes.box_pile(3, 3, 3, mixed=True)
+    n = len(s["kind"])
+    extra = scenes._empty(n + 2)
+    for k in s:
+        if k != "joints":
+            extra[k][:n] = s[k]
+    extra["kind"][n] = scenes.KIND_KINEMATIC; extra["pos"][n] = (0, 5, 0); extra["shape_type"][n] = scenes.SHAPE_BOX
+    extra["shape_param"][n, :3] = 0.5; extra["linvel"][n] = (0, -0.5, 0)
+    extra["pos"][n + 1] = (9, 9, 9); extra["inertia"][n + 1] = np.eye(3).reshape(9); extra["has_inertia"][n + 1] = 1
+    w, o = gpu_world(extra), oracle_world(extra)
+    w.step_simulation(15); o.step(15)
+    assert np.array_equal(w.get_pairs(), o.get_pairs())
+    for a, b in zip(w.get_state(), o.get_state()):
+        assert np.abs(a - b).max() <= 1e-4
+    assert set(np.unique(w.get_manifolds()["num_points"])) >= {0, 1}
+
+
+def test_capacity_overflow_is_an_error_not_ub():
+    s = scenes.box_pile(4, 4, 4)
+    w = edyn_amd.World(edyn_amd.init_config(max_manifolds=16))
+    w.set_scene(s)
+    with pytest.raises(edyn_amd.EdynHipError) as ei:
+        w.step_simulation(1)
+    assert ei.value.code == -4
+
+
+def test_restitution_is_rejected():
+    s = scenes.box_pile(2, 2, 2)
+    s["restitution"][1] = 0.5
+    w = edyn_amd.World()
+    with pytest.raises(edyn_amd.EdynHipError) as ei:
+        w.set_scene(s)
+    assert ei.value.code == -6
+
+
+def test_update_accumulator_runs_fixed_steps():
+    s = scenes.box_pile(2, 2, 2)
+    w = gpu_world(s)
+    assert w.update(0.051) == 3         # floor(0.051 / float32(1/60))
+    assert w.update(0.051 + 1 / 60) == 1
+    assert w.update(10.0) == 10         # max_steps_per_update clamp
+    w.set_paused(True)
+    assert w.update(20.0) == 0
+
+
+# ------------------------------------------------------------------ properties at the benchmark's full size
+def test_headline_scene_properties_and_determinism():
+    scene = scenes.box_pile(32, 32, 32)
+    runs = []
+    for _ in range(2):
+        w = gpu_world(scene)
+        w.step_simulation(40)
+        pos, orn, lv, av = w.get_state()
+        runs.append((pos, orn, w.get_pairs()))
+        st = w.get_stats()
+        assert np.isfinite(pos).all() and np.isfinite(lv).all()
+        assert np.abs(np.linalg.norm(orn, axis=1) - 1).max() < 1e-5          # unit quaternions
+        assert st["num_islands"] == 1 and st["num_colours"] <= 16 and st["num_points"] > 400000
+        keys = w.get_pairs()
+        assert (np.diff(keys.astype(np.uint64)) > 0).all()                    # sorted, unique canonical pairs
+        m = w.get_manifolds()
+        d = m["pt"]["distance"]
+        pen = min(float(d[m["num_points"] > k, k].min()) for k in range(4))
+        assert pen > -0.03                                                    # penetration bounded
+        assert pos[1:, 1].min() > 0.45                                        # nothing sinks through the plane
+        ni = m["pt"]["normal_impulse"]
+        assert all((ni[m["num_points"] > k, k] >= 0).all() for k in range(4))  # contacts only push
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])   # bit-reproducible
+    assert np.array_equal(runs[0][2], runs[1][2])
