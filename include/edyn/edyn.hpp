@@ -1,0 +1,343 @@
+// edyn.hpp — drop-in C++ shim that keeps Edyn's registry-facing stepping API on top of the MI355X C-ABI.
+//
+// Same names, argument meaning and ownership as the reference:
+//   edyn::init_config, attach, detach, update, step_simulation, set_paused, is_paused, get/set_fixed_dt,
+//   set_max_steps_per_update, get/set_solver_*_iterations, get/set_gravity            include/edyn/edyn.hpp:39-186,
+//                                                                                      config/solver_iteration_config.hpp:13-66, util/gravity_util.hpp:15-23
+//   edyn::rigidbody_def, rigidbody_kind, make_rigidbody                                include/edyn/util/rigidbody.hpp:22-93
+//   edyn::make_constraint<point_constraint|hinge_constraint>(registry, body0, body1, setup)   include/edyn/util/constraint_util.hpp:38-54
+//   components: position, orientation, linvel, angvel, mass, mass_inv, inertia, material, box_shape, sphere_shape,
+//               plane_shape, AABB, dynamic_tag / kinematic_tag / static_tag, rigidbody_tag, contact_manifold (read-only view)
+//
+// Semantics: the registry stays caller-owned; like the reference's sequential stepper, all mutation happens inside
+// update()/step_simulation() on the calling thread. Bodies and constraints created since the last step are uploaded
+// at the next step; after a step position/orientation/linvel/angvel of every rigid body are written back. Direct
+// writes by the user to those four components are picked up after edyn::refresh(registry) (full re-upload of the
+// state) — the analogue of registry.patch in the reference's asynchronous mode. Contact manifolds are materialised
+// lazily by edyn::get_contact_manifolds(registry). Uses the real EnTT when <entt/entt.hpp> is available, otherwise the
+// bundled minimal registry (include/edyn/detail/mini_entt.hpp).
+#pragma once
+#if __has_include(<entt/entt.hpp>)
+#include <entt/entt.hpp>
+#else
+#include "detail/mini_entt.hpp"
+#endif
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+#include "../edynhip.h"
+
+namespace edyn {
+
+using scalar = float;
+struct vector3 { scalar x{}, y{}, z{}; };
+struct quaternion { scalar x{}, y{}, z{}, w{1}; };
+struct matrix3x3 { std::array<vector3, 3> row{}; };
+inline constexpr vector3 vector3_zero{0, 0, 0};
+inline constexpr vector3 gravity_earth{0, scalar(-9.8), 0};   // math/constants.hpp:24
+inline constexpr quaternion quaternion_identity{0, 0, 0, 1};
+
+// components (comp/*.hpp) — thin wrappers, as in the reference
+struct position : vector3 {};
+struct orientation : quaternion {};
+struct linvel : vector3 {};
+struct angvel : vector3 {};
+struct mass { scalar s; };
+struct mass_inv { scalar s; };
+struct inertia : matrix3x3 {};
+struct gravity : vector3 {};
+struct material { scalar restitution{0}, friction{scalar(0.5)}; };   // comp/material.hpp:15-22 (hot-path fields)
+struct AABB { vector3 min, max; };
+struct dynamic_tag {};
+struct kinematic_tag {};
+struct static_tag {};
+struct procedural_tag {};
+struct rigidbody_tag {};
+struct collision_filter { uint64_t group{~0ull}, mask{~0ull}; };
+
+struct box_shape { vector3 half_extents; };
+struct sphere_shape { scalar radius; };
+struct plane_shape { vector3 normal; scalar constant; };
+using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape>;
+
+enum class rigidbody_kind : uint8_t { rb_dynamic, rb_kinematic, rb_static };   // util/rigidbody.hpp:22-27
+
+struct rigidbody_def {   // util/rigidbody.hpp:29-81 (hot-path fields)
+    rigidbody_kind kind{rigidbody_kind::rb_dynamic};
+    vector3 position{vector3_zero};
+    quaternion orientation{quaternion_identity};
+    scalar mass{1};
+    std::optional<matrix3x3> inertia;
+    vector3 linvel{vector3_zero};
+    vector3 angvel{vector3_zero};
+    std::optional<vector3> gravity;
+    std::optional<shapes_variant_t> shape;
+    std::optional<edyn::material> material{edyn::material{}};
+    uint64_t collision_group{~0ull};
+    uint64_t collision_mask{~0ull};
+};
+
+struct constraint_base { std::array<entt::entity, 2> body; };
+struct point_constraint : constraint_base { std::array<vector3, 2> pivot; };                 // constraints/point_constraint.hpp:21-34
+struct hinge_constraint : constraint_base {                                                   // constraints/hinge_constraint.hpp:22-93
+    std::array<vector3, 2> pivot;
+    std::array<vector3, 2> axis{vector3{1, 0, 0}, vector3{1, 0, 0}};
+    void set_axes(const vector3 &axisA, const vector3 &axisB) { axis = {axisA, axisB}; }
+};
+struct contact_manifold { std::array<entt::entity, 2> body; unsigned num_points; };           // collision/contact_manifold.hpp:14-22
+
+enum class execution_mode : uint8_t { sequential, sequential_multithreaded, asynchronous };
+struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
+    edyn::execution_mode execution_mode{execution_mode::sequential};   // every mode maps to the synchronous GPU stepper
+    scalar fixed_dt{scalar(1.0 / 60)};
+    unsigned num_solver_velocity_iterations{8};
+    unsigned num_solver_position_iterations{3};
+    unsigned max_steps_per_update{10};
+    vector3 gravity{gravity_earth};
+    int device{0};
+    unsigned max_bodies{0};      // 0 = sized at the first upload (count + 25 % head-room)
+    unsigned max_manifolds{0};
+};
+
+class stepper_error : public std::runtime_error {
+public:
+    stepper_error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    int code;
+};
+
+namespace detail {
+// The analogue of stepper_sequential in registry.ctx() (edyn.cpp:117-123).
+struct gpu_stepper {
+    init_config cfg;
+    edynhip_ctx *ctx{nullptr};
+    std::vector<entt::entity> bodies;          // body index -> entity (creation order)
+    std::vector<entt::entity> constraints;
+    bool scene_dirty{true}, state_dirty{false}, paused{false};
+    double accumulated{0}, last_time{0};
+    unsigned capacity{0};
+    ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
+};
+struct body_index { uint32_t value; };
+
+inline void check(gpu_stepper &s, int rc) {
+    if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + edynhip_last_error(s.ctx));
+}
+
+inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
+    const uint32_t n = (uint32_t)s.bodies.size();
+    if (!s.ctx || n > s.capacity) {
+        if (s.ctx) { edynhip_destroy(s.ctx); s.ctx = nullptr; }
+        edynhip_config c{};
+        c.device = s.cfg.device;
+        c.max_bodies = s.cfg.max_bodies ? s.cfg.max_bodies : n + n / 4 + 16;
+        c.max_manifolds = s.cfg.max_manifolds;
+        c.max_joints = (uint32_t)s.constraints.size() + 16;
+        c.fixed_dt = s.cfg.fixed_dt;
+        c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
+        c.num_position_iterations = s.cfg.num_solver_position_iterations;
+        c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
+        int st = 0;
+        s.ctx = edynhip_create(&c, &st);
+        if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
+        s.capacity = c.max_bodies;
+    }
+    std::vector<int32_t> kind(n), stype(n);
+    std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
+    std::vector<uint8_t> hasI(n, 0);
+    std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[i];
+        kind[i] = registry.all_of<dynamic_tag>(e) ? EDYNHIP_KIND_DYNAMIC : registry.all_of<kinematic_tag>(e) ? EDYNHIP_KIND_KINEMATIC : EDYNHIP_KIND_STATIC;
+        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+        orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
+        if (auto *v = registry.try_get<linvel>(e)) { lv[3 * i] = v->x; lv[3 * i + 1] = v->y; lv[3 * i + 2] = v->z; }
+        if (auto *w = registry.try_get<angvel>(e)) { av[3 * i] = w->x; av[3 * i + 1] = w->y; av[3 * i + 2] = w->z; }
+        if (auto *ms = registry.try_get<mass>(e)) m[i] = ms->s;
+        if (auto *in = registry.try_get<inertia>(e)) {
+            hasI[i] = 1;
+            for (int r = 0; r < 3; ++r) { I[9 * i + 3 * r] = in->row[r].x; I[9 * i + 3 * r + 1] = in->row[r].y; I[9 * i + 3 * r + 2] = in->row[r].z; }
+        }
+        if (auto *b = registry.try_get<box_shape>(e)) { stype[i] = EDYNHIP_SHAPE_BOX; sp[4 * i] = b->half_extents.x; sp[4 * i + 1] = b->half_extents.y; sp[4 * i + 2] = b->half_extents.z; }
+        else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
+        else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
+        else stype[i] = EDYNHIP_SHAPE_NONE;
+        if (auto *mt = registry.try_get<material>(e)) { fr[i] = mt->friction; re[i] = mt->restitution; }
+        if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
+        if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
+    }
+    edynhip_bodies b{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
+                     fr.data(), re.data(), grp.data(), msk.data(), g.data()};
+    check(s, edynhip_set_bodies(s.ctx, n, &b));
+    const uint32_t nj = (uint32_t)s.constraints.size();
+    std::vector<int32_t> jt(nj); std::vector<uint32_t> jb(2 * nj); std::vector<float> jp(6 * nj), ja(6 * nj, 0.f);
+    for (uint32_t j = 0; j < nj; ++j) {
+        const entt::entity e = s.constraints[j];
+        auto fill = [&](const constraint_base &cb, const std::array<vector3, 2> &pv) {
+            for (int k = 0; k < 2; ++k) {
+                jb[2 * j + k] = registry.get<body_index>(cb.body[k]).value;
+                jp[6 * j + 3 * k] = pv[k].x; jp[6 * j + 3 * k + 1] = pv[k].y; jp[6 * j + 3 * k + 2] = pv[k].z;
+            }
+        };
+        if (auto *pc = registry.try_get<point_constraint>(e)) { jt[j] = EDYNHIP_JOINT_POINT; fill(*pc, pc->pivot); }
+        else {
+            auto &hc = registry.get<hinge_constraint>(e);
+            jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
+            for (int k = 0; k < 2; ++k) { ja[6 * j + 3 * k] = hc.axis[k].x; ja[6 * j + 3 * k + 1] = hc.axis[k].y; ja[6 * j + 3 * k + 2] = hc.axis[k].z; }
+        }
+    }
+    edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data()};
+    check(s, edynhip_set_joints(s.ctx, nj, nj ? &js : nullptr));
+    s.scene_dirty = false; s.state_dirty = false;
+}
+
+inline void upload_state(entt::registry &registry, gpu_stepper &s) {
+    const uint32_t n = (uint32_t)s.bodies.size();
+    std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n, 0.f), av(3 * n, 0.f);
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[i];
+        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+        orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
+        if (auto *v = registry.try_get<linvel>(e)) { lv[3 * i] = v->x; lv[3 * i + 1] = v->y; lv[3 * i + 2] = v->z; }
+        if (auto *w = registry.try_get<angvel>(e)) { av[3 * i] = w->x; av[3 * i + 1] = w->y; av[3 * i + 2] = w->z; }
+    }
+    check(s, edynhip_set_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
+    s.state_dirty = false;
+}
+
+inline void write_back(entt::registry &registry, gpu_stepper &s) {
+    const uint32_t n = (uint32_t)s.bodies.size();
+    std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n);
+    check(s, edynhip_get_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[i];
+        if (!registry.all_of<dynamic_tag>(e)) continue;
+        auto &p = registry.get<position>(e); p.x = pos[3 * i]; p.y = pos[3 * i + 1]; p.z = pos[3 * i + 2];
+        auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
+        auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
+        auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
+    }
+}
+
+inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps) {
+    if (s.scene_dirty) upload_scene(registry, s);
+    else if (s.state_dirty) upload_state(registry, s);
+    if (steps == 0 || s.bodies.empty()) return;
+    check(s, edynhip_step(s.ctx, steps));
+    write_back(registry, s);
+}
+}  // namespace detail
+
+// ---- edyn.hpp:66-150
+inline void attach(entt::registry &registry, const init_config &config = {}) {
+    auto &s = registry.ctx().emplace<detail::gpu_stepper>();
+    s.cfg = config;
+}
+inline void detach(entt::registry &registry) { registry.ctx().erase<detail::gpu_stepper>(); }
+inline scalar get_fixed_dt(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.fixed_dt; }
+inline void set_fixed_dt(entt::registry &registry, scalar dt) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.fixed_dt = dt; s.scene_dirty = true; s.capacity = 0; }
+inline void set_max_steps_per_update(entt::registry &registry, unsigned n) { registry.ctx().get<detail::gpu_stepper>().cfg.max_steps_per_update = n; }
+inline bool is_paused(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().paused; }
+inline void set_paused(entt::registry &registry, bool paused) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.paused = paused; s.accumulated = 0; }
+inline vector3 get_gravity(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.gravity; }
+inline void set_gravity(entt::registry &registry, vector3 g) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.gravity = g; s.scene_dirty = true; s.capacity = 0; }
+inline unsigned get_solver_velocity_iterations(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.num_solver_velocity_iterations; }
+inline void set_solver_velocity_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_velocity_iterations = n; s.scene_dirty = true; s.capacity = 0; }
+inline unsigned get_solver_position_iterations(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.num_solver_position_iterations; }
+inline void set_solver_position_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_position_iterations = n; s.scene_dirty = true; s.capacity = 0; }
+/// Tell the stepper that position/orientation/linvel/angvel were edited by the user (registry.patch analogue).
+inline void refresh(entt::registry &registry) { registry.ctx().get<detail::gpu_stepper>().state_dirty = true; }
+
+/// stepper_sequential::update (stepper_sequential.cpp:28-119): fixed-dt accumulator, clamped to max_steps_per_update.
+inline void update(entt::registry &registry, double time) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    if (s.paused) { detail::run_steps(registry, s, 0); return; }
+    const double elapsed = std::max(time - s.last_time, 0.0);
+    s.accumulated += elapsed;
+    const double dt = s.cfg.fixed_dt;
+    const auto num_steps = static_cast<uint64_t>(std::floor(s.accumulated / dt));
+    s.accumulated -= static_cast<double>(num_steps) * dt;
+    const unsigned steps = (unsigned)std::min<uint64_t>(num_steps, s.cfg.max_steps_per_update);
+    detail::run_steps(registry, s, steps);
+    s.last_time = time;
+}
+/// stepper_sequential::step_simulation (stepper_sequential.cpp:121-147): exactly one step; requires paused.
+inline void step_simulation(entt::registry &registry, double time = 0) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    s.last_time = time;
+    detail::run_steps(registry, s, 1);
+}
+
+// ---- util/rigidbody.hpp:84-93, rigidbody.cpp:47-191
+inline void make_rigidbody(entt::entity entity, entt::registry &registry, const rigidbody_def &def) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    registry.emplace<position>(entity, position{def.position});
+    registry.emplace<orientation>(entity, orientation{def.orientation});
+    if (def.kind == rigidbody_kind::rb_dynamic) {
+        registry.emplace<mass>(entity, mass{def.mass});
+        registry.emplace<mass_inv>(entity, mass_inv{scalar(1) / def.mass});
+        if (def.inertia) registry.emplace<inertia>(entity, inertia{*def.inertia});
+    }
+    if (def.kind != rigidbody_kind::rb_static) {
+        registry.emplace<linvel>(entity, linvel{def.linvel});
+        registry.emplace<angvel>(entity, angvel{def.angvel});
+    }
+    const vector3 g = def.gravity ? *def.gravity : s.cfg.gravity;
+    if (def.kind == rigidbody_kind::rb_dynamic) registry.emplace<gravity>(entity, gravity{g});
+    if (def.material) registry.emplace<material>(entity, *def.material);
+    if (def.shape) {
+        std::visit([&](auto &&sh) { registry.emplace<std::decay_t<decltype(sh)>>(entity, sh); }, *def.shape);
+        if (def.collision_group != ~0ull || def.collision_mask != ~0ull) registry.emplace<collision_filter>(entity, collision_filter{def.collision_group, def.collision_mask});
+    }
+    switch (def.kind) {
+    case rigidbody_kind::rb_dynamic: registry.emplace<dynamic_tag>(entity); registry.emplace<procedural_tag>(entity); break;
+    case rigidbody_kind::rb_kinematic: registry.emplace<kinematic_tag>(entity); break;
+    case rigidbody_kind::rb_static: registry.emplace<static_tag>(entity); break;
+    }
+    registry.emplace<detail::body_index>(entity, detail::body_index{(uint32_t)s.bodies.size()});
+    s.bodies.push_back(entity);
+    s.scene_dirty = true;
+    registry.emplace<rigidbody_tag>(entity);
+}
+inline entt::entity make_rigidbody(entt::registry &registry, const rigidbody_def &def) {
+    auto e = registry.create();
+    make_rigidbody(e, registry, def);
+    return e;
+}
+
+// ---- util/constraint_util.hpp:38-54
+template <typename T, typename SetupFunc>
+entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt::entity body1, SetupFunc setup) {
+    static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint>,
+                  "only point_constraint and hinge_constraint are on the accelerated path");
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    auto e = registry.create();
+    auto &con = registry.emplace<T>(e);
+    con.body = {body0, body1};
+    setup(con);
+    s.constraints.push_back(e);
+    s.scene_dirty = true;
+    return e;
+}
+
+/// Current contact manifolds (body pair + point count), materialised on demand.
+inline std::vector<contact_manifold> get_contact_manifolds(entt::registry &registry) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    std::vector<contact_manifold> out;
+    if (!s.ctx) return out;
+    uint32_t n = 0;
+    detail::check(s, edynhip_num_manifolds(s.ctx, &n));
+    std::vector<edynhip_manifold> recs(n);
+    if (n) detail::check(s, edynhip_get_manifolds(s.ctx, recs.data(), n, &n));
+    out.reserve(n);
+    for (auto &r : recs) out.push_back({{s.bodies[r.body[0]], s.bodies[r.body[1]]}, r.num_points});
+    return out;
+}
+
+}  // namespace edyn
