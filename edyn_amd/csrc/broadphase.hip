@@ -27,7 +27,7 @@ __global__ void k_step_reset(Counters *cnt) {
     int t = threadIdx.x;
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0;
+        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0;
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
     if (t < (int)kMaxColours) { cnt->colour_start[t] = 0; cnt->colour_end[t] = 0; }
@@ -131,13 +131,14 @@ __global__ void k_bp_build(const uint64_t *__restrict__ keys, int n, uint32_t *p
 // agent-scope atomics on both sides (per-CU L1s and per-XCD L2s are not coherent for plain accesses).
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 DI unsigned long long pack2(float a, float b) { return ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a); }
-DI void store_box(float4 *nmin, float4 *nmax, uint32_t node, f3 mn, f3 mx) {
+// node record: nmin = (min.xyz, bits(left child)), nmax = (max.xyz, bits(right child)); leaves carry 0xFFFFFFFF
+DI void store_box(float4 *nmin, float4 *nmax, uint32_t node, f3 mn, f3 mx, uint32_t lc, uint32_t rc) {
     unsigned long long *p0 = (unsigned long long *)&nmin[node];
     unsigned long long *p1 = (unsigned long long *)&nmax[node];
     __hip_atomic_store(p0, pack2(mn.x, mn.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p0 + 1, pack2(mn.z, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p0 + 1, pack2(mn.z, __uint_as_float(lc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p1, pack2(mx.x, mx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p1 + 1, pack2(mx.z, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p1 + 1, pack2(mx.z, __uint_as_float(rc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 DI void load_box(const float4 *nmin, const float4 *nmax, uint32_t node, f3 &mn, f3 &mx) {
     unsigned long long *p0 = (unsigned long long *)&nmin[node];
@@ -159,7 +160,7 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
     uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
     f3 mn = from4(amin[body]), mx = from4(amax[body]);
     uint32_t node = (uint32_t)(n - 1 + k);
-    store_box(nmin, nmax, node, mn, mx);
+    store_box(nmin, nmax, node, mn, mx, 0xFFFFFFFFu, 0xFFFFFFFFu);
     if (n == 1) return;
     uint32_t p = parent[node];
     while (p != 0xFFFFFFFFu) {
@@ -171,7 +172,7 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
         load_box(nmin, nmax, sib, smn, smx);
         mn = {fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z)};
         mx = {fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z)};
-        store_box(nmin, nmax, p, mn, mx);
+        store_box(nmin, nmax, p, mn, mx, left[p], right[p]);
         node = p;
         p = parent[p];
     }
@@ -250,14 +251,15 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict_
             stk[sp++][tx] = 0;
             while (sp > 0) {
                 uint32_t node = stk[--sp][tx];
-                box3 nb{from4(nmin[node]), from4(nmax[node])};
+                const float4 lo4 = nmin[node], hi4 = nmax[node];
+                box3 nb{from4(lo4), from4(hi4)};
                 if (!intersect(nb, q)) continue;
                 if (node >= (uint32_t)(n - 1)) {
                     uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
                     if (j < i) consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);
                 } else if (sp <= 46) {
-                    stk[sp++][tx] = left[node];
-                    stk[sp++][tx] = right[node];
+                    stk[sp++][tx] = __float_as_uint(lo4.w);
+                    stk[sp++][tx] = __float_as_uint(hi4.w);
                 } else {
                     cnt->pair_overflow = 2;   // traversal stack exhausted: reported as an error, never silently dropped
                 }
@@ -282,9 +284,10 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict_
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
 __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
-                                     Counters *cnt) {
+                                     Counters *cnt, uint2 *new_edges) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    uint32_t found = 0;
+    if (m < M) {
     if (m == 0 && M != pm) cnt->pairs_changed = 1;
     const uint64_t sk = skeys[m];
     const uint64_t key = sk >> 1;
@@ -301,8 +304,12 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     }
     uint32_t p = find_prev(prev, pm, hi, lo);
     uint32_t info = kNoColour << 8;
-    if (p == 0xFFFFFFFFu) cnt->pairs_changed = 1;
+    if (p == 0xFFFFFFFFu) {
+        cnt->pairs_changed = 1;
+        new_edges[atomicAdd(&cnt->num_new, 1u)] = make_uint2(hi, lo);
+    }
     if (p != 0xFFFFFFFFu) {
+        found = 1;
         info = prev.info[p];
         const uint32_t np = info & 0xFF;
         for (uint32_t k = 0; k < np; ++k) {
@@ -312,6 +319,10 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
         }
     }
     cur.info[m] = info;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(&cnt->num_found, found);
 }
 
 static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
@@ -326,7 +337,7 @@ int broadphase(edynhip_ctx *c) {
     if (np > 0) {
         hipLaunchKernelGGL(k_bp_bounds, dim3(std::min(blocks(np, 256), 32u)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt);
         hipLaunchKernelGGL(k_bp_morton, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt, c->bvh.keys);
-        EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 62));
+        EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 32, 62));   // stable: equal codes keep ascending body order
         if (np > 1)
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
@@ -336,14 +347,15 @@ int broadphase(edynhip_ctx *c) {
         EH_HIP(c, hipStreamSynchronize(s));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         M = c->cnt_host->num_pairs;
-        EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 64));
+        { int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb; EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb)); }
         EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges);
         else if (pm != 0) c->force_islands = true;
     }
     c->cur ^= 1;
+    c->prev_num_manifolds = pm;
     c->num_manifolds = M;
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;

@@ -59,7 +59,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.parent, (size_t)2 * nb)); EH_TRY(dalloc(c, t.left, nb)); EH_TRY(dalloc(c, t.right, nb));
     EH_TRY(dalloc(c, t.nmin, (size_t)2 * nb)); EH_TRY(dalloc(c, t.nmax, (size_t)2 * nb)); EH_TRY(dalloc(c, t.visit, nb));
     EH_TRY(dalloc(c, t.np_list, nb));
-    EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M));
+    EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M)); EH_TRY(dalloc(c, c->col_vals, M));
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));

@@ -107,6 +107,8 @@ struct Counters {
     uint32_t colour_overflow;
     uint32_t num_islands;
     uint32_t pairs_changed;      // this step's pair set differs from the previous step's
+    uint32_t num_found;          // new manifolds that already existed last step (== previous count <=> none removed)
+    uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     uint32_t colour_start[kMaxColours], colour_end[kMaxColours];
 };
@@ -136,6 +138,8 @@ struct edynhip_ctx {
     eh::Rows rows;
     eh::LBVH bvh;
     uint64_t *pair_keys = nullptr, *pair_keys_sorted = nullptr;
+    uint2 *new_edges = nullptr;    // body pairs of manifolds created this step (incremental island update)
+    uint32_t prev_num_manifolds = 0;
     uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr, *col_vals = nullptr;   // colour sort
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
@@ -164,7 +168,7 @@ int islands(edynhip_ctx *c);
 int solve(edynhip_ctx *c);
 // sort helpers (sort.hip)
 size_t sort_temp_bytes(uint32_t max_items);
-int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int end_bit);
+int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit);
 int sort_pairs_u32(edynhip_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n, int end_bit);
 int set_error(edynhip_ctx *c, int code, const char *what, hipError_t e = hipSuccess);
 }  // namespace eh

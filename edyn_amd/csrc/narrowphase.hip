@@ -73,7 +73,7 @@ DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
     return nd > thr || length_sqr(td) > thr2;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) {

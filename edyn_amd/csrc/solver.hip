@@ -54,25 +54,55 @@ DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
         if (atomicCAS(&parent[ra], ra, rb) == ra) return;
     }
 }
-// The three island kernels are skipped on the device when the pair set is unchanged since the last step
-// (labels stay valid); `force` overrides that after scene edits.
-__global__ void k_cc_init(uint32_t n, uint32_t *island, Counters *cnt, uint32_t force) {
-    if (!force && !cnt->pairs_changed) return;
+// Island labels are maintained incrementally; the mode is decided ON THE DEVICE from the broadphase counters
+// (no host sync):  unchanged pair set -> nothing to do;  only additions -> start from last step's labels and
+// hook the new edges;  any removal (or a scene edit, `force`) -> full recompute over all manifolds and joints.
+enum { CC_SKIP = 0, CC_INCREMENTAL = 1, CC_FULL = 2 };
+DI int cc_mode(const Counters *cnt, uint32_t prev_m, uint32_t force) {
+    if (force) return CC_FULL;
+    if (!cnt->pairs_changed) return CC_SKIP;
+    return cnt->num_found == prev_m ? CC_INCREMENTAL : CC_FULL;
+}
+__global__ void k_cc_init(uint32_t n, uint32_t *forest, const uint32_t *__restrict__ label, Counters *cnt, uint32_t prev_m, uint32_t force,
+                          Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags) {
+    const int mode = cc_mode(cnt, prev_m, force);
+    if (mode == CC_SKIP) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->num_islands = 0;
-    if (i < n) island[i] = i;
+    if (i >= n) return;
+    if (mode == CC_INCREMENTAL) { forest[i] = label[i]; return; }   // labels are roots (min index): a valid depth-1 forest
+    // full recompute: start every body at its smallest dynamic neighbour with a lower index (its manifolds with
+    // lower-index partners are the contiguous segment [seg_start, seg_end) of the sorted array). Links point to
+    // smaller indices, so this is a valid forest and most unions below find their roots already merged.
+    uint32_t parent = i;
+    if (M && is_dynamic(flags[i])) {
+        for (uint32_t s = mf.seg_start[i], e = mf.seg_end[i]; s < e; ++s) {
+            const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
+            if (is_dynamic(flags[lo])) { parent = lo; break; }
+        }
+    }
+    forest[i] = parent;
 }
 __global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                          const uint32_t *__restrict__ flags, uint32_t *island, const Counters *cnt, uint32_t force) {
-    if (!force && !cnt->pairs_changed) return;
+                          const uint32_t *__restrict__ flags, uint32_t *island, const Counters *cnt, uint32_t prev_m, uint32_t force) {
+    if (cc_mode(cnt, prev_m, force) != CC_FULL) return;
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M) return;
     uint32_t a = bA[e], b = bB[e];
     if (is_dynamic(flags[a]) && is_dynamic(flags[b])) cc_union(island, a, b);
 }
+__global__ void k_cc_hook_new(const uint2 *__restrict__ edges, const uint32_t *__restrict__ flags, uint32_t *island,
+                              const Counters *cnt, uint32_t prev_m, uint32_t force) {
+    if (cc_mode(cnt, prev_m, force) != CC_INCREMENTAL) return;
+    const uint32_t n = cnt->num_new;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        uint2 ed = edges[e];
+        if (is_dynamic(flags[ed.x]) && is_dynamic(flags[ed.y])) cc_union(island, ed.x, ed.y);
+    }
+}
 __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt,
-                             uint32_t force) {
-    if (!force && !cnt->pairs_changed) return;
+                             uint32_t prev_m, uint32_t force) {
+    if (cc_mode(cnt, prev_m, force) == CC_SKIP) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t root = 0;
     if (i < n) {
@@ -675,11 +705,13 @@ int islands(edynhip_ctx *c) {
     // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
     uint32_t *forest = c->isl_done;
     const uint32_t force = c->force_islands ? 1u : 0u;
+    const uint32_t pm = c->prev_num_manifolds;
     c->force_islands = false;
-    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->cnt, force);
-    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest, c->cnt, force);
-    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, force);
-    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, force);
+    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.island, c->cnt, pm, force, mf, M, c->b.flags);
+    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest, c->cnt, pm, force);
+    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
+    hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }

@@ -13,10 +13,10 @@ size_t sort_temp_bytes(uint32_t max_items) {
     return (a > b ? a : b) + 256;
 }
 
-int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int end_bit) {
+int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit) {
     if (n == 0) return EDYNHIP_OK;
     size_t bytes = c->sort_tmp_bytes;
-    EH_HIP(c, rocprim::radix_sort_keys(c->sort_tmp, bytes, in, out, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    EH_HIP(c, rocprim::radix_sort_keys(c->sort_tmp, bytes, in, out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream));
     return EDYNHIP_OK;
 }
 
