@@ -11,6 +11,8 @@
 #include "ctx.hpp"
 #include "dmath.hpp"
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
 
 namespace eh {
 using namespace dm;
@@ -228,13 +230,17 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
     }
 }
 
+// Two phases per lane so that the wave stays converged: (1) BVH traversal that only records the candidate leaves
+// (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be paid by the
+// whole wave on every iteration), (2) a dense loop over the recorded candidates running the exact predicates.
+constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(128)
-k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
-           const float4 *__restrict__ nmin, const float4 *__restrict__ nmax, const float4 *__restrict__ amin,
-           const float4 *__restrict__ amax, const uint64_t *__restrict__ group, const uint64_t *__restrict__ mask,
-           const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
+k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
+           const float4 *__restrict__ amin, const float4 *__restrict__ amax, const uint64_t *__restrict__ group,
+           const uint64_t *__restrict__ mask, const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
            uint64_t *out, uint32_t cap, Counters *cnt) {
     __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
+    __shared__ uint32_t cand[kCandCap][128];     // candidate bodies per lane
     __shared__ uint64_t wbuf[2][kWaveBuf];       // per-wave staging of emitted pairs
     __shared__ uint32_t wcount[2];
     const int tx = threadIdx.x, wave = tx >> 6, lane = tx & 63;
@@ -246,17 +252,20 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict_
         const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
         const box3 bi = body_box(amin, amax, i);
         const box3 q = inset(bi, -kQueryGrow);
+        int nc = 0;
         if (n > 1) {
             int sp = 0;
             stk[sp++][tx] = 0;
             while (sp > 0) {
-                uint32_t node = stk[--sp][tx];
+                const uint32_t node = stk[--sp][tx];
                 const float4 lo4 = nmin[node], hi4 = nmax[node];
-                box3 nb{from4(lo4), from4(hi4)};
-                if (!intersect(nb, q)) continue;
+                if (!intersect(box3{from4(lo4), from4(hi4)}, q)) continue;
                 if (node >= (uint32_t)(n - 1)) {
-                    uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
-                    if (j < i) consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);
+                    const uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
+                    if (j < i) {
+                        if (nc < kCandCap) cand[nc++][tx] = j;
+                        else consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);   // rare overflow path
+                    }
                 } else if (sp <= 46) {
                     stk[sp++][tx] = __float_as_uint(lo4.w);
                     stk[sp++][tx] = __float_as_uint(hi4.w);
@@ -265,6 +274,7 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict_
                 }
             }
         }
+        for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, group, mask, true, prev, pm, em);
         for (uint32_t t = 0; t < num_np; ++t) {
             uint32_t j = np_list[t];
             box3 bj = body_box(amin, amax, j);
@@ -341,7 +351,7 @@ int broadphase(edynhip_ctx *c) {
         if (np > 1)
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.left, c->bvh.right, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt);
         // pair count is needed on the host to size the sort and the manifold kernels
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
