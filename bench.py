@@ -38,6 +38,8 @@ WORKLOADS = {
     "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, desc="20x20x20 = 8000-box pile (config C2)"),
     "mixed32k": dict(gen=lambda: scenes.box_pile(32, 32, 32, mixed=True), vel=20, pos=3, desc="32768 mixed box/sphere stack, 20 it (config C3)"),
     "pile512": dict(gen=lambda: scenes.box_pile(8, 8, 8), vel=10, pos=3, desc="8x8x8 pile (smoke)"),
+    "islands256k": dict(gen=lambda: scenes.c4_islands(), vel=10, pos=3, desc="262144 boxes in 4096 independent 4x4x4 mini-piles (config C4)"),
+    "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
 
 

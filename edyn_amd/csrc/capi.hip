@@ -52,7 +52,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(alloc_manifolds(c, c->m[0], M, nb));
     EH_TRY(alloc_manifolds(c, c->m[1], M, nb));
     Rows &r = c->rows;
-    EH_TRY(dalloc(c, r.order, M)); EH_TRY(dalloc(c, r.bA, M)); EH_TRY(dalloc(c, r.bB, M)); EH_TRY(dalloc(c, r.np, M));
+    EH_TRY(dalloc(c, r.order, M)); EH_TRY(dalloc(c, r.bA, M)); EH_TRY(dalloc(c, r.bB, M)); EH_TRY(dalloc(c, r.np, M)); EH_TRY(dalloc(c, r.label, M));
     EH_TRY(dalloc(c, r.rw, (size_t)M * kMaxPts * kRowsPerPoint * kRowF));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));

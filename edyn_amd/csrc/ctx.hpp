@@ -83,6 +83,7 @@ struct Joints {
 struct Rows {
     uint32_t *order = nullptr;    // p -> manifold index
     uint32_t *bA = nullptr, *bB = nullptr, *np = nullptr;
+    uint32_t *label = nullptr;    // island label of the manifold (p-indexed copy: keeps the position kernel's load chain short)
     float4 *rw = nullptr;
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;

@@ -256,6 +256,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
     const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
     const uint32_t np = mf.info[m] & 0xFF;
     rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
+    rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     for (uint32_t k = 0; k < np; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
@@ -569,50 +570,99 @@ DI void publish_error(bool active, float max_err, uint32_t label, float *isl_err
     }
 }
 
-__global__ void __launch_bounds__(64)
-k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
-    const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
+// Position solve of one colour with TWO lanes per manifold: even lane = body A side, odd lane = body B side.
+// The kernel is instruction-bound (each correction re-normalises the quaternion and rebuilds I_w = R I_l R^T, as
+// position_solver::solve does), and the two bodies' updates are independent, so each lane owns one body. The few
+// shared scalars (world pivots, normal, effective-mass terms) are swapped with the partner lane through DPP.
+// Every quantity is computed by exactly the same fp32 operations in the same order as the one-lane formulation.
+DI float xchg1(float v) {   // value held by the partner lane (lane ^ 1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+}
+DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
+DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
+                          float *isl_err, const uint32_t *isl_done) {
+    const uint32_t p = start + (t >> 1);
+    const bool sideB = t & 1;
     bool active = p < end;
     uint32_t label = 0;
     float max_err = 0;
-    if (active) {
-        const uint32_t m = rows.order[p];
-        const uint32_t ia = rows.bA[p], ib = rows.bB[p], np = rows.np[p];
-        float4 a4[kMaxPts], b4[kMaxPts], l4[kMaxPts], n4[kMaxPts];
+    // all lanes stay in the code below (no early exit): DPP exchanges need both partners executing
+    const uint32_t pc = active ? p : start;
+    const uint32_t m = rows.order[pc];
+    const uint32_t ia = rows.bA[pc], ib = rows.bB[pc], np = active ? rows.np[pc] : 0;
+    const uint32_t ix = sideB ? ib : ia;
+    float4 piv[kMaxPts], l4[kMaxPts], n4[kMaxPts];
 #pragma unroll
-        for (int k = 0; k < kMaxPts; ++k) {   // all loads up front: this kernel is latency-bound
-            const size_t s = (size_t)k * mf.cap + m;
-            if ((uint32_t)k < np) { a4[k] = mf.pA[s]; b4[k] = mf.pB[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s]; }
-        }
-        PBody A = load_pbody(b, ia), B = load_pbody(b, ib);
-        label = b.island[A.proc ? ia : ib];
-        active = isl_done[label] == 0;
-        if (active) {
+    for (int k = 0; k < kMaxPts; ++k) {   // all loads up front
+        const size_t s = (size_t)k * mf.cap + m;
+        if ((uint32_t)k < np) { piv[k] = sideB ? mf.pB[s] : mf.pA[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s]; }
+    }
+    label = rows.label[pc];
+    PBody X = load_pbody(b, ix);
+    active = active && isl_done[label] == 0;
+    const float sgn = sideB ? -1.0f : 1.0f;
 #pragma unroll
-            for (int k = 0; k < kMaxPts; ++k) {
-                if ((uint32_t)k < np) {
-                    const int attach = __float_as_int(n4[k].w);
-                    const f3 pAw = to_world(from4(a4[k]), A.pos, A.orn), pBw = to_world(from4(b4[k]), B.pos, B.orn);
-                    f3 n = from4(n4[k]);
-                    if (attach == dc::NA_ON_A) n = rotate(A.orn, from4(l4[k]));
-                    else if (attach == dc::NA_ON_B) n = rotate(B.orn, from4(l4[k]));
-                    const float distance = dot(pAw - pBw, n);
-                    const f3 rA = pAw - A.pos, rB = pBw - B.pos;
-                    a4[k].w = distance;
-                    n4[k] = to4(n, n4[k].w);
-                    if (!(distance > -kEps)) pos_solve(A, B, n, cross(rA, n), -n, -cross(rB, n), -distance, max_err);
-                }
+    for (int k = 0; k < kMaxPts; ++k) {
+        if ((uint32_t)k < np && active) {   // uniform within a lane pair
+            const int attach = __float_as_int(n4[k].w);
+            const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
+            const f3 pOw = xchg1(pXw);
+            const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
+            // the normal rotates with the body it is attached to; that body's lane computes it and shares it
+            const f3 nrot = rotate(X.orn, from4(l4[k]));
+            const f3 nother = xchg1(nrot);
+            f3 n = from4(n4[k]);
+            if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
+            else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
+            const float distance = dot(pAw - pBw, n);
+            const f3 rX = pXw - X.pos;
+            n4[k] = to4(n, n4[k].w);
+            piv[k].w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
+            if (!(distance > -kEps)) {
+                // J = {n, rA x n, -n, -(rB x n)}
+                const f3 Jl = sideB ? -n : n;
+                const f3 cx = cross(rX, n);
+                const f3 Ja = sideB ? -cx : cx;
+                const float t1 = dot(Jl, Jl) * X.inv_m, t2 = dot(mul(X.iw, Ja), Ja);
+                const float o1 = xchg1(t1), o2 = xchg1(t2);
+                const float a1 = sideB ? o1 : t1, a2 = sideB ? o2 : t2, b1 = sideB ? t1 : o1, b2 = sideB ? t2 : o2;
+                const float em = 1.0f / (a1 + a2 + b1 + b2);
+                const float error = -distance;
+                const float corr = error * 0.2f * em;
+                pos_apply(X, Jl, Ja, corr);
+                max_err = fmaxf(fabsf(error), max_err);
             }
-#pragma unroll
-            for (int k = 0; k < kMaxPts; ++k) {
-                const size_t s = (size_t)k * mf.cap + m;
-                if ((uint32_t)k < np) { mf.pA[s] = a4[k]; mf.nrm[s] = n4[k]; }
-            }
-            store_pbody(b, ia, A);
-            store_pbody(b, ib, B);
         }
     }
-    publish_error(active, max_err, label, isl_err);
+    (void)sgn;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < kMaxPts; ++k) {
+            const size_t s = (size_t)k * mf.cap + m;
+            if ((uint32_t)k < np) {
+                if (!sideB) { float4 a = piv[k]; mf.pA[s] = a; }
+                else mf.nrm[s] = n4[k];
+            }
+        }
+        store_pbody(b, ix, X);
+    }
+    publish_error(active && !sideB, max_err, label, isl_err);
+}
+__global__ void __launch_bounds__(128)
+k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
+    pos_contacts_lane(start, end, blockIdx.x * blockDim.x + threadIdx.x, rows, mf, b, isl_err, isl_done);
+}
+// Tail colours of the position solve in ONE workgroup (see k_contact_solve_tail); uniform trip counts so that every
+// lane reaches the wave-level reductions.
+__global__ void __launch_bounds__(256)
+k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *isl_done) {
+    for (uint32_t c = 0; c < tr.n; ++c) {
+        for (uint32_t base = tr.start[c]; base < tr.end[c]; base += 128) {
+            pos_contacts_lane(base, tr.end[c], threadIdx.x, rows, mf, b, isl_err, isl_done);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
     const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
@@ -745,12 +795,14 @@ static int colour_contacts(edynhip_ctx *c) {
         return EDYNHIP_OK;
     };
     // Steady state: the few new edges colour within the speculative rounds and ONE host sync fetches the offsets.
-    run_rounds(2);
+    run_rounds(3);
     EH_TRY(sort_and_fetch());
     if (c->cnt_host->uncoloured != 0) {
+        uint32_t batch = 4;
         while (c->cnt_host->uncoloured != 0) {
             if (c->cnt_host->colour_overflow) break;
-            run_rounds(16);
+            run_rounds(batch);
+            if (batch < 64) batch *= 2;   // a scene coloured from scratch needs hundreds of rounds; steady state needs none
             EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             EH_HIP(c, hipStreamSynchronize(s));
             if (total_rounds > 65536) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
@@ -840,10 +892,11 @@ int solve(edynhip_ctx *c) {
                 uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
                 if (e > a) hipLaunchKernelGGL(k_pos_joints, dim3(blocks(e - a, 128)), dim3(128), 0, s, a, e, j, c->b, c->isl_err, c->isl_done);
             }
-            for (uint32_t k = 0; k < nc; ++k) {
+            for (uint32_t k = 0; k < first_tail; ++k) {
                 uint32_t a = c->colour_start[k], e = c->colour_end[k];
-                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
+                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(2 * (e - a), 128)), dim3(128), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
             }
+            if (tail.n) hipLaunchKernelGGL(k_pos_contacts_tail, dim3(1), dim3(256), 0, s, tail, c->rows, mf, c->b, c->isl_err, c->isl_done);
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
     }
