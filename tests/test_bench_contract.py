@@ -1,0 +1,28 @@
+"""bench.py prints ONE JSON line with the driver's contract keys plus roofline / cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pile512", "--steps", "10", "--warmup", "5",
+                          "--cpu-sample-steps", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["unit"] == "steps/sec" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
