@@ -72,30 +72,44 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
-    torch.cuda.set_device(local_rank)
+    ngpu = torch.cuda.device_count()
+    # One process per GPU over RCCL is the real configuration. If there are fewer GPUs than ranks (functional test of
+    # this code path on a 1-GPU box: EDYN_BENCH_SHARE_GPU=1) ranks share devices and the gather is staged through gloo.
+    share = world_size > ngpu
+    if share and os.environ.get("EDYN_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: {world_size} ranks but {ngpu} GPU(s); set EDYN_BENCH_SHARE_GPU=1 only for functional tests")
+    device_index = local_rank % ngpu
+    torch.cuda.set_device(device_index)
     distributed = world_size > 1
+    backend = "gloo" if share else "nccl"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     wl = WORKLOADS[args.workload]
     scene = wl["gen"]()
     n_bodies = len(scene["kind"])
     cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
-                               device=local_rank, timing=True)
+                               device=device_index, timing=True)
     w = edyn_amd.World(cfg)
     w.set_scene(scene)
     stream = torch.cuda.current_stream()
     w.set_stream(stream.cuda_stream)   # stepper kernels and the RCCL gather share torch's stream => ordered
 
     state = torch.empty((n_bodies, 13), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world_size * n_bodies, 13), dtype=torch.float32, device="cuda") if distributed else None
+    gathered = torch.empty((world_size * n_bodies, 13), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu") if distributed else None
 
     def one_step():
         w.step_simulation(1)
         if distributed:
             w.pack_state_device(state.data_ptr())
-            dist.all_gather_into_tensor(gathered.view(-1), state.view(-1))
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered.view(-1), state.view(-1))
+            else:
+                dist.all_gather_into_tensor(gathered.view(-1), state.cpu().view(-1))
 
     for _ in range(args.warmup):
         one_step()
@@ -113,7 +127,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -144,7 +158,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}; {wl['vel']} velocity / {wl['pos']} position iterations, dt 1/60, "
-                                   f"friction 0.5, restitution 0" + (f"; {world_size} replicas (one island per GPU), per-step RCCL all-gather of state" if distributed else ""),
+                                   f"friction 0.5, restitution 0" + (f"; {world_size} replicas (one island per GPU), per-step {'RCCL' if backend == 'nccl' else 'gloo (shared-GPU functional test)'} all-gather of state" if distributed else ""),
                        "bodies": n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

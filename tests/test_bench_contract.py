@@ -26,3 +26,18 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_two_ranks_on_one_gpu_functional():
+    """The N>1 code path (rendezvous, per-step pack + all-gather, max-over-ranks timing) on a 1-GPU box: two ranks share
+    cuda:0 and gather through gloo. The 8-GPU RCCL run itself is the driver's; this guards everything around it."""
+    env = dict(os.environ, EDYN_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pile512",
+           "--steps", "8", "--warmup", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
