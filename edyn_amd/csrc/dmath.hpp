@@ -73,6 +73,10 @@ DI f3 rotate(q4 q, f3 v) {
     f3 r{q.x, q.y, q.z};
     return v + cross(2.0f * r, cross(r, v) + q.w * v);
 }
+// Correctly rounded fp32 sin/cos (double evaluation, one rounding): libm-independent, so the device agrees bit for
+// bit with a CPU evaluation of the same formula (the reference's std::sin(float) depends on the C library's last bit).
+DI float sin_cr(float x) { return (float)sin((double)x); }
+DI float cos_cr(float x) { return (float)cos((double)x); }
 // src/edyn/math/quaternion.cpp:7-22
 DI q4 integrate(q4 q, f3 w, float dt) {
     const float ws = length(w);
@@ -81,9 +85,9 @@ DI q4 integrate(q4 q, f3 w, float dt) {
         const float k = 1.0f / 48.0f;
         t = 0.5f * dt - dt * dt * dt * k * ws * ws;
     } else {
-        t = sinf(0.5f * ws * dt) / ws;
+        t = sin_cr(0.5f * ws * dt) / ws;
     }
-    q4 r{w.x * t, w.y * t, w.z * t, cosf(0.5f * ws * dt)};
+    q4 r{w.x * t, w.y * t, w.z * t, cos_cr(0.5f * ws * dt)};
     return normalize(r * q);
 }
 DI q4 quaternion_derivative(q4 q, f3 w) { return (q4{w.x, w.y, w.z, 0.0f} * q) * 0.5f; }

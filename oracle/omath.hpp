@@ -96,6 +96,11 @@ inline vec3 rotate(quat q, vec3 v) {
     vec3 r{q.x, q.y, q.z};
     return v + cross(2.0f * r, cross(r, v) + q.w * v);
 }
+// sin/cos: the reference calls std::sin/std::cos on floats, whose last bit depends on the C library. Both the
+// oracle and the GPU evaluate them in double precision and round once, i.e. correctly rounded fp32 (equal to
+// glibc's sinf/cosf except in rare 1-ulp cases), so that CPU and GPU agree bit for bit over long horizons.
+inline float sin_cr(float x) { return (float)std::sin((double)x); }
+inline float cos_cr(float x) { return (float)std::cos((double)x); }
 // quaternion.cpp:7-22 (exponential map; Taylor branch for |w| < 0.001)
 inline quat integrate(quat q, vec3 w, float dt) {
     const float ws = length(w);
@@ -105,9 +110,9 @@ inline quat integrate(quat q, vec3 w, float dt) {
         const float k = 1.0f / 48.0f;
         t = half * dt - dt * dt * dt * k * ws * ws;
     } else {
-        t = std::sin(half * ws * dt) / ws;
+        t = sin_cr(half * ws * dt) / ws;
     }
-    quat r{w.x * t, w.y * t, w.z * t, std::cos(half * ws * dt)};
+    quat r{w.x * t, w.y * t, w.z * t, cos_cr(half * ws * dt)};
     return normalize(r * q);
 }
 // quaternion.hpp:244-246: quaternion{w,0} * q * 0.5
