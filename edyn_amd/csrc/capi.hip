@@ -44,8 +44,7 @@ static int allocate(edynhip_ctx *c) {
     const uint32_t nb = c->cfg.max_bodies, M = c->cfg.max_manifolds, nj = c->cfg.max_joints;
     Bodies &b = c->b;
     b.cap = nb;
-    EH_TRY(dalloc(c, b.pos, nb)); EH_TRY(dalloc(c, b.orn, nb)); EH_TRY(dalloc(c, b.linvel, nb)); EH_TRY(dalloc(c, b.angvel, nb));
-    EH_TRY(dalloc(c, b.dv, nb)); EH_TRY(dalloc(c, b.dw, nb)); EH_TRY(dalloc(c, b.iw, (size_t)nb * 3)); EH_TRY(dalloc(c, b.il, (size_t)nb * 3));
+    EH_TRY(dalloc(c, b.xf, (size_t)nb * 8)); EH_TRY(dalloc(c, b.dvw, (size_t)nb * 2)); EH_TRY(dalloc(c, b.linvel, nb)); EH_TRY(dalloc(c, b.angvel, nb));
     EH_TRY(dalloc(c, b.amin, nb)); EH_TRY(dalloc(c, b.amax, nb)); EH_TRY(dalloc(c, b.shape, nb)); EH_TRY(dalloc(c, b.grav, nb));
     EH_TRY(dalloc(c, b.mat, nb)); EH_TRY(dalloc(c, b.flags, nb)); EH_TRY(dalloc(c, b.group, nb)); EH_TRY(dalloc(c, b.mask, nb));
     EH_TRY(dalloc(c, b.island, nb));
@@ -126,14 +125,14 @@ __global__ void k_init_bodies(uint32_t n, RawBodies r, Bodies b, float3 default_
         m3 basis = to_m3(orn);
         iw = mul(mul(basis, il), transpose(basis));
     }
-    b.pos[i] = to4(pos, inv_m);
-    b.orn[i] = to4(orn);
+    B_POS(b, i) = to4(pos, inv_m);
+    B_ORN(b, i) = to4(orn);
     const bool moving = kind != EDYNHIP_KIND_STATIC;
     b.linvel[i] = moving ? make_float4(r.linvel[3 * i], r.linvel[3 * i + 1], r.linvel[3 * i + 2], 0) : make_float4(0, 0, 0, 0);
     b.angvel[i] = moving ? make_float4(r.angvel[3 * i], r.angvel[3 * i + 1], r.angvel[3 * i + 2], 0) : make_float4(0, 0, 0, 0);
-    b.dv[i] = make_float4(0, 0, 0, 0); b.dw[i] = make_float4(0, 0, 0, 0);
-    b.iw[3 * i] = to4(iw.r0, 0); b.iw[3 * i + 1] = to4(iw.r1, 0); b.iw[3 * i + 2] = to4(iw.r2, 0);
-    b.il[3 * i] = to4(il.r0, 0); b.il[3 * i + 1] = to4(il.r1, 0); b.il[3 * i + 2] = to4(il.r2, 0);
+    B_DV(b, i) = make_float4(0, 0, 0, 0); B_DW(b, i) = make_float4(0, 0, 0, 0);
+    B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
+    B_IL(b, i, 0) = to4(il.r0, 0); B_IL(b, i, 1) = to4(il.r1, 0); B_IL(b, i, 2) = to4(il.r2, 0);
     b.shape[i] = sp;
     f3 g = r.gravity ? mk3(r.gravity[3 * i], r.gravity[3 * i + 1], r.gravity[3 * i + 2]) : mk3(default_gravity.x, default_gravity.y, default_gravity.z);
     b.grav[i] = kind == EDYNHIP_KIND_DYNAMIC ? to4(g, 0) : make_float4(0, 0, 0, 0);
@@ -234,7 +233,7 @@ __global__ void k_pack_state(uint32_t first, uint32_t count, Bodies b, float *ds
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t i = first + t;
-    float4 p = b.pos[i], q = b.orn[i], v = b.linvel[i], w = b.angvel[i];
+    float4 p = B_POS(b, i), q = B_ORN(b, i), v = b.linvel[i], w = b.angvel[i];
     float *o = dst + (size_t)t * 13;
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
     o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
@@ -243,8 +242,8 @@ __global__ void k_unpack_state(uint32_t n, const float *src, Bodies b) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *o = src + (size_t)i * 13;
-    b.pos[i] = make_float4(o[0], o[1], o[2], b.pos[i].w);
-    b.orn[i] = make_float4(o[3], o[4], o[5], o[6]);
+    B_POS(b, i) = make_float4(o[0], o[1], o[2], B_POS(b, i).w);
+    B_ORN(b, i) = make_float4(o[3], o[4], o[5], o[6]);
     b.linvel[i] = make_float4(o[7], o[8], o[9], 0);
     b.angvel[i] = make_float4(o[10], o[11], o[12], 0);
 }
@@ -253,7 +252,7 @@ __global__ void k_pack_derived(uint32_t n, Bodies b, float *aabb, float *iw) {
     if (i >= n) return;
     float4 a = b.amin[i], c = b.amax[i];
     aabb[6 * i] = a.x; aabb[6 * i + 1] = a.y; aabb[6 * i + 2] = a.z; aabb[6 * i + 3] = c.x; aabb[6 * i + 4] = c.y; aabb[6 * i + 5] = c.z;
-    for (int r = 0; r < 3; ++r) { float4 x = b.iw[3 * i + r]; iw[9 * i + 3 * r] = x.x; iw[9 * i + 3 * r + 1] = x.y; iw[9 * i + 3 * r + 2] = x.z; }
+    for (int r = 0; r < 3; ++r) { float4 x = B_IW(b, i, r); iw[9 * i + 3 * r] = x.x; iw[9 * i + 3 * r + 1] = x.y; iw[9 * i + 3 * r + 2] = x.z; }
 }
 
 constexpr uint32_t kMaxTimedSteps = 4096;

@@ -22,14 +22,15 @@ constexpr uint32_t BF_SHAPE_MASK = 0xF0u;
 
 struct Bodies {
     uint32_t n = 0, cap = 0;
-    float4 *pos = nullptr;      // xyz, w = mass_inv (dynamic) or 0
-    float4 *orn = nullptr;      // xyzw
-    float4 *linvel = nullptr;   // xyz
+    // Gathered state lives in cache-line sized RECORDS (the solver reads bodies by index; random 16-B accesses to
+    // separate arrays were measured ~6x slower than one aligned record, scripts/ubench/solve_model.hip):
+    //   xf[8*i + 0] pos xyz, w = mass_inv (dynamic) or 0      xf[8*i + 1] orn xyzw
+    //   xf[8*i + 2..4] inertia_world_inv rows                   xf[8*i + 5..7] inertia_inv (local) rows      (128 B, one line)
+    //   dvw[2*i + 0] delta_linvel xyz, w = effective inv mass (0 for non-procedural)   dvw[2*i + 1] delta_angvel   (32 B)
+    float4 *xf = nullptr;
+    float4 *dvw = nullptr;
+    float4 *linvel = nullptr;   // xyz   (streamed, body-parallel kernels only)
     float4 *angvel = nullptr;   // xyz
-    float4 *dv = nullptr;       // delta_linvel xyz, w = effective inv mass (0 for non-procedural)
-    float4 *dw = nullptr;       // delta_angvel xyz
-    float4 *iw = nullptr;       // inertia_world_inv, 3 rows per body [3*i + r]
-    float4 *il = nullptr;       // inertia_inv (local), 3 rows per body
     float4 *amin = nullptr;     // AABB min
     float4 *amax = nullptr;     // AABB max
     float4 *shape = nullptr;    // box half extents | sphere radius | plane normal+constant
@@ -122,6 +123,13 @@ struct StageTimer {
     uint32_t capacity = 0;          // steps for which events exist
     hipEvent_t *e = nullptr;        // events of the step being recorded (nullptr = not recording)
 };
+
+#define B_POS(b, i) ((b).xf[8 * (size_t)(i)])
+#define B_ORN(b, i) ((b).xf[8 * (size_t)(i) + 1])
+#define B_IW(b, i, r) ((b).xf[8 * (size_t)(i) + 2 + (r)])
+#define B_IL(b, i, r) ((b).xf[8 * (size_t)(i) + 5 + (r)])
+#define B_DV(b, i) ((b).dvw[2 * (size_t)(i)])
+#define B_DW(b, i) ((b).dvw[2 * (size_t)(i) + 1])
 
 }  // namespace eh
 

@@ -83,10 +83,10 @@ k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt) {
         const uint32_t fa = b.flags[ia], fb = b.flags[ib];
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
         BodyIn A, B;
-        { float4 p = b.pos[ia]; A.pos = from4(p); A.orn = q_from4(b.orn[ia]); A.angvel = from4(b.angvel[ia]);
+        { float4 p = B_POS(b, ia); A.pos = from4(p); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
           float2 mt = b.mat[ia]; A.friction = mt.x; A.restitution = mt.y;
           A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tA == SHAPE_SPHERE; }
-        { float4 p = b.pos[ib]; B.pos = from4(p); B.orn = q_from4(b.orn[ib]); B.angvel = from4(b.angvel[ib]);
+        { float4 p = B_POS(b, ib); B.pos = from4(p); B.orn = q_from4(B_ORN(b, ib)); B.angvel = from4(b.angvel[ib]);
           float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
           B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tB == SHAPE_SPHERE; }
 

@@ -204,12 +204,12 @@ __global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sort
 struct BRef { f3 pos; q4 orn; f3 v, w; float inv_m; m3 inv_I; };
 DI BRef load_bref(const Bodies &b, uint32_t i) {
     BRef r;
-    float4 p = b.pos[i];
+    float4 p = B_POS(b, i);
     uint32_t fl = b.flags[i];
-    r.pos = from4(p); r.orn = q_from4(b.orn[i]);
+    r.pos = from4(p); r.orn = q_from4(B_ORN(b, i));
     if (is_dynamic(fl)) {
         r.inv_m = p.w;
-        r.inv_I = {from4(b.iw[3 * i]), from4(b.iw[3 * i + 1]), from4(b.iw[3 * i + 2])};
+        r.inv_I = {from4(B_IW(b, i, 0)), from4(B_IW(b, i, 1)), from4(B_IW(b, i, 2))};
     } else { r.inv_m = 0; r.inv_I = m3_zero(); }
     if ((fl & BF_KIND_MASK) == EDYNHIP_KIND_STATIC) { r.v = mk3(0, 0, 0); r.w = mk3(0, 0, 0); }
     else { r.v = from4(b.linvel[i]); r.w = from4(b.angvel[i]); }
@@ -229,7 +229,7 @@ __global__ void k_solve_begin(uint32_t n, Bodies b, float dt) {
     uint32_t fl = b.flags[i];
     float inv_m = 0;
     if (is_dynamic(fl)) {
-        inv_m = b.pos[i].w;
+        inv_m = B_POS(b, i).w;
         f3 g = from4(b.grav[i]);
         if (!(g.x == 0 && g.y == 0 && g.z == 0)) {
             f3 v = from4(b.linvel[i]);
@@ -237,8 +237,8 @@ __global__ void k_solve_begin(uint32_t n, Bodies b, float dt) {
             b.linvel[i] = to4(v, 0);
         }
     }
-    b.dv[i] = make_float4(0, 0, 0, inv_m);
-    b.dw[i] = make_float4(0, 0, 0, 0);
+    B_DV(b, i) = make_float4(0, 0, 0, inv_m);
+    B_DW(b, i) = make_float4(0, 0, 0, 0);
 }
 
 DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, float eff, float rhs, float imp, float mu,
@@ -290,15 +290,15 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
 // ------------------------------------------------------------------ velocity solve: contacts
 struct Delta { f3 dvA, dwA, dvB, dwB; float imA, imB; m3 iA, iB; };
 DI void load_delta(const Bodies &b, uint32_t ia, uint32_t ib, Delta &d) {
-    float4 va = b.dv[ia], vb = b.dv[ib];
-    d.dvA = from4(va); d.imA = va.w; d.dwA = from4(b.dw[ia]);
-    d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(b.dw[ib]);
-    d.iA = {from4(b.iw[3 * ia]), from4(b.iw[3 * ia + 1]), from4(b.iw[3 * ia + 2])};
-    d.iB = {from4(b.iw[3 * ib]), from4(b.iw[3 * ib + 1]), from4(b.iw[3 * ib + 2])};
+    float4 va = B_DV(b, ia), vb = B_DV(b, ib);
+    d.dvA = from4(va); d.imA = va.w; d.dwA = from4(B_DW(b, ia));
+    d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(B_DW(b, ib));
+    d.iA = {from4(B_IW(b, ia, 0)), from4(B_IW(b, ia, 1)), from4(B_IW(b, ia, 2))};
+    d.iB = {from4(B_IW(b, ib, 0)), from4(B_IW(b, ib, 1)), from4(B_IW(b, ib, 2))};
 }
 DI void store_delta(const Bodies &b, uint32_t ia, uint32_t ib, const Delta &d) {
-    if (d.imA != 0) { b.dv[ia] = to4(d.dvA, d.imA); b.dw[ia] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
-    if (d.imB != 0) { b.dv[ib] = to4(d.dvB, d.imB); b.dw[ib] = to4(d.dwB, 0); }
+    if (d.imA != 0) { B_DV(b, ia) = to4(d.dvA, d.imA); B_DW(b, ia) = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { B_DV(b, ib) = to4(d.dvB, d.imB); B_DW(b, ib) = to4(d.dwB, 0); }
 }
 DI void apply_impulse(Delta &d, f3 J0, f3 J1, f3 J2, f3 J3, float imp) {   // apply_row_impulse
     d.dvA += d.imA * J0 * imp;
@@ -325,7 +325,7 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
 template <bool WARM>
 DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                            const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
-                           float4 *__restrict__ bdv, float4 *__restrict__ bdw) {
+                           float4 *__restrict__ bdvw) {
     const uint32_t ia = rbA[p], ib = rbB[p], np = rnp[p];
     RowReg R[kMaxPts][kRowsPerPoint];
 #pragma unroll
@@ -339,7 +339,7 @@ DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const u
     }
     Delta d;
     {
-        const float4 va = bdv[ia], vb = bdv[ib], wa = bdw[ia], wb = bdw[ib];
+        const float4 va = bdvw[2 * (size_t)ia], wa = bdvw[2 * (size_t)ia + 1], vb = bdvw[2 * (size_t)ib], wb = bdvw[2 * (size_t)ib + 1];
         d.dvA = from4(va); d.imA = va.w; d.dwA = from4(wa);
         d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(wb);
     }
@@ -397,16 +397,16 @@ DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const u
             }
         }
     }
-    if (d.imA != 0) { bdv[ia] = to4(d.dvA, d.imA); bdw[ia] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
-    if (d.imB != 0) { bdv[ib] = to4(d.dvB, d.imB); bdw[ib] = to4(d.dwB, 0); }
+    if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, d.imA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, d.imB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
 }
 template <bool WARM>
 __global__ void __launch_bounds__(64)
 k_contact_solve(uint32_t start, uint32_t end, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                 const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
-                float4 *__restrict__ bdv, float4 *__restrict__ bdw) {
+                float4 *__restrict__ bdvw) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdv, bdw);
+    if (p < end) contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdvw);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
@@ -415,10 +415,10 @@ constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD ke
 template <bool WARM>
 __global__ void __launch_bounds__(256)
 k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, const uint32_t *rnp, float4 *rw, uint32_t rcap,
-                     float4 *bdv, float4 *bdw) {
+                     float4 *bdvw) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdv, bdw);
+            contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdvw);
         __threadfence_block();
         __syncthreads();
     }
@@ -508,35 +508,35 @@ __global__ void k_integrate(uint32_t n, Bodies b, float dt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!is_dynamic(b.flags[i])) return;
-    float4 p4 = b.pos[i];
+    float4 p4 = B_POS(b, i);
     f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
-    v += from4(b.dv[i]);
-    w += from4(b.dw[i]);
+    v += from4(B_DV(b, i));
+    w += from4(B_DW(b, i));
     f3 pos = from4(p4);
     pos += v * dt;
-    q4 orn = integrate(q_from4(b.orn[i]), w, dt);
+    q4 orn = integrate(q_from4(B_ORN(b, i)), w, dt);
     b.linvel[i] = to4(v, 0); b.angvel[i] = to4(w, 0);
-    b.pos[i] = to4(pos, p4.w); b.orn[i] = to4(orn);
+    B_POS(b, i) = to4(pos, p4.w); B_ORN(b, i) = to4(orn);
 }
 
 // ------------------------------------------------------------------ position solver
 struct PBody { f3 pos; q4 orn; float inv_m; m3 iw, il; bool proc; };
 DI PBody load_pbody(const Bodies &b, uint32_t i) {
     PBody r;
-    float4 p = b.pos[i];
-    r.pos = from4(p); r.orn = q_from4(b.orn[i]);
+    float4 p = B_POS(b, i);
+    r.pos = from4(p); r.orn = q_from4(B_ORN(b, i));
     r.proc = is_dynamic(b.flags[i]);
     if (r.proc) {
         r.inv_m = p.w;
-        r.iw = {from4(b.iw[3 * i]), from4(b.iw[3 * i + 1]), from4(b.iw[3 * i + 2])};
-        r.il = {from4(b.il[3 * i]), from4(b.il[3 * i + 1]), from4(b.il[3 * i + 2])};
+        r.iw = {from4(B_IW(b, i, 0)), from4(B_IW(b, i, 1)), from4(B_IW(b, i, 2))};
+        r.il = {from4(B_IL(b, i, 0)), from4(B_IL(b, i, 1)), from4(B_IL(b, i, 2))};
     } else { r.inv_m = 0; r.iw = m3_zero(); r.il = m3_zero(); }
     return r;
 }
 DI void store_pbody(const Bodies &b, uint32_t i, const PBody &r) {
     if (!r.proc) return;
-    b.pos[i] = to4(r.pos, r.inv_m); b.orn[i] = to4(r.orn);
-    b.iw[3 * i] = to4(r.iw.r0, 0); b.iw[3 * i + 1] = to4(r.iw.r1, 0); b.iw[3 * i + 2] = to4(r.iw.r2, 0);
+    B_POS(b, i) = to4(r.pos, r.inv_m); B_ORN(b, i) = to4(r.orn);
+    B_IW(b, i, 0) = to4(r.iw.r0, 0); B_IW(b, i, 1) = to4(r.iw.r1, 0); B_IW(b, i, 2) = to4(r.iw.r2, 0);
 }
 DI void pos_apply(PBody &x, f3 Jl, f3 Ja, float corr) {
     if (!x.proc) return;
@@ -713,8 +713,8 @@ __global__ void k_finish(uint32_t n, Bodies b) {
     const uint32_t kind = fl & BF_KIND_MASK;
     if (kind == EDYNHIP_KIND_STATIC) return;
     const int st = (int)((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-    const f3 pos = from4(b.pos[i]);
-    const q4 orn = q_from4(b.orn[i]);
+    const f3 pos = from4(B_POS(b, i));
+    const q4 orn = q_from4(B_ORN(b, i));
     const m3 basis = to_m3(orn);
     if (st == dc::SHAPE_BOX) {   // aabb_util.cpp:42-63
         const f3 h = from4(b.shape[i]);
@@ -736,9 +736,9 @@ __global__ void k_finish(uint32_t n, Bodies b) {
         b.amax[i] = make_float4(pos.x + r, pos.y + r, pos.z + r, 0);
     }
     if (kind == EDYNHIP_KIND_DYNAMIC) {   // update_inertias.cpp:12-24
-        const m3 il = {from4(b.il[3 * i]), from4(b.il[3 * i + 1]), from4(b.il[3 * i + 2])};
+        const m3 il = {from4(B_IL(b, i, 0)), from4(B_IL(b, i, 1)), from4(B_IL(b, i, 2))};
         const m3 iw = mul(mul(basis, il), transpose(basis));
-        b.iw[3 * i] = to4(iw.r0, 0); b.iw[3 * i + 1] = to4(iw.r1, 0); b.iw[3 * i + 2] = to4(iw.r2, 0);
+        B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
     }
 }
 
@@ -862,14 +862,14 @@ int solve(edynhip_ctx *c) {
             uint32_t a = c->colour_start[k], e = c->colour_end[k];
             if (e <= a) continue;
             const Rows &r = c->rows;
-            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
-            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
+            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
+            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
             ++launches;
         }
         if (tail.n) {
             const Rows &r = c->rows;
-            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
-            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dv, c->b.dw);
+            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
+            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
             ++launches;
         }
     };
