@@ -32,7 +32,7 @@ __global__ void k_step_reset(Counters *cnt) {
         cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0;
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
-    if (t < (int)kMaxColours) { cnt->colour_start[t] = 0; cnt->colour_end[t] = 0; }
+    for (int k = t; k < 4 * (int)kMaxColours; k += 64) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
 }
 
 __global__ void __launch_bounds__(256)

@@ -112,7 +112,8 @@ struct Counters {
     uint32_t num_found;          // new manifolds that already existed last step (== previous count <=> none removed)
     uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
-    uint32_t colour_start[kMaxColours], colour_end[kMaxColours];
+    // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
+    uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];
 };
 
 // Per-step stage events; resolved lazily by edynhip_get_timings so that timing adds no host sync.
@@ -163,6 +164,7 @@ struct edynhip_ctx {
     edynhip_stats stats{};
     uint32_t num_colours = 0;
     uint32_t colour_start[eh::kMaxColours] = {0}, colour_end[eh::kMaxColours] = {0};
+    uint32_t colour_split[eh::kMaxColours][3] = {{0}};   // ends of the 4-, 3- and 2-point groups inside each colour's range
     uint32_t num_active = 0;
     std::vector<void *> allocs;
     bool force_islands = true;     // recompute island labels even if the pair set did not change

@@ -187,15 +187,18 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
 __global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, uint32_t *vals) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    // within a colour, manifolds are grouped by point count (4 first): the solve kernels then know a lane's point
+    // count from its position alone (no dependent load) and waves are uniform in it
     uint32_t in = info[m];
-    keys[m] = (in & 0xFF) ? (in >> 8) : 0xFFu;
+    uint32_t np = in & 0xFF;
+    keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0x1FFu;
     vals[m] = m;
 }
 __global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sorted, Counters *cnt) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= M) return;
     uint32_t c = keys_sorted[p];
-    if (c >= kMaxColours) return;
+    if (c >= 4 * kMaxColours) return;
     if (p == 0 || keys_sorted[p - 1] != c) cnt->colour_start[c] = p;
     if (p == M - 1 || keys_sorted[p + 1] != c) cnt->colour_end[c] = p + 1;
 }
@@ -322,21 +325,22 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
     const f3 Jl = from4(r.f[0]);
     return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
 }
-template <bool WARM>
-DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                           const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
-                           float4 *__restrict__ bdvw) {
-    const uint32_t ia = rbA[p], ib = rbB[p], np = rnp[p];
-    RowReg R[kMaxPts][kRowsPerPoint];
+// NP (points of the manifold) is a template parameter: lanes are grouped by point count inside a colour, so a wave
+// runs one instantiation, every loop is fully unrolled without predication and the compiler can issue all
+// 15*NP row loads plus the body loads back to back before the first use (one memory round trip after the indices).
+template <bool WARM, int NP>
+DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                         float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
+    const uint32_t ia = rbA[p], ib = rbB[p];
+    RowReg R[NP][kRowsPerPoint];
+    // slots [0, NP) are loaded unconditionally (slots >= np hold stale but finite rows that are never used or stored);
+    // NP is 4 for 3-4 point manifolds and 2 for 1-2 point ones, so at most one slot is fetched in vain
 #pragma unroll
-    for (int k = 0; k < kMaxPts; ++k) {
-        if ((uint32_t)k < np) {
+    for (int k = 0; k < NP; ++k)
 #pragma unroll
-            for (int r = 0; r < kRowsPerPoint; ++r)
+        for (int r = 0; r < kRowsPerPoint; ++r)
 #pragma unroll
-                for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
-        }
-    }
+            for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
     Delta d;
     {
         const float4 va = bdvw[2 * (size_t)ia], wa = bdvw[2 * (size_t)ia + 1], vb = bdvw[2 * (size_t)ib], wb = bdvw[2 * (size_t)ib + 1];
@@ -344,81 +348,84 @@ DI void contact_solve_lane(uint32_t p, const uint32_t *__restrict__ rbA, const u
         d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(wb);
     }
 #pragma unroll
-    for (int k = 0; k < kMaxPts; ++k) {
-        if ((uint32_t)k < np) {
-            RowReg &r = R[k][0];
-            if (WARM) {
-                row_apply(d, r, r.f[2].w);
-            } else {
-                float drel = row_relspeed(d, r);
-                float dimp = (r.f[1].w - drel) * r.f[0].w;
-                float cur = r.f[2].w;
-                float imp = cur + dimp;
-                if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
-                else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
-                else cur = imp;
-                r.f[2].w = cur;
-                row_apply(d, r, dimp);
-            }
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
+        RowReg &r = R[k][0];
+        if (WARM) {
+            row_apply(d, r, r.f[2].w);
+        } else {
+            float drel = row_relspeed(d, r);
+            float dimp = (r.f[1].w - drel) * r.f[0].w;
+            float cur = r.f[2].w;
+            float imp = cur + dimp;
+            if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
+            else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
+            else cur = imp;
+            r.f[2].w = cur;
+            row_apply(d, r, dimp);
         }
     }
 #pragma unroll
-    for (int k = 0; k < kMaxPts; ++k) {
-        if ((uint32_t)k < np) {
-            RowReg &ra = R[k][1], &rb = R[k][2];
-            if (WARM) {   // warm_start(constraint_row_friction&)
-                row_apply(d, ra, ra.f[2].w);
-                row_apply(d, rb, rb.f[2].w);
-            } else {
-                float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
-                float i0 = ra.f[2].w + di0;
-                float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
-                float i1 = rb.f[2].w + di1;
-                float len2 = i0 * i0 + i1 * i1;
-                float max_len = R[k][0].f[3].w * R[k][0].f[2].w;   // mu * current normal impulse
-                if (len2 > square(max_len)) {
-                    float len = sqrtf(len2);
-                    if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-                    else { i0 = 0; i1 = 0; }
-                    di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
-                }
-                ra.f[2].w = i0; rb.f[2].w = i1;
-                row_apply(d, ra, di0);
-                row_apply(d, rb, di1);
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
+        RowReg &ra = R[k][1], &rb = R[k][2];
+        if (WARM) {   // warm_start(constraint_row_friction&)
+            row_apply(d, ra, ra.f[2].w);
+            row_apply(d, rb, rb.f[2].w);
+        } else {
+            float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
+            float i0 = ra.f[2].w + di0;
+            float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
+            float i1 = rb.f[2].w + di1;
+            float len2 = i0 * i0 + i1 * i1;
+            float max_len = R[k][0].f[3].w * R[k][0].f[2].w;   // mu * current normal impulse
+            if (len2 > square(max_len)) {
+                float len = sqrtf(len2);
+                if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+                else { i0 = 0; i1 = 0; }
+                di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
             }
+            ra.f[2].w = i0; rb.f[2].w = i1;
+            row_apply(d, ra, di0);
+            row_apply(d, rb, di1);
         }
     }
     if (!WARM) {
 #pragma unroll
-        for (int k = 0; k < kMaxPts; ++k) {
-            if ((uint32_t)k < np) {
+        for (int k = 0; k < NP; ++k) {
+            if ((uint32_t)k >= np) continue;
 #pragma unroll
-                for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
-            }
+            for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
         }
     }
     if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, d.imA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
     if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, d.imB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
 }
 template <bool WARM>
+DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                           float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
+    if (np > 2) contact_solve_np<WARM, 4>(p, np, rbA, rbB, rw, rcap, bdvw);
+    else contact_solve_np<WARM, 2>(p, np, rbA, rbB, rw, rcap, bdvw);
+}
+struct Split { uint32_t e4, e3, e2; };   // ends of the 4-, 3-, 2-point groups of a colour's sorted range
+DI uint32_t np_of(uint32_t p, const Split &sp) { return p < sp.e4 ? 4u : (p < sp.e3 ? 3u : (p < sp.e2 ? 2u : 1u)); }
+template <bool WARM>
 __global__ void __launch_bounds__(64)
-k_contact_solve(uint32_t start, uint32_t end, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                const uint32_t *__restrict__ rnp, float4 *__restrict__ rw, uint32_t rcap,
-                float4 *__restrict__ bdvw) {
+k_contact_solve(uint32_t start, uint32_t end, Split sp, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdvw);
+    if (p < end) contact_solve_lane<WARM>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
-struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxColours]; };
+struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxColours]; Split split[kMaxColours]; };
 constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
 template <bool WARM>
 __global__ void __launch_bounds__(256)
-k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, const uint32_t *rnp, float4 *rw, uint32_t rcap,
-                     float4 *bdvw) {
+k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM>(p, rbA, rbB, rnp, rw, rcap, bdvw);
+            contact_solve_lane<WARM>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw);
         __threadfence_block();
         __syncthreads();
     }
@@ -774,7 +781,7 @@ static int colour_contacts(edynhip_ctx *c) {
     if (M == 0) { c->num_colours = 0; return EDYNHIP_OK; }
     EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
     EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
-    EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 2 * kMaxColours * sizeof(uint32_t), s));
+    EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     const uint32_t reinsert = c->num_colours >= 2 ? c->num_colours - 1 : kNoColour;
     hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert);
     uint32_t round = 0, total_rounds = 0;
@@ -788,7 +795,7 @@ static int colour_contacts(edynhip_ctx *c) {
     };
     auto sort_and_fetch = [&]() -> int {
         hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals);
-        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
+        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 9));
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
@@ -807,16 +814,26 @@ static int colour_contacts(edynhip_ctx *c) {
             EH_HIP(c, hipStreamSynchronize(s));
             if (total_rounds > 65536) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
         }
-        EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 2 * kMaxColours * sizeof(uint32_t), s));
+        EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
         EH_TRY(sort_and_fetch());
     }
     if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 64 colours");
     c->stats.colour_rounds = total_rounds;
     uint32_t nc = 0, na = 0;
     for (uint32_t k = 0; k < kMaxColours; ++k) {
-        c->colour_start[k] = c->cnt_host->colour_start[k];
-        c->colour_end[k] = c->cnt_host->colour_end[k];
-        if (c->colour_end[k] > c->colour_start[k]) { nc = k + 1; na = c->colour_end[k] > na ? c->colour_end[k] : na; }
+        uint32_t begin = 0xFFFFFFFFu, pos = 0, cnt4[4];
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t a = c->cnt_host->colour_start[4 * k + g], e = c->cnt_host->colour_end[4 * k + g];
+            cnt4[g] = e - a;
+            if (e > a && a < begin) begin = a;
+        }
+        if (begin == 0xFFFFFFFFu) { c->colour_start[k] = c->colour_end[k] = 0; continue; }
+        c->colour_start[k] = begin;
+        pos = begin;
+        for (uint32_t g = 0; g < 3; ++g) { pos += cnt4[g]; c->colour_split[k][g] = pos; }
+        c->colour_end[k] = pos + cnt4[3];
+        nc = k + 1;
+        na = c->colour_end[k] > na ? c->colour_end[k] : na;
     }
     c->num_colours = nc;
     c->num_active = na;
@@ -855,21 +872,26 @@ int solve(edynhip_ctx *c) {
     while (first_tail > 0 && c->colour_end[first_tail - 1] - c->colour_start[first_tail - 1] <= kTailMax) --first_tail;
     if (nc - first_tail >= 2) {
         for (uint32_t k = first_tail; k < nc; ++k)
-            if (c->colour_end[k] > c->colour_start[k]) { tail.start[tail.n] = c->colour_start[k]; tail.end[tail.n] = c->colour_end[k]; ++tail.n; }
+            if (c->colour_end[k] > c->colour_start[k]) {
+                tail.start[tail.n] = c->colour_start[k]; tail.end[tail.n] = c->colour_end[k];
+                tail.split[tail.n] = Split{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
+                ++tail.n;
+            }
     } else first_tail = nc;
     auto contacts_pass = [&](bool warm) {
         for (uint32_t k = 0; k < first_tail; ++k) {
             uint32_t a = c->colour_start[k], e = c->colour_end[k];
             if (e <= a) continue;
             const Rows &r = c->rows;
-            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
-            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
+            const Split sp{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
+            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
             ++launches;
         }
         if (tail.n) {
             const Rows &r = c->rows;
-            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
-            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.np, r.rw, rcap, c->b.dvw);
+            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
             ++launches;
         }
     };
