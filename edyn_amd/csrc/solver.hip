@@ -586,31 +586,25 @@ DI float xchg1(float v) {   // value held by the partner lane (lane ^ 1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
 }
 DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
-DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
-                          float *isl_err, const uint32_t *isl_done) {
-    const uint32_t p = start + (t >> 1);
-    const bool sideB = t & 1;
-    bool active = p < end;
-    uint32_t label = 0;
-    float max_err = 0;
-    // all lanes stay in the code below (no early exit): DPP exchanges need both partners executing
-    const uint32_t pc = active ? p : start;
-    const uint32_t m = rows.order[pc];
-    const uint32_t ia = rows.bA[pc], ib = rows.bB[pc], np = active ? rows.np[pc] : 0;
+template <int NP>
+DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, const Rows &rows, const Manifolds &mf, const Bodies &b,
+                        float *isl_err, const uint32_t *isl_done, uint32_t m, uint32_t ia, uint32_t ib, uint32_t label) {
     const uint32_t ix = sideB ? ib : ia;
-    float4 piv[kMaxPts], l4[kMaxPts], n4[kMaxPts];
+    const float4 *__restrict__ pvsrc = sideB ? mf.pB : mf.pA;
+    float4 piv[NP], l4[NP], n4[NP];
 #pragma unroll
-    for (int k = 0; k < kMaxPts; ++k) {   // all loads up front
+    for (int k = 0; k < NP; ++k) {   // unconditional: slots >= np hold finite stale data that is never used or stored
         const size_t s = (size_t)k * mf.cap + m;
-        if ((uint32_t)k < np) { piv[k] = sideB ? mf.pB[s] : mf.pA[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s]; }
+        piv[k] = pvsrc[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s];
     }
-    label = rows.label[pc];
     PBody X = load_pbody(b, ix);
-    active = active && isl_done[label] == 0;
-    const float sgn = sideB ? -1.0f : 1.0f;
+    // the island's early-out flag is a third-level dependent load (p -> label -> flag): it is consumed only by the
+    // stores, so the arithmetic does not wait for it (a finished island merely computes into registers it drops)
+    const uint32_t done = isl_done[label];
+    float max_err = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxPts; ++k) {
-        if ((uint32_t)k < np && active) {   // uniform within a lane pair
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k < np && in_range) {   // uniform within a lane pair
             const int attach = __float_as_int(n4[k].w);
             const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
             const f3 pOw = xchg1(pXw);
@@ -641,19 +635,33 @@ DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &
             }
         }
     }
-    (void)sgn;
+    const bool active = in_range && done == 0;
     if (active) {
 #pragma unroll
-        for (int k = 0; k < kMaxPts; ++k) {
+        for (int k = 0; k < NP; ++k) {
             const size_t s = (size_t)k * mf.cap + m;
             if ((uint32_t)k < np) {
-                if (!sideB) { float4 a = piv[k]; mf.pA[s] = a; }
+                if (!sideB) mf.pA[s] = piv[k];
                 else mf.nrm[s] = n4[k];
             }
         }
         store_pbody(b, ix, X);
     }
     publish_error(active && !sideB, max_err, label, isl_err);
+}
+DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
+                          float *isl_err, const uint32_t *isl_done) {
+    const uint32_t p = start + (t >> 1);
+    const bool sideB = t & 1;
+    const bool in_range = p < end;
+    // all lanes stay in the code below (no early exit): DPP exchanges and wave reductions need every lane executing
+    const uint32_t pc = in_range ? p : start;
+    const uint32_t m = rows.order[pc];
+    const uint32_t ia = rows.bA[pc], ib = rows.bB[pc], np = in_range ? rows.np[pc] : 0;
+    const uint32_t label = rows.label[pc];
+    // lanes are grouped by point count inside a colour, so a wave takes one branch (except at a group boundary)
+    if (__any(np > 2)) pos_contacts_np<4>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
+    else pos_contacts_np<2>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
 }
 __global__ void __launch_bounds__(128)
 k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
