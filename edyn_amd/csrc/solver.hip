@@ -35,23 +35,28 @@ DI bool is_dynamic(uint32_t flags) { return (flags & BF_KIND_MASK) == EDYNHIP_KI
 DI uint64_t edge_prio(uint32_t e) { return (uint64_t)(0xFFFFFFFFu - e); }
 
 // ------------------------------------------------------------------ islands (lock-free union-find)
-DI uint32_t cc_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// find with path halving: links always point to a smaller index, so storing a grandparent is safe under races
+// Links always point to a SMALLER body index and only ever move towards the root, so any value ever stored in
+// parent[x] is an ancestor of x (or x itself) for the rest of the launch. Plain, possibly stale (per-CU L1 / per-XCD
+// L2) loads are therefore safe for the walks: a stale value is merely a longer path. Only the hook itself must be
+// exact - it is a device-scope compare-and-swap on the true memory value, and on failure the walk continues from the
+// fresh value it returned. (Agent-scope atomic loads here were measured ~8x slower: every step went to the fabric.)
 DI uint32_t cc_find(uint32_t *parent, uint32_t x) {
-    uint32_t p = cc_load(&parent[x]);
+    uint32_t p = parent[x];
     while (p != x) {
-        uint32_t gp = cc_load(&parent[p]);
-        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t gp = parent[p];
+        if (gp != p) parent[x] = gp;   // path halving; racing writers all store ancestors
         x = p; p = gp;
     }
     return x;
 }
 DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
-    for (;;) {
-        uint32_t ra = cc_find(parent, a), rb = cc_find(parent, b);
-        if (ra == rb) return;
-        if (ra < rb) { uint32_t t = ra; ra = rb; rb = t; }   // hook the larger root under the smaller
-        if (atomicCAS(&parent[ra], ra, rb) == ra) return;
+    uint32_t ra = cc_find(parent, a), rb = cc_find(parent, b);
+    while (ra != rb) {
+        if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }   // hook the larger root under the smaller
+        const uint32_t seen = atomicCAS(&parent[ra], ra, rb);
+        if (seen == ra) return;
+        ra = cc_find(parent, seen);   // ra was no longer a root: continue from what it points to now
+        rb = cc_find(parent, rb);
     }
 }
 // Island labels are maintained incrementally; the mode is decided ON THE DEVICE from the broadphase counters
@@ -90,6 +95,20 @@ __global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uin
     if (e >= M) return;
     uint32_t a = bA[e], b = bB[e];
     if (is_dynamic(flags[a]) && is_dynamic(flags[b])) cc_union(island, a, b);
+}
+// Vertex-centric hooking for the full recompute: one lane per body walks the contiguous run of manifolds in which it
+// is the higher-index partner. All unions of one body are issued by one lane in sequence, so lanes do not fight over
+// the same root the way one-lane-per-edge does when a body has 6-12 partners.
+__global__ void k_cc_hook_bodies(uint32_t n, Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags, uint32_t *island,
+                                 const Counters *cnt, uint32_t prev_m, uint32_t force) {
+    if (cc_mode(cnt, prev_m, force) != CC_FULL) return;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || M == 0 || !is_dynamic(flags[i])) return;
+    const uint32_t s0 = mf.seg_start[i], s1 = mf.seg_end[i];
+    for (uint32_t s = s0; s < s1; ++s) {
+        const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
+        if (is_dynamic(flags[lo])) cc_union(island, i, lo);
+    }
 }
 __global__ void k_cc_hook_new(const uint2 *__restrict__ edges, const uint32_t *__restrict__ flags, uint32_t *island,
                               const Counters *cnt, uint32_t prev_m, uint32_t force) {
@@ -773,7 +792,7 @@ int islands(edynhip_ctx *c) {
     const uint32_t pm = c->prev_num_manifolds;
     c->force_islands = false;
     hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.island, c->cnt, pm, force, mf, M, c->b.flags);
-    if (M) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.bodyA, mf.bodyB, c->b.flags, forest, c->cnt, pm, force);
+    if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt, pm, force);
     if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
     hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
     hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
