@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(128)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, const uint64_t *__restrict__ group,
            const uint64_t *__restrict__ mask, const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
-           uint64_t *out, uint32_t cap, Counters *cnt) {
+           uint64_t *out, uint32_t cap, Counters *cnt, uint32_t *visit) {
     __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
     __shared__ uint32_t cand[kCandCap][128];     // candidate bodies per lane
     __shared__ uint64_t wbuf[2][kWaveBuf];       // per-wave staging of emitted pairs
@@ -248,6 +248,7 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     __syncthreads();
     const Emit em{wbuf[wave], &wcount[wave], out, cap, cnt};
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next step (the topology may be reused)
     if (k < n) {
         const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
         const box3 bi = body_box(amin, amax, i);
@@ -345,21 +346,31 @@ int broadphase(edynhip_ctx *c) {
     hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
     uint32_t M = 0;
     if (np > 0) {
+        // The tree TOPOLOGY (Morton order + Karras hierarchy) is rebuilt every kRebuildPeriod steps; in between only the
+        // boxes are refitted. A refitted tree is still a valid BVH (boxes stay conservative) and the exact predicates
+        // run at the leaves, so the pair set is unaffected - only traversal efficiency degrades slowly as bodies move.
+        constexpr uint32_t kRebuildPeriod = 8;
+        const bool rebuild = c->bvh.age == 0;
+        c->bvh.age = (c->bvh.age + 1) % kRebuildPeriod;
+        if (rebuild) {
         hipLaunchKernelGGL(k_bp_bounds, dim3(std::min(blocks(np, 256), 32u)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt);
         hipLaunchKernelGGL(k_bp_morton, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, c->cnt, c->bvh.keys);
         EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 32, 62));   // stable: equal codes keep ascending body order
         if (np > 1)
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
+        }
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt, c->bvh.visit);
         // pair count is needed on the host to size the sort and the manifold kernels
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         M = c->cnt_host->num_pairs;
         { int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb; EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb)); }
-        EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
-        EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
+        if (!c->full_step) {   // inside edynhip_step the previous step's k_finish already cleared these
+            EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
+            EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
+        }
         if (M > 0)
             hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges);
         else if (pm != 0) c->force_islands = true;

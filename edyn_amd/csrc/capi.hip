@@ -287,6 +287,7 @@ static void resolve_timings(edynhip_ctx *c) {
 
 static int run_stages(edynhip_ctx *c, uint32_t mask) {
     c->timer.e = nullptr;
+    c->full_step = mask == EDYNHIP_STAGE_ALL && c->clears_primed;
     if (mask == EDYNHIP_STAGE_ALL) EH_TRY(begin_timed_step(c));
     else c->force_islands = true;   // partial runs (tests) never rely on a previous step's labels
     auto rec = [&](int i) { if (c->timer.e) (void)hipEventRecord(c->timer.e[i], c->stream); };
@@ -298,6 +299,7 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     if (mask & EDYNHIP_STAGE_ISLANDS) EH_TRY(islands(c));
     if (mask & EDYNHIP_STAGE_SOLVE) EH_TRY(solve(c));   // records events 3..9
     rec(10);
+    c->clears_primed = (mask & EDYNHIP_STAGE_SOLVE) != 0;   // k_finish left the next step's scratch cleared
     if (c->timer.e) { c->timer.recorded += 1; c->timer.e = nullptr; }
     return EDYNHIP_OK;
 }
@@ -400,6 +402,7 @@ int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
         if (in->shape_type[i] == EDYNHIP_SHAPE_NONE) continue;
         (in->kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
     }
+    c->bvh.age = 0;
     c->bvh.num_np = (uint32_t)np_list.size();
     c->bvh.num_proc = (uint32_t)proc_list.size();
     np_list.insert(np_list.end(), proc_list.begin(), proc_list.end());
@@ -410,6 +413,7 @@ int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
     for (void *p : tmp) (void)hipFree(p);
     c->num_manifolds = 0;
     c->force_islands = true;
+    c->clears_primed = false;
     c->stats.num_bodies = n;
     if (rc == EDYNHIP_OK) EH_HIP(c, hipGetLastError());
     return rc;
@@ -636,6 +640,7 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     }
     c->num_manifolds = n;
     c->force_islands = true;
+    c->clears_primed = false;
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     if (n == 0) return EDYNHIP_OK;

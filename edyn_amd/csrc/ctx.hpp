@@ -13,6 +13,7 @@ namespace eh {
 
 constexpr uint32_t kNoColour = 0xFFu;
 constexpr uint32_t kMaxColours = 64;
+constexpr uint32_t kMaxContactColours = 63;   // contact colours 0..62: (colour, point count) then fits an 8-bit sort key, 0xFF = inactive
 constexpr int kMaxPts = 4;
 
 // body flags
@@ -97,6 +98,7 @@ struct LBVH {
     uint32_t *visit = nullptr;      // refit counters
     uint32_t *np_list = nullptr;    // shaped non-procedural bodies
     uint32_t num_proc = 0, num_np = 0;
+    uint32_t age = 0;               // steps since the tree topology was last rebuilt (0 = rebuild now)
 };
 
 // Device counters / flags block, mirrored to pinned host memory once or twice per step.
@@ -167,6 +169,8 @@ struct edynhip_ctx {
     uint32_t colour_split[eh::kMaxColours][3] = {{0}};   // ends of the 4-, 3- and 2-point groups inside each colour's range
     uint32_t num_active = 0;
     std::vector<void *> allocs;
+    bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
+    bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
     bool force_islands = true;     // recompute island labels even if the pair set did not change
 };
 

@@ -191,7 +191,7 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
             if (!(da && best_cur[a] != pr) && !(db && best_cur[b] != pr)) {
                 uint64_t busy = (da ? used[a] : 0ull) | (db ? used[b] : 0ull);
                 uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
-                if (c >= kMaxColours) { cnt->colour_overflow = 1; c = kMaxColours - 1; }
+                if (c >= kMaxContactColours) { cnt->colour_overflow = 1; c = kMaxContactColours - 1; }
                 info[m] = (in & 0xFF) | (c << 8);
                 if (da) used[a] |= 1ull << c;
                 if (db) used[b] |= 1ull << c;
@@ -210,14 +210,14 @@ __global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32
     // count from its position alone (no dependent load) and waves are uniform in it
     uint32_t in = info[m];
     uint32_t np = in & 0xFF;
-    keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0x1FFu;
+    keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0xFFu;
     vals[m] = m;
 }
 __global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sorted, Counters *cnt) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= M) return;
     uint32_t c = keys_sorted[p];
-    if (c >= 4 * kMaxColours) return;
+    if (c >= 4 * kMaxContactColours) return;
     if (p == 0 || keys_sorted[p - 1] != c) cnt->colour_start[c] = p;
     if (p == M - 1 || keys_sorted[p + 1] != c) cnt->colour_end[c] = p + 1;
 }
@@ -530,9 +530,10 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
 }
 
 // ------------------------------------------------------------------ integration
-__global__ void k_integrate(uint32_t n, Bodies b, float dt) {
+__global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint32_t *isl_done) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    isl_err[i] = 0; isl_done[i] = 0;   // per-island position-solver state (indexed by island label = a body index)
     if (!is_dynamic(b.flags[i])) return;
     float4 p4 = B_POS(b, i);
     f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
@@ -740,9 +741,11 @@ __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
 }
 
 // ------------------------------------------------------------------ derived state
-__global__ void k_finish(uint32_t n, Bodies b) {
+__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
+    used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
     const uint32_t fl = b.flags[i];
     const uint32_t kind = fl & BF_KIND_MASK;
     if (kind == EDYNHIP_KIND_STATIC) return;
@@ -806,9 +809,11 @@ static int colour_contacts(edynhip_ctx *c) {
     Manifolds &mf = c->m[c->cur];
     c->num_active = 0;
     if (M == 0) { c->num_colours = 0; return EDYNHIP_OK; }
-    EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
-    EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
-    EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
+    if (!c->full_step) {   // inside edynhip_step: `used` was cleared by the previous k_finish, the counters by k_step_reset
+        EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
+        EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
+        EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
+    }
     const uint32_t reinsert = c->num_colours >= 2 ? c->num_colours - 1 : kNoColour;
     hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert);
     uint32_t round = 0, total_rounds = 0;
@@ -822,7 +827,7 @@ static int colour_contacts(edynhip_ctx *c) {
     };
     auto sort_and_fetch = [&]() -> int {
         hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals);
-        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 9));
+        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
@@ -844,7 +849,7 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
         EH_TRY(sort_and_fetch());
     }
-    if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 64 colours");
+    if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 63 contact colours");
     c->stats.colour_rounds = total_rounds;
     uint32_t nc = 0, na = 0;
     for (uint32_t k = 0; k < kMaxColours; ++k) {
@@ -930,12 +935,10 @@ int solve(edynhip_ctx *c) {
     }
     c->timings.solve_velocity_launches += launches;
     rec(c, 6);
-    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt);
+    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done);
     if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
     rec(c, 7);
     if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
-        EH_HIP(c, hipMemsetAsync(c->isl_done, 0, (size_t)n * sizeof(uint32_t), s));
-        EH_HIP(c, hipMemsetAsync(c->isl_err, 0, (size_t)n * sizeof(float), s));
         for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
             for (uint32_t k = 0; k < j.num_colours; ++k) {
                 uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
@@ -950,7 +953,7 @@ int solve(edynhip_ctx *c) {
         }
     }
     rec(c, 8);
-    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b);
+    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end);
     rec(c, 9);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
