@@ -87,6 +87,13 @@ struct Rows {
     uint32_t *bA = nullptr, *bB = nullptr, *np = nullptr;
     uint32_t *label = nullptr;    // island label of the manifold (p-indexed copy: keeps the position kernel's load chain short)
     float4 *rw = nullptr;
+    // "Push" hand-off of the body deltas between consecutive manifolds of a body (used when the scene has no joints):
+    // lane p reads the deltas of its two bodies from its OWN slots dslot[2*(2p+side) + {0,1}] (coalesced, no dependent
+    // gather) and writes the updated deltas into the slots of each body's next manifold in colour order (cyclic).
+    float4 *dslot = nullptr;      // [2 sides][2 float4] per lane p
+    uint32_t *next = nullptr;     // [2p + side] -> slot (2p' + side') of the same body's next manifold in the sweep
+    uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
+    uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;
 

@@ -245,9 +245,10 @@ DI float rel_speed(f3 J0, f3 J1, f3 J2, f3 J3, f3 vA, f3 wA, f3 vB, f3 wB) {
     return dot(J0, vA) + dot(J1, wA) + dot(J2, vB) + dot(J3, wB);
 }
 
-__global__ void k_solve_begin(uint32_t n, Bodies b, float dt) {
+__global__ void k_solve_begin(uint32_t n, Bodies b, float dt, uint32_t *first_slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    first_slot[i] = 0xFFFFFFFFu;
     uint32_t fl = b.flags[i];
     float inv_m = 0;
     if (is_dynamic(fl)) {
@@ -347,10 +348,15 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
 // NP (points of the manifold) is a template parameter: lanes are grouped by point count inside a colour, so a wave
 // runs one instantiation, every loop is fully unrolled without predication and the compiler can issue all
 // 15*NP row loads plus the body loads back to back before the first use (one memory round trip after the indices).
-template <bool WARM, int NP>
+// PUSH = false: body deltas are gathered from / scattered to the body records (bdvw indexed by rbA/rbB).
+// PUSH = true : rbA = nullptr-free variant - deltas arrive in this lane's own slots and leave towards the slots of
+//               each body's next manifold (`rbA` then carries Rows::next, `bdvw` carries Rows::dslot).
+template <bool WARM, int NP, bool PUSH>
 DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                          float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
-    const uint32_t ia = rbA[p], ib = rbB[p];
+    uint32_t ia, ib;   // PUSH: destination slots; else body indices
+    if (PUSH) { ia = rbA[2 * (size_t)p]; ib = rbA[2 * (size_t)p + 1]; }
+    else { ia = rbA[p]; ib = rbB[p]; }
     RowReg R[NP][kRowsPerPoint];
     // slots [0, NP) are loaded unconditionally (slots >= np hold stale but finite rows that are never used or stored);
     // NP is 4 for 3-4 point manifolds and 2 for 1-2 point ones, so at most one slot is fetched in vain
@@ -362,7 +368,8 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
             for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
     Delta d;
     {
-        const float4 va = bdvw[2 * (size_t)ia], wa = bdvw[2 * (size_t)ia + 1], vb = bdvw[2 * (size_t)ib], wb = bdvw[2 * (size_t)ib + 1];
+        const size_t sa = PUSH ? 2 * (size_t)p : ia, sb = PUSH ? 2 * (size_t)p + 1 : ib;
+        const float4 va = bdvw[2 * sa], wa = bdvw[2 * sa + 1], vb = bdvw[2 * sb], wb = bdvw[2 * sb + 1];
         d.dvA = from4(va); d.imA = va.w; d.dwA = from4(wa);
         d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(wb);
     }
@@ -420,33 +427,67 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
     if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, d.imA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
     if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, d.imB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
 }
-template <bool WARM>
+template <bool WARM, bool PUSH>
 DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                            float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
-    if (np > 2) contact_solve_np<WARM, 4>(p, np, rbA, rbB, rw, rcap, bdvw);
-    else contact_solve_np<WARM, 2>(p, np, rbA, rbB, rw, rcap, bdvw);
+    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw);
+    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw);
 }
 struct Split { uint32_t e4, e3, e2; };   // ends of the 4-, 3-, 2-point groups of a colour's sorted range
 DI uint32_t np_of(uint32_t p, const Split &sp) { return p < sp.e4 ? 4u : (p < sp.e3 ? 3u : (p < sp.e2 ? 2u : 1u)); }
-template <bool WARM>
+template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(64)
 k_contact_solve(uint32_t start, uint32_t end, Split sp, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                 float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw);
+    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
 struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxColours]; Split split[kMaxColours]; };
 constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
-template <bool WARM>
+template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(256)
 k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw);
+            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw);
         __threadfence_block();
         __syncthreads();
+    }
+}
+
+// ---- push hand-off: link every (lane, side) to the same body's next manifold in colour order (cyclic) ----
+__global__ void k_push_slots(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ flags) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_active) return;
+    const uint32_t col = keys_sorted[p] >> 2;
+    const uint32_t ia = rows.bA[p], ib = rows.bB[p];
+    if (is_dynamic(flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
+    if (is_dynamic(flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
+}
+__global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_active) return;
+    const uint32_t col = keys_sorted[p] >> 2;
+#pragma unroll
+    for (uint32_t side = 0; side < 2; ++side) {
+        const uint32_t body = side ? rows.bB[p] : rows.bA[p];
+        const uint32_t slot = 2 * p + side;
+        if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
+            rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, 0); rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
+            rows.next[slot] = slot;
+            continue;
+        }
+        const uint64_t mask = used[body];                         // colours of this body's active manifolds
+        const uint64_t above = col >= 63 ? 0ull : mask & ~((2ull << col) - 1ull);
+        const uint32_t nextc = (uint32_t)__ffsll((long long)(above ? above : mask)) - 1;
+        rows.next[slot] = rows.slot_of[(size_t)body * kMaxColours + nextc];
+        if (col == (uint32_t)__ffsll((long long)mask) - 1) {      // the body's first manifold of a sweep: seed the chain
+            rows.first_slot[body] = slot;
+            rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, B_POS(b, body).w);
+            rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -530,15 +571,22 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
 }
 
 // ------------------------------------------------------------------ integration
-__global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint32_t *isl_done) {
+__global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint32_t *isl_done, const float4 *__restrict__ dslot,
+                            const uint32_t *__restrict__ first_slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     isl_err[i] = 0; isl_done[i] = 0;   // per-island position-solver state (indexed by island label = a body index)
     if (!is_dynamic(b.flags[i])) return;
     float4 p4 = B_POS(b, i);
     f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
-    v += from4(B_DV(b, i));
-    w += from4(B_DW(b, i));
+    f3 dv, dw;
+    if (dslot) {   // push hand-off: a sweep leaves each body's deltas in the slots of its first manifold
+        const uint32_t fs = first_slot[i];
+        dv = fs != 0xFFFFFFFFu ? from4(dslot[2 * (size_t)fs]) : mk3(0, 0, 0);
+        dw = fs != 0xFFFFFFFFu ? from4(dslot[2 * (size_t)fs + 1]) : mk3(0, 0, 0);
+    } else { dv = from4(B_DV(b, i)); dw = from4(B_DW(b, i)); }
+    v += dv;
+    w += dw;
     f3 pos = from4(p4);
     pos += v * dt;
     q4 orn = integrate(q_from4(B_ORN(b, i)), w, dt);
@@ -884,9 +932,15 @@ int solve(edynhip_ctx *c) {
     rec(c, 4);
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;
-    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt);
+    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
     if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt);
+    // Without joints every delta hand-off stays inside the contact sweeps: use the push slots (no dependent gathers).
+    const bool push = j.n == 0 && na > 0;
+    if (push) {
+        hipLaunchKernelGGL(k_push_slots, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b.flags);
+        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
+    }
     rec(c, 5);
     uint32_t launches = 0;
     auto joints_pass = [&](bool warm) {
@@ -916,14 +970,26 @@ int solve(edynhip_ctx *c) {
             if (e <= a) continue;
             const Rows &r = c->rows;
             const Split sp{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
-            if (warm) hipLaunchKernelGGL(k_contact_solve<true>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
-            else hipLaunchKernelGGL(k_contact_solve<false>, dim3(blocks(e - a, 64)), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            const dim3 g(blocks(e - a, 64)), bl(64);
+            if (push) {
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot);
+                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot);
+            } else {
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            }
             ++launches;
         }
         if (tail.n) {
             const Rows &r = c->rows;
-            if (warm) hipLaunchKernelGGL(k_contact_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
-            else hipLaunchKernelGGL(k_contact_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            const dim3 g(1), bl(kTailThreads);
+            if (push) {
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot);
+            } else {
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+            }
             ++launches;
         }
     };
@@ -935,7 +1001,7 @@ int solve(edynhip_ctx *c) {
     }
     c->timings.solve_velocity_launches += launches;
     rec(c, 6);
-    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done);
+    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done, push ? c->rows.dslot : nullptr, c->rows.first_slot);
     if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
     rec(c, 7);
     if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
