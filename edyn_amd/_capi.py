@@ -62,7 +62,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_joints", "edynhip_step", "edynhip_run_stages", "edynhip_synchronize", "edynhip_get_state",
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
-           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version"]
+           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies"]
 
 _lib = None
 
@@ -96,6 +96,7 @@ def lib():
         L.edynhip_get_joint_impulses.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
         L.edynhip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.edynhip_debug_collide.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L
     return _lib

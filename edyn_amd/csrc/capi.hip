@@ -85,21 +85,22 @@ struct RawBodies {
     const int32_t *kind; const float *pos, *orn, *linvel, *angvel, *mass, *inertia; const uint8_t *has_inertia;
     const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity;
 };
-__global__ void k_init_bodies(uint32_t n, RawBodies r, Bodies b, float3 default_gravity) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int kind = r.kind[i], st = r.shape_type[i];
-    const f3 pos = mk3(r.pos[3 * i], r.pos[3 * i + 1], r.pos[3 * i + 2]);
-    const q4 orn{r.orn[4 * i], r.orn[4 * i + 1], r.orn[4 * i + 2], r.orn[4 * i + 3]};
-    const float4 sp = make_float4(r.shape_param[4 * i], r.shape_param[4 * i + 1], r.shape_param[4 * i + 2], r.shape_param[4 * i + 3]);
+__global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b, float3 default_gravity) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;   // index into the caller's arrays
+    if (l >= n) return;
+    const uint32_t i = first + l;                                // body index
+    const int kind = r.kind[l], st = r.shape_type[l];
+    const f3 pos = mk3(r.pos[3 * l], r.pos[3 * l + 1], r.pos[3 * l + 2]);
+    const q4 orn{r.orn[4 * l], r.orn[4 * l + 1], r.orn[4 * l + 2], r.orn[4 * l + 3]};
+    const float4 sp = make_float4(r.shape_param[4 * l], r.shape_param[4 * l + 1], r.shape_param[4 * l + 2], r.shape_param[4 * l + 3]);
     float inv_m = 0;
     m3 il = m3_zero(), iw = m3_zero();
     if (kind == EDYNHIP_KIND_DYNAMIC) {
-        const float mass = r.mass[i];
+        const float mass = r.mass[l];
         inv_m = 1.0f / mass;
         m3 I;
-        if (r.has_inertia && r.has_inertia[i]) {
-            const float *p = r.inertia + 9 * i;
+        if (r.has_inertia && r.has_inertia[l]) {
+            const float *p = r.inertia + 9 * l;
             I = {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}};
         } else if (st == dc::SHAPE_BOX) {   // moment_of_inertia.cpp:11-17,179-181
             f3 ext = from4(sp) * 2.0f;
@@ -130,18 +131,18 @@ __global__ void k_init_bodies(uint32_t n, RawBodies r, Bodies b, float3 default_
     B_POS(b, i) = to4(pos, inv_m);
     B_ORN(b, i) = to4(orn);
     const bool moving = kind != EDYNHIP_KIND_STATIC;
-    b.linvel[i] = moving ? make_float4(r.linvel[3 * i], r.linvel[3 * i + 1], r.linvel[3 * i + 2], 0) : make_float4(0, 0, 0, 0);
-    b.angvel[i] = moving ? make_float4(r.angvel[3 * i], r.angvel[3 * i + 1], r.angvel[3 * i + 2], 0) : make_float4(0, 0, 0, 0);
+    b.linvel[i] = moving ? make_float4(r.linvel[3 * l], r.linvel[3 * l + 1], r.linvel[3 * l + 2], 0) : make_float4(0, 0, 0, 0);
+    b.angvel[i] = moving ? make_float4(r.angvel[3 * l], r.angvel[3 * l + 1], r.angvel[3 * l + 2], 0) : make_float4(0, 0, 0, 0);
     B_DV(b, i) = make_float4(0, 0, 0, 0); B_DW(b, i) = make_float4(0, 0, 0, 0);
     B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
     B_IL(b, i, 0) = to4(il.r0, 0); B_IL(b, i, 1) = to4(il.r1, 0); B_IL(b, i, 2) = to4(il.r2, 0);
     b.shape[i] = sp;
-    f3 g = r.gravity ? mk3(r.gravity[3 * i], r.gravity[3 * i + 1], r.gravity[3 * i + 2]) : mk3(default_gravity.x, default_gravity.y, default_gravity.z);
+    f3 g = r.gravity ? mk3(r.gravity[3 * l], r.gravity[3 * l + 1], r.gravity[3 * l + 2]) : mk3(default_gravity.x, default_gravity.y, default_gravity.z);
     b.grav[i] = kind == EDYNHIP_KIND_DYNAMIC ? to4(g, 0) : make_float4(0, 0, 0, 0);
-    b.mat[i] = make_float2(r.friction[i], r.restitution[i]);
+    b.mat[i] = make_float2(r.friction[l], r.restitution[l]);
     b.flags[i] = (uint32_t)kind | ((uint32_t)st << BF_SHAPE_SHIFT);
-    b.group[i] = r.group ? r.group[i] : ~0ull;
-    b.mask[i] = r.mask ? r.mask[i] : ~0ull;
+    b.group[i] = r.group ? r.group[l] : ~0ull;
+    b.mask[i] = r.mask ? r.mask[l] : ~0ull;
     b.island[i] = i;
     // shape_aabb (aabb_util.cpp:11-70)
     f3 mn = pos, mx = pos;
@@ -373,15 +374,15 @@ int edynhip_synchronize(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
-int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
+static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip_bodies *in, const char *who) {
     if (!c || !in) return EDYNHIP_ERR_INVALID;
-    if (n > c->b.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_set_bodies: n > max_bodies");
-    if (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
-        !in->friction || !in->restitution)
-        return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_bodies: missing array");
+    if ((uint64_t)first + n > c->b.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, (std::string(who) + ": more than max_bodies").c_str());
+    if (n && (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
+              !in->friction || !in->restitution))
+        return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] != 0.0f)
-            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, "edynhip_set_bodies: restitution > 0 needs the restitution solver (out of scope)");
+            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": restitution > 0 needs the restitution solver (out of scope)").c_str());
     EH_HIP(c, hipSetDevice(c->device));
     std::vector<void *> tmp;
     RawBodies r{};
@@ -393,18 +394,24 @@ int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
     up(in->shape_type, n, r.shape_type); up(in->shape_param, (size_t)n * 4, r.shape_param);
     up(in->friction, n, r.friction); up(in->restitution, n, r.restitution);
     up(in->group, n, r.group); up(in->mask, n, r.mask); up(in->gravity, (size_t)n * 3, r.gravity);
-    if (rc == EDYNHIP_OK && n) {
-        c->b.n = n;
-        hipLaunchKernelGGL(k_init_bodies, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, r, c->b,
-                           make_float3(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]));
+    const uint32_t total = first + n;
+    if (rc == EDYNHIP_OK) {
+        c->b.n = total;
+        if (n)
+            hipLaunchKernelGGL(k_init_bodies, dim3((n + 255) / 256), dim3(256), 0, c->stream, first, n, r, c->b,
+                               make_float3(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]));
+        c->host_kind.resize(first); c->host_shape.resize(first);
+        c->host_kind.insert(c->host_kind.end(), in->kind, in->kind + n);
+        c->host_shape.insert(c->host_shape.end(), in->shape_type, in->shape_type + n);
     }
     // broadphase participants: [shaped non-procedural ..., shaped procedural ...]
     std::vector<uint32_t> np_list, proc_list;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (in->shape_type[i] == EDYNHIP_SHAPE_NONE) continue;
-        (in->kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
-    }
-    c->bvh.age = 0;
+    if (rc == EDYNHIP_OK)
+        for (uint32_t i = 0; i < total; ++i) {
+            if (c->host_shape[i] == EDYNHIP_SHAPE_NONE) continue;
+            (c->host_kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
+        }
+    c->bvh.age = 0;   // the tree topology is rebuilt on the next step
     c->bvh.num_np = (uint32_t)np_list.size();
     c->bvh.num_proc = (uint32_t)proc_list.size();
     np_list.insert(np_list.end(), proc_list.begin(), proc_list.end());
@@ -413,12 +420,19 @@ int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
                  ? EDYNHIP_OK : set_error(c, EDYNHIP_ERR_HIP, "upload broadphase lists");
     (void)hipStreamSynchronize(c->stream);
     for (void *p : tmp) (void)hipFree(p);
-    c->num_manifolds = 0;
+    if (first == 0) c->num_manifolds = 0;   // appended bodies keep every index stable, so existing manifolds stay valid
     c->force_islands = true;
     c->clears_primed = false;
-    c->stats.num_bodies = n;
+    c->stats.num_bodies = total;
     if (rc == EDYNHIP_OK) EH_HIP(c, hipGetLastError());
     return rc;
+}
+
+int edynhip_set_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) { return load_bodies(c, 0, n, in, "edynhip_set_bodies"); }
+
+int edynhip_add_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    return load_bodies(c, c->b.n, n, in, "edynhip_add_bodies");
 }
 
 int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
@@ -682,6 +696,13 @@ int edynhip_get_joint_impulses(edynhip_ctx *c, float *out) {
     for (uint32_t p = 0; p < n; ++p)
         for (int r = 0; r < 5; ++r) out[5 * orig[p] + r] = imp[(size_t)r * c->j.cap + p];
     return EDYNHIP_OK;
+}
+
+int edynhip_debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *shape_type, const float *shape_param, const float *pos,
+                          const float *orn, float threshold, float *out_points, uint32_t *out_count) {
+    if (!c || (n && (!shape_type || !shape_param || !pos || !orn || !out_points || !out_count))) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    return debug_collide(c, n, shape_type, shape_param, pos, orn, threshold, out_points, out_count);
 }
 
 int edynhip_get_timings(edynhip_ctx *c, edynhip_timings *out) {

@@ -179,6 +179,7 @@ struct edynhip_ctx {
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
     bool force_islands = true;     // recompute island labels even if the pair set did not change
+    std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
 };
 
 namespace eh {
@@ -186,6 +187,8 @@ namespace eh {
 int broadphase(edynhip_ctx *c);
 int narrowphase(edynhip_ctx *c);
 int count_points(edynhip_ctx *c);
+int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
+                  float *out, uint32_t *count);
 int islands(edynhip_ctx *c);
 int solve(edynhip_ctx *c);
 // sort helpers (sort.hip)

@@ -211,6 +211,47 @@ int count_points(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
+__global__ void k_debug_collide(uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
+                                const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ctx ctx{mk3(pos[6 * i], pos[6 * i + 1], pos[6 * i + 2]), q_from4(orn[2 * i]), mk3(pos[6 * i + 3], pos[6 * i + 4], pos[6 * i + 5]),
+            q_from4(orn[2 * i + 1]), threshold};
+    CResult r;
+    collide(st[2 * i], sp[2 * i], st[2 * i + 1], sp[2 * i + 1], ctx, r);
+    count[i] = (uint32_t)r.num;
+    for (int k = 0; k < r.num; ++k) {
+        float *o = out + ((size_t)i * 4 + k) * 11;
+        o[0] = r.pt[k].pivotA.x; o[1] = r.pt[k].pivotA.y; o[2] = r.pt[k].pivotA.z;
+        o[3] = r.pt[k].pivotB.x; o[4] = r.pt[k].pivotB.y; o[5] = r.pt[k].pivotB.z;
+        o[6] = r.pt[k].normal.x; o[7] = r.pt[k].normal.y; o[8] = r.pt[k].normal.z;
+        o[9] = r.pt[k].distance; o[10] = (float)r.pt[k].attachment;
+    }
+}
+int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
+                  float *out, uint32_t *count) {
+    if (n == 0) return EDYNHIP_OK;
+    int32_t *d_st; float4 *d_sp; float *d_pos; float4 *d_orn; float *d_out; uint32_t *d_cnt;
+    EH_HIP(c, hipMalloc((void **)&d_st, (size_t)n * 8)); EH_HIP(c, hipMalloc((void **)&d_sp, (size_t)n * 32));
+    EH_HIP(c, hipMalloc((void **)&d_pos, (size_t)n * 24)); EH_HIP(c, hipMalloc((void **)&d_orn, (size_t)n * 32));
+    EH_HIP(c, hipMalloc((void **)&d_out, (size_t)n * 44 * 4)); EH_HIP(c, hipMalloc((void **)&d_cnt, (size_t)n * 4));
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d_st, st, (size_t)n * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sp, sp, (size_t)n * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_orn, orn, (size_t)n * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * 44 * 4, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_collide, dim3((n + 63) / 64), dim3(64), 0, s, n, d_st, d_sp, d_pos, d_orn, threshold, d_out, d_cnt);
+        e = hipMemcpyAsync(out, d_out, (size_t)n * 44 * 4, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(count, d_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_st); (void)hipFree(d_sp); (void)hipFree(d_pos); (void)hipFree(d_orn); (void)hipFree(d_out); (void)hipFree(d_cnt);
+    if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_debug_collide", e);
+    return EDYNHIP_OK;
+}
+
 int narrowphase(edynhip_ctx *c) {
     const uint32_t M = c->num_manifolds;
     if (M == 0) return EDYNHIP_OK;

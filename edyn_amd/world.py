@@ -131,12 +131,8 @@ class World:
         self._dirty = True
         return len(self._joints) - 1
 
-    def set_scene(self, scene):
-        """Bulk scene upload from a dict of arrays (see edyn_amd.scenes)."""
+    def _body_arrays(self, scene):
         n = len(scene["kind"])
-        joints = scene.get("joints") or []
-        if self._h is None:
-            self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
         a = {}
         a["kind"] = np.ascontiguousarray(scene["kind"], np.int32)
         for k, w in (("pos", 3), ("orn", 4), ("linvel", 3), ("angvel", 3), ("shape_param", 4)):
@@ -157,8 +153,9 @@ class World:
         b = _capi.Bodies()
         for f, _ in _capi.Bodies._fields_:
             setattr(b, f, _ptr(a.get(f)))
-        self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
-        self.n = n
+        return n, a, b   # `a` keeps the arrays alive while `b` points into them
+
+    def _upload_joints(self, joints):
         self.nj = len(joints)
         if joints:
             jt = np.array([j[0] for j in joints], np.int32)
@@ -169,12 +166,44 @@ class World:
             self._check(self._L.edynhip_set_joints(self._h, len(joints), C.byref(js)))
         else:
             self._check(self._L.edynhip_set_joints(self._h, 0, None))
+
+    def set_scene(self, scene):
+        """Bulk scene upload from a dict of arrays (see edyn_amd.scenes). Replaces the whole world."""
+        joints = scene.get("joints") or []
+        n, keep, b = self._body_arrays(scene)
+        if self._h is None:
+            self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
+        self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
+        self.n = n
+        self._upload_joints(joints)
+        self._uploaded = (n, len(joints))
         self._dirty = False
+
+    def add_scene(self, scene):
+        """Append the bodies of `scene` to a running world (contact manifolds and cached impulses of the existing bodies
+        are kept). Returns the index of the first new body. Joints in `scene` are ignored here."""
+        n, keep, b = self._body_arrays(scene)
+        if self._h is None:
+            raise EdynHipError(-1, "add_scene needs an attached world (call set_scene or attach first)")
+        first = self.n
+        self._check(self._L.edynhip_add_bodies(self._h, n, C.byref(b)))
+        self.n += n
+        return first
 
     def _flush_defs(self):
         if not self._dirty:
             return
         from .scenes import scene_from_defs
+        up_b, up_j = getattr(self, "_uploaded", (0, 0))
+        if self._h is not None and 0 < up_b <= len(self._defs) and self.n == up_b:
+            # bodies were only appended since the last upload: keep the running contact state
+            if len(self._defs) > up_b:
+                self.add_scene(scene_from_defs(self._defs[up_b:], []))
+            if len(self._joints) != up_j:
+                self._upload_joints(self._joints)
+            self._uploaded = (len(self._defs), len(self._joints))
+            self._dirty = False
+            return
         self.set_scene(scene_from_defs(self._defs, self._joints))
 
     # ---- stepping (stepper_sequential.cpp:28-147)
@@ -262,6 +291,19 @@ class World:
         if self.nj:
             self._check(self._L.edynhip_get_joint_impulses(self._h, _ptr(out)))
         return out
+
+    def debug_collide(self, shape_type, shape_param, pos, orn, threshold=0.01):
+        """Device collide() on n independent shape pairs: returns (points[n,4,11], count[n])."""
+        st = np.ascontiguousarray(shape_type, np.int32).reshape(-1, 2)
+        n = len(st)
+        sp = np.ascontiguousarray(shape_param, np.float32).reshape(n, 2, 4)
+        ps = np.ascontiguousarray(pos, np.float32).reshape(n, 2, 3)
+        qs = np.ascontiguousarray(orn, np.float32).reshape(n, 2, 4)
+        out = np.zeros((n, 4, 11), np.float32); cnt = np.zeros(n, np.uint32)
+        if self._h is None:
+            self.attach(1)
+        self._check(self._L.edynhip_debug_collide(self._h, n, _ptr(st), _ptr(sp), _ptr(ps), _ptr(qs), threshold, _ptr(out), _ptr(cnt)))
+        return out, cnt
 
     def get_timings(self):
         t = _capi.Timings()

@@ -119,7 +119,8 @@ struct gpu_stepper {
     std::vector<entt::entity> constraints;
     bool scene_dirty{true}, state_dirty{false}, paused{false};
     double accumulated{0}, last_time{0};
-    unsigned capacity{0};
+    unsigned capacity{0}, joint_capacity{0};
+    unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
 };
 struct body_index { uint32_t value; };
@@ -129,14 +130,16 @@ inline void check(gpu_stepper &s, int rc) {
 }
 
 inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
-    const uint32_t n = (uint32_t)s.bodies.size();
-    if (!s.ctx || n > s.capacity) {
+    const uint32_t total = (uint32_t)s.bodies.size();
+    const uint32_t nj = (uint32_t)s.constraints.size();
+    if (!s.ctx || total > s.capacity || nj > s.joint_capacity) {
         if (s.ctx) { edynhip_destroy(s.ctx); s.ctx = nullptr; }
+        s.uploaded_bodies = s.uploaded_constraints = 0;
         edynhip_config c{};
         c.device = s.cfg.device;
-        c.max_bodies = s.cfg.max_bodies ? s.cfg.max_bodies : n + n / 4 + 16;
+        c.max_bodies = s.cfg.max_bodies ? s.cfg.max_bodies : total + total / 4 + 16;
         c.max_manifolds = s.cfg.max_manifolds;
-        c.max_joints = (uint32_t)s.constraints.size() + 16;
+        c.max_joints = nj + nj / 4 + 16;
         c.fixed_dt = s.cfg.fixed_dt;
         c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
@@ -144,14 +147,16 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
-        s.capacity = c.max_bodies;
+        s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
     }
+    // Bodies created since the last upload are appended (edynhip_add_bodies): the running contact state of the others stays.
+    const uint32_t first = s.uploaded_bodies, n = total - first;
     std::vector<int32_t> kind(n), stype(n);
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
     std::vector<uint8_t> hasI(n, 0);
     std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
     for (uint32_t i = 0; i < n; ++i) {
-        const entt::entity e = s.bodies[i];
+        const entt::entity e = s.bodies[first + i];
         kind[i] = registry.all_of<dynamic_tag>(e) ? EDYNHIP_KIND_DYNAMIC : registry.all_of<kinematic_tag>(e) ? EDYNHIP_KIND_KINEMATIC : EDYNHIP_KIND_STATIC;
         const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
@@ -173,8 +178,10 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     }
     edynhip_bodies b{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
                      fr.data(), re.data(), grp.data(), msk.data(), g.data()};
-    check(s, edynhip_set_bodies(s.ctx, n, &b));
-    const uint32_t nj = (uint32_t)s.constraints.size();
+    if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
+    else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
+    s.uploaded_bodies = total;
+    if (first != 0 && nj == s.uploaded_constraints) { s.scene_dirty = false; return; }
     std::vector<int32_t> jt(nj); std::vector<uint32_t> jb(2 * nj); std::vector<float> jp(6 * nj), ja(6 * nj, 0.f);
     for (uint32_t j = 0; j < nj; ++j) {
         const entt::entity e = s.constraints[j];
@@ -193,7 +200,9 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     }
     edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data()};
     check(s, edynhip_set_joints(s.ctx, nj, nj ? &js : nullptr));
-    s.scene_dirty = false; s.state_dirty = false;
+    s.uploaded_constraints = nj;
+    s.scene_dirty = false;
+    if (first == 0) s.state_dirty = false;
 }
 
 inline void upload_state(entt::registry &registry, gpu_stepper &s) {

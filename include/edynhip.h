@@ -145,6 +145,12 @@ int edynhip_set_stream(edynhip_ctx *ctx, void *hip_stream);
 
 int edynhip_set_bodies(edynhip_ctx *ctx, uint32_t n, const edynhip_bodies *bodies);
 int edynhip_set_joints(edynhip_ctx *ctx, uint32_t n, const edynhip_joints *joints);
+/* Append `n` bodies after the existing ones (indices num_bodies .. num_bodies+n-1). Existing bodies, their contact
+ * manifolds (cached impulses, colours) and joints are untouched: this is registry.create + make_rigidbody on a running
+ * world (src/edyn/util/rigidbody.cpp:18-161; the reference's island worker receives the new entities through
+ * registry_operation insertions, src/edyn/simulation/simulation_worker.cpp). Removal is not supported without a
+ * full edynhip_set_bodies (indices would shift). */
+int edynhip_add_bodies(edynhip_ctx *ctx, uint32_t n, const edynhip_bodies *bodies);
 
 /* Advance `nsteps` fixed-dt steps. Returns after the work is enqueued and error flags were checked. */
 int edynhip_step(edynhip_ctx *ctx, uint32_t nsteps);
@@ -166,6 +172,13 @@ int edynhip_set_manifolds(edynhip_ctx *ctx, const edynhip_manifold *in, uint32_t
 /* Canonical broadphase pairs: keys[i] = (max(body)<<32 | min(body)), ascending. */
 int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint32_t *n);
 int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses5);
+
+/* Test hook: run the device closest-feature routine on `n` independent shape pairs (no world state involved).
+ * shape_type[n][2], shape_param[n][2][4], pos[n][2][3], orn[n][2][4]; out_points[n][4][11] =
+ * (pivotA3, pivotB3, normal3, distance, attachment) per point, out_count[n]. Replaces nothing in the reference: it
+ * exposes edyn::collide(shA, shB, ctx, result) (include/edyn/collision/collide.hpp) for parity tests. */
+int edynhip_debug_collide(edynhip_ctx *ctx, uint32_t n, const int32_t *shape_type, const float *shape_param, const float *pos,
+                          const float *orn, float threshold, float *out_points, uint32_t *out_count);
 
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);

@@ -285,3 +285,17 @@ class World:
         self.L.orc_get_stats(self.h, s.ctypes.data_as(C.POINTER(C.c_uint32)))
         return dict(zip(["num_manifolds", "num_points", "num_rows", "num_islands", "num_colours",
                          "num_joint_colours", "colour_rounds"], [int(x) for x in s]))
+
+
+def collide_batch(shape_type, shape_param, pos, orn, threshold=0.01):
+    st = np.ascontiguousarray(shape_type, np.int32).reshape(-1, 2)
+    n = len(st)
+    sp = np.ascontiguousarray(shape_param, np.float32).reshape(n, 2, 4)
+    ps = np.ascontiguousarray(pos, np.float32).reshape(n, 2, 3)
+    qs = np.ascontiguousarray(orn, np.float32).reshape(n, 2, 4)
+    out = np.zeros((n, 4, 11), np.float32); cnt = np.zeros(n, np.uint32)
+    f = lib().orc_collide_batch
+    f.argtypes = [C.c_uint32] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(n, st.ctypes.data, sp.ctypes.data, ps.ctypes.data, qs.ctypes.data, threshold, out.ctypes.data, cnt.ctypes.data)
+    return out, cnt

@@ -219,3 +219,11 @@ int orc_should_collide(uint64_t groupA, uint64_t maskA, uint64_t groupB, uint64_
 uint32_t orc_sizeof_manifold_rec() { return (uint32_t)sizeof(orc_manifold_rec); }
 
 }  // extern "C"
+
+// Batch form of orc_collide for the randomized device-vs-oracle narrowphase test.
+extern "C" void orc_collide_batch(uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
+                                  float *out, uint32_t *count) {
+    for (uint32_t i = 0; i < n; ++i)
+        count[i] = (uint32_t)orc_collide(st[2 * i], sp + 8 * i, pos + 6 * i, orn + 8 * i, st[2 * i + 1], sp + 8 * i + 4, pos + 6 * i + 3,
+                                         orn + 8 * i + 4, threshold, out + (size_t)i * 44);
+}

@@ -276,3 +276,134 @@ def test_headline_scene_properties_and_determinism():
         assert all((ni[m["num_points"] > k, k] >= 0).all() for k in range(4))  # contacts only push
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])   # bit-reproducible
     assert np.array_equal(runs[0][2], runs[1][2])
+
+
+# ------------------------------------------------------------------ closest-feature routines, pair by pair
+def _random_quats(rng, n, snap_fraction=0.3):
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    # a share of exactly axis-aligned / 45-degree / 90-degree orientations: the degenerate SAT cases (parallel faces and
+    # edges) are where the feature-selection branches of box_box differ most
+    special = np.array([[0, 0, 0, 1], [0, 0.70710678, 0, 0.70710678], [0.38268343, 0, 0, 0.92387953],
+                        [0, 0, 0.70710678, 0.70710678], [0.5, 0.5, 0.5, 0.5]], np.float32)
+    pick = rng.random(n) < snap_fraction
+    q[pick] = special[rng.integers(0, len(special), pick.sum())]
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    return q.astype(np.float32)
+
+
+def _pair_batch(rng, n, tA, tB):
+    """n shape pairs placed so that a good share are within the contact threshold of each other."""
+    st = np.empty((n, 2), np.int32); st[:, 0] = tA; st[:, 1] = tB
+    sp = np.zeros((n, 2, 4), np.float32)
+    pos = np.zeros((n, 2, 3), np.float32)
+    orn = np.stack([_random_quats(rng, n), _random_quats(rng, n)], axis=1)
+    reach = np.zeros((n, 2), np.float32)
+    for side, t in enumerate((tA, tB)):
+        if t == scenes.SHAPE_BOX:
+            h = rng.uniform(0.1, 0.6, size=(n, 3)).astype(np.float32)
+            if side == 1:   # equal boxes in a share of the pairs (stacked-brick degeneracy)
+                same = rng.random(n) < 0.3
+                h[same] = sp[same, 0, :3] if tA == scenes.SHAPE_BOX else h[same]
+            sp[:, side, :3] = h
+            reach[:, side] = h.min(axis=1) + rng.random(n).astype(np.float32) * (np.linalg.norm(h, axis=1) - h.min(axis=1))
+        elif t == scenes.SHAPE_SPHERE:
+            sp[:, side, 0] = rng.uniform(0.1, 0.5, size=n)
+            reach[:, side] = sp[:, side, 0]
+        else:   # plane through a random offset with a random (or +Y) normal
+            nrm = rng.normal(size=(n, 3)).astype(np.float32)
+            nrm[rng.random(n) < 0.5] = (0, 1, 0)
+            nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+            sp[:, side, :3] = nrm
+            sp[:, side, 3] = rng.uniform(-0.5, 0.5, size=n)
+            orn[:, side] = (0, 0, 0, 1)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    snap = rng.random(n) < 0.4
+    axes = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n)] * rng.choice(np.float32([-1, 1]), size=(n, 1))
+    d[snap] = axes[snap]
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    gap = rng.uniform(-0.08, 0.04, size=n).astype(np.float32)
+    pos[:, 0] = rng.uniform(-2, 2, size=(n, 3))
+    if tB == scenes.SHAPE_PLANE:
+        pos[:, 1] = 0
+        nrm = sp[:, 1, :3]
+        pos[:, 0] = nrm * (sp[:, 1, 3:4] + reach[:, 0:1] + gap[:, None]) + np.cross(nrm, d) * 2
+    elif tA == scenes.SHAPE_PLANE:
+        pos[:, 0] = 0
+        nrm = sp[:, 0, :3]
+        pos[:, 1] = nrm * (sp[:, 0, 3:4] + reach[:, 1:2] + gap[:, None]) + np.cross(nrm, d) * 2
+    else:
+        pos[:, 1] = pos[:, 0] + d * (reach[:, 0] + reach[:, 1] + gap)[:, None]
+    return st, sp, pos.astype(np.float32), orn.astype(np.float32)
+
+
+@pytest.mark.parametrize("tA,tB", [
+    (scenes.SHAPE_BOX, scenes.SHAPE_BOX), (scenes.SHAPE_SPHERE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_SPHERE),
+    (scenes.SHAPE_SPHERE, scenes.SHAPE_SPHERE), (scenes.SHAPE_BOX, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_BOX),
+    (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE)])
+def test_collide_routines_bit_exact_on_random_pairs(tA, tB):
+    """200k random pairs per shape combination through the device collide() (edynhip_debug_collide) and the oracle's:
+    point counts, pivots, normals, distances and normal attachments must be identical bit for bit."""
+    rng = np.random.default_rng(1000 + 10 * tA + tB)
+    n = 200_000
+    st, sp, pos, orn = _pair_batch(rng, n, tA, tB)
+    w = edyn_amd.World(edyn_amd.init_config())
+    gp, gc = w.debug_collide(st, sp, pos, orn, threshold=0.02)
+    op, oc = ob.collide_batch(st, sp, pos, orn, threshold=0.02)
+    assert np.array_equal(gc, oc)
+    assert (gc > 0).mean() > 0.15, "generator must produce a meaningful share of touching pairs"
+    if tA == scenes.SHAPE_BOX and tB == scenes.SHAPE_BOX:
+        assert set(np.unique(gc)) == {0, 1, 2, 3, 4}
+    assert np.array_equal(gp.view(np.uint32), op.view(np.uint32))
+
+
+# ------------------------------------------------------------------ bodies appended to a running world
+def _shifted(scene, dy, keep_static=False):
+    s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    sel = slice(None) if keep_static else (s["kind"] == scenes.KIND_DYNAMIC)
+    for k in ("kind", "pos", "orn", "linvel", "angvel", "mass", "shape_type", "shape_param", "friction", "restitution", "group", "mask"):
+        s[k] = s[k][sel]
+    s["pos"] = s["pos"] + np.float32([0, dy, 0])
+    s.pop("joints", None); s.pop("inertia", None); s.pop("has_inertia", None)
+    return s
+
+
+def test_append_bodies_keeps_contact_state_and_matches_oracle():
+    """make_rigidbody on a running world (edynhip_add_bodies): the settled pile keeps its manifolds and cached impulses, the
+    dropped bricks land on it, and everything matches the oracle given the same sequence of calls, bit for bit."""
+    base = scenes.box_pile(4, 4, 4)
+    extra = _shifted(scenes.box_pile(3, 2, 3), 6.0)
+    g = gpu_world(base, max_bodies=256); o = oracle_world(base)
+    g.step_simulation(40); o.step(40)
+    before = g.get_manifolds()
+    assert before["pt"]["normal_impulse"].max() > 0
+    first = g.add_scene(extra); o.add_bodies(extra)
+    assert first == len(base["kind"]) and g.n == first + len(extra["kind"])
+    after = g.get_manifolds()
+    assert np.array_equal(before.view(np.uint8), after.view(np.uint8)), "appending must not touch existing manifolds"
+    for step in range(80):
+        g.step_simulation(1); o.step(1)
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="after append")
+    # the new bricks really interact with the old ones
+    m = g.get_manifolds()
+    assert ((m["body"].min(axis=1) < first) & (m["body"].max(axis=1) >= first) & (m["body"].min(axis=1) > 0)).any()
+    with pytest.raises(edyn_amd.EdynHipError):
+        g.add_scene(_shifted(scenes.box_pile(6, 6, 6), 20.0))   # beyond max_bodies
+
+
+def test_make_rigidbody_after_update_appends():
+    w = edyn_amd.World(edyn_amd.init_config(max_bodies=16))
+    w.make_rigidbody(edyn_amd.rigidbody_def(kind=scenes.KIND_STATIC, shape_type=scenes.SHAPE_PLANE, shape_param=(0, 1, 0, 0)))
+    w.make_rigidbody(edyn_amd.rigidbody_def(position=(0, 0.5, 0), shape_type=scenes.SHAPE_BOX, shape_param=(0.5, 0.5, 0.5, 0)))
+    w.step_simulation(31)
+    imp = w.get_manifolds()["pt"]["normal_impulse"][:, 0].copy()
+    assert imp.max() > 0
+    b2 = w.make_rigidbody(edyn_amd.rigidbody_def(position=(0, 1.5, 0), shape_type=scenes.SHAPE_BOX, shape_param=(0.5, 0.5, 0.5, 0)))
+    w.step_simulation()
+    m = w.get_manifolds()
+    assert w.n == 3 and b2 == 2
+    ground = m[(m["body"].min(axis=1) == 0) & (m["body"].max(axis=1) == 1)]
+    assert len(ground) == 1 and ground["pt"]["normal_impulse"][0, 0] > 0.5 * imp.max(), "warm start of the old contact survived"
+    w.step_simulation(60)
+    assert abs(w.get_state()[0][2, 1] - 1.5) < 0.02
