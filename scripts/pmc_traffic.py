@@ -13,7 +13,7 @@ def per_kernel(path, counter, pat):
 fetch_dir, write_dir, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 out = {"workload": workload, "kernels": {}}
 tot_launch = tot_bytes = 0
-for pat in ("k_contact_solve<false>", "k_contact_solve<true>", "k_contact_solve_tail"):
+for pat in ("k_contact_solve<false", "k_contact_solve<true", "k_contact_solve_tail"):   # <WARM, PUSH> instantiations
     nf, f = per_kernel(fetch_dir, "FETCH_SIZE", pat)
     nw, w = per_kernel(write_dir, "WRITE_SIZE", pat)
     if nf == 0: continue
