@@ -365,6 +365,7 @@ int broadphase(edynhip_ctx *c) {
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
+        if (c->cnt_host->df_abort) return set_error(c, EDYNHIP_ERR_INTERNAL, "dataflow solve: a hand-off never arrived in the previous step (workgroups not co-resident?)");
         M = c->cnt_host->num_pairs;
         { int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb; EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb)); }
         if (!c->full_step) {   // inside edynhip_step the previous step's k_finish already cleared these

@@ -91,11 +91,14 @@ struct Rows {
     // lane p reads the deltas of its two bodies from its OWN slots dslot[2*(2p+side) + {0,1}] (coalesced, no dependent
     // gather) and writes the updated deltas into the slots of each body's next manifold in colour order (cyclic).
     float4 *dslot = nullptr;      // [2 sides][2 float4] per lane p
-    uint32_t *next = nullptr;     // [2p + side] -> slot (2p' + side') of the same body's next manifold in the sweep
+    uint32_t *next = nullptr;     // [2p + side] -> slot (2p' + side') of the same body's next manifold in the sweep;
+                                  // bit 31 (kHeadBit) marks THIS slot as the head of its body's chain
+    float *im = nullptr;          // [2p + side] inverse mass of that side's body (0 = read-only body: no hand-off)
     uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;
+constexpr uint32_t kHeadBit = 0x80000000u, kSlotMask = 0x7FFFFFFFu;
 
 struct LBVH {
     uint64_t *keys = nullptr, *keys_sorted = nullptr;   // morton<<32 | body
@@ -120,6 +123,7 @@ struct Counters {
     uint32_t pairs_changed;      // this step's pair set differs from the previous step's
     uint32_t num_found;          // new manifolds that already existed last step (== previous count <=> none removed)
     uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
+    uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
     uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];
@@ -178,6 +182,8 @@ struct edynhip_ctx {
     std::vector<void *> allocs;
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
+    int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
+    uint32_t df_lanes = 0;         // resident lanes of the dataflow kernel (grid stride)
     bool force_islands = true;     // recompute island labels even if the pair set did not change
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
 };

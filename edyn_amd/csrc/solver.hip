@@ -351,13 +351,8 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
 // PUSH = false: body deltas are gathered from / scattered to the body records (bdvw indexed by rbA/rbB).
 // PUSH = true : rbA = nullptr-free variant - deltas arrive in this lane's own slots and leave towards the slots of
 //               each body's next manifold (`rbA` then carries Rows::next, `bdvw` carries Rows::dslot).
-template <bool WARM, int NP, bool PUSH>
-DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                         float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
-    uint32_t ia, ib;   // PUSH: destination slots; else body indices
-    if (PUSH) { ia = rbA[2 * (size_t)p]; ib = rbA[2 * (size_t)p + 1]; }
-    else { ia = rbA[p]; ib = rbB[p]; }
-    RowReg R[NP][kRowsPerPoint];
+template <int NP>
+DI void rows_load(RowReg (&R)[NP][kRowsPerPoint], const float4 *__restrict__ rw, uint32_t rcap, uint32_t p) {
     // slots [0, NP) are loaded unconditionally (slots >= np hold stale but finite rows that are never used or stored);
     // NP is 4 for 3-4 point manifolds and 2 for 1-2 point ones, so at most one slot is fetched in vain
 #pragma unroll
@@ -366,13 +361,10 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
         for (int r = 0; r < kRowsPerPoint; ++r)
 #pragma unroll
             for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
-    Delta d;
-    {
-        const size_t sa = PUSH ? 2 * (size_t)p : ia, sb = PUSH ? 2 * (size_t)p + 1 : ib;
-        const float4 va = bdvw[2 * sa], wa = bdvw[2 * sa + 1], vb = bdvw[2 * sb], wb = bdvw[2 * sb + 1];
-        d.dvA = from4(va); d.imA = va.w; d.dwA = from4(wa);
-        d.dvB = from4(vb); d.imB = vb.w; d.dwB = from4(wb);
-    }
+}
+// One manifold's share of a sweep: its normal rows, then its friction pairs, in contact-list order.
+template <bool WARM, int NP>
+DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if ((uint32_t)k >= np) continue;
@@ -416,31 +408,53 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
             row_apply(d, rb, di1);
         }
     }
-    if (!WARM) {
+}
+template <int NP>
+DI void rows_store_impulses(const RowReg (&R)[NP][kRowsPerPoint], float4 *__restrict__ rw, uint32_t rcap, uint32_t p, uint32_t np) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if ((uint32_t)k >= np) continue;
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
 #pragma unroll
-            for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
-        }
+        for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
     }
-    if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, d.imA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
-    if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, d.imB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
+}
+template <bool WARM, int NP, bool PUSH>
+DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
+                         float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
+    uint32_t ia, ib;   // PUSH: destination slots; else body indices
+    if (PUSH) { ia = rbA[2 * (size_t)p] & kSlotMask; ib = rbA[2 * (size_t)p + 1] & kSlotMask; }
+    else { ia = rbA[p]; ib = rbB[p]; }
+    RowReg R[NP][kRowsPerPoint];
+    rows_load<NP>(R, rw, rcap, p);
+    Delta d;
+    {
+        const size_t sa = PUSH ? 2 * (size_t)p : ia, sb = PUSH ? 2 * (size_t)p + 1 : ib;
+        const float4 va = bdvw[2 * sa], wa = bdvw[2 * sa + 1], vb = bdvw[2 * sb], wb = bdvw[2 * sb + 1];
+        d.dvA = from4(va); d.dwA = from4(wa);
+        d.dvB = from4(vb); d.dwB = from4(wb);
+        if (PUSH) { d.imA = im[2 * (size_t)p]; d.imB = im[2 * (size_t)p + 1]; }   // slot .w lanes carry hand-off tags
+        else { d.imA = va.w; d.imB = vb.w; }
+    }
+    rows_solve<WARM, NP>(d, R, np);
+    if (!WARM) rows_store_impulses<NP>(R, rw, rcap, p, np);
+    const float wA = PUSH ? 0.0f : d.imA, wB = PUSH ? 0.0f : d.imB;
+    if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, wA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, wB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
 }
 template <bool WARM, bool PUSH>
 DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                           float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
-    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw);
-    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw);
+                           float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
+    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im);
+    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im);
 }
 struct Split { uint32_t e4, e3, e2; };   // ends of the 4-, 3-, 2-point groups of a colour's sorted range
 DI uint32_t np_of(uint32_t p, const Split &sp) { return p < sp.e4 ? 4u : (p < sp.e3 ? 3u : (p < sp.e2 ? 2u : 1u)); }
 template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(64)
 k_contact_solve(uint32_t start, uint32_t end, Split sp, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw) {
+                float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw);
+    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, im);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
@@ -448,13 +462,140 @@ struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxCo
 constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
 template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(256)
-k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw) {
+k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, const float *im) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw);
+            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw, im);
         __threadfence_block();
         __syncthreads();
     }
+}
+
+// ---- dataflow sweep: ONE launch runs the warm start and every iteration over every colour ------------------------
+// The per-colour launches above serialise a step into ~colours x (iterations+1) dependent kernels (~6.5 us each on
+// MI355X, of which the arithmetic is ~1.5 us). The dependencies are much finer than that: manifold p only needs the
+// deltas of ITS two bodies as left by each body's previous manifold in colour order - exactly the push hand-off
+// slots. Here every resident lane owns the manifolds p = t, t+G, t+2G, ... (G = resident lanes) and walks them sweep
+// after sweep; before solving one it polls its own two slots until both carry the tag of the hand-off it is waiting
+// for, and afterwards it stores the updated deltas, tagged, into the slots of each body's next manifold. A hand-off
+// between two waves through device-coherent (sc1) 16-byte accesses costs ~0.5 us (scripts/ubench/pingpong.hip), so a
+// colour step costs ~2 us instead of a kernel boundary, and different bodies advance through their chains
+// independently (no barrier of any kind). The arithmetic and the order in which each body sees its manifolds are
+// exactly those of the per-colour sweeps, so the results are bit-identical.
+//
+// Progress: tasks are visited in (sweep, p) order by every lane and every dependency points to a smaller (sweep, p),
+// so with all G lanes resident the smallest unfinished task can always run. Lanes of one wave that depend on each
+// other (a colour boundary inside the wave) are handled by solving only the wave's lowest pending colour at a time.
+// Tags: a slot handed over during sweep s carries s+1; a chain head (its body's first manifold) consumes the value its
+// body's last manifold left in the previous sweep, i.e. tag s, every other slot tag s+1; k_push_links zeroes all tags.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct DfArgs {
+    uint32_t na, stride, sweeps;      // active manifolds, resident lanes, iterations + 1
+    const uint32_t *keys_sorted;      // [p] colour*4 + (4 - num_points)
+    const uint32_t *next;             // Rows::next
+    const float *im;                  // Rows::im
+    float4 *rw; uint32_t rcap;
+    float4 *dslot;
+    Counters *cnt;
+    uint32_t backoff_cap;             // longest pause between two polls, in units of ~0.1 us
+    uint32_t predict_eighths;         // sleep through this many eighths of the wait the same task had in the previous sweep
+    uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
+};
+DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): 64 contiguous bytes
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(slot) : "memory");
+}
+DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {
+    const float t = __uint_as_float(tag);
+    const v4f v = {dv.x, dv.y, dv.z, t}, w = {dw.x, dw.y, dw.z, t};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(slot), "v"(v), "v"(w) : "memory");
+}
+constexpr uint32_t kDfSpinLimit = 1u << 22;   // ~seconds; a hand-off normally arrives within microseconds
+template <bool WARM, int NP>
+DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t col, uint32_t sweep, uint32_t *hist, uint64_t *trace_slot) {
+    RowReg R[NP][kRowsPerPoint];
+    const uint64_t w0 = a.trace ? wall_clock64() : 0;
+    rows_load<NP>(R, a.rw, a.rcap, p);
+    const uint64_t t0 = clock64();
+    uint64_t w1 = 0, w2 = 0;
+    const uint32_t nA = a.next[2 * (size_t)p], nB = a.next[2 * (size_t)p + 1];
+    Delta d;
+    d.imA = a.im[2 * (size_t)p]; d.imB = a.im[2 * (size_t)p + 1];
+    d.dvA = d.dwA = d.dvB = d.dwB = mk3(0, 0, 0);
+    const uint32_t wantA = (nA & kHeadBit) ? sweep : sweep + 1, wantB = (nB & kHeadBit) ? sweep : sweep + 1;
+    bool gotA = d.imA == 0, gotB = d.imB == 0;   // read-only bodies hand nothing over: their deltas stay zero
+    bool done = !valid;
+    const float4 *mine = a.dslot + 4 * (size_t)p;
+    uint32_t pause = 1;
+    // The hand-off pattern repeats from sweep to sweep: sleep through most of the wait this task had last time instead
+    // of polling through it (polls are device-coherent reads that compete with the row streams).
+    if (hist && sweep >= 2 && a.predict_eighths) {
+        const uint64_t until = t0 + (((uint64_t)*hist * a.predict_eighths) >> 3);
+        while (clock64() < until) __builtin_amdgcn_s_sleep(2);
+    }
+    for (uint32_t spin = 0;; ++spin) {
+        if (!done && !(gotA && gotB)) {
+            v4f a0, a1, b0, b1;
+            df_poll(mine, a0, a1, b0, b1);
+            if (a.trace && w1 == 0) w1 = wall_clock64();
+            if (!gotA && __float_as_uint(a0.w) == wantA && __float_as_uint(a1.w) == wantA) {
+                d.dvA = mk3(a0.x, a0.y, a0.z); d.dwA = mk3(a1.x, a1.y, a1.z); gotA = true;
+            }
+            if (!gotB && __float_as_uint(b0.w) == wantB && __float_as_uint(b1.w) == wantB) {
+                d.dvB = mk3(b0.x, b0.y, b0.z); d.dwB = mk3(b1.x, b1.y, b1.z); gotB = true;
+            }
+        }
+        const uint64_t pending = __ballot(!done);
+        if (pending == 0) {
+            if (hist) *hist = (uint32_t)min((unsigned long long)(clock64() - t0), 0xFFFFFFFFull);
+            if (trace_slot && (threadIdx.x & 63) == 0) { trace_slot[0] = w0; trace_slot[1] = w1; trace_slot[2] = w2; trace_slot[3] = wall_clock64(); }
+            break;
+        }
+        const uint32_t minc = __shfl(col, __ffsll((long long)pending) - 1);   // lanes are in colour order
+        const bool mine_now = !done && col == minc;
+        if (__ballot(mine_now && !(gotA && gotB)) == 0) {
+            if (a.trace && w2 == 0) w2 = wall_clock64();
+            if (mine_now) {
+                rows_solve<WARM, NP>(d, R, np);
+                if (!WARM) rows_store_impulses<NP>(R, a.rw, a.rcap, p, np);
+                if (d.imA != 0) df_publish(a.dslot + 2 * (size_t)(nA & kSlotMask), d.dvA, d.dwA, sweep + 1);
+                if (d.imB != 0) df_publish(a.dslot + 2 * (size_t)(nB & kSlotMask), d.dvB, d.dwB, sweep + 1);
+                done = true;
+            }
+        } else {
+            if (spin > kDfSpinLimit || ((spin & 1023u) == 1023u && __hip_atomic_load(&a.cnt->df_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
+                break;
+            }
+            for (uint32_t i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(4);   // exponential back-off keeps the polling traffic low
+            pause = min(pause * 2, a.backoff_cap);
+        }
+    }
+}
+constexpr uint32_t kDfHist = 32, kDfBlock = 64;   // one wave per workgroup: the dispatcher spreads the waves over all CUs
+__global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
+    __shared__ uint32_t wait_hist[kDfBlock / 64][kDfHist];   // per wave, per round: cycles the task waited in the previous sweep
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
+        for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
+            uint32_t *hist = round < kDfHist ? &wait_hist[threadIdx.x >> 6][round] : nullptr;
+            const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 6;
+            uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + (t >> 6)) : nullptr;
+            const uint32_t pt = base + t;
+            const bool valid = pt < a.na;
+            if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
+            const uint32_t p = valid ? pt : a.na - 1;
+            const uint32_t key = a.keys_sorted[p];
+            const uint32_t np = 4u - (key & 3u), col = key >> 2;
+            const bool big = __any(valid && np > 2);  // lanes are grouped by point count: uniform except at a group boundary
+            if (sweep == 0) { if (big) df_task<true, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<true, 2>(a, p, valid, np, col, sweep, hist, tr); }
+            else { if (big) df_task<false, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<false, 2>(a, p, valid, np, col, sweep, hist, tr); }
+        }
 }
 
 // ---- push hand-off: link every (lane, side) to the same body's next manifold in colour order (cyclic) ----
@@ -474,20 +615,20 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
     for (uint32_t side = 0; side < 2; ++side) {
         const uint32_t body = side ? rows.bB[p] : rows.bA[p];
         const uint32_t slot = 2 * p + side;
+        // every slot starts a step as (0,0,0 | tag 0): the chain head's seed, and "nothing handed over yet" elsewhere
+        rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, 0); rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
         if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
-            rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, 0); rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
             rows.next[slot] = slot;
+            rows.im[slot] = 0.0f;
             continue;
         }
+        rows.im[slot] = B_POS(b, body).w;
         const uint64_t mask = used[body];                         // colours of this body's active manifolds
         const uint64_t above = col >= 63 ? 0ull : mask & ~((2ull << col) - 1ull);
         const uint32_t nextc = (uint32_t)__ffsll((long long)(above ? above : mask)) - 1;
-        rows.next[slot] = rows.slot_of[(size_t)body * kMaxColours + nextc];
-        if (col == (uint32_t)__ffsll((long long)mask) - 1) {      // the body's first manifold of a sweep: seed the chain
-            rows.first_slot[body] = slot;
-            rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, B_POS(b, body).w);
-            rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
-        }
+        const bool head = col == (uint32_t)__ffsll((long long)mask) - 1;   // the body's first manifold of a sweep
+        rows.next[slot] = rows.slot_of[(size_t)body * kMaxColours + nextc] | (head ? kHeadBit : 0u);
+        if (head) rows.first_slot[body] = slot;
     }
 }
 
@@ -972,11 +1113,11 @@ int solve(edynhip_ctx *c) {
             const Split sp{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
             const dim3 g(blocks(e - a, 64)), bl(64);
             if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot);
-                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot);
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
+                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
             } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
-                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
+                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
             }
             ++launches;
         }
@@ -984,20 +1125,71 @@ int solve(edynhip_ctx *c) {
             const Rows &r = c->rows;
             const dim3 g(1), bl(kTailThreads);
             if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot);
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
             } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw);
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
             }
             ++launches;
         }
     };
-    joints_pass(true);
-    contacts_pass(true);
-    for (uint32_t it = 0; it < c->cfg.num_velocity_iterations; ++it) {
-        joints_pass(false);
-        contacts_pass(false);
+    // Contact-only scenes: the whole velocity solve as one dataflow launch (see k_contact_solve_df).
+    if (c->df_mode < 0) {
+        c->df_mode = 0;
+        const char *env = getenv("EDYNHIP_DATAFLOW");
+        int per_cu = 0, ncu = 0, coop = 0;
+        if (!(env && env[0] == '0') &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contact_solve_df, kDfBlock, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
+            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
+            c->df_lanes = (uint32_t)ncu * kDfBlock;   // measured best: one wave per CU (more waves only add polling traffic)
+            c->df_mode = 1;
+        }
+        (void)hipGetLastError();
+    }
+    if (push && c->df_mode == 1) {
+        const Rows &r = c->rows;
+        uint32_t grid = std::min(blocks(na, kDfBlock), c->df_lanes / kDfBlock);
+        static const uint32_t lanes_cap = getenv("EDYNHIP_DF_LANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_LANES")) : 0u;
+        static const uint32_t backoff = getenv("EDYNHIP_DF_BACKOFF") ? (uint32_t)atoi(getenv("EDYNHIP_DF_BACKOFF")) : 4u;
+        static const uint32_t predict = getenv("EDYNHIP_DF_PREDICT") ? (uint32_t)atoi(getenv("EDYNHIP_DF_PREDICT")) : 0u;
+        if (lanes_cap >= kDfBlock) grid = std::min(grid, lanes_cap / kDfBlock);
+        DfArgs a{na, grid * kDfBlock, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, std::max(backoff, 1u), predict, nullptr};
+        // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
+        static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
+        static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
+        const bool tracing = trace_path && solve_calls++ == trace_step;
+        size_t trace_words = 0;
+        if (tracing) {
+            const uint32_t rounds = (na + a.stride - 1) / a.stride;
+            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride >> 6);
+            EH_HIP(c, hipMalloc((void **)&a.trace, trace_words * 8));
+            EH_HIP(c, hipMemsetAsync(a.trace, 0, trace_words * 8, s));
+        }
+        void *params[] = {&a};
+        // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
+        // hand-off polling relies on
+        EH_HIP(c, hipLaunchCooperativeKernel((const void *)k_contact_solve_df, dim3(grid), dim3(kDfBlock), params, 0, s));
+        ++launches;
+        if (tracing) {
+            std::vector<uint64_t> tr(trace_words); std::vector<uint32_t> keys(na);
+            EH_HIP(c, hipStreamSynchronize(s));
+            EH_HIP(c, hipMemcpy(tr.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
+            EH_HIP(c, hipMemcpy(keys.data(), c->col_keys_sorted, (size_t)na * 4, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(trace_path, "wb")) {
+                const uint32_t hdr[4] = {na, a.stride, a.sweeps, 0};
+                fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, trace_words, f); fclose(f);
+            }
+            (void)hipFree(a.trace);
+        }
+    } else {
+        joints_pass(true);
+        contacts_pass(true);
+        for (uint32_t it = 0; it < c->cfg.num_velocity_iterations; ++it) {
+            joints_pass(false);
+            contacts_pass(false);
+        }
     }
     c->timings.solve_velocity_launches += launches;
     rec(c, 6);

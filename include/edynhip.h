@@ -41,7 +41,8 @@ typedef enum {
     EDYNHIP_ERR_HIP = -3,           /* a HIP runtime call failed (see edynhip_last_error) */
     EDYNHIP_ERR_CAPACITY = -4,      /* pair / manifold capacity exceeded */
     EDYNHIP_ERR_COLOURS = -5,       /* a body has more simultaneous contact partners than colours (64) */
-    EDYNHIP_ERR_UNSUPPORTED = -6    /* feature outside the hot-path scope */
+    EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope */
+    EDYNHIP_ERR_INTERNAL = -7       /* a device-side invariant failed (e.g. the dataflow solve timed out waiting for a hand-off) */
 } edynhip_status;
 
 /* rigidbody_kind (include/edyn/util/rigidbody.hpp:22-27) */
