@@ -500,6 +500,7 @@ struct DfArgs {
     uint32_t backoff_cap;             // longest pause between two polls, in units of ~0.1 us
     uint32_t predict_eighths;         // sleep through this many eighths of the wait the same task had in the previous sweep
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
+    uint32_t wave_lanes;              // lanes of each wave that carry a manifold (power of two <= 64), see solve()
 };
 DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): 64 contiguous bytes
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -579,20 +580,21 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
 }
 constexpr uint32_t kDfHist = 32, kDfBlock = 64;   // one wave per workgroup: the dispatcher spreads the waves over all CUs
 __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
-    __shared__ uint32_t wait_hist[kDfBlock / 64][kDfHist];   // per wave, per round: cycles the task waited in the previous sweep
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t wait_hist[kDfHist];     // per round: cycles the task waited in the previous sweep
+    const bool lane_used = threadIdx.x < a.wave_lanes;
+    const uint32_t t = blockIdx.x * a.wave_lanes + threadIdx.x;
+    const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride / a.wave_lanes;
     for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
         for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
-            uint32_t *hist = round < kDfHist ? &wait_hist[threadIdx.x >> 6][round] : nullptr;
-            const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 6;
-            uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + (t >> 6)) : nullptr;
             const uint32_t pt = base + t;
-            const bool valid = pt < a.na;
+            const bool valid = lane_used && pt < a.na;
             if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
             const uint32_t p = valid ? pt : a.na - 1;
             const uint32_t key = a.keys_sorted[p];
             const uint32_t np = 4u - (key & 3u), col = key >> 2;
             const bool big = __any(valid && np > 2);  // lanes are grouped by point count: uniform except at a group boundary
+            uint32_t *hist = round < kDfHist ? &wait_hist[round] : nullptr;
+            uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
             if (sweep == 0) { if (big) df_task<true, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<true, 2>(a, p, valid, np, col, sweep, hist, tr); }
             else { if (big) df_task<false, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<false, 2>(a, p, valid, np, col, sweep, hist, tr); }
         }
@@ -1143,19 +1145,22 @@ int solve(edynhip_ctx *c) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contact_solve_df, kDfBlock, 0) == hipSuccess &&
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
             hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
-            c->df_lanes = (uint32_t)ncu * kDfBlock;   // measured best: one wave per CU (more waves only add polling traffic)
+            c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
             c->df_mode = 1;
         }
         (void)hipGetLastError();
     }
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
-        uint32_t grid = std::min(blocks(na, kDfBlock), c->df_lanes / kDfBlock);
-        static const uint32_t lanes_cap = getenv("EDYNHIP_DF_LANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_LANES")) : 0u;
-        static const uint32_t backoff = getenv("EDYNHIP_DF_BACKOFF") ? (uint32_t)atoi(getenv("EDYNHIP_DF_BACKOFF")) : 4u;
+        // Shape of the resident set (defaults measured on MI355X, 32k-box pile): `wave_lanes` manifolds per wave - a wave
+        // advances only when ALL its manifolds' hand-offs arrived, so narrower waves wait less - on `waves` waves.
+        static const uint32_t env_wl = getenv("EDYNHIP_DF_WAVELANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVELANES")) : 64u;
+        static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 256u;
+        static const uint32_t backoff = getenv("EDYNHIP_DF_BACKOFF") ? (uint32_t)atoi(getenv("EDYNHIP_DF_BACKOFF")) : 1u;
         static const uint32_t predict = getenv("EDYNHIP_DF_PREDICT") ? (uint32_t)atoi(getenv("EDYNHIP_DF_PREDICT")) : 0u;
-        if (lanes_cap >= kDfBlock) grid = std::min(grid, lanes_cap / kDfBlock);
-        DfArgs a{na, grid * kDfBlock, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, std::max(backoff, 1u), predict, nullptr};
+        uint32_t wl = 64; while (wl > 1 && wl > env_wl) wl >>= 1;
+        const uint32_t grid = std::min(blocks(na, wl), std::min(c->df_lanes, std::max(env_waves, 1u)));
+        DfArgs a{na, grid * wl, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, std::max(backoff, 1u), predict, nullptr, wl};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
@@ -1163,7 +1168,7 @@ int solve(edynhip_ctx *c) {
         size_t trace_words = 0;
         if (tracing) {
             const uint32_t rounds = (na + a.stride - 1) / a.stride;
-            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride >> 6);
+            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride / a.wave_lanes);
             EH_HIP(c, hipMalloc((void **)&a.trace, trace_words * 8));
             EH_HIP(c, hipMemsetAsync(a.trace, 0, trace_words * 8, s));
         }
@@ -1178,7 +1183,7 @@ int solve(edynhip_ctx *c) {
             EH_HIP(c, hipMemcpy(tr.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
             EH_HIP(c, hipMemcpy(keys.data(), c->col_keys_sorted, (size_t)na * 4, hipMemcpyDeviceToHost));
             if (FILE *f = fopen(trace_path, "wb")) {
-                const uint32_t hdr[4] = {na, a.stride, a.sweeps, 0};
+                const uint32_t hdr[4] = {na, a.stride, a.sweeps, a.wave_lanes};
                 fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, trace_words, f); fclose(f);
             }
             (void)hipFree(a.trace);

@@ -3,10 +3,11 @@ Timestamps are wall_clock64 ticks (100 MHz): w0 task start, w1 first poll return
 w2 all inputs of the wave's current colour arrived, w3 task finished (hand-offs issued)."""
 import sys, numpy as np
 raw = open(sys.argv[1], "rb").read()
-na, stride, sweeps, _ = np.frombuffer(raw[:16], np.uint32)
+na, stride, sweeps, wl = (int(x) for x in np.frombuffer(raw[:16], np.uint32))
+wl = wl or 64
 keys = np.frombuffer(raw[16:16 + 4 * na], np.uint32)
 tr = np.frombuffer(raw[16 + 4 * na:], np.uint64)
-rounds = (na + stride - 1) // stride; nw = stride // 64
+rounds = (na + stride - 1) // stride; nw = stride // wl
 tr = tr.reshape(sweeps, rounds, nw, 4).astype(np.int64)
 valid = tr[..., 3] > 0
 t_begin = tr[..., 0][valid].min()
@@ -25,7 +26,7 @@ base = tr[s][..., 0][valid[s]].min()
 for c in range(int(col.max()) + 1):
     ps = np.nonzero(col == c)[0]
     if len(ps) == 0: continue
-    wv = np.unique(ps // 64)            # global wave-task index -> (round, wave)
-    r, w = (wv * 64) // stride, ((wv * 64) % stride) // 64
+    wv = np.unique(ps // wl)            # global wave-task index -> (round, wave)
+    r, w = (wv * wl) // stride, ((wv * wl) % stride) // wl
     ready = tr[s, r, w, 2]; fin = tr[s, r, w, 3]; start = tr[s, r, w, 0]
     print(f"  colour {c:2d}: {len(ps):6d} manifolds {len(wv):4d} wave-tasks  start {us(start.mean() - base):7.1f}  ready {us(ready.mean() - base):7.1f} (min {us(ready.min() - base):7.1f} max {us(ready.max() - base):7.1f})  done {us(fin.mean() - base):7.1f}")
