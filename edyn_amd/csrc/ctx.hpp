@@ -93,6 +93,7 @@ struct Rows {
     float4 *dslot = nullptr;      // [2 sides][2 float4] per lane p
     uint32_t *next = nullptr;     // [2p + side] -> slot (2p' + side') of the same body's next manifold in the sweep;
                                   // bit 31 (kHeadBit) marks THIS slot as the head of its body's chain
+    float4 *pslot = nullptr;      // position-solve hand-off slots, 3 float4 per (lane, side): see k_pos_contacts_df
     float *im = nullptr;          // [2p + side] inverse mass of that side's body (0 = read-only body: no hand-off)
     uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
@@ -183,7 +184,8 @@ struct edynhip_ctx {
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
-    uint32_t df_lanes = 0;         // resident lanes of the dataflow kernel (grid stride)
+    uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
+    uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel
     bool force_islands = true;     // recompute island labels even if the pair set did not change
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
 };

@@ -924,6 +924,174 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     }
     publish_error(active, max_err, label, isl_err);
 }
+// ---- dataflow position solve: one launch per position iteration (the island early-out between iterations stays a
+// separate tiny kernel). Same protocol as k_contact_solve_df with lane = (manifold, side): the hand-off is the body's
+// position, orientation and a "corrected in this solve" bit (48 bytes, three tagged 16-byte pieces); a corrected body's
+// world inertia is rebuilt from the orientation with the operations of position_solver::solve (bit-identical), an
+// uncorrected body still carries the inertia of its record (which active lanes only ever overwrite with equal values).
+struct DfPosArgs {
+    uint32_t na, stride, iter;      // active manifolds, resident manifolds per round, position iteration (= hand-off sweep)
+    const uint32_t *keys_sorted;
+    const uint32_t *next;
+    float4 *pslot;                  // [3 * (2p + side) + {0,1,2}] = (pos|tag) (orn.xyz|tag) (orn.w, corrected, 0 | tag)
+    Rows rows; Manifolds mf; Bodies b;
+    float *isl_err; const uint32_t *isl_done;
+    Counters *cnt;
+};
+DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1), "=&v"(h2) : "v"(slot) : "memory");
+}
+DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) {
+    const float t = __uint_as_float(tag);
+    const v4f h0 = {pos.x, pos.y, pos.z, t}, h1 = {orn.x, orn.y, orn.z, t}, h2 = {orn.w, corrected ? 1.0f : 0.0f, 0.0f, t};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:32 sc1" : : "v"(slot), "v"(h0), "v"(h1), "v"(h2) : "memory");
+}
+__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= 2 * n_active) return;
+    const uint32_t p = slot >> 1, body = (slot & 1u) ? rows.bB[p] : rows.bA[p];
+    float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
+    if ((rows.next[slot] & kHeadBit) && is_dynamic(b.flags[body])) {   // the chain head starts from the integrated transform
+        const float4 ps = B_POS(b, body), q = B_ORN(b, body);
+        h0 = make_float4(ps.x, ps.y, ps.z, 0); h1 = make_float4(q.x, q.y, q.z, 0); h2 = make_float4(q.w, 0, 0, 0);
+    }
+    pslot[3 * (size_t)slot] = h0; pslot[3 * (size_t)slot + 1] = h1; pslot[3 * (size_t)slot + 2] = h2;
+}
+__global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !is_dynamic(b.flags[i])) return;
+    const uint32_t fs = first_slot[i];
+    if (fs == 0xFFFFFFFFu) return;                       // no contacts: nothing moved it
+    const float4 h0 = pslot[3 * (size_t)fs], h1 = pslot[3 * (size_t)fs + 1], h2 = pslot[3 * (size_t)fs + 2];
+    if (h2.y == 0.0f) return;                            // never corrected: the record already holds this transform
+    PBody X = load_pbody(b, i);
+    X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
+    const m3 basis = to_m3(X.orn);
+    X.iw = mul(mul(basis, X.il), transpose(basis));
+    store_pbody(b, i, X);
+}
+template <int NP>
+DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col) {
+    const Manifolds &mf = a.mf; const Bodies &b = a.b;
+    const uint32_t m = a.rows.order[p], ix = sideB ? a.rows.bB[p] : a.rows.bA[p], label = a.rows.label[p];
+    const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
+    const uint32_t nx = a.next[slot];
+    const float4 *__restrict__ pvsrc = sideB ? mf.pB : mf.pA;
+    float4 piv[NP], l4[NP], n4[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const size_t s = (size_t)k * mf.cap + m;
+        piv[k] = pvsrc[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s];
+    }
+    PBody X = load_pbody(b, ix);                       // pos/orn/iw of a procedural body are replaced by the hand-off
+    const uint32_t done_isl = a.isl_done[label];
+    const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
+    bool got = !X.proc;                                // read-only bodies: the record is the truth
+    bool corrected = false;
+    bool done = !valid;
+    const float4 *mine = a.pslot + 3 * (size_t)slot;
+    float max_err = 0;
+    bool act = false;
+    uint32_t pause = 1;
+    for (uint32_t spin = 0;; ++spin) {
+        if (!done && !got) {
+            v4f h0, h1, h2;
+            dfp_poll(mine, h0, h1, h2);
+            if (__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want && __float_as_uint(h2.w) == want) {
+                X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
+                corrected = h2.y != 0.0f;
+                if (corrected) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); }
+                got = true;
+            }
+        }
+        const uint64_t pending = __ballot(!done);
+        if (pending == 0) break;
+        const uint32_t minc = __shfl(col, __ffsll((long long)pending) - 1);
+        const bool mine_now = !done && col == minc;            // both lanes of a pair share p, hence colour
+        if (__ballot(mine_now && !got) == 0) {
+            // the arithmetic below is pos_contacts_np's; `act` is uniform within a lane pair (DPP exchanges)
+            act = mine_now && done_isl == 0;
+            bool applied = false;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if ((uint32_t)k < np && act) {
+                    const int attach = __float_as_int(n4[k].w);
+                    const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
+                    const f3 pOw = xchg1(pXw);
+                    const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
+                    const f3 nrot = rotate(X.orn, from4(l4[k]));
+                    const f3 nother = xchg1(nrot);
+                    f3 n = from4(n4[k]);
+                    if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
+                    else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
+                    const float distance = dot(pAw - pBw, n);
+                    const f3 rX = pXw - X.pos;
+                    n4[k] = to4(n, n4[k].w);
+                    piv[k].w = distance;
+                    if (!(distance > -kEps)) {
+                        const f3 Jl = sideB ? -n : n;
+                        const f3 cx = cross(rX, n);
+                        const f3 Ja = sideB ? -cx : cx;
+                        const float t1 = dot(Jl, Jl) * X.inv_m, t2 = dot(mul(X.iw, Ja), Ja);
+                        const float o1 = xchg1(t1), o2 = xchg1(t2);
+                        const float a1 = sideB ? o1 : t1, a2 = sideB ? o2 : t2, b1 = sideB ? t1 : o1, b2 = sideB ? t2 : o2;
+                        const float em = 1.0f / (a1 + a2 + b1 + b2);
+                        const float error = -distance;
+                        const float corr = error * 0.2f * em;
+                        pos_apply(X, Jl, Ja, corr);
+                        applied = applied || X.proc;
+                        max_err = fmaxf(fabsf(error), max_err);
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const size_t s = (size_t)k * mf.cap + m;
+                    if ((uint32_t)k < np) {
+                        if (!sideB) mf.pA[s] = piv[k];
+                        else mf.nrm[s] = n4[k];
+                    }
+                }
+                // the body record is NOT written here: two waves on different XCDs would leave the same line dirty in
+                // two L2s; k_pos_writeback stores each body's final transform once, from its chain head's slot
+            }
+            if (mine_now) {
+                if (X.proc) dfp_publish(a.pslot + 3 * (size_t)(nx & kSlotMask), X.pos, X.orn, corrected || applied, a.iter + 1);
+                done = true;
+            }
+        } else {
+            if (spin > kDfSpinLimit || ((spin & 1023u) == 1023u && __hip_atomic_load(&a.cnt->df_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
+                break;
+            }
+            for (uint32_t i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(4);
+            pause = min(pause * 2, 2u);
+        }
+    }
+    publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.isl_err);
+}
+__global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
+    const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
+    const bool sideB = threadIdx.x & 1u;
+    for (uint32_t base = 0; base < a.na; base += a.stride) {
+        const uint32_t pt = base + t;
+        const bool valid = pt < a.na;
+        if (!__any(valid)) continue;
+        const uint32_t p = valid ? pt : a.na - 1;
+        const uint32_t key = a.keys_sorted[p];
+        const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
+        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col);
+        else dfp_task<2>(a, p, valid, sideB, np, col);
+    }
+}
+
 __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1146,6 +1314,9 @@ int solve(edynhip_ctx *c) {
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
             hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
             c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
+            int per_cu_p = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
+                c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
             c->df_mode = 1;
         }
         (void)hipGetLastError();
@@ -1201,7 +1372,20 @@ int solve(edynhip_ctx *c) {
     hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done, push ? c->rows.dslot : nullptr, c->rows.first_slot);
     if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
     rec(c, 7);
-    if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
+    static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
+    if (c->cfg.num_position_iterations > 0 && push && c->df_mode == 1 && pos_df_env) {
+        static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 512u;
+        const Rows &r = c->rows;
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot);
+        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, std::max(env_pw, 1u)));
+        for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
+            DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
+            void *params[] = {&a};
+            EH_HIP(c, hipLaunchCooperativeKernel((const void *)k_pos_contacts_df, dim3(grid), dim3(64), params, 0, s));
+            hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
+        }
+        hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
+    } else if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
         for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
             for (uint32_t k = 0; k < j.num_colours; ++k) {
                 uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
