@@ -1326,11 +1326,14 @@ int solve(edynhip_ctx *c) {
         // Shape of the resident set (defaults measured on MI355X, 32k-box pile): `wave_lanes` manifolds per wave - a wave
         // advances only when ALL its manifolds' hand-offs arrived, so narrower waves wait less - on `waves` waves.
         static const uint32_t env_wl = getenv("EDYNHIP_DF_WAVELANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVELANES")) : 64u;
-        static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 256u;
+        static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 0u;
         static const uint32_t backoff = getenv("EDYNHIP_DF_BACKOFF") ? (uint32_t)atoi(getenv("EDYNHIP_DF_BACKOFF")) : 1u;
         static const uint32_t predict = getenv("EDYNHIP_DF_PREDICT") ? (uint32_t)atoi(getenv("EDYNHIP_DF_PREDICT")) : 0u;
         uint32_t wl = 64; while (wl > 1 && wl > env_wl) wl >>= 1;
-        const uint32_t grid = std::min(blocks(na, wl), std::min(c->df_lanes, std::max(env_waves, 1u)));
+        // one wave per CU while a sweep is latency-bound (<= ~9 tasks per wave and sweep); more waves once the row
+        // stream dominates (many islands / millions of points), up to what can be resident
+        const uint32_t want_waves = env_waves ? env_waves : std::max(256u, blocks(na, wl * 9));
+        const uint32_t grid = std::min(blocks(na, wl), std::min(c->df_lanes, want_waves));
         DfArgs a{na, grid * wl, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, std::max(backoff, 1u), predict, nullptr, wl};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
@@ -1374,10 +1377,10 @@ int solve(edynhip_ctx *c) {
     rec(c, 7);
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
     if (c->cfg.num_position_iterations > 0 && push && c->df_mode == 1 && pos_df_env) {
-        static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 512u;
+        static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
         hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot);
-        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, std::max(env_pw, 1u)));
+        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
         for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
             void *params[] = {&a};
