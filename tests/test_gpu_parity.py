@@ -407,3 +407,32 @@ def test_make_rigidbody_after_update_appends():
     assert len(ground) == 1 and ground["pt"]["normal_impulse"][0, 0] > 0.5 * imp.max(), "warm start of the old contact survived"
     w.step_simulation(60)
     assert abs(w.get_state()[0][2, 1] - 1.5) < 0.02
+
+
+# ------------------------------------------------------------------ both solver schedules
+def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
+    """Contact-only scenes run the velocity and position solves as dataflow launches (tagged hand-offs between
+    manifolds); scenes with joints, or EDYNHIP_DATAFLOW=0, run one launch per colour. Both visit every body's manifolds
+    in colour order, so they must agree bit for bit (and both with the oracle, which the other tests check for the
+    default schedule)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import edyn_amd; from edyn_amd import scenes\n"
+        "w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3))\n"
+        "w.set_scene(scenes.box_pile(6, 6, 6, mixed=True)); w.step_simulation(80)\n"
+        "p, q, v, a = w.get_state(); m = w.get_manifolds()\n"
+        "np.savez(sys.argv[1], p=p, q=q, v=v, a=a, m=m.view(np.uint8))\n" % root)
+    outs = []
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"state_{mode}.npz")
+        env = dict(os.environ, EDYNHIP_DATAFLOW=mode)
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    for k in ("p", "q", "v", "a", "m"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # and the default schedule against the oracle on the same scene
+    o = oracle_world(scenes.box_pile(6, 6, 6, mixed=True)); o.step(80)
+    for a, b in zip((outs[0]["p"], outs[0]["q"], outs[0]["v"], outs[0]["a"]), o.get_state()):
+        assert np.array_equal(a, b)
