@@ -418,6 +418,56 @@ DI void rows_store_impulses(const RowReg (&R)[NP][kRowsPerPoint], float4 *__rest
         for (int r = 0; r < kRowsPerPoint; ++r) rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * rcap + p] = R[k][r].f[2];
     }
 }
+// The same sweep with the rows held as separate normal / friction sets, so that a caller can fetch the friction rows
+// of the later points while the normal rows are already being solved (k_contact_solve_df). Identical arithmetic.
+DI void row_load(RowReg &r, const float4 *__restrict__ rw, uint32_t rcap, uint32_t p, int k, int row) {
+#pragma unroll
+    for (int f = 0; f < kRowF; ++f) r.f[f] = rw[(size_t)((k * kRowsPerPoint + row) * kRowF + f) * rcap + p];
+}
+template <bool WARM, int NP>
+DI void rows_solve_normals(Delta &d, RowReg (&Rn)[NP], uint32_t np) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
+        RowReg &r = Rn[k];
+        if (WARM) {
+            row_apply(d, r, r.f[2].w);
+        } else {
+            float drel = row_relspeed(d, r);
+            float dimp = (r.f[1].w - drel) * r.f[0].w;
+            float cur = r.f[2].w;
+            float imp = cur + dimp;
+            if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
+            else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
+            else cur = imp;
+            r.f[2].w = cur;
+            row_apply(d, r, dimp);
+        }
+    }
+}
+template <bool WARM>
+DI void rows_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) {
+    if (WARM) {   // warm_start(constraint_row_friction&)
+        row_apply(d, ra, ra.f[2].w);
+        row_apply(d, rb, rb.f[2].w);
+    } else {
+        float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
+        float i0 = ra.f[2].w + di0;
+        float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
+        float i1 = rb.f[2].w + di1;
+        float len2 = i0 * i0 + i1 * i1;
+        float max_len = rn.f[3].w * rn.f[2].w;   // mu * current normal impulse
+        if (len2 > square(max_len)) {
+            float len = sqrtf(len2);
+            if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+            else { i0 = 0; i1 = 0; }
+            di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
+        }
+        ra.f[2].w = i0; rb.f[2].w = i1;
+        row_apply(d, ra, di0);
+        row_apply(d, rb, di1);
+    }
+}
 template <bool WARM, int NP, bool PUSH>
 DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                          float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
@@ -519,9 +569,16 @@ DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {
 constexpr uint32_t kDfSpinLimit = 1u << 22;   // ~seconds; a hand-off normally arrives within microseconds
 template <bool WARM, int NP>
 DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t col, uint32_t sweep, uint32_t *hist, uint64_t *trace_slot) {
-    RowReg R[NP][kRowsPerPoint];
+    // Rows fetched before the wait: every normal row and the friction rows of the first two points. The friction rows
+    // of points 2 and 3 are fetched when the hand-offs have arrived and land while the normal rows are being solved;
+    // holding all 15*NP float4 across the wait would push the kernel into AGPR copies.
+    constexpr int kEarly = NP > 2 ? 2 : NP;
+    RowReg Rn[NP], Rf[NP][2];
     const uint64_t w0 = a.trace ? wall_clock64() : 0;
-    rows_load<NP>(R, a.rw, a.rcap, p);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) row_load(Rn[k], a.rw, a.rcap, p, k, 0);
+#pragma unroll
+    for (int k = 0; k < kEarly; ++k) { row_load(Rf[k][0], a.rw, a.rcap, p, k, 1); row_load(Rf[k][1], a.rw, a.rcap, p, k, 2); }
     const uint64_t t0 = clock64();
     uint64_t w1 = 0, w2 = 0;
     const uint32_t nA = a.next[2 * (size_t)p], nB = a.next[2 * (size_t)p + 1];
@@ -562,10 +619,24 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
         if (__ballot(mine_now && !(gotA && gotB)) == 0) {
             if (a.trace && w2 == 0) w2 = wall_clock64();
             if (mine_now) {
-                rows_solve<WARM, NP>(d, R, np);
-                if (!WARM) rows_store_impulses<NP>(R, a.rw, a.rcap, p, np);
+#pragma unroll
+                for (int k = kEarly; k < NP; ++k) { row_load(Rf[k][0], a.rw, a.rcap, p, k, 1); row_load(Rf[k][1], a.rw, a.rcap, p, k, 2); }
+                rows_solve_normals<WARM, NP>(d, Rn, np);
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if ((uint32_t)k < np) rows_solve_friction<WARM>(d, Rn[k], Rf[k][0], Rf[k][1]);
+                // hand the deltas over first (the next manifolds are waiting for them), then store the impulses
                 if (d.imA != 0) df_publish(a.dslot + 2 * (size_t)(nA & kSlotMask), d.dvA, d.dwA, sweep + 1);
                 if (d.imB != 0) df_publish(a.dslot + 2 * (size_t)(nB & kSlotMask), d.dvB, d.dwB, sweep + 1);
+                if (!WARM) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if ((uint32_t)k >= np) continue;
+                        a.rw[(size_t)((k * kRowsPerPoint + 0) * kRowF + 2) * a.rcap + p] = Rn[k].f[2];
+                        a.rw[(size_t)((k * kRowsPerPoint + 1) * kRowF + 2) * a.rcap + p] = Rf[k][0].f[2];
+                        a.rw[(size_t)((k * kRowsPerPoint + 2) * kRowF + 2) * a.rcap + p] = Rf[k][1].f[2];
+                    }
+                }
                 done = true;
             }
         } else {
