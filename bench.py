@@ -9,9 +9,10 @@ Contract (one JSON line on rank 0):
            the pile (N islands sharded one per GPU, no data-path collective) and the integrated state
            (13 floats/body) is all-gathered over RCCL every step, as the registry write-back would need;
            value counts pile-steps, scaling = "weak".
-  roofline the SI velocity-solve kernels (k_contact_solve, one launch per colour): algorithmic bytes
-           (380 B per contact point per iteration) / time measured with HIP events recorded
-           on the stepper's stream inside the timed region.
+  roofline the SI velocity-solve kernel (k_contact_solve_df: ONE dataflow launch per step runs the warm start and
+           every iteration over every colour; scenes with joints use one k_contact_solve launch per colour):
+           algorithmic bytes (380 B per contact point per iteration) / time measured with HIP events
+           recorded on the stepper's stream around that launch inside the timed region.
   cpu_baseline  the CPU oracle (reference-order restatement, 1 thread) timed on a bounded sample of the
            same scene on rank 0 at N=1. A reported baseline, not the target.
 """
@@ -162,7 +163,9 @@ def main():
                        "bodies": n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_contact_solve<false/true> (every colour, every iteration + warm start)",
+                         "traffic": traffic,
+                         "kernel": ("k_contact_solve_df (one dataflow launch: warm start + every iteration over every colour)" if launches < 1.5
+                                    else "k_contact_solve<WARM,PUSH> (+ _tail): one launch per colour, every iteration + warm start"),
                          "algorithmic_bytes_per_launch": alg_bytes_step / max(launches, 1), "launches_per_step": launches,
                          "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
             "stages_ms_per_step": {k: tm[k] / steps_timed for k in ("broadphase_ms", "narrowphase_ms", "islands_ms", "colouring_ms",

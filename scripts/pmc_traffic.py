@@ -1,6 +1,7 @@
 """HBM traffic per launch of the solve kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd dbs).
 gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B -> x2
-for this kernel's 16 B/lane row streams; WRITE_SIZE is uncalibrated and taken as is. Units: FETCH/WRITE_SIZE in KiB."""
+for this kernel's 16 B/lane row streams (the dataflow kernel's hand-off polls are device-coherent 16-B reads and are
+counted too: they are real fabric traffic); WRITE_SIZE is uncalibrated and taken as is. Units: FETCH/WRITE_SIZE in KiB."""
 import json, sqlite3, sys, glob, os
 
 def per_kernel(path, counter, pat):
@@ -13,7 +14,7 @@ def per_kernel(path, counter, pat):
 fetch_dir, write_dir, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 out = {"workload": workload, "kernels": {}}
 tot_launch = tot_bytes = 0
-for pat in ("k_contact_solve<false", "k_contact_solve<true", "k_contact_solve_tail"):   # <WARM, PUSH> instantiations
+for pat in ("k_contact_solve_df", "k_contact_solve<false", "k_contact_solve<true", "k_contact_solve_tail"):
     nf, f = per_kernel(fetch_dir, "FETCH_SIZE", pat)
     nw, w = per_kernel(write_dir, "WRITE_SIZE", pat)
     if nf == 0: continue

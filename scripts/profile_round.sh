@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 W=/tmp/prof_$R; rm -rf $W; mkdir -p $W
-STEPS=200; WARM=20
+STEPS=300; WARM=120   # bench.py's defaults: the same command the bench line comes from
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --steps $STEPS --warmup $WARM > $OUT/bench_under_rocprof.json 2> $W/kt.log )
 python scripts/prof_summary.py $W/kt $((STEPS + WARM)) > $OUT/${R}_kernel_stats_pile32k.txt
 for C in FETCH_SIZE WRITE_SIZE; do
