@@ -53,7 +53,9 @@ static int allocate(edynhip_ctx *c) {
     Rows &r = c->rows;
     EH_TRY(dalloc(c, r.order, M)); EH_TRY(dalloc(c, r.bA, M)); EH_TRY(dalloc(c, r.bB, M)); EH_TRY(dalloc(c, r.np, M)); EH_TRY(dalloc(c, r.label, M));
     EH_TRY(dalloc(c, r.rw, (size_t)M * kMaxPts * kRowsPerPoint * kRowF));
-    EH_TRY(dalloc(c, r.dslot, (size_t)M * 4)); EH_TRY(dalloc(c, r.next, (size_t)M * 2)); EH_TRY(dalloc(c, r.im, (size_t)M * 2)); EH_TRY(dalloc(c, r.pslot, (size_t)M * 6));
+    EH_TRY(dalloc(c, r.dslot, ((size_t)M + 64) * 4));   // whole 64-lane blocks (dslot_at)
+    EH_TRY(dalloc(c, r.pslot, ((size_t)M + 32) * 6));   // whole 32-lane blocks (pslot_at)
+    EH_TRY(dalloc(c, r.next, (size_t)M * 2)); EH_TRY(dalloc(c, r.im, (size_t)M * 2));
     EH_TRY(dalloc(c, r.slot_of, (size_t)nb * kMaxColours)); EH_TRY(dalloc(c, r.first_slot, nb));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));

@@ -100,6 +100,18 @@ struct Rows {
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;
 constexpr uint32_t kHeadBit = 0x80000000u, kSlotMask = 0x7FFFFFFFu;
+// Hand-off slot addressing (float4 units). A slot is (lane p, side); its pieces are laid out so that ONE vector load of a
+// wave - 64 consecutive p for the velocity slots, 32 consecutive p x 2 sides for the position slots - reads contiguous
+// memory: the consumers poll their slots with device-coherent loads that go to the fabric every time, and a poll that
+// touches each 128-byte line once instead of four times is a quarter of the traffic.
+__host__ __device__ inline size_t dslot_at(uint32_t slot, uint32_t half) {   // velocity: pieces (side, half) = 4 per p
+    const uint32_t p = slot >> 1, side = slot & 1u;
+    return ((size_t)(p >> 6) << 8) + (((side << 1) + half) << 6) + (p & 63u);
+}
+__host__ __device__ inline size_t pslot_at(uint32_t slot, uint32_t piece) {   // position: 3 pieces per (p, side)
+    const uint32_t p = slot >> 1;
+    return (size_t)(p >> 5) * 192u + (piece << 6) + (slot & 63u);
+}
 
 struct LBVH {
     uint64_t *keys = nullptr, *keys_sorted = nullptr;   // morton<<32 | body

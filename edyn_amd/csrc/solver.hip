@@ -478,8 +478,9 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
     rows_load<NP>(R, rw, rcap, p);
     Delta d;
     {
-        const size_t sa = PUSH ? 2 * (size_t)p : ia, sb = PUSH ? 2 * (size_t)p + 1 : ib;
-        const float4 va = bdvw[2 * sa], wa = bdvw[2 * sa + 1], vb = bdvw[2 * sb], wb = bdvw[2 * sb + 1];
+        float4 va, wa, vb, wb;
+        if (PUSH) { va = bdvw[dslot_at(2 * p, 0)]; wa = bdvw[dslot_at(2 * p, 1)]; vb = bdvw[dslot_at(2 * p + 1, 0)]; wb = bdvw[dslot_at(2 * p + 1, 1)]; }
+        else { va = bdvw[2 * (size_t)ia]; wa = bdvw[2 * (size_t)ia + 1]; vb = bdvw[2 * (size_t)ib]; wb = bdvw[2 * (size_t)ib + 1]; }
         d.dvA = from4(va); d.dwA = from4(wa);
         d.dvB = from4(vb); d.dwB = from4(wb);
         if (PUSH) { d.imA = im[2 * (size_t)p]; d.imB = im[2 * (size_t)p + 1]; }   // slot .w lanes carry hand-off tags
@@ -488,8 +489,10 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
     rows_solve<WARM, NP>(d, R, np);
     if (!WARM) rows_store_impulses<NP>(R, rw, rcap, p, np);
     const float wA = PUSH ? 0.0f : d.imA, wB = PUSH ? 0.0f : d.imB;
-    if (d.imA != 0) { bdvw[2 * (size_t)ia] = to4(d.dvA, wA); bdvw[2 * (size_t)ia + 1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
-    if (d.imB != 0) { bdvw[2 * (size_t)ib] = to4(d.dvB, wB); bdvw[2 * (size_t)ib + 1] = to4(d.dwB, 0); }
+    const size_t oa0 = PUSH ? dslot_at(ia, 0) : 2 * (size_t)ia, oa1 = PUSH ? dslot_at(ia, 1) : 2 * (size_t)ia + 1;
+    const size_t ob0 = PUSH ? dslot_at(ib, 0) : 2 * (size_t)ib, ob1 = PUSH ? dslot_at(ib, 1) : 2 * (size_t)ib + 1;
+    if (d.imA != 0) { bdvw[oa0] = to4(d.dvA, wA); bdvw[oa1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
+    if (d.imB != 0) { bdvw[ob0] = to4(d.dvB, wB); bdvw[ob1] = to4(d.dwB, 0); }
 }
 template <bool WARM, bool PUSH>
 DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
@@ -552,19 +555,19 @@ struct DfArgs {
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
     uint32_t wave_lanes;              // lanes of each wave that carry a manifold (power of two <= 64), see solve()
 };
-DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): 64 contiguous bytes
+DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): pieces 1 KiB apart (dslot_at)
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
-                 "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(slot) : "memory");
 }
-DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {
+DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {   // slot = &dslot[dslot_at(s, 0)]; the dw piece is 1 KiB further
     const float t = __uint_as_float(tag);
     const v4f v = {dv.x, dv.y, dv.z, t}, w = {dw.x, dw.y, dw.z, t};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
-                 "global_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(slot), "v"(v), "v"(w) : "memory");
+                 "global_store_dwordx4 %0, %2, off offset:1024 sc1" : : "v"(slot), "v"(v), "v"(w) : "memory");
 }
 constexpr uint32_t kDfSpinLimit = 1u << 22;   // ~seconds; a hand-off normally arrives within microseconds
 template <bool WARM, int NP>
@@ -588,7 +591,7 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
     const uint32_t wantA = (nA & kHeadBit) ? sweep : sweep + 1, wantB = (nB & kHeadBit) ? sweep : sweep + 1;
     bool gotA = d.imA == 0, gotB = d.imB == 0;   // read-only bodies hand nothing over: their deltas stay zero
     bool done = !valid;
-    const float4 *mine = a.dslot + 4 * (size_t)p;
+    const float4 *mine = a.dslot + dslot_at(2 * p, 0);
     uint32_t pause = 1;
     // The hand-off pattern repeats from sweep to sweep: sleep through most of the wait this task had last time instead
     // of polling through it (polls are device-coherent reads that compete with the row streams).
@@ -626,8 +629,8 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
                 for (int k = 0; k < NP; ++k)
                     if ((uint32_t)k < np) rows_solve_friction<WARM>(d, Rn[k], Rf[k][0], Rf[k][1]);
                 // hand the deltas over first (the next manifolds are waiting for them), then store the impulses
-                if (d.imA != 0) df_publish(a.dslot + 2 * (size_t)(nA & kSlotMask), d.dvA, d.dwA, sweep + 1);
-                if (d.imB != 0) df_publish(a.dslot + 2 * (size_t)(nB & kSlotMask), d.dvB, d.dwB, sweep + 1);
+                if (d.imA != 0) df_publish(a.dslot + dslot_at(nA & kSlotMask, 0), d.dvA, d.dwA, sweep + 1);
+                if (d.imB != 0) df_publish(a.dslot + dslot_at(nB & kSlotMask, 0), d.dvB, d.dwB, sweep + 1);
                 if (!WARM) {
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
@@ -689,7 +692,7 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
         const uint32_t body = side ? rows.bB[p] : rows.bA[p];
         const uint32_t slot = 2 * p + side;
         // every slot starts a step as (0,0,0 | tag 0): the chain head's seed, and "nothing handed over yet" elsewhere
-        rows.dslot[2 * (size_t)slot] = make_float4(0, 0, 0, 0); rows.dslot[2 * (size_t)slot + 1] = make_float4(0, 0, 0, 0);
+        rows.dslot[dslot_at(slot, 0)] = make_float4(0, 0, 0, 0); rows.dslot[dslot_at(slot, 1)] = make_float4(0, 0, 0, 0);
         if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
             rows.next[slot] = slot;
             rows.im[slot] = 0.0f;
@@ -796,8 +799,8 @@ __global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint
     f3 dv, dw;
     if (dslot) {   // push hand-off: a sweep leaves each body's deltas in the slots of its first manifold
         const uint32_t fs = first_slot[i];
-        dv = fs != 0xFFFFFFFFu ? from4(dslot[2 * (size_t)fs]) : mk3(0, 0, 0);
-        dw = fs != 0xFFFFFFFFu ? from4(dslot[2 * (size_t)fs + 1]) : mk3(0, 0, 0);
+        dv = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 0)]) : mk3(0, 0, 0);
+        dw = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 1)]) : mk3(0, 0, 0);
     } else { dv = from4(B_DV(b, i)); dw = from4(B_DW(b, i)); }
     v += dv;
     w += dw;
@@ -1011,8 +1014,8 @@ struct DfPosArgs {
 };
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
     asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:2048 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(h0), "=&v"(h1), "=&v"(h2) : "v"(slot) : "memory");
 }
@@ -1020,8 +1023,8 @@ DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) 
     const float t = __uint_as_float(tag);
     const v4f h0 = {pos.x, pos.y, pos.z, t}, h1 = {orn.x, orn.y, orn.z, t}, h2 = {orn.w, corrected ? 1.0f : 0.0f, 0.0f, t};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
-                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
-                 "global_store_dwordx4 %0, %3, off offset:32 sc1" : : "v"(slot), "v"(h0), "v"(h1), "v"(h2) : "memory");
+                 "global_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:2048 sc1" : : "v"(slot), "v"(h0), "v"(h1), "v"(h2) : "memory");
 }
 __global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1032,14 +1035,14 @@ __global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot
         const float4 ps = B_POS(b, body), q = B_ORN(b, body);
         h0 = make_float4(ps.x, ps.y, ps.z, 0); h1 = make_float4(q.x, q.y, q.z, 0); h2 = make_float4(q.w, 0, 0, 0);
     }
-    pslot[3 * (size_t)slot] = h0; pslot[3 * (size_t)slot + 1] = h1; pslot[3 * (size_t)slot + 2] = h2;
+    pslot[pslot_at(slot, 0)] = h0; pslot[pslot_at(slot, 1)] = h1; pslot[pslot_at(slot, 2)] = h2;
 }
 __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !is_dynamic(b.flags[i])) return;
     const uint32_t fs = first_slot[i];
     if (fs == 0xFFFFFFFFu) return;                       // no contacts: nothing moved it
-    const float4 h0 = pslot[3 * (size_t)fs], h1 = pslot[3 * (size_t)fs + 1], h2 = pslot[3 * (size_t)fs + 2];
+    const float4 h0 = pslot[pslot_at(fs, 0)], h1 = pslot[pslot_at(fs, 1)], h2 = pslot[pslot_at(fs, 2)];
     if (h2.y == 0.0f) return;                            // never corrected: the record already holds this transform
     PBody X = load_pbody(b, i);
     X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
@@ -1066,7 +1069,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     bool got = !X.proc;                                // read-only bodies: the record is the truth
     bool corrected = false;
     bool done = !valid;
-    const float4 *mine = a.pslot + 3 * (size_t)slot;
+    const float4 *mine = a.pslot + pslot_at(slot, 0);
     float max_err = 0;
     bool act = false;
     uint32_t pause = 1;
@@ -1134,7 +1137,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
                 // two L2s; k_pos_writeback stores each body's final transform once, from its chain head's slot
             }
             if (mine_now) {
-                if (X.proc) dfp_publish(a.pslot + 3 * (size_t)(nx & kSlotMask), X.pos, X.orn, corrected || applied, a.iter + 1);
+                if (X.proc) dfp_publish(a.pslot + pslot_at(nx & kSlotMask, 0), X.pos, X.orn, corrected || applied, a.iter + 1);
                 done = true;
             }
         } else {
