@@ -550,10 +550,7 @@ struct DfArgs {
     float4 *rw; uint32_t rcap;
     float4 *dslot;
     Counters *cnt;
-    uint32_t backoff_cap;             // longest pause between two polls, in units of ~0.1 us
-    uint32_t predict_eighths;         // sleep through this many eighths of the wait the same task had in the previous sweep
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
-    uint32_t wave_lanes;              // lanes of each wave that carry a manifold (power of two <= 64), see solve()
 };
 DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): pieces 1 KiB apart (dslot_at)
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -571,7 +568,7 @@ DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {   // slot = &dslo
 }
 constexpr uint32_t kDfSpinLimit = 1u << 22;   // ~seconds; a hand-off normally arrives within microseconds
 template <bool WARM, int NP>
-DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t col, uint32_t sweep, uint32_t *hist, uint64_t *trace_slot) {
+DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
     // Rows fetched before the wait: every normal row and the friction rows of the first two points. The friction rows
     // of points 2 and 3 are fetched when the hand-offs have arrived and land while the normal rows are being solved;
     // holding all 15*NP float4 across the wait would push the kernel into AGPR copies.
@@ -582,7 +579,6 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
     for (int k = 0; k < NP; ++k) row_load(Rn[k], a.rw, a.rcap, p, k, 0);
 #pragma unroll
     for (int k = 0; k < kEarly; ++k) { row_load(Rf[k][0], a.rw, a.rcap, p, k, 1); row_load(Rf[k][1], a.rw, a.rcap, p, k, 2); }
-    const uint64_t t0 = clock64();
     uint64_t w1 = 0, w2 = 0;
     const uint32_t nA = a.next[2 * (size_t)p], nB = a.next[2 * (size_t)p + 1];
     Delta d;
@@ -592,13 +588,6 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
     bool gotA = d.imA == 0, gotB = d.imB == 0;   // read-only bodies hand nothing over: their deltas stay zero
     bool done = !valid;
     const float4 *mine = a.dslot + dslot_at(2 * p, 0);
-    uint32_t pause = 1;
-    // The hand-off pattern repeats from sweep to sweep: sleep through most of the wait this task had last time instead
-    // of polling through it (polls are device-coherent reads that compete with the row streams).
-    if (hist && sweep >= 2 && a.predict_eighths) {
-        const uint64_t until = t0 + (((uint64_t)*hist * a.predict_eighths) >> 3);
-        while (clock64() < until) __builtin_amdgcn_s_sleep(2);
-    }
     for (uint32_t spin = 0;; ++spin) {
         if (!done && !(gotA && gotB)) {
             v4f a0, a1, b0, b1;
@@ -613,7 +602,6 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
         }
         const uint64_t pending = __ballot(!done);
         if (pending == 0) {
-            if (hist) *hist = (uint32_t)min((unsigned long long)(clock64() - t0), 0xFFFFFFFFull);
             if (trace_slot && (threadIdx.x & 63) == 0) { trace_slot[0] = w0; trace_slot[1] = w1; trace_slot[2] = w2; trace_slot[3] = wall_clock64(); }
             break;
         }
@@ -647,30 +635,26 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
                 if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
                 break;
             }
-            for (uint32_t i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(4);   // exponential back-off keeps the polling traffic low
-            pause = min(pause * 2, a.backoff_cap);
+            __builtin_amdgcn_s_sleep(4);   // ~0.1 us between polls
         }
     }
 }
-constexpr uint32_t kDfHist = 32, kDfBlock = 64;   // one wave per workgroup: the dispatcher spreads the waves over all CUs
+constexpr uint32_t kDfBlock = 64;   // one wave per workgroup: the dispatcher spreads the waves over all CUs
 __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
-    __shared__ uint32_t wait_hist[kDfHist];     // per round: cycles the task waited in the previous sweep
-    const bool lane_used = threadIdx.x < a.wave_lanes;
-    const uint32_t t = blockIdx.x * a.wave_lanes + threadIdx.x;
-    const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride / a.wave_lanes;
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 6;
     for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
         for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
             const uint32_t pt = base + t;
-            const bool valid = lane_used && pt < a.na;
+            const bool valid = pt < a.na;
             if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
             const uint32_t p = valid ? pt : a.na - 1;
             const uint32_t key = a.keys_sorted[p];
             const uint32_t np = 4u - (key & 3u), col = key >> 2;
             const bool big = __any(valid && np > 2);  // lanes are grouped by point count: uniform except at a group boundary
-            uint32_t *hist = round < kDfHist ? &wait_hist[round] : nullptr;
             uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
-            if (sweep == 0) { if (big) df_task<true, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<true, 2>(a, p, valid, np, col, sweep, hist, tr); }
-            else { if (big) df_task<false, 4>(a, p, valid, np, col, sweep, hist, tr); else df_task<false, 2>(a, p, valid, np, col, sweep, hist, tr); }
+            if (sweep == 0) { if (big) df_task<true, 4>(a, p, valid, np, col, sweep, tr); else df_task<true, 2>(a, p, valid, np, col, sweep, tr); }
+            else { if (big) df_task<false, 4>(a, p, valid, np, col, sweep, tr); else df_task<false, 2>(a, p, valid, np, col, sweep, tr); }
         }
 }
 
@@ -1072,7 +1056,6 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const float4 *mine = a.pslot + pslot_at(slot, 0);
     float max_err = 0;
     bool act = false;
-    uint32_t pause = 1;
     for (uint32_t spin = 0;; ++spin) {
         if (!done && !got) {
             v4f h0, h1, h2;
@@ -1145,12 +1128,13 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
                 if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
                 break;
             }
-            for (uint32_t i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(4);
-            pause = min(pause * 2, 2u);
+            __builtin_amdgcn_s_sleep(4);
         }
     }
     publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.isl_err);
 }
+// (Requesting a wave's next task's indices or point data one task ahead was measured and is slower: a wave's vector
+// memory operations complete in order, so anything issued before a poll delays noticing the hand-off.)
 __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
@@ -1397,18 +1381,12 @@ int solve(edynhip_ctx *c) {
     }
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
-        // Shape of the resident set (defaults measured on MI355X, 32k-box pile): `wave_lanes` manifolds per wave - a wave
-        // advances only when ALL its manifolds' hand-offs arrived, so narrower waves wait less - on `waves` waves.
-        static const uint32_t env_wl = getenv("EDYNHIP_DF_WAVELANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVELANES")) : 64u;
+        // Resident waves (measured on MI355X): two per CU while a sweep is latency-bound - more only add polling traffic -
+        // and up to every resident slot once the row stream dominates (many islands, millions of points).
         static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 0u;
-        static const uint32_t backoff = getenv("EDYNHIP_DF_BACKOFF") ? (uint32_t)atoi(getenv("EDYNHIP_DF_BACKOFF")) : 1u;
-        static const uint32_t predict = getenv("EDYNHIP_DF_PREDICT") ? (uint32_t)atoi(getenv("EDYNHIP_DF_PREDICT")) : 0u;
-        uint32_t wl = 64; while (wl > 1 && wl > env_wl) wl >>= 1;
-        // one wave per CU while a sweep is latency-bound (<= ~9 tasks per wave and sweep); more waves once the row
-        // stream dominates (many islands / millions of points), up to what can be resident
-        const uint32_t want_waves = env_waves ? env_waves : std::max(256u, blocks(na, wl * 9));
-        const uint32_t grid = std::min(blocks(na, wl), std::min(c->df_lanes, want_waves));
-        DfArgs a{na, grid * wl, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, std::max(backoff, 1u), predict, nullptr, wl};
+        const uint32_t want_waves = env_waves ? env_waves : std::max(512u, blocks(na, 64 * 9));
+        const uint32_t grid = std::min(blocks(na, 64), std::min(c->df_lanes, want_waves));
+        DfArgs a{na, grid * 64u, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
@@ -1416,7 +1394,7 @@ int solve(edynhip_ctx *c) {
         size_t trace_words = 0;
         if (tracing) {
             const uint32_t rounds = (na + a.stride - 1) / a.stride;
-            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride / a.wave_lanes);
+            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride >> 6);
             EH_HIP(c, hipMalloc((void **)&a.trace, trace_words * 8));
             EH_HIP(c, hipMemsetAsync(a.trace, 0, trace_words * 8, s));
         }
@@ -1431,7 +1409,7 @@ int solve(edynhip_ctx *c) {
             EH_HIP(c, hipMemcpy(tr.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
             EH_HIP(c, hipMemcpy(keys.data(), c->col_keys_sorted, (size_t)na * 4, hipMemcpyDeviceToHost));
             if (FILE *f = fopen(trace_path, "wb")) {
-                const uint32_t hdr[4] = {na, a.stride, a.sweeps, a.wave_lanes};
+                const uint32_t hdr[4] = {na, a.stride, a.sweeps, 64};
                 fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, trace_words, f); fclose(f);
             }
             (void)hipFree(a.trace);
