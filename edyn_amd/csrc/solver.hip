@@ -1379,6 +1379,7 @@ int solve(edynhip_ctx *c) {
         }
         (void)hipGetLastError();
     }
+    bool df_velocity = false;
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
         // Resident waves (measured on MI355X): two per CU while a sweep is latency-bound - more only add polling traffic -
@@ -1401,9 +1402,14 @@ int solve(edynhip_ctx *c) {
         void *params[] = {&a};
         // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
         // hand-off polling relies on
-        EH_HIP(c, hipLaunchCooperativeKernel((const void *)k_contact_solve_df, dim3(grid), dim3(kDfBlock), params, 0, s));
-        ++launches;
-        if (tracing) {
+        if (hipLaunchCooperativeKernel((const void *)k_contact_solve_df, dim3(grid), dim3(kDfBlock), params, 0, s) == hipSuccess) {
+            df_velocity = true;
+            ++launches;
+        } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
+            (void)hipGetLastError();
+            c->df_mode = 0;
+        }
+        if (tracing && df_velocity) {
             std::vector<uint64_t> tr(trace_words); std::vector<uint32_t> keys(na);
             EH_HIP(c, hipStreamSynchronize(s));
             EH_HIP(c, hipMemcpy(tr.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
@@ -1413,8 +1419,9 @@ int solve(edynhip_ctx *c) {
                 fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, trace_words, f); fclose(f);
             }
             (void)hipFree(a.trace);
-        }
-    } else {
+        } else if (tracing) (void)hipFree(a.trace);
+    }
+    if (!df_velocity) {
         joints_pass(true);
         contacts_pass(true);
         for (uint32_t it = 0; it < c->cfg.num_velocity_iterations; ++it) {
@@ -1428,20 +1435,8 @@ int solve(edynhip_ctx *c) {
     if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
     rec(c, 7);
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
-    if (c->cfg.num_position_iterations > 0 && push && c->df_mode == 1 && pos_df_env) {
-        static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
-        const Rows &r = c->rows;
-        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot);
-        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
-        for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
-            DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
-            void *params[] = {&a};
-            EH_HIP(c, hipLaunchCooperativeKernel((const void *)k_pos_contacts_df, dim3(grid), dim3(64), params, 0, s));
-            hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
-        }
-        hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
-    } else if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
-        for (uint32_t it = 0; it < c->cfg.num_position_iterations; ++it) {
+    auto pos_per_colour = [&](uint32_t first_it) {
+        for (uint32_t it = first_it; it < c->cfg.num_position_iterations; ++it) {
             for (uint32_t k = 0; k < j.num_colours; ++k) {
                 uint32_t a = j.colour_start[k], e = j.colour_start[k + 1];
                 if (e > a) hipLaunchKernelGGL(k_pos_joints, dim3(blocks(e - a, 128)), dim3(128), 0, s, a, e, j, c->b, c->isl_err, c->isl_done);
@@ -1453,6 +1448,28 @@ int solve(edynhip_ctx *c) {
             if (tail.n) hipLaunchKernelGGL(k_pos_contacts_tail, dim3(1), dim3(256), 0, s, tail, c->rows, mf, c->b, c->isl_err, c->isl_done);
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
+    };
+    if (c->cfg.num_position_iterations > 0 && push && c->df_mode == 1 && pos_df_env) {
+        static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
+        const Rows &r = c->rows;
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot);
+        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
+        uint32_t it = 0;
+        for (; it < c->cfg.num_position_iterations; ++it) {
+            DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
+            void *params[] = {&a};
+            if (hipLaunchCooperativeKernel((const void *)k_pos_contacts_df, dim3(grid), dim3(64), params, 0, s) != hipSuccess) {
+                (void)hipGetLastError();
+                c->df_mode = 0;
+                break;
+            }
+            hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
+        }
+        // the bodies' transforms live in the hand-off slots while the dataflow launches run
+        hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
+        pos_per_colour(it);   // nothing unless a cooperative launch was refused
+    } else if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
+        pos_per_colour(0);
     }
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end);

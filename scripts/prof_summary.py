@@ -12,3 +12,13 @@ print(f"{'kernel':60s} {'calls':>8s} {'total_us':>12s} {'avg_us':>9s} {'pct':>6s
 for name, calls, total, avg, pct in rows:
     short = name.replace("void ", "").split("(")[0][:60]
     print(f"{short:60s} {calls:8d} {total:12.1f} {avg:9.3f} {pct:6.2f} {total / steps:10.1f}")
+
+# The bench's roofline figure covers the TIMED region only (the last `timed` steps of the run): report the roofline
+# kernel's average over exactly those launches as well, so that it can be compared with bench.py's avg_launch_us.
+if len(sys.argv) > 4:
+    pat, timed = sys.argv[3], int(sys.argv[4])
+    d = [(e - s) / 1e3 for name, s, e in cur.execute("select name, start, end from kernels order by start") if pat in name]
+    per_step = len(d) / steps
+    tail = d[-int(round(timed * per_step)):]
+    print(f"# {pat}: {len(d)} launches; timed region = last {timed} steps = {len(tail)} launches: avg {sum(tail) / len(tail):.3f} us, "
+          f"{sum(tail) / timed:.1f} us/step")
