@@ -29,7 +29,7 @@ __global__ void k_step_reset(Counters *cnt) {
     int t = threadIdx.x;
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0;
+        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0;
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
     for (int k = t; k < 4 * (int)kMaxColours; k += 64) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
@@ -193,40 +193,40 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
         if ((uint32_t)(prev.skey[s] >> 1) == lo) return s;
     return 0xFFFFFFFFu;
 }
-// Pairs are staged per wave in LDS and flushed with ONE global atomic per wave: a single hot counter takes
-// ~12 ns per atomic on this chip, which would otherwise dominate the traversal.
-constexpr uint32_t kWaveBuf = 1536;   // keys per wave (64 lanes x 24 neighbours)
-struct Emit { uint64_t *buf; uint32_t *count; uint64_t *out; uint32_t cap; Counters *cnt; };
-DI void emit_pair(uint64_t skey, const Emit &e) {
-    uint32_t idx = atomicAdd(e.count, 1u);   // LDS atomic
-    if (idx < kWaveBuf) { e.buf[idx] = skey; return; }
-    uint32_t g = atomicAdd(&e.cnt->num_pairs, 1u);   // staging full: rare direct path
-    if (g < e.cap) e.out[g] = skey; else e.cnt->pair_overflow = 1;
+// Canonical pair key: (owner << 32 | other) << 1 | swapped. The OWNER is the procedural body whose query reports the
+// pair - the higher index when both are procedural (the other side skips lower->higher hits) - so every pair is
+// produced by exactly one lane, and the sorted pair list is simply "every owner's partners in ascending order,
+// owners in ascending order": each lane sorts its few keys in LDS, a scan over the per-owner counts gives the
+// offsets, a compaction kernel writes the list. No global sort (it used to be 7 radix passes, ~150 us per step).
+// swapped = the manifold's body[0] is `other` (the querying body is body[0], broadphase.cpp:151,171).
+constexpr int kOwnCap = 32;   // partners kept in the per-lane list; more go through the sorted fallback path
+struct Emit { uint64_t (*mine)[128]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; };
+DI void emit_pair(uint64_t skey, Emit &e) {
+    if (e.n < kOwnCap) { e.mine[e.n++][e.tx] = skey; return; }
+    const uint32_t g = atomicAdd(&e.cnt->num_extra, 1u);   // rare: an owner with more than kOwnCap partners
+    if (g < e.cap) e.extra[g] = skey; else e.cnt->pair_overflow = 1;
 }
-// Decide whether the unordered pair {i (procedural, the querying body), j} is in this step's set.
+// Decide whether the pair {i (procedural, the querying body = owner), j} is in this step's set.
 DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
-                      const uint64_t *mask, bool j_procedural, const Manifolds &prev, uint32_t pm, const Emit &em) {
-    const uint32_t hi = i > j ? i : j, lo = i > j ? j : i;
-    const uint64_t key = ((uint64_t)hi << 32) | lo;
+                      const uint64_t *mask, bool j_procedural, const Manifolds &prev, uint32_t pm, Emit &em) {
+    const uint64_t key = ((uint64_t)i << 32) | j;
     const box3 bj = body_box(amin, amax, j);
-    uint32_t pidx = find_prev(prev, pm, hi, lo);
+    uint32_t pidx = find_prev(prev, pm, i, j);
     if (pidx != 0xFFFFFFFFu) {   // destroy_separated_manifolds, broadphase.cpp:119-134
         const uint64_t ps = prev.skey[pidx];
-        const bool swapped = ps & 1;
-        const uint32_t b0 = swapped ? lo : hi;
-        const box3 &x0 = b0 == i ? bi : bj, &x1 = b0 == i ? bj : bi;
+        const bool swapped = ps & 1;                      // body[0] == j
+        const box3 &x0 = swapped ? bj : bi, &x1 = swapped ? bi : bj;
         if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, em);
         return;
     }
     if (!filter_ok(group, mask, i, j)) return;
     // collide_tree, broadphase.cpp:136-155: querying body's box grown by 0.02 vs the other's true box.
-    // Bodies are visited in descending index order, so the higher index gets to create the pair first.
-    const box3 &bh = hi == i ? bi : bj, &bl = hi == i ? bj : bi;
+    // Bodies are visited in descending index order, so the higher index (= i here) gets to create the pair first.
     if (j_procedural) {
-        if (intersect(inset(bh, -kBreaking), bl)) emit_pair(key << 1, em);
-        else if (intersect(inset(bl, -kBreaking), bh)) emit_pair((key << 1) | 1, em);
+        if (intersect(inset(bi, -kBreaking), bj)) emit_pair(key << 1, em);
+        else if (intersect(inset(bj, -kBreaking), bi)) emit_pair((key << 1) | 1, em);
     } else {
-        if (intersect(inset(bi, -kBreaking), bj)) emit_pair((key << 1) | (i == lo ? 1u : 0u), em);
+        if (intersect(inset(bi, -kBreaking), bj)) emit_pair(key << 1, em);
     }
 }
 
@@ -238,59 +238,68 @@ __global__ void __launch_bounds__(128)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, const uint64_t *__restrict__ group,
            const uint64_t *__restrict__ mask, const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
-           uint64_t *out, uint32_t cap, Counters *cnt, uint32_t *visit) {
+           uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit) {
     __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
     __shared__ uint32_t cand[kCandCap][128];     // candidate bodies per lane
-    __shared__ uint64_t wbuf[2][kWaveBuf];       // per-wave staging of emitted pairs
-    __shared__ uint32_t wcount[2];
-    const int tx = threadIdx.x, wave = tx >> 6, lane = tx & 63;
-    if (lane == 0) wcount[wave] = 0;
-    __syncthreads();
-    const Emit em{wbuf[wave], &wcount[wave], out, cap, cnt};
+    __shared__ uint64_t mine[kOwnCap][128];      // this lane's (= this owner's) pair keys
+    const int tx = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next step (the topology may be reused)
-    if (k < n) {
-        const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-        const box3 bi = body_box(amin, amax, i);
-        const box3 q = inset(bi, -kQueryGrow);
-        int nc = 0;
-        if (n > 1) {
-            int sp = 0;
-            stk[sp++][tx] = 0;
-            while (sp > 0) {
-                const uint32_t node = stk[--sp][tx];
-                const float4 lo4 = nmin[node], hi4 = nmax[node];
-                if (!intersect(box3{from4(lo4), from4(hi4)}, q)) continue;
-                if (node >= (uint32_t)(n - 1)) {
-                    const uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
-                    if (j < i) {
-                        if (nc < kCandCap) cand[nc++][tx] = j;
-                        else consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);   // rare overflow path
-                    }
-                } else if (sp <= 46) {
-                    stk[sp++][tx] = __float_as_uint(lo4.w);
-                    stk[sp++][tx] = __float_as_uint(hi4.w);
-                } else {
-                    cnt->pair_overflow = 2;   // traversal stack exhausted: reported as an error, never silently dropped
+    if (k >= n) return;
+    Emit em{mine, tx, 0, extra, cap, cnt};
+    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+    const box3 bi = body_box(amin, amax, i);
+    const box3 q = inset(bi, -kQueryGrow);
+    int nc = 0;
+    if (n > 1) {
+        int sp = 0;
+        stk[sp++][tx] = 0;
+        while (sp > 0) {
+            const uint32_t node = stk[--sp][tx];
+            const float4 lo4 = nmin[node], hi4 = nmax[node];
+            if (!intersect(box3{from4(lo4), from4(hi4)}, q)) continue;
+            if (node >= (uint32_t)(n - 1)) {
+                const uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
+                if (j < i) {
+                    if (nc < kCandCap) cand[nc++][tx] = j;
+                    else consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);   // rare overflow path
                 }
+            } else if (sp <= 46) {
+                stk[sp++][tx] = __float_as_uint(lo4.w);
+                stk[sp++][tx] = __float_as_uint(hi4.w);
+            } else {
+                cnt->pair_overflow = 2;   // traversal stack exhausted: reported as an error, never silently dropped
             }
         }
-        for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, group, mask, true, prev, pm, em);
-        for (uint32_t t = 0; t < num_np; ++t) {
-            uint32_t j = np_list[t];
-            box3 bj = body_box(amin, amax, j);
-            if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, prev, pm, em);
-        }
     }
-    __syncthreads();
-    // flush this wave's staging buffer with one global atomic
-    const uint32_t total = min(wcount[wave], kWaveBuf);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(&cnt->num_pairs, total);
-    base = __shfl(base, 0);
-    for (uint32_t t = lane; t < total; t += 64) {
-        if (base + t < cap) out[base + t] = wbuf[wave][t]; else cnt->pair_overflow = 1;
+    for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, group, mask, true, prev, pm, em);
+    for (uint32_t t = 0; t < num_np; ++t) {
+        uint32_t j = np_list[t];
+        box3 bj = body_box(amin, amax, j);
+        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, prev, pm, em);
     }
+    // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
+    for (int a = 1; a < em.n; ++a) {
+        const uint64_t v = mine[a][tx];
+        int b = a - 1;
+        while (b >= 0 && mine[b][tx] > v) { mine[b + 1][tx] = mine[b][tx]; --b; }
+        mine[b + 1][tx] = v;
+    }
+    for (int a = 0; a < em.n; ++a) own_keys[(size_t)i * kOwnCap + a] = mine[a][tx];
+    own_count[i] = (uint32_t)em.n;
+}
+// After the scan of own_count: total pair count for the host, and the per-owner blocks copied to their final places.
+__global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_keys, const uint32_t *__restrict__ own_count,
+                             const uint32_t *__restrict__ own_offset, const uint64_t *__restrict__ extra, uint64_t *out, uint32_t cap,
+                             Counters *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = own_offset[nbodies], nextra = min(cnt->num_extra, cap);
+    if (i == 0) { cnt->num_pairs = total + nextra; if (total + nextra > cap) cnt->pair_overflow = 1; }
+    if (i < nbodies) {
+        const uint32_t c = own_count[i], o = own_offset[i];
+        for (uint32_t a = 0; a < c; ++a) if (o + a < cap) out[o + a] = own_keys[(size_t)i * kOwnCap + a];
+    }
+    for (uint32_t e = i; e < nextra; e += gridDim.x * blockDim.x) if (total + e < cap) out[total + e] = extra[e];
 }
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
@@ -360,14 +369,21 @@ int broadphase(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         }
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->pair_keys, cur.cap, c->cnt, c->bvh.visit);
-        // pair count is needed on the host to size the sort and the manifold kernels
-        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit);
+        // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
+        EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
+        hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);
+        // pair count is needed on the host to size the manifold kernels
+        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours, hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         if (c->cnt_host->df_abort) return set_error(c, EDYNHIP_ERR_INTERNAL, "dataflow solve: a hand-off never arrived in the previous step (workgroups not co-resident?)");
         M = c->cnt_host->num_pairs;
-        { int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb; EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb)); }
+        if (c->cnt_host->num_extra) {   // some owner had more than kOwnCap partners: its surplus sits unsorted at the end
+            int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb;
+            EH_HIP(c, hipMemcpyAsync(c->pair_keys, c->pair_keys_sorted, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+            EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb));
+        }
         if (!c->full_step) {   // inside edynhip_step the previous step's k_finish already cleared these
             EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
             EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));

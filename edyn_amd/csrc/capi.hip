@@ -63,6 +63,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.nmin, (size_t)2 * nb)); EH_TRY(dalloc(c, t.nmax, (size_t)2 * nb)); EH_TRY(dalloc(c, t.visit, nb));
     EH_TRY(dalloc(c, t.np_list, nb));
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
+    EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M)); EH_TRY(dalloc(c, c->col_vals, M));
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));
@@ -209,17 +210,23 @@ __global__ void k_manifolds_to_records(uint32_t M, Manifolds mf, edynhip_manifol
     }
     out[m] = r;
 }
-__global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, Manifolds mf) {
+// Owner of a pair (see broadphase.hip): the procedural body, the higher index if both are.
+__host__ __device__ inline uint32_t pair_owner(uint32_t a, uint32_t b, bool proc_a, bool proc_b) {
+    if (proc_a && proc_b) return a > b ? a : b;
+    return proc_a ? a : b;
+}
+__global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, Manifolds mf, const uint32_t *__restrict__ flags) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const edynhip_manifold r = in[m];
     const uint32_t a = r.body[0], b = r.body[1];
-    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    auto owner_of = [&](const edynhip_manifold &x) { return pair_owner(x.body[0], x.body[1], (flags[x.body[0]] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC, (flags[x.body[1]] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC); };
+    const uint32_t hi = owner_of(r), lo = hi == a ? b : a;
     mf.skey[m] = ((((uint64_t)hi << 32) | lo) << 1) | (a == lo ? 1u : 0u);
     mf.bodyA[m] = a; mf.bodyB[m] = b;
     {
-        const uint32_t ph = m > 0 ? (in[m - 1].body[0] > in[m - 1].body[1] ? in[m - 1].body[0] : in[m - 1].body[1]) : 0xFFFFFFFFu;
-        const uint32_t nh = m + 1 < M ? (in[m + 1].body[0] > in[m + 1].body[1] ? in[m + 1].body[0] : in[m + 1].body[1]) : 0xFFFFFFFFu;
+        const uint32_t ph = m > 0 ? owner_of(in[m - 1]) : 0xFFFFFFFFu;
+        const uint32_t nh = m + 1 < M ? owner_of(in[m + 1]) : 0xFFFFFFFFu;
         if (ph != hi) mf.seg_start[hi] = m;
         if (nh != hi) mf.seg_end[hi] = m + 1;
     }
@@ -413,6 +420,9 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
             if (c->host_shape[i] == EDYNHIP_SHAPE_NONE) continue;
             (c->host_kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
         }
+    // only procedural shaped bodies own pairs; everybody else's count must read 0 in the scan
+    if (rc == EDYNHIP_OK && hipMemsetAsync(c->own_count, 0, ((size_t)c->b.cap + 1) * sizeof(uint32_t), c->stream) != hipSuccess)
+        rc = set_error(c, EDYNHIP_ERR_HIP, "clear pair counts");
     c->bvh.age = 0;   // the tree topology is rebuilt on the next step
     c->bvh.num_np = (uint32_t)np_list.size();
     c->bvh.num_proc = (uint32_t)proc_list.size();
@@ -650,9 +660,11 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     EH_HIP(c, hipSetDevice(c->device));
     // records must arrive in ascending canonical key order (the order edynhip_get_manifolds returns)
     for (uint32_t i = 1; i < n; ++i) {
-        auto key = [&](const edynhip_manifold &m) {
-            uint32_t hi = std::max(m.body[0], m.body[1]), lo = std::min(m.body[0], m.body[1]);
-            return ((uint64_t)hi << 32) | lo;
+        auto key = [&](const edynhip_manifold &m) -> uint64_t {
+            const uint32_t a = m.body[0], b = m.body[1];
+            if (a >= c->b.n || b >= c->b.n) return (uint64_t)~0ull;
+            const uint32_t o = pair_owner(a, b, c->host_kind[a] == EDYNHIP_KIND_DYNAMIC, c->host_kind[b] == EDYNHIP_KIND_DYNAMIC);
+            return ((uint64_t)o << 32) | (o == a ? b : a);
         };
         if (!(key(in[i - 1]) < key(in[i]))) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_manifolds: records not sorted by canonical pair key");
     }
@@ -665,7 +677,7 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     edynhip_manifold *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, (size_t)n * sizeof(edynhip_manifold)));
     hipError_t e = hipMemcpyAsync(d, in, (size_t)n * sizeof(edynhip_manifold), hipMemcpyHostToDevice, c->stream);
-    hipLaunchKernelGGL(k_records_to_manifolds, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, d, c->m[c->cur]);
+    hipLaunchKernelGGL(k_records_to_manifolds, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, d, c->m[c->cur], c->b.flags);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_manifolds", e);
@@ -681,7 +693,11 @@ int edynhip_get_pairs(edynhip_ctx *c, uint64_t *keys, uint32_t capacity, uint32_
     EH_HIP(c, hipSetDevice(c->device));
     EH_HIP(c, hipMemcpyAsync(keys, c->m[c->cur].skey, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
-    for (uint32_t i = 0; i < M; ++i) keys[i] >>= 1;   // drop the orientation bit
+    for (uint32_t i = 0; i < M; ++i) {   // drop the orientation bit; (owner, other) -> the documented (max, min)
+        const uint32_t a = (uint32_t)(keys[i] >> 33), b = (uint32_t)(keys[i] >> 1);
+        keys[i] = ((uint64_t)std::max(a, b) << 32) | std::min(a, b);
+    }
+    std::sort(keys, keys + M);
     return EDYNHIP_OK;
 }
 

@@ -136,6 +136,7 @@ struct Counters {
     uint32_t pairs_changed;      // this step's pair set differs from the previous step's
     uint32_t num_found;          // new manifolds that already existed last step (== previous count <=> none removed)
     uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
+    uint32_t num_extra;          // pair keys beyond an owner's in-LDS list (broadphase fallback path)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
@@ -174,6 +175,8 @@ struct edynhip_ctx {
     eh::Rows rows;
     eh::LBVH bvh;
     uint64_t *pair_keys = nullptr, *pair_keys_sorted = nullptr;
+    uint64_t *own_keys = nullptr;                                  // [body][kOwnCap] sorted pair keys of each owner (broadphase.hip)
+    uint32_t *own_count = nullptr, *own_offset = nullptr;          // [bodies + 1]
     uint2 *new_edges = nullptr;    // body pairs of manifolds created this step (incremental island update)
     uint32_t prev_num_manifolds = 0;
     uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr, *col_vals = nullptr;   // colour sort
@@ -207,6 +210,7 @@ namespace eh {
 int broadphase(edynhip_ctx *c);
 int narrowphase(edynhip_ctx *c);
 int count_points(edynhip_ctx *c);
+int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);   // exclusive prefix sum
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count);
 int islands(edynhip_ctx *c);

@@ -2,6 +2,7 @@
 // Plain library primitive (rocPRIM device radix sort) — not a hot-path kernel.
 #include "ctx.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace eh {
 
@@ -10,7 +11,17 @@ size_t sort_temp_bytes(uint32_t max_items) {
     (void)rocprim::radix_sort_keys<rocprim::default_config, const uint64_t *, uint64_t *>(nullptr, a, nullptr, nullptr, max_items, 0, 64, nullptr);
     (void)rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
         nullptr, b, nullptr, nullptr, nullptr, nullptr, max_items, 0, 32, nullptr);
-    return (a > b ? a : b) + 256;
+    size_t d = 0;
+    (void)rocprim::exclusive_scan(nullptr, d, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)max_items, rocprim::plus<uint32_t>(), nullptr);
+    size_t m = a > b ? a : b;
+    return (m > d ? m : d) + 256;
+}
+
+int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n) {
+    if (n == 0) return EDYNHIP_OK;
+    size_t bytes = c->sort_tmp_bytes;
+    EH_HIP(c, rocprim::exclusive_scan(c->sort_tmp, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream));
+    return EDYNHIP_OK;
 }
 
 int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit) {

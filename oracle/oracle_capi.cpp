@@ -129,7 +129,7 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
             c.attachment = p.attachment; c.lifetime = p.lifetime;
             c.normal_impulse = p.normal_impulse; c.friction_impulse[0] = p.friction_impulse[0]; c.friction_impulse[1] = p.friction_impulse[1];
         }
-        w->manifolds.emplace(pair_key(m.body[0], m.body[1]), m);
+        w->manifolds.emplace(w->pair_key(m.body[0], m.body[1]), m);
     }
 }
 void orc_get_joint_impulses(void *h, float *imp5) {

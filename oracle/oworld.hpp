@@ -98,10 +98,11 @@ struct FrictionRow {
 };
 struct RowOptions { float error = 0, erp = 0.2f, restitution = 0; };
 
-inline uint64_t pair_key(uint32_t a, uint32_t b) {
-    uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
-    return ((uint64_t)hi << 32) | lo;
-}
+// Canonical key of an unordered body pair: (owner << 32) | other, where the OWNER is the procedural body - the one with
+// the higher index when both are procedural. Manifolds are kept, coloured and solved in ascending key order. (EnTT's
+// pool order is not reproducible, so a canonical order is needed anyway; owner-major order is what a GPU broadphase
+// produces without a sort: the owner is the body whose tree query finds the pair, broadphase.cpp:136-171.)
+inline uint64_t pair_key_owned(uint32_t owner, uint32_t other) { return ((uint64_t)owner << 32) | other; }
 inline uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
@@ -183,6 +184,12 @@ public:
     std::map<uint64_t, Manifold> manifolds;
     std::vector<uint32_t> island_label;   // per body; valid for procedural bodies after update_islands()
     StepStats stats;
+
+    uint64_t pair_key(uint32_t a, uint32_t b) const {   // see pair_key_owned
+        const bool pa = bodies[a].procedural(), pb = bodies[b].procedural();
+        if (pa && pb) return a > b ? pair_key_owned(a, b) : pair_key_owned(b, a);
+        return pa ? pair_key_owned(a, b) : pair_key_owned(b, a);
+    }
 
     // rigidbody.cpp:47-191 (make_rigidbody), restricted to the components on the hot path.
     uint32_t add_body(int kind, vec3 pos, quat orn, vec3 linvel, vec3 angvel, float mass, const shape &sh,

@@ -436,3 +436,65 @@ def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
     o = oracle_world(scenes.box_pile(6, 6, 6, mixed=True)); o.step(80)
     for a, b in zip((outs[0]["p"], outs[0]["q"], outs[0]["v"], outs[0]["a"]), o.get_state()):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ pair ownership (sort-free broadphase output)
+def _append_body(scene, **kw):
+    s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    n = len(s["kind"])
+    defaults = dict(kind=scenes.KIND_DYNAMIC, pos=(0, 0, 0), orn=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0), mass=1.0,
+                    shape_type=scenes.SHAPE_BOX, shape_param=(0.5, 0.5, 0.5, 0), friction=0.5, restitution=0.0,
+                    group=np.uint64(0xFFFFFFFFFFFFFFFF), mask=np.uint64(0xFFFFFFFFFFFFFFFF))
+    defaults.update(kw)
+    for k, v in defaults.items():
+        row = np.asarray(v, dtype=s[k].dtype).reshape((1,) + s[k].shape[1:])
+        s[k] = np.concatenate([s[k], row], axis=0)
+    for k in ("inertia", "has_inertia", "gravity"):
+        s.pop(k, None)
+    assert len(s["kind"]) == n + 1
+    return s
+
+
+def _drop_body(scene, idx):
+    s = {k: (np.delete(v, idx, axis=0) if isinstance(v, np.ndarray) and len(v) == len(scene["kind"]) else v) for k, v in scene.items()}
+    return s
+
+
+def test_static_body_with_the_highest_index():
+    """Pairs are owned by their procedural body; a static floor created AFTER the boxes (index above all of them) is the
+    case where owner != higher index. Same scene as the pile, floor moved to the end: bit-exact against the oracle."""
+    base = scenes.box_pile(5, 5, 5)
+    assert base["kind"][0] == scenes.KIND_STATIC
+    s = _drop_body(base, 0)
+    s = _append_body(s, kind=scenes.KIND_STATIC, shape_type=scenes.SHAPE_PLANE, shape_param=(0, 1, 0, 0), mass=0.0)
+    g = gpu_world(s); o = oracle_world(s)
+    for step in range(60):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="floor last")
+    m = g.get_manifolds()
+    floor = len(s["kind"]) - 1
+    assert (m["body"][:, 1] == floor).any() and not (m["body"][:, 0] == floor).any(), "the box is body[0], the floor body[1]"
+
+
+def test_owner_with_more_partners_than_the_in_kernel_list():
+    """One wide plate, created last, rests on 49 bricks: it owns more pairs than the per-lane list holds (32), so the
+    surplus takes the sorted fallback path. Pair sets, manifolds and trajectories must still match the oracle exactly."""
+    s = scenes.box_pile(7, 1, 7)   # (a body with more than 63 simultaneous partners exceeds the colour masks: EDYNHIP_ERR_COLOURS)
+    top = float(s["pos"][:, 1].max()) + 0.5
+    xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
+    s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(4.1, 0.25, 4.1, 0), mass=20.0)
+    g = gpu_world(s); o = oracle_world(s)
+    plate = len(s["kind"]) - 1
+    most = 0
+    for step in range(50):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+        m = g.get_manifolds()
+        most = max(most, int(((m["body"] == plate).any(axis=1)).sum()))
+    assert most > 40, most
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="plate")
