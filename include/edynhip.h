@@ -167,6 +167,9 @@ int edynhip_pack_state_device(edynhip_ctx *ctx, void *dst_device, uint32_t first
 /* Derived per-body state: aabb[n][6] (min,max), inertia_world_inv[n][9], island label[n]; any may be NULL. */
 int edynhip_get_derived(edynhip_ctx *ctx, float *aabb, float *inertia_world_inv, uint32_t *island);
 
+/* Manifolds are kept (and returned) in ascending canonical order: key = (owner << 32) | other, where the owner is the
+ * pair's procedural (dynamic) body - the one with the higher index when both are dynamic. edynhip_set_manifolds expects
+ * records in that order. (EnTT's pool order is not reproducible; the solver visits manifolds in this order.) */
 int edynhip_num_manifolds(edynhip_ctx *ctx, uint32_t *n);
 int edynhip_get_manifolds(edynhip_ctx *ctx, edynhip_manifold *out, uint32_t capacity, uint32_t *n);
 int edynhip_set_manifolds(edynhip_ctx *ctx, const edynhip_manifold *in, uint32_t n);
