@@ -64,6 +64,10 @@ def lib():
             C.c_uint64, C.c_uint64, C.POINTER(C.c_float)]
         L.orc_add_joint.restype = C.c_uint32
         L.orc_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_float)] * 4
+        L.orc_set_sleeping.argtypes = [C.c_void_p, C.c_int]; L.orc_set_sleeping.restype = None
+        L.orc_set_sleeping_disabled.argtypes = [C.c_void_p, C.c_uint32, C.c_int]; L.orc_set_sleeping_disabled.restype = None
+        L.orc_wake_all.argtypes = [C.c_void_p]; L.orc_wake_all.restype = None
+        L.orc_get_asleep.argtypes = [C.c_void_p, C.c_void_p]; L.orc_get_asleep.restype = None
         L.orc_step.argtypes = [C.c_void_p, C.c_int]
         L.orc_run_stage.argtypes = [C.c_void_p, C.c_int]
         L.orc_num_bodies.restype = C.c_uint32
@@ -225,6 +229,20 @@ class World:
         self.n_joints += 1
         return self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
                                     _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+
+    def set_sleeping(self, enable=True):
+        self.L.orc_set_sleeping(self.h, 1 if enable else 0)
+
+    def set_sleeping_disabled(self, body, disabled=True):
+        self.L.orc_set_sleeping_disabled(self.h, int(body), 1 if disabled else 0)
+
+    def wake_all(self):
+        self.L.orc_wake_all(self.h)
+
+    def get_asleep(self):
+        out = np.zeros(self.num_bodies, np.uint8)
+        self.L.orc_get_asleep(self.h, out.ctypes.data)
+        return out.astype(bool)
 
     def step(self, n=1):
         self.L.orc_step(self.h, n)

@@ -57,6 +57,14 @@ uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *p
                        const float *axisA, const float *axisB) {
     return ((World *)h)->add_joint(type, a, b, v3(pivotA), v3(pivotB), v3(axisA), v3(axisB));
 }
+// island sleeping (off by default)
+void orc_set_sleeping(void *h, int enable) { ((World *)h)->sleeping = enable != 0; }
+void orc_set_sleeping_disabled(void *h, uint32_t body, int disabled) { ((World *)h)->bodies[body].sleeping_disabled = disabled != 0; }
+void orc_wake_all(void *h) { ((World *)h)->wake_all(); }
+void orc_get_asleep(void *h, uint8_t *out) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) out[i] = w->bodies[i].asleep ? 1 : 0;
+}
 void orc_step(void *h, int n) { World *w = (World *)h; for (int i = 0; i < n; ++i) w->step(); }
 void orc_run_stage(void *h, int stage) {
     World *w = (World *)h;

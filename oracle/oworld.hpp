@@ -54,6 +54,8 @@ struct Body {
     aabb box{};
     vec3 dv{0, 0, 0}, dw{0, 0, 0};
     uint32_t leaf = DynTree::NIL;
+    bool asleep = false;             // sleeping_tag (island_manager.cpp:541-565)
+    bool sleeping_disabled = false;  // sleeping_disabled_tag
     bool procedural() const { return kind == KIND_DYNAMIC; }
     bool rolling() const { return kind == KIND_DYNAMIC && sh.type == SHAPE_SPHERE; }
 };
@@ -184,6 +186,13 @@ public:
     std::map<uint64_t, Manifold> manifolds;
     std::vector<uint32_t> island_label;   // per body; valid for procedural bodies after update_islands()
     StepStats stats;
+    // Island sleeping (island_manager.cpp:541-623). Off by default: the benchmark scenes tag every body
+    // sleeping_disabled. Islands are identified by their label (lowest body index); the reference keeps
+    // island entities and, on a merge, the larger island's timer - a difference only in which timer survives a merge.
+    bool sleeping = false;
+    uint64_t step_index = 0;
+    std::vector<int64_t> sleep_since;      // per label: step at which the island first qualified for sleep, -1 = not counting
+    std::vector<uint64_t> new_keys;        // manifolds created by this step's broadphase (they wake their island)
 
     uint64_t pair_key(uint32_t a, uint32_t b) const {   // see pair_key_owned
         const bool pa = bodies[a].procedural(), pb = bodies[b].procedural();
@@ -237,7 +246,23 @@ public:
         narrowphase();
         update_islands();
         solve();
+        ++step_index;
     }
+    bool manifold_asleep(const Manifold &m) const {   // every procedural endpoint sleeps (an island sleeps as a whole)
+        const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        bool any_proc = false;
+        if (A.procedural()) { if (!A.asleep) return false; any_proc = true; }
+        if (B.procedural()) { if (!B.asleep) return false; any_proc = true; }
+        return any_proc;
+    }
+    bool joint_asleep(const Joint &j) const {
+        const Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        bool any_proc = false;
+        if (A.procedural()) { if (!A.asleep) return false; any_proc = true; }
+        if (B.procedural()) { if (!B.asleep) return false; any_proc = true; }
+        return any_proc;
+    }
+    void wake_all() { for (auto &b : bodies) b.asleep = false; std::fill(sleep_since.begin(), sleep_since.end(), (int64_t)-1); }
 
     // ---------------- broadphase ----------------
     bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:23-57 (no exclusion lists)
@@ -250,20 +275,21 @@ public:
         const float sep = kContactBreakingThreshold * 1.3f;   // broadphase.hpp:18
         const vec3 sep_off = vec3{1, 1, 1} * -sep;
         const vec3 q_off = vec3{1, 1, 1} * -kContactBreakingThreshold;   // broadphase.hpp:15
-        for (auto it = manifolds.begin(); it != manifolds.end();) {   // destroy_separated_manifolds
+        new_keys.clear();
+        for (auto it = manifolds.begin(); it != manifolds.end();) {   // destroy_separated_manifolds (sleeping manifolds excluded)
             const aabb &b0 = bodies[it->second.body[0]].box, &b1 = bodies[it->second.body[1]].box;
-            if (!intersect(b0.inset(sep_off), b1)) it = manifolds.erase(it);
+            if (!manifold_asleep(it->second) && !intersect(b0.inset(sep_off), b1)) it = manifolds.erase(it);
             else ++it;
         }
         for (auto &b : bodies) {   // move_aabbs
-            if (b.sh.type == SHAPE_NONE) continue;
+            if (b.sh.type == SHAPE_NONE || b.asleep) continue;
             if (b.procedural()) tree_.move(b.leaf, b.box);
             else if (b.kind == KIND_KINEMATIC) np_tree_.move(b.leaf, b.box);
         }
         // EnTT views iterate a pool back to front, i.e. most recently created body first.
         for (uint32_t k = (uint32_t)bodies.size(); k-- > 0;) {
             const Body &b = bodies[k];
-            if (!b.procedural() || b.sh.type == SHAPE_NONE) continue;
+            if (!b.procedural() || b.sh.type == SHAPE_NONE || b.asleep) continue;   // sleeping bodies do not query
             const aabb q = b.box.inset(q_off);
             auto visit_tree = [&](const DynTree &t) {
                 t.query(q, [&](uint32_t leaf) {
@@ -274,6 +300,7 @@ public:
                     if (!intersect(q, bodies[other].box)) return;
                     Manifold m; m.body[0] = k; m.body[1] = other;   // constraint_util.cpp:60-102
                     manifolds.emplace(key, m);
+                    new_keys.push_back(key);
                 });
             };
             visit_tree(tree_);
@@ -428,8 +455,9 @@ public:
         if (n_out == 0) m.colour = kNoColour;   // inactive pairs hold no solver colour
     }
     void narrowphase() {
-        for (auto &kv : manifolds) {   // update_contact_distances, collision_util.cpp:28-45
+        for (auto &kv : manifolds) {   // update_contact_distances, collision_util.cpp:28-45 (narrowphase.cpp:31 excludes sleeping)
             Manifold &m = kv.second;
+            if (manifold_asleep(m)) continue;
             const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
             for (int i = 0; i < m.num_points; ++i) {
                 vec3 pA = to_world(m.pt[i].pivotA, A.pos, A.orn), pB = to_world(m.pt[i].pivotB, B.pos, B.orn);
@@ -437,6 +465,7 @@ public:
             }
         }
         for (auto &kv : manifolds) {
+            if (manifold_asleep(kv.second)) continue;
             coll_result res;
             detect(kv.second, res);
             process_collision(kv.second, res);
@@ -466,6 +495,51 @@ public:
             if (bodies[i].procedural() && island_label[i] == i) ++count;
         }
         stats.num_islands = count;
+        if (sleeping) update_sleep();
+    }
+    // wake_up / put_islands_to_sleep (island_manager.cpp:524-539, 573-623). An island that received a new edge, or
+    // that holds both sleeping and awake bodies (a merge), wakes as a whole. An awake island whose bodies are all below
+    // the thresholds starts / continues its timer and goes to sleep once it has run for more than island_time_to_sleep;
+    // the timer compares the PREVIOUS update's time stamps, i.e. (steps elapsed) * dt.
+    void update_sleep() {
+        const uint32_t n = (uint32_t)bodies.size();
+        enum { FAST = 1, DISABLED = 2, HAS_ASLEEP = 4, HAS_AWAKE = 8, WAKE = 16 };
+        std::vector<uint8_t> st(n, 0);
+        sleep_since.resize(n, -1);
+        const float lin2 = 0.005f * 0.005f, ang = kPi / 48.0f, ang2 = ang * ang;   // config/constants.hpp:41-42
+        for (uint32_t i = 0; i < n; ++i) {
+            const Body &b = bodies[i];
+            if (!b.procedural()) continue;
+            uint8_t &s = st[island_label[i]];
+            if (length_sqr(b.linvel) > lin2 || length_sqr(b.angvel) > ang2) s |= FAST;
+            if (b.sleeping_disabled) s |= DISABLED;
+            s |= b.asleep ? HAS_ASLEEP : HAS_AWAKE;
+        }
+        for (uint64_t key : new_keys) {
+            auto it = manifolds.find(key);
+            if (it == manifolds.end()) continue;
+            const uint32_t a = it->second.body[0], b = it->second.body[1];
+            st[bodies[a].procedural() ? island_label[a] : island_label[b]] |= WAKE;
+        }
+        std::vector<uint8_t> action(n, 0);   // 0 keep, 1 awake, 2 sleep
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!bodies[i].procedural() || island_label[i] != i) { sleep_since[i] = -1; continue; }
+            const uint8_t s = st[i];
+            const bool wake = (s & WAKE) || ((s & HAS_ASLEEP) && (s & HAS_AWAKE));
+            if ((s & HAS_ASLEEP) && !(s & HAS_AWAKE) && !wake) { action[i] = 0; continue; }   // stays asleep
+            action[i] = 1;
+            if (!(s & DISABLED) && !(s & FAST)) {
+                if (sleep_since[i] < 0) sleep_since[i] = (int64_t)step_index;
+                else if ((double)(step_index - (uint64_t)sleep_since[i]) * (double)dt > 2.0) { action[i] = 2; sleep_since[i] = -1; }
+            } else sleep_since[i] = -1;
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            Body &b = bodies[i];
+            if (!b.procedural()) continue;
+            const uint8_t a = action[island_label[i]];
+            if (a == 1) b.asleep = false;
+            else if (a == 2) { b.asleep = true; b.linvel = {0, 0, 0}; b.angvel = {0, 0, 0}; }
+        }
     }
 
     // ---------------- colouring (shared spec with the GPU; see DESIGN.md "Colouring") ----------------
@@ -517,6 +591,10 @@ public:
         // last step's top colour is released and first-fit again (keeps the colour count from drifting up)
         const uint32_t reinsert = stats.num_colours >= 2 ? stats.num_colours - 1 : kNoColour;
         for (Manifold *m : ms) {
+            if (manifold_asleep(*m)) {   // out of the solve, but it keeps its colour for when the island wakes
+                if (m->colour != kNoColour) for (int s = 0; s < 2; ++s) if (bodies[m->body[s]].procedural()) used[m->body[s]] |= 1ull << m->colour;
+                continue;
+            }
             if (m->num_points == 0) { m->colour = kNoColour; continue; }   // inactive edges hold no colour
             if (m->colour == reinsert) m->colour = kNoColour;
             if (m->colour != kNoColour) {
@@ -525,7 +603,7 @@ public:
         }
         stats.colour_rounds = colour_edges((uint32_t)ms.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
             a = ms[e]->body[0]; b = ms[e]->body[1];
-            col = ms[e]->num_points > 0 ? &ms[e]->colour : nullptr;
+            col = (ms[e]->num_points > 0 && !manifold_asleep(*ms[e])) ? &ms[e]->colour : nullptr;
         }, used);
         uint32_t nc = 0;
         for (Manifold *m : ms) if (m->colour != kNoColour) nc = std::max(nc, m->colour + 1);
@@ -692,9 +770,10 @@ public:
         dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
         // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
         for (auto &b : bodies)   // apply_gravity.hpp:12-17
-            if (b.kind == KIND_DYNAMIC && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
+            if (b.kind == KIND_DYNAMIC && !b.asleep && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
         if (order == ORDER_SEQUENTIAL) solve_sequential(); else solve_coloured();
         for (auto &b : bodies) {   // update_aabbs (dynamic + kinematic), update_inertias (dynamic)
+            if (b.asleep) continue;   // update_aabbs / update_inertias views exclude sleeping entities
             if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.pos, b.orn);
             if (b.kind == KIND_DYNAMIC) {
                 mat3 basis = to_mat3(b.orn);
@@ -713,7 +792,7 @@ public:
         std::map<uint32_t, std::vector<Joint *>> isl_j;
         std::map<uint32_t, std::vector<uint32_t>> isl_b;
         auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
-        for (uint32_t i = 0; i < bodies.size(); ++i) if (bodies[i].procedural()) isl_b[island_label[i]].push_back(i);
+        for (uint32_t i = 0; i < bodies.size(); ++i) if (bodies[i].procedural() && !bodies[i].asleep) isl_b[island_label[i]].push_back(i);   // solver.cpp:408 excludes sleeping islands
         for (auto &kv : manifolds) isl_m[label_of(kv.second.body[0], kv.second.body[1])].push_back(&kv.second);
         for (auto &j : joints) isl_j[label_of(j.body[0], j.body[1])].push_back(&j);
         stats.num_rows = 0;
@@ -779,6 +858,7 @@ public:
         std::vector<std::vector<JRows>> jc(stats.num_joint_colours);
         stats.num_rows = 0;
         for (auto &j : joints) {
+            if (joint_asleep(j)) continue;
             JRows jr; jr.j = &j;
             jr.n = prepare_joint(j, body_ref(j.body[0]), body_ref(j.body[1]), jr.r);
             stats.num_rows += jr.n;
@@ -786,7 +866,7 @@ public:
         }
         for (auto &kv : manifolds) {
             Manifold &m = kv.second;
-            if (m.num_points == 0) continue;
+            if (m.num_points == 0 || manifold_asleep(m)) continue;
             CRows cr; cr.m = &m;
             BodyRef A = body_ref(m.body[0]), B = body_ref(m.body[1]);
             for (int i = 0; i < m.num_points; ++i) prepare_contact(m.pt[i], A, B, cr.nr[i], cr.fr[i]);
@@ -805,7 +885,7 @@ public:
                 for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
             }
         }
-        for (auto &b : bodies) if (b.kind == KIND_DYNAMIC) integrate_body(b);
+        for (auto &b : bodies) if (b.kind == KIND_DYNAMIC && !b.asleep) integrate_body(b);
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) jr.j->impulse[i] = jr.r[i].impulse;
         for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) {
             cr.m->pt[i].normal_impulse = cr.nr[i].impulse;
