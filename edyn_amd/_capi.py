@@ -27,7 +27,8 @@ class Bodies(C.Structure):
     _fields_ = [("kind", C.c_void_p), ("pos", C.c_void_p), ("orn", C.c_void_p), ("linvel", C.c_void_p),
                 ("angvel", C.c_void_p), ("mass", C.c_void_p), ("inertia", C.c_void_p), ("has_inertia", C.c_void_p),
                 ("shape_type", C.c_void_p), ("shape_param", C.c_void_p), ("friction", C.c_void_p),
-                ("restitution", C.c_void_p), ("group", C.c_void_p), ("mask", C.c_void_p), ("gravity", C.c_void_p)]
+                ("restitution", C.c_void_p), ("group", C.c_void_p), ("mask", C.c_void_p), ("gravity", C.c_void_p),
+                ("sleeping_disabled", C.c_void_p)]
 
 
 class Joints(C.Structure):
@@ -54,7 +55,7 @@ POINT_DTYPE = np.dtype([
 MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
-FLAG_TIMING, FLAG_NO_GRAPH = 1, 2
+FLAG_TIMING, FLAG_NO_GRAPH, FLAG_SLEEPING = 1, 2, 4
 STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
 
 # every symbol include/edynhip.h declares (checked by tests/test_abi.py)
@@ -62,7 +63,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_joints", "edynhip_step", "edynhip_run_stages", "edynhip_synchronize", "edynhip_get_state",
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
-           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies"]
+           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all"]
 
 _lib = None
 
@@ -97,6 +98,8 @@ def lib():
         L.edynhip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
         L.edynhip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.edynhip_debug_collide.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
+        L.edynhip_get_asleep.argtypes = [C.c_void_p, C.c_void_p]
+        L.edynhip_wake_all.argtypes = [C.c_void_p]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L
     return _lib

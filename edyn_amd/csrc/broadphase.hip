@@ -230,6 +230,20 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
     }
 }
 
+// A sleeping body does not query (broadphase.cpp:101,183 views exclude sleeping_tag), so an awake body i that touches a
+// sleeping body j with a HIGHER index has to report the pair itself although j is its owner. Such pairs are new contacts
+// onto a sleeping island - rare events - and take the unsorted `extra` path (j re-emits its existing manifolds itself).
+DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
+                                const uint64_t *mask, const Manifolds &prev, uint32_t pm, Emit &em) {
+    if (find_prev(prev, pm, j, i) != 0xFFFFFFFFu) return;
+    if (!filter_ok(group, mask, i, j)) return;
+    const box3 bj = body_box(amin, amax, j);
+    if (!intersect(inset(bi, -kBreaking), bj)) return;
+    const uint64_t skey = (((((uint64_t)j << 32) | i) << 1) | 1u);   // body[0] = i, the querying body
+    const uint32_t g = atomicAdd(&em.cnt->num_extra, 1u);
+    if (g < em.cap) em.extra[g] = skey; else em.cnt->pair_overflow = 1;
+}
+
 // Two phases per lane so that the wave stays converged: (1) BVH traversal that only records the candidate leaves
 // (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be paid by the
 // whole wave on every iteration), (2) a dense loop over the recorded candidates running the exact predicates.
@@ -238,7 +252,8 @@ __global__ void __launch_bounds__(128)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, const uint64_t *__restrict__ group,
            const uint64_t *__restrict__ mask, const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
-           uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit) {
+           uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit,
+           const uint32_t *__restrict__ flags, bool sleeping) {
     __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
     __shared__ uint32_t cand[kCandCap][128];     // candidate bodies per lane
     __shared__ uint64_t mine[kOwnCap][128];      // this lane's (= this owner's) pair keys
@@ -248,6 +263,17 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     if (k >= n) return;
     Emit em{mine, tx, 0, extra, cap, cnt};
     const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+    if (sleeping && (flags[i] & BF_ASLEEP)) {
+        // a sleeping owner keeps its manifolds as they are (destroy_separated_manifolds excludes them): its previous
+        // segment is already in ascending order
+        uint32_t c = 0;
+        if (pm) for (uint32_t s = prev.seg_start[i], e = prev.seg_end[i]; s < e; ++s, ++c) {
+            if (c < (uint32_t)kOwnCap) own_keys[(size_t)i * kOwnCap + c] = prev.skey[s];
+            else { const uint32_t g = atomicAdd(&cnt->num_extra, 1u); if (g < cap) extra[g] = prev.skey[s]; else cnt->pair_overflow = 1; }
+        }
+        own_count[i] = min(c, (uint32_t)kOwnCap);
+        return;
+    }
     const box3 bi = body_box(amin, amax, i);
     const box3 q = inset(bi, -kQueryGrow);
     int nc = 0;
@@ -263,6 +289,8 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
                 if (j < i) {
                     if (nc < kCandCap) cand[nc++][tx] = j;
                     else consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);   // rare overflow path
+                } else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) {
+                    consider_sleeping_owner(i, j, bi, amin, amax, group, mask, prev, pm, em);
                 }
             } else if (sp <= 46) {
                 stk[sp++][tx] = __float_as_uint(lo4.w);
@@ -369,7 +397,7 @@ int broadphase(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         }
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);

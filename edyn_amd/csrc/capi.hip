@@ -67,6 +67,8 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M)); EH_TRY(dalloc(c, c->col_vals, M));
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));
+    EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
+    EH_HIP(c, hipMemsetAsync(c->sleep_since, 0xFF, (size_t)nb * sizeof(int32_t), c->stream));   // -1: no timer running
     Joints &j = c->j;
     j.cap = nj;
     EH_TRY(dalloc(c, j.orig, nj)); EH_TRY(dalloc(c, j.type, nj)); EH_TRY(dalloc(c, j.bodyA, nj)); EH_TRY(dalloc(c, j.bodyB, nj));
@@ -86,7 +88,7 @@ static int allocate(edynhip_ctx *c) {
 // Scene upload: raw packed arrays -> float4 SoA + derived quantities (rigidbody.cpp:47-131).
 struct RawBodies {
     const int32_t *kind; const float *pos, *orn, *linvel, *angvel, *mass, *inertia; const uint8_t *has_inertia;
-    const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity;
+    const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity; const uint8_t *sleeping_disabled;
 };
 __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b, float3 default_gravity) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;   // index into the caller's arrays
@@ -143,7 +145,7 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
     f3 g = r.gravity ? mk3(r.gravity[3 * l], r.gravity[3 * l + 1], r.gravity[3 * l + 2]) : mk3(default_gravity.x, default_gravity.y, default_gravity.z);
     b.grav[i] = kind == EDYNHIP_KIND_DYNAMIC ? to4(g, 0) : make_float4(0, 0, 0, 0);
     b.mat[i] = make_float2(r.friction[l], r.restitution[l]);
-    b.flags[i] = (uint32_t)kind | ((uint32_t)st << BF_SHAPE_SHIFT);
+    b.flags[i] = (uint32_t)kind | ((uint32_t)st << BF_SHAPE_SHIFT) | ((r.sleeping_disabled && r.sleeping_disabled[l]) ? BF_NOSLEEP : 0u);
     b.group[i] = r.group ? r.group[l] : ~0ull;
     b.mask[i] = r.mask ? r.mask[l] : ~0ull;
     b.island[i] = i;
@@ -322,7 +324,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 1; }
+uint32_t edynhip_abi_version(void) { return 2; }   // 2: edynhip_bodies.sleeping_disabled, edynhip_add_bodies, sleeping entry points
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -341,6 +343,7 @@ edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out) {
     if (e != hipSuccess) return fail(EDYNHIP_ERR_HIP, "hipSetDevice", e);
     edynhip_ctx *c = new edynhip_ctx();
     c->cfg = *cfg;
+    c->sleeping = (cfg->flags & EDYNHIP_FLAG_SLEEPING) != 0;
     c->device = cfg->device;
     if (c->cfg.max_manifolds == 0) c->cfg.max_manifolds = 16 * c->cfg.max_bodies + 1024;
     if (c->cfg.fixed_dt <= 0) c->cfg.fixed_dt = 1.0f / 60.0f;
@@ -403,6 +406,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     up(in->shape_type, n, r.shape_type); up(in->shape_param, (size_t)n * 4, r.shape_param);
     up(in->friction, n, r.friction); up(in->restitution, n, r.restitution);
     up(in->group, n, r.group); up(in->mask, n, r.mask); up(in->gravity, (size_t)n * 3, r.gravity);
+    up(in->sleeping_disabled, n, r.sleeping_disabled);
     const uint32_t total = first + n;
     if (rc == EDYNHIP_OK) {
         c->b.n = total;
@@ -602,6 +606,33 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_state", e);
+    if (c->sleeping) return edynhip_wake_all(c);   // an edited body wakes its island (wake_up_entity); all of them here
+    return EDYNHIP_OK;
+}
+
+__global__ void k_wake_all(uint32_t n, uint32_t *flags, int32_t *since) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] &= ~BF_ASLEEP;
+    since[i] = -1;
+}
+int edynhip_wake_all(edynhip_ctx *c) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    if (c->b.n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_wake_all, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b.flags, c->sleep_since);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
+}
+int edynhip_get_asleep(edynhip_ctx *c, uint8_t *asleep) {
+    if (!c || !asleep) return EDYNHIP_ERR_INVALID;
+    const uint32_t n = c->b.n;
+    if (n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    std::vector<uint32_t> fl(n);
+    EH_HIP(c, hipMemcpyAsync(fl.data(), c->b.flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) asleep[i] = (fl[i] & BF_ASLEEP) ? 1 : 0;
     return EDYNHIP_OK;
 }
 

@@ -20,6 +20,13 @@ constexpr int kMaxPts = 4;
 constexpr uint32_t BF_KIND_MASK = 0x3u;        // EDYNHIP_KIND_*
 constexpr uint32_t BF_SHAPE_SHIFT = 4;         // EDYNHIP_SHAPE_* in bits 4..7
 constexpr uint32_t BF_SHAPE_MASK = 0xF0u;
+constexpr uint32_t BF_ASLEEP = 0x100u;         // sleeping_tag: the body's island is asleep (island sleeping, solver.hip k_sleep_*)
+constexpr uint32_t BF_NOSLEEP = 0x200u;        // sleeping_disabled_tag
+// An edge (manifold, joint) sleeps when every procedural endpoint sleeps (an island sleeps as a whole).
+__host__ __device__ inline bool edge_asleep(uint32_t fa, uint32_t fb) {
+    const bool da = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC, db = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC;
+    return (da || db) && (!da || (fa & BF_ASLEEP)) && (!db || (fb & BF_ASLEEP));
+}
 
 struct Bodies {
     uint32_t n = 0, cap = 0;
@@ -198,6 +205,10 @@ struct edynhip_ctx {
     std::vector<void *> allocs;
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
+    bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
+    uint32_t step_index = 0;       // completed steps (island sleep timers count in steps)
+    uint32_t *sleep_state = nullptr, *sleep_action = nullptr;   // per island label: reduction bits / decision
+    int32_t *sleep_since = nullptr;                             // per island label: step at which its timer started, -1 = not running
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel

@@ -74,13 +74,14 @@ DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
 }
 
 __global__ void __launch_bounds__(64, 2)
-k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt) {
+k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) {
         const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
         const uint32_t info = mf.info[m];
         const int n_old = (int)(info & 0xFF);
         const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+        if (sleeping && edge_asleep(fa, fb)) return;   // narrowphase.cpp:31: sleeping manifolds are left as they are
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
         BodyIn A, B;
         { float4 p = B_POS(b, ia); A.pos = from4(p); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
@@ -255,7 +256,7 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
 int narrowphase(edynhip_ctx *c) {
     const uint32_t M = c->num_manifolds;
     if (M == 0) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt);
+    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }

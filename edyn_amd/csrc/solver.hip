@@ -134,6 +134,59 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
     if ((threadIdx.x & 63) == 0 && root) atomicAdd(&cnt->num_islands, root);
 }
 
+// ------------------------------------------------------------------ island sleeping (island_manager.cpp:524-623)
+// Islands are identified by their label (lowest body index). Per step, after the labels: (1) reduce every island's
+// bodies into state bits, (2) mark the islands that received a manifold created this step, (3) one lane per island
+// decides - wake (new edge, or sleeping and awake bodies merged), keep sleeping, run / restart the timer, go to sleep
+// once the timer has run for more than island_time_to_sleep (the reference compares the previous update's time
+// stamps, i.e. elapsed steps x dt) - (4) every body applies its island's decision (put_to_sleep zeroes velocities).
+enum { SL_FAST = 1, SL_DISABLED = 2, SL_HAS_ASLEEP = 4, SL_HAS_AWAKE = 8, SL_WAKE = 16 };
+enum { SLA_KEEP = 0, SLA_AWAKE = 1, SLA_SLEEP = 2 };
+__global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t fl = b.flags[i];
+    if (!is_dynamic(fl)) return;
+    const f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
+    const float lin = 0.005f, ang = 3.1415926535897932384626433832795029f / 48.0f;   // config/constants.hpp:41-42
+    uint32_t bits = (fl & BF_ASLEEP) ? SL_HAS_ASLEEP : SL_HAS_AWAKE;
+    if (length_sqr(v) > lin * lin || length_sqr(w) > ang * ang) bits |= SL_FAST;
+    if (fl & BF_NOSLEEP) bits |= SL_DISABLED;
+    atomicOr(&state[b.island[i]], bits);
+}
+__global__ void k_sleep_edges(const uint2 *__restrict__ edges, const Counters *cnt, const uint32_t *__restrict__ label, uint32_t *state) {
+    const uint32_t n = cnt->num_new;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
+        atomicOr(&state[label[edges[e].x]], (uint32_t)SL_WAKE);   // .x = the pair's owner: always procedural
+}
+__global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *action, int32_t *since, uint32_t step, float dt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = state[i];
+    state[i] = 0;
+    if (!is_dynamic(b.flags[i]) || b.island[i] != i) { since[i] = -1; return; }
+    const bool wake = (s & SL_WAKE) || ((s & SL_HAS_ASLEEP) && (s & SL_HAS_AWAKE));
+    if ((s & SL_HAS_ASLEEP) && !(s & SL_HAS_AWAKE) && !wake) { action[i] = SLA_KEEP; return; }
+    uint32_t a = SLA_AWAKE;
+    if (!(s & SL_DISABLED) && !(s & SL_FAST)) {
+        if (since[i] < 0) since[i] = (int32_t)step;
+        else if ((double)(step - (uint32_t)since[i]) * (double)dt > 2.0) { a = SLA_SLEEP; since[i] = -1; }
+    } else since[i] = -1;
+    action[i] = a;
+}
+__global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__ action) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t fl = b.flags[i];
+    if (!is_dynamic(fl)) return;
+    const uint32_t a = action[b.island[i]];
+    if (a == SLA_AWAKE) { if (fl & BF_ASLEEP) b.flags[i] = fl & ~BF_ASLEEP; }
+    else if (a == SLA_SLEEP) {
+        b.flags[i] = fl | BF_ASLEEP;
+        b.linvel[i] = make_float4(0, 0, 0, 0); b.angvel[i] = make_float4(0, 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------ colouring
 // `reinsert` = last step's top colour: its edges are released and first-fit again, so colour classes freed by
 // vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards.
@@ -145,14 +198,17 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
     if (m < M) {
         uint32_t in = info[m];
         uint32_t np = in & 0xFF, col = in >> 8;
-        if (np > 0 && col == reinsert) { col = kNoColour; info[m] = np | (kNoColour << 8); }
+        const uint32_t a = bA[m], b = bB[m];
+        const uint32_t fa = flags[a], fb = flags[b];
+        // a sleeping manifold is out of the solve but keeps (and blocks) its colour for when its island wakes
+        const bool asleep = edge_asleep(fa, fb);
+        if (np > 0 && col == reinsert && !asleep) { col = kNoColour; info[m] = np | (kNoColour << 8); }
         if (np > 0) {
-            uint32_t a = bA[m], b = bB[m];
-            bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
+            bool da = is_dynamic(fa), db = is_dynamic(fb);
             if (col != kNoColour) {
                 if (da) atomicOr((unsigned long long *)&used[a], 1ull << col);
                 if (db) atomicOr((unsigned long long *)&used[b], 1ull << col);
-            } else {
+            } else if (!asleep) {
                 unc = 1;
                 if (da) { best0[a] = 0; best1[a] = 0; }
                 if (db) { best0[b] = 0; best1[b] = 0; }
@@ -172,6 +228,7 @@ __global__ void k_col_best(uint32_t M, const uint32_t *__restrict__ info, const 
     uint32_t in = info[m];
     if ((in & 0xFF) == 0 || (in >> 8) != kNoColour) return;
     uint32_t a = bA[m], b = bB[m];
+    if (edge_asleep(flags[a], flags[b])) return;
     uint64_t pr = edge_prio(m);
     if (is_dynamic(flags[a])) { atomicMax((unsigned long long *)&best_cur[a], pr); best_next[a] = 0; }
     if (is_dynamic(flags[b])) { atomicMax((unsigned long long *)&best_cur[b], pr); best_next[b] = 0; }
@@ -188,7 +245,7 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
             uint32_t a = bA[m], b = bB[m];
             bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
             uint64_t pr = edge_prio(m);
-            if (!(da && best_cur[a] != pr) && !(db && best_cur[b] != pr)) {
+            if (!edge_asleep(flags[a], flags[b]) && !(da && best_cur[a] != pr) && !(db && best_cur[b] != pr)) {
                 uint64_t busy = (da ? used[a] : 0ull) | (db ? used[b] : 0ull);
                 uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
                 if (c >= kMaxContactColours) { cnt->colour_overflow = 1; c = kMaxContactColours - 1; }
@@ -203,13 +260,15 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicSub(&cnt->uncoloured, done);
 }
-__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, uint32_t *vals) {
+__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, uint32_t *vals, const uint32_t *__restrict__ bA,
+                           const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, bool sleeping) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     // within a colour, manifolds are grouped by point count (4 first): the solve kernels then know a lane's point
     // count from its position alone (no dependent load) and waves are uniform in it
     uint32_t in = info[m];
     uint32_t np = in & 0xFF;
+    if (sleeping && np && edge_asleep(flags[bA[m]], flags[bB[m]])) np = 0;   // not part of this step's solve
     keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0xFFu;
     vals[m] = m;
 }
@@ -254,7 +313,7 @@ __global__ void k_solve_begin(uint32_t n, Bodies b, float dt, uint32_t *first_sl
     if (is_dynamic(fl)) {
         inv_m = B_POS(b, i).w;
         f3 g = from4(b.grav[i]);
-        if (!(g.x == 0 && g.y == 0 && g.z == 0)) {
+        if (!(g.x == 0 && g.y == 0 && g.z == 0) && !(fl & BF_ASLEEP)) {   // apply_gravity.hpp:13 excludes sleeping bodies
             f3 v = from4(b.linvel[i]);
             v += g * dt;
             b.linvel[i] = to4(v, 0);
@@ -723,6 +782,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= j.n) return;
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    if (edge_asleep(b.flags[ia], b.flags[ib])) return;   // sleeping island: its joints are not prepared or solved
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
@@ -747,6 +807,7 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= end) return;
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    if (edge_asleep(b.flags[ia], b.flags[ib])) return;
     Delta d;
     load_delta(b, ia, ib, d);
     const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]);
@@ -777,7 +838,7 @@ __global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     isl_err[i] = 0; isl_done[i] = 0;   // per-island position-solver state (indexed by island label = a body index)
-    if (!is_dynamic(b.flags[i])) return;
+    if (!is_dynamic(b.flags[i]) || (b.flags[i] & BF_ASLEEP)) return;   // sleeping islands are not solved or integrated (solver.cpp:408)
     float4 p4 = B_POS(b, i);
     f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
     f3 dv, dw;
@@ -952,6 +1013,7 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
     // point_constraint has no solve_position (island_solver.cpp:252-260)
     bool active = i < end && j.type[i] == EDYNHIP_JOINT_HINGE;
+    if (active && edge_asleep(b.flags[j.bodyA[i]], b.flags[j.bodyB[i]])) active = false;
     uint32_t label = 0;
     float max_err = 0;
     if (active) {
@@ -1165,7 +1227,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
     used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
     const uint32_t fl = b.flags[i];
     const uint32_t kind = fl & BF_KIND_MASK;
-    if (kind == EDYNHIP_KIND_STATIC) return;
+    if (kind == EDYNHIP_KIND_STATIC || (fl & BF_ASLEEP)) return;   // update_aabbs / update_inertias exclude sleeping bodies
     const int st = (int)((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
     const f3 pos = from4(B_POS(b, i));
     const q4 orn = q_from4(B_ORN(b, i));
@@ -1216,6 +1278,12 @@ int islands(edynhip_ctx *c) {
     if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
     hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
     hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
+    if (c->sleeping) {
+        hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
+        hipLaunchKernelGGL(k_sleep_edges, dim3(32), dim3(256), 0, s, c->new_edges, c->cnt, c->b.island, c->sleep_state);
+        hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->step_index, c->cfg.fixed_dt);
+        hipLaunchKernelGGL(k_sleep_apply, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_action);
+    }
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }
@@ -1243,7 +1311,7 @@ static int colour_contacts(edynhip_ctx *c) {
         total_rounds += count;
     };
     auto sort_and_fetch = [&]() -> int {
-        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals);
+        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
         EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1474,6 +1542,7 @@ int solve(edynhip_ctx *c) {
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end);
     rec(c, 9);
+    ++c->step_index;
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }

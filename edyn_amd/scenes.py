@@ -228,6 +228,8 @@ def scene_from_defs(defs, joints):
         if d.gravity is not None:
             any_grav = True
             grav[i] = d.gravity
+    if any(getattr(d, "sleeping_disabled", False) for d in defs):
+        s["sleeping_disabled"] = np.array([1 if getattr(d, "sleeping_disabled", False) else 0 for d in defs], np.uint8)
     if any_grav:
         raise NotImplementedError("per-body gravity via rigidbody_def: pass a full 'gravity' array with set_scene")
     s["joints"] = list(joints)

@@ -34,6 +34,7 @@ class init_config:
     max_manifolds: int = 0
     max_joints: int = 0
     timing: bool = False
+    sleeping: bool = False       # island sleeping (off = every body sleeping_disabled, as the benchmark scenes are)
 
 
 @dataclass
@@ -53,6 +54,7 @@ class rigidbody_def:
     restitution: float = 0.0
     collision_group: int = ALL_GROUPS
     collision_mask: int = ALL_GROUPS
+    sleeping_disabled: bool = False
 
 
 def _ptr(a):
@@ -98,7 +100,7 @@ class World:
         cfg.num_velocity_iterations = self.cfg.num_solver_velocity_iterations
         cfg.num_position_iterations = self.cfg.num_solver_position_iterations
         cfg.gravity = (C.c_float * 3)(*[float(x) for x in self.cfg.gravity])
-        cfg.flags = _capi.FLAG_TIMING if self.cfg.timing else 0
+        cfg.flags = (_capi.FLAG_TIMING if self.cfg.timing else 0) | (_capi.FLAG_SLEEPING if self.cfg.sleeping else 0)
         st = C.c_int(0)
         h = self._L.edynhip_create(C.byref(cfg), C.byref(st))
         if not h:
@@ -150,6 +152,8 @@ class World:
         grav = scene.get("gravity")
         if grav is not None:
             a["gravity"] = np.ascontiguousarray(grav, np.float32).reshape(n, 3)
+        if scene.get("sleeping_disabled") is not None:
+            a["sleeping_disabled"] = np.ascontiguousarray(scene["sleeping_disabled"], np.uint8)
         b = _capi.Bodies()
         for f, _ in _capi.Bodies._fields_:
             setattr(b, f, _ptr(a.get(f)))
@@ -304,6 +308,15 @@ class World:
             self.attach(1)
         self._check(self._L.edynhip_debug_collide(self._h, n, _ptr(st), _ptr(sp), _ptr(ps), _ptr(qs), threshold, _ptr(out), _ptr(cnt)))
         return out, cnt
+
+    def get_asleep(self):
+        out = np.zeros(self.n, np.uint8)
+        if self.n:
+            self._check(self._L.edynhip_get_asleep(self._h, _ptr(out)))
+        return out.astype(bool)
+
+    def wake_all(self):
+        self._check(self._L.edynhip_wake_all(self._h))
 
     def get_timings(self):
         t = _capi.Timings()

@@ -58,6 +58,8 @@ struct kinematic_tag {};
 struct static_tag {};
 struct procedural_tag {};
 struct rigidbody_tag {};
+struct sleeping_tag {};            // comp/tag.hpp: the body's island is asleep (kept in sync after every update)
+struct sleeping_disabled_tag {};   // comp/tag.hpp
 struct collision_filter { uint64_t group{~0ull}, mask{~0ull}; };
 
 struct box_shape { vector3 half_extents; };
@@ -80,6 +82,7 @@ struct rigidbody_def {   // util/rigidbody.hpp:29-81 (hot-path fields)
     std::optional<edyn::material> material{edyn::material{}};
     uint64_t collision_group{~0ull};
     uint64_t collision_mask{~0ull};
+    bool sleeping_disabled{false};
 };
 
 struct constraint_base { std::array<entt::entity, 2> body; };
@@ -102,6 +105,7 @@ struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
     int device{0};
     unsigned max_bodies{0};      // 0 = sized at the first upload (count + 25 % head-room)
     unsigned max_manifolds{0};
+    bool island_sleeping{true};  // the reference always sleeps islands (bodies opt out with sleeping_disabled)
 };
 
 class stepper_error : public std::runtime_error {
@@ -144,6 +148,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
         c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
+        c.flags = s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u;
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
@@ -153,7 +158,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     const uint32_t first = s.uploaded_bodies, n = total - first;
     std::vector<int32_t> kind(n), stype(n);
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
-    std::vector<uint8_t> hasI(n, 0);
+    std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
     std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
     for (uint32_t i = 0; i < n; ++i) {
         const entt::entity e = s.bodies[first + i];
@@ -174,10 +179,11 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         else stype[i] = EDYNHIP_SHAPE_NONE;
         if (auto *mt = registry.try_get<material>(e)) { fr[i] = mt->friction; re[i] = mt->restitution; }
         if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
+        if (registry.all_of<sleeping_disabled_tag>(e)) nosleep[i] = 1;
         if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
     }
     edynhip_bodies b{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
-                     fr.data(), re.data(), grp.data(), msk.data(), g.data()};
+                     fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data()};
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
     s.uploaded_bodies = total;
@@ -231,6 +237,16 @@ inline void write_back(entt::registry &registry, gpu_stepper &s) {
         auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
         auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
         auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
+    }
+    if (s.cfg.island_sleeping) {   // mirror sleeping_tag (island_manager.cpp:541-565, util/island_util.cpp:7-13)
+        std::vector<uint8_t> asleep(n, 0);
+        check(s, edynhip_get_asleep(s.ctx, asleep.data()));
+        for (uint32_t i = 0; i < n; ++i) {
+            const entt::entity e = s.bodies[i];
+            const bool tagged = registry.all_of<sleeping_tag>(e);
+            if (asleep[i] && !tagged) registry.emplace<sleeping_tag>(e);
+            else if (!asleep[i] && tagged) registry.remove<sleeping_tag>(e);
+        }
     }
 }
 
@@ -304,6 +320,7 @@ inline void make_rigidbody(entt::entity entity, entt::registry &registry, const 
         std::visit([&](auto &&sh) { registry.emplace<std::decay_t<decltype(sh)>>(entity, sh); }, *def.shape);
         if (def.collision_group != ~0ull || def.collision_mask != ~0ull) registry.emplace<collision_filter>(entity, collision_filter{def.collision_group, def.collision_mask});
     }
+    if (def.sleeping_disabled) registry.emplace<sleeping_disabled_tag>(entity);
     switch (def.kind) {
     case rigidbody_kind::rb_dynamic: registry.emplace<dynamic_tag>(entity); registry.emplace<procedural_tag>(entity); break;
     case rigidbody_kind::rb_kinematic: registry.emplace<kinematic_tag>(entity); break;

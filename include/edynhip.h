@@ -67,7 +67,8 @@ typedef struct {
 
 enum {
     EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings) */
-    EDYNHIP_FLAG_NO_GRAPH = 2u       /* launch the solver eagerly instead of replaying captured hipGraphs */
+    EDYNHIP_FLAG_NO_GRAPH = 2u,      /* (unused) */
+    EDYNHIP_FLAG_SLEEPING = 4u       /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
 };
 
 /* Scene description, one entry per body, index = body id. Arrays are packed row-major
@@ -88,6 +89,7 @@ typedef struct {
     const uint64_t *group;           /* [n] collision_filter.group (all ones = default) */
     const uint64_t *mask;            /* [n] collision_filter.mask */
     const float *gravity;            /* [n][3] per-body gravity or NULL = config gravity */
+    const uint8_t *sleeping_disabled;/* [n] or NULL: sleeping_disabled_tag (only meaningful with EDYNHIP_FLAG_SLEEPING) */
 } edynhip_bodies;
 
 typedef struct {
@@ -183,6 +185,11 @@ int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses5);
  * exposes edyn::collide(shA, shB, ctx, result) (include/edyn/collision/collide.hpp) for parity tests. */
 int edynhip_debug_collide(edynhip_ctx *ctx, uint32_t n, const int32_t *shape_type, const float *shape_param, const float *pos,
                           const float *orn, float threshold, float *out_points, uint32_t *out_count);
+
+/* Island sleeping (EDYNHIP_FLAG_SLEEPING): asleep[n] = 1 where the body carries sleeping_tag; wake_all = wake_up_entity on
+ * everything (also implied by edynhip_set_state). island_manager.cpp:541-565, util/island_util.cpp:61-66. */
+int edynhip_get_asleep(edynhip_ctx *ctx, uint8_t *asleep);
+int edynhip_wake_all(edynhip_ctx *ctx);
 
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);

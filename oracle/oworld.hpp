@@ -246,7 +246,6 @@ public:
         narrowphase();
         update_islands();
         solve();
-        ++step_index;
     }
     bool manifold_asleep(const Manifold &m) const {   // every procedural endpoint sleeps (an island sleeps as a whole)
         const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
@@ -784,6 +783,7 @@ public:
         for (auto &kv : manifolds) np += kv.second.num_points;
         stats.num_manifolds = (uint32_t)manifolds.size();
         stats.num_points = np;
+        ++step_index;
     }
 
     // Reference order (island_solver.cpp:513-543 per island).

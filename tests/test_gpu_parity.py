@@ -498,3 +498,75 @@ def test_owner_with_more_partners_than_the_in_kernel_list():
         most = max(most, int(((m["body"] == plate).any(axis=1)).sum()))
     assert most > 40, most
     assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="plate")
+
+
+# ------------------------------------------------------------------ island sleeping (EDYNHIP_FLAG_SLEEPING)
+def _sleep_worlds(scene, **kw):
+    g = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, sleeping=True, **kw))
+    g.set_scene(scene)
+    o = oracle_world(scene)
+    o.set_sleeping(True)
+    return g, o
+
+
+def _assert_same(g, o, step):
+    assert np.array_equal(g.get_asleep(), o.get_asleep()), step
+    for a, b in zip(g.get_state(), o.get_state()):
+        assert np.array_equal(a, b), step
+
+
+def test_sleeping_collapse_settle_sleep_bit_exact():
+    """A small brick pile collapses into several islands that settle and fall asleep one after the other: sleeping
+    flags, transforms and velocities match the oracle at every step, through every put-to-sleep event."""
+    scene = scenes.box_pile(3, 3, 3)
+    g, o = _sleep_worlds(scene)
+    seen_asleep, seen_all = False, False
+    for step in range(420):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+        a = g.get_asleep()
+        seen_asleep |= bool(a.any()); seen_all |= bool(a[1:].all())
+    assert seen_asleep and seen_all
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="asleep")
+    p = g.get_state()[0].copy()
+    g.step_simulation(30); o.step(30)
+    assert np.array_equal(g.get_state()[0], p)            # frozen
+    assert not g.get_state()[2].any()                      # put_to_sleep zeroed the velocities
+
+
+def test_sleeping_island_wakes_when_hit_bit_exact():
+    """A sleeping stack is hit by a body appended later (lower AND higher index than its partner: the floor-side box was
+    created first, the falling one last): the new manifold wakes the island in the same step as in the oracle."""
+    base = scenes.box_pile(1, 2, 1)
+    base["pos"][2] = base["pos"][1] + np.float32([0.0, 1.005, 0.0])
+    g, o = _sleep_worlds(base, max_bodies=8)
+    g.step_simulation(320); o.step(320)
+    _assert_same(g, o, "settled")
+    assert g.get_asleep()[1] and g.get_asleep()[2]
+    extra = _shifted(scenes.box_pile(1, 1, 1), 4.0)
+    extra["pos"][:, 0] += 0.1
+    g.add_scene(extra); o.add_bodies(extra)
+    woke = None
+    for step in range(200):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+        if woke is None and not g.get_asleep()[2]:
+            woke = step
+    assert woke is not None and 20 < woke < 90
+    g.step_simulation(300); o.step(300)
+    _assert_same(g, o, "asleep again")
+    assert g.get_asleep()[1:].all()
+    # set_state wakes (wake_up_entity), wake_all too
+    st = g.get_state(); g.set_state(*st)
+    assert not g.get_asleep().any()
+
+
+def test_sleeping_off_by_default_and_flag_does_not_change_awake_physics():
+    scene = scenes.box_pile(4, 4, 4)
+    g0 = gpu_world(scene)
+    g1 = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, sleeping=True))
+    g1.set_scene(scene)
+    g0.step_simulation(100); g1.step_simulation(100)        # nothing has been still for 2 s yet
+    assert not g0.get_asleep().any() and not g1.get_asleep().any()
+    for a, b in zip(g0.get_state(), g1.get_state()):
+        assert np.array_equal(a, b)

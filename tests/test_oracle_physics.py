@@ -129,3 +129,75 @@ def test_chain_joint_anchors_stay_together():
     for (jt, a, b, pa, pb, _, _) in sc["joints"]:
         wa = p[a] + _rot(q[a], pa); wb = p[b] + _rot(q[b], pb)
         assert np.linalg.norm(wa - wb) < 0.02, (jt, a, b)
+
+
+# ------------------------------------------------------------------ island sleeping (island_manager.cpp:524-623)
+def _stack2():
+    """A floor and two boxes stacked exactly on top of each other (box_pile offsets alternate layers like bricks)."""
+    from edyn_amd import scenes
+    s = scenes.box_pile(1, 2, 1)
+    s["pos"][2] = s["pos"][1] + np.float32([0.0, 1.005, 0.0])
+    return s
+
+
+def test_island_falls_asleep_after_two_seconds_and_freezes():
+    from edyn_amd import scenes
+    for order in (ob.ORDER_SEQUENTIAL, ob.ORDER_COLOURED):
+        o = ob.World(vel_iters=10, pos_iters=3, order=order)
+        o.add_bodies(scenes.box_pile(1, 1, 1))
+        o.set_sleeping(True)
+        first = None
+        for k in range(400):
+            o.step(1)
+            if first is None and o.get_asleep()[1]:
+                first = k
+        assert first is not None and 120 <= first <= 200, first     # settle, then island_time_to_sleep = 2 s = 120 steps
+        p0, q0, v0, w0 = o.get_state()
+        assert not v0[1].any() and not w0[1].any()                    # put_to_sleep zeroes the velocities
+        o.step(50)
+        p1, q1, v1, w1 = o.get_state()
+        assert np.array_equal(p0, p1) and np.array_equal(q0, q1) and not v1.any()
+        assert not o.get_asleep()[0]                                  # the static floor never carries the tag
+
+
+def test_sleeping_disabled_body_keeps_its_island_awake_and_default_is_off():
+    from edyn_amd import scenes
+    o = ob.World(vel_iters=10, pos_iters=3, order=ob.ORDER_COLOURED)
+    o.add_bodies(_stack2())
+    o.set_sleeping(True)
+    o.set_sleeping_disabled(2, True)       # the upper box; the lower one shares its island
+    o.step(400)
+    assert not o.get_asleep().any()
+    o1 = ob.World(vel_iters=10, pos_iters=3, order=ob.ORDER_COLOURED)
+    o1.add_bodies(_stack2())
+    o1.set_sleeping(True)
+    o1.step(400)
+    assert o1.get_asleep()[1] and o1.get_asleep()[2]
+    o2 = ob.World(vel_iters=10, pos_iters=3, order=ob.ORDER_COLOURED)
+    o2.add_bodies(_stack2())
+    o2.step(400)
+    assert not o2.get_asleep().any()       # sleeping is opt-in
+
+
+def test_new_contact_wakes_a_sleeping_island():
+    from edyn_amd import scenes
+    o = ob.World(vel_iters=10, pos_iters=3, order=ob.ORDER_COLOURED)
+    base = scenes.box_pile(1, 1, 1)
+    o.add_bodies(base)
+    o.set_sleeping(True)
+    o.step(300)
+    assert o.get_asleep()[1]
+    falling = {k: (v[1:2].copy() if isinstance(v, np.ndarray) and len(v) == 2 else v) for k, v in base.items()}
+    falling["pos"] = falling["pos"] + np.float32([0.05, 3.0, 0.0])
+    falling.pop("joints", None)
+    o.add_bodies(falling)
+    woke = None
+    for k in range(120):
+        o.step(1)
+        if woke is None and not o.get_asleep()[1]:
+            woke = k
+    assert woke is not None and 20 < woke < 80, woke                  # ~0.75 s of free fall
+    assert len(o.get_manifolds()) == 2
+    o.step(400)
+    assert o.get_asleep()[1] and o.get_asleep()[2]                     # the stack goes back to sleep as one island
+    assert abs(o.get_state()[0][2, 1] - 1.5) < 0.02
