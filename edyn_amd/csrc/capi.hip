@@ -64,7 +64,8 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.np_list, nb));
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
-    EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M)); EH_TRY(dalloc(c, c->col_vals, M));
+    EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
+    { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));
     EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
@@ -76,7 +77,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, j.qA, nj)); EH_TRY(dalloc(c, j.axB, nj)); EH_TRY(dalloc(c, j.impulse, (size_t)nj * 5));
     EH_TRY(dalloc(c, j.rA, nj)); EH_TRY(dalloc(c, j.rB, nj)); EH_TRY(dalloc(c, j.wp, nj)); EH_TRY(dalloc(c, j.wq, nj));
     EH_TRY(dalloc(c, j.eff, (size_t)nj * 5)); EH_TRY(dalloc(c, j.rhs, (size_t)nj * 5));
-    c->sort_tmp_bytes = sort_temp_bytes(std::max(std::max(M, nb), 1u));
+    c->sort_tmp_bytes = sort_temp_bytes(std::max(std::max(M, nb + 1), 256u * ((M + 1023u) / 1024u) + 1u));
     { void *q = nullptr; EH_HIP(c, hipMalloc(&q, c->sort_tmp_bytes)); c->allocs.push_back(q); c->sort_tmp = q; }
     EH_TRY(dalloc(c, c->cnt, 1));
     EH_HIP(c, hipHostMalloc((void **)&c->cnt_host, sizeof(Counters), hipHostMallocDefault));

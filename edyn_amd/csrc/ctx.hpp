@@ -186,7 +186,8 @@ struct edynhip_ctx {
     uint32_t *own_count = nullptr, *own_offset = nullptr;          // [bodies + 1]
     uint2 *new_edges = nullptr;    // body pairs of manifolds created this step (incremental island update)
     uint32_t prev_num_manifolds = 0;
-    uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr, *col_vals = nullptr;   // colour sort
+    uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr;   // colour sort (counting sort, solver.hip k_cs_*)
+    uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)
@@ -229,7 +230,6 @@ int solve(edynhip_ctx *c);
 // sort helpers (sort.hip)
 size_t sort_temp_bytes(uint32_t max_items);
 int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit);
-int sort_pairs_u32(edynhip_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n, int end_bit);
 int set_error(edynhip_ctx *c, int code, const char *what, hipError_t e = hipSuccess);
 }  // namespace eh
 

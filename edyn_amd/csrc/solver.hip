@@ -260,7 +260,7 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicSub(&cnt->uncoloured, done);
 }
-__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, uint32_t *vals, const uint32_t *__restrict__ bA,
+__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, const uint32_t *__restrict__ bA,
                            const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, bool sleeping) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
@@ -270,7 +270,54 @@ __global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32
     uint32_t np = in & 0xFF;
     if (sleeping && np && edge_asleep(flags[bA[m]], flags[bB[m]])) np = 0;   // not part of this step's solve
     keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0xFFu;
-    vals[m] = m;
+}
+// Stable counting sort of the manifolds by (colour, point count) key - at most 256 distinct keys. (rocPRIM's radix sort
+// falls back to a merge sort for an 8-bit key range: 1 block-sort + 16 merge launches, ~90 us per step.)
+//  k_cs_hist:    per 1024-element block, the count of every key          -> hist[key * nblocks + block]
+//  scan_u32:     exclusive scan of that key-major table                   -> where each (key, block) run starts
+//  k_cs_scatter: every element's slot = its run's start + its rank among the block's earlier elements with its key
+constexpr uint32_t kCsBlock = 1024, kCsKeys = 256;
+__global__ void __launch_bounds__(kCsBlock) k_cs_hist(uint32_t M, const uint32_t *__restrict__ keys, uint32_t *hist, uint32_t nblocks) {
+    __shared__ uint32_t h[kCsKeys];
+    if (threadIdx.x < kCsKeys) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t m = blockIdx.x * kCsBlock + threadIdx.x;
+    if (m < M) atomicAdd(&h[keys[m] & 0xFFu], 1u);
+    __syncthreads();
+    if (threadIdx.x < kCsKeys) hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(kCsBlock) k_cs_scatter(uint32_t M, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ start,
+                                                         uint32_t nblocks, uint32_t *keys_sorted, uint32_t *order) {
+    __shared__ uint32_t base[kCsKeys];
+    if (threadIdx.x < kCsKeys) base[threadIdx.x] = start[threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t m = blockIdx.x * kCsBlock + threadIdx.x;
+    const bool valid = m < M;
+    const uint32_t key = valid ? (keys[m] & 0xFFu) : 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // rank among the lower lanes of this wave with the same key, and the wave's count of that key (at its first lane)
+    uint32_t rank = 0, count = 0;
+    bool first = false;
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const uint32_t k = __shfl(key, __ffsll((long long)todo) - 1);
+        const uint64_t same = __ballot(valid && key == k);
+        if (valid && key == k) {
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            count = (uint32_t)__popcll(same);
+            first = rank == 0;
+        }
+        todo &= ~same;
+    }
+    for (uint32_t w = 0; w < kCsBlock / 64; ++w) {   // waves take their turns in order: keeps the sort stable
+        if (wave == w && valid) {
+            const uint32_t pos = base[key] + rank;
+            keys_sorted[pos] = key; order[pos] = m;
+        }
+        __syncthreads();
+        if (wave == w && valid && first) base[key] += count;
+        __syncthreads();
+    }
 }
 __global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sorted, Counters *cnt) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1311,8 +1358,13 @@ static int colour_contacts(edynhip_ctx *c) {
         total_rounds += count;
     };
     auto sort_and_fetch = [&]() -> int {
-        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, c->col_vals, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
-        EH_TRY(sort_pairs_u32(c, c->col_keys, c->col_keys_sorted, c->col_vals, c->rows.order, M, 8));
+        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
+        {
+            const uint32_t nb = blocks(M, kCsBlock);
+            hipLaunchKernelGGL(k_cs_hist, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb);
+            EH_TRY(scan_u32(c, c->cs_hist, c->cs_start, kCsKeys * nb));
+            hipLaunchKernelGGL(k_cs_scatter, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order);
+        }
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         EH_HIP(c, hipStreamSynchronize(s));

@@ -1,3 +1,2 @@
-timeout 120 python scripts/dev_parity.py pile8 10 2>&1 | tail -2
-timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 echo -n "pile32k: "; timeout 100 python bench.py --steps 150 --warmup 100 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), {k: round(v,3) for k,v in d['stages_ms_per_step'].items()})"

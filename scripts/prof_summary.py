@@ -10,7 +10,12 @@ steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 print(f"# {os.path.basename(path)}  (durations in us; per_step = total / {steps:g} steps)")
 print(f"{'kernel':60s} {'calls':>8s} {'total_us':>12s} {'avg_us':>9s} {'pct':>6s} {'us/step':>10s}")
 for name, calls, total, avg, pct in rows:
-    short = name.replace("void ", "").split("(")[0][:60]
+    short = name.replace("void ", "").split("(")[0]
+    if "rocprim" in short:   # keep what tells the library kernels apart
+        import re
+        m = re.search(r"(radix_sort_\w+|onesweep\w*|histogram\w*|scan\w*|merge\w*|block_sort\w*|lookback\w*)", name)
+        short = "rocprim::" + (m.group(1) if m else "?") + " " + short[-24:]
+    short = short[:60]
     print(f"{short:60s} {calls:8d} {total:12.1f} {avg:9.3f} {pct:6.2f} {total / steps:10.1f}")
 
 # The bench's roofline figure covers the TIMED region only (the last `timed` steps of the run): report the roofline

@@ -570,3 +570,40 @@ def test_sleeping_off_by_default_and_flag_does_not_change_awake_physics():
     assert not g0.get_asleep().any() and not g1.get_asleep().any()
     for a, b in zip(g0.get_state(), g1.get_state()):
         assert np.array_equal(a, b)
+
+
+def test_headline_scene_first_steps_bit_exact():
+    """The full 32 768-box pile, first 4 steps (initial BVH build, ~100k manifolds created and coloured from scratch,
+    the dataflow solves at full width) against the oracle, bit for bit."""
+    scene = scenes.box_pile(32, 32, 32)
+    g = gpu_world(scene); o = oracle_world(scene)
+    for step in range(4):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="pile32k")
+
+
+def test_sleeping_with_joints_per_colour_schedule():
+    """A pendulum hanging straight down at rest plus a box on the floor: the jointed island and the contact island both
+    fall asleep (scenes with joints run the per-colour schedule), a nudge through set_state wakes them; bit-exact."""
+    s = scenes.box_pile(1, 1, 1)
+    s = _append_body(s, kind=scenes.KIND_STATIC, pos=(5, 5, 0), shape_type=scenes.SHAPE_NONE, shape_param=(0, 0, 0, 0), mass=0.0)
+    s = _append_body(s, pos=(5, 4, 0), shape_type=scenes.SHAPE_NONE, shape_param=(0, 0, 0, 0), mass=1.0)
+    s["inertia"] = np.zeros((4, 9), np.float32); s["has_inertia"] = np.zeros(4, np.uint8)
+    s["inertia"][3] = np.diag([0.01, 0.01, 0.01]).reshape(9); s["has_inertia"][3] = 1
+    s["joints"] = [(scenes.JOINT_HINGE, 2, 3, (0, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 1))]
+    g, o = _sleep_worlds(s)
+    for step in range(260):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+    assert g.get_asleep()[1] and g.get_asleep()[3] and not g.get_asleep()[2]
+    assert np.array_equal(g.get_joint_impulses(), o.get_joint_impulses())
+    p, q, v, w = g.get_state()
+    v[3] = (0.5, 0, 0)
+    g.set_state(p, q, v, w); o.set_state(p, q, v, w); o.wake_all()
+    for step in range(60):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+    assert not g.get_asleep()[3]
