@@ -67,7 +67,6 @@ typedef struct {
 
 enum {
     EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings) */
-    EDYNHIP_FLAG_NO_GRAPH = 2u,      /* (unused) */
     EDYNHIP_FLAG_SLEEPING = 4u       /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
 };
 
