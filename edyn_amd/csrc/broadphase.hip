@@ -332,7 +332,7 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
 __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
-                                     Counters *cnt, uint2 *new_edges) {
+                                     Counters *cnt, uint2 *new_edges, bool copy_points) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t found = 0;
     if (m < M) {
@@ -356,10 +356,12 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
         cnt->pairs_changed = 1;
         new_edges[atomicAdd(&cnt->num_new, 1u)] = make_uint2(hi, lo);
     }
+    cur.prev_idx[m] = p;
     if (p != 0xFFFFFFFFu) {
         found = 1;
         info = prev.info[p];
-        const uint32_t np = info & 0xFF;
+        // inside a full step the narrowphase reads the old points straight from the previous array (no copy here)
+        const uint32_t np = copy_points ? (info & 0xFF) : 0u;
         for (uint32_t k = 0; k < np; ++k) {
             const size_t s = (size_t)k * prev.cap + p, d = (size_t)k * cur.cap + m;
             cur.pA[d] = prev.pA[s]; cur.pB[d] = prev.pB[s]; cur.nrm[d] = prev.nrm[s];
@@ -417,9 +419,10 @@ int broadphase(edynhip_ctx *c) {
             EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         }
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, !c->full_step);
         else if (pm != 0) c->force_islands = true;
     }
+    c->points_in_prev = c->full_step && M > 0 && np > 0;
     c->cur ^= 1;
     c->prev_num_manifolds = pm;
     c->num_manifolds = M;

@@ -32,7 +32,7 @@ static int dalloc(edynhip_ctx *c, T *&p, size_t count) {
 
 static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap, uint32_t nb) {
     m.cap = cap;
-    EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb));
+    EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb)); EH_TRY(dalloc(c, m.prev_idx, cap));
     EH_TRY(dalloc(c, m.skey, cap)); EH_TRY(dalloc(c, m.bodyA, cap)); EH_TRY(dalloc(c, m.bodyB, cap)); EH_TRY(dalloc(c, m.info, cap));
     EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
     EH_TRY(dalloc(c, m.nrm, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.lnrm, (size_t)cap * kMaxPts));

@@ -52,10 +52,12 @@ struct Bodies {
 // Contact manifolds, rebuilt every step in ascending canonical key order (double buffered).
 struct Manifolds {
     uint32_t cap = 0;
-    uint64_t *skey = nullptr;     // (hi<<32|lo)<<1 | swapped   (swapped: body[0] == lo)
+    uint64_t *skey = nullptr;     // (owner<<32|other)<<1 | swapped   (swapped: body[0] == other), see broadphase.hip
     uint32_t *bodyA = nullptr, *bodyB = nullptr;
     uint32_t *info = nullptr;     // num_points | colour << 8
-    uint32_t *seg_start = nullptr, *seg_end = nullptr;   // per body b: manifolds whose higher body index is b
+    uint32_t *seg_start = nullptr, *seg_end = nullptr;   // per body b: the manifolds it owns
+    uint32_t *prev_idx = nullptr; // inside a full step: index of the same pair in the previous array (~0u = created now);
+                                  // the narrowphase then reads the old points from there instead of a copy
     // per point slot k (list order, newest first): index k*cap + m
     float4 *pA = nullptr;         // pivotA xyz, w = distance
     float4 *pB = nullptr;         // pivotB xyz, w = friction
@@ -213,6 +215,7 @@ struct edynhip_ctx {
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel
+    bool points_in_prev = false;   // this step's manifold array holds no copied points yet (see Manifolds::prev_idx)
     bool force_islands = true;     // recompute island labels even if the pair set did not change
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
 };

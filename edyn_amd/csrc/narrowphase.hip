@@ -74,14 +74,24 @@ DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
 }
 
 __global__ void __launch_bounds__(64, 2)
-k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping) {
+k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) {
         const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
         const uint32_t info = mf.info[m];
         const int n_old = (int)(info & 0xFF);
         const uint32_t fa = b.flags[ia], fb = b.flags[ib];
-        if (sleeping && edge_asleep(fa, fb)) return;   // narrowphase.cpp:31: sleeping manifolds are left as they are
+        // old contact points: in this array (copied by the broadphase), or still in the previous array
+        const Manifolds &src = points_in_old ? old : mf;
+        const uint32_t sidx = points_in_old ? mf.prev_idx[m] : m;
+        if (sleeping && edge_asleep(fa, fb)) {   // narrowphase.cpp:31: sleeping manifolds are left as they are
+            if (points_in_old)
+                for (int k = 0; k < n_old; ++k) {
+                    const size_t s = (size_t)k * src.cap + sidx, d = (size_t)k * mf.cap + m;
+                    mf.pA[d] = src.pA[s]; mf.pB[d] = src.pB[s]; mf.nrm[d] = src.nrm[s]; mf.lnrm[d] = src.lnrm[s]; mf.imp[d] = src.imp[s];
+                }
+            return;
+        }
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
         BodyIn A, B;
         { float4 p = B_POS(b, ia); A.pos = from4(p); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
@@ -93,8 +103,8 @@ k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping) {
 
         Pt pts[kMaxPts];
         for (int k = 0; k < n_old; ++k) {
-            const size_t s = (size_t)k * mf.cap + m;
-            float4 a = mf.pA[s], bb = mf.pB[s], n = mf.nrm[s], l = mf.lnrm[s], im = mf.imp[s];
+            const size_t s = (size_t)k * src.cap + sidx;
+            float4 a = src.pA[s], bb = src.pB[s], n = src.nrm[s], l = src.lnrm[s], im = src.imp[s];
             Pt &p = pts[k];
             p.pivotA = from4(a); p.pivotB = from4(bb); p.normal = from4(n); p.lnormal = from4(l);
             p.friction = bb.w; p.attachment = __float_as_int(n.w); p.restitution = l.w;
@@ -256,7 +266,8 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
 int narrowphase(edynhip_ctx *c) {
     const uint32_t M = c->num_manifolds;
     if (M == 0) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping);
+    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev);
+    c->points_in_prev = false;
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }
