@@ -428,6 +428,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     // only procedural shaped bodies own pairs; everybody else's count must read 0 in the scan
     if (rc == EDYNHIP_OK && hipMemsetAsync(c->own_count, 0, ((size_t)c->b.cap + 1) * sizeof(uint32_t), c->stream) != hipSuccess)
         rc = set_error(c, EDYNHIP_ERR_HIP, "clear pair counts");
+    c->all_asleep = false;
     c->bvh.age = 0;   // the tree topology is rebuilt on the next step
     c->bvh.num_np = (uint32_t)np_list.size();
     c->bvh.num_proc = (uint32_t)proc_list.size();
@@ -439,6 +440,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     for (void *p : tmp) (void)hipFree(p);
     if (first == 0) c->num_manifolds = 0;   // appended bodies keep every index stable, so existing manifolds stay valid
     c->force_islands = true;
+    c->all_asleep = false;
     c->clears_primed = false;
     c->stats.num_bodies = total;
     if (rc == EDYNHIP_OK) EH_HIP(c, hipGetLastError());
@@ -459,6 +461,7 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     Joints &j = c->j;
     j.n = n; j.num_colours = 0; j.rows = 0;
     c->force_islands = true;
+    c->all_asleep = false;
     std::memset(j.colour_start, 0, sizeof(j.colour_start));
     if (n == 0) return EDYNHIP_OK;
     // body kinds are needed for the colouring (only procedural endpoints constrain a colour)
@@ -562,7 +565,12 @@ int edynhip_step(edynhip_ctx *c, uint32_t nsteps) {
     EH_HIP(c, hipSetDevice(c->device));
     c->timings = edynhip_timings{};
     c->timer.recorded = 0;
-    for (uint32_t i = 0; i < nsteps; ++i) EH_TRY(run_stages(c, EDYNHIP_STAGE_ALL));
+    for (uint32_t i = 0; i < nsteps; ++i) {
+        // every procedural body asleep and nothing edited since: the step changes nothing (each stage excludes sleeping
+        // entities), so it is not run at all - a world at rest costs no GPU time, as in the reference
+        if (c->all_asleep) { ++c->step_index; continue; }
+        EH_TRY(run_stages(c, EDYNHIP_STAGE_ALL));
+    }
     return EDYNHIP_OK;
 }
 
@@ -619,6 +627,7 @@ __global__ void k_wake_all(uint32_t n, uint32_t *flags, int32_t *since) {
 }
 int edynhip_wake_all(edynhip_ctx *c) {
     if (!c) return EDYNHIP_ERR_INVALID;
+    c->all_asleep = false;
     if (c->b.n == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_wake_all, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b.flags, c->sleep_since);
@@ -702,6 +711,7 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     }
     c->num_manifolds = n;
     c->force_islands = true;
+    c->all_asleep = false;
     c->clears_primed = false;
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));

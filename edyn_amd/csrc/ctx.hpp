@@ -146,6 +146,7 @@ struct Counters {
     uint32_t num_found;          // new manifolds that already existed last step (== previous count <=> none removed)
     uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
     uint32_t num_extra;          // pair keys beyond an owner's in-LDS list (broadphase fallback path)
+    uint32_t num_awake;          // procedural bodies left awake by this step's sleep decisions (island sleeping)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
@@ -209,6 +210,7 @@ struct edynhip_ctx {
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
+    bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     uint32_t step_index = 0;       // completed steps (island sleep timers count in steps)
     uint32_t *sleep_state = nullptr, *sleep_action = nullptr;   // per island label: reduction bits / decision
     int32_t *sleep_since = nullptr;                             // per island label: step at which its timer started, -1 = not running

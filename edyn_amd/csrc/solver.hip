@@ -174,17 +174,24 @@ __global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *
     } else since[i] = -1;
     action[i] = a;
 }
-__global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__ action) {
+__global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__ action, Counters *cnt) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t fl = b.flags[i];
-    if (!is_dynamic(fl)) return;
-    const uint32_t a = action[b.island[i]];
-    if (a == SLA_AWAKE) { if (fl & BF_ASLEEP) b.flags[i] = fl & ~BF_ASLEEP; }
-    else if (a == SLA_SLEEP) {
-        b.flags[i] = fl | BF_ASLEEP;
-        b.linvel[i] = make_float4(0, 0, 0, 0); b.angvel[i] = make_float4(0, 0, 0, 0);
+    uint32_t awake = 0;
+    if (i < n) {
+        uint32_t fl = b.flags[i];
+        if (is_dynamic(fl)) {
+            const uint32_t a = action[b.island[i]];
+            if (a == SLA_AWAKE) { if (fl & BF_ASLEEP) { fl &= ~BF_ASLEEP; b.flags[i] = fl; } }
+            else if (a == SLA_SLEEP) {
+                fl |= BF_ASLEEP; b.flags[i] = fl;
+                b.linvel[i] = make_float4(0, 0, 0, 0); b.angvel[i] = make_float4(0, 0, 0, 0);
+            }
+            awake = (fl & BF_ASLEEP) ? 0u : 1u;
+        }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) awake += __shfl_xor(awake, off);
+    if ((threadIdx.x & 63) == 0 && awake) atomicAdd(&cnt->num_awake, awake);
 }
 
 // ------------------------------------------------------------------ colouring
@@ -1329,7 +1336,7 @@ int islands(edynhip_ctx *c) {
         hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
         hipLaunchKernelGGL(k_sleep_edges, dim3(32), dim3(256), 0, s, c->new_edges, c->cnt, c->b.island, c->sleep_state);
         hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->step_index, c->cfg.fixed_dt);
-        hipLaunchKernelGGL(k_sleep_apply, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_action);
+        hipLaunchKernelGGL(k_sleep_apply, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_action, c->cnt);
     }
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
@@ -1418,6 +1425,8 @@ int solve(edynhip_ctx *c) {
     const uint32_t rcap = mf.cap;
     rec(c, 3);
     EH_TRY(colour_contacts(c));
+    // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
+    c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
     rec(c, 4);
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;

@@ -607,3 +607,25 @@ def test_sleeping_with_joints_per_colour_schedule():
         g.step_simulation(1); o.step(1)
         _assert_same(g, o, step)
     assert not g.get_asleep()[3]
+
+
+def test_world_at_rest_costs_no_gpu_time():
+    """Once every island sleeps and nothing is edited, edynhip_step does not launch anything; it resumes when a body is
+    added (or the state is edited), and the results still match the oracle, which always runs every stage."""
+    scene = scenes.box_pile(2, 2, 2)
+    g = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, sleeping=True,
+                                            timing=True, max_bodies=16))
+    g.set_scene(scene)
+    o = oracle_world(scene); o.set_sleeping(True)
+    g.step_simulation(500); o.step(500)
+    _assert_same(g, o, "rest")
+    assert g.get_asleep()[1:].all()
+    g.step_simulation(50); o.step(50)
+    assert g.get_timings()["steps"] == 0, "no step ran any stage"
+    _assert_same(g, o, "still at rest")
+    extra = _shifted(scenes.box_pile(1, 1, 1), 3.0)
+    g.add_scene(extra); o.add_bodies(extra)
+    for step in range(150):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+    assert not g.get_asleep()[-1] or g.get_state()[0][-1, 1] < 2.0
