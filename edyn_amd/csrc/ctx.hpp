@@ -217,6 +217,7 @@ struct edynhip_ctx {
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel
+    uint32_t df2_waves = 0;        // resident waves of the two-lane dataflow velocity kernel
     bool points_in_prev = false;   // this step's manifold array holds no copied points yet (see Manifolds::prev_idx)
     bool force_islands = true;     // recompute island labels even if the pair set did not change
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended

@@ -970,6 +970,173 @@ DI float xchg1(float v) {   // value held by the partner lane (lane ^ 1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
 }
 DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
+
+// ---- dataflow velocity sweep, two lanes per manifold (even lane = body A's side, odd lane = body B's side) ----
+// The per-hop cost of k_contact_solve_df is "notice the hand-off" + the manifold's arithmetic, and the arithmetic is a
+// serial chain on one lane. Here each lane owns ONE body of the manifold: it holds that body's deltas, loads only its
+// side's row pieces (J_lin, own J_ang, own I^-1 J_ang: 3 of the 5 float4 per row), computes its two terms of the
+// relative speed and applies the impulse to its own body; the partner's two terms and the scalars that live in the
+// other side's pieces (rhs / accumulated impulse, mu) cross over with DPP quad_perm[1,0,3,2]. The sums are formed in
+// the same order as rel_speed() (((JlA.dvA + JaA.dwA) + JlB.dvB) + JaB.dwB), so results stay bit-identical.
+struct Row2 { float4 f0, fa, fi; };   // f0 = (J_lin, eff); A: fa = (J_angA, rhs), fi = (I_A^-1 J_angA, mu); B: fa = (J_angB, impulse), fi = (I_B^-1 J_angB, -)
+DI void df2_poll(const float4 *slot, v4f &h0, v4f &h1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1) : "v"(slot) : "memory");
+}
+struct Side { f3 dv, dw; float im; };
+DI float df2_relspeed(const Side &x, const Row2 &r, bool sideB) {
+    const f3 Jl = from4(r.f0);
+    const float lin = dot(sideB ? -Jl : Jl, x.dv), ang = dot(from4(r.fa), x.dw);
+    const float olin = xchg1(lin), oang = xchg1(ang);
+    const float a0 = sideB ? olin : lin, a1 = sideB ? oang : ang, b0 = sideB ? lin : olin, b1 = sideB ? ang : oang;
+    return a0 + a1 + b0 + b1;
+}
+DI void df2_apply(Side &x, const Row2 &r, bool sideB, float imp) {
+    const f3 Jl = from4(r.f0);
+    x.dv += x.im * (sideB ? -Jl : Jl) * imp;
+    x.dw += from4(r.fi) * imp;
+}
+template <bool WARM, int NP>
+DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
+    Row2 R[NP][kRowsPerPoint];
+    const uint64_t w0 = a.trace ? wall_clock64() : 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int r = 0; r < kRowsPerPoint; ++r) {
+            const size_t base = (size_t)((k * kRowsPerPoint + r) * kRowF) * a.rcap + p;
+            R[k][r].f0 = a.rw[base];
+            R[k][r].fa = a.rw[base + (size_t)(sideB ? 2 : 1) * a.rcap];
+            R[k][r].fi = a.rw[base + (size_t)(sideB ? 4 : 3) * a.rcap];
+        }
+    const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
+    const uint32_t nx = a.next[slot];
+    Side x;
+    x.im = a.im[slot];
+    x.dv = x.dw = mk3(0, 0, 0);
+    const uint32_t want = (nx & kHeadBit) ? sweep : sweep + 1;
+    bool got = x.im == 0;   // read-only bodies hand nothing over: their deltas stay zero
+    bool done = !valid;
+    const float4 *mine = a.dslot + dslot_at(slot, 0);
+    uint64_t w1 = 0, w2 = 0;
+    for (uint32_t spin = 0;; ++spin) {
+        if (!done && !got) {
+            v4f h0, h1;
+            df2_poll(mine, h0, h1);
+            if (__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want) {
+                x.dv = mk3(h0.x, h0.y, h0.z); x.dw = mk3(h1.x, h1.y, h1.z); got = true;
+            }
+        }
+        if (a.trace && w1 == 0) w1 = wall_clock64();
+        const uint64_t pending = __ballot(!done);
+        if (pending == 0) {
+            if (trace_slot && (threadIdx.x & 63) == 0) { trace_slot[0] = w0; trace_slot[1] = w1; trace_slot[2] = w2; trace_slot[3] = wall_clock64(); }
+            break;
+        }
+        const uint32_t minc = __shfl(col, __ffsll((long long)pending) - 1);   // lanes are in colour order
+        const bool mine_now = !done && col == minc;                           // both lanes of a pair share p, hence colour
+        if (__ballot(mine_now && !got) == 0) {
+            if (a.trace && w2 == 0) w2 = wall_clock64();
+            // the DPP exchanges below need both lanes of a pair: `run` is uniform within a pair
+            const bool run = mine_now;
+            float nimp[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                nimp[k] = 0;
+                if ((uint32_t)k < np && run) {
+                    Row2 &r = R[k][0];
+                    const float ow = xchg1(r.fa.w);
+                    const float rhs = sideB ? ow : r.fa.w, cur0 = sideB ? r.fa.w : ow;
+                    if (WARM) {
+                        df2_apply(x, r, sideB, cur0);
+                        nimp[k] = cur0;
+                    } else {
+                        const float drel = df2_relspeed(x, r, sideB);
+                        float dimp = (rhs - drel) * r.f0.w;
+                        float cur = cur0;
+                        const float imp = cur + dimp;
+                        if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
+                        else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
+                        else cur = imp;
+                        if (sideB) r.fa.w = cur;
+                        nimp[k] = cur;
+                        df2_apply(x, r, sideB, dimp);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if ((uint32_t)k < np && run) {
+                    Row2 &ra = R[k][1], &rb = R[k][2];
+                    const float owa = xchg1(ra.fa.w), owb = xchg1(rb.fa.w);
+                    const float rhs0 = sideB ? owa : ra.fa.w, c0 = sideB ? ra.fa.w : owa;
+                    const float rhs1 = sideB ? owb : rb.fa.w, c1 = sideB ? rb.fa.w : owb;
+                    if (WARM) {   // warm_start(constraint_row_friction&)
+                        df2_apply(x, ra, sideB, c0);
+                        df2_apply(x, rb, sideB, c1);
+                    } else {
+                        const float omu = xchg1(R[k][0].fi.w);
+                        const float mu = sideB ? omu : R[k][0].fi.w;
+                        float di0 = (rhs0 - df2_relspeed(x, ra, sideB)) * ra.f0.w;
+                        float i0 = c0 + di0;
+                        float di1 = (rhs1 - df2_relspeed(x, rb, sideB)) * rb.f0.w;
+                        float i1 = c1 + di1;
+                        const float len2 = i0 * i0 + i1 * i1;
+                        const float max_len = mu * nimp[k];   // mu * current normal impulse
+                        if (len2 > square(max_len)) {
+                            const float len = sqrtf(len2);
+                            if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+                            else { i0 = 0; i1 = 0; }
+                            di0 = i0 - c0; di1 = i1 - c1;
+                        }
+                        if (sideB) { ra.fa.w = i0; rb.fa.w = i1; }
+                        df2_apply(x, ra, sideB, di0);
+                        df2_apply(x, rb, sideB, di1);
+                    }
+                }
+            }
+            if (mine_now) {
+                // hand the deltas over first (the next manifold of this body is waiting for them), then store the impulses
+                if (x.im != 0) df_publish(a.dslot + dslot_at(nx & kSlotMask, 0), x.dv, x.dw, sweep + 1);
+                if (!WARM && sideB) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if ((uint32_t)k >= np) continue;
+#pragma unroll
+                        for (int r = 0; r < kRowsPerPoint; ++r) a.rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * a.rcap + p] = R[k][r].fa;
+                    }
+                }
+                done = true;
+            }
+        } else {
+            if (spin > kDfSpinLimit || ((spin & 1023u) == 1023u && __hip_atomic_load(&a.cnt->df_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);   // ~0.1 us between polls
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
+    const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
+    const bool sideB = threadIdx.x & 1u;
+    const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 5;
+    for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
+        for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
+            const uint32_t pt = base + t;
+            const bool valid = pt < a.na;
+            if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
+            const uint32_t p = valid ? pt : a.na - 1;
+            const uint32_t key = a.keys_sorted[p];
+            const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
+            const bool big = __any(np > 2);           // lanes are grouped by point count: uniform except at a group boundary
+            uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
+            if (sweep == 0) { if (big) df2_task<true, 4>(a, p, valid, sideB, np, col, sweep, tr); else df2_task<true, 2>(a, p, valid, sideB, np, col, sweep, tr); }
+            else { if (big) df2_task<false, 4>(a, p, valid, sideB, np, col, sweep, tr); else df2_task<false, 2>(a, p, valid, sideB, np, col, sweep, tr); }
+        }
+}
 template <int NP>
 DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, const Rows &rows, const Manifolds &mf, const Bodies &b,
                         float *isl_err, const uint32_t *isl_done, uint32_t m, uint32_t ia, uint32_t ib, uint32_t label) {
@@ -1501,6 +1668,9 @@ int solve(edynhip_ctx *c) {
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
             hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
             c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
+            int per_cu2 = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_contact_solve_df2, 64, 0) == hipSuccess && per_cu2 > 0)
+                c->df2_waves = (uint32_t)per_cu2 * (uint32_t)ncu;
             int per_cu_p = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
                 c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
@@ -1511,12 +1681,16 @@ int solve(edynhip_ctx *c) {
     bool df_velocity = false;
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
-        // Resident waves (measured on MI355X): two per CU while a sweep is latency-bound - more only add polling traffic -
-        // and up to every resident slot once the row stream dominates (many islands, millions of points).
+        // Two lanes per manifold (k_contact_solve_df2) unless disabled; resident waves (measured on MI355X): enough for
+        // ~4-5 tasks per wave and sweep while the sweep is latency-bound - more only add polling traffic - and up to every
+        // resident slot once the row stream dominates (many islands, millions of points).
+        static const bool two_lane_env = !(getenv("EDYNHIP_DF_TWOLANE") && getenv("EDYNHIP_DF_TWOLANE")[0] == '0');
         static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 0u;
-        const uint32_t want_waves = env_waves ? env_waves : std::max(512u, blocks(na, 64 * 9));
-        const uint32_t grid = std::min(blocks(na, 64), std::min(c->df_lanes, want_waves));
-        DfArgs a{na, grid * 64u, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr};
+        const bool two_lane = two_lane_env && c->df2_waves > 0;
+        const uint32_t per_wave = two_lane ? 32u : 64u;
+        const uint32_t want_waves = env_waves ? env_waves : std::max(two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
+        const uint32_t grid = std::min(blocks(na, per_wave), std::min(two_lane ? c->df2_waves : c->df_lanes, want_waves));
+        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
@@ -1524,14 +1698,14 @@ int solve(edynhip_ctx *c) {
         size_t trace_words = 0;
         if (tracing) {
             const uint32_t rounds = (na + a.stride - 1) / a.stride;
-            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride >> 6);
+            trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride / per_wave);
             EH_HIP(c, hipMalloc((void **)&a.trace, trace_words * 8));
             EH_HIP(c, hipMemsetAsync(a.trace, 0, trace_words * 8, s));
         }
         void *params[] = {&a};
         // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
         // hand-off polling relies on
-        if (hipLaunchCooperativeKernel((const void *)k_contact_solve_df, dim3(grid), dim3(kDfBlock), params, 0, s) == hipSuccess) {
+        if (hipLaunchCooperativeKernel(two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, dim3(grid), dim3(64), params, 0, s) == hipSuccess) {
             df_velocity = true;
             ++launches;
         } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
@@ -1544,7 +1718,7 @@ int solve(edynhip_ctx *c) {
             EH_HIP(c, hipMemcpy(tr.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost));
             EH_HIP(c, hipMemcpy(keys.data(), c->col_keys_sorted, (size_t)na * 4, hipMemcpyDeviceToHost));
             if (FILE *f = fopen(trace_path, "wb")) {
-                const uint32_t hdr[4] = {na, a.stride, a.sweeps, 64};
+                const uint32_t hdr[4] = {na, a.stride, a.sweeps, per_wave};
                 fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, trace_words, f); fclose(f);
             }
             (void)hipFree(a.trace);
