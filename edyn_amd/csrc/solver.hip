@@ -1686,7 +1686,9 @@ int solve(edynhip_ctx *c) {
         // resident slot once the row stream dominates (many islands, millions of points).
         static const bool two_lane_env = !(getenv("EDYNHIP_DF_TWOLANE") && getenv("EDYNHIP_DF_TWOLANE")[0] == '0');
         static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 0u;
-        const bool two_lane = two_lane_env && c->df2_waves > 0;
+        // (the two-lane form reads J_lin on both lanes: ~20 % more row traffic, which only matters once the sweep is
+        // bandwidth-bound - then the one-lane kernel is the better one)
+        const bool two_lane = two_lane_env && c->df2_waves > 0 && na <= 16u * 32u * c->df2_waves;
         const uint32_t per_wave = two_lane ? 32u : 64u;
         const uint32_t want_waves = env_waves ? env_waves : std::max(two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
         const uint32_t grid = std::min(blocks(na, per_wave), std::min(two_lane ? c->df2_waves : c->df_lanes, want_waves));
