@@ -9,7 +9,7 @@ Contract (one JSON line on rank 0):
            the pile (N islands sharded one per GPU, no data-path collective) and the integrated state
            (13 floats/body) is all-gathered over RCCL every step, as the registry write-back would need;
            value counts pile-steps, scaling = "weak".
-  roofline the SI velocity-solve kernel (k_contact_solve_df: ONE dataflow launch per step runs the warm start and
+  roofline the SI velocity-solve kernel (k_contact_solve_df2 / _df: ONE dataflow launch per step runs the warm start and
            every iteration over every colour; scenes with joints use one k_contact_solve launch per colour):
            algorithmic bytes (380 B per contact point per iteration) / time measured with HIP events
            recorded on the stepper's stream around that launch inside the timed region.
@@ -164,7 +164,7 @@ def main():
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": ("k_contact_solve_df (one dataflow launch: warm start + every iteration over every colour)" if launches < 1.5
+                         "kernel": ("k_contact_solve_df2 (one dataflow launch per step: warm start + every iteration over every colour; two lanes per manifold - k_contact_solve_df, one lane, on bandwidth-bound scenes)" if launches < 1.5
                                     else "k_contact_solve<WARM,PUSH> (+ _tail): one launch per colour, every iteration + warm start"),
                          "algorithmic_bytes_per_launch": alg_bytes_step / max(launches, 1), "launches_per_step": launches,
                          "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
