@@ -94,7 +94,10 @@ def main():
     scene = wl["gen"]()
     n_bodies = len(scene["kind"])
     cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
-                               device=device_index, timing=True)
+                               device=device_index, timing=True,
+                               # one stepper per GPU, its kernels and the RCCL gather serialised on one stream: the stepper owns
+                               # the device (not so when several ranks share a GPU in the functional gloo mode)
+                               exclusive_device=(backend != "gloo"))
     w = edyn_amd.World(cfg)
     w.set_scene(scene)
     stream = torch.cuda.current_stream()

@@ -1480,6 +1480,16 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
 }
 
 // ------------------------------------------------------------------ host orchestration
+// The dataflow kernels need all their workgroups resident together. hipLaunchCooperativeKernel guarantees that, but on
+// this runtime every cooperative launch is bracketed by ~12 us of idle GPU on each side (4 launches per step = ~0.1 ms,
+// scripts/prof_timeline.py). A caller that owns the device (EDYNHIP_FLAG_EXCLUSIVE_DEVICE: no other context, stream or
+// process launches work on it while a step runs - the benchmark, one process per GPU) gets plain launches instead: the
+// grid is sized to what the occupancy query says fits, nothing else competes for the slots, so it is resident as a whole;
+// the spin limit still turns a violated assumption into an error instead of a hang.
+static hipError_t launch_resident(edynhip_ctx *c, const void *kernel, uint32_t grid, uint32_t block, void **params) {
+    if (c->cfg.flags & EDYNHIP_FLAG_EXCLUSIVE_DEVICE) return hipLaunchKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
+    return hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
+}
 static void rec(edynhip_ctx *c, int idx) {
     if (c->timer.e) (void)hipEventRecord(c->timer.e[idx], c->stream);
 }
@@ -1707,7 +1717,7 @@ int solve(edynhip_ctx *c) {
         void *params[] = {&a};
         // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
         // hand-off polling relies on
-        if (hipLaunchCooperativeKernel(two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, dim3(grid), dim3(64), params, 0, s) == hipSuccess) {
+        if (launch_resident(c, two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, grid, 64, params) == hipSuccess) {
             df_velocity = true;
             ++launches;
         } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
@@ -1763,7 +1773,7 @@ int solve(edynhip_ctx *c) {
         for (; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
             void *params[] = {&a};
-            if (hipLaunchCooperativeKernel((const void *)k_pos_contacts_df, dim3(grid), dim3(64), params, 0, s) != hipSuccess) {
+            if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
                 c->df_mode = 0;
                 break;

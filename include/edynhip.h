@@ -67,7 +67,11 @@ typedef struct {
 
 enum {
     EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings) */
-    EDYNHIP_FLAG_SLEEPING = 4u       /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
+    EDYNHIP_FLAG_SLEEPING = 4u,      /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
+    EDYNHIP_FLAG_EXCLUSIVE_DEVICE = 8u /* promise: nothing else launches work on this device while a step runs (one stepper per
+                                        GPU). The resident-grid solver kernels are then launched plainly instead of
+                                        cooperatively (~0.1 ms per step less idle GPU). Without the promise the default,
+                                        cooperative launches, is always safe. */
 };
 
 /* Scene description, one entry per body, index = body id. Arrays are packed row-major

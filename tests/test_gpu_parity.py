@@ -629,3 +629,14 @@ def test_world_at_rest_costs_no_gpu_time():
         g.step_simulation(1); o.step(1)
         _assert_same(g, o, step)
     assert not g.get_asleep()[-1] or g.get_state()[0][-1, 1] < 2.0
+
+
+def test_exclusive_device_launch_mode_is_bit_identical():
+    """EDYNHIP_FLAG_EXCLUSIVE_DEVICE only changes HOW the resident-grid solver kernels are launched."""
+    scene = scenes.box_pile(6, 6, 6)
+    a = gpu_world(scene)
+    b = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, exclusive_device=True))
+    b.set_scene(scene)
+    a.step_simulation(60); b.step_simulation(60)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
