@@ -1,13 +1,15 @@
 // Broadphase on the GPU: the reference keeps three incrementally-updated dynamic AABB trees on the
 // CPU (src/edyn/collision/broadphase.cpp:99-195, dynamic_tree.cpp); here the tree over the
-// procedural bodies is REBUILT every step as a linear BVH (Morton sort + Karras radix-tree
-// construction + bottom-up refit), every procedural body queries it in parallel, and the shaped
+// procedural bodies is a linear BVH (Morton sort + Karras radix-tree construction every 8th step,
+// bottom-up refit every step), every procedural body queries it in parallel, and the shaped
 // non-procedural bodies (static planes etc.) are tested by brute force. Because the reference's
 // final predicates use the true AABBs (broadphase.cpp:119-155), the manifold set
 //     S_t = { p in S_{t-1} : intersect(box0 grown 0.026, box1) }  U  { p : should_collide, intersect(query grown 0.02, other) }
 // does not depend on the tree, and is reproduced bit-exactly including pair orientation.
-// The pair list is emitted, radix-sorted by canonical key and becomes this step's manifold array;
-// contact points persist by a binary search of the previous step's sorted array.
+// Every pair is reported by exactly one lane - its owner, the querying procedural body - so the sorted pair list
+// needs no global sort: each lane sorts its few keys, a scan over the per-owner counts places them (k_bp_compact).
+// The list becomes this step's manifold array; contact points persist through a lookup in the owner's segment of
+// the previous step's sorted array.
 #include "ctx.hpp"
 #include "dmath.hpp"
 #include <algorithm>

@@ -14,12 +14,19 @@
 //                               hinge_constraint.cpp:180-213, island_solver.cpp:350-353,538-542
 //   update_aabbs / inertias     src/edyn/util/aabb_util.cpp:42-70, src/edyn/sys/update_inertias.cpp:12-24
 //
+//   sleeping                    src/edyn/simulation/island_manager.cpp:524-623 (k_sleep_*)
+//
 // What is NOT in the reference: within an island the reference sweeps rows strictly sequentially
 // (Gauss-Seidel). Here the contact graph is edge-coloured so that the manifolds of one colour share no
-// procedural body; each colour is one launch with one manifold per lane (its <=4 points in sequence).
-// Per iteration: joints by colour, then contacts by colour; within a colour each lane sweeps the normal rows
-// of its manifold and then its friction rows (the friction circle uses the normal impulse just updated, as
-// in the reference). The reference's global "all rows, then all friction rows" split is kept per manifold.
+// procedural body, and every body meets its manifolds in colour order. Per iteration: joints by colour, then
+// contacts by colour; a manifold sweeps its normal rows and then its friction rows (the friction circle uses
+// the normal impulse just updated, as in the reference); the reference's global "all rows, then all friction
+// rows" split is kept per manifold. Two schedules produce that order, with bit-identical results:
+//   * dataflow (contact-only scenes): ONE launch per velocity solve (k_contact_solve_df2 / _df) and per position
+//     iteration (k_pos_contacts_df); a manifold waits for the tagged hand-off of its two bodies' state from each
+//     body's previous manifold and hands it on to the next - no kernel boundary or barrier per colour;
+//   * per colour (scenes with joints, or when the resident-grid launch is refused): one launch per colour with one
+//     manifold per lane (k_contact_solve, k_joint_solve, k_pos_contacts, k_pos_joints).
 #include "ctx.hpp"
 #include "dcollide.hpp"
 
