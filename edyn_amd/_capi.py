@@ -55,7 +55,7 @@ POINT_DTYPE = np.dtype([
 MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
-FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE = 1, 4, 8
+FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE, FLAG_TIMING_SOLVE = 1, 4, 8, 16
 STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
 
 # every symbol include/edynhip.h declares (checked by tests/test_abi.py)

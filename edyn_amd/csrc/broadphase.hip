@@ -406,8 +406,7 @@ int broadphase(edynhip_ctx *c) {
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);
         // pair count is needed on the host to size the manifold kernels
-        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours, hipMemcpyDeviceToHost, s));
-        EH_HIP(c, hipStreamSynchronize(s));
+        EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         if (c->cnt_host->df_abort) return set_error(c, EDYNHIP_ERR_INTERNAL, "dataflow solve: a hand-off never arrived in the previous step (workgroups not co-resident?)");
         M = c->cnt_host->num_pairs;

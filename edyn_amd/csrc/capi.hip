@@ -4,6 +4,8 @@
 #include "ctx.hpp"
 #include "dcollide.hpp"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -17,6 +19,34 @@ int set_error(edynhip_ctx *c, int code, const char *what, hipError_t e) {
     if (e != hipSuccess) { msg += ": "; msg += hipGetErrorString(e); }
     if (c) c->err = msg; else g_create_error = msg;
     return code;
+}
+
+// Host <- device counters without a stream synchronisation: a one-workgroup kernel copies the counter block into pinned
+// host memory, fences, and then publishes a sequence number; the host spins on that number. hipStreamSynchronize wakes
+// the host through an interrupt (~25-50 us of idle GPU per sync, scripts/prof_timeline.py); the spin sees the write
+// within a few microseconds. If the number does not arrive (a kernel faulted), a real synchronise reports the error.
+__global__ void k_publish_counters(const uint32_t *__restrict__ src, uint32_t *dst, uint32_t words, volatile uint32_t *seq, uint32_t value) {
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __hip_atomic_store((uint32_t *)seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+int fetch_counters(edynhip_ctx *c, size_t bytes) {
+    const uint32_t value = ++c->cnt_seq_next;
+    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->cnt, (uint32_t *)c->cnt_host,
+                       (uint32_t)(bytes / sizeof(uint32_t)), c->cnt_seq, value);
+    EH_HIP(c, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *c->cnt_seq != value; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            EH_HIP(c, hipStreamSynchronize(c->stream));   // surfaces a device fault; otherwise the counters are there now
+            if (*c->cnt_seq != value) return set_error(c, EDYNHIP_ERR_INTERNAL, "fetch_counters: the published sequence number never arrived");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return EDYNHIP_OK;
 }
 
 template <typename T>
@@ -82,6 +112,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->cnt, 1));
     EH_HIP(c, hipHostMalloc((void **)&c->cnt_host, sizeof(Counters), hipHostMallocDefault));
     std::memset(c->cnt_host, 0, sizeof(Counters));
+    { void *q = nullptr; EH_HIP(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); std::memset(q, 0, 64); c->cnt_seq = (volatile uint32_t *)q; }
     EH_HIP(c, hipStreamSynchronize(c->stream));
     return EDYNHIP_OK;
 }
@@ -274,7 +305,8 @@ constexpr uint32_t kMaxTimedSteps = 4096;
 static int begin_timed_step(edynhip_ctx *c) {
     StageTimer &t = c->timer;
     t.e = nullptr;
-    if (!(c->cfg.flags & EDYNHIP_FLAG_TIMING) || t.recorded >= kMaxTimedSteps) return EDYNHIP_OK;
+    if (!(c->cfg.flags & (EDYNHIP_FLAG_TIMING | EDYNHIP_FLAG_TIMING_SOLVE)) || t.recorded >= kMaxTimedSteps) return EDYNHIP_OK;
+    t.mask = (c->cfg.flags & EDYNHIP_FLAG_TIMING) ? 0x7FFu : ((1u << 5) | (1u << 6));
     if (t.recorded >= t.capacity) {
         for (int k = 0; k < StageTimer::kEvents; ++k) { hipEvent_t e; EH_HIP(c, hipEventCreate(&e)); t.ev.push_back(e); }
         t.capacity += 1;
@@ -289,10 +321,11 @@ static void resolve_timings(edynhip_ctx *c) {
     t = edynhip_timings{};
     t.solve_velocity_launches = launches;
     if (tm.recorded == 0) return;
-    (void)hipEventSynchronize(tm.ev[(size_t)(tm.recorded - 1) * StageTimer::kEvents + 10]);
+    const bool all = tm.mask == 0x7FFu;
+    (void)hipEventSynchronize(tm.ev[(size_t)(tm.recorded - 1) * StageTimer::kEvents + (all ? 10 : 6)]);
     for (uint32_t s = 0; s < tm.recorded; ++s) {
         hipEvent_t *e = &tm.ev[(size_t)s * StageTimer::kEvents];
-        auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e[a], e[b]); return ms; };
+        auto el = [&](int a, int b) { float ms = 0; if (all || (a == 5 && b == 6)) (void)hipEventElapsedTime(&ms, e[a], e[b]); return ms; };
         t.broadphase_ms += el(0, 1); t.narrowphase_ms += el(1, 2); t.islands_ms += el(2, 3); t.colouring_ms += el(3, 4);
         t.prepare_ms += el(4, 5); t.solve_velocity_ms += el(5, 6); t.integrate_ms += el(6, 7); t.solve_position_ms += el(7, 8);
         t.finish_ms += el(8, 9); t.step_ms += el(0, 10);
@@ -305,7 +338,7 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     c->full_step = mask == EDYNHIP_STAGE_ALL && c->clears_primed;
     if (mask == EDYNHIP_STAGE_ALL) EH_TRY(begin_timed_step(c));
     else c->force_islands = true;   // partial runs (tests) never rely on a previous step's labels
-    auto rec = [&](int i) { if (c->timer.e) (void)hipEventRecord(c->timer.e[i], c->stream); };
+    auto rec = [&](int i) { if (c->timer.e && ((c->timer.mask >> i) & 1u)) (void)hipEventRecord(c->timer.e[i], c->stream); };
     rec(0);
     if (mask & EDYNHIP_STAGE_BROADPHASE) EH_TRY(broadphase(c));
     rec(1);
@@ -367,6 +400,7 @@ void edynhip_destroy(edynhip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
+    if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
     for (auto &e : c->timer.ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

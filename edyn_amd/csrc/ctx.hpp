@@ -160,6 +160,7 @@ struct StageTimer {
     uint32_t recorded = 0;          // steps recorded since the last edynhip_step call
     uint32_t capacity = 0;          // steps for which events exist
     hipEvent_t *e = nullptr;        // events of the step being recorded (nullptr = not recording)
+    uint32_t mask = 0;              // which of the kEvents are recorded (an event record idles the GPU ~6 us)
 };
 
 #define B_POS(b, i) ((b).xf[8 * (size_t)(i)])
@@ -198,7 +199,9 @@ struct edynhip_ctx {
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     eh::Counters *cnt = nullptr;   // device
-    eh::Counters *cnt_host = nullptr;   // pinned
+    eh::Counters *cnt_host = nullptr;   // pinned, device-visible: k_publish_counters writes it, the host spins on cnt_seq
+    volatile uint32_t *cnt_seq = nullptr;   // pinned: sequence number of the last published counters
+    uint32_t cnt_seq_next = 0;
     eh::StageTimer timer;
     edynhip_timings timings{};
     edynhip_stats stats{};
@@ -228,6 +231,7 @@ namespace eh {
 int broadphase(edynhip_ctx *c);
 int narrowphase(edynhip_ctx *c);
 int count_points(edynhip_ctx *c);
+int fetch_counters(edynhip_ctx *c, size_t bytes);   // device counters -> cnt_host, waits for them (capi.hip)
 int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);   // exclusive prefix sum
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count);

@@ -1498,7 +1498,7 @@ static hipError_t launch_resident(edynhip_ctx *c, const void *kernel, uint32_t g
     return hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
 }
 static void rec(edynhip_ctx *c, int idx) {
-    if (c->timer.e) (void)hipEventRecord(c->timer.e[idx], c->stream);
+    if (c->timer.e && ((c->timer.mask >> idx) & 1u)) (void)hipEventRecord(c->timer.e[idx], c->stream);
 }
 
 int islands(edynhip_ctx *c) {
@@ -1557,8 +1557,7 @@ static int colour_contacts(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_cs_scatter, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order);
         }
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
-        EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        EH_HIP(c, hipStreamSynchronize(s));
+        EH_TRY(fetch_counters(c, sizeof(Counters)));
         return EDYNHIP_OK;
     };
     // Steady state: the few new edges colour within the speculative rounds and ONE host sync fetches the offsets.
@@ -1570,8 +1569,7 @@ static int colour_contacts(edynhip_ctx *c) {
             if (c->cnt_host->colour_overflow) break;
             run_rounds(batch);
             if (batch < 64) batch *= 2;   // a scene coloured from scratch needs hundreds of rounds; steady state needs none
-            EH_HIP(c, hipMemcpyAsync(c->cnt_host, c->cnt, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            EH_HIP(c, hipStreamSynchronize(s));
+            EH_TRY(fetch_counters(c, 8 * sizeof(uint32_t)));
             if (total_rounds > 65536) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring did not converge");
         }
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));

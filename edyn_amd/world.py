@@ -33,7 +33,8 @@ class init_config:
     max_bodies: int = 0          # 0 = size from the first scene upload
     max_manifolds: int = 0
     max_joints: int = 0
-    timing: bool = False
+    timing: bool = False         # HIP events around every stage (diagnostic: each event idles the GPU ~6 us)
+    timing_solve: bool = False   # HIP events around the velocity solve only
     sleeping: bool = False       # island sleeping (off = every body sleeping_disabled, as the benchmark scenes are)
     exclusive_device: bool = False   # promise that this stepper is the only user of its GPU while it steps (see edynhip.h)
 
@@ -101,7 +102,8 @@ class World:
         cfg.num_velocity_iterations = self.cfg.num_solver_velocity_iterations
         cfg.num_position_iterations = self.cfg.num_solver_position_iterations
         cfg.gravity = (C.c_float * 3)(*[float(x) for x in self.cfg.gravity])
-        cfg.flags = ((_capi.FLAG_TIMING if self.cfg.timing else 0) | (_capi.FLAG_SLEEPING if self.cfg.sleeping else 0)
+        cfg.flags = ((_capi.FLAG_TIMING if self.cfg.timing else 0) | (_capi.FLAG_TIMING_SOLVE if self.cfg.timing_solve else 0)
+                     | (_capi.FLAG_SLEEPING if self.cfg.sleeping else 0)
                      | (_capi.FLAG_EXCLUSIVE_DEVICE if self.cfg.exclusive_device else 0))
         st = C.c_int(0)
         h = self._L.edynhip_create(C.byref(cfg), C.byref(st))

@@ -66,7 +66,8 @@ typedef struct {
 } edynhip_config;
 
 enum {
-    EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings) */
+    EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings); each event costs ~6 us of idle GPU */
+    EDYNHIP_FLAG_TIMING_SOLVE = 16u, /* record only the two events around the velocity solve (solve_velocity_ms) */
     EDYNHIP_FLAG_SLEEPING = 4u,      /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
     EDYNHIP_FLAG_EXCLUSIVE_DEVICE = 8u /* promise: nothing else launches work on this device while a step runs (one stepper per
                                         GPU). The resident-grid solver kernels are then launched plainly instead of
