@@ -11,6 +11,8 @@ W=/tmp/prof_$R; rm -rf $W; mkdir -p $W
 STEPS=300; WARM=120   # bench.py's defaults: the same command the bench line comes from
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --steps $STEPS --warmup $WARM > $OUT/bench_under_rocprof.json 2> $W/kt.log )
 python scripts/prof_summary.py $W/kt $((STEPS + WARM)) k_contact_solve $STEPS > $OUT/${R}_kernel_stats_pile32k.txt
+python scripts/prof_timeline.py $W/kt $((STEPS + WARM - 50)) > $OUT/${R}_timeline_pile32k.txt 2>&1 || true
+python bench.py --stage-timing --no-cpu-baseline > $OUT/${R}_bench_stage_timing.json 2> /dev/null || true
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --steps 60 --warmup 5 > /dev/null 2> $W/$C.log )
 done
