@@ -27,7 +27,7 @@ __device__ __forceinline__ float separation_threshold() { return 0.02f * 1.3f; }
 DI int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 DI float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-__global__ void k_step_reset(Counters *cnt) {
+__global__ void k_step_reset(Counters *cnt) {   // (inside edynhip_step the previous step's k_finish does this instead)
     int t = threadIdx.x;
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
@@ -384,7 +384,7 @@ int broadphase(edynhip_ctx *c) {
     const uint32_t np = c->bvh.num_proc;
     Manifolds &prev = c->m[c->cur], &cur = c->m[c->cur ^ 1];
     const uint32_t pm = c->num_manifolds;
-    hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
+    if (!c->full_step) hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
     uint32_t M = 0;
     if (np > 0) {
         // The tree TOPOLOGY (Morton order + Karras hierarchy) is rebuilt every kRebuildPeriod steps; in between only the

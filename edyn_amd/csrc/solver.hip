@@ -274,16 +274,14 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicSub(&cnt->uncoloured, done);
 }
-__global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32_t *keys, const uint32_t *__restrict__ bA,
-                           const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, bool sleeping) {
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+DI uint32_t colour_key(uint32_t m, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                       const uint32_t *__restrict__ flags, bool sleeping) {
     // within a colour, manifolds are grouped by point count (4 first): the solve kernels then know a lane's point
     // count from its position alone (no dependent load) and waves are uniform in it
     uint32_t in = info[m];
     uint32_t np = in & 0xFF;
     if (sleeping && np && edge_asleep(flags[bA[m]], flags[bB[m]])) np = 0;   // not part of this step's solve
-    keys[m] = np ? (((in >> 8) << 2) | (4u - np)) : 0xFFu;
+    return np ? (((in >> 8) << 2) | (4u - np)) : 0xFFu;
 }
 // Stable counting sort of the manifolds by (colour, point count) key - at most 256 distinct keys. (rocPRIM's radix sort
 // falls back to a merge sort for an 8-bit key range: 1 block-sort + 16 merge launches, ~90 us per step.)
@@ -291,12 +289,18 @@ __global__ void k_col_keys(uint32_t M, const uint32_t *__restrict__ info, uint32
 //  scan_u32:     exclusive scan of that key-major table                   -> where each (key, block) run starts
 //  k_cs_scatter: every element's slot = its run's start + its rank among the block's earlier elements with its key
 constexpr uint32_t kCsBlock = 1024, kCsKeys = 256;
-__global__ void __launch_bounds__(kCsBlock) k_cs_hist(uint32_t M, const uint32_t *__restrict__ keys, uint32_t *hist, uint32_t nblocks) {
+__global__ void __launch_bounds__(kCsBlock) k_cs_hist(uint32_t M, uint32_t *keys, uint32_t *hist, uint32_t nblocks, const uint32_t *__restrict__ info,
+                                                      const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                                                      const uint32_t *__restrict__ flags, bool sleeping) {
     __shared__ uint32_t h[kCsKeys];
     if (threadIdx.x < kCsKeys) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t m = blockIdx.x * kCsBlock + threadIdx.x;
-    if (m < M) atomicAdd(&h[keys[m] & 0xFFu], 1u);
+    if (m < M) {
+        const uint32_t key = colour_key(m, info, bA, bB, flags, sleeping);
+        keys[m] = key;
+        atomicAdd(&h[key & 0xFFu], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < kCsKeys) hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
@@ -392,7 +396,8 @@ DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, fl
     rw[base + 3 * cap] = to4(mul(A.inv_I, JaA), mu);
     rw[base + 4 * cap] = to4(mul(B.inv_I, JaB), 0.0f);
 }
-__global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt) {
+__global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt,
+                                const uint32_t *__restrict__ keys_sorted, bool push) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
     const uint32_t m = rows.order[p];
@@ -400,6 +405,11 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
     const uint32_t np = mf.info[m] & 0xFF;
     rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
     rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
+    if (push) {   // hand-off slot of (body, colour): k_push_links turns these into each body's chain
+        const uint32_t col = keys_sorted[p] >> 2;
+        if (is_dynamic(b.flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
+        if (is_dynamic(b.flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
+    }
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     for (uint32_t k = 0; k < np; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
@@ -779,14 +789,6 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 }
 
 // ---- push hand-off: link every (lane, side) to the same body's next manifold in colour order (cyclic) ----
-__global__ void k_push_slots(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ flags) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_active) return;
-    const uint32_t col = keys_sorted[p] >> 2;
-    const uint32_t ia = rows.bA[p], ib = rows.bB[p];
-    if (is_dynamic(flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
-    if (is_dynamic(flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
-}
 __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
@@ -1448,8 +1450,17 @@ __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
 }
 
 // ------------------------------------------------------------------ derived state
-__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end) {
+__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
+        const int t = threadIdx.x;
+        if (t == 0) {
+            cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0;
+        }
+        if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
+        for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
+    }
     if (i >= n) return;
     // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
     used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
@@ -1549,10 +1560,9 @@ static int colour_contacts(edynhip_ctx *c) {
         total_rounds += count;
     };
     auto sort_and_fetch = [&]() -> int {
-        hipLaunchKernelGGL(k_col_keys, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, c->col_keys, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
         {
             const uint32_t nb = blocks(M, kCsBlock);
-            hipLaunchKernelGGL(k_cs_hist, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb);
+            hipLaunchKernelGGL(k_cs_hist, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
             EH_TRY(scan_u32(c, c->cs_hist, c->cs_start, kCsKeys * nb));
             hipLaunchKernelGGL(k_cs_scatter, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order);
         }
@@ -1606,19 +1616,18 @@ int solve(edynhip_ctx *c) {
     const float dt = c->cfg.fixed_dt;
     const uint32_t rcap = mf.cap;
     rec(c, 3);
+    // gravity / zeroed deltas do not depend on the colouring: enqueued first, they run while the host waits for the counters
+    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
     EH_TRY(colour_contacts(c));
     // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
     c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
     rec(c, 4);
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;
-    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
-    if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt);
-    // Without joints every delta hand-off stays inside the contact sweeps: use the push slots (no dependent gathers).
-    const bool push = j.n == 0 && na > 0;
+    const bool push = j.n == 0 && na > 0;   // without joints every delta hand-off stays inside the contact sweeps
+    if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
     if (push) {
-        hipLaunchKernelGGL(k_push_slots, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b.flags);
         hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
     }
     rec(c, 5);
@@ -1792,7 +1801,7 @@ int solve(edynhip_ctx *c) {
         pos_per_colour(0);
     }
     rec(c, 8);
-    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end);
+    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt);
     rec(c, 9);
     ++c->step_index;
     EH_HIP(c, hipGetLastError());
