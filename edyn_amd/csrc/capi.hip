@@ -95,6 +95,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
+    EH_TRY(dalloc(c, c->col_unc, kColUncCap));
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));

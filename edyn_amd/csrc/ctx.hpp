@@ -108,6 +108,7 @@ struct Rows {
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;
+constexpr uint32_t kColUncCap = 16384;   // uncoloured edges one workgroup colours by itself (more: the multi-block rounds)
 constexpr uint32_t kHeadBit = 0x80000000u, kSlotMask = 0x7FFFFFFFu;
 // Hand-off slot addressing (float4 units). A slot is (lane p, side); its pieces are laid out so that ONE vector load of a
 // wave - 64 consecutive p for the velocity slots, 32 consecutive p x 2 sides for the position slots - reads contiguous
@@ -147,6 +148,7 @@ struct Counters {
     uint32_t num_new;            // manifolds created this step (their body pairs are listed in new_edges)
     uint32_t num_extra;          // pair keys beyond an owner's in-LDS list (broadphase fallback path)
     uint32_t num_awake;          // procedural bodies left awake by this step's sleep decisions (island sleeping)
+    uint32_t unc_count;          // edges k_col_prepare found uncoloured (listed in col_unc while they fit)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
@@ -192,6 +194,7 @@ struct edynhip_ctx {
     uint32_t prev_num_manifolds = 0;
     uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr;   // colour sort (counting sort, solver.hip k_cs_*)
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
+    uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)

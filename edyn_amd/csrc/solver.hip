@@ -206,7 +206,7 @@ __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__
 // vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards.
 __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
-                              uint64_t *best0, uint64_t *best1, Counters *cnt, uint32_t reinsert) {
+                              uint64_t *best0, uint64_t *best1, Counters *cnt, uint32_t reinsert, uint32_t *unc_list) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t unc = 0;
     if (m < M) {
@@ -229,9 +229,73 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
             }
         }
     }
+    {   // list the uncoloured edges (one atomic per wave) for k_col_rounds; beyond its capacity only the count matters
+        const uint64_t mask = __ballot(unc != 0);
+        if (mask) {
+            const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cnt->unc_count, (uint32_t)__popcll(mask));
+            base = __shfl(base, leader);
+            const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (unc && at < kColUncCap) unc_list[at] = m;
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) unc += __shfl_xor(unc, off);
     if ((threadIdx.x & 63) == 0 && unc) atomicAdd(&cnt->uncoloured, unc);
+}
+// The rounds for a SHORT list of uncoloured edges - the steady state: a few hundred new contacts per step - run in one
+// workgroup with workgroup barriers between the phases instead of two launches per round; same rule, same result as
+// k_col_best / k_col_assign. Longer lists are left to those (the host sees cnt->uncoloured != 0).
+__global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                                                     const uint32_t *__restrict__ flags, uint64_t *best, uint64_t *used, Counters *cnt,
+                                                     const uint32_t *__restrict__ list, uint32_t max_rounds) {
+    __shared__ uint32_t remaining;
+    const uint32_t n = cnt->unc_count;
+    if (n == 0 || n > kColUncCap) return;
+    if (threadIdx.x == 0) remaining = n;
+    __syncthreads();
+    auto ld = [](const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // other waves' stores: not through a stale L1 line
+    for (uint32_t round = 0; round < max_rounds; ++round) {
+        if (remaining == 0) break;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 1: every endpoint learns its best uncoloured edge
+            const uint32_t m = list[e];
+            if ((ld32(&info[m]) >> 8) != kNoColour) continue;
+            const uint32_t a = bA[m], b = bB[m];
+            const uint64_t pr = edge_prio(m);
+            if (is_dynamic(flags[a])) atomicMax((unsigned long long *)&best[a], pr);
+            if (is_dynamic(flags[b])) atomicMax((unsigned long long *)&best[b], pr);
+        }
+        __threadfence(); __syncthreads();
+        uint32_t done = 0;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 2: edges that are best at both ends take a colour
+            const uint32_t m = list[e];
+            const uint32_t in = ld32(&info[m]);
+            if ((in >> 8) != kNoColour) continue;
+            const uint32_t a = bA[m], b = bB[m];
+            const bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
+            const uint64_t pr = edge_prio(m);
+            if ((da && ld(&best[a]) != pr) || (db && ld(&best[b]) != pr)) continue;
+            const uint64_t busy = (da ? ld(&used[a]) : 0ull) | (db ? ld(&used[b]) : 0ull);
+            uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
+            if (c >= kMaxContactColours) { cnt->colour_overflow = 1; c = kMaxContactColours - 1; }
+            info[m] = (in & 0xFF) | (c << 8);
+            if (da) atomicOr((unsigned long long *)&used[a], 1ull << c);
+            if (db) atomicOr((unsigned long long *)&used[b], 1ull << c);
+            ++done;
+        }
+        __threadfence(); __syncthreads();
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 3: clear the marks for the next round
+            const uint32_t m = list[e];
+            const uint32_t a = bA[m], b = bB[m];
+            if (is_dynamic(flags[a])) best[a] = 0;
+            if (is_dynamic(flags[b])) best[b] = 0;
+        }
+        if (done) atomicSub(&remaining, done);
+        __threadfence(); __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt->uncoloured = remaining;
 }
 __global__ void k_col_best(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                            const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *best_cur,
@@ -1456,7 +1520,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
         const int t = threadIdx.x;
         if (t == 0) {
             cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0;
         }
         if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
         for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
@@ -1549,7 +1613,7 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }
     const uint32_t reinsert = c->num_colours >= 2 ? c->num_colours - 1 : kNoColour;
-    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert);
+    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert, c->col_unc);
     uint32_t round = 0, total_rounds = 0;
     auto run_rounds = [&](uint32_t count) {
         for (uint32_t r = 0; r < count; ++r, ++round) {
@@ -1570,8 +1634,9 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_TRY(fetch_counters(c, sizeof(Counters)));
         return EDYNHIP_OK;
     };
-    // Steady state: the few new edges colour within the speculative rounds and ONE host sync fetches the offsets.
-    run_rounds(3);
+    // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
+    // could not finish (a long list, or more rounds than it runs) is left to the multi-block rounds below.
+    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), 0, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->used, c->cnt, c->col_unc, 16u);
     EH_TRY(sort_and_fetch());
     if (c->cnt_host->uncoloured != 0) {
         uint32_t batch = 4;
