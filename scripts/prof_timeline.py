@@ -5,7 +5,7 @@ path = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 if os.path.isdir(path): path = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))[0]
 cur = sqlite3.connect(path).cursor()
 rows = list(cur.execute("select name, start, end from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if "k_step_reset" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_bp_refit" in r[0]]   # first kernel of every step
 a, b = starts[which], starts[which + 1]
 t0 = rows[a][1]; prev_end = t0
 tot_gap = 0
