@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
             if (is_dynamic(flags[a])) atomicMax((unsigned long long *)&best[a], pr);
             if (is_dynamic(flags[b])) atomicMax((unsigned long long *)&best[b], pr);
         }
-        __threadfence(); __syncthreads();
+        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
         uint32_t done = 0;
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 2: edges that are best at both ends take a colour
             const uint32_t m = list[e];
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
             if (db) atomicOr((unsigned long long *)&used[b], 1ull << c);
             ++done;
         }
-        __threadfence(); __syncthreads();
+        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 3: clear the marks for the next round
             const uint32_t m = list[e];
             const uint32_t a = bA[m], b = bB[m];
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
             if (is_dynamic(flags[b])) best[b] = 0;
         }
         if (done) atomicSub(&remaining, done);
-        __threadfence(); __syncthreads();
+        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
     }
     if (threadIdx.x == 0) cnt->uncoloured = remaining;
 }
