@@ -99,6 +99,8 @@ static int allocate(edynhip_ctx *c) {
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));
+    EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
+    EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));
     EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
     EH_HIP(c, hipMemsetAsync(c->sleep_since, 0xFF, (size_t)nb * sizeof(int32_t), c->stream));   // -1: no timer running
     Joints &j = c->j;
@@ -402,6 +404,7 @@ void edynhip_destroy(edynhip_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
     if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
+    if (c->state_host) (void)hipHostFree(c->state_host);
     for (auto &e : c->timer.ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -614,13 +617,11 @@ int edynhip_get_state(edynhip_ctx *c, float *pos, float *orn, float *linvel, flo
     const uint32_t n = c->b.n;
     if (n == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
-    float *d = nullptr;
-    EH_HIP(c, hipMalloc((void **)&d, (size_t)n * 13 * sizeof(float)));
+    float *d = c->state_dev;
+    const float *h = c->state_host;
     hipLaunchKernelGGL(k_pack_state, dim3((n + 255) / 256), dim3(256), 0, c->stream, 0u, n, c->b, d);
-    std::vector<float> h((size_t)n * 13);
-    hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipMemcpyAsync(c->state_host, d, (size_t)n * 13 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_get_state", e);
     for (uint32_t i = 0; i < n; ++i) {
         const float *o = &h[(size_t)i * 13];
@@ -637,18 +638,15 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     const uint32_t n = c->b.n;
     if (n == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
-    std::vector<float> h((size_t)n * 13);
+    float *h = c->state_host, *d = c->state_dev;
     for (uint32_t i = 0; i < n; ++i) {
         float *o = &h[(size_t)i * 13];
         std::memcpy(o, pos + 3 * i, 12); std::memcpy(o + 3, orn + 4 * i, 16);
         std::memcpy(o + 7, linvel + 3 * i, 12); std::memcpy(o + 10, angvel + 3 * i, 12);
     }
-    float *d = nullptr;
-    EH_HIP(c, hipMalloc((void **)&d, h.size() * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(d, h, (size_t)n * 13 * sizeof(float), hipMemcpyHostToDevice, c->stream);
     hipLaunchKernelGGL(k_unpack_state, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, c->b);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the staging buffers are reused by the next call
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_state", e);
     if (c->sleeping) return edynhip_wake_all(c);   // an edited body wakes its island (wake_up_entity); all of them here
     return EDYNHIP_OK;

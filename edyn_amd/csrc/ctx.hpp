@@ -215,6 +215,8 @@ struct edynhip_ctx {
     std::vector<void *> allocs;
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
+    float *state_dev = nullptr;    // [max_bodies][13] staging of the packed state (get/set_state run every update in the C++ shim)
+    float *state_host = nullptr;   // pinned mirror
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     uint32_t step_index = 0;       // completed steps (island sleep timers count in steps)

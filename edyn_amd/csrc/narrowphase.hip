@@ -242,23 +242,26 @@ __global__ void k_debug_collide(uint32_t n, const int32_t *__restrict__ st, cons
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count) {
     if (n == 0) return EDYNHIP_OK;
-    int32_t *d_st; float4 *d_sp; float *d_pos; float4 *d_orn; float *d_out; uint32_t *d_cnt;
-    EH_HIP(c, hipMalloc((void **)&d_st, (size_t)n * 8)); EH_HIP(c, hipMalloc((void **)&d_sp, (size_t)n * 32));
-    EH_HIP(c, hipMalloc((void **)&d_pos, (size_t)n * 24)); EH_HIP(c, hipMalloc((void **)&d_orn, (size_t)n * 32));
-    EH_HIP(c, hipMalloc((void **)&d_out, (size_t)n * 44 * 4)); EH_HIP(c, hipMalloc((void **)&d_cnt, (size_t)n * 4));
+    // one scratch allocation, carved up: [shape types | shape params | positions | orientations | points | counts]
+    const size_t b_st = (size_t)n * 8, b_sp = (size_t)n * 32, b_pos = (size_t)n * 24, b_orn = (size_t)n * 32, b_out = (size_t)n * 44 * 4, b_cnt = (size_t)n * 4;
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_sp = up16(b_st), o_pos = o_sp + up16(b_sp), o_orn = o_pos + up16(b_pos), o_out = o_orn + up16(b_orn), o_cnt = o_out + up16(b_out);
+    char *d = nullptr;
+    EH_HIP(c, hipMalloc((void **)&d, o_cnt + up16(b_cnt)));
     hipStream_t s = c->stream;
-    hipError_t e = hipMemcpyAsync(d_st, st, (size_t)n * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_sp, sp, (size_t)n * 32, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos, (size_t)n * 24, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_orn, orn, (size_t)n * 32, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * 44 * 4, s);
+    hipError_t e = hipMemcpyAsync(d, st, b_st, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, sp, b_sp, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_pos, pos, b_pos, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_orn, orn, b_orn, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_out, 0, b_out, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_collide, dim3((n + 63) / 64), dim3(64), 0, s, n, d_st, d_sp, d_pos, d_orn, threshold, d_out, d_cnt);
-        e = hipMemcpyAsync(out, d_out, (size_t)n * 44 * 4, hipMemcpyDeviceToHost, s);
+        hipLaunchKernelGGL(k_debug_collide, dim3((n + 63) / 64), dim3(64), 0, s, n, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
+                           (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt));
+        e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, s);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(count, d_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(count, d + o_cnt, b_cnt, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_st); (void)hipFree(d_sp); (void)hipFree(d_pos); (void)hipFree(d_orn); (void)hipFree(d_out); (void)hipFree(d_cnt);
+    (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_debug_collide", e);
     return EDYNHIP_OK;
 }
