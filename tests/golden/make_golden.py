@@ -33,6 +33,10 @@ CASES = {
     "columns": (columns_small, 30, 8),
     "chains": (lambda: scenes.c5_chains(4, 6), 40, 10),
 }
+# island sleeping enabled: a 3x3x3 brick pile collapses into several islands that settle and fall asleep one by one
+SLEEP_CASES = {
+    "sleep3": (lambda: scenes.box_pile(3, 3, 3), 420, 10),
+}
 
 
 def main():
@@ -55,5 +59,28 @@ def main():
         print(name, "bodies", len(scene["kind"]), "manifolds", len(m), "points", int(m["num_points"].sum()))
 
 
+def main_sleep():
+    for name, (gen, steps, vel) in SLEEP_CASES.items():
+        scene = gen()
+        w = ob.World(vel_iters=vel, pos_iters=3, order=ob.ORDER_COLOURED)
+        w.add_bodies(scene)
+        w.set_sleeping(True)
+        asleep_count, first_sleep = [], np.full(len(scene["kind"]), -1, np.int32)
+        for k in range(steps):
+            w.step(1)
+            a = w.get_asleep()
+            asleep_count.append(int(a.sum()))
+            first_sleep[(first_sleep < 0) & a] = k
+        pos, orn, lv, av = w.get_state()
+        out = {"steps": steps, "vel_iters": vel, "pos": pos, "orn": orn, "linvel": lv, "angvel": av, "asleep": w.get_asleep(),
+               "asleep_count": np.array(asleep_count, np.int32), "first_sleep": first_sleep, "manifolds": w.get_manifolds()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "bodies", len(scene["kind"]), "asleep at the end", asleep_count[-1], "first sleep at steps", sorted(set(first_sleep[first_sleep >= 0].tolist()))[:6])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sleep":
+        main_sleep()       # only the sleeping fixtures (leaves the other files untouched)
+    else:
+        main()
+        main_sleep()

@@ -640,3 +640,23 @@ def test_exclusive_device_launch_mode_is_bit_identical():
     a.step_simulation(60); b.step_simulation(60)
     for x, y in zip(a.get_state(), b.get_state()):
         assert np.array_equal(x, y)
+
+
+def test_golden_sleeping_fixture():
+    """Committed fixture (tests/golden/make_golden.py sleep): the number of sleeping bodies after every step, the step at
+    which each body first fell asleep, and the final state / manifolds of a collapsing pile with island sleeping on."""
+    g = np.load(os.path.join(GOLDEN, "sleep3.npz"))
+    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=int(g["vel_iters"]), num_solver_position_iterations=3, sleeping=True))
+    w.set_scene(scenes.box_pile(3, 3, 3))
+    counts, first = [], np.full(len(g["asleep"]), -1, np.int32)
+    for k in range(int(g["steps"])):
+        w.step_simulation(1)
+        a = w.get_asleep()
+        counts.append(int(a.sum()))
+        first[(first < 0) & a] = k
+    assert np.array_equal(np.array(counts, np.int32), g["asleep_count"])
+    assert np.array_equal(first, g["first_sleep"])
+    assert np.array_equal(w.get_asleep(), g["asleep"])
+    for a, key in zip(w.get_state(), ("pos", "orn", "linvel", "angvel")):
+        assert np.array_equal(a, g[key]), key
+    assert_manifolds_equal(w.get_manifolds(), g["manifolds"], what="sleep3")
