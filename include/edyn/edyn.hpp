@@ -47,6 +47,8 @@ struct position : vector3 {};
 struct orientation : quaternion {};
 struct linvel : vector3 {};
 struct angvel : vector3 {};
+struct present_position : vector3 {};      // comp/present_position.hpp: what a renderer should draw (interpolated)
+struct present_orientation : quaternion {};
 struct mass { scalar s; };
 struct mass_inv { scalar s; };
 struct inertia : matrix3x3 {};
@@ -83,6 +85,7 @@ struct rigidbody_def {   // util/rigidbody.hpp:29-81 (hot-path fields)
     uint64_t collision_group{~0ull};
     uint64_t collision_mask{~0ull};
     bool sleeping_disabled{false};
+    bool presentation{true};
 };
 
 struct constraint_base { std::array<entt::entity, 2> body; };
@@ -257,6 +260,35 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps) 
     check(s, edynhip_step(s.ctx, steps));
     write_back(registry, s);
 }
+// update_presentation (src/edyn/sys/update_presentation.cpp:56-84), local simulation (no discontinuities): transforms are
+// extrapolated from the last simulated state to `presentation_delay` = fixed_dt behind the current time.
+inline quaternion integrate(const quaternion &q, const vector3 &w, scalar dt) {   // math/quaternion.cpp:7-22
+    const scalar ws = std::sqrt(w.x * w.x + w.y * w.y + w.z * w.z);
+    const scalar half = scalar(0.5);
+    scalar t;
+    if (ws < scalar(0.001)) t = half * dt - dt * dt * dt * (scalar(1) / scalar(48)) * ws * ws;
+    else t = std::sin(half * ws * dt) / ws;
+    const quaternion r{w.x * t, w.y * t, w.z * t, std::cos(half * ws * dt)};
+    quaternion o{r.w * q.x + r.x * q.w + r.y * q.z - r.z * q.y, r.w * q.y + r.y * q.w + r.z * q.x - r.x * q.z,
+                 r.w * q.z + r.z * q.w + r.x * q.y - r.y * q.x, r.w * q.w - r.x * q.x - r.y * q.y - r.z * q.z};
+    const scalar l = std::sqrt(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
+    o.x /= l; o.y /= l; o.z /= l; o.w /= l;
+    return o;
+}
+inline void update_presentation(entt::registry &registry, gpu_stepper &s, double time) {
+    const double sim_time = s.last_time - s.accumulated;
+    const scalar idt = std::min(static_cast<scalar>(time - s.cfg.fixed_dt - sim_time), s.cfg.fixed_dt);
+    for (const entt::entity e : s.bodies) {
+        if (!registry.all_of<present_position>(e) || registry.all_of<sleeping_tag>(e)) continue;
+        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
+        const auto &v = registry.get<linvel>(e); const auto &w = registry.get<angvel>(e);
+        auto &pp = registry.get<present_position>(e);
+        pp.x = p.x + v.x * idt; pp.y = p.y + v.y * idt; pp.z = p.z + v.z * idt;
+        const quaternion o = integrate(q, w, idt);
+        auto &po = registry.get<present_orientation>(e);
+        po.x = o.x; po.y = o.y; po.z = o.z; po.w = o.w;
+    }
+}
 }  // namespace detail
 
 // ---- edyn.hpp:66-150
@@ -291,6 +323,7 @@ inline void update(entt::registry &registry, double time) {
     const unsigned steps = (unsigned)std::min<uint64_t>(num_steps, s.cfg.max_steps_per_update);
     detail::run_steps(registry, s, steps);
     s.last_time = time;
+    detail::update_presentation(registry, s, time);
 }
 /// stepper_sequential::step_simulation (stepper_sequential.cpp:121-147): exactly one step; requires paused.
 inline void step_simulation(entt::registry &registry, double time = 0) {
@@ -312,6 +345,10 @@ inline void make_rigidbody(entt::entity entity, entt::registry &registry, const 
     if (def.kind != rigidbody_kind::rb_static) {
         registry.emplace<linvel>(entity, linvel{def.linvel});
         registry.emplace<angvel>(entity, angvel{def.angvel});
+    }
+    if (def.kind == rigidbody_kind::rb_dynamic && def.presentation) {   // rigidbody.cpp:71-75
+        registry.emplace<present_position>(entity, present_position{def.position});
+        registry.emplace<present_orientation>(entity, present_orientation{def.orientation});
     }
     const vector3 g = def.gravity ? *def.gravity : s.cfg.gravity;
     if (def.kind == rigidbody_kind::rb_dynamic) registry.emplace<gravity>(entity, gravity{g});
