@@ -660,3 +660,36 @@ def test_golden_sleeping_fixture():
     for a, key in zip(w.get_state(), ("pos", "orn", "linvel", "angvel")):
         assert np.array_equal(a, g[key]), key
     assert_manifolds_equal(w.get_manifolds(), g["manifolds"], what="sleep3")
+
+
+def test_awake_body_hits_sleeping_owner_with_higher_index():
+    """The hard case for the owner-major pair list: body 1 is created first and falls from 150 m; the pile created after it
+    settles and falls asleep long before it arrives. When it lands, the pairs it forms belong to SLEEPING owners (higher
+    index) that do not query the broadphase themselves - the awake body has to report them (consider_sleeping_owner),
+    the new manifolds wake the island in the same step. Bit-exact against the oracle through impact and re-sleep."""
+    pile = scenes.box_pile(3, 1, 3)   # one layer: at rest from the start, asleep after ~2 s
+    s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in pile.items()}
+    falling = {k: v[1:2].copy() for k, v in pile.items() if isinstance(v, np.ndarray) and len(v) == len(pile["kind"])}
+    falling["pos"] = np.float32([[0.2, 150.0, 0.1]])
+    for k, v in falling.items():   # insert right after the floor: index 1, below every pile body
+        s[k] = np.concatenate([s[k][:1], v, s[k][1:]], axis=0)
+    g, o = _sleep_worlds(s)
+    impact, woke_bodies = None, 0
+    prev = None
+    for step in range(620):
+        g.step_simulation(1); o.step(1)
+        a = g.get_asleep()
+        assert np.array_equal(a, o.get_asleep()), step
+        if step % 10 == 9 or (impact is not None and step < impact + 40):
+            for x, y in zip(g.get_state(), o.get_state()):
+                assert np.array_equal(x, y), step
+        if prev is not None and (prev & ~a).any():
+            if impact is None:
+                impact = step
+            woke_bodies += int((prev & ~a).sum())
+        prev = a
+    assert impact is not None and 300 < impact < 360, impact      # sqrt(2*150/9.8) = 5.5 s
+    assert woke_bodies >= 2
+    m = g.get_manifolds()
+    assert ((m["body"] == 1).any(axis=1)).any(), "body 1 rests on the pile"
+    assert_manifolds_equal(m, o.get_manifolds(), what="impact")
