@@ -1,7 +1,8 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.
 
 ctypes binding for oracle/liboracle.so (the CPU restatement of the reference step loop) and, when
-built, oracle/_ref/libedynref.so (the EnTT-free reference translation units compiled as they lie).
+built, oracle/_ref/libedynref.so (the REAL reference engine: its own translation units compiled where
+they lie against oracle/entt_min, driven by ref_world.cpp / ref_xcheck.cpp).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product package (edyn_amd/) never does.
 """
@@ -23,14 +24,14 @@ MANIFOLD_DTYPE = np.dtype([
 SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
 JOINT_POINT, JOINT_HINGE = 0, 1
-ORDER_SEQUENTIAL, ORDER_COLOURED = 0, 1
+ORDER_SEQUENTIAL, ORDER_COLOURED, ORDER_EXTERNAL = 0, 1, 2
 
 
 def build(ref=True):
     """Compile liboracle.so (and _ref/libedynref.so when /root/reference is present)."""
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     if ref and os.path.isdir("/root/reference/src/edyn"):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-j%d" % max(2, os.cpu_count() or 2), "-C", _HERE, "ref"])
 
 
 def _fp(a):
@@ -230,6 +231,18 @@ class World:
         return self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
                                     _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
 
+    def set_ext_order(self, contacts, joints=()):
+        """ORDER_EXTERNAL: visiting order for the next step (RefWorld.get_solve_order() of the same step)."""
+        c = np.ascontiguousarray(contacts, np.uint32).reshape(-1, 3); j = np.ascontiguousarray(joints, np.uint32)
+        f = self.L.orc_set_ext_order
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, c.ctypes.data, len(c), j.ctypes.data, len(j))
+
+    def ext_order_mismatch(self):
+        f = self.L.orc_ext_order_mismatch
+        f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        return bool(f(self.h))
+
     def set_sleeping(self, enable=True):
         self.L.orc_set_sleeping(self.h, 1 if enable else 0)
 
@@ -317,3 +330,196 @@ def collide_batch(shape_type, shape_param, pos, orn, threshold=0.01):
     f.restype = None
     f(n, st.ctypes.data, sp.ctypes.data, ps.ctypes.data, qs.ctypes.data, threshold, out.ctypes.data, cnt.ctypes.data)
     return out, cnt
+
+
+def _batch(fn, shape_type, shape_param, pos, orn, threshold):
+    st = np.ascontiguousarray(shape_type, np.int32).reshape(-1, 2)
+    n = len(st)
+    sp = np.ascontiguousarray(shape_param, np.float32).reshape(n, 2, 4)
+    ps = np.ascontiguousarray(pos, np.float32).reshape(n, 2, 3)
+    qs = np.ascontiguousarray(orn, np.float32).reshape(n, 2, 4)
+    out = np.zeros((n, 4, 11), np.float32); cnt = np.zeros(n, np.uint32)
+    fn.argtypes = [C.c_uint32] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(n, st.ctypes.data, sp.ctypes.data, ps.ctypes.data, qs.ctypes.data, threshold, out.ctypes.data, cnt.ctypes.data)
+    return out, cnt
+
+
+def ref_collide_batch(shape_type, shape_param, pos, orn, threshold=0.01):
+    """The real edyn::collide overloads (collide.hpp:43-330) on a batch of pairs."""
+    return _batch(ref().ref_collide_batch, shape_type, shape_param, pos, orn, threshold)
+
+
+def tree_run(ops, boxes, real=False, max_hits=1 << 22):
+    """Scripted dynamic-tree session; see ref_xcheck.cpp ref_tree_run. Returns (hits, moved)."""
+    ops = np.ascontiguousarray(ops, np.int32).reshape(-1, 2)
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(len(ops), 6)
+    hits = np.zeros(max_hits, np.uint32); moved = np.zeros(len(ops), np.uint8)
+    fn = ref().ref_tree_run if real else lib().orc_tree_run
+    fn.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    fn.restype = C.c_uint32
+    n = fn(len(ops), ops.ctypes.data, boxes.ctypes.data, hits.ctypes.data, max_hits, moved.ctypes.data)
+    assert n < max_hits
+    return hits[:n].copy(), moved
+
+
+def friction_solve(normal, fric, delta, warm=True, sweeps=1, real=False):
+    """Friction pair vs its normal row; see ref_xcheck.cpp ref_friction_solve. Returns (impulses[2], delta[12])."""
+    d = _f32(delta, 12).copy(); out = np.zeros(2, np.float32)
+    fn = ref().ref_friction_solve if real else lib().orc_friction_solve
+    fn.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_int, C.c_int, C.POINTER(C.c_float)]
+    fn.restype = None
+    fn(_fp(_f32(normal, 33)), _fp(_f32(fric, 31)), _fp(d), int(warm), int(sweeps), _fp(out))
+    return out, d
+
+
+class RefWorld:
+    """The REAL reference engine (oracle/_ref/libedynref.so, ref_world.cpp) behind the same interface as World.
+
+    mode 0 = execution_mode::sequential, 1 = sequential_multithreaded (workers=0 -> hardware_concurrency-1).
+    """
+
+    def __init__(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3, gravity=(0, -9.8, 0), mode=0, workers=0):
+        L = ref()
+        if L is None:
+            raise RuntimeError("oracle/_ref/libedynref.so is not built (make -C oracle ref)")
+        self.L = L
+        L.refw_create.restype = C.c_void_p
+        L.refw_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.refw_destroy.argtypes = [C.c_void_p]
+        L.refw_add_body.restype = C.c_uint32
+        L.refw_add_body.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_float)] * 4 + [
+            C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int,
+            C.c_uint64, C.c_uint64, C.POINTER(C.c_float), C.c_int]
+        L.refw_add_joint.restype = C.c_uint32
+        L.refw_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_float)] * 4
+        L.refw_set_joint_params.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+        L.refw_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.refw_set_restitution_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.refw_step.argtypes = [C.c_void_p, C.c_int]
+        L.refw_time_steps.argtypes = [C.c_void_p, C.c_int]; L.refw_time_steps.restype = C.c_double
+        L.refw_update.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.refw_set_max_steps_per_update.argtypes = [C.c_void_p, C.c_uint]
+        L.refw_num_bodies.argtypes = [C.c_void_p]; L.refw_num_bodies.restype = C.c_uint32
+        L.refw_get_state.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
+        L.refw_set_state.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
+        L.refw_get_derived.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        L.refw_num_islands.argtypes = [C.c_void_p]; L.refw_num_islands.restype = C.c_uint32
+        L.refw_num_manifolds.argtypes = [C.c_void_p]; L.refw_num_manifolds.restype = C.c_uint32
+        L.refw_get_manifolds.argtypes = [C.c_void_p, C.c_void_p]
+        L.refw_get_joint_impulses.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.refw_sizeof_manifold_rec.restype = C.c_uint32
+        assert L.refw_sizeof_manifold_rec() == MANIFOLD_DTYPE.itemsize
+        self.h = C.c_void_p(L.refw_create(mode, workers, dt, vel_iters, pos_iters, _fp(_f32(gravity, 3))))
+        self.n_joints = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.refw_destroy(self.h)
+            self.h = None
+
+    def add_body(self, kind=KIND_DYNAMIC, pos=(0, 0, 0), orn=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0),
+                 mass=1.0, shape_type=SHAPE_NONE, shape_param=(0, 0, 0, 0), inertia=None, friction=0.5,
+                 restitution=0.0, has_material=True, group=2**64 - 1, mask=2**64 - 1, gravity=None,
+                 sleeping_disabled=True):
+        I = _fp(_f32(inertia, 9)) if inertia is not None else None
+        g = _fp(_f32(gravity, 3)) if gravity is not None else None
+        return self.L.refw_add_body(self.h, kind, _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), _fp(_f32(linvel, 3)),
+                                    _fp(_f32(angvel, 3)), mass, shape_type, _fp(_f32(shape_param, 4)), I,
+                                    friction, restitution, int(has_material), group, mask, g, int(sleeping_disabled))
+
+    def add_bodies(self, scene, sleeping_disabled=True):
+        n = len(scene["kind"])
+        inertia = scene.get("inertia")
+        has_inertia = scene.get("has_inertia")
+        for i in range(n):
+            I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
+            self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
+                          scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
+                          scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
+                          True, int(scene["group"][i]), int(scene["mask"][i]), None, sleeping_disabled)
+        for j in scene.get("joints") or []:
+            self.add_joint(*j)
+
+    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0)):
+        self.n_joints += 1
+        return self.L.refw_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
+                                     _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+
+    def set_joint_params(self, joint, params):
+        p = np.zeros(10, np.float32); p[:len(params)] = params
+        self.L.refw_set_joint_params(self.h, joint, _fp(p))
+
+    def exclude_collision(self, a, b):
+        self.L.refw_exclude_collision(self.h, a, b)
+
+    def set_restitution_iterations(self, iters, individual=3):
+        self.L.refw_set_restitution_iterations(self.h, iters, individual)
+
+    def step(self, n=1):
+        self.L.refw_step(self.h, n)
+
+    def time_steps(self, n):
+        return self.L.refw_time_steps(self.h, n)
+
+    def update(self, time, paused=False):
+        self.L.refw_update(self.h, float(time), int(paused))
+
+    def set_max_steps_per_update(self, n):
+        self.L.refw_set_max_steps_per_update(self.h, n)
+
+    @property
+    def num_bodies(self):
+        return self.L.refw_num_bodies(self.h)
+
+    def get_state(self):
+        n = self.num_bodies
+        pos = np.zeros((n, 3), np.float32); orn = np.zeros((n, 4), np.float32)
+        lv = np.zeros((n, 3), np.float32); av = np.zeros((n, 3), np.float32)
+        self.L.refw_get_state(self.h, _fp(pos), _fp(orn), _fp(lv), _fp(av))
+        return pos, orn, lv, av
+
+    def set_state(self, pos, orn, lv, av):
+        n = self.num_bodies
+        self.L.refw_set_state(self.h, _fp(_f32(pos, 3 * n)), _fp(_f32(orn, 4 * n)), _fp(_f32(lv, 3 * n)), _fp(_f32(av, 3 * n)))
+
+    def get_derived(self):
+        n = self.num_bodies
+        aabb = np.zeros((n, 6), np.float32); iw = np.zeros((n, 9), np.float32)
+        isl = np.zeros(n, np.uint32); asleep = np.zeros(n, np.uint8)
+        self.L.refw_get_derived(self.h, _fp(aabb), _fp(iw), isl.ctypes.data, asleep.ctypes.data)
+        return aabb, iw, isl, asleep.astype(bool)
+
+    def get_asleep(self):
+        return self.get_derived()[3]
+
+    @property
+    def num_islands(self):
+        return self.L.refw_num_islands(self.h)
+
+    def get_manifolds(self):
+        m = self.L.refw_num_manifolds(self.h)
+        out = np.zeros(m, MANIFOLD_DTYPE)
+        if m:
+            self.L.refw_get_manifolds(self.h, out.ctypes.data)
+        return out
+
+    def get_pairs(self):
+        m = self.get_manifolds()
+        b = m["body"].astype(np.uint64)
+        hi = np.maximum(b[:, 0], b[:, 1]); lo = np.minimum(b[:, 0], b[:, 1])
+        return np.sort((hi << np.uint64(32)) | lo)
+
+    def get_solve_order(self, max_entries=1 << 22):
+        """(contacts[n,3], joints[m]) in the order the last step's island solvers visited them."""
+        c = np.zeros((max_entries, 3), np.uint32); j = np.zeros(max(self.n_joints, 1), np.uint32)
+        f = self.L.refw_get_contact_order; f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]; f.restype = C.c_uint32
+        g = self.L.refw_get_joint_order; g.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]; g.restype = C.c_uint32
+        nc = f(self.h, c.ctypes.data, max_entries); nj = g(self.h, j.ctypes.data, len(j))
+        return c[:nc].copy(), j[:nj].copy()
+
+    def get_joint_impulses(self):
+        out = np.zeros((self.n_joints, 10), np.float32)
+        if self.n_joints:
+            self.L.refw_get_joint_impulses(self.h, _fp(out))
+        return out

@@ -57,6 +57,15 @@ uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *p
                        const float *axisA, const float *axisB) {
     return ((World *)h)->add_joint(type, a, b, v3(pivotA), v3(pivotB), v3(axisA), v3(axisB));
 }
+// ORDER_EXTERNAL: the visiting order of the next step(s), as exported by ref_world.cpp (3 uint32 per contact entry).
+void orc_set_ext_order(void *h, const uint32_t *contacts3, uint32_t nc, const uint32_t *joints, uint32_t nj) {
+    World *w = (World *)h;
+    w->ext_contact_order.clear(); w->ext_joint_order.clear();
+    for (uint32_t i = 0; i < nc; ++i) w->ext_contact_order.push_back({contacts3[3 * i], contacts3[3 * i + 1], contacts3[3 * i + 2]});
+    for (uint32_t i = 0; i < nj; ++i) w->ext_joint_order.push_back(joints[i]);
+    w->ext_order_mismatch = false;
+}
+int orc_ext_order_mismatch(void *h) { return ((World *)h)->ext_order_mismatch ? 1 : 0; }
 // island sleeping (off by default)
 void orc_set_sleeping(void *h, int enable) { ((World *)h)->sleeping = enable != 0; }
 void orc_set_sleeping_disabled(void *h, uint32_t body, int disabled) { ((World *)h)->bodies[body].sleeping_disabled = disabled != 0; }
@@ -234,4 +243,49 @@ extern "C" void orc_collide_batch(uint32_t n, const int32_t *st, const float *sp
     for (uint32_t i = 0; i < n; ++i)
         count[i] = (uint32_t)orc_collide(st[2 * i], sp + 8 * i, pos + 6 * i, orn + 8 * i, st[2 * i + 1], sp + 8 * i + 4, pos + 6 * i + 3,
                                          orn + 8 * i + 4, threshold, out + (size_t)i * 44);
+}
+
+// Twins of oracle/ref_xcheck.cpp's ref_tree_run / ref_friction_solve over the restatement (same argument layouts).
+extern "C" uint32_t orc_tree_run(uint32_t nops, const int32_t *ops, const float *boxes, uint32_t *hits, uint32_t max_hits, uint8_t *moved) {
+    DynTree tree;
+    std::vector<uint32_t> id_of;
+    uint32_t nh = 0;
+    for (uint32_t i = 0; i < nops; ++i) {
+        aabb box{v3(boxes + 6 * i), v3(boxes + 6 * i + 3)};
+        int op = ops[2 * i], hnd = ops[2 * i + 1];
+        moved[i] = 0;
+        if (op == 0) {
+            if ((size_t)hnd >= id_of.size()) id_of.resize(hnd + 1, DynTree::NIL);
+            id_of[hnd] = tree.create(box, (uint32_t)hnd);
+        } else if (op == 1) {
+            moved[i] = tree.move(id_of[hnd], box) ? 1 : 0;
+        } else if (op == 2) {
+            tree.destroy(id_of[hnd]);
+            id_of[hnd] = DynTree::NIL;
+        } else {
+            tree.query(box, [&](uint32_t id) { if (nh < max_hits) hits[nh++] = tree.payload(id); });
+            if (nh < max_hits) hits[nh++] = 0xFFFFFFFFu;
+        }
+    }
+    return nh;
+}
+extern "C" void orc_friction_solve(const float *nd, const float *fd, float *delta, int warm, int sweeps, float *out) {
+    Row r;
+    for (int i = 0; i < 4; ++i) r.J[i] = v3(nd + 3 * i);
+    r.inv_mA = nd[12]; r.inv_mB = nd[13];
+    for (int k = 0; k < 3; ++k) { r.inv_IA.row[k] = v3(nd + 14 + 3 * k); r.inv_IB.row[k] = v3(nd + 23 + 3 * k); }
+    r.impulse = nd[32];
+    vec3 d[4] = {v3(delta), v3(delta + 3), v3(delta + 6), v3(delta + 9)};
+    r.dvA = &d[0]; r.dwA = &d[1]; r.dvB = &d[2]; r.dwB = &d[3];
+    FrictionRow f;
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < 4; ++i) f.row[k].J[i] = v3(fd + 15 * k + 3 * i);
+        f.row[k].eff_mass = fd[15 * k + 12]; f.row[k].rhs = fd[15 * k + 13]; f.row[k].impulse = fd[15 * k + 14];
+    }
+    f.mu = fd[30];
+    f.normal_row = 0;
+    if (warm) warm_start_friction(f, r);
+    for (int s = 0; s < sweeps; ++s) solve_friction(f, r);
+    out[0] = f.row[0].impulse; out[1] = f.row[1].impulse;
+    for (int i = 0; i < 4; ++i) put3(delta + 3 * i, d[i]);
 }

@@ -35,7 +35,10 @@ namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
 enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1 };
-enum solver_order : int { ORDER_SEQUENTIAL = 0, ORDER_COLOURED = 1 };
+// ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
+// ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
+// EnTT pool history), exported by oracle/ref_world.cpp. With it the restatement and the reference agree bit for bit.
+enum solver_order : int { ORDER_SEQUENTIAL = 0, ORDER_COLOURED = 1, ORDER_EXTERNAL = 2 };
 constexpr uint32_t kNoColour = 0xFFu;
 constexpr uint32_t kMaxColours = 64;
 
@@ -181,6 +184,9 @@ public:
     int vel_iters = 8, pos_iters = 3;   // context/settings.hpp:22-30 defaults
     vec3 gravity{0, -9.8f, 0};
     int order = ORDER_SEQUENTIAL;
+    struct ExtContact { uint32_t a, b, slot; };
+    std::vector<ExtContact> ext_contact_order;   // ORDER_EXTERNAL: every active contact point, in the reference's visiting order
+    std::vector<uint32_t> ext_joint_order;       // ORDER_EXTERNAL: joint indices, in the reference's visiting order
     std::vector<Body> bodies;
     std::vector<Joint> joints;
     std::map<uint64_t, Manifold> manifolds;
@@ -770,7 +776,7 @@ public:
         // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
         for (auto &b : bodies)   // apply_gravity.hpp:12-17
             if (b.kind == KIND_DYNAMIC && !b.asleep && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
-        if (order == ORDER_SEQUENTIAL) solve_sequential(); else solve_coloured();
+        if (order == ORDER_COLOURED) solve_coloured(); else solve_sequential();
         for (auto &b : bodies) {   // update_aabbs (dynamic + kinematic), update_inertias (dynamic)
             if (b.asleep) continue;   // update_aabbs / update_inertias views exclude sleeping entities
             if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.pos, b.orn);
@@ -803,6 +809,28 @@ public:
             std::vector<std::pair<Joint *, int>> jrows;       // joint, first row
             std::vector<std::pair<ContactPoint *, uint32_t>> crows;   // point, normal row index
             auto &js = isl_j[label];
+            // (manifold, slot) pairs in visiting order: list order of the canonical manifold sequence, or the caller's order
+            std::vector<std::pair<Manifold *, int>> cps;
+            if (order == ORDER_EXTERNAL) {
+                std::vector<Joint *> ordered;
+                for (uint32_t ji : ext_joint_order) {
+                    Joint *j = &joints[ji];
+                    if (label_of(j->body[0], j->body[1]) == label) ordered.push_back(j);
+                }
+                if (ordered.size() != js.size()) ext_order_mismatch = true;
+                js = ordered;
+                for (const ExtContact &e : ext_contact_order) {
+                    if (label_of(e.a, e.b) != label) continue;
+                    auto it = manifolds.find(pair_key(e.a, e.b));
+                    if (it == manifolds.end() || (int)e.slot >= it->second.num_points) { ext_order_mismatch = true; continue; }
+                    cps.push_back({&it->second, (int)e.slot});
+                }
+                size_t expect = 0;
+                for (Manifold *m : isl_m[label]) expect += (size_t)m->num_points;
+                if (expect != cps.size()) ext_order_mismatch = true;
+            } else {
+                for (Manifold *m : isl_m[label]) for (int i = 0; i < m->num_points; ++i) cps.push_back({m, i});
+            }
             for (int type : {JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: hinge ... point, contact
                 for (Joint *j : js) {
                     if (j->type != type) continue;
@@ -811,16 +839,15 @@ public:
                     jrows.push_back({j, (int)rows.size()});
                     for (int i = 0; i < n; ++i) rows.push_back(tmp[i]);
                 }
-            for (Manifold *m : isl_m[label]) {
+            for (auto &cp : cps) {
+                Manifold *m = cp.first;
                 BodyRef A = body_ref(m->body[0]), B = body_ref(m->body[1]);
-                for (int i = 0; i < m->num_points; ++i) {
-                    Row nr; FrictionRow fr;
-                    prepare_contact(m->pt[i], A, B, nr, fr);
-                    fr.normal_row = (uint32_t)rows.size();
-                    crows.push_back({&m->pt[i], fr.normal_row});
-                    rows.push_back(nr);
-                    fric.push_back(fr);
-                }
+                Row nr; FrictionRow fr;
+                prepare_contact(m->pt[cp.second], A, B, nr, fr);
+                fr.normal_row = (uint32_t)rows.size();
+                crows.push_back({&m->pt[cp.second], fr.normal_row});
+                rows.push_back(nr);
+                fric.push_back(fr);
             }
             stats.num_rows += (uint32_t)rows.size();
             for (auto &r : rows) apply_row_impulse(r.impulse, r);                 // warm start
@@ -842,7 +869,7 @@ public:
             for (int it = 0; it < pos_iters; ++it) {
                 PosSolver hs, cs;
                 for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
-                for (Manifold *m : isl_m[label]) for (int i = 0; i < m->num_points; ++i) contact_solve_position(*m, m->pt[i], cs);
+                for (auto &cp : cps) contact_solve_position(*cp.first, cp.first->pt[cp.second], cs);
                 if (std::max(hs.max_error, cs.max_error) < 0.005f) break;
             }
         }
@@ -917,6 +944,7 @@ public:
     }
 
     bool colour_overflow() const { return colour_overflow_; }
+    bool ext_order_mismatch = false;   // ORDER_EXTERNAL: the supplied order did not cover exactly this step's constraints
 
 private:
     DynTree tree_, np_tree_;

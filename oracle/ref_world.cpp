@@ -1,0 +1,363 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// C ABI over the REAL reference engine: the reference's own translation units (src/edyn/**, everything
+// except networking/ and serialization/) are compiled where they lie under /root/reference against
+// oracle/entt_min (a from-scratch implementation of the EnTT subset the reference uses — EnTT itself is
+// not in this image) and linked with this driver into oracle/_ref/libedynref.so by `make ref`.
+// The driver only calls the reference's public API (edyn::attach / make_rigidbody / make_constraint /
+// step_simulation, include/edyn/edyn.hpp:66-150, util/rigidbody.hpp:84-93, util/constraint_util.hpp:38-54)
+// and reads components back. Used by tests/ as the checker for the restatement (liboracle.so) and by
+// bench.py's cpu_baseline leg (kind "reference"); never by the product path.
+// Nothing from /root/reference is copied into this repository.
+#include <edyn/edyn.hpp>
+#include <edyn/collision/contact_manifold.hpp>
+#include <edyn/util/contact_manifold_util.hpp>
+#include <edyn/collision/contact_point.hpp>
+#include <edyn/comp/aabb.hpp>
+#include <edyn/comp/inertia.hpp>
+#include <edyn/comp/island.hpp>
+#include <edyn/comp/tag.hpp>
+#include <edyn/config/solver_iteration_config.hpp>
+#include <edyn/constraints/contact_constraint.hpp>
+#include <edyn/constraints/hinge_constraint.hpp>
+#include <edyn/constraints/point_constraint.hpp>
+#include <edyn/util/constraint_util.hpp>
+#include <edyn/util/exclude_collision.hpp>
+#include <edyn/util/gravity_util.hpp>
+#include <edyn/util/rigidbody.hpp>
+#include <entt/entity/registry.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// Same record layout as oracle_capi.cpp / include/edynhip.h (one numpy dtype describes all three).
+struct point_rec {
+    float pivotA[3], pivotB[3], normal[3], local_normal[3];
+    float distance, friction, restitution;
+    int32_t attachment;
+    uint32_t lifetime;
+    float normal_impulse, friction_impulse[2];
+};
+struct manifold_rec {
+    uint32_t body[2];
+    uint32_t num_points;
+    uint32_t colour;
+    point_rec pt[4];
+};
+
+struct ref_world {
+    entt::registry registry;
+    std::vector<entt::entity> bodies;
+    std::unordered_map<uint32_t, uint32_t> index_of;   // entity id -> body index
+    std::vector<entt::entity> joints;
+    double time = 0;
+    float dt = 1.0f / 60;
+    bool attached = false;
+    ~ref_world() { if (attached) edyn::detach(registry); }
+};
+
+edyn::vector3 v3(const float *p) { return {p[0], p[1], p[2]}; }
+void put3(float *d, const edyn::vector3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+}  // namespace
+
+extern "C" {
+
+// mode: 0 = execution_mode::sequential, 1 = sequential_multithreaded (num_workers 0 = hardware_concurrency - 1).
+void *refw_create(int mode, int num_workers, float dt, int vel_iters, int pos_iters, const float *g) {
+    auto *w = new ref_world();
+    edyn::init_config cfg;
+    cfg.execution_mode = mode == 0 ? edyn::execution_mode::sequential : edyn::execution_mode::sequential_multithreaded;
+    cfg.num_worker_threads = (size_t)num_workers;
+    cfg.fixed_dt = dt;
+    cfg.timestamp = 0.0;
+    edyn::attach(w->registry, cfg);
+    w->attached = true;
+    w->dt = dt;
+    edyn::set_solver_velocity_iterations(w->registry, (unsigned)vel_iters);
+    edyn::set_solver_position_iterations(w->registry, (unsigned)pos_iters);
+    edyn::set_gravity(w->registry, v3(g));
+    edyn::set_paused(w->registry, true);
+    return w;
+}
+void refw_destroy(void *h) { delete (ref_world *)h; }
+
+void refw_set_restitution_iterations(void *h, int iters, int individual_iters) {
+    auto *w = (ref_world *)h;
+    edyn::set_solver_restitution_iterations(w->registry, (unsigned)iters);
+    edyn::set_solver_individual_restitution_iterations(w->registry, (unsigned)individual_iters);
+}
+
+// shape_type: 0 none, 1 box (half extents), 2 sphere (radius), 3 plane (normal, constant) — edyn_amd.scenes' encoding.
+uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, const float *linvel, const float *angvel,
+                       float mass, int shape_type, const float *sp, const float *inertia9, float friction,
+                       float restitution, int has_material, uint64_t group, uint64_t mask, const float *grav,
+                       int sleeping_disabled) {
+    auto *w = (ref_world *)h;
+    edyn::rigidbody_def def;
+    def.kind = kind == 0 ? edyn::rigidbody_kind::rb_dynamic : kind == 1 ? edyn::rigidbody_kind::rb_kinematic : edyn::rigidbody_kind::rb_static;
+    def.position = v3(pos);
+    def.orientation = edyn::quaternion{orn[0], orn[1], orn[2], orn[3]};
+    def.linvel = v3(linvel);
+    def.angvel = v3(angvel);
+    def.mass = mass;
+    if (shape_type == 1) def.shape = edyn::box_shape{v3(sp)};
+    else if (shape_type == 2) def.shape = edyn::sphere_shape{sp[0]};
+    else if (shape_type == 3) def.shape = edyn::plane_shape{v3(sp), sp[3]};
+    if (inertia9) {
+        def.inertia = edyn::matrix3x3{{edyn::vector3{inertia9[0], inertia9[1], inertia9[2]},
+                                       edyn::vector3{inertia9[3], inertia9[4], inertia9[5]},
+                                       edyn::vector3{inertia9[6], inertia9[7], inertia9[8]}}};
+    }
+    if (has_material) {
+        edyn::material m;
+        m.friction = friction;
+        m.restitution = restitution;
+        def.material = m;
+    } else {
+        def.material.reset();
+    }
+    def.collision_group = group;
+    def.collision_mask = mask;
+    if (grav) def.gravity = v3(grav);
+    def.sleeping_disabled = sleeping_disabled != 0;
+    def.presentation = false;
+    auto e = edyn::make_rigidbody(w->registry, def);
+    w->index_of[entt::to_integral(e)] = (uint32_t)w->bodies.size();
+    w->bodies.push_back(e);
+    return (uint32_t)w->bodies.size() - 1;
+}
+
+// type 0 = point_constraint, 1 = hinge_constraint (set_axes(axisA, axisB)).
+uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
+                        const float *axisA, const float *axisB) {
+    auto *w = (ref_world *)h;
+    entt::entity e;
+    if (type == 0) {
+        e = edyn::make_constraint<edyn::point_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::point_constraint &c) {
+            c.pivot[0] = v3(pivotA);
+            c.pivot[1] = v3(pivotB);
+        });
+    } else {
+        e = edyn::make_constraint<edyn::hinge_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::hinge_constraint &c) {
+            c.pivot[0] = v3(pivotA);
+            c.pivot[1] = v3(pivotB);
+            c.set_axes(v3(axisA), v3(axisB));
+        });
+    }
+    w->joints.push_back(e);
+    return (uint32_t)w->joints.size() - 1;
+}
+
+// Optional rows of the joints (hinge_constraint.hpp:30-62, point_constraint.hpp:25).
+// params: angle_min, angle_max, limit_restitution, bump_stop_angle, bump_stop_stiffness, torque, speed,
+//         rest_angle, stiffness, damping  (hinge) ; friction_torque (point, params[0]).
+void refw_set_joint_params(void *h, uint32_t joint, const float *p) {
+    auto *w = (ref_world *)h;
+    auto e = w->joints[joint];
+    if (auto *hc = w->registry.try_get<edyn::hinge_constraint>(e)) {
+        hc->angle_min = p[0]; hc->angle_max = p[1]; hc->limit_restitution = p[2];
+        hc->bump_stop_angle = p[3]; hc->bump_stop_stiffness = p[4];
+        hc->torque = p[5]; hc->speed = p[6];
+        hc->rest_angle = p[7]; hc->stiffness = p[8]; hc->damping = p[9];
+        auto &ornA = w->registry.get<edyn::orientation>(hc->body[0]);
+        auto &ornB = w->registry.get<edyn::orientation>(hc->body[1]);
+        hc->reset_angle(ornA, ornB);
+    } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(e)) {
+        pc->friction_torque = p[0];
+    }
+}
+void refw_exclude_collision(void *h, uint32_t a, uint32_t b) {
+    auto *w = (ref_world *)h;
+    edyn::exclude_collision(w->registry, w->bodies[a], w->bodies[b]);
+}
+
+void refw_step(void *h, int n) {
+    auto *w = (ref_world *)h;
+    for (int i = 0; i < n; ++i) {
+        w->time += (double)w->dt;
+        edyn::step_simulation(w->registry, w->time);
+    }
+}
+double refw_time_steps(void *h, int n) {
+    auto t0 = std::chrono::steady_clock::now();
+    refw_step(h, n);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+// edyn::update(registry, time) with the accumulator (stepper_sequential.cpp:28-119); returns nothing, state is read back.
+void refw_update(void *h, double time, int paused) {
+    auto *w = (ref_world *)h;
+    edyn::set_paused(w->registry, paused != 0);
+    edyn::update(w->registry, time);
+}
+void refw_set_max_steps_per_update(void *h, unsigned n) { edyn::set_max_steps_per_update(((ref_world *)h)->registry, n); }
+
+uint32_t refw_num_bodies(void *h) { return (uint32_t)((ref_world *)h)->bodies.size(); }
+void refw_get_state(void *h, float *pos, float *orn, float *linvel, float *angvel) {
+    auto *w = (ref_world *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        auto e = w->bodies[i];
+        put3(pos + 3 * i, w->registry.get<edyn::position>(e));
+        auto &q = w->registry.get<edyn::orientation>(e);
+        orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
+        // static bodies carry no velocity components (rigidbody.cpp:84-92)
+        if (auto *v = w->registry.try_get<edyn::linvel>(e)) put3(linvel + 3 * i, *v); else std::memset(linvel + 3 * i, 0, 12);
+        if (auto *v = w->registry.try_get<edyn::angvel>(e)) put3(angvel + 3 * i, *v); else std::memset(angvel + 3 * i, 0, 12);
+    }
+}
+void refw_set_state(void *h, const float *pos, const float *orn, const float *linvel, const float *angvel) {
+    auto *w = (ref_world *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        auto e = w->bodies[i];
+        static_cast<edyn::vector3 &>(w->registry.get<edyn::position>(e)) = v3(pos + 3 * i);
+        static_cast<edyn::quaternion &>(w->registry.get<edyn::orientation>(e)) = edyn::quaternion{orn[4 * i], orn[4 * i + 1], orn[4 * i + 2], orn[4 * i + 3]};
+        if (auto *v = w->registry.try_get<edyn::linvel>(e)) static_cast<edyn::vector3 &>(*v) = v3(linvel + 3 * i);
+        if (auto *v = w->registry.try_get<edyn::angvel>(e)) static_cast<edyn::vector3 &>(*v) = v3(angvel + 3 * i);
+    }
+}
+// aabb6 / inertia_world9 / island label (lowest body index among the island's nodes; own index when none) / asleep flag
+void refw_get_derived(void *h, float *aabb6, float *iw9, uint32_t *island, uint8_t *asleep) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    std::unordered_map<uint32_t, uint32_t> label;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        auto e = w->bodies[i];
+        if (aabb6) {
+            if (auto *bb = reg.try_get<edyn::AABB>(e)) { put3(aabb6 + 6 * i, bb->min); put3(aabb6 + 6 * i + 3, bb->max); }
+            else std::memset(aabb6 + 6 * i, 0, 24);
+        }
+        if (iw9) {
+            if (auto *iw = reg.try_get<edyn::inertia_world_inv>(e)) for (int r = 0; r < 3; ++r) put3(iw9 + 9 * i + 3 * r, iw->row[r]);
+            else std::memset(iw9 + 9 * i, 0, 36);
+        }
+        if (asleep) asleep[i] = reg.all_of<edyn::sleeping_tag>(e) ? 1 : 0;
+        if (island) {
+            island[i] = (uint32_t)i;
+            if (auto *res = reg.try_get<edyn::island_resident>(e); res && res->island_entity != entt::null) {
+                auto key = entt::to_integral(res->island_entity);
+                auto it = label.find(key);
+                if (it == label.end()) label.emplace(key, (uint32_t)i);   // bodies are visited in ascending index
+            }
+        }
+    }
+    if (island) {
+        for (size_t i = 0; i < w->bodies.size(); ++i) {
+            if (auto *res = reg.try_get<edyn::island_resident>(w->bodies[i]); res && res->island_entity != entt::null)
+                island[i] = label[entt::to_integral(res->island_entity)];
+        }
+    }
+}
+uint32_t refw_num_islands(void *h) {
+    auto &reg = ((ref_world *)h)->registry;
+    return (uint32_t)reg.view<edyn::island>().size();
+}
+
+uint32_t refw_num_manifolds(void *h) {
+    auto &reg = ((ref_world *)h)->registry;
+    return (uint32_t)reg.view<edyn::contact_manifold>().size();
+}
+// Manifolds sorted by canonical unordered pair (max body index << 32 | min); points in the manifold's list order.
+void refw_get_manifolds(void *h, manifold_rec *out) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    std::vector<std::pair<uint64_t, entt::entity>> order;
+    for (auto [e, m] : reg.view<edyn::contact_manifold>().each()) {
+        uint64_t a = w->index_of.at(entt::to_integral(m.body[0])), b = w->index_of.at(entt::to_integral(m.body[1]));
+        order.emplace_back((std::max(a, b) << 32) | std::min(a, b), e);
+    }
+    std::sort(order.begin(), order.end());
+    size_t k = 0;
+    for (auto &[key, e] : order) {
+        auto &m = reg.get<edyn::contact_manifold>(e);
+        manifold_rec &r = out[k++];
+        std::memset(&r, 0, sizeof(r));
+        r.body[0] = w->index_of.at(entt::to_integral(m.body[0]));
+        r.body[1] = w->index_of.at(entt::to_integral(m.body[1]));
+        r.colour = 0xFFFFFFFFu;
+        uint32_t n = 0;
+        edyn::contact_manifold_each_point(reg, e, [&](entt::entity pe) {
+            if (n >= 4) return;
+            point_rec &p = r.pt[n++];
+            auto &cp = reg.get<edyn::contact_point>(pe);
+            auto &geom = reg.get<edyn::contact_point_geometry>(pe);
+            put3(p.pivotA, cp.pivotA); put3(p.pivotB, cp.pivotB); put3(p.normal, cp.normal);
+            put3(p.local_normal, geom.local_normal);
+            p.distance = geom.distance;
+            p.attachment = (int32_t)geom.normal_attachment;
+            p.lifetime = cp.lifetime;
+            if (auto *mat = reg.try_get<edyn::contact_point_material>(pe)) { p.friction = mat->friction; p.restitution = mat->restitution; }
+            if (auto *imp = reg.try_get<edyn::contact_point_impulse>(pe)) {
+                p.normal_impulse = imp->normal_impulse;
+                p.friction_impulse[0] = imp->friction_impulse[0];
+                p.friction_impulse[1] = imp->friction_impulse[1];
+            }
+        });
+        r.num_points = n;
+    }
+}
+// hinge: linear[3], hinge[2], limit, bump_stop, spring, torque, angle (10) ; point: applied[3], friction (4, rest 0)
+void refw_get_joint_impulses(void *h, float *out10) {
+    auto *w = (ref_world *)h;
+    for (size_t i = 0; i < w->joints.size(); ++i) {
+        float *o = out10 + 10 * i;
+        std::memset(o, 0, 40);
+        if (auto *hc = w->registry.try_get<edyn::hinge_constraint>(w->joints[i])) {
+            for (int k = 0; k < 3; ++k) o[k] = hc->applied_impulse.linear[k];
+            o[3] = hc->applied_impulse.hinge[0]; o[4] = hc->applied_impulse.hinge[1];
+            o[5] = hc->applied_impulse.limit; o[6] = hc->applied_impulse.bump_stop;
+            o[7] = hc->applied_impulse.spring; o[8] = hc->applied_impulse.torque; o[9] = hc->angle;
+        } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(w->joints[i])) {
+            for (int k = 0; k < 3; ++k) o[k] = pc->applied_impulse[k];
+            o[3] = pc->applied_friction_impulse;
+        }
+    }
+}
+// The order in which the last step's island solvers visited their constraints: island.edges in iteration order,
+// filtered per constraint type (island_solver.cpp:113-175 insert_rows / pack_rows). Contacts: 3 uint32 per entry
+// (body index A, body index B, slot of the point in the manifold's list order); joints: joint indices. Islands are
+// independent, so only the relative order inside an island is meaningful. Returns the number of entries written.
+uint32_t refw_get_contact_order(void *h, uint32_t *out3, uint32_t max_entries) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    uint32_t n = 0;
+    auto con_view = reg.view<edyn::contact_constraint>();
+    for (auto [ie, isl] : reg.view<edyn::island>().each()) {
+        for (auto edge : isl.edges) {
+            if (!con_view.contains(edge) || n >= max_entries) continue;
+            auto manifold_entity = reg.get<edyn::contact_point_list>(edge).parent;
+            auto &m = reg.get<edyn::contact_manifold>(manifold_entity);
+            uint32_t slot = 0, found = 0xFFFFFFFFu;
+            edyn::contact_manifold_each_point(reg, manifold_entity, [&](entt::entity pe) {
+                if (pe == edge) found = slot;
+                ++slot;
+            });
+            out3[3 * n] = w->index_of.at(entt::to_integral(m.body[0]));
+            out3[3 * n + 1] = w->index_of.at(entt::to_integral(m.body[1]));
+            out3[3 * n + 2] = found;
+            ++n;
+        }
+    }
+    return n;
+}
+uint32_t refw_get_joint_order(void *h, uint32_t *out, uint32_t max_entries) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    std::unordered_map<uint32_t, uint32_t> joint_index;
+    for (size_t i = 0; i < w->joints.size(); ++i) joint_index[entt::to_integral(w->joints[i])] = (uint32_t)i;
+    uint32_t n = 0;
+    for (auto [ie, isl] : reg.view<edyn::island>().each()) {
+        for (auto edge : isl.edges) {
+            auto it = joint_index.find(entt::to_integral(edge));
+            if (it != joint_index.end() && n < max_entries) out[n++] = it->second;
+        }
+    }
+    return n;
+}
+uint32_t refw_sizeof_manifold_rec() { return (uint32_t)sizeof(manifold_rec); }
+
+}  // extern "C"

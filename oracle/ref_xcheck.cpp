@@ -77,3 +77,108 @@ void ref_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
     put3(delta, dv[0]); put3(delta + 3, dw[0]); put3(delta + 6, dv[1]); put3(delta + 9, dw[1]);
 }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Leaves that need the EnTT-dependent translation units (built against oracle/entt_min): closest-feature
+// routines, collision_result, dynamic_tree, friction rows.
+#include <edyn/collision/collide.hpp>
+#include <edyn/collision/dynamic_tree.hpp>
+#include <edyn/constraints/constraint_row_friction.hpp>
+#include <edyn/util/aabb_util.hpp>
+#include <variant>
+#include <vector>
+
+namespace {
+using ref_shape = std::variant<std::monostate, box_shape, sphere_shape, plane_shape>;
+ref_shape make_ref_shape(int type, const float *p) {
+    if (type == 1) return box_shape{v3(p)};
+    if (type == 2) return sphere_shape{p[0]};
+    if (type == 3) return plane_shape{v3(p), p[3]};
+    return std::monostate{};
+}
+}  // namespace
+
+extern "C" {
+// Same signature as orc_collide_batch: per pair shape types st[2], shape params sp[2][4], pos[2][3], orn[2][4];
+// out per point 11 floats (pivotA, pivotB, normal, distance, normal_attachment). collide.hpp:43-330 overloads.
+void ref_collide_batch(uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
+                       float *out, uint32_t *count) {
+    for (uint32_t i = 0; i < n; ++i) {
+        auto shA = make_ref_shape(st[2 * i], sp + 8 * i), shB = make_ref_shape(st[2 * i + 1], sp + 8 * i + 4);
+        const float *pa = pos + 6 * i, *pb = pa + 3, *qa = orn + 8 * i, *qb = qa + 4;
+        collision_result result;
+        std::visit([&](auto &&a) {
+            std::visit([&](auto &&b) {
+                using A = std::decay_t<decltype(a)>;
+                using B = std::decay_t<decltype(b)>;
+                if constexpr (!std::is_same_v<A, std::monostate> && !std::is_same_v<B, std::monostate> &&
+                              !(std::is_same_v<A, plane_shape> && std::is_same_v<B, plane_shape>)) {
+                    quaternion ornA{qa[0], qa[1], qa[2], qa[3]}, ornB{qb[0], qb[1], qb[2], qb[3]};
+                    collision_context ctx{v3(pa), ornA, shape_aabb(a, v3(pa), ornA), v3(pb), ornB, shape_aabb(b, v3(pb), ornB), threshold};
+                    collide(a, b, ctx, result);
+                }
+            }, shB);
+        }, shA);
+        count[i] = (uint32_t)result.num_points;
+        for (size_t k = 0; k < result.num_points; ++k) {
+            float *o = out + (size_t)i * 44 + 11 * k;
+            put3(o, result.point[k].pivotA); put3(o + 3, result.point[k].pivotB); put3(o + 6, result.point[k].normal);
+            o[9] = result.point[k].distance; o[10] = (float)(int)result.point[k].normal_attachment;
+        }
+    }
+}
+
+// Scripted dynamic_tree session (dynamic_tree.cpp:41-339, query_tree.hpp:9-42).
+// ops: nops x {op, handle}; op 0 create(handle = payload), 1 move(handle), 2 destroy(handle), 3 query.
+// boxes: nops x 6 (min, max). hits: visited payloads in visit order, each query terminated by 0xFFFFFFFF;
+// moved[i] = move()'s return value. Returns the number of uint32 written to hits.
+uint32_t ref_tree_run(uint32_t nops, const int32_t *ops, const float *boxes, uint32_t *hits, uint32_t max_hits, uint8_t *moved) {
+    dynamic_tree tree;
+    std::vector<tree_node_id_t> id_of;
+    uint32_t nh = 0;
+    for (uint32_t i = 0; i < nops; ++i) {
+        AABB box{v3(boxes + 6 * i), v3(boxes + 6 * i + 3)};
+        int op = ops[2 * i], hnd = ops[2 * i + 1];
+        moved[i] = 0;
+        if (op == 0) {
+            if ((size_t)hnd >= id_of.size()) id_of.resize(hnd + 1, null_tree_node_id);
+            id_of[hnd] = tree.create(box, entt::entity{(uint32_t)hnd});
+        } else if (op == 1) {
+            moved[i] = tree.move(id_of[hnd], box) ? 1 : 0;
+        } else if (op == 2) {
+            tree.destroy(id_of[hnd]);
+            id_of[hnd] = null_tree_node_id;
+        } else {
+            tree.query(box, [&](tree_node_id_t id) { if (nh < max_hits) hits[nh++] = entt::to_integral(tree.get_node(id).entity); });
+            if (nh < max_hits) hits[nh++] = 0xFFFFFFFFu;
+        }
+    }
+    return nh;
+}
+
+// Friction pair against its normal row (constraint_row_friction.cpp:11-66): warm_start (optional) then `sweeps` x solve_friction.
+// normal: J[12], inv_mA, inv_mB, inv_IA[9], inv_IB[9], impulse (33) ; fric: 2 x {J[12], eff_mass, rhs, impulse} (30), mu (1)
+// delta in/out: dvA, dwA, dvB, dwB (12) ; out: the two friction impulses.
+void ref_friction_solve(const float *nd, const float *fd, float *delta, int warm, int sweeps, float *out) {
+    std::vector<constraint_row> rows(1);
+    constraint_row &r = rows[0];
+    for (int i = 0; i < 4; ++i) r.J[i] = v3(nd + 3 * i);
+    r.inv_mA = nd[12]; r.inv_mB = nd[13];
+    for (int k = 0; k < 3; ++k) { r.inv_IA.row[k] = v3(nd + 14 + 3 * k); r.inv_IB.row[k] = v3(nd + 23 + 3 * k); }
+    r.impulse = nd[32];
+    delta_linvel dv[2] = {delta_linvel{v3(delta)}, delta_linvel{v3(delta + 6)}};
+    delta_angvel dw[2] = {delta_angvel{v3(delta + 3)}, delta_angvel{v3(delta + 9)}};
+    r.dvA = &dv[0]; r.dwA = &dw[0]; r.dvB = &dv[1]; r.dwB = &dw[1];
+    constraint_row_friction f;
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < 4; ++i) f.row[k].J[i] = v3(fd + 15 * k + 3 * i);
+        f.row[k].eff_mass = fd[15 * k + 12]; f.row[k].rhs = fd[15 * k + 13]; f.row[k].impulse = fd[15 * k + 14];
+    }
+    f.friction_coefficient = fd[30];
+    f.normal_row_index = 0;
+    if (warm) warm_start(f, rows);
+    for (int s = 0; s < sweeps; ++s) solve_friction(f, rows);
+    out[0] = f.row[0].impulse; out[1] = f.row[1].impulse;
+    put3(delta, dv[0]); put3(delta + 3, dw[0]); put3(delta + 6, dv[1]); put3(delta + 9, dw[1]);
+}
+}

@@ -35,7 +35,7 @@ def build_native():
     The product library is built by __graft_entry__.build(); tests never rebuild it on the GPU box."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     if os.path.isdir("/root/reference/src/edyn") :
-        subprocess.call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        subprocess.call(["make", "-s", "-j%d" % max(2, os.cpu_count() or 2), "-C", os.path.join(ROOT, "oracle"), "ref"])
     if not os.path.exists(os.path.join(ROOT, "edyn_amd", "libedynhip.so")):
         subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "edyn_amd", "csrc")])
     yield
