@@ -161,6 +161,13 @@ class _Leaf:
         return out, d
 
 
+def set_libm_trig(on):
+    """integrate(): C library sinf/cosf (what the reference calls) instead of the correctly rounded fp32 value."""
+    f = lib().orc_set_libm_trig
+    f.argtypes = [C.c_int]; f.restype = None
+    f(int(bool(on)))
+
+
 def leaf():
     return _Leaf(lib(), "orc_")
 

@@ -99,8 +99,12 @@ inline vec3 rotate(quat q, vec3 v) {
 // sin/cos: the reference calls std::sin/std::cos on floats, whose last bit depends on the C library. Both the
 // oracle and the GPU evaluate them in double precision and round once, i.e. correctly rounded fp32 (equal to
 // glibc's sinf/cosf except in rare 1-ulp cases), so that CPU and GPU agree bit for bit over long horizons.
-inline float sin_cr(float x) { return (float)std::sin((double)x); }
-inline float cos_cr(float x) { return (float)std::cos((double)x); }
+// g_libm_trig (test switch, default off): evaluate them exactly as the reference does - std::sin/std::cos on float,
+// i.e. the C library's sinf/cosf - so that the restatement can be compared bit for bit with the real engine
+// (oracle/_ref) in scenes that spin; the default remains the library-independent, correctly rounded value.
+inline bool g_libm_trig = false;
+inline float sin_cr(float x) { return g_libm_trig ? std::sin(x) : (float)std::sin((double)x); }
+inline float cos_cr(float x) { return g_libm_trig ? std::cos(x) : (float)std::cos((double)x); }
 // quaternion.cpp:7-22 (exponential map; Taylor branch for |w| < 0.001)
 inline quat integrate(quat q, vec3 w, float dt) {
     const float ws = length(w);
