@@ -13,8 +13,12 @@ Contract (one JSON line on rank 0):
            every iteration over every colour; scenes with joints use one k_contact_solve launch per colour):
            algorithmic bytes (380 B per contact point per iteration) / time measured with HIP events
            recorded on the stepper's stream around that launch inside the timed region.
-  cpu_baseline  the CPU oracle (reference-order restatement, 1 thread) timed on a bounded sample of the
-           same scene on rank 0 at N=1. A reported baseline, not the target.
+  cpu_baseline  Edyn's own multithreaded CPU path: the REAL reference engine (oracle/_ref/libedynref.so = the reference's
+           translation units compiled where they lie, driven through edyn::attach / step_simulation in
+           execution_mode::sequential_multithreaded on all host cores) timed on a bounded sample of the same scene on rank 0
+           at N=1, in a subprocess with a wall-clock budget; next to it, in `sample`, the 1-thread restatement (oracle).
+           Falls back to the restatement (kind "port", cores 1) where oracle/_ref is not built or the budget is exceeded.
+           A reported baseline, not the target.
 """
 import argparse
 import json
@@ -47,18 +51,75 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(workload, sample_steps, warm_steps):
-    """Time the CPU oracle (reference order, single thread) on a bounded sample. Checker code, timed - never shipped."""
+def _cpu_scene(workload):
+    """The scene the CPU legs time: the workload itself, or - for the many-island scene, whose reference run would need
+    tens of GB - a block of its independent sites (steps/s then scale with the site count, stated in `sample`)."""
+    wl = WORKLOADS[workload]
+    if "shard" in wl:
+        sites = 256
+        return wl["shard"](0, sites), wl["shard_units"] / sites, f"sites 0..{sites - 1} of {wl['shard_units']} (independent islands; steps/s divided by {wl['shard_units'] // sites})"
+    return wl["gen"](), 1.0, "the whole scene"
+
+
+def cpu_reference_leg(workload, sample_steps, warm_steps):
+    """Child process (bench.py --cpu-reference-leg): time the real reference engine, multithreaded. Prints one JSON line."""
     from oracle import binding as ob
     wl = WORKLOADS[workload]
-    scene = wl["gen"]()
+    scene, scale, what = _cpu_scene(workload)
+    cores = os.cpu_count() or 1
+    r = ob.RefWorld(vel_iters=wl["vel"], pos_iters=wl["pos"], mode=1, workers=0)   # sequential_multithreaded, hardware_concurrency - 1 workers + the caller
+    r.add_bodies(scene)
+    t0 = time.perf_counter()
+    r.step(warm_steps)
+    warm_s = time.perf_counter() - t0
+    t = r.time_steps(sample_steps)
+    print(json.dumps({"value": sample_steps / t / scale, "cores": cores, "warm_s": warm_s, "what": what,
+                      "points": int(r.get_manifolds()["num_points"].sum())}))
+
+
+def cpu_baseline(workload, sample_steps, warm_steps, budget_s):
+    """CPU legs, timed on the host cores of the bench box. Checker code, timed - never shipped."""
+    import subprocess
+    from oracle import binding as ob
+    wl = WORKLOADS[workload]
+    scene, scale, what = _cpu_scene(workload)
     o = ob.World(vel_iters=wl["vel"], pos_iters=wl["pos"], order=ob.ORDER_SEQUENTIAL)
     o.add_bodies(scene)
     o.step(warm_steps)
-    t = o.time_steps(sample_steps)
-    return {"value": sample_steps / t, "unit": "steps/sec", "cores": 1, "kind": "port",
-            "sample": f"{sample_steps} steps after {warm_steps} warm-up steps of the same scene from its initial state "
-                      f"({o.get_stats()['num_points']} contact points at the end), oracle in reference (sequential) row order"}
+    port = sample_steps / o.time_steps(sample_steps) / scale
+    port_note = (f"1-thread restatement (oracle, reference row order): {port:.3f} steps/s over {sample_steps} steps after {warm_steps} "
+                 f"warm-up steps of {what} from its initial state ({o.get_stats()['num_points']} contact points at the end)")
+    ref = None
+    if ob.ref() is not None and budget_s > 0:
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-reference-leg", "--workload", workload,
+                                  "--cpu-sample-steps", str(sample_steps), "--cpu-warm-steps", str(warm_steps)],
+                                 capture_output=True, text=True, timeout=budget_s)
+            ref = json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else None
+        except (subprocess.TimeoutExpired, ValueError):
+            ref = None
+    if ref is not None:
+        return {"value": ref["value"], "unit": "steps/sec", "cores": ref["cores"], "kind": "reference",
+                "sample": f"the reference engine itself (edyn::attach, execution_mode::sequential_multithreaded, {ref['cores']} host threads): "
+                          f"{sample_steps} steps after {warm_steps} warm-up steps ({ref['warm_s']:.1f} s, they build ~{ref['points']} contact points "
+                          f"and their islands) of {ref['what']}; beside it the {port_note}"}
+    return {"value": port, "unit": "steps/sec", "cores": 1, "kind": "port",
+            "sample": port_note + "; the multithreaded reference-engine leg was unavailable (oracle/_ref not built or over its time budget)"}
+
+
+def copy_ceiling_gbs():
+    """Measured device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy, best of 5): SURVEY 8(d)'s
+    practical ceiling, reported beside the 8 TB/s spec peak."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+        best = max(best, 2.0 * n / 1e9 / (e0.elapsed_time(e1) / 1e3))
+    del a, b
+    return best
 
 
 def main():
@@ -70,8 +131,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-timing", action="store_true",
                     help="HIP events around every stage (adds stages_ms_per_step; each event idles the GPU ~6 us, so the headline\n                    value is measured without it: only the two events around the velocity solve are recorded)")
-    ap.add_argument("--cpu-sample-steps", type=int, default=16)
+    ap.add_argument("--cpu-sample-steps", type=int, default=6)
+    ap.add_argument("--cpu-warm-steps", type=int, default=2)
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock budget of the reference-engine CPU leg")
+    ap.add_argument("--cpu-reference-leg", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_reference_leg:
+        cpu_reference_leg(args.workload, args.cpu_sample_steps, args.cpu_warm_steps)
+        return
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,37 +164,37 @@ def main():
 
     wl = WORKLOADS[args.workload]
     sharded = distributed and "shard" in wl
+    from edyn_amd.parallel import shard_range, StateGather
     if sharded:
-        from edyn_amd.parallel import shard_range
         first, count = shard_range(wl["shard_units"], rank, world_size)
         scene = wl["shard"](first, count)
-        max_count = shard_range(wl["shard_units"], 0, world_size)[1]          # rank 0 holds a largest block
-        n_gather = len(wl["shard"](0, max_count)["kind"]) if count != max_count else len(scene["kind"])
+        per_site = (len(scene["kind"]) - 1) // count                          # bodies per site + the replicated static plane
+        counts = [1 + per_site * shard_range(wl["shard_units"], r, world_size)[1] for r in range(world_size)]
     else:
         scene = wl["gen"]()
-        n_gather = len(scene["kind"])
+        counts = [len(scene["kind"])] * world_size
     n_bodies = len(scene["kind"])
+    assert counts[rank] == n_bodies
     cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
                                device=device_index, timing=args.stage_timing, timing_solve=not args.stage_timing,
-                               # one stepper per GPU, its kernels and the RCCL gather serialised on one stream: the stepper owns
-                               # the device (not so when several ranks share a GPU in the functional gloo mode)
-                               exclusive_device=(backend != "gloo"))
+                               # a single-rank run owns its GPU: plain launches for the resident-grid kernels
+                               exclusive_device=not distributed)   # RCCL kernels share the GPU in multi-rank runs: cooperative launches there
     w = edyn_amd.World(cfg)
     w.set_scene(scene)
-    stream = torch.cuda.current_stream()
-    w.set_stream(stream.cuda_stream)   # stepper kernels and the RCCL gather share torch's stream => ordered
+    # The stepper, the pack kernel and the RCCL gather all run on ONE explicitly created torch stream (a non-zero
+    # handle: edynhip_set_stream(NULL) would mean "a private stream"), entered for the whole run => ordered.
+    stream = torch.cuda.Stream(device=device_index)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    w.set_stream(stream.cuda_stream)
 
-    state = torch.zeros((n_gather, 13), dtype=torch.float32, device="cuda")   # ragged shards are padded to the largest block
-    gathered = torch.empty((world_size * n_gather, 13), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu") if distributed else None
+    gath = StateGather(counts, "cuda", backend) if distributed else None   # edyn_amd.parallel: the registry write-back gather
 
     def one_step():
         w.step_simulation(1)
         if distributed:
-            w.pack_state_device(state.data_ptr())
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered.view(-1), state.view(-1))
-            else:
-                dist.all_gather_into_tensor(gathered.view(-1), state.cpu().view(-1))
+            w.pack_state_device(gath.local.data_ptr())   # same stream as the stepper and (through torch) the collective
+            gath.gather()
 
     for _ in range(args.warmup):
         one_step()
@@ -165,16 +232,23 @@ def main():
         solve_ms = tm["solve_velocity_ms"] / steps_timed
         launches = tm["solve_velocity_launches"] / max(args.steps if not distributed else 1, 1)
         alg_bytes_step = BYTES_PER_POINT_ITER * stats["num_points"] * (wl["vel"] + 1)   # +1: warm start sweep
-        achieved = (alg_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
+        # measured fabric traffic per launch: a KEPT rocprofv3 PMC profile of this command (profiles/traffic.json, keyed
+        # by workload; FETCH_SIZE/WRITE_SIZE cannot be read from inside the run) - null when no profile was kept
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                ent = tj.get(args.workload) if isinstance(tj.get(args.workload), dict) else (tj if tj.get("workload") == args.workload else None)
+                traffic = ent.get("hbm_bytes_per_launch") if ent else None
             except Exception:
                 traffic = None
+        per_launch_alg = alg_bytes_step / max(launches, 1)
+        # achieved = min(algorithmic, measured) bytes / kernel time
+        eff_bytes_step = min(alg_bytes_step, traffic * max(launches, 1)) if traffic else alg_bytes_step
+        achieved = (eff_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
+        ceiling = copy_ceiling_gbs()
+        peak = min(HBM_PEAK_GBS, ceiling) if ceiling > 0 else HBM_PEAK_GBS
         out = {
             "metric": "steps/sec (whole node), 32k-box pile, 10 SI iters; HBM GB/s in solve",
             "value": value, "unit": "steps/sec", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -184,11 +258,13 @@ def main():
                                    f"friction 0.5, restitution 0" + dist_note,
                        "bodies": n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": traffic, "traffic_source": "kept rocprofv3 PMC profile (profiles/traffic.json), not measured in this run",
+                         "peak_spec": HBM_PEAK_GBS, "frac_of_spec_peak": achieved / HBM_PEAK_GBS, "measured_copy_ceiling": ceiling,
+                         "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = min(spec 8000, measured device-copy ceiling)",
                          "kernel": ("k_contact_solve_df2 (one dataflow launch per step: warm start + every iteration over every colour; two lanes per manifold - k_contact_solve_df, one lane, on bandwidth-bound scenes)" if launches < 1.5
                                     else "k_contact_solve<WARM,PUSH> (+ _tail): one launch per colour, every iteration + warm start"),
-                         "algorithmic_bytes_per_launch": alg_bytes_step / max(launches, 1), "launches_per_step": launches,
+                         "algorithmic_bytes_per_launch": per_launch_alg, "launches_per_step": launches,
                          "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
         }
         if args.stage_timing:
@@ -196,7 +272,7 @@ def main():
                                                                          "prepare_ms", "solve_velocity_ms", "integrate_ms", "solve_position_ms",
                                                                          "finish_ms", "step_ms")}
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_steps, 4)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_steps, args.cpu_warm_steps, args.cpu_budget_s)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

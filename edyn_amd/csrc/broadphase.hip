@@ -32,6 +32,7 @@ __global__ void k_step_reset(Counters *cnt) {   // (inside edynhip_step the prev
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
         cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0;
+        cnt->unc_count = 0; cnt->df_abort = 0;   // also the sticky ones: a stand-alone run follows set_* calls or a failed step
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
     for (int k = t; k < 4 * (int)kMaxColours; k += 64) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }

@@ -342,13 +342,20 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     if (mask == EDYNHIP_STAGE_ALL) EH_TRY(begin_timed_step(c));
     else c->force_islands = true;   // partial runs (tests) never rely on a previous step's labels
     auto rec = [&](int i) { if (c->timer.e && ((c->timer.mask >> i) & 1u)) (void)hipEventRecord(c->timer.e[i], c->stream); };
+    // A stage that fails (capacity, colour limit, device-side invariant) leaves the step half done: k_finish did not run, so
+    // nothing pre-cleared the next step's scratch and the island labels are stale. The next call must start from the
+    // stand-alone path (memsets + k_step_reset, which also clears the sticky error counters) and relabel the islands.
+    auto guarded = [&](int rc) {
+        if (rc != EDYNHIP_OK) { c->clears_primed = false; c->full_step = false; c->force_islands = true; c->timer.e = nullptr; }
+        return rc;
+    };
     rec(0);
-    if (mask & EDYNHIP_STAGE_BROADPHASE) EH_TRY(broadphase(c));
+    if (mask & EDYNHIP_STAGE_BROADPHASE) EH_TRY(guarded(broadphase(c)));
     rec(1);
-    if (mask & EDYNHIP_STAGE_NARROWPHASE) EH_TRY(narrowphase(c));
+    if (mask & EDYNHIP_STAGE_NARROWPHASE) EH_TRY(guarded(narrowphase(c)));
     rec(2);
-    if (mask & EDYNHIP_STAGE_ISLANDS) EH_TRY(islands(c));
-    if (mask & EDYNHIP_STAGE_SOLVE) EH_TRY(solve(c));   // records events 3..9
+    if (mask & EDYNHIP_STAGE_ISLANDS) EH_TRY(guarded(islands(c)));
+    if (mask & EDYNHIP_STAGE_SOLVE) EH_TRY(guarded(solve(c)));   // records events 3..9
     rec(10);
     c->clears_primed = (mask & EDYNHIP_STAGE_SOLVE) != 0;   // k_finish left the next step's scratch cleared
     if (c->timer.e) { c->timer.recorded += 1; c->timer.e = nullptr; }
@@ -476,7 +483,16 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
                  ? EDYNHIP_OK : set_error(c, EDYNHIP_ERR_HIP, "upload broadphase lists");
     (void)hipStreamSynchronize(c->stream);
     for (void *p : tmp) (void)hipFree(p);
-    if (first == 0) c->num_manifolds = 0;   // appended bodies keep every index stable, so existing manifolds stay valid
+    if (first == 0) {   // a new world: no manifolds, no running sleep timers (appended bodies keep every index stable instead)
+        c->num_manifolds = 0;
+        c->prev_num_manifolds = 0;
+        c->step_index = 0;
+        c->num_colours = 0;
+        (void)hipMemsetAsync(c->sleep_since, 0xFF, (size_t)c->b.cap * sizeof(int32_t), c->stream);
+        (void)hipMemsetAsync(c->sleep_state, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
     c->force_islands = true;
     c->all_asleep = false;
     c->clears_primed = false;
@@ -652,6 +668,12 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     return EDYNHIP_OK;
 }
 
+int edynhip_refresh_derived(edynhip_ctx *c) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    return refresh_derived(c);
+}
+
 __global__ void k_wake_all(uint32_t n, uint32_t *flags, int32_t *since) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -680,7 +702,7 @@ int edynhip_get_asleep(edynhip_ctx *c, uint8_t *asleep) {
 }
 
 int edynhip_pack_state_device(edynhip_ctx *c, void *dst, uint32_t first, uint32_t count) {
-    if (!c || !dst || first + count > c->b.n) return EDYNHIP_ERR_INVALID;
+    if (!c || !dst || (uint64_t)first + count > c->b.n) return EDYNHIP_ERR_INVALID;
     if (count == 0) return EDYNHIP_OK;
     hipLaunchKernelGGL(k_pack_state, dim3((count + 255) / 256), dim3(256), 0, c->stream, first, count, c->b, (float *)dst);
     EH_HIP(c, hipGetLastError());
@@ -732,6 +754,9 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     if (!c || (n && !in)) return EDYNHIP_ERR_INVALID;
     if (n > c->m[c->cur].cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_set_manifolds: n > max_manifolds");
     EH_HIP(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (in[i].body[0] >= c->b.n || in[i].body[1] >= c->b.n || in[i].num_points > (uint32_t)kMaxPts)
+            return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_manifolds: body index or point count out of range");
     // records must arrive in ascending canonical key order (the order edynhip_get_manifolds returns)
     for (uint32_t i = 1; i < n; ++i) {
         auto key = [&](const edynhip_manifold &m) -> uint64_t {

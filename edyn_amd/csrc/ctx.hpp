@@ -242,6 +242,7 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
                   float *out, uint32_t *count);
 int islands(edynhip_ctx *c);
 int solve(edynhip_ctx *c);
+int refresh_derived(edynhip_ctx *c);   // AABBs + world inertias from the current transforms (solver.hip)
 // sort helpers (sort.hip)
 size_t sort_temp_bytes(uint32_t max_items);
 int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit);

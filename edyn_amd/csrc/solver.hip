@@ -1514,20 +1514,8 @@ __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
 }
 
 // ------------------------------------------------------------------ derived state
-__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
-        const int t = threadIdx.x;
-        if (t == 0) {
-            cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0;
-        }
-        if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
-        for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
-    }
-    if (i >= n) return;
-    // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
-    used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
+// update_aabbs (update_aabbs.cpp:53-78 -> aabb_util.cpp:42-70) and update_inertias (update_inertias.cpp:12-24) of one body.
+__device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
     const uint32_t fl = b.flags[i];
     const uint32_t kind = fl & BF_KIND_MASK;
     if (kind == EDYNHIP_KIND_STATIC || (fl & BF_ASLEEP)) return;   // update_aabbs / update_inertias exclude sleeping bodies
@@ -1559,6 +1547,32 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
         const m3 iw = mul(mul(basis, il), transpose(basis));
         B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
     }
+}
+__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
+        const int t = threadIdx.x;
+        if (t == 0) {
+            cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0;
+        }
+        if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
+        for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
+    }
+    if (i >= n) return;
+    // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
+    used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
+    derive_body(b, i);
+}
+__global__ void k_refresh_derived(uint32_t n, Bodies b) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) derive_body(b, i);
+}
+int refresh_derived(edynhip_ctx *c) {
+    if (c->b.n == 0) return EDYNHIP_OK;
+    hipLaunchKernelGGL(k_refresh_derived, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
 }
 
 // ------------------------------------------------------------------ host orchestration

@@ -35,5 +35,32 @@ def gather_state(local_state: torch.Tensor, counts):
     return torch.cat([out[r * nmax: r * nmax + counts[r]] for r in range(world_size)], 0)
 
 
+class StateGather:
+    """The per-step state gather with persistent buffers (no allocation inside the timed loop): every rank contributes
+    its [n_r, 13] block, ragged blocks padded to the largest; `gather()` returns the [world, nmax, 13] buffer, rows beyond
+    counts[r] of block r are padding. On ROCm the "nccl" backend is RCCL (device buffers); "gloo" stages through the host."""
+
+    def __init__(self, counts, device, backend):
+        self.counts = [int(c) for c in counts]
+        self.world = len(self.counts)
+        self.nmax = max(self.counts)
+        self.backend = backend
+        self.local = torch.zeros((self.nmax, 13), dtype=torch.float32, device=device)
+        self.out = torch.empty((self.world, self.nmax, 13), dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+
+    def gather(self):
+        """`self.local` holds this rank's packed state (rows beyond its count stay zero)."""
+        if self.world == 1 or not dist.is_initialized():
+            self.out[0].copy_(self.local)
+            return self.out
+        src = self.local if self.backend == "nccl" else self.local.cpu()
+        dist.all_gather_into_tensor(self.out.view(-1), src.view(-1))
+        return self.out
+
+    def split(self):
+        """Per-rank [n_r, 13] views of the last gather."""
+        return [self.out[r, : self.counts[r]] for r in range(self.world)]
+
+
 def pack_state(pos, orn, linvel, angvel):
     return np.concatenate([pos, orn, linvel, angvel], axis=1).astype(np.float32)

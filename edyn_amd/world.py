@@ -265,6 +265,10 @@ class World:
         arrs = [np.ascontiguousarray(x, np.float32).reshape(n, w) for x, w in ((pos, 3), (orn, 4), (lv, 3), (av, 3))]
         self._check(self._L.edynhip_set_state(self._h, *[_ptr(x) for x in arrs]))
 
+    def refresh_derived(self):
+        """update_aabbs + update_inertias from the current transforms (after set_state)."""
+        self._check(self._L.edynhip_refresh_derived(self._h))
+
     def pack_state_device(self, dst_ptr, first=0, count=None):
         self._check(self._L.edynhip_pack_state_device(self._h, C.c_void_p(dst_ptr), first, self.n if count is None else count))
 

@@ -168,6 +168,11 @@ int edynhip_synchronize(edynhip_ctx *ctx);
 
 int edynhip_get_state(edynhip_ctx *ctx, float *pos, float *orn, float *linvel, float *angvel);
 int edynhip_set_state(edynhip_ctx *ctx, const float *pos, const float *orn, const float *linvel, const float *angvel);
+/* Recompute every awake body's AABB and world-space inverse inertia from its current transform: the reference's public
+ * update_aabbs(registry) / update_inertias(registry) (include/edyn/sys/update_aabbs.hpp:18-25, update_inertias.hpp:18-28).
+ * A step does this at its end (solver.cpp:456-465); after edynhip_set_state the derived state is stale until then -
+ * exactly as in the reference, where the broadphase of the next step still sees the old AABB - unless this is called. */
+int edynhip_refresh_derived(edynhip_ctx *ctx);
 /* Pack (pos3, orn4, linvel3, angvel3) = 13 floats per body into DEVICE memory `dst` (for RCCL gathers). */
 int edynhip_pack_state_device(edynhip_ctx *ctx, void *dst_device, uint32_t first_body, uint32_t count);
 /* Derived per-body state: aabb[n][6] (min,max), inertia_world_inv[n][9], island label[n]; any may be NULL. */

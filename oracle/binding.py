@@ -288,6 +288,11 @@ class World:
         n = self.num_bodies
         self.L.orc_set_state(self.h, _fp(_f32(pos, 3 * n)), _fp(_f32(orn, 4 * n)), _fp(_f32(lv, 3 * n)), _fp(_f32(av, 3 * n)))
 
+    def refresh_derived(self):
+        f = self.L.orc_refresh_derived
+        f.argtypes = [C.c_void_p]; f.restype = None
+        f(self.h)
+
     def get_derived(self):
         n = self.num_bodies
         aabb = np.zeros((n, 6), np.float32); iw = np.zeros((n, 9), np.float32); isl = np.zeros(n, np.uint32)

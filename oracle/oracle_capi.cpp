@@ -105,6 +105,7 @@ void orc_set_state(void *h, const float *pos, const float *orn, const float *lin
         b.linvel = v3(linvel + 3 * i); b.angvel = v3(angvel + 3 * i);
     }
 }
+void orc_refresh_derived(void *h) { ((World *)h)->refresh_derived(); }
 void orc_get_derived(void *h, float *aabb6, float *inertia_world9, uint32_t *island) {
     World *w = (World *)h;
     for (size_t i = 0; i < w->bodies.size(); ++i) {

@@ -771,13 +771,8 @@ public:
         b.dv = {0, 0, 0}; b.dw = {0, 0, 0};
     }
 
-    void solve() {
-        dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
-        // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
-        for (auto &b : bodies)   // apply_gravity.hpp:12-17
-            if (b.kind == KIND_DYNAMIC && !b.asleep && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
-        if (order == ORDER_COLOURED) solve_coloured(); else solve_sequential();
-        for (auto &b : bodies) {   // update_aabbs (dynamic + kinematic), update_inertias (dynamic)
+    void refresh_derived() {   // update_aabbs (dynamic + kinematic, update_aabbs.cpp:53-78), update_inertias (dynamic, update_inertias.cpp:12-24)
+        for (auto &b : bodies) {
             if (b.asleep) continue;   // update_aabbs / update_inertias views exclude sleeping entities
             if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.pos, b.orn);
             if (b.kind == KIND_DYNAMIC) {
@@ -785,6 +780,15 @@ public:
                 b.I_inv_world = basis * b.I_inv * transpose(basis);
             }
         }
+    }
+
+    void solve() {
+        dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
+        // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
+        for (auto &b : bodies)   // apply_gravity.hpp:12-17
+            if (b.kind == KIND_DYNAMIC && !b.asleep && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
+        if (order == ORDER_COLOURED) solve_coloured(); else solve_sequential();
+        refresh_derived();
         uint32_t np = 0;
         for (auto &kv : manifolds) np += kv.second.num_points;
         stats.num_manifolds = (uint32_t)manifolds.size();
