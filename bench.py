@@ -247,8 +247,11 @@ def main():
         # achieved = min(algorithmic, measured) bytes / kernel time
         eff_bytes_step = min(alg_bytes_step, traffic * max(launches, 1)) if traffic else alg_bytes_step
         achieved = (eff_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
+        # The denominator stays the 8 TB/s spec peak: the measured device-to-device copy rate (reported beside it) is NOT a
+        # ceiling for this read-dominated kernel - on the many-island scene the solve streams rows faster than a copy moves
+        # bytes (a copy alternates reads and writes on every channel), which would put the fraction above 1.
         ceiling = copy_ceiling_gbs()
-        peak = min(HBM_PEAK_GBS, ceiling) if ceiling > 0 else HBM_PEAK_GBS
+        peak = HBM_PEAK_GBS
         out = {
             "metric": "steps/sec (whole node), 32k-box pile, 10 SI iters; HBM GB/s in solve",
             "value": value, "unit": "steps/sec", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -260,8 +263,8 @@ def main():
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": "kept rocprofv3 PMC profile (profiles/traffic.json), not measured in this run",
-                         "peak_spec": HBM_PEAK_GBS, "frac_of_spec_peak": achieved / HBM_PEAK_GBS, "measured_copy_ceiling": ceiling,
-                         "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = min(spec 8000, measured device-copy ceiling)",
+                         "measured_copy_ceiling": ceiling, "frac_of_measured_copy_ceiling": achieved / ceiling if ceiling > 0 else None,
+                         "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = HBM3E spec; the measured device-to-device copy rate (read + write bytes) is reported beside it",
                          "kernel": ("k_contact_solve_df2 (one dataflow launch per step: warm start + every iteration over every colour; two lanes per manifold - k_contact_solve_df, one lane, on bandwidth-bound scenes)" if launches < 1.5
                                     else "k_contact_solve<WARM,PUSH> (+ _tail): one launch per colour, every iteration + warm start"),
                          "algorithmic_bytes_per_launch": per_launch_alg, "launches_per_step": launches,

@@ -64,7 +64,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all",
-           "edynhip_refresh_derived"]
+           "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion"]
 
 _lib = None
 
@@ -102,6 +102,8 @@ def lib():
         L.edynhip_get_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_wake_all.argtypes = [C.c_void_p]
         L.edynhip_refresh_derived.argtypes = [C.c_void_p]
+        L.edynhip_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.edynhip_remove_collision_exclusion.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L
     return _lib

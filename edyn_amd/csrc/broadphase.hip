@@ -184,8 +184,24 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
 }
 
 DI box3 body_box(const float4 *amin, const float4 *amax, uint32_t b) { return {from4(amin[b]), from4(amax[b])}; }
-DI bool filter_ok(const uint64_t *group, const uint64_t *mask, uint32_t a, uint32_t b) {   // should_collide.cpp:23-57
-    return (group[a] & mask[b]) != 0 && (group[b] & mask[a]) != 0;
+// should_collide_default (should_collide.cpp:23-57): group/mask bits both ways, minus the explicit exclusion lists
+// (collision_exclusion: <= 16 entities per body, comp/collision_exclusion.hpp:16-31). It gates the CREATION of a manifold
+// only (broadphase.cpp:145,165); an existing manifold lives until its AABBs separate.
+constexpr uint32_t kMaxExclusions = 16;
+struct Filt { const uint64_t *group, *mask; const uint32_t *excl; };   // excl: [body][16], ~0u-terminated, or nullptr (no lists)
+DI bool excluded_one_way(const uint32_t *excl, uint32_t a, uint32_t b) {
+    const uint32_t *l = excl + (size_t)a * kMaxExclusions;
+    for (uint32_t k = 0; k < kMaxExclusions; ++k) {
+        const uint32_t e = l[k];
+        if (e == 0xFFFFFFFFu) break;
+        if (e == b) return true;
+    }
+    return false;
+}
+DI bool filter_ok(const Filt &f, uint32_t a, uint32_t b) {
+    if ((f.group[a] & f.mask[b]) == 0 || (f.group[b] & f.mask[a]) == 0) return false;
+    if (f.excl && (excluded_one_way(f.excl, a, b) || excluded_one_way(f.excl, b, a))) return false;
+    return true;
 }
 // Previous-step manifold of the canonical pair (hi, lo), or ~0u. The previous array is sorted by (hi, lo), so
 // the candidates are the short contiguous run of manifolds whose higher body is `hi`.
@@ -210,8 +226,8 @@ DI void emit_pair(uint64_t skey, Emit &e) {
     if (g < e.cap) e.extra[g] = skey; else e.cnt->pair_overflow = 1;
 }
 // Decide whether the pair {i (procedural, the querying body = owner), j} is in this step's set.
-DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
-                      const uint64_t *mask, bool j_procedural, const Manifolds &prev, uint32_t pm, Emit &em) {
+DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const Filt &f,
+                      bool j_procedural, const Manifolds &prev, uint32_t pm, Emit &em) {
     const uint64_t key = ((uint64_t)i << 32) | j;
     const box3 bj = body_box(amin, amax, j);
     uint32_t pidx = find_prev(prev, pm, i, j);
@@ -222,7 +238,7 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
         if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, em);
         return;
     }
-    if (!filter_ok(group, mask, i, j)) return;
+    if (!filter_ok(f, i, j)) return;
     // collide_tree, broadphase.cpp:136-155: querying body's box grown by 0.02 vs the other's true box.
     // Bodies are visited in descending index order, so the higher index (= i here) gets to create the pair first.
     if (j_procedural) {
@@ -236,10 +252,10 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
 // A sleeping body does not query (broadphase.cpp:101,183 views exclude sleeping_tag), so an awake body i that touches a
 // sleeping body j with a HIGHER index has to report the pair itself although j is its owner. Such pairs are new contacts
 // onto a sleeping island - rare events - and take the unsorted `extra` path (j re-emits its existing manifolds itself).
-DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const uint64_t *group,
-                                const uint64_t *mask, const Manifolds &prev, uint32_t pm, Emit &em) {
+DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin, const float4 *amax, const Filt &f,
+                                const Manifolds &prev, uint32_t pm, Emit &em) {
     if (find_prev(prev, pm, j, i) != 0xFFFFFFFFu) return;
-    if (!filter_ok(group, mask, i, j)) return;
+    if (!filter_ok(f, i, j)) return;
     const box3 bj = body_box(amin, amax, j);
     if (!intersect(inset(bi, -kBreaking), bj)) return;
     const uint64_t skey = (((((uint64_t)j << 32) | i) << 1) | 1u);   // body[0] = i, the querying body
@@ -253,8 +269,8 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(128)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
-           const float4 *__restrict__ amin, const float4 *__restrict__ amax, const uint64_t *__restrict__ group,
-           const uint64_t *__restrict__ mask, const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
+           const float4 *__restrict__ amin, const float4 *__restrict__ amax, Filt f,
+           const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
            uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit,
            const uint32_t *__restrict__ flags, bool sleeping) {
     __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
@@ -291,9 +307,9 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
                 const uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
                 if (j < i) {
                     if (nc < kCandCap) cand[nc++][tx] = j;
-                    else consider_pair(i, j, bi, amin, amax, group, mask, true, prev, pm, em);   // rare overflow path
+                    else consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);   // rare overflow path
                 } else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) {
-                    consider_sleeping_owner(i, j, bi, amin, amax, group, mask, prev, pm, em);
+                    consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
                 }
             } else if (sp <= 46) {
                 stk[sp++][tx] = __float_as_uint(lo4.w);
@@ -303,11 +319,11 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
             }
         }
     }
-    for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, group, mask, true, prev, pm, em);
+    for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, f, true, prev, pm, em);
     for (uint32_t t = 0; t < num_np; ++t) {
         uint32_t j = np_list[t];
         box3 bj = body_box(amin, amax, j);
-        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, group, mask, false, prev, pm, em);
+        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, f, false, prev, pm, em);
     }
     // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
     for (int a = 1; a < em.n; ++a) {
@@ -402,7 +418,7 @@ int broadphase(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         }
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, c->b.group, c->b.mask, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);

@@ -668,6 +668,48 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     return EDYNHIP_OK;
 }
 
+// ---- collision exclusion lists (util/exclude_collision.cpp:9-71)
+static int upload_exclusion_rows(edynhip_ctx *c, uint32_t a, uint32_t b) {
+    if (!c->excl) {
+        EH_TRY(dalloc(c, c->excl, (size_t)c->b.cap * 16));
+        c->host_excl.assign((size_t)c->b.cap * 16, 0xFFFFFFFFu);
+        EH_HIP(c, hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream));
+    }
+    for (uint32_t x : {a, b})
+        EH_HIP(c, hipMemcpyAsync(c->excl + (size_t)x * 16, c->host_excl.data() + (size_t)x * 16, 16 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    return EDYNHIP_OK;
+}
+int edynhip_exclude_collision(edynhip_ctx *c, uint32_t a, uint32_t b) {
+    if (!c || a >= c->b.n || b >= c->b.n || a == b) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    if (c->host_excl.empty()) c->host_excl.assign((size_t)c->b.cap * 16, 0xFFFFFFFFu);
+    auto add = [&](uint32_t x, uint32_t y) -> int {   // exclude_collision_one_way
+        uint32_t *l = &c->host_excl[(size_t)x * 16];
+        uint32_t k = 0;
+        for (; k < 16 && l[k] != 0xFFFFFFFFu; ++k) if (l[k] == y) return EDYNHIP_OK;
+        if (k == 16) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_exclude_collision: more than 16 exclusions on one body (collision_exclusion::max_exclusions)");
+        l[k] = y;
+        return EDYNHIP_OK;
+    };
+    EH_TRY(add(a, b)); EH_TRY(add(b, a));
+    return upload_exclusion_rows(c, a, b);
+}
+int edynhip_remove_collision_exclusion(edynhip_ctx *c, uint32_t a, uint32_t b) {
+    if (!c || a >= c->b.n || b >= c->b.n) return EDYNHIP_ERR_INVALID;
+    if (c->host_excl.empty()) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    auto drop = [&](uint32_t x, uint32_t y) {   // remove_collision_exclusion_one_way: the last entry takes the hole
+        uint32_t *l = &c->host_excl[(size_t)x * 16];
+        uint32_t size = 0;
+        while (size < 16 && l[size] != 0xFFFFFFFFu) ++size;
+        for (uint32_t i = size; i; --i)
+            if (l[i - 1] == y) { l[i - 1] = l[size - 1]; l[size - 1] = 0xFFFFFFFFu; break; }
+    };
+    drop(a, b); drop(b, a);
+    return upload_exclusion_rows(c, a, b);
+}
+
 int edynhip_refresh_derived(edynhip_ctx *c) {
     if (!c) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));

@@ -228,6 +228,8 @@ struct edynhip_ctx {
     uint32_t df2_waves = 0;        // resident waves of the two-lane dataflow velocity kernel
     bool points_in_prev = false;   // this step's manifold array holds no copied points yet (see Manifolds::prev_idx)
     bool force_islands = true;     // recompute island labels even if the pair set did not change
+    uint32_t *excl = nullptr;      // collision exclusion lists [max_bodies][16], ~0u-terminated; allocated by the first edynhip_exclude_collision
+    std::vector<uint32_t> host_excl;   // host mirror of excl (edits are rare: scene construction)
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
 };
 

@@ -265,6 +265,15 @@ class World:
         arrs = [np.ascontiguousarray(x, np.float32).reshape(n, w) for x, w in ((pos, 3), (orn, 4), (lv, 3), (av, 3))]
         self._check(self._L.edynhip_set_state(self._h, *[_ptr(x) for x in arrs]))
 
+    def exclude_collision(self, a, b):
+        """edyn::exclude_collision(registry, first, second)."""
+        self._flush_defs()
+        self._check(self._L.edynhip_exclude_collision(self._h, int(a), int(b)))
+
+    def remove_collision_exclusion(self, a, b):
+        self._flush_defs()
+        self._check(self._L.edynhip_remove_collision_exclusion(self._h, int(a), int(b)))
+
     def refresh_derived(self):
         """update_aabbs + update_inertias from the current transforms (after set_state)."""
         self._check(self._L.edynhip_refresh_derived(self._h))

@@ -168,6 +168,12 @@ int edynhip_synchronize(edynhip_ctx *ctx);
 
 int edynhip_get_state(edynhip_ctx *ctx, float *pos, float *orn, float *linvel, float *angvel);
 int edynhip_set_state(edynhip_ctx *ctx, const float *pos, const float *orn, const float *linvel, const float *angvel);
+/* collision_exclusion lists (include/edyn/util/exclude_collision.hpp:20-47, src/edyn/util/exclude_collision.cpp:9-71;
+ * evaluated by should_collide_default, src/edyn/collision/should_collide.cpp:11-57): no NEW manifold is created for an
+ * excluded pair (symmetric; at most 16 partners per body, EDYNHIP_ERR_CAPACITY beyond). A manifold that already exists
+ * lives on until its AABBs separate, as in the reference. */
+int edynhip_exclude_collision(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);
+int edynhip_remove_collision_exclusion(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);
 /* Recompute every awake body's AABB and world-space inverse inertia from its current transform: the reference's public
  * update_aabbs(registry) / update_inertias(registry) (include/edyn/sys/update_aabbs.hpp:18-25, update_inertias.hpp:18-28).
  * A step does this at its end (solver.cpp:456-465); after edynhip_set_state the derived state is stale until then -

@@ -238,6 +238,14 @@ class World:
         return self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
                                     _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
 
+    def exclude_collision(self, a, b):
+        f = self.L.orc_exclude_collision; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
+        f(self.h, a, b)
+
+    def remove_collision_exclusion(self, a, b):
+        f = self.L.orc_remove_collision_exclusion; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
+        f(self.h, a, b)
+
     def set_ext_order(self, contacts, joints=()):
         """ORDER_EXTERNAL: visiting order for the next step (RefWorld.get_solve_order() of the same step)."""
         c = np.ascontiguousarray(contacts, np.uint32).reshape(-1, 3); j = np.ascontiguousarray(joints, np.uint32)

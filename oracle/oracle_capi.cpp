@@ -68,6 +68,8 @@ void orc_set_ext_order(void *h, const uint32_t *contacts3, uint32_t nc, const ui
 int orc_ext_order_mismatch(void *h) { return ((World *)h)->ext_order_mismatch ? 1 : 0; }
 // Process-wide: integrate() calls the C library's sinf/cosf like the reference instead of the correctly rounded value.
 void orc_set_libm_trig(int on) { g_libm_trig = on != 0; }
+void orc_exclude_collision(void *h, uint32_t a, uint32_t b) { ((World *)h)->exclude_collision(a, b); }
+void orc_remove_collision_exclusion(void *h, uint32_t a, uint32_t b) { ((World *)h)->remove_collision_exclusion(a, b); }
 // island sleeping (off by default)
 void orc_set_sleeping(void *h, int enable) { ((World *)h)->sleeping = enable != 0; }
 void orc_set_sleeping_disabled(void *h, uint32_t body, int disabled) { ((World *)h)->bodies[body].sleeping_disabled = disabled != 0; }

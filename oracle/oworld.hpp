@@ -54,6 +54,7 @@ struct Body {
     bool has_material = true;
     float friction = 0.5f, restitution = 0.0f;
     uint64_t group = ~0ull, mask = ~0ull;
+    std::vector<uint32_t> exclusions;   // collision_exclusion (comp/collision_exclusion.hpp:16-31)
     aabb box{};
     vec3 dv{0, 0, 0}, dw{0, 0, 0};
     uint32_t leaf = DynTree::NIL;
@@ -270,11 +271,30 @@ public:
     void wake_all() { for (auto &b : bodies) b.asleep = false; std::fill(sleep_since.begin(), sleep_since.end(), (int64_t)-1); }
 
     // ---------------- broadphase ----------------
-    bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:23-57 (no exclusion lists)
+    bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:11-57
         if (a == b) return false;
         const Body &A = bodies[a], &B = bodies[b];
         if ((A.group & B.mask) == 0 || (B.group & A.mask) == 0) return false;
+        auto excluded = [&](const Body &X, uint32_t other) {   // should_exclude: the body's collision_exclusion list
+            for (uint32_t e : X.exclusions) if (e == other) return true;
+            return false;
+        };
+        if (excluded(A, b) || excluded(B, a)) return false;
         return true;
+    }
+    void exclude_collision(uint32_t a, uint32_t b) {   // util/exclude_collision.cpp:9-35 (both ways, no duplicates, <= 16 each)
+        auto one_way = [&](uint32_t x, uint32_t y) {
+            auto &l = bodies[x].exclusions;
+            if (std::find(l.begin(), l.end(), y) == l.end() && l.size() < 16) l.push_back(y);
+        };
+        one_way(a, b); one_way(b, a);
+    }
+    void remove_collision_exclusion(uint32_t a, uint32_t b) {   // :41-60 (the last entry takes the hole)
+        auto one_way = [&](uint32_t x, uint32_t y) {
+            auto &l = bodies[x].exclusions;
+            for (size_t i = l.size(); i; --i) if (l[i - 1] == y) { l[i - 1] = l.back(); l.pop_back(); break; }
+        };
+        one_way(a, b); one_way(b, a);
     }
     void broadphase() {
         const float sep = kContactBreakingThreshold * 1.3f;   // broadphase.hpp:18

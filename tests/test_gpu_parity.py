@@ -641,6 +641,33 @@ def test_awake_body_hits_sleeping_owner_with_higher_index():
     assert_manifolds_equal(m, o.get_manifolds(), what="impact")
 
 
+def test_collision_exclusion_lists_bit_exact():
+    """edynhip_exclude_collision = edyn::exclude_collision (should_collide.cpp:11-57): excluded pairs never get a manifold, an
+    existing manifold outlives a later exclusion until its AABBs separate, removing the exclusion lets the pair form again."""
+    sc = scenes.box_pile(3, 3, 3)
+    excl = [(1, 10), (2, 11), (3, 12), (13, 22), (14, 23), (10, 19)]
+    g = gpu_world(sc); o = oracle_world(sc)
+    for a, b in excl:
+        g.exclude_collision(a, b); o.exclude_collision(a, b)
+    for step in range(60):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+    pairs = {(int(k >> 32), int(k & 0xFFFFFFFF)) for k in g.get_pairs()}
+    for a, b in excl:
+        assert (max(a, b), min(a, b)) not in pairs
+    have = sorted(pairs)[len(pairs) // 2]
+    g.exclude_collision(*have); o.exclude_collision(*have)          # excluding a pair that already touches changes nothing ...
+    g.remove_collision_exclusion(1, 10); o.remove_collision_exclusion(1, 10)   # ... and a removed exclusion lets the pair form
+    for step in range(40):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="exclusion")
+
+
 # ------------------------------------------------------------------ BASELINE.json configs at FULL size
 @pytest.mark.parametrize("name,gen,vel,steps", [
     ("C2_pile8k", scenes.c2_pile, 10, 6),
