@@ -25,7 +25,9 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    if c["kind"] == "reference":   # the real engine, multithreaded: both thread counts are in the sample text
+        assert c["cores"] > 1 and "1-thread" in c["sample"] and "sequential_multithreaded" in c["sample"]
 
 
 def test_bench_two_ranks_on_one_gpu_functional():
