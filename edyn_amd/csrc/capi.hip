@@ -672,7 +672,6 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
 static int upload_exclusion_rows(edynhip_ctx *c, uint32_t a, uint32_t b) {
     if (!c->excl) {
         EH_TRY(dalloc(c, c->excl, (size_t)c->b.cap * 16));
-        c->host_excl.assign((size_t)c->b.cap * 16, 0xFFFFFFFFu);
         EH_HIP(c, hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream));
     }
     for (uint32_t x : {a, b})
