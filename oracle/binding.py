@@ -326,10 +326,32 @@ class World:
         return np.sort((hi << np.uint64(32)) | lo)
 
     def get_joint_impulses(self):
-        out = np.zeros((self.n_joints, 5), np.float32)
+        """[n, 10]: the 9 applied-impulse slots + the tracked hinge angle (see oracle_capi.cpp)."""
+        out = np.zeros((self.n_joints, 10), np.float32)
         if self.n_joints:
             self.L.orc_get_joint_impulses(self.h, _fp(out))
         return out
+
+    def set_joint_params(self, joint, params):
+        p = np.zeros(10, np.float32); p[:len(params)] = params
+        f = self.L.orc_set_joint_params; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, joint, _fp(p))
+
+    def remove_body(self, body):
+        f = self.L.orc_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, body)
+
+    def remove_joint(self, joint):
+        f = self.L.orc_remove_joint; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, joint)
+
+    def set_params(self, dt, vel_iters, pos_iters, gravity=None):
+        f = self.L.orc_set_params; f.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, dt, vel_iters, pos_iters, _fp(_f32(gravity, 3)) if gravity is not None else None)
+
+    def step_timed(self, n, first_time, step_dt):
+        f = self.L.orc_step_timed; f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]; f.restype = None
+        f(self.h, n, first_time, step_dt)
 
     def get_stats(self):
         s = np.zeros(7, np.uint32)
@@ -472,6 +494,18 @@ class RefWorld:
 
     def exclude_collision(self, a, b):
         self.L.refw_exclude_collision(self.h, a, b)
+
+    def remove_body(self, body):
+        f = self.L.refw_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, body)
+
+    def remove_joint(self, joint):
+        f = self.L.refw_remove_joint; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, joint)
+
+    def set_params(self, dt, vel_iters, pos_iters, gravity=None):
+        f = self.L.refw_set_params; f.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, dt, vel_iters, pos_iters, _fp(_f32(gravity, 3)) if gravity is not None else None)
 
     def set_restitution_iterations(self, iters, individual=3):
         self.L.refw_set_restitution_iterations(self.h, iters, individual)

@@ -154,9 +154,31 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
         w->manifolds.emplace(w->pair_key(m.body[0], m.body[1]), m);
     }
 }
-void orc_get_joint_impulses(void *h, float *imp5) {
+// per joint 10 floats: the 9 applied-impulse slots (hinge: linear[3], hinge[2], limit, bump_stop, spring, torque; point:
+// applied[3], friction) + the tracked hinge angle - the layout of ref_world.cpp's refw_get_joint_impulses
+void orc_get_joint_impulses(void *h, float *imp10) {
     World *w = (World *)h;
-    for (size_t i = 0; i < w->joints.size(); ++i) for (int k = 0; k < 5; ++k) imp5[5 * i + k] = w->joints[i].impulse[k];
+    for (size_t i = 0; i < w->joints.size(); ++i) {
+        for (int k = 0; k < 9; ++k) imp10[10 * i + k] = w->joints[i].impulse[k];
+        imp10[10 * i + 9] = w->joints[i].angle;
+    }
+}
+void orc_set_joint_params(void *h, uint32_t joint, const float *p) {
+    World *w = (World *)h;
+    Joint &j = w->joints[joint];
+    for (int k = 0; k < 10; ++k) j.params[k] = p[k];
+    if (j.type == JOINT_HINGE) w->reset_joint_angle(j);
+}
+void orc_remove_body(void *h, uint32_t body) { ((World *)h)->remove_body(body); }
+void orc_remove_joint(void *h, uint32_t joint) { ((World *)h)->remove_joint(joint); }
+void orc_set_params(void *h, float dt, int vel_iters, int pos_iters, const float *g) {
+    World *w = (World *)h;
+    w->dt = dt; w->vel_iters = vel_iters; w->pos_iters = pos_iters;
+    if (g) w->set_gravity(v3(g));
+}
+void orc_step_timed(void *h, int n, double first_time, double step_dt) {
+    World *w = (World *)h;
+    for (int i = 0; i < n; ++i) w->step_timed(first_time + step_dt * i);
 }
 void orc_get_stats(void *h, uint32_t *out7) {
     const StepStats &s = ((World *)h)->stats;

@@ -55,6 +55,7 @@ struct Body {
     float friction = 0.5f, restitution = 0.0f;
     uint64_t group = ~0ull, mask = ~0ull;
     std::vector<uint32_t> exclusions;   // collision_exclusion (comp/collision_exclusion.hpp:16-31)
+    bool removed = false;               // destroyed entity: the index stays reserved
     aabb box{};
     vec3 dv{0, 0, 0}, dw{0, 0, 0};
     uint32_t leaf = DynTree::NIL;
@@ -86,7 +87,13 @@ struct Joint {
     uint32_t body[2];
     vec3 pivot[2];
     mat3 frame[2] = {kMat3Identity, kMat3Identity};   // hinge: column 0 = axis
-    float impulse[5] = {0, 0, 0, 0, 0};
+    // Optional rows (hinge_constraint.hpp:30-62, point_constraint.hpp:25). hinge params: angle_min, angle_max, limit_restitution,
+    // bump_stop_angle, bump_stop_stiffness, torque, speed, rest_angle, stiffness, damping; point: params[0] = friction_torque.
+    float params[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float angle = 0;   // hinge: relative angle tracked across wraps (hinge_constraint.cpp:80-89)
+    // applied impulses by SLOT: hinge linear[0..2], hinge[3..4], limit 5, bump_stop 6, spring 7, torque 8; point [0..2], friction 3
+    float impulse[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool alive = true; // false: removed (the index stays reserved)
     uint32_t colour = kNoColour;
 };
 
@@ -198,7 +205,11 @@ public:
     // island entities and, on a merge, the larger island's timer - a difference only in which timer survives a merge.
     bool sleeping = false;
     uint64_t step_index = 0;
-    std::vector<int64_t> sleep_since;      // per label: step at which the island first qualified for sleep, -1 = not counting
+    // Island sleep timers run on the step TIME STAMPS the stepper hands to the island manager (stepper_sequential.cpp:60-75,
+    // island_manager.cpp:605-623): sim_clock is the stamp of the step being run; step() advances it by fixed dt, step_timed()
+    // by the caller's stretched step_dt (the max_steps_per_update clamp scales the stamps, not the integration dt).
+    double sim_clock = 0;
+    std::vector<double> sleep_since;       // per label: time stamp at which the island first qualified for sleep, < 0 = not counting
     std::vector<uint64_t> new_keys;        // manifolds created by this step's broadphase (they wake their island)
 
     uint64_t pair_key(uint32_t a, uint32_t b) const {   // see pair_key_owned
@@ -234,6 +245,51 @@ public:
         }
         return id;
     }
+    // registry.destroy(body): every edge of the node goes with it - manifolds, contact points, joints - and the islands it
+    // touched wake up and are re-examined (island_manager.cpp:47-115). The index stays reserved (a tombstone).
+    void remove_body(uint32_t i) {
+        Body &b = bodies[i];
+        if (b.removed) return;
+        std::vector<uint32_t> wake;   // island labels to wake: its own, or (non-procedural) those of its partners
+        if (b.procedural() && i < island_label.size()) wake.push_back(island_label[i]);
+        for (auto it = manifolds.begin(); it != manifolds.end();) {
+            if (it->second.body[0] == i || it->second.body[1] == i) {
+                const uint32_t o = it->second.body[0] == i ? it->second.body[1] : it->second.body[0];
+                if (bodies[o].procedural() && o < island_label.size()) wake.push_back(island_label[o]);
+                it = manifolds.erase(it);
+            } else ++it;
+        }
+        for (auto &j : joints)
+            if (j.alive && (j.body[0] == i || j.body[1] == i)) {
+                const uint32_t o = j.body[0] == i ? j.body[1] : j.body[0];
+                if (bodies[o].procedural() && o < island_label.size()) wake.push_back(island_label[o]);
+                j.alive = false; joints_coloured_ = false;
+            }
+        if (b.sh.type != SHAPE_NONE) (b.procedural() ? tree_ : np_tree_).destroy(b.leaf);
+        b.removed = true; b.kind = KIND_STATIC; b.sh.type = SHAPE_NONE; b.asleep = false;
+        b.linvel = b.angvel = {0, 0, 0}; b.mass_inv = 0; b.gravity = {0, 0, 0};
+        for (uint32_t k = 0; k < bodies.size() && k < island_label.size(); ++k)
+            if (bodies[k].procedural() && std::find(wake.begin(), wake.end(), island_label[k]) != wake.end()) {
+                bodies[k].asleep = false;
+                if (island_label[k] < sleep_since.size()) sleep_since[island_label[k]] = -1.0;
+            }
+    }
+    void remove_joint(uint32_t ji) {
+        Joint &j = joints[ji];
+        if (!j.alive) return;
+        j.alive = false; joints_coloured_ = false;
+        for (uint32_t e : {j.body[0], j.body[1]}) {   // destroying an edge wakes its island (on_destroy_island_resident)
+            if (!bodies[e].procedural() || e >= island_label.size()) continue;
+            const uint32_t l = island_label[e];
+            for (uint32_t k = 0; k < bodies.size() && k < island_label.size(); ++k)
+                if (bodies[k].procedural() && island_label[k] == l) bodies[k].asleep = false;
+            if (l < sleep_since.size()) sleep_since[l] = -1.0;
+        }
+    }
+    void set_gravity(vec3 g) {   // gravity_util.cpp:12-20: the setting and every body that carries a gravity component
+        gravity = g;
+        for (auto &b : bodies) if (b.kind == KIND_DYNAMIC && !b.removed) b.gravity = g;
+    }
     uint32_t add_joint(int type, uint32_t a, uint32_t b, vec3 pivotA, vec3 pivotB, vec3 axisA, vec3 axisB) {
         Joint j;
         j.type = type; j.body[0] = a; j.body[1] = b; j.pivot[0] = pivotA; j.pivot[1] = pivotB;
@@ -248,7 +304,9 @@ public:
     }
 
     // One fixed-dt step (stepper_sequential.cpp:121-147 step_simulation order).
-    void step() {
+    void step() { step_timed(sim_clock + (double)dt); }
+    void step_timed(double step_time) {
+        sim_clock = step_time;
         broadphase();
         narrowphase();
         update_islands();
@@ -268,7 +326,7 @@ public:
         if (B.procedural()) { if (!B.asleep) return false; any_proc = true; }
         return any_proc;
     }
-    void wake_all() { for (auto &b : bodies) b.asleep = false; std::fill(sleep_since.begin(), sleep_since.end(), (int64_t)-1); }
+    void wake_all() { for (auto &b : bodies) b.asleep = false; std::fill(sleep_since.begin(), sleep_since.end(), -1.0); }
 
     // ---------------- broadphase ----------------
     bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:11-57
@@ -513,7 +571,7 @@ public:
             if (ra < rb) island_label[rb] = ra; else island_label[ra] = rb;
         };
         for (auto &kv : manifolds) unite(kv.second.body[0], kv.second.body[1]);   // every manifold is a graph edge
-        for (auto &j : joints) unite(j.body[0], j.body[1]);
+        for (auto &j : joints) if (j.alive) unite(j.body[0], j.body[1]);
         uint32_t count = 0;
         for (uint32_t i = 0; i < n; ++i) {
             island_label[i] = find(i);
@@ -530,7 +588,7 @@ public:
         const uint32_t n = (uint32_t)bodies.size();
         enum { FAST = 1, DISABLED = 2, HAS_ASLEEP = 4, HAS_AWAKE = 8, WAKE = 16 };
         std::vector<uint8_t> st(n, 0);
-        sleep_since.resize(n, -1);
+        sleep_since.resize(n, -1.0);
         const float lin2 = 0.005f * 0.005f, ang = kPi / 48.0f, ang2 = ang * ang;   // config/constants.hpp:41-42
         for (uint32_t i = 0; i < n; ++i) {
             const Body &b = bodies[i];
@@ -554,8 +612,8 @@ public:
             if ((s & HAS_ASLEEP) && !(s & HAS_AWAKE) && !wake) { action[i] = 0; continue; }   // stays asleep
             action[i] = 1;
             if (!(s & DISABLED) && !(s & FAST)) {
-                if (sleep_since[i] < 0) sleep_since[i] = (int64_t)step_index;
-                else if ((double)(step_index - (uint64_t)sleep_since[i]) * (double)dt > 2.0) { action[i] = 2; sleep_since[i] = -1; }
+                if (sleep_since[i] < 0) sleep_since[i] = sim_clock;
+                else if (sim_clock - sleep_since[i] > 2.0) { action[i] = 2; sleep_since[i] = -1; }   // island_time_to_sleep
             } else sleep_since[i] = -1;
         }
         for (uint32_t i = 0; i < n; ++i) {
@@ -638,11 +696,13 @@ public:
         if (joints_coloured_) return;
         for (auto &j : joints) j.colour = kNoColour;
         std::vector<uint64_t> used(bodies.size(), 0);
-        colour_edges((uint32_t)joints.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
-            a = joints[e].body[0]; b = joints[e].body[1]; col = &joints[e].colour;
+        std::vector<uint32_t> live;   // removed joints keep their index but take no colour
+        for (uint32_t e = 0; e < joints.size(); ++e) if (joints[e].alive) live.push_back(e);
+        colour_edges((uint32_t)live.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
+            a = joints[live[e]].body[0]; b = joints[live[e]].body[1]; col = &joints[live[e]].colour;
         }, used);
         uint32_t nc = 0;
-        for (auto &j : joints) nc = std::max(nc, j.colour + 1);
+        for (auto &j : joints) if (j.alive) nc = std::max(nc, j.colour + 1);
         stats.num_joint_colours = nc;
         joints_coloured_ = true;
     }
@@ -689,8 +749,17 @@ public:
             ri.rhs = -relative_speed(ri.J, A.linvel, A.angvel, B.linvel, B.angvel);
         }
     }
-    // point_constraint.cpp:9-46 (friction_torque == 0) / hinge_constraint.cpp:26-67 (no limit/spring/torque rows)
-    int prepare_joint(const Joint &j, const BodyRef &A, const BodyRef &B, Row *rows) {
+    // point_constraint.cpp:9-46 / hinge_constraint.cpp:26-178. Returns the number of rows; slot[r] = the applied-impulse slot
+    // row r reads and (after the solve) writes (store_applied_impulses, point_constraint.cpp:48-58, hinge_constraint.cpp:215-257).
+    static constexpr int kMaxJointRows = 9;
+    static float atan2_cr(float y, float x) { return g_libm_trig ? std::atan2(y, x) : (float)std::atan2((double)y, (double)x); }
+    static float normalize_angle(float a) {   // math.hpp:53-63
+        a = std::fmod(a, kPi2);
+        if (a < -kPi) return a + kPi2;
+        if (a > kPi) return a - kPi2;
+        return a;
+    }
+    int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
         mat3 sA = skew(rA), sB = skew(rB);
@@ -703,21 +772,91 @@ public:
             RowOptions o;
             if (j.type == JOINT_POINT) o.error = (pA[i] - pB[i]) / dt;
             finish_row(r, o, A, B);
+            slot[n] = n;
             ++n;
         }
-        if (j.type == JOINT_HINGE) {
-            vec3 p = rotate(A.orn, j.frame[0].column(1)), q = rotate(A.orn, j.frame[0].column(2));
-            const vec3 ax[2] = {p, q};
-            for (int i = 0; i < 2; ++i) {
-                Row &r = rows[n];
-                r.J[0] = {0, 0, 0}; r.J[1] = ax[i]; r.J[2] = {0, 0, 0}; r.J[3] = -ax[i];
-                r.lower = -kScalarMax; r.upper = kScalarMax;
-                r.impulse = j.impulse[n];
-                finish_row(r, RowOptions{}, A, B);
-                ++n;
+        auto axial_row = [&](vec3 ax, int sl, float lo, float hi, const RowOptions &o) {
+            Row &r = rows[n];
+            r.J[0] = {0, 0, 0}; r.J[1] = ax; r.J[2] = {0, 0, 0}; r.J[3] = -ax;
+            r.lower = lo; r.upper = hi;
+            r.impulse = j.impulse[sl];
+            finish_row(r, o, A, B);
+            slot[n] = sl;
+            ++n;
+        };
+        if (j.type == JOINT_POINT) {
+            const float friction_torque = j.params[0];
+            if (friction_torque > 0) {   // point_constraint.cpp:33-46
+                vec3 spin = A.angvel - B.angvel;
+                const float lsqr = length_sqr(spin);
+                if ((double)lsqr > 1e-18) {   // try_normalize, vector3.hpp:239-248
+                    spin /= std::sqrt(lsqr);
+                    const float fi = friction_torque * dt;
+                    axial_row(spin, 3, -fi, fi, RowOptions{});
+                }
+            }
+            return n;
+        }
+        vec3 p = rotate(A.orn, j.frame[0].column(1)), q = rotate(A.orn, j.frame[0].column(2));
+        axial_row(p, 3, -kScalarMax, kScalarMax, RowOptions{});
+        axial_row(q, 4, -kScalarMax, kScalarMax, RowOptions{});
+        const float angle_min = j.params[0], angle_max = j.params[1], limit_restitution = j.params[2], bump_stop_angle = j.params[3],
+                    bump_stop_stiffness = j.params[4], torque = j.params[5], speed = j.params[6], rest_angle = j.params[7],
+                    stiffness = j.params[8], damping = j.params[9];
+        const bool has_limit = angle_min < angle_max, has_spring = stiffness > 0, has_torque = torque > 0 || damping > 0;
+        vec3 hinge_axis{0, 0, 0};
+        if (has_limit || has_spring || has_torque) hinge_axis = rotate(A.orn, j.frame[0].column(0));
+        if (has_limit || has_spring) {   // hinge_constraint.cpp:80-89
+            const vec3 angle_axisB = rotate(B.orn, j.frame[1].column(1));
+            const float current = atan2_cr(dot(angle_axisB, q), dot(angle_axisB, p));
+            const float previous = normalize_angle(j.angle);
+            const float d0 = current - previous;
+            const float d1 = d0 + kPi2 * (d0 < 0 ? 1.0f : -1.0f);
+            j.angle += std::fabs(d0) < std::fabs(d1) ? d0 : d1;
+        }
+        if (has_limit) {   // :91-142
+            RowOptions o;
+            float lo, hi, limit_error;
+            const float halfway = (angle_min + angle_max) / 2.0f;
+            if (j.angle < halfway) { limit_error = angle_min - j.angle; lo = -kLarge; hi = 0; }
+            else { limit_error = angle_max - j.angle; lo = 0; hi = kLarge; }
+            o.error = limit_error / dt;
+            o.restitution = limit_restitution;
+            axial_row(hinge_axis, 5, lo, hi, o);
+            if (bump_stop_stiffness > 0 && bump_stop_angle > 0) {
+                float defl = 0;
+                const float bmin = angle_min + bump_stop_angle, bmax = angle_max - bump_stop_angle;
+                if (j.angle < bmin) defl = j.angle - bmin;
+                else if (j.angle > bmax) defl = j.angle - bmax;
+                if (defl != 0) {
+                    const float imp = bump_stop_stiffness * defl * dt;
+                    RowOptions ob; ob.error = -defl / dt;
+                    axial_row(hinge_axis, 6, std::min(imp, 0.0f), std::max(0.0f, imp), ob);
+                }
             }
         }
+        if (has_spring) {   // :144-158
+            const float defl = j.angle - rest_angle;
+            const float imp = stiffness * defl * dt;
+            RowOptions o; o.error = -defl / dt;
+            axial_row(hinge_axis, 7, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+        }
+        if (has_torque) {   // :160-178
+            float ti = torque * dt;
+            if (damping > 0) {
+                const float relvel = dot(A.angvel, hinge_axis) - dot(B.angvel, hinge_axis);
+                ti += std::fabs(relvel) * damping * dt;
+            }
+            RowOptions o; o.error = -speed;
+            axial_row(hinge_axis, 8, -ti, ti, o);
+        }
         return n;
+    }
+    void reset_joint_angle(Joint &j) {   // hinge_constraint::reset_angle, hinge_constraint.cpp:19-24
+        const Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        const vec3 p = rotate(A.orn, j.frame[0].column(1)), q = rotate(A.orn, j.frame[0].column(2));
+        const vec3 angle_axisB = rotate(B.orn, j.frame[1].column(1));
+        j.angle = atan2_cr(dot(angle_axisB, q), dot(angle_axisB, p));
     }
 
     // position_solver.hpp:16-51. Transforms of non-procedural bodies are left untouched (the reference
@@ -824,13 +963,14 @@ public:
         auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
         for (uint32_t i = 0; i < bodies.size(); ++i) if (bodies[i].procedural() && !bodies[i].asleep) isl_b[island_label[i]].push_back(i);   // solver.cpp:408 excludes sleeping islands
         for (auto &kv : manifolds) isl_m[label_of(kv.second.body[0], kv.second.body[1])].push_back(&kv.second);
-        for (auto &j : joints) isl_j[label_of(j.body[0], j.body[1])].push_back(&j);
+        for (auto &j : joints) if (j.alive) isl_j[label_of(j.body[0], j.body[1])].push_back(&j);
         stats.num_rows = 0;
         for (auto &ib : isl_b) {
             const uint32_t label = ib.first;
             std::vector<Row> rows;
             std::vector<FrictionRow> fric;
-            std::vector<std::pair<Joint *, int>> jrows;       // joint, first row
+            struct JSpan { Joint *j; int first, n; int slot[kMaxJointRows]; };
+            std::vector<JSpan> jrows;
             std::vector<std::pair<ContactPoint *, uint32_t>> crows;   // point, normal row index
             auto &js = isl_j[label];
             // (manifold, slot) pairs in visiting order: list order of the canonical manifold sequence, or the caller's order
@@ -858,10 +998,11 @@ public:
             for (int type : {JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: hinge ... point, contact
                 for (Joint *j : js) {
                     if (j->type != type) continue;
-                    Row tmp[5];
-                    int n = prepare_joint(*j, body_ref(j->body[0]), body_ref(j->body[1]), tmp);
-                    jrows.push_back({j, (int)rows.size()});
-                    for (int i = 0; i < n; ++i) rows.push_back(tmp[i]);
+                    Row tmp[kMaxJointRows];
+                    JSpan sp; sp.j = j; sp.first = (int)rows.size();
+                    sp.n = prepare_joint(*j, body_ref(j->body[0]), body_ref(j->body[1]), tmp, sp.slot);
+                    jrows.push_back(sp);
+                    for (int i = 0; i < sp.n; ++i) rows.push_back(tmp[i]);
                 }
             for (auto &cp : cps) {
                 Manifold *m = cp.first;
@@ -881,10 +1022,8 @@ public:
                 for (auto &f : fric) solve_friction(f, rows[f.normal_row]);
             }
             for (uint32_t b : ib.second) integrate_body(bodies[b]);
-            for (auto &jr : jrows) {                                               // assign_applied_impulses
-                int n = jr.first->type == JOINT_HINGE ? 5 : 3;
-                for (int i = 0; i < n; ++i) jr.first->impulse[i] = rows[jr.second + i].impulse;
-            }
+            for (auto &jr : jrows)                                                 // assign_applied_impulses
+                for (int i = 0; i < jr.n; ++i) jr.j->impulse[jr.slot[i]] = rows[jr.first + i].impulse;
             for (size_t k = 0; k < crows.size(); ++k) {
                 crows[k].first->normal_impulse = rows[crows[k].second].impulse;
                 crows[k].first->friction_impulse[0] = fric[k].row[0].impulse;
@@ -904,14 +1043,14 @@ public:
         colour_joints();
         colour_contacts();
         struct CRows { Manifold *m; Row nr[kMaxContacts]; FrictionRow fr[kMaxContacts]; };
-        struct JRows { Joint *j; int n; Row r[5]; };
+        struct JRows { Joint *j; int n; Row r[kMaxJointRows]; int slot[kMaxJointRows]; };
         std::vector<std::vector<CRows>> cc(stats.num_colours);
         std::vector<std::vector<JRows>> jc(stats.num_joint_colours);
         stats.num_rows = 0;
         for (auto &j : joints) {
-            if (joint_asleep(j)) continue;
+            if (!j.alive || joint_asleep(j)) continue;
             JRows jr; jr.j = &j;
-            jr.n = prepare_joint(j, body_ref(j.body[0]), body_ref(j.body[1]), jr.r);
+            jr.n = prepare_joint(j, body_ref(j.body[0]), body_ref(j.body[1]), jr.r, jr.slot);
             stats.num_rows += jr.n;
             jc[j.colour].push_back(jr);
         }
@@ -937,7 +1076,7 @@ public:
             }
         }
         for (auto &b : bodies) if (b.kind == KIND_DYNAMIC && !b.asleep) integrate_body(b);
-        for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) jr.j->impulse[i] = jr.r[i].impulse;
+        for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) jr.j->impulse[jr.slot[i]] = jr.r[i].impulse;
         for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) {
             cr.m->pt[i].normal_impulse = cr.nr[i].impulse;
             cr.m->pt[i].friction_impulse[0] = cr.fr[i].row[0].impulse;

@@ -172,6 +172,24 @@ void refw_set_joint_params(void *h, uint32_t joint, const float *p) {
         pc->friction_torque = p[0];
     }
 }
+// registry.destroy on a rigid body / a constraint entity (the reference's hooks clean up edges, manifolds, islands:
+// island_manager.cpp:47-115). The body / joint index stays reserved in this driver.
+void refw_remove_body(void *h, uint32_t body) {
+    auto *w = (ref_world *)h;
+    if (w->registry.valid(w->bodies[body])) w->registry.destroy(w->bodies[body]);
+}
+void refw_remove_joint(void *h, uint32_t joint) {
+    auto *w = (ref_world *)h;
+    if (w->registry.valid(w->joints[joint])) w->registry.destroy(w->joints[joint]);
+}
+void refw_set_params(void *h, float dt, int vel_iters, int pos_iters, const float *g) {
+    auto *w = (ref_world *)h;
+    edyn::set_fixed_dt(w->registry, dt);
+    w->dt = dt;
+    edyn::set_solver_velocity_iterations(w->registry, (unsigned)vel_iters);
+    edyn::set_solver_position_iterations(w->registry, (unsigned)pos_iters);
+    if (g) edyn::set_gravity(w->registry, v3(g));
+}
 void refw_exclude_collision(void *h, uint32_t a, uint32_t b) {
     auto *w = (ref_world *)h;
     edyn::exclude_collision(w->registry, w->bodies[a], w->bodies[b]);
@@ -202,6 +220,7 @@ void refw_get_state(void *h, float *pos, float *orn, float *linvel, float *angve
     auto *w = (ref_world *)h;
     for (size_t i = 0; i < w->bodies.size(); ++i) {
         auto e = w->bodies[i];
+        if (!w->registry.valid(e)) { std::memset(pos + 3 * i, 0, 12); std::memset(orn + 4 * i, 0, 16); std::memset(linvel + 3 * i, 0, 12); std::memset(angvel + 3 * i, 0, 12); continue; }
         put3(pos + 3 * i, w->registry.get<edyn::position>(e));
         auto &q = w->registry.get<edyn::orientation>(e);
         orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
@@ -214,6 +233,7 @@ void refw_set_state(void *h, const float *pos, const float *orn, const float *li
     auto *w = (ref_world *)h;
     for (size_t i = 0; i < w->bodies.size(); ++i) {
         auto e = w->bodies[i];
+        if (!w->registry.valid(e)) continue;
         static_cast<edyn::vector3 &>(w->registry.get<edyn::position>(e)) = v3(pos + 3 * i);
         static_cast<edyn::quaternion &>(w->registry.get<edyn::orientation>(e)) = edyn::quaternion{orn[4 * i], orn[4 * i + 1], orn[4 * i + 2], orn[4 * i + 3]};
         if (auto *v = w->registry.try_get<edyn::linvel>(e)) static_cast<edyn::vector3 &>(*v) = v3(linvel + 3 * i);
@@ -227,6 +247,13 @@ void refw_get_derived(void *h, float *aabb6, float *iw9, uint32_t *island, uint8
     std::unordered_map<uint32_t, uint32_t> label;
     for (size_t i = 0; i < w->bodies.size(); ++i) {
         auto e = w->bodies[i];
+        if (!reg.valid(e)) {
+            if (aabb6) std::memset(aabb6 + 6 * i, 0, 24);
+            if (iw9) std::memset(iw9 + 9 * i, 0, 36);
+            if (asleep) asleep[i] = 0;
+            if (island) island[i] = (uint32_t)i;
+            continue;
+        }
         if (aabb6) {
             if (auto *bb = reg.try_get<edyn::AABB>(e)) { put3(aabb6 + 6 * i, bb->min); put3(aabb6 + 6 * i + 3, bb->max); }
             else std::memset(aabb6 + 6 * i, 0, 24);
@@ -247,6 +274,7 @@ void refw_get_derived(void *h, float *aabb6, float *iw9, uint32_t *island, uint8
     }
     if (island) {
         for (size_t i = 0; i < w->bodies.size(); ++i) {
+            if (!reg.valid(w->bodies[i])) continue;
             if (auto *res = reg.try_get<edyn::island_resident>(w->bodies[i]); res && res->island_entity != entt::null)
                 island[i] = label[entt::to_integral(res->island_entity)];
         }
@@ -306,6 +334,7 @@ void refw_get_joint_impulses(void *h, float *out10) {
     for (size_t i = 0; i < w->joints.size(); ++i) {
         float *o = out10 + 10 * i;
         std::memset(o, 0, 40);
+        if (!w->registry.valid(w->joints[i])) continue;
         if (auto *hc = w->registry.try_get<edyn::hinge_constraint>(w->joints[i])) {
             for (int k = 0; k < 3; ++k) o[k] = hc->applied_impulse.linear[k];
             o[3] = hc->applied_impulse.hinge[0]; o[4] = hc->applied_impulse.hinge[1];
