@@ -32,7 +32,12 @@ class Bodies(C.Structure):
 
 
 class Joints(C.Structure):
-    _fields_ = [("type", C.c_void_p), ("body", C.c_void_p), ("pivot", C.c_void_p), ("axis", C.c_void_p)]
+    _fields_ = [("type", C.c_void_p), ("body", C.c_void_p), ("pivot", C.c_void_p), ("axis", C.c_void_p), ("params", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("fixed_dt", C.c_float), ("num_velocity_iterations", C.c_uint32), ("num_position_iterations", C.c_uint32),
+                ("gravity", C.c_float * 3)]
 
 
 class Timings(C.Structure):
@@ -64,7 +69,9 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all",
-           "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion"]
+           "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
+           "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
+           "edynhip_step_timed"]
 
 _lib = None
 
@@ -102,6 +109,13 @@ def lib():
         L.edynhip_get_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_wake_all.argtypes = [C.c_void_p]
         L.edynhip_refresh_derived.argtypes = [C.c_void_p]
+        L.edynhip_add_joints.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Joints), C.POINTER(C.c_uint32)]
+        L.edynhip_remove_joints.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.edynhip_set_joint_params.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.edynhip_remove_bodies.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.edynhip_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.edynhip_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.edynhip_step_timed.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
         L.edynhip_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_remove_collision_exclusion.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_abi_version.restype = C.c_uint32

@@ -102,14 +102,16 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
     EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));
     EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
-    EH_HIP(c, hipMemsetAsync(c->sleep_since, 0xFF, (size_t)nb * sizeof(int32_t), c->stream));   // -1: no timer running
+    EH_HIP(c, hipMemsetAsync(c->sleep_since, 0xFF, (size_t)nb * sizeof(double), c->stream));   // all ones (a NaN): no timer running
     Joints &j = c->j;
     j.cap = nj;
     EH_TRY(dalloc(c, j.orig, nj)); EH_TRY(dalloc(c, j.type, nj)); EH_TRY(dalloc(c, j.bodyA, nj)); EH_TRY(dalloc(c, j.bodyB, nj));
     EH_TRY(dalloc(c, j.pivA, nj)); EH_TRY(dalloc(c, j.pivB, nj)); EH_TRY(dalloc(c, j.axA, nj)); EH_TRY(dalloc(c, j.pA, nj));
-    EH_TRY(dalloc(c, j.qA, nj)); EH_TRY(dalloc(c, j.axB, nj)); EH_TRY(dalloc(c, j.impulse, (size_t)nj * 5));
-    EH_TRY(dalloc(c, j.rA, nj)); EH_TRY(dalloc(c, j.rB, nj)); EH_TRY(dalloc(c, j.wp, nj)); EH_TRY(dalloc(c, j.wq, nj));
-    EH_TRY(dalloc(c, j.eff, (size_t)nj * 5)); EH_TRY(dalloc(c, j.rhs, (size_t)nj * 5));
+    EH_TRY(dalloc(c, j.qA, nj)); EH_TRY(dalloc(c, j.axB, nj)); EH_TRY(dalloc(c, j.pB, nj)); EH_TRY(dalloc(c, j.impulse, (size_t)nj * kJointSlots));
+    EH_TRY(dalloc(c, j.params, (size_t)nj * kJointParams)); EH_TRY(dalloc(c, j.angle, nj)); EH_TRY(dalloc(c, j.rmask, nj));
+    EH_TRY(dalloc(c, j.rA, nj)); EH_TRY(dalloc(c, j.rB, nj)); EH_TRY(dalloc(c, j.wp, nj)); EH_TRY(dalloc(c, j.wq, nj)); EH_TRY(dalloc(c, j.wax, nj));
+    EH_TRY(dalloc(c, j.eff, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.rhs, (size_t)nj * kJointSlots));
+    EH_TRY(dalloc(c, j.lo, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.hi, (size_t)nj * kJointSlots));
     c->sort_tmp_bytes = sort_temp_bytes(std::max(std::max(M, nb + 1), 256u * ((M + 1023u) / 1024u) + 1u));
     { void *q = nullptr; EH_HIP(c, hipMalloc(&q, c->sort_tmp_bytes)); c->allocs.push_back(q); c->sort_tmp = q; }
     EH_TRY(dalloc(c, c->cnt, 1));
@@ -362,13 +364,65 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     return EDYNHIP_OK;
 }
 
+// ---- removal (registry.destroy on a rigid body: island_manager.cpp:47-115)
+__global__ void k_mark_removed(uint32_t n, const uint32_t *__restrict__ list, Bodies b, uint32_t *wake) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = list[t];
+    const uint32_t fl = b.flags[i];
+    if ((fl & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) wake[b.island[i]] = 1u;
+    b.flags[i] = EDYNHIP_KIND_STATIC | BF_REMOVED;     // shapeless, static, awake: no stage touches it any more
+    b.linvel[i] = make_float4(0, 0, 0, 0); b.angvel[i] = make_float4(0, 0, 0, 0);
+    b.grav[i] = make_float4(0, 0, 0, 0);
+    float4 p = B_POS(b, i); p.w = 0; B_POS(b, i) = p;
+    B_DV(b, i) = make_float4(0, 0, 0, 0); B_DW(b, i) = make_float4(0, 0, 0, 0);
+    b.island[i] = i;
+}
+__global__ void k_mark_touching(uint32_t n, const uint32_t *__restrict__ list, Bodies b, uint32_t *wake) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = list[t];
+    if ((b.flags[i] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) wake[b.island[i]] = 1u;
+}
+__global__ void k_wake_partners(uint32_t M, Manifolds mf, Bodies b, uint32_t *wake) {   // islands resting on a removed static/kinematic body
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t a = mf.bodyA[m], bb = mf.bodyB[m];
+    const bool ra = b.flags[a] & BF_REMOVED, rb = b.flags[bb] & BF_REMOVED;
+    if (ra && (b.flags[bb] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) wake[b.island[bb]] = 1u;
+    if (rb && (b.flags[a] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) wake[b.island[a]] = 1u;
+}
+__global__ void k_wake_marked(uint32_t n, Bodies b, uint32_t *wake, double *since) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t fl = b.flags[i];
+    if ((fl & BF_KIND_MASK) != EDYNHIP_KIND_DYNAMIC) return;
+    const uint32_t l = b.island[i];
+    if (wake[l]) { b.flags[i] = fl & ~BF_ASLEEP; if (l == i) since[i] = -1.0; }
+}
+// wake the islands of the listed bodies (wake_up_island, island_manager.cpp:541-571)
+int wake_islands_of(edynhip_ctx *c, const std::vector<uint32_t> &bodies) {
+    if (!c->sleeping || bodies.empty() || c->b.n == 0) { c->all_asleep = false; return EDYNHIP_OK; }
+    uint32_t *list = nullptr;
+    EH_HIP(c, hipMalloc((void **)&list, bodies.size() * sizeof(uint32_t)));
+    EH_HIP(c, hipMemcpyAsync(list, bodies.data(), bodies.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.n * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_mark_touching, dim3(((uint32_t)bodies.size() + 127) / 128), dim3(128), 0, c->stream, (uint32_t)bodies.size(), list, c->b, c->sleep_action);
+    hipLaunchKernelGGL(k_wake_marked, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, c->sleep_action, c->sleep_since);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(list);
+    c->all_asleep = false;
+    if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "wake_islands_of", e);
+    return EDYNHIP_OK;
+}
+
 }  // namespace eh
 
 using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 2; }   // 2: edynhip_bodies.sleeping_disabled, edynhip_add_bodies, sleeping entry points
+uint32_t edynhip_abi_version(void) { return 3; }   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -432,6 +486,26 @@ int edynhip_synchronize(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
+// broadphase participants from the host mirror of (kind, shape): [shaped non-procedural ..., shaped procedural ...]
+static int rebuild_broadphase_lists(edynhip_ctx *c) {
+    std::vector<uint32_t> np_list, proc_list;
+    for (uint32_t i = 0; i < (uint32_t)c->host_kind.size(); ++i) {
+        if (c->host_shape[i] == EDYNHIP_SHAPE_NONE) continue;
+        (c->host_kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
+    }
+    // only procedural shaped bodies own pairs; everybody else's count must read 0 in the scan
+    EH_HIP(c, hipMemsetAsync(c->own_count, 0, ((size_t)c->b.cap + 1) * sizeof(uint32_t), c->stream));
+    c->all_asleep = false;
+    c->bvh.age = 0;   // the tree topology is rebuilt on the next step
+    c->bvh.num_np = (uint32_t)np_list.size();
+    c->bvh.num_proc = (uint32_t)proc_list.size();
+    np_list.insert(np_list.end(), proc_list.begin(), proc_list.end());
+    if (!np_list.empty())
+        EH_HIP(c, hipMemcpyAsync(c->bvh.np_list, np_list.data(), np_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));   // np_list (a local) must outlive the copy
+    return EDYNHIP_OK;
+}
+
 static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip_bodies *in, const char *who) {
     if (!c || !in) return EDYNHIP_ERR_INVALID;
     if ((uint64_t)first + n > c->b.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, (std::string(who) + ": more than max_bodies").c_str());
@@ -441,6 +515,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] != 0.0f)
             return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": restitution > 0 needs the restitution solver (out of scope)").c_str());
+    if (first == 0) { c->host_joints.clear(); c->j.n = 0; c->j.num_colours = 0; c->j.rows = 0; c->host_excl.clear(); if (c->excl) (void)hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream); }
     EH_HIP(c, hipSetDevice(c->device));
     std::vector<void *> tmp;
     RawBodies r{};
@@ -463,24 +538,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         c->host_kind.insert(c->host_kind.end(), in->kind, in->kind + n);
         c->host_shape.insert(c->host_shape.end(), in->shape_type, in->shape_type + n);
     }
-    // broadphase participants: [shaped non-procedural ..., shaped procedural ...]
-    std::vector<uint32_t> np_list, proc_list;
-    if (rc == EDYNHIP_OK)
-        for (uint32_t i = 0; i < total; ++i) {
-            if (c->host_shape[i] == EDYNHIP_SHAPE_NONE) continue;
-            (c->host_kind[i] == EDYNHIP_KIND_DYNAMIC ? proc_list : np_list).push_back(i);
-        }
-    // only procedural shaped bodies own pairs; everybody else's count must read 0 in the scan
-    if (rc == EDYNHIP_OK && hipMemsetAsync(c->own_count, 0, ((size_t)c->b.cap + 1) * sizeof(uint32_t), c->stream) != hipSuccess)
-        rc = set_error(c, EDYNHIP_ERR_HIP, "clear pair counts");
-    c->all_asleep = false;
-    c->bvh.age = 0;   // the tree topology is rebuilt on the next step
-    c->bvh.num_np = (uint32_t)np_list.size();
-    c->bvh.num_proc = (uint32_t)proc_list.size();
-    np_list.insert(np_list.end(), proc_list.begin(), proc_list.end());
-    if (rc == EDYNHIP_OK && !np_list.empty())
-        rc = hipMemcpyAsync(c->bvh.np_list, np_list.data(), np_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess
-                 ? EDYNHIP_OK : set_error(c, EDYNHIP_ERR_HIP, "upload broadphase lists");
+    if (rc == EDYNHIP_OK) rc = rebuild_broadphase_lists(c);
     (void)hipStreamSynchronize(c->stream);
     for (void *p : tmp) (void)hipFree(p);
     if (first == 0) {   // a new world: no manifolds, no running sleep timers (appended bodies keep every index stable instead)
@@ -488,7 +546,8 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         c->prev_num_manifolds = 0;
         c->step_index = 0;
         c->num_colours = 0;
-        (void)hipMemsetAsync(c->sleep_since, 0xFF, (size_t)c->b.cap * sizeof(int32_t), c->stream);
+        (void)hipMemsetAsync(c->sleep_since, 0xFF, (size_t)c->b.cap * sizeof(double), c->stream);
+        c->sim_clock = 0;
         (void)hipMemsetAsync(c->sleep_state, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
         (void)hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
         (void)hipStreamSynchronize(c->stream);
@@ -508,21 +567,37 @@ int edynhip_add_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
     return load_bodies(c, c->b.n, n, in, "edynhip_add_bodies");
 }
 
-int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
-    if (!c || (n && !in)) return EDYNHIP_ERR_INVALID;
-    if (n > c->j.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_set_joints: n > max_joints");
-    EH_HIP(c, hipSetDevice(c->device));
+// Host joint list -> device arrays: deterministic edge colouring over the live joints in caller-index order (the rule of the
+// per-step contact colouring, solver.hip k_col_*), colour-sorted upload, applied impulses and hinge angles carried along.
+// fetch = first read the current impulses / angles back from the device (the joints were stepped since the last rebuild).
+static int rebuild_joints(edynhip_ctx *c, bool fetch) {
     Joints &j = c->j;
+    hipStream_t s = c->stream;
+    std::vector<HostJoint> &hj = c->host_joints;
+    if (fetch && j.n) {
+        std::vector<float> imp((size_t)j.cap * kJointSlots), ang(j.n);
+        std::vector<uint32_t> orig(j.n);
+        EH_HIP(c, hipMemcpyAsync(imp.data(), j.impulse, imp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        EH_HIP(c, hipMemcpyAsync(ang.data(), j.angle, (size_t)j.n * sizeof(float), hipMemcpyDeviceToHost, s));
+        EH_HIP(c, hipMemcpyAsync(orig.data(), j.orig, (size_t)j.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        EH_HIP(c, hipStreamSynchronize(s));
+        for (uint32_t p = 0; p < j.n; ++p) {
+            HostJoint &h = hj[orig[p]];
+            for (int r = 0; r < kJointSlots; ++r) h.impulse[r] = imp[(size_t)r * j.cap + p];
+            h.angle = ang[p];
+        }
+    }
+    std::vector<uint32_t> live;
+    for (uint32_t e = 0; e < hj.size(); ++e) if (hj[e].alive) live.push_back(e);
+    const uint32_t n = (uint32_t)live.size();
+    if (n > j.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "joints: more live joints than max_joints");
     j.n = n; j.num_colours = 0; j.rows = 0;
     c->force_islands = true;
     c->all_asleep = false;
     std::memset(j.colour_start, 0, sizeof(j.colour_start));
+    c->stats.num_joints = n; c->stats.num_joint_rows = 0; c->stats.num_joint_colours = 0;
     if (n == 0) return EDYNHIP_OK;
-    // body kinds are needed for the colouring (only procedural endpoints constrain a colour)
-    std::vector<uint32_t> flags(c->b.n);
-    EH_HIP(c, hipMemcpy(flags.data(), c->b.flags, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    auto dyn = [&](uint32_t b) { return (flags[b] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC; };
-    // Deterministic edge colouring, identical to the per-step contact colouring kernels (solver.hip k_col_*).
+    auto dyn = [&](uint32_t b) { return c->host_kind[b] == EDYNHIP_KIND_DYNAMIC; };
     std::vector<uint32_t> colour(n, kNoColour);
     std::vector<uint64_t> used(c->b.n, 0), best(c->b.n, 0);
     for (;;) {
@@ -530,23 +605,22 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
         for (uint32_t e = 0; e < n; ++e) {
             if (colour[e] != kNoColour) continue;
             any = true;
-            uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
-            uint32_t a = in->body[2 * e], b = in->body[2 * e + 1];
-            if (a >= c->b.n || b >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joints: body index out of range");
+            const uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
+            const uint32_t a = hj[live[e]].body[0], b = hj[live[e]].body[1];
             if (dyn(a)) best[a] = std::max(best[a], pr);
             if (dyn(b)) best[b] = std::max(best[b], pr);
         }
         if (!any) break;
         for (uint32_t e = 0; e < n; ++e) {
             if (colour[e] != kNoColour) continue;
-            uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
-            uint32_t a = in->body[2 * e], b = in->body[2 * e + 1];
-            bool da = dyn(a), db = dyn(b);
+            const uint64_t pr = (uint64_t)(0xFFFFFFFFu - e);
+            const uint32_t a = hj[live[e]].body[0], b = hj[live[e]].body[1];
+            const bool da = dyn(a), db = dyn(b);
             if ((da && best[a] != pr) || (db && best[b] != pr)) continue;
-            uint64_t busy = (da ? used[a] : 0) | (db ? used[b] : 0);
+            const uint64_t busy = (da ? used[a] : 0) | (db ? used[b] : 0);
             uint32_t col = 0;
             while (col < kMaxColours && (busy >> col & 1)) ++col;
-            if (col >= kMaxColours) return set_error(c, EDYNHIP_ERR_COLOURS, "edynhip_set_joints: more than 64 joint colours");
+            if (col >= kMaxColours) return set_error(c, EDYNHIP_ERR_COLOURS, "joints: more than 64 joint colours");
             colour[e] = col;
             if (da) used[a] |= 1ull << col;
             if (db) used[b] |= 1ull << col;
@@ -556,8 +630,9 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return colour[x] < colour[y]; });
-    std::vector<uint32_t> type(n), bA(n), bB(n);
-    std::vector<float4> pivA(n), pivB(n), axA(n), pA(n), qA(n), axB(n);
+    std::vector<uint32_t> orig(n), type(n), bA(n), bB(n);
+    std::vector<float4> pivA(n), pivB(n), axA(n), pA(n), qA(n), axB(n), pB(n);
+    std::vector<float> params((size_t)j.cap * kJointParams, 0.0f), impulse((size_t)j.cap * kJointSlots, 0.0f), angle(n);
     auto plane_space_h = [](const float *nn, float *p, float *q) {   // geom.cpp:730-754 (host, fp32)
         if (std::fabs(nn[2]) > dm::kHalfSqrt2) {
             float a = nn[1] * nn[1] + nn[2] * nn[2]; float k = 1.0f / std::sqrt(a);
@@ -569,30 +644,31 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     };
     uint32_t ncol = 0, rows = 0;
     for (uint32_t p = 0; p < n; ++p) {
-        const uint32_t e = order[p];
-        type[p] = (uint32_t)in->type[e]; bA[p] = in->body[2 * e]; bB[p] = in->body[2 * e + 1];
-        const float *pv = in->pivot + 6 * e;
-        pivA[p] = make_float4(pv[0], pv[1], pv[2], 0); pivB[p] = make_float4(pv[3], pv[4], pv[5], 0);
-        axA[p] = pA[p] = qA[p] = axB[p] = make_float4(0, 0, 0, 0);
-        if (in->type[e] == EDYNHIP_JOINT_HINGE) {
-            if (!in->axis) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joints: hinge needs axes");
-            const float *ax = in->axis + 6 * e;
+        const HostJoint &h = hj[live[order[p]]];
+        orig[p] = live[order[p]];
+        type[p] = (uint32_t)h.type; bA[p] = h.body[0]; bB[p] = h.body[1];
+        pivA[p] = make_float4(h.pivot[0], h.pivot[1], h.pivot[2], 0); pivB[p] = make_float4(h.pivot[3], h.pivot[4], h.pivot[5], 0);
+        axA[p] = pA[p] = qA[p] = axB[p] = pB[p] = make_float4(0, 0, 0, 0);
+        if (h.type == EDYNHIP_JOINT_HINGE) {   // hinge_constraint::set_axes, hinge_constraint.cpp:11-17
             float p3[3], q3[3];
-            plane_space_h(ax, p3, q3);
-            axA[p] = make_float4(ax[0], ax[1], ax[2], 0); pA[p] = make_float4(p3[0], p3[1], p3[2], 0); qA[p] = make_float4(q3[0], q3[1], q3[2], 0);
-            axB[p] = make_float4(ax[3], ax[4], ax[5], 0);
+            plane_space_h(h.axis, p3, q3);
+            axA[p] = make_float4(h.axis[0], h.axis[1], h.axis[2], 0); pA[p] = make_float4(p3[0], p3[1], p3[2], 0); qA[p] = make_float4(q3[0], q3[1], q3[2], 0);
+            plane_space_h(h.axis + 3, p3, q3);
+            axB[p] = make_float4(h.axis[3], h.axis[4], h.axis[5], 0); pB[p] = make_float4(p3[0], p3[1], p3[2], 0);
             rows += 5;
         } else rows += 3;
-        ncol = std::max(ncol, colour[e] + 1);
+        for (int k = 0; k < kJointParams; ++k) params[(size_t)k * j.cap + p] = h.params[k];
+        for (int r = 0; r < kJointSlots; ++r) impulse[(size_t)r * j.cap + p] = h.impulse[r];
+        angle[p] = h.angle;
+        ncol = std::max(ncol, colour[order[p]] + 1);
     }
     for (uint32_t k = 0; k <= ncol; ++k) {
-        uint32_t s = 0;
-        while (s < n && colour[order[s]] < k) ++s;
-        j.colour_start[k] = s;
+        uint32_t q = 0;
+        while (q < n && colour[order[q]] < k) ++q;
+        j.colour_start[k] = q;
     }
     j.num_colours = ncol; j.rows = rows;
-    hipStream_t s = c->stream;
-    EH_HIP(c, hipMemcpyAsync(j.orig, order.data(), n * 4, hipMemcpyHostToDevice, s));
+    EH_HIP(c, hipMemcpyAsync(j.orig, orig.data(), n * 4, hipMemcpyHostToDevice, s));
     EH_HIP(c, hipMemcpyAsync(j.type, type.data(), n * 4, hipMemcpyHostToDevice, s));
     EH_HIP(c, hipMemcpyAsync(j.bodyA, bA.data(), n * 4, hipMemcpyHostToDevice, s));
     EH_HIP(c, hipMemcpyAsync(j.bodyB, bB.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -602,10 +678,103 @@ int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     EH_HIP(c, hipMemcpyAsync(j.pA, pA.data(), n * 16, hipMemcpyHostToDevice, s));
     EH_HIP(c, hipMemcpyAsync(j.qA, qA.data(), n * 16, hipMemcpyHostToDevice, s));
     EH_HIP(c, hipMemcpyAsync(j.axB, axB.data(), n * 16, hipMemcpyHostToDevice, s));
-    EH_HIP(c, hipMemsetAsync(j.impulse, 0, (size_t)j.cap * 5 * sizeof(float), s));
+    EH_HIP(c, hipMemcpyAsync(j.pB, pB.data(), n * 16, hipMemcpyHostToDevice, s));
+    EH_HIP(c, hipMemcpyAsync(j.params, params.data(), params.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    EH_HIP(c, hipMemcpyAsync(j.impulse, impulse.data(), impulse.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    EH_HIP(c, hipMemcpyAsync(j.angle, angle.data(), n * sizeof(float), hipMemcpyHostToDevice, s));
     EH_HIP(c, hipStreamSynchronize(s));
     c->stats.num_joints = n; c->stats.num_joint_rows = rows; c->stats.num_joint_colours = ncol;
     return EDYNHIP_OK;
+}
+static int append_host_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in, const char *who) {
+    for (uint32_t e = 0; e < n; ++e) {
+        HostJoint h;
+        h.type = in->type[e]; h.body[0] = in->body[2 * e]; h.body[1] = in->body[2 * e + 1];
+        if (h.body[0] >= c->b.n || h.body[1] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": body index out of range").c_str());
+        if (h.type != EDYNHIP_JOINT_POINT && h.type != EDYNHIP_JOINT_HINGE) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
+        std::memcpy(h.pivot, in->pivot + 6 * e, sizeof(h.pivot));
+        if (h.type == EDYNHIP_JOINT_HINGE) {
+            if (!in->axis) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": hinge needs axes").c_str());
+            std::memcpy(h.axis, in->axis + 6 * e, sizeof(h.axis));
+        }
+        if (in->params) std::memcpy(h.params, in->params + (size_t)kJointParams * e, sizeof(h.params));
+        c->host_joints.push_back(h);
+    }
+    return EDYNHIP_OK;
+}
+// hinges whose parameters enable the angle-dependent rows start from the angle of the current pose (reset_angle)
+static int reset_new_angles(edynhip_ctx *c, uint32_t first_caller_index) {
+    Joints &j = c->j;
+    if (j.n == 0) return EDYNHIP_OK;
+    std::vector<uint32_t> orig(j.n);
+    EH_HIP(c, hipMemcpy(orig.data(), j.orig, (size_t)j.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> which(j.n, 0);
+    bool any = false;
+    for (uint32_t p = 0; p < j.n; ++p) if (orig[p] >= first_caller_index) { which[p] = 1; any = true; }
+    if (!any) return EDYNHIP_OK;
+    uint8_t *d = nullptr;
+    EH_HIP(c, hipMalloc((void **)&d, j.n));
+    EH_HIP(c, hipMemcpy(d, which.data(), j.n, hipMemcpyHostToDevice));
+    int rc = joint_reset_angles(c, d);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
+    if (!c || (n && !in)) return EDYNHIP_ERR_INVALID;
+    if (n > c->j.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_set_joints: n > max_joints");
+    EH_HIP(c, hipSetDevice(c->device));
+    c->host_joints.clear();
+    if (n) EH_TRY(append_host_joints(c, n, in, "edynhip_set_joints"));
+    EH_TRY(rebuild_joints(c, false));
+    return reset_new_angles(c, 0);
+}
+int edynhip_add_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in, uint32_t *first_index) {
+    if (!c || (n && !in)) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    const uint32_t first = (uint32_t)c->host_joints.size();
+    if (first_index) *first_index = first;
+    if (n == 0) return EDYNHIP_OK;
+    EH_TRY(append_host_joints(c, n, in, "edynhip_add_joints"));
+    int rc = rebuild_joints(c, true);
+    if (rc != EDYNHIP_OK) { c->host_joints.resize(first); (void)rebuild_joints(c, false); return rc; }
+    return reset_new_angles(c, first);
+}
+int edynhip_remove_joints(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
+    if (!c || (n && !indices)) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    for (uint32_t k = 0; k < n; ++k) if (indices[k] >= c->host_joints.size()) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_remove_joints: index out of range");
+    // fetch first: the impulses of the survivors come from the device
+    EH_TRY(rebuild_joints(c, true));
+    std::vector<uint32_t> touched;
+    for (uint32_t k = 0; k < n; ++k) {
+        HostJoint &h = c->host_joints[indices[k]];
+        if (!h.alive) continue;
+        h.alive = false;
+        touched.push_back(h.body[0]); touched.push_back(h.body[1]);
+    }
+    EH_TRY(rebuild_joints(c, false));
+    return wake_islands_of(c, touched);   // destroying an edge wakes its island (island_manager.cpp:74-97)
+}
+int edynhip_set_joint_params(edynhip_ctx *c, uint32_t joint, const float *params) {
+    if (!c || !params || joint >= c->host_joints.size() || !c->host_joints[joint].alive) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(rebuild_joints(c, true));
+    std::memcpy(c->host_joints[joint].params, params, sizeof(float) * kJointParams);
+    EH_TRY(rebuild_joints(c, false));
+    // reset_angle for this joint only
+    std::vector<uint32_t> orig(c->j.n);
+    EH_HIP(c, hipMemcpy(orig.data(), c->j.orig, (size_t)c->j.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> which(c->j.n, 0);
+    for (uint32_t p = 0; p < c->j.n; ++p) if (orig[p] == joint) which[p] = 1;
+    uint8_t *d = nullptr;
+    EH_HIP(c, hipMalloc((void **)&d, c->j.n));
+    EH_HIP(c, hipMemcpy(d, which.data(), c->j.n, hipMemcpyHostToDevice));
+    int rc = joint_reset_angles(c, d);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 int edynhip_run_stages(edynhip_ctx *c, uint32_t mask) {
@@ -614,17 +783,92 @@ int edynhip_run_stages(edynhip_ctx *c, uint32_t mask) {
     return run_stages(c, mask);
 }
 
-int edynhip_step(edynhip_ctx *c, uint32_t nsteps) {
-    if (!c) return EDYNHIP_ERR_INVALID;
+static int step_stamped(edynhip_ctx *c, uint32_t nsteps, bool timed, double first_time, double step_dt) {
     EH_HIP(c, hipSetDevice(c->device));
     c->timings = edynhip_timings{};
     c->timer.recorded = 0;
     for (uint32_t i = 0; i < nsteps; ++i) {
+        // island_manager::update runs put_islands_to_sleep() against the PREVIOUS step's stamp and only then takes the new one
+        // (island_manager.cpp:533-539): the kernels read c->sim_clock, which is advanced after the step
+        const double stamp = timed ? first_time + step_dt * (double)i : c->sim_clock + (double)c->cfg.fixed_dt;
         // every procedural body asleep and nothing edited since: the step changes nothing (each stage excludes sleeping
         // entities), so it is not run at all - a world at rest costs no GPU time, as in the reference
-        if (c->all_asleep) { ++c->step_index; continue; }
-        EH_TRY(run_stages(c, EDYNHIP_STAGE_ALL));
+        if (c->all_asleep) { ++c->step_index; c->sim_clock = stamp; continue; }
+        const int rc = run_stages(c, EDYNHIP_STAGE_ALL);
+        c->sim_clock = stamp;
+        if (rc != EDYNHIP_OK) return rc;
     }
+    return EDYNHIP_OK;
+}
+int edynhip_step(edynhip_ctx *c, uint32_t nsteps) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    return step_stamped(c, nsteps, false, 0, 0);
+}
+int edynhip_step_timed(edynhip_ctx *c, uint32_t nsteps, double first_step_time, double step_dt) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    return step_stamped(c, nsteps, true, first_step_time, step_dt);
+}
+
+int edynhip_get_params(edynhip_ctx *c, edynhip_params *out) {
+    if (!c || !out) return EDYNHIP_ERR_INVALID;
+    out->fixed_dt = c->cfg.fixed_dt;
+    out->num_velocity_iterations = c->cfg.num_velocity_iterations;
+    out->num_position_iterations = c->cfg.num_position_iterations;
+    std::memcpy(out->gravity, c->cfg.gravity, sizeof(out->gravity));
+    return EDYNHIP_OK;
+}
+__global__ void k_set_gravity(uint32_t n, Bodies b, float4 g) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (b.flags[i] & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) b.grav[i] = g;
+}
+int edynhip_set_params(edynhip_ctx *c, const edynhip_params *p) {
+    if (!c || !p || !(p->fixed_dt > 0)) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    c->cfg.fixed_dt = p->fixed_dt;
+    c->cfg.num_velocity_iterations = p->num_velocity_iterations;
+    c->cfg.num_position_iterations = p->num_position_iterations;
+    if (std::memcmp(c->cfg.gravity, p->gravity, sizeof(p->gravity)) != 0) {   // set_gravity: the setting and every body's gravity
+        std::memcpy(c->cfg.gravity, p->gravity, sizeof(p->gravity));
+        if (c->b.n) hipLaunchKernelGGL(k_set_gravity, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, make_float4(p->gravity[0], p->gravity[1], p->gravity[2], 0));
+        EH_HIP(c, hipGetLastError());
+        if (c->sleeping) EH_TRY(edynhip_wake_all(c));
+    }
+    return EDYNHIP_OK;
+}
+
+int edynhip_remove_bodies(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
+    if (!c || (n && !indices)) return EDYNHIP_ERR_INVALID;
+    if (n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    for (uint32_t k = 0; k < n; ++k) if (indices[k] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_remove_bodies: index out of range");
+    // joints attached to a removed body go with it (the node's edges are destroyed, island_manager.cpp:56-62)
+    std::vector<uint8_t> gone(c->b.n, 0);
+    for (uint32_t k = 0; k < n; ++k) gone[indices[k]] = 1;
+    bool joints_changed = false;
+    std::vector<uint32_t> partners;
+    if (!c->host_joints.empty()) {
+        EH_TRY(rebuild_joints(c, true));
+        for (HostJoint &h : c->host_joints)
+            if (h.alive && (gone[h.body[0]] || gone[h.body[1]])) { h.alive = false; joints_changed = true; partners.push_back(h.body[0]); partners.push_back(h.body[1]); }
+    }
+    uint32_t *list = nullptr;
+    EH_HIP(c, hipMalloc((void **)&list, (size_t)n * sizeof(uint32_t)));
+    EH_HIP(c, hipMemcpyAsync(list, indices, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.n * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_mark_removed, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, list, c->b, c->sleep_action);
+    if (c->num_manifolds) hipLaunchKernelGGL(k_wake_partners, dim3((c->num_manifolds + 255) / 256), dim3(256), 0, c->stream, c->num_manifolds, c->m[c->cur], c->b, c->sleep_action);
+    hipLaunchKernelGGL(k_wake_marked, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, c->sleep_action, c->sleep_since);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(list);
+    if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_remove_bodies", e);
+    for (uint32_t k = 0; k < n; ++k) { c->host_kind[indices[k]] = EDYNHIP_KIND_STATIC; c->host_shape[indices[k]] = EDYNHIP_SHAPE_NONE; }
+    if (!c->host_excl.empty())
+        for (uint32_t k = 0; k < n; ++k) std::fill(c->host_excl.begin() + (size_t)indices[k] * 16, c->host_excl.begin() + (size_t)indices[k] * 16 + 16, 0xFFFFFFFFu);
+    EH_TRY(rebuild_broadphase_lists(c));
+    if (joints_changed) { EH_TRY(rebuild_joints(c, false)); EH_TRY(wake_islands_of(c, partners)); }
+    c->force_islands = true;
+    c->all_asleep = false;
+    c->clears_primed = false;
     return EDYNHIP_OK;
 }
 
@@ -715,11 +959,11 @@ int edynhip_refresh_derived(edynhip_ctx *c) {
     return refresh_derived(c);
 }
 
-__global__ void k_wake_all(uint32_t n, uint32_t *flags, int32_t *since) {
+__global__ void k_wake_all(uint32_t n, uint32_t *flags, double *since) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     flags[i] &= ~BF_ASLEEP;
-    since[i] = -1;
+    since[i] = -1.0;
 }
 int edynhip_wake_all(edynhip_ctx *c) {
     if (!c) return EDYNHIP_ERR_INVALID;
@@ -844,16 +1088,22 @@ int edynhip_get_pairs(edynhip_ctx *c, uint64_t *keys, uint32_t capacity, uint32_
 
 int edynhip_get_joint_impulses(edynhip_ctx *c, float *out) {
     if (!c || !out) return EDYNHIP_ERR_INVALID;
+    const uint32_t total = (uint32_t)c->host_joints.size();
+    if (total == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    std::memset(out, 0, (size_t)total * 10 * sizeof(float));
     const uint32_t n = c->j.n;
     if (n == 0) return EDYNHIP_OK;
-    EH_HIP(c, hipSetDevice(c->device));
-    std::vector<float> imp((size_t)c->j.cap * 5);
+    std::vector<float> imp((size_t)c->j.cap * kJointSlots), ang(n);
     std::vector<uint32_t> orig(n);
     EH_HIP(c, hipMemcpyAsync(imp.data(), c->j.impulse, imp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipMemcpyAsync(ang.data(), c->j.angle, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipMemcpyAsync(orig.data(), c->j.orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
-    for (uint32_t p = 0; p < n; ++p)
-        for (int r = 0; r < 5; ++r) out[5 * orig[p] + r] = imp[(size_t)r * c->j.cap + p];
+    for (uint32_t p = 0; p < n; ++p) {
+        for (int r = 0; r < kJointSlots; ++r) out[10 * (size_t)orig[p] + r] = imp[(size_t)r * c->j.cap + p];
+        out[10 * (size_t)orig[p] + 9] = ang[p];
+    }
     return EDYNHIP_OK;
 }
 

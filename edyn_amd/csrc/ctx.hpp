@@ -22,6 +22,7 @@ constexpr uint32_t BF_SHAPE_SHIFT = 4;         // EDYNHIP_SHAPE_* in bits 4..7
 constexpr uint32_t BF_SHAPE_MASK = 0xF0u;
 constexpr uint32_t BF_ASLEEP = 0x100u;         // sleeping_tag: the body's island is asleep (island sleeping, solver.hip k_sleep_*)
 constexpr uint32_t BF_NOSLEEP = 0x200u;        // sleeping_disabled_tag
+constexpr uint32_t BF_REMOVED = 0x400u;        // destroyed entity: the index stays reserved (edynhip_remove_bodies)
 // An edge (manifold, joint) sleeps when every procedural endpoint sleeps (an island sleeps as a whole).
 __host__ __device__ inline bool edge_asleep(uint32_t fa, uint32_t fb) {
     const bool da = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC, db = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC;
@@ -66,21 +67,42 @@ struct Manifolds {
     float4 *imp = nullptr;        // normal_impulse, friction_impulse[0], [1], bitcast(lifetime)
 };
 
+// Joint rows live in SLOTS that mirror the constraints' applied_impulse fields (hinge_constraint.hpp:64-71,
+// point_constraint.hpp:28-29): hinge 0..2 linear, 3..4 hinge p/q, 5 limit, 6 bump stop, 7 spring, 8 torque; point 0..2 linear,
+// 3 friction torque. Which optional slots carry a row this step is decided by k_prep_joints (rmask).
+constexpr int kJointSlots = 9, kJointParams = 10;
 struct Joints {
     uint32_t n = 0, cap = 0, num_colours = 0, rows = 0;
-    // definitions, in colour-sorted order (static); orig[] maps back to the caller's index
+    // definitions, in colour-sorted order; orig[] maps back to the caller's index
     uint32_t *orig = nullptr;
     uint32_t *type = nullptr, *bodyA = nullptr, *bodyB = nullptr;
     float4 *pivA = nullptr, *pivB = nullptr;       // object-space pivots
     float4 *axA = nullptr;                          // frame[0] column 0 (hinge axis on A)
     float4 *pA = nullptr, *qA = nullptr;            // frame[0] columns 1, 2
-    float4 *axB = nullptr;                          // frame[1] column 0
-    float *impulse = nullptr;                       // [5][cap]
+    float4 *axB = nullptr, *pB = nullptr;           // frame[1] columns 0, 1
+    float *params = nullptr;                        // [kJointParams][cap]: hinge angle_min, angle_max, limit_restitution, bump_stop_angle,
+                                                    // bump_stop_stiffness, torque, speed, rest_angle, stiffness, damping; point: friction_torque
+    float *angle = nullptr;                         // [cap] hinge angle tracked across wraps (hinge_constraint.cpp:80-89)
+    float *impulse = nullptr;                       // [kJointSlots][cap] applied impulses (warm start)
     // rows (per step)
     float4 *rA = nullptr, *rB = nullptr;            // lever arms
     float4 *wp = nullptr, *wq = nullptr;            // world hinge p, q
-    float *eff = nullptr, *rhs = nullptr;           // [5][cap]
+    float4 *wax = nullptr;                          // world axis of the optional rows (hinge axis / relative spin direction)
+    float *eff = nullptr, *rhs = nullptr;           // [kJointSlots][cap]
+    float *lo = nullptr, *hi = nullptr;             // [kJointSlots][cap] impulse limits of the optional rows
+    uint32_t *rmask = nullptr;                      // [cap] slots that carry a row this step
     uint32_t colour_start[kMaxColours + 1] = {0};   // host copy
+};
+// Host mirror of the joint definitions by CALLER index (stable; a removed joint stays as a dead entry): the device arrays are
+// rebuilt from it - colouring included - whenever joints are added or removed, carrying the applied impulses over.
+struct HostJoint {
+    int32_t type = 0;
+    uint32_t body[2] = {0, 0};
+    float pivot[6] = {0}, axis[6] = {0};
+    float params[kJointParams] = {0};
+    float impulse[kJointSlots] = {0};
+    float angle = 0;
+    bool alive = true;
 };
 
 // Solver rows in colour-sorted order p. The per-colour solve kernels are latency / issue bound (a colour of
@@ -185,6 +207,7 @@ struct edynhip_ctx {
     int cur = 0;                   // index of the current manifold buffer
     uint32_t num_manifolds = 0;    // in m[cur]
     eh::Joints j;
+    std::vector<eh::HostJoint> host_joints;   // by caller index (see HostJoint)
     eh::Rows rows;
     eh::LBVH bvh;
     uint64_t *pair_keys = nullptr, *pair_keys_sorted = nullptr;
@@ -219,9 +242,14 @@ struct edynhip_ctx {
     float *state_host = nullptr;   // pinned mirror
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
-    uint32_t step_index = 0;       // completed steps (island sleep timers count in steps)
+    uint32_t step_index = 0;       // completed steps
+    // Island sleep timers run on the step time stamps the stepper hands to the island manager (stepper_sequential.cpp:60-75,
+    // island_manager.cpp:533-539,605-623): sim_clock is the island manager's m_last_time, i.e. the stamp of the PREVIOUS step while
+    // a step runs - advanced by fixed_dt per edynhip_step step, set by the caller in edynhip_step_timed (the
+    // max_steps_per_update clamp stretches the stamps, not the integration dt).
+    double sim_clock = 0;
     uint32_t *sleep_state = nullptr, *sleep_action = nullptr;   // per island label: reduction bits / decision
-    int32_t *sleep_since = nullptr;                             // per island label: step at which its timer started, -1 = not running
+    double *sleep_since = nullptr;                              // per island label: stamp at which its timer started, < 0 = not running
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel
@@ -244,7 +272,9 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
                   float *out, uint32_t *count);
 int islands(edynhip_ctx *c);
 int solve(edynhip_ctx *c);
-int refresh_derived(edynhip_ctx *c);   // AABBs + world inertias from the current transforms (solver.hip)
+int refresh_derived(edynhip_ctx *c);
+int joint_reset_angles(edynhip_ctx *c, const uint8_t *which_dev);   // reset_angle of the marked (sorted-order) joints
+int wake_islands_of(edynhip_ctx *c, const std::vector<uint32_t> &bodies);   // capi.hip   // AABBs + world inertias from the current transforms (solver.hip)
 // sort helpers (sort.hip)
 size_t sort_temp_bytes(uint32_t max_items);
 int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit);

@@ -14,6 +14,8 @@ namespace dm {
 constexpr float kEps = FLT_EPSILON;
 constexpr float kScalarMax = FLT_MAX;
 constexpr float kLarge = 1e18f;
+constexpr float kPi = 3.1415926535897932384626433832795029f;   // math/constants.hpp:10-12
+constexpr float kPi2 = kPi * 2.0f;
 constexpr float kHalfSqrt2 = 0.7071067811865475244008443621048490f;
 
 struct f3 { float x, y, z; };

@@ -145,8 +145,7 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
 // Islands are identified by their label (lowest body index). Per step, after the labels: (1) reduce every island's
 // bodies into state bits, (2) mark the islands that received a manifold created this step, (3) one lane per island
 // decides - wake (new edge, or sleeping and awake bodies merged), keep sleeping, run / restart the timer, go to sleep
-// once the timer has run for more than island_time_to_sleep (the reference compares the previous update's time
-// stamps, i.e. elapsed steps x dt) - (4) every body applies its island's decision (put_to_sleep zeroes velocities).
+// once the timer has run for more than island_time_to_sleep (measured on the step time stamps, ctx.hpp sim_clock) - (4) every body applies its island's decision (put_to_sleep zeroes velocities).
 enum { SL_FAST = 1, SL_DISABLED = 2, SL_HAS_ASLEEP = 4, SL_HAS_AWAKE = 8, SL_WAKE = 16 };
 enum { SLA_KEEP = 0, SLA_AWAKE = 1, SLA_SLEEP = 2 };
 __global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state) {
@@ -166,19 +165,20 @@ __global__ void k_sleep_edges(const uint2 *__restrict__ edges, const Counters *c
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
         atomicOr(&state[label[edges[e].x]], (uint32_t)SL_WAKE);   // .x = the pair's owner: always procedural
 }
-__global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *action, int32_t *since, uint32_t step, float dt) {
+__global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *action, double *since, double now) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = state[i];
     state[i] = 0;
-    if (!is_dynamic(b.flags[i]) || b.island[i] != i) { since[i] = -1; return; }
+    if (!is_dynamic(b.flags[i]) || b.island[i] != i) { since[i] = -1.0; return; }
     const bool wake = (s & SL_WAKE) || ((s & SL_HAS_ASLEEP) && (s & SL_HAS_AWAKE));
     if ((s & SL_HAS_ASLEEP) && !(s & SL_HAS_AWAKE) && !wake) { action[i] = SLA_KEEP; return; }
     uint32_t a = SLA_AWAKE;
     if (!(s & SL_DISABLED) && !(s & SL_FAST)) {
-        if (since[i] < 0) since[i] = (int32_t)step;
-        else if ((double)(step - (uint32_t)since[i]) * (double)dt > 2.0) { a = SLA_SLEEP; since[i] = -1; }
-    } else since[i] = -1;
+        const double t0 = since[i];
+        if (!(t0 >= 0.0)) since[i] = now;                                    // not running (a negative value or the all-ones fill)
+        else if (now - t0 > 2.0) { a = SLA_SLEEP; since[i] = -1.0; }         // island_time_to_sleep, constants.hpp:48
+    } else since[i] = -1.0;
     action[i] = a;
 }
 __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__ action, Counters *cnt) {
@@ -893,7 +893,9 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
 }
 
 // ------------------------------------------------------------------ joints (point, hinge)
-DI void joint_rowJ(int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
+// Slot r of a joint (ctx.hpp Joints): 0..2 the three linear rows, hinge 3/4 the rows along p and q, every other slot an
+// axial row {0, ax, 0, -ax} along `wax` (hinge axis for slots 5..8 of a hinge, relative spin for slot 3 of a point joint).
+DI void joint_rowJ(bool hinge, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
     if (r < 3) {
         // J = {I.row[i], -skew(rA).row[i], -I.row[i], skew(rB).row[i]}
         f3 e = r == 0 ? mk3(1, 0, 0) : (r == 1 ? mk3(0, 1, 0) : mk3(0, 0, 1));
@@ -901,9 +903,18 @@ DI void joint_rowJ(int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 &J0, f3 &J1, f3 &J2, f3
         f3 sb = r == 0 ? mk3(0, -rB.z, rB.y) : (r == 1 ? mk3(rB.z, 0, -rB.x) : mk3(-rB.y, rB.x, 0));
         J0 = e; J1 = -sa; J2 = -e; J3 = sb;
     } else {
-        f3 ax = r == 3 ? wp : wq;
+        f3 ax = (hinge && r == 3) ? wp : ((hinge && r == 4) ? wq : wax);
         J0 = mk3(0, 0, 0); J1 = ax; J2 = mk3(0, 0, 0); J3 = -ax;
     }
+}
+// atan2 evaluated in double and rounded once: correctly rounded fp32, the same value on the device and in the oracle
+// (the reference's std::atan2(float) depends on the C library's last bit - the same convention as integrate()'s sin/cos).
+DI float atan2_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+DI float normalize_angle(float a) {   // math.hpp:53-63
+    a = fmodf(a, kPi2);
+    if (a < -kPi) return a + kPi2;
+    if (a > kPi) return a - kPi2;
+    return a;
 }
 __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -914,19 +925,94 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
     const bool hinge = j.type[i] == EDYNHIP_JOINT_HINGE;
-    f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0);
+    f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0), wax = mk3(0, 0, 0);
     if (hinge) { wp = rotate(A.orn, from4(j.pA[i])); wq = rotate(A.orn, from4(j.qA[i])); }
-    j.rA[i] = to4(rA, 0); j.rB[i] = to4(rB, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0);
-    const int nr = hinge ? 5 : 3;
-    for (int r = 0; r < nr; ++r) {
+    auto P = [&](int k) { return j.params[(size_t)k * j.cap + i]; };
+    uint32_t mask = hinge ? 0x1Fu : 0x7u;
+    // optional rows: per-slot error / restitution / limits (hinge_constraint.cpp:69-178, point_constraint.cpp:33-46)
+    float err[kJointSlots], rest[kJointSlots], lo[kJointSlots], hi[kJointSlots];
+#pragma unroll
+    for (int r = 0; r < kJointSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
+    if (!hinge) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) err[r] = (comp(pA, r) - comp(pB, r)) / dt;
+        const float friction_torque = P(0);
+        if (friction_torque > 0) {
+            f3 spin = A.w - B.w;
+            const float lsqr = length_sqr(spin);
+            if ((double)lsqr > 1e-18) {   // try_normalize, vector3.hpp:239-248
+                wax = spin / sqrtf(lsqr);
+                const float fi = friction_torque * dt;
+                lo[3] = -fi; hi[3] = fi;
+                mask |= 1u << 3;
+            }
+        }
+    } else {
+        const float angle_min = P(0), angle_max = P(1), limit_restitution = P(2), bump_stop_angle = P(3), bump_stop_stiffness = P(4),
+                    torque = P(5), speed = P(6), rest_angle = P(7), stiffness = P(8), damping = P(9);
+        const bool has_limit = angle_min < angle_max, has_spring = stiffness > 0, has_torque = torque > 0 || damping > 0;
+        if (has_limit || has_spring || has_torque) wax = rotate(A.orn, from4(j.axA[i]));
+        float angle = j.angle[i];
+        if (has_limit || has_spring) {
+            const f3 angle_axisB = rotate(B.orn, from4(j.pB[i]));
+            const float current = atan2_cr(dot(angle_axisB, wq), dot(angle_axisB, wp));
+            const float previous = normalize_angle(angle);
+            const float d0 = current - previous;
+            const float d1 = d0 + kPi2 * (d0 < 0 ? 1.0f : -1.0f);
+            angle += fabsf(d0) < fabsf(d1) ? d0 : d1;
+            j.angle[i] = angle;
+        }
+        if (has_limit) {
+            const float halfway = (angle_min + angle_max) / 2.0f;
+            float limit_error;
+            if (angle < halfway) { limit_error = angle_min - angle; lo[5] = -kLarge; hi[5] = 0; }
+            else { limit_error = angle_max - angle; lo[5] = 0; hi[5] = kLarge; }
+            err[5] = limit_error / dt; rest[5] = limit_restitution;
+            mask |= 1u << 5;
+            if (bump_stop_stiffness > 0 && bump_stop_angle > 0) {
+                float defl = 0;
+                const float bmin = angle_min + bump_stop_angle, bmax = angle_max - bump_stop_angle;
+                if (angle < bmin) defl = angle - bmin;
+                else if (angle > bmax) defl = angle - bmax;
+                if (defl != 0) {
+                    const float imp = bump_stop_stiffness * defl * dt;
+                    lo[6] = fminf(imp, 0.0f); hi[6] = fmaxf(0.0f, imp);
+                    err[6] = -defl / dt;
+                    mask |= 1u << 6;
+                }
+            }
+        }
+        if (has_spring) {
+            const float defl = angle - rest_angle;
+            const float imp = stiffness * defl * dt;
+            lo[7] = fminf(imp, 0.0f); hi[7] = fmaxf(0.0f, imp);
+            err[7] = -defl / dt;
+            mask |= 1u << 7;
+        }
+        if (has_torque) {
+            float ti = torque * dt;
+            if (damping > 0) {
+                const float relvel = dot(A.w, wax) - dot(B.w, wax);
+                ti += fabsf(relvel) * damping * dt;
+            }
+            lo[8] = -ti; hi[8] = ti;
+            err[8] = -speed;
+            mask |= 1u << 8;
+        }
+    }
+    j.rA[i] = to4(rA, 0); j.rB[i] = to4(rB, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0); j.wax[i] = to4(wax, 0);
+    j.rmask[i] = mask;
+#pragma unroll
+    for (int r = 0; r < kJointSlots; ++r) {
+        if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(r, rA, rB, wp, wq, J0, J1, J2, J3);
-        float error = 0;
-        if (!hinge) error = (comp(pA, r) - comp(pB, r)) / dt;
-        float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
-        float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
-        j.eff[(size_t)r * j.cap + i] = em;
-        j.rhs[(size_t)r * j.cap + i] = -(error * 0.2f + relvel * (1 + 0.0f));
+        joint_rowJ(hinge, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
+        const float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
+        const size_t s = (size_t)r * j.cap + i;
+        j.eff[s] = em;
+        j.rhs[s] = -(err[r] * 0.2f + relvel * (1 + rest[r]));
+        j.lo[s] = lo[r]; j.hi[s] = hi[r];
     }
 }
 template <bool WARM>
@@ -937,26 +1023,44 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;
     Delta d;
     load_delta(b, ia, ib, d);
-    const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]);
-    const int nr = j.type[i] == EDYNHIP_JOINT_HINGE ? 5 : 3;
-    for (int r = 0; r < nr; ++r) {
+    const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]);
+    const bool hinge = j.type[i] == EDYNHIP_JOINT_HINGE;
+    const uint32_t mask = j.rmask[i];
+    for (int r = 0; r < kJointSlots; ++r) {
+        if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(r, rA, rB, wp, wq, J0, J1, J2, J3);
+        joint_rowJ(hinge, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
         const size_t s = (size_t)r * j.cap + i;
         float imp = j.impulse[s];
         if (WARM) {
             apply_impulse(d, J0, J1, J2, J3, imp);
         } else {
+            const float lo = j.lo[s], hi = j.hi[s];
             float drel = rel_speed(J0, J1, J2, J3, d.dvA, d.dwA, d.dvB, d.dwB);
             float dimp = (j.rhs[s] - drel) * j.eff[s];
             float ni = imp + dimp;
-            if (ni < -kScalarMax) { dimp = -kScalarMax - imp; ni = -kScalarMax; }
-            else if (ni > kScalarMax) { dimp = kScalarMax - imp; ni = kScalarMax; }
+            if (ni < lo) { dimp = lo - imp; ni = lo; }
+            else if (ni > hi) { dimp = hi - imp; ni = hi; }
             j.impulse[s] = ni;
             apply_impulse(d, J0, J1, J2, J3, dimp);
         }
     }
     store_delta(b, ia, ib, d);
+}
+// hinge_constraint::reset_angle (hinge_constraint.cpp:19-24) for the joints whose definition was just (re)written
+__global__ void k_joint_reset_angle(Joints j, Bodies b, const uint8_t *__restrict__ which) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n || !which[i] || j.type[i] != EDYNHIP_JOINT_HINGE) return;
+    const q4 ornA = q_from4(B_ORN(b, j.bodyA[i])), ornB = q_from4(B_ORN(b, j.bodyB[i]));
+    const f3 p = rotate(ornA, from4(j.pA[i])), q = rotate(ornA, from4(j.qA[i]));
+    const f3 angle_axisB = rotate(ornB, from4(j.pB[i]));
+    j.angle[i] = atan2_cr(dot(angle_axisB, q), dot(angle_axisB, p));
+}
+int joint_reset_angles(edynhip_ctx *c, const uint8_t *which_dev) {
+    if (c->j.n == 0) return EDYNHIP_OK;
+    hipLaunchKernelGGL(k_joint_reset_angle, dim3(blocks(c->j.n, 128)), dim3(128), 0, c->stream, c->j, c->b, which_dev);
+    EH_HIP(c, hipGetLastError());
+    return EDYNHIP_OK;
 }
 
 // ------------------------------------------------------------------ integration
@@ -1608,7 +1712,7 @@ int islands(edynhip_ctx *c) {
     if (c->sleeping) {
         hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
         hipLaunchKernelGGL(k_sleep_edges, dim3(32), dim3(256), 0, s, c->new_edges, c->cnt, c->b.island, c->sleep_state);
-        hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->step_index, c->cfg.fixed_dt);
+        hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->sim_clock);
         hipLaunchKernelGGL(k_sleep_apply, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_action, c->cnt);
     }
     EH_HIP(c, hipGetLastError());

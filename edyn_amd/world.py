@@ -64,14 +64,18 @@ def _ptr(a):
 
 
 def fixed_step_plan(accumulated, elapsed, fixed_dt, max_steps):
-    """stepper_sequential::update's accumulator (stepper_sequential.cpp:45-65): returns
-    (effective_steps, new_accumulated). num_steps = floor(acc / dt); the remainder stays accumulated; the number
-    of steps actually run is clamped to max_steps_per_update (the reference then stretches step_dt, which this
-    stepper does not: it always steps by fixed_dt and drops the excess)."""
+    """stepper_sequential::update's accumulator (stepper_sequential.cpp:45-66): returns
+    (effective_steps, new_accumulated, step_dt). num_steps = floor(acc / dt); the remainder stays accumulated; the
+    number of steps actually run is clamped to max_steps_per_update, and then the time stamps of the steps that do run
+    are stretched over the whole advance: step_dt = num_steps * dt / effective_steps (it feeds the island sleep
+    timers only - the solver always integrates with fixed_dt, solver.cpp:390)."""
     accumulated += max(elapsed, 0.0)
     num_steps = int(math.floor(accumulated / fixed_dt))
-    accumulated -= num_steps * fixed_dt
-    return min(num_steps, max_steps), accumulated
+    advance = num_steps * fixed_dt
+    accumulated -= advance
+    if num_steps > max_steps:
+        return max_steps, accumulated, advance / max_steps
+    return num_steps, accumulated, fixed_dt
 
 
 class World:
@@ -132,8 +136,10 @@ class World:
         self._dirty = True
         return len(self._defs) - 1
 
-    def make_constraint(self, jtype, body0, body1, pivot0, pivot1, axis0=(1, 0, 0), axis1=(1, 0, 0)) -> int:
-        self._joints.append((jtype, body0, body1, tuple(pivot0), tuple(pivot1), tuple(axis0), tuple(axis1)))
+    def make_constraint(self, jtype, body0, body1, pivot0, pivot1, axis0=(1, 0, 0), axis1=(1, 0, 0), params=None) -> int:
+        """edyn::make_constraint<point_constraint|hinge_constraint>; params = the optional-row settings (see edynhip_joints)."""
+        j = (jtype, body0, body1, tuple(pivot0), tuple(pivot1), tuple(axis0), tuple(axis1))
+        self._joints.append(j + ((tuple(params),) if params is not None else ()))
         self._dirty = True
         return len(self._joints) - 1
 
@@ -163,17 +169,70 @@ class World:
             setattr(b, f, _ptr(a.get(f)))
         return n, a, b   # `a` keeps the arrays alive while `b` points into them
 
+    @staticmethod
+    def _joint_arrays(joints):
+        jt = np.array([j[0] for j in joints], np.int32)
+        jb = np.array([[j[1], j[2]] for j in joints], np.uint32)
+        jp = np.array([[j[3], j[4]] for j in joints], np.float32).reshape(-1, 6)
+        ja = np.array([[j[5], j[6]] for j in joints], np.float32).reshape(-1, 6)
+        jq = np.zeros((len(joints), 10), np.float32)
+        for i, j in enumerate(joints):
+            if len(j) > 7:
+                jq[i, :len(j[7])] = j[7]
+        keep = (jt, jb, jp, ja, jq)
+        return keep, _capi.Joints(_ptr(jt), _ptr(jb), _ptr(jp), _ptr(ja), _ptr(jq))
+
     def _upload_joints(self, joints):
         self.nj = len(joints)
         if joints:
-            jt = np.array([j[0] for j in joints], np.int32)
-            jb = np.array([[j[1], j[2]] for j in joints], np.uint32)
-            jp = np.array([[j[3], j[4]] for j in joints], np.float32).reshape(-1, 6)
-            ja = np.array([[j[5], j[6]] for j in joints], np.float32).reshape(-1, 6)
-            js = _capi.Joints(_ptr(jt), _ptr(jb), _ptr(jp), _ptr(ja))
+            keep, js = self._joint_arrays(joints)
             self._check(self._L.edynhip_set_joints(self._h, len(joints), C.byref(js)))
         else:
             self._check(self._L.edynhip_set_joints(self._h, 0, None))
+
+    def add_joints(self, joints):
+        """Append joints to a running world (applied impulses of the existing ones are kept). Returns the first new index."""
+        keep, js = self._joint_arrays(joints)
+        first = C.c_uint32(0)
+        self._check(self._L.edynhip_add_joints(self._h, len(joints), C.byref(js), C.byref(first)))
+        self.nj += len(joints)
+        return first.value
+
+    def remove_joints(self, indices):
+        """registry.destroy(constraint entity): the indices stay reserved."""
+        self._flush_defs()
+        idx = np.ascontiguousarray(indices, np.uint32)
+        self._check(self._L.edynhip_remove_joints(self._h, len(idx), _ptr(idx)))
+
+    def set_joint_params(self, joint, params):
+        self._flush_defs()
+        p = np.zeros(10, np.float32); p[:len(params)] = params
+        self._check(self._L.edynhip_set_joint_params(self._h, int(joint), _ptr(p)))
+
+    def remove_bodies(self, indices):
+        """registry.destroy(rigid body) on a running world: manifolds and joints of the body go with it, its index stays reserved."""
+        self._flush_defs()
+        idx = np.ascontiguousarray(indices, np.uint32)
+        self._check(self._L.edynhip_remove_bodies(self._h, len(idx), _ptr(idx)))
+
+    def set_params(self, fixed_dt=None, velocity_iterations=None, position_iterations=None, gravity=None):
+        """set_fixed_dt / set_solver_*_iterations / set_gravity on the running world: no contact state is lost."""
+        self._flush_defs()
+        p = _capi.Params()
+        self._check(self._L.edynhip_get_params(self._h, C.byref(p)))
+        if fixed_dt is not None:
+            p.fixed_dt = fixed_dt; self.cfg.fixed_dt = fixed_dt
+        if velocity_iterations is not None:
+            p.num_velocity_iterations = velocity_iterations; self.cfg.num_solver_velocity_iterations = velocity_iterations
+        if position_iterations is not None:
+            p.num_position_iterations = position_iterations; self.cfg.num_solver_position_iterations = position_iterations
+        if gravity is not None:
+            p.gravity = (C.c_float * 3)(*[float(x) for x in gravity]); self.cfg.gravity = tuple(gravity)
+        self._check(self._L.edynhip_set_params(self._h, C.byref(p)))
+
+    def step_timed(self, n, first_step_time, step_dt):
+        self._flush_defs()
+        self._check(self._L.edynhip_step_timed(self._h, n, float(first_step_time), float(step_dt)))
 
     def set_scene(self, scene):
         """Bulk scene upload from a dict of arrays (see edyn_amd.scenes). Replaces the whole world."""
@@ -230,10 +289,11 @@ class World:
         self._flush_defs()
         if self._paused:
             return 0
-        steps, self._accum = fixed_step_plan(self._accum, time - self._last_time, float(np.float32(self.cfg.fixed_dt)),
-                                             self.cfg.max_steps_per_update)
+        sim_time = self._last_time - self._accum      # get_simulation_timestamp() before this update
+        steps, self._accum, step_dt = fixed_step_plan(self._accum, time - self._last_time, float(np.float32(self.cfg.fixed_dt)),
+                                                      self.cfg.max_steps_per_update)
         if steps:
-            self._check(self._L.edynhip_step(self._h, steps))
+            self._check(self._L.edynhip_step_timed(self._h, steps, sim_time, step_dt))
         self._last_time = time
         return steps
 
@@ -308,7 +368,8 @@ class World:
         return keys
 
     def get_joint_impulses(self):
-        out = np.zeros((self.nj, 5), np.float32)
+        """[n, 10] by caller index: the 9 applied-impulse slots + the tracked hinge angle (edynhip_get_joint_impulses)."""
+        out = np.zeros((self.nj, 10), np.float32)
         if self.nj:
             self._check(self._L.edynhip_get_joint_impulses(self._h, _ptr(out)))
         return out

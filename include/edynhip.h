@@ -101,7 +101,20 @@ typedef struct {
     const uint32_t *body;            /* [n][2] */
     const float *pivot;              /* [n][2][3] object-space pivots */
     const float *axis;               /* [n][2][3] hinge axes in object space (ignored for point joints) */
+    const float *params;             /* [n][10] or NULL (all zero). hinge_constraint (hinge_constraint.hpp:30-62): angle_min, angle_max,
+                                        limit_restitution, bump_stop_angle, bump_stop_stiffness, torque, speed, rest_angle, stiffness,
+                                        damping - limits are active when angle_min < angle_max, the spring when stiffness > 0, the
+                                        torque row when torque > 0 or damping > 0. point_constraint (point_constraint.hpp:25):
+                                        [0] = friction_torque. */
 } edynhip_joints;
+
+/* settings that may change on a running world (include/edyn/context/settings.hpp:22-30) */
+typedef struct {
+    float fixed_dt;
+    uint32_t num_velocity_iterations;
+    uint32_t num_position_iterations;
+    float gravity[3];
+} edynhip_params;
 
 /* One contact point; mirrors contact_point + contact_point_geometry + _material + _impulse. */
 typedef struct {
@@ -156,11 +169,33 @@ int edynhip_set_joints(edynhip_ctx *ctx, uint32_t n, const edynhip_joints *joint
  * manifolds (cached impulses, colours) and joints are untouched: this is registry.create + make_rigidbody on a running
  * world (src/edyn/util/rigidbody.cpp:18-161; the reference's island worker receives the new entities through
  * registry_operation insertions, src/edyn/simulation/simulation_worker.cpp). Removal is not supported without a
- * full edynhip_set_bodies (indices would shift). */
+ * full edynhip_set_bodies (indices would shift) - or edynhip_remove_bodies, which keeps indices by leaving a tombstone. */
 int edynhip_add_bodies(edynhip_ctx *ctx, uint32_t n, const edynhip_bodies *bodies);
+
+/* Joints on a running world: make_constraint / registry.destroy(constraint entity) (include/edyn/util/constraint_util.hpp:38-54,
+ * island_manager.cpp:68-97). Joint indices are the order of creation and stay valid for the life of the world (a removed joint
+ * keeps its index); applied impulses and hinge angles of the other joints are carried over. *first_index = index of the first
+ * joint added. edynhip_set_joint_params = registry.patch<hinge|point_constraint> followed by reset_angle. */
+int edynhip_add_joints(edynhip_ctx *ctx, uint32_t n, const edynhip_joints *joints, uint32_t *first_index);
+int edynhip_remove_joints(edynhip_ctx *ctx, uint32_t n, const uint32_t *joint_indices);
+int edynhip_set_joint_params(edynhip_ctx *ctx, uint32_t joint_index, const float *params10);
+/* registry.destroy(rigid body) on a running world (src/edyn/edyn.cpp:148-197 hooks, island_manager.cpp:47-115): the body's
+ * manifolds and contact points disappear with the next step, joints attached to it are removed, the islands it touched wake
+ * up. The body INDEX stays reserved (the slot reads back as a shapeless static body); every other index, manifold, warm-start
+ * impulse and sleep timer is untouched. */
+int edynhip_remove_bodies(edynhip_ctx *ctx, uint32_t n, const uint32_t *body_indices);
+/* settings on a running world WITHOUT losing state: set_fixed_dt, set_solver_velocity/position_iterations, set_gravity
+ * (src/edyn/edyn.cpp:203-207, src/edyn/config/solver_iteration_config.cpp:9-75, src/edyn/util/gravity_util.cpp:12-20 - like the
+ * reference, set_gravity also replaces the gravity of every dynamic body). */
+int edynhip_get_params(edynhip_ctx *ctx, edynhip_params *out);
+int edynhip_set_params(edynhip_ctx *ctx, const edynhip_params *params);
 
 /* Advance `nsteps` fixed-dt steps. Returns after the work is enqueued and error flags were checked. */
 int edynhip_step(edynhip_ctx *ctx, uint32_t nsteps);
+/* The same with explicit step time stamps: step i runs at first_step_time + i * step_dt. The stamps only feed the island
+ * sleep timers; integration always uses fixed_dt. This is stepper_sequential::update's behaviour when more steps are due
+ * than max_steps_per_update allows: the steps that do run get stretched stamps (stepper_sequential.cpp:60-75). */
+int edynhip_step_timed(edynhip_ctx *ctx, uint32_t nsteps, double first_step_time, double step_dt);
 /* Run a subset of one step's stages (parity tests). */
 int edynhip_run_stages(edynhip_ctx *ctx, uint32_t stage_mask);
 /* Block until all enqueued work of this ctx has finished. */
@@ -192,7 +227,9 @@ int edynhip_get_manifolds(edynhip_ctx *ctx, edynhip_manifold *out, uint32_t capa
 int edynhip_set_manifolds(edynhip_ctx *ctx, const edynhip_manifold *in, uint32_t n);
 /* Canonical broadphase pairs: keys[i] = (max(body)<<32 | min(body)), ascending. */
 int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint32_t *n);
-int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses5);
+/* Per joint (by caller index, removed joints read 0) 10 floats: the applied impulses by slot - hinge: linear[3], hinge[2], limit,
+ * bump_stop, spring, torque; point: applied[3], friction - and the tracked hinge angle (hinge_constraint.hpp:62-71). */
+int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses10);
 
 /* Test hook: run the device closest-feature routine on `n` independent shape pairs (no world state involved).
  * shape_type[n][2], shape_param[n][2][4], pos[n][2][3], orn[n][2][4]; out_points[n][4][11] =

@@ -233,10 +233,13 @@ class World:
             for j in joints:
                 self.add_joint(*j)
 
-    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0)):
+    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0), params=None):
         self.n_joints += 1
-        return self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
-                                    _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+        j = self.L.orc_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
+                                 _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+        if params is not None:
+            self.set_joint_params(j, params)
+        return j
 
     def exclude_collision(self, a, b):
         f = self.L.orc_exclude_collision; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
@@ -483,10 +486,13 @@ class RefWorld:
         for j in scene.get("joints") or []:
             self.add_joint(*j)
 
-    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0)):
+    def add_joint(self, jtype, a, b, pivotA, pivotB, axisA=(1, 0, 0), axisB=(1, 0, 0), params=None):
         self.n_joints += 1
-        return self.L.refw_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
-                                     _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+        j = self.L.refw_add_joint(self.h, jtype, a, b, _fp(_f32(pivotA, 3)), _fp(_f32(pivotB, 3)),
+                                  _fp(_f32(axisA, 3)), _fp(_f32(axisB, 3)))
+        if params is not None:
+            self.set_joint_params(j, params)
+        return j
 
     def set_joint_params(self, joint, params):
         p = np.zeros(10, np.float32); p[:len(params)] = params

@@ -208,7 +208,7 @@ public:
     // Island sleep timers run on the step TIME STAMPS the stepper hands to the island manager (stepper_sequential.cpp:60-75,
     // island_manager.cpp:605-623): sim_clock is the stamp of the step being run; step() advances it by fixed dt, step_timed()
     // by the caller's stretched step_dt (the max_steps_per_update clamp scales the stamps, not the integration dt).
-    double sim_clock = 0;
+    double sim_clock = 0;   // the island manager's m_last_time: the stamp of the last step whose island update has run
     std::vector<double> sleep_since;       // per label: time stamp at which the island first qualified for sleep, < 0 = not counting
     std::vector<uint64_t> new_keys;        // manifolds created by this step's broadphase (they wake their island)
 
@@ -306,7 +306,7 @@ public:
     // One fixed-dt step (stepper_sequential.cpp:121-147 step_simulation order).
     void step() { step_timed(sim_clock + (double)dt); }
     void step_timed(double step_time) {
-        sim_clock = step_time;
+        pending_stamp_ = step_time;
         broadphase();
         narrowphase();
         update_islands();
@@ -578,7 +578,8 @@ public:
             if (bodies[i].procedural() && island_label[i] == i) ++count;
         }
         stats.num_islands = count;
-        if (sleeping) update_sleep();
+        if (sleeping) update_sleep();   // island_manager::update: put_islands_to_sleep() still sees the PREVIOUS step's stamp ...
+        sim_clock = pending_stamp_;     // ... and only then m_last_time = timestamp (island_manager.cpp:533-539)
     }
     // wake_up / put_islands_to_sleep (island_manager.cpp:524-539, 573-623). An island that received a new edge, or
     // that holds both sleeping and awake bodies (a merge), wakes as a whole. An awake island whose bodies are all below
@@ -1113,6 +1114,7 @@ private:
     DynTree tree_, np_tree_;
     vec3 dummy_dv_{0, 0, 0}, dummy_dw_{0, 0, 0};
     bool joints_coloured_ = false;
+    double pending_stamp_ = 0;
     bool colour_overflow_ = false;
 };
 

@@ -58,6 +58,7 @@ struct ref_world {
     double time = 0;
     float dt = 1.0f / 60;
     bool attached = false;
+    bool paused = true;
     ~ref_world() { if (attached) edyn::detach(registry); }
 };
 
@@ -197,6 +198,7 @@ void refw_exclude_collision(void *h, uint32_t a, uint32_t b) {
 
 void refw_step(void *h, int n) {
     auto *w = (ref_world *)h;
+    if (!w->paused) { edyn::set_paused(w->registry, true); w->paused = true; }
     for (int i = 0; i < n; ++i) {
         w->time += (double)w->dt;
         edyn::step_simulation(w->registry, w->time);
@@ -210,7 +212,10 @@ double refw_time_steps(void *h, int n) {
 // edyn::update(registry, time) with the accumulator (stepper_sequential.cpp:28-119); returns nothing, state is read back.
 void refw_update(void *h, double time, int paused) {
     auto *w = (ref_world *)h;
-    edyn::set_paused(w->registry, paused != 0);
+    if ((paused != 0) != w->paused) {   // set_paused also clears the accumulator (stepper_sequential.cpp:149-152): only on a change
+        edyn::set_paused(w->registry, paused != 0);
+        w->paused = paused != 0;
+    }
     edyn::update(w->registry, time);
 }
 void refw_set_max_steps_per_update(void *h, unsigned n) { edyn::set_max_steps_per_update(((ref_world *)h)->registry, n); }

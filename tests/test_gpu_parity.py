@@ -668,6 +668,104 @@ def test_collision_exclusion_lists_bit_exact():
     assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="exclusion")
 
 
+# ------------------------------------------------------------------ optional joint rows, removal, runtime settings
+def _lock_gpu_oracle(g, o, steps, keep=None, what=""):
+    for step in range(steps):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), (what, step)
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a if keep is None else a[keep], b if keep is None else b[keep]), (what, step)
+    assert np.array_equal(g.get_joint_impulses(), o.get_joint_impulses()), what
+
+
+def test_hinge_and_point_optional_rows_bit_exact():
+    """hinge_constraint.cpp:69-178 (angle tracking, limit + restitution, bump stop, spring, torque / damping) and
+    point_constraint.cpp:33-46 (friction torque) on swinging chains: state, applied impulses by slot and tracked angles
+    identical to the oracle's (which tests/test_reference_engine.py pins to the real engine)."""
+    sc = scenes.c5_chains(16, 8)
+    sc["angvel"][:] = (np.random.default_rng(3).normal(size=sc["angvel"].shape) * 2).astype(np.float32)
+    hinge_p = [-0.5, 0.5, 0.3, 0.2, 2.0, 0.01, 0.0, 0.1, 1.0, 0.02]
+    sc["joints"] = [j + ((hinge_p if j[0] == scenes.JOINT_HINGE else [0.03]),) for j in sc["joints"]]
+    g = gpu_world(sc); o = oracle_world(sc)
+    for i, j in enumerate(sc["joints"]):
+        o.set_joint_params(i, j[7])
+    _lock_gpu_oracle(g, o, 250, what="optional rows")
+    ji = g.get_joint_impulses()
+    assert np.abs(ji[:, 5:9]).max() > 0 and np.abs(ji[:, 9]).max() > 0
+    # parameters changed on the running world (patch<hinge_constraint> + reset_angle)
+    g.set_joint_params(0 if sc["joints"][0][0] == scenes.JOINT_HINGE else 1, [-0.1, 0.1, 0, 0, 0, 0, 0, 0, 0, 0])
+    o.set_joint_params(0 if sc["joints"][0][0] == scenes.JOINT_HINGE else 1, [-0.1, 0.1, 0, 0, 0, 0, 0, 0, 0, 0])
+    _lock_gpu_oracle(g, o, 60, what="patched joint")
+
+
+def test_remove_bodies_and_joints_on_a_running_world_bit_exact():
+    """edynhip_remove_bodies / edynhip_remove_joints / edynhip_add_joints = registry.destroy / make_constraint on a running
+    world: manifolds and joints of a destroyed body disappear, the other bodies keep their contact state and indices."""
+    sc = scenes.box_pile(4, 4, 4)
+    g = gpu_world(sc); o = oracle_world(sc)
+    _lock_gpu_oracle(g, o, 25, what="before removal")
+    gone = [22, 7, 41, 0 + 1]
+    g.remove_bodies(gone)
+    for b in gone:
+        o.remove_body(b)
+    keep = np.ones(len(sc["kind"]), bool); keep[gone] = False
+    _lock_gpu_oracle(g, o, 60, keep=keep, what="after removal")
+    pairs = {(int(k >> 32), int(k & 0xFFFFFFFF)) for k in g.get_pairs()}
+    assert not any(a in gone or b in gone for a, b in pairs)
+    ch = scenes.c5_chains(6, 8)
+    g = gpu_world(ch); o = oracle_world(ch)
+    _lock_gpu_oracle(g, o, 40, what="chains")
+    g.remove_joints([11]); o.remove_joint(11)
+    _lock_gpu_oracle(g, o, 40, what="joint removed")
+    body = 1 + 2 * 8 + 3                       # a link of the third chain: both its joints go with it
+    g.remove_bodies([body]); o.remove_body(body)
+    keep = np.ones(len(ch["kind"]), bool); keep[body] = False
+    _lock_gpu_oracle(g, o, 40, keep=keep, what="link removed")
+    first = g.add_joints([(scenes.JOINT_POINT, 1 + 8 + 7, 1 + 4 * 8 + 7, (0, -0.25, 0), (0, -0.25, 0), (1, 0, 0), (1, 0, 0))])
+    assert first == len(ch["joints"])
+    o.add_joint(scenes.JOINT_POINT, 1 + 8 + 7, 1 + 4 * 8 + 7, (0, -0.25, 0), (0, -0.25, 0))
+    _lock_gpu_oracle(g, o, 60, keep=keep, what="joint added")
+
+
+def test_runtime_settings_keep_contact_state_bit_exact():
+    """edynhip_set_params = set_solver_*_iterations / set_gravity / set_fixed_dt without re-creating the context."""
+    sc = scenes.box_pile(4, 4, 4)
+    g = gpu_world(sc, vel=8); o = oracle_world(sc, vel=8)
+    _lock_gpu_oracle(g, o, 30, what="initial")
+    g.set_params(velocity_iterations=14, position_iterations=2, gravity=(0.5, -6.0, 0.0)); o.set_params(1 / 60, 14, 2, (0.5, -6.0, 0.0))
+    _lock_gpu_oracle(g, o, 30, what="iterations + gravity")
+    g.set_params(fixed_dt=1 / 90, velocity_iterations=5, position_iterations=3, gravity=(0, -9.8, 0)); o.set_params(1 / 90, 5, 3, (0.0, -9.8, 0.0))
+    _lock_gpu_oracle(g, o, 30, what="dt")
+    assert g.get_manifolds()["pt"]["lifetime"].max() > 60
+
+
+def test_update_clamp_stretches_the_sleep_time_stamps():
+    """World.update(time) = edyn::update(registry, time): with more steps due than max_steps_per_update the steps that run carry
+    stretched stamps (stepper_sequential.cpp:60-66) - islands fall asleep after 2 s of STAMPS. Same clock through the oracle."""
+    from edyn_amd.world import fixed_step_plan
+    sc = scenes.box_pile(2, 2, 2)
+    g = gpu_world(sc, sleeping=True, max_steps_per_update=4)
+    o = oracle_world(sc); o.set_sleeping(True)
+    dt = float(np.float32(1 / 60))
+    last, acc, t, total = 0.0, 0.0, 0.0, 0
+    rng = np.random.default_rng(9)
+    first_sleep = None
+    for k in range(120):
+        t += float(rng.choice([0.004, 0.016, 0.2, 0.35]))
+        g.update(t)
+        sim_time = last - acc
+        steps, acc, step_dt = fixed_step_plan(acc, t - last, dt, 4)
+        if steps:
+            o.step_timed(steps, sim_time, step_dt)
+        last = t; total += steps
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), k
+        assert np.array_equal(g.get_asleep(), o.get_asleep()), k
+        if first_sleep is None and g.get_asleep().any():
+            first_sleep = total
+    assert first_sleep is not None
+
+
 # ------------------------------------------------------------------ BASELINE.json configs at FULL size
 @pytest.mark.parametrize("name,gen,vel,steps", [
     ("C2_pile8k", scenes.c2_pile, 10, 6),

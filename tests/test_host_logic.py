@@ -45,11 +45,11 @@ def test_shard_range_balanced_and_covering():
 
 def test_fixed_step_accumulator():
     dt = 1 / 60
-    steps, acc = fixed_step_plan(0.0, 0.05, dt, 10)          # 3 steps, remainder kept
+    steps, acc, sdt = fixed_step_plan(0.0, 0.05, dt, 10)          # 3 steps, remainder kept
     assert steps == 3 and abs(acc - (0.05 - 3 * dt)) < 1e-12
-    steps, acc = fixed_step_plan(acc, dt - acc + 1e-9, dt, 10)
+    steps, acc, sdt = fixed_step_plan(acc, dt - acc + 1e-9, dt, 10)
     assert steps == 1
-    steps, acc = fixed_step_plan(0.0, 1.0, dt, 10)           # clamp to max_steps_per_update
+    steps, acc, sdt = fixed_step_plan(0.0, 1.0, dt, 10)           # clamp to max_steps_per_update
     assert steps == 10 and acc < dt
-    steps, acc = fixed_step_plan(0.0, -5.0, dt, 10)          # negative elapsed clamps to 0
+    steps, acc, sdt = fixed_step_plan(0.0, -5.0, dt, 10)          # negative elapsed clamps to 0
     assert steps == 0 and acc == 0.0

@@ -375,3 +375,40 @@ def test_runtime_settings_match_the_real_engine():
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), s
     m = ref.get_manifolds()
     assert m["pt"]["lifetime"].max() > 60   # contacts (and their impulses) survived both changes
+
+
+def test_update_accumulator_and_stretched_time_stamps_match_the_real_engine():
+    """edyn::update(registry, time) (stepper_sequential.cpp:28-119): floor(acc / dt) steps per call, clamped to
+    max_steps_per_update; when clamped, the steps that do run carry stretched time stamps (:60-66) - which only the island
+    sleep timers see. Spheres at rest on a plane (one contact point per island: no visiting order to inject) driven by the
+    same irregular clock through the real engine and through edyn_amd.world.fixed_step_plan + the oracle's step_timed:
+    identical state and identical sleeping flags after every update, and sleep arrives after far fewer STEPS than 2 s / dt."""
+    from edyn_amd.world import fixed_step_plan
+    n = 6
+    sc = scenes._empty(n + 1); scenes._add_plane(sc, 0)
+    for i in range(n):
+        sc["kind"][i + 1] = scenes.KIND_DYNAMIC; sc["pos"][i + 1] = (2.0 * i, 0.5 + 0.01 * i, 0.3 * i)
+        sc["shape_type"][i + 1] = scenes.SHAPE_SPHERE; sc["shape_param"][i + 1] = (0.5, 0, 0, 0)
+    ref = ob.RefWorld(vel_iters=8); ref.add_bodies(sc, sleeping_disabled=False)
+    orc = ob.World(vel_iters=8, order=ob.ORDER_SEQUENTIAL); orc.add_bodies(sc); orc.set_sleeping(True)
+    max_steps = 5
+    ref.set_max_steps_per_update(max_steps)
+    dt = float(np.float32(1 / 60))
+    last, acc, t, total_steps, first_sleep_steps = 0.0, 0.0, 0.0, 0, None
+    rng = np.random.default_rng(5)
+    for k in range(40):
+        t += float(rng.choice([0.004, 0.016, 0.021, 0.3, 0.45]))     # frames shorter than dt, normal frames, long stalls
+        ref.update(t)
+        sim_time = last - acc
+        steps, acc, step_dt = fixed_step_plan(acc, t - last, dt, max_steps)
+        if steps:
+            orc.step_timed(steps, sim_time, step_dt)
+        last = t
+        total_steps += steps
+        for a, b in zip(ref.get_state(), orc.get_state()):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+        ra, oa = ref.get_asleep()[1:], orc.get_asleep()[1:]
+        assert np.array_equal(ra, oa), k
+        if first_sleep_steps is None and ra.any():
+            first_sleep_steps = total_steps
+    assert first_sleep_steps is not None and first_sleep_steps < 90   # 2 s of stamps, far fewer than 120 steps
