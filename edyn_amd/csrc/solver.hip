@@ -907,7 +907,7 @@ DI void joint_rowJ(bool hinge, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 &J0
         J0 = mk3(0, 0, 0); J1 = ax; J2 = mk3(0, 0, 0); J3 = -ax;
     }
 }
-// atan2 evaluated in double and rounded once: correctly rounded fp32, the same value on the device and in the oracle
+// atan2 evaluated in double and rounded once: correctly rounded fp32, a value that does not depend on a math library
 // (the reference's std::atan2(float) depends on the C library's last bit - the same convention as integrate()'s sin/cos).
 DI float atan2_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
 DI float normalize_angle(float a) {   // math.hpp:53-63
