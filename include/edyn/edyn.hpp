@@ -5,7 +5,9 @@
 //   set_max_steps_per_update, get/set_solver_*_iterations, get/set_gravity            include/edyn/edyn.hpp:39-186,
 //                                                                                      config/solver_iteration_config.hpp:13-66, util/gravity_util.hpp:15-23
 //   edyn::rigidbody_def, rigidbody_kind, make_rigidbody                                include/edyn/util/rigidbody.hpp:22-93
-//   edyn::make_constraint<point_constraint|hinge_constraint>(registry, body0, body1, setup)   include/edyn/util/constraint_util.hpp:38-54
+//   edyn::make_constraint<point_constraint|hinge_constraint>(registry, [entity,] body0, body1, setup...)   include/edyn/util/constraint_util.hpp:38-54
+//   edyn::exclude_collision, remove_collision_exclusion, clear_rigidbody                include/edyn/util/exclude_collision.hpp:20-47, util/rigidbody.hpp:95-103
+//   registry.destroy(body / constraint entity) on a running world                      noticed at the next update (island_manager.cpp:47-115 semantics)
 //   components: position, orientation, linvel, angvel, mass, mass_inv, inertia, material, box_shape, sphere_shape,
 //               plane_shape, AABB, dynamic_tag / kinematic_tag / static_tag, rigidbody_tag, contact_manifold (read-only view)
 //
@@ -23,6 +25,7 @@
 #include "detail/mini_entt.hpp"
 #endif
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <optional>
@@ -89,10 +92,17 @@ struct rigidbody_def {   // util/rigidbody.hpp:29-81 (hot-path fields)
 };
 
 struct constraint_base { std::array<entt::entity, 2> body; };
-struct point_constraint : constraint_base { std::array<vector3, 2> pivot; };                 // constraints/point_constraint.hpp:21-34
+struct point_constraint : constraint_base {                                                   // constraints/point_constraint.hpp:21-34
+    std::array<vector3, 2> pivot;
+    scalar friction_torque{};
+};
 struct hinge_constraint : constraint_base {                                                   // constraints/hinge_constraint.hpp:22-93
     std::array<vector3, 2> pivot;
     std::array<vector3, 2> axis{vector3{1, 0, 0}, vector3{1, 0, 0}};
+    scalar angle_min{}, angle_max{}, limit_restitution{};     // limits are active when angle_min < angle_max
+    scalar bump_stop_angle{}, bump_stop_stiffness{};
+    scalar torque{}, speed{};
+    scalar rest_angle{}, stiffness{}, damping{};
     void set_axes(const vector3 &axisA, const vector3 &axisB) { axis = {axisA, axisB}; }
 };
 struct contact_manifold { std::array<entt::entity, 2> body; unsigned num_points; };           // collision/contact_manifold.hpp:14-22
@@ -122,9 +132,10 @@ namespace detail {
 struct gpu_stepper {
     init_config cfg;
     edynhip_ctx *ctx{nullptr};
-    std::vector<entt::entity> bodies;          // body index -> entity (creation order)
-    std::vector<entt::entity> constraints;
-    bool scene_dirty{true}, state_dirty{false}, paused{false};
+    std::vector<entt::entity> bodies;          // body index -> entity (creation order); entt::null = destroyed (the index stays reserved)
+    std::vector<entt::entity> constraints;     // joint index -> entity, same convention
+    std::vector<std::array<uint32_t, 2>> pending_exclusions;   // exclude_collision calls made before the bodies were uploaded
+    bool scene_dirty{true}, state_dirty{false}, paused{false}, params_dirty{false};
     double accumulated{0}, last_time{0};
     unsigned capacity{0}, joint_capacity{0};
     unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
@@ -136,17 +147,69 @@ inline void check(gpu_stepper &s, int rc) {
     if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + edynhip_last_error(s.ctx));
 }
 
+inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t first, std::vector<int32_t> &jt, std::vector<uint32_t> &jb,
+                         std::vector<float> &jp, std::vector<float> &ja, std::vector<float> &jq) {
+    const uint32_t nj = (uint32_t)s.constraints.size() - first;
+    jt.assign(nj, 0); jb.assign(2 * nj, 0); jp.assign(6 * nj, 0.f); ja.assign(6 * nj, 0.f); jq.assign(10 * nj, 0.f);
+    for (uint32_t j = 0; j < nj; ++j) {
+        const entt::entity e = s.constraints[first + j];
+        auto fill = [&](const constraint_base &cb, const std::array<vector3, 2> &pv) {
+            for (int k = 0; k < 2; ++k) {
+                jb[2 * j + k] = registry.get<body_index>(cb.body[k]).value;
+                jp[6 * j + 3 * k] = pv[k].x; jp[6 * j + 3 * k + 1] = pv[k].y; jp[6 * j + 3 * k + 2] = pv[k].z;
+            }
+        };
+        if (auto *pc = registry.try_get<point_constraint>(e)) { jt[j] = EDYNHIP_JOINT_POINT; fill(*pc, pc->pivot); jq[10 * j] = pc->friction_torque; }
+        else {
+            auto &hc = registry.get<hinge_constraint>(e);
+            jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
+            for (int k = 0; k < 2; ++k) { ja[6 * j + 3 * k] = hc.axis[k].x; ja[6 * j + 3 * k + 1] = hc.axis[k].y; ja[6 * j + 3 * k + 2] = hc.axis[k].z; }
+            const float q[10] = {hc.angle_min, hc.angle_max, hc.limit_restitution, hc.bump_stop_angle, hc.bump_stop_stiffness, hc.torque, hc.speed,
+                                 hc.rest_angle, hc.stiffness, hc.damping};
+            for (int k = 0; k < 10; ++k) jq[10 * j + k] = q[k];
+        }
+    }
+}
+
+// Full joint list for a fresh context. A destroyed constraint keeps its index: it is uploaded as a placeholder and listed in
+// `dead` so that the caller removes it again before any step runs.
+inline void joint_arrays_with_dead(entt::registry &registry, gpu_stepper &s, std::vector<int32_t> &jt, std::vector<uint32_t> &jb,
+                                   std::vector<float> &jp, std::vector<float> &ja, std::vector<float> &jq, std::vector<uint32_t> &dead) {
+    const uint32_t nj = (uint32_t)s.constraints.size();
+    std::vector<entt::entity> saved = s.constraints;
+    jt.assign(nj, 0); jb.assign(2 * nj, 0); jp.assign(6 * nj, 0.f); ja.assign(6 * nj, 0.f); jq.assign(10 * nj, 0.f);
+    for (uint32_t j = 0; j < nj; ++j) {
+        if (saved[j] == entt::null) { dead.push_back(j); jt[j] = EDYNHIP_JOINT_POINT; continue; }   // body indices 0,0 - removed before any step
+        std::vector<int32_t> t1; std::vector<uint32_t> b1; std::vector<float> p1, a1, q1;
+        gpu_stepper tmp_view;   // reuse joint_arrays on a one-element window
+        tmp_view.constraints = {saved[j]};
+        joint_arrays(registry, tmp_view, 0, t1, b1, p1, a1, q1);
+        jt[j] = t1[0]; jb[2 * j] = b1[0]; jb[2 * j + 1] = b1[1];
+        for (int k = 0; k < 6; ++k) { jp[6 * j + k] = p1[k]; ja[6 * j + k] = a1[k]; }
+        for (int k = 0; k < 10; ++k) jq[10 * j + k] = q1[k];
+    }
+}
+
 inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     const uint32_t total = (uint32_t)s.bodies.size();
     const uint32_t nj = (uint32_t)s.constraints.size();
+    std::vector<edynhip_manifold> carried;   // contact state carried over a capacity growth (indices are stable)
+    bool regrown = false;
     if (!s.ctx || total > s.capacity || nj > s.joint_capacity) {
-        if (s.ctx) { edynhip_destroy(s.ctx); s.ctx = nullptr; }
+        if (s.ctx) {
+            uint32_t m = 0;
+            check(s, edynhip_num_manifolds(s.ctx, &m));
+            carried.resize(m);
+            if (m) check(s, edynhip_get_manifolds(s.ctx, carried.data(), m, &m));
+            edynhip_destroy(s.ctx); s.ctx = nullptr;
+            regrown = true;
+        }
         s.uploaded_bodies = s.uploaded_constraints = 0;
         edynhip_config c{};
         c.device = s.cfg.device;
-        c.max_bodies = s.cfg.max_bodies ? s.cfg.max_bodies : total + total / 4 + 16;
+        c.max_bodies = s.cfg.max_bodies > total ? s.cfg.max_bodies : total + total / 2 + 16;
         c.max_manifolds = s.cfg.max_manifolds;
-        c.max_joints = nj + nj / 4 + 16;
+        c.max_joints = nj + nj / 2 + 16;
         c.fixed_dt = s.cfg.fixed_dt;
         c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
@@ -156,6 +219,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         s.ctx = edynhip_create(&c, &st);
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
+        s.params_dirty = false;
     }
     // Bodies created since the last upload are appended (edynhip_add_bodies): the running contact state of the others stays.
     const uint32_t first = s.uploaded_bodies, n = total - first;
@@ -163,8 +227,13 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
     std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
     std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
+    std::vector<uint32_t> dead;
     for (uint32_t i = 0; i < n; ++i) {
         const entt::entity e = s.bodies[first + i];
+        if (e == entt::null) {   // destroyed before it was ever uploaded (or before a re-upload): a shapeless static placeholder
+            kind[i] = EDYNHIP_KIND_STATIC; stype[i] = EDYNHIP_SHAPE_NONE; orn[4 * i + 3] = 1.f; dead.push_back(first + i);
+            continue;
+        }
         kind[i] = registry.all_of<dynamic_tag>(e) ? EDYNHIP_KIND_DYNAMIC : registry.all_of<kinematic_tag>(e) ? EDYNHIP_KIND_KINEMATIC : EDYNHIP_KIND_STATIC;
         const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
@@ -189,27 +258,28 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
                      fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data()};
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
+    if (!dead.empty()) check(s, edynhip_remove_bodies(s.ctx, (uint32_t)dead.size(), dead.data()));
     s.uploaded_bodies = total;
-    if (first != 0 && nj == s.uploaded_constraints) { s.scene_dirty = false; return; }
-    std::vector<int32_t> jt(nj); std::vector<uint32_t> jb(2 * nj); std::vector<float> jp(6 * nj), ja(6 * nj, 0.f);
-    for (uint32_t j = 0; j < nj; ++j) {
-        const entt::entity e = s.constraints[j];
-        auto fill = [&](const constraint_base &cb, const std::array<vector3, 2> &pv) {
-            for (int k = 0; k < 2; ++k) {
-                jb[2 * j + k] = registry.get<body_index>(cb.body[k]).value;
-                jp[6 * j + 3 * k] = pv[k].x; jp[6 * j + 3 * k + 1] = pv[k].y; jp[6 * j + 3 * k + 2] = pv[k].z;
-            }
-        };
-        if (auto *pc = registry.try_get<point_constraint>(e)) { jt[j] = EDYNHIP_JOINT_POINT; fill(*pc, pc->pivot); }
-        else {
-            auto &hc = registry.get<hinge_constraint>(e);
-            jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
-            for (int k = 0; k < 2; ++k) { ja[6 * j + 3 * k] = hc.axis[k].x; ja[6 * j + 3 * k + 1] = hc.axis[k].y; ja[6 * j + 3 * k + 2] = hc.axis[k].z; }
-        }
+    if (regrown && !carried.empty()) check(s, edynhip_set_manifolds(s.ctx, carried.data(), (uint32_t)carried.size()));
+    // joints: everything after a (re)creation of the context, otherwise only the ones made since the last upload
+    std::vector<int32_t> jt; std::vector<uint32_t> jb; std::vector<float> jp, ja, jq;
+    if (first == 0) {
+        std::vector<uint32_t> dead_joints;
+        std::vector<entt::entity> live = s.constraints;
+        // destroyed constraints keep their index: upload a placeholder between two existing bodies and remove it again
+        joint_arrays_with_dead(registry, s, jt, jb, jp, ja, jq, dead_joints);
+        edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
+        check(s, edynhip_set_joints(s.ctx, nj, nj ? &js : nullptr));
+        if (!dead_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)dead_joints.size(), dead_joints.data()));
+    } else if (nj > s.uploaded_constraints) {
+        joint_arrays(registry, s, s.uploaded_constraints, jt, jb, jp, ja, jq);
+        edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
+        uint32_t first_joint = 0;
+        check(s, edynhip_add_joints(s.ctx, nj - s.uploaded_constraints, &js, &first_joint));
     }
-    edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data()};
-    check(s, edynhip_set_joints(s.ctx, nj, nj ? &js : nullptr));
     s.uploaded_constraints = nj;
+    for (auto &ex : s.pending_exclusions) check(s, edynhip_exclude_collision(s.ctx, ex[0], ex[1]));
+    s.pending_exclusions.clear();
     s.scene_dirty = false;
     if (first == 0) s.state_dirty = false;
 }
@@ -219,6 +289,7 @@ inline void upload_state(entt::registry &registry, gpu_stepper &s) {
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n, 0.f), av(3 * n, 0.f);
     for (uint32_t i = 0; i < n; ++i) {
         const entt::entity e = s.bodies[i];
+        if (e == entt::null) { orn[4 * i + 3] = 1.f; continue; }
         const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
         pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
         orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
@@ -235,7 +306,7 @@ inline void write_back(entt::registry &registry, gpu_stepper &s) {
     check(s, edynhip_get_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
     for (uint32_t i = 0; i < n; ++i) {
         const entt::entity e = s.bodies[i];
-        if (!registry.all_of<dynamic_tag>(e)) continue;
+        if (e == entt::null || !registry.all_of<dynamic_tag>(e)) continue;
         auto &p = registry.get<position>(e); p.x = pos[3 * i]; p.y = pos[3 * i + 1]; p.z = pos[3 * i + 2];
         auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
         auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
@@ -246,6 +317,7 @@ inline void write_back(entt::registry &registry, gpu_stepper &s) {
         check(s, edynhip_get_asleep(s.ctx, asleep.data()));
         for (uint32_t i = 0; i < n; ++i) {
             const entt::entity e = s.bodies[i];
+            if (e == entt::null) continue;
             const bool tagged = registry.all_of<sleeping_tag>(e);
             if (asleep[i] && !tagged) registry.emplace<sleeping_tag>(e);
             else if (!asleep[i] && tagged) registry.remove<sleeping_tag>(e);
@@ -253,11 +325,53 @@ inline void write_back(entt::registry &registry, gpu_stepper &s) {
     }
 }
 
-inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps) {
+// registry.destroy(entity) / clear_rigidbody on bodies and constraints since the last update: the reference reacts through
+// on_destroy hooks (island_manager.cpp:24-27); this shim notices at the next update that the entity is gone (or no longer
+// carries the component that made it a body / a joint) and removes it from the device world, keeping every other index.
+inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
+    std::vector<uint32_t> gone_bodies, gone_joints;
+    for (uint32_t i = 0; i < (uint32_t)s.bodies.size(); ++i) {
+        const entt::entity e = s.bodies[i];
+        if (e == entt::null) continue;
+        const bool alive = registry.valid(e) && registry.all_of<rigidbody_tag, body_index>(e) && registry.get<body_index>(e).value == i;
+        if (!alive) { s.bodies[i] = entt::null; if (i < s.uploaded_bodies) gone_bodies.push_back(i); }
+    }
+    for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
+        const entt::entity e = s.constraints[j];
+        if (e == entt::null) continue;
+        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint>(e);
+        if (alive) {   // a joint whose body was destroyed goes with it
+            const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
+                                                                             : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
+            for (int k = 0; k < 2; ++k) if (!registry.valid(cb.body[k]) || !registry.all_of<body_index>(cb.body[k])) alive = false;
+        }
+        if (!alive) {
+            s.constraints[j] = entt::null;
+            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (j < s.uploaded_constraints) gone_joints.push_back(j);
+        }
+    }
+    if (!s.ctx) return;
+    if (!gone_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)gone_joints.size(), gone_joints.data()));
+    if (!gone_bodies.empty()) check(s, edynhip_remove_bodies(s.ctx, (uint32_t)gone_bodies.size(), gone_bodies.data()));
+}
+inline void apply_params(gpu_stepper &s) {   // settings on the running context: nothing is re-created, no contact state is lost
+    if (!s.ctx || !s.params_dirty) { s.params_dirty = false; return; }
+    edynhip_params p{};
+    p.fixed_dt = s.cfg.fixed_dt;
+    p.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
+    p.num_position_iterations = s.cfg.num_solver_position_iterations;
+    p.gravity[0] = s.cfg.gravity.x; p.gravity[1] = s.cfg.gravity.y; p.gravity[2] = s.cfg.gravity.z;
+    check(s, edynhip_set_params(s.ctx, &p));
+    s.params_dirty = false;
+}
+inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, bool timed = false, double first_time = 0, double step_dt = 0) {
+    sync_removed(registry, s);
     if (s.scene_dirty) upload_scene(registry, s);
-    else if (s.state_dirty) upload_state(registry, s);
+    if (s.state_dirty) upload_state(registry, s);   // also after an append: edits made in the same frame are not lost
+    apply_params(s);
     if (steps == 0 || s.bodies.empty()) return;
-    check(s, edynhip_step(s.ctx, steps));
+    check(s, timed ? edynhip_step_timed(s.ctx, steps, first_time, step_dt) : edynhip_step(s.ctx, steps));
     write_back(registry, s);
 }
 // update_presentation (src/edyn/sys/update_presentation.cpp:56-84), local simulation (no discontinuities): transforms are
@@ -298,39 +412,67 @@ inline void attach(entt::registry &registry, const init_config &config = {}) {
 }
 inline void detach(entt::registry &registry) { registry.ctx().erase<detail::gpu_stepper>(); }
 inline scalar get_fixed_dt(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.fixed_dt; }
-inline void set_fixed_dt(entt::registry &registry, scalar dt) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.fixed_dt = dt; s.scene_dirty = true; s.capacity = 0; }
+inline void set_fixed_dt(entt::registry &registry, scalar dt) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.fixed_dt = dt; s.params_dirty = true; }
 inline void set_max_steps_per_update(entt::registry &registry, unsigned n) { registry.ctx().get<detail::gpu_stepper>().cfg.max_steps_per_update = n; }
 inline bool is_paused(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().paused; }
 inline void set_paused(entt::registry &registry, bool paused) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.paused = paused; s.accumulated = 0; }
 inline vector3 get_gravity(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.gravity; }
-inline void set_gravity(entt::registry &registry, vector3 g) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.gravity = g; s.scene_dirty = true; s.capacity = 0; }
+inline void set_gravity(entt::registry &registry, vector3 g) {   // gravity_util.cpp:12-20: the setting and every body's gravity component
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    s.cfg.gravity = g; s.params_dirty = true;
+    for (const entt::entity e : s.bodies) if (e != entt::null && registry.valid(e)) if (auto *gr = registry.try_get<gravity>(e)) { gr->x = g.x; gr->y = g.y; gr->z = g.z; }
+}
 inline unsigned get_solver_velocity_iterations(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.num_solver_velocity_iterations; }
-inline void set_solver_velocity_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_velocity_iterations = n; s.scene_dirty = true; s.capacity = 0; }
+inline void set_solver_velocity_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_velocity_iterations = n; s.params_dirty = true; }
 inline unsigned get_solver_position_iterations(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.num_solver_position_iterations; }
-inline void set_solver_position_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_position_iterations = n; s.scene_dirty = true; s.capacity = 0; }
+inline void set_solver_position_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_position_iterations = n; s.params_dirty = true; }
 /// Tell the stepper that position/orientation/linvel/angvel were edited by the user (registry.patch analogue).
 inline void refresh(entt::registry &registry) { registry.ctx().get<detail::gpu_stepper>().state_dirty = true; }
 
-/// stepper_sequential::update (stepper_sequential.cpp:28-119): fixed-dt accumulator, clamped to max_steps_per_update.
+/// stepper_sequential::update (stepper_sequential.cpp:28-119): fixed-dt accumulator; when more steps are due than
+/// max_steps_per_update, the steps that do run carry stretched time stamps (:60-66; they feed the island sleep timers, the
+/// solver always integrates with fixed_dt).
 inline void update(entt::registry &registry, double time) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     if (s.paused) { detail::run_steps(registry, s, 0); return; }
+    const double sim_time = s.last_time - s.accumulated;   // get_simulation_timestamp() before this update
     const double elapsed = std::max(time - s.last_time, 0.0);
     s.accumulated += elapsed;
     const double dt = s.cfg.fixed_dt;
     const auto num_steps = static_cast<uint64_t>(std::floor(s.accumulated / dt));
-    s.accumulated -= static_cast<double>(num_steps) * dt;
-    const unsigned steps = (unsigned)std::min<uint64_t>(num_steps, s.cfg.max_steps_per_update);
-    detail::run_steps(registry, s, steps);
+    const double advance_dt = static_cast<double>(num_steps) * dt;
+    s.accumulated -= advance_dt;
+    uint64_t effective_steps = num_steps;
+    double step_dt = dt;
+    if (effective_steps > s.cfg.max_steps_per_update) {
+        effective_steps = s.cfg.max_steps_per_update;
+        step_dt = advance_dt / static_cast<double>(effective_steps);
+    }
+    detail::run_steps(registry, s, (unsigned)effective_steps, true, sim_time, step_dt);
     s.last_time = time;
     detail::update_presentation(registry, s, time);
 }
+namespace detail {
+inline double performance_time() {   // time/time.hpp performance_time(): seconds on a monotonic clock
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace detail
+/// edyn::update(registry) (edyn.hpp:124, edyn.cpp:234-238): the time comes from settings.time_func (a monotonic clock).
+inline void update(entt::registry &registry) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const double now = detail::performance_time();
+    if (s.last_time == 0 && s.accumulated == 0) s.last_time = now;   // attach() stamps the stepper with the current time
+    update(registry, now);
+}
 /// stepper_sequential::step_simulation (stepper_sequential.cpp:121-147): exactly one step; requires paused.
-inline void step_simulation(entt::registry &registry, double time = 0) {
+inline void step_simulation(entt::registry &registry, double time) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     s.last_time = time;
-    detail::run_steps(registry, s, 1);
+    detail::run_steps(registry, s, 1, true, time, s.cfg.fixed_dt);
 }
+/// edyn::step_simulation(registry) (edyn.hpp:142).
+inline void step_simulation(entt::registry &registry) { step_simulation(registry, detail::performance_time()); }
 
 // ---- util/rigidbody.hpp:84-93, rigidbody.cpp:47-191
 inline void make_rigidbody(entt::entity entity, entt::registry &registry, const rigidbody_def &def) {
@@ -374,19 +516,51 @@ inline entt::entity make_rigidbody(entt::registry &registry, const rigidbody_def
     return e;
 }
 
-// ---- util/constraint_util.hpp:38-54
-template <typename T, typename SetupFunc>
-entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt::entity body1, SetupFunc setup) {
+// ---- util/constraint_util.hpp:38-54: make_constraint<T>(registry, entity, body0, body1, setup...) and the entity-creating form
+template <typename T, typename... SetupFunc>
+void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
     static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint>,
                   "only point_constraint and hinge_constraint are on the accelerated path");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
-    auto e = registry.create();
-    auto &con = registry.emplace<T>(e);
+    auto &con = registry.emplace<T>(entity);
     con.body = {body0, body1};
-    setup(con);
-    s.constraints.push_back(e);
+    (setup(con), ...);
+    s.constraints.push_back(entity);
     s.scene_dirty = true;
+}
+template <typename T, typename... SetupFunc>
+entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt::entity body1, SetupFunc... setup) {
+    auto e = registry.create();
+    make_constraint<T>(registry, e, body0, body1, setup...);
     return e;
+}
+
+// ---- util/exclude_collision.hpp:20-47
+inline void exclude_collision(entt::registry &registry, entt::entity first, entt::entity second) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const uint32_t a = registry.get<detail::body_index>(first).value, b = registry.get<detail::body_index>(second).value;
+    if (s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies && !s.scene_dirty) detail::check(s, edynhip_exclude_collision(s.ctx, a, b));
+    else { s.pending_exclusions.push_back({a, b}); s.scene_dirty = true; }
+}
+inline void remove_collision_exclusion(entt::registry &registry, entt::entity first, entt::entity second) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const uint32_t a = registry.get<detail::body_index>(first).value, b = registry.get<detail::body_index>(second).value;
+    for (size_t k = s.pending_exclusions.size(); k; --k) {
+        auto &ex = s.pending_exclusions[k - 1];
+        if ((ex[0] == a && ex[1] == b) || (ex[0] == b && ex[1] == a)) s.pending_exclusions.erase(s.pending_exclusions.begin() + (k - 1));
+    }
+    if (s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies) detail::check(s, edynhip_remove_collision_exclusion(s.ctx, a, b));
+}
+/// util/rigidbody.hpp:95-103, rigidbody.cpp:193-226: strips everything make_rigidbody assigned; the entity itself lives on.
+inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
+    registry.remove<rigidbody_tag>(entity); registry.remove<dynamic_tag>(entity); registry.remove<kinematic_tag>(entity);
+    registry.remove<static_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<sleeping_disabled_tag>(entity);
+    registry.remove<sleeping_tag>(entity); registry.remove<collision_filter>(entity); registry.remove<box_shape>(entity);
+    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<material>(entity);
+    registry.remove<gravity>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
+    registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
+    registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
+    registry.remove<detail::body_index>(entity);   // the stepper drops the body from the device world at the next update
 }
 
 /// Current contact manifolds (body pair + point count), materialised on demand.
@@ -399,7 +573,7 @@ inline std::vector<contact_manifold> get_contact_manifolds(entt::registry &regis
     std::vector<edynhip_manifold> recs(n);
     if (n) detail::check(s, edynhip_get_manifolds(s.ctx, recs.data(), n, &n));
     out.reserve(n);
-    for (auto &r : recs) out.push_back({{s.bodies[r.body[0]], s.bodies[r.body[1]]}, r.num_points});
+    for (auto &r : recs) if (s.bodies[r.body[0]] != entt::null && s.bodies[r.body[1]] != entt::null) out.push_back({{s.bodies[r.body[0]], s.bodies[r.body[1]]}, r.num_points});
     return out;
 }
 

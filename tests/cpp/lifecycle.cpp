@@ -1,0 +1,110 @@
+// Life-cycle of a running world through the C++ drop-in shim: everything the reference lets a user do between two
+// edyn::update calls without losing the simulation state.
+//   registry.destroy(body) / registry.destroy(constraint) / edyn::clear_rigidbody      src/edyn/edyn.cpp:148-197 hooks, island_manager.cpp:47-115
+//   set_solver_*_iterations / set_gravity / set_fixed_dt on a running world            solver_iteration_config.cpp:9-75, gravity_util.cpp:12-20
+//   make_constraint<T>(registry, entity, body0, body1, setup...) and the zero-setup form   util/constraint_util.hpp:38-54
+//   exclude_collision                                                                   util/exclude_collision.hpp:20-47
+//   capacity growth while running (contacts carried over), update(registry) without a time argument
+#include <edyn/edyn.hpp>
+#include <cmath>
+#include <cstdio>
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); ++failures; } } while (0)
+
+int main() {
+    entt::registry registry;
+    auto config = edyn::init_config{};
+    config.num_solver_velocity_iterations = 10;
+    config.max_bodies = 8;   // small on purpose: the world outgrows it below
+    edyn::attach(registry, config);
+
+    auto floor_def = edyn::rigidbody_def{};
+    floor_def.kind = edyn::rigidbody_kind::rb_static;
+    floor_def.shape = edyn::plane_shape{{0, 1, 0}, 0};
+    edyn::make_rigidbody(registry, floor_def);
+
+    auto def = edyn::rigidbody_def{};
+    def.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}};
+    def.sleeping_disabled = true;
+    entt::entity stack[3];
+    for (int i = 0; i < 3; ++i) { def.position = {0, 0.5f + 1.0f * i, 0}; stack[i] = edyn::make_rigidbody(registry, def); }
+
+    double t = 0;
+    auto run = [&](int frames) { for (int i = 0; i < frames; ++i) { t += 1.0 / 60 + 1e-6; edyn::update(registry, t); } };
+    run(60);
+    CHECK(edyn::get_contact_manifolds(registry).size() == 3);
+    CHECK(std::fabs(registry.get<edyn::position>(stack[2]).y - 2.5f) < 2e-2f);
+
+    // settings on the running world: the stack must not twitch (contacts and warm-start impulses survive)
+    edyn::set_solver_velocity_iterations(registry, 14);
+    edyn::set_solver_position_iterations(registry, 2);
+    run(1);
+    CHECK(std::fabs(registry.get<edyn::linvel>(stack[2]).y) < 0.02f);
+    CHECK(edyn::get_solver_velocity_iterations(registry) == 14);
+    edyn::set_gravity(registry, {0, -4.9f, 0});
+    run(30);
+    CHECK(std::fabs(registry.get<edyn::position>(stack[2]).y - 2.5f) < 2e-2f);
+    edyn::set_gravity(registry, edyn::gravity_earth);
+
+    // destroy the middle box: the top one falls onto the bottom one
+    registry.destroy(stack[1]);
+    run(90);
+    CHECK(std::fabs(registry.get<edyn::position>(stack[2]).y - 1.5f) < 3e-2f);
+    CHECK(edyn::get_contact_manifolds(registry).size() == 2);
+
+    // outgrow max_bodies: eight more boxes in a row; the resting pair keeps its contacts through the re-allocation
+    for (int i = 0; i < 8; ++i) { def.position = {3.0f + 1.5f * i, 0.5f, 0}; edyn::make_rigidbody(registry, def); }
+    run(1);
+    CHECK(std::fabs(registry.get<edyn::linvel>(stack[2]).y) < 0.05f);
+    run(60);
+    CHECK(edyn::get_contact_manifolds(registry).size() == 10);
+
+    // constraints: entity form with two setup functions, zero-setup form, destruction
+    auto anchor_def = edyn::rigidbody_def{};
+    anchor_def.kind = edyn::rigidbody_kind::rb_static;
+    anchor_def.position = {-5, 5, 0};
+    auto anchor = edyn::make_rigidbody(registry, anchor_def);
+    auto bob_def = edyn::rigidbody_def{};
+    bob_def.position = {-4, 5, 0};
+    bob_def.sleeping_disabled = true;
+    bob_def.inertia = edyn::matrix3x3{{edyn::vector3{0.01f, 0, 0}, edyn::vector3{0, 0.01f, 0}, edyn::vector3{0, 0, 0.01f}}};
+    auto bob = edyn::make_rigidbody(registry, bob_def);
+    auto hinge_entity = registry.create();
+    edyn::make_constraint<edyn::hinge_constraint>(registry, hinge_entity, anchor, bob,
+        [](edyn::hinge_constraint &h) { h.pivot = {edyn::vector3{0, 0, 0}, edyn::vector3{-1, 0, 0}}; },
+        [](edyn::hinge_constraint &h) { h.set_axes({0, 0, 1}, {0, 0, 1}); h.angle_min = -0.4f; h.angle_max = 0.4f; });
+    auto loose = edyn::make_constraint<edyn::point_constraint>(registry, anchor, bob);   // pivots at the origins: removed right away
+    registry.destroy(loose);
+    run(120);
+    {
+        const auto &pb = registry.get<edyn::position>(bob);
+        const float L = std::sqrt((pb.x + 5) * (pb.x + 5) + (pb.y - 5) * (pb.y - 5) + pb.z * pb.z);
+        const float angle = std::atan2(5 - pb.y, pb.x + 5);   // 0 = horizontal start, positive = swung down
+        CHECK(std::fabs(L - 1.0f) < 3e-2f);
+        CHECK(angle < 0.4f + 0.06f);                          // the limit holds the pendulum up
+    }
+    registry.destroy(hinge_entity);                           // now it simply falls
+    run(60);
+    CHECK(registry.get<edyn::position>(bob).y < 3.5f);
+
+    // exclude_collision: a box dropped onto an excluded partner falls through it to the floor
+    def.position = {-10, 0.5f, 0}; auto lower = edyn::make_rigidbody(registry, def);
+    def.position = {-10, 1.6f, 0}; auto upper = edyn::make_rigidbody(registry, def);
+    edyn::exclude_collision(registry, lower, upper);
+    run(90);
+    CHECK(std::fabs(registry.get<edyn::position>(upper).y - 0.5f) < 3e-2f);
+
+    // clear_rigidbody keeps the entity but takes the body out of the world
+    edyn::clear_rigidbody(registry, lower);
+    CHECK(registry.valid(lower));
+    run(5);
+    for (auto &m : edyn::get_contact_manifolds(registry)) CHECK(m.body[0] != lower && m.body[1] != lower);
+
+    // update(registry) without a time: the monotonic clock drives the accumulator
+    edyn::update(registry);
+    edyn::update(registry);
+    edyn::detach(registry);
+    std::printf(failures == 0 ? "LIFECYCLE_OK\n" : "LIFECYCLE_FAIL\n");
+    return failures == 0 ? 0 : 1;
+}
