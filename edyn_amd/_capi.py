@@ -37,7 +37,8 @@ class Joints(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("fixed_dt", C.c_float), ("num_velocity_iterations", C.c_uint32), ("num_position_iterations", C.c_uint32),
-                ("gravity", C.c_float * 3)]
+                ("gravity", C.c_float * 3), ("num_restitution_iterations", C.c_uint32),
+                ("num_individual_restitution_iterations", C.c_uint32)]
 
 
 class Timings(C.Structure):

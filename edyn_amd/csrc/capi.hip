@@ -512,9 +512,9 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     if (n && (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
               !in->friction || !in->restitution))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
+    if (first == 0) c->has_restitution = false;
     for (uint32_t i = 0; i < n; ++i)
-        if (in->restitution[i] != 0.0f)
-            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": restitution > 0 needs the restitution solver (out of scope)").c_str());
+        if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)
     if (first == 0) { c->host_joints.clear(); c->j.n = 0; c->j.num_colours = 0; c->j.rows = 0; c->host_excl.clear(); if (c->excl) (void)hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream); }
     EH_HIP(c, hipSetDevice(c->device));
     std::vector<void *> tmp;
@@ -707,14 +707,15 @@ static int reset_new_angles(edynhip_ctx *c, uint32_t first_caller_index) {
     Joints &j = c->j;
     if (j.n == 0) return EDYNHIP_OK;
     std::vector<uint32_t> orig(j.n);
-    EH_HIP(c, hipMemcpy(orig.data(), j.orig, (size_t)j.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EH_HIP(c, hipMemcpyAsync(orig.data(), j.orig, (size_t)j.n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<uint8_t> which(j.n, 0);
     bool any = false;
     for (uint32_t p = 0; p < j.n; ++p) if (orig[p] >= first_caller_index) { which[p] = 1; any = true; }
     if (!any) return EDYNHIP_OK;
     uint8_t *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, j.n));
-    EH_HIP(c, hipMemcpy(d, which.data(), j.n, hipMemcpyHostToDevice));
+    EH_HIP(c, hipMemcpyAsync(d, which.data(), j.n, hipMemcpyHostToDevice, c->stream));
     int rc = joint_reset_angles(c, d);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d);
@@ -765,12 +766,13 @@ int edynhip_set_joint_params(edynhip_ctx *c, uint32_t joint, const float *params
     EH_TRY(rebuild_joints(c, false));
     // reset_angle for this joint only
     std::vector<uint32_t> orig(c->j.n);
-    EH_HIP(c, hipMemcpy(orig.data(), c->j.orig, (size_t)c->j.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EH_HIP(c, hipMemcpyAsync(orig.data(), c->j.orig, (size_t)c->j.n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<uint8_t> which(c->j.n, 0);
     for (uint32_t p = 0; p < c->j.n; ++p) if (orig[p] == joint) which[p] = 1;
     uint8_t *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, c->j.n));
-    EH_HIP(c, hipMemcpy(d, which.data(), c->j.n, hipMemcpyHostToDevice));
+    EH_HIP(c, hipMemcpyAsync(d, which.data(), c->j.n, hipMemcpyHostToDevice, c->stream));
     int rc = joint_reset_angles(c, d);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d);
@@ -815,6 +817,8 @@ int edynhip_get_params(edynhip_ctx *c, edynhip_params *out) {
     out->num_velocity_iterations = c->cfg.num_velocity_iterations;
     out->num_position_iterations = c->cfg.num_position_iterations;
     std::memcpy(out->gravity, c->cfg.gravity, sizeof(out->gravity));
+    out->num_restitution_iterations = c->restitution_iterations;
+    out->num_individual_restitution_iterations = c->individual_restitution_iterations;
     return EDYNHIP_OK;
 }
 __global__ void k_set_gravity(uint32_t n, Bodies b, float4 g) {
@@ -827,6 +831,8 @@ int edynhip_set_params(edynhip_ctx *c, const edynhip_params *p) {
     c->cfg.fixed_dt = p->fixed_dt;
     c->cfg.num_velocity_iterations = p->num_velocity_iterations;
     c->cfg.num_position_iterations = p->num_position_iterations;
+    c->restitution_iterations = p->num_restitution_iterations;
+    c->individual_restitution_iterations = p->num_individual_restitution_iterations;
     if (std::memcmp(c->cfg.gravity, p->gravity, sizeof(p->gravity)) != 0) {   // set_gravity: the setting and every body's gravity
         std::memcpy(c->cfg.gravity, p->gravity, sizeof(p->gravity));
         if (c->b.n) hipLaunchKernelGGL(k_set_gravity, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, make_float4(p->gravity[0], p->gravity[1], p->gravity[2], 0));

@@ -256,6 +256,13 @@ struct edynhip_ctx {
     uint32_t df2_waves = 0;        // resident waves of the two-lane dataflow velocity kernel
     bool points_in_prev = false;   // this step's manifold array holds no copied points yet (see Manifolds::prev_idx)
     bool force_islands = true;     // recompute island labels even if the pair set did not change
+    // restitution solver (restitution.hip): on when any body has restitution > 0
+    bool has_restitution = false;
+    uint32_t restitution_iterations = 8, individual_restitution_iterations = 3;   // settings.hpp:28-29
+    uint32_t *rdeg = nullptr, *roff = nullptr, *rcursor = nullptr, *radj = nullptr, *rvisited = nullptr, *rqnext = nullptr;
+    uint8_t *rstar = nullptr;
+    uint64_t *rbest = nullptr;
+    float4 *rimp = nullptr;
     uint32_t *excl = nullptr;      // collision exclusion lists [max_bodies][16], ~0u-terminated; allocated by the first edynhip_exclude_collision
     std::vector<uint32_t> host_excl;   // host mirror of excl (edits are rare: scene construction)
     std::vector<int32_t> host_kind, host_shape;   // per body, for rebuilding the broadphase lists when bodies are appended
@@ -271,6 +278,7 @@ int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);   /
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count);
 int islands(edynhip_ctx *c);
+int restitution(edynhip_ctx *c);   // restitution.hip: solve_restitution, before gravity and the constraint solver (solver.cpp:397)
 int solve(edynhip_ctx *c);
 int refresh_derived(edynhip_ctx *c);
 int joint_reset_angles(edynhip_ctx *c, const uint8_t *which_dev);   // reset_angle of the marked (sorted-order) joints

@@ -941,7 +941,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
             f3 spin = A.w - B.w;
             const float lsqr = length_sqr(spin);
             if ((double)lsqr > 1e-18) {   // try_normalize, vector3.hpp:239-248
-                wax = spin / sqrtf(lsqr);
+                wax = div_recip(spin, sqrtf(lsqr));   // vector3 operator/= multiplies by the reciprocal
                 const float fi = friction_torque * dt;
                 lo[3] = -fi; hi[3] = fi;
                 mask |= 1u << 3;
@@ -1799,6 +1799,7 @@ int solve(edynhip_ctx *c) {
     const float dt = c->cfg.fixed_dt;
     const uint32_t rcap = mf.cap;
     rec(c, 3);
+    EH_TRY(restitution(c));   // solve_restitution comes first in solver::update (solver.cpp:397); a no-op without bouncy materials
     // gravity / zeroed deltas do not depend on the colouring: enqueued first, they run while the host waits for the counters
     hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
     EH_TRY(colour_contacts(c));

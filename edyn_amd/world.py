@@ -215,7 +215,8 @@ class World:
         idx = np.ascontiguousarray(indices, np.uint32)
         self._check(self._L.edynhip_remove_bodies(self._h, len(idx), _ptr(idx)))
 
-    def set_params(self, fixed_dt=None, velocity_iterations=None, position_iterations=None, gravity=None):
+    def set_params(self, fixed_dt=None, velocity_iterations=None, position_iterations=None, gravity=None,
+                   restitution_iterations=None, individual_restitution_iterations=None):
         """set_fixed_dt / set_solver_*_iterations / set_gravity on the running world: no contact state is lost."""
         self._flush_defs()
         p = _capi.Params()
@@ -228,6 +229,10 @@ class World:
             p.num_position_iterations = position_iterations; self.cfg.num_solver_position_iterations = position_iterations
         if gravity is not None:
             p.gravity = (C.c_float * 3)(*[float(x) for x in gravity]); self.cfg.gravity = tuple(gravity)
+        if restitution_iterations is not None:
+            p.num_restitution_iterations = restitution_iterations
+        if individual_restitution_iterations is not None:
+            p.num_individual_restitution_iterations = individual_restitution_iterations
         self._check(self._L.edynhip_set_params(self._h, C.byref(p)))
 
     def step_timed(self, n, first_step_time, step_dt):

@@ -147,12 +147,16 @@ inline void check(gpu_stepper &s, int rc) {
     if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + edynhip_last_error(s.ctx));
 }
 
+// Joint definitions [first, end) for edynhip_set_joints / edynhip_add_joints. A constraint destroyed before it was ever
+// uploaded keeps its index: it goes up as a placeholder and is listed in `dead` so that the caller removes it again before
+// any step runs.
 inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t first, std::vector<int32_t> &jt, std::vector<uint32_t> &jb,
-                         std::vector<float> &jp, std::vector<float> &ja, std::vector<float> &jq) {
+                         std::vector<float> &jp, std::vector<float> &ja, std::vector<float> &jq, std::vector<uint32_t> &dead) {
     const uint32_t nj = (uint32_t)s.constraints.size() - first;
-    jt.assign(nj, 0); jb.assign(2 * nj, 0); jp.assign(6 * nj, 0.f); ja.assign(6 * nj, 0.f); jq.assign(10 * nj, 0.f);
+    jt.assign(nj, EDYNHIP_JOINT_POINT); jb.assign(2 * nj, 0); jp.assign(6 * nj, 0.f); ja.assign(6 * nj, 0.f); jq.assign(10 * nj, 0.f);
     for (uint32_t j = 0; j < nj; ++j) {
         const entt::entity e = s.constraints[first + j];
+        if (e == entt::null) { dead.push_back(first + j); continue; }
         auto fill = [&](const constraint_base &cb, const std::array<vector3, 2> &pv) {
             for (int k = 0; k < 2; ++k) {
                 jb[2 * j + k] = registry.get<body_index>(cb.body[k]).value;
@@ -168,25 +172,6 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
                                  hc.rest_angle, hc.stiffness, hc.damping};
             for (int k = 0; k < 10; ++k) jq[10 * j + k] = q[k];
         }
-    }
-}
-
-// Full joint list for a fresh context. A destroyed constraint keeps its index: it is uploaded as a placeholder and listed in
-// `dead` so that the caller removes it again before any step runs.
-inline void joint_arrays_with_dead(entt::registry &registry, gpu_stepper &s, std::vector<int32_t> &jt, std::vector<uint32_t> &jb,
-                                   std::vector<float> &jp, std::vector<float> &ja, std::vector<float> &jq, std::vector<uint32_t> &dead) {
-    const uint32_t nj = (uint32_t)s.constraints.size();
-    std::vector<entt::entity> saved = s.constraints;
-    jt.assign(nj, 0); jb.assign(2 * nj, 0); jp.assign(6 * nj, 0.f); ja.assign(6 * nj, 0.f); jq.assign(10 * nj, 0.f);
-    for (uint32_t j = 0; j < nj; ++j) {
-        if (saved[j] == entt::null) { dead.push_back(j); jt[j] = EDYNHIP_JOINT_POINT; continue; }   // body indices 0,0 - removed before any step
-        std::vector<int32_t> t1; std::vector<uint32_t> b1; std::vector<float> p1, a1, q1;
-        gpu_stepper tmp_view;   // reuse joint_arrays on a one-element window
-        tmp_view.constraints = {saved[j]};
-        joint_arrays(registry, tmp_view, 0, t1, b1, p1, a1, q1);
-        jt[j] = t1[0]; jb[2 * j] = b1[0]; jb[2 * j + 1] = b1[1];
-        for (int k = 0; k < 6; ++k) { jp[6 * j + k] = p1[k]; ja[6 * j + k] = a1[k]; }
-        for (int k = 0; k < 10; ++k) jq[10 * j + k] = q1[k];
     }
 }
 
@@ -263,20 +248,18 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     if (regrown && !carried.empty()) check(s, edynhip_set_manifolds(s.ctx, carried.data(), (uint32_t)carried.size()));
     // joints: everything after a (re)creation of the context, otherwise only the ones made since the last upload
     std::vector<int32_t> jt; std::vector<uint32_t> jb; std::vector<float> jp, ja, jq;
+    std::vector<uint32_t> dead_joints;
     if (first == 0) {
-        std::vector<uint32_t> dead_joints;
-        std::vector<entt::entity> live = s.constraints;
-        // destroyed constraints keep their index: upload a placeholder between two existing bodies and remove it again
-        joint_arrays_with_dead(registry, s, jt, jb, jp, ja, jq, dead_joints);
+        joint_arrays(registry, s, 0, jt, jb, jp, ja, jq, dead_joints);
         edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
         check(s, edynhip_set_joints(s.ctx, nj, nj ? &js : nullptr));
-        if (!dead_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)dead_joints.size(), dead_joints.data()));
     } else if (nj > s.uploaded_constraints) {
-        joint_arrays(registry, s, s.uploaded_constraints, jt, jb, jp, ja, jq);
+        joint_arrays(registry, s, s.uploaded_constraints, jt, jb, jp, ja, jq, dead_joints);
         edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
         uint32_t first_joint = 0;
         check(s, edynhip_add_joints(s.ctx, nj - s.uploaded_constraints, &js, &first_joint));
     }
+    if (!dead_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)dead_joints.size(), dead_joints.data()));
     s.uploaded_constraints = nj;
     for (auto &ex : s.pending_exclusions) check(s, edynhip_exclude_collision(s.ctx, ex[0], ex[1]));
     s.pending_exclusions.clear();

@@ -41,7 +41,7 @@ typedef enum {
     EDYNHIP_ERR_HIP = -3,           /* a HIP runtime call failed (see edynhip_last_error) */
     EDYNHIP_ERR_CAPACITY = -4,      /* pair / manifold capacity exceeded */
     EDYNHIP_ERR_COLOURS = -5,       /* a body has more simultaneous contact partners than colours (64) */
-    EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope */
+    EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope (e.g. a joint type other than point / hinge) */
     EDYNHIP_ERR_INTERNAL = -7       /* a device-side invariant failed (e.g. the dataflow solve timed out waiting for a hand-off) */
 } edynhip_status;
 
@@ -89,7 +89,8 @@ typedef struct {
     const int32_t *shape_type;       /* EDYNHIP_SHAPE_* */
     const float *shape_param;        /* [n][4]: box half_extents xyz | sphere radius | plane normal xyz + constant */
     const float *friction;           /* [n] material.friction */
-    const float *restitution;        /* [n] material.restitution (must be 0: restitution solver is out of scope) */
+    const float *restitution;        /* [n] material.restitution; any value > 0 turns the restitution solver on
+                                        (src/edyn/dynamics/restitution_solver.cpp:86-408) */
     const uint64_t *group;           /* [n] collision_filter.group (all ones = default) */
     const uint64_t *mask;            /* [n] collision_filter.mask */
     const float *gravity;            /* [n][3] per-body gravity or NULL = config gravity */
@@ -114,6 +115,8 @@ typedef struct {
     uint32_t num_velocity_iterations;
     uint32_t num_position_iterations;
     float gravity[3];
+    uint32_t num_restitution_iterations;             /* default 8; 0 turns the restitution solver off */
+    uint32_t num_individual_restitution_iterations;  /* default 3 */
 } edynhip_params;
 
 /* One contact point; mirrors contact_point + contact_point_geometry + _material + _impulse. */

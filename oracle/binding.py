@@ -249,6 +249,10 @@ class World:
         f = self.L.orc_remove_collision_exclusion; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
         f(self.h, a, b)
 
+    def set_restitution_iterations(self, iters, individual=3):
+        f = self.L.orc_set_restitution_iterations; f.argtypes = [C.c_void_p, C.c_int, C.c_int]; f.restype = None
+        f(self.h, iters, individual)
+
     def set_ext_order(self, contacts, joints=()):
         """ORDER_EXTERNAL: visiting order for the next step (RefWorld.get_solve_order() of the same step)."""
         c = np.ascontiguousarray(contacts, np.uint32).reshape(-1, 3); j = np.ascontiguousarray(joints, np.uint32)

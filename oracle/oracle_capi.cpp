@@ -67,6 +67,7 @@ void orc_set_ext_order(void *h, const uint32_t *contacts3, uint32_t nc, const ui
 }
 int orc_ext_order_mismatch(void *h) { return ((World *)h)->ext_order_mismatch ? 1 : 0; }
 // Process-wide: integrate() calls the C library's sinf/cosf like the reference instead of the correctly rounded value.
+void orc_set_restitution_iterations(void *h, int iters, int individual) { World *w = (World *)h; w->restitution_iters = iters; w->individual_restitution_iters = individual; }
 void orc_set_libm_trig(int on) { g_libm_trig = on != 0; }
 void orc_exclude_collision(void *h, uint32_t a, uint32_t b) { ((World *)h)->exclude_collision(a, b); }
 void orc_remove_collision_exclusion(void *h, uint32_t a, uint32_t b) { ((World *)h)->remove_collision_exclusion(a, b); }
@@ -151,6 +152,7 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
             c.attachment = p.attachment; c.lifetime = p.lifetime;
             c.normal_impulse = p.normal_impulse; c.friction_impulse[0] = p.friction_impulse[0]; c.friction_impulse[1] = p.friction_impulse[1];
         }
+        m.with_restitution = w->tags_restitution(m.body[0], m.body[1]);
         w->manifolds.emplace(w->pair_key(m.body[0], m.body[1]), m);
     }
 }
@@ -159,8 +161,9 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
 void orc_get_joint_impulses(void *h, float *imp10) {
     World *w = (World *)h;
     for (size_t i = 0; i < w->joints.size(); ++i) {
-        for (int k = 0; k < 9; ++k) imp10[10 * i + k] = w->joints[i].impulse[k];
-        imp10[10 * i + 9] = w->joints[i].angle;
+        const bool alive = w->joints[i].alive;   // a removed joint reads 0, like the device side
+        for (int k = 0; k < 9; ++k) imp10[10 * i + k] = alive ? w->joints[i].impulse[k] : 0.0f;
+        imp10[10 * i + 9] = alive ? w->joints[i].angle : 0.0f;
     }
 }
 void orc_set_joint_params(void *h, uint32_t joint, const float *p) {

@@ -70,6 +70,7 @@ struct ContactPoint {
     int attachment;
     float distance;
     float friction, restitution;
+    float normal_restitution_impulse = 0, friction_restitution_impulse[2] = {0, 0};   // contact_point.hpp:46-58
     uint32_t lifetime;
     float normal_impulse;
     float friction_impulse[2];
@@ -80,6 +81,7 @@ struct Manifold {
     int num_points = 0;
     ContactPoint pt[kMaxContacts];   // list order: newest first
     uint32_t colour = kNoColour;
+    bool with_restitution = false;   // contact_manifold_with_restitution: mixed restitution > eps at creation (constraint_util.cpp:83-101)
 };
 
 struct Joint {
@@ -191,6 +193,7 @@ public:
     float dt = 1.0f / 60.0f;
     int vel_iters = 8, pos_iters = 3;   // context/settings.hpp:22-30 defaults
     vec3 gravity{0, -9.8f, 0};
+    int restitution_iters = 8, individual_restitution_iters = 3;   // settings.hpp:28-29
     int order = ORDER_SEQUENTIAL;
     struct ExtContact { uint32_t a, b, slot; };
     std::vector<ExtContact> ext_contact_order;   // ORDER_EXTERNAL: every active contact point, in the reference's visiting order
@@ -354,6 +357,10 @@ public:
         };
         one_way(a, b); one_way(b, a);
     }
+    bool tags_restitution(uint32_t a, uint32_t b) const {   // constraint_util.cpp:83-101 (no material table: material_mix_restitution = min)
+        const Body &A = bodies[a], &B = bodies[b];
+        return A.has_material && B.has_material && std::min(A.restitution, B.restitution) > kEps;
+    }
     void broadphase() {
         const float sep = kContactBreakingThreshold * 1.3f;   // broadphase.hpp:18
         const vec3 sep_off = vec3{1, 1, 1} * -sep;
@@ -382,6 +389,7 @@ public:
                     if (manifolds.count(key)) return;
                     if (!intersect(q, bodies[other].box)) return;
                     Manifold m; m.body[0] = k; m.body[1] = other;   // constraint_util.cpp:60-102
+                    m.with_restitution = tags_restitution(k, other);
                     manifolds.emplace(key, m);
                     new_keys.push_back(key);
                 });
@@ -942,9 +950,133 @@ public:
         }
     }
 
+    // ---------------- restitution solver (restitution_solver.cpp:31-408) ----------------
+    // Shock propagation before the constraint solver: per island and iteration, find the manifold that closes fastest; if it
+    // closes faster than 0.005 m/s, walk the island breadth-first from the faster of its two bodies and, at every procedural
+    // body, solve the manifolds around it that are still closing (rows with the contact's restitution, impulses from zero,
+    // `individual_restitution_iters` Gauss-Seidel sweeps) and apply the velocity changes at once. The reference walks its
+    // entity graph in adjacency-list order (an artefact of insertion history); here every choice is canonical: manifolds in
+    // ascending pair-key order, ties to the lower key, neighbours in that same order - the order the device pass uses too.
+    float manifold_min_relvel(const Manifold &m) const {   // :31-81
+        const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        const vec3 vA = A.kind == KIND_STATIC ? vec3{0, 0, 0} : A.linvel, wA = A.kind == KIND_STATIC ? vec3{0, 0, 0} : A.angvel;
+        const vec3 vB = B.kind == KIND_STATIC ? vec3{0, 0, 0} : B.linvel, wB = B.kind == KIND_STATIC ? vec3{0, 0, 0} : B.angvel;
+        float mn = kScalarMax;
+        for (int i = 0; i < m.num_points; ++i) {
+            const ContactPoint &cp = m.pt[i];
+            const vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+            const vec3 rA = pA - A.pos, rB = pB - B.pos;
+            const vec3 velA = vA + cross(wA, rA), velB = vB + cross(wB, rB);
+            mn = std::min(dot(velA - velB, cp.normal), mn);
+        }
+        return mn;
+    }
+    void restitution_solve_star(const std::vector<Manifold *> &ms) {   // solve_manifolds, :149-314
+        std::vector<Row> rows;
+        std::vector<FrictionRow> fric;
+        std::vector<ContactPoint *> cps;
+        for (Manifold *m : ms) {
+            BodyRef A = body_ref(m->body[0]), B = body_ref(m->body[1]);
+            for (int i = 0; i < m->num_points; ++i) {
+                ContactPoint &cp = m->pt[i];
+                const vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+                const vec3 rA = pA - A.pos, rB = pB - B.pos, n = cp.normal;
+                Row r;
+                r.J[0] = n; r.J[1] = cross(rA, n); r.J[2] = -n; r.J[3] = -cross(rB, n);
+                r.lower = 0; r.upper = kLarge; r.impulse = 0;
+                RowOptions o; o.restitution = cp.restitution;
+                finish_row(r, o, A, B);
+                FrictionRow f;
+                f.mu = cp.friction; f.normal_row = (uint32_t)rows.size();
+                vec3 t[2];
+                plane_space(n, t[0], t[1]);
+                for (int k = 0; k < 2; ++k) {
+                    f.row[k].J[0] = t[k]; f.row[k].J[1] = cross(rA, t[k]); f.row[k].J[2] = -t[k]; f.row[k].J[3] = -cross(rB, t[k]);
+                    f.row[k].eff_mass = effective_mass(f.row[k].J, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+                    f.row[k].rhs = -relative_speed(f.row[k].J, A.linvel, A.angvel, B.linvel, B.angvel);
+                    f.row[k].impulse = 0;
+                }
+                rows.push_back(r); fric.push_back(f); cps.push_back(&cp);
+            }
+        }
+        for (int it = 0; it < individual_restitution_iters; ++it)
+            for (size_t k = 0; k < rows.size(); ++k) {
+                const float d = solve_row(rows[k]);
+                apply_row_impulse(d, rows[k]);
+                solve_friction(fric[k], rows[fric[k].normal_row]);
+            }
+        for (size_t k = 0; k < rows.size(); ++k) {
+            cps[k]->normal_restitution_impulse = rows[k].impulse;
+            cps[k]->friction_restitution_impulse[0] = fric[k].row[0].impulse;
+            cps[k]->friction_restitution_impulse[1] = fric[k].row[1].impulse;
+        }
+        for (Manifold *m : ms)
+            for (uint32_t bi : m->body) {
+                Body &b = bodies[bi];
+                if (b.kind == KIND_STATIC) continue;
+                b.linvel += b.dv; b.angvel += b.dw;
+                b.dv = {0, 0, 0}; b.dw = {0, 0, 0};
+            }
+        dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
+    }
+    void solve_restitution() {   // :388-408
+        if (restitution_iters <= 0) return;
+        bool any = false;
+        for (auto &kv : manifolds) if (kv.second.with_restitution) { any = true; break; }
+        if (!any) return;
+        const uint32_t n = (uint32_t)bodies.size();
+        // canonical adjacency: every body's manifolds in ascending key order (std::map order)
+        std::vector<std::vector<Manifold *>> adj(n);
+        std::map<uint32_t, std::vector<Manifold *>> by_island;
+        auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
+        for (auto &kv : manifolds) {
+            Manifold &m = kv.second;
+            if (manifold_asleep(m)) continue;   // island_view excludes sleeping islands
+            adj[m.body[0]].push_back(&m); adj[m.body[1]].push_back(&m);
+            by_island[label_of(m.body[0], m.body[1])].push_back(&m);
+        }
+        const float threshold = -0.005f;
+        std::vector<uint8_t> island_done(n, 0);
+        for (int it = 0; it < restitution_iters; ++it) {
+            bool all_solved = true;
+            for (auto &isl : by_island) {
+                // (the reference re-examines every island in every iteration, solved or not: an island that was quiet can be
+                // hit again later - islands do not interact, so skipping is equivalent only within one iteration)
+                float min_relvel = kScalarMax;
+                Manifold *fastest = nullptr;
+                for (Manifold *m : isl.second) {
+                    if (!m->with_restitution) continue;
+                    const float r = manifold_min_relvel(*m);
+                    if (r < min_relvel) { min_relvel = r; fastest = m; }
+                }
+                if (!fastest || min_relvel > threshold) continue;   // solved
+                all_solved = false;
+                const Body &FA = bodies[fastest->body[0]], &FB = bodies[fastest->body[1]];
+                const float sA = FA.kind == KIND_STATIC ? 0.0f : length_sqr(FA.linvel), sB = FB.kind == KIND_STATIC ? 0.0f : length_sqr(FB.linvel);
+                uint32_t start;
+                if (sA > sB) start = FA.procedural() ? fastest->body[0] : fastest->body[1];
+                else start = FB.procedural() ? fastest->body[1] : fastest->body[0];
+                std::vector<uint8_t> visited(n, 0);
+                std::vector<uint32_t> queue{start};
+                visited[start] = 1;
+                for (size_t qi = 0; qi < queue.size(); ++qi) {   // breadth-first (entity_graph.hpp:356-422)
+                    const uint32_t node = queue[qi];
+                    std::vector<Manifold *> star;
+                    for (Manifold *m : adj[node]) if (manifold_min_relvel(*m) < threshold) star.push_back(m);
+                    if (!star.empty()) restitution_solve_star(star);
+                    for (Manifold *m : adj[node]) {
+                        const uint32_t o = m->body[0] == node ? m->body[1] : m->body[0];
+                        if (!visited[o] && bodies[o].procedural()) { visited[o] = 1; queue.push_back(o); }
+                    }
+                }
+            }
+            if (all_solved) break;
+        }
+    }
+
     void solve() {
         dummy_dv_ = {0, 0, 0}; dummy_dw_ = {0, 0, 0};
-        // solve_restitution: no-op for restitution-free scenes (restitution_solver.cpp:388-408) — out of scope.
+        solve_restitution();
         for (auto &b : bodies)   // apply_gravity.hpp:12-17
             if (b.kind == KIND_DYNAMIC && !b.asleep && b.gravity != vec3{0, 0, 0}) b.linvel += b.gravity * dt;
         if (order == ORDER_COLOURED) solve_coloured(); else solve_sequential();

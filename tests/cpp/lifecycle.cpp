@@ -13,6 +13,7 @@ static int failures = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); ++failures; } } while (0)
 
 int main() {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);
     entt::registry registry;
     auto config = edyn::init_config{};
     config.num_solver_velocity_iterations = 10;

@@ -233,13 +233,59 @@ def test_capacity_overflow_is_an_error_not_ub():
     assert ei.value.code == -4
 
 
-def test_restitution_is_rejected():
-    s = scenes.box_pile(2, 2, 2)
-    s["restitution"][1] = 0.5
-    w = edyn_amd.World()
-    with pytest.raises(edyn_amd.EdynHipError) as ei:
-        w.set_scene(s)
-    assert ei.value.code == -6
+def _bouncy(n, rest, shape="sphere", stacked=False, seed=1):
+    rng = np.random.default_rng(seed)
+    s = scenes._empty(n + 1); scenes._add_plane(s, 0); s["restitution"][0] = 1.0
+    for i in range(n):
+        s["kind"][i + 1] = scenes.KIND_DYNAMIC
+        s["pos"][i + 1] = (0.02 * i, 1.0 + 1.3 * i, 0.01 * i) if stacked else (3.0 * i, 1.0 + 0.7 * i, 0.5 * i)
+        if shape == "sphere":
+            s["shape_type"][i + 1] = scenes.SHAPE_SPHERE; s["shape_param"][i + 1] = (0.5, 0, 0, 0)
+        else:
+            s["shape_type"][i + 1] = scenes.SHAPE_BOX; s["shape_param"][i + 1] = (0.5, 0.4, 0.3, 0)
+            q = rng.normal(size=4); s["orn"][i + 1] = q / np.linalg.norm(q); s["angvel"][i + 1] = rng.normal(size=3)
+        s["restitution"][i + 1] = rest[i % len(rest)]
+        s["linvel"][i + 1] = (0.0, 0.0, 0.0) if stacked else (0.3 * i, 0, 0.1)
+    return s
+
+
+@pytest.mark.parametrize("name,make,steps", [
+    ("spheres", lambda: _bouncy(6, [0.9, 0.5, 0.2, 0.0, 0.7]), 300),
+    ("boxes", lambda: _bouncy(5, [0.8, 0.4, 0.6, 0.3], "box"), 300),
+    ("sphere_column", lambda: _bouncy(5, [0.8, 0.6], stacked=True), 300),      # one island: the walk propagates the shock upwards
+    ("box_column", lambda: _bouncy(4, [0.7, 0.5, 0.9], "box", stacked=True), 300),
+])
+def test_restitution_solver_bit_exact(name, make, steps):
+    """restitution_solver.cpp:86-408 on the device (restitution.hip) against the oracle's canonical-order statement of it
+    (which tests/test_reference_engine.py checks against the real engine): bouncing bodies stay bit-identical."""
+    sc = make()
+    g = gpu_world(sc); o = oracle_world(sc)
+    top = 0.0
+    for step in range(steps):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), (name, step)
+        for a, b in zip(g.get_state(), o.get_state()):
+            assert np.array_equal(a, b), (name, step)
+        top = max(top, float(g.get_state()[2][:, 1].max()))
+    assert top > 1.0   # something did bounce back up
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=name)
+
+
+def test_restitution_in_a_pile_and_switched_off():
+    """A pile where every third box is bouncy (one big island walked by one lane) stays bit-identical; with
+    num_restitution_iterations = 0 the pass is skipped on both sides."""
+    sc = scenes.box_pile(4, 4, 4)
+    sc["restitution"][0] = 0.8
+    sc["restitution"][1::3] = 0.6
+    sc["pos"][1:, 1] += 0.4
+    for iters in (8, 0):
+        g = gpu_world(sc); o = oracle_world(sc)
+        if iters == 0:
+            g.set_params(restitution_iterations=0); o.set_restitution_iterations(0)
+        for step in range(80):
+            g.step_simulation(1); o.step(1)
+            for a, b in zip(g.get_state(), o.get_state()):
+                assert np.array_equal(a, b), (iters, step)
 
 
 def test_update_accumulator_runs_fixed_steps():
