@@ -10,6 +10,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .scenes import KIND_DYNAMIC, subset
+
 
 def shard_range(total, rank, world_size):
     """Contiguous, balanced [first, first+count) of `total` items for `rank`."""
@@ -64,3 +66,206 @@ class StateGather:
 
 def pack_state(pos, orn, linvel, angvel):
     return np.concatenate([pos, orn, linvel, angvel], axis=1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ island partitioner
+def partition_islands(labels, kind, weights, world_size):
+    """Assign every island to a rank, balancing the summed weight ("balancing sum(contact rows)").
+
+    labels  [n] island label per body (the device labels of edynhip_get_derived: lowest body index of the island)
+    kind    [n] body kinds; non-dynamic bodies belong to no island and are replicated on every rank
+    weights [n] per-body cost (e.g. contact points the body takes part in; 1 = balance body counts)
+    Deterministic: islands by descending weight, ties by ascending label, each to the currently lightest rank (ties to
+    the lowest rank) - longest-processing-time-first. Returns rank_of_body [n] (-1 = replicated)."""
+    labels = np.asarray(labels); kind = np.asarray(kind); weights = np.asarray(weights, np.float64)
+    dyn = kind == KIND_DYNAMIC
+    rank_of = np.full(len(kind), -1, np.int32)
+    if not dyn.any():
+        return rank_of
+    isl, inv = np.unique(labels[dyn], return_inverse=True)
+    w = np.bincount(inv, weights=weights[dyn], minlength=len(isl))
+    order = np.lexsort((isl, -w))
+    load = np.zeros(world_size)
+    owner = np.zeros(len(isl), np.int32)
+    for k in order:
+        r = int(np.argmin(load))          # first minimum = lowest rank on ties
+        owner[k] = r
+        load[r] += w[k]
+    rank_of[dyn] = owner[inv]
+    return rank_of
+
+
+def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026):
+    """Cross-shard merge detection ("re-partition only when an island merge crosses shards"): island bounding
+    boxes (union of the body AABBs, grown by the manifold separation threshold) of islands owned by DIFFERENT ranks that
+    overlap. Returns the list of (label_a, label_b) pairs; empty = the partition is still valid. Conservative: overlapping
+    island boxes do not yet touch, but no contact between two shards can appear without it."""
+    kind = np.asarray(kind); labels = np.asarray(labels); rank_of = np.asarray(rank_of)
+    dyn = kind == KIND_DYNAMIC
+    isl, inv = np.unique(labels[dyn], return_inverse=True)
+    if len(isl) < 2:
+        return []
+    lo = np.full((len(isl), 3), np.inf); hi = np.full((len(isl), 3), -np.inf)
+    np.minimum.at(lo, inv, aabb[dyn][:, :3]); np.maximum.at(hi, inv, aabb[dyn][:, 3:])
+    lo -= margin; hi += margin
+    owner = np.zeros(len(isl), np.int32); owner[inv] = rank_of[dyn]
+    out = []
+    order = np.argsort(lo[:, 0], kind="stable")       # sweep along x
+    active = []
+    for k in order:
+        active = [a for a in active if hi[a, 0] >= lo[k, 0]]
+        for a in active:
+            if owner[a] != owner[k] and np.all(lo[a] <= hi[k]) and np.all(lo[k] <= hi[a]):
+                out.append((int(min(isl[a], isl[k])), int(max(isl[a], isl[k]))))
+        active.append(k)
+    return sorted(set(out))
+
+
+class ShardedWorld:
+    """One simulation sharded over the ranks of a process group at island granularity (solver.cpp:408-428: the
+    island is the reference's own unit of parallelism). Every rank owns the dynamic bodies of its islands plus a replica of
+    all non-dynamic bodies and steps them with its own stepper - NO collective inside a step. Once per step the integrated
+    state is gathered (StateGather: RCCL on GPUs, gloo on CPU) so that every rank - and the host registry - sees the whole
+    world; the gathered AABBs also tell when islands of different ranks come close (island_boxes_overlap), and then the
+    islands are re-partitioned with their contact manifolds (warm-start impulses, colours) carried to their new owner.
+
+    make_world(scene) -> a stepper with the World interface (edyn_amd.World on a GPU; the CPU tests pass the checker).
+    Body order inside a shard is ascending global index, so canonical pair keys, island labels (lowest index) and the
+    colouring keep their relative order: a shard computes exactly what the unsharded world computes for those islands."""
+
+    def __init__(self, scene, make_world, rank, world_size, backend="nccl", device="cuda", labels=None, weights=None):
+        self.scene, self.make_world = scene, make_world
+        self.rank, self.world_size, self.backend, self.device = rank, world_size, backend, device
+        self.kind = np.asarray(scene["kind"])
+        self.n = len(self.kind)
+        if labels is None:
+            # the islands of the initial state, from the stepper itself: broadphase pairs (AABBs within the contact margin) and
+            # joints connect dynamic bodies - exactly the graph the island manager partitions (island_manager.cpp:117-247)
+            probe = make_world(scene)
+            if hasattr(probe, "run_stages"):
+                probe.run_stages(1 | 2 | 4)                      # EDYNHIP_STAGE_BROADPHASE | NARROWPHASE | ISLANDS
+            else:
+                for stage in (0, 1, 2):
+                    probe.run_stage(stage)
+            labels = np.asarray(probe.get_derived()[2]).copy()
+            del probe
+        if weights is None:
+            weights = np.ones(self.n)
+        self.repartitions = 0
+        self._build(partition_islands(labels, self.kind, weights, world_size), scene, manifolds=None)
+
+    # -- shard construction
+    def _build(self, rank_of, scene, manifolds):
+        self.rank_of = rank_of
+        mine = (rank_of == self.rank) | (rank_of < 0)
+        self.local_ids = np.nonzero(mine)[0].astype(np.int64)            # ascending global indices
+        self.to_local = np.full(self.n, -1, np.int64); self.to_local[self.local_ids] = np.arange(len(self.local_ids))
+        self.owned = np.nonzero(rank_of == self.rank)[0]                   # what this rank contributes to the gather
+        counts = [int((rank_of == r).sum()) for r in range(self.world_size)]
+        self.owners = [np.nonzero(rank_of == r)[0] for r in range(self.world_size)]
+        local_scene = subset(scene, self.local_ids)
+        local_scene["joints"] = [(j[0], int(self.to_local[j[1]]), int(self.to_local[j[2]])) + tuple(j[3:])
+                                 for j in scene.get("joints") or [] if self.to_local[j[1]] >= 0 and self.to_local[j[2]] >= 0
+                                 and (rank_of[j[1]] == self.rank or rank_of[j[2]] == self.rank)]
+        self.world = self.make_world(local_scene)
+        if manifolds is not None and len(manifolds):
+            a, b = manifolds["body"][:, 0], manifolds["body"][:, 1]
+            keep = ((rank_of[a] == self.rank) | (rank_of[b] == self.rank))
+            rec = manifolds[keep].copy()
+            rec["body"] = self.to_local[rec["body"]]
+            self.world.set_manifolds(rec)                                  # relative order = canonical order (monotone index map)
+        self.gather = StateGather(counts, self.device, self.backend)
+        self.state = np.zeros((self.n, 13), np.float32)
+
+    # -- stepping
+    def step(self, n=1):
+        for _ in range(n):
+            self.world.step_simulation(1) if hasattr(self.world, "step_simulation") else self.world.step(1)
+            self._gather_state()
+
+    def _gather_state(self):
+        pos, orn, lv, av = self.world.get_state()
+        loc = self.to_local[self.owned]
+        local = pack_state(pos[loc], orn[loc], lv[loc], av[loc])
+        self.gather.local.zero_()
+        if len(local):
+            self.gather.local[: len(local)].copy_(torch.from_numpy(local))
+        self.gather.gather()
+        blocks = self.gather.split()
+        for r in range(self.world_size):
+            if len(self.owners[r]):
+                self.state[self.owners[r]] = blocks[r].cpu().numpy()
+        rep = np.nonzero(self.rank_of < 0)[0]                              # replicated bodies: every rank has the same values
+        if len(rep):
+            l = self.to_local[rep]
+            self.state[rep] = pack_state(pos[l], orn[l], lv[l], av[l])
+
+    def get_state(self):
+        """The whole world's (pos, orn, linvel, angvel), identical on every rank."""
+        s = self.state
+        return s[:, 0:3].copy(), s[:, 3:7].copy(), s[:, 7:10].copy(), s[:, 10:13].copy()
+
+    # -- global views needed for (re)partitioning: rare, so they travel as Python objects over the group
+    def _all_gather_object(self, obj):
+        if self.world_size == 1 or not dist.is_initialized():
+            return [obj]
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj)
+        return out
+
+    def global_islands(self):
+        """(labels [n], aabb [n,6], weights [n]) of the whole world from every rank's device labels."""
+        aabb_l, _, isl_l = self.world.get_derived()[:3]
+        m = self.world.get_manifolds()
+        w_l = np.zeros(len(self.local_ids))
+        if len(m):
+            np.add.at(w_l, m["body"][:, 0], m["num_points"]); np.add.at(w_l, m["body"][:, 1], m["num_points"])
+        loc = self.to_local[self.owned]
+        parts = self._all_gather_object((self.owned, self.local_ids[isl_l[loc]], aabb_l[loc], w_l[loc]))
+        labels = np.arange(self.n); aabb = np.zeros((self.n, 6), np.float32); weights = np.ones(self.n)
+        for ids, lab, bb, w in parts:
+            labels[ids] = lab; aabb[ids] = bb; weights[ids] = 1 + w
+        return labels, aabb, weights
+
+    def maybe_repartition(self, force=False):
+        """Re-partition when islands owned by different ranks approach each other (or on request). The contact manifolds
+        move with their islands. Returns True when the shards were rebuilt."""
+        labels, aabb, weights = self.global_islands()
+        close = island_boxes_overlap(aabb, labels, self.kind, self.rank_of)
+        if not close and not force:
+            return False
+        # islands whose boxes overlap must end up on one rank: weld them for the partitioner
+        parent = {}
+        def find(x):
+            while parent.get(x, x) != x:
+                x = parent[x]
+            return x
+        for a, b in close:
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+        welded = np.array([find(int(l)) for l in labels])
+        rank_of = partition_islands(welded, self.kind, weights, self.world_size)
+        m = self.world.get_manifolds()
+        rec = m.copy()
+        if len(rec):
+            rec["body"] = self.local_ids[rec["body"]]
+            a, b = rec["body"][:, 0], rec["body"][:, 1]
+            rec = rec[(self.rank_of[a] == self.rank) | ((self.rank_of[a] < 0) & (self.rank_of[b] == self.rank))]   # each manifold once
+        all_m = [x for x in self._all_gather_object(rec) if len(x)]
+        manifolds = np.concatenate(all_m) if all_m else rec[:0]
+        if len(manifolds):   # canonical order: ascending (owner << 32 | other), owner = the dynamic body, the higher index of two
+            a, b = manifolds["body"][:, 0].astype(np.uint64), manifolds["body"][:, 1].astype(np.uint64)
+            da, db = self.kind[manifolds["body"][:, 0]] == KIND_DYNAMIC, self.kind[manifolds["body"][:, 1]] == KIND_DYNAMIC
+            owner = np.where(da & db, np.maximum(a, b), np.where(da, a, b)); other = np.where(owner == a, b, a)
+            manifolds = manifolds[np.argsort((owner << np.uint64(32)) | other, kind="stable")]
+        scene = dict(self.scene)
+        pos, orn, lv, av = self.get_state()
+        scene["pos"], scene["orn"], scene["linvel"], scene["angvel"] = pos, orn, lv, av
+        self._build(rank_of, scene, manifolds)
+        self.repartitions += 1
+        self._gather_state_without_step()
+        return True
+
+    def _gather_state_without_step(self):
+        self._gather_state()
