@@ -132,11 +132,27 @@ __global__ void k_bp_build(const uint64_t *__restrict__ keys, int n, uint32_t *p
     if (i == 0) parent[0] = 0xFFFFFFFFu;
 }
 
+// Ropes ("escape links") for a stackless traversal: rope[x] = the node a depth-first walk visits after x's subtree - the right
+// sibling of the first ancestor-or-self that is a left child, or kRopeEnd. Computed with the topology (every few steps).
+constexpr uint32_t kRopeEnd = 0xFFFFFFFFu;
+__global__ void k_bp_ropes(int n, const uint32_t *__restrict__ parent, const uint32_t *__restrict__ right, uint32_t *rope) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= 2 * n - 1) return;
+    uint32_t c = (uint32_t)x, r = kRopeEnd;
+    for (;;) {
+        const uint32_t p = parent[c];
+        if (p == 0xFFFFFFFFu) break;                     // reached the root: nothing follows
+        if (right[p] != c) { r = right[p]; break; }      // c is a left child: its right sibling comes next
+        c = p;
+    }
+    rope[x] = r;
+}
+
 // Node boxes are exchanged between workgroups inside this launch, so they travel as 8-byte
 // agent-scope atomics on both sides (per-CU L1s and per-XCD L2s are not coherent for plain accesses).
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 DI unsigned long long pack2(float a, float b) { return ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a); }
-// node record: nmin = (min.xyz, bits(left child)), nmax = (max.xyz, bits(right child)); leaves carry 0xFFFFFFFF
+// node record: nmin = (min.xyz, bits(left child)), nmax = (max.xyz, bits(rope)); leaves carry 0xFFFFFFFF as left child
 DI void store_box(float4 *nmin, float4 *nmax, uint32_t node, f3 mn, f3 mx, uint32_t lc, uint32_t rc) {
     unsigned long long *p0 = (unsigned long long *)&nmin[node];
     unsigned long long *p1 = (unsigned long long *)&nmax[node];
@@ -157,7 +173,7 @@ DI void load_box(const float4 *nmin, const float4 *nmax, uint32_t node, f3 &mn, 
 }
 
 __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ parent,
-                           const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                           const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ rope,
                            const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
                            uint32_t *visit) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +181,7 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
     uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
     f3 mn = from4(amin[body]), mx = from4(amax[body]);
     uint32_t node = (uint32_t)(n - 1 + k);
-    store_box(nmin, nmax, node, mn, mx, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    store_box(nmin, nmax, node, mn, mx, 0xFFFFFFFFu, n > 1 ? rope[node] : kRopeEnd);
     if (n == 1) return;
     uint32_t p = parent[node];
     while (p != 0xFFFFFFFFu) {
@@ -177,7 +193,7 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
         load_box(nmin, nmax, sib, smn, smx);
         mn = {fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z)};
         mx = {fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z)};
-        store_box(nmin, nmax, p, mn, mx, left[p], right[p]);
+        store_box(nmin, nmax, p, mn, mx, left[p], rope[p]);
         node = p;
         p = parent[p];
     }
@@ -219,9 +235,11 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
 // offsets, a compaction kernel writes the list. No global sort (it used to be 7 radix passes, ~150 us per step).
 // swapped = the manifold's body[0] is `other` (the querying body is body[0], broadphase.cpp:151,171).
 constexpr int kOwnCap = 32;   // partners kept in the per-lane list; more go through the sorted fallback path
-struct Emit { uint64_t (*mine)[128]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; };
+constexpr int kBpBlock = 64;  // one wave per workgroup: LDS per block stays small, so many blocks share a CU
+// The lane's own keys all start with the same owner: LDS keeps only the low half, (other << 1 | swapped), 4 bytes a key.
+struct Emit { uint32_t (*mine)[kBpBlock]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; };
 DI void emit_pair(uint64_t skey, Emit &e) {
-    if (e.n < kOwnCap) { e.mine[e.n++][e.tx] = skey; return; }
+    if (e.n < kOwnCap) { e.mine[e.n++][e.tx] = (uint32_t)skey; return; }
     const uint32_t g = atomicAdd(&e.cnt->num_extra, 1u);   // rare: an owner with more than kOwnCap partners
     if (g < e.cap) e.extra[g] = skey; else e.cnt->pair_overflow = 1;
 }
@@ -267,15 +285,14 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be paid by the
 // whole wave on every iteration), (2) a dense loop over the recorded candidates running the exact predicates.
 constexpr int kCandCap = 40;
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, Filt f,
            const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
            uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit,
            const uint32_t *__restrict__ flags, bool sleeping) {
-    __shared__ uint32_t stk[48][128];            // traversal stacks in LDS, [depth][thread]: conflict-free
-    __shared__ uint32_t cand[kCandCap][128];     // candidate bodies per lane
-    __shared__ uint64_t mine[kOwnCap][128];      // this lane's (= this owner's) pair keys
+    __shared__ uint32_t cand[kCandCap][kBpBlock];     // candidate bodies per lane, [slot][thread]: conflict-free
+    __shared__ uint32_t mine[kOwnCap][kBpBlock];      // this lane's (= this owner's) pair keys, low halves
     const int tx = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next step (the topology may be reused)
@@ -297,26 +314,25 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     const box3 q = inset(bi, -kQueryGrow);
     int nc = 0;
     if (n > 1) {
-        int sp = 0;
-        stk[sp++][tx] = 0;
-        while (sp > 0) {
-            const uint32_t node = stk[--sp][tx];
+        // Stackless depth-first walk: descend into the left child while the box overlaps, otherwise (or at a leaf) follow the
+        // rope to whatever comes after this subtree. No per-lane stack: the loop carries one node id. The walk only records
+        // candidate leaves (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be
+        // paid by the whole wave on every iteration); the exact predicates run in the dense loop below.
+        uint32_t node = 0;
+        const uint32_t first_leaf = (uint32_t)(n - 1);
+        while (node != kRopeEnd) {
             const float4 lo4 = nmin[node], hi4 = nmax[node];
-            if (!intersect(box3{from4(lo4), from4(hi4)}, q)) continue;
-            if (node >= (uint32_t)(n - 1)) {
-                const uint32_t j = (uint32_t)(keys[node - (n - 1)] & 0xFFFFFFFFu);
+            const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
+            if (hit && node >= first_leaf) {
+                const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
                 if (j < i) {
                     if (nc < kCandCap) cand[nc++][tx] = j;
                     else consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);   // rare overflow path
                 } else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) {
                     consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
                 }
-            } else if (sp <= 46) {
-                stk[sp++][tx] = __float_as_uint(lo4.w);
-                stk[sp++][tx] = __float_as_uint(hi4.w);
-            } else {
-                cnt->pair_overflow = 2;   // traversal stack exhausted: reported as an error, never silently dropped
             }
+            node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
         }
     }
     for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, f, true, prev, pm, em);
@@ -327,12 +343,12 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     }
     // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
     for (int a = 1; a < em.n; ++a) {
-        const uint64_t v = mine[a][tx];
+        const uint32_t v = mine[a][tx];
         int b = a - 1;
         while (b >= 0 && mine[b][tx] > v) { mine[b + 1][tx] = mine[b][tx]; --b; }
         mine[b + 1][tx] = v;
     }
-    for (int a = 0; a < em.n; ++a) own_keys[(size_t)i * kOwnCap + a] = mine[a][tx];
+    for (int a = 0; a < em.n; ++a) own_keys[(size_t)i * kOwnCap + a] = ((uint64_t)i << 33) | mine[a][tx];
     own_count[i] = (uint32_t)em.n;
 }
 // After the scan of own_count: total pair count for the host, and the per-owner blocks copied to their final places.
@@ -416,9 +432,11 @@ int broadphase(edynhip_ctx *c) {
         EH_TRY(sort_u64(c, c->bvh.keys, c->bvh.keys_sorted, np, 32, 62));   // stable: equal codes keep ascending body order
         if (np > 1)
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
+        if (np > 1)
+            hipLaunchKernelGGL(k_bp_ropes, dim3(blocks(2 * np - 1, 256)), dim3(256), 0, s, (int)np, c->bvh.parent, c->bvh.right, c->bvh.rope);
         }
-        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, 128)), dim3(128), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
+        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);

@@ -149,6 +149,7 @@ struct LBVH {
     uint64_t *keys = nullptr, *keys_sorted = nullptr;   // morton<<32 | body
     uint32_t *parent = nullptr;     // [2n-1]: internal 0..n-2, leaves n-1..2n-2
     uint32_t *left = nullptr, *right = nullptr;   // internal nodes
+    uint32_t *rope = nullptr;       // [2n-1] stackless traversal: the node that follows this subtree in a depth-first walk
     float4 *nmin = nullptr, *nmax = nullptr;      // node boxes [2n-1]
     uint32_t *visit = nullptr;      // refit counters
     uint32_t *np_list = nullptr;    // shaped non-procedural bodies
