@@ -32,7 +32,7 @@ __global__ void k_step_reset(Counters *cnt) {   // (inside edynhip_step the prev
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
         cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0;
-        cnt->unc_count = 0; cnt->df_abort = 0;   // also the sticky ones: a stand-alone run follows set_* calls or a failed step
+        cnt->unc_count = 0; cnt->df_abort = 0; cnt->bp_rebuild = 0;   // also the sticky ones: a stand-alone run follows set_* calls or a failed step
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
     for (int k = t; k < 4 * (int)kMaxColours; k += 64) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
@@ -175,7 +175,8 @@ DI void load_box(const float4 *nmin, const float4 *nmax, uint32_t node, f3 &mn, 
 __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ parent,
                            const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ rope,
                            const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
-                           uint32_t *visit) {
+                           uint32_t *visit, const Counters *cnt) {
+    if (!cnt->bp_rebuild) return;   // the candidate lists are still valid: nobody walks the tree this step
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
@@ -281,21 +282,88 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
     if (g < em.cap) em.extra[g] = skey; else em.cnt->pair_overflow = 1;
 }
 
-// Two phases per lane so that the wave stays converged: (1) BVH traversal that only records the candidate leaves
-// (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be paid by the
-// whole wave on every iteration), (2) a dense loop over the recorded candidates running the exact predicates.
+// ---- candidate lists (Verlet lists) -----------------------------------------------------------------------------------
+// The tree walk is a chain of dependent loads (~150 node visits per body, a few hundred nanoseconds each) with only one lane
+// per body to hide it: ~140 us per step on a 32k pile whose pair set barely changes. So the walk is NOT done every step:
+// when it runs it queries with a FAT box (kListMargin) and leaves every body a list of candidate partners plus a copy of
+// the AABBs it was built from (ref boxes); the steps that follow only run the exact predicates over those lists - until
+// some body has moved further than kListSlack from its ref box, which a body-parallel check detects on the device at the
+// start of the step (no host round trip: the refit and the walk are enqueued every step and return at once when the
+// lists are still valid).
+// Why the pair set stays exact: every predicate below tests box_i grown by at most 0.026 against box_j. If no face of
+// either box has moved more than d since the lists were built, then grow(box_i(t), 0.026) lies inside grow(box_i(t0),
+// 0.026 + d) and box_j(t) inside grow(box_j(t0), d); an overlap now therefore implies that grow(box_i(t0), 0.026 + 2d)
+// overlapped box_j(t0) - and that pair is on the list as long as kListMargin >= 0.026 + 2 * kListSlack.
+constexpr float kListMargin = 0.1f, kListSlack = 0.035f;
+static_assert(kListMargin >= 0.026f + 2.0f * kListSlack, "candidate lists must cover every pair the exact tests can accept");
+constexpr uint32_t kListCap = 64;                 // candidates kept per body; a body with more walks the tree every step
+constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of such a body
+constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
+                                                  // sleeping is on: it matters only while that body sleeps, see below)
+struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };
+
+// Start of the step: are the lists still valid? (`force`: the host changed the set of bodies.)
+__global__ void k_bp_check(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin, const float4 *__restrict__ amax,
+                           CandLists cl, Counters *cnt, uint32_t force) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (t < np) {
+        const uint32_t b = proc[t];
+        const float4 a = amin[b], c = amax[b], ra = cl.ref_min[b], rc = cl.ref_max[b];
+        const float d = fmaxf(fmaxf(fmaxf(fabsf(a.x - ra.x), fabsf(a.y - ra.y)), fabsf(a.z - ra.z)),
+                              fmaxf(fmaxf(fabsf(c.x - rc.x), fabsf(c.y - rc.y)), fabsf(c.z - rc.z)));
+        moved = !(d <= kListSlack) || cl.count[b] == kListOverflow;   // (a NaN box counts as moved)
+    }
+    if (t == 0 && force) moved = true;
+    if (__any(moved) && (threadIdx.x & 63) == 0) cnt->bp_rebuild = 1u;
+}
+
+// The tree walk, only in the steps that rebuild the lists: one lane per body, stackless (ropes), fat query box.
+__global__ void __launch_bounds__(256)
+k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
+          const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways) {
+    if (!cnt->bp_rebuild) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next refit
+    if (k >= n) return;
+    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+    const float4 a4 = amin[i], c4 = amax[i];
+    cl.ref_min[i] = a4; cl.ref_max[i] = c4;
+    const box3 q = inset(box3{from4(a4), from4(c4)}, -kListMargin);
+    uint32_t *row = cl.list + (size_t)i * kListCap;
+    uint32_t nc = 0;
+    if (n > 1) {
+        uint32_t node = 0;
+        const uint32_t first_leaf = (uint32_t)(n - 1);
+        while (node != kRopeEnd) {   // descend left while the box overlaps, else follow the rope past this subtree
+            const float4 lo4 = nmin[node], hi4 = nmax[node];
+            const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
+            if (hit && node >= first_leaf) {
+                const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
+                if (j < i || (both_ways && j > i)) {
+                    if (nc < kListCap) row[nc] = j < i ? j : (j | kHigherBit);
+                    ++nc;
+                }
+            }
+            node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
+        }
+    }
+    cl.count[i] = nc <= kListCap ? nc : kListOverflow;
+}
+
+// Every step: the exact predicates over each body's candidates (or, for a body whose list overflowed, over a fresh tree
+// walk - k_bp_check forces the refit in that case), then the static / kinematic bodies, then the owner's keys in order.
 constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, Filt f,
            const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
-           uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, uint32_t *visit,
+           uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, CandLists cl,
            const uint32_t *__restrict__ flags, bool sleeping) {
-    __shared__ uint32_t cand[kCandCap][kBpBlock];     // candidate bodies per lane, [slot][thread]: conflict-free
+    __shared__ uint32_t cand[kCandCap][kBpBlock];     // tree-walk path only: candidate bodies per lane, [slot][thread]
     __shared__ uint32_t mine[kOwnCap][kBpBlock];      // this lane's (= this owner's) pair keys, low halves
     const int tx = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next step (the topology may be reused)
     if (k >= n) return;
     Emit em{mine, tx, 0, extra, cap, cnt};
     const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
@@ -311,13 +379,17 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
         return;
     }
     const box3 bi = body_box(amin, amax, i);
-    const box3 q = inset(bi, -kQueryGrow);
-    int nc = 0;
-    if (n > 1) {
-        // Stackless depth-first walk: descend into the left child while the box overlaps, otherwise (or at a leaf) follow the
-        // rope to whatever comes after this subtree. No per-lane stack: the loop carries one node id. The walk only records
-        // candidate leaves (cheap box tests; 64 lanes walk different paths, so anything expensive inside this loop would be
-        // paid by the whole wave on every iteration); the exact predicates run in the dense loop below.
+    const uint32_t lc = cl.count[i];
+    if (lc != kListOverflow) {
+        const uint32_t *row = cl.list + (size_t)i * kListCap;
+        for (uint32_t t = 0; t < lc; ++t) {
+            const uint32_t e = row[t], j = e & ~kHigherBit;
+            if (!(e & kHigherBit)) consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
+            else if (sleeping && (flags[j] & BF_ASLEEP)) consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
+        }
+    } else if (n > 1) {   // more than kListCap bodies around this one: walk the (freshly refitted) tree
+        const box3 q = inset(bi, -kQueryGrow);
+        int nc = 0;
         uint32_t node = 0;
         const uint32_t first_leaf = (uint32_t)(n - 1);
         while (node != kRopeEnd) {
@@ -327,19 +399,22 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
                 const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
                 if (j < i) {
                     if (nc < kCandCap) cand[nc++][tx] = j;
-                    else consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);   // rare overflow path
+                    else consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
                 } else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) {
                     consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
                 }
             }
             node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
         }
+        for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, f, true, prev, pm, em);
     }
-    for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, f, true, prev, pm, em);
-    for (uint32_t t = 0; t < num_np; ++t) {
-        uint32_t j = np_list[t];
-        box3 bj = body_box(amin, amax, j);
-        if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, f, false, prev, pm, em);
+    {
+        const box3 q = inset(bi, -kQueryGrow);
+        for (uint32_t t = 0; t < num_np; ++t) {
+            uint32_t j = np_list[t];
+            box3 bj = body_box(amin, amax, j);
+            if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, f, false, prev, pm, em);
+        }
     }
     // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
     for (int a = 1; a < em.n; ++a) {
@@ -411,6 +486,10 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
 }
 
 static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
+static bool bp_lists_enabled() {   // development knob: EDYNHIP_BP_LISTS=0 walks the tree every step
+    static const bool on = !(getenv("EDYNHIP_BP_LISTS") && getenv("EDYNHIP_BP_LISTS")[0] == '0');
+    return on;
+}
 
 int broadphase(edynhip_ctx *c) {
     hipStream_t s = c->stream;
@@ -435,8 +514,16 @@ int broadphase(edynhip_ctx *c) {
         if (np > 1)
             hipLaunchKernelGGL(k_bp_ropes, dim3(blocks(2 * np - 1, 256)), dim3(256), 0, s, (int)np, c->bvh.parent, c->bvh.right, c->bvh.rope);
         }
-        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, c->bvh.visit, c->b.flags, c->sleeping);
+        // candidate lists: check -> (refit -> walk, both no-ops while the lists are valid) -> exact predicates over the lists.
+        // A new topology re-sorts the leaves but the lists are indexed by body, so they survive it; they are rebuilt when a
+        // body has moved too far (device-side check) or when the host changed the set of bodies (lists_dirty).
+        const CandLists cl{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max};
+        const uint32_t force = (c->bvh.lists_dirty || !bp_lists_enabled()) ? 1u : 0u;
+        c->bvh.lists_dirty = false;
+        hipLaunchKernelGGL(k_bp_check, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, cl, c->cnt, force);
+        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt);
+        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);

@@ -92,6 +92,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.parent, (size_t)2 * nb)); EH_TRY(dalloc(c, t.left, nb)); EH_TRY(dalloc(c, t.right, nb));
     EH_TRY(dalloc(c, t.nmin, (size_t)2 * nb)); EH_TRY(dalloc(c, t.nmax, (size_t)2 * nb)); EH_TRY(dalloc(c, t.visit, nb));
     EH_TRY(dalloc(c, t.np_list, nb)); EH_TRY(dalloc(c, t.rope, (size_t)2 * nb));
+    EH_TRY(dalloc(c, t.cand_list, (size_t)nb * 64)); EH_TRY(dalloc(c, t.cand_count, nb)); EH_TRY(dalloc(c, t.ref_min, nb)); EH_TRY(dalloc(c, t.ref_max, nb));
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
@@ -497,6 +498,7 @@ static int rebuild_broadphase_lists(edynhip_ctx *c) {
     EH_HIP(c, hipMemsetAsync(c->own_count, 0, ((size_t)c->b.cap + 1) * sizeof(uint32_t), c->stream));
     c->all_asleep = false;
     c->bvh.age = 0;   // the tree topology is rebuilt on the next step
+    c->bvh.lists_dirty = true;
     c->bvh.num_np = (uint32_t)np_list.size();
     c->bvh.num_proc = (uint32_t)proc_list.size();
     np_list.insert(np_list.end(), proc_list.begin(), proc_list.end());

@@ -150,6 +150,11 @@ struct LBVH {
     uint32_t *parent = nullptr;     // [2n-1]: internal 0..n-2, leaves n-1..2n-2
     uint32_t *left = nullptr, *right = nullptr;   // internal nodes
     uint32_t *rope = nullptr;       // [2n-1] stackless traversal: the node that follows this subtree in a depth-first walk
+    // candidate lists (broadphase.hip "Verlet lists"): per body its possible partners within a fat margin, and the AABBs
+    // they were built from; valid until a body strays from its ref box
+    uint32_t *cand_list = nullptr, *cand_count = nullptr;
+    float4 *ref_min = nullptr, *ref_max = nullptr;
+    bool lists_dirty = true;        // the host changed the set of bodies: rebuild at the next step
     float4 *nmin = nullptr, *nmax = nullptr;      // node boxes [2n-1]
     uint32_t *visit = nullptr;      // refit counters
     uint32_t *np_list = nullptr;    // shaped non-procedural bodies
@@ -172,6 +177,7 @@ struct Counters {
     uint32_t num_extra;          // pair keys beyond an owner's in-LDS list (broadphase fallback path)
     uint32_t num_awake;          // procedural bodies left awake by this step's sleep decisions (island sleeping)
     uint32_t unc_count;          // edges k_col_prepare found uncoloured (listed in col_unc while they fit)
+    uint32_t bp_rebuild;         // this step rebuilds the broadphase candidate lists (set by k_bp_check, cleared at the step's end)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)

@@ -224,10 +224,11 @@ class World:
         has_inertia = scene.get("has_inertia")
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
+            grav = scene["gravity"][i] if scene.get("gravity") is not None else None
             self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
                           scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
                           scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
-                          True, int(scene["group"][i]), int(scene["mask"][i]))
+                          True, int(scene["group"][i]), int(scene["mask"][i]), grav)
         joints = scene.get("joints")
         if joints is not None:
             for j in joints:
@@ -483,10 +484,11 @@ class RefWorld:
         has_inertia = scene.get("has_inertia")
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
+            grav = scene["gravity"][i] if scene.get("gravity") is not None else None
             self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
                           scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
                           scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
-                          True, int(scene["group"][i]), int(scene["mask"][i]), None, sleeping_disabled)
+                          True, int(scene["group"][i]), int(scene["mask"][i]), grav, sleeping_disabled)
         for j in scene.get("joints") or []:
             self.add_joint(*j)
 
