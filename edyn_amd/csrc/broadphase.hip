@@ -21,6 +21,11 @@ using namespace dm;
 
 constexpr float kQueryGrow = 0.03f;              // conservative candidate margin (> 0.026)
 constexpr float kBreaking = 0.02f;               // broadphase.hpp:15 (m_aabb_offset)
+// candidate lists (see "candidate lists" below)
+constexpr float kListSlack = 0.035f;     // base slack
+constexpr float kListLookahead = 6.0f;   // + this many steps of motion at the current velocity
+constexpr float kListTest = 0.026f;      // the widest margin any exact predicate uses (separation threshold 0.02 * 1.3)
+static_assert(kListTest >= 0.02f * 1.3f - 1e-6f && kListTest <= kQueryGrow, "list margin must cover every exact predicate");
 // broadphase.hpp:18: contact_breaking_threshold * scalar(1.3), evaluated in fp32 like the reference
 __device__ __forceinline__ float separation_threshold() { return 0.02f * 1.3f; }
 
@@ -175,12 +180,22 @@ DI void load_box(const float4 *nmin, const float4 *nmax, uint32_t node, f3 &mn, 
 __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint32_t *__restrict__ parent,
                            const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ rope,
                            const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
-                           uint32_t *visit, const Counters *cnt) {
+                           uint32_t *visit, const Counters *cnt, float4 *ref_min, float4 *ref_max, const float4 *__restrict__ linvel,
+                           const float4 *__restrict__ angvel, float dt) {
     if (!cnt->bp_rebuild) return;   // the candidate lists are still valid: nobody walks the tree this step
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
     f3 mn = from4(amin[body]), mx = from4(amax[body]);
+    {   // this body's ref box and slack (see "candidate lists"); the leaf holds the ref box grown by the slack
+        const f3 v = from4(linvel[body]), w = from4(angvel[body]);
+        const f3 ext = mx - mn;
+        const float reach = 0.5f * sqrtf(ext.x * ext.x + ext.y * ext.y + ext.z * ext.z);   // no point of the body is further from its centre
+        float slack = kListSlack + kListLookahead * dt * (sqrtf(length_sqr(v)) + sqrtf(length_sqr(w)) * reach);
+        if (!(slack < 4.0f)) slack = 4.0f;   // also catches NaN / inf velocities
+        ref_min[body] = to4(mn, slack); ref_max[body] = to4(mx, 0.0f);
+        mn = mn - mk3(slack, slack, slack); mx = mx + mk3(slack, slack, slack);
+    }
     uint32_t node = (uint32_t)(n - 1 + k);
     store_box(nmin, nmax, node, mn, mx, 0xFFFFFFFFu, n > 1 ? rope[node] : kRopeEnd);
     if (n == 1) return;
@@ -285,22 +300,25 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // ---- candidate lists (Verlet lists) -----------------------------------------------------------------------------------
 // The tree walk is a chain of dependent loads (~150 node visits per body, a few hundred nanoseconds each) with only one lane
 // per body to hide it: ~140 us per step on a 32k pile whose pair set barely changes. So the walk is NOT done every step:
-// when it runs it queries with a FAT box (kListMargin) and leaves every body a list of candidate partners plus a copy of
+// when it runs it queries with a FAT box and leaves every body a list of candidate partners plus a copy of
 // the AABBs it was built from (ref boxes); the steps that follow only run the exact predicates over those lists - until
 // some body has moved further than kListSlack from its ref box, which a body-parallel check detects on the device at the
 // start of the step (no host round trip: the refit and the walk are enqueued every step and return at once when the
 // lists are still valid).
-// Why the pair set stays exact: every predicate below tests box_i grown by at most 0.026 against box_j. If no face of
-// either box has moved more than d since the lists were built, then grow(box_i(t), 0.026) lies inside grow(box_i(t0),
-// 0.026 + d) and box_j(t) inside grow(box_j(t0), d); an overlap now therefore implies that grow(box_i(t0), 0.026 + 2d)
-// overlapped box_j(t0) - and that pair is on the list as long as kListMargin >= 0.026 + 2 * kListSlack.
-constexpr float kListMargin = 0.1f, kListSlack = 0.035f;
-static_assert(kListMargin >= 0.026f + 2.0f * kListSlack, "candidate lists must cover every pair the exact tests can accept");
+// Every body carries its own slack s_i (how far any face of its AABB may stray from the ref box before the lists are void):
+// a base value plus the distance it would cover in a few steps at its current speed, so that fast bodies do not force a walk
+// every step. The leaves of the tree hold the ref boxes GROWN by the body's slack, and body i queries with its ref box grown
+// by 0.026 + s_i.
+// Why the pair set stays exact: every predicate below tests one box grown by at most 0.026 against the other. While no face
+// of box_i has moved more than s_i and none of box_j more than s_j, grow(box_i(t), 0.026) lies inside grow(box_i(t0),
+// 0.026 + s_i) and box_j(t) inside grow(box_j(t0), s_j): an overlap now implies that those two overlapped at t0, which is
+// exactly the walk's leaf test - the pair is on the list. (The slack only has to be a number; how it is chosen decides
+// how long the lists live, not whether they are right.)
 constexpr uint32_t kListCap = 64;                 // candidates kept per body; a body with more walks the tree every step
 constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of such a body
 constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
                                                   // sleeping is on: it matters only while that body sleeps, see below)
-struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };
+struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };   // ref_min.w = the body's slack
 
 // Start of the step: are the lists still valid? (`force`: the host changed the set of bodies.)
 __global__ void k_bp_check(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin, const float4 *__restrict__ amax,
@@ -312,7 +330,7 @@ __global__ void k_bp_check(const uint32_t *__restrict__ proc, uint32_t np, const
         const float4 a = amin[b], c = amax[b], ra = cl.ref_min[b], rc = cl.ref_max[b];
         const float d = fmaxf(fmaxf(fmaxf(fabsf(a.x - ra.x), fabsf(a.y - ra.y)), fabsf(a.z - ra.z)),
                               fmaxf(fmaxf(fabsf(c.x - rc.x), fabsf(c.y - rc.y)), fabsf(c.z - rc.z)));
-        moved = !(d <= kListSlack) || cl.count[b] == kListOverflow;   // (a NaN box counts as moved)
+        moved = !(d <= ra.w) || cl.count[b] == kListOverflow;   // ra.w = this body's slack (a NaN box counts as moved)
     }
     if (t == 0 && force) moved = true;
     if (__any(moved) && (threadIdx.x & 63) == 0) cnt->bp_rebuild = 1u;
@@ -327,9 +345,8 @@ k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ n
     if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next refit
     if (k >= n) return;
     const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-    const float4 a4 = amin[i], c4 = amax[i];
-    cl.ref_min[i] = a4; cl.ref_max[i] = c4;
-    const box3 q = inset(box3{from4(a4), from4(c4)}, -kListMargin);
+    const float4 a4 = cl.ref_min[i], c4 = cl.ref_max[i];          // written by this step's refit: the current AABB and the slack
+    const box3 q = inset(box3{from4(a4), from4(c4)}, -(kListTest + a4.w));
     uint32_t *row = cl.list + (size_t)i * kListCap;
     uint32_t nc = 0;
     if (n > 1) {
@@ -521,7 +538,7 @@ int broadphase(edynhip_ctx *c) {
         const uint32_t force = (c->bvh.lists_dirty || !bp_lists_enabled()) ? 1u : 0u;
         c->bvh.lists_dirty = false;
         hipLaunchKernelGGL(k_bp_check, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, cl, c->cnt, force);
-        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt);
+        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt);
         hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping);
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
