@@ -499,7 +499,7 @@ def test_body_with_more_neighbours_than_a_candidate_list_holds():
     s = scenes.box_pile(9, 1, 9)
     top = float(s["pos"][:, 1].max()) + 0.5
     xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
-    s = _append_body(s, pos=(xc, top + 0.06 + 0.05, zc), shape_param=(5.2, 0.05, 5.2, 0), mass=50.0)
+    s = _append_body(s, pos=(xc, top + 0.06 + 0.05, zc), shape_param=(5.2, 0.05, 5.2, 0), mass=1000.0)
     plate = len(s["kind"]) - 1
     s = _append_body(s, pos=(xc - 1.0, top + 0.16 + 0.8, zc), shape_param=(0.5, 0.5, 0.5, 0), mass=1.0)
     s = _append_body(s, pos=(xc + 1.5, top + 0.16 + 1.1, zc + 0.7), shape_param=(0.5, 0.5, 0.5, 0), mass=1.0)
