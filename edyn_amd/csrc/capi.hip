@@ -93,6 +93,8 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.nmin, (size_t)2 * nb)); EH_TRY(dalloc(c, t.nmax, (size_t)2 * nb)); EH_TRY(dalloc(c, t.visit, nb));
     EH_TRY(dalloc(c, t.np_list, nb)); EH_TRY(dalloc(c, t.rope, (size_t)2 * nb));
     EH_TRY(dalloc(c, t.cand_list, (size_t)nb * 64)); EH_TRY(dalloc(c, t.cand_count, nb)); EH_TRY(dalloc(c, t.ref_min, nb)); EH_TRY(dalloc(c, t.ref_max, nb));
+    EH_TRY(dalloc(c, c->np_ra, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rb, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rn, (size_t)M * kMaxPts));
+    EH_TRY(dalloc(c, c->np_rnum, M));
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));

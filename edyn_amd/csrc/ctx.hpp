@@ -217,6 +217,8 @@ struct edynhip_ctx {
     std::vector<eh::HostJoint> host_joints;   // by caller index (see HostJoint)
     eh::Rows rows;
     eh::LBVH bvh;
+    float4 *np_ra = nullptr, *np_rb = nullptr, *np_rn = nullptr;   // narrowphase staging: the raw collide() result per manifold
+    uint32_t *np_rnum = nullptr;
     uint64_t *pair_keys = nullptr, *pair_keys_sorted = nullptr;
     uint64_t *own_keys = nullptr;                                  // [body][kOwnCap] sorted pair keys of each owner (broadphase.hip)
     uint32_t *own_count = nullptr, *own_offset = nullptr;          // [bodies + 1]

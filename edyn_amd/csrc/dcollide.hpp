@@ -46,6 +46,23 @@ DI int support_face_index(f3 d) {   // box_shape.cpp:227-235 via max_index_abs
     if (az > m) { i = 2; }
     return comp(d, i) < 0 ? i * 2 + 1 : i * 2;
 }
+// Value selects: `d = c ? v : d` per scalar. The per-lane point lists (4 entries) are indexed with compile-time constants
+// only - unrolled loops with guards, these select chains for the few data-dependent indices, array rotation inside rolled
+// loops - so that they stay in registers; a dynamically indexed local array is scratch memory on this target.
+DI void sel(int &d, bool c, int v) { d = c ? v : d; }
+DI void sel(float &d, bool c, float v) { d = c ? v : d; }
+DI void sel(f3 &d, bool c, const f3 &v) { sel(d.x, c, v.x); sel(d.y, c, v.y); sel(d.z, c, v.z); }
+template <class T> DI T pick4(const T (&a)[4], int i) {
+    T r = a[0];
+    sel(r, i == 1, a[1]); sel(r, i == 2, a[2]); sel(r, i == 3, a[3]);
+    return r;
+}
+template <class T> DI void put4(T (&a)[4], int i, const T &v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel(a[k], k == i, v);
+}
+template <class T> DI void rotate4(T (&a)[4]) { T t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t; }
+
 DI int edge_index(int v0, int v1) {
     for (int i = 0; i < 12; ++i) {
         int a = kEdgeIdx[i * 2], b = kEdgeIdx[i * 2 + 1];
@@ -56,7 +73,8 @@ DI int edge_index(int v0, int v1) {
 // box_shape.cpp:30-96, object-space direction
 DI void support_feature_local(f3 h, f3 dir, int &feature, int &findex, float &projection, float threshold) {
     const int face = support_face_index(dir);
-    float proj[4]; int vidx[4]; int idx[4] = {0, 0, 0, 0};
+    float proj[4]; int vidx[4];
+    int i0 = 0, i1 = 0, i2 = 0;   // idx[0..2] of the reference's list of vertices within the threshold
     int count = 1, maxi = 0;
     projection = -kScalarMax;
 #pragma unroll
@@ -65,19 +83,20 @@ DI void support_feature_local(f3 h, f3 dir, int &feature, int &findex, float &pr
         vidx[i] = vi;
         float p = dot(box_vertex(h, vi), dir);
         proj[i] = p;
-        if (p > projection) { projection = p; idx[0] = i; maxi = i; }
+        if (p > projection) { projection = p; i0 = i; maxi = i; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (i != maxi && proj[i] > projection - threshold) idx[count++] = i;
-    if (count == 1) { feature = BF_VERTEX; findex = vidx[idx[0]]; }
-    else if (count == 2) { feature = BF_EDGE; findex = edge_index(vidx[idx[0]], vidx[idx[1]]); }
+        if (i != maxi && proj[i] > projection - threshold) { sel(i1, count == 1, i); sel(i2, count == 2, i); ++count; }
+    const int v0 = pick4(vidx, i0), v1 = pick4(vidx, i1), v2 = pick4(vidx, i2);
+    if (count == 1) { feature = BF_VERTEX; findex = v0; }
+    else if (count == 2) { feature = BF_EDGE; findex = edge_index(v0, v1); }
     else if (count == 3) {
         feature = BF_EDGE;
-        float p0 = proj[idx[0]], p1 = proj[idx[1]], p2 = proj[idx[2]];
-        if (p0 <= p1 && p0 <= p2) findex = edge_index(vidx[idx[1]], vidx[idx[2]]);
-        else if (p1 <= p0 && p1 <= p2) findex = edge_index(vidx[idx[0]], vidx[idx[2]]);
-        else findex = edge_index(vidx[idx[0]], vidx[idx[1]]);
+        float p0 = pick4(proj, i0), p1 = pick4(proj, i1), p2 = pick4(proj, i2);
+        if (p0 <= p1 && p0 <= p2) findex = edge_index(v1, v2);
+        else if (p1 <= p0 && p1 <= p2) findex = edge_index(v0, v2);
+        else findex = edge_index(v0, v1);
     } else { feature = BF_FACE; findex = face; }
 }
 DI void support_feature(f3 h, f3 pos, q4 orn, f3 axis_pos, f3 axis_dir, int &feature, int &findex, float &projection,
@@ -86,11 +105,11 @@ DI void support_feature(f3 h, f3 pos, q4 orn, f3 axis_pos, f3 axis_dir, int &fea
     support_feature_local(h, ld, feature, findex, projection, threshold);
     projection += dot(pos - axis_pos, axis_dir);
 }
-DI void face_world(f3 h, int f, f3 pos, q4 orn, f3 out[4]) {
+DI void face_world(f3 h, int f, f3 pos, q4 orn, f3 (&out)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = to_world(box_vertex(h, kFaceIdx[f * 4 + i]), pos, orn);
 }
-DI void edge_world(f3 h, int e, f3 pos, q4 orn, f3 out[2]) {
+DI void edge_world(f3 h, int e, f3 pos, q4 orn, f3 (&out)[2]) {
     out[0] = to_world(box_vertex(h, kEdgeIdx[e * 2]), pos, orn);
     out[1] = to_world(box_vertex(h, kEdgeIdx[e * 2 + 1]), pos, orn);
 }
@@ -107,7 +126,7 @@ DI f2 face_half_extents(f3 h, int f) {
 }
 
 // include/edyn/math/geom.hpp:331-348 (N = 4)
-DI bool point_in_quad_prism(const f3 v[4], f3 normal, f3 point) {
+DI bool point_in_quad_prism(const f3 (&v)[4], f3 normal, f3 point) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int j = (i + 1) & 3;
@@ -212,7 +231,7 @@ DI float manifold_score(f3 p0, f3 p1, f3 p2, f3 p3) {   // geom.cpp:846-855
     return length_sqr(c0) + length_sqr(c1) + length_sqr(c2) + length_sqr(c3);
 }
 // geom.cpp:857-985. Returns type | index << 8; increments num_points on append.
-DI int insertion_point_index(const f3 p[4], int &num_points, f3 np) {
+DI int insertion_point_index(const f3 (&p)[4], int &num_points, f3 np) {
     const float sim2 = kMergingThreshold * kMergingThreshold;
     if (num_points == 0) { int i = num_points++; return INS_APPEND | i << 8; }
     if (num_points == 1) {
@@ -257,7 +276,7 @@ DI int insertion_point_index(const f3 p[4], int &num_points, f3 np) {
     if (s2 > best) { best = s2; bi = 2; }
     if (s3 > best) { best = s3; bi = 3; }
     if (bi >= 0) {
-        f3 pb = bi == 0 ? p[0] : (bi == 1 ? p[1] : (bi == 2 ? p[2] : p[3]));
+        const f3 pb = pick4(p, bi);
         return (distance_sqr(pb, np) < sim2 ? INS_SIMILAR : INS_REPLACE) | bi << 8;
     }
     return INS_NONE;
@@ -274,7 +293,11 @@ DI void cp_swap(CPoint &p) {   // collision_result.hpp:23-35
     if (p.attachment == NA_ON_A) p.attachment = NA_ON_B;
     else if (p.attachment == NA_ON_B) p.attachment = NA_ON_A;
 }
-DI void res_add(CResult &r, const CPoint &p) { r.pt[r.num++] = p; }
+DI void sel(CPoint &d, bool c, const CPoint &v) {
+    sel(d.pivotA, c, v.pivotA); sel(d.pivotB, c, v.pivotB); sel(d.normal, c, v.normal);
+    sel(d.distance, c, v.distance); sel(d.attachment, c, v.attachment);
+}
+DI void res_add(CResult &r, const CPoint &p) { put4(r.pt, r.num, p); ++r.num; }
 DI void res_maybe_add(CResult &r, const CPoint &np) {   // collision_result.cpp:12-33
     f3 piv[kMaxContacts];
 #pragma unroll
@@ -285,7 +308,7 @@ DI void res_maybe_add(CResult &r, const CPoint &np) {   // collision_result.cpp:
         for (int i = 0; i < kMaxContacts; ++i) piv[i] = r.pt[i].pivotB;
         res = insertion_point_index(piv, r.num, np.pivotB);
     }
-    if ((res & 0xFF) != INS_NONE) r.pt[res >> 8] = np;
+    put4(r.pt, (res & 0xFF) != INS_NONE ? res >> 8 : -1, np);
 }
 
 struct Ctx { f3 posA; q4 ornA; f3 posB; q4 ornB; float threshold; };
@@ -349,32 +372,47 @@ DI void collide_box_box(f3 hA, f3 hB, const Ctx &c, CResult &result) {
         face_world(hB, idxB, posB, ornB, fvB);
         f3 fnB = face_normal_world(idxB, ornB);
         point.attachment = NA_ON_B;
-        for (int i = 0; i < 4; ++i)
-            if (point_in_quad_prism(fvA, fnA, fvB[i])) {
-                f3 pf = project_plane(fvB[i], fvA[0], fnA);
+        // rolled loops (res_maybe_add is large); the vertex list is rotated by one each pass so that the current vertex is
+        // always element 0, and is back in its original order after the fourth
+        const f3 fvA0 = fvA[0], fvB0 = fvB[0];
+#pragma nounroll
+        for (int i = 0; i < 4; ++i) {
+            const f3 vb = fvB[0];
+            rotate4(fvB);
+            if (point_in_quad_prism(fvA, fnA, vb)) {
+                f3 pf = project_plane(vb, fvA0, fnA);
                 point.pivotA = to_object(pf, posA, ornA);
-                point.pivotB = to_object(fvB[i], posB, ornB);
+                point.pivotB = to_object(vb, posB, ornB);
                 res_maybe_add(result, point);
             }
-        for (int i = 0; i < 4; ++i)
-            if (point_in_quad_prism(fvB, fnB, fvA[i])) {
-                f3 pf = project_plane(fvA[i], fvB[0], fnB);
-                point.pivotA = to_object(fvA[i], posA, ornA);
+        }
+#pragma nounroll
+        for (int i = 0; i < 4; ++i) {
+            const f3 va = fvA[0];
+            rotate4(fvA);
+            if (point_in_quad_prism(fvB, fnB, va)) {
+                f3 pf = project_plane(va, fvB0, fnB);
+                point.pivotA = to_object(va, posA, ornA);
                 point.pivotB = to_object(pf, posB, ornB);
                 res_maybe_add(result, point);
             }
+        }
         if (result.num < 4) {
             f3 fc = face_center(hA, idxA, posA, ornA);
             m3 fb = face_basis(idxA, ornA);
             f2 he = face_half_extents(hA, idxA);
+#pragma nounroll
             for (int j = 0; j < 4; ++j) {
-                f3 b0w = fvB[j], b1w = fvB[(j + 1) & 3];
+                const f3 b0w = fvB[0], b1w = fvB[1];
+                rotate4(fvB);
                 f3 b0 = to_object(b0w, fc, fb), b1 = to_object(b1w, fc, fb);
-                float s[2];
-                int n = intersect_line_aabb({b0.x, b0.z}, {b1.x, b1.z}, -he, he, s[0], s[1]);
+                float s0, s1;
+                int n = intersect_line_aabb({b0.x, b0.z}, {b1.x, b1.z}, -he, he, s0, s1);
+#pragma nounroll
                 for (int k = 0; k < n; ++k) {
-                    if (s[k] < 0 || s[k] > 1) continue;
-                    f3 q1 = lerp(b0w, b1w, s[k]);
+                    const float sk = k ? s1 : s0;
+                    if (sk < 0 || sk > 1) continue;
+                    f3 q1 = lerp(b0w, b1w, sk);
                     f3 q0 = project_plane(q1, fc, fnA);
                     point.pivotA = to_object(q0, posA, ornA);
                     point.pivotB = to_object(q1, posB, ornB);
@@ -389,11 +427,12 @@ DI void collide_box_box(f3 hA, f3 hB, const Ctx &c, CResult &result) {
         if (fA) { face_world(hA, idxA, posA, ornA, fv); edge_world(hB, idxB, posB, ornB, ev); }
         else { face_world(hB, idxB, posB, ornB, fv); edge_world(hA, idxA, posA, ornA, ev); }
         point.attachment = fA ? NA_ON_A : NA_ON_B;
+#pragma unroll
         for (int i = 0; i < 2; ++i)
             if (point_in_quad_prism(fv, fn, ev[i])) {
                 f3 pf = project_plane(ev[i], fv[0], fn);
-                point.pivotA = fA ? to_object(pf, posA, ornA) : to_object(ev[i], posA, ornA);
-                point.pivotB = fA ? to_object(ev[i], posB, ornB) : to_object(pf, posB, ornB);
+                point.pivotA = to_object(fA ? pf : ev[i], posA, ornA);
+                point.pivotB = to_object(fA ? ev[i] : pf, posB, ornB);
                 res_add(result, point);
             }
         if (result.num < 2) {
@@ -401,11 +440,13 @@ DI void collide_box_box(f3 hA, f3 hB, const Ctx &c, CResult &result) {
             m3 fb = fA ? face_basis(idxA, ornA) : face_basis(idxB, ornB);
             f2 he = fA ? face_half_extents(hA, idxA) : face_half_extents(hB, idxB);
             f3 e0 = to_object(ev[0], fc, fb), e1 = to_object(ev[1], fc, fb);
-            float s[2];
-            int n = intersect_line_aabb({e0.x, e0.z}, {e1.x, e1.z}, -he, he, s[0], s[1]);
-            for (int i = 0; i < n; ++i) {
-                if (s[i] < 0 || s[i] > 1) continue;
-                f3 ep = lerp(ev[0], ev[1], s[i]);
+            float s0, s1;
+            int n = intersect_line_aabb({e0.x, e0.z}, {e1.x, e1.z}, -he, he, s0, s1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float si = i ? s1 : s0;
+                if (i >= n || si < 0 || si > 1) continue;
+                f3 ep = lerp(ev[0], ev[1], si);
                 f3 fp = project_plane(ep, fc, sep);
                 point.pivotA = to_object(fA ? fp : ep, posA, ornA);
                 point.pivotB = to_object(fA ? ep : fp, posB, ornB);
@@ -453,7 +494,9 @@ DI void collide_box_plane(f3 hA, f3 pn, float pc, const Ctx &c, CResult &result)
     }
     CPoint point;
     point.normal = pn; point.attachment = NA_ON_B;
-    for (int i = 0; i < nv; ++i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= nv) break;
         point.pivotA = verts[i];
         f3 pAw = to_world(point.pivotA, c.posA, c.ornA);
         f3 pBw = project_plane(pAw, center, pn);
@@ -522,7 +565,10 @@ DI void collide(int tA, float4 sA, int tB, float4 sB, const Ctx &c, CResult &r) 
     else if (tA == SHAPE_PLANE && tB == SHAPE_SPHERE) { collide_sphere_plane(sB.x, from4(sA), sA.w, sw, r); swapped = true; }
     else if (tA == SHAPE_SPHERE && tB == SHAPE_BOX) collide_sphere_box(sA.x, from4(sB), c, r);
     else if (tA == SHAPE_BOX && tB == SHAPE_SPHERE) { collide_sphere_box(sB.x, from4(sA), sw, r); swapped = true; }
-    if (swapped) for (int i = 0; i < r.num; ++i) cp_swap(r.pt[i]);
+    if (swapped) {
+#pragma unroll
+        for (int i = 0; i < kMaxContacts; ++i) if (i < r.num) cp_swap(r.pt[i]);
+    }
 }
 
 }  // namespace dc

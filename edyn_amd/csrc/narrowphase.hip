@@ -13,59 +13,41 @@
 namespace eh {
 using namespace dc;
 
-struct Pt {
-    f3 pivotA, pivotB, normal, lnormal;
-    float distance, friction, restitution;
-    int attachment;
-    uint32_t lifetime;
-    float ni, f0, f1;
-};
-
 struct BodyIn { f3 pos; q4 orn; f3 angvel; float friction, restitution; bool rolling; };
 
-DI void set_local_normal(Pt &p, const BodyIn &A, const BodyIn &B) {
-    if (p.attachment != NA_NONE) p.lnormal = rotate(conjugate(p.attachment == NA_ON_A ? A.orn : B.orn), p.normal);
-    else p.lnormal = mk3(0, 0, 0);
+DI f3 local_normal(const CPoint &rp, const BodyIn &A, const BodyIn &B) {
+    return rp.attachment != NA_NONE ? rotate(conjugate(rp.attachment == NA_ON_A ? A.orn : B.orn), rp.normal) : mk3(0, 0, 0);
 }
-DI void merge_point(Pt &p, const CPoint &rp, const BodyIn &A, const BodyIn &B) {
-    p.pivotA = rp.pivotA; p.pivotB = rp.pivotB; p.normal = rp.normal;
-    p.distance = rp.distance; p.attachment = rp.attachment;
-    set_local_normal(p, A, B);
-}
-DI Pt make_point(const CPoint &rp, const BodyIn &A, const BodyIn &B) {
-    Pt p;
-    p.pivotA = rp.pivotA; p.pivotB = rp.pivotB; p.normal = rp.normal;
-    p.attachment = rp.attachment; p.distance = rp.distance;
-    set_local_normal(p, A, B);
-    p.friction = sqrtf(A.friction * B.friction);          // material_mixing.hpp:16-18
-    p.restitution = fminf(A.restitution, B.restitution);  // :12-14
-    p.lifetime = 0; p.ni = 0; p.f0 = 0; p.f1 = 0;
-    return p;
-}
-DI int find_nearest(const Pt &cp, const CResult &res) {
+DI int find_nearest(const CPoint &cp, const CPoint (&rs)[4], int R) {
     float best = square(kCachingThreshold);
-    int idx = res.num;
-    for (int i = 0; i < res.num; ++i) {
-        float dA = length_sqr(res.pt[i].pivotA - cp.pivotA);
-        float dB = length_sqr(res.pt[i].pivotB - cp.pivotB);
-        if (dA < best) { best = dA; idx = i; }
-        if (dB < best) { best = dB; idx = i; }
+    int idx = R;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < R) {
+            float dA = length_sqr(rs[i].pivotA - cp.pivotA);
+            float dB = length_sqr(rs[i].pivotB - cp.pivotB);
+            if (dA < best) { best = dA; idx = i; }
+            if (dB < best) { best = dB; idx = i; }
+        }
     }
     return idx;
 }
-DI int find_nearest_rolling(const CResult &res, f3 cp_pivot, f3 origin, q4 orn, f3 angvel, float dt) {
-    int idx = res.num;
+DI int find_nearest_rolling(const CPoint (&rs)[4], int R, f3 cp_pivot, f3 origin, q4 orn, f3 angvel, float dt) {
+    int idx = R;
     q4 prev_orn = integrate(orn, angvel, -dt);
     f3 prev_pivot = to_world(cp_pivot, origin, prev_orn);
     float best = square(kCachingThreshold);
-    for (int i = 0; i < res.num; ++i) {
-        f3 pA = to_world(res.pt[i].pivotA, origin, orn);   // pivotA for both bodies, as the reference does
-        float d2 = distance_sqr(pA, prev_pivot);
-        if (d2 < best) { best = d2; idx = i; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < R) {
+            f3 pA = to_world(rs[i].pivotA, origin, orn);   // pivotA for both bodies, as the reference does
+            float d2 = distance_sqr(pA, prev_pivot);
+            if (d2 < best) { best = d2; idx = i; }
+        }
     }
     return idx;
 }
-DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
+DI bool should_remove(const CPoint &cp, const BodyIn &A, const BodyIn &B) {
     const float thr = kBreakingThreshold, thr2 = thr * thr;
     f3 d = to_world(cp.pivotA, A.pos, A.orn) - to_world(cp.pivotB, B.pos, B.orn);
     float nd = dot(d, cp.normal);
@@ -73,8 +55,41 @@ DI bool should_remove(const Pt &cp, const BodyIn &A, const BodyIn &B) {
     return nd > thr || length_sqr(td) > thr2;
 }
 
+// Two kernels, so that neither has to hold the closest-feature search and the manifold bookkeeping in registers at once:
+//   k_np_detect  detect_collision: AABB pre-check + collide() -> the raw result (<= 4 points) into a staging array
+//   k_np_merge   update_contact_distances + process_collision: old points x result -> the manifold's new point list
+// Staging layout per result point slot k of manifold m, at [k * cap + m]: ra = (pivotA, distance), rb = (pivotB, bits(attachment)),
+// rn = (normal, -); rnum[m] = number of result points.
+struct Staging { float4 *ra, *rb, *rn; uint32_t *rnum; };
+
 __global__ void __launch_bounds__(64, 2)
-k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old) {
+k_np_detect(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+    const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+    if (sleeping && edge_asleep(fa, fb)) { st.rnum[m] = 0; return; }
+    CResult res;
+    res.num = 0;
+    const box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
+    if (intersect(inset(ba, -kBreakingThreshold), bbx)) {
+        const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+        Ctx ctx{from4(B_POS(b, ia)), q_from4(B_ORN(b, ia)), from4(B_POS(b, ib)), q_from4(B_ORN(b, ib)), kCollisionThreshold};
+        collide(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
+    }
+    st.rnum[m] = (uint32_t)res.num;
+#pragma unroll
+    for (int k = 0; k < kMaxPts; ++k) {
+        if (k >= res.num) break;
+        const size_t d = (size_t)k * mf.cap + m;
+        st.ra[d] = to4(res.pt[k].pivotA, res.pt[k].distance);
+        st.rb[d] = to4(res.pt[k].pivotB, __int_as_float(res.pt[k].attachment));
+        st.rn[d] = to4(res.pt[k].normal, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(64, 2)
+k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old, Staging st) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) {
         const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
@@ -101,105 +116,154 @@ k_narrowphase(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manif
           float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
           B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tB == SHAPE_SPHERE; }
 
-        Pt pts[kMaxPts];
-        for (int k = 0; k < n_old; ++k) {
-            const size_t s = (size_t)k * src.cap + sidx;
-            float4 a = src.pA[s], bb = src.pB[s], n = src.nrm[s], l = src.lnrm[s], im = src.imp[s];
-            Pt &p = pts[k];
-            p.pivotA = from4(a); p.pivotB = from4(bb); p.normal = from4(n); p.lnormal = from4(l);
-            p.friction = bb.w; p.attachment = __float_as_int(n.w); p.restitution = l.w;
-            p.ni = im.x; p.f0 = im.y; p.f1 = im.z; p.lifetime = __float_as_uint(im.w);
-            // update_contact_distances
-            p.distance = dot(p.normal, to_world(p.pivotA, A.pos, A.orn) - to_world(p.pivotB, B.pos, B.orn));
+        // Old points: only what the matching needs is held across it (pivots, normal, distance); friction, restitution, the
+        // local normal, the warm-start impulses and the lifetime are re-read just before the stores.
+        CPoint pts[kMaxPts];
+#pragma unroll
+        for (int k = 0; k < kMaxPts; ++k) {
+            if (k < n_old) {
+                const size_t s = (size_t)k * src.cap + sidx;
+                const float4 a = src.pA[s], bb = src.pB[s], n = src.nrm[s];
+                CPoint &p = pts[k];
+                p.pivotA = from4(a); p.pivotB = from4(bb); p.normal = from4(n); p.attachment = __float_as_int(n.w);
+                // update_contact_distances
+                p.distance = dot(p.normal, to_world(p.pivotA, A.pos, A.orn) - to_world(p.pivotB, B.pos, B.orn));
+            } else {
+                pts[k] = CPoint{};
+            }
         }
 
-        CResult res;
-        res.num = 0;
-        {
-            box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
-            if (intersect(inset(ba, -kBreakingThreshold), bbx)) {
-                Ctx ctx{A.pos, A.orn, B.pos, B.orn, kCollisionThreshold};
-                collide(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
+        const int R = (int)st.rnum[m];
+        CPoint rs[kMaxPts];
+#pragma unroll
+        for (int k = 0; k < kMaxPts; ++k) {
+            if (k < R) {
+                const size_t d = (size_t)k * mf.cap + m;
+                const float4 ra = st.ra[d], rb = st.rb[d], rn = st.rn[d];
+                rs[k] = CPoint{from4(ra), from4(rb), from4(rn), ra.w, __float_as_int(rb.w)};
+            } else {
+                rs[k] = CPoint{};
             }
         }
 
         // ---- process_collision ----
-        const int R = res.num;
-        bool merged[kMaxPts] = {false, false, false, false};
-        bool dead[kMaxPts] = {false, false, false, false};
+        uint32_t merged = 0, dead = 0, changed = 0;   // bit r: result point r consumed; bit i: old point i removed / rewritten
         int num_points = n_old;
-        for (int i = 0; i < n_old; ++i) {
-            Pt &cp = pts[i];
-            ++cp.lifetime;
-            int nearest = find_nearest(cp, res);
-            if (nearest == R && A.rolling) nearest = find_nearest_rolling(res, cp.pivotA, A.pos, A.orn, A.angvel, dt);
-            if (nearest == R && B.rolling) nearest = find_nearest_rolling(res, cp.pivotB, B.pos, B.orn, B.angvel, dt);
-            if (nearest < R && !merged[nearest]) { merge_point(cp, res.pt[nearest], A, B); merged[nearest] = true; }
-            else if (should_remove(cp, A, B)) { dead[i] = true; --num_points; }
+#pragma unroll
+        for (int i = 0; i < kMaxPts; ++i) {
+            if (i < n_old) {
+                CPoint &cp = pts[i];
+                int nearest = find_nearest(cp, rs, R);
+                if (nearest == R && A.rolling) nearest = find_nearest_rolling(rs, R, cp.pivotA, A.pos, A.orn, A.angvel, dt);
+                if (nearest == R && B.rolling) nearest = find_nearest_rolling(rs, R, cp.pivotB, B.pos, B.orn, B.angvel, dt);
+                if (nearest < R && !((merged >> nearest) & 1u)) { cp = pick4(rs, nearest); changed |= 1u << i; merged |= 1u << nearest; }
+                else if (should_remove(cp, A, B)) { dead |= 1u << i; --num_points; }
+            }
         }
-        bool all_merged = true;
-        for (int r = 0; r < R; ++r) all_merged = all_merged && merged[r];
+        const uint32_t all_r = (1u << R) - 1u;
 
-        Pt created[kMaxPts];
-        int n_created = 0;
-        if (!all_merged) {
-            CPoint lp[kMaxPts];
+        CPoint lp[kMaxPts];
+        uint32_t create = 0;   // bit i: local slot i becomes a new contact point
+        if ((merged & all_r) != all_r) {
             int lold[kMaxPts] = {-1, -1, -1, -1};
             int ltype[kMaxPts] = {INS_NONE, INS_NONE, INS_NONE, INS_NONE};
+#pragma unroll
+            for (int i = 0; i < kMaxPts; ++i) lp[i] = CPoint{};
             if (num_points > 0) {
                 int k = 0;
-                for (int i = 0; i < n_old; ++i) {
-                    if (dead[i]) continue;
-                    lp[k] = CPoint{pts[i].pivotA, pts[i].pivotB, pts[i].normal, pts[i].distance, NA_NONE};
-                    lold[k] = i;
-                    ++k;
+#pragma unroll
+                for (int i = 0; i < kMaxPts; ++i) {
+                    if (i < n_old && !((dead >> i) & 1u)) {
+                        CPoint loc = pts[i];
+                        loc.attachment = NA_NONE;
+                        put4(lp, k, loc);
+                        put4(lold, k, i);
+                        ++k;
+                    }
                 }
             } else {
                 num_points = 1;
-                lp[0] = res.pt[0];
+                lp[0] = rs[0];
                 ltype[0] = INS_APPEND;
-                merged[0] = true;
+                merged |= 1u;
             }
-            for (int r = 0; r < R; ++r) {
-                if (merged[r]) continue;
-                const CPoint rp = res.pt[r];
-                f3 piv[kMaxPts];
-                for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotA;
-                int ir = insertion_point_index(piv, num_points, rp.pivotA);
-                if ((ir & 0xFF) == INS_NONE) {
-                    for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotB;
-                    ir = insertion_point_index(piv, num_points, rp.pivotB);
+#pragma unroll
+            for (int r = 0; r < kMaxPts; ++r) {
+                if (r < R && !((merged >> r) & 1u)) {
+                    const CPoint rp = rs[r];
+                    f3 piv[kMaxPts];
+#pragma unroll
+                    for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotA;
+                    int ir = insertion_point_index(piv, num_points, rp.pivotA);
+                    if ((ir & 0xFF) == INS_NONE) {
+#pragma unroll
+                        for (int i = 0; i < kMaxPts; ++i) piv[i] = lp[i].pivotB;
+                        ir = insertion_point_index(piv, num_points, rp.pivotB);
+                    }
+                    if ((ir & 0xFF) != INS_NONE) { put4(lp, ir >> 8, rp); put4(ltype, ir >> 8, ir & 0xFF); }
                 }
-                if ((ir & 0xFF) != INS_NONE) { lp[ir >> 8] = rp; ltype[ir >> 8] = ir & 0xFF; }
             }
-            for (int i = 0; i < num_points; ++i) {
-                switch (ltype[i]) {
-                case INS_APPEND: created[n_created++] = make_point(lp[i], A, B); break;
-                case INS_SIMILAR:
-                    if (lold[i] < 0) created[n_created++] = make_point(lp[i], A, B);
-                    else merge_point(pts[lold[i]], lp[i], A, B);
-                    break;
-                case INS_REPLACE:
-                    if (lold[i] >= 0) dead[lold[i]] = true;
-                    created[n_created++] = make_point(lp[i], A, B);
-                    break;
-                default: break;
+#pragma unroll
+            for (int i = 0; i < kMaxPts; ++i) {
+                if (i < num_points) {
+                    const int ty = ltype[i], lo = lold[i];
+                    if (ty == INS_APPEND || (ty == INS_SIMILAR && lo < 0)) create |= 1u << i;
+                    else if (ty == INS_SIMILAR) {
+#pragma unroll
+                        for (int j = 0; j < kMaxPts; ++j) sel(pts[j], j == lo, lp[i]);
+                        changed |= 1u << lo;
+                    } else if (ty == INS_REPLACE) {
+                        if (lo >= 0) dead |= 1u << lo;
+                        create |= 1u << i;
+                    }
                 }
             }
         }
-        // new points go to the head of the list in creation order; survivors keep their order
+        // new points go to the head of the list in creation order (the last created first); survivors keep their order
+        // the survivors' remaining fields, read before anything is written (the source may be this very array)
+        float4 ext_l[kMaxPts], ext_i[kMaxPts];
+        float ext_f[kMaxPts];
+#pragma unroll
+        for (int i = 0; i < kMaxPts; ++i) {
+            if (i < n_old && !((dead >> i) & 1u)) {
+                const size_t s = (size_t)i * src.cap + sidx;
+                ext_l[i] = src.lnrm[s]; ext_i[i] = src.imp[s]; ext_f[i] = src.pB[s].w;
+            } else {
+                ext_l[i] = ext_i[i] = make_float4(0, 0, 0, 0); ext_f[i] = 0;
+            }
+        }
         int n_out = 0;
-        auto store = [&](const Pt &p) {
-            const size_t d = (size_t)n_out * mf.cap + m;
-            mf.pA[d] = to4(p.pivotA, p.distance);
-            mf.pB[d] = to4(p.pivotB, p.friction);
-            mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
-            mf.lnrm[d] = to4(p.lnormal, p.restitution);
-            mf.imp[d] = make_float4(p.ni, p.f0, p.f1, __uint_as_float(p.lifetime));
-            ++n_out;
-        };
-        for (int i = n_created - 1; i >= 0; --i) store(created[i]);
-        for (int i = 0; i < n_old; ++i) if (!dead[i]) store(pts[i]);
+        if (create) {
+            const float friction = sqrtf(A.friction * B.friction);             // material_mixing.hpp:16-18
+            const float restitution = fminf(A.restitution, B.restitution);     // :12-14
+#pragma unroll
+            for (int i = kMaxPts - 1; i >= 0; --i) {
+                if ((create >> i) & 1u) {
+                    const CPoint &p = lp[i];
+                    const size_t d = (size_t)n_out * mf.cap + m;
+                    mf.pA[d] = to4(p.pivotA, p.distance);
+                    mf.pB[d] = to4(p.pivotB, friction);
+                    mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
+                    mf.lnrm[d] = to4(local_normal(p, A, B), restitution);
+                    mf.imp[d] = make_float4(0, 0, 0, __uint_as_float(0u));
+                    ++n_out;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxPts; ++i) {
+            if (i < n_old && !((dead >> i) & 1u)) {
+                const CPoint &p = pts[i];
+                const size_t d = (size_t)n_out * mf.cap + m;
+                const f3 ln = ((changed >> i) & 1u) ? local_normal(p, A, B) : from4(ext_l[i]);
+                mf.pA[d] = to4(p.pivotA, p.distance);
+                mf.pB[d] = to4(p.pivotB, ext_f[i]);
+                mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
+                mf.lnrm[d] = to4(ln, ext_l[i].w);
+                mf.imp[d] = make_float4(ext_i[i].x, ext_i[i].y, ext_i[i].z, __uint_as_float(__float_as_uint(ext_i[i].w) + 1u));
+                ++n_out;
+            }
+        }
         uint32_t colour = info >> 8;
         if (n_out == 0) colour = kNoColour;   // inactive pairs hold no solver colour
         mf.info[m] = (uint32_t)n_out | (colour << 8);
@@ -222,7 +286,7 @@ int count_points(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
-__global__ void k_debug_collide(uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
+__global__ void __launch_bounds__(64, 2) k_debug_collide(uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
                                 const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -269,7 +333,9 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
 int narrowphase(edynhip_ctx *c) {
     const uint32_t M = c->num_manifolds;
     if (M == 0) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_narrowphase, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev);
+    const Staging st{c->np_ra, c->np_rb, c->np_rn, c->np_rnum};
+    hipLaunchKernelGGL(k_np_detect, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
+    hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st);
     c->points_in_prev = false;
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
