@@ -1155,46 +1155,104 @@ DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
 // relative speed and applies the impulse to its own body; the partner's two terms and the scalars that live in the
 // other side's pieces (rhs / accumulated impulse, mu) cross over with DPP quad_perm[1,0,3,2]. The sums are formed in
 // the same order as rel_speed() (((JlA.dvA + JaA.dwA) + JlB.dvB) + JaB.dwB), so results stay bit-identical.
-struct Row2 { float4 f0, fa, fi; };   // f0 = (J_lin, eff); A: fa = (J_angA, rhs), fi = (I_A^-1 J_angA, mu); B: fa = (J_angB, impulse), fi = (I_B^-1 J_angB, -)
+// What a lane keeps per row is prepared while the hand-offs are still in flight, so that the section between "inputs
+// arrived" and "deltas published" - the part every later manifold of the two bodies waits for - is as short as
+// possible: jl = +-J_lin (body B's linear Jacobian is -J_lin), ijl = inv_mass * jl, ja = own J_ang, ija = own
+// I^-1 J_ang, the row's scalars (eff, rhs) and the accumulated impulse in BOTH lanes (each lane computes the same
+// impulse; no exchange and no select is needed for it). A relative speed is four terms summed in rel_speed()'s order,
+// ((JlA.dvA + JaA.dwA) + JlB.dvB) + JaB.dwB; each lane computes its two terms and reads the pair's four with
+// quad_perm broadcasts ([0,0,2,2] = the A lane's value, [1,1,3,3] = the B lane's), which fold into the adds as DPP
+// operands. Results are bit-identical to the one-lane formulation (same operations in the same order).
+struct Row2 { f3 jl, ijl, ja, ija; float eff, rhs, imp; };
+DI float dppA(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xA0 /* quad_perm:[0,0,2,2] */, 0xF, 0xF, true)); }
+DI float dppB(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true)); }
 DI void df2_poll(const float4 *slot, v4f &h0, v4f &h1) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
                  "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(h0), "=&v"(h1) : "v"(slot) : "memory");
 }
-struct Side { f3 dv, dw; float im; };
-DI float df2_relspeed(const Side &x, const Row2 &r, bool sideB) {
-    const f3 Jl = from4(r.f0);
-    const float lin = dot(sideB ? -Jl : Jl, x.dv), ang = dot(from4(r.fa), x.dw);
-    const float olin = xchg1(lin), oang = xchg1(ang);
-    const float a0 = sideB ? olin : lin, a1 = sideB ? oang : ang, b0 = sideB ? lin : olin, b1 = sideB ? ang : oang;
-    return a0 + a1 + b0 + b1;
+struct Side { f3 dv, dw; };
+DI float df2_relspeed(const Side &x, const Row2 &r) {
+    const float lin = dot(r.jl, x.dv), ang = dot(r.ja, x.dw);
+    return dppA(lin) + dppA(ang) + dppB(lin) + dppB(ang);
 }
-DI void df2_apply(Side &x, const Row2 &r, bool sideB, float imp) {
-    const f3 Jl = from4(r.f0);
-    x.dv += x.im * (sideB ? -Jl : Jl) * imp;
-    x.dw += from4(r.fi) * imp;
+DI void df2_apply(Side &x, const Row2 &r, float imp) {
+    x.dv += r.ijl * imp;
+    x.dw += r.ija * imp;
 }
-template <bool WARM, int NP>
+template <bool WARM>
+DI void df2_point(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
+    Row2 &rn = R[0], &ra = R[1], &rb = R[2];
+    if (WARM) {   // warm_start: the normal row, then the friction pair
+        df2_apply(x, rn, rn.imp);
+        return;
+    }
+    float dimp = (rn.rhs - df2_relspeed(x, rn)) * rn.eff;
+    const float imp = rn.imp + dimp;
+    if (imp < 0.0f) { dimp = 0.0f - rn.imp; rn.imp = 0.0f; }
+    else if (imp > kLarge) { dimp = kLarge - rn.imp; rn.imp = kLarge; }
+    else rn.imp = imp;
+    df2_apply(x, rn, dimp);
+    (void)ra; (void)rb; (void)mu;
+}
+template <bool WARM>
+DI void df2_friction(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
+    Row2 &ra = R[1], &rb = R[2];
+    if (WARM) {   // warm_start(constraint_row_friction&)
+        df2_apply(x, ra, ra.imp);
+        df2_apply(x, rb, rb.imp);
+        return;
+    }
+    const float c0 = ra.imp, c1 = rb.imp;
+    float di0 = (ra.rhs - df2_relspeed(x, ra)) * ra.eff;
+    float i0 = c0 + di0;
+    float di1 = (rb.rhs - df2_relspeed(x, rb)) * rb.eff;
+    float i1 = c1 + di1;
+    const float len2 = i0 * i0 + i1 * i1;
+    const float max_len = mu * R[0].imp;   // mu * current normal impulse
+    if (len2 > square(max_len)) {
+        const float len = sqrtf(len2);
+        if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+        else { i0 = 0; i1 = 0; }
+        di0 = i0 - c0; di1 = i1 - c1;
+    }
+    ra.imp = i0; rb.imp = i1;
+    df2_apply(x, ra, di0);
+    df2_apply(x, rb, di1);
+}
+// EXACT: every live lane of the wave has exactly NP points (the common case: lanes are grouped by point count), so the
+// rows need no per-lane point-count predicate.
+template <bool WARM, int NP, bool EXACT>
 DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
     Row2 R[NP][kRowsPerPoint];
+    float mu[NP];
     const uint64_t w0 = a.trace ? wall_clock64() : 0;
+    const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
+    const uint32_t nx = a.next[slot];
+    const float im = a.im[slot];
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
+    for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int r = 0; r < kRowsPerPoint; ++r) {
             const size_t base = (size_t)((k * kRowsPerPoint + r) * kRowF) * a.rcap + p;
-            R[k][r].f0 = a.rw[base];
-            R[k][r].fa = a.rw[base + (size_t)(sideB ? 2 : 1) * a.rcap];
-            R[k][r].fi = a.rw[base + (size_t)(sideB ? 4 : 3) * a.rcap];
+            const float4 f0 = a.rw[base];                                           // (J_lin, eff)
+            const float4 fa = a.rw[base + (size_t)(sideB ? 2 : 1) * a.rcap];        // A: (J_angA, rhs)   B: (J_angB, impulse)
+            const float4 fi = a.rw[base + (size_t)(sideB ? 4 : 3) * a.rcap];        // A: (I_A^-1 J_angA, mu)   B: (I_B^-1 J_angB, -)
+            Row2 &q = R[k][r];
+            const f3 Jl = from4(f0);
+            q.jl = sideB ? -Jl : Jl;
+            q.ijl = im * q.jl;
+            q.ja = from4(fa); q.ija = from4(fi);
+            q.eff = f0.w;
+            q.rhs = dppA(fa.w); q.imp = dppB(fa.w);
+            if (r == 0) mu[k] = dppA(fi.w);
         }
-    const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
-    const uint32_t nx = a.next[slot];
+    }
     Side x;
-    x.im = a.im[slot];
     x.dv = x.dw = mk3(0, 0, 0);
     const uint32_t want = (nx & kHeadBit) ? sweep : sweep + 1;
-    bool got = x.im == 0;   // read-only bodies hand nothing over: their deltas stay zero
+    bool got = im == 0;   // read-only bodies hand nothing over: their deltas stay zero
     bool done = !valid;
     const float4 *mine = a.dslot + dslot_at(slot, 0);
     uint64_t w1 = 0, w2 = 0;
@@ -1216,73 +1274,23 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
         const bool mine_now = !done && col == minc;                           // both lanes of a pair share p, hence colour
         if (__ballot(mine_now && !got) == 0) {
             if (a.trace && w2 == 0) w2 = wall_clock64();
-            // the DPP exchanges below need both lanes of a pair: `run` is uniform within a pair
-            const bool run = mine_now;
-            float nimp[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                nimp[k] = 0;
-                if ((uint32_t)k < np && run) {
-                    Row2 &r = R[k][0];
-                    const float ow = xchg1(r.fa.w);
-                    const float rhs = sideB ? ow : r.fa.w, cur0 = sideB ? r.fa.w : ow;
-                    if (WARM) {
-                        df2_apply(x, r, sideB, cur0);
-                        nimp[k] = cur0;
-                    } else {
-                        const float drel = df2_relspeed(x, r, sideB);
-                        float dimp = (rhs - drel) * r.f0.w;
-                        float cur = cur0;
-                        const float imp = cur + dimp;
-                        if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
-                        else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
-                        else cur = imp;
-                        if (sideB) r.fa.w = cur;
-                        nimp[k] = cur;
-                        df2_apply(x, r, sideB, dimp);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if ((uint32_t)k < np && run) {
-                    Row2 &ra = R[k][1], &rb = R[k][2];
-                    const float owa = xchg1(ra.fa.w), owb = xchg1(rb.fa.w);
-                    const float rhs0 = sideB ? owa : ra.fa.w, c0 = sideB ? ra.fa.w : owa;
-                    const float rhs1 = sideB ? owb : rb.fa.w, c1 = sideB ? rb.fa.w : owb;
-                    if (WARM) {   // warm_start(constraint_row_friction&)
-                        df2_apply(x, ra, sideB, c0);
-                        df2_apply(x, rb, sideB, c1);
-                    } else {
-                        const float omu = xchg1(R[k][0].fi.w);
-                        const float mu = sideB ? omu : R[k][0].fi.w;
-                        float di0 = (rhs0 - df2_relspeed(x, ra, sideB)) * ra.f0.w;
-                        float i0 = c0 + di0;
-                        float di1 = (rhs1 - df2_relspeed(x, rb, sideB)) * rb.f0.w;
-                        float i1 = c1 + di1;
-                        const float len2 = i0 * i0 + i1 * i1;
-                        const float max_len = mu * nimp[k];   // mu * current normal impulse
-                        if (len2 > square(max_len)) {
-                            const float len = sqrtf(len2);
-                            if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-                            else { i0 = 0; i1 = 0; }
-                            di0 = i0 - c0; di1 = i1 - c1;
-                        }
-                        if (sideB) { ra.fa.w = i0; rb.fa.w = i1; }
-                        df2_apply(x, ra, sideB, di0);
-                        df2_apply(x, rb, sideB, di1);
-                    }
-                }
-            }
+            // the DPP reads need both lanes of a pair: `mine_now` is uniform within a pair
             if (mine_now) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (EXACT || (uint32_t)k < np) df2_point<WARM>(x, R[k], mu[k]);
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (EXACT || (uint32_t)k < np) df2_friction<WARM>(x, R[k], mu[k]);
                 // hand the deltas over first (the next manifold of this body is waiting for them), then store the impulses
-                if (x.im != 0) df_publish(a.dslot + dslot_at(nx & kSlotMask, 0), x.dv, x.dw, sweep + 1);
+                if (im != 0) df_publish(a.dslot + dslot_at(nx & kSlotMask, 0), x.dv, x.dw, sweep + 1);
                 if (!WARM && sideB) {
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
-                        if ((uint32_t)k >= np) continue;
+                        if (!EXACT && (uint32_t)k >= np) continue;
 #pragma unroll
-                        for (int r = 0; r < kRowsPerPoint; ++r) a.rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * a.rcap + p] = R[k][r].fa;
+                        for (int r = 0; r < kRowsPerPoint; ++r)
+                            a.rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * a.rcap + p] = to4(R[k][r].ja, R[k][r].imp);
                     }
                 }
                 done = true;
@@ -1296,6 +1304,15 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
         }
     }
 }
+template <bool WARM>
+DI void df2_dispatch(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
+    // lanes are grouped by point count: np is uniform over a wave except at a group boundary
+    if (__all(!valid || np == 4u)) df2_task<WARM, 4, true>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (__all(!valid || np == 2u)) df2_task<WARM, 2, true>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (__all(!valid || np == 1u)) df2_task<WARM, 1, true>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (__any(np > 2u)) df2_task<WARM, 4, false>(a, p, valid, sideB, np, col, sweep, tr);
+    else df2_task<WARM, 2, false>(a, p, valid, sideB, np, col, sweep, tr);
+}
 __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
@@ -1308,10 +1325,9 @@ __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
             const uint32_t p = valid ? pt : a.na - 1;
             const uint32_t key = a.keys_sorted[p];
             const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
-            const bool big = __any(np > 2);           // lanes are grouped by point count: uniform except at a group boundary
             uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
-            if (sweep == 0) { if (big) df2_task<true, 4>(a, p, valid, sideB, np, col, sweep, tr); else df2_task<true, 2>(a, p, valid, sideB, np, col, sweep, tr); }
-            else { if (big) df2_task<false, 4>(a, p, valid, sideB, np, col, sweep, tr); else df2_task<false, 2>(a, p, valid, sideB, np, col, sweep, tr); }
+            if (sweep == 0) df2_dispatch<true>(a, p, valid, sideB, np, col, sweep, tr);
+            else df2_dispatch<false>(a, p, valid, sideB, np, col, sweep, tr);
         }
 }
 template <int NP>
@@ -1512,7 +1528,10 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = !X.proc;                                // read-only bodies: the record is the truth
     bool corrected = false;
-    bool done = !valid;
+    // An island that met the error threshold in an earlier iteration takes no part in this one (island_solver.cpp:350-353):
+    // its lanes neither wait for nor publish hand-offs - every consumer of its bodies is in the same island, equally
+    // finished - and each body's chain-head slot keeps the transform of the island's last iteration for k_pos_writeback.
+    bool done = !valid || done_isl != 0;
     const float4 *mine = a.pslot + pslot_at(slot, 0);
     float max_err = 0;
     bool act = false;
