@@ -1306,10 +1306,10 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
 }
 template <bool WARM>
 DI void df2_dispatch(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
-    // lanes are grouped by point count: np is uniform over a wave except at a group boundary
-    if (__all(!valid || np == 4u)) df2_task<WARM, 4, true>(a, p, valid, sideB, np, col, sweep, tr);
-    else if (__all(!valid || np == 2u)) df2_task<WARM, 2, true>(a, p, valid, sideB, np, col, sweep, tr);
-    else if (__all(!valid || np == 1u)) df2_task<WARM, 1, true>(a, p, valid, sideB, np, col, sweep, tr);
+    // lanes are grouped by point count: np is uniform over a wave except at a group boundary. The warm-start sweep runs
+    // once and keeps the predicated form only (fewer instantiations: the kernel has to stay within the instruction cache).
+    if (!WARM && __all(!valid || np == 4u)) df2_task<WARM, 4, true>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 2u)) df2_task<WARM, 2, true>(a, p, valid, sideB, np, col, sweep, tr);
     else if (__any(np > 2u)) df2_task<WARM, 4, false>(a, p, valid, sideB, np, col, sweep, tr);
     else df2_task<WARM, 2, false>(a, p, valid, sideB, np, col, sweep, tr);
 }
