@@ -181,8 +181,8 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
                            const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ rope,
                            const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
                            uint32_t *visit, const Counters *cnt, float4 *ref_min, float4 *ref_max, const float4 *__restrict__ linvel,
-                           const float4 *__restrict__ angvel, float dt) {
-    if (!cnt->bp_rebuild) return;   // the candidate lists are still valid: nobody walks the tree this step
+                           const float4 *__restrict__ angvel, float dt, uint32_t force, float gacc) {
+    if (!(cnt->bp_rebuild | force)) return;   // the candidate lists are still valid: nobody walks the tree this step
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t body = (uint32_t)(keys[k] & 0xFFFFFFFFu);
@@ -191,7 +191,9 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
         const f3 v = from4(linvel[body]), w = from4(angvel[body]);
         const f3 ext = mx - mn;
         const float reach = 0.5f * sqrtf(ext.x * ext.x + ext.y * ext.y + ext.z * ext.z);   // no point of the body is further from its centre
-        float slack = kListSlack + kListLookahead * dt * (sqrtf(length_sqr(v)) + sqrtf(length_sqr(w)) * reach);
+        // the motion of the next kListLookahead steps at the current velocity, plus what gravity adds to it
+        const float horizon = kListLookahead * dt;
+        float slack = kListSlack + horizon * (sqrtf(length_sqr(v)) + sqrtf(length_sqr(w)) * reach) + 0.5f * gacc * horizon * horizon;
         if (!(slack < 4.0f)) slack = 4.0f;   // also catches NaN / inf velocities
         ref_min[body] = to4(mn, slack); ref_max[body] = to4(mx, 0.0f);
         mn = mn - mk3(slack, slack, slack); mx = mx + mk3(slack, slack, slack);
@@ -315,32 +317,13 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // exactly the walk's leaf test - the pair is on the list. (The slack only has to be a number; how it is chosen decides
 // how long the lists live, not whether they are right.)
 constexpr uint32_t kListCap = 64;                 // candidates kept per body; a body with more walks the tree every step
-constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of such a body
 constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
                                                   // sleeping is on: it matters only while that body sleeps, see below)
-struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };   // ref_min.w = the body's slack
-
-// Start of the step: are the lists still valid? (`force`: the host changed the set of bodies.)
-__global__ void k_bp_check(const uint32_t *__restrict__ proc, uint32_t np, const float4 *__restrict__ amin, const float4 *__restrict__ amax,
-                           CandLists cl, Counters *cnt, uint32_t force) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    bool moved = false;
-    if (t < np) {
-        const uint32_t b = proc[t];
-        const float4 a = amin[b], c = amax[b], ra = cl.ref_min[b], rc = cl.ref_max[b];
-        const float d = fmaxf(fmaxf(fmaxf(fabsf(a.x - ra.x), fabsf(a.y - ra.y)), fabsf(a.z - ra.z)),
-                              fmaxf(fmaxf(fabsf(c.x - rc.x), fabsf(c.y - rc.y)), fabsf(c.z - rc.z)));
-        moved = !(d <= ra.w) || cl.count[b] == kListOverflow;   // ra.w = this body's slack (a NaN box counts as moved)
-    }
-    if (t == 0 && force) moved = true;
-    if (__any(moved) && (threadIdx.x & 63) == 0) cnt->bp_rebuild = 1u;
-}
-
 // The tree walk, only in the steps that rebuild the lists: one lane per body, stackless (ropes), fat query box.
 __global__ void __launch_bounds__(256)
 k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
-          const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways) {
-    if (!cnt->bp_rebuild) return;
+          const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways, uint32_t force) {
+    if (!(cnt->bp_rebuild | force)) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next refit
     if (k >= n) return;
@@ -369,7 +352,7 @@ k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ n
 }
 
 // Every step: the exact predicates over each body's candidates (or, for a body whose list overflowed, over a fresh tree
-// walk - k_bp_check forces the refit in that case), then the static / kinematic bodies, then the owner's keys in order.
+// walk - the check in k_finish forces the refit in that case), then the static / kinematic bodies, then the owner's keys in order.
 constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
@@ -449,7 +432,10 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
                              Counters *cnt) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = own_offset[nbodies], nextra = min(cnt->num_extra, cap);
-    if (i == 0) { cnt->num_pairs = total + nextra; if (total + nextra > cap) cnt->pair_overflow = 1; }
+    if (i == 0) {
+        cnt->num_pairs = total + nextra; if (total + nextra > cap) cnt->pair_overflow = 1;
+        cnt->bp_rebuild = 0;   // consumed by k_bp_refit / k_bp_walk above; this step's k_finish decides for the next step
+    }
     if (i < nbodies) {
         const uint32_t c = own_count[i], o = own_offset[i];
         for (uint32_t a = 0; a < c; ++a) if (o + a < cap) out[o + a] = own_keys[(size_t)i * kOwnCap + a];
@@ -531,15 +517,16 @@ int broadphase(edynhip_ctx *c) {
         if (np > 1)
             hipLaunchKernelGGL(k_bp_ropes, dim3(blocks(2 * np - 1, 256)), dim3(256), 0, s, (int)np, c->bvh.parent, c->bvh.right, c->bvh.rope);
         }
-        // candidate lists: check -> (refit -> walk, both no-ops while the lists are valid) -> exact predicates over the lists.
+        // candidate lists: (refit -> walk, both no-ops while the lists are valid) -> exact predicates over the lists.
         // A new topology re-sorts the leaves but the lists are indexed by body, so they survive it; they are rebuilt when a
-        // body has moved too far (device-side check) or when the host changed the set of bodies (lists_dirty).
+        // body has moved too far (checked on the device by the previous step's k_finish: Counters::bp_rebuild) or when the
+        // host touched the bodies in between (lists_dirty), and always in a stand-alone stage run.
         const CandLists cl{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max};
-        const uint32_t force = (c->bvh.lists_dirty || !bp_lists_enabled()) ? 1u : 0u;
+        const uint32_t force = (c->bvh.lists_dirty || !c->full_step || !bp_lists_enabled()) ? 1u : 0u;
         c->bvh.lists_dirty = false;
-        hipLaunchKernelGGL(k_bp_check, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.np_list + c->bvh.num_np, np, c->b.amin, c->b.amax, cl, c->cnt, force);
-        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt);
-        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping);
+        hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
+                           sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
+        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force);
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));

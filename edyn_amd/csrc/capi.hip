@@ -101,7 +101,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
-    EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb));
+    EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb)); EH_TRY(dalloc(c, c->pos_err, (size_t)nb * kMaxDfPosIters));
     EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
     EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));
     EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
@@ -918,6 +918,7 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     hipLaunchKernelGGL(k_unpack_state, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, c->b);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the staging buffers are reused by the next call
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_state", e);
+    c->bvh.lists_dirty = true;   // moved behind the broadphase's back: the candidate lists are rebuilt at the next step
     if (c->sleeping) return edynhip_wake_all(c);   // an edited body wakes its island (wake_up_entity); all of them here
     return EDYNHIP_OK;
 }
@@ -966,6 +967,7 @@ int edynhip_remove_collision_exclusion(edynhip_ctx *c, uint32_t a, uint32_t b) {
 int edynhip_refresh_derived(edynhip_ctx *c) {
     if (!c) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
+    c->bvh.lists_dirty = true;
     return refresh_derived(c);
 }
 

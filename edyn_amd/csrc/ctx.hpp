@@ -163,6 +163,12 @@ struct LBVH {
 };
 
 // Device counters / flags block, mirrored to pinned host memory once or twice per step.
+// Broadphase candidate lists (broadphase.hip); k_finish checks them at the end of a step.
+struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };   // ref_min.w = the body's slack
+constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of a body with more candidates than a list holds
+
+constexpr uint32_t kMaxDfPosIters = 8;   // more position iterations than this run on the per-colour schedule
+
 struct Counters {
     uint32_t num_pairs;          // pairs emitted this step
     uint32_t pair_overflow;
@@ -177,7 +183,7 @@ struct Counters {
     uint32_t num_extra;          // pair keys beyond an owner's in-LDS list (broadphase fallback path)
     uint32_t num_awake;          // procedural bodies left awake by this step's sleep decisions (island sleeping)
     uint32_t unc_count;          // edges k_col_prepare found uncoloured (listed in col_unc while they fit)
-    uint32_t bp_rebuild;         // this step rebuilds the broadphase candidate lists (set by k_bp_check, cleared at the step's end)
+    uint32_t bp_rebuild;         // this step rebuilds the broadphase candidate lists (set by the previous step's k_finish, cleared by k_bp_compact)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
@@ -229,6 +235,7 @@ struct edynhip_ctx {
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
+    float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)
     uint32_t *isl_done = nullptr;
     void *sort_tmp = nullptr;

@@ -878,9 +878,7 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
     }
 }
 
-__global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_active) return;
+DI void store_impulses_of(uint32_t p, const Rows &rows, uint32_t rcap, const Manifolds &mf) {
     const uint32_t m = rows.order[p], np = rows.np[p];
     for (uint32_t k = 0; k < np; ++k) {
         const size_t d = (size_t)k * mf.cap + m;
@@ -890,6 +888,10 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
         im.z = rows.rw[(size_t)((k * kRowsPerPoint + 2) * kRowF + 2) * rcap + p].w;
         mf.imp[d] = im;
     }
+}
+__global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_active) store_impulses_of(p, rows, rcap, mf);
 }
 
 // ------------------------------------------------------------------ joints (point, hinge)
@@ -1065,10 +1067,11 @@ int joint_reset_angles(edynhip_ctx *c, const uint8_t *which_dev) {
 
 // ------------------------------------------------------------------ integration
 __global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint32_t *isl_done, const float4 *__restrict__ dslot,
-                            const uint32_t *__restrict__ first_slot) {
+                            const uint32_t *__restrict__ first_slot, float *pos_err, uint32_t pos_iters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     isl_err[i] = 0; isl_done[i] = 0;   // per-island position-solver state (indexed by island label = a body index)
+    for (uint32_t it = 0; it < pos_iters; ++it) pos_err[(size_t)it * b.cap + i] = 0;
     if (!is_dynamic(b.flags[i]) || (b.flags[i] & BF_ASLEEP)) return;   // sleeping islands are not solved or integrated (solver.cpp:408)
     float4 p4 = B_POS(b, i);
     f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
@@ -1469,9 +1472,13 @@ struct DfPosArgs {
     const uint32_t *next;
     float4 *pslot;                  // [3 * (2p + side) + {0,1,2}] = (pos|tag) (orn.xyz|tag) (orn.w, corrected, 0 | tag)
     Rows rows; Manifolds mf; Bodies b;
-    float *isl_err; const uint32_t *isl_done;
+    float *err_out;                 // [island label] max |error| of THIS iteration (atomicMax on the bits)
+    const float *err_prev;          // the previous iteration's, nullptr in the first: an island whose previous iteration stayed
+                                    // below the threshold is finished (island_solver.cpp:350-353); a finished island publishes
+                                    // no error, so its entry stays 0 and it stays finished - no separate flag pass is needed
     Counters *cnt;
 };
+constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
     asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
                  "global_load_dwordx4 %1, %3, off offset:1024 sc1\n\t"
@@ -1486,10 +1493,13 @@ DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) 
                  "global_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
                  "global_store_dwordx4 %0, %3, off offset:2048 sc1" : : "v"(slot), "v"(h0), "v"(h1), "v"(h2) : "memory");
 }
-__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot) {
+// Seeds the position hand-off chains from the integrated transforms; the side-A lane also copies its manifold's solved
+// impulses back to the contact points (what k_store_impulses does when the position solve runs per colour).
+__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= 2 * n_active) return;
     const uint32_t p = slot >> 1, body = (slot & 1u) ? rows.bB[p] : rows.bA[p];
+    if (!(slot & 1u)) store_impulses_of(p, rows, rcap, mf);
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
     if ((rows.next[slot] & kHeadBit) && is_dynamic(b.flags[body])) {   // the chain head starts from the integrated transform
         const float4 ps = B_POS(b, body), q = B_ORN(b, body);
@@ -1497,9 +1507,7 @@ __global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot
     }
     pslot[pslot_at(slot, 0)] = h0; pslot[pslot_at(slot, 1)] = h1; pslot[pslot_at(slot, 2)] = h2;
 }
-__global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !is_dynamic(b.flags[i])) return;
+DI void pos_writeback(Bodies &b, uint32_t i, const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot) {
     const uint32_t fs = first_slot[i];
     if (fs == 0xFFFFFFFFu) return;                       // no contacts: nothing moved it
     const float4 h0 = pslot[pslot_at(fs, 0)], h1 = pslot[pslot_at(fs, 1)], h2 = pslot[pslot_at(fs, 2)];
@@ -1509,6 +1517,10 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
     const m3 basis = to_m3(X.orn);
     X.iw = mul(mul(basis, X.il), transpose(basis));
     store_pbody(b, i, X);
+}
+__global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && is_dynamic(b.flags[i])) pos_writeback(b, i, pslot, first_slot);
 }
 template <int NP>
 DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col) {
@@ -1524,7 +1536,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
         piv[k] = pvsrc[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s];
     }
     PBody X = load_pbody(b, ix);                       // pos/orn/iw of a procedural body are replaced by the hand-off
-    const uint32_t done_isl = a.isl_done[label];
+    const uint32_t done_isl = (a.err_prev && a.err_prev[label] < kPosErrorThreshold) ? 1u : 0u;
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = !X.proc;                                // read-only bodies: the record is the truth
     bool corrected = false;
@@ -1610,7 +1622,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             __builtin_amdgcn_s_sleep(4);
         }
     }
-    publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.isl_err);
+    publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.err_out);
 }
 // (Requesting a wave's next task's indices or point data one task ahead was measured and is slower: a wave's vector
 // memory operations complete in order, so anything issued before a poll delays noticing the hand-off.)
@@ -1632,7 +1644,7 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
 __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (isl_err[i] < 0.005f) isl_done[i] = 1;
+    if (isl_err[i] < kPosErrorThreshold) isl_done[i] = 1;
     isl_err[i] = 0;
 }
 
@@ -1671,21 +1683,37 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
         B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
     }
 }
-__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt) {
+// End of the step. Per body: the position solve's final transform (dataflow mode: it lives in the body's chain-head slot
+// until now), the derived state (AABB, world inertia), the next step's scratch, and the broadphase's question for the next
+// step - has this body left the slack box its candidate list was built for? (Counters::bp_rebuild, see broadphase.hip.)
+__global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt,
+                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
         const int t = threadIdx.x;
         if (t == 0) {
             cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0; cnt->bp_rebuild = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0;
         }
         if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
         for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
     }
-    if (i >= n) return;
     // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
-    used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
-    derive_body(b, i);
+    bool moved = false;
+    if (i < n) {
+        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
+        const uint32_t fl = b.flags[i];
+        if (pslot && is_dynamic(fl)) pos_writeback(b, i, pslot, first_slot);
+        derive_body(b, i);
+        if (cl.count && is_dynamic(fl) && !(fl & BF_REMOVED)) {
+            const float4 a = b.amin[i], c = b.amax[i], ra = cl.ref_min[i], rc = cl.ref_max[i];
+            const float d = fmaxf(fmaxf(fmaxf(fabsf(a.x - ra.x), fabsf(a.y - ra.y)), fabsf(a.z - ra.z)),
+                                  fmaxf(fmaxf(fabsf(c.x - rc.x), fabsf(c.y - rc.y)), fabsf(c.z - rc.z)));
+            moved = !(d <= ra.w);   // ra.w = this body's slack (a NaN box counts as moved); a body whose list overflowed walks the
+                                    // (still valid) tree in k_bp_pairs instead - no reason to rebuild everybody's list
+        }
+    }
+    if (__any(moved) && (threadIdx.x & 63) == 0) cnt->bp_rebuild = 1u;
 }
 __global__ void k_refresh_derived(uint32_t n, Bodies b) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1963,10 +1991,15 @@ int solve(edynhip_ctx *c) {
     }
     c->timings.solve_velocity_launches += launches;
     rec(c, 6);
-    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done, push ? c->rows.dslot : nullptr, c->rows.first_slot);
-    if (na) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
-    rec(c, 7);
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
+    const uint32_t P = c->cfg.num_position_iterations;
+    // one error array per position iteration (DfPosArgs::err_out / err_prev): kMaxDfPosIters of them are allocated
+    const bool pos_df = P > 0 && P <= kMaxDfPosIters && push && c->df_mode == 1 && pos_df_env;
+    hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done, push ? c->rows.dslot : nullptr, c->rows.first_slot,
+                       c->pos_err, pos_df ? P : 0u);
+    if (na && !pos_df) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);
+    rec(c, 7);
+    const float4 *final_pslot = nullptr;   // set while the bodies' final transforms still live in the hand-off slots
     auto pos_per_colour = [&](uint32_t first_it) {
         for (uint32_t it = first_it; it < c->cfg.num_position_iterations; ++it) {
             for (uint32_t k = 0; k < j.num_colours; ++k) {
@@ -1981,30 +2014,35 @@ int solve(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
     };
-    if (c->cfg.num_position_iterations > 0 && push && c->df_mode == 1 && pos_df_env) {
+    if (pos_df) {
         static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
-        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot);
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf);
         const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
-            DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->isl_err, c->isl_done, c->cnt};
+            DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt};
             void *params[] = {&a};
             if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
                 c->df_mode = 0;
                 break;
             }
-            hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
-        // the bodies' transforms live in the hand-off slots while the dataflow launches run
-        hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
-        pos_per_colour(it);   // nothing unless a cooperative launch was refused
-    } else if (c->cfg.num_position_iterations > 0 && (na || j.n)) {
+        // the bodies' transforms live in the hand-off slots while the dataflow launches run; k_finish picks them up
+        if (it == P) final_pslot = r.pslot;
+        else {   // a cooperative launch was refused: finish per colour (rare; never on an exclusive device)
+            hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
+            if (it > 0) hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->pos_err + (size_t)(it - 1) * c->b.cap, c->isl_done);
+            pos_per_colour(it);
+        }
+    } else if (P > 0 && (na || j.n)) {
         pos_per_colour(0);
     }
     rec(c, 8);
-    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt);
+    hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt,
+                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max});
     rec(c, 9);
     ++c->step_index;
     EH_HIP(c, hipGetLastError());
