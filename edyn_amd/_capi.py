@@ -61,7 +61,9 @@ POINT_DTYPE = np.dtype([
 MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
-FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE, FLAG_TIMING_SOLVE = 1, 4, 8, 16
+FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE, FLAG_TIMING_SOLVE, FLAG_CONTACT_EVENTS = 1, 4, 8, 16, 32
+EVENT_DTYPE = np.dtype([("type", np.uint32), ("step", np.uint32), ("body", np.uint32, 2), ("point_id", np.uint64)])
+EVENT_MANIFOLD_CREATED, EVENT_MANIFOLD_DESTROYED, EVENT_POINT_CREATED, EVENT_POINT_DESTROYED = 1, 2, 3, 4
 STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
 
 # every symbol include/edynhip.h declares (checked by tests/test_abi.py)
@@ -72,7 +74,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
-           "edynhip_step_timed"]
+           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read"]
 
 _lib = None
 
@@ -110,6 +112,10 @@ def lib():
         L.edynhip_get_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_wake_all.argtypes = [C.c_void_p]
         L.edynhip_refresh_derived.argtypes = [C.c_void_p]
+        L.edynhip_get_contact_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_snapshot.argtypes = [C.c_void_p]
+        L.edynhip_snapshot_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.edynhip_add_joints.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Joints), C.POINTER(C.c_uint32)]
         L.edynhip_remove_joints.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.edynhip_set_joint_params.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]

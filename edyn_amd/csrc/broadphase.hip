@@ -445,7 +445,7 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
 __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
-                                     Counters *cnt, uint2 *new_edges, bool copy_points) {
+                                     Counters *cnt, uint2 *new_edges, bool copy_points, EventSink ev, uint8_t *prev_matched) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t found = 0;
     if (m < M) {
@@ -468,17 +468,20 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     if (p == 0xFFFFFFFFu) {
         cnt->pairs_changed = 1;
         new_edges[atomicAdd(&cnt->num_new, 1u)] = make_uint2(hi, lo);
+        if (ev.buf) emit_event(ev, EDYNHIP_EVENT_MANIFOLD_CREATED, swapped ? lo : hi, swapped ? hi : lo, 0);
     }
     cur.prev_idx[m] = p;
     if (p != 0xFFFFFFFFu) {
         found = 1;
         info = prev.info[p];
+        if (ev.buf) prev_matched[p] = 1;
         // inside a full step the narrowphase reads the old points straight from the previous array (no copy here)
         const uint32_t np = copy_points ? (info & 0xFF) : 0u;
         for (uint32_t k = 0; k < np; ++k) {
             const size_t s = (size_t)k * prev.cap + p, d = (size_t)k * cur.cap + m;
             cur.pA[d] = prev.pA[s]; cur.pB[d] = prev.pB[s]; cur.nrm[d] = prev.nrm[s];
             cur.lnrm[d] = prev.lnrm[s]; cur.imp[d] = prev.imp[s];
+            if (cur.pid) cur.pid[d] = prev.pid[s];
         }
     }
     cur.info[m] = info;
@@ -492,6 +495,19 @@ static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / b
 static bool bp_lists_enabled() {   // development knob: EDYNHIP_BP_LISTS=0 walks the tree every step
     static const bool on = !(getenv("EDYNHIP_BP_LISTS") && getenv("EDYNHIP_BP_LISTS")[0] == '0');
     return on;
+}
+
+// Contact events: the previous step's manifolds that no pair of this step continues (destroy_separated_manifolds,
+// broadphase.cpp:99-134; or a body was removed) - their points end with them.
+__global__ void k_ev_destroyed(uint32_t pm, Manifolds prev, uint8_t *matched, EventSink ev) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pm) return;
+    if (!matched[p]) {
+        const uint32_t a = prev.bodyA[p], b = prev.bodyB[p], np = prev.info[p] & 0xFF;
+        for (uint32_t k = 0; k < np; ++k) emit_event(ev, EDYNHIP_EVENT_POINT_DESTROYED, a, b, prev.pid[(size_t)k * prev.cap + p]);
+        emit_event(ev, EDYNHIP_EVENT_MANIFOLD_DESTROYED, a, b, 0);
+    }
+    matched[p] = 0;   // armed for the step in which this array is `prev` again
 }
 
 int broadphase(edynhip_ctx *c) {
@@ -545,9 +561,11 @@ int broadphase(edynhip_ctx *c) {
             EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
             EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         }
+        const EventSink ev = event_sink(c);
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, !c->full_step);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, !c->full_step, ev, c->prev_matched);
         else if (pm != 0) c->force_islands = true;
+        if (ev.buf && pm > 0) hipLaunchKernelGGL(k_ev_destroyed, dim3(blocks(pm, 256)), dim3(256), 0, s, pm, prev, c->prev_matched, ev);
     }
     c->points_in_prev = c->full_step && M > 0 && np > 0;
     c->cur ^= 1;

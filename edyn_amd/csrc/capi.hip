@@ -62,6 +62,7 @@ static int dalloc(edynhip_ctx *c, T *&p, size_t count) {
 
 static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap, uint32_t nb) {
     m.cap = cap;
+    if (c->cfg.flags & EDYNHIP_FLAG_CONTACT_EVENTS) EH_TRY(dalloc(c, m.pid, (size_t)cap * kMaxPts));
     EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb)); EH_TRY(dalloc(c, m.prev_idx, cap));
     EH_TRY(dalloc(c, m.skey, cap)); EH_TRY(dalloc(c, m.bodyA, cap)); EH_TRY(dalloc(c, m.bodyB, cap)); EH_TRY(dalloc(c, m.info, cap));
     EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
@@ -95,6 +96,10 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.cand_list, (size_t)nb * 64)); EH_TRY(dalloc(c, t.cand_count, nb)); EH_TRY(dalloc(c, t.ref_min, nb)); EH_TRY(dalloc(c, t.ref_max, nb));
     EH_TRY(dalloc(c, c->np_ra, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rb, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rn, (size_t)M * kMaxPts));
     EH_TRY(dalloc(c, c->np_rnum, M));
+    if (c->cfg.flags & EDYNHIP_FLAG_CONTACT_EVENTS) {
+        c->event_cap = 5u * M + 1024u;
+        EH_TRY(dalloc(c, c->events, c->event_cap)); EH_TRY(dalloc(c, c->event_count, 4)); EH_TRY(dalloc(c, c->prev_matched, M));
+    }
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
@@ -281,6 +286,7 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
         mf.nrm[s] = make_float4(p.normal[0], p.normal[1], p.normal[2], __int_as_float(p.attachment));
         mf.lnrm[s] = make_float4(p.local_normal[0], p.local_normal[1], p.local_normal[2], p.restitution);
         mf.imp[s] = make_float4(p.normal_impulse, p.friction_impulse[0], p.friction_impulse[1], __uint_as_float(p.lifetime));
+        if (mf.pid) mf.pid[s] = ((uint64_t)m << 2) | k;   // injected points: high word 0
     }
 }
 __global__ void k_pack_state(uint32_t first, uint32_t count, Bodies b, float *dst) {
@@ -425,7 +431,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 3; }   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 4; }   // 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -469,6 +475,12 @@ void edynhip_destroy(edynhip_ctx *c) {
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
     if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
     if (c->state_host) (void)hipHostFree(c->state_host);
+    for (int k = 0; k < 2; ++k) {
+        if (c->snap_host[k]) (void)hipHostFree(c->snap_host[k]);
+        if (c->snap_event[k]) (void)hipEventDestroy(c->snap_event[k]);
+    }
+    if (c->snap_ready) (void)hipEventDestroy(c->snap_ready);
+    if (c->snap_stream) (void)hipStreamDestroy(c->snap_stream);
     for (auto &e : c->timer.ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -793,6 +805,7 @@ static int step_stamped(edynhip_ctx *c, uint32_t nsteps, bool timed, double firs
     EH_HIP(c, hipSetDevice(c->device));
     c->timings = edynhip_timings{};
     c->timer.recorded = 0;
+    if (c->events) EH_HIP(c, hipMemsetAsync(c->event_count, 0, sizeof(uint32_t), c->stream));   // the events of THIS call
     for (uint32_t i = 0; i < nsteps; ++i) {
         // island_manager::update runs put_islands_to_sleep() against the PREVIOUS step's stamp and only then takes the new one
         // (island_manager.cpp:533-539): the kernels read c->sim_clock, which is advanced after the step
@@ -1078,6 +1091,91 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_manifolds", e);
+    return EDYNHIP_OK;
+}
+
+int edynhip_get_contact_events(edynhip_ctx *c, edynhip_contact_event *out, uint32_t capacity, uint32_t *n) {
+    static_assert(sizeof(edynhip_contact_event) == sizeof(ContactEvent), "event record layout");
+    if (!c || !n) return EDYNHIP_ERR_INVALID;
+    *n = 0;
+    if (!c->events) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, "edynhip_get_contact_events: create the context with EDYNHIP_FLAG_CONTACT_EVENTS");
+    EH_HIP(c, hipSetDevice(c->device));
+    uint32_t count = 0;
+    EH_HIP(c, hipMemcpyAsync(&count, c->event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t held = std::min(count, c->event_cap);
+    *n = held;
+    if (out) {
+        if (capacity < held) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_get_contact_events: capacity too small");
+        if (held) {
+            EH_HIP(c, hipMemcpyAsync(out, c->events, (size_t)held * sizeof(ContactEvent), hipMemcpyDeviceToHost, c->stream));
+            EH_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    if (count > c->event_cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_get_contact_events: more events than the context holds; resynchronise from edynhip_get_manifolds");
+    return EDYNHIP_OK;
+}
+int edynhip_get_point_ids(edynhip_ctx *c, uint64_t *ids, uint32_t capacity, uint32_t *n) {
+    if (!c || !n) return EDYNHIP_ERR_INVALID;
+    const uint32_t M = c->num_manifolds;
+    *n = M;
+    if (!c->events) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, "edynhip_get_point_ids: create the context with EDYNHIP_FLAG_CONTACT_EVENTS");
+    if (M == 0 || !ids) return EDYNHIP_OK;
+    if (capacity < M) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_get_point_ids: capacity too small");
+    EH_HIP(c, hipSetDevice(c->device));
+    const Manifolds &mf = c->m[c->cur];
+    std::vector<uint64_t> col(M);
+    std::vector<uint32_t> info(M);
+    EH_HIP(c, hipMemcpyAsync(info.data(), mf.info, (size_t)M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
+        EH_HIP(c, hipMemcpyAsync(col.data(), mf.pid + (size_t)k * mf.cap, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        EH_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint32_t m = 0; m < M; ++m) ids[(size_t)4 * m + k] = k < (info[m] & 0xFF) ? col[m] : 0;
+    }
+    return EDYNHIP_OK;
+}
+
+// ---- double-buffered read-back (simulation_worker.cpp:406-444: finished steps are handed over while the next one runs)
+int edynhip_snapshot(edynhip_ctx *c) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = c->b.n;
+    const int slot = (c->snap_last + 1) & 1;
+    if (!c->snap_stream) {
+        EH_HIP(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+        EH_HIP(c, hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            EH_HIP(c, hipEventCreateWithFlags(&c->snap_event[k], hipEventDisableTiming));
+            EH_HIP(c, hipHostMalloc((void **)&c->snap_host[k], (size_t)c->b.cap * 13 * sizeof(float), hipHostMallocDefault));
+            EH_TRY(dalloc(c, c->snap_dev[k], (size_t)c->b.cap * 13));
+        }
+    }
+    // pack on the stepper's stream (it must see the finished step), copy on the side stream: the copy engine moves the
+    // bytes while the stepper's next kernels already run
+    if (n) hipLaunchKernelGGL(k_pack_state, dim3((n + 255) / 256), dim3(256), 0, c->stream, 0u, n, c->b, c->snap_dev[slot]);
+    EH_HIP(c, hipEventRecord(c->snap_ready, c->stream));
+    EH_HIP(c, hipStreamWaitEvent(c->snap_stream, c->snap_ready, 0));
+    if (n) EH_HIP(c, hipMemcpyAsync(c->snap_host[slot], c->snap_dev[slot], (size_t)n * 13 * sizeof(float), hipMemcpyDeviceToHost, c->snap_stream));
+    EH_HIP(c, hipEventRecord(c->snap_event[slot], c->snap_stream));
+    c->snap_step[slot] = c->step_index; c->snap_bodies[slot] = n; c->snap_last = slot;
+    return EDYNHIP_OK;
+}
+int edynhip_snapshot_read(edynhip_ctx *c, float *pos, float *orn, float *linvel, float *angvel, uint32_t *step_index) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    if (c->snap_last < 0) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_snapshot_read: no snapshot was taken");
+    EH_HIP(c, hipSetDevice(c->device));
+    const int slot = c->snap_last;
+    EH_HIP(c, hipEventSynchronize(c->snap_event[slot]));   // that copy only - not the steps enqueued after it
+    const float *h = c->snap_host[slot];
+    for (uint32_t i = 0; i < c->snap_bodies[slot]; ++i) {
+        const float *o = &h[(size_t)i * 13];
+        if (pos) std::memcpy(pos + 3 * i, o, 12);
+        if (orn) std::memcpy(orn + 4 * i, o + 3, 16);
+        if (linvel) std::memcpy(linvel + 3 * i, o + 7, 12);
+        if (angvel) std::memcpy(angvel + 3 * i, o + 10, 12);
+    }
+    if (step_index) *step_index = c->snap_step[slot];
     return EDYNHIP_OK;
 }
 

@@ -65,7 +65,16 @@ struct Manifolds {
     float4 *nrm = nullptr;        // normal xyz, w = bitcast(attachment)
     float4 *lnrm = nullptr;       // local_normal xyz, w = restitution
     float4 *imp = nullptr;        // normal_impulse, friction_impulse[0], [1], bitcast(lifetime)
+    uint64_t *pid = nullptr;      // contact events only (else nullptr): the point's id from creation to destruction
 };
+
+// Contact events (EDYNHIP_FLAG_CONTACT_EVENTS; edynhip.h edynhip_contact_event has the same layout).
+struct ContactEvent { uint32_t type, step, bodyA, bodyB; uint64_t pid; };
+struct EventSink { ContactEvent *buf; uint32_t *count; uint32_t cap; uint32_t step; };   // buf == nullptr: events are off
+__device__ __forceinline__ void emit_event(const EventSink &ev, uint32_t type, uint32_t a, uint32_t b, uint64_t pid) {
+    const uint32_t i = atomicAdd(ev.count, 1u);   // may run past cap: the host reports the overflow
+    if (i < ev.cap) ev.buf[i] = ContactEvent{type, ev.step, a, b, pid};
+}
 
 // Joint rows live in SLOTS that mirror the constraints' applied_impulse fields (hinge_constraint.hpp:64-71,
 // point_constraint.hpp:28-29): hinge 0..2 linear, 3..4 hinge p/q, 5 limit, 6 bump stop, 7 spring, 8 torque; point 0..2 linear,
@@ -259,6 +268,11 @@ struct edynhip_ctx {
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     uint32_t step_index = 0;       // completed steps
+    // contact events: device list of the current edynhip_step call, per-manifold "still there" marks of the previous array
+    eh::ContactEvent *events = nullptr; uint32_t *event_count = nullptr; uint32_t event_cap = 0; uint8_t *prev_matched = nullptr;
+    // double-buffered read-back (edynhip_snapshot): pinned host copies of the packed state, the event that completes each
+    float *snap_host[2] = {nullptr, nullptr}; float *snap_dev[2] = {nullptr, nullptr}; hipEvent_t snap_event[2] = {nullptr, nullptr};
+    uint32_t snap_step[2] = {0, 0}, snap_bodies[2] = {0, 0}; int snap_last = -1; hipStream_t snap_stream = nullptr; hipEvent_t snap_ready = nullptr;
     // Island sleep timers run on the step time stamps the stepper hands to the island manager (stepper_sequential.cpp:60-75,
     // island_manager.cpp:533-539,605-623): sim_clock is the island manager's m_last_time, i.e. the stamp of the PREVIOUS step while
     // a step runs - advanced by fixed_dt per edynhip_step step, set by the caller in edynhip_step_timed (the
@@ -294,6 +308,7 @@ int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);   /
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count);
 int islands(edynhip_ctx *c);
+inline EventSink event_sink(const edynhip_ctx *c) { return EventSink{c->events, c->event_count, c->event_cap, c->step_index}; }
 int restitution(edynhip_ctx *c);   // restitution.hip: solve_restitution, before gravity and the constraint solver (solver.cpp:397)
 int solve(edynhip_ctx *c);
 int refresh_derived(edynhip_ctx *c);

@@ -89,7 +89,7 @@ k_np_detect(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
 }
 
 __global__ void __launch_bounds__(64, 2)
-k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old, Staging st) {
+k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old, Staging st, EventSink ev) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) {
         const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
@@ -104,6 +104,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                 for (int k = 0; k < n_old; ++k) {
                     const size_t s = (size_t)k * src.cap + sidx, d = (size_t)k * mf.cap + m;
                     mf.pA[d] = src.pA[s]; mf.pB[d] = src.pB[s]; mf.nrm[d] = src.nrm[s]; mf.lnrm[d] = src.lnrm[s]; mf.imp[d] = src.imp[s];
+                    if (mf.pid) mf.pid[d] = src.pid[s];
                 }
             return;
         }
@@ -223,6 +224,16 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         // the survivors' remaining fields, read before anything is written (the source may be this very array)
         float4 ext_l[kMaxPts], ext_i[kMaxPts];
         float ext_f[kMaxPts];
+        uint64_t ext_id[kMaxPts] = {0, 0, 0, 0};
+        if (mf.pid) {   // contact events: ids of the old points; the ones that end here are reported
+#pragma unroll
+            for (int i = 0; i < kMaxPts; ++i) {
+                if (i < n_old) {
+                    ext_id[i] = src.pid[(size_t)i * src.cap + sidx];
+                    if ((dead >> i) & 1u) emit_event(ev, EDYNHIP_EVENT_POINT_DESTROYED, ia, ib, ext_id[i]);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < kMaxPts; ++i) {
             if (i < n_old && !((dead >> i) & 1u)) {
@@ -246,6 +257,11 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                     mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
                     mf.lnrm[d] = to4(local_normal(p, A, B), restitution);
                     mf.imp[d] = make_float4(0, 0, 0, __uint_as_float(0u));
+                    if (mf.pid) {   // id = (step of creation + 1) << 32 | manifold index << 2 | local slot
+                        const uint64_t id = ((uint64_t)(ev.step + 1u) << 32) | ((uint64_t)m << 2) | (uint64_t)i;
+                        mf.pid[d] = id;
+                        emit_event(ev, EDYNHIP_EVENT_POINT_CREATED, ia, ib, id);
+                    }
                     ++n_out;
                 }
             }
@@ -261,6 +277,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                 mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
                 mf.lnrm[d] = to4(ln, ext_l[i].w);
                 mf.imp[d] = make_float4(ext_i[i].x, ext_i[i].y, ext_i[i].z, __uint_as_float(__float_as_uint(ext_i[i].w) + 1u));
+                if (mf.pid) mf.pid[d] = ext_id[i];
                 ++n_out;
             }
         }
@@ -335,7 +352,7 @@ int narrowphase(edynhip_ctx *c) {
     if (M == 0) return EDYNHIP_OK;
     const Staging st{c->np_ra, c->np_rb, c->np_rn, c->np_rnum};
     hipLaunchKernelGGL(k_np_detect, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
-    hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st);
+    hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st, event_sink(c));
     c->points_in_prev = false;
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;

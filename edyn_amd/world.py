@@ -36,6 +36,7 @@ class init_config:
     timing: bool = False         # HIP events around every stage (diagnostic: each event idles the GPU ~6 us)
     timing_solve: bool = False   # HIP events around the velocity solve only
     sleeping: bool = False       # island sleeping (off = every body sleeping_disabled, as the benchmark scenes are)
+    contact_events: bool = False # record manifold / contact point creation and destruction (get_contact_events)
     exclusive_device: bool = False   # promise that this stepper is the only user of its GPU while it steps (see edynhip.h)
 
 
@@ -108,6 +109,7 @@ class World:
         cfg.gravity = (C.c_float * 3)(*[float(x) for x in self.cfg.gravity])
         cfg.flags = ((_capi.FLAG_TIMING if self.cfg.timing else 0) | (_capi.FLAG_TIMING_SOLVE if self.cfg.timing_solve else 0)
                      | (_capi.FLAG_SLEEPING if self.cfg.sleeping else 0)
+                     | (_capi.FLAG_CONTACT_EVENTS if self.cfg.contact_events else 0)
                      | (_capi.FLAG_EXCLUSIVE_DEVICE if self.cfg.exclusive_device else 0))
         st = C.c_int(0)
         h = self._L.edynhip_create(C.byref(cfg), C.byref(st))
@@ -359,6 +361,37 @@ class World:
         if m.value:
             self._check(self._L.edynhip_get_manifolds(self._h, _ptr(out), m.value, C.byref(m)))
         return out
+
+    # ---- contact events: what registry.on_construct / on_destroy<contact_manifold | contact_point> deliver in the reference
+    def get_contact_events(self):
+        """Events of the steps of the last step() / update() call: structured array (type, step, body[2], point_id)."""
+        n = C.c_uint32(0)
+        self._check(self._L.edynhip_get_contact_events(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, _capi.EVENT_DTYPE)
+        if n.value:
+            self._check(self._L.edynhip_get_contact_events(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def get_point_ids(self):
+        """[num_manifolds, 4] point ids in get_manifolds() order (0 = no point)."""
+        m = C.c_uint32(0)
+        self._check(self._L.edynhip_num_manifolds(self._h, C.byref(m)))
+        out = np.zeros((m.value, 4), np.uint64)
+        if m.value:
+            self._check(self._L.edynhip_get_point_ids(self._h, _ptr(out), m.value, C.byref(m)))
+        return out
+
+    # ---- double-buffered read-back: step(); snapshot(); step(); snapshot_read() returns the first step's state while the second runs
+    def snapshot(self):
+        self._check(self._L.edynhip_snapshot(self._h))
+
+    def snapshot_read(self):
+        n = self.n
+        pos = np.zeros((n, 3), np.float32); orn = np.zeros((n, 4), np.float32)
+        lin = np.zeros((n, 3), np.float32); ang = np.zeros((n, 3), np.float32)
+        step = C.c_uint32(0)
+        self._check(self._L.edynhip_snapshot_read(self._h, _ptr(pos), _ptr(orn), _ptr(lin), _ptr(ang), C.byref(step)))
+        return (pos, orn, lin, ang), step.value
 
     def set_manifolds(self, recs):
         recs = np.ascontiguousarray(recs, MANIFOLD_DTYPE)

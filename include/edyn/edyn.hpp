@@ -24,6 +24,7 @@
 #else
 #include "detail/mini_entt.hpp"
 #endif
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -31,6 +32,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <variant>
 #include <vector>
 #include "../edynhip.h"
@@ -106,6 +108,13 @@ struct hinge_constraint : constraint_base {                                     
     void set_axes(const vector3 &axisA, const vector3 &axisB) { axis = {axisA, axisB}; }
 };
 struct contact_manifold { std::array<entt::entity, 2> body; unsigned num_points; };           // collision/contact_manifold.hpp:14-22
+// Contact points are entities of their own, as in the reference (collision/contact_point.hpp:17-58): created and destroyed
+// in the registry as the device reports them (init_config::materialize_contacts), so registry.view<contact_point>() and,
+// with EnTT, on_construct / on_destroy<contact_point> work as they do against the reference.
+struct contact_point { vector3 pivotA, pivotB, normal; };
+struct contact_point_geometry { vector3 local_normal; scalar distance{0}; int normal_attachment{0}; };
+struct contact_point_impulse { scalar normal_impulse{0}; std::array<scalar, 2> friction_impulse{0, 0}; };
+struct contact_point_list { entt::entity parent; uint64_t id; };   // parent manifold; id: the device's point id
 
 enum class execution_mode : uint8_t { sequential, sequential_multithreaded, asynchronous };
 struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
@@ -119,6 +128,11 @@ struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
     unsigned max_bodies{0};      // 0 = sized at the first upload (count + 25 % head-room)
     unsigned max_manifolds{0};
     bool island_sleeping{true};  // the reference always sleeps islands (bodies opt out with sleeping_disabled)
+    // contact_manifold / contact_point entities in the registry, kept in step with the device through its event list.
+    // contact_point_data: also refresh every live point's pivots / normal / distance / impulses after each update (a full
+    // read-back of the manifolds; off = call edyn::refresh_contact_points(registry) when the data is needed).
+    bool materialize_contacts{true};
+    bool contact_point_data{false};
 };
 
 class stepper_error : public std::runtime_error {
@@ -139,6 +153,10 @@ struct gpu_stepper {
     double accumulated{0}, last_time{0};
     unsigned capacity{0}, joint_capacity{0};
     unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
+    std::unordered_map<uint64_t, entt::entity> manifold_entities;   // (body index A << 32 | body index B) -> contact_manifold entity
+    std::unordered_map<uint64_t, entt::entity> point_entities;      // device point id -> contact_point entity
+    bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
+    bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
 };
 struct body_index { uint32_t value; };
@@ -188,6 +206,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             if (m) check(s, edynhip_get_manifolds(s.ctx, carried.data(), m, &m));
             edynhip_destroy(s.ctx); s.ctx = nullptr;
             regrown = true;
+            s.contacts_resync = true; s.snapshot_pending = false;
         }
         s.uploaded_bodies = s.uploaded_constraints = 0;
         edynhip_config c{};
@@ -199,7 +218,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
         c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
-        c.flags = s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u;
+        c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.materialize_contacts ? EDYNHIP_FLAG_CONTACT_EVENTS : 0u);
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
@@ -348,14 +367,137 @@ inline void apply_params(gpu_stepper &s) {   // settings on the running context:
     check(s, edynhip_set_params(s.ctx, &p));
     s.params_dirty = false;
 }
+// Contact entities. The device reports what changed (edynhip_get_contact_events); the registry follows: a
+// contact_manifold entity per overlapping pair (make_contact_manifold, constraint_util.cpp:60-102), a contact_point entity
+// per point (create_contact_point, collision_util.cpp:311-388), destroyed when the device says so.
+inline uint64_t manifold_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 32) | b; }
+inline void refresh_contact_points(entt::registry &registry, gpu_stepper &s) {
+    uint32_t n = 0;
+    check(s, edynhip_num_manifolds(s.ctx, &n));
+    if (n == 0) return;
+    std::vector<edynhip_manifold> recs(n);
+    std::vector<uint64_t> ids((size_t)4 * n);
+    check(s, edynhip_get_manifolds(s.ctx, recs.data(), n, &n));
+    check(s, edynhip_get_point_ids(s.ctx, ids.data(), n, &n));
+    for (uint32_t m = 0; m < n; ++m)
+        for (uint32_t k = 0; k < recs[m].num_points; ++k) {
+            auto it = s.point_entities.find(ids[(size_t)4 * m + k]);
+            if (it == s.point_entities.end()) continue;
+            const edynhip_point &p = recs[m].pt[k];
+            registry.get<contact_point>(it->second) = {{p.pivotA[0], p.pivotA[1], p.pivotA[2]}, {p.pivotB[0], p.pivotB[1], p.pivotB[2]}, {p.normal[0], p.normal[1], p.normal[2]}};
+            registry.get<contact_point_geometry>(it->second) = {{p.local_normal[0], p.local_normal[1], p.local_normal[2]}, p.distance, p.attachment};
+            registry.get<contact_point_impulse>(it->second) = {p.normal_impulse, {p.friction_impulse[0], p.friction_impulse[1]}};
+        }
+}
+inline void sync_contacts(entt::registry &registry, gpu_stepper &s) {
+    if (!s.cfg.materialize_contacts || !s.ctx) return;
+    uint32_t n = 0;
+    int rc = edynhip_get_contact_events(s.ctx, nullptr, 0, &n);
+    std::vector<edynhip_contact_event> ev(n);
+    if (rc == EDYNHIP_OK && n) rc = edynhip_get_contact_events(s.ctx, ev.data(), n, &n);
+    auto body_of = [&](uint32_t i) { return i < s.bodies.size() ? s.bodies[i] : entt::entity{entt::null}; };
+    auto make_manifold = [&](uint32_t a, uint32_t b) {
+        const entt::entity e = registry.create();
+        registry.emplace<contact_manifold>(e, contact_manifold{{body_of(a), body_of(b)}, 0u});
+        s.manifold_entities[manifold_key(a, b)] = e;
+        return e;
+    };
+    auto make_point = [&](uint32_t a, uint32_t b, uint64_t id) {
+        auto mit = s.manifold_entities.find(manifold_key(a, b));
+        const entt::entity parent = mit != s.manifold_entities.end() ? mit->second : make_manifold(a, b);
+        const entt::entity e = registry.create();
+        registry.emplace<contact_point_list>(e, contact_point_list{parent, id});
+        registry.emplace<contact_point_geometry>(e);
+        registry.emplace<contact_point_impulse>(e);
+        registry.emplace<contact_point>(e);   // last, as create_contact_point does: a listener finds the other components
+        ++registry.get<contact_manifold>(parent).num_points;
+        s.point_entities[id] = e;
+    };
+    if (rc == EDYNHIP_ERR_CAPACITY || s.contacts_resync) {   // more events than the context holds, or a re-created context: rebuild from the manifolds
+        s.contacts_resync = false;
+        for (auto &kv : s.point_entities) registry.destroy(kv.second);
+        for (auto &kv : s.manifold_entities) registry.destroy(kv.second);
+        s.point_entities.clear(); s.manifold_entities.clear();
+        uint32_t m = 0;
+        check(s, edynhip_num_manifolds(s.ctx, &m));
+        std::vector<edynhip_manifold> recs(m);
+        std::vector<uint64_t> ids((size_t)4 * m);
+        if (m) { check(s, edynhip_get_manifolds(s.ctx, recs.data(), m, &m)); check(s, edynhip_get_point_ids(s.ctx, ids.data(), m, &m)); }
+        for (uint32_t i = 0; i < m; ++i) {
+            make_manifold(recs[i].body[0], recs[i].body[1]);
+            for (uint32_t k = 0; k < recs[i].num_points; ++k) make_point(recs[i].body[0], recs[i].body[1], ids[(size_t)4 * i + k]);
+        }
+    } else {
+        check(s, rc);
+        // within a step: ends before beginnings (a replaced point leaves before its successor arrives); steps in order
+        auto rank = [](uint32_t t) { return t == EDYNHIP_EVENT_POINT_DESTROYED ? 0 : t == EDYNHIP_EVENT_MANIFOLD_DESTROYED ? 1 : t == EDYNHIP_EVENT_MANIFOLD_CREATED ? 2 : 3; };
+        std::stable_sort(ev.begin(), ev.end(), [&](const edynhip_contact_event &x, const edynhip_contact_event &y) {
+            return x.step != y.step ? x.step < y.step : rank(x.type) < rank(y.type);
+        });
+        for (const auto &e : ev) {
+            switch (e.type) {
+            case EDYNHIP_EVENT_MANIFOLD_CREATED: make_manifold(e.body[0], e.body[1]); break;
+            case EDYNHIP_EVENT_POINT_CREATED: make_point(e.body[0], e.body[1], e.point_id); break;
+            case EDYNHIP_EVENT_POINT_DESTROYED: {
+                auto it = s.point_entities.find(e.point_id);
+                if (it == s.point_entities.end()) break;
+                const entt::entity parent = registry.get<contact_point_list>(it->second).parent;
+                if (auto *m = registry.try_get<contact_manifold>(parent)) if (m->num_points) --m->num_points;
+                registry.destroy(it->second);
+                s.point_entities.erase(it);
+                break;
+            }
+            case EDYNHIP_EVENT_MANIFOLD_DESTROYED: {
+                auto it = s.manifold_entities.find(manifold_key(e.body[0], e.body[1]));
+                if (it == s.manifold_entities.end()) break;
+                registry.destroy(it->second);
+                s.manifold_entities.erase(it);
+                break;
+            }
+            default: break;
+            }
+        }
+    }
+    if (s.cfg.contact_point_data) refresh_contact_points(registry, s);
+}
+inline void import_state(entt::registry &registry, gpu_stepper &s, const std::vector<float> &pos, const std::vector<float> &orn,
+                         const std::vector<float> &lv, const std::vector<float> &av) {
+    const uint32_t n = (uint32_t)std::min(s.bodies.size(), pos.size() / 3);
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[i];
+        if (e == entt::null || !registry.all_of<dynamic_tag>(e)) continue;
+        auto &p = registry.get<position>(e); p.x = pos[3 * i]; p.y = pos[3 * i + 1]; p.z = pos[3 * i + 2];
+        auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
+        auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
+        auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
+    }
+}
 inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, bool timed = false, double first_time = 0, double step_dt = 0) {
+    const bool async = s.cfg.execution_mode == execution_mode::asynchronous;
+    if (async && s.snapshot_pending) {
+        // execution_mode::asynchronous: the registry receives the PREVIOUS update's result (handed over while this update's
+        // steps run, like the simulation worker's snapshots, simulation_worker.cpp:406-444) - contact entities and sleeping
+        // tags of that update too, all read before the next steps are enqueued.
+        const uint32_t n = (uint32_t)s.bodies.size();
+        std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n);
+        check(s, edynhip_snapshot_read(s.ctx, pos.data(), orn.data(), lv.data(), av.data(), nullptr));
+        import_state(registry, s, pos, orn, lv, av);
+        sync_contacts(registry, s);
+        s.snapshot_pending = false;
+    }
     sync_removed(registry, s);
     if (s.scene_dirty) upload_scene(registry, s);
     if (s.state_dirty) upload_state(registry, s);   // also after an append: edits made in the same frame are not lost
     apply_params(s);
     if (steps == 0 || s.bodies.empty()) return;
     check(s, timed ? edynhip_step_timed(s.ctx, steps, first_time, step_dt) : edynhip_step(s.ctx, steps));
+    if (async) {
+        check(s, edynhip_snapshot(s.ctx));   // returns at once; read at the next update
+        s.snapshot_pending = true;
+        return;
+    }
     write_back(registry, s);
+    sync_contacts(registry, s);
 }
 // update_presentation (src/edyn/sys/update_presentation.cpp:56-84), local simulation (no discontinuities): transforms are
 // extrapolated from the last simulated state to `presentation_delay` = fixed_dt behind the current time.
@@ -544,6 +686,12 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
     registry.remove<detail::body_index>(entity);   // the stepper drops the body from the device world at the next update
+}
+
+/// Refreshes pivots / normal / distance / impulses of every contact_point entity from the device (one read-back).
+inline void refresh_contact_points(entt::registry &registry) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    if (s.ctx && s.cfg.materialize_contacts) detail::refresh_contact_points(registry, s);
 }
 
 /// Current contact manifolds (body pair + point count), materialised on demand.

@@ -69,6 +69,7 @@ enum {
     EDYNHIP_FLAG_TIMING = 1u,        /* record per-stage HIP events (edynhip_get_timings); each event costs ~6 us of idle GPU */
     EDYNHIP_FLAG_TIMING_SOLVE = 16u, /* record only the two events around the velocity solve (solve_velocity_ms) */
     EDYNHIP_FLAG_SLEEPING = 4u,      /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
+    EDYNHIP_FLAG_CONTACT_EVENTS = 32u, /* record manifold / contact point creation and destruction (edynhip_get_contact_events) */
     EDYNHIP_FLAG_EXCLUSIVE_DEVICE = 8u /* promise: nothing else launches work on this device while a step runs (one stepper per
                                         GPU). The resident-grid solver kernels are then launched plainly instead of
                                         cooperatively (~0.1 ms per step less idle GPU). Without the promise the default,
@@ -233,6 +234,33 @@ int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint3
 /* Per joint (by caller index, removed joints read 0) 10 floats: the applied impulses by slot - hinge: linear[3], hinge[2], limit,
  * bump_stop, spring, torque; point: applied[3], friction - and the tracked hinge angle (hinge_constraint.hpp:62-71). */
 int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses10);
+
+/* Contact events (EDYNHIP_FLAG_CONTACT_EVENTS): what an application observes in the reference through
+ * registry.on_construct / on_destroy<contact_manifold> (make_contact_manifold, constraint_util.cpp:60-102;
+ * broadphase::destroy_separated_manifolds, broadphase.cpp:99-134) and <contact_point> (create_contact_point,
+ * collision_util.cpp:311-388; destroy_contact_point, :390-430; contact_started_tag, narrowphase.cpp:111-130).
+ * The events of all steps of the last edynhip_step / edynhip_step_timed call, in no particular order within a step.
+ * A point keeps its id from creation to destruction: id = (step of creation + 1) << 32 | manifold index << 2 | slot
+ * (points injected with edynhip_set_manifolds: high word 0). If more events occurred than the context can hold
+ * (5 x max_manifolds), `n` is capped and EDYNHIP_ERR_CAPACITY is returned: resynchronise from edynhip_get_manifolds. */
+enum { EDYNHIP_EVENT_MANIFOLD_CREATED = 1, EDYNHIP_EVENT_MANIFOLD_DESTROYED = 2, EDYNHIP_EVENT_POINT_CREATED = 3, EDYNHIP_EVENT_POINT_DESTROYED = 4 };
+typedef struct {
+    uint32_t type;       /* EDYNHIP_EVENT_* */
+    uint32_t step;       /* step index (steps since edynhip_create / edynhip_set_bodies) in which it happened */
+    uint32_t body[2];    /* the manifold's bodies, as in edynhip_manifold.body */
+    uint64_t point_id;   /* point events; 0 for manifold events */
+} edynhip_contact_event;
+int edynhip_get_contact_events(edynhip_ctx *ctx, edynhip_contact_event *out, uint32_t capacity, uint32_t *n);
+/* ids[4 * i + k] = id of point k of manifold i in edynhip_get_manifolds order (0 where there is no point). */
+int edynhip_get_point_ids(edynhip_ctx *ctx, uint64_t *ids, uint32_t capacity_manifolds, uint32_t *n);
+
+/* Double-buffered state read-back - the analogue of the asynchronous stepper handing finished steps to the main thread
+ * (simulation_worker.cpp:406-444): edynhip_snapshot enqueues, behind the steps issued so far, a copy of the packed state
+ * (13 floats / body) into one of two pinned host buffers and returns at once; edynhip_snapshot_read waits for THAT copy
+ * only (not for steps enqueued after it) and unpacks it. step -> snapshot -> step -> snapshot_read hands the host the
+ * first step's result while the second one runs. `step_index` (may be NULL) = steps completed when the snapshot was taken. */
+int edynhip_snapshot(edynhip_ctx *ctx);
+int edynhip_snapshot_read(edynhip_ctx *ctx, float *pos, float *orn, float *linvel, float *angvel, uint32_t *step_index);
 
 /* Test hook: run the device closest-feature routine on `n` independent shape pairs (no world state involved).
  * shape_type[n][2], shape_param[n][2][4], pos[n][2][3], orn[n][2][4]; out_points[n][4][11] =

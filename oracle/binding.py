@@ -90,6 +90,9 @@ def lib():
     return _lib
 
 
+EVENT_DTYPE = np.dtype([("type", np.uint32), ("step", np.uint32), ("body", np.uint32, 2), ("point_id", np.uint64)])
+
+
 def ref():
     """The real reference leaf functions (None if oracle/_ref was not built)."""
     global _ref
@@ -325,6 +328,33 @@ class World:
     def set_manifolds(self, recs):
         recs = np.ascontiguousarray(recs, dtype=MANIFOLD_DTYPE)
         self.L.orc_set_manifolds(self.h, recs.ctypes.data_as(C.c_void_p), len(recs))
+
+    # contact events (the test counterpart of edynhip_get_contact_events / edynhip_get_point_ids)
+    def record_events(self, on=True):
+        f = self.L.orc_record_events; f.argtypes = [C.c_void_p, C.c_int]; f.restype = None
+        f(self.h, int(on))
+
+    def clear_events(self):
+        f = self.L.orc_clear_events; f.argtypes = [C.c_void_p]; f.restype = None
+        f(self.h)
+
+    def get_events(self):
+        """Structured array (type, step, body[2], point_id) of the events since record_events / clear_events."""
+        f = self.L.orc_num_events; f.argtypes = [C.c_void_p]; f.restype = C.c_uint32
+        n = f(self.h)
+        out = np.zeros(n, EVENT_DTYPE)
+        if n:
+            g = self.L.orc_get_events; g.argtypes = [C.c_void_p, C.c_void_p]; g.restype = None
+            g(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def get_point_ids(self):
+        m = self.L.orc_num_manifolds(self.h)
+        out = np.zeros((m, 4), np.uint64)
+        if m:
+            g = self.L.orc_get_point_ids; g.argtypes = [C.c_void_p, C.c_void_p]; g.restype = None
+            g(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def get_pairs(self):
         """Canonical (hi, lo) pairs sorted ascending — the representation bit-exact parity is checked on."""
@@ -575,6 +605,24 @@ class RefWorld:
         b = m["body"].astype(np.uint64)
         hi = np.maximum(b[:, 0], b[:, 1]); lo = np.minimum(b[:, 0], b[:, 1])
         return np.sort((hi << np.uint64(32)) | lo)
+
+    def record_events(self, on=True):
+        f = self.L.refw_record_events; f.argtypes = [C.c_void_p, C.c_int]; f.restype = None
+        f(self.h, int(on))
+
+    def clear_events(self):
+        f = self.L.refw_clear_events; f.argtypes = [C.c_void_p]; f.restype = None
+        f(self.h)
+
+    def get_events(self):
+        """[n, 3] (type, body A, body B): the engine's on_construct / on_destroy of contact_manifold (1, 2) and contact_point (3, 4)."""
+        f = self.L.refw_num_events; f.argtypes = [C.c_void_p]; f.restype = C.c_uint32
+        n = f(self.h)
+        out = np.zeros((n, 3), np.uint32)
+        if n:
+            g = self.L.refw_get_events; g.argtypes = [C.c_void_p, C.c_void_p]; g.restype = None
+            g(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def get_solve_order(self, max_entries=1 << 22):
         """(contacts[n,3], joints[m]) in the order the last step's island solvers visited them."""

@@ -150,6 +150,7 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
             c.pivotA = v3(p.pivotA); c.pivotB = v3(p.pivotB); c.normal = v3(p.normal); c.local_normal = v3(p.local_normal);
             c.distance = p.distance; c.friction = p.friction; c.restitution = p.restitution;
             c.attachment = p.attachment; c.lifetime = p.lifetime;
+            c.id = ((uint64_t)k << 2) | (uint64_t)i;   // injected points: high word 0 (edynhip_set_manifolds does the same)
             c.normal_impulse = p.normal_impulse; c.friction_impulse[0] = p.friction_impulse[0]; c.friction_impulse[1] = p.friction_impulse[1];
         }
         m.with_restitution = w->tags_restitution(m.body[0], m.body[1]);
@@ -262,6 +263,22 @@ void orc_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
 }
 int orc_should_collide(uint64_t groupA, uint64_t maskA, uint64_t groupB, uint64_t maskB) {
     return ((groupA & maskB) != 0 && (groupB & maskA) != 0) ? 1 : 0;
+}
+// contact events (test counterpart of edynhip_get_contact_events / edynhip_get_point_ids)
+void orc_record_events(void *h, int on) { World *w = (World *)h; w->record_events = on != 0; w->events.clear(); }
+void orc_clear_events(void *h) { ((World *)h)->events.clear(); }
+uint32_t orc_num_events(void *h) { return (uint32_t)((World *)h)->events.size(); }
+void orc_get_events(void *h, ContactEvent *out) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->events.size(); ++i) out[i] = w->events[i];
+}
+void orc_get_point_ids(void *h, uint64_t *ids) {   // [4 * manifold + k], canonical manifold order
+    World *w = (World *)h;
+    size_t m = 0;
+    for (auto &kv : w->manifolds) {
+        for (int k = 0; k < 4; ++k) ids[4 * m + k] = k < kv.second.num_points ? kv.second.pt[k].id : 0;
+        ++m;
+    }
 }
 uint32_t orc_sizeof_manifold_rec() { return (uint32_t)sizeof(orc_manifold_rec); }
 

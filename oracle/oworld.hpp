@@ -74,7 +74,12 @@ struct ContactPoint {
     uint32_t lifetime;
     float normal_impulse;
     float friction_impulse[2];
+    uint64_t id = 0;   // contact events: (step of creation + 1) << 32 | manifold index << 2 | local slot (the GPU's rule)
 };
+
+// Contact events as an application observes them through on_construct / on_destroy<contact_manifold | contact_point>.
+enum { EV_MANIFOLD_CREATED = 1, EV_MANIFOLD_DESTROYED = 2, EV_POINT_CREATED = 3, EV_POINT_DESTROYED = 4 };
+struct ContactEvent { uint32_t type, step, bodyA, bodyB; uint64_t id; };
 
 struct Manifold {
     uint32_t body[2];
@@ -208,6 +213,15 @@ public:
     // island entities and, on a merge, the larger island's timer - a difference only in which timer survives a merge.
     bool sleeping = false;
     uint64_t step_index = 0;
+    bool record_events = false;
+    mutable std::vector<ContactEvent> events;
+    void emit(uint32_t type, const Manifold &m, uint64_t id) const {
+        if (record_events) events.push_back(ContactEvent{type, (uint32_t)step_index, m.body[0], m.body[1], id});
+    }
+    void emit_destroyed(const Manifold &m) const {
+        for (int k = 0; k < m.num_points; ++k) emit(EV_POINT_DESTROYED, m, m.pt[k].id);
+        emit(EV_MANIFOLD_DESTROYED, m, 0);
+    }
     // Island sleep timers run on the step TIME STAMPS the stepper hands to the island manager (stepper_sequential.cpp:60-75,
     // island_manager.cpp:605-623): sim_clock is the stamp of the step being run; step() advances it by fixed dt, step_timed()
     // by the caller's stretched step_dt (the max_steps_per_update clamp scales the stamps, not the integration dt).
@@ -259,6 +273,7 @@ public:
             if (it->second.body[0] == i || it->second.body[1] == i) {
                 const uint32_t o = it->second.body[0] == i ? it->second.body[1] : it->second.body[0];
                 if (bodies[o].procedural() && o < island_label.size()) wake.push_back(island_label[o]);
+                emit_destroyed(it->second);   // (the device notices at the next step's broadphase: same step index)
                 it = manifolds.erase(it);
             } else ++it;
         }
@@ -368,7 +383,7 @@ public:
         new_keys.clear();
         for (auto it = manifolds.begin(); it != manifolds.end();) {   // destroy_separated_manifolds (sleeping manifolds excluded)
             const aabb &b0 = bodies[it->second.body[0]].box, &b1 = bodies[it->second.body[1]].box;
-            if (!manifold_asleep(it->second) && !intersect(b0.inset(sep_off), b1)) it = manifolds.erase(it);
+            if (!manifold_asleep(it->second) && !intersect(b0.inset(sep_off), b1)) { emit_destroyed(it->second); it = manifolds.erase(it); }
             else ++it;
         }
         for (auto &b : bodies) {   // move_aabbs
@@ -392,6 +407,7 @@ public:
                     m.with_restitution = tags_restitution(k, other);
                     manifolds.emplace(key, m);
                     new_keys.push_back(key);
+                    emit(EV_MANIFOLD_CREATED, m, 0);
                 });
             };
             visit_tree(tree_);
@@ -461,7 +477,7 @@ public:
         vec3 td = d - nd * cp.normal;
         return nd > thr || length_sqr(td) > thr2;
     }
-    void process_collision(Manifold &m, const coll_result &res) const {   // collision_util.hpp:104-276
+    void process_collision(Manifold &m, const coll_result &res, uint32_t midx = 0) const {   // collision_util.hpp:104-276
         const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
         const size_t R = res.num_points;
         bool merged[kMaxContacts] = {false, false, false, false};
@@ -520,23 +536,30 @@ public:
         for (int i = 0; i < n_old; ++i) dead[i] = removed[i];
         ContactPoint created[kMaxContacts];
         int n_created = 0;
+        auto create = [&](size_t slot, const coll_point &p) {
+            ContactPoint &cp = created[n_created++];
+            cp = make_point(m, p);
+            cp.id = ((uint64_t)(step_index + 1) << 32) | ((uint64_t)midx << 2) | (uint64_t)slot;
+            emit(EV_POINT_CREATED, m, cp.id);
+        };
         if (!all_merged) {
             for (size_t i = 0; i < num_points; ++i) {
                 Local &lp = local[i];
                 switch (lp.type) {
                 case insert_type::none: break;
-                case insert_type::append: created[n_created++] = make_point(m, lp.point); break;
+                case insert_type::append: create(i, lp.point); break;
                 case insert_type::similar:
-                    if (lp.old_index < 0) created[n_created++] = make_point(m, lp.point);
+                    if (lp.old_index < 0) create(i, lp.point);
                     else merge_point(m, lp.point, m.pt[lp.old_index]);
                     break;
                 case insert_type::replace:
                     if (lp.old_index >= 0) dead[lp.old_index] = true;
-                    created[n_created++] = make_point(m, lp.point);
+                    create(i, lp.point);
                     break;
                 }
             }
         }
+        for (int i = 0; i < n_old; ++i) if (dead[i]) emit(EV_POINT_DESTROYED, m, m.pt[i].id);
         ContactPoint out[kMaxContacts];
         int n_out = 0;
         for (int i = n_created - 1; i >= 0; --i) out[n_out++] = created[i];
@@ -555,11 +578,13 @@ public:
                 m.pt[i].distance = dot(m.pt[i].normal, pA - pB);
             }
         }
+        uint32_t midx = 0;   // index in canonical order = the device's manifold index
         for (auto &kv : manifolds) {
+            const uint32_t mi = midx++;
             if (manifold_asleep(kv.second)) continue;
             coll_result res;
             detect(kv.second, res);
-            process_collision(kv.second, res);
+            process_collision(kv.second, res, mi);
         }
     }
 

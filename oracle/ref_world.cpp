@@ -59,6 +59,28 @@ struct ref_world {
     float dt = 1.0f / 60;
     bool attached = false;
     bool paused = true;
+    // what an application sees of contacts: on_construct / on_destroy of contact_manifold and contact_point
+    bool record_events = false;
+    std::vector<uint32_t> events;   // 3 per event: type (1 manifold created, 2 destroyed, 3 point created, 4 destroyed), body A, body B
+    uint32_t body_index(entt::entity e) const {
+        auto it = index_of.find(entt::to_integral(e));
+        return it == index_of.end() ? 0xFFFFFFFFu : it->second;
+    }
+    void push_manifold_event(uint32_t type, entt::registry &reg, entt::entity manifold_entity) {
+        uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+        if (reg.valid(manifold_entity))
+            if (auto *m = reg.try_get<edyn::contact_manifold>(manifold_entity)) { a = body_index(m->body[0]); b = body_index(m->body[1]); }
+        events.push_back(type); events.push_back(a); events.push_back(b);
+    }
+    void on_manifold_created(entt::registry &reg, entt::entity e) { if (record_events) push_manifold_event(1, reg, e); }
+    void on_manifold_destroyed(entt::registry &reg, entt::entity e) { if (record_events) push_manifold_event(2, reg, e); }
+    void on_point(uint32_t type, entt::registry &reg, entt::entity e) {
+        if (!record_events) return;
+        auto *lst = reg.try_get<edyn::contact_point_list>(e);
+        push_manifold_event(type, reg, lst ? lst->parent : entt::entity{entt::null});
+    }
+    void on_point_created(entt::registry &reg, entt::entity e) { on_point(3, reg, e); }
+    void on_point_destroyed(entt::registry &reg, entt::entity e) { on_point(4, reg, e); }
     ~ref_world() { if (attached) edyn::detach(registry); }
 };
 
@@ -84,8 +106,16 @@ void *refw_create(int mode, int num_workers, float dt, int vel_iters, int pos_it
     edyn::set_solver_position_iterations(w->registry, (unsigned)pos_iters);
     edyn::set_gravity(w->registry, v3(g));
     edyn::set_paused(w->registry, true);
+    w->registry.on_construct<edyn::contact_manifold>().connect<&ref_world::on_manifold_created>(*w);
+    w->registry.on_destroy<edyn::contact_manifold>().connect<&ref_world::on_manifold_destroyed>(*w);
+    w->registry.on_construct<edyn::contact_point>().connect<&ref_world::on_point_created>(*w);
+    w->registry.on_destroy<edyn::contact_point_list>().connect<&ref_world::on_point_destroyed>(*w);   // (the list component still names the parent then)
     return w;
 }
+void refw_record_events(void *h, int on) { auto *w = (ref_world *)h; w->record_events = on != 0; w->events.clear(); }
+void refw_clear_events(void *h) { ((ref_world *)h)->events.clear(); }
+uint32_t refw_num_events(void *h) { return (uint32_t)(((ref_world *)h)->events.size() / 3); }
+void refw_get_events(void *h, uint32_t *out3) { auto *w = (ref_world *)h; std::copy(w->events.begin(), w->events.end(), out3); }
 void refw_destroy(void *h) { delete (ref_world *)h; }
 
 void refw_set_restitution_iterations(void *h, int iters, int individual_iters) {

@@ -1,0 +1,93 @@
+// Contact entities and the asynchronous execution mode through the C++ shim:
+//  * contact_manifold / contact_point entities appear and disappear in the registry as the device reports them
+//    (make_contact_manifold constraint_util.cpp:60-102, create_contact_point collision_util.cpp:311-388);
+//  * execution_mode::asynchronous hands the registry the previous update's state while the next one runs
+//    (simulation_worker.cpp:406-444): its trajectory is the synchronous one, one update late.
+#include <edyn/edyn.hpp>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static void build(entt::registry &registry, std::vector<entt::entity> &boxes) {
+    auto floor_def = edyn::rigidbody_def{};
+    floor_def.kind = edyn::rigidbody_kind::rb_static;
+    floor_def.shape = edyn::plane_shape{{0, 1, 0}, 0};
+    edyn::make_rigidbody(registry, floor_def);
+    for (int i = 0; i < 27; ++i) {
+        auto def = edyn::rigidbody_def{};
+        def.mass = 1;
+        def.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}};
+        def.position = {1.02f * (i % 3), 0.505f + 1.005f * ((i / 3) % 3), 1.02f * (i / 9)};
+        def.sleeping_disabled = true;
+        boxes.push_back(edyn::make_rigidbody(registry, def));
+    }
+}
+template <typename T> static size_t count(entt::registry &registry) {
+    size_t n = 0;
+    registry.view<T>().each([&](auto, auto &) { ++n; });
+    return n;
+}
+
+int main() {
+    // ---- contact entities
+    entt::registry registry;
+    auto cfg = edyn::init_config{};
+    cfg.contact_point_data = true;
+    edyn::attach(registry, cfg);
+    std::vector<entt::entity> boxes;
+    build(registry, boxes);
+    double t = 0;
+    for (int i = 0; i < 90; ++i) { t += 1.0 / 60; edyn::update(registry, t); }
+    const auto manifolds = edyn::get_contact_manifolds(registry);   // straight from the device
+    size_t device_points = 0;
+    for (auto &m : manifolds) device_points += m.num_points;
+    REQUIRE(!manifolds.empty() && device_points > 27);
+    REQUIRE(count<edyn::contact_manifold>(registry) == manifolds.size());
+    REQUIRE(count<edyn::contact_point>(registry) == device_points);
+    size_t listed = 0, penetrating = 0;
+    registry.view<edyn::contact_manifold>().each([&](auto, edyn::contact_manifold &m) { listed += m.num_points; });
+    REQUIRE(listed == device_points);
+    bool parents_ok = true, data_ok = true;
+    registry.view<edyn::contact_point_list>().each([&](auto e, edyn::contact_point_list &l) {
+        parents_ok = parents_ok && registry.all_of<edyn::contact_manifold>(l.parent);
+        const auto &cp = registry.get<edyn::contact_point>(e);
+        const float len = std::sqrt(cp.normal.x * cp.normal.x + cp.normal.y * cp.normal.y + cp.normal.z * cp.normal.z);
+        data_ok = data_ok && std::fabs(len - 1.0f) < 1e-4f;   // contact_point_data: the normals were read back
+        if (registry.get<edyn::contact_point_geometry>(e).distance < 0.02f) ++penetrating;
+    });
+    REQUIRE(parents_ok && data_ok && penetrating > 0);
+    // destroying a body takes its manifolds and points with it (at the next update)
+    registry.destroy(boxes.back());
+    t += 1.0 / 60; edyn::update(registry, t);
+    const auto after = edyn::get_contact_manifolds(registry);
+    size_t after_points = 0;
+    for (auto &m : after) after_points += m.num_points;
+    REQUIRE(after.size() < manifolds.size());
+    REQUIRE(count<edyn::contact_manifold>(registry) == after.size() && count<edyn::contact_point>(registry) == after_points);
+
+    // ---- asynchronous mode: the synchronous trajectory, one update late
+    entt::registry sync_reg, async_reg;
+    auto acfg = edyn::init_config{};
+    edyn::attach(sync_reg, acfg);
+    acfg.execution_mode = edyn::execution_mode::asynchronous;
+    edyn::attach(async_reg, acfg);
+    std::vector<entt::entity> sb, ab;
+    build(sync_reg, sb); build(async_reg, ab);
+    std::vector<edyn::position> history;
+    double ts = 0;
+    for (int i = 0; i < 40; ++i) {
+        ts += 1.0 / 60;
+        edyn::update(sync_reg, ts); edyn::update(async_reg, ts);
+        history.push_back(sync_reg.get<edyn::position>(sb[13]));
+        if (i > 0) {
+            const auto &p = async_reg.get<edyn::position>(ab[13]);
+            REQUIRE(p.x == history[i - 1].x && p.y == history[i - 1].y && p.z == history[i - 1].z);
+        }
+    }
+    REQUIRE(count<edyn::contact_manifold>(async_reg) > 0);
+    std::printf("contacts OK: %zu manifolds, %zu points mirrored; asynchronous mode lags one update, bit-identical\n", manifolds.size(), device_points);
+    return 0;
+}

@@ -28,3 +28,12 @@ def test_shim_lifecycle_runs():
     subprocess.check_call(["make", "-s", "-C", CPP, "lifecycle"])
     out = subprocess.run([os.path.join(CPP, "lifecycle")], capture_output=True, text=True, timeout=300)
     assert "LIFECYCLE_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_contact_entities_and_asynchronous_mode():
+    """contact_manifold / contact_point entities mirrored from the device's event list; execution_mode::asynchronous delivers
+    the synchronous trajectory one update late - tests/cpp/contacts.cpp."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "contacts"])
+    out = subprocess.run([os.path.join(CPP, "contacts")], capture_output=True, text=True, timeout=300)
+    assert "contacts OK" in out.stdout, out.stdout + out.stderr

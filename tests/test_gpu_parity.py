@@ -919,3 +919,55 @@ def test_gpu_against_the_real_reference_engine(name, gen, vel):
     g = gpu_world(scene, vel=vel)
     r = ob.RefWorld(vel_iters=vel); r.add_bodies(scene)
     resync_lockstep(g, r, scene["kind"], 40)
+
+
+def assert_state_equal(g, o):
+    for a, b in zip(g.get_state(), o.get_state()):
+        assert np.array_equal(a, b)
+
+
+def _sorted_events(ev):
+    return np.sort(ev, order=["step", "type", "body", "point_id"])
+
+
+def test_contact_events_and_point_ids_bit_exact():
+    """EDYNHIP_FLAG_CONTACT_EVENTS: the device's event list (manifold / contact point created / destroyed) and the
+    persistent point ids against the oracle's - whose events tests/test_reference_engine.py pins to the real engine's
+    on_construct / on_destroy signals. Collapsing mixed pile, a body removed mid-run, several steps per call."""
+    scene = scenes.box_pile(5, 5, 5, mixed=True)
+    g = gpu_world(scene, contact_events=True)
+    o = oracle_world(scene); o.record_events(True)
+    seen = 0
+    for call in range(40):
+        if call == 20:
+            g.remove_bodies([17]); o.remove_body(17)
+        k = 1 + call % 3
+        g.step_simulation(k); o.step(k)
+        eg, eo = g.get_contact_events(), o.get_events()
+        assert len(eg) == len(eo), call
+        assert np.array_equal(_sorted_events(eg), _sorted_events(eo)), call
+        assert np.array_equal(g.get_point_ids(), o.get_point_ids()), call
+        seen += len(eg)
+        o.clear_events()
+    assert seen > 1000
+    assert_state_equal(g, o)
+    # a world created without the flag answers with an error, not with an empty list
+    plain = gpu_world(scenes.box_pile(2, 2, 2)); plain.step_simulation(1)
+    with pytest.raises(edyn_amd.EdynHipError):
+        plain.get_contact_events()
+
+
+def test_double_buffered_snapshots_deliver_the_previous_step():
+    """edynhip_snapshot / snapshot_read: step, snapshot, step, snapshot_read hands over the FIRST step's state (bit-identical
+    to a synchronous read at that point) while the second step is already enqueued; the step index travels with it."""
+    scene = scenes.box_pile(6, 6, 6)
+    a, b = gpu_world(scene), gpu_world(scene)
+    for i in range(1, 25):
+        a.step_simulation(1); a.snapshot(); a.step_simulation(1)           # two steps in flight, one snapshot between them
+        (p, q, v, w), idx = a.snapshot_read()
+        b.step_simulation(1)
+        bp, bq, bv, bw = b.get_state()
+        assert idx == 2 * i - 1
+        assert np.array_equal(p, bp) and np.array_equal(q, bq) and np.array_equal(v, bv) and np.array_equal(w, bw), i
+        b.step_simulation(1)
+    assert_state_equal(a, b)

@@ -459,3 +459,42 @@ def test_restitution_shock_propagation_close_to_the_real_engine():
         rebound = max(rebound, float(ref.get_state()[2][1:, 1].max()))
         assert np.abs(ref.get_state()[0] - orc.get_state()[0]).max() < 2e-3, s
     assert rebound > 2.0
+
+
+def _event_multiset(ev3):
+    """(type, min body, max body) -> count"""
+    from collections import Counter
+    return Counter((int(t), int(min(a, b)), int(max(a, b))) for t, a, b in ev3)
+
+
+def test_contact_events_match_what_the_engine_signals():
+    """Contact events: the oracle's event list (manifold / contact point created / destroyed, the
+    device's edynhip_get_contact_events spec) against what an application observes on the real engine's registry through
+    on_construct / on_destroy<contact_manifold> and <contact_point>, step by step over a collapsing mixed pile and a body
+    removal. Point ids are created once, destroyed once, and the live set equals the manifolds' points."""
+    scene = scenes.box_pile(4, 4, 4, mixed=True)
+    o = ob.World(order=ob.ORDER_EXTERNAL); o.add_bodies(scene); ob.set_libm_trig(True)
+    r = ob.RefWorld(); r.add_bodies(scene)
+    try:
+        o.record_events(True); r.record_events(True)
+        live = set()
+        total = 0
+        for step in range(120):
+            if step == 60:   # registry.destroy(body): its manifolds and points go with it
+                o.remove_body(10); r.remove_body(10)
+            r.step(1)
+            o.set_ext_order(*r.get_solve_order()); o.step(1)
+            eo, er = o.get_events(), r.get_events()
+            assert _event_multiset(zip(eo["type"], eo["body"][:, 0], eo["body"][:, 1])) == _event_multiset(er), step
+            for e in eo:
+                if e["type"] == 3:
+                    assert int(e["point_id"]) not in live; live.add(int(e["point_id"]))
+                elif e["type"] == 4:
+                    live.remove(int(e["point_id"]))
+            ids = o.get_point_ids()
+            assert set(int(x) for x in ids.ravel() if x) == live, step
+            total += len(eo)
+            o.clear_events(); r.clear_events()
+        assert total > 500
+    finally:
+        ob.set_libm_trig(False)
