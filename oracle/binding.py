@@ -329,6 +329,20 @@ class World:
         recs = np.ascontiguousarray(recs, dtype=MANIFOLD_DTYPE)
         self.L.orc_set_manifolds(self.h, recs.ctypes.data_as(C.c_void_p), len(recs))
 
+    # contact_extras (rolling / spinning friction, soft contacts)
+    def set_material_extras(self, body, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
+        f = self.L.orc_set_material_extras; f.argtypes = [C.c_void_p, C.c_uint32] + [C.c_float] * 4; f.restype = None
+        f(self.h, body, spin, roll, stiffness, damping)
+
+    def get_point_extras(self):
+        """[num_manifolds, 4, 7]: rolling impulse 0/1, spin impulse, roll mu, spin mu, stiffness, damping (canonical manifold order)."""
+        m = self.L.orc_num_manifolds(self.h)
+        out = np.zeros((m, 4, 7), np.float32)
+        if m:
+            g = self.L.orc_get_point_extras; g.argtypes = [C.c_void_p, C.c_void_p]; g.restype = None
+            g(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
     # contact events (the test counterpart of edynhip_get_contact_events / edynhip_get_point_ids)
     def record_events(self, on=True):
         f = self.L.orc_record_events; f.argtypes = [C.c_void_p, C.c_int]; f.restype = None
@@ -605,6 +619,18 @@ class RefWorld:
         b = m["body"].astype(np.uint64)
         hi = np.maximum(b[:, 0], b[:, 1]); lo = np.minimum(b[:, 0], b[:, 1])
         return np.sort((hi << np.uint64(32)) | lo)
+
+    def set_material_extras(self, body, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
+        f = self.L.refw_set_material_extras; f.argtypes = [C.c_void_p, C.c_uint32] + [C.c_float] * 4; f.restype = None
+        f(self.h, body, spin, roll, stiffness, damping)
+
+    def get_point_extras(self):
+        m = self.L.refw_num_manifolds(self.h)
+        out = np.zeros((m, 4, 7), np.float32)
+        if m:
+            g = self.L.refw_get_point_extras; g.argtypes = [C.c_void_p, C.c_void_p]; g.restype = None
+            g(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def record_events(self, on=True):
         f = self.L.refw_record_events; f.argtypes = [C.c_void_p, C.c_int]; f.restype = None

@@ -264,6 +264,26 @@ void orc_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
 int orc_should_collide(uint64_t groupA, uint64_t maskA, uint64_t groupB, uint64_t maskB) {
     return ((groupA & maskB) != 0 && (groupB & maskA) != 0) ? 1 : 0;
 }
+// contact_extras materials and impulses
+void orc_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
+    Body &b = ((World *)h)->bodies[body];
+    b.spin_friction = spin; b.roll_friction = roll; b.stiffness = stiffness; b.damping = damping;
+}
+void orc_get_point_extras(void *h, float *out7) {   // [manifold][4][7]: rolling impulse 0/1, spin impulse, roll mu, spin mu, stiffness, damping
+    World *w = (World *)h;
+    size_t m = 0;
+    for (auto &kv : w->manifolds) {
+        for (int k = 0; k < 4; ++k) {
+            float *o = out7 + (4 * m + k) * 7;
+            for (int i = 0; i < 7; ++i) o[i] = 0;
+            if (k >= kv.second.num_points) continue;
+            const ContactPoint &c = kv.second.pt[k];
+            o[0] = c.rolling_impulse[0]; o[1] = c.rolling_impulse[1]; o[2] = c.spin_impulse;
+            o[3] = c.roll_friction; o[4] = c.spin_friction; o[5] = c.stiffness; o[6] = c.damping;
+        }
+        ++m;
+    }
+}
 // contact events (test counterpart of edynhip_get_contact_events / edynhip_get_point_ids)
 void orc_record_events(void *h, int on) { World *w = (World *)h; w->record_events = on != 0; w->events.clear(); }
 void orc_clear_events(void *h) { ((World *)h)->events.clear(); }

@@ -53,6 +53,7 @@ struct Body {
     shape sh{};
     bool has_material = true;
     float friction = 0.5f, restitution = 0.0f;
+    float spin_friction = 0, roll_friction = 0, stiffness = kLarge, damping = kLarge;   // comp/material.hpp:15-22
     uint64_t group = ~0ull, mask = ~0ull;
     std::vector<uint32_t> exclusions;   // collision_exclusion (comp/collision_exclusion.hpp:16-31)
     bool removed = false;               // destroyed entity: the index stays reserved
@@ -74,6 +75,10 @@ struct ContactPoint {
     uint32_t lifetime;
     float normal_impulse;
     float friction_impulse[2];
+    // contact_extras_constraint (contact_point_material / _spin_friction_impulse / _roll_friction_impulse)
+    float spin_friction = 0, roll_friction = 0, stiffness = kLarge, damping = kLarge;
+    float rolling_impulse[2] = {0, 0}, spin_impulse = 0;
+    bool extras() const { return stiffness < kLarge || damping < kLarge || spin_friction > 0 || roll_friction > 0; }   // collision_util.cpp:372-373
     uint64_t id = 0;   // contact events: (step of creation + 1) << 32 | manifold index << 2 | local slot (the GPU's rule)
 };
 
@@ -116,6 +121,7 @@ struct FrictionRow {
     float mu;
     uint32_t normal_row;
 };
+struct SpinRow { vec3 J[2]; float eff_mass, rhs, impulse, mu; uint32_t normal_row; };   // constraint_row_spin_friction.hpp
 struct RowOptions { float error = 0, erp = 0.2f, restitution = 0; };
 
 // Canonical key of an unordered body pair: (owner << 32) | other, where the OWNER is the procedural body - the one with
@@ -178,6 +184,22 @@ inline void solve_friction(FrictionRow &f, Row &n) {
         *n.dvB += n.inv_mB * f.row[i].J[2] * dimp[i];
         *n.dwB += n.inv_IB * f.row[i].J[3] * dimp[i];
     }
+}
+inline void solve_spin_friction(SpinRow &r, Row &n) {   // constraint_row_spin_friction.cpp:5-29
+    const float max_len = r.mu * n.impulse;
+    const float drel = dot(r.J[0], *n.dwA) + dot(r.J[1], *n.dwB);
+    float dimp = (r.rhs - drel) * r.eff_mass;
+    const float imp = r.impulse + dimp;
+    const float lo = -max_len, hi = max_len;
+    if (imp < lo) { dimp = lo - r.impulse; r.impulse = lo; }
+    else if (imp > hi) { dimp = hi - r.impulse; r.impulse = hi; }
+    else r.impulse = imp;
+    *n.dwA += n.inv_IA * r.J[0] * dimp;
+    *n.dwB += n.inv_IB * r.J[1] * dimp;
+}
+inline void warm_start_spin(SpinRow &r, Row &n) {   // :31-36
+    *n.dwA += n.inv_IA * r.J[0] * r.impulse;
+    *n.dwB += n.inv_IB * r.J[1] * r.impulse;
 }
 inline void warm_start_friction(FrictionRow &f, Row &n) {
     for (int i = 0; i < 2; ++i) {
@@ -467,6 +489,12 @@ public:
         const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
         cp.friction = std::sqrt(A.friction * B.friction);            // material_mixing.hpp:16-18
         cp.restitution = std::min(A.restitution, B.restitution);     // :12-14
+        cp.roll_friction = std::max(A.roll_friction, B.roll_friction);   // :24-26 (assign_material_properties, collision_util.cpp:309-315)
+        cp.spin_friction = std::max(A.spin_friction, B.spin_friction);   // :20-22
+        if (A.stiffness < kLarge || B.stiffness < kLarge) {
+            cp.stiffness = 1 / (1 / A.stiffness + 1 / B.stiffness);      // :28-30
+            cp.damping = 1 / (1 / A.damping + 1 / B.damping);            // :32-34
+        }
         return cp;
     }
     bool should_remove(const ContactPoint &cp, const Body &A, const Body &B) const {   // collision_util.cpp:397-413
@@ -761,7 +789,8 @@ public:
         prepare_row(r, o, A.linvel, A.angvel, B.linvel, B.angvel);
     }
     // contact_constraint.cpp:15-56
-    void prepare_contact(const ContactPoint &cp, const BodyRef &A, const BodyRef &B, Row &nr, FrictionRow &fr) {
+    struct ExtraRows { bool roll = false, spin = false; FrictionRow rr; SpinRow sr; };
+    void prepare_contact(const ContactPoint &cp, const BodyRef &A, const BodyRef &B, Row &nr, FrictionRow &fr, ExtraRows *ex = nullptr, int num_points = 1) {
         vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
         vec3 rA = pAw - A.pos, rB = pBw - B.pos;
         const vec3 n = cp.normal;
@@ -771,7 +800,41 @@ public:
         RowOptions o;
         o.restitution = 0;   // solver.cpp:282-283: restitution solver enabled => rows carry zero restitution
         if (cp.distance > 0) o.error = cp.distance / dt;
+        if (cp.extras() && cp.distance < 0 && cp.stiffness < kLarge) {   // soft contact, contact_extras_constraint.cpp:16-35
+            const vec3 vA = A.linvel + cross(A.angvel, rA), vB = B.linvel + cross(B.angvel, rB);
+            const float normal_relvel = dot(vA - vB, n);
+            const float spring_force = -cp.distance * cp.stiffness / (float)num_points;
+            const float damper_force = -normal_relvel * cp.damping / (float)num_points;
+            nr.upper = std::max(spring_force + damper_force, 0.0f) * dt;
+            o.error = -kLarge;
+        }
         finish_row(nr, o, A, B);
+        if (ex) {
+            ex->roll = cp.extras() && cp.roll_friction > 0;
+            ex->spin = cp.extras() && cp.spin_friction > 0;
+            if (ex->roll) {   // :37-64 (no roll_direction components on this path: the axes stay unscaled)
+                ex->rr.mu = cp.roll_friction;
+                vec3 t[2];
+                plane_space(n, t[0], t[1]);
+                for (int i = 0; i < 2; ++i) {
+                    auto &ri = ex->rr.row[i];
+                    ri.J[0] = {0, 0, 0}; ri.J[1] = t[i]; ri.J[2] = {0, 0, 0}; ri.J[3] = -t[i];
+                    ri.impulse = cp.rolling_impulse[i];
+                    const float s = dot(A.inv_I * ri.J[1], ri.J[1]) + dot(B.inv_I * ri.J[3], ri.J[3]);
+                    ri.eff_mass = s > kEps ? 1.0f / s : 0.0f;
+                    ri.rhs = -relative_speed(ri.J, A.linvel, A.angvel, B.linvel, B.angvel);
+                }
+            }
+            if (ex->spin) {   // :66-78
+                SpinRow &sr = ex->sr;
+                sr.mu = cp.spin_friction;
+                sr.J[0] = n; sr.J[1] = -n;
+                sr.impulse = cp.spin_impulse;
+                const float s = dot(A.inv_I * sr.J[0], sr.J[0]) + dot(B.inv_I * sr.J[1], sr.J[1]);
+                sr.eff_mass = 1.0f / s;
+                sr.rhs = -(dot(sr.J[0], A.angvel) + dot(sr.J[1], B.angvel));
+            }
+        }
         fr.mu = cp.friction;
         vec3 t[2];
         plane_space(n, t[0], t[1]);
@@ -923,6 +986,7 @@ public:
         }
     };
     void contact_solve_position(Manifold &m, ContactPoint &cp, PosSolver &ps) {   // contact_constraint.cpp:58-90
+        if (cp.extras() && cp.stiffness < kLarge) return;   // soft contacts take no position correction (contact_extras_constraint.cpp:81-86)
         Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
         ps.bind(A, B);
         vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
@@ -1151,8 +1215,13 @@ public:
                 for (Manifold *m : isl_m[label]) expect += (size_t)m->num_points;
                 if (expect != cps.size()) ext_order_mismatch = true;
             } else {
-                for (Manifold *m : isl_m[label]) for (int i = 0; i < m->num_points; ++i) cps.push_back({m, i});
+                // constraints_tuple order: every contact_constraint, then every contact_extras_constraint
+                for (int pass = 0; pass < 2; ++pass)
+                    for (Manifold *m : isl_m[label]) for (int i = 0; i < m->num_points; ++i) if ((int)m->pt[i].extras() == pass) cps.push_back({m, i});
             }
+            std::vector<FrictionRow> roll;
+            std::vector<SpinRow> spin;
+            std::vector<ContactPoint *> roll_cp, spin_cp;
             for (int type : {JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: hinge ... point, contact
                 for (Joint *j : js) {
                     if (j->type != type) continue;
@@ -1165,19 +1234,25 @@ public:
             for (auto &cp : cps) {
                 Manifold *m = cp.first;
                 BodyRef A = body_ref(m->body[0]), B = body_ref(m->body[1]);
-                Row nr; FrictionRow fr;
-                prepare_contact(m->pt[cp.second], A, B, nr, fr);
+                Row nr; FrictionRow fr; ExtraRows ex;
+                prepare_contact(m->pt[cp.second], A, B, nr, fr, &ex, m->num_points);
                 fr.normal_row = (uint32_t)rows.size();
                 crows.push_back({&m->pt[cp.second], fr.normal_row});
+                if (ex.roll) { ex.rr.normal_row = fr.normal_row; roll.push_back(ex.rr); roll_cp.push_back(&m->pt[cp.second]); }
+                if (ex.spin) { ex.sr.normal_row = fr.normal_row; spin.push_back(ex.sr); spin_cp.push_back(&m->pt[cp.second]); }
                 rows.push_back(nr);
                 fric.push_back(fr);
             }
             stats.num_rows += (uint32_t)rows.size();
             for (auto &r : rows) apply_row_impulse(r.impulse, r);                 // warm start
             for (auto &f : fric) warm_start_friction(f, rows[f.normal_row]);
-            for (int it = 0; it < vel_iters; ++it) {
+            for (auto &f : roll) warm_start_friction(f, rows[f.normal_row]);
+            for (auto &r : spin) warm_start_spin(r, rows[r.normal_row]);
+            for (int it = 0; it < vel_iters; ++it) {   // island_solver.cpp:94-111
                 for (auto &r : rows) { float d = solve_row(r); apply_row_impulse(d, r); }
                 for (auto &f : fric) solve_friction(f, rows[f.normal_row]);
+                for (auto &f : roll) solve_friction(f, rows[f.normal_row]);
+                for (auto &r : spin) solve_spin_friction(r, rows[r.normal_row]);
             }
             for (uint32_t b : ib.second) integrate_body(bodies[b]);
             for (auto &jr : jrows)                                                 // assign_applied_impulses
@@ -1187,6 +1262,8 @@ public:
                 crows[k].first->friction_impulse[0] = fric[k].row[0].impulse;
                 crows[k].first->friction_impulse[1] = fric[k].row[1].impulse;
             }
+            for (size_t k = 0; k < roll.size(); ++k) { roll_cp[k]->rolling_impulse[0] = roll[k].row[0].impulse; roll_cp[k]->rolling_impulse[1] = roll[k].row[1].impulse; }
+            for (size_t k = 0; k < spin.size(); ++k) spin_cp[k]->spin_impulse = spin[k].impulse;
             for (int it = 0; it < pos_iters; ++it) {
                 PosSolver hs, cs;
                 for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
@@ -1200,7 +1277,7 @@ public:
     void solve_coloured() {
         colour_joints();
         colour_contacts();
-        struct CRows { Manifold *m; Row nr[kMaxContacts]; FrictionRow fr[kMaxContacts]; };
+        struct CRows { Manifold *m; Row nr[kMaxContacts]; FrictionRow fr[kMaxContacts]; ExtraRows ex[kMaxContacts]; };
         struct JRows { Joint *j; int n; Row r[kMaxJointRows]; int slot[kMaxJointRows]; };
         std::vector<std::vector<CRows>> cc(stats.num_colours);
         std::vector<std::vector<JRows>> jc(stats.num_joint_colours);
@@ -1217,7 +1294,7 @@ public:
             if (m.num_points == 0 || manifold_asleep(m)) continue;
             CRows cr; cr.m = &m;
             BodyRef A = body_ref(m.body[0]), B = body_ref(m.body[1]);
-            for (int i = 0; i < m.num_points; ++i) prepare_contact(m.pt[i], A, B, cr.nr[i], cr.fr[i]);
+            for (int i = 0; i < m.num_points; ++i) prepare_contact(m.pt[i], A, B, cr.nr[i], cr.fr[i], &cr.ex[i], m.num_points);
             stats.num_rows += m.num_points;
             cc[m.colour].push_back(cr);
         }
@@ -1225,12 +1302,17 @@ public:
         for (auto &col : cc) for (auto &cr : col) {
             for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
             for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+            for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) warm_start_friction(cr.ex[i].rr, cr.nr[i]);
+            for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) warm_start_spin(cr.ex[i].sr, cr.nr[i]);
         }
         for (int it = 0; it < vel_iters; ++it) {
             for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) { float d = solve_row(jr.r[i]); apply_row_impulse(d, jr.r[i]); }
             for (auto &col : cc) for (auto &cr : col) {
                 for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
                 for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+                // inside a manifold the reference's order of row kinds: normals, friction, rolling, spinning
+                for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) solve_friction(cr.ex[i].rr, cr.nr[i]);
+                for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) solve_spin_friction(cr.ex[i].sr, cr.nr[i]);
             }
         }
         for (auto &b : bodies) if (b.kind == KIND_DYNAMIC && !b.asleep) integrate_body(b);
@@ -1239,6 +1321,8 @@ public:
             cr.m->pt[i].normal_impulse = cr.nr[i].impulse;
             cr.m->pt[i].friction_impulse[0] = cr.fr[i].row[0].impulse;
             cr.m->pt[i].friction_impulse[1] = cr.fr[i].row[1].impulse;
+            if (cr.ex[i].roll) { cr.m->pt[i].rolling_impulse[0] = cr.ex[i].rr.row[0].impulse; cr.m->pt[i].rolling_impulse[1] = cr.ex[i].rr.row[1].impulse; }
+            if (cr.ex[i].spin) cr.m->pt[i].spin_impulse = cr.ex[i].sr.impulse;
         }
         // Position iterations: per-island early-out, islands keyed by label.
         std::vector<uint8_t> done(bodies.size(), 0);

@@ -363,6 +363,30 @@ void refw_get_manifolds(void *h, manifold_rec *out) {
         r.num_points = n;
     }
 }
+// [manifold][4][7] in refw_get_manifolds order: rolling impulse 0/1, spin impulse, roll mu, spin mu, stiffness, damping
+void refw_get_point_extras(void *h, float *out7) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    std::vector<std::pair<uint64_t, entt::entity>> order;
+    for (auto [e, m] : reg.view<edyn::contact_manifold>().each()) {
+        uint64_t a = w->index_of.at(entt::to_integral(m.body[0])), b = w->index_of.at(entt::to_integral(m.body[1]));
+        order.emplace_back((std::max(a, b) << 32) | std::min(a, b), e);
+    }
+    std::sort(order.begin(), order.end());
+    size_t k = 0;
+    for (auto &[key, e] : order) {
+        float *base = out7 + 28 * k++;
+        for (int i = 0; i < 28; ++i) base[i] = 0;
+        uint32_t n = 0;
+        edyn::contact_manifold_each_point(reg, e, [&](entt::entity pe) {
+            if (n >= 4) return;
+            float *o = base + 7 * n++;
+            if (auto *r = reg.try_get<edyn::contact_point_roll_friction_impulse>(pe)) { o[0] = r->rolling_friction_impulse[0]; o[1] = r->rolling_friction_impulse[1]; }
+            if (auto *sp = reg.try_get<edyn::contact_point_spin_friction_impulse>(pe)) o[2] = sp->spin_friction_impulse;
+            if (auto *mat = reg.try_get<edyn::contact_point_material>(pe)) { o[3] = mat->roll_friction; o[4] = mat->spin_friction; o[5] = mat->stiffness; o[6] = mat->damping; }
+        });
+    }
+}
 // hinge: linear[3], hinge[2], limit, bump_stop, spring, torque, angle (10) ; point: applied[3], friction (4, rest 0)
 void refw_get_joint_impulses(void *h, float *out10) {
     auto *w = (ref_world *)h;
@@ -389,24 +413,34 @@ uint32_t refw_get_contact_order(void *h, uint32_t *out3, uint32_t max_entries) {
     auto *w = (ref_world *)h;
     auto &reg = w->registry;
     uint32_t n = 0;
-    auto con_view = reg.view<edyn::contact_constraint>();
-    for (auto [ie, isl] : reg.view<edyn::island>().each()) {
-        for (auto edge : isl.edges) {
-            if (!con_view.contains(edge) || n >= max_entries) continue;
-            auto manifold_entity = reg.get<edyn::contact_point_list>(edge).parent;
-            auto &m = reg.get<edyn::contact_manifold>(manifold_entity);
-            uint32_t slot = 0, found = 0xFFFFFFFFu;
-            edyn::contact_manifold_each_point(reg, manifold_entity, [&](entt::entity pe) {
-                if (pe == edge) found = slot;
-                ++slot;
-            });
-            out3[3 * n] = w->index_of.at(entt::to_integral(m.body[0]));
-            out3[3 * n + 1] = w->index_of.at(entt::to_integral(m.body[1]));
-            out3[3 * n + 2] = found;
-            ++n;
+    // constraints_tuple order (constraint.hpp:23-34): every contact_constraint of the island, then every contact_extras_constraint
+    auto emit = [&](auto con_view) {
+        for (auto [ie, isl] : reg.view<edyn::island>().each()) {
+            for (auto edge : isl.edges) {
+                if (!con_view.contains(edge) || n >= max_entries) continue;
+                auto manifold_entity = reg.get<edyn::contact_point_list>(edge).parent;
+                auto &m = reg.get<edyn::contact_manifold>(manifold_entity);
+                uint32_t slot = 0, found = 0xFFFFFFFFu;
+                edyn::contact_manifold_each_point(reg, manifold_entity, [&](entt::entity pe) {
+                    if (pe == edge) found = slot;
+                    ++slot;
+                });
+                out3[3 * n] = w->index_of.at(entt::to_integral(m.body[0]));
+                out3[3 * n + 1] = w->index_of.at(entt::to_integral(m.body[1]));
+                out3[3 * n + 2] = found;
+                ++n;
+            }
         }
-    }
+    };
+    emit(reg.view<edyn::contact_constraint>());
+    emit(reg.view<edyn::contact_extras_constraint>());
     return n;
+}
+// material extras of a body (before its contacts are created): comp/material.hpp:15-22
+void refw_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
+    auto *w = (ref_world *)h;
+    auto &m = w->registry.get<edyn::material>(w->bodies[body]);
+    m.spin_friction = spin; m.roll_friction = roll; m.stiffness = stiffness; m.damping = damping;
 }
 uint32_t refw_get_joint_order(void *h, uint32_t *out, uint32_t max_entries) {
     auto *w = (ref_world *)h;

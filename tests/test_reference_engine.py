@@ -498,3 +498,61 @@ def test_contact_events_match_what_the_engine_signals():
         assert total > 500
     finally:
         ob.set_libm_trig(False)
+
+
+def _extras_scene(kind):
+    """Spheres and boxes on the plane with contact_extras materials: rolling + spinning friction, or soft contacts."""
+    sc = scenes.box_pile(3, 2, 3, mixed=True)
+    n = len(sc["kind"])
+    rng = np.random.default_rng(3)
+    sc["linvel"][1:] = (rng.normal(size=(n - 1, 3)) * (1.5, 0.2, 1.5)).astype(np.float32)
+    sc["angvel"][1:] = (rng.normal(size=(n - 1, 3)) * 3).astype(np.float32)
+    ex = {}
+    for i in range(n):
+        if kind == "roll_spin":
+            ex[i] = dict(spin=0.02 + 0.01 * (i % 3), roll=0.05 if i % 2 else 0.0)
+        elif kind == "soft":
+            ex[i] = dict(stiffness=4000.0 + 500.0 * (i % 4), damping=60.0) if (i % 3 != 1) else {}
+        else:   # everything at once; some bodies keep the plain contact_constraint
+            ex[i] = dict(spin=0.03, roll=0.04, stiffness=6000.0, damping=80.0) if i % 2 == 0 else (dict(roll=0.02) if i % 4 == 1 else {})
+    return sc, ex
+
+
+@pytest.mark.parametrize("kind", ["roll_spin", "soft", "both"])
+def test_contact_extras_match_the_real_engine(kind):
+    """contact_extras_constraint (contact_extras_constraint.cpp:12-110, constraint_row_spin_friction.cpp:5-36,
+    island_solver.cpp:76-111 row-kind order, material_mixing.hpp:20-34): rolling and spinning friction rows and soft
+    (stiffness / damping limited) normal rows - state, the rolling / spinning impulses carried by the contact points and
+    the mixed material values, bit for bit against the real engine over a rolling, spinning, settling scene."""
+    sc, ex = _extras_scene(kind)
+    ref = ob.RefWorld(); ref.add_bodies(sc)
+    orc = ob.World(order=ob.ORDER_EXTERNAL); orc.add_bodies(sc); ob.set_libm_trig(True)
+    try:
+        for i, kw in ex.items():
+            if kw:
+                ref.set_material_extras(i, **kw); orc.set_material_extras(i, **kw)
+        seen_roll = seen_spin = seen_soft = 0
+        for s in range(1, 241):
+            ref.step(1)
+            orc.set_ext_order(*ref.get_solve_order())
+            orc.step(1)
+            assert not orc.ext_order_mismatch(), s
+            for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {s}: {name} differs, max |d| = {np.abs(a - b).max()}"
+            if s % 10 == 0:
+                rm, om = _canon(ref.get_manifolds()), _canon(orc.get_manifolds())
+                assert np.array_equal(rm["body"], om["body"]) and np.array_equal(rm["num_points"], om["num_points"]), s
+                for fld in ("normal_impulse", "friction_impulse", "distance"):
+                    assert np.array_equal(rm["pt"][fld], om["pt"][fld]), (s, fld)
+                rx, ox = ref.get_point_extras(), orc.get_point_extras()   # both in ascending (max, min) pair order
+                ob_ = orc.get_manifolds()["body"].astype(np.uint64)
+                okey = (np.maximum(ob_[:, 0], ob_[:, 1]) << np.uint64(32)) | np.minimum(ob_[:, 0], ob_[:, 1])
+                ox = ox[np.argsort(okey, kind="stable")]
+                assert np.array_equal(rx.view(np.uint32), ox.view(np.uint32)), f"step {s}: rolling / spinning impulses or mixed materials differ"
+                seen_roll += int((rx[..., 0] != 0).sum()); seen_spin += int((rx[..., 2] != 0).sum()); seen_soft += int((rx[..., 5] < 1e17).sum() - (rx[..., 5] == 0).sum())
+        if kind in ("roll_spin", "both"):
+            assert seen_roll > 0 and seen_spin > 0
+        if kind in ("soft", "both"):
+            assert seen_soft > 0
+    finally:
+        ob.set_libm_trig(False)
