@@ -74,7 +74,8 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
-           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read"]
+           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
+           "edynhip_set_material_extras", "edynhip_get_point_extras"]
 
 _lib = None
 
@@ -115,6 +116,8 @@ def lib():
         L.edynhip_get_contact_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_snapshot.argtypes = [C.c_void_p]
+        L.edynhip_set_material_extras.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edynhip_get_point_extras.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_snapshot_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.edynhip_add_joints.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Joints), C.POINTER(C.c_uint32)]
         L.edynhip_remove_joints.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]

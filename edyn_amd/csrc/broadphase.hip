@@ -482,6 +482,7 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
             cur.pA[d] = prev.pA[s]; cur.pB[d] = prev.pB[s]; cur.nrm[d] = prev.nrm[s];
             cur.lnrm[d] = prev.lnrm[s]; cur.imp[d] = prev.imp[s];
             if (cur.pid) cur.pid[d] = prev.pid[s];
+            if (cur.xmat) { cur.xmat[d] = prev.xmat[s]; cur.ximp[d] = prev.ximp[s]; }
         }
     }
     cur.info[m] = info;

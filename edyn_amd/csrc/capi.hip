@@ -77,7 +77,7 @@ static int allocate(edynhip_ctx *c) {
     b.cap = nb;
     EH_TRY(dalloc(c, b.xf, (size_t)nb * 8)); EH_TRY(dalloc(c, b.dvw, (size_t)nb * 2)); EH_TRY(dalloc(c, b.linvel, nb)); EH_TRY(dalloc(c, b.angvel, nb));
     EH_TRY(dalloc(c, b.amin, nb)); EH_TRY(dalloc(c, b.amax, nb)); EH_TRY(dalloc(c, b.shape, nb)); EH_TRY(dalloc(c, b.grav, nb));
-    EH_TRY(dalloc(c, b.mat, nb)); EH_TRY(dalloc(c, b.flags, nb)); EH_TRY(dalloc(c, b.group, nb)); EH_TRY(dalloc(c, b.mask, nb));
+    EH_TRY(dalloc(c, b.mat, nb)); EH_TRY(dalloc(c, b.mat2, nb)); EH_TRY(dalloc(c, b.flags, nb)); EH_TRY(dalloc(c, b.group, nb)); EH_TRY(dalloc(c, b.mask, nb));
     EH_TRY(dalloc(c, b.island, nb));
     EH_TRY(alloc_manifolds(c, c->m[0], M, nb));
     EH_TRY(alloc_manifolds(c, c->m[1], M, nb));
@@ -190,6 +190,7 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
     f3 g = r.gravity ? mk3(r.gravity[3 * l], r.gravity[3 * l + 1], r.gravity[3 * l + 2]) : mk3(default_gravity.x, default_gravity.y, default_gravity.z);
     b.grav[i] = kind == EDYNHIP_KIND_DYNAMIC ? to4(g, 0) : make_float4(0, 0, 0, 0);
     b.mat[i] = make_float2(r.friction[l], r.restitution[l]);
+    b.mat2[i] = make_float4(0.0f, 0.0f, kLarge, kLarge);   // material defaults (comp/material.hpp:15-22); edynhip_set_material_extras changes them
     b.flags[i] = (uint32_t)kind | ((uint32_t)st << BF_SHAPE_SHIFT) | ((r.sleeping_disabled && r.sleeping_disabled[l]) ? BF_NOSLEEP : 0u);
     b.group[i] = r.group ? r.group[l] : ~0ull;
     b.mask[i] = r.mask ? r.mask[l] : ~0ull;
@@ -287,6 +288,7 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
         mf.lnrm[s] = make_float4(p.local_normal[0], p.local_normal[1], p.local_normal[2], p.restitution);
         mf.imp[s] = make_float4(p.normal_impulse, p.friction_impulse[0], p.friction_impulse[1], __uint_as_float(p.lifetime));
         if (mf.pid) mf.pid[s] = ((uint64_t)m << 2) | k;   // injected points: high word 0
+        if (mf.xmat) { mf.xmat[s] = make_float4(0.0f, 0.0f, kLarge, kLarge); mf.ximp[s] = make_float4(0, 0, 0, 0); }   // (the record carries no extras)
     }
 }
 __global__ void k_pack_state(uint32_t first, uint32_t count, Bodies b, float *dst) {
@@ -431,7 +433,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 4; }   // 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 5; }   // 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -528,7 +530,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     if (n && (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
               !in->friction || !in->restitution))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
-    if (first == 0) c->has_restitution = false;
+    if (first == 0) { c->has_restitution = false; c->extras = false; }
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)
     if (first == 0) { c->host_joints.clear(); c->j.n = 0; c->j.num_colours = 0; c->j.rows = 0; c->host_excl.clear(); if (c->excl) (void)hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream); }
@@ -1091,6 +1093,63 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_manifolds", e);
+    return EDYNHIP_OK;
+}
+
+// ---- contact_extras materials (comp/material.hpp:15-22; contact_extras_constraint.cpp)
+int edynhip_set_material_extras(edynhip_ctx *c, uint32_t first, uint32_t n, const float *spin, const float *roll, const float *stiffness, const float *damping) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    if ((uint64_t)first + n > c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_extras: body range out of bounds");
+    if (n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> h(n);
+    bool any = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        h[i] = make_float4(spin ? spin[i] : 0.0f, roll ? roll[i] : 0.0f, stiffness ? stiffness[i] : kLarge, damping ? damping[i] : kLarge);
+        if (h[i].x < 0 || h[i].y < 0 || !(h[i].z > 0) || !(h[i].w > 0)) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_extras: negative friction or non-positive stiffness / damping");
+        any = any || h[i].x > 0 || h[i].y > 0 || h[i].z < kLarge || h[i].w < kLarge;
+    }
+    if (any && !c->m[0].xmat) {   // first such material: the per-point storage and the extras rows come into existence
+        for (int k = 0; k < 2; ++k) {
+            EH_TRY(dalloc(c, c->m[k].xmat, (size_t)c->m[k].cap * kMaxPts)); EH_TRY(dalloc(c, c->m[k].ximp, (size_t)c->m[k].cap * kMaxPts));
+        }
+        EH_TRY(dalloc(c, c->rows.rwx, (size_t)c->m[0].cap * kMaxPts * kXPoint));
+        // points that already exist keep plain contact_constraint behaviour: default material, no impulses
+        std::vector<float4> def((size_t)c->m[0].cap * kMaxPts, make_float4(0, 0, kLarge, kLarge));
+        for (int k = 0; k < 2; ++k) EH_HIP(c, hipMemcpyAsync(c->m[k].xmat, def.data(), def.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        EH_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (any) c->extras = true;
+    EH_HIP(c, hipMemcpyAsync(c->b.mat2 + first, h.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    return EDYNHIP_OK;
+}
+int edynhip_get_point_extras(edynhip_ctx *c, float *out7, uint32_t capacity, uint32_t *n) {
+    if (!c || !n) return EDYNHIP_ERR_INVALID;
+    const uint32_t M = c->num_manifolds;
+    *n = M;
+    if (M == 0 || !out7) return EDYNHIP_OK;
+    if (capacity < M) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_get_point_extras: capacity too small");
+    EH_HIP(c, hipSetDevice(c->device));
+    const Manifolds &mf = c->m[c->cur];
+    std::vector<uint32_t> info(M);
+    EH_HIP(c, hipMemcpyAsync(info.data(), mf.info, (size_t)M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> xm(M), xi(M);
+    for (uint32_t k = 0; k < (uint32_t)kMaxPts; ++k) {
+        if (mf.xmat) {
+            EH_HIP(c, hipMemcpyAsync(xm.data(), mf.xmat + (size_t)k * mf.cap, (size_t)M * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+            EH_HIP(c, hipMemcpyAsync(xi.data(), mf.ximp + (size_t)k * mf.cap, (size_t)M * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+            EH_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        for (uint32_t m = 0; m < M; ++m) {
+            float *o = out7 + ((size_t)4 * m + k) * 7;
+            const bool live = k < (info[m] & 0xFF);
+            const float4 a = mf.xmat ? xm[m] : make_float4(0, 0, kLarge, kLarge), b = mf.xmat ? xi[m] : make_float4(0, 0, 0, 0);
+            o[0] = live ? b.x : 0; o[1] = live ? b.y : 0; o[2] = live ? b.z : 0;
+            o[3] = live ? a.x : 0; o[4] = live ? a.y : 0; o[5] = live ? a.z : 0; o[6] = live ? a.w : 0;
+        }
+    }
     return EDYNHIP_OK;
 }
 

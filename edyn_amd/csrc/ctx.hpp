@@ -45,6 +45,7 @@ struct Bodies {
     float4 *shape = nullptr;    // box half extents | sphere radius | plane normal+constant
     float4 *grav = nullptr;     // per-body gravity
     float2 *mat = nullptr;      // friction, restitution
+    float4 *mat2 = nullptr;     // contact_extras materials: spin_friction, roll_friction, stiffness, damping (comp/material.hpp:15-22)
     uint32_t *flags = nullptr;  // kind | shape << 4
     uint64_t *group = nullptr, *mask = nullptr;
     uint32_t *island = nullptr; // connected-component label (min body index)
@@ -66,7 +67,14 @@ struct Manifolds {
     float4 *lnrm = nullptr;       // local_normal xyz, w = restitution
     float4 *imp = nullptr;        // normal_impulse, friction_impulse[0], [1], bitcast(lifetime)
     uint64_t *pid = nullptr;      // contact events only (else nullptr): the point's id from creation to destruction
+    // contact_extras only (else nullptr; allocated when a body gets such a material, edynhip_set_material_extras)
+    float4 *xmat = nullptr;       // mixed at creation: roll_friction, spin_friction, stiffness, damping (contact_point_material)
+    float4 *ximp = nullptr;       // rolling_friction_impulse[0], [1], spin_friction_impulse, -
 };
+// Extras rows of a point (contact_extras_constraint.cpp:37-78), angular only: J = {0, axis, 0, -axis}. Per point 10 float4 at
+// rwx[(k * kXPoint + slot) * cap + p]: rows roll0, roll1, spin as (axis, eff) (I_A^-1 axis, rhs) (I_B^-1 (-axis), impulse) in
+// slots 3r..3r+2, and slot 9 = (roll mu, spin mu, -, -); mu = 0: the row does not exist.
+constexpr int kXRowF = 3, kXRows = 3, kXPoint = kXRows * kXRowF + 1;
 
 // Contact events (EDYNHIP_FLAG_CONTACT_EVENTS; edynhip.h edynhip_contact_event has the same layout).
 struct ContactEvent { uint32_t type, step, bodyA, bodyB; uint64_t pid; };
@@ -127,6 +135,7 @@ struct Rows {
     uint32_t *bA = nullptr, *bB = nullptr, *np = nullptr;
     uint32_t *label = nullptr;    // island label of the manifold (p-indexed copy: keeps the position kernel's load chain short)
     float4 *rw = nullptr;
+    float4 *rwx = nullptr;        // contact_extras rows (kXPoint float4 per point), nullptr unless the world has such materials
     // "Push" hand-off of the body deltas between consecutive manifolds of a body (used when the scene has no joints):
     // lane p reads the deltas of its two bodies from its OWN slots dslot[2*(2p+side) + {0,1}] (coalesced, no dependent
     // gather) and writes the updated deltas into the slots of each body's next manifold in colour order (cyclic).
@@ -267,6 +276,7 @@ struct edynhip_ctx {
     float *state_host = nullptr;   // pinned mirror
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
+    bool extras = false;           // some body carries a contact_extras material: extras storage exists, per-colour schedule
     uint32_t step_index = 0;       // completed steps
     // contact events: device list of the current edynhip_step call, per-manifold "still there" marks of the previous array
     eh::ContactEvent *events = nullptr; uint32_t *event_count = nullptr; uint32_t event_cap = 0; uint8_t *prev_matched = nullptr;

@@ -105,6 +105,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                     const size_t s = (size_t)k * src.cap + sidx, d = (size_t)k * mf.cap + m;
                     mf.pA[d] = src.pA[s]; mf.pB[d] = src.pB[s]; mf.nrm[d] = src.nrm[s]; mf.lnrm[d] = src.lnrm[s]; mf.imp[d] = src.imp[s];
                     if (mf.pid) mf.pid[d] = src.pid[s];
+                    if (mf.xmat) { mf.xmat[d] = src.xmat[s]; mf.ximp[d] = src.ximp[s]; }
                 }
             return;
         }
@@ -280,6 +281,26 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                 if (mf.pid) mf.pid[d] = ext_id[i];
                 ++n_out;
             }
+        }
+        if (mf.xmat) {
+            // contact_extras: the survivors' mixed material and rolling / spinning impulses move to their new slots (read
+            // first: the source may be this very array), created points get the materials mixed now and zero impulses
+            // (assign_material_properties, collision_util.cpp:309-315; material_mixing.hpp:20-34)
+            float4 xm[kMaxPts], xi[kMaxPts];
+#pragma unroll
+            for (int i = 0; i < kMaxPts; ++i) {
+                if (i < n_old && !((dead >> i) & 1u)) { const size_t s = (size_t)i * src.cap + sidx; xm[i] = src.xmat[s]; xi[i] = src.ximp[s]; }
+                else { xm[i] = xi[i] = make_float4(0, 0, 0, 0); }
+            }
+            const float4 ma = b.mat2[ia], mb = b.mat2[ib];
+            float stiff = kLarge, damp = kLarge;
+            if (ma.z < kLarge || mb.z < kLarge) { stiff = 1.0f / (1.0f / ma.z + 1.0f / mb.z); damp = 1.0f / (1.0f / ma.w + 1.0f / mb.w); }
+            const float4 fresh = make_float4(fmaxf(ma.y, mb.y), fmaxf(ma.x, mb.x), stiff, damp);
+            int slot = 0;
+#pragma unroll
+            for (int i = kMaxPts - 1; i >= 0; --i) if ((create >> i) & 1u) { const size_t d = (size_t)slot * mf.cap + m; mf.xmat[d] = fresh; mf.ximp[d] = make_float4(0, 0, 0, 0); ++slot; }
+#pragma unroll
+            for (int i = 0; i < kMaxPts; ++i) if (i < n_old && !((dead >> i) & 1u)) { const size_t d = (size_t)slot * mf.cap + m; mf.xmat[d] = xm[i]; mf.ximp[d] = xi[i]; ++slot; }
         }
         uint32_t colour = info >> 8;
         if (n_out == 0) colour = kNoColour;   // inactive pairs hold no solver colour

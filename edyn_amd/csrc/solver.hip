@@ -458,7 +458,7 @@ DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, fl
     rw[base + cap] = to4(JaA, rhs);
     rw[base + 2 * cap] = to4(JaB, imp);
     rw[base + 3 * cap] = to4(mul(A.inv_I, JaA), mu);
-    rw[base + 4 * cap] = to4(mul(B.inv_I, JaB), 0.0f);
+    rw[base + 4 * cap] = to4(mul(B.inv_I, JaB), kLarge);   // .w of a normal row: its upper limit (soft contacts lower it)
 }
 __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt,
                                 const uint32_t *__restrict__ keys_sorted, bool push) {
@@ -486,7 +486,18 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
         const float effn = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
         const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
-        const float error = distance > 0 ? distance / dt : 0.0f;
+        float error = distance > 0 ? distance / dt : 0.0f;
+        float upper = kLarge;
+        float4 xm = make_float4(0, 0, kLarge, kLarge), xi = make_float4(0, 0, 0, 0);
+        if (mf.xmat) { xm = mf.xmat[s]; xi = mf.ximp[s]; }
+        if (distance < 0 && xm.z < kLarge) {   // soft contact (contact_extras_constraint.cpp:16-35): force-limited normal row
+            const f3 vA = A.v + cross(A.w, rA), vB = B.v + cross(B.w, rB);
+            const float normal_relvel = dot(vA - vB, n);
+            const float spring_force = -distance * xm.z / (float)np;
+            const float damper_force = -normal_relvel * xm.w / (float)np;
+            upper = fmaxf(spring_force + damper_force, 0.0f) * dt;
+            error = -kLarge;
+        }
         const float rhsn = -(error * 0.2f + relvel * (1 + 0.0f));   // erp 0.2, zero restitution (restitution solver path)
         // friction rows
         f3 t0, t1;
@@ -499,6 +510,22 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
         const size_t base = (size_t)(k * kRowsPerPoint) * kRowF * rcap + p, rstride = (size_t)kRowF * rcap;
         store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
+        if (upper != kLarge) rows.rw[base + 4 * (size_t)rcap].w = upper;
+        if (rows.rwx && mf.xmat) {   // rolling pair and spinning row (:37-78); roll_direction components do not exist on this path
+            const size_t xb = (size_t)(k * kXPoint) * rcap + p;
+            rows.rwx[xb + 9 * (size_t)rcap] = make_float4(xm.x, xm.y, 0, 0);
+            auto axial = [&](int r, f3 ax, float imp, bool guarded) {
+                const f3 ia = mul(A.inv_I, ax), ib = mul(B.inv_I, -ax);
+                const float ssum = dot(ia, ax) + dot(ib, -ax);
+                const float eff = guarded ? (ssum > kEps ? 1.0f / ssum : 0.0f) : 1.0f / ssum;
+                const float rhs = guarded ? -rel_speed(mk3(0, 0, 0), ax, mk3(0, 0, 0), -ax, A.v, A.w, B.v, B.w) : -(dot(ax, A.w) + dot(-ax, B.w));
+                rows.rwx[xb + (size_t)(3 * r) * rcap] = to4(ax, eff);
+                rows.rwx[xb + (size_t)(3 * r + 1) * rcap] = to4(ia, rhs);
+                rows.rwx[xb + (size_t)(3 * r + 2) * rcap] = to4(ib, imp);
+            };
+            if (xm.x > 0) { axial(0, t0, xi.x, true); axial(1, t1, xi.y, true); }
+            if (xm.y > 0) axial(2, n, xi.z, false);
+        }
         store_row(rows.rw, base + rstride, rcap, t0, K1, K3, eff0, rhs0, im.y, 0.0f, A, B);
         store_row(rows.rw, base + 2 * rstride, rcap, t1, L1, L3, eff1, rhs1, im.z, 0.0f, A, B);
     }
@@ -570,8 +597,9 @@ DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
             float dimp = (r.f[1].w - drel) * r.f[0].w;
             float cur = r.f[2].w;
             float imp = cur + dimp;
+            const float upper = r.f[4].w;   // large_scalar, or a soft contact's force limit
             if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
-            else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
+            else if (imp > upper) { dimp = upper - cur; cur = upper; }
             else cur = imp;
             r.f[2].w = cur;
             row_apply(d, r, dimp);
@@ -662,9 +690,65 @@ DI void rows_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) 
         row_apply(d, rb, di1);
     }
 }
+// contact_extras rows of one manifold after its normal and friction rows: the rolling pairs of all points, then the
+// spinning rows (island_solver.cpp:76-111 keeps the row kinds in this order). Rolling is solve_friction with the roll
+// coefficient (constraint_row_friction.cpp:11-66), spinning is constraint_row_spin_friction.cpp:5-36; both angular only.
+struct XRow { float4 f[kXRowF]; };
+DI void xrow_apply(Delta &d, const XRow &r, float imp) { d.dwA += from4(r.f[1]) * imp; d.dwB += from4(r.f[2]) * imp; }
+DI float xrow_relspeed(const Delta &d, const XRow &r) { const f3 ax = from4(r.f[0]); return dot(ax, d.dwA) + dot(-ax, d.dwB); }
+template <bool WARM, int NP>
+DI void extras_solve(Delta &d, const RowReg (&R)[NP][kRowsPerPoint], uint32_t np, float4 *__restrict__ rwx, uint32_t rcap, uint32_t p) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
+        const size_t xb = (size_t)(k * kXPoint) * rcap + p;
+        const float mu = rwx[xb + 9 * (size_t)rcap].x;
+        if (!(mu > 0)) continue;
+        XRow ra, rb;
+#pragma unroll
+        for (int f = 0; f < kXRowF; ++f) { ra.f[f] = rwx[xb + (size_t)f * rcap]; rb.f[f] = rwx[xb + (size_t)(3 + f) * rcap]; }
+        if (WARM) { xrow_apply(d, ra, ra.f[2].w); xrow_apply(d, rb, rb.f[2].w); continue; }
+        float di0 = (ra.f[1].w - xrow_relspeed(d, ra)) * ra.f[0].w;
+        float i0 = ra.f[2].w + di0;
+        float di1 = (rb.f[1].w - xrow_relspeed(d, rb)) * rb.f[0].w;
+        float i1 = rb.f[2].w + di1;
+        const float len2 = i0 * i0 + i1 * i1;
+        const float max_len = mu * R[k][0].f[2].w;   // roll coefficient * current normal impulse
+        if (len2 > square(max_len)) {
+            const float len = sqrtf(len2);
+            if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+            else { i0 = 0; i1 = 0; }
+            di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
+        }
+        rwx[xb + 2 * (size_t)rcap].w = i0; rwx[xb + 5 * (size_t)rcap].w = i1;
+        xrow_apply(d, ra, di0);
+        xrow_apply(d, rb, di1);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if ((uint32_t)k >= np) continue;
+        const size_t xb = (size_t)(k * kXPoint) * rcap + p;
+        const float mu = rwx[xb + 9 * (size_t)rcap].y;
+        if (!(mu > 0)) continue;
+        XRow r;
+#pragma unroll
+        for (int f = 0; f < kXRowF; ++f) r.f[f] = rwx[xb + (size_t)(6 + f) * rcap];
+        if (WARM) { xrow_apply(d, r, r.f[2].w); continue; }
+        const float max_len = mu * R[k][0].f[2].w;
+        float dimp = (r.f[1].w - xrow_relspeed(d, r)) * r.f[0].w;
+        const float cur = r.f[2].w, imp = cur + dimp, lo = -max_len, hi = max_len;
+        float out;
+        if (imp < lo) { dimp = lo - cur; out = lo; }
+        else if (imp > hi) { dimp = hi - cur; out = hi; }
+        else out = imp;
+        rwx[xb + 8 * (size_t)rcap].w = out;
+        xrow_apply(d, r, dimp);
+    }
+}
 template <bool WARM, int NP, bool PUSH>
 DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                         float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
+                         float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im,
+                         float4 *__restrict__ rwx = nullptr) {
     uint32_t ia, ib;   // PUSH: destination slots; else body indices
     if (PUSH) { ia = rbA[2 * (size_t)p] & kSlotMask; ib = rbA[2 * (size_t)p + 1] & kSlotMask; }
     else { ia = rbA[p]; ib = rbB[p]; }
@@ -681,6 +765,7 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
         else { d.imA = va.w; d.imB = vb.w; }
     }
     rows_solve<WARM, NP>(d, R, np);
+    if (rwx) extras_solve<WARM, NP>(d, R, np, rwx, rcap, p);
     if (!WARM) rows_store_impulses<NP>(R, rw, rcap, p, np);
     const float wA = PUSH ? 0.0f : d.imA, wB = PUSH ? 0.0f : d.imB;
     const size_t oa0 = PUSH ? dslot_at(ia, 0) : 2 * (size_t)ia, oa1 = PUSH ? dslot_at(ia, 1) : 2 * (size_t)ia + 1;
@@ -690,18 +775,19 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
 }
 template <bool WARM, bool PUSH>
 DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                           float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
-    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im);
-    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im);
+                           float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im,
+                           float4 *__restrict__ rwx = nullptr) {
+    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
+    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
 }
 struct Split { uint32_t e4, e3, e2; };   // ends of the 4-, 3-, 2-point groups of a colour's sorted range
 DI uint32_t np_of(uint32_t p, const Split &sp) { return p < sp.e4 ? 4u : (p < sp.e3 ? 3u : (p < sp.e2 ? 2u : 1u)); }
 template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(64)
 k_contact_solve(uint32_t start, uint32_t end, Split sp, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
-                float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im) {
+                float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im, float4 *__restrict__ rwx) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, im);
+    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, im, rwx);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
@@ -709,10 +795,10 @@ struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxCo
 constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
 template <bool WARM, bool PUSH>
 __global__ void __launch_bounds__(256)
-k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, const float *im) {
+k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, const float *im, float4 *rwx) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw, im);
+            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw, im, rwx);
         __threadfence_block();
         __syncthreads();
     }
@@ -887,6 +973,14 @@ DI void store_impulses_of(uint32_t p, const Rows &rows, uint32_t rcap, const Man
         im.y = rows.rw[(size_t)((k * kRowsPerPoint + 1) * kRowF + 2) * rcap + p].w;
         im.z = rows.rw[(size_t)((k * kRowsPerPoint + 2) * kRowF + 2) * rcap + p].w;
         mf.imp[d] = im;
+        if (rows.rwx && mf.ximp) {   // contact_extras_constraint::store_applied_impulses (contact_extras_constraint.cpp:88-107)
+            const size_t xb = (size_t)(k * kXPoint) * rcap + p;
+            const float4 mu = rows.rwx[xb + 9 * (size_t)rcap];
+            float4 xi = mf.ximp[d];
+            if (mu.x > 0) { xi.x = rows.rwx[xb + 2 * (size_t)rcap].w; xi.y = rows.rwx[xb + 5 * (size_t)rcap].w; }
+            if (mu.y > 0) xi.z = rows.rwx[xb + 8 * (size_t)rcap].w;
+            mf.ximp[d] = xi;
+        }
     }
 }
 __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf) {
@@ -1349,9 +1443,12 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     // stores, so the arithmetic does not wait for it (a finished island merely computes into registers it drops)
     const uint32_t done = isl_done[label];
     float max_err = 0;
+    bool soft[NP];   // soft contacts take no position correction (contact_extras_constraint.cpp:81-86)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) soft[k] = mf.xmat != nullptr && mf.xmat[(size_t)k * mf.cap + m].z < kLarge;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        if ((uint32_t)k < np && in_range) {   // uniform within a lane pair
+        if ((uint32_t)k < np && in_range && !soft[k]) {   // uniform within a lane pair
             const int attach = __float_as_int(n4[k].w);
             const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
             const f3 pOw = xchg1(pXw);
@@ -1387,7 +1484,7 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const size_t s = (size_t)k * mf.cap + m;
-            if ((uint32_t)k < np) {
+            if ((uint32_t)k < np && !soft[k]) {
                 if (!sideB) mf.pA[s] = piv[k];
                 else mf.nrm[s] = n4[k];
             }
@@ -1856,7 +1953,8 @@ int solve(edynhip_ctx *c) {
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
-    const bool push = j.n == 0 && na > 0;   // without joints every delta hand-off stays inside the contact sweeps
+    // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
+    const bool push = j.n == 0 && na > 0 && !c->extras;
     if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
     if (push) {
         hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
@@ -1892,11 +1990,11 @@ int solve(edynhip_ctx *c) {
             const Split sp{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
             const dim3 g(blocks(e - a, 64)), bl(64);
             if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
-                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
+                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
             } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
-                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
+                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
+                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
             }
             ++launches;
         }
@@ -1904,11 +2002,11 @@ int solve(edynhip_ctx *c) {
             const Rows &r = c->rows;
             const dim3 g(1), bl(kTailThreads);
             if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im);
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
             } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr);
+                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
+                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
             }
             ++launches;
         }

@@ -341,6 +341,23 @@ class World:
         self._flush_defs()
         self._check(self._L.edynhip_remove_collision_exclusion(self._h, int(a), int(b)))
 
+    def set_material_extras(self, first, spin=None, roll=None, stiffness=None, damping=None):
+        """material::{spin_friction, roll_friction, stiffness, damping} of bodies [first, first + n) - contact_extras_constraint
+        (rolling / spinning friction, soft contacts). Arrays of equal length; None = the reference's default."""
+        self._flush_defs()
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (spin, roll, stiffness, damping)]
+        n = max(len(a) for a in arrs if a is not None)
+        self._check(self._L.edynhip_set_material_extras(self._h, int(first), n, *[None if a is None else _ptr(a) for a in arrs]))
+
+    def get_point_extras(self):
+        """[num_manifolds, 4, 7]: rolling impulse 0/1, spin impulse, roll mu, spin mu, stiffness, damping (get_manifolds order)."""
+        m = C.c_uint32(0)
+        self._check(self._L.edynhip_num_manifolds(self._h, C.byref(m)))
+        out = np.zeros((m.value, 4, 7), np.float32)
+        if m.value:
+            self._check(self._L.edynhip_get_point_extras(self._h, _ptr(out), m.value, C.byref(m)))
+        return out
+
     def refresh_derived(self):
         """update_aabbs + update_inertias from the current transforms (after set_state)."""
         self._check(self._L.edynhip_refresh_derived(self._h))

@@ -235,6 +235,18 @@ int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint3
  * bump_stop, spring, torque; point: applied[3], friction - and the tracked hinge angle (hinge_constraint.hpp:62-71). */
 int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses10);
 
+/* contact_extras materials: material::{spin_friction, roll_friction, stiffness, damping} of bodies [first, first + n)
+ * (comp/material.hpp:15-22; any array may be NULL = the default 0, 0, large_scalar, large_scalar). Contact points created
+ * from then on mix them (material_mixing.hpp:20-34) and, where a mixed value is not the default, get the rolling-friction
+ * pair, the spinning-friction row and / or the force-limited ("soft") normal row of contact_extras_constraint
+ * (contact_extras_constraint.cpp:12-110, constraint_row_spin_friction.cpp:5-36); soft contacts take no position
+ * correction. A world with such materials solves on the per-colour schedule. roll_direction components are not modelled.
+ * edynhip_get_point_extras: out[4 * i + k][7] = rolling impulse[2], spin impulse, mixed roll / spin coefficient, stiffness,
+ * damping of point k of manifold i in edynhip_get_manifolds order. */
+int edynhip_set_material_extras(edynhip_ctx *ctx, uint32_t first, uint32_t n, const float *spin_friction, const float *roll_friction,
+                                const float *stiffness, const float *damping);
+int edynhip_get_point_extras(edynhip_ctx *ctx, float *out7, uint32_t capacity_manifolds, uint32_t *n);
+
 /* Contact events (EDYNHIP_FLAG_CONTACT_EVENTS): what an application observes in the reference through
  * registry.on_construct / on_destroy<contact_manifold> (make_contact_manifold, constraint_util.cpp:60-102;
  * broadphase::destroy_separated_manifolds, broadphase.cpp:99-134) and <contact_point> (create_contact_point,

@@ -971,3 +971,33 @@ def test_double_buffered_snapshots_deliver_the_previous_step():
         assert np.array_equal(p, bp) and np.array_equal(q, bq) and np.array_equal(v, bv) and np.array_equal(w, bw), i
         b.step_simulation(1)
     assert_state_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["roll_spin", "soft", "both"])
+def test_contact_extras_bit_exact(kind):
+    """contact_extras_constraint on the device (rolling / spinning friction rows, soft normal rows, material mixing, no
+    position correction for soft contacts) against the oracle in the same colour order; the oracle's version is pinned bit
+    for bit to the real engine in tests/test_reference_engine.py::test_contact_extras_match_the_real_engine."""
+    from test_reference_engine import _extras_scene
+    sc, ex = _extras_scene(kind)
+    n = len(sc["kind"])
+    g = gpu_world(sc); o = oracle_world(sc)
+    spin = np.zeros(n, np.float32); roll = np.zeros(n, np.float32)
+    stiff = np.full(n, 1e18, np.float32); damp = np.full(n, 1e18, np.float32)
+    for i, kw in ex.items():
+        spin[i] = kw.get("spin", 0.0); roll[i] = kw.get("roll", 0.0); stiff[i] = kw.get("stiffness", 1e18); damp[i] = kw.get("damping", 1e18)
+        if kw:
+            o.set_material_extras(i, **kw)
+    g.set_material_extras(0, spin, roll, stiff, damp)
+    seen = 0
+    for s in range(1, 241):
+        g.step_simulation(1); o.step(1)
+        if s % 20 == 0 or s < 4:
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            gx, ox = g.get_point_extras(), o.get_point_extras()
+            assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32)), s
+            seen += int((gx[..., :3] != 0).sum())
+    assert_state_equal(g, o)
+    if kind != "soft":
+        assert seen > 0
