@@ -58,7 +58,10 @@ struct mass { scalar s; };
 struct mass_inv { scalar s; };
 struct inertia : matrix3x3 {};
 struct gravity : vector3 {};
-struct material { scalar restitution{0}, friction{scalar(0.5)}; };   // comp/material.hpp:15-22 (hot-path fields)
+inline constexpr scalar large_scalar = scalar(1e18);   // math/constants.hpp:17
+struct material {   // comp/material.hpp:15-22; the last four select contact_extras_constraint (rolling / spinning friction, soft contacts)
+    scalar restitution{0}, friction{scalar(0.5)}, spin_friction{0}, roll_friction{0}, stiffness{large_scalar}, damping{large_scalar};
+};
 struct AABB { vector3 min, max; };
 struct dynamic_tag {};
 struct kinematic_tag {};
@@ -230,6 +233,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     std::vector<int32_t> kind(n), stype(n);
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
     std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
+    std::vector<float> xspin(n, 0.f), xroll(n, 0.f), xstiff(n, float(large_scalar)), xdamp(n, float(large_scalar));
+    bool any_extras = false;
     std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
     std::vector<uint32_t> dead;
     for (uint32_t i = 0; i < n; ++i) {
@@ -253,7 +258,11 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
         else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
         else stype[i] = EDYNHIP_SHAPE_NONE;
-        if (auto *mt = registry.try_get<material>(e)) { fr[i] = mt->friction; re[i] = mt->restitution; }
+        if (auto *mt = registry.try_get<material>(e)) {
+            fr[i] = mt->friction; re[i] = mt->restitution;
+            xspin[i] = mt->spin_friction; xroll[i] = mt->roll_friction; xstiff[i] = mt->stiffness; xdamp[i] = mt->damping;
+            any_extras = any_extras || mt->spin_friction > 0 || mt->roll_friction > 0 || mt->stiffness < large_scalar || mt->damping < large_scalar;
+        }
         if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
         if (registry.all_of<sleeping_disabled_tag>(e)) nosleep[i] = 1;
         if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
@@ -262,6 +271,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
                      fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data()};
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
+    if (any_extras) check(s, edynhip_set_material_extras(s.ctx, first, n, xspin.data(), xroll.data(), xstiff.data(), xdamp.data()));
     if (!dead.empty()) check(s, edynhip_remove_bodies(s.ctx, (uint32_t)dead.size(), dead.data()));
     s.uploaded_bodies = total;
     if (regrown && !carried.empty()) check(s, edynhip_set_manifolds(s.ctx, carried.data(), (uint32_t)carried.size()));

@@ -88,6 +88,36 @@ int main() {
         }
     }
     REQUIRE(count<edyn::contact_manifold>(async_reg) > 0);
+    // ---- contact_extras through the shim: material::roll_friction stops a rolling sphere, the default lets it roll on
+    entt::registry roll_reg;
+    edyn::attach(roll_reg, edyn::init_config{});
+    {
+        auto floor_def = edyn::rigidbody_def{};
+        floor_def.kind = edyn::rigidbody_kind::rb_static;
+        floor_def.shape = edyn::plane_shape{{0, 1, 0}, 0};
+        floor_def.material = edyn::material{};
+        floor_def.material->friction = 1;
+        edyn::make_rigidbody(roll_reg, floor_def);
+    }
+    entt::entity balls[2];
+    for (int i = 0; i < 2; ++i) {
+        auto def = edyn::rigidbody_def{};
+        def.mass = 1;
+        def.shape = edyn::sphere_shape{0.5f};
+        def.position = {0, 0.5f, 3.0f * i};
+        def.linvel = {2, 0, 0};
+        def.angvel = {0, 0, -4};   // rolling without slipping: v = w x r
+        def.sleeping_disabled = true;
+        def.material = edyn::material{};
+        def.material->friction = 1;
+        if (i == 1) def.material->roll_friction = 0.2f;
+        balls[i] = edyn::make_rigidbody(roll_reg, def);
+    }
+    double tr = 0;
+    for (int i = 0; i < 180; ++i) { tr += 1.0 / 60; edyn::update(roll_reg, tr); }
+    const float v_free = roll_reg.get<edyn::linvel>(balls[0]).x, v_braked = roll_reg.get<edyn::linvel>(balls[1]).x;
+    REQUIRE(v_free > 1.5f);            // nothing slows a sphere rolling on a plane
+    REQUIRE(std::fabs(v_braked) < 0.2f);   // rolling friction brought this one to rest
     std::printf("contacts OK: %zu manifolds, %zu points mirrored; asynchronous mode lags one update, bit-identical\n", manifolds.size(), device_points);
     return 0;
 }
