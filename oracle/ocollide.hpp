@@ -287,6 +287,201 @@ inline void collide_sphere_box(float radius, vec3 hB, const coll_ctx &ctx, coll_
     result.add_point({pivotA, pivotB, normal, center_distance - radius, attach});
 }
 
+// ---- capsule pairs
+inline float closest_point_segment(vec3 q0, vec3 q1, vec3 p, float &t, vec3 &q) {   // geom.cpp:12-22
+    const vec3 v = q1 - q0, w = p - q0;
+    const float a = dot(w, v), b = dot(v, v);
+    t = clamp_unit(a / b);
+    q = q0 + v * t;
+    return length_sqr(p - q);
+}
+inline float closest_point_line(vec3 q0, vec3 dir, vec3 p, float &t, vec3 &r) {   // geom.cpp:35-44
+    const vec3 w = p - q0;
+    const float a = dot(w, dir), b = dot(dir, dir);
+    t = a / b;
+    r = q0 + dir * t;
+    return length_sqr(p - r);
+}
+// collide_capsule_plane.cpp:6-38
+inline void collide_capsule_plane(const shape &shA, vec3 pn, float pc, const coll_ctx &ctx, coll_result &result) {
+    const vec3 center = pn * pc;
+    vec3 cv[2];
+    capsule_vertices(shA, ctx.posA, ctx.ornA, cv);
+    const float proj[2] = {dot(cv[0] - center, pn), dot(cv[1] - center, pn)};
+    for (int i = 0; i < 2; ++i) {
+        const float distance = proj[i] - shA.radius;
+        if (distance > ctx.threshold) continue;
+        const vec3 vertex = cv[i];
+        const vec3 pivotA_world = vertex - pn * shA.radius;
+        const vec3 pivotA = to_object(pivotA_world, ctx.posA, ctx.ornA);
+        const vec3 pivotB = project_plane(vertex, center, pn);
+        result.add_point({pivotA, pivotB, pn, distance, NA_ON_B});
+    }
+}
+// collide_capsule_sphere.cpp:10-51
+inline void collide_capsule_sphere(const shape &shA, float rB, const coll_ctx &ctx, coll_result &result) {
+    vec3 cv[2];
+    capsule_vertices(shA, ctx.posA, ctx.ornA, cv);
+    vec3 closest; float t;
+    const float dist_sqr = closest_point_segment(cv[0], cv[1], ctx.posB, t, closest);
+    const float min_dist = shA.radius + rB + ctx.threshold;
+    if (dist_sqr > min_dist * min_dist) return;
+    vec3 normal = closest - ctx.posB;
+    const float nl2 = length_sqr(normal);
+    float distance;
+    if (nl2 > kEps) {
+        const float nl = std::sqrt(nl2);
+        normal /= nl;
+        distance = nl - shA.radius - rB;
+    } else {
+        normal = rotate(ctx.ornA, vec3{0, 0, 1});   // quaternion_z
+        distance = -(shA.radius + rB);
+    }
+    const vec3 normalB = rotate(conjugate(ctx.ornB), normal);
+    const vec3 pivotA_world = closest - normal * shA.radius;
+    result.add_point({to_object(pivotA_world, ctx.posA, ctx.ornA), normalB * rB, normal, distance, NA_NONE});
+}
+// collide_capsule_capsule.cpp:7-80
+inline void collide_capsule_capsule(const shape &shA, const shape &shB, const coll_ctx &ctx, coll_result &result) {
+    vec3 vA[2], vB[2];
+    capsule_vertices(shA, ctx.posA, ctx.ornA, vA);
+    capsule_vertices(shB, ctx.posB, ctx.ornB, vB);
+    float s[2], t[2];
+    vec3 cA[2], cB[2];
+    size_t num_points = 0;
+    const float dist_sqr = closest_point_segment_segment(vA[0], vA[1], vB[0], vB[1], s[0], t[0], cA[0], cB[0], &num_points,
+                                                         &s[1], &t[1], &cA[1], &cB[1]);
+    const float min_dist = shA.radius + shB.radius + ctx.threshold;
+    if (dist_sqr > min_dist * min_dist) return;
+    vec3 normal;
+    float distance;
+    if (dist_sqr > kEps) {
+        const float dist = std::sqrt(dist_sqr);
+        normal = (cA[0] - cB[0]) / dist;
+        distance = dist - shA.radius - shB.radius;
+    } else {
+        const vec3 axisA = vA[1] - vA[0], axisB = vB[1] - vB[0];
+        normal = cross(axisA, axisB);
+        if (dot(ctx.posA - ctx.posB, normal) < 0) normal *= -1.0f;
+        if (!try_normalize(normal)) normal = vec3{0, 1, 0};
+        distance = -(shA.radius + shB.radius);
+    }
+    for (size_t i = 0; i < num_points; ++i) {
+        const vec3 pA = cA[i] - normal * shA.radius, pB = cB[i] + normal * shB.radius;
+        result.add_point({to_object(pA, ctx.posA, ctx.ornA), to_object(pB, ctx.posB, ctx.ornB), normal, distance, NA_NONE});
+    }
+}
+// collide_capsule_box.cpp:14-213
+inline void collide_capsule_box(const shape &shA, vec3 hB, const coll_ctx &ctx, coll_result &result) {
+    const vec3 posA{0, 0, 0};
+    const quat ornA = ctx.ornA, ornB = ctx.ornB;
+    const vec3 posB = ctx.posB - ctx.posA;
+    vec3 cv[2];
+    capsule_vertices(shA, posA, ornA, cv);
+    const vec3 box_axes[3] = {rotate(ornB, vec3{1, 0, 0}), rotate(ornB, vec3{0, 1, 0}), rotate(ornB, vec3{0, 0, 1})};
+    float distance = -kScalarMax, projection_box = -kScalarMax;
+    vec3 sep{0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        vec3 dir = box_axes[i];
+        if (dot(posA - posB, dir) < 0) dir = -dir;
+        const float projA = -capsule_support_projection(cv, shA.radius, -dir);
+        const float projB = dot(posB, dir) + hB[i];
+        const float dist = projA - projB;
+        if (dist > distance) { distance = dist; projection_box = projB; sep = dir; }
+    }
+    for (int i = 0; i < 12; ++i) {
+        vec3 ev[2];
+        box_edge_world(hB, i, posB, ornB, ev);
+        float s, t;
+        vec3 cA, cB;
+        closest_point_segment_segment(ev[0], ev[1], cv[0], cv[1], s, t, cA, cB, nullptr, nullptr, nullptr, nullptr, nullptr);
+        vec3 dir = cA - cB;
+        if (!try_normalize(dir)) continue;
+        if (dot(posA - posB, dir) < 0) dir *= -1.0f;
+        const float projA = -capsule_support_projection(cv, shA.radius, -dir);
+        const float projB = box_support_projection(hB, posB, ornB, dir);
+        const float dist = projA - projB;
+        if (dist > distance) { distance = dist; projection_box = projB; sep = dir; }
+    }
+    if (distance > ctx.threshold) return;
+    const float proj[2] = {dot(cv[0], sep), dot(cv[1], sep)};
+    const bool is_capsule_edge = std::fabs(proj[0] - proj[1]) < kSupportFeatureTolerance;
+    const vec3 contact_origin_box = sep * projection_box;
+    int featB, idxB;
+    float fdB;
+    box_support_feature(hB, posB, ornB, contact_origin_box, sep, featB, idxB, fdB, kSupportFeatureTolerance);
+    coll_point point;
+    point.normal = sep; point.distance = distance;
+    point.pivotA = {0, 0, 0}; point.pivotB = {0, 0, 0};
+    if (featB == BF_FACE) {
+        vec3 fv[4];
+        box_face_world(hB, idxB, posB, ornB, fv);
+        point.attachment = NA_ON_B;
+        if (is_capsule_edge) {
+            for (int k = 0; k < 2; ++k) {
+                const vec3 pointA = cv[k];
+                if (point_in_quad_prism(fv, sep, pointA)) {
+                    point.pivotA = to_object(pointA - sep * shA.radius, posA, ornA);
+                    point.pivotB = to_object(project_plane(pointA, contact_origin_box, sep), posB, ornB);
+                    result.add_point(point);
+                }
+            }
+            if (result.num_points == 2) return;
+            const vec3 fc = box_face_center(hB, idxB, posB, ornB);
+            const mat3 fb = box_face_basis(idxB, ornB);
+            const vec2 he = box_face_half_extents(hB, idxB);
+            const vec3 q0 = to_object(cv[0], fc, fb), q1 = to_object(cv[1], fc, fb);
+            float ss[2];
+            const size_t n = intersect_line_aabb({q0.x, q0.z}, {q1.x, q1.z}, -he, he, ss[0], ss[1]);
+            for (size_t i = 0; i < n; ++i) {
+                if (ss[i] < 0 || ss[i] > 1) continue;
+                const vec3 edge_pivot = lerp(cv[0], cv[1], ss[i]);
+                const vec3 face_pivot = project_plane(edge_pivot, fc, sep);
+                point.pivotA = to_object(edge_pivot - sep * shA.radius, posA, ornA);
+                point.pivotB = to_object(face_pivot, posB, ornB);
+                result.add_point(point);
+            }
+        } else {
+            const vec3 cvx = proj[0] < proj[1] ? cv[0] : cv[1];
+            const vec3 pA = cvx - sep * shA.radius;
+            const vec3 pB = project_plane(pA, contact_origin_box, sep);
+            point.pivotA = to_object(pA, posA, ornA);
+            point.pivotB = to_object(pB, posB, ornB);
+            result.add_point(point);
+        }
+    } else if (featB == BF_EDGE) {
+        vec3 ev[2];
+        box_edge_world(hB, idxB, posB, ornB, ev);
+        point.attachment = NA_NONE;
+        if (is_capsule_edge) {
+            float s[2], t[2];
+            vec3 cA[2], cB[2];
+            size_t n = 0;
+            closest_point_segment_segment(cv[0], cv[1], ev[0], ev[1], s[0], t[0], cA[0], cB[0], &n, &s[1], &t[1], &cA[1], &cB[1]);
+            for (size_t i = 0; i < n; ++i) {
+                point.pivotA = to_object(cA[i] - sep * shA.radius, posA, ornA);
+                point.pivotB = to_object(cB[i], posB, ornB);
+                result.add_point(point);
+            }
+        } else {
+            const vec3 cvx = proj[0] < proj[1] ? cv[0] : cv[1];
+            const vec3 edge_dir = ev[1] - ev[0];
+            vec3 pB; float t;
+            closest_point_line(ev[0], edge_dir, cvx, t, pB);
+            point.pivotB = to_object(pB, posB, ornB);
+            point.pivotA = to_object(cvx - sep * shA.radius, posA, ornA);
+            result.add_point(point);
+        }
+    } else {
+        point.pivotB = box_vertex(hB, idxB);
+        const vec3 pB = to_world(point.pivotB, posB, ornB);
+        const vec3 pA = pB + sep * distance;
+        point.pivotA = to_object(pA, posA, ornA);
+        point.attachment = NA_NONE;
+        result.add_point(point);
+    }
+}
+
 // Dispatch on the shape pair; mirrored overloads go through swap_collide (collide.hpp:369-374).
 inline void collide(const shape &shA, const shape &shB, const coll_ctx &ctx, coll_result &r) {
     const int a = shA.type, b = shB.type;
@@ -301,7 +496,13 @@ inline void collide(const shape &shA, const shape &shB, const coll_ctx &ctx, col
     } else if (a == SHAPE_SPHERE && b == SHAPE_BOX) collide_sphere_box(shA.radius, shB.half_extents, ctx, r);
     else if (a == SHAPE_BOX && b == SHAPE_SPHERE) {
         collide_sphere_box(shB.radius, shA.half_extents, ctx.swapped(), r); r.swap();
-    }
+    } else if (a == SHAPE_CAPSULE && b == SHAPE_PLANE) collide_capsule_plane(shA, shB.normal, shB.constant, ctx, r);
+    else if (a == SHAPE_PLANE && b == SHAPE_CAPSULE) { collide_capsule_plane(shB, shA.normal, shA.constant, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CAPSULE && b == SHAPE_SPHERE) collide_capsule_sphere(shA, shB.radius, ctx, r);
+    else if (a == SHAPE_SPHERE && b == SHAPE_CAPSULE) { collide_capsule_sphere(shB, shA.radius, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CAPSULE && b == SHAPE_CAPSULE) collide_capsule_capsule(shA, shB, ctx, r);
+    else if (a == SHAPE_CAPSULE && b == SHAPE_BOX) collide_capsule_box(shA, shB.half_extents, ctx, r);
+    else if (a == SHAPE_BOX && b == SHAPE_CAPSULE) { collide_capsule_box(shB, shA.half_extents, ctx.swapped(), r); r.swap(); }
     // plane-plane: both static, never paired (only procedural bodies query the broadphase).
 }
 

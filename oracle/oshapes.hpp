@@ -9,7 +9,7 @@
 
 namespace orc {
 
-enum shape_type : int { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3 };
+enum shape_type : int { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4 };
 enum box_feature : int { BF_VERTEX = 0, BF_EDGE = 1, BF_FACE = 2 };
 
 struct shape {
@@ -18,7 +18,18 @@ struct shape {
     float radius = 0;             // sphere
     vec3 normal{0, 1, 0};         // plane
     float constant = 0;           // plane
+    float half_length = 0;        // capsule (radius above); shapes/capsule_shape.hpp:17-30
+    int axis = 0;                 // capsule: coordinate_axis x, y, z
 };
+inline vec3 coordinate_axis_vector(int axis) { return axis == 0 ? vec3{1, 0, 0} : (axis == 1 ? vec3{0, 1, 0} : vec3{0, 0, 1}); }   // math/coordinate_axis.hpp:23-44
+inline void capsule_vertices(const shape &s, vec3 pos, quat orn, vec3 out[2]) {   // capsule_shape::get_vertices
+    const vec3 dir = rotate(orn, coordinate_axis_vector(s.axis));
+    out[0] = pos + dir * s.half_length;
+    out[1] = pos - dir * s.half_length;
+}
+inline float capsule_support_projection(const vec3 v[2], float radius, vec3 dir) {   // shape_util.cpp:297-305
+    return std::max(dot(v[0], dir), dot(v[1], dir)) + radius;
+}
 
 static const int kBoxEdgeIndices[24] = {0, 1, 1, 2, 2, 3, 3, 0, 4, 5, 5, 6, 6, 7, 7, 4, 0, 4, 1, 7, 2, 6, 3, 5};
 static const int kBoxFaceIndices[24] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 3, 5, 4, 1, 7, 6, 2, 0, 4, 7, 1, 3, 2, 6, 5};
@@ -149,6 +160,12 @@ inline aabb shape_aabb(const shape &s, vec3 pos, quat orn) {
     case SHAPE_BOX: return box_aabb(s.half_extents, pos, orn);
     case SHAPE_SPHERE: return sphere_aabb(s.radius, pos);
     case SHAPE_PLANE: return plane_aabb(s.normal, s.constant);
+    case SHAPE_CAPSULE: {   // aabb_util.cpp:81-88
+        const vec3 v = rotate(orn, coordinate_axis_vector(s.axis)) * s.half_length;
+        const vec3 p0 = pos - v, p1 = pos + v, off{s.radius, s.radius, s.radius};
+        return {vec3{std::min(p0.x, p1.x), std::min(p0.y, p1.y), std::min(p0.z, p1.z)} - off,
+                vec3{std::max(p0.x, p1.x), std::max(p0.y, p1.y), std::max(p0.z, p1.z)} + off};
+    }
     default: return {pos, pos};
     }
 }
@@ -163,6 +180,24 @@ inline mat3 moment_of_inertia(const shape &s, float mass) {
     if (s.type == SHAPE_SPHERE) {
         float i = 0.4f * mass * s.radius * s.radius;
         return {{{1 * i, 0 * i, 0 * i}, {0 * i, 1 * i, 0 * i}, {0 * i, 0 * i, 1 * i}}};
+    }
+    if (s.type == SHAPE_CAPSULE) {   // moment_of_inertia.cpp:65-90,171-173, shape_volume.cpp:10-16
+        const float kPiF = 3.1415926535897932384626433832795029f;
+        const float len = s.half_length * 2, radius = s.radius;
+        const float cyl_vol = kPiF * radius * radius * len;
+        const float sph_vol = kPiF * radius * radius * radius * 4.0f / 3.0f;
+        const float total_vol = cyl_vol + sph_vol;
+        const float cyl_mass = mass * cyl_vol / total_vol, sph_mass = mass * sph_vol / total_vol;
+        const float cyl_xx = 0.5f * cyl_mass * radius * radius;   // moment_of_inertia_solid_cylinder :28-46
+        const float cyl_yy = 1.0f / 12.0f * cyl_mass * (3.0f * radius * radius + len * len);
+        const float sph_inertia = 0.4f * sph_mass * radius * radius;
+        // moment_of_inertia_solid_cylinder returns its vector already permuted for the axis, and the capsule formula reads
+        // .x as the axial and .y as the transverse term whatever the axis is (:77-81) - so for axis y / z the cylinder's
+        // two terms arrive swapped / equal. Reproduced as is: this is the inertia the reference simulates with.
+        const vec3 cyl = s.axis == 0 ? vec3{cyl_xx, cyl_yy, cyl_yy} : (s.axis == 1 ? vec3{cyl_yy, cyl_xx, cyl_yy} : vec3{cyl_yy, cyl_yy, cyl_xx});
+        const float xx = sph_inertia + cyl.x;
+        const float yy_zz = sph_inertia + sph_mass * square(4.0f * len + 3.0f * radius) / 64.0f + cyl.y;
+        return diagonal(s.axis == 0 ? vec3{xx, yy_zz, yy_zz} : (s.axis == 1 ? vec3{yy_zz, xx, yy_zz} : vec3{yy_zz, yy_zz, xx}));
     }
     return diagonal({kScalarMax, kScalarMax, kScalarMax});
 }

@@ -63,7 +63,10 @@ struct Body {
     bool asleep = false;             // sleeping_tag (island_manager.cpp:541-565)
     bool sleeping_disabled = false;  // sleeping_disabled_tag
     bool procedural() const { return kind == KIND_DYNAMIC; }
-    bool rolling() const { return kind == KIND_DYNAMIC && sh.type == SHAPE_SPHERE; }
+    bool rolling() const { return kind == KIND_DYNAMIC && (sh.type == SHAPE_SPHERE || sh.type == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t, shapes.hpp:40-44
+    vec3 roll_direction() const {   // roll_direction component: dynamic capsules roll about their axis (rigidbody.cpp:119-130, shapes.hpp:136-139)
+        return kind == KIND_DYNAMIC && sh.type == SHAPE_CAPSULE ? coordinate_axis_vector(sh.axis) : vec3{0, 0, 0};
+    }
 };
 
 struct ContactPoint {
@@ -772,11 +775,12 @@ public:
     // ---------------- solver ----------------
     struct BodyRef {   // solver.cpp:83-147: static => zero velocity; non-procedural => zero inverse mass, dummy deltas
         vec3 pos; quat orn; vec3 linvel, angvel; float inv_m; mat3 inv_I; vec3 *dv, *dw;
+        vec3 roll_dir{0, 0, 0};
     };
     BodyRef body_ref(uint32_t i) {
         Body &b = bodies[i];
         BodyRef r;
-        r.pos = b.pos; r.orn = b.orn;
+        r.pos = b.pos; r.orn = b.orn; r.roll_dir = b.roll_direction();
         if (b.procedural()) { r.inv_m = b.mass_inv; r.inv_I = b.I_inv_world; r.dv = &b.dv; r.dw = &b.dw; }
         else { r.inv_m = 0; r.inv_I = kMat3Zero; r.dv = &dummy_dv_; r.dw = &dummy_dw_; }
         if (b.kind == KIND_STATIC) { r.linvel = {0, 0, 0}; r.angvel = {0, 0, 0}; }
@@ -812,12 +816,16 @@ public:
         if (ex) {
             ex->roll = cp.extras() && cp.roll_friction > 0;
             ex->spin = cp.extras() && cp.spin_friction > 0;
-            if (ex->roll) {   // :37-64 (no roll_direction components on this path: the axes stay unscaled)
+            if (ex->roll) {   // :37-64
                 ex->rr.mu = cp.roll_friction;
                 vec3 t[2];
                 plane_space(n, t[0], t[1]);
                 for (int i = 0; i < 2; ++i) {
                     auto &ri = ex->rr.row[i];
+                    // a body with a rolling direction scales the axis down by the projection of that direction on it
+                    // (both directions are rotated by body A's orientation, as the reference does, :50-55)
+                    for (const vec3 &rd : {A.roll_dir, B.roll_dir})
+                        if (rd.x != 0 || rd.y != 0 || rd.z != 0) t[i] *= dot(rotate(A.orn, rd), t[i]);
                     ri.J[0] = {0, 0, 0}; ri.J[1] = t[i]; ri.J[2] = {0, 0, 0}; ri.J[3] = -t[i];
                     ri.impulse = cp.rolling_impulse[i];
                     const float s = dot(A.inv_I * ri.J[1], ri.J[1]) + dot(B.inv_I * ri.J[3], ri.J[3]);

@@ -140,6 +140,7 @@ uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, co
     if (shape_type == 1) def.shape = edyn::box_shape{v3(sp)};
     else if (shape_type == 2) def.shape = edyn::sphere_shape{sp[0]};
     else if (shape_type == 3) def.shape = edyn::plane_shape{v3(sp), sp[3]};
+    else if (shape_type == 4) def.shape = edyn::capsule_shape{sp[0], sp[1], (edyn::coordinate_axis)(int)sp[2]};
     if (inertia9) {
         def.inertia = edyn::matrix3x3{{edyn::vector3{inertia9[0], inertia9[1], inertia9[2]},
                                        edyn::vector3{inertia9[3], inertia9[4], inertia9[5]},

@@ -34,6 +34,11 @@ def pair_batch(rng, n, tA, tB):
         elif t == scenes.SHAPE_SPHERE:
             sp[:, side, 0] = rng.uniform(0.1, 0.5, size=n)
             reach[:, side] = sp[:, side, 0]
+        elif t == getattr(scenes, "SHAPE_CAPSULE", 4):   # (radius, half_length, axis)
+            sp[:, side, 0] = rng.uniform(0.1, 0.4, size=n)
+            sp[:, side, 1] = rng.uniform(0.05, 0.6, size=n)
+            sp[:, side, 2] = rng.integers(0, 3, n)
+            reach[:, side] = sp[:, side, 0] + rng.random(n).astype(np.float32) * sp[:, side, 1]
         else:   # plane through a random offset with a random (or +Y) normal
             nrm = rng.normal(size=(n, 3)).astype(np.float32)
             nrm[rng.random(n) < 0.5] = (0, 1, 0)

@@ -40,7 +40,10 @@ def _libm_trig():
 @pytest.mark.parametrize("tA,tB", [
     (scenes.SHAPE_BOX, scenes.SHAPE_BOX), (scenes.SHAPE_SPHERE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_SPHERE),
     (scenes.SHAPE_SPHERE, scenes.SHAPE_SPHERE), (scenes.SHAPE_BOX, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_BOX),
-    (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE)])
+    (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_CAPSULE), (scenes.SHAPE_CAPSULE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE)])
 def test_collide_matches_the_reference_routines(tA, tB):
     """collide_box_box.cpp:14-266, collide_box_plane.cpp, collide_sphere_{sphere,plane,box}.cpp, swap_collide
     (collide.hpp:369-374), collision_result.cpp: counts, pivots, normals, distances, attachments — the same 200k random
@@ -554,5 +557,43 @@ def test_contact_extras_match_the_real_engine(kind):
             assert seen_roll > 0 and seen_spin > 0
         if kind in ("soft", "both"):
             assert seen_soft > 0
+    finally:
+        ob.set_libm_trig(False)
+
+
+def _capsule_scene():
+    sc = scenes.box_pile(3, 3, 3, mixed=True)
+    n = len(sc["kind"])
+    for i in range(1, n, 2):
+        sc["shape_type"][i] = scenes.SHAPE_CAPSULE
+        sc["shape_param"][i] = (0.3, 0.2 + 0.05 * (i % 4), float(i % 3), 0)
+    rng = np.random.default_rng(9)
+    sc["angvel"][1:] = (rng.normal(size=(n - 1, 3)) * 2).astype(np.float32)
+    sc["linvel"][1:] = (rng.normal(size=(n - 1, 3)) * (0.8, 0.1, 0.8)).astype(np.float32)
+    return sc
+
+
+def test_capsules_whole_steps_bit_exact_against_the_real_engine():
+    """capsule_shape: AABB (aabb_util.cpp:81-88), solid-capsule inertia (moment_of_inertia.cpp:65-90), the
+    four capsule pair routines and rolling_tag matching in the narrowphase - a tumbling heap of capsules, boxes and spheres
+    stays bit-identical to the real engine for 250 steps."""
+    _lockstep(_capsule_scene(), 250, 10)
+
+
+def test_capsule_rolling_friction_uses_the_roll_direction():
+    """contact_extras rolling rows of bodies with a roll_direction (dynamic capsules: their axis, shapes.hpp:136-139): the
+    tangent axes are scaled by the projection of the rolling direction (contact_extras_constraint.cpp:44-55)."""
+    sc = _capsule_scene()
+    ref = ob.RefWorld(); ref.add_bodies(sc)
+    orc = ob.World(order=ob.ORDER_EXTERNAL); orc.add_bodies(sc); ob.set_libm_trig(True)
+    try:
+        for i in range(len(sc["kind"])):
+            ref.set_material_extras(i, roll=0.05, spin=0.01); orc.set_material_extras(i, roll=0.05, spin=0.01)
+        for s in range(1, 201):
+            ref.step(1)
+            orc.set_ext_order(*ref.get_solve_order()); orc.step(1)
+            assert not orc.ext_order_mismatch(), s
+            for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {s}: {name} differs, max |d| = {np.abs(a - b).max()}"
     finally:
         ob.set_libm_trig(False)
