@@ -159,6 +159,23 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         } else if (st == dc::SHAPE_SPHERE) {   // :19-21,163-165
             float s = 0.4f * mass * sp.x * sp.x;
             I = {{1 * s, 0 * s, 0 * s}, {0 * s, 1 * s, 0 * s}, {0 * s, 0 * s, 1 * s}};
+        } else if (st == dc::SHAPE_CAPSULE) {   // moment_of_inertia.cpp:65-90,171-173, shape_volume.cpp:10-16
+            const float kPiF = 3.1415926535897932384626433832795029f;
+            const float len = sp.y * 2, radius = sp.x;
+            const float cyl_vol = kPiF * radius * radius * len;
+            const float sph_vol = kPiF * radius * radius * radius * 4.0f / 3.0f;
+            const float total_vol = cyl_vol + sph_vol;
+            const float cyl_mass = mass * cyl_vol / total_vol, sph_mass = mass * sph_vol / total_vol;
+            const float cyl_xx = 0.5f * cyl_mass * radius * radius;
+            const float cyl_yy = 1.0f / 12.0f * cyl_mass * (3.0f * radius * radius + len * len);
+            const float sph_inertia = 0.4f * sph_mass * radius * radius;
+            // the capsule formula reads the cylinder's vector as (.x axial, .y transverse) although it arrives permuted for
+            // the axis (:77-81): reproduced - it is the inertia the reference simulates with
+            const f3 cyl = sp.z == 0.0f ? mk3(cyl_xx, cyl_yy, cyl_yy) : (sp.z == 1.0f ? mk3(cyl_yy, cyl_xx, cyl_yy) : mk3(cyl_yy, cyl_yy, cyl_xx));
+            const float xx = sph_inertia + cyl.x;
+            const float yy_zz = sph_inertia + sph_mass * square(4.0f * len + 3.0f * radius) / 64.0f + cyl.y;
+            const f3 d = sp.z == 0.0f ? mk3(xx, yy_zz, yy_zz) : (sp.z == 1.0f ? mk3(yy_zz, xx, yy_zz) : mk3(yy_zz, yy_zz, xx));
+            I = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}};
         } else {
             I = {{kScalarMax, 0, 0}, {0, kScalarMax, 0}, {0, 0, kScalarMax}};
         }
@@ -211,6 +228,11 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         mn = mk3(lo[0], lo[1], lo[2]); mx = mk3(hi[0], hi[1], hi[2]);
     } else if (st == dc::SHAPE_SPHERE) {
         mn = mk3(pos.x - sp.x, pos.y - sp.x, pos.z - sp.x); mx = mk3(pos.x + sp.x, pos.y + sp.x, pos.z + sp.x);
+    } else if (st == dc::SHAPE_CAPSULE) {   // aabb_util.cpp:81-88
+        const f3 v = rotate(orn, dc::axis_vector(sp.z)) * sp.y;
+        const f3 p0 = pos - v, p1 = pos + v;
+        mn = mk3(fminf(p0.x, p1.x) - sp.x, fminf(p0.y, p1.y) - sp.x, fminf(p0.z, p1.z) - sp.x);
+        mx = mk3(fmaxf(p0.x, p1.x) + sp.x, fmaxf(p0.y, p1.y) + sp.x, fmaxf(p0.z, p1.z) + sp.x);
     } else if (st == dc::SHAPE_PLANE) {
         const f3 nrm = from4(sp);
         f3 umin = mk3(-1, -1, -1), umax = mk3(1, 1, 1);
@@ -530,6 +552,9 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     if (n && (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
               !in->friction || !in->restitution))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
+    for (uint32_t i = 0; i < n; ++i)
+        if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_CAPSULE)
+            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule)").c_str());
     if (first == 0) { c->has_restitution = false; c->extras = false; }
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)

@@ -15,7 +15,7 @@ constexpr float kMergingThreshold = 0.01f;          // :27
 constexpr float kCachingThreshold = 0.04f;          // :34
 constexpr float kSupportTolerance = 0.005f;         // :56
 
-enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3 };
+enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4 };
 enum { BF_VERTEX = 0, BF_EDGE = 1, BF_FACE = 2 };
 enum { NA_NONE = 0, NA_ON_A = 1, NA_ON_B = 2 };
 enum { INS_NONE = 0, INS_APPEND = 1, INS_SIMILAR = 2, INS_REPLACE = 3 };
@@ -168,7 +168,9 @@ DI int intersect_line_aabb(f2 p0, f2 p1, f2 bmin, f2 bmax, float &s0, float &s1)
           if (n == 0) { s0 = t; ++n; } else if (fabsf(t - s0) > kEps) { s1 = t; ++n; } } }
     return n;
 }
-// src/edyn/math/geom.cpp:73-170 (always called with num_points != nullptr on this path)
+// src/edyn/math/geom.cpp:73-170. MULTI = called with num_points != nullptr (parallel segments may yield two closest pairs);
+// without it the parallel case takes s = 0, as the reference does when the optional outputs are absent.
+template <bool MULTI = true>
 DI void closest_segment_segment(f3 p1, f3 q1, f3 p2, f3 q2, f3 &c1, f3 &c2, int &num, f3 &c1p, f3 &c2p) {
     const f3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
@@ -186,6 +188,8 @@ DI void closest_segment_segment(f3 p1, f3 q1, f3 p2, f3 q2, f3 &c1, f3 &c2, int 
             if (denom > kEps) {
                 s = clamp_unit((b * f - c * e) / denom);
                 num = 1;
+            } else if (!MULTI) {
+                s = 0;
             } else {
                 f3 r1 = p1 - q2;
                 float f1 = dot(d1, r1);
@@ -551,6 +555,184 @@ DI void collide_sphere_box(float radius, f3 hB, const Ctx &c, CResult &result) {
     res_add(result, CPoint{pivotA, closest, rotate(c.ornB, nB), cd - radius, attach});
 }
 
+// ---- capsule pairs. Shape param float4 of a capsule: radius, half_length, axis (0 x, 1 y, 2 z) - shapes/capsule_shape.hpp:17-30.
+DI f3 axis_vector(float axis) { return axis == 0.0f ? mk3(1, 0, 0) : (axis == 1.0f ? mk3(0, 1, 0) : mk3(0, 0, 1)); }
+DI void capsule_vertices(float4 sh, f3 pos, q4 orn, f3 &v0, f3 &v1) {   // capsule_shape::get_vertices
+    const f3 dir = rotate(orn, axis_vector(sh.z));
+    v0 = pos + dir * sh.y;
+    v1 = pos - dir * sh.y;
+}
+DI float capsule_support_projection(f3 v0, f3 v1, float radius, f3 dir) { return fmaxf(dot(v0, dir), dot(v1, dir)) + radius; }   // shape_util.cpp:297-300
+// collide_capsule_plane.cpp:6-38
+DI void collide_capsule_plane(float4 shA, f3 pn, float pc, const Ctx &c, CResult &result) {
+    const f3 center = pn * pc;
+    f3 cv[2];
+    capsule_vertices(shA, c.posA, c.ornA, cv[0], cv[1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float distance = dot(cv[i] - center, pn) - shA.x;
+        if (distance > c.threshold) continue;
+        const f3 pivotA_world = cv[i] - pn * shA.x;
+        res_add(result, CPoint{to_object(pivotA_world, c.posA, c.ornA), project_plane(cv[i], center, pn), pn, distance, NA_ON_B});
+    }
+}
+// collide_capsule_sphere.cpp:10-51
+DI void collide_capsule_sphere(float4 shA, float rB, const Ctx &c, CResult &result) {
+    f3 v0, v1;
+    capsule_vertices(shA, c.posA, c.ornA, v0, v1);
+    const f3 v = v1 - v0, w = c.posB - v0;   // closest_point_segment, geom.cpp:12-22
+    const float t = clamp_unit(dot(w, v) / dot(v, v));
+    const f3 closest = v0 + v * t;
+    const float dist_sqr = length_sqr(c.posB - closest);
+    const float min_dist = shA.x + rB + c.threshold;
+    if (dist_sqr > min_dist * min_dist) return;
+    f3 normal = closest - c.posB;
+    const float nl2 = length_sqr(normal);
+    float distance;
+    if (nl2 > kEps) {
+        const float nl = sqrtf(nl2);
+        normal = div_recip(normal, nl);   // vector3::operator/= multiplies by the reciprocal
+        distance = nl - shA.x - rB;
+    } else {
+        normal = rotate(c.ornA, mk3(0, 0, 1));
+        distance = -(shA.x + rB);
+    }
+    const f3 normalB = rotate(conjugate(c.ornB), normal);
+    const f3 pivotA_world = closest - normal * shA.x;
+    res_add(result, CPoint{to_object(pivotA_world, c.posA, c.ornA), normalB * rB, normal, distance, NA_NONE});
+}
+// collide_capsule_capsule.cpp:7-80
+DI void collide_capsule_capsule(float4 shA, float4 shB, const Ctx &c, CResult &result) {
+    f3 a0, a1, b0, b1;
+    capsule_vertices(shA, c.posA, c.ornA, a0, a1);
+    capsule_vertices(shB, c.posB, c.ornB, b0, b1);
+    f3 cA0, cB0, cA1 = mk3(0, 0, 0), cB1 = mk3(0, 0, 0);
+    int n = 0;
+    closest_segment_segment(a0, a1, b0, b1, cA0, cB0, n, cA1, cB1);
+    const float dist_sqr = length_sqr(cA0 - cB0);
+    const float min_dist = shA.x + shB.x + c.threshold;
+    if (dist_sqr > min_dist * min_dist) return;
+    f3 normal;
+    float distance;
+    if (dist_sqr > kEps) {
+        const float dist = sqrtf(dist_sqr);
+        normal = (cA0 - cB0) / dist;
+        distance = dist - shA.x - shB.x;
+    } else {
+        normal = cross(a1 - a0, b1 - b0);
+        if (dot(c.posA - c.posB, normal) < 0) normal *= -1.0f;
+        if (!try_normalize(normal)) normal = mk3(0, 1, 0);
+        distance = -(shA.x + shB.x);
+    }
+    if (n >= 1) res_add(result, CPoint{to_object(cA0 - normal * shA.x, c.posA, c.ornA), to_object(cB0 + normal * shB.x, c.posB, c.ornB), normal, distance, NA_NONE});
+    if (n >= 2) res_add(result, CPoint{to_object(cA1 - normal * shA.x, c.posA, c.ornA), to_object(cB1 + normal * shB.x, c.posB, c.ornB), normal, distance, NA_NONE});
+}
+// collide_capsule_box.cpp:14-213
+DI void collide_capsule_box(float4 shA, f3 hB, const Ctx &c, CResult &result) {
+    const f3 posA = mk3(0, 0, 0), posB = c.posB - c.posA;
+    const q4 ornA = c.ornA, ornB = c.ornB;
+    f3 cv0, cv1;
+    capsule_vertices(shA, posA, ornA, cv0, cv1);
+    const f3 axB[3] = {rotate(ornB, mk3(1, 0, 0)), rotate(ornB, mk3(0, 1, 0)), rotate(ornB, mk3(0, 0, 1))};
+    float distance = -kScalarMax, projection_box = -kScalarMax;
+    f3 sep = mk3(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f3 dir = axB[i];
+        if (dot(posA - posB, dir) < 0) dir = -dir;
+        const float projA = -capsule_support_projection(cv0, cv1, shA.x, -dir);
+        const float projB = dot(posB, dir) + comp(hB, i);
+        const float dist = projA - projB;
+        if (dist > distance) { distance = dist; projection_box = projB; sep = dir; }
+    }
+#pragma nounroll
+    for (int i = 0; i < 12; ++i) {
+        f3 ev[2];
+        edge_world(hB, i, posB, ornB, ev);
+        f3 cA, cB, u0, u1;
+        int nn = 0;
+        closest_segment_segment<false>(ev[0], ev[1], cv0, cv1, cA, cB, nn, u0, u1);
+        f3 dir = cA - cB;
+        if (!try_normalize(dir)) continue;
+        if (dot(posA - posB, dir) < 0) dir *= -1.0f;
+        const float projA = -capsule_support_projection(cv0, cv1, shA.x, -dir);
+        const float projB = box_support_projection(hB, posB, ornB, dir);
+        const float dist = projA - projB;
+        if (dist > distance) { distance = dist; projection_box = projB; sep = dir; }
+    }
+    if (distance > c.threshold) return;
+    const float pr0 = dot(cv0, sep), pr1 = dot(cv1, sep);
+    const bool is_capsule_edge = fabsf(pr0 - pr1) < kSupportTolerance;
+    const f3 contact_origin_box = sep * projection_box;
+    int featB, idxB; float fdB;
+    support_feature(hB, posB, ornB, contact_origin_box, sep, featB, idxB, fdB, kSupportTolerance);
+    const f3 cvx = pr0 < pr1 ? cv0 : cv1;   // the capsule vertex nearer to the box
+    CPoint point;
+    point.normal = sep; point.distance = distance; point.attachment = NA_NONE;
+    point.pivotA = mk3(0, 0, 0); point.pivotB = mk3(0, 0, 0);
+    if (featB == BF_FACE) {
+        f3 fv[4];
+        face_world(hB, idxB, posB, ornB, fv);
+        point.attachment = NA_ON_B;
+        if (is_capsule_edge) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f3 pointA = k == 0 ? cv0 : cv1;
+                if (point_in_quad_prism(fv, sep, pointA)) {
+                    point.pivotA = to_object(pointA - sep * shA.x, posA, ornA);
+                    point.pivotB = to_object(project_plane(pointA, contact_origin_box, sep), posB, ornB);
+                    res_add(result, point);
+                }
+            }
+            if (result.num == 2) return;
+            const f3 fc = face_center(hB, idxB, posB, ornB);
+            const m3 fb = face_basis(idxB, ornB);
+            const f2 he = face_half_extents(hB, idxB);
+            const f3 q0 = to_object(cv0, fc, fb), q1 = to_object(cv1, fc, fb);
+            float s0, s1;
+            const int n = intersect_line_aabb({q0.x, q0.z}, {q1.x, q1.z}, -he, he, s0, s1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float si = i ? s1 : s0;
+                if (i >= n || si < 0 || si > 1) continue;
+                const f3 edge_pivot = lerp(cv0, cv1, si);
+                const f3 face_pivot = project_plane(edge_pivot, fc, sep);
+                point.pivotA = to_object(edge_pivot - sep * shA.x, posA, ornA);
+                point.pivotB = to_object(face_pivot, posB, ornB);
+                res_add(result, point);
+            }
+        } else {
+            const f3 pA = cvx - sep * shA.x;
+            const f3 pB = project_plane(pA, contact_origin_box, sep);
+            point.pivotA = to_object(pA, posA, ornA);
+            point.pivotB = to_object(pB, posB, ornB);
+            res_add(result, point);
+        }
+    } else if (featB == BF_EDGE) {
+        f3 ev[2];
+        edge_world(hB, idxB, posB, ornB, ev);
+        if (is_capsule_edge) {
+            f3 cA0, cB0, cA1 = mk3(0, 0, 0), cB1 = mk3(0, 0, 0);
+            int n = 0;
+            closest_segment_segment(cv0, cv1, ev[0], ev[1], cA0, cB0, n, cA1, cB1);
+            if (n >= 1) { point.pivotA = to_object(cA0 - sep * shA.x, posA, ornA); point.pivotB = to_object(cB0, posB, ornB); res_add(result, point); }
+            if (n >= 2) { point.pivotA = to_object(cA1 - sep * shA.x, posA, ornA); point.pivotB = to_object(cB1, posB, ornB); res_add(result, point); }
+        } else {
+            const f3 edge_dir = ev[1] - ev[0], w = cvx - ev[0];   // closest_point_line, geom.cpp:35-44
+            const float t = dot(w, edge_dir) / dot(edge_dir, edge_dir);
+            const f3 pB = ev[0] + edge_dir * t;
+            point.pivotB = to_object(pB, posB, ornB);
+            point.pivotA = to_object(cvx - sep * shA.x, posA, ornA);
+            res_add(result, point);
+        }
+    } else {
+        point.pivotB = box_vertex(hB, idxB);
+        const f3 pB = to_world(point.pivotB, posB, ornB);
+        point.pivotA = to_object(pB + sep * distance, posA, ornA);
+        res_add(result, point);
+    }
+}
+
 // Shape pair dispatch incl. swap_collide (include/edyn/collision/collide.hpp:369-374).
 // shape param float4: box = half extents xyz; sphere = radius in x; plane = normal xyz, constant w.
 DI void collide(int tA, float4 sA, int tB, float4 sB, const Ctx &c, CResult &r) {
@@ -565,6 +747,13 @@ DI void collide(int tA, float4 sA, int tB, float4 sB, const Ctx &c, CResult &r) 
     else if (tA == SHAPE_PLANE && tB == SHAPE_SPHERE) { collide_sphere_plane(sB.x, from4(sA), sA.w, sw, r); swapped = true; }
     else if (tA == SHAPE_SPHERE && tB == SHAPE_BOX) collide_sphere_box(sA.x, from4(sB), c, r);
     else if (tA == SHAPE_BOX && tB == SHAPE_SPHERE) { collide_sphere_box(sB.x, from4(sA), sw, r); swapped = true; }
+    else if (tA == SHAPE_CAPSULE && tB == SHAPE_PLANE) collide_capsule_plane(sA, from4(sB), sB.w, c, r);
+    else if (tA == SHAPE_PLANE && tB == SHAPE_CAPSULE) { collide_capsule_plane(sB, from4(sA), sA.w, sw, r); swapped = true; }
+    else if (tA == SHAPE_CAPSULE && tB == SHAPE_SPHERE) collide_capsule_sphere(sA, sB.x, c, r);
+    else if (tA == SHAPE_SPHERE && tB == SHAPE_CAPSULE) { collide_capsule_sphere(sB, sA.x, sw, r); swapped = true; }
+    else if (tA == SHAPE_CAPSULE && tB == SHAPE_CAPSULE) collide_capsule_capsule(sA, sB, c, r);
+    else if (tA == SHAPE_CAPSULE && tB == SHAPE_BOX) collide_capsule_box(sA, from4(sB), c, r);
+    else if (tA == SHAPE_BOX && tB == SHAPE_CAPSULE) { collide_capsule_box(sB, from4(sA), sw, r); swapped = true; }
     if (swapped) {
 #pragma unroll
         for (int i = 0; i < kMaxContacts; ++i) if (i < r.num) cp_swap(r.pt[i]);

@@ -113,10 +113,10 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         BodyIn A, B;
         { float4 p = B_POS(b, ia); A.pos = from4(p); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
           float2 mt = b.mat[ia]; A.friction = mt.x; A.restitution = mt.y;
-          A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tA == SHAPE_SPHERE; }
+          A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tA == SHAPE_SPHERE || tA == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t
         { float4 p = B_POS(b, ib); B.pos = from4(p); B.orn = q_from4(B_ORN(b, ib)); B.angvel = from4(b.angvel[ib]);
           float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
-          B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && tB == SHAPE_SPHERE; }
+          B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tB == SHAPE_SPHERE || tB == SHAPE_CAPSULE); }
 
         // Old points: only what the matching needs is held across it (pivots, normal, distance); friction, restitution, the
         // local normal, the warm-start impulses and the lifetime are re-read just before the stores.

@@ -523,7 +523,22 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
                 rows.rwx[xb + (size_t)(3 * r + 1) * rcap] = to4(ia, rhs);
                 rows.rwx[xb + (size_t)(3 * r + 2) * rcap] = to4(ib, imp);
             };
-            if (xm.x > 0) { axial(0, t0, xi.x, true); axial(1, t1, xi.y, true); }
+            if (xm.x > 0) {
+                // a dynamic capsule rolls about its axis (roll_direction, shapes.hpp:136-139): the tangent axes are scaled by
+                // the projection of that direction - both bodies' directions rotated by A's orientation, as the reference does
+                // (contact_extras_constraint.cpp:44-55)
+                f3 ax0 = t0, ax1 = t1;
+                const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t fl = side ? fb : fa;
+                    if (is_dynamic(fl) && ((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == (uint32_t)dc::SHAPE_CAPSULE) {
+                        const f3 rdw = rotate(A.orn, dc::axis_vector(b.shape[side ? ib : ia].z));
+                        ax0 *= dot(rdw, ax0); ax1 *= dot(rdw, ax1);
+                    }
+                }
+                axial(0, ax0, xi.x, true); axial(1, ax1, xi.y, true);
+            }
             if (xm.y > 0) axial(2, n, xi.z, false);
         }
         store_row(rows.rw, base + rstride, rcap, t0, K1, K3, eff0, rhs0, im.y, 0.0f, A, B);
@@ -1773,6 +1788,12 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
         const float r = b.shape[i].x;
         b.amin[i] = make_float4(pos.x - r, pos.y - r, pos.z - r, 0);
         b.amax[i] = make_float4(pos.x + r, pos.y + r, pos.z + r, 0);
+    } else if (st == dc::SHAPE_CAPSULE) {   // aabb_util.cpp:81-88
+        const float4 sh = b.shape[i];
+        const f3 v = rotate(orn, dc::axis_vector(sh.z)) * sh.y;
+        const f3 p0 = pos - v, p1 = pos + v;
+        b.amin[i] = make_float4(fminf(p0.x, p1.x) - sh.x, fminf(p0.y, p1.y) - sh.x, fminf(p0.z, p1.z) - sh.x, 0);
+        b.amax[i] = make_float4(fmaxf(p0.x, p1.x) + sh.x, fmaxf(p0.y, p1.y) + sh.x, fmaxf(p0.z, p1.z) + sh.x, 0);
     }
     if (kind == EDYNHIP_KIND_DYNAMIC) {   // update_inertias.cpp:12-24
         const m3 il = {from4(B_IL(b, i, 0)), from4(B_IL(b, i, 1)), from4(B_IL(b, i, 2))};

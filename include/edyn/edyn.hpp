@@ -75,7 +75,9 @@ struct collision_filter { uint64_t group{~0ull}, mask{~0ull}; };
 struct box_shape { vector3 half_extents; };
 struct sphere_shape { scalar radius; };
 struct plane_shape { vector3 normal; scalar constant; };
-using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape>;
+enum class coordinate_axis : unsigned char { x, y, z };                                       // math/coordinate_axis.hpp
+struct capsule_shape { scalar radius; scalar half_length; coordinate_axis axis{coordinate_axis::x}; };   // shapes/capsule_shape.hpp:17-30
+using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape, capsule_shape>;
 
 enum class rigidbody_kind : uint8_t { rb_dynamic, rb_kinematic, rb_static };   // util/rigidbody.hpp:22-27
 
@@ -256,6 +258,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         }
         if (auto *b = registry.try_get<box_shape>(e)) { stype[i] = EDYNHIP_SHAPE_BOX; sp[4 * i] = b->half_extents.x; sp[4 * i + 1] = b->half_extents.y; sp[4 * i + 2] = b->half_extents.z; }
         else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
+        else if (auto *cs = registry.try_get<capsule_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CAPSULE; sp[4 * i] = cs->radius; sp[4 * i + 1] = cs->half_length; sp[4 * i + 2] = (float)(int)cs->axis; }
         else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
         else stype[i] = EDYNHIP_SHAPE_NONE;
         if (auto *mt = registry.try_get<material>(e)) {
@@ -691,7 +694,7 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<rigidbody_tag>(entity); registry.remove<dynamic_tag>(entity); registry.remove<kinematic_tag>(entity);
     registry.remove<static_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<sleeping_disabled_tag>(entity);
     registry.remove<sleeping_tag>(entity); registry.remove<collision_filter>(entity); registry.remove<box_shape>(entity);
-    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<material>(entity);
+    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<material>(entity);
     registry.remove<gravity>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);

@@ -331,7 +331,10 @@ from pairgen import pair_batch as _pair_batch  # noqa: E402
 @pytest.mark.parametrize("tA,tB", [
     (scenes.SHAPE_BOX, scenes.SHAPE_BOX), (scenes.SHAPE_SPHERE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_SPHERE),
     (scenes.SHAPE_SPHERE, scenes.SHAPE_SPHERE), (scenes.SHAPE_BOX, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_BOX),
-    (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE)])
+    (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_CAPSULE), (scenes.SHAPE_CAPSULE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE)])
 def test_collide_routines_bit_exact_on_random_pairs(tA, tB):
     """200k random pairs per shape combination through the device collide() (edynhip_debug_collide) and the oracle's:
     point counts, pivots, normals, distances and normal attachments must be identical bit for bit."""
@@ -1001,3 +1004,31 @@ def test_contact_extras_bit_exact(kind):
     assert_state_equal(g, o)
     if kind != "soft":
         assert seen > 0
+
+
+def test_capsules_bit_exact():
+    """capsule_shape on the device (AABB, inertia, the four capsule pair routines, rolling-shape matching, roll_direction in
+    the rolling rows): a tumbling heap of capsules, boxes and spheres against the oracle, every stage, then with rolling /
+    spinning friction materials; the oracle's capsules are pinned to the real engine in tests/test_reference_engine.py."""
+    from test_reference_engine import _capsule_scene
+    sc = _capsule_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for s in range(1, 201):
+        g.step_simulation(1); o.step(1)
+        if s % 25 == 0 or s < 3:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            gd, od = g.get_derived(), o.get_derived()
+            assert np.array_equal(gd[0], od[0]) and np.array_equal(gd[1], od[1]), s   # AABBs, world inertias
+    g2, o2 = gpu_world(sc), oracle_world(sc)
+    n = len(sc["kind"])
+    g2.set_material_extras(0, np.full(n, 0.01, np.float32), np.full(n, 0.05, np.float32))
+    for i in range(n):
+        o2.set_material_extras(i, spin=0.01, roll=0.05)
+    for s in range(1, 151):
+        g2.step_simulation(1); o2.step(1)
+        if s % 25 == 0:
+            assert_state_equal(g2, o2)
+            assert np.array_equal(g2.get_point_extras().view(np.uint32), o2.get_point_extras().view(np.uint32)), s
+    assert_state_equal(g2, o2)
