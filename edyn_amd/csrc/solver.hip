@@ -460,6 +460,9 @@ DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, fl
     rw[base + 3 * cap] = to4(mul(A.inv_I, JaA), mu);
     rw[base + 4 * cap] = to4(mul(B.inv_I, JaB), kLarge);   // .w of a normal row: its upper limit (soft contacts lower it)
 }
+// EXTRAS: the world has contact_extras materials (soft normal rows, rolling / spinning rows); the plain instantiation is the
+// headline path and carries none of that code.
+template <bool EXTRAS>
 __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt,
                                 const uint32_t *__restrict__ keys_sorted, bool push) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,8 +492,8 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         float error = distance > 0 ? distance / dt : 0.0f;
         float upper = kLarge;
         float4 xm = make_float4(0, 0, kLarge, kLarge), xi = make_float4(0, 0, 0, 0);
-        if (mf.xmat) { xm = mf.xmat[s]; xi = mf.ximp[s]; }
-        if (distance < 0 && xm.z < kLarge) {   // soft contact (contact_extras_constraint.cpp:16-35): force-limited normal row
+        if (EXTRAS) { xm = mf.xmat[s]; xi = mf.ximp[s]; }
+        if (EXTRAS && distance < 0 && xm.z < kLarge) {   // soft contact (contact_extras_constraint.cpp:16-35): force-limited normal row
             const f3 vA = A.v + cross(A.w, rA), vB = B.v + cross(B.w, rB);
             const float normal_relvel = dot(vA - vB, n);
             const float spring_force = -distance * xm.z / (float)np;
@@ -510,8 +513,8 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
         const size_t base = (size_t)(k * kRowsPerPoint) * kRowF * rcap + p, rstride = (size_t)kRowF * rcap;
         store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
-        if (upper != kLarge) rows.rw[base + 4 * (size_t)rcap].w = upper;
-        if (rows.rwx && mf.xmat) {   // rolling pair and spinning row (:37-78); roll_direction components do not exist on this path
+        if (EXTRAS && upper != kLarge) rows.rw[base + 4 * (size_t)rcap].w = upper;
+        if (EXTRAS) {   // rolling pair and spinning row (:37-78); roll_direction components do not exist on this path
             const size_t xb = (size_t)(k * kXPoint) * rcap + p;
             rows.rwx[xb + 9 * (size_t)rcap] = make_float4(xm.x, xm.y, 0, 0);
             auto axial = [&](int r, f3 ax, float imp, bool guarded) {
@@ -1006,8 +1009,12 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
 // ------------------------------------------------------------------ joints (point, hinge)
 // Slot r of a joint (ctx.hpp Joints): 0..2 the three linear rows, hinge 3/4 the rows along p and q, every other slot an
 // axial row {0, ax, 0, -ax} along `wax` (hinge axis for slots 5..8 of a hinge, relative spin for slot 3 of a point joint).
-DI void joint_rowJ(bool hinge, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
-    if (r < 3) {
+DI void joint_rowJ(int type, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
+    const bool hinge = type == EDYNHIP_JOINT_HINGE;
+    if (type == EDYNHIP_JOINT_DISTANCE || type == EDYNHIP_JOINT_SOFT_DISTANCE) {
+        // every row of the distance constraints runs along the pivot separation (kept in wp; wq, wax = rA x d, rB x d)
+        J0 = wp; J1 = wq; J2 = -wp; J3 = -wax;
+    } else if (r < 3) {
         // J = {I.row[i], -skew(rA).row[i], -I.row[i], skew(rB).row[i]}
         f3 e = r == 0 ? mk3(1, 0, 0) : (r == 1 ? mk3(0, 1, 0) : mk3(0, 0, 1));
         f3 sa = r == 0 ? mk3(0, -rA.z, rA.y) : (r == 1 ? mk3(rA.z, 0, -rA.x) : mk3(-rA.y, rA.x, 0));
@@ -1035,7 +1042,8 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
-    const bool hinge = j.type[i] == EDYNHIP_JOINT_HINGE;
+    const int type = j.type[i];
+    const bool hinge = type == EDYNHIP_JOINT_HINGE;
     f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0), wax = mk3(0, 0, 0);
     if (hinge) { wp = rotate(A.orn, from4(j.pA[i])); wq = rotate(A.orn, from4(j.qA[i])); }
     auto P = [&](int k) { return j.params[(size_t)k * j.cap + i]; };
@@ -1044,7 +1052,28 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     float err[kJointSlots], rest[kJointSlots], lo[kJointSlots], hi[kJointSlots];
 #pragma unroll
     for (int r = 0; r < kJointSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
-    if (!hinge) {
+    if (type == EDYNHIP_JOINT_DISTANCE) {   // distance_constraint.cpp:7-31
+        f3 d = pA - pB;
+        const float dist_sqr = length_sqr(d);
+        if (!(dist_sqr > kEps)) d = mk3(1, 0, 0);
+        wp = d; wq = cross(rA, d); wax = cross(rB, d);
+        const float distance = P(0);
+        err[0] = 0.5f * (dist_sqr - distance * distance) / dt;
+        lo[0] = -kLarge; hi[0] = kLarge;
+        mask = 0x1u;
+    } else if (type == EDYNHIP_JOINT_SOFT_DISTANCE) {   // soft_distance_constraint.cpp:8-62
+        const f3 d = pA - pB;
+        const float dist_sqr = length_sqr(d), dist = sqrtf(dist_sqr);
+        const f3 dn = dist_sqr > kEps ? d / dist : mk3(1, 0, 0);
+        wp = dn; wq = cross(rA, dn); wax = cross(rB, dn);
+        const float spring_impulse = P(1) * (P(0) - dist) * dt;
+        lo[0] = fminf(spring_impulse, 0.0f); hi[0] = fmaxf(0.0f, spring_impulse);
+        err[0] = spring_impulse > 0 ? -kLarge : kLarge;
+        const float relspd = rel_speed(dn, wq, -dn, -wax, A.v, A.w, B.v, B.w);
+        const float damping_impulse = P(2) * relspd * dt;
+        lo[1] = -fabsf(damping_impulse); hi[1] = fabsf(damping_impulse);
+        mask = 0x3u;
+    } else if (!hinge) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) err[r] = (comp(pA, r) - comp(pB, r)) / dt;
         const float friction_torque = P(0);
@@ -1117,7 +1146,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     for (int r = 0; r < kJointSlots; ++r) {
         if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(hinge, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
+        joint_rowJ(type, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
         const float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
         const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
         const size_t s = (size_t)r * j.cap + i;
@@ -1135,12 +1164,12 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     Delta d;
     load_delta(b, ia, ib, d);
     const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]);
-    const bool hinge = j.type[i] == EDYNHIP_JOINT_HINGE;
+    const int type = j.type[i];
     const uint32_t mask = j.rmask[i];
     for (int r = 0; r < kJointSlots; ++r) {
         if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(hinge, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
+        joint_rowJ(type, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
         const size_t s = (size_t)r * j.cap + i;
         float imp = j.impulse[s];
         if (WARM) {
@@ -1976,7 +2005,10 @@ int solve(edynhip_ctx *c) {
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
     // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
     const bool push = j.n == 0 && na > 0 && !c->extras;
-    if (na) hipLaunchKernelGGL(k_prep_contacts, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
+    if (na) {
+        if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
+        else hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
+    }
     if (push) {
         hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
     }

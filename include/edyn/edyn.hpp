@@ -103,6 +103,14 @@ struct point_constraint : constraint_base {                                     
     std::array<vector3, 2> pivot;
     scalar friction_torque{};
 };
+struct distance_constraint : constraint_base {                                                // constraints/distance_constraint.hpp
+    std::array<vector3, 2> pivot;
+    scalar distance{0};
+};
+struct soft_distance_constraint : constraint_base {                                           // constraints/soft_distance_constraint.hpp
+    std::array<vector3, 2> pivot;
+    scalar distance{0}, stiffness{scalar(1e10)}, damping{scalar(1e10)};
+};
 struct hinge_constraint : constraint_base {                                                   // constraints/hinge_constraint.hpp:22-93
     std::array<vector3, 2> pivot;
     std::array<vector3, 2> axis{vector3{1, 0, 0}, vector3{1, 0, 0}};
@@ -187,7 +195,10 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
             }
         };
         if (auto *pc = registry.try_get<point_constraint>(e)) { jt[j] = EDYNHIP_JOINT_POINT; fill(*pc, pc->pivot); jq[10 * j] = pc->friction_torque; }
-        else {
+        else if (auto *dc = registry.try_get<distance_constraint>(e)) { jt[j] = EDYNHIP_JOINT_DISTANCE; fill(*dc, dc->pivot); jq[10 * j] = dc->distance; }
+        else if (auto *sc = registry.try_get<soft_distance_constraint>(e)) {
+            jt[j] = EDYNHIP_JOINT_SOFT_DISTANCE; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
+        } else {
             auto &hc = registry.get<hinge_constraint>(e);
             jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
             for (int k = 0; k < 2; ++k) { ja[6 * j + 3 * k] = hc.axis[k].x; ja[6 * j + 3 * k + 1] = hc.axis[k].y; ja[6 * j + 3 * k + 2] = hc.axis[k].z; }
@@ -354,15 +365,17 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
     for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
         const entt::entity e = s.constraints[j];
         if (e == entt::null) continue;
-        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint>(e);
+        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint>(e);
         if (alive) {   // a joint whose body was destroyed goes with it
             const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
-                                                                             : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
+                                      : registry.all_of<distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<distance_constraint>(e))
+                                      : registry.all_of<soft_distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<soft_distance_constraint>(e))
+                                      : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
             for (int k = 0; k < 2; ++k) if (!registry.valid(cb.body[k]) || !registry.all_of<body_index>(cb.body[k])) alive = false;
         }
         if (!alive) {
             s.constraints[j] = entt::null;
-            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint>(e)) registry.destroy(e);   // its body is gone
             if (j < s.uploaded_constraints) gone_joints.push_back(j);
         }
     }
@@ -657,8 +670,9 @@ inline entt::entity make_rigidbody(entt::registry &registry, const rigidbody_def
 // ---- util/constraint_util.hpp:38-54: make_constraint<T>(registry, entity, body0, body1, setup...) and the entity-creating form
 template <typename T, typename... SetupFunc>
 void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
-    static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint>,
-                  "only point_constraint and hinge_constraint are on the accelerated path");
+    static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint> || std::is_same_v<T, distance_constraint> ||
+                      std::is_same_v<T, soft_distance_constraint>,
+                  "point, hinge, distance and soft_distance constraints are on the accelerated path");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     auto &con = registry.emplace<T>(entity);
     con.body = {body0, body1};

@@ -34,7 +34,7 @@
 namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
-enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3 };
 // ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
 // ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
 // EnTT pool history), exported by oracle/ref_world.cpp. With it the restatement and the reference agree bit for bit.
@@ -867,6 +867,36 @@ public:
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
+        if (j.type == JOINT_DISTANCE || j.type == JOINT_SOFT_DISTANCE) {
+            // distance_constraint.cpp:7-31 (params[0] = distance) / soft_distance_constraint.cpp:8-62 (distance, stiffness, damping)
+            vec3 d = pA - pB;
+            const float dist_sqr = length_sqr(d);
+            auto dir_row = [&](int n, vec3 dir, vec3 p, vec3 q, float lo, float hi, const RowOptions &o) {
+                Row &r = rows[n];
+                r.J[0] = dir; r.J[1] = p; r.J[2] = -dir; r.J[3] = -q;
+                r.lower = lo; r.upper = hi; r.impulse = j.impulse[n];
+                finish_row(r, o, A, B);
+                slot[n] = n;
+            };
+            if (j.type == JOINT_DISTANCE) {
+                if (!(dist_sqr > kEps)) d = vec3{1, 0, 0};
+                RowOptions o; o.error = 0.5f * (dist_sqr - j.params[0] * j.params[0]) / dt;
+                dir_row(0, d, cross(rA, d), cross(rB, d), -kLarge, kLarge, o);
+                return 1;
+            }
+            const float dist = std::sqrt(dist_sqr);
+            vec3 dn;
+            if (dist_sqr > kEps) dn = d / dist; else dn = vec3{1, 0, 0};
+            const vec3 p = cross(rA, dn), q = cross(rB, dn);
+            const float spring_impulse = j.params[1] * (j.params[0] - dist) * dt;
+            RowOptions os; os.error = spring_impulse > 0 ? -kLarge : kLarge;
+            dir_row(0, dn, p, q, std::min(spring_impulse, 0.0f), std::max(0.0f, spring_impulse), os);
+            const vec3 Jd[4] = {dn, p, -dn, -q};
+            const float relspd = relative_speed(Jd, A.linvel, A.angvel, B.linvel, B.angvel);
+            const float damping_impulse = j.params[2] * relspd * dt;
+            dir_row(1, dn, p, q, -std::fabs(damping_impulse), std::fabs(damping_impulse), RowOptions{});
+            return 2;
+        }
         mat3 sA = skew(rA), sB = skew(rB);
         int n = 0;
         for (int i = 0; i < 3; ++i) {
@@ -1230,7 +1260,7 @@ public:
             std::vector<FrictionRow> roll;
             std::vector<SpinRow> spin;
             std::vector<ContactPoint *> roll_cp, spin_cp;
-            for (int type : {JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: hinge ... point, contact
+            for (int type : {JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: distance, soft_distance, hinge ... point, contact
                 for (Joint *j : js) {
                     if (j->type != type) continue;
                     Row tmp[kMaxJointRows];

@@ -175,6 +175,14 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
             c.pivot[0] = v3(pivotA);
             c.pivot[1] = v3(pivotB);
         });
+    } else if (type == 2) {
+        e = edyn::make_constraint<edyn::distance_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::distance_constraint &c) {
+            c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
+        });
+    } else if (type == 3) {
+        e = edyn::make_constraint<edyn::soft_distance_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::soft_distance_constraint &c) {
+            c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
+        });
     } else {
         e = edyn::make_constraint<edyn::hinge_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::hinge_constraint &c) {
             c.pivot[0] = v3(pivotA);
@@ -202,6 +210,10 @@ void refw_set_joint_params(void *h, uint32_t joint, const float *p) {
         hc->reset_angle(ornA, ornB);
     } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(e)) {
         pc->friction_torque = p[0];
+    } else if (auto *dc = w->registry.try_get<edyn::distance_constraint>(e)) {
+        dc->distance = p[0];
+    } else if (auto *sc = w->registry.try_get<edyn::soft_distance_constraint>(e)) {
+        sc->distance = p[0]; sc->stiffness = p[1]; sc->damping = p[2];
     }
 }
 // registry.destroy on a rigid body / a constraint entity (the reference's hooks clean up edges, manifolds, islands:
@@ -403,6 +415,10 @@ void refw_get_joint_impulses(void *h, float *out10) {
         } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(w->joints[i])) {
             for (int k = 0; k < 3; ++k) o[k] = pc->applied_impulse[k];
             o[3] = pc->applied_friction_impulse;
+        } else if (auto *dc = w->registry.try_get<edyn::distance_constraint>(w->joints[i])) {
+            o[0] = dc->applied_impulse;
+        } else if (auto *sc = w->registry.try_get<edyn::soft_distance_constraint>(w->joints[i])) {
+            o[0] = sc->applied_spring_impulse; o[1] = sc->applied_damping_impulse;
         }
     }
 }

@@ -1032,3 +1032,20 @@ def test_capsules_bit_exact():
             assert_state_equal(g2, o2)
             assert np.array_equal(g2.get_point_extras().view(np.uint32), o2.get_point_extras().view(np.uint32)), s
     assert_state_equal(g2, o2)
+
+
+def test_distance_and_soft_distance_constraints_bit_exact():
+    """distance_constraint / soft_distance_constraint on the device (k_prep_joints rows along the pivot separation, impulse
+    limited spring row, damping row) against the oracle, joint impulses included; pinned to the real engine in
+    tests/test_reference_engine.py::test_distance_and_soft_distance_constraints_match_the_real_engine."""
+    from test_reference_engine import _distance_scene, _distance_setup
+    sc = _distance_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    _distance_setup(sc)(g); _distance_setup(sc)(o)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 30 == 0 or s < 3:
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert np.abs(g.get_joint_impulses()[kinds == scenes.JOINT_SOFT_DISTANCE][:, :2]).max() > 0

@@ -597,3 +597,36 @@ def test_capsule_rolling_friction_uses_the_roll_direction():
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {s}: {name} differs, max |d| = {np.abs(a - b).max()}"
     finally:
         ob.set_libm_trig(False)
+
+
+def _distance_scene():
+    """Chains whose links hang on distance / soft-distance constraints (mixed with the hinges and points of the C5 chains)."""
+    sc = scenes.c5_chains(4, 6)
+    joints = []
+    for i, j in enumerate(sc["joints"]):
+        jt = (scenes.JOINT_DISTANCE, scenes.JOINT_SOFT_DISTANCE, j[0])[i % 3]
+        joints.append((jt,) + tuple(j[1:]))
+    sc["joints"] = joints
+    return sc
+
+
+def _distance_setup(sc):
+    def setup(w):
+        for i, j in enumerate(sc["joints"]):
+            if j[0] == scenes.JOINT_DISTANCE:
+                w.set_joint_params(i, [0.1])
+            elif j[0] == scenes.JOINT_SOFT_DISTANCE:
+                w.set_joint_params(i, [0.15, 400.0, 3.0])
+    return setup
+
+
+def test_distance_and_soft_distance_constraints_match_the_real_engine():
+    """distance_constraint.cpp:7-35 (one row along the unnormalised separation, error 0.5 (d^2 - L^2) / dt) and
+    soft_distance_constraint.cpp:8-67 (spring row with impulse limits and +-large error, damping row), their applied
+    impulses, and their place in the constraint order (constraint.hpp:23-34: before hinges and points) - bit-identical."""
+    sc = _distance_scene()
+    ref, _ = _joint_lockstep(sc, 300, _distance_setup(sc))
+    ji = ref.get_joint_impulses()
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert np.abs(ji[kinds == scenes.JOINT_DISTANCE][:, 0]).max() > 0
+    assert np.abs(ji[kinds == scenes.JOINT_SOFT_DISTANCE][:, :2]).max() > 0
