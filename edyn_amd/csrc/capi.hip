@@ -116,7 +116,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, j.orig, nj)); EH_TRY(dalloc(c, j.type, nj)); EH_TRY(dalloc(c, j.bodyA, nj)); EH_TRY(dalloc(c, j.bodyB, nj));
     EH_TRY(dalloc(c, j.pivA, nj)); EH_TRY(dalloc(c, j.pivB, nj)); EH_TRY(dalloc(c, j.axA, nj)); EH_TRY(dalloc(c, j.pA, nj));
     EH_TRY(dalloc(c, j.qA, nj)); EH_TRY(dalloc(c, j.axB, nj)); EH_TRY(dalloc(c, j.pB, nj)); EH_TRY(dalloc(c, j.impulse, (size_t)nj * kJointSlots));
-    EH_TRY(dalloc(c, j.params, (size_t)nj * kJointParams)); EH_TRY(dalloc(c, j.angle, nj)); EH_TRY(dalloc(c, j.rmask, nj));
+    EH_TRY(dalloc(c, j.wbx, nj)); EH_TRY(dalloc(c, j.params, (size_t)nj * kJointParams)); EH_TRY(dalloc(c, j.angle, nj)); EH_TRY(dalloc(c, j.rmask, nj));
     EH_TRY(dalloc(c, j.rA, nj)); EH_TRY(dalloc(c, j.rB, nj)); EH_TRY(dalloc(c, j.wp, nj)); EH_TRY(dalloc(c, j.wq, nj)); EH_TRY(dalloc(c, j.wax, nj));
     EH_TRY(dalloc(c, j.eff, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.rhs, (size_t)nj * kJointSlots));
     EH_TRY(dalloc(c, j.lo, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.hi, (size_t)nj * kJointSlots));
@@ -699,6 +699,10 @@ static int rebuild_joints(edynhip_ctx *c, bool fetch) {
             plane_space_h(h.axis + 3, p3, q3);
             axB[p] = make_float4(h.axis[3], h.axis[4], h.axis[5], 0); pB[p] = make_float4(p3[0], p3[1], p3[2], 0);
             rows += 5;
+        } else if (h.has_frames) {   // cone / cvjoint: full frames (column k of a row-major 3x3 = elements k, 3 + k, 6 + k)
+            auto col = [&](int f, int k) { return make_float4(h.frame[9 * f + k], h.frame[9 * f + 3 + k], h.frame[9 * f + 6 + k], 0); };
+            axA[p] = col(0, 0); pA[p] = col(0, 1); qA[p] = col(0, 2); axB[p] = col(1, 0); pB[p] = col(1, 1);
+            rows += h.type == EDYNHIP_JOINT_CVJOINT ? 9 : 2;
         } else rows += 3;
         for (int k = 0; k < kJointParams; ++k) params[(size_t)k * j.cap + p] = h.params[k];
         for (int r = 0; r < kJointSlots; ++r) impulse[(size_t)r * j.cap + p] = h.impulse[r];
@@ -734,13 +738,19 @@ static int append_host_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *
         HostJoint h;
         h.type = in->type[e]; h.body[0] = in->body[2 * e]; h.body[1] = in->body[2 * e + 1];
         if (h.body[0] >= c->b.n || h.body[1] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": body index out of range").c_str());
-        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_SOFT_DISTANCE) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
+        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_CVJOINT) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
         std::memcpy(h.pivot, in->pivot + 6 * e, sizeof(h.pivot));
         if (h.type == EDYNHIP_JOINT_HINGE) {
             if (!in->axis) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": hinge needs axes").c_str());
             std::memcpy(h.axis, in->axis + 6 * e, sizeof(h.axis));
         }
-        if (in->params) std::memcpy(h.params, in->params + (size_t)kJointParams * e, sizeof(h.params));
+        if (in->params) std::memcpy(h.params, in->params + (size_t)kJointApiParams * e, sizeof(float) * kJointApiParams);
+        if (h.type == EDYNHIP_JOINT_CONE || h.type == EDYNHIP_JOINT_CVJOINT) {   // identity frames, an open cone, until edynhip_set_joint_definition
+            const float id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(h.frame, id, sizeof(id)); std::memcpy(h.frame + 9, id, sizeof(id));
+            h.has_frames = true;
+            if (h.type == EDYNHIP_JOINT_CONE && !(h.params[0] > 0 && h.params[1] > 0)) { h.params[0] = 1; h.params[1] = 1; }
+        }
         c->host_joints.push_back(h);
     }
     return EDYNHIP_OK;
@@ -801,11 +811,23 @@ int edynhip_remove_joints(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
     EH_TRY(rebuild_joints(c, false));
     return wake_islands_of(c, touched);   // destroying an edge wakes its island (island_manager.cpp:74-97)
 }
+static int redefine_joint(edynhip_ctx *c, uint32_t joint, const float *params, int nparams, const float *frameA, const float *frameB);
 int edynhip_set_joint_params(edynhip_ctx *c, uint32_t joint, const float *params) {
     if (!c || !params || joint >= c->host_joints.size() || !c->host_joints[joint].alive) return EDYNHIP_ERR_INVALID;
+    return redefine_joint(c, joint, params, kJointApiParams, nullptr, nullptr);
+}
+int edynhip_set_joint_definition(edynhip_ctx *c, uint32_t joint, const float *frameA, const float *frameB, const float *params16) {
+    if (!c || !params16 || !frameA || !frameB || joint >= c->host_joints.size() || !c->host_joints[joint].alive) return EDYNHIP_ERR_INVALID;
+    const int t = c->host_joints[joint].type;
+    if (t != EDYNHIP_JOINT_CONE && t != EDYNHIP_JOINT_CVJOINT) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joint_definition: cone and cvjoint constraints only");
+    if (t == EDYNHIP_JOINT_CONE && !(params16[0] > 0 && params16[1] > 0)) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joint_definition: cone span tangents must be positive");
+    return redefine_joint(c, joint, params16, kJointParams, frameA, frameB);
+}
+static int redefine_joint(edynhip_ctx *c, uint32_t joint, const float *params, int nparams, const float *frameA, const float *frameB) {
     EH_HIP(c, hipSetDevice(c->device));
     EH_TRY(rebuild_joints(c, true));
-    std::memcpy(c->host_joints[joint].params, params, sizeof(float) * kJointParams);
+    std::memcpy(c->host_joints[joint].params, params, sizeof(float) * nparams);
+    if (frameA) { std::memcpy(c->host_joints[joint].frame, frameA, 9 * sizeof(float)); std::memcpy(c->host_joints[joint].frame + 9, frameB, 9 * sizeof(float)); c->host_joints[joint].has_frames = true; }
     EH_TRY(rebuild_joints(c, false));
     // reset_angle for this joint only
     std::vector<uint32_t> orig(c->j.n);

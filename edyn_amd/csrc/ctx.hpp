@@ -87,7 +87,7 @@ __device__ __forceinline__ void emit_event(const EventSink &ev, uint32_t type, u
 // Joint rows live in SLOTS that mirror the constraints' applied_impulse fields (hinge_constraint.hpp:64-71,
 // point_constraint.hpp:28-29): hinge 0..2 linear, 3..4 hinge p/q, 5 limit, 6 bump stop, 7 spring, 8 torque; point 0..2 linear,
 // 3 friction torque. Which optional slots carry a row this step is decided by k_prep_joints (rmask).
-constexpr int kJointSlots = 9, kJointParams = 10;
+constexpr int kJointSlots = 9, kJointParams = 16, kJointApiParams = 10;   // edynhip_joints.params / set_joint_params carry the first 10
 struct Joints {
     uint32_t n = 0, cap = 0, num_colours = 0, rows = 0;
     // definitions, in colour-sorted order; orig[] maps back to the caller's index
@@ -105,6 +105,7 @@ struct Joints {
     float4 *rA = nullptr, *rB = nullptr;            // lever arms
     float4 *wp = nullptr, *wq = nullptr;            // world hinge p, q
     float4 *wax = nullptr;                          // world axis of the optional rows (hinge axis / relative spin direction)
+    float4 *wbx = nullptr;                          // cvjoint: axis of the bend-spring row (slot 8)
     float *eff = nullptr, *rhs = nullptr;           // [kJointSlots][cap]
     float *lo = nullptr, *hi = nullptr;             // [kJointSlots][cap] impulse limits of the optional rows
     uint32_t *rmask = nullptr;                      // [cap] slots that carry a row this step
@@ -116,6 +117,8 @@ struct HostJoint {
     int32_t type = 0;
     uint32_t body[2] = {0, 0};
     float pivot[6] = {0}, axis[6] = {0};
+    float frame[18] = {0};        // cone / cvjoint: frames A and B, row-major 3x3 (edynhip_set_joint_definition)
+    bool has_frames = false;
     float params[kJointParams] = {0};
     float impulse[kJointSlots] = {0};
     float angle = 0;

@@ -45,6 +45,7 @@ DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DI float length_sqr(f3 a) { return dot(a, a); }
 DI float length(f3 a) { return sqrtf(length_sqr(a)); }
+DI f3 normalize(f3 a) { return a / length(a); }   // vector3.hpp:231-235 (true division)
 DI float distance_sqr(f3 a, f3 b) { return length_sqr(a - b); }
 DI f3 project_plane(f3 p, f3 q, f3 n) { return p - n * dot(p - q, n); }
 DI f3 lerp(f3 a, f3 b, float s) { return a * (1.0f - s) + b * s; }

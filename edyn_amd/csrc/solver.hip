@@ -1009,11 +1009,17 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
 // ------------------------------------------------------------------ joints (point, hinge)
 // Slot r of a joint (ctx.hpp Joints): 0..2 the three linear rows, hinge 3/4 the rows along p and q, every other slot an
 // axial row {0, ax, 0, -ax} along `wax` (hinge axis for slots 5..8 of a hinge, relative spin for slot 3 of a point joint).
-DI void joint_rowJ(int type, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
+DI void joint_rowJ(int type, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 wbx, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
     const bool hinge = type == EDYNHIP_JOINT_HINGE;
-    if (type == EDYNHIP_JOINT_DISTANCE || type == EDYNHIP_JOINT_SOFT_DISTANCE) {
-        // every row of the distance constraints runs along the pivot separation (kept in wp; wq, wax = rA x d, rB x d)
+    if (type == EDYNHIP_JOINT_DISTANCE || type == EDYNHIP_JOINT_SOFT_DISTANCE || type == EDYNHIP_JOINT_CONE) {
+        // every row of the distance constraints runs along the pivot separation, of the cone along the cone normal
+        // (kept in wp; wq, wax = the two lever arms crossed with it)
         J0 = wp; J1 = wq; J2 = -wp; J3 = -wax;
+    } else if (type == EDYNHIP_JOINT_CVJOINT && r >= 3) {
+        // twist rows 3..6: {0, twist axis of A (wp), 0, -twist axis of B (wq)}; 7: bend friction axis (wax); 8: bend spring axis (wbx)
+        J0 = mk3(0, 0, 0); J2 = mk3(0, 0, 0);
+        if (r < 7) { J1 = wp; J3 = -wq; }
+        else { const f3 ax = r == 7 ? wax : wbx; J1 = ax; J3 = -ax; }
     } else if (r < 3) {
         // J = {I.row[i], -skew(rA).row[i], -I.row[i], skew(rB).row[i]}
         f3 e = r == 0 ? mk3(1, 0, 0) : (r == 1 ? mk3(0, 1, 0) : mk3(0, 0, 1));
@@ -1034,6 +1040,30 @@ DI float normalize_angle(float a) {   // math.hpp:53-63
     if (a > kPi) return a - kPi2;
     return a;
 }
+// cvjoint_constraint.cpp:25-37 relative twist angle; quaternion.cpp:25-38 shortest_arc
+DI q4 shortest_arc(f3 v0, f3 v1) {
+    const f3 c = cross(v0, v1);
+    const float d = dot(v0, v1);
+    if (d <= -1 + kEps) {
+        f3 n, m;
+        plane_space(v0, n, m);
+        return q4{n.x, n.y, n.z, 0};
+    }
+    const float s = sqrtf((1 + d) * 2);
+    const float rs = 1 / s;
+    return normalize(q4{c.x * rs, c.y * rs, c.z * rs, s * 0.5f});
+}
+DI float cvjoint_relative_angle(q4 ornA, q4 ornB, f3 tA, f3 tB, f3 colA1, f3 colA2, f3 colB1) {
+    const q4 arc = shortest_arc(tB, tA);
+    const f3 angle_axisB = rotate(conjugate(ornA) * arc * ornB, colB1);
+    return atan2_cr(dot(angle_axisB, colA2), dot(angle_axisB, colA1));
+}
+DI float track_angle(float tracked, float new_angle) {   // update_angle (hinge_constraint.cpp:80-89, cvjoint_constraint.cpp:39-47)
+    const float previous = normalize_angle(tracked);
+    const float d0 = new_angle - previous;
+    const float d1 = d0 + kPi2 * (d0 < 0 ? 1.0f : -1.0f);
+    return tracked + (fabsf(d0) < fabsf(d1) ? d0 : d1);
+}
 __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= j.n) return;
@@ -1044,7 +1074,8 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     const f3 rA = pA - A.pos, rB = pB - B.pos;
     const int type = j.type[i];
     const bool hinge = type == EDYNHIP_JOINT_HINGE;
-    f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0), wax = mk3(0, 0, 0);
+    f3 wp = mk3(0, 0, 0), wq = mk3(0, 0, 0), wax = mk3(0, 0, 0), wbx = mk3(0, 0, 0);
+    f3 rAx = rA, rBx = rB;   // lever arms stored for the solve kernel (the cone's A arm ends on the cone, not at its pivot)
     if (hinge) { wp = rotate(A.orn, from4(j.pA[i])); wq = rotate(A.orn, from4(j.qA[i])); }
     auto P = [&](int k) { return j.params[(size_t)k * j.cap + i]; };
     uint32_t mask = hinge ? 0x1Fu : 0x7u;
@@ -1052,7 +1083,114 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     float err[kJointSlots], rest[kJointSlots], lo[kJointSlots], hi[kJointSlots];
 #pragma unroll
     for (int r = 0; r < kJointSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
-    if (type == EDYNHIP_JOINT_DISTANCE) {   // distance_constraint.cpp:7-31
+    if (type == EDYNHIP_JOINT_CONE) {   // cone_constraint.cpp:12-95
+        const f3 fx = from4(j.axA[i]), fy = from4(j.pA[i]), fz = from4(j.qA[i]);   // columns of the frame in A
+        const m3 frame = m3_columns(fx, fy, fz);
+        const f3 pivA = from4(j.pivA[i]);
+        const f3 pivotB_in_A = to_object(pB, A.pos, A.orn);
+        const f3 pf = to_object(pivotB_in_A, pivA, frame);
+        const float scaling_y = 1.0f / P(0), scaling_z = 1.0f / P(1);
+        const f3 ps = pf * mk3(1, scaling_y, scaling_z);
+        const float proj = ps.y * ps.y + ps.z * ps.z;
+        f3 normal_scaled, tangent_scaled;
+        if (proj > kEps) {
+            normal_scaled = normalize(mk3(-sqrtf(proj), ps.y, ps.z));
+            tangent_scaled = normalize(mk3(0, -ps.z, ps.y));
+        } else {
+            normal_scaled = normalize(mk3(-1, 1, 0));
+            tangent_scaled = normalize(mk3(0, 0, 1));
+        }
+        const float error = dot(ps, normal_scaled);
+        const f3 dir_on_cone = mk3(-normal_scaled.x, normal_scaled.y, normal_scaled.z);
+        const float cone_proj = dot(ps, dir_on_cone);
+        const f3 descale = mk3(1, 1 / scaling_y, 1 / scaling_z);
+        const f3 point_on_cone = (dir_on_cone * cone_proj) * descale;
+        const f3 pivotA_world = to_world(pivA + mul(frame, point_on_cone), A.pos, A.orn);
+        const f3 tangent = normalize(tangent_scaled * descale);
+        const f3 normal = normalize(cross(tangent, point_on_cone));
+        const f3 nw = rotate(A.orn, mul(frame, normal));
+        rAx = pivotA_world - A.pos;
+        wp = nw; wq = cross(rAx, nw); wax = cross(rB, nw);
+        err[0] = -error / dt; rest[0] = P(2); lo[0] = 0; hi[0] = kLarge;
+        mask = 0x1u;
+        if (P(3) > 0 && P(4) > 0) {
+            const float deflection = P(4) + error;
+            const float spring_impulse = P(3) * deflection * dt;
+            lo[1] = 0; hi[1] = fmaxf(0.0f, spring_impulse);
+            err[1] = -deflection / dt;
+            mask = 0x3u;
+        }
+    } else if (type == EDYNHIP_JOINT_CVJOINT) {   // cvjoint_constraint.cpp:49-222
+        const float twist_min = P(0), twist_max = P(1), twist_restitution = P(2), bump_angle = P(3), bump_stiffness = P(4),
+                    twist_friction_torque = P(5), twist_rest_angle = P(6), twist_stiffness = P(7), twist_damping = P(8),
+                    bend_stiffness = P(12), bend_friction_torque = P(13), bend_damping = P(14);
+        const f3 tA = rotate(A.orn, from4(j.axA[i])), tB = rotate(B.orn, from4(j.axB[i]));
+        wp = tA; wq = tB;
+        lo[0] = lo[1] = lo[2] = -kLarge; hi[0] = hi[1] = hi[2] = kLarge;
+        mask = 0xFu;   // three pivot rows (no error term: cvjoint leaves the pivots to its position solve) + the twist row
+        const bool has_limit = twist_min < twist_max;
+        float angle = j.angle[i];
+        lo[3] = -kLarge; hi[3] = kLarge;
+        if (has_limit) {
+            const float current = cvjoint_relative_angle(A.orn, B.orn, tA, tB, from4(j.pA[i]), from4(j.qA[i]), from4(j.pB[i]));
+            angle = track_angle(angle, current);
+            j.angle[i] = angle;
+            float limit_error;
+            const float mid = (twist_min + twist_max) / 2.0f;
+            if (angle < mid) { limit_error = twist_min - angle; lo[3] = -kLarge; hi[3] = 0; }
+            else { limit_error = twist_max - angle; lo[3] = 0; hi[3] = kLarge; }
+            if (angle > twist_min && angle < twist_max) err[3] = limit_error / dt;
+            rest[3] = twist_restitution;
+        }
+        if (has_limit && bump_stiffness > 0 && bump_angle > 0) {
+            float defl = 0;
+            const float bmin = twist_min + bump_angle, bmax = twist_max - bump_angle;
+            if (angle < bmin) defl = angle - bmin;
+            else if (angle > bmax) defl = angle - bmax;
+            const float imp = bump_stiffness * defl * dt;
+            lo[4] = fminf(imp, 0.0f); hi[4] = fmaxf(0.0f, imp);
+            err[4] = -defl / dt;
+            mask |= 1u << 4;
+        }
+        if (has_limit && twist_stiffness > 0) {
+            const float defl = angle - twist_rest_angle;
+            const float imp = twist_stiffness * defl * dt;
+            lo[5] = fminf(imp, 0.0f); hi[5] = fmaxf(0.0f, imp);
+            err[5] = -defl / dt;
+            mask |= 1u << 5;
+        }
+        if (has_limit && (twist_friction_torque > 0 || twist_damping > 0)) {
+            float fi = twist_friction_torque * dt;
+            if (twist_damping > 0) {
+                const float relvel = dot(A.w, tA) - dot(B.w, tB);
+                fi += fabsf(relvel) * twist_damping * dt;
+            }
+            lo[6] = -fi; hi[6] = fi;
+            mask |= 1u << 6;
+        }
+        if (bend_friction_torque > 0 || bend_damping > 0) {
+            const f3 twA = dot(A.w, tA) * tA, twB = dot(B.w, tB) * tB;
+            const f3 angvel_rel = (A.w - twA) - (B.w - twB);
+            const float angspd_rel = sqrtf(length_sqr(angvel_rel));
+            wax = angspd_rel > kEps ? angvel_rel / angspd_rel : rotate(A.orn, from4(j.pA[i]));
+            float fi = bend_friction_torque * dt;
+            if (twist_damping > 0) fi += fabsf(angspd_rel) * bend_damping * dt;   // (the reference tests twist_damping here, :199)
+            lo[7] = -fi; hi[7] = fi;
+            mask |= 1u << 7;
+        }
+        if (bend_stiffness > 0) {
+            f3 bend_axis = cross(rotate(A.orn, mk3(P(9), P(10), P(11))), tB);
+            const float len = sqrtf(length_sqr(bend_axis));
+            const float bend_angle = (float)asin((double)len);   // correctly rounded, like atan2_cr
+            if (len > kEps) bend_axis = div_recip(bend_axis, len);
+            else bend_axis = rotate(A.orn, from4(j.pA[i]));
+            wbx = bend_axis;
+            const float imp = bend_stiffness * bend_angle * dt;
+            lo[8] = fminf(imp, 0.0f); hi[8] = fmaxf(0.0f, imp);
+            err[8] = -bend_angle / dt;
+            mask |= 1u << 8;
+        }
+    } else if (type == EDYNHIP_JOINT_DISTANCE) {   // distance_constraint.cpp:7-31
         f3 d = pA - pB;
         const float dist_sqr = length_sqr(d);
         if (!(dist_sqr > kEps)) d = mk3(1, 0, 0);
@@ -1140,13 +1278,13 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
             mask |= 1u << 8;
         }
     }
-    j.rA[i] = to4(rA, 0); j.rB[i] = to4(rB, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0); j.wax[i] = to4(wax, 0);
+    j.rA[i] = to4(rAx, 0); j.rB[i] = to4(rBx, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0); j.wax[i] = to4(wax, 0); j.wbx[i] = to4(wbx, 0);
     j.rmask[i] = mask;
 #pragma unroll
     for (int r = 0; r < kJointSlots; ++r) {
         if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(type, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
+        joint_rowJ(type, r, rAx, rBx, wp, wq, wax, wbx, J0, J1, J2, J3);
         const float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
         const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
         const size_t s = (size_t)r * j.cap + i;
@@ -1163,13 +1301,13 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;
     Delta d;
     load_delta(b, ia, ib, d);
-    const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]);
+    const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]), wbx = from4(j.wbx[i]);
     const int type = j.type[i];
     const uint32_t mask = j.rmask[i];
     for (int r = 0; r < kJointSlots; ++r) {
         if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
-        joint_rowJ(type, r, rA, rB, wp, wq, wax, J0, J1, J2, J3);
+        joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
         const size_t s = (size_t)r * j.cap + i;
         float imp = j.impulse[s];
         if (WARM) {
@@ -1190,8 +1328,13 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
 // hinge_constraint::reset_angle (hinge_constraint.cpp:19-24) for the joints whose definition was just (re)written
 __global__ void k_joint_reset_angle(Joints j, Bodies b, const uint8_t *__restrict__ which) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= j.n || !which[i] || j.type[i] != EDYNHIP_JOINT_HINGE) return;
+    if (i >= j.n || !which[i] || (j.type[i] != EDYNHIP_JOINT_HINGE && j.type[i] != EDYNHIP_JOINT_CVJOINT)) return;
     const q4 ornA = q_from4(B_ORN(b, j.bodyA[i])), ornB = q_from4(B_ORN(b, j.bodyB[i]));
+    if (j.type[i] == EDYNHIP_JOINT_CVJOINT) {   // cvjoint_constraint::reset_angle, cvjoint_constraint.cpp:12-23
+        j.angle[i] = cvjoint_relative_angle(ornA, ornB, rotate(ornA, from4(j.axA[i])), rotate(ornB, from4(j.axB[i])),
+                                            from4(j.pA[i]), from4(j.qA[i]), from4(j.pB[i]));
+        return;
+    }
     const f3 p = rotate(ornA, from4(j.pA[i])), q = rotate(ornA, from4(j.qA[i]));
     const f3 angle_axisB = rotate(ornB, from4(j.pB[i]));
     j.angle[i] = atan2_cr(dot(angle_axisB, q), dot(angle_axisB, p));
@@ -1569,8 +1712,8 @@ k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl
 }
 __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
     const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
-    // point_constraint has no solve_position (island_solver.cpp:252-260)
-    bool active = i < end && j.type[i] == EDYNHIP_JOINT_HINGE;
+    // point, distance and cone constraints have no solve_position (island_solver.cpp:252-260)
+    bool active = i < end && (j.type[i] == EDYNHIP_JOINT_HINGE || j.type[i] == EDYNHIP_JOINT_CVJOINT);
     if (active && edge_asleep(b.flags[j.bodyA[i]], b.flags[j.bodyB[i]])) active = false;
     uint32_t label = 0;
     float max_err = 0;
@@ -1580,6 +1723,21 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     label = b.island[A.proc ? ia : ib];
     active = isl_done[label] == 0;
     if (active) {
+    if (j.type[i] == EDYNHIP_JOINT_CVJOINT) {   // cvjoint_constraint.cpp:224-246: angular correction along the twist axes
+        const f3 tA = rotate(A.orn, from4(j.axA[i])), tB = rotate(B.orn, from4(j.axB[i]));
+        const float current = cvjoint_relative_angle(A.orn, B.orn, tA, tB, from4(j.pA[i]), from4(j.qA[i]), from4(j.pB[i]));
+        const float twist_min = j.params[i], twist_max = j.params[(size_t)j.cap + i];
+        float twist_error = 0;
+        if (twist_min < twist_max) {
+            const float angle = track_angle(j.angle[i], current);
+            j.angle[i] = angle;
+            if (angle < twist_min) twist_error = angle - twist_min;
+            else if (angle > twist_max) twist_error = angle - twist_max;
+        } else {
+            twist_error = current;
+        }
+        pos_solve(A, B, mk3(0, 0, 0), tA, mk3(0, 0, 0), -tB, twist_error, max_err);
+    } else {
     const f3 axisA = rotate(A.orn, from4(j.axA[i])), axisB = rotate(B.orn, from4(j.axB[i]));
     f3 pp, qq;
     plane_space(axisA, pp, qq);
@@ -1588,6 +1746,7 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     if (fabsf(e) > kEps) pos_solve(A, B, mk3(0, 0, 0), pp, mk3(0, 0, 0), -pp, e, max_err);
     e = dot(u, qq);
     if (fabsf(e) > kEps) pos_solve(A, B, mk3(0, 0, 0), qq, mk3(0, 0, 0), -qq, e, max_err);
+    }
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     f3 dir = pA - pB;
     const float err = length(dir);

@@ -17,7 +17,7 @@ from ._capi import EdynHipError, MANIFOLD_DTYPE
 
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2          # rigidbody_kind
 SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE = 0, 1, 2, 3, 4
-JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE = 0, 1, 2, 3
+JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT = 0, 1, 2, 3, 4, 5
 ALL_GROUPS = 2**64 - 1                                       # collision_filter::all_groups
 
 
@@ -210,6 +210,13 @@ class World:
         self._flush_defs()
         p = np.zeros(10, np.float32); p[:len(params)] = params
         self._check(self._L.edynhip_set_joint_params(self._h, int(joint), _ptr(p)))
+
+    def set_joint_definition(self, joint, frameA, frameB, params):
+        """Frames (3x3, first column = cone direction / twist axis) and parameters of a cone or cvjoint constraint (edynhip.h)."""
+        self._flush_defs()
+        p = np.zeros(16, np.float32); p[:len(params)] = params
+        fa = np.ascontiguousarray(np.asarray(frameA, np.float32).reshape(9)); fb = np.ascontiguousarray(np.asarray(frameB, np.float32).reshape(9))
+        self._check(self._L.edynhip_set_joint_definition(self._h, int(joint), _ptr(fa), _ptr(fb), _ptr(p)))
 
     def remove_bodies(self, indices):
         """registry.destroy(rigid body) on a running world: manifolds and joints of the body go with it, its index stays reserved."""

@@ -111,6 +111,21 @@ struct soft_distance_constraint : constraint_base {                             
     std::array<vector3, 2> pivot;
     scalar distance{0}, stiffness{scalar(1e10)}, damping{scalar(1e10)};
 };
+inline constexpr matrix3x3 matrix3x3_identity{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}};
+struct cone_constraint : constraint_base {                                                    // constraints/cone_constraint.hpp:19-49
+    std::array<vector3, 2> pivot;
+    matrix3x3 frame{matrix3x3_identity};   // in body 0; first column = the cone direction
+    std::array<scalar, 2> span_tan{1, 1};
+    scalar restitution{}, bump_stop_stiffness{}, bump_stop_length{};
+};
+struct cvjoint_constraint : constraint_base {                                                 // constraints/cvjoint_constraint.hpp:20-102
+    std::array<vector3, 2> pivot;
+    std::array<matrix3x3, 2> frame{matrix3x3_identity, matrix3x3_identity};   // first column = the twist axis
+    scalar twist_min{}, twist_max{}, twist_restitution{}, twist_bump_stop_angle{}, twist_bump_stop_stiffness{}, twist_friction_torque{},
+           twist_rest_angle{}, twist_stiffness{}, twist_damping{};
+    vector3 rest_direction{};
+    scalar bend_stiffness{}, bend_friction_torque{}, bend_damping{};
+};
 struct hinge_constraint : constraint_base {                                                   // constraints/hinge_constraint.hpp:22-93
     std::array<vector3, 2> pivot;
     std::array<vector3, 2> axis{vector3{1, 0, 0}, vector3{1, 0, 0}};
@@ -198,7 +213,9 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
         else if (auto *dc = registry.try_get<distance_constraint>(e)) { jt[j] = EDYNHIP_JOINT_DISTANCE; fill(*dc, dc->pivot); jq[10 * j] = dc->distance; }
         else if (auto *sc = registry.try_get<soft_distance_constraint>(e)) {
             jt[j] = EDYNHIP_JOINT_SOFT_DISTANCE; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
-        } else {
+        } else if (auto *cc = registry.try_get<cone_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CONE; fill(*cc, cc->pivot); }      // frames / parameters follow
+        else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CVJOINT; fill(*cv, cv->pivot); }  // (define_frames below)
+        else {
             auto &hc = registry.get<hinge_constraint>(e);
             jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
             for (int k = 0; k < 2; ++k) { ja[6 * j + 3 * k] = hc.axis[k].x; ja[6 * j + 3 * k + 1] = hc.axis[k].y; ja[6 * j + 3 * k + 2] = hc.axis[k].z; }
@@ -302,6 +319,25 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         uint32_t first_joint = 0;
         check(s, edynhip_add_joints(s.ctx, nj - s.uploaded_constraints, &js, &first_joint));
     }
+    // frames and parameter blocks of the cone / cvjoint constraints that went up just now
+    for (uint32_t j = (first == 0 ? 0u : s.uploaded_constraints); j < nj; ++j) {
+        const entt::entity e = s.constraints[j];
+        if (e == entt::null) continue;
+        auto rows9 = [](const matrix3x3 &m, float *o) { for (int r = 0; r < 3; ++r) { o[3 * r] = m.row[r].x; o[3 * r + 1] = m.row[r].y; o[3 * r + 2] = m.row[r].z; } };
+        float fa[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, fb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, q[16] = {0};
+        if (auto *cc = registry.try_get<cone_constraint>(e)) {
+            rows9(cc->frame, fa);
+            q[0] = cc->span_tan[0]; q[1] = cc->span_tan[1]; q[2] = cc->restitution; q[3] = cc->bump_stop_stiffness; q[4] = cc->bump_stop_length;
+            check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
+        } else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) {
+            rows9(cv->frame[0], fa); rows9(cv->frame[1], fb);
+            const float v[15] = {cv->twist_min, cv->twist_max, cv->twist_restitution, cv->twist_bump_stop_angle, cv->twist_bump_stop_stiffness,
+                                 cv->twist_friction_torque, cv->twist_rest_angle, cv->twist_stiffness, cv->twist_damping,
+                                 cv->rest_direction.x, cv->rest_direction.y, cv->rest_direction.z, cv->bend_stiffness, cv->bend_friction_torque, cv->bend_damping};
+            for (int k = 0; k < 15; ++k) q[k] = v[k];
+            check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
+        }
+    }
     if (!dead_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)dead_joints.size(), dead_joints.data()));
     s.uploaded_constraints = nj;
     for (auto &ex : s.pending_exclusions) check(s, edynhip_exclude_collision(s.ctx, ex[0], ex[1]));
@@ -365,17 +401,19 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
     for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
         const entt::entity e = s.constraints[j];
         if (e == entt::null) continue;
-        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint>(e);
+        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint>(e);
         if (alive) {   // a joint whose body was destroyed goes with it
             const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
                                       : registry.all_of<distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<distance_constraint>(e))
                                       : registry.all_of<soft_distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<soft_distance_constraint>(e))
+                                      : registry.all_of<cone_constraint>(e) ? static_cast<constraint_base &>(registry.get<cone_constraint>(e))
+                                      : registry.all_of<cvjoint_constraint>(e) ? static_cast<constraint_base &>(registry.get<cvjoint_constraint>(e))
                                       : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
             for (int k = 0; k < 2; ++k) if (!registry.valid(cb.body[k]) || !registry.all_of<body_index>(cb.body[k])) alive = false;
         }
         if (!alive) {
             s.constraints[j] = entt::null;
-            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint>(e)) registry.destroy(e);   // its body is gone
             if (j < s.uploaded_constraints) gone_joints.push_back(j);
         }
     }
@@ -671,8 +709,8 @@ inline entt::entity make_rigidbody(entt::registry &registry, const rigidbody_def
 template <typename T, typename... SetupFunc>
 void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
     static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint> || std::is_same_v<T, distance_constraint> ||
-                      std::is_same_v<T, soft_distance_constraint>,
-                  "point, hinge, distance and soft_distance constraints are on the accelerated path");
+                      std::is_same_v<T, soft_distance_constraint> || std::is_same_v<T, cone_constraint> || std::is_same_v<T, cvjoint_constraint>,
+                  "point, hinge, distance, soft_distance, cone and cvjoint constraints are on the accelerated path");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     auto &con = registry.emplace<T>(entity);
     con.body = {body0, body1};

@@ -52,7 +52,9 @@ enum { EDYNHIP_SHAPE_NONE = 0, EDYNHIP_SHAPE_BOX = 1, EDYNHIP_SHAPE_SPHERE = 2, 
        EDYNHIP_SHAPE_CAPSULE = 4 /* shape_param = radius, half_length, axis (0 x, 1 y, 2 z): shapes/capsule_shape.hpp:17-30 */ };
 enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_DISTANCE = 2,       /* distance_constraint.cpp:7-31; params[0] = distance; impulse slot 0 */
-       EDYNHIP_JOINT_SOFT_DISTANCE = 3   /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */ };
+       EDYNHIP_JOINT_SOFT_DISTANCE = 3,  /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */
+       EDYNHIP_JOINT_CONE = 4,           /* cone_constraint.cpp:12-104; frames + params through edynhip_set_joint_definition */
+       EDYNHIP_JOINT_CVJOINT = 5         /* cvjoint_constraint.cpp:12-302; frames + params through edynhip_set_joint_definition */ };
 /* contact_normal_attachment (include/edyn/collision/contact_normal_attachment.hpp:17-21) */
 enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2 };
 
@@ -237,6 +239,17 @@ int edynhip_get_pairs(edynhip_ctx *ctx, uint64_t *keys, uint32_t capacity, uint3
 /* Per joint (by caller index, removed joints read 0) 10 floats: the applied impulses by slot - hinge: linear[3], hinge[2], limit,
  * bump_stop, spring, torque; point: applied[3], friction - and the tracked hinge angle (hinge_constraint.hpp:62-71). */
 int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses10);
+
+/* Frames (row-major 3x3, first COLUMN = the cone direction / the twist axis) and the parameter block of a cone or cvjoint
+ * constraint (created with identity frames by edynhip_set_joints / add_joints); resets the cvjoint's twist angle.
+ *   cone   : span_tan[0], span_tan[1], restitution, bump_stop_stiffness, bump_stop_length (cone_constraint.hpp:19-49);
+ *            impulse slots: 0 limit, 1 bump stop. frame_b is ignored.
+ *   cvjoint: twist_min, twist_max, twist_restitution, twist_bump_stop_angle, twist_bump_stop_stiffness, twist_friction_torque,
+ *            twist_rest_angle, twist_stiffness, twist_damping, rest_direction[3], bend_stiffness, bend_friction_torque,
+ *            bend_damping (cvjoint_constraint.hpp:20-102); impulse slots: 0..2 linear, 3 twist limit, 4 twist bump stop,
+ *            5 twist spring, 6 twist friction / damping, 7 bend friction / damping, 8 bend spring; [9] of
+ *            edynhip_get_joint_impulses = the tracked twist angle. */
+int edynhip_set_joint_definition(edynhip_ctx *ctx, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params16);
 
 /* contact_extras materials: material::{spin_friction, roll_friction, stiffness, damping} of bodies [first, first + n)
  * (comp/material.hpp:15-22; any array may be NULL = the default 0, 0, large_scalar, large_scalar). Contact points created

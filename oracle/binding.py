@@ -23,7 +23,7 @@ MANIFOLD_DTYPE = np.dtype([
 
 SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
-JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE = 0, 1, 2, 3
+JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT = 0, 1, 2, 3, 4, 5
 ORDER_SEQUENTIAL, ORDER_COLOURED, ORDER_EXTERNAL = 0, 1, 2
 
 
@@ -389,6 +389,11 @@ class World:
         f = self.L.orc_set_joint_params; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
         f(self.h, joint, _fp(p))
 
+    def set_joint_definition(self, joint, frameA, frameB, params):
+        p = np.zeros(16, np.float32); p[:len(params)] = params
+        f = self.L.orc_set_joint_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
+        f(self.h, joint, _fp(_f32(np.asarray(frameA).ravel(), 9)), _fp(_f32(np.asarray(frameB).ravel(), 9)), _fp(p))
+
     def remove_body(self, body):
         f = self.L.orc_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
         f(self.h, body)
@@ -554,6 +559,11 @@ class RefWorld:
     def remove_body(self, body):
         f = self.L.refw_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
         f(self.h, body)
+
+    def set_joint_definition(self, joint, frameA, frameB, params):
+        p = np.zeros(16, np.float32); p[:len(params)] = params
+        f = self.L.refw_set_joint_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
+        f(self.h, joint, _fp(_f32(np.asarray(frameA).ravel(), 9)), _fp(_f32(np.asarray(frameB).ravel(), 9)), _fp(p))
 
     def remove_joint(self, joint):
         f = self.L.refw_remove_joint; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None

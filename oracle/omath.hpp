@@ -175,6 +175,7 @@ inline mat3 inverse_symmetric(const mat3 &m) {   // matrix3x3.hpp:190-218
 inline vec3 to_world(vec3 p, vec3 pos, quat orn) { return pos + rotate(orn, p); }
 inline vec3 to_object(vec3 p, vec3 pos, quat orn) { return rotate(conjugate(orn), p - pos); }
 inline vec3 to_object(vec3 p, vec3 pos, const mat3 &basis) { return (p - pos) * basis; }
+inline vec3 to_world(vec3 p, vec3 pos, const mat3 &basis) { return pos + basis * p; }   // transform.hpp:33-35
 
 struct aabb {
     vec3 min, max;

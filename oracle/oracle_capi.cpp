@@ -265,6 +265,14 @@ void orc_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
 int orc_should_collide(uint64_t groupA, uint64_t maskA, uint64_t groupB, uint64_t maskB) {
     return ((groupA & maskB) != 0 && (groupB & maskA) != 0) ? 1 : 0;
 }
+// frames + the full parameter block of a joint (cone / cvjoint): frames row-major 3x3, params[16] (see oworld.hpp Joint)
+void orc_set_joint_definition(void *h, uint32_t joint, const float *fA, const float *fB, const float *params16) {
+    World *w = (World *)h;
+    Joint &j = w->joints[joint];
+    for (int r = 0; r < 3; ++r) { j.frame[0].row[r] = v3(fA + 3 * r); j.frame[1].row[r] = v3(fB + 3 * r); }
+    for (int k = 0; k < 16; ++k) j.params[k] = params16[k];
+    if (j.type == JOINT_HINGE || j.type == JOINT_CVJOINT) w->reset_joint_angle(j);
+}
 // contact_extras materials and impulses
 void orc_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
     Body &b = ((World *)h)->bodies[body];

@@ -34,7 +34,7 @@
 namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
-enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5 };
 // ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
 // ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
 // EnTT pool history), exported by oracle/ref_world.cpp. With it the restatement and the reference agree bit for bit.
@@ -104,8 +104,13 @@ struct Joint {
     mat3 frame[2] = {kMat3Identity, kMat3Identity};   // hinge: column 0 = axis
     // Optional rows (hinge_constraint.hpp:30-62, point_constraint.hpp:25). hinge params: angle_min, angle_max, limit_restitution,
     // bump_stop_angle, bump_stop_stiffness, torque, speed, rest_angle, stiffness, damping; point: params[0] = friction_torque.
-    float params[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float angle = 0;   // hinge: relative angle tracked across wraps (hinge_constraint.cpp:80-89)
+    // cone (cone_constraint.hpp): span_tan[0], span_tan[1], restitution, bump_stop_stiffness, bump_stop_length; slots 0 limit, 1 bump stop.
+    // cvjoint (cvjoint_constraint.hpp): twist_min, twist_max, twist_restitution, twist_bump_stop_angle, twist_bump_stop_stiffness,
+    // twist_friction_torque, twist_rest_angle, twist_stiffness, twist_damping, rest_direction xyz, bend_stiffness,
+    // bend_friction_torque, bend_damping; slots 0..2 linear, 3 twist limit, 4 bump stop, 5 spring, 6 twist friction/damping,
+    // 7 bend friction/damping, 8 bend spring.
+    float params[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float angle = 0;   // hinge / cvjoint twist: relative angle tracked across wraps (hinge_constraint.cpp:80-89, cvjoint_constraint.cpp:39-47)
     // applied impulses by SLOT: hinge linear[0..2], hinge[3..4], limit 5, bump_stop 6, spring 7, torque 8; point [0..2], friction 3
     float impulse[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool alive = true; // false: removed (the index stays reserved)
@@ -858,6 +863,30 @@ public:
     // row r reads and (after the solve) writes (store_applied_impulses, point_constraint.cpp:48-58, hinge_constraint.cpp:215-257).
     static constexpr int kMaxJointRows = 9;
     static float atan2_cr(float y, float x) { return g_libm_trig ? std::atan2(y, x) : (float)std::atan2((double)y, (double)x); }
+    static float asin_cr(float x) { return g_libm_trig ? std::asin(x) : (float)std::asin((double)x); }
+    static quat shortest_arc(vec3 v0, vec3 v1) {   // quaternion.cpp:25-38
+        const vec3 c = cross(v0, v1);
+        const float d = dot(v0, v1);
+        if (d <= -1 + kEps) {
+            vec3 n, m;
+            plane_space(v0, n, m);
+            return {n.x, n.y, n.z, 0};
+        }
+        const float s = std::sqrt((1 + d) * 2);
+        const float rs = 1 / s;
+        return normalize(quat{c.x * rs, c.y * rs, c.z * rs, s * 0.5f});
+    }
+    static float cvjoint_relative_angle(const Joint &j, quat ornA, quat ornB, vec3 twist_axisA, vec3 twist_axisB) {   // cvjoint_constraint.cpp:25-37
+        const quat arc = shortest_arc(twist_axisB, twist_axisA);
+        const vec3 angle_axisB = rotate(conjugate(ornA) * arc * ornB, j.frame[1].column(1));
+        return atan2_cr(dot(angle_axisB, j.frame[0].column(2)), dot(angle_axisB, j.frame[0].column(1)));
+    }
+    static void track_angle(Joint &j, float new_angle) {   // update_angle, :39-47 (the hinge's rule)
+        const float previous = normalize_angle(j.angle);
+        const float d0 = new_angle - previous;
+        const float d1 = d0 + kPi2 * (d0 < 0 ? 1.0f : -1.0f);
+        j.angle += std::fabs(d0) < std::fabs(d1) ? d0 : d1;
+    }
     static float normalize_angle(float a) {   // math.hpp:53-63
         a = std::fmod(a, kPi2);
         if (a < -kPi) return a + kPi2;
@@ -867,6 +896,136 @@ public:
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
+        if (j.type == JOINT_CONE) {   // cone_constraint.cpp:12-95
+            const vec3 pivotB_world = pB;
+            const vec3 pivotB_in_A = to_object(pivotB_world, A.pos, A.orn);
+            const vec3 pf = to_object(pivotB_in_A, j.pivot[0], j.frame[0]);
+            const float scaling_y = 1.0f / j.params[0], scaling_z = 1.0f / j.params[1];
+            const vec3 ps = pf * vec3{1, scaling_y, scaling_z};
+            const float proj_yz_len_sqr = ps.y * ps.y + ps.z * ps.z;
+            vec3 normal_scaled, tangent_scaled;
+            if (proj_yz_len_sqr > kEps) {
+                normal_scaled = normalize(vec3{-std::sqrt(proj_yz_len_sqr), ps.y, ps.z});
+                tangent_scaled = normalize(vec3{0, -ps.z, ps.y});
+            } else {
+                normal_scaled = normalize(vec3{-1, 1, 0});
+                tangent_scaled = normalize(vec3{0, 0, 1});
+            }
+            const float error = dot(ps, normal_scaled);
+            const vec3 dir_on_cone{-normal_scaled.x, normal_scaled.y, normal_scaled.z};
+            const float cone_proj = dot(ps, dir_on_cone);
+            const vec3 point_on_cone_scaled = dir_on_cone * cone_proj;
+            const vec3 descale{1, 1 / scaling_y, 1 / scaling_z};
+            const vec3 point_on_cone = point_on_cone_scaled * descale;
+            const vec3 pivotA = to_world(point_on_cone, j.pivot[0], j.frame[0]);
+            const vec3 pivotA_world = to_world(pivotA, A.pos, A.orn);
+            const vec3 tangent = normalize(tangent_scaled * descale);
+            const vec3 normal = normalize(cross(tangent, point_on_cone));
+            const vec3 nw = rotate(A.orn, j.frame[0] * normal);
+            const vec3 cA = pivotA_world - A.pos, cB = pivotB_world - B.pos;
+            auto cone_row = [&](int n, float lo, float hi, const RowOptions &o) {
+                Row &r = rows[n];
+                r.J[0] = nw; r.J[1] = cross(cA, nw); r.J[2] = -nw; r.J[3] = -cross(cB, nw);
+                r.lower = lo; r.upper = hi; r.impulse = j.impulse[n];
+                finish_row(r, o, A, B);
+                slot[n] = n;
+            };
+            RowOptions o; o.error = -error / dt; o.restitution = j.params[2];
+            cone_row(0, 0, kLarge, o);
+            if (j.params[3] > 0 && j.params[4] > 0) {
+                const float deflection = j.params[4] + error;
+                const float spring_impulse = j.params[3] * deflection * dt;
+                RowOptions ob; ob.error = -deflection / dt;
+                cone_row(1, 0, std::max(0.0f, spring_impulse), ob);
+                return 2;
+            }
+            return 1;
+        }
+        if (j.type == JOINT_CVJOINT) {   // cvjoint_constraint.cpp:49-222
+            const float *P = j.params;
+            const float twist_min = P[0], twist_max = P[1], twist_restitution = P[2], bump_angle = P[3], bump_stiffness = P[4],
+                        twist_friction_torque = P[5], twist_rest_angle = P[6], twist_stiffness = P[7], twist_damping = P[8],
+                        bend_stiffness = P[12], bend_friction_torque = P[13], bend_damping = P[14];
+            const vec3 rest_direction{P[9], P[10], P[11]};
+            mat3 sA = skew(rA), sB = skew(rB);
+            int n = 0;
+            for (int i = 0; i < 3; ++i) {
+                Row &r = rows[n];
+                r.J[0] = kMat3Identity.row[i]; r.J[1] = -sA.row[i]; r.J[2] = -kMat3Identity.row[i]; r.J[3] = sB.row[i];
+                r.lower = -kLarge; r.upper = kLarge; r.impulse = j.impulse[n];
+                finish_row(r, RowOptions{}, A, B);
+                slot[n] = n; ++n;
+            }
+            const vec3 tA = rotate(A.orn, j.frame[0].column(0)), tB = rotate(B.orn, j.frame[1].column(0));
+            auto ang_row = [&](vec3 axA, vec3 axB, int sl, float lo, float hi, const RowOptions &o) {
+                Row &r = rows[n];
+                r.J[0] = {0, 0, 0}; r.J[1] = axA; r.J[2] = {0, 0, 0}; r.J[3] = -axB;
+                r.lower = lo; r.upper = hi; r.impulse = j.impulse[sl];
+                finish_row(r, o, A, B);
+                slot[n] = sl; ++n;
+            };
+            const bool has_limit = twist_min < twist_max;
+            {
+                const float angle = cvjoint_relative_angle(j, A.orn, B.orn, tA, tB);
+                RowOptions o;
+                float lo = -kLarge, hi = kLarge;
+                if (has_limit) {
+                    track_angle(j, angle);
+                    float limit_error;
+                    const float mid = (twist_min + twist_max) / 2.0f;
+                    if (j.angle < mid) { limit_error = twist_min - j.angle; lo = -kLarge; hi = 0; }
+                    else { limit_error = twist_max - j.angle; lo = 0; hi = kLarge; }
+                    if (j.angle > twist_min && j.angle < twist_max) o.error = limit_error / dt;
+                    o.restitution = twist_restitution;
+                }
+                ang_row(tA, tB, 3, lo, hi, o);
+            }
+            if (has_limit && bump_stiffness > 0 && bump_angle > 0) {
+                float defl = 0;
+                const float bmin = twist_min + bump_angle, bmax = twist_max - bump_angle;
+                if (j.angle < bmin) defl = j.angle - bmin;
+                else if (j.angle > bmax) defl = j.angle - bmax;
+                const float imp = bump_stiffness * defl * dt;
+                RowOptions o; o.error = -defl / dt;
+                ang_row(tA, tB, 4, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+            }
+            if (has_limit && twist_stiffness > 0) {
+                const float defl = j.angle - twist_rest_angle;
+                const float imp = twist_stiffness * defl * dt;
+                RowOptions o; o.error = -defl / dt;
+                ang_row(tA, tB, 5, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+            }
+            if (has_limit && (twist_friction_torque > 0 || twist_damping > 0)) {
+                float fi = twist_friction_torque * dt;
+                if (twist_damping > 0) {
+                    const float relvel = dot(A.angvel, tA) - dot(B.angvel, tB);
+                    fi += std::fabs(relvel) * twist_damping * dt;
+                }
+                ang_row(tA, tB, 6, -fi, fi, RowOptions{});
+            }
+            if (bend_friction_torque > 0 || bend_damping > 0) {
+                const vec3 twA = dot(A.angvel, tA) * tA, twB = dot(B.angvel, tB) * tB;
+                const vec3 angvel_rel = (A.angvel - twA) - (B.angvel - twB);
+                const float angspd_rel = length(angvel_rel);
+                vec3 axis;
+                if (angspd_rel > kEps) axis = angvel_rel / angspd_rel;
+                else axis = rotate(A.orn, j.frame[0].column(1));
+                float fi = bend_friction_torque * dt;
+                if (twist_damping > 0) fi += std::fabs(angspd_rel) * bend_damping * dt;   // (the reference tests twist_damping here, :199)
+                ang_row(axis, axis, 7, -fi, fi, RowOptions{});
+            }
+            if (bend_stiffness > 0) {
+                vec3 bend_axis = cross(rotate(A.orn, rest_direction), tB);
+                const float len = length(bend_axis);
+                const float angle = asin_cr(len);
+                if (len > kEps) bend_axis /= len;
+                else bend_axis = rotate(A.orn, j.frame[0].column(1));
+                const float imp = bend_stiffness * angle * dt;
+                RowOptions o; o.error = -angle / dt;
+                ang_row(bend_axis, bend_axis, 8, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+            }
+            return n;
+        }
         if (j.type == JOINT_DISTANCE || j.type == JOINT_SOFT_DISTANCE) {
             // distance_constraint.cpp:7-31 (params[0] = distance) / soft_distance_constraint.cpp:8-62 (distance, stiffness, damping)
             vec3 d = pA - pB;
@@ -989,6 +1148,10 @@ public:
     }
     void reset_joint_angle(Joint &j) {   // hinge_constraint::reset_angle, hinge_constraint.cpp:19-24
         const Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        if (j.type == JOINT_CVJOINT) {   // cvjoint_constraint::reset_angle, cvjoint_constraint.cpp:12-23
+            j.angle = cvjoint_relative_angle(j, A.orn, B.orn, rotate(A.orn, j.frame[0].column(0)), rotate(B.orn, j.frame[1].column(0)));
+            return;
+        }
         const vec3 p = rotate(A.orn, j.frame[0].column(1)), q = rotate(A.orn, j.frame[0].column(2));
         const vec3 angle_axisB = rotate(B.orn, j.frame[1].column(1));
         j.angle = atan2_cr(dot(angle_axisB, q), dot(angle_axisB, p));
@@ -1036,6 +1199,31 @@ public:
         float error = -cp.distance;
         vec3 J[4] = {cp.normal, cross(rA, cp.normal), -cp.normal, -cross(rB, cp.normal)};
         ps.solve(J, error);
+    }
+    void cvjoint_solve_position(Joint &j, PosSolver &ps) {   // cvjoint_constraint.cpp:224-265
+        Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        ps.bind(A, B);
+        const vec3 tA = rotate(A.orn, j.frame[0].column(0)), tB = rotate(B.orn, j.frame[1].column(0));
+        const float angle = cvjoint_relative_angle(j, A.orn, B.orn, tA, tB);
+        const float twist_min = j.params[0], twist_max = j.params[1];
+        float twist_error = 0;
+        if (twist_min < twist_max) {
+            track_angle(j, angle);
+            if (j.angle < twist_min) twist_error = j.angle - twist_min;
+            else if (j.angle > twist_max) twist_error = j.angle - twist_max;
+        } else {
+            twist_error = angle;
+        }
+        { vec3 J[4] = {{0, 0, 0}, tA, {0, 0, 0}, -tB}; ps.solve(J, twist_error); }
+        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 dir = pA - pB;
+        const float err = length(dir);
+        if (err > kEps) {
+            dir /= err;
+            vec3 rA = pA - A.pos, rB = pB - B.pos;
+            vec3 J[4] = {dir, cross(rA, dir), -dir, -cross(rB, dir)};
+            ps.solve(J, -err);
+        }
     }
     void hinge_solve_position(Joint &j, PosSolver &ps) {   // hinge_constraint.cpp:180-213
         Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
@@ -1260,7 +1448,7 @@ public:
             std::vector<FrictionRow> roll;
             std::vector<SpinRow> spin;
             std::vector<ContactPoint *> roll_cp, spin_cp;
-            for (int type : {JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_POINT})   // constraints_tuple order: distance, soft_distance, hinge ... point, contact
+            for (int type : {JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_CVJOINT, JOINT_CONE, JOINT_POINT})   // constraints_tuple order (constraint.hpp:23-34)
                 for (Joint *j : js) {
                     if (j->type != type) continue;
                     Row tmp[kMaxJointRows];
@@ -1305,6 +1493,7 @@ public:
             for (int it = 0; it < pos_iters; ++it) {
                 PosSolver hs, cs;
                 for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
+                for (Joint *j : js) if (j->type == JOINT_CVJOINT) cvjoint_solve_position(*j, hs);
                 for (auto &cp : cps) contact_solve_position(*cp.first, cp.first->pt[cp.second], cs);
                 if (std::max(hs.max_error, cs.max_error) < 0.005f) break;
             }
@@ -1369,10 +1558,11 @@ public:
         for (int it = 0; it < pos_iters; ++it) {
             std::fill(err.begin(), err.end(), 0.0f);
             for (auto &col : jc) for (auto &jr : col) {
-                if (jr.j->type != JOINT_HINGE) continue;
+                if (jr.j->type != JOINT_HINGE && jr.j->type != JOINT_CVJOINT) continue;
                 uint32_t l = label_of(jr.j->body[0], jr.j->body[1]);
                 if (done[l]) continue;
-                PosSolver ps; hinge_solve_position(*jr.j, ps);
+                PosSolver ps;
+                if (jr.j->type == JOINT_HINGE) hinge_solve_position(*jr.j, ps); else cvjoint_solve_position(*jr.j, ps);
                 err[l] = std::max(err[l], ps.max_error);
             }
             for (auto &col : cc) for (auto &cr : col) {

@@ -175,6 +175,14 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
             c.pivot[0] = v3(pivotA);
             c.pivot[1] = v3(pivotB);
         });
+    } else if (type == 4) {
+        e = edyn::make_constraint<edyn::cone_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::cone_constraint &c) {
+            c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB); c.span_tan = {1, 1};
+        });
+    } else if (type == 5) {
+        e = edyn::make_constraint<edyn::cvjoint_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::cvjoint_constraint &c) {
+            c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
+        });
     } else if (type == 2) {
         e = edyn::make_constraint<edyn::distance_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::distance_constraint &c) {
             c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
@@ -214,6 +222,23 @@ void refw_set_joint_params(void *h, uint32_t joint, const float *p) {
         dc->distance = p[0];
     } else if (auto *sc = w->registry.try_get<edyn::soft_distance_constraint>(e)) {
         sc->distance = p[0]; sc->stiffness = p[1]; sc->damping = p[2];
+    }
+}
+// frames (row-major 3x3) and the parameter block of a cone / cvjoint (layout: oworld.hpp Joint::params)
+void refw_set_joint_definition(void *h, uint32_t joint, const float *fA, const float *fB, const float *p) {
+    auto *w = (ref_world *)h;
+    auto e = w->joints[joint];
+    auto m3 = [](const float *f) { return edyn::matrix3x3{{edyn::vector3{f[0], f[1], f[2]}, edyn::vector3{f[3], f[4], f[5]}, edyn::vector3{f[6], f[7], f[8]}}}; };
+    if (auto *cc = w->registry.try_get<edyn::cone_constraint>(e)) {
+        cc->frame = m3(fA);
+        cc->span_tan = {p[0], p[1]}; cc->restitution = p[2]; cc->bump_stop_stiffness = p[3]; cc->bump_stop_length = p[4];
+    } else if (auto *cv = w->registry.try_get<edyn::cvjoint_constraint>(e)) {
+        cv->frame = {m3(fA), m3(fB)};
+        cv->twist_min = p[0]; cv->twist_max = p[1]; cv->twist_restitution = p[2]; cv->twist_bump_stop_angle = p[3];
+        cv->twist_bump_stop_stiffness = p[4]; cv->twist_friction_torque = p[5]; cv->twist_rest_angle = p[6];
+        cv->twist_stiffness = p[7]; cv->twist_damping = p[8]; cv->rest_direction = {p[9], p[10], p[11]};
+        cv->bend_stiffness = p[12]; cv->bend_friction_torque = p[13]; cv->bend_damping = p[14];
+        cv->reset_angle(w->registry.get<edyn::orientation>(cv->body[0]), w->registry.get<edyn::orientation>(cv->body[1]));
     }
 }
 // registry.destroy on a rigid body / a constraint entity (the reference's hooks clean up edges, manifolds, islands:
@@ -415,6 +440,13 @@ void refw_get_joint_impulses(void *h, float *out10) {
         } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(w->joints[i])) {
             for (int k = 0; k < 3; ++k) o[k] = pc->applied_impulse[k];
             o[3] = pc->applied_friction_impulse;
+        } else if (auto *cc = w->registry.try_get<edyn::cone_constraint>(w->joints[i])) {
+            o[0] = cc->limit_impulse; o[1] = cc->bump_stop_impulse;
+        } else if (auto *cv = w->registry.try_get<edyn::cvjoint_constraint>(w->joints[i])) {
+            for (int k = 0; k < 3; ++k) o[k] = cv->applied_impulse.linear[k];
+            o[3] = cv->applied_impulse.twist_limit; o[4] = cv->applied_impulse.twist_bump_stop; o[5] = cv->applied_impulse.twist_spring;
+            o[6] = cv->applied_impulse.twist_friction_damping; o[7] = cv->applied_impulse.bend_friction_damping;
+            o[8] = cv->applied_impulse.bend_spring; o[9] = cv->twist_angle;
         } else if (auto *dc = w->registry.try_get<edyn::distance_constraint>(w->joints[i])) {
             o[0] = dc->applied_impulse;
         } else if (auto *sc = w->registry.try_get<edyn::soft_distance_constraint>(w->joints[i])) {

@@ -1049,3 +1049,21 @@ def test_distance_and_soft_distance_constraints_bit_exact():
             assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
     kinds = np.array([j[0] for j in sc["joints"]])
     assert np.abs(g.get_joint_impulses()[kinds == scenes.JOINT_SOFT_DISTANCE][:, :2]).max() > 0
+
+
+def test_cone_and_cvjoint_constraints_bit_exact():
+    """cone_constraint and cvjoint_constraint on the device (limit row on the elliptic cone with bump stop; point rows, twist
+    limit / bump stop / spring / friction, bending friction and spring, twist + pivot position correction) against the oracle,
+    applied impulses and tracked twist angles included; pinned to the real engine in tests/test_reference_engine.py."""
+    from test_reference_engine import _ragdoll_like_scene
+    sc, defs = _ragdoll_like_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for j, fa, fb, p in defs:
+        g.set_joint_definition(j, fa, fb, p); o.set_joint_definition(j, fa, fb, p)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 30 == 0 or s < 3:
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert (np.abs(g.get_joint_impulses()[kinds == scenes.JOINT_CVJOINT][:, 3:9]).max(axis=0) > 0).all()

@@ -124,6 +124,7 @@ def _lockstep(scene, steps, iters=10, sleeping=False, check_manifolds_every=20):
         orc.step(1)
         assert not orc.ext_order_mismatch(), f"step {s}: the reference's constraint list differs from the oracle's"
         for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+            assert np.isfinite(a).all(), f"step {s}: {name} is not finite"
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"step {s}: {name} differs, max |d| = {np.abs(a - b).max()}"
         if sleeping:
             ra, oa = ref.get_asleep()[dyn], orc.get_asleep()[dyn]
@@ -277,6 +278,7 @@ def _joint_lockstep(scene, steps, setup, iters=10):
         orc.set_ext_order(*ref.get_solve_order()); orc.step(1)
         assert not orc.ext_order_mismatch(), s
         for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+            assert np.isfinite(a).all(), (s, name)   # (equal NaN bit patterns would pass the comparison below)
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (s, name)
         assert np.array_equal(ref.get_joint_impulses().view(np.uint32), orc.get_joint_impulses().view(np.uint32)), s
     return ref, orc
@@ -630,3 +632,51 @@ def test_distance_and_soft_distance_constraints_match_the_real_engine():
     kinds = np.array([j[0] for j in sc["joints"]])
     assert np.abs(ji[kinds == scenes.JOINT_DISTANCE][:, 0]).max() > 0
     assert np.abs(ji[kinds == scenes.JOINT_SOFT_DISTANCE][:, :2]).max() > 0
+
+
+def _frame(axis_x):
+    """Orthonormal basis (row-major 3x3) whose first COLUMN is axis_x."""
+    x = np.asarray(axis_x, np.float64); x /= np.linalg.norm(x)
+    y = np.cross(x, (0.0, 0.0, 1.0) if abs(x[2]) < 0.9 else (1.0, 0.0, 0.0)); y /= np.linalg.norm(y)
+    z = np.cross(x, y)
+    return np.stack([x, y, z], axis=1).astype(np.float32)
+
+
+def _ragdoll_like_scene():
+    """Chains whose links hang on cvjoints (twist limits, springs, friction, bending) with a cone limiting every other link -
+    the constraint pair make_ragdoll builds its limbs from (ragdoll.cpp:471-914)."""
+    sc = scenes.c5_chains(4, 6)
+    joints, defs = [], []
+    down = _frame((0.0, -1.0, 0.0))
+    for i, j in enumerate(sc["joints"]):
+        joints.append((scenes.JOINT_CVJOINT,) + tuple(j[1:]))
+        cv = [-0.6, 0.8, 0.2, 0.15, 3.0, 0.01, 0.1, 2.0, 0.05, 0.0, -1.0, 0.0, 1.5, 0.02, 0.03] if i % 2 == 0 else \
+             [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 0.8, 0.0, 0.0]
+        defs.append((len(joints) - 1, down, down, cv))
+    for i, j in enumerate(sc["joints"]):
+        if i % 2 == 0 and j[1] != 0:
+            a, b = j[1], j[2]
+            joints.append((scenes.JOINT_CONE, a, b, (0.0, 0.0, 0.0), (0.0, -0.5, 0.0)) + tuple(j[5:]))
+            defs.append((len(joints) - 1, down, np.eye(3, dtype=np.float32), [0.6, 0.9, 0.3, 40.0, 0.1]))
+    sc["joints"] = joints
+    rng = np.random.default_rng(17)
+    # gentle: a bend of 90 degrees makes |rest x twist| round to just above 1 and std::asin return NaN - in the reference too
+    sc["angvel"][1:] = (rng.normal(size=(len(sc["kind"]) - 1, 3)) * 0.6).astype(np.float32)
+    return sc, defs
+
+
+def test_cone_and_cvjoint_constraints_match_the_real_engine():
+    """cone_constraint.cpp:12-104 (point-in-elliptic-cone limit row with restitution + bump stop) and
+    cvjoint_constraint.cpp:12-302 (point rows, twist limit with angle tracking, bump stop, spring, friction / damping, bending
+    friction and spring, position correction of twist and pivots) - state, applied impulses and tracked twist angle
+    bit-identical with the real engine on swinging, twisting chains."""
+    sc, defs = _ragdoll_like_scene()
+
+    def setup(w):
+        for j, fa, fb, p in defs:
+            w.set_joint_definition(j, fa, fb, p)
+    ref, _ = _joint_lockstep(sc, 300, setup)
+    ji = ref.get_joint_impulses()
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert np.abs(ji[kinds == scenes.JOINT_CONE][:, :2]).max() > 0
+    assert (np.abs(ji[kinds == scenes.JOINT_CVJOINT][:, 3:9]).max(axis=0) > 0).all()   # every optional cvjoint row acted
