@@ -1011,7 +1011,9 @@ __global__ void k_store_impulses(uint32_t n_active, Rows rows, uint32_t rcap, Ma
 // axial row {0, ax, 0, -ax} along `wax` (hinge axis for slots 5..8 of a hinge, relative spin for slot 3 of a point joint).
 DI void joint_rowJ(int type, int r, f3 rA, f3 rB, f3 wp, f3 wq, f3 wax, f3 wbx, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
     const bool hinge = type == EDYNHIP_JOINT_HINGE;
-    if (type == EDYNHIP_JOINT_DISTANCE || type == EDYNHIP_JOINT_SOFT_DISTANCE || type == EDYNHIP_JOINT_CONE) {
+    if (type == EDYNHIP_JOINT_GRAVITY) {   // {dn, 0, -dn, -0}: no lever arms
+        J0 = wp; J1 = mk3(0, 0, 0); J2 = -wp; J3 = -mk3(0, 0, 0);
+    } else if (type == EDYNHIP_JOINT_DISTANCE || type == EDYNHIP_JOINT_SOFT_DISTANCE || type == EDYNHIP_JOINT_CONE) {
         // every row of the distance constraints runs along the pivot separation, of the cone along the cone normal
         // (kept in wp; wq, wax = the two lever arms crossed with it)
         J0 = wp; J1 = wq; J2 = -wp; J3 = -wax;
@@ -1083,7 +1085,16 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     float err[kJointSlots], rest[kJointSlots], lo[kJointSlots], hi[kJointSlots];
 #pragma unroll
     for (int r = 0; r < kJointSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
-    if (type == EDYNHIP_JOINT_CONE) {   // cone_constraint.cpp:12-95
+    if (type == EDYNHIP_JOINT_GRAVITY) {   // gravity_constraint.cpp:6-28
+        const f3 d = A.pos - B.pos;
+        const float l2 = fmaxf(length_sqr(d), kEps);
+        const float l = sqrtf(l2);
+        wp = d / l;
+        const float F = 6.674e-11f / (l2 * A.inv_m * B.inv_m);   // gravitational_constant, math/constants.hpp
+        const float Pg = F * dt;
+        lo[0] = -Pg; hi[0] = Pg; err[0] = kLarge;
+        mask = 0x1u;
+    } else if (type == EDYNHIP_JOINT_CONE) {   // cone_constraint.cpp:12-95
         const f3 fx = from4(j.axA[i]), fy = from4(j.pA[i]), fz = from4(j.qA[i]);   // columns of the frame in A
         const m3 frame = m3_columns(fx, fy, fz);
         const f3 pivA = from4(j.pivA[i]);

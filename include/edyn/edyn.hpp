@@ -111,6 +111,7 @@ struct soft_distance_constraint : constraint_base {                             
     std::array<vector3, 2> pivot;
     scalar distance{0}, stiffness{scalar(1e10)}, damping{scalar(1e10)};
 };
+struct gravity_constraint : constraint_base {};                                               // constraints/gravity_constraint.hpp (Newtonian attraction)
 inline constexpr matrix3x3 matrix3x3_identity{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}};
 struct cone_constraint : constraint_base {                                                    // constraints/cone_constraint.hpp:19-49
     std::array<vector3, 2> pivot;
@@ -213,7 +214,8 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
         else if (auto *dc = registry.try_get<distance_constraint>(e)) { jt[j] = EDYNHIP_JOINT_DISTANCE; fill(*dc, dc->pivot); jq[10 * j] = dc->distance; }
         else if (auto *sc = registry.try_get<soft_distance_constraint>(e)) {
             jt[j] = EDYNHIP_JOINT_SOFT_DISTANCE; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
-        } else if (auto *cc = registry.try_get<cone_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CONE; fill(*cc, cc->pivot); }      // frames / parameters follow
+        } else if (auto *gc = registry.try_get<gravity_constraint>(e)) { jt[j] = EDYNHIP_JOINT_GRAVITY; fill(*gc, std::array<vector3, 2>{}); }
+        else if (auto *cc = registry.try_get<cone_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CONE; fill(*cc, cc->pivot); }      // frames / parameters follow
         else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CVJOINT; fill(*cv, cv->pivot); }  // (define_frames below)
         else {
             auto &hc = registry.get<hinge_constraint>(e);
@@ -401,11 +403,12 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
     for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
         const entt::entity e = s.constraints[j];
         if (e == entt::null) continue;
-        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint>(e);
+        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint>(e);
         if (alive) {   // a joint whose body was destroyed goes with it
             const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
                                       : registry.all_of<distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<distance_constraint>(e))
                                       : registry.all_of<soft_distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<soft_distance_constraint>(e))
+                                      : registry.all_of<gravity_constraint>(e) ? static_cast<constraint_base &>(registry.get<gravity_constraint>(e))
                                       : registry.all_of<cone_constraint>(e) ? static_cast<constraint_base &>(registry.get<cone_constraint>(e))
                                       : registry.all_of<cvjoint_constraint>(e) ? static_cast<constraint_base &>(registry.get<cvjoint_constraint>(e))
                                       : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
@@ -413,7 +416,7 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
         }
         if (!alive) {
             s.constraints[j] = entt::null;
-            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint>(e)) registry.destroy(e);   // its body is gone
             if (j < s.uploaded_constraints) gone_joints.push_back(j);
         }
     }
@@ -709,8 +712,9 @@ inline entt::entity make_rigidbody(entt::registry &registry, const rigidbody_def
 template <typename T, typename... SetupFunc>
 void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
     static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint> || std::is_same_v<T, distance_constraint> ||
-                      std::is_same_v<T, soft_distance_constraint> || std::is_same_v<T, cone_constraint> || std::is_same_v<T, cvjoint_constraint>,
-                  "point, hinge, distance, soft_distance, cone and cvjoint constraints are on the accelerated path");
+                      std::is_same_v<T, soft_distance_constraint> || std::is_same_v<T, cone_constraint> || std::is_same_v<T, cvjoint_constraint> ||
+                      std::is_same_v<T, gravity_constraint>,
+                  "point, hinge, distance, soft_distance, cone, cvjoint and gravity constraints are on the accelerated path");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     auto &con = registry.emplace<T>(entity);
     con.body = {body0, body1};

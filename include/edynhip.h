@@ -54,7 +54,8 @@ enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_DISTANCE = 2,       /* distance_constraint.cpp:7-31; params[0] = distance; impulse slot 0 */
        EDYNHIP_JOINT_SOFT_DISTANCE = 3,  /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */
        EDYNHIP_JOINT_CONE = 4,           /* cone_constraint.cpp:12-104; frames + params through edynhip_set_joint_definition */
-       EDYNHIP_JOINT_CVJOINT = 5         /* cvjoint_constraint.cpp:12-302; frames + params through edynhip_set_joint_definition */ };
+       EDYNHIP_JOINT_CVJOINT = 5,        /* cvjoint_constraint.cpp:12-302; frames + params through edynhip_set_joint_definition */
+       EDYNHIP_JOINT_GRAVITY = 6         /* gravity_constraint.cpp:6-34: Newtonian attraction between the two bodies; impulse slot 0 */ };
 /* contact_normal_attachment (include/edyn/collision/contact_normal_attachment.hpp:17-21) */
 enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2 };
 

@@ -23,7 +23,7 @@ MANIFOLD_DTYPE = np.dtype([
 
 SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
-JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT = 0, 1, 2, 3, 4, 5
+JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY = 0, 1, 2, 3, 4, 5, 6
 ORDER_SEQUENTIAL, ORDER_COLOURED, ORDER_EXTERNAL = 0, 1, 2
 
 

@@ -21,6 +21,7 @@ namespace orc {
 constexpr float kEps = FLT_EPSILON;          // EDYN_EPSILON, math/scalar.hpp:17
 constexpr float kScalarMax = FLT_MAX;        // EDYN_SCALAR_MAX
 constexpr float kLarge = 1e18f;              // large_scalar, math/constants.hpp:17
+constexpr float kGravitationalConstant = 6.674e-11f;   // math/constants.hpp
 constexpr float kPi = 3.1415926535897932384626433832795029f;
 constexpr float kPi2 = kPi * 2.0f;
 constexpr float kHalfSqrt2 = 0.7071067811865475244008443621048490f;

@@ -34,7 +34,7 @@
 namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
-enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5, JOINT_GRAVITY = 6 };
 // ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
 // ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
 // EnTT pool history), exported by oracle/ref_world.cpp. With it the restatement and the reference agree bit for bit.
@@ -896,6 +896,21 @@ public:
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
+        if (j.type == JOINT_GRAVITY) {   // gravity_constraint.cpp:6-28: Newtonian attraction as an impulse-limited row
+            const vec3 d = A.pos - B.pos;
+            const float l2 = std::max(length_sqr(d), kEps);
+            const float l = std::sqrt(l2);
+            const vec3 dn = d / l;
+            const float F = kGravitationalConstant / (l2 * A.inv_m * B.inv_m);
+            const float P = F * dt;
+            Row &r = rows[0];
+            r.J[0] = dn; r.J[1] = {0, 0, 0}; r.J[2] = -dn; r.J[3] = -vec3{0, 0, 0};
+            r.lower = -P; r.upper = P; r.impulse = j.impulse[0];
+            RowOptions o; o.error = kLarge;
+            finish_row(r, o, A, B);
+            slot[0] = 0;
+            return 1;
+        }
         if (j.type == JOINT_CONE) {   // cone_constraint.cpp:12-95
             const vec3 pivotB_world = pB;
             const vec3 pivotB_in_A = to_object(pivotB_world, A.pos, A.orn);
@@ -1448,7 +1463,7 @@ public:
             std::vector<FrictionRow> roll;
             std::vector<SpinRow> spin;
             std::vector<ContactPoint *> roll_cp, spin_cp;
-            for (int type : {JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_CVJOINT, JOINT_CONE, JOINT_POINT})   // constraints_tuple order (constraint.hpp:23-34)
+            for (int type : {JOINT_GRAVITY, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_CVJOINT, JOINT_CONE, JOINT_POINT})   // constraints_tuple order (constraint.hpp:23-34)
                 for (Joint *j : js) {
                     if (j->type != type) continue;
                     Row tmp[kMaxJointRows];

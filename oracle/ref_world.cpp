@@ -175,6 +175,8 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
             c.pivot[0] = v3(pivotA);
             c.pivot[1] = v3(pivotB);
         });
+    } else if (type == 6) {
+        e = edyn::make_constraint<edyn::gravity_constraint>(w->registry, w->bodies[a], w->bodies[b]);
     } else if (type == 4) {
         e = edyn::make_constraint<edyn::cone_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::cone_constraint &c) {
             c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB); c.span_tan = {1, 1};
@@ -440,6 +442,8 @@ void refw_get_joint_impulses(void *h, float *out10) {
         } else if (auto *pc = w->registry.try_get<edyn::point_constraint>(w->joints[i])) {
             for (int k = 0; k < 3; ++k) o[k] = pc->applied_impulse[k];
             o[3] = pc->applied_friction_impulse;
+        } else if (auto *gc = w->registry.try_get<edyn::gravity_constraint>(w->joints[i])) {
+            o[0] = gc->applied_impulse;
         } else if (auto *cc = w->registry.try_get<edyn::cone_constraint>(w->joints[i])) {
             o[0] = cc->limit_impulse; o[1] = cc->bump_stop_impulse;
         } else if (auto *cv = w->registry.try_get<edyn::cvjoint_constraint>(w->joints[i])) {

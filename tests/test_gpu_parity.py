@@ -1067,3 +1067,17 @@ def test_cone_and_cvjoint_constraints_bit_exact():
             assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
     kinds = np.array([j[0] for j in sc["joints"]])
     assert (np.abs(g.get_joint_impulses()[kinds == scenes.JOINT_CVJOINT][:, 3:9]).max(axis=0) > 0).all()
+
+
+def test_gravity_constraint_bit_exact():
+    """gravity_constraint on the device (k_prep_joints: one row along the centre line, impulse limits +-G m_A m_B / l^2 dt)
+    against the oracle; pinned to the real engine in tests/test_reference_engine.py."""
+    from test_reference_engine import _gravity_scene
+    sc = _gravity_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 50 == 0 or s < 3:
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
+    assert np.isfinite(g.get_state()[0]).all() and np.abs(g.get_joint_impulses()[:, 0]).min() > 0
