@@ -285,7 +285,8 @@ __host__ __device__ inline uint32_t pair_owner(uint32_t a, uint32_t b, bool proc
     if (proc_a && proc_b) return a > b ? a : b;
     return proc_a ? a : b;
 }
-__global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, Manifolds mf, const uint32_t *__restrict__ flags) {
+__global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, Manifolds mf, const uint32_t *__restrict__ flags,
+                                       const float4 *__restrict__ mat2) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const edynhip_manifold r = in[m];
@@ -310,7 +311,13 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
         mf.lnrm[s] = make_float4(p.local_normal[0], p.local_normal[1], p.local_normal[2], p.restitution);
         mf.imp[s] = make_float4(p.normal_impulse, p.friction_impulse[0], p.friction_impulse[1], __uint_as_float(p.lifetime));
         if (mf.pid) mf.pid[s] = ((uint64_t)m << 2) | k;   // injected points: high word 0
-        if (mf.xmat) { mf.xmat[s] = make_float4(0.0f, 0.0f, kLarge, kLarge); mf.ximp[s] = make_float4(0, 0, 0, 0); }   // (the record carries no extras)
+        if (mf.xmat) {   // the record carries no extras: the materials are mixed as for a new point, the extras impulses start at 0
+            const float4 ma = mat2[a], mb = mat2[b];
+            float stiff = kLarge, damp = kLarge;
+            if (ma.z < kLarge || mb.z < kLarge) { stiff = 1.0f / (1.0f / ma.z + 1.0f / mb.z); damp = 1.0f / (1.0f / ma.w + 1.0f / mb.w); }
+            mf.xmat[s] = make_float4(fmaxf(ma.y, mb.y), fmaxf(ma.x, mb.x), stiff, damp);
+            mf.ximp[s] = make_float4(0, 0, 0, 0);
+        }
     }
 }
 __global__ void k_pack_state(uint32_t first, uint32_t count, Bodies b, float *dst) {
@@ -1136,7 +1143,7 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     edynhip_manifold *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, (size_t)n * sizeof(edynhip_manifold)));
     hipError_t e = hipMemcpyAsync(d, in, (size_t)n * sizeof(edynhip_manifold), hipMemcpyHostToDevice, c->stream);
-    hipLaunchKernelGGL(k_records_to_manifolds, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, d, c->m[c->cur], c->b.flags);
+    hipLaunchKernelGGL(k_records_to_manifolds, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, d, c->m[c->cur], c->b.flags, c->b.mat2);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_set_manifolds", e);

@@ -152,6 +152,11 @@ void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
             c.distance = p.distance; c.friction = p.friction; c.restitution = p.restitution;
             c.attachment = p.attachment; c.lifetime = p.lifetime;
             c.id = ((uint64_t)k << 2) | (uint64_t)i;   // injected points: high word 0 (edynhip_set_manifolds does the same)
+            {   // the record carries no contact_extras data: mixed as for a new point (as edynhip_set_manifolds does)
+                const Body &A = w->bodies[m.body[0]], &B = w->bodies[m.body[1]];
+                c.roll_friction = std::max(A.roll_friction, B.roll_friction); c.spin_friction = std::max(A.spin_friction, B.spin_friction);
+                if (A.stiffness < kLarge || B.stiffness < kLarge) { c.stiffness = 1 / (1 / A.stiffness + 1 / B.stiffness); c.damping = 1 / (1 / A.damping + 1 / B.damping); }
+            }
             c.normal_impulse = p.normal_impulse; c.friction_impulse[0] = p.friction_impulse[0]; c.friction_impulse[1] = p.friction_impulse[1];
         }
         m.with_restitution = w->tags_restitution(m.body[0], m.body[1]);
