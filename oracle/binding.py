@@ -23,7 +23,7 @@ MANIFOLD_DTYPE = np.dtype([
 
 SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
-JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY = 0, 1, 2, 3, 4, 5, 6
+JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY, JOINT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 ORDER_SEQUENTIAL, ORDER_COLOURED, ORDER_EXTERNAL = 0, 1, 2
 
 
@@ -389,6 +389,20 @@ class World:
         f = self.L.orc_set_joint_params; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
         f(self.h, joint, _fp(p))
 
+    def set_generic_definition(self, joint, frameA, frameB, dofs):
+        """dofs: [6][10] (linear x, y, z, angular x, y, z) - limit_enabled, min, max, restitution, bump length|angle, bump stiffness,
+        friction, rest, spring stiffness, damping."""
+        p = np.ascontiguousarray(np.asarray(dofs, np.float32).reshape(60))
+        f = self.L.orc_set_generic_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
+        f(self.h, joint, _fp(_f32(np.asarray(frameA).ravel(), 9)), _fp(_f32(np.asarray(frameB).ravel(), 9)), _fp(p))
+
+    def get_joint_impulses24(self):
+        out = np.zeros((self.n_joints, 24), np.float32)
+        if self.n_joints:
+            f = self.L.orc_get_joint_impulses24; f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; f.restype = None
+            f(self.h, _fp(out))
+        return out
+
     def set_joint_definition(self, joint, frameA, frameB, params):
         p = np.zeros(16, np.float32); p[:len(params)] = params
         f = self.L.orc_set_joint_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
@@ -559,6 +573,18 @@ class RefWorld:
     def remove_body(self, body):
         f = self.L.refw_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
         f(self.h, body)
+
+    def set_generic_definition(self, joint, frameA, frameB, dofs):
+        p = np.ascontiguousarray(np.asarray(dofs, np.float32).reshape(60))
+        f = self.L.refw_set_generic_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
+        f(self.h, joint, _fp(_f32(np.asarray(frameA).ravel(), 9)), _fp(_f32(np.asarray(frameB).ravel(), 9)), _fp(p))
+
+    def get_joint_impulses24(self):
+        out = np.zeros((self.n_joints, 24), np.float32)
+        if self.n_joints:
+            f = self.L.refw_get_joint_impulses24; f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; f.restype = None
+            f(self.h, _fp(out))
+        return out
 
     def set_joint_definition(self, joint, frameA, frameB, params):
         p = np.zeros(16, np.float32); p[:len(params)] = params

@@ -278,6 +278,18 @@ void orc_set_joint_definition(void *h, uint32_t joint, const float *fA, const fl
     for (int k = 0; k < 16; ++k) j.params[k] = params16[k];
     if (j.type == JOINT_HINGE || j.type == JOINT_CVJOINT) w->reset_joint_angle(j);
 }
+// generic_constraint: frames + 6 x 10 parameters (oworld.hpp Joint::params); impulses of all 24 slots
+void orc_set_generic_definition(void *h, uint32_t joint, const float *fA, const float *fB, const float *dof60) {
+    World *w = (World *)h;
+    Joint &j = w->joints[joint];
+    for (int r = 0; r < 3; ++r) { j.frame[0].row[r] = v3(fA + 3 * r); j.frame[1].row[r] = v3(fB + 3 * r); }
+    for (int k = 0; k < 60; ++k) j.params[k] = dof60[k];
+}
+void orc_get_joint_impulses24(void *h, float *out24) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->joints.size(); ++i)
+        for (int k = 0; k < 24; ++k) out24[24 * i + k] = w->joints[i].alive ? w->joints[i].impulse[k] : 0.0f;
+}
 // contact_extras materials and impulses
 void orc_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
     Body &b = ((World *)h)->bodies[body];

@@ -34,7 +34,8 @@
 namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
-enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5, JOINT_GRAVITY = 6 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5, JOINT_GRAVITY = 6, JOINT_GENERIC = 7 };
+constexpr int kJointSlotsO = 24, kJointParamsO = 64;
 // ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
 // ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
 // EnTT pool history), exported by oracle/ref_world.cpp. With it the restatement and the reference agree bit for bit.
@@ -109,10 +110,13 @@ struct Joint {
     // twist_friction_torque, twist_rest_angle, twist_stiffness, twist_damping, rest_direction xyz, bend_stiffness,
     // bend_friction_torque, bend_damping; slots 0..2 linear, 3 twist limit, 4 bump stop, 5 spring, 6 twist friction/damping,
     // 7 bend friction/damping, 8 bend spring.
-    float params[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // generic (generic_constraint.hpp): 6 degrees of freedom (linear x, y, z along frame[0]'s columns, then angular), 10 floats
+    // each: limit_enabled, min, max, limit_restitution, bump_stop_length|angle, bump_stop_stiffness, friction, rest, spring_stiffness,
+    // damping; impulse slot 4 * dof + {0 limit, 1 bump stop, 2 spring, 3 friction/damping}.
+    float params[kJointParamsO] = {0};
     float angle = 0;   // hinge / cvjoint twist: relative angle tracked across wraps (hinge_constraint.cpp:80-89, cvjoint_constraint.cpp:39-47)
     // applied impulses by SLOT: hinge linear[0..2], hinge[3..4], limit 5, bump_stop 6, spring 7, torque 8; point [0..2], friction 3
-    float impulse[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float impulse[kJointSlotsO] = {0};
     bool alive = true; // false: removed (the index stays reserved)
     uint32_t colour = kNoColour;
 };
@@ -861,7 +865,8 @@ public:
     }
     // point_constraint.cpp:9-46 / hinge_constraint.cpp:26-178. Returns the number of rows; slot[r] = the applied-impulse slot
     // row r reads and (after the solve) writes (store_applied_impulses, point_constraint.cpp:48-58, hinge_constraint.cpp:215-257).
-    static constexpr int kMaxJointRows = 9;
+    static constexpr int kMaxJointRows = kJointSlotsO;
+    static float acos_cr(float x) { return g_libm_trig ? std::acos(x) : (float)std::acos((double)x); }
     static float atan2_cr(float y, float x) { return g_libm_trig ? std::atan2(y, x) : (float)std::atan2((double)y, (double)x); }
     static float asin_cr(float x) { return g_libm_trig ? std::asin(x) : (float)std::asin((double)x); }
     static quat shortest_arc(vec3 v0, vec3 v1) {   // quaternion.cpp:25-38
@@ -896,6 +901,89 @@ public:
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
+        if (j.type == JOINT_GENERIC) {   // generic_constraint.cpp:10-258
+            const vec3 pivot_offset = pB - pA;
+            int n = 0;
+            auto add = [&](const vec3 (&J)[4], int sl, float lo, float hi, const RowOptions &o) {
+                Row &r = rows[n];
+                for (int k = 0; k < 4; ++k) r.J[k] = J[k];
+                r.lower = lo; r.upper = hi; r.impulse = j.impulse[sl];
+                finish_row(r, o, A, B);
+                slot[n] = sl; ++n;
+            };
+            const vec3 axisA_x = rotate(A.orn, j.frame[0].column(0)), axisB_x = rotate(B.orn, j.frame[1].column(0));
+            for (int d = 0; d < 6; ++d) {
+                const float *P = j.params + 10 * d;
+                const bool limit_enabled = P[0] != 0, angular = d >= 3;
+                const float vmin = P[1], vmax = P[2], limit_restitution = P[3], bump_len = P[4], bump_stiffness = P[5], friction = P[6],
+                            rest = P[7], spring_stiffness = P[8], damping = P[9];
+                const bool non_zero_limit = vmin < vmax;
+                vec3 J[4];
+                float current;
+                vec3 axA, axB;
+                if (!angular) {
+                    const vec3 axisA = rotate(A.orn, j.frame[0].column(d));
+                    J[0] = axisA; J[1] = cross(rA, axisA); J[2] = -axisA; J[3] = -cross(rB, axisA);
+                    current = dot(pivot_offset, axisA);
+                } else {
+                    const int i = d - 3;
+                    if (i == 0) {
+                        const quat arc = shortest_arc(axisB_x, axisA_x);
+                        const vec3 angle_axisB = rotate(conjugate(A.orn) * arc * B.orn, j.frame[1].column(1));
+                        current = atan2_cr(dot(angle_axisB, j.frame[0].column(2)), dot(angle_axisB, j.frame[0].column(1)));
+                        axA = axisA_x; axB = axisB_x;
+                    } else {
+                        const vec3 other = rotate(A.orn, j.frame[0].column(i == 1 ? 2 : 1));
+                        const float cos_angle = std::min(std::max(dot(axisB_x, other), -1.0f), 1.0f);
+                        current = kPi * 0.5f - acos_cr(cos_angle);
+                        vec3 axis = cross(other, axisB_x);
+                        if (!try_normalize(axis)) axis = i == 1 ? vec3{0, 0, 1} : vec3{0, 1, 0};
+                        axA = axB = -axis;
+                    }
+                    J[0] = {0, 0, 0}; J[1] = axA; J[2] = {0, 0, 0}; J[3] = -axB;
+                }
+                if (limit_enabled) {
+                    RowOptions o;
+                    float lo = -kLarge, hi = kLarge;
+                    if (non_zero_limit) {
+                        float limit_error;
+                        const float mid = (vmin + vmax) / 2.0f;
+                        if (current < mid) { limit_error = vmin - current; lo = -kLarge; hi = 0; }
+                        else { limit_error = vmax - current; lo = 0; hi = kLarge; }
+                        if (angular) o.error = limit_error / dt;
+                        else { if (current > vmin && current < vmax) o.error = limit_error / dt; o.erp = 0.9f; }
+                        o.restitution = limit_restitution;
+                    } else if (angular) {
+                        o.error = -current / dt;
+                    }
+                    add(J, 4 * d, lo, hi, o);
+                }
+                if (limit_enabled && non_zero_limit && bump_stiffness > 0 && bump_len > 0) {
+                    float defl = 0;
+                    const float bmin = vmin + bump_len, bmax = vmax - bump_len;
+                    if (current < bmin) defl = current - bmin;
+                    else if (current > bmax) defl = current - bmax;
+                    const float imp = bump_stiffness * defl * dt;
+                    RowOptions o; o.error = -defl / dt;
+                    add(J, 4 * d + 1, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+                }
+                if (spring_stiffness > 0) {
+                    const float defl = current - rest;
+                    const float imp = spring_stiffness * defl * dt;
+                    RowOptions o; o.error = -defl / dt;
+                    add(J, 4 * d + 2, std::min(imp, 0.0f), std::max(0.0f, imp), o);
+                }
+                if (friction > 0 || damping > 0) {
+                    float fi = friction * dt;
+                    if (damping > 0) {
+                        const float rel = angular ? dot(A.angvel, axA) - dot(B.angvel, axB) : relative_speed(J, A.linvel, A.angvel, B.linvel, B.angvel);
+                        fi += std::fabs(rel) * damping * dt;
+                    }
+                    add(J, 4 * d + 3, -fi, fi, RowOptions{});
+                }
+            }
+            return n;
+        }
         if (j.type == JOINT_GRAVITY) {   // gravity_constraint.cpp:6-28: Newtonian attraction as an impulse-limited row
             const vec3 d = A.pos - B.pos;
             const float l2 = std::max(length_sqr(d), kEps);
@@ -1215,6 +1303,23 @@ public:
         vec3 J[4] = {cp.normal, cross(rA, cp.normal), -cp.normal, -cross(rB, cp.normal)};
         ps.solve(J, error);
     }
+    void generic_solve_position(Joint &j, PosSolver &ps) {   // generic_constraint.cpp:260-290: the limited linear degrees of freedom
+        Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
+        ps.bind(A, B);
+        for (int i = 0; i < 3; ++i) {
+            const float *P = j.params + 10 * i;
+            if (P[0] == 0) continue;
+            const vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+            const vec3 pivot_offset = pB - pA, rA = pA - A.pos, rB = pB - B.pos;
+            const vec3 axisA = rotate(A.orn, j.frame[0].column(i));
+            const float proj = dot(pivot_offset, axisA);
+            float error = 0;
+            if (proj < P[1]) error = proj - P[1];
+            else if (proj > P[2]) error = proj - P[2];
+            vec3 J[4] = {axisA, cross(rA, axisA), -axisA, -cross(rB, axisA)};
+            ps.solve(J, error);
+        }
+    }
     void cvjoint_solve_position(Joint &j, PosSolver &ps) {   // cvjoint_constraint.cpp:224-265
         Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
         ps.bind(A, B);
@@ -1463,7 +1568,7 @@ public:
             std::vector<FrictionRow> roll;
             std::vector<SpinRow> spin;
             std::vector<ContactPoint *> roll_cp, spin_cp;
-            for (int type : {JOINT_GRAVITY, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_CVJOINT, JOINT_CONE, JOINT_POINT})   // constraints_tuple order (constraint.hpp:23-34)
+            for (int type : {JOINT_GRAVITY, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_HINGE, JOINT_GENERIC, JOINT_CVJOINT, JOINT_CONE, JOINT_POINT})   // constraints_tuple order (constraint.hpp:23-34)
                 for (Joint *j : js) {
                     if (j->type != type) continue;
                     Row tmp[kMaxJointRows];
@@ -1508,6 +1613,7 @@ public:
             for (int it = 0; it < pos_iters; ++it) {
                 PosSolver hs, cs;
                 for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
+                for (Joint *j : js) if (j->type == JOINT_GENERIC) generic_solve_position(*j, hs);
                 for (Joint *j : js) if (j->type == JOINT_CVJOINT) cvjoint_solve_position(*j, hs);
                 for (auto &cp : cps) contact_solve_position(*cp.first, cp.first->pt[cp.second], cs);
                 if (std::max(hs.max_error, cs.max_error) < 0.005f) break;
@@ -1573,11 +1679,13 @@ public:
         for (int it = 0; it < pos_iters; ++it) {
             std::fill(err.begin(), err.end(), 0.0f);
             for (auto &col : jc) for (auto &jr : col) {
-                if (jr.j->type != JOINT_HINGE && jr.j->type != JOINT_CVJOINT) continue;
+                if (jr.j->type != JOINT_HINGE && jr.j->type != JOINT_CVJOINT && jr.j->type != JOINT_GENERIC) continue;
                 uint32_t l = label_of(jr.j->body[0], jr.j->body[1]);
                 if (done[l]) continue;
                 PosSolver ps;
-                if (jr.j->type == JOINT_HINGE) hinge_solve_position(*jr.j, ps); else cvjoint_solve_position(*jr.j, ps);
+                if (jr.j->type == JOINT_HINGE) hinge_solve_position(*jr.j, ps);
+                else if (jr.j->type == JOINT_GENERIC) generic_solve_position(*jr.j, ps);
+                else cvjoint_solve_position(*jr.j, ps);
                 err[l] = std::max(err[l], ps.max_error);
             }
             for (auto &col : cc) for (auto &cr : col) {

@@ -90,6 +90,7 @@ void put3(float *d, const edyn::vector3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z
 }  // namespace
 
 extern "C" {
+void refw_get_joint_impulses(void *h, float *out10);
 
 // mode: 0 = execution_mode::sequential, 1 = sequential_multithreaded (num_workers 0 = hardware_concurrency - 1).
 void *refw_create(int mode, int num_workers, float dt, int vel_iters, int pos_iters, const float *g) {
@@ -175,6 +176,10 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
             c.pivot[0] = v3(pivotA);
             c.pivot[1] = v3(pivotB);
         });
+    } else if (type == 7) {
+        e = edyn::make_constraint<edyn::generic_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::generic_constraint &c) {
+            c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
+        });
     } else if (type == 6) {
         e = edyn::make_constraint<edyn::gravity_constraint>(w->registry, w->bodies[a], w->bodies[b]);
     } else if (type == 4) {
@@ -241,6 +246,42 @@ void refw_set_joint_definition(void *h, uint32_t joint, const float *fA, const f
         cv->twist_stiffness = p[7]; cv->twist_damping = p[8]; cv->rest_direction = {p[9], p[10], p[11]};
         cv->bend_stiffness = p[12]; cv->bend_friction_torque = p[13]; cv->bend_damping = p[14];
         cv->reset_angle(w->registry.get<edyn::orientation>(cv->body[0]), w->registry.get<edyn::orientation>(cv->body[1]));
+    }
+}
+// generic_constraint: frames (row-major) + per degree of freedom (linear x, y, z, angular x, y, z) 10 floats:
+// limit_enabled, min, max, limit_restitution, bump_stop_length|angle, bump_stop_stiffness, friction, rest, spring_stiffness, damping
+void refw_set_generic_definition(void *h, uint32_t joint, const float *fA, const float *fB, const float *p) {
+    auto *w = (ref_world *)h;
+    auto &gc = w->registry.get<edyn::generic_constraint>(w->joints[joint]);
+    auto m3 = [](const float *f) { return edyn::matrix3x3{{edyn::vector3{f[0], f[1], f[2]}, edyn::vector3{f[3], f[4], f[5]}, edyn::vector3{f[6], f[7], f[8]}}}; };
+    gc.frame = {m3(fA), m3(fB)};
+    for (int i = 0; i < 3; ++i) {
+        const float *q = p + 10 * i;
+        auto &d = gc.linear_dofs[i];
+        d.limit_enabled = q[0] != 0; d.offset_min = q[1]; d.offset_max = q[2]; d.limit_restitution = q[3]; d.bump_stop_length = q[4];
+        d.bump_stop_stiffness = q[5]; d.friction_force = q[6]; d.rest_offset = q[7]; d.spring_stiffness = q[8]; d.damping = q[9];
+        const float *r = p + 10 * (3 + i);
+        auto &a = gc.angular_dofs[i];
+        a.limit_enabled = r[0] != 0; a.angle_min = r[1]; a.angle_max = r[2]; a.limit_restitution = r[3]; a.bump_stop_angle = r[4];
+        a.bump_stop_stiffness = r[5]; a.friction_torque = r[6]; a.rest_angle = r[7]; a.spring_stiffness = r[8]; a.damping = r[9];
+    }
+}
+void refw_get_joint_impulses24(void *h, float *out24) {
+    auto *w = (ref_world *)h;
+    std::vector<float> ten(10 * w->joints.size());
+    refw_get_joint_impulses(h, ten.data());
+    for (size_t i = 0; i < w->joints.size(); ++i) {
+        float *o = out24 + 24 * i;
+        std::memset(o, 0, 96);
+        for (int k = 0; k < 9; ++k) o[k] = ten[10 * i + k];
+        if (!w->registry.valid(w->joints[i])) continue;
+        if (auto *gc = w->registry.try_get<edyn::generic_constraint>(w->joints[i])) {
+            for (int d = 0; d < 3; ++d) {
+                const auto &l = gc->linear_dofs[d].applied_impulse; const auto &a = gc->angular_dofs[d].applied_impulse;
+                o[4 * d] = l.limit; o[4 * d + 1] = l.bump_stop; o[4 * d + 2] = l.spring; o[4 * d + 3] = l.friction_damping;
+                o[12 + 4 * d] = a.limit; o[12 + 4 * d + 1] = a.bump_stop; o[12 + 4 * d + 2] = a.spring; o[12 + 4 * d + 3] = a.friction_damping;
+            }
+        }
     }
 }
 // registry.destroy on a rigid body / a constraint entity (the reference's hooks clean up edges, manifolds, islands:
