@@ -116,7 +116,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, j.orig, nj)); EH_TRY(dalloc(c, j.type, nj)); EH_TRY(dalloc(c, j.bodyA, nj)); EH_TRY(dalloc(c, j.bodyB, nj));
     EH_TRY(dalloc(c, j.pivA, nj)); EH_TRY(dalloc(c, j.pivB, nj)); EH_TRY(dalloc(c, j.axA, nj)); EH_TRY(dalloc(c, j.pA, nj));
     EH_TRY(dalloc(c, j.qA, nj)); EH_TRY(dalloc(c, j.axB, nj)); EH_TRY(dalloc(c, j.pB, nj)); EH_TRY(dalloc(c, j.impulse, (size_t)nj * kJointSlots));
-    EH_TRY(dalloc(c, j.wbx, nj)); EH_TRY(dalloc(c, j.params, (size_t)nj * kJointParams)); EH_TRY(dalloc(c, j.angle, nj)); EH_TRY(dalloc(c, j.rmask, nj));
+    EH_TRY(dalloc(c, j.wbx, nj)); EH_TRY(dalloc(c, j.gJ, (size_t)nj * 18)); EH_TRY(dalloc(c, j.params, (size_t)nj * kJointParams)); EH_TRY(dalloc(c, j.angle, nj)); EH_TRY(dalloc(c, j.rmask, nj));
     EH_TRY(dalloc(c, j.rA, nj)); EH_TRY(dalloc(c, j.rB, nj)); EH_TRY(dalloc(c, j.wp, nj)); EH_TRY(dalloc(c, j.wq, nj)); EH_TRY(dalloc(c, j.wax, nj));
     EH_TRY(dalloc(c, j.eff, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.rhs, (size_t)nj * kJointSlots));
     EH_TRY(dalloc(c, j.lo, (size_t)nj * kJointSlots)); EH_TRY(dalloc(c, j.hi, (size_t)nj * kJointSlots));
@@ -638,7 +638,8 @@ static int rebuild_joints(edynhip_ctx *c, bool fetch) {
         }
     }
     std::vector<uint32_t> live;
-    for (uint32_t e = 0; e < hj.size(); ++e) if (hj[e].alive) live.push_back(e);
+    c->has_generic = false;
+    for (uint32_t e = 0; e < hj.size(); ++e) if (hj[e].alive) { live.push_back(e); if (hj[e].type == EDYNHIP_JOINT_GENERIC) c->has_generic = true; }
     const uint32_t n = (uint32_t)live.size();
     if (n > j.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "joints: more live joints than max_joints");
     j.n = n; j.num_colours = 0; j.rows = 0;
@@ -709,7 +710,7 @@ static int rebuild_joints(edynhip_ctx *c, bool fetch) {
         } else if (h.has_frames) {   // cone / cvjoint: full frames (column k of a row-major 3x3 = elements k, 3 + k, 6 + k)
             auto col = [&](int f, int k) { return make_float4(h.frame[9 * f + k], h.frame[9 * f + 3 + k], h.frame[9 * f + 6 + k], 0); };
             axA[p] = col(0, 0); pA[p] = col(0, 1); qA[p] = col(0, 2); axB[p] = col(1, 0); pB[p] = col(1, 1);
-            rows += h.type == EDYNHIP_JOINT_CVJOINT ? 9 : 2;
+            rows += h.type == EDYNHIP_JOINT_CVJOINT ? 9 : (h.type == EDYNHIP_JOINT_GENERIC ? 24 : 2);
         } else rows += 3;
         for (int k = 0; k < kJointParams; ++k) params[(size_t)k * j.cap + p] = h.params[k];
         for (int r = 0; r < kJointSlots; ++r) impulse[(size_t)r * j.cap + p] = h.impulse[r];
@@ -745,14 +746,14 @@ static int append_host_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *
         HostJoint h;
         h.type = in->type[e]; h.body[0] = in->body[2 * e]; h.body[1] = in->body[2 * e + 1];
         if (h.body[0] >= c->b.n || h.body[1] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": body index out of range").c_str());
-        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_GRAVITY) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
+        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_GENERIC) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
         std::memcpy(h.pivot, in->pivot + 6 * e, sizeof(h.pivot));
         if (h.type == EDYNHIP_JOINT_HINGE) {
             if (!in->axis) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": hinge needs axes").c_str());
             std::memcpy(h.axis, in->axis + 6 * e, sizeof(h.axis));
         }
         if (in->params) std::memcpy(h.params, in->params + (size_t)kJointApiParams * e, sizeof(float) * kJointApiParams);
-        if (h.type == EDYNHIP_JOINT_CONE || h.type == EDYNHIP_JOINT_CVJOINT) {   // identity frames, an open cone, until edynhip_set_joint_definition
+        if (h.type == EDYNHIP_JOINT_CONE || h.type == EDYNHIP_JOINT_CVJOINT || h.type == EDYNHIP_JOINT_GENERIC) {   // identity frames, an open cone / free dofs, until defined
             const float id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             std::memcpy(h.frame, id, sizeof(id)); std::memcpy(h.frame + 9, id, sizeof(id));
             h.has_frames = true;
@@ -828,7 +829,31 @@ int edynhip_set_joint_definition(edynhip_ctx *c, uint32_t joint, const float *fr
     const int t = c->host_joints[joint].type;
     if (t != EDYNHIP_JOINT_CONE && t != EDYNHIP_JOINT_CVJOINT) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joint_definition: cone and cvjoint constraints only");
     if (t == EDYNHIP_JOINT_CONE && !(params16[0] > 0 && params16[1] > 0)) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_joint_definition: cone span tangents must be positive");
-    return redefine_joint(c, joint, params16, kJointParams, frameA, frameB);
+    return redefine_joint(c, joint, params16, 16, frameA, frameB);
+}
+int edynhip_set_generic_definition(edynhip_ctx *c, uint32_t joint, const float *frameA, const float *frameB, const float *dof60) {
+    if (!c || !dof60 || !frameA || !frameB || joint >= c->host_joints.size() || !c->host_joints[joint].alive) return EDYNHIP_ERR_INVALID;
+    if (c->host_joints[joint].type != EDYNHIP_JOINT_GENERIC) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_generic_definition: generic constraints only");
+    for (int d = 0; d < 6; ++d)
+        if (dof60[10 * d] != 0 && dof60[10 * d + 1] > dof60[10 * d + 2]) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_generic_definition: a limit's minimum exceeds its maximum");
+    return redefine_joint(c, joint, dof60, 60, frameA, frameB);
+}
+int edynhip_get_joint_slot_impulses(edynhip_ctx *c, float *out) {
+    if (!c || !out) return EDYNHIP_ERR_INVALID;
+    const uint32_t total = (uint32_t)c->host_joints.size();
+    if (total == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    std::memset(out, 0, (size_t)total * kJointSlots * sizeof(float));
+    const uint32_t n = c->j.n;
+    if (n == 0) return EDYNHIP_OK;
+    std::vector<float> imp((size_t)c->j.cap * kJointSlots);
+    std::vector<uint32_t> orig(n);
+    EH_HIP(c, hipMemcpyAsync(imp.data(), c->j.impulse, imp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipMemcpyAsync(orig.data(), c->j.orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t p = 0; p < n; ++p)
+        for (int r = 0; r < kJointSlots; ++r) out[(size_t)kJointSlots * orig[p] + r] = imp[(size_t)r * c->j.cap + p];
+    return EDYNHIP_OK;
 }
 static int redefine_joint(edynhip_ctx *c, uint32_t joint, const float *params, int nparams, const float *frameA, const float *frameB) {
     EH_HIP(c, hipSetDevice(c->device));
@@ -1324,7 +1349,7 @@ int edynhip_get_joint_impulses(edynhip_ctx *c, float *out) {
     EH_HIP(c, hipMemcpyAsync(orig.data(), c->j.orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
     for (uint32_t p = 0; p < n; ++p) {
-        for (int r = 0; r < kJointSlots; ++r) out[10 * (size_t)orig[p] + r] = imp[(size_t)r * c->j.cap + p];
+        for (int r = 0; r < kJointApiSlots; ++r) out[10 * (size_t)orig[p] + r] = imp[(size_t)r * c->j.cap + p];
         out[10 * (size_t)orig[p] + 9] = ang[p];
     }
     return EDYNHIP_OK;

@@ -87,7 +87,10 @@ __device__ __forceinline__ void emit_event(const EventSink &ev, uint32_t type, u
 // Joint rows live in SLOTS that mirror the constraints' applied_impulse fields (hinge_constraint.hpp:64-71,
 // point_constraint.hpp:28-29): hinge 0..2 linear, 3..4 hinge p/q, 5 limit, 6 bump stop, 7 spring, 8 torque; point 0..2 linear,
 // 3 friction torque. Which optional slots carry a row this step is decided by k_prep_joints (rmask).
-constexpr int kJointSlots = 9, kJointParams = 16, kJointApiParams = 10;   // edynhip_joints.params / set_joint_params carry the first 10
+// 24 slots / 64 parameters are the generic constraint's (6 degrees of freedom x 4 row kinds / 10 floats); the other types use the
+// first 9 / 16. edynhip_joints.params and edynhip_set_joint_params carry the first 10 parameters, edynhip_get_joint_impulses the
+// first 9 slots.
+constexpr int kJointSlots = 24, kJointParams = 64, kJointApiParams = 10, kJointApiSlots = 9, kJointBaseSlots = 9;
 struct Joints {
     uint32_t n = 0, cap = 0, num_colours = 0, rows = 0;
     // definitions, in colour-sorted order; orig[] maps back to the caller's index
@@ -106,6 +109,8 @@ struct Joints {
     float4 *wp = nullptr, *wq = nullptr;            // world hinge p, q
     float4 *wax = nullptr;                          // world axis of the optional rows (hinge axis / relative spin direction)
     float4 *wbx = nullptr;                          // cvjoint: axis of the bend-spring row (slot 8)
+    float4 *gJ = nullptr;                           // generic: [18][cap] per degree of freedom d three vectors at (3 d + v) * cap + i -
+                                                    // linear: axis, rA x axis, rB x axis; angular: axis on A, axis on B, -
     float *eff = nullptr, *rhs = nullptr;           // [kJointSlots][cap]
     float *lo = nullptr, *hi = nullptr;             // [kJointSlots][cap] impulse limits of the optional rows
     uint32_t *rmask = nullptr;                      // [cap] slots that carry a row this step
@@ -279,6 +284,7 @@ struct edynhip_ctx {
     float *state_host = nullptr;   // pinned mirror
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
+    bool has_generic = false;      // some joint is a generic_constraint (k_prep_generic runs)
     bool extras = false;           // some body carries a contact_extras material: extras storage exists, per-colour schedule
     uint32_t step_index = 0;       // completed steps
     // contact events: device list of the current edynhip_step call, per-manifold "still there" marks of the previous array

@@ -1082,9 +1082,10 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     auto P = [&](int k) { return j.params[(size_t)k * j.cap + i]; };
     uint32_t mask = hinge ? 0x1Fu : 0x7u;
     // optional rows: per-slot error / restitution / limits (hinge_constraint.cpp:69-178, point_constraint.cpp:33-46)
-    float err[kJointSlots], rest[kJointSlots], lo[kJointSlots], hi[kJointSlots];
+    if (type == EDYNHIP_JOINT_GENERIC) return;   // k_prep_generic
+    float err[kJointBaseSlots], rest[kJointBaseSlots], lo[kJointBaseSlots], hi[kJointBaseSlots];
 #pragma unroll
-    for (int r = 0; r < kJointSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
+    for (int r = 0; r < kJointBaseSlots; ++r) { err[r] = 0; rest[r] = 0; lo[r] = -kScalarMax; hi[r] = kScalarMax; }
     if (type == EDYNHIP_JOINT_GRAVITY) {   // gravity_constraint.cpp:6-28
         const f3 d = A.pos - B.pos;
         const float l2 = fmaxf(length_sqr(d), kEps);
@@ -1292,7 +1293,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
     j.rA[i] = to4(rAx, 0); j.rB[i] = to4(rBx, 0); j.wp[i] = to4(wp, 0); j.wq[i] = to4(wq, 0); j.wax[i] = to4(wax, 0); j.wbx[i] = to4(wbx, 0);
     j.rmask[i] = mask;
 #pragma unroll
-    for (int r = 0; r < kJointSlots; ++r) {
+    for (int r = 0; r < kJointBaseSlots; ++r) {
         if (!((mask >> r) & 1u)) continue;
         f3 J0, J1, J2, J3;
         joint_rowJ(type, r, rAx, rBx, wp, wq, wax, wbx, J0, J1, J2, J3);
@@ -1304,6 +1305,103 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt) {
         j.lo[s] = lo[r]; j.hi[s] = hi[r];
     }
 }
+// generic_constraint.cpp:10-258. One lane per joint; degree of freedom d = 0..2 linear along frame[0]'s columns (rotated by A),
+// 3..5 angular (twist about the x axes via shortest_arc; the other two from the angle between B's x axis and A's z / y axis);
+// rows of d in slots 4 d + {0 limit, 1 bump stop, 2 spring, 3 friction/damping}. The Jacobian vectors of each degree of
+// freedom are kept for the solve kernel (Joints::gJ).
+DI void generic_rowJ(const Joints &j, uint32_t i, int d, f3 &J0, f3 &J1, f3 &J2, f3 &J3) {
+    const f3 v0 = from4(j.gJ[(size_t)(3 * d) * j.cap + i]), v1 = from4(j.gJ[(size_t)(3 * d + 1) * j.cap + i]);
+    if (d < 3) { J0 = v0; J1 = v1; J2 = -v0; J3 = -from4(j.gJ[(size_t)(3 * d + 2) * j.cap + i]); }
+    else { J0 = mk3(0, 0, 0); J1 = v0; J2 = mk3(0, 0, 0); J3 = -v1; }
+}
+__global__ void k_prep_generic(Joints j, Bodies b, float dt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n || j.type[i] != EDYNHIP_JOINT_GENERIC) return;
+    const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
+    if (edge_asleep(b.flags[ia], b.flags[ib])) return;
+    const BRef A = load_bref(b, ia), B = load_bref(b, ib);
+    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    const f3 rA = pA - A.pos, rB = pB - B.pos;
+    const f3 pivot_offset = pB - pA;
+    const f3 colA[3] = {from4(j.axA[i]), from4(j.pA[i]), from4(j.qA[i])};
+    const f3 axisA_x = rotate(A.orn, colA[0]), axisB_x = rotate(B.orn, from4(j.axB[i]));
+    uint32_t mask = 0;
+    for (int d = 0; d < 6; ++d) {
+        auto P = [&](int k) { return j.params[(size_t)(10 * d + k) * j.cap + i]; };
+        const bool limit_enabled = P(0) != 0, angular = d >= 3;
+        const float vmin = P(1), vmax = P(2), limit_restitution = P(3), bump_len = P(4), bump_stiffness = P(5), friction = P(6),
+                    rest = P(7), spring_stiffness = P(8), damping = P(9);
+        const bool non_zero_limit = vmin < vmax;
+        f3 J0, J1, J2, J3, axA = mk3(0, 0, 0), axB = mk3(0, 0, 0);
+        float current;
+        if (!angular) {
+            const f3 axisA = rotate(A.orn, d == 0 ? colA[0] : (d == 1 ? colA[1] : colA[2]));
+            J0 = axisA; J1 = cross(rA, axisA); J2 = -axisA; J3 = -cross(rB, axisA);
+            current = dot(pivot_offset, axisA);
+            j.gJ[(size_t)(3 * d) * j.cap + i] = to4(axisA, 0); j.gJ[(size_t)(3 * d + 1) * j.cap + i] = to4(J1, 0);
+            j.gJ[(size_t)(3 * d + 2) * j.cap + i] = to4(cross(rB, axisA), 0);
+        } else {
+            const int k = d - 3;
+            if (k == 0) {
+                current = cvjoint_relative_angle(A.orn, B.orn, axisA_x, axisB_x, colA[1], colA[2], from4(j.pB[i]));
+                axA = axisA_x; axB = axisB_x;
+            } else {
+                const f3 other = rotate(A.orn, k == 1 ? colA[2] : colA[1]);
+                const float cos_angle = fminf(fmaxf(dot(axisB_x, other), -1.0f), 1.0f);
+                current = kPi * 0.5f - (float)acos((double)cos_angle);   // correctly rounded, like atan2_cr
+                f3 axis = cross(other, axisB_x);
+                if (!try_normalize(axis)) axis = k == 1 ? mk3(0, 0, 1) : mk3(0, 1, 0);
+                axA = axB = -axis;
+            }
+            J0 = mk3(0, 0, 0); J1 = axA; J2 = mk3(0, 0, 0); J3 = -axB;
+            j.gJ[(size_t)(3 * d) * j.cap + i] = to4(axA, 0); j.gJ[(size_t)(3 * d + 1) * j.cap + i] = to4(axB, 0);
+        }
+        const float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.inv_I, B.inv_m, B.inv_I);
+        const float relvel = rel_speed(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
+        auto put = [&](int kind, float error, float erp, float restitution, float lo, float hi) {
+            const size_t s = (size_t)(4 * d + kind) * j.cap + i;
+            j.eff[s] = em; j.rhs[s] = -(error * erp + relvel * (1 + restitution)); j.lo[s] = lo; j.hi[s] = hi;
+            mask |= 1u << (4 * d + kind);
+        };
+        if (limit_enabled) {
+            float error = 0, erp = 0.2f, restitution = 0, lo = -kLarge, hi = kLarge;
+            if (non_zero_limit) {
+                float limit_error;
+                const float mid = (vmin + vmax) / 2.0f;
+                if (current < mid) { limit_error = vmin - current; lo = -kLarge; hi = 0; }
+                else { limit_error = vmax - current; lo = 0; hi = kLarge; }
+                if (angular) error = limit_error / dt;
+                else { if (current > vmin && current < vmax) error = limit_error / dt; erp = 0.9f; }
+                restitution = limit_restitution;
+            } else if (angular) {
+                error = -current / dt;
+            }
+            put(0, error, erp, restitution, lo, hi);
+        }
+        if (limit_enabled && non_zero_limit && bump_stiffness > 0 && bump_len > 0) {
+            float defl = 0;
+            const float bmin = vmin + bump_len, bmax = vmax - bump_len;
+            if (current < bmin) defl = current - bmin;
+            else if (current > bmax) defl = current - bmax;
+            const float imp = bump_stiffness * defl * dt;
+            put(1, -defl / dt, 0.2f, 0.0f, fminf(imp, 0.0f), fmaxf(0.0f, imp));
+        }
+        if (spring_stiffness > 0) {
+            const float defl = current - rest;
+            const float imp = spring_stiffness * defl * dt;
+            put(2, -defl / dt, 0.2f, 0.0f, fminf(imp, 0.0f), fmaxf(0.0f, imp));
+        }
+        if (friction > 0 || damping > 0) {
+            float fi = friction * dt;
+            if (damping > 0) {
+                const float rel = angular ? dot(A.w, axA) - dot(B.w, axB) : relvel;
+                fi += fabsf(rel) * damping * dt;
+            }
+            put(3, 0.0f, 0.2f, 0.0f, -fi, fi);
+        }
+    }
+    j.rmask[i] = mask;
+}
 template <bool WARM>
 __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) {
     uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1314,11 +1412,13 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     load_delta(b, ia, ib, d);
     const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]), wbx = from4(j.wbx[i]);
     const int type = j.type[i];
-    const uint32_t mask = j.rmask[i];
-    for (int r = 0; r < kJointSlots; ++r) {
-        if (!((mask >> r) & 1u)) continue;
+    uint32_t todo = j.rmask[i];
+    while (todo) {   // slots in ascending order (the reference's row order inside a constraint)
+        const int r = __ffs((int)todo) - 1;
+        todo &= todo - 1u;
         f3 J0, J1, J2, J3;
-        joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
+        if (type == EDYNHIP_JOINT_GENERIC) generic_rowJ(j, i, r >> 2, J0, J1, J2, J3);
+        else joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
         const size_t s = (size_t)r * j.cap + i;
         float imp = j.impulse[s];
         if (WARM) {
@@ -1724,7 +1824,7 @@ k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl
 __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
     const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
     // point, distance and cone constraints have no solve_position (island_solver.cpp:252-260)
-    bool active = i < end && (j.type[i] == EDYNHIP_JOINT_HINGE || j.type[i] == EDYNHIP_JOINT_CVJOINT);
+    bool active = i < end && (j.type[i] == EDYNHIP_JOINT_HINGE || j.type[i] == EDYNHIP_JOINT_CVJOINT || j.type[i] == EDYNHIP_JOINT_GENERIC);
     if (active && edge_asleep(b.flags[j.bodyA[i]], b.flags[j.bodyB[i]])) active = false;
     uint32_t label = 0;
     float max_err = 0;
@@ -1734,6 +1834,21 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     label = b.island[A.proc ? ia : ib];
     active = isl_done[label] == 0;
     if (active) {
+    if (j.type[i] == EDYNHIP_JOINT_GENERIC) {   // generic_constraint.cpp:260-290: the limited linear degrees of freedom
+        for (int k = 0; k < 3; ++k) {
+            if (j.params[(size_t)(10 * k) * j.cap + i] == 0) continue;
+            const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+            const f3 off = pB - pA, rA = pA - A.pos, rB = pB - B.pos;
+            const f3 axisA = rotate(A.orn, from4(k == 0 ? j.axA[i] : (k == 1 ? j.pA[i] : j.qA[i])));
+            const float proj = dot(off, axisA), vmin = j.params[(size_t)(10 * k + 1) * j.cap + i], vmax = j.params[(size_t)(10 * k + 2) * j.cap + i];
+            float error = 0;
+            if (proj < vmin) error = proj - vmin;
+            else if (proj > vmax) error = proj - vmax;
+            pos_solve(A, B, axisA, cross(rA, axisA), -axisA, -cross(rB, axisA), error, max_err);
+        }
+        store_pbody(b, ia, A);
+        store_pbody(b, ib, B);
+    } else {
     if (j.type[i] == EDYNHIP_JOINT_CVJOINT) {   // cvjoint_constraint.cpp:224-246: angular correction along the twist axes
         const f3 tA = rotate(A.orn, from4(j.axA[i])), tB = rotate(B.orn, from4(j.axB[i]));
         const float current = cvjoint_relative_angle(A.orn, B.orn, tA, tB, from4(j.pA[i]), from4(j.qA[i]), from4(j.pB[i]));
@@ -1768,6 +1883,7 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     }
     store_pbody(b, ia, A);
     store_pbody(b, ib, B);
+    }
     }
     }
     publish_error(active, max_err, label, isl_err);
@@ -2173,6 +2289,7 @@ int solve(edynhip_ctx *c) {
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
+    if (j.n && c->has_generic) hipLaunchKernelGGL(k_prep_generic, dim3(blocks(j.n, 64)), dim3(64), 0, s, j, c->b, dt);
     // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
     const bool push = j.n == 0 && na > 0 && !c->extras;
     if (na) {

@@ -211,6 +211,20 @@ class World:
         p = np.zeros(10, np.float32); p[:len(params)] = params
         self._check(self._L.edynhip_set_joint_params(self._h, int(joint), _ptr(p)))
 
+    def set_generic_definition(self, joint, frameA, frameB, dofs):
+        """generic_constraint: frames and [6][10] degree-of-freedom parameters (edynhip.h edynhip_set_generic_definition)."""
+        self._flush_defs()
+        p = np.ascontiguousarray(np.asarray(dofs, np.float32).reshape(60))
+        fa = np.ascontiguousarray(np.asarray(frameA, np.float32).reshape(9)); fb = np.ascontiguousarray(np.asarray(frameB, np.float32).reshape(9))
+        self._check(self._L.edynhip_set_generic_definition(self._h, int(joint), _ptr(fa), _ptr(fb), _ptr(p)))
+
+    def get_joint_impulses24(self):
+        self._flush_defs()
+        out = np.zeros((self.nj, 24), np.float32)
+        if self.nj:
+            self._check(self._L.edynhip_get_joint_slot_impulses(self._h, _ptr(out)))
+        return out
+
     def set_joint_definition(self, joint, frameA, frameB, params):
         """Frames (3x3, first column = cone direction / twist axis) and parameters of a cone or cvjoint constraint (edynhip.h)."""
         self._flush_defs()

@@ -111,6 +111,22 @@ struct soft_distance_constraint : constraint_base {                             
     std::array<vector3, 2> pivot;
     scalar distance{0}, stiffness{scalar(1e10)}, damping{scalar(1e10)};
 };
+struct generic_constraint : constraint_base {                                                 // constraints/generic_constraint.hpp:18-76
+    struct linear_dof {
+        bool limit_enabled{true};
+        scalar offset_min{}, offset_max{}, limit_restitution{}, bump_stop_length{}, bump_stop_stiffness{}, friction_force{}, rest_offset{},
+               spring_stiffness{}, damping{};
+    };
+    struct angular_dof {
+        bool limit_enabled{true};
+        scalar angle_min{}, angle_max{}, limit_restitution{}, bump_stop_angle{}, bump_stop_stiffness{}, friction_torque{}, rest_angle{},
+               spring_stiffness{}, damping{};
+    };
+    std::array<vector3, 2> pivot;
+    std::array<matrix3x3, 2> frame{matrix3x3{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}}, matrix3x3{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}}};
+    std::array<linear_dof, 3> linear_dofs;
+    std::array<angular_dof, 3> angular_dofs;
+};
 struct gravity_constraint : constraint_base {};                                               // constraints/gravity_constraint.hpp (Newtonian attraction)
 inline constexpr matrix3x3 matrix3x3_identity{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}};
 struct cone_constraint : constraint_base {                                                    // constraints/cone_constraint.hpp:19-49
@@ -215,6 +231,7 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
         else if (auto *sc = registry.try_get<soft_distance_constraint>(e)) {
             jt[j] = EDYNHIP_JOINT_SOFT_DISTANCE; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
         } else if (auto *gc = registry.try_get<gravity_constraint>(e)) { jt[j] = EDYNHIP_JOINT_GRAVITY; fill(*gc, std::array<vector3, 2>{}); }
+        else if (auto *ge = registry.try_get<generic_constraint>(e)) { jt[j] = EDYNHIP_JOINT_GENERIC; fill(*ge, ge->pivot); }   // (definition follows)
         else if (auto *cc = registry.try_get<cone_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CONE; fill(*cc, cc->pivot); }      // frames / parameters follow
         else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CVJOINT; fill(*cv, cv->pivot); }  // (define_frames below)
         else {
@@ -331,6 +348,18 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             rows9(cc->frame, fa);
             q[0] = cc->span_tan[0]; q[1] = cc->span_tan[1]; q[2] = cc->restitution; q[3] = cc->bump_stop_stiffness; q[4] = cc->bump_stop_length;
             check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
+        } else if (auto *ge = registry.try_get<generic_constraint>(e)) {
+            rows9(ge->frame[0], fa); rows9(ge->frame[1], fb);
+            float dof[60];
+            for (int d = 0; d < 3; ++d) {
+                const auto &l = ge->linear_dofs[d]; const auto &a = ge->angular_dofs[d];
+                const float lv[10] = {l.limit_enabled ? 1.f : 0.f, l.offset_min, l.offset_max, l.limit_restitution, l.bump_stop_length, l.bump_stop_stiffness,
+                                      l.friction_force, l.rest_offset, l.spring_stiffness, l.damping};
+                const float av[10] = {a.limit_enabled ? 1.f : 0.f, a.angle_min, a.angle_max, a.limit_restitution, a.bump_stop_angle, a.bump_stop_stiffness,
+                                      a.friction_torque, a.rest_angle, a.spring_stiffness, a.damping};
+                for (int k = 0; k < 10; ++k) { dof[10 * d + k] = lv[k]; dof[10 * (3 + d) + k] = av[k]; }
+            }
+            check(s, edynhip_set_generic_definition(s.ctx, j, fa, fb, dof));
         } else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) {
             rows9(cv->frame[0], fa); rows9(cv->frame[1], fb);
             const float v[15] = {cv->twist_min, cv->twist_max, cv->twist_restitution, cv->twist_bump_stop_angle, cv->twist_bump_stop_stiffness,
@@ -403,12 +432,13 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
     for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
         const entt::entity e = s.constraints[j];
         if (e == entt::null) continue;
-        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint>(e);
+        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint, generic_constraint>(e);
         if (alive) {   // a joint whose body was destroyed goes with it
             const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
                                       : registry.all_of<distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<distance_constraint>(e))
                                       : registry.all_of<soft_distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<soft_distance_constraint>(e))
                                       : registry.all_of<gravity_constraint>(e) ? static_cast<constraint_base &>(registry.get<gravity_constraint>(e))
+                                      : registry.all_of<generic_constraint>(e) ? static_cast<constraint_base &>(registry.get<generic_constraint>(e))
                                       : registry.all_of<cone_constraint>(e) ? static_cast<constraint_base &>(registry.get<cone_constraint>(e))
                                       : registry.all_of<cvjoint_constraint>(e) ? static_cast<constraint_base &>(registry.get<cvjoint_constraint>(e))
                                       : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
@@ -416,7 +446,7 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
         }
         if (!alive) {
             s.constraints[j] = entt::null;
-            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint, generic_constraint>(e)) registry.destroy(e);   // its body is gone
             if (j < s.uploaded_constraints) gone_joints.push_back(j);
         }
     }
@@ -713,8 +743,8 @@ template <typename T, typename... SetupFunc>
 void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
     static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint> || std::is_same_v<T, distance_constraint> ||
                       std::is_same_v<T, soft_distance_constraint> || std::is_same_v<T, cone_constraint> || std::is_same_v<T, cvjoint_constraint> ||
-                      std::is_same_v<T, gravity_constraint>,
-                  "point, hinge, distance, soft_distance, cone, cvjoint and gravity constraints are on the accelerated path");
+                      std::is_same_v<T, gravity_constraint> || std::is_same_v<T, generic_constraint>,
+                  "unknown constraint type");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     auto &con = registry.emplace<T>(entity);
     con.body = {body0, body1};

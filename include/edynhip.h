@@ -55,7 +55,8 @@ enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_SOFT_DISTANCE = 3,  /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */
        EDYNHIP_JOINT_CONE = 4,           /* cone_constraint.cpp:12-104; frames + params through edynhip_set_joint_definition */
        EDYNHIP_JOINT_CVJOINT = 5,        /* cvjoint_constraint.cpp:12-302; frames + params through edynhip_set_joint_definition */
-       EDYNHIP_JOINT_GRAVITY = 6         /* gravity_constraint.cpp:6-34: Newtonian attraction between the two bodies; impulse slot 0 */ };
+       EDYNHIP_JOINT_GRAVITY = 6,        /* gravity_constraint.cpp:6-34: Newtonian attraction between the two bodies; impulse slot 0 */
+       EDYNHIP_JOINT_GENERIC = 7         /* generic_constraint.cpp:10-330; frames + 6 x 10 parameters through edynhip_set_generic_definition */ };
 /* contact_normal_attachment (include/edyn/collision/contact_normal_attachment.hpp:17-21) */
 enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2 };
 
@@ -251,6 +252,15 @@ int edynhip_get_joint_impulses(edynhip_ctx *ctx, float *impulses10);
  *            5 twist spring, 6 twist friction / damping, 7 bend friction / damping, 8 bend spring; [9] of
  *            edynhip_get_joint_impulses = the tracked twist angle. */
 int edynhip_set_joint_definition(edynhip_ctx *ctx, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params16);
+
+/* generic_constraint: frames (row-major 3x3) and, per degree of freedom d (0..2 translation along frame_a's columns, 3..5 rotation:
+ * twist about x, then the two bending angles), 10 floats dof[10 d + ..]: limit_enabled, min, max, limit_restitution,
+ * bump_stop_length (angle), bump_stop_stiffness, friction force (torque), rest offset (angle), spring_stiffness, damping
+ * (generic_constraint.hpp:23-70). Created by edynhip_set_joints / add_joints with identity frames and every degree of freedom
+ * free. edynhip_get_joint_slot_impulses: out[n][24], slot 4 d + {0 limit, 1 bump stop, 2 spring, 3 friction / damping} for
+ * generic constraints, the first 9 slots as documented above for the other types. */
+int edynhip_set_generic_definition(edynhip_ctx *ctx, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *dof60);
+int edynhip_get_joint_slot_impulses(edynhip_ctx *ctx, float *impulses24);
 
 /* contact_extras materials: material::{spin_friction, roll_friction, stiffness, damping} of bodies [first, first + n)
  * (comp/material.hpp:15-22; any array may be NULL = the default 0, 0, large_scalar, large_scalar). Contact points created

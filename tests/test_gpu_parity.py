@@ -1081,3 +1081,21 @@ def test_gravity_constraint_bit_exact():
             assert_state_equal(g, o)
             assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
     assert np.isfinite(g.get_state()[0]).all() and np.abs(g.get_joint_impulses()[:, 0]).min() > 0
+
+
+def test_generic_constraint_bit_exact():
+    """generic_constraint on the device (k_prep_generic: six degrees of freedom x limit / bump stop / spring / friction rows,
+    erp 0.9 on the linear limits; k_joint_solve over 24 slots; linear position correction) against the oracle, all 24 applied
+    impulses included; pinned to the real engine in tests/test_reference_engine.py::test_generic_constraint_matches_the_real_engine."""
+    from test_reference_engine import _generic_scene
+    sc, defs = _generic_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for j, fa, fb, d in defs:
+        g.set_generic_definition(j, fa, fb, d); o.set_generic_definition(j, fa, fb, d)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 30 == 0 or s < 3:
+            assert np.isfinite(g.get_state()[0]).all(), s
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses24().view(np.uint32), o.get_joint_impulses24().view(np.uint32)), s
+    assert (np.abs(g.get_joint_impulses24()).max(axis=0) > 0).sum() >= 15
