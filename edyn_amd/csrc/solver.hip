@@ -1412,13 +1412,8 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
     load_delta(b, ia, ib, d);
     const f3 rA = from4(j.rA[i]), rB = from4(j.rB[i]), wp = from4(j.wp[i]), wq = from4(j.wq[i]), wax = from4(j.wax[i]), wbx = from4(j.wbx[i]);
     const int type = j.type[i];
-    uint32_t todo = j.rmask[i];
-    while (todo) {   // slots in ascending order (the reference's row order inside a constraint)
-        const int r = __ffs((int)todo) - 1;
-        todo &= todo - 1u;
-        f3 J0, J1, J2, J3;
-        if (type == EDYNHIP_JOINT_GENERIC) generic_rowJ(j, i, r >> 2, J0, J1, J2, J3);
-        else joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
+    const uint32_t mask = j.rmask[i];
+    auto row = [&](int r, f3 J0, f3 J1, f3 J2, f3 J3) {
         const size_t s = (size_t)r * j.cap + i;
         float imp = j.impulse[s];
         if (WARM) {
@@ -1432,6 +1427,24 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
             else if (ni > hi) { dimp = hi - imp; ni = hi; }
             j.impulse[s] = ni;
             apply_impulse(d, J0, J1, J2, J3, dimp);
+        }
+    };
+    if (type == EDYNHIP_JOINT_GENERIC) {   // up to 24 rows: visit the set slots in ascending order
+        uint32_t todo = mask;
+        while (todo) {
+            const int r = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            f3 J0, J1, J2, J3;
+            generic_rowJ(j, i, r >> 2, J0, J1, J2, J3);
+            row(r, J0, J1, J2, J3);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kJointBaseSlots; ++r) {   // unrolled: the loads of all rows issue together
+            if (!((mask >> r) & 1u)) continue;
+            f3 J0, J1, J2, J3;
+            joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
+            row(r, J0, J1, J2, J3);
         }
     }
     store_delta(b, ia, ib, d);

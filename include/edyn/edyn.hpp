@@ -200,6 +200,8 @@ struct gpu_stepper {
     unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
     std::unordered_map<uint64_t, entt::entity> manifold_entities;   // (body index A << 32 | body index B) -> contact_manifold entity
     std::unordered_map<uint64_t, entt::entity> point_entities;      // device point id -> contact_point entity
+    void (*pre_step)(entt::registry &){nullptr};    // settings.pre_step_callback / post_step_callback (context/step_callback.hpp)
+    void (*post_step)(entt::registry &){nullptr};
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
@@ -587,6 +589,19 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
     if (s.state_dirty) upload_state(registry, s);   // also after an append: edits made in the same frame are not lost
     apply_params(s);
     if (steps == 0 || s.bodies.empty()) return;
+    if (s.pre_step || s.post_step) {
+        // step callbacks (stepper_sequential.cpp:76-78,97-99) see the registry between steps: one step per launch, the state
+        // written back after each, edits made by a callback (followed by edyn::refresh) uploaded before the next
+        for (unsigned k = 0; k < steps; ++k) {
+            if (s.pre_step) s.pre_step(registry);
+            if (s.state_dirty) upload_state(registry, s);
+            check(s, timed ? edynhip_step_timed(s.ctx, 1, first_time + step_dt * k, step_dt) : edynhip_step(s.ctx, 1));
+            write_back(registry, s);
+            sync_contacts(registry, s);
+            if (s.post_step) s.post_step(registry);
+        }
+        return;
+    }
     check(s, timed ? edynhip_step_timed(s.ctx, steps, first_time, step_dt) : edynhip_step(s.ctx, steps));
     if (async) {
         check(s, edynhip_snapshot(s.ctx));   // returns at once; read at the next update
@@ -649,6 +664,10 @@ inline void set_solver_velocity_iterations(entt::registry &registry, unsigned n)
 inline unsigned get_solver_position_iterations(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.num_solver_position_iterations; }
 inline void set_solver_position_iterations(entt::registry &registry, unsigned n) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.num_solver_position_iterations = n; s.params_dirty = true; }
 /// Tell the stepper that position/orientation/linvel/angvel were edited by the user (registry.patch analogue).
+/// edyn::set_pre_step_callback / set_post_step_callback (edyn.hpp, context/step_callback.hpp): called before / after every fixed step.
+using step_callback_t = void (*)(entt::registry &);
+inline void set_pre_step_callback(entt::registry &registry, step_callback_t func) { registry.ctx().get<detail::gpu_stepper>().pre_step = func; }
+inline void set_post_step_callback(entt::registry &registry, step_callback_t func) { registry.ctx().get<detail::gpu_stepper>().post_step = func; }
 inline void refresh(entt::registry &registry) { registry.ctx().get<detail::gpu_stepper>().state_dirty = true; }
 
 /// stepper_sequential::update (stepper_sequential.cpp:28-119): fixed-dt accumulator; when more steps are due than

@@ -329,6 +329,15 @@ class World:
         recs = np.ascontiguousarray(recs, dtype=MANIFOLD_DTYPE)
         self.L.orc_set_manifolds(self.h, recs.ctypes.data_as(C.c_void_p), len(recs))
 
+    def set_material_id(self, body, mid):
+        f = self.L.orc_set_material_id; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
+        f(self.h, body, mid)
+
+    def insert_material_mixing(self, id0, id1, restitution=0.0, friction=0.5, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
+        m = np.array([restitution, friction, spin, roll, stiffness, damping], np.float32)
+        f = self.L.orc_insert_material_mixing; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, id0, id1, _fp(m))
+
     # contact_extras (rolling / spinning friction, soft contacts)
     def set_material_extras(self, body, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
         f = self.L.orc_set_material_extras; f.argtypes = [C.c_void_p, C.c_uint32] + [C.c_float] * 4; f.restype = None
@@ -655,6 +664,15 @@ class RefWorld:
         b = m["body"].astype(np.uint64)
         hi = np.maximum(b[:, 0], b[:, 1]); lo = np.minimum(b[:, 0], b[:, 1])
         return np.sort((hi << np.uint64(32)) | lo)
+
+    def set_material_id(self, body, mid):
+        f = self.L.refw_set_material_id; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
+        f(self.h, body, mid)
+
+    def insert_material_mixing(self, id0, id1, restitution=0.0, friction=0.5, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
+        m = np.array([restitution, friction, spin, roll, stiffness, damping], np.float32)
+        f = self.L.refw_insert_material_mixing; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, id0, id1, _fp(m))
 
     def set_material_extras(self, body, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
         f = self.L.refw_set_material_extras; f.argtypes = [C.c_void_p, C.c_uint32] + [C.c_float] * 4; f.restype = None

@@ -290,6 +290,12 @@ void orc_get_joint_impulses24(void *h, float *out24) {
     for (size_t i = 0; i < w->joints.size(); ++i)
         for (int k = 0; k < 24; ++k) out24[24 * i + k] = w->joints[i].alive ? w->joints[i].impulse[k] : 0.0f;
 }
+// material ids and the mix table (edyn::insert_material_mixing)
+void orc_set_material_id(void *h, uint32_t body, uint32_t id) { ((World *)h)->bodies[body].material_id = id; }
+void orc_insert_material_mixing(void *h, uint32_t id0, uint32_t id1, const float *m6) {
+    World *w = (World *)h;
+    w->mix_table[World::IdPair{id0, id1}] = {m6[0], m6[1], m6[2], m6[3], m6[4], m6[5]};
+}
 // contact_extras materials and impulses
 void orc_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
     Body &b = ((World *)h)->bodies[body];

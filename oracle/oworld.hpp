@@ -55,6 +55,7 @@ struct Body {
     bool has_material = true;
     float friction = 0.5f, restitution = 0.0f;
     float spin_friction = 0, roll_friction = 0, stiffness = kLarge, damping = kLarge;   // comp/material.hpp:15-22
+    uint32_t material_id = 0xFFFFu;   // material::id (UnassignedID): key into the material mix table (material_mixing.hpp:36-82)
     uint64_t group = ~0ull, mask = ~0ull;
     std::vector<uint32_t> exclusions;   // collision_exclusion (comp/collision_exclusion.hpp:16-31)
     bool removed = false;               // destroyed entity: the index stays reserved
@@ -406,9 +407,30 @@ public:
         };
         one_way(a, b); one_way(b, a);
     }
-    bool tags_restitution(uint32_t a, uint32_t b) const {   // constraint_util.cpp:83-101 (no material table: material_mix_restitution = min)
+    // material mix table (registry.ctx material_mix_table; edyn::insert_material_mixing): an entry for the unordered pair of material
+    // ids replaces every mixing rule. Values: restitution, friction, spin_friction, roll_friction, stiffness, damping.
+    // The reference keeps the table in a std::map keyed by unordered_pair, whose operator< (core/unordered_pair.hpp:32-40) treats
+    // {a, b} and {b, a} as equivalent but orders everything else by (first, second) - not a strict weak ordering, so whether a
+    // lookup with the ids in the other order FINDS its entry depends on the tree's shape. That is what the reference simulates
+    // with; it is reproduced by using the same container with the same comparator and the same insertion sequence (same libstdc++).
+    struct IdPair { uint32_t first, second; };
+    struct IdPairLess {
+        bool operator()(const IdPair &a, const IdPair &b) const {
+            if (a.first == b.second && a.second == b.first) return false;
+            if (a.first == b.first) return a.second < b.second;
+            return a.first < b.first;
+        }
+    };
+    std::map<IdPair, std::array<float, 6>, IdPairLess> mix_table;
+    const std::array<float, 6> *mix_entry(const Body &A, const Body &B) const {   // key = {material of body[0], material of body[1]}
+        auto it = mix_table.find(IdPair{A.material_id, B.material_id});
+        return it == mix_table.end() ? nullptr : &it->second;
+    }
+    bool tags_restitution(uint32_t a, uint32_t b) const {   // constraint_util.cpp:83-101
         const Body &A = bodies[a], &B = bodies[b];
-        return A.has_material && B.has_material && std::min(A.restitution, B.restitution) > kEps;
+        if (!(A.has_material && B.has_material)) return false;
+        if (const auto *e = mix_entry(A, B)) return (*e)[0] > kEps;
+        return std::min(A.restitution, B.restitution) > kEps;
     }
     void broadphase() {
         const float sep = kContactBreakingThreshold * 1.3f;   // broadphase.hpp:18
@@ -499,6 +521,11 @@ public:
         cp.attachment = rp.attachment; cp.distance = rp.distance;
         set_local_normal(m, cp);
         const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        if (const auto *e = mix_entry(A, B)) {   // assign_material_properties, collision_util.cpp:293-299
+            cp.restitution = (*e)[0]; cp.friction = (*e)[1]; cp.spin_friction = (*e)[2]; cp.roll_friction = (*e)[3];
+            cp.stiffness = (*e)[4]; cp.damping = (*e)[5];
+            return cp;
+        }
         cp.friction = std::sqrt(A.friction * B.friction);            // material_mixing.hpp:16-18
         cp.restitution = std::min(A.restitution, B.restitution);     // :12-14
         cp.roll_friction = std::max(A.roll_friction, B.roll_friction);   // :24-26 (assign_material_properties, collision_util.cpp:309-315)
@@ -1611,11 +1638,16 @@ public:
             for (size_t k = 0; k < roll.size(); ++k) { roll_cp[k]->rolling_impulse[0] = roll[k].row[0].impulse; roll_cp[k]->rolling_impulse[1] = roll[k].row[1].impulse; }
             for (size_t k = 0; k < spin.size(); ++k) spin_cp[k]->spin_impulse = spin[k].impulse;
             for (int it = 0; it < pos_iters; ++it) {
+                // The per-type position passes are the ARGUMENTS of one function call (max_variadic(solve_each<C>(...)...),
+                // island_solver.cpp:324-333): their order is unspecified in C++, and the reference as built here (g++, x86-64)
+                // evaluates them right to left - the constraint types run in REVERSE tuple order: contact_extras, contact,
+                // cvjoint, generic, hinge. Pinned to that build (tests/test_reference_engine.py mixes the types).
                 PosSolver hs, cs;
-                for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
-                for (Joint *j : js) if (j->type == JOINT_GENERIC) generic_solve_position(*j, hs);
+                for (int pass = 1; pass >= 0; --pass)
+                    for (auto &cp : cps) if ((int)cp.first->pt[cp.second].extras() == pass) contact_solve_position(*cp.first, cp.first->pt[cp.second], cs);
                 for (Joint *j : js) if (j->type == JOINT_CVJOINT) cvjoint_solve_position(*j, hs);
-                for (auto &cp : cps) contact_solve_position(*cp.first, cp.first->pt[cp.second], cs);
+                for (Joint *j : js) if (j->type == JOINT_GENERIC) generic_solve_position(*j, hs);
+                for (Joint *j : js) if (j->type == JOINT_HINGE) hinge_solve_position(*j, hs);
                 if (std::max(hs.max_error, cs.max_error) < 0.005f) break;
             }
         }

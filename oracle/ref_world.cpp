@@ -530,6 +530,16 @@ uint32_t refw_get_contact_order(void *h, uint32_t *out3, uint32_t max_entries) {
     emit(reg.view<edyn::contact_extras_constraint>());
     return n;
 }
+void refw_set_material_id(void *h, uint32_t body, uint32_t id) {
+    auto *w = (ref_world *)h;
+    w->registry.get<edyn::material>(w->bodies[body]).id = (edyn::material::id_type)id;
+}
+void refw_insert_material_mixing(void *h, uint32_t id0, uint32_t id1, const float *m) {   // restitution, friction, spin, roll, stiffness, damping
+    auto *w = (ref_world *)h;
+    edyn::material_base mb;
+    mb.restitution = m[0]; mb.friction = m[1]; mb.spin_friction = m[2]; mb.roll_friction = m[3]; mb.stiffness = m[4]; mb.damping = m[5];
+    edyn::insert_material_mixing(w->registry, (edyn::material::id_type)id0, (edyn::material::id_type)id1, mb);
+}
 // material extras of a body (before its contacts are created): comp/material.hpp:15-22
 void refw_set_material_extras(void *h, uint32_t body, float spin, float roll, float stiffness, float damping) {
     auto *w = (ref_world *)h;

@@ -102,6 +102,19 @@ int main() {
     run(5);
     for (auto &m : edyn::get_contact_manifolds(registry)) CHECK(m.body[0] != lower && m.body[1] != lower);
 
+    // step callbacks: called once before and once after every fixed step, with the registry current in between
+    static int pre_calls = 0, post_calls = 0;
+    static float last_seen_y = 0;
+    static entt::entity watched;
+    watched = upper;
+    edyn::set_pre_step_callback(registry, [](entt::registry &) { ++pre_calls; });
+    edyn::set_post_step_callback(registry, [](entt::registry &r) { ++post_calls; last_seen_y = r.get<edyn::position>(watched).y; });
+    run(7);
+    CHECK(pre_calls == 7 && post_calls == 7);
+    CHECK(last_seen_y == registry.get<edyn::position>(upper).y);
+    edyn::set_pre_step_callback(registry, nullptr);
+    edyn::set_post_step_callback(registry, nullptr);
+
     // update(registry) without a time: the monotonic clock drives the accumulator
     edyn::update(registry);
     edyn::update(registry);

@@ -748,3 +748,40 @@ def test_generic_constraint_matches_the_real_engine():
     ji = ref.get_joint_impulses24()
     acted = np.abs(ji).max(axis=0) > 0
     assert acted[[0, 1, 2, 3, 4, 8, 11, 12, 13, 14, 15, 16, 18, 22, 23]].all(), acted
+
+
+def _mix_table_setup(w, n):
+    """Three material ids over the bodies (the plane is id 0) and a mix table covering some of the pairs."""
+    for i in range(n):
+        w.set_material_id(i, 0 if i == 0 else 1 + i % 3)
+    w.insert_material_mixing(0, 1, restitution=0.0, friction=0.9)
+    w.insert_material_mixing(1, 2, restitution=0.4, friction=0.1)
+    w.insert_material_mixing(2, 2, restitution=0.0, friction=0.3, roll=0.05, spin=0.02)
+    w.insert_material_mixing(0, 3, restitution=0.0, friction=0.6, stiffness=5000.0, damping=70.0)
+
+
+def test_material_mix_table_matches_the_real_engine():
+    """material_mix_table (material_mixing.hpp:36-82, assign_material_properties collision_util.cpp:291-299, the restitution tag
+    of a manifold constraint_util.cpp:90-100): an entry for a pair of material ids replaces every mixing rule - friction,
+    restitution (incl. whether the restitution solver sees the manifold), rolling / spinning friction, soft contacts."""
+    sc = scenes.box_pile(3, 3, 3, mixed=True)
+    n = len(sc["kind"])
+    sc["linvel"][1:] = (np.random.default_rng(4).normal(size=(n - 1, 3)) * (1.0, 0.5, 1.0)).astype(np.float32)
+    ref = ob.RefWorld(); ref.add_bodies(sc)
+    orc = ob.World(order=ob.ORDER_EXTERNAL); orc.add_bodies(sc)
+    _mix_table_setup(ref, n); _mix_table_setup(orc, n)
+    frictions = set()
+    for s in range(1, 201):
+        ref.step(1)
+        orc.set_ext_order(*ref.get_solve_order()); orc.step(1)
+        assert not orc.ext_order_mismatch(), s
+        for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+            assert np.isfinite(a).all(), (s, name)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (s, name, float(np.abs(a - b).max()))
+        if s % 20 == 0:
+            rm, om = _canon(ref.get_manifolds()), _canon(orc.get_manifolds())
+            assert np.array_equal(rm["num_points"], om["num_points"]), s
+            for fld in ("friction", "restitution", "normal_impulse"):
+                assert np.array_equal(rm["pt"][fld], om["pt"][fld]), (s, fld)
+            frictions |= set(int(round(float(x) * 100)) for x in rm["pt"]["friction"][rm["pt"]["friction"] > 0])
+    assert {90, 30} <= frictions and 50 in frictions   # table entries and the sqrt rule both occurred
