@@ -76,7 +76,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
            "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
-           "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses"]
+           "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing"]
 
 _lib = None
 
@@ -118,6 +118,8 @@ def lib():
         L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_snapshot.argtypes = [C.c_void_p]
         L.edynhip_set_joint_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edynhip_set_material_ids.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.edynhip_insert_material_mixing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.edynhip_set_generic_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_get_joint_slot_impulses.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_set_material_extras.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

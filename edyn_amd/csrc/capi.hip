@@ -462,7 +462,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 5; }   // 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 6; }   // 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -553,6 +553,7 @@ static int rebuild_broadphase_lists(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
+static int rebuild_mix_table(edynhip_ctx *c);
 static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip_bodies *in, const char *who) {
     if (!c || !in) return EDYNHIP_ERR_INVALID;
     if ((uint64_t)first + n > c->b.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, (std::string(who) + ": more than max_bodies").c_str());
@@ -562,7 +563,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     for (uint32_t i = 0; i < n; ++i)
         if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_CAPSULE)
             return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule)").c_str());
-    if (first == 0) { c->has_restitution = false; c->extras = false; }
+    if (first == 0) { c->has_restitution = false; c->extras = false; c->host_mat_id.clear(); c->b.mix_K = 0; for (auto &kv : c->host_mix) if (kv.second[0] > 0) c->has_restitution = true; }
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)
     if (first == 0) { c->host_joints.clear(); c->j.n = 0; c->j.num_colours = 0; c->j.rows = 0; c->host_excl.clear(); if (c->excl) (void)hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream); }
@@ -589,6 +590,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         c->host_shape.insert(c->host_shape.end(), in->shape_type, in->shape_type + n);
     }
     if (rc == EDYNHIP_OK) rc = rebuild_broadphase_lists(c);
+    if (rc == EDYNHIP_OK && first != 0 && c->b.mix_K) rc = rebuild_mix_table(c);   // appended bodies carry no material id yet
     (void)hipStreamSynchronize(c->stream);
     for (void *p : tmp) (void)hipFree(p);
     if (first == 0) {   // a new world: no manifolds, no running sleep timers (appended bodies keep every index stable instead)
@@ -1176,6 +1178,20 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
 }
 
 // ---- contact_extras materials (comp/material.hpp:15-22; contact_extras_constraint.cpp)
+static int ensure_extras_storage(edynhip_ctx *c) {   // the per-point storage and the extras rows come into existence with the first such material
+    if (!c->m[0].xmat) {
+        for (int k = 0; k < 2; ++k) {
+            EH_TRY(dalloc(c, c->m[k].xmat, (size_t)c->m[k].cap * kMaxPts)); EH_TRY(dalloc(c, c->m[k].ximp, (size_t)c->m[k].cap * kMaxPts));
+        }
+        EH_TRY(dalloc(c, c->rows.rwx, (size_t)c->m[0].cap * kMaxPts * kXPoint));
+        // points that already exist keep plain contact_constraint behaviour: default material, no impulses
+        std::vector<float4> def((size_t)c->m[0].cap * kMaxPts, make_float4(0, 0, kLarge, kLarge));
+        for (int k = 0; k < 2; ++k) EH_HIP(c, hipMemcpyAsync(c->m[k].xmat, def.data(), def.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        EH_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->extras = true;
+    return EDYNHIP_OK;
+}
 int edynhip_set_material_extras(edynhip_ctx *c, uint32_t first, uint32_t n, const float *spin, const float *roll, const float *stiffness, const float *damping) {
     if (!c) return EDYNHIP_ERR_INVALID;
     if ((uint64_t)first + n > c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_extras: body range out of bounds");
@@ -1188,20 +1204,63 @@ int edynhip_set_material_extras(edynhip_ctx *c, uint32_t first, uint32_t n, cons
         if (h[i].x < 0 || h[i].y < 0 || !(h[i].z > 0) || !(h[i].w > 0)) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_extras: negative friction or non-positive stiffness / damping");
         any = any || h[i].x > 0 || h[i].y > 0 || h[i].z < kLarge || h[i].w < kLarge;
     }
-    if (any && !c->m[0].xmat) {   // first such material: the per-point storage and the extras rows come into existence
-        for (int k = 0; k < 2; ++k) {
-            EH_TRY(dalloc(c, c->m[k].xmat, (size_t)c->m[k].cap * kMaxPts)); EH_TRY(dalloc(c, c->m[k].ximp, (size_t)c->m[k].cap * kMaxPts));
-        }
-        EH_TRY(dalloc(c, c->rows.rwx, (size_t)c->m[0].cap * kMaxPts * kXPoint));
-        // points that already exist keep plain contact_constraint behaviour: default material, no impulses
-        std::vector<float4> def((size_t)c->m[0].cap * kMaxPts, make_float4(0, 0, kLarge, kLarge));
-        for (int k = 0; k < 2; ++k) EH_HIP(c, hipMemcpyAsync(c->m[k].xmat, def.data(), def.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-        EH_HIP(c, hipStreamSynchronize(c->stream));
-    }
-    if (any) c->extras = true;
+    if (any) EH_TRY(ensure_extras_storage(c));
     EH_HIP(c, hipMemcpyAsync(c->b.mat2 + first, h.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
     return EDYNHIP_OK;
+}
+// ---- material ids and the mix table (material_mixing.hpp:36-82, util/insert_material_mixing.cpp)
+static int rebuild_mix_table(edynhip_ctx *c) {
+    const uint32_t nb = c->b.n;
+    c->host_mat_id.resize(nb, 0xFFFFu);
+    std::map<uint32_t, uint32_t> compact;   // material id -> compact index, ids in use only
+    for (uint32_t i = 0; i < nb; ++i) if (c->host_mat_id[i] != 0xFFFFu) compact.emplace(c->host_mat_id[i], 0u);
+    uint32_t K = 0;
+    for (auto &kv : compact) kv.second = K++;
+    if (c->host_mix.empty() || K == 0) { c->b.mix_K = 0; return EDYNHIP_OK; }
+    std::vector<uint32_t> cid(nb, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < nb; ++i) if (c->host_mat_id[i] != 0xFFFFu) cid[i] = compact[c->host_mat_id[i]];
+    std::vector<float> vals;
+    std::map<const void *, int32_t> entry_index;
+    bool extras = false;
+    for (auto &kv : c->host_mix) {
+        entry_index[&kv.second] = (int32_t)(vals.size() / 6);
+        vals.insert(vals.end(), kv.second.begin(), kv.second.end());
+        if (kv.second[0] > 0) c->has_restitution = true;
+        extras = extras || kv.second[2] > 0 || kv.second[3] > 0 || kv.second[4] < kLarge || kv.second[5] < kLarge;
+    }
+    std::vector<int32_t> lut((size_t)K * K, -1);
+    for (auto &a : compact)
+        for (auto &b : compact) {   // the reference's own lookup, ordered pair (id of body[0], id of body[1])
+            auto it = c->host_mix.find(edynhip_ctx::MixIdPair{a.first, b.first});
+            if (it != c->host_mix.end()) lut[(size_t)a.second * K + b.second] = entry_index[&it->second];
+        }
+    if (extras) EH_TRY(ensure_extras_storage(c));
+    if (!c->d_mat_cid) EH_TRY(dalloc(c, c->d_mat_cid, c->b.cap));
+    if (c->mix_lut_cap < lut.size()) { c->d_mix_lut = nullptr; EH_TRY(dalloc(c, c->d_mix_lut, lut.size())); c->mix_lut_cap = (uint32_t)lut.size(); }
+    if (c->mix_vals_cap < vals.size()) { c->d_mix_vals = nullptr; EH_TRY(dalloc(c, c->d_mix_vals, vals.size())); c->mix_vals_cap = (uint32_t)vals.size(); }
+    EH_HIP(c, hipMemcpyAsync(c->d_mat_cid, cid.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipMemcpyAsync(c->d_mix_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipMemcpyAsync(c->d_mix_vals, vals.data(), vals.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    c->b.mat_cid = c->d_mat_cid; c->b.mix_lut = c->d_mix_lut; c->b.mix_vals = c->d_mix_vals; c->b.mix_K = K;
+    return EDYNHIP_OK;
+}
+int edynhip_set_material_ids(edynhip_ctx *c, uint32_t first, uint32_t n, const uint32_t *ids) {
+    if (!c || (n && !ids)) return EDYNHIP_ERR_INVALID;
+    if ((uint64_t)first + n > c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_ids: body range out of bounds");
+    for (uint32_t i = 0; i < n; ++i) if (ids[i] > 0xFFFFu) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_material_ids: material::id_type is 16 bits (0xFFFF = unassigned)");
+    EH_HIP(c, hipSetDevice(c->device));
+    c->host_mat_id.resize(c->b.n, 0xFFFFu);
+    for (uint32_t i = 0; i < n; ++i) c->host_mat_id[first + i] = ids[i];
+    return rebuild_mix_table(c);
+}
+int edynhip_insert_material_mixing(edynhip_ctx *c, uint32_t id0, uint32_t id1, const float *material6) {
+    if (!c || !material6) return EDYNHIP_ERR_INVALID;
+    if (id0 >= 0xFFFFu || id1 >= 0xFFFFu) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_insert_material_mixing: unassigned material id");
+    EH_HIP(c, hipSetDevice(c->device));
+    c->host_mix[edynhip_ctx::MixIdPair{id0, id1}] = {material6[0], material6[1], material6[2], material6[3], material6[4], material6[5]};
+    return rebuild_mix_table(c);
 }
 int edynhip_get_point_extras(edynhip_ctx *c, float *out7, uint32_t capacity, uint32_t *n) {
     if (!c || !n) return EDYNHIP_ERR_INVALID;

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <string>
+#include <array>
+#include <map>
 #include <vector>
 #include "../../include/edynhip.h"
 
@@ -46,6 +48,11 @@ struct Bodies {
     float4 *grav = nullptr;     // per-body gravity
     float2 *mat = nullptr;      // friction, restitution
     float4 *mat2 = nullptr;     // contact_extras materials: spin_friction, roll_friction, stiffness, damping (comp/material.hpp:15-22)
+    // material mix table (material_mixing.hpp:36-82), off while mix_K == 0: per body the compact index of its material id (~0u = none),
+    // mix_lut[cA * mix_K + cB] = entry for the ORDERED pair (body[0]'s id, body[1]'s id) or -1 - built on the host with the
+    // reference's own container semantics (a lookup with the ids the other way round does not always find its entry) -,
+    // mix_vals[6 e ..] = restitution, friction, spin_friction, roll_friction, stiffness, damping.
+    const uint32_t *mat_cid = nullptr; const int32_t *mix_lut = nullptr; const float *mix_vals = nullptr; uint32_t mix_K = 0;
     uint32_t *flags = nullptr;  // kind | shape << 4
     uint64_t *group = nullptr, *mask = nullptr;
     uint32_t *island = nullptr; // connected-component label (min body index)
@@ -75,6 +82,14 @@ struct Manifolds {
 // rwx[(k * kXPoint + slot) * cap + p]: rows roll0, roll1, spin as (axis, eff) (I_A^-1 axis, rhs) (I_B^-1 (-axis), impulse) in
 // slots 3r..3r+2, and slot 9 = (roll mu, spin mu, -, -); mu = 0: the row does not exist.
 constexpr int kXRowF = 3, kXRows = 3, kXPoint = kXRows * kXRowF + 1;
+
+__device__ __forceinline__ const float *mix_lookup(const Bodies &b, uint32_t body0, uint32_t body1) {
+    if (b.mix_K == 0) return nullptr;
+    const uint32_t c0 = b.mat_cid[body0], c1 = b.mat_cid[body1];
+    if (c0 == 0xFFFFFFFFu || c1 == 0xFFFFFFFFu) return nullptr;
+    const int32_t e = b.mix_lut[(size_t)c0 * b.mix_K + c1];
+    return e < 0 ? nullptr : b.mix_vals + 6 * (size_t)e;
+}
 
 // Contact events (EDYNHIP_FLAG_CONTACT_EVENTS; edynhip.h edynhip_contact_event has the same layout).
 struct ContactEvent { uint32_t type, step, bodyA, bodyB; uint64_t pid; };
@@ -285,6 +300,19 @@ struct edynhip_ctx {
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     bool has_generic = false;      // some joint is a generic_constraint (k_prep_generic runs)
+    // material mix table, host side: the reference's container (std::map under unordered_pair's comparator) so that lookups behave
+    // exactly like its own; ids by body; device buffers are rebuilt on every change (rebuild_mix_table, capi.hip)
+    struct MixIdPair { uint32_t first, second; };
+    struct MixIdPairLess {
+        bool operator()(const MixIdPair &a, const MixIdPair &b) const {   // core/unordered_pair.hpp:32-40
+            if (a.first == b.second && a.second == b.first) return false;
+            if (a.first == b.first) return a.second < b.second;
+            return a.first < b.first;
+        }
+    };
+    std::map<MixIdPair, std::array<float, 6>, MixIdPairLess> host_mix;
+    std::vector<uint32_t> host_mat_id;   // per body, 0xFFFF = material::UnassignedID
+    uint32_t *d_mat_cid = nullptr; int32_t *d_mix_lut = nullptr; float *d_mix_vals = nullptr; uint32_t mix_lut_cap = 0, mix_vals_cap = 0;
     bool extras = false;           // some body carries a contact_extras material: extras storage exists, per-colour schedule
     uint32_t step_index = 0;       // completed steps
     // contact events: device list of the current edynhip_step call, per-manifold "still there" marks of the previous array

@@ -246,8 +246,9 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         }
         int n_out = 0;
         if (create) {
-            const float friction = sqrtf(A.friction * B.friction);             // material_mixing.hpp:16-18
-            const float restitution = fminf(A.restitution, B.restitution);     // :12-14
+            float friction = sqrtf(A.friction * B.friction);             // material_mixing.hpp:16-18
+            float restitution = fminf(A.restitution, B.restitution);     // :12-14
+            if (const float *e = mix_lookup(b, ia, ib)) { restitution = e[0]; friction = e[1]; }   // assign_material_properties, collision_util.cpp:293-299
 #pragma unroll
             for (int i = kMaxPts - 1; i >= 0; --i) {
                 if ((create >> i) & 1u) {
@@ -295,7 +296,8 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
             const float4 ma = b.mat2[ia], mb = b.mat2[ib];
             float stiff = kLarge, damp = kLarge;
             if (ma.z < kLarge || mb.z < kLarge) { stiff = 1.0f / (1.0f / ma.z + 1.0f / mb.z); damp = 1.0f / (1.0f / ma.w + 1.0f / mb.w); }
-            const float4 fresh = make_float4(fmaxf(ma.y, mb.y), fmaxf(ma.x, mb.x), stiff, damp);
+            float4 fresh = make_float4(fmaxf(ma.y, mb.y), fmaxf(ma.x, mb.x), stiff, damp);
+            if (const float *e = mix_lookup(b, ia, ib)) fresh = make_float4(e[3], e[2], e[4], e[5]);
             int slot = 0;
 #pragma unroll
             for (int i = kMaxPts - 1; i >= 0; --i) if ((create >> i) & 1u) { const size_t d = (size_t)slot * mf.cap + m; mf.xmat[d] = fresh; mf.ximp[d] = make_float4(0, 0, 0, 0); ++slot; }

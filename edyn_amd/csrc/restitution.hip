@@ -59,6 +59,7 @@ DI float manifold_min_relvel(const Manifolds &mf, const Bodies &b, uint32_t m) {
     return mn;
 }
 DI bool tagged(const Bodies &b, uint32_t a, uint32_t bb) {   // contact_manifold_with_restitution (constraint_util.cpp:83-101)
+    if (const float *e = mix_lookup(b, a, bb)) return e[0] > kEps;
     return fminf(b.mat[a].y, b.mat[bb].y) > kEps;
 }
 DI bool manifold_asleep_r(const Bodies &b, uint32_t a, uint32_t bb) { return edge_asleep(b.flags[a], b.flags[bb]); }

@@ -370,6 +370,18 @@ class World:
         n = max(len(a) for a in arrs if a is not None)
         self._check(self._L.edynhip_set_material_extras(self._h, int(first), n, *[None if a is None else _ptr(a) for a in arrs]))
 
+    def set_material_ids(self, first, ids):
+        """material::id of bodies [first, first + len(ids)) (0xFFFF = unassigned): keys into the material mix table."""
+        self._flush_defs()
+        a = np.ascontiguousarray(ids, np.uint32)
+        self._check(self._L.edynhip_set_material_ids(self._h, int(first), len(a), _ptr(a)))
+
+    def insert_material_mixing(self, id0, id1, restitution=0.0, friction=0.5, spin=0.0, roll=0.0, stiffness=1e18, damping=1e18):
+        """edyn::insert_material_mixing: the material of contact points between bodies with these material ids."""
+        self._flush_defs()
+        m = np.array([restitution, friction, spin, roll, stiffness, damping], np.float32)
+        self._check(self._L.edynhip_insert_material_mixing(self._h, int(id0), int(id1), _ptr(m)))
+
     def get_point_extras(self):
         """[num_manifolds, 4, 7]: rolling impulse 0/1, spin impulse, roll mu, spin mu, stiffness, damping (get_manifolds order)."""
         m = C.c_uint32(0)

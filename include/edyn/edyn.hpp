@@ -59,8 +59,13 @@ struct mass_inv { scalar s; };
 struct inertia : matrix3x3 {};
 struct gravity : vector3 {};
 inline constexpr scalar large_scalar = scalar(1e18);   // math/constants.hpp:17
-struct material {   // comp/material.hpp:15-22; the last four select contact_extras_constraint (rolling / spinning friction, soft contacts)
+struct material_base {   // comp/material.hpp:15-22; the last four select contact_extras_constraint (rolling / spinning friction, soft contacts)
     scalar restitution{0}, friction{scalar(0.5)}, spin_friction{0}, roll_friction{0}, stiffness{large_scalar}, damping{large_scalar};
+};
+struct material : material_base {   // :27-31: optional identifier for the material mix table
+    using id_type = uint16_t;
+    static constexpr id_type UnassignedID = 0xFFFF;
+    id_type id{UnassignedID};
 };
 struct AABB { vector3 min, max; };
 struct dynamic_tag {};
@@ -202,6 +207,8 @@ struct gpu_stepper {
     std::unordered_map<uint64_t, entt::entity> point_entities;      // device point id -> contact_point entity
     void (*pre_step)(entt::registry &){nullptr};    // settings.pre_step_callback / post_step_callback (context/step_callback.hpp)
     void (*post_step)(entt::registry &){nullptr};
+    struct mixing { uint32_t id0, id1; float v[6]; };
+    std::vector<mixing> mixings;   // insert_material_mixing calls, replayed into a (re)created context
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
@@ -285,7 +292,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
     std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
     std::vector<float> xspin(n, 0.f), xroll(n, 0.f), xstiff(n, float(large_scalar)), xdamp(n, float(large_scalar));
-    bool any_extras = false;
+    std::vector<uint32_t> mat_ids(n, 0xFFFFu);
+    bool any_extras = false, any_ids = false;
     std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
     std::vector<uint32_t> dead;
     for (uint32_t i = 0; i < n; ++i) {
@@ -314,6 +322,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             fr[i] = mt->friction; re[i] = mt->restitution;
             xspin[i] = mt->spin_friction; xroll[i] = mt->roll_friction; xstiff[i] = mt->stiffness; xdamp[i] = mt->damping;
             any_extras = any_extras || mt->spin_friction > 0 || mt->roll_friction > 0 || mt->stiffness < large_scalar || mt->damping < large_scalar;
+            mat_ids[i] = mt->id; any_ids = any_ids || mt->id != material::UnassignedID;
         }
         if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
         if (registry.all_of<sleeping_disabled_tag>(e)) nosleep[i] = 1;
@@ -324,6 +333,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
     if (any_extras) check(s, edynhip_set_material_extras(s.ctx, first, n, xspin.data(), xroll.data(), xstiff.data(), xdamp.data()));
+    if (first == 0) for (auto &m : s.mixings) check(s, edynhip_insert_material_mixing(s.ctx, m.id0, m.id1, m.v));   // a (re)created context
+    if (any_ids) check(s, edynhip_set_material_ids(s.ctx, first, n, mat_ids.data()));
     if (!dead.empty()) check(s, edynhip_remove_bodies(s.ctx, (uint32_t)dead.size(), dead.data()));
     s.uploaded_bodies = total;
     if (regrown && !carried.empty()) check(s, edynhip_set_manifolds(s.ctx, carried.data(), (uint32_t)carried.size()));
@@ -804,6 +815,15 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
     registry.remove<detail::body_index>(entity);   // the stepper drops the body from the device world at the next update
+}
+
+/// edyn::insert_material_mixing (util/insert_material_mixing.hpp:17): the material of contacts between bodies whose materials carry
+/// these ids. As in the reference the lookup is sensitive to the order in which the two bodies meet (edynhip.h).
+inline void insert_material_mixing(entt::registry &registry, material::id_type id0, material::id_type id1, const material_base &m) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    detail::gpu_stepper::mixing e{id0, id1, {m.restitution, m.friction, m.spin_friction, m.roll_friction, m.stiffness, m.damping}};
+    s.mixings.push_back(e);
+    if (s.ctx) detail::check(s, edynhip_insert_material_mixing(s.ctx, id0, id1, e.v));
 }
 
 /// Refreshes pivots / normal / distance / impulses of every contact_point entity from the device (one read-back).

@@ -274,6 +274,15 @@ int edynhip_set_material_extras(edynhip_ctx *ctx, uint32_t first, uint32_t n, co
                                 const float *stiffness, const float *damping);
 int edynhip_get_point_extras(edynhip_ctx *ctx, float *out7, uint32_t capacity_manifolds, uint32_t *n);
 
+/* Material ids and the material mix table (material::id, comp/material.hpp:27-31; material_mix_table, dynamics/material_mixing.hpp:36-82;
+ * edyn::insert_material_mixing, util/insert_material_mixing.hpp:17): an entry for a pair of ids replaces every mixing rule for
+ * contact points created from then on - material6 = restitution, friction, spin_friction, roll_friction, stiffness, damping.
+ * ids: 16 bits, 0xFFFF = unassigned. Faithful to the reference down to its lookup: the table is keyed by the ids of
+ * (manifold body[0], body[1]) in a std::map under unordered_pair's comparator, so an entry inserted as (a, b) is not always found
+ * for a pair that meets as (b, a) - insert both orders if in doubt (core/unordered_pair.hpp:32-40). */
+int edynhip_set_material_ids(edynhip_ctx *ctx, uint32_t first, uint32_t n, const uint32_t *ids);
+int edynhip_insert_material_mixing(edynhip_ctx *ctx, uint32_t id0, uint32_t id1, const float *material6);
+
 /* Contact events (EDYNHIP_FLAG_CONTACT_EVENTS): what an application observes in the reference through
  * registry.on_construct / on_destroy<contact_manifold> (make_contact_manifold, constraint_util.cpp:60-102;
  * broadphase::destroy_separated_manifolds, broadphase.cpp:99-134) and <contact_point> (create_contact_point,

@@ -1099,3 +1099,28 @@ def test_generic_constraint_bit_exact():
             assert_state_equal(g, o)
             assert np.array_equal(g.get_joint_impulses24().view(np.uint32), o.get_joint_impulses24().view(np.uint32)), s
     assert (np.abs(g.get_joint_impulses24()).max(axis=0) > 0).sum() >= 15
+
+
+def test_material_mix_table_bit_exact():
+    """Material ids + mix table on the device (per-body compact ids, a host-built lookup table that reproduces the reference's
+    order-sensitive std::map lookups, overrides in k_np_merge and in the restitution tag) against the oracle; pinned to the real
+    engine in tests/test_reference_engine.py::test_material_mix_table_matches_the_real_engine."""
+    from test_reference_engine import _mix_table_setup
+    sc = scenes.box_pile(3, 3, 3, mixed=True)
+    n = len(sc["kind"])
+    sc["linvel"][1:] = (np.random.default_rng(4).normal(size=(n - 1, 3)) * (1.0, 0.5, 1.0)).astype(np.float32)
+    g, o = gpu_world(sc), oracle_world(sc)
+    _mix_table_setup(o, n)
+
+    class _G:   # the same calls against the device world
+        def set_material_id(self, i, mid): g.set_material_ids(i, [mid])
+        def insert_material_mixing(self, *a, **k): g.insert_material_mixing(*a, **k)
+    _mix_table_setup(_G(), n)
+    for s in range(1, 201):
+        g.step_simulation(1); o.step(1)
+        if s % 20 == 0 or s < 3:
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            assert np.array_equal(g.get_point_extras().view(np.uint32), o.get_point_extras().view(np.uint32)), s
+    fr = g.get_manifolds()["pt"]["friction"]
+    assert {90, 30, 50} <= set(int(round(float(x) * 100)) for x in fr[fr > 0])
