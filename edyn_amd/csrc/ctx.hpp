@@ -16,6 +16,10 @@ namespace eh {
 constexpr uint32_t kNoColour = 0xFFu;
 constexpr uint32_t kMaxColours = 64;
 constexpr uint32_t kMaxContactColours = 63;   // contact colours 0..62: (colour, point count) then fits an 8-bit sort key, 0xFF = inactive
+// Colours 0..61 are conflict-free sets, solved in parallel. Colour 62 is the SERIAL bucket: a manifold that finds all of 0..61
+// taken at one of its bodies (a body with more than 62 coloured contacts - a plate carrying a crowd) goes there, and the bucket is
+// solved by one lane, one manifold after the other, after the parallel colours of every sweep. No contact count is an error.
+constexpr uint32_t kSerialColour = 62;
 constexpr int kMaxPts = 4;
 
 // body flags

@@ -278,8 +278,8 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
             const uint64_t pr = edge_prio(m);
             if ((da && ld(&best[a]) != pr) || (db && ld(&best[b]) != pr)) continue;
             const uint64_t busy = (da ? ld(&used[a]) : 0ull) | (db ? ld(&used[b]) : 0ull);
-            uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
-            if (c >= kMaxContactColours) { cnt->colour_overflow = 1; c = kMaxContactColours - 1; }
+            const uint64_t avail = ~busy & ((1ull << kSerialColour) - 1ull);
+            const uint32_t c = avail ? (uint32_t)__ffsll((long long)avail) - 1 : kSerialColour;   // nothing free: the serial bucket
             info[m] = (in & 0xFF) | (c << 8);
             if (da) atomicOr((unsigned long long *)&used[a], 1ull << c);
             if (db) atomicOr((unsigned long long *)&used[b], 1ull << c);
@@ -325,8 +325,8 @@ __global__ void k_col_assign(uint32_t M, uint32_t *info, const uint32_t *__restr
             uint64_t pr = edge_prio(m);
             if (!edge_asleep(flags[a], flags[b]) && !(da && best_cur[a] != pr) && !(db && best_cur[b] != pr)) {
                 uint64_t busy = (da ? used[a] : 0ull) | (db ? used[b] : 0ull);
-                uint32_t c = busy == ~0ull ? kMaxColours : (uint32_t)__ffsll((long long)~busy) - 1;
-                if (c >= kMaxContactColours) { cnt->colour_overflow = 1; c = kMaxContactColours - 1; }
+                const uint64_t avail = ~busy & ((1ull << kSerialColour) - 1ull);
+                const uint32_t c = avail ? (uint32_t)__ffsll((long long)avail) - 1 : kSerialColour;   // nothing free: the serial bucket
                 info[m] = (in & 0xFF) | (c << 8);
                 if (da) used[a] |= 1ull << c;
                 if (db) used[b] |= 1ull << c;
@@ -1834,6 +1834,24 @@ k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl
         __syncthreads();
     }
 }
+// The serial bucket (ctx.hpp kSerialColour): its manifolds may share bodies, so one lane (velocity) / one lane pair (position)
+// takes them one after the other, in sorted order; the fence makes each manifold's stores visible to the next one's loads.
+template <bool WARM>
+__global__ void __launch_bounds__(64)
+k_contact_solve_serial(uint32_t start, uint32_t end, Split sp, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, float4 *rwx) {
+    if (threadIdx.x != 0) return;
+    for (uint32_t p = start; p < end; ++p) {
+        contact_solve_lane<WARM, false>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, nullptr, rwx);
+        __threadfence();
+    }
+}
+__global__ void __launch_bounds__(64)
+k_pos_contacts_serial(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *isl_done) {
+    for (uint32_t p = start; p < end; ++p) {
+        pos_contacts_lane(p, p + 1, threadIdx.x, rows, mf, b, isl_err, isl_done);
+        __threadfence();
+    }
+}
 __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
     const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
     // point, distance and cone constraints have no solve_position (island_solver.cpp:252-260)
@@ -2261,7 +2279,7 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
         EH_TRY(sort_and_fetch());
     }
-    if (c->cnt_host->colour_overflow) return set_error(c, EDYNHIP_ERR_COLOURS, "colouring: a body needs more than 63 contact colours");
+    // (no contact count is an error any more: what does not fit the 62 parallel colours goes to the serial bucket, ctx.hpp)
     c->stats.colour_rounds = total_rounds;
     uint32_t nc = 0, na = 0;
     for (uint32_t k = 0; k < kMaxColours; ++k) {
@@ -2304,7 +2322,10 @@ int solve(edynhip_ctx *c) {
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
     if (j.n && c->has_generic) hipLaunchKernelGGL(k_prep_generic, dim3(blocks(j.n, 64)), dim3(64), 0, s, j, c->b, dt);
     // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
-    const bool push = j.n == 0 && na > 0 && !c->extras;
+    // a non-empty serial bucket (a body with more than 62 coloured contacts) also needs the per-colour schedule
+    const bool serial = nc == kSerialColour + 1 && c->colour_end[kSerialColour] > c->colour_start[kSerialColour];
+    const uint32_t nc_par = serial ? kSerialColour : nc;   // colours solved in parallel
+    const bool push = j.n == 0 && na > 0 && !c->extras && !serial;
     if (na) {
         if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
         else hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
@@ -2325,16 +2346,16 @@ int solve(edynhip_ctx *c) {
     };
     // maximal suffix of colours that each fit one workgroup -> one launch for all of them
     TailRanges tail{};
-    uint32_t first_tail = nc;
+    uint32_t first_tail = nc_par;
     while (first_tail > 0 && c->colour_end[first_tail - 1] - c->colour_start[first_tail - 1] <= kTailMax) --first_tail;
-    if (nc - first_tail >= 2) {
-        for (uint32_t k = first_tail; k < nc; ++k)
+    if (nc_par - first_tail >= 2) {
+        for (uint32_t k = first_tail; k < nc_par; ++k)
             if (c->colour_end[k] > c->colour_start[k]) {
                 tail.start[tail.n] = c->colour_start[k]; tail.end[tail.n] = c->colour_end[k];
                 tail.split[tail.n] = Split{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
                 ++tail.n;
             }
-    } else first_tail = nc;
+    } else first_tail = nc_par;
     auto contacts_pass = [&](bool warm) {
         for (uint32_t k = 0; k < first_tail; ++k) {
             uint32_t a = c->colour_start[k], e = c->colour_end[k];
@@ -2361,6 +2382,14 @@ int solve(edynhip_ctx *c) {
                 if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
                 else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
             }
+            ++launches;
+        }
+        if (serial) {
+            const Rows &r = c->rows;
+            const uint32_t a = c->colour_start[kSerialColour], e = c->colour_end[kSerialColour];
+            const Split sp{c->colour_split[kSerialColour][0], c->colour_split[kSerialColour][1], c->colour_split[kSerialColour][2]};
+            if (warm) hipLaunchKernelGGL(k_contact_solve_serial<true>, dim3(1), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, c->extras ? r.rwx : nullptr);
+            else hipLaunchKernelGGL(k_contact_solve_serial<false>, dim3(1), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, c->extras ? r.rwx : nullptr);
             ++launches;
         }
     };
@@ -2462,6 +2491,7 @@ int solve(edynhip_ctx *c) {
                 if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(2 * (e - a), 128)), dim3(128), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
             }
             if (tail.n) hipLaunchKernelGGL(k_pos_contacts_tail, dim3(1), dim3(256), 0, s, tail, c->rows, mf, c->b, c->isl_err, c->isl_done);
+            if (serial) hipLaunchKernelGGL(k_pos_contacts_serial, dim3(1), dim3(64), 0, s, c->colour_start[kSerialColour], c->colour_end[kSerialColour], c->rows, mf, c->b, c->isl_err, c->isl_done);
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
     };

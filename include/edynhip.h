@@ -40,7 +40,7 @@ typedef enum {
     EDYNHIP_ERR_NO_DEVICE = -2,     /* no usable HIP device */
     EDYNHIP_ERR_HIP = -3,           /* a HIP runtime call failed (see edynhip_last_error) */
     EDYNHIP_ERR_CAPACITY = -4,      /* pair / manifold capacity exceeded */
-    EDYNHIP_ERR_COLOURS = -5,       /* a body has more simultaneous contact partners than colours (64) */
+    EDYNHIP_ERR_COLOURS = -5,       /* a body has more joints than joint colours (64); contacts have no such limit */
     EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope (e.g. a joint type other than point / hinge) */
     EDYNHIP_ERR_INTERNAL = -7       /* a device-side invariant failed (e.g. the dataflow solve timed out waiting for a hand-off) */
 } edynhip_status;

@@ -42,6 +42,7 @@ constexpr int kJointSlotsO = 24, kJointParamsO = 64;
 enum solver_order : int { ORDER_SEQUENTIAL = 0, ORDER_COLOURED = 1, ORDER_EXTERNAL = 2 };
 constexpr uint32_t kNoColour = 0xFFu;
 constexpr uint32_t kMaxColours = 64;
+constexpr uint32_t kSerialColour = 62;   // contacts: colours 0..61 are conflict-free, 62 is the serial bucket (edyn_amd/csrc/ctx.hpp)
 
 struct Body {
     int kind = KIND_DYNAMIC;
@@ -731,7 +732,7 @@ public:
     // uncoloured edge whose priority is the maximum among the uncoloured edges at all of its procedural endpoints
     // takes the lowest colour free at those endpoints. Decisions in a round depend only on the state before it.
     template <typename EdgeAt>
-    uint32_t colour_edges(uint32_t num_edges, EdgeAt &&edge, std::vector<uint64_t> &used) {
+    uint32_t colour_edges(uint32_t num_edges, EdgeAt &&edge, std::vector<uint64_t> &used, bool serial_bucket) {
         std::vector<uint64_t> best(bodies.size(), 0);
         uint32_t rounds = 0;
         for (;;) {
@@ -756,9 +757,15 @@ public:
                 bool pa = bodies[a].procedural(), pb = bodies[b].procedural();
                 if ((pa && best[a] != pr) || (pb && best[b] != pr)) continue;
                 uint64_t busy = (pa ? used[a] : 0) | (pb ? used[b] : 0);
+                // colours 0..61 are conflict-free sets; what finds none of them free (a body with more than 62 coloured
+                // contacts) goes to colour 62, the bucket the device solves serially - and this loop visits serially anyway
                 uint32_t c = 0;
-                while (c < kMaxColours && (busy >> c & 1)) ++c;
-                if (c >= kMaxColours) { colour_overflow_ = true; c = kMaxColours - 1; }
+                if (serial_bucket) {
+                    while (c < kSerialColour && (busy >> c & 1)) ++c;
+                } else {   // joints: 64 colours, more is an error on the device
+                    while (c < kMaxColours && (busy >> c & 1)) ++c;
+                    if (c >= kMaxColours) { colour_overflow_ = true; c = kMaxColours - 1; }
+                }
                 *col = c;
                 if (pa) used[a] |= 1ull << c;
                 if (pb) used[b] |= 1ull << c;
@@ -788,7 +795,7 @@ public:
         stats.colour_rounds = colour_edges((uint32_t)ms.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
             a = ms[e]->body[0]; b = ms[e]->body[1];
             col = (ms[e]->num_points > 0 && !manifold_asleep(*ms[e])) ? &ms[e]->colour : nullptr;
-        }, used);
+        }, used, true);
         uint32_t nc = 0;
         for (Manifold *m : ms) if (m->colour != kNoColour) nc = std::max(nc, m->colour + 1);
         stats.num_colours = nc;
@@ -801,7 +808,7 @@ public:
         for (uint32_t e = 0; e < joints.size(); ++e) if (joints[e].alive) live.push_back(e);
         colour_edges((uint32_t)live.size(), [&](uint32_t e, uint32_t &a, uint32_t &b, uint32_t *&col) {
             a = joints[live[e]].body[0]; b = joints[live[e]].body[1]; col = &joints[live[e]].colour;
-        }, used);
+        }, used, false);
         uint32_t nc = 0;
         for (auto &j : joints) if (j.alive) nc = std::max(nc, j.colour + 1);
         stats.num_joint_colours = nc;

@@ -477,7 +477,7 @@ def test_static_body_with_the_highest_index():
 def test_owner_with_more_partners_than_the_in_kernel_list():
     """One wide plate, created last, rests on 49 bricks: it owns more pairs than the per-lane list holds (32), so the
     surplus takes the sorted fallback path. Pair sets, manifolds and trajectories must still match the oracle exactly."""
-    s = scenes.box_pile(7, 1, 7)   # (a body with more than 63 simultaneous partners exceeds the colour masks: EDYNHIP_ERR_COLOURS)
+    s = scenes.box_pile(7, 1, 7)
     top = float(s["pos"][:, 1].max()) + 0.5
     xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
     s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(4.1, 0.25, 4.1, 0), mass=20.0)
@@ -1124,3 +1124,28 @@ def test_material_mix_table_bit_exact():
             assert np.array_equal(g.get_point_extras().view(np.uint32), o.get_point_extras().view(np.uint32)), s
     fr = g.get_manifolds()["pt"]["friction"]
     assert {90, 30, 50} <= set(int(round(float(x) * 100)) for x in fr[fr > 0])
+
+
+def test_plate_with_more_contacts_than_parallel_colours_bit_exact():
+    """A dynamic plate resting on 100 bricks has more simultaneous contact manifolds than there are conflict-free colours (62):
+    the surplus goes to the serial bucket (colour 62), which one lane solves manifold by manifold after the parallel colours of
+    every sweep - the reference has no such limit, and neither has the drop-in any more (formerly EDYNHIP_ERR_COLOURS). Pairs,
+    manifolds, colours and trajectories against the oracle, which colours by the same rule."""
+    s = scenes.box_pile(10, 1, 10)
+    top = float(s["pos"][:, 1].max()) + 0.5
+    xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
+    s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(5.6, 0.25, 5.6, 0), mass=50.0)
+    plate = len(s["kind"]) - 1
+    s = _append_body(s, pos=(xc + 1.0, top + 0.52 + 0.8, zc - 0.5), shape_param=(0.5, 0.5, 0.5, 0), mass=1.0)   # and something lands on it
+    g, o = gpu_world(s), oracle_world(s)
+    most, serial = 0, 0
+    for step in range(1, 91):
+        g.step_simulation(1); o.step(1)
+        if step % 10 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+            gm, om = g.get_manifolds(), o.get_manifolds()
+            assert_manifolds_equal(gm, om, what=f"step {step}")
+            on = (gm["body"] == plate).any(axis=1) & (gm["num_points"] > 0)
+            most = max(most, int(on.sum())); serial = max(serial, int((gm["colour"][on] == 62).sum()))
+    assert most >= 100 and serial >= 30, (most, serial)

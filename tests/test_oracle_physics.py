@@ -201,3 +201,35 @@ def test_new_contact_wakes_a_sleeping_island():
     o.step(400)
     assert o.get_asleep()[1] and o.get_asleep()[2]                     # the stack goes back to sleep as one island
     assert abs(o.get_state()[0][2, 1] - 1.5) < 0.02
+
+
+def test_serial_colour_bucket_holds_what_62_colours_cannot():
+    """A dynamic plate on 81 bricks: its contacts beyond the 62 conflict-free colours share the serial bucket (colour 62,
+    solved one after the other after the parallel colours). Colours below 62 stay conflict free, and the plate rests as it
+    does in the reference's sequential order."""
+    s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scenes.box_pile(9, 1, 9).items()}
+    n = len(s["kind"])
+    top = float(s["pos"][:, 1].max()) + 0.5
+    plate = dict(kind=scenes.KIND_DYNAMIC, pos=(float(s["pos"][1:, 0].mean()), top + 0.26, float(s["pos"][1:, 2].mean())),
+                 orn=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0), mass=40.0, shape_type=scenes.SHAPE_BOX,
+                 shape_param=(5.1, 0.25, 5.1, 0), friction=0.5, restitution=0.0,
+                 group=np.uint64(0xFFFFFFFFFFFFFFFF), mask=np.uint64(0xFFFFFFFFFFFFFFFF))
+    for k, v in plate.items():
+        s[k] = np.concatenate([s[k], np.asarray(v, dtype=s[k].dtype).reshape((1,) + s[k].shape[1:])], axis=0)
+    for k in ("inertia", "has_inertia", "gravity"):
+        s.pop(k, None)
+    res = []
+    for order in (ob.ORDER_SEQUENTIAL, ob.ORDER_COLOURED):
+        w = ob.World(order=order, vel_iters=10)
+        w.add_bodies(s)
+        w.step(120)
+        res.append((w.get_state(), w.get_manifolds()))
+    (st0, _), (st1, m) = res
+    live = m["num_points"] > 0
+    on = live & (m["body"] == n).any(axis=1)
+    assert on.sum() == 81 and (m["colour"][on] == 62).sum() >= 81 - 62
+    for c in range(62):                                   # parallel colours: no dynamic body twice
+        bodies = m["body"][live & (m["colour"] == c)].ravel()
+        bodies = bodies[s["kind"][bodies] == ob.KIND_DYNAMIC]
+        assert len(bodies) == len(set(bodies.tolist())), c
+    assert np.isfinite(st1[0]).all() and abs(st1[0][n, 1] - st0[0][n, 1]) < 2e-3 and np.abs(st1[2][n]).max() < 0.02
