@@ -47,6 +47,10 @@ WORKLOADS = {
     # collective - strong scaling of ONE scene (value = scene-steps/s), unlike the single-island pile's replicas
     "islands256k": dict(gen=lambda: scenes.c4_islands(), vel=10, pos=3, desc="262144 boxes in 4096 independent 4x4x4 mini-piles (config C4)",
                         shard=lambda first, count: scenes.c4_islands(first_site=first, num_sites=count), shard_units=4096),
+    # 1024 of the reference's own rag dolls (edyn::make_ragdoll, exported from the real engine: tests/golden/make_ragdoll.py)
+    # collapsing on a plane: 22 529 bodies, 36 864 cone / cvjoint / hinge constraints, capsule contacts
+    "ragdolls1k": dict(gen=lambda: scenes.figures(scenes.load_figure(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ragdoll_capsule.npz")), 32, 32),
+                       vel=10, pos=3, desc="1024 rag dolls (22 bodies, 36 cone/cvjoint/hinge constraints each) falling on a plane"),
     "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
 
@@ -68,7 +72,7 @@ def cpu_reference_leg(workload, sample_steps, warm_steps):
     scene, scale, what = _cpu_scene(workload)
     cores = os.cpu_count() or 1
     r = ob.RefWorld(vel_iters=wl["vel"], pos_iters=wl["pos"], mode=1, workers=0)   # sequential_multithreaded, hardware_concurrency - 1 workers + the caller
-    r.add_bodies(scene)
+    r.add_bodies(scene); scenes.apply_figure_settings(r, scene)
     t0 = time.perf_counter()
     r.step(warm_steps)
     warm_s = time.perf_counter() - t0
@@ -84,7 +88,7 @@ def cpu_baseline(workload, sample_steps, warm_steps, budget_s):
     wl = WORKLOADS[workload]
     scene, scale, what = _cpu_scene(workload)
     o = ob.World(vel_iters=wl["vel"], pos_iters=wl["pos"], order=ob.ORDER_SEQUENTIAL)
-    o.add_bodies(scene)
+    o.add_bodies(scene); scenes.apply_figure_settings(o, scene)
     o.step(warm_steps)
     port = sample_steps / o.time_steps(sample_steps) / scale
     port_note = (f"1-thread restatement (oracle, reference row order): {port:.3f} steps/s over {sample_steps} steps after {warm_steps} "
@@ -181,6 +185,7 @@ def main():
                                exclusive_device=not distributed)   # RCCL kernels share the GPU in multi-rank runs: cooperative launches there
     w = edyn_amd.World(cfg)
     w.set_scene(scene)
+    scenes.apply_figure_settings(w, scene)
     # The stepper, the pack kernel and the RCCL gather all run on ONE explicitly created torch stream (a non-zero
     # handle: edynhip_set_stream(NULL) would mean "a private stream"), entered for the whole run => ordered.
     stream = torch.cuda.Stream(device=device_index)

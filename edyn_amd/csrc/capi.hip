@@ -785,11 +785,13 @@ static int reset_new_angles(edynhip_ctx *c, uint32_t first_caller_index) {
     return rc;
 }
 
+static int flush_joint_redefs(edynhip_ctx *c);
 int edynhip_set_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in) {
     if (!c || (n && !in)) return EDYNHIP_ERR_INVALID;
     if (n > c->j.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, "edynhip_set_joints: n > max_joints");
     EH_HIP(c, hipSetDevice(c->device));
     c->host_joints.clear();
+    c->pending_redefs.clear();
     if (n) EH_TRY(append_host_joints(c, n, in, "edynhip_set_joints"));
     EH_TRY(rebuild_joints(c, false));
     return reset_new_angles(c, 0);
@@ -800,6 +802,7 @@ int edynhip_add_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *in, uin
     const uint32_t first = (uint32_t)c->host_joints.size();
     if (first_index) *first_index = first;
     if (n == 0) return EDYNHIP_OK;
+    EH_TRY(flush_joint_redefs(c));
     EH_TRY(append_host_joints(c, n, in, "edynhip_add_joints"));
     int rc = rebuild_joints(c, true);
     if (rc != EDYNHIP_OK) { c->host_joints.resize(first); (void)rebuild_joints(c, false); return rc; }
@@ -809,6 +812,7 @@ int edynhip_remove_joints(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
     if (!c || (n && !indices)) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
     for (uint32_t k = 0; k < n; ++k) if (indices[k] >= c->host_joints.size()) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_remove_joints: index out of range");
+    EH_TRY(flush_joint_redefs(c));
     // fetch first: the impulses of the survivors come from the device
     EH_TRY(rebuild_joints(c, true));
     std::vector<uint32_t> touched;
@@ -845,6 +849,7 @@ int edynhip_get_joint_slot_impulses(edynhip_ctx *c, float *out) {
     const uint32_t total = (uint32_t)c->host_joints.size();
     if (total == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));
     std::memset(out, 0, (size_t)total * kJointSlots * sizeof(float));
     const uint32_t n = c->j.n;
     if (n == 0) return EDYNHIP_OK;
@@ -857,18 +862,30 @@ int edynhip_get_joint_slot_impulses(edynhip_ctx *c, float *out) {
         for (int r = 0; r < kJointSlots; ++r) out[(size_t)kJointSlots * orig[p] + r] = imp[(size_t)r * c->j.cap + p];
     return EDYNHIP_OK;
 }
+// Redefinitions are applied lazily: the host copy is edited at once, the device arrays are rebuilt (and the angles of the
+// edited joints reset against the current orientations, as hinge_constraint / cvjoint_constraint::reset_angle) by the next entry
+// point that reads or advances them - a figure's thousands of definitions cost one rebuild, not one each.
 static int redefine_joint(edynhip_ctx *c, uint32_t joint, const float *params, int nparams, const float *frameA, const float *frameB) {
-    EH_HIP(c, hipSetDevice(c->device));
-    EH_TRY(rebuild_joints(c, true));
     std::memcpy(c->host_joints[joint].params, params, sizeof(float) * nparams);
     if (frameA) { std::memcpy(c->host_joints[joint].frame, frameA, 9 * sizeof(float)); std::memcpy(c->host_joints[joint].frame + 9, frameB, 9 * sizeof(float)); c->host_joints[joint].has_frames = true; }
+    c->pending_redefs.push_back(joint);
+    return EDYNHIP_OK;
+}
+static int flush_joint_redefs(edynhip_ctx *c) {
+    if (c->pending_redefs.empty()) return EDYNHIP_OK;
+    std::vector<uint32_t> pending;
+    pending.swap(c->pending_redefs);
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(rebuild_joints(c, true));    // applied impulses and angles of the others come from the device
     EH_TRY(rebuild_joints(c, false));
-    // reset_angle for this joint only
+    if (c->j.n == 0) return EDYNHIP_OK;
+    std::vector<uint8_t> edited(c->host_joints.size(), 0);
+    for (uint32_t j : pending) if (j < edited.size()) edited[j] = 1;
     std::vector<uint32_t> orig(c->j.n);
     EH_HIP(c, hipMemcpyAsync(orig.data(), c->j.orig, (size_t)c->j.n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     EH_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<uint8_t> which(c->j.n, 0);
-    for (uint32_t p = 0; p < c->j.n; ++p) if (orig[p] == joint) which[p] = 1;
+    for (uint32_t p = 0; p < c->j.n; ++p) which[p] = edited[orig[p]];
     uint8_t *d = nullptr;
     EH_HIP(c, hipMalloc((void **)&d, c->j.n));
     EH_HIP(c, hipMemcpyAsync(d, which.data(), c->j.n, hipMemcpyHostToDevice, c->stream));
@@ -881,11 +898,13 @@ static int redefine_joint(edynhip_ctx *c, uint32_t joint, const float *params, i
 int edynhip_run_stages(edynhip_ctx *c, uint32_t mask) {
     if (!c) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));
     return run_stages(c, mask);
 }
 
 static int step_stamped(edynhip_ctx *c, uint32_t nsteps, bool timed, double first_time, double step_dt) {
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));
     c->timings = edynhip_timings{};
     c->timer.recorded = 0;
     if (c->events) EH_HIP(c, hipMemsetAsync(c->event_count, 0, sizeof(uint32_t), c->stream));   // the events of THIS call
@@ -953,6 +972,7 @@ int edynhip_remove_bodies(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
     bool joints_changed = false;
     std::vector<uint32_t> partners;
     if (!c->host_joints.empty()) {
+        EH_TRY(flush_joint_redefs(c));
         EH_TRY(rebuild_joints(c, true));
         for (HostJoint &h : c->host_joints)
             if (h.alive && (gone[h.body[0]] || gone[h.body[1]])) { h.alive = false; joints_changed = true; partners.push_back(h.body[0]); partners.push_back(h.body[1]); }
@@ -1004,6 +1024,7 @@ int edynhip_set_state(edynhip_ctx *c, const float *pos, const float *orn, const 
     const uint32_t n = c->b.n;
     if (n == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));   // pending angle resets refer to the orientations before this edit
     float *h = c->state_host, *d = c->state_dev;
     for (uint32_t i = 0; i < n; ++i) {
         float *o = &h[(size_t)i * 13];
@@ -1398,6 +1419,7 @@ int edynhip_get_joint_impulses(edynhip_ctx *c, float *out) {
     const uint32_t total = (uint32_t)c->host_joints.size();
     if (total == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));
     std::memset(out, 0, (size_t)total * 10 * sizeof(float));
     const uint32_t n = c->j.n;
     if (n == 0) return EDYNHIP_OK;

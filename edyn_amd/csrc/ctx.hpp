@@ -266,6 +266,7 @@ struct edynhip_ctx {
     uint32_t num_manifolds = 0;    // in m[cur]
     eh::Joints j;
     std::vector<eh::HostJoint> host_joints;   // by caller index (see HostJoint)
+    std::vector<uint32_t> pending_redefs;     // joints edited since the device arrays were built (capi.hip flush_joint_redefs)
     eh::Rows rows;
     eh::LBVH bvh;
     float4 *np_ra = nullptr, *np_rb = nullptr, *np_rn = nullptr;   // narrowphase staging: the raw collide() result per manifold

@@ -203,6 +203,76 @@ def c5_chains(num_chains=1024, links=16):
     return s
 
 
+def _quat_mul(a, b):
+    ax, ay, az, aw = (a[..., k] for k in range(4)); bx, by, bz, bw = (b[..., k] for k in range(4))
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], axis=-1).astype(np.float32)
+
+
+def _quat_rotate(q, v):
+    u = q[..., :3]; w = q[..., 3:4]
+    t = np.float32(2) * np.cross(u, v)
+    return (v + w * t + np.cross(u, t)).astype(np.float32)
+
+
+def load_figure(path):
+    """An articulated figure template (tests/golden/ragdoll_*.npz: the reference's make_ragdoll, exported from the real engine)."""
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def figures(template, nx, nz, pitch=2.2, hip_height=1.25, tumble=0.5, floor=True, ny=1, pitch_v=2.0):
+    """nx x nz (x ny layers) copies of an articulated figure (load_figure) standing over a floor plane, each turned about the vertical by a
+    seeded angle and given a small seeded spin so that they fall differently. Beside the body arrays and "joints" the scene carries
+    what the constraints and the figure need after upload - apply_figure_settings(world, scene):
+    "hinge_params" [(joint, 10 floats)], "joint_defs" [(joint, frameA, frameB, 16 floats)], "exclusions" [k, 2]."""
+    nb, nj = len(template["kind"]), len(template["joint_type"])
+    count = nx * nz * ny
+    first = 1 if floor else 0
+    s = _empty(first + count * nb)
+    if floor:
+        _add_plane(s)
+    u = splitmix64_uniform(4 * count, stream=7).reshape(count, 4)
+    joints, hinge_params, joint_defs, excl = [], [], [], []
+    shapeless = template["shape_type"] == SHAPE_NONE
+    for c in range(count):
+        base = first + c * nb
+        sl = slice(base, base + nb)
+        yaw = _yaw_quat(np.full(nb, (u[c, 0] * 2 - 1) * np.float32(math.pi), np.float32))
+        origin = np.array([(c % nx) * pitch, hip_height + (c // (nx * nz)) * pitch_v, ((c // nx) % nz) * pitch], np.float32)
+        s["pos"][sl] = _quat_rotate(yaw, template["pos"]) + origin
+        s["orn"][sl] = _quat_mul(yaw, template["orn"])
+        s["angvel"][sl] = ((u[c, 1:4] * 2 - 1) * np.float32(tumble)).astype(np.float32)
+        for k in ("kind", "mass", "shape_type", "shape_param", "friction", "restitution", "group", "mask"):
+            s[k][sl] = template[k]
+        s["inertia"][sl][shapeless] = template["inertia"][shapeless]
+        s["has_inertia"][sl] = shapeless
+        for j in range(nj):
+            jt = int(template["joint_type"][j])
+            a, b = (int(x) + base for x in template["joint_body"][j])
+            joints.append((jt, a, b, tuple(template["pivotA"][j]), tuple(template["pivotB"][j]), tuple(template["axisA"][j]), tuple(template["axisB"][j])))
+            if jt == JOINT_HINGE:
+                hinge_params.append((len(joints) - 1, template["params10"][j]))
+            elif jt in (JOINT_CONE, JOINT_CVJOINT):
+                joint_defs.append((len(joints) - 1, template["frameA"][j].reshape(3, 3), template["frameB"][j].reshape(3, 3), template["params16"][j]))
+        excl.append(template["exclusions"].astype(np.uint32) + np.uint32(base))
+    s["joints"] = joints
+    s["hinge_params"] = hinge_params
+    s["joint_defs"] = joint_defs
+    s["exclusions"] = np.concatenate(excl) if excl else np.zeros((0, 2), np.uint32)
+    return s
+
+
+def apply_figure_settings(world, scene):
+    """What a figure scene needs after its bodies and joints are uploaded (any of the three world classes)."""
+    for j, p in scene.get("hinge_params", []):
+        world.set_joint_params(j, p)
+    for j, fa, fb, p in scene.get("joint_defs", []):
+        world.set_joint_definition(j, fa, fb, p)
+    for a, b in scene.get("exclusions", []):
+        world.exclude_collision(int(a), int(b))
+
+
 def scene_from_defs(defs, joints):
     """Pack a list of edyn_amd.rigidbody_def (+ joint tuples) into the array layout."""
     n = len(defs)
@@ -240,7 +310,7 @@ def subset(scene, idx):
     """Bodies `idx` (array of body ids, ascending) as a new scene; joints are dropped."""
     out = {}
     for k, v in scene.items():
-        if k == "joints":
+        if k in ("joints", "hinge_params", "joint_defs", "exclusions"):
             out[k] = []
         else:
             out[k] = np.ascontiguousarray(v[idx])

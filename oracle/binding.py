@@ -600,6 +600,53 @@ class RefWorld:
         f = self.L.refw_set_joint_definition; f.argtypes = [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_float)] * 3; f.restype = None
         f(self.h, joint, _fp(_f32(np.asarray(frameA).ravel(), 9)), _fp(_f32(np.asarray(frameB).ravel(), 9)), _fp(p))
 
+    def make_ragdoll(self, shape="capsule", pos=(0, 0, 0), orn=(0, 0, 0, 1), height=1.7, weight=72.0, friction=0.5, restitution=0.0):
+        """edyn::make_ragdoll (util/ragdoll.cpp:65-914) run by the real engine. Returns (first body, first joint) of the figure."""
+        f = self.L.refw_make_ragdoll; f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)] + [C.c_float] * 4
+        g = self.L.refw_num_joints; g.argtypes = [C.c_void_p]; g.restype = C.c_uint32
+        first_body, first_joint = self.num_bodies, self.n_joints
+        f(self.h, {"box": 0, "capsule": 1}[shape], _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), height, weight, friction, restitution)
+        self.n_joints = g(self.h)
+        return first_body, first_joint
+
+    def export_figure(self, first_body=0, first_joint=0):
+        """Bodies [first_body:] and constraints [first_joint:] as plain arrays (indices relative to first_body): what
+        World.add_bodies / set_joint_params / set_joint_definition / exclude_collision take - see tests/golden/make_ragdoll.py."""
+        L = self.L
+        fb = L.refw_export_body; fb.restype = None
+        fb.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)] + [C.POINTER(C.c_float)] * 5 + [C.POINTER(C.c_int32)] + \
+                      [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        fj = L.refw_export_joint; fj.restype = None
+        fj.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)] + [C.POINTER(C.c_float)] * 8
+        fx = L.refw_export_exclusions; fx.restype = C.c_uint32; fx.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        nb, nj = self.num_bodies - first_body, self.n_joints - first_joint
+        out = dict(kind=np.zeros(nb, np.int32), pos=np.zeros((nb, 3), np.float32), orn=np.zeros((nb, 4), np.float32),
+                   linvel=np.zeros((nb, 3), np.float32), angvel=np.zeros((nb, 3), np.float32), mass=np.zeros(nb, np.float32),
+                   shape_type=np.zeros(nb, np.int32), shape_param=np.zeros((nb, 4), np.float32), inertia=np.zeros((nb, 9), np.float32),
+                   friction=np.zeros(nb, np.float32), restitution=np.zeros(nb, np.float32), has_material=np.zeros(nb, np.int32),
+                   group=np.zeros(nb, np.uint64), mask=np.zeros(nb, np.uint64))
+        i32 = lambda a, i: a[i:i + 1].ctypes.data_as(C.POINTER(C.c_int32))
+        u64 = lambda a, i: a[i:i + 1].ctypes.data_as(C.POINTER(C.c_uint64))
+        for i in range(nb):
+            fb(self.h, first_body + i, i32(out["kind"], i), _fp(out["pos"][i]), _fp(out["orn"][i]), _fp(out["linvel"][i]), _fp(out["angvel"][i]),
+               _fp(out["mass"][i:i + 1]), i32(out["shape_type"], i), _fp(out["shape_param"][i]), _fp(out["inertia"][i]),
+               _fp(out["friction"][i:i + 1]), _fp(out["restitution"][i:i + 1]), i32(out["has_material"], i), u64(out["group"], i), u64(out["mask"], i))
+        j = dict(joint_type=np.zeros(nj, np.int32), joint_body=np.zeros((nj, 2), np.uint32), pivotA=np.zeros((nj, 3), np.float32),
+                 pivotB=np.zeros((nj, 3), np.float32), axisA=np.zeros((nj, 3), np.float32), axisB=np.zeros((nj, 3), np.float32),
+                 params10=np.zeros((nj, 10), np.float32), frameA=np.zeros((nj, 9), np.float32), frameB=np.zeros((nj, 9), np.float32),
+                 params16=np.zeros((nj, 16), np.float32))
+        for i in range(nj):
+            fj(self.h, first_joint + i, i32(j["joint_type"], i), j["joint_body"][i].ctypes.data_as(C.POINTER(C.c_uint32)), _fp(j["pivotA"][i]),
+               _fp(j["pivotB"][i]), _fp(j["axisA"][i]), _fp(j["axisB"][i]), _fp(j["params10"][i]), _fp(j["frameA"][i]), _fp(j["frameB"][i]), _fp(j["params16"][i]))
+        j["joint_body"] -= np.uint32(first_body)
+        ex = np.zeros((4096, 2), np.uint32)
+        ne = fx(self.h, ex.ctypes.data_as(C.POINTER(C.c_uint32)), len(ex))
+        ex = ex[:ne]
+        ex = ex[(ex >= first_body).all(axis=1)] - np.uint32(first_body)
+        out.update(j); out["exclusions"] = ex
+        return out
+
     def remove_joint(self, joint):
         f = self.L.refw_remove_joint; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None
         f(self.h, joint)

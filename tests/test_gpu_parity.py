@@ -1149,3 +1149,27 @@ def test_plate_with_more_contacts_than_parallel_colours_bit_exact():
             on = (gm["body"] == plate).any(axis=1) & (gm["num_points"] > 0)
             most = max(most, int(on.sum())); serial = max(serial, int((gm["colour"][on] == 62).sum()))
     assert most >= 100 and serial >= 30, (most, serial)
+
+
+@pytest.mark.parametrize("shape", ["capsule", "box"])
+def test_ragdolls_bit_exact(shape):
+    """Twelve of the reference's own rag dolls (edyn::make_ragdoll run by the real engine and exported, tests/golden/make_ragdoll.py:
+    22 bodies - two of them shapeless twist bodies with explicit inertia - on 36 cone / cvjoint / hinge constraints with bump
+    stops, twist limits, friction and damping, 21 collision exclusions each) in three layers collapse onto the floor and into one heap (one island):
+    pairs, manifolds, state, applied impulses and tracked angles against the oracle, itself pinned to the real engine on this
+    scene (tests/test_reference_engine.py::test_ragdolls_match_the_real_engine)."""
+    sc = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, f"ragdoll_{shape}.npz")), 2, 2, pitch=1.0, ny=3, pitch_v=1.9)
+    g, o = gpu_world(sc), oracle_world(sc)
+    scenes.apply_figure_settings(g, sc); scenes.apply_figure_settings(o, sc)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 25 == 0 or s < 4:
+            assert np.isfinite(g.get_state()[0]).all(), s
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
+    ji = g.get_joint_impulses()
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert np.abs(ji[kinds == scenes.JOINT_CONE][:, 1]).max() > 0 and (np.abs(ji[kinds == scenes.JOINT_CVJOINT][:, [3, 4, 6, 7]]).max(axis=0) > 0).all()
+    assert len(g.get_manifolds()) > 200 and g.get_stats()["num_islands"] <= 2

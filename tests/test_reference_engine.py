@@ -19,6 +19,7 @@ Two switches make the bit-for-bit comparison possible, both test-only and both o
 Everything else — broadphase, narrowphase, manifold persistence, row preparation, row arithmetic, integration, position
 solver, sleeping — is therefore identical to the reference's, operation for operation.
 Skipped where oracle/_ref was never built (it needs /root/reference at build time; the built library travels)."""
+import os
 import numpy as np
 import pytest
 
@@ -785,3 +786,35 @@ def test_material_mix_table_matches_the_real_engine():
                 assert np.array_equal(rm["pt"][fld], om["pt"][fld]), (s, fld)
             frictions |= set(int(round(float(x) * 100)) for x in rm["pt"]["friction"][rm["pt"]["friction"] > 0])
     assert {90, 30} <= frictions and 50 in frictions   # table entries and the sqrt rule both occurred
+
+
+# ------------------------------------------------------------------------------------------------ the reference's rag doll
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("shape", ["capsule", "box"])
+def test_ragdoll_template_is_what_the_engine_builds(shape):
+    """tests/golden/ragdoll_*.npz (what the -m gpu tests and the bench build their figures from) against edyn::make_ragdoll
+    (util/ragdoll.cpp:65-914) run by the real engine now: every body and constraint field bit for bit."""
+    r = ob.RefWorld()
+    fig = r.export_figure(*r.make_ragdoll(shape, pos=(0, 0, 0), height=1.7, weight=72.0))
+    tpl = scenes.load_figure(os.path.join(GOLDEN, f"ragdoll_{shape}.npz"))
+    assert sorted(fig) == sorted(tpl)
+    for k in fig:
+        assert fig[k].dtype == tpl[k].dtype and np.array_equal(fig[k].view(np.uint8), tpl[k].view(np.uint8)), k
+    assert len(fig["kind"]) == 22 and len(fig["joint_type"]) == 36 and len(fig["exclusions"]) == 21
+
+
+@pytest.mark.parametrize("shape", ["capsule", "box"])
+def test_ragdolls_match_the_real_engine(shape):
+    """Four of the reference's rag dolls (22 bodies on 36 cone / cvjoint / hinge constraints with bump stops, twist limits,
+    friction and damping; shapeless twist bodies with explicit inertia; 21 collision exclusions) collapse onto the floor:
+    positions, velocities, applied impulses and tracked angles bit-identical with the real engine for 300 steps."""
+    sc = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, f"ragdoll_{shape}.npz")), 2, 2)
+    ref, _ = _joint_lockstep(sc, 300, lambda w: scenes.apply_figure_settings(w, sc))
+    ji = ref.get_joint_impulses()
+    kinds = np.array([j[0] for j in sc["joints"]])
+    assert np.abs(ji[kinds == scenes.JOINT_CONE][:, 1]).max() > 0            # cone bump stops
+    assert (np.abs(ji[kinds == scenes.JOINT_CVJOINT][:, [3, 4, 6, 7]]).max(axis=0) > 0).all()   # twist limit, bump stop, friction rows
+    assert np.abs(ji[kinds == scenes.JOINT_HINGE][:, [6, 8]]).max() > 0      # knee / elbow bump stops and torque
+    assert len(ref.get_manifolds()) > 40 and ref.get_state()[0][1:, 1].max() < 0.6   # everybody is lying on the floor
