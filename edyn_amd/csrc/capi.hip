@@ -33,6 +33,7 @@ __global__ void k_publish_counters(const uint32_t *__restrict__ src, uint32_t *d
 }
 int fetch_counters(edynhip_ctx *c, size_t bytes) {
     const uint32_t value = ++c->cnt_seq_next;
+    c->last_fetch_step = c->step_index;
     hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->cnt, (uint32_t *)c->cnt_host,
                        (uint32_t)(bytes / sizeof(uint32_t)), c->cnt_seq, value);
     EH_HIP(c, hipGetLastError());
@@ -106,6 +107,8 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
+    EH_TRY(dalloc(c, c->isl_cnt, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_off, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_list, nb));
+    EH_TRY(dalloc(c, c->isl_items, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_sorted, (size_t)M + nj));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb)); EH_TRY(dalloc(c, c->pos_err, (size_t)nb * kMaxDfPosIters));
     EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
     EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));
@@ -555,6 +558,7 @@ static int rebuild_broadphase_lists(edynhip_ctx *c) {
 
 static int rebuild_mix_table(edynhip_ctx *c);
 static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip_bodies *in, const char *who) {
+    if (c) ++c->topology_epoch;
     if (!c || !in) return EDYNHIP_ERR_INVALID;
     if ((uint64_t)first + n > c->b.cap) return set_error(c, EDYNHIP_ERR_CAPACITY, (std::string(who) + ": more than max_bodies").c_str());
     if (n && (!in->kind || !in->pos || !in->orn || !in->linvel || !in->angvel || !in->mass || !in->shape_type || !in->shape_param ||
@@ -624,6 +628,7 @@ int edynhip_add_bodies(edynhip_ctx *c, uint32_t n, const edynhip_bodies *in) {
 // fetch = first read the current impulses / angles back from the device (the joints were stepped since the last rebuild).
 static int rebuild_joints(edynhip_ctx *c, bool fetch) {
     Joints &j = c->j;
+    ++c->topology_epoch;
     hipStream_t s = c->stream;
     std::vector<HostJoint> &hj = c->host_joints;
     if (fetch && j.n) {

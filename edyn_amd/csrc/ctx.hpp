@@ -230,6 +230,8 @@ struct Counters {
     uint32_t unc_count;          // edges k_col_prepare found uncoloured (listed in col_unc while they fit)
     uint32_t bp_rebuild;         // this step rebuilds the broadphase candidate lists (set by the previous step's k_finish, cleared by k_bp_compact)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
+    uint32_t isl_num;            // island-fused schedule: islands that have constraints this step (solver.hip k_isl_fill)
+    uint32_t isl_max_items;      //   and the largest of them, in constraints (read by the NEXT step's schedule decision)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
     uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];
@@ -282,6 +284,11 @@ struct edynhip_ctx {
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
     float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
+    uint32_t *isl_cnt = nullptr, *isl_off = nullptr, *isl_list = nullptr, *isl_items = nullptr, *isl_sorted = nullptr;   // island-fused schedule (solver.hip IslLists)
+    uint32_t isl_prep_step = 0xFFFFFFF0u;   // step_index of the last step that bucketed its constraints by island (its isl_max_items reaches cnt_host with the next step's fetch)
+    uint32_t last_fetch_step = 0xFFFFFFF0u; // step_index during which fetch_counters last ran
+    uint32_t topology_epoch = 0;            // bumped when bodies or joints are added / removed / redefined
+    uint32_t isl_cache_epoch = 0xFFFFFFFFu, isl_cache_max = 0;   // largest island of a scene whose steps fetch no counters (no shapes, no contacts)
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)
     uint32_t *isl_done = nullptr;
     void *sort_tmp = nullptr;

@@ -1402,10 +1402,64 @@ __global__ void k_prep_generic(Joints j, Bodies b, float dt) {
     }
     j.rmask[i] = mask;
 }
+// The same joint solve with everything that is constant during a step's sweeps held in registers (the island-fused fast
+// path, k_island_velocity): load once, solve per sweep against the caller's Delta, store the impulses once at the end.
+// A lane of that kernel owns either a joint or a manifold, so the joint's registers are a VIEW of the manifold's row
+// registers RowReg[4][3] (every index is a compile-time constant after unrolling):
+//   slot r -> R[r/3][r%3]: f[0] = (impulse, lo, hi, rhs), f[1].x = eff        R[3][0].f[0..4] = rA, rB, wp, wq, wax
+//   R[3][1].f[0] = wbx, f[1..3] = rows of I_A^-1      R[3][2].f[0..2] = rows of I_B^-1, f[3] = (type, mask) as bits
+// Not for generic constraints (24 slots). Identical arithmetic to joint_solve_lane.
+typedef RowReg JRegs[4][kRowsPerPoint];
+DI void jlane_load(JRegs &R, const Joints &j, const Bodies &b, uint32_t i, uint32_t ia, uint32_t ib) {
+    const uint32_t mask = j.rmask[i];
+    R[3][2].f[3] = make_float4(__int_as_float((int)j.type[i]), __uint_as_float(mask), 0, 0);
+    R[3][0].f[0] = j.rA[i]; R[3][0].f[1] = j.rB[i]; R[3][0].f[2] = j.wp[i]; R[3][0].f[3] = j.wq[i]; R[3][0].f[4] = j.wax[i];
+    R[3][1].f[0] = j.wbx[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { R[3][1].f[1 + r] = B_IW(b, ia, r); R[3][2].f[r] = B_IW(b, ib, r); }
+#pragma unroll
+    for (int r = 0; r < kJointBaseSlots; ++r) {
+        const size_t s = (size_t)r * j.cap + i;
+        const bool on = (mask >> r) & 1u;
+        R[r / 3][r % 3].f[0] = on ? make_float4(j.impulse[s], j.lo[s], j.hi[s], j.rhs[s]) : make_float4(0, 0, 0, 0);
+        R[r / 3][r % 3].f[1].x = on ? j.eff[s] : 0.0f;
+    }
+}
 template <bool WARM>
-__global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) {
-    uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= end) return;
+DI void jlane_solve(JRegs &R, Delta &d) {
+    const int type = __float_as_int(R[3][2].f[3].x);
+    const uint32_t mask = __float_as_uint(R[3][2].f[3].y);
+    const f3 rA = from4(R[3][0].f[0]), rB = from4(R[3][0].f[1]), wp = from4(R[3][0].f[2]), wq = from4(R[3][0].f[3]), wax = from4(R[3][0].f[4]), wbx = from4(R[3][1].f[0]);
+    d.iA = {from4(R[3][1].f[1]), from4(R[3][1].f[2]), from4(R[3][1].f[3])};
+    d.iB = {from4(R[3][2].f[0]), from4(R[3][2].f[1]), from4(R[3][2].f[2])};
+#pragma unroll
+    for (int r = 0; r < kJointBaseSlots; ++r) {
+        if (!((mask >> r) & 1u)) continue;
+        float4 &q = R[r / 3][r % 3].f[0];   // (impulse, lo, hi, rhs)
+        f3 J0, J1, J2, J3;
+        joint_rowJ(type, r, rA, rB, wp, wq, wax, wbx, J0, J1, J2, J3);
+        if (WARM) {
+            apply_impulse(d, J0, J1, J2, J3, q.x);
+        } else {
+            const float imp = q.x;
+            float drel = rel_speed(J0, J1, J2, J3, d.dvA, d.dwA, d.dvB, d.dwB);
+            float dimp = (q.w - drel) * R[r / 3][r % 3].f[1].x;
+            float ni = imp + dimp;
+            if (ni < q.y) { dimp = q.y - imp; ni = q.y; }
+            else if (ni > q.z) { dimp = q.z - imp; ni = q.z; }
+            q.x = ni;
+            apply_impulse(d, J0, J1, J2, J3, dimp);
+        }
+    }
+}
+DI void jlane_store(const JRegs &R, const Joints &j, uint32_t i) {
+    const uint32_t mask = __float_as_uint(R[3][2].f[3].y);
+#pragma unroll
+    for (int r = 0; r < kJointBaseSlots; ++r)
+        if ((mask >> r) & 1u) j.impulse[(size_t)r * j.cap + i] = R[r / 3][r % 3].f[0].x;
+}
+template <bool WARM>
+DI void joint_solve_lane(uint32_t i, const Joints &j, const Bodies &b) {
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;
     Delta d;
@@ -1448,6 +1502,11 @@ __global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) 
         }
     }
     store_delta(b, ia, ib, d);
+}
+template <bool WARM>
+__global__ void k_joint_solve(uint32_t start, uint32_t end, Joints j, Bodies b) {
+    const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < end) joint_solve_lane<WARM>(i, j, b);
 }
 // hinge_constraint::reset_angle (hinge_constraint.cpp:19-24) for the joints whose definition was just (re)written
 __global__ void k_joint_reset_angle(Joints j, Bodies b, const uint8_t *__restrict__ which) {
@@ -1804,19 +1863,21 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     }
     publish_error(active && !sideB, max_err, label, isl_err);
 }
-DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
+// one (manifold, side) lane of the position solve; `pc` must be a valid sorted position even when !in_range
+// all lanes stay in the code below (no early exit): DPP exchanges and wave reductions need every lane executing
+DI void pos_contacts_item(bool in_range, uint32_t pc, bool sideB, const Rows &rows, const Manifolds &mf, const Bodies &b,
                           float *isl_err, const uint32_t *isl_done) {
-    const uint32_t p = start + (t >> 1);
-    const bool sideB = t & 1;
-    const bool in_range = p < end;
-    // all lanes stay in the code below (no early exit): DPP exchanges and wave reductions need every lane executing
-    const uint32_t pc = in_range ? p : start;
     const uint32_t m = rows.order[pc];
     const uint32_t ia = rows.bA[pc], ib = rows.bB[pc], np = in_range ? rows.np[pc] : 0;
     const uint32_t label = rows.label[pc];
     // lanes are grouped by point count inside a colour, so a wave takes one branch (except at a group boundary)
     if (__any(np > 2)) pos_contacts_np<4>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
     else pos_contacts_np<2>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
+}
+DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
+                          float *isl_err, const uint32_t *isl_done) {
+    const uint32_t p = start + (t >> 1);
+    pos_contacts_item(p < end, p < end ? p : start, t & 1, rows, mf, b, isl_err, isl_done);
 }
 __global__ void __launch_bounds__(128)
 k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
@@ -1852,10 +1913,11 @@ k_pos_contacts_serial(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bod
         __threadfence();
     }
 }
-__global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
-    const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+// one joint of the position solve; every lane of the wave calls it (publish_error reduces over the wave), `in_range` says
+// whether `i` is a joint of this pass
+DI void pos_joints_lane(uint32_t i, bool in_range, const Joints &j, const Bodies &b, float *isl_err, const uint32_t *__restrict__ isl_done) {
     // point, distance and cone constraints have no solve_position (island_solver.cpp:252-260)
-    bool active = i < end && (j.type[i] == EDYNHIP_JOINT_HINGE || j.type[i] == EDYNHIP_JOINT_CVJOINT || j.type[i] == EDYNHIP_JOINT_GENERIC);
+    bool active = in_range && (j.type[i] == EDYNHIP_JOINT_HINGE || j.type[i] == EDYNHIP_JOINT_CVJOINT || j.type[i] == EDYNHIP_JOINT_GENERIC);
     if (active && edge_asleep(b.flags[j.bodyA[i]], b.flags[j.bodyB[i]])) active = false;
     uint32_t label = 0;
     float max_err = 0;
@@ -1918,6 +1980,10 @@ __global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, f
     }
     }
     publish_error(active, max_err, label, isl_err);
+}
+__global__ void k_pos_joints(uint32_t start, uint32_t end, Joints j, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
+    const uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x;
+    pos_joints_lane(i, i < end, j, b, isl_err, isl_done);
 }
 // ---- dataflow position solve: one launch per position iteration (the island early-out between iterations stays a
 // separate tiny kernel). Same protocol as k_contact_solve_df with lane = (manifold, side): the hand-off is the body's
@@ -2096,6 +2162,247 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
         const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
         if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col);
         else dfp_task<2>(a, p, valid, sideB, np, col);
+    }
+}
+
+// ---- island-fused schedule -----------------------------------------------------------------------------------------
+// Scenes whose velocity solve cannot take the dataflow launch (joints, contact_extras rows) used to cost one launch per
+// colour and sweep - ~180 dependent 5-10 us launches a step for a field of rag dolls. Islands are independent, so ONE
+// wave per island runs its whole solve instead: the island's constraints (joints and active manifolds) are bucketed by
+// island label, sorted by phase (joint colours, then contact colours) in LDS, and the wave walks the phases of every
+// sweep in the order of the per-colour schedule with a workgroup barrier between them (same CU, same L1: what
+// k_contact_solve_tail does for one colour suffix). The arithmetic is the per-colour kernels' lane functions on the same
+// global arrays, so results are bit-identical with the per-colour schedule; only islands too large for one wave to be
+// worth it (host decision from the previous step's largest island, kIslFusedLimit) keep the launches.
+struct JointColours { uint32_t n; uint32_t start[kMaxColours + 1]; };
+struct IslLists {
+    uint32_t *cnt;      // [bodies + 1] items per island label; zero between steps (the fill counts it back down)
+    uint32_t *off;      // [bodies + 1] exclusive scan of cnt
+    uint32_t *list;     // labels of the islands that have items, in no particular order (islands are independent)
+    uint32_t *items;    // phase << 24 | index (joint: position in colour order; manifold: sorted position p), by island
+    uint32_t *sorted;   // the same, sorted by phase: only islands beyond the LDS list use it
+};
+constexpr uint32_t kIslPhaseShift = 24, kIslIdMask = 0xFFFFFFu, kIslContactPhase = 64, kIslPhases = 128;
+constexpr uint32_t kIslLdsItems = 1024;    // an island's phase-sorted list lives in LDS up to this size
+constexpr uint32_t kIslFusedLimit = 4096;  // largest island (items) for which one wave per island beats the launches
+DI uint32_t isl_item_label(uint32_t t, uint32_t nj, uint32_t na, const Joints &j, const Rows &rows, const Bodies &b, bool &is_joint, uint32_t &id) {
+    if (t < nj) {
+        is_joint = true; id = t;
+        const uint32_t ia = j.bodyA[t], ib = j.bodyB[t], fa = b.flags[ia], fb = b.flags[ib];
+        if (edge_asleep(fa, fb)) return 0xFFFFFFFFu;
+        if (is_dynamic(fa)) return b.island[ia];
+        if (is_dynamic(fb)) return b.island[ib];
+        return 0xFFFFFFFFu;
+    }
+    is_joint = false; id = t - nj;
+    return id < na ? rows.label[id] : 0xFFFFFFFFu;
+}
+__global__ void k_isl_count(uint32_t nj, uint32_t na, Joints j, Rows rows, Bodies b, IslLists L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_joint; uint32_t id;
+    const uint32_t label = t < nj + na ? isl_item_label(t, nj, na, j, rows, b, is_joint, id) : 0xFFFFFFFFu;
+    if (label != 0xFFFFFFFFu) atomicAdd(&L.cnt[label], 1u);
+}
+__global__ void k_isl_fill(uint32_t nj, uint32_t na, Joints j, JointColours jc, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b,
+                           IslLists L, Counters *cnt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_joint; uint32_t id;
+    const uint32_t label = t < nj + na ? isl_item_label(t, nj, na, j, rows, b, is_joint, id) : 0xFFFFFFFFu;
+    if (label == 0xFFFFFFFFu) return;
+    uint32_t phase;
+    if (is_joint) { phase = 0; while (phase + 1 < jc.n && id >= jc.start[phase + 1]) ++phase; }
+    else phase = kIslContactPhase + (keys_sorted[id] >> 2);
+    const uint32_t left = atomicSub(&L.cnt[label], 1u);            // counts back down to zero: no clearing pass
+    const uint32_t o = L.off[label];
+    L.items[o + left - 1] = (phase << kIslPhaseShift) | id;
+    if (left == 1) {
+        L.list[atomicAdd(&cnt->isl_num, 1u)] = label;
+        atomicMax(&cnt->isl_max_items, L.off[label + 1] - o);
+    }
+}
+// Sorts one island's items by phase (counting sort through LDS) and lists the phases that occur. Returns the list to
+// walk (LDS, or the global scratch for an island beyond kIslLdsItems) - all lanes of the (single-wave) workgroup call it.
+struct IslShared { uint32_t items[kIslLdsItems]; uint32_t start[kIslPhases + 1]; uint32_t cursor[kIslPhases]; uint32_t phases[kIslPhases]; uint32_t nph; };
+DI const uint32_t *isl_sort(IslShared &S, const IslLists &L, uint32_t o, uint32_t size) {
+    const uint32_t t = threadIdx.x;
+    __syncthreads();   // the previous island's walk is over
+    S.cursor[t] = 0; S.cursor[t + 64] = 0;
+    __syncthreads();
+    for (uint32_t q = t; q < size; q += 64) atomicAdd(&S.cursor[L.items[o + q] >> kIslPhaseShift], 1u);
+    __syncthreads();
+    // exclusive scan of the 128 counts: lane t owns phases t and t + 64
+    const uint32_t c0 = S.cursor[t], c1 = S.cursor[t + 64];
+    uint32_t s0 = c0, s1 = c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u0 = __shfl_up(s0, d), u1 = __shfl_up(s1, d);
+        if ((int)t >= d) { s0 += u0; s1 += u1; }
+    }
+    const uint32_t total0 = __shfl(s0, 63);
+    S.start[t] = s0 - c0; S.start[t + 64] = total0 + s1 - c1;
+    if (t == 63) S.start[kIslPhases] = total0 + s1;
+    const uint64_t m0 = __ballot(c0 != 0), m1 = __ballot(c1 != 0);
+    const uint64_t below = (1ull << t) - 1ull;
+    if (c0) S.phases[__popcll(m0 & below)] = t;
+    if (c1) S.phases[__popcll(m0) + __popcll(m1 & below)] = t + 64;
+    if (t == 0) S.nph = (uint32_t)(__popcll(m0) + __popcll(m1));
+    __syncthreads();
+    S.cursor[t] = S.start[t]; S.cursor[t + 64] = S.start[t + 64];
+    __syncthreads();
+    uint32_t *dst = size <= kIslLdsItems ? S.items : L.sorted + o;
+    for (uint32_t q = t; q < size; q += 64) {
+        const uint32_t it = L.items[o + q];
+        dst[atomicAdd(&S.cursor[it >> kIslPhaseShift], 1u)] = it;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return dst;
+}
+struct IslSolveArgs {
+    IslLists L; const Counters *cnt;
+    Joints j; Bodies b; Rows rows; Manifolds mf; uint32_t rcap; float4 *rwx;
+    uint32_t iters;                 // velocity: iterations after the warm start; position: position iterations
+    float *isl_err; uint32_t *isl_done;
+};
+template <bool WARM>
+DI void isl_velocity_sweep(const IslSolveArgs &a, const IslShared &S, const uint32_t *lst) {
+    const uint32_t nph = S.nph;
+    for (uint32_t k = 0; k < nph; ++k) {
+        const uint32_t ph = S.phases[k], q0 = S.start[ph], q1 = S.start[ph + 1];
+        if (ph < kIslContactPhase) {
+            for (uint32_t q = q0 + threadIdx.x; q < q1; q += 64) joint_solve_lane<WARM>(lst[q] & kIslIdMask, a.j, a.b);
+        } else {
+            for (uint32_t q = q0 + threadIdx.x; q < q1; q += 64) {
+                const uint32_t p = lst[q] & kIslIdMask, np = a.rows.np[p];
+                if (__any(np > 2)) contact_solve_np<WARM, 4, false>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
+                else contact_solve_np<WARM, 2, false>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+// Fast path for an island of at most 64 constraints whose dynamic bodies lie within kIslBodySlots indices of each other (a
+// rag doll, a chain, a small heap): each lane owns ONE constraint and keeps its rows in registers for the whole solve, the
+// bodies' velocity deltas live in LDS, and a phase costs an LDS round trip plus the row arithmetic instead of two
+// dependent trips to memory. Same operations in the same order as the lane functions above.
+constexpr uint32_t kIslBodySlots = 256, kIslNoSlot = 0xFFFFFFFFu;
+struct IslFast { float4 dv[kIslBodySlots], dw[kIslBodySlots]; };
+DI void isl_velocity_fast(const IslSolveArgs &a, const IslShared &S, IslFast &F, bool has, uint32_t item, uint32_t ia, uint32_t ib, uint32_t base) {
+    const uint32_t ph = item >> kIslPhaseShift, id = item & kIslIdMask;
+    const bool is_joint = ph < kIslContactPhase;
+    Delta d;
+    d.dvA = d.dwA = d.dvB = d.dwB = mk3(0, 0, 0); d.imA = d.imB = 0;
+    d.iA = d.iB = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    uint32_t sa = kIslNoSlot, sb = kIslNoSlot, np = 0;
+    RowReg R[4][kRowsPerPoint];
+    if (has) {
+        const float4 va = B_DV(a.b, ia), vb = B_DV(a.b, ib);
+        d.imA = va.w; d.imB = vb.w;
+        if (va.w != 0) { sa = ia - base; F.dv[sa] = va; F.dw[sa] = B_DW(a.b, ia); }
+        if (vb.w != 0) { sb = ib - base; F.dv[sb] = vb; F.dw[sb] = B_DW(a.b, ib); }
+        if (is_joint) {
+            jlane_load(R, a.j, a.b, id, ia, ib);
+        } else {
+            np = a.rows.np[id];
+            rows_load<4>(R, a.rows.rw, a.rcap, id);
+        }
+    }
+    __syncthreads();
+    const uint32_t nph = S.nph;
+    for (uint32_t sweep = 0; sweep <= a.iters; ++sweep) {
+        for (uint32_t k = 0; k < nph; ++k) {
+            if (has && S.phases[k] == ph) {
+                if (sa != kIslNoSlot) { d.dvA = from4(F.dv[sa]); d.dwA = from4(F.dw[sa]); } else { d.dvA = d.dwA = mk3(0, 0, 0); }
+                if (sb != kIslNoSlot) { d.dvB = from4(F.dv[sb]); d.dwB = from4(F.dw[sb]); } else { d.dvB = d.dwB = mk3(0, 0, 0); }
+                if (is_joint) { if (sweep == 0) jlane_solve<true>(R, d); else jlane_solve<false>(R, d); }
+                else { if (sweep == 0) rows_solve<true, 4>(d, R, np); else rows_solve<false, 4>(d, R, np); }
+                if (sa != kIslNoSlot) { F.dv[sa] = to4(d.dvA, d.imA); F.dw[sa] = to4(d.dwA, 0); }
+                if (sb != kIslNoSlot) { F.dv[sb] = to4(d.dvB, d.imB); F.dw[sb] = to4(d.dwB, 0); }
+            }
+            __syncthreads();
+        }
+    }
+    if (has) {
+        if (sa != kIslNoSlot) { B_DV(a.b, ia) = F.dv[sa]; B_DW(a.b, ia) = F.dw[sa]; }
+        if (sb != kIslNoSlot) { B_DV(a.b, ib) = F.dv[sb]; B_DW(a.b, ib) = F.dw[sb]; }
+        if (is_joint) jlane_store(R, a.j, id);
+        else if (a.iters) rows_store_impulses<4>(R, a.rows.rw, a.rcap, id, np);
+    }
+}
+__global__ void __launch_bounds__(64) k_island_velocity(IslSolveArgs a) {
+    __shared__ IslShared S;
+    __shared__ IslFast F;
+    const uint32_t num = a.cnt->isl_num, t = threadIdx.x;
+    for (uint32_t k = blockIdx.x; k < num; k += gridDim.x) {
+        const uint32_t label = a.L.list[k], o = a.L.off[label], size = a.L.off[label + 1] - o;
+        const uint32_t *lst = isl_sort(S, a.L, o, size);
+        bool fast = false;
+        uint32_t item = 0, ia = 0, ib = 0, base = 0;
+        const bool has = t < size;
+        if (size <= 64 && a.rwx == nullptr) {
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            bool generic = false;
+            if (has) {
+                item = lst[t];
+                const uint32_t id = item & kIslIdMask;
+                if ((item >> kIslPhaseShift) < kIslContactPhase) { ia = a.j.bodyA[id]; ib = a.j.bodyB[id]; generic = a.j.type[id] == EDYNHIP_JOINT_GENERIC; }
+                else { ia = a.rows.bA[id]; ib = a.rows.bB[id]; }
+                if (B_DV(a.b, ia).w != 0) { lo = min(lo, ia); hi = max(hi, ia); }
+                if (B_DV(a.b, ib).w != 0) { lo = min(lo, ib); hi = max(hi, ib); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, off)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, off)); }
+            fast = !__any(generic) && lo <= hi && hi - lo < kIslBodySlots;
+            base = lo;
+        }
+        if (fast) {
+            isl_velocity_fast(a, S, F, has, item, ia, ib, base);
+        } else {
+            isl_velocity_sweep<true>(a, S, lst);
+            for (uint32_t it = 0; it < a.iters; ++it) isl_velocity_sweep<false>(a, S, lst);
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_island_position(IslSolveArgs a) {
+    __shared__ IslShared S;
+    __shared__ uint32_t s_done;
+    const uint32_t num = a.cnt->isl_num, t = threadIdx.x;
+    for (uint32_t k = blockIdx.x; k < num; k += gridDim.x) {
+        const uint32_t label = a.L.list[k], o = a.L.off[label], size = a.L.off[label + 1] - o;
+        const uint32_t *lst = isl_sort(S, a.L, o, size);
+        const uint32_t nph = S.nph;
+        for (uint32_t it = 0; it < a.iters; ++it) {
+            for (uint32_t kk = 0; kk < nph; ++kk) {
+                const uint32_t ph = S.phases[kk], q0 = S.start[ph], q1 = S.start[ph + 1];
+                // uniform trip counts: every lane reaches the wave-level exchanges and reductions of the lane functions
+                if (ph < kIslContactPhase) {
+                    for (uint32_t base = q0; base < q1; base += 64) {
+                        const bool in = base + t < q1;
+                        pos_joints_lane(lst[in ? base + t : q0] & kIslIdMask, in, a.j, a.b, a.isl_err, a.isl_done);
+                    }
+                } else {
+                    for (uint32_t base = q0; base < q1; base += 32) {
+                        const uint32_t q = base + (t >> 1);
+                        const bool in = q < q1;
+                        pos_contacts_item(in, lst[in ? q : q0] & kIslIdMask, t & 1u, a.rows, a.mf, a.b, a.isl_err, a.isl_done);
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            // k_pos_flags for this island: below the threshold it takes no part in further iterations (island_solver.cpp:350-353)
+            if (t == 0) {
+                const float e = __uint_as_float(__hip_atomic_load((const uint32_t *)&a.isl_err[label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const uint32_t done = e < kPosErrorThreshold ? 1u : 0u;
+                if (done) a.isl_done[label] = 1;
+                __hip_atomic_store((uint32_t *)&a.isl_err[label], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_done = done;
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (s_done) break;
+        }
     }
 }
 
@@ -2333,6 +2640,36 @@ int solve(edynhip_ctx *c) {
     if (push) {
         hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
     }
+    // island-fused schedule (k_island_velocity / k_island_position): bucket this step's constraints by island, and use the
+    // fused launches if the largest island of the PREVIOUS step (the value this step's counter fetch brought) is small enough
+    static const bool isl_env = !(getenv("EDYNHIP_ISLAND_FUSED") && getenv("EDYNHIP_ISLAND_FUSED")[0] == '0');
+    const bool isl_candidate = isl_env && !push && !serial && (na + j.n) > 0 && (size_t)na + j.n < kIslIdMask;
+    const IslLists isl{c->isl_cnt, c->isl_off, c->isl_list, c->isl_items, c->isl_sorted};
+    bool isl_fused = false;
+    if (isl_candidate) {
+        JointColours jc{};
+        jc.n = j.num_colours;
+        for (uint32_t k = 0; k <= j.num_colours && k <= kMaxColours; ++k) jc.start[k] = j.colour_start[k];
+        EH_HIP(c, hipMemsetAsync(&c->cnt->isl_num, 0, 2 * sizeof(uint32_t), s));   // isl_num, isl_max_items
+        hipLaunchKernelGGL(k_isl_count, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, c->rows, c->b, isl);
+        EH_TRY(scan_u32(c, c->isl_cnt, c->isl_off, n + 1));
+        hipLaunchKernelGGL(k_isl_fill, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, jc, c->rows, c->col_keys_sorted, c->b, isl, c->cnt);
+        uint32_t largest = 0xFFFFFFFFu;
+        const bool fetched = c->last_fetch_step == c->step_index;   // this step's counters were read after the previous step's fill
+        if (fetched && c->isl_prep_step + 1 == c->step_index) largest = c->cnt_host->isl_max_items;
+        else if (!fetched && c->isl_cache_epoch == c->topology_epoch) largest = c->isl_cache_max;
+        else if (!fetched) {
+            // no contacts and nothing with a shape: the step reads no counters at all and the islands are those of the
+            // joints, fixed until the scene is edited - read this step's value once and keep it
+            EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
+            largest = c->isl_cache_max = c->cnt_host->isl_max_items;
+            c->isl_cache_epoch = c->topology_epoch;
+        }
+        c->isl_prep_step = c->step_index;
+        isl_fused = largest <= kIslFusedLimit;
+    }
+    IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done};
+    constexpr uint32_t kIslGrid = 4096;   // one wave each; a block takes islands blockIdx.x, + kIslGrid, ...
     rec(c, 5);
     uint32_t launches = 0;
     auto joints_pass = [&](bool warm) {
@@ -2461,7 +2798,11 @@ int solve(edynhip_ctx *c) {
             (void)hipFree(a.trace);
         } else if (tracing) (void)hipFree(a.trace);
     }
-    if (!df_velocity) {
+    if (!df_velocity && isl_fused) {
+        isl_args.iters = c->cfg.num_velocity_iterations;
+        hipLaunchKernelGGL(k_island_velocity, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+        ++launches;
+    } else if (!df_velocity) {
         joints_pass(true);
         contacts_pass(true);
         for (uint32_t it = 0; it < c->cfg.num_velocity_iterations; ++it) {
@@ -2519,7 +2860,10 @@ int solve(edynhip_ctx *c) {
             pos_per_colour(it);
         }
     } else if (P > 0 && (na || j.n)) {
-        pos_per_colour(0);
+        if (isl_fused) {
+            isl_args.iters = P;
+            hipLaunchKernelGGL(k_island_position, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+        } else pos_per_colour(0);
     }
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt,
