@@ -433,6 +433,36 @@ def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
         assert np.array_equal(a, b)
 
 
+def test_island_fused_and_per_colour_schedules_are_bit_identical(tmp_path):
+    """Scenes with joints run the velocity and position solves as ONE launch each, a wave per island (k_island_velocity /
+    k_island_position; islands of up to 64 constraints keep their rows in registers and their bodies' deltas in LDS, larger
+    ones walk the lane functions of the per-colour kernels); EDYNHIP_ISLAND_FUSED=0 keeps one launch per colour and sweep.
+    Same row arithmetic in the same order per island: state, manifolds and applied impulses must agree bit for bit - on rag
+    dolls that merge into islands too large for the register path, and on chains."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import os, sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import edyn_amd; from edyn_amd import scenes\n"
+        "out = {}\n"
+        "for name in ('ragdolls', 'chains'):\n"
+        "    sc = scenes.figures(scenes.load_figure(os.path.join(%r, 'ragdoll_capsule.npz')), 3, 2, pitch=1.0, ny=2, pitch_v=1.9) if name == 'ragdolls' else scenes.c5_chains(6, 9)\n"
+        "    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3))\n"
+        "    w.set_scene(sc); scenes.apply_figure_settings(w, sc); w.step_simulation(150)\n"
+        "    p, q, v, a = w.get_state()\n"
+        "    out.update({name + '_p': p, name + '_q': q, name + '_v': v, name + '_a': a, name + '_m': w.get_manifolds().view(np.uint8), name + '_j': w.get_joint_impulses()})\n"
+        "np.savez(sys.argv[1], **out)\n" % (root, GOLDEN))
+    outs = []
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"fused_{mode}.npz")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, EDYNHIP_ISLAND_FUSED=mode), timeout=300)
+        outs.append(np.load(out))
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 12
+    for k in outs[0].files:
+        assert np.isfinite(outs[0][k]).all() if outs[0][k].dtype.kind == "f" else True, k
+        assert np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8)), k
+
+
 # ------------------------------------------------------------------ pair ownership (sort-free broadphase output)
 def _append_body(scene, **kw):
     s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
