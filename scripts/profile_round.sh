@@ -14,7 +14,9 @@ for WL in $WLS; do
   W=/tmp/prof_${R}_$WL; rm -rf $W; mkdir -p $W
   case $WL in islands256k) STEPS=60; WARM=60;; *) STEPS=300; WARM=120;; esac
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline > $OUT/${R}_bench_under_rocprof_$WL.json 2> $W/kt.log )
-  python scripts/prof_summary.py $W/kt $((STEPS + WARM)) k_contact_solve $STEPS > $OUT/${R}_kernel_stats_$WL.txt
+  case $WL in chains16k|ragdolls1k) KN=k_island_velocity;; *) KN=k_contact_solve;; esac
+  python scripts/prof_summary.py $W/kt $((STEPS + WARM)) $KN $STEPS > $OUT/${R}_kernel_stats_$WL.txt
+  case $WL in chains16k|ragdolls1k) continue;; esac   # joint scenes: kernel statistics only (the traffic model is the contact solve's)
   for C in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps 40 --warmup 5 --no-cpu-baseline > /dev/null 2> $W/$C.log )
   done
