@@ -198,6 +198,7 @@ struct gpu_stepper {
     edynhip_ctx *ctx{nullptr};
     std::vector<entt::entity> bodies;          // body index -> entity (creation order); entt::null = destroyed (the index stays reserved)
     std::vector<entt::entity> constraints;     // joint index -> entity, same convention
+    std::vector<uint8_t> constraint_kind;      // joint index -> EDYNHIP_JOINT_*: one entity may carry several constraint types (make_ragdoll: cone + cvjoint)
     std::vector<std::array<uint32_t, 2>> pending_exclusions;   // exclude_collision calls made before the bodies were uploaded
     bool scene_dirty{true}, state_dirty{false}, paused{false}, params_dirty{false};
     double accumulated{0}, last_time{0};
@@ -214,6 +215,30 @@ struct gpu_stepper {
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
 };
 struct body_index { uint32_t value; };
+template <typename T> constexpr int joint_kind_of() {
+    if constexpr (std::is_same_v<T, point_constraint>) return EDYNHIP_JOINT_POINT;
+    else if constexpr (std::is_same_v<T, hinge_constraint>) return EDYNHIP_JOINT_HINGE;
+    else if constexpr (std::is_same_v<T, distance_constraint>) return EDYNHIP_JOINT_DISTANCE;
+    else if constexpr (std::is_same_v<T, soft_distance_constraint>) return EDYNHIP_JOINT_SOFT_DISTANCE;
+    else if constexpr (std::is_same_v<T, cone_constraint>) return EDYNHIP_JOINT_CONE;
+    else if constexpr (std::is_same_v<T, cvjoint_constraint>) return EDYNHIP_JOINT_CVJOINT;
+    else if constexpr (std::is_same_v<T, gravity_constraint>) return EDYNHIP_JOINT_GRAVITY;
+    else return EDYNHIP_JOINT_GENERIC;
+}
+// the constraint component of kind `kind` on `e`, or nullptr (also when the entity itself is gone)
+inline constraint_base *constraint_of(entt::registry &registry, entt::entity e, int kind) {
+    if (!registry.valid(e)) return nullptr;
+    switch (kind) {
+    case EDYNHIP_JOINT_POINT: return registry.try_get<point_constraint>(e);
+    case EDYNHIP_JOINT_HINGE: return registry.try_get<hinge_constraint>(e);
+    case EDYNHIP_JOINT_DISTANCE: return registry.try_get<distance_constraint>(e);
+    case EDYNHIP_JOINT_SOFT_DISTANCE: return registry.try_get<soft_distance_constraint>(e);
+    case EDYNHIP_JOINT_CONE: return registry.try_get<cone_constraint>(e);
+    case EDYNHIP_JOINT_CVJOINT: return registry.try_get<cvjoint_constraint>(e);
+    case EDYNHIP_JOINT_GRAVITY: return registry.try_get<gravity_constraint>(e);
+    default: return registry.try_get<generic_constraint>(e);
+    }
+}
 
 inline void check(gpu_stepper &s, int rc) {
     if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + edynhip_last_error(s.ctx));
@@ -235,14 +260,16 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
                 jp[6 * j + 3 * k] = pv[k].x; jp[6 * j + 3 * k + 1] = pv[k].y; jp[6 * j + 3 * k + 2] = pv[k].z;
             }
         };
-        if (auto *pc = registry.try_get<point_constraint>(e)) { jt[j] = EDYNHIP_JOINT_POINT; fill(*pc, pc->pivot); jq[10 * j] = pc->friction_torque; }
-        else if (auto *dc = registry.try_get<distance_constraint>(e)) { jt[j] = EDYNHIP_JOINT_DISTANCE; fill(*dc, dc->pivot); jq[10 * j] = dc->distance; }
-        else if (auto *sc = registry.try_get<soft_distance_constraint>(e)) {
-            jt[j] = EDYNHIP_JOINT_SOFT_DISTANCE; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
-        } else if (auto *gc = registry.try_get<gravity_constraint>(e)) { jt[j] = EDYNHIP_JOINT_GRAVITY; fill(*gc, std::array<vector3, 2>{}); }
-        else if (auto *ge = registry.try_get<generic_constraint>(e)) { jt[j] = EDYNHIP_JOINT_GENERIC; fill(*ge, ge->pivot); }   // (definition follows)
-        else if (auto *cc = registry.try_get<cone_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CONE; fill(*cc, cc->pivot); }      // frames / parameters follow
-        else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) { jt[j] = EDYNHIP_JOINT_CVJOINT; fill(*cv, cv->pivot); }  // (define_frames below)
+        const int kind = s.constraint_kind[first + j];
+        if (kind == EDYNHIP_JOINT_POINT) { auto *pc = &registry.get<point_constraint>(e); jt[j] = kind; fill(*pc, pc->pivot); jq[10 * j] = pc->friction_torque; }
+        else if (kind == EDYNHIP_JOINT_DISTANCE) { auto *dc = &registry.get<distance_constraint>(e); jt[j] = kind; fill(*dc, dc->pivot); jq[10 * j] = dc->distance; }
+        else if (kind == EDYNHIP_JOINT_SOFT_DISTANCE) {
+            auto *sc = &registry.get<soft_distance_constraint>(e);
+            jt[j] = kind; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
+        } else if (kind == EDYNHIP_JOINT_GRAVITY) { jt[j] = kind; fill(registry.get<gravity_constraint>(e), std::array<vector3, 2>{}); }
+        else if (kind == EDYNHIP_JOINT_GENERIC) { auto *ge = &registry.get<generic_constraint>(e); jt[j] = kind; fill(*ge, ge->pivot); }   // (definition follows)
+        else if (kind == EDYNHIP_JOINT_CONE) { auto *cc = &registry.get<cone_constraint>(e); jt[j] = kind; fill(*cc, cc->pivot); }      // frames / parameters follow
+        else if (kind == EDYNHIP_JOINT_CVJOINT) { auto *cv = &registry.get<cvjoint_constraint>(e); jt[j] = kind; fill(*cv, cv->pivot); }  // (define_frames below)
         else {
             auto &hc = registry.get<hinge_constraint>(e);
             jt[j] = EDYNHIP_JOINT_HINGE; fill(hc, hc.pivot);
@@ -357,11 +384,14 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         if (e == entt::null) continue;
         auto rows9 = [](const matrix3x3 &m, float *o) { for (int r = 0; r < 3; ++r) { o[3 * r] = m.row[r].x; o[3 * r + 1] = m.row[r].y; o[3 * r + 2] = m.row[r].z; } };
         float fa[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, fb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, q[16] = {0};
-        if (auto *cc = registry.try_get<cone_constraint>(e)) {
+        const int kind = s.constraint_kind[j];
+        if (kind == EDYNHIP_JOINT_CONE) {
+            auto *cc = &registry.get<cone_constraint>(e);
             rows9(cc->frame, fa);
             q[0] = cc->span_tan[0]; q[1] = cc->span_tan[1]; q[2] = cc->restitution; q[3] = cc->bump_stop_stiffness; q[4] = cc->bump_stop_length;
             check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
-        } else if (auto *ge = registry.try_get<generic_constraint>(e)) {
+        } else if (kind == EDYNHIP_JOINT_GENERIC) {
+            auto *ge = &registry.get<generic_constraint>(e);
             rows9(ge->frame[0], fa); rows9(ge->frame[1], fb);
             float dof[60];
             for (int d = 0; d < 3; ++d) {
@@ -373,7 +403,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
                 for (int k = 0; k < 10; ++k) { dof[10 * d + k] = lv[k]; dof[10 * (3 + d) + k] = av[k]; }
             }
             check(s, edynhip_set_generic_definition(s.ctx, j, fa, fb, dof));
-        } else if (auto *cv = registry.try_get<cvjoint_constraint>(e)) {
+        } else if (kind == EDYNHIP_JOINT_CVJOINT) {
+            auto *cv = &registry.get<cvjoint_constraint>(e);
             rows9(cv->frame[0], fa); rows9(cv->frame[1], fb);
             const float v[15] = {cv->twist_min, cv->twist_max, cv->twist_restitution, cv->twist_bump_stop_angle, cv->twist_bump_stop_stiffness,
                                  cv->twist_friction_torque, cv->twist_rest_angle, cv->twist_stiffness, cv->twist_damping,
@@ -445,21 +476,13 @@ inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
     for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
         const entt::entity e = s.constraints[j];
         if (e == entt::null) continue;
-        bool alive = registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint, generic_constraint>(e);
-        if (alive) {   // a joint whose body was destroyed goes with it
-            const constraint_base &cb = registry.all_of<point_constraint>(e) ? static_cast<constraint_base &>(registry.get<point_constraint>(e))
-                                      : registry.all_of<distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<distance_constraint>(e))
-                                      : registry.all_of<soft_distance_constraint>(e) ? static_cast<constraint_base &>(registry.get<soft_distance_constraint>(e))
-                                      : registry.all_of<gravity_constraint>(e) ? static_cast<constraint_base &>(registry.get<gravity_constraint>(e))
-                                      : registry.all_of<generic_constraint>(e) ? static_cast<constraint_base &>(registry.get<generic_constraint>(e))
-                                      : registry.all_of<cone_constraint>(e) ? static_cast<constraint_base &>(registry.get<cone_constraint>(e))
-                                      : registry.all_of<cvjoint_constraint>(e) ? static_cast<constraint_base &>(registry.get<cvjoint_constraint>(e))
-                                      : static_cast<constraint_base &>(registry.get<hinge_constraint>(e));
-            for (int k = 0; k < 2; ++k) if (!registry.valid(cb.body[k]) || !registry.all_of<body_index>(cb.body[k])) alive = false;
-        }
+        const constraint_base *cb = constraint_of(registry, e, s.constraint_kind[j]);
+        bool alive = cb != nullptr;
+        if (alive)   // a joint whose body was destroyed goes with it
+            for (int k = 0; k < 2; ++k) if (!registry.valid(cb->body[k]) || !registry.all_of<body_index>(cb->body[k])) alive = false;
         if (!alive) {
             s.constraints[j] = entt::null;
-            if (registry.valid(e) && registry.any_of<point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint, cone_constraint, cvjoint_constraint, gravity_constraint, generic_constraint>(e)) registry.destroy(e);   // its body is gone
+            if (cb != nullptr) registry.destroy(e);   // its body is gone (an entity carrying two constraints: the second sees it gone)
             if (j < s.uploaded_constraints) gone_joints.push_back(j);
         }
     }
@@ -780,6 +803,7 @@ void make_constraint(entt::registry &registry, entt::entity entity, entt::entity
     con.body = {body0, body1};
     (setup(con), ...);
     s.constraints.push_back(entity);
+    s.constraint_kind.push_back((uint8_t)detail::joint_kind_of<T>());
     s.scene_dirty = true;
 }
 template <typename T, typename... SetupFunc>

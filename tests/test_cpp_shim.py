@@ -37,3 +37,66 @@ def test_shim_contact_entities_and_asynchronous_mode():
     subprocess.check_call(["make", "-s", "-C", CPP, "contacts"])
     out = subprocess.run([os.path.join(CPP, "contacts")], capture_output=True, text=True, timeout=300)
     assert "contacts OK" in out.stdout, out.stdout + out.stderr
+
+
+def _parse_dump(text):
+    bodies, joints, excl = [], [], []
+    for line in text.splitlines():
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] in ("body", "joint"):
+            rec, key = {}, None
+            for w in tok[2:]:
+                try:
+                    rec[key].append(float(w))
+                except (ValueError, KeyError):
+                    key = w; rec[key] = []
+            (bodies if tok[0] == "body" else joints).append(rec)
+        elif tok[0] == "exclude":
+            excl.append((int(tok[1]), int(tok[2])))
+    return bodies, joints, excl
+
+
+@pytest.mark.parametrize("shape", ["capsule", "box"])
+def test_shim_make_ragdoll_builds_the_reference_figure(shape):
+    """edyn::make_ragdoll of the shim (include/edyn/util/ragdoll.hpp, tables of parts and joints) against the real engine's own
+    rag doll (tests/golden/ragdoll_*.npz: edyn::make_ragdoll run by the reference and exported): every body - mass, transform,
+    shape, the explicit inertia of the shapeless shoulders and twist bodies - every constraint - type, bodies, pivots, axes,
+    frames, all parameters - and the exclusion list. No GPU needed: the shim uploads lazily."""
+    import numpy as np
+    subprocess.check_call(["make", "-s", "-C", CPP, "ragdoll"])
+    out = subprocess.run([os.path.join(CPP, "ragdoll"), shape], capture_output=True, text=True, timeout=60)
+    assert "RAGDOLL_DUMP_OK" in out.stdout, out.stdout + out.stderr
+    bodies, joints, excl = _parse_dump(out.stdout)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", f"ragdoll_{shape}.npz"))
+    close = lambda a, b: np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=2e-6, atol=2e-7)
+    assert len(bodies) == len(ref["kind"]) == 22 and len(joints) == len(ref["joint_type"]) == 36
+    for i, b in enumerate(bodies):
+        assert close(b["mass"], [ref["mass"][i]]) and close(b["pos"], ref["pos"][i]), (i, b["pos"], ref["pos"][i])
+        assert close(np.abs(b["orn"]), np.abs(ref["orn"][i])), (i, b["orn"], ref["orn"][i])     # (q and -q are one rotation)
+        assert int(b["shape"][0]) == int(ref["shape_type"][i]) and close(b["param"], ref["shape_param"][i][:3]), (i, b["param"], ref["shape_param"][i])
+        assert close(b["friction"], [ref["friction"][i]]) and close(b["restitution"], [ref["restitution"][i]])
+        if int(b["shape"][0]) == 0:
+            assert close(b["inertia"], ref["inertia"][i]), (i, b["inertia"], ref["inertia"][i])
+    for j, c in enumerate(joints):
+        assert int(c["kind"][0]) == int(ref["joint_type"][j]) and [int(x) for x in c["bodies"]] == list(ref["joint_body"][j]), j
+        assert close(c["pivotA"], ref["pivotA"][j]) and close(c["pivotB"], ref["pivotB"][j]), (j, c["pivotA"], ref["pivotA"][j], c["pivotB"], ref["pivotB"][j])
+        kind = int(c["kind"][0])
+        if kind == 1:
+            assert close(c["axisA"], ref["axisA"][j]) and close(c["axisB"], ref["axisB"][j]) and close(c["p"], ref["params10"][j]), (j, c["p"], ref["params10"][j])
+        elif kind == 4:
+            assert close(c["frameA"], ref["frameA"][j]) and close(c["p"], ref["params16"][j][:5]), (j, c["frameA"], ref["frameA"][j], c["p"], ref["params16"][j][:5])
+        else:
+            assert close(c["frameA"], ref["frameA"][j]) and close(c["frameB"], ref["frameB"][j]) and close(c["p"], ref["params16"][j][:15]), (j, c["p"], ref["params16"][j])
+    assert sorted(tuple(sorted(x)) for x in excl) == sorted(tuple(sorted(int(v) for v in x)) for x in ref["exclusions"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["capsule", "box"])
+def test_shim_ragdoll_falls_on_the_floor(shape):
+    """The shim's rag doll dropped on a plane: cone + cvjoint on one constraint entity, shapeless parts, exclusions - one second of
+    simulation leaves a finite, connected figure lying on the floor."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "ragdoll"])
+    out = subprocess.run([os.path.join(CPP, "ragdoll"), shape, "run"], capture_output=True, text=True, timeout=300)
+    assert "RAGDOLL_RUN_OK" in out.stdout, out.stdout + out.stderr
