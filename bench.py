@@ -51,6 +51,9 @@ WORKLOADS = {
     # collapsing on a plane: 22 529 bodies, 36 864 cone / cvjoint / hinge constraints, capsule contacts
     "ragdolls1k": dict(gen=lambda: scenes.figures(scenes.load_figure(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ragdoll_capsule.npz")), 32, 32),
                        vel=10, pos=3, desc="1024 rag dolls (22 bodies, 36 cone/cvjoint/hinge constraints each) falling on a plane"),
+    # north_star's body count on ONE GPU: 1 048 576 boxes in 16 384 islands (the C4 scene at 4x the sites)
+    "islands1m": dict(gen=lambda: scenes.mini_piles(128, 128), vel=10, pos=3, desc="1048576 boxes in 16384 independent 4x4x4 mini-piles",
+                      shard=lambda first, count: scenes.mini_piles(128, 128, first_site=first, num_sites=count), shard_units=16384),
     "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
 

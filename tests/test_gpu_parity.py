@@ -898,6 +898,25 @@ def test_baseline_configs_at_full_size_bit_exact(name, gen, vel, steps):
         assert st["num_manifolds"] == 0 and st["num_joints"] == 1024 * 16
 
 
+def test_field_of_ragdolls_at_bench_size_bit_exact():
+    """The rag-doll bench scene at full size (1024 of the reference's figures: 22 529 bodies, 36 864 constraints): the fall, the
+    landing on the floor and onto the neighbours - 1024 islands solved concurrently by the island-fused schedule, heaps of
+    merged figures on its slow path - against the oracle, bit for bit: pairs and state along the way, manifolds and applied
+    impulses at the end."""
+    sc = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 32, 32)
+    g, o = gpu_world(sc), oracle_world(sc)
+    scenes.apply_figure_settings(g, sc); scenes.apply_figure_settings(o, sc)
+    for step in range(1, 91):
+        g.step_simulation(1); o.step(1)
+        if step % 30 == 0 or step == 1:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="ragdolls1k")
+    assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32))
+    st = g.get_stats()
+    assert st["num_joints"] == 36 * 1024 and st["num_manifolds"] > 5000 and np.isfinite(g.get_state()[0]).all()
+
+
 # ------------------------------------------------------------------ the REAL reference engine as the checker
 def canonical_records(m, kind):
     """Reference-engine manifold records in the order edynhip_set_manifolds expects: ascending (owner << 32 | other), the
