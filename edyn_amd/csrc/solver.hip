@@ -2197,22 +2197,45 @@ DI uint32_t isl_item_label(uint32_t t, uint32_t nj, uint32_t na, const Joints &j
     is_joint = false; id = t - nj;
     return id < na ? rows.label[id] : 0xFFFFFFFFu;
 }
+// Lanes of a wave that bucket into the same island share ONE atomic (a pile with a few joints is a single island: without this
+// every constraint of the scene would hit the same counter). Returns what `op(label, lanes)` gave the group's first lane; `rank`
+// is this lane's position within its group.
+template <typename Op>
+DI uint32_t isl_wave_reserve(uint32_t label, Op op, uint32_t &rank) {
+    uint32_t result = 0;
+    rank = 0;
+    uint64_t todo = __ballot(label != 0xFFFFFFFFu);
+    const uint64_t below = (1ull << (threadIdx.x & 63u)) - 1ull;
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t l = (uint32_t)__shfl((int)label, lead);
+        const uint64_t same = __ballot(label == l);
+        uint32_t got = 0;
+        if ((int)(threadIdx.x & 63u) == lead) got = op(l, (uint32_t)__popcll(same));
+        got = (uint32_t)__shfl((int)got, lead);
+        if (label == l) { result = got; rank = (uint32_t)__popcll(same & below); }
+        todo &= ~same;
+    }
+    return result;
+}
 __global__ void k_isl_count(uint32_t nj, uint32_t na, Joints j, Rows rows, Bodies b, IslLists L) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_joint; uint32_t id;
+    bool is_joint; uint32_t id, rank;
     const uint32_t label = t < nj + na ? isl_item_label(t, nj, na, j, rows, b, is_joint, id) : 0xFFFFFFFFu;
-    if (label != 0xFFFFFFFFu) atomicAdd(&L.cnt[label], 1u);
+    isl_wave_reserve(label, [&](uint32_t l, uint32_t count) { return atomicAdd(&L.cnt[l], count); }, rank);
 }
 __global__ void k_isl_fill(uint32_t nj, uint32_t na, Joints j, JointColours jc, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b,
                            IslLists L, Counters *cnt) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_joint; uint32_t id;
+    bool is_joint = false; uint32_t id = 0, rank;
     const uint32_t label = t < nj + na ? isl_item_label(t, nj, na, j, rows, b, is_joint, id) : 0xFFFFFFFFu;
+    // the counter counts back down to zero: no clearing pass between steps
+    const uint32_t before = isl_wave_reserve(label, [&](uint32_t l, uint32_t count) { return atomicSub(&L.cnt[l], count); }, rank);
     if (label == 0xFFFFFFFFu) return;
     uint32_t phase;
     if (is_joint) { phase = 0; while (phase + 1 < jc.n && id >= jc.start[phase + 1]) ++phase; }
     else phase = kIslContactPhase + (keys_sorted[id] >> 2);
-    const uint32_t left = atomicSub(&L.cnt[label], 1u);            // counts back down to zero: no clearing pass
+    const uint32_t left = before - rank;   // this lane's share of the group's reservation
     const uint32_t o = L.off[label];
     L.items[o + left - 1] = (phase << kIslPhaseShift) | id;
     if (left == 1) {

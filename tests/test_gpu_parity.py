@@ -1222,3 +1222,30 @@ def test_ragdolls_bit_exact(shape):
     kinds = np.array([j[0] for j in sc["joints"]])
     assert np.abs(ji[kinds == scenes.JOINT_CONE][:, 1]).max() > 0 and (np.abs(ji[kinds == scenes.JOINT_CVJOINT][:, [3, 4, 6, 7]]).max(axis=0) > 0).all()
     assert len(g.get_manifolds()) > 200 and g.get_stats()["num_islands"] <= 2
+
+
+def test_pile_with_a_few_joints_keeps_the_per_colour_launches_bit_exact():
+    """A single large island (a 1 152-box pile, ~6 000 manifolds) with a handful of point constraints between neighbouring bricks:
+    joints rule out the dataflow launch, and the island is beyond what one wave should solve (kIslFusedLimit), so after
+    bucketing - every constraint of the scene lands on ONE island counter: the wave-aggregated reservation - the step keeps the
+    per-colour launches. Pairs, manifolds, state and joint impulses against the oracle."""
+    sc = scenes.box_pile(12, 8, 12)
+    pos = sc["pos"]
+    joints = []
+    top = np.nonzero(pos[:, 1] > pos[:, 1].max() - 0.1)[0]
+    for a in top:
+        d = pos[top] - pos[a]
+        near = top[(np.abs(d[:, 0] - 1.02) < 0.03) & (np.abs(d[:, 2]) < 0.03)]
+        if len(near) and len(joints) < 6 and a % 3 == 0:
+            joints.append((scenes.JOINT_POINT, int(a), int(near[0]), (0.51, 0.0, 0.0), (-0.51, 0.0, 0.0), (1.0, 0.0, 0.0), (1.0, 0.0, 0.0)))
+    assert len(joints) == 6
+    sc["joints"] = joints
+    g, o = gpu_world(sc), oracle_world(sc)
+    for step in range(1, 41):
+        g.step_simulation(1); o.step(1)
+        if step % 10 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="pile with joints")
+    assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32))
+    assert np.abs(g.get_joint_impulses()[:, :3]).max() > 0 and g.get_stats()["num_manifolds"] > 4096
