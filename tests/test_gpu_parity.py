@@ -437,8 +437,9 @@ def test_island_fused_and_per_colour_schedules_are_bit_identical(tmp_path):
     """Scenes with joints run the velocity and position solves as ONE launch each, a wave per island (k_island_velocity /
     k_island_position; islands of up to 64 constraints keep their rows in registers and their bodies' deltas in LDS, larger
     ones walk the lane functions of the per-colour kernels); EDYNHIP_ISLAND_FUSED=0 keeps one launch per colour and sweep.
-    Same row arithmetic in the same order per island: state, manifolds and applied impulses must agree bit for bit - on rag
-    dolls that merge into islands too large for the register path, and on chains."""
+    Same row arithmetic in the same order per island: state, manifolds and applied impulses must agree bit for bit - on thirty rag
+    dolls that start as separate islands (register path), merge into heaps (LDS list) and end as ONE island of ~1 500
+    constraints (beyond the LDS list: the global scratch list), and on chains."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = (
@@ -446,7 +447,7 @@ def test_island_fused_and_per_colour_schedules_are_bit_identical(tmp_path):
         "import edyn_amd; from edyn_amd import scenes\n"
         "out = {}\n"
         "for name in ('ragdolls', 'chains'):\n"
-        "    sc = scenes.figures(scenes.load_figure(os.path.join(%r, 'ragdoll_capsule.npz')), 3, 2, pitch=1.0, ny=2, pitch_v=1.9) if name == 'ragdolls' else scenes.c5_chains(6, 9)\n"
+        "    sc = scenes.figures(scenes.load_figure(os.path.join(%r, 'ragdoll_capsule.npz')), 3, 2, pitch=1.0, ny=5, pitch_v=1.9) if name == 'ragdolls' else scenes.c5_chains(6, 9)\n"
         "    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3))\n"
         "    w.set_scene(sc); scenes.apply_figure_settings(w, sc); w.step_simulation(150)\n"
         "    p, q, v, a = w.get_state()\n"
