@@ -316,7 +316,6 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // 0.026 + s_i) and box_j(t) inside grow(box_j(t0), s_j): an overlap now implies that those two overlapped at t0, which is
 // exactly the walk's leaf test - the pair is on the list. (The slack only has to be a number; how it is chosen decides
 // how long the lists live, not whether they are right.)
-constexpr uint32_t kListCap = 64;                 // candidates kept per body; a body with more walks the tree every step
 constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
                                                   // sleeping is on: it matters only while that body sleeps, see below)
 // The tree walk, only in the steps that rebuild the lists: one lane per body, stackless (ropes), fat query box.

@@ -1250,3 +1250,36 @@ def test_pile_with_a_few_joints_keeps_the_per_colour_launches_bit_exact():
     assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="pile with joints")
     assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32))
     assert np.abs(g.get_joint_impulses()[:, :3]).max() > 0 and g.get_stats()["num_manifolds"] > 4096
+
+
+def test_joint_redefinition_is_applied_lazily_but_in_call_order():
+    """edynhip_set_joint_params / set_joint_definition edit the host copy and rebuild the device arrays once, at the next entry
+    point that needs them; the angle reset of a redefined hinge still refers to the orientations at the time of the CALL: an
+    edit of the state right after it must not leak into the reset. Sequence against the oracle (which applies both at once)."""
+    sc = scenes.c5_chains(3, 6)
+    hinges = [i for i, j in enumerate(sc["joints"]) if j[0] == scenes.JOINT_HINGE]
+    g, o = gpu_world(sc), oracle_world(sc)
+    g.step_simulation(25); o.step(25)
+    for w in (g, o):
+        for i in hinges:
+            w.set_joint_params(i, [-0.4, 0.5, 0.2, 0.1, 4.0, 0.01, 0.0, 0.1, 1.0, 0.02])
+    assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32))   # (flushes: tracked angles included)
+    g.step_simulation(5); o.step(5)
+    assert_state_equal(g, o)
+    p, q, v, a = (x.copy() for x in g.get_state())
+    for w in (g, o):
+        for i in hinges[::2]:
+            w.set_joint_params(i, [-0.2, 0.3, 0.0, 0.05, 2.0, 0.0, 0.0, 0.0, 0.5, 0.01])   # reset against the CURRENT orientations ...
+    rng = np.random.default_rng(5)
+    dyn = sc["kind"] == scenes.KIND_DYNAMIC
+    a[dyn] += rng.normal(size=(int(dyn.sum()), 3)).astype(np.float32) * 0.3
+    tw = rng.normal(size=(len(q), 4)).astype(np.float32) * 0.05
+    q2 = q + tw * dyn[:, None]
+    q2 /= np.linalg.norm(q2, axis=1, keepdims=True)
+    g.set_state(p, q2.astype(np.float32), v, a); o.set_state(p, q2.astype(np.float32), v, a)   # ... not these
+    for s in range(1, 61):
+        g.step_simulation(1); o.step(1)
+        if s % 10 == 0 or s < 3:
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
+    assert np.isfinite(g.get_state()[0]).all()
