@@ -54,8 +54,16 @@ WORKLOADS = {
     # north_star's body count on ONE GPU: 1 048 576 boxes in 16 384 islands (the C4 scene at 4x the sites)
     "islands1m": dict(gen=lambda: scenes.mini_piles(128, 128), vel=10, pos=3, desc="1048576 boxes in 16384 independent 4x4x4 mini-piles",
                       shard=lambda first, count: scenes.mini_piles(128, 128, first_site=first, num_sites=count), shard_units=16384),
+    # the headline pile with 64 rag dolls standing beside it: islands with joints next to a large island without (mixed schedule)
+    "pile32k_ragdolls": dict(gen=lambda: _pile_and_ragdolls(), vel=10, pos=3, desc="the 32768-box pile beside 64 rag dolls (36 constraints each)"),
     "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
+
+
+def _pile_and_ragdolls():
+    figs = scenes.figures(scenes.load_figure(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ragdoll_capsule.npz")), 8, 8, floor=False)
+    figs["pos"][:, 0] += np.float32(60.0)
+    return scenes.merge(scenes.box_pile(32, 32, 32), figs)
 
 
 def _cpu_scene(workload):

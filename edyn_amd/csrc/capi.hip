@@ -88,7 +88,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, r.dslot, ((size_t)M + 64) * 4));   // whole 64-lane blocks (dslot_at)
     EH_TRY(dalloc(c, r.pslot, ((size_t)M + 32) * 6));   // whole 32-lane blocks (pslot_at)
     EH_TRY(dalloc(c, r.next, (size_t)M * 2)); EH_TRY(dalloc(c, r.im, (size_t)M * 2));
-    EH_TRY(dalloc(c, r.slot_of, (size_t)nb * kMaxColours)); EH_TRY(dalloc(c, r.first_slot, nb));
+    EH_TRY(dalloc(c, r.slot_of, (size_t)nb * kMaxColours)); EH_TRY(dalloc(c, r.first_slot, nb)); EH_TRY(dalloc(c, r.skip, M));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));
     EH_TRY(dalloc(c, t.parent, (size_t)2 * nb)); EH_TRY(dalloc(c, t.left, nb)); EH_TRY(dalloc(c, t.right, nb));
@@ -108,7 +108,7 @@ static int allocate(edynhip_ctx *c) {
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->isl_cnt, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_off, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_list, nb));
-    EH_TRY(dalloc(c, c->isl_items, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_sorted, (size_t)M + nj));
+    EH_TRY(dalloc(c, c->isl_items, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_sorted, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_joint, nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb)); EH_TRY(dalloc(c, c->pos_err, (size_t)nb * kMaxDfPosIters));
     EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
     EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));

@@ -173,6 +173,7 @@ struct Rows {
     float *im = nullptr;          // [2p + side] inverse mass of that side's body (0 = read-only body: no hand-off)
     uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
+    uint8_t *skip = nullptr;          // [p] mixed schedule: the manifold's island has joints (solved by the island-fused kernels, not on the chains)
 };
 constexpr int kRowF = 5, kRowsPerPoint = 3;
 constexpr uint32_t kColUncCap = 16384;   // uncoloured edges one workgroup colours by itself (more: the multi-block rounds)
@@ -233,6 +234,8 @@ struct Counters {
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
     uint32_t isl_num;            // island-fused schedule: islands that have constraints this step (solver.hip k_isl_fill)
     uint32_t isl_max_items;      //   and the largest of them, in constraints (read by the NEXT step's schedule decision)
+    uint32_t isl_max_jitems;     //   the largest island that has joints
+    uint32_t isl_free;           //   active manifolds in islands without joints (mixed schedule: those go to the dataflow launch)
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
     uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];
@@ -285,11 +288,11 @@ struct edynhip_ctx {
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
     float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
-    uint32_t *isl_cnt = nullptr, *isl_off = nullptr, *isl_list = nullptr, *isl_items = nullptr, *isl_sorted = nullptr;   // island-fused schedule (solver.hip IslLists)
+    uint32_t *isl_cnt = nullptr, *isl_off = nullptr, *isl_list = nullptr, *isl_items = nullptr, *isl_sorted = nullptr, *isl_joint = nullptr;   // island-fused schedule (solver.hip IslLists)
     uint32_t isl_prep_step = 0xFFFFFFF0u;   // step_index of the last step that bucketed its constraints by island (its isl_max_items reaches cnt_host with the next step's fetch)
     uint32_t last_fetch_step = 0xFFFFFFF0u; // step_index during which fetch_counters last ran
     uint32_t topology_epoch = 0;            // bumped when bodies or joints are added / removed / redefined
-    uint32_t isl_cache_epoch = 0xFFFFFFFFu, isl_cache_max = 0;   // largest island of a scene whose steps fetch no counters (no shapes, no contacts)
+    uint32_t isl_cache_epoch = 0xFFFFFFFFu, isl_cache_max = 0, isl_cache_free = 0, isl_cache_jmax = 0;   // largest island of a scene whose steps fetch no counters (no shapes, no contacts)
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)
     uint32_t *isl_done = nullptr;
     void *sort_tmp = nullptr;

@@ -849,6 +849,7 @@ struct DfArgs {
     float4 *dslot;
     Counters *cnt;
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
+    const uint8_t *skip;              // mixed schedule: [p] != 0 = the manifold's island has joints and is solved by k_island_velocity; else nullptr
 };
 DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): pieces 1 KiB apart (dslot_at)
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -944,7 +945,7 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
     for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
         for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
             const uint32_t pt = base + t;
-            const bool valid = pt < a.na;
+            const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
             if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
             const uint32_t p = valid ? pt : a.na - 1;
             const uint32_t key = a.keys_sorted[p];
@@ -957,9 +958,17 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 }
 
 // ---- push hand-off: link every (lane, side) to the same body's next manifold in colour order (cyclic) ----
-__global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used) {
+// `isl_joint` (mixed schedule, else nullptr): islands with joints take no part in the hand-off chains - their manifolds are marked in
+// Rows::skip and their bodies keep first_slot = none (k_island_velocity / k_island_position solve them on the body records).
+__global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used,
+                             const uint32_t *__restrict__ isl_joint) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
+    if (isl_joint) {
+        const bool fused = isl_joint[rows.label[p]] != 0;
+        rows.skip[p] = fused ? 1 : 0;
+        if (fused) return;
+    }
     const uint32_t col = keys_sorted[p] >> 2;
 #pragma unroll
     for (uint32_t side = 0; side < 2; ++side) {
@@ -1066,11 +1075,14 @@ DI float track_angle(float tracked, float new_angle) {   // update_angle (hinge_
     const float d1 = d0 + kPi2 * (d0 < 0 ? 1.0f : -1.0f);
     return tracked + (fabsf(d0) < fabsf(d1) ? d0 : d1);
 }
-__global__ void k_prep_joints(Joints j, Bodies b, float dt) {
+// (also marks the island of every awake joint in `isl_joint`, cleared again by k_finish: what the schedules in solve() key on)
+__global__ void k_prep_joints(Joints j, Bodies b, float dt, uint32_t *__restrict__ isl_joint) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= j.n) return;
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;   // sleeping island: its joints are not prepared or solved
+    if (is_dynamic(b.flags[ia])) isl_joint[b.island[ia]] = 1u;
+    else if (is_dynamic(b.flags[ib])) isl_joint[b.island[ib]] = 1u;
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
@@ -1542,8 +1554,9 @@ __global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint
     f3 dv, dw;
     if (dslot) {   // push hand-off: a sweep leaves each body's deltas in the slots of its first manifold
         const uint32_t fs = first_slot[i];
-        dv = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 0)]) : mk3(0, 0, 0);
-        dw = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 1)]) : mk3(0, 0, 0);
+        // (no slot: no contact touched it - zero deltas - or, mixed schedule, its island was solved on the body records)
+        dv = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 0)]) : from4(B_DV(b, i));
+        dw = fs != 0xFFFFFFFFu ? from4(dslot[dslot_at(fs, 1)]) : from4(B_DW(b, i));
     } else { dv = from4(B_DV(b, i)); dw = from4(B_DW(b, i)); }
     v += dv;
     w += dw;
@@ -1787,7 +1800,7 @@ __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
     for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
         for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
             const uint32_t pt = base + t;
-            const bool valid = pt < a.na;
+            const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
             if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
             const uint32_t p = valid ? pt : a.na - 1;
             const uint32_t key = a.keys_sorted[p];
@@ -2001,6 +2014,7 @@ struct DfPosArgs {
                                     // below the threshold is finished (island_solver.cpp:350-353); a finished island publishes
                                     // no error, so its entry stays 0 and it stays finished - no separate flag pass is needed
     Counters *cnt;
+    const uint8_t *skip;            // mixed schedule: manifolds of islands with joints (k_island_position solves those), else nullptr
 };
 constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
@@ -2019,11 +2033,12 @@ DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) 
 }
 // Seeds the position hand-off chains from the integrated transforms; the side-A lane also copies its manifold's solved
 // impulses back to the contact points (what k_store_impulses does when the position solve runs per colour).
-__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf) {
+__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf, const uint8_t *__restrict__ skip) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= 2 * n_active) return;
     const uint32_t p = slot >> 1, body = (slot & 1u) ? rows.bB[p] : rows.bA[p];
     if (!(slot & 1u)) store_impulses_of(p, rows, rcap, mf);
+    if (skip && skip[p]) return;   // an island with joints: not on the hand-off chains
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
     if ((rows.next[slot] & kHeadBit) && is_dynamic(b.flags[body])) {   // the chain head starts from the integrated transform
         const float4 ps = B_POS(b, body), q = B_ORN(b, body);
@@ -2155,7 +2170,7 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const bool sideB = threadIdx.x & 1u;
     for (uint32_t base = 0; base < a.na; base += a.stride) {
         const uint32_t pt = base + t;
-        const bool valid = pt < a.na;
+        const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
         if (!__any(valid)) continue;
         const uint32_t p = valid ? pt : a.na - 1;
         const uint32_t key = a.keys_sorted[p];
@@ -2181,6 +2196,7 @@ struct IslLists {
     uint32_t *list;     // labels of the islands that have items, in no particular order (islands are independent)
     uint32_t *items;    // phase << 24 | index (joint: position in colour order; manifold: sorted position p), by island
     uint32_t *sorted;   // the same, sorted by phase: only islands beyond the LDS list use it
+    uint32_t *joint;    // [label] != 0: the island has (awake) joints - marked per step by k_prep_joints, cleared by k_finish
 };
 constexpr uint32_t kIslPhaseShift = 24, kIslIdMask = 0xFFFFFFu, kIslContactPhase = 64, kIslPhases = 128;
 constexpr uint32_t kIslLdsItems = 1024;    // an island's phase-sorted list lives in LDS up to this size
@@ -2231,6 +2247,9 @@ __global__ void k_isl_fill(uint32_t nj, uint32_t na, Joints j, JointColours jc, 
     const uint32_t label = t < nj + na ? isl_item_label(t, nj, na, j, rows, b, is_joint, id) : 0xFFFFFFFFu;
     // the counter counts back down to zero: no clearing pass between steps
     const uint32_t before = isl_wave_reserve(label, [&](uint32_t l, uint32_t count) { return atomicSub(&L.cnt[l], count); }, rank);
+    const bool jointed = label != 0xFFFFFFFFu && L.joint[label] != 0;
+    const uint64_t free_lanes = __ballot(label != 0xFFFFFFFFu && !is_joint && !jointed);   // manifolds of islands without joints
+    if (free_lanes && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)free_lanes) - 1)) atomicAdd(&cnt->isl_free, (uint32_t)__popcll(free_lanes));
     if (label == 0xFFFFFFFFu) return;
     uint32_t phase;
     if (is_joint) { phase = 0; while (phase + 1 < jc.n && id >= jc.start[phase + 1]) ++phase; }
@@ -2240,7 +2259,9 @@ __global__ void k_isl_fill(uint32_t nj, uint32_t na, Joints j, JointColours jc, 
     L.items[o + left - 1] = (phase << kIslPhaseShift) | id;
     if (left == 1) {
         L.list[atomicAdd(&cnt->isl_num, 1u)] = label;
-        atomicMax(&cnt->isl_max_items, L.off[label + 1] - o);
+        const uint32_t size = L.off[label + 1] - o;
+        atomicMax(&cnt->isl_max_items, size);
+        if (jointed) atomicMax(&cnt->isl_max_jitems, size);
     }
 }
 // Sorts one island's items by phase (counting sort through LDS) and lists the phases that occur. Returns the list to
@@ -2286,6 +2307,7 @@ struct IslSolveArgs {
     Joints j; Bodies b; Rows rows; Manifolds mf; uint32_t rcap; float4 *rwx;
     uint32_t iters;                 // velocity: iterations after the warm start; position: position iterations
     float *isl_err; uint32_t *isl_done;
+    uint32_t only_jointed;          // mixed schedule: islands without joints belong to the dataflow launch - skip them here
 };
 template <bool WARM>
 DI void isl_velocity_sweep(const IslSolveArgs &a, const IslShared &S, const uint32_t *lst) {
@@ -2359,6 +2381,7 @@ __global__ void __launch_bounds__(64) k_island_velocity(IslSolveArgs a) {
     const uint32_t num = a.cnt->isl_num, t = threadIdx.x;
     for (uint32_t k = blockIdx.x; k < num; k += gridDim.x) {
         const uint32_t label = a.L.list[k], o = a.L.off[label], size = a.L.off[label + 1] - o;
+        if (a.only_jointed && !a.L.joint[label]) continue;
         const uint32_t *lst = isl_sort(S, a.L, o, size);
         bool fast = false;
         uint32_t item = 0, ia = 0, ib = 0, base = 0;
@@ -2393,6 +2416,7 @@ __global__ void __launch_bounds__(64) k_island_position(IslSolveArgs a) {
     const uint32_t num = a.cnt->isl_num, t = threadIdx.x;
     for (uint32_t k = blockIdx.x; k < num; k += gridDim.x) {
         const uint32_t label = a.L.list[k], o = a.L.off[label], size = a.L.off[label + 1] - o;
+        if (a.only_jointed && !a.L.joint[label]) continue;
         const uint32_t *lst = isl_sort(S, a.L, o, size);
         const uint32_t nph = S.nph;
         for (uint32_t it = 0; it < a.iters; ++it) {
@@ -2481,7 +2505,7 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
 // until now), the derived state (AABB, world inertia), the next step's scratch, and the broadphase's question for the next
 // step - has this body left the slack box its candidate list was built for? (Counters::bp_rebuild, see broadphase.hip.)
 __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt,
-                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl) {
+                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
         const int t = threadIdx.x;
@@ -2495,7 +2519,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
     // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
     bool moved = false;
     if (i < n) {
-        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0;
+        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0;
         const uint32_t fl = b.flags[i];
         if (pslot && is_dynamic(fl)) pos_writeback(b, i, pslot, first_slot);
         derive_body(b, i);
@@ -2649,49 +2673,84 @@ int solve(edynhip_ctx *c) {
     rec(c, 4);
     const uint32_t na = c->num_active, nc = c->num_colours;
     const Joints &j = c->j;
-    if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt);
+    if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt, c->isl_joint);
     if (j.n && c->has_generic) hipLaunchKernelGGL(k_prep_generic, dim3(blocks(j.n, 64)), dim3(64), 0, s, j, c->b, dt);
+    // Contact-only scenes: the whole velocity solve as one dataflow launch (see k_contact_solve_df).
+    if (c->df_mode < 0) {
+        c->df_mode = 0;
+        const char *env = getenv("EDYNHIP_DATAFLOW");
+        int per_cu = 0, ncu = 0, coop = 0;
+        if (!(env && env[0] == '0') &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contact_solve_df, kDfBlock, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
+            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
+            c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
+            int per_cu2 = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_contact_solve_df2, 64, 0) == hipSuccess && per_cu2 > 0)
+                c->df2_waves = (uint32_t)per_cu2 * (uint32_t)ncu;
+            int per_cu_p = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
+                c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
+            c->df_mode = 1;
+        }
+        (void)hipGetLastError();
+    }
     // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
     // a non-empty serial bucket (a body with more than 62 coloured contacts) also needs the per-colour schedule
     const bool serial = nc == kSerialColour + 1 && c->colour_end[kSerialColour] > c->colour_start[kSerialColour];
     const uint32_t nc_par = serial ? kSerialColour : nc;   // colours solved in parallel
-    const bool push = j.n == 0 && na > 0 && !c->extras && !serial;
+    // Schedules. Contact-only scene: one dataflow launch (push hand-offs). With joints (or contact_extras rows): the constraints are
+    // bucketed by island every step, and the statistics of the PREVIOUS step's bucketing (they arrive with the counters this step
+    // fetched anyway) choose: "mixed" - islands with joints go to the island-fused kernels, the (many) manifolds of islands without
+    // joints stay on the dataflow launch: a pile next to a rag doll keeps its fast path; "fused" - every island is small: one wave per
+    // island; else one launch per colour.
+    static const bool isl_env = !(getenv("EDYNHIP_ISLAND_FUSED") && getenv("EDYNHIP_ISLAND_FUSED")[0] == '0');
+    static const bool mixed_env = !(getenv("EDYNHIP_MIXED") && getenv("EDYNHIP_MIXED")[0] == '0');
+    const IslLists isl{c->isl_cnt, c->isl_off, c->isl_list, c->isl_items, c->isl_sorted, c->isl_joint};
+    const bool contacts_only = j.n == 0 && !c->extras;
+    const bool isl_candidate = isl_env && !contacts_only && !serial && (na + j.n) > 0 && (size_t)na + j.n < kIslIdMask;
+    uint32_t largest = 0xFFFFFFFFu, largest_jointed = 0xFFFFFFFFu, free_manifolds = 0;
+    if (isl_candidate) {
+        const bool fetched = c->last_fetch_step == c->step_index;   // this step's counters were read after the previous step's fill
+        if (fetched && c->isl_prep_step + 1 == c->step_index) {
+            largest = c->cnt_host->isl_max_items; largest_jointed = c->cnt_host->isl_max_jitems; free_manifolds = c->cnt_host->isl_free;
+        } else if (!fetched && c->isl_cache_epoch == c->topology_epoch) {
+            largest = c->isl_cache_max; largest_jointed = c->isl_cache_jmax; free_manifolds = c->isl_cache_free;
+        }
+    }
+    constexpr uint32_t kMixedMinFree = 1024;   // manifolds outside jointed islands that make the dataflow launch worth its fixed cost
+    const bool mixed = isl_candidate && mixed_env && j.n > 0 && !c->extras && na > 0 && c->df_mode == 1 && c->cfg.num_position_iterations <= kMaxDfPosIters &&
+                       free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit;
+    const bool push = na > 0 && !serial && (contacts_only || mixed);
     if (na) {
         if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
         else hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
     }
-    if (push) {
-        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used);
-    }
-    // island-fused schedule (k_island_velocity / k_island_position): bucket this step's constraints by island, and use the
-    // fused launches if the largest island of the PREVIOUS step (the value this step's counter fetch brought) is small enough
-    static const bool isl_env = !(getenv("EDYNHIP_ISLAND_FUSED") && getenv("EDYNHIP_ISLAND_FUSED")[0] == '0');
-    const bool isl_candidate = isl_env && !push && !serial && (na + j.n) > 0 && (size_t)na + j.n < kIslIdMask;
-    const IslLists isl{c->isl_cnt, c->isl_off, c->isl_list, c->isl_items, c->isl_sorted};
     bool isl_fused = false;
     if (isl_candidate) {
         JointColours jc{};
         jc.n = j.num_colours;
         for (uint32_t k = 0; k <= j.num_colours && k <= kMaxColours; ++k) jc.start[k] = j.colour_start[k];
-        EH_HIP(c, hipMemsetAsync(&c->cnt->isl_num, 0, 2 * sizeof(uint32_t), s));   // isl_num, isl_max_items
+        EH_HIP(c, hipMemsetAsync(&c->cnt->isl_num, 0, 4 * sizeof(uint32_t), s));   // isl_num, isl_max_items, isl_max_jitems, isl_free
         hipLaunchKernelGGL(k_isl_count, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, c->rows, c->b, isl);
         EH_TRY(scan_u32(c, c->isl_cnt, c->isl_off, n + 1));
         hipLaunchKernelGGL(k_isl_fill, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, jc, c->rows, c->col_keys_sorted, c->b, isl, c->cnt);
-        uint32_t largest = 0xFFFFFFFFu;
-        const bool fetched = c->last_fetch_step == c->step_index;   // this step's counters were read after the previous step's fill
-        if (fetched && c->isl_prep_step + 1 == c->step_index) largest = c->cnt_host->isl_max_items;
-        else if (!fetched && c->isl_cache_epoch == c->topology_epoch) largest = c->isl_cache_max;
-        else if (!fetched) {
+        if (largest == 0xFFFFFFFFu && c->last_fetch_step != c->step_index) {
             // no contacts and nothing with a shape: the step reads no counters at all and the islands are those of the
-            // joints, fixed until the scene is edited - read this step's value once and keep it
+            // joints, fixed until the scene is edited - read this step's values once and keep them
             EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
             largest = c->isl_cache_max = c->cnt_host->isl_max_items;
+            c->isl_cache_jmax = c->cnt_host->isl_max_jitems; c->isl_cache_free = c->cnt_host->isl_free;
             c->isl_cache_epoch = c->topology_epoch;
         }
         c->isl_prep_step = c->step_index;
-        isl_fused = largest <= kIslFusedLimit;
+        isl_fused = !mixed && largest <= kIslFusedLimit;
     }
-    IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done};
+    if (push) {
+        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr);
+    }
+    const uint8_t *df_skip = mixed ? c->rows.skip : nullptr;
+    IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done, mixed ? 1u : 0u};
     constexpr uint32_t kIslGrid = 4096;   // one wave each; a block takes islands blockIdx.x, + kIslGrid, ...
     rec(c, 5);
     uint32_t launches = 0;
@@ -2753,26 +2812,6 @@ int solve(edynhip_ctx *c) {
             ++launches;
         }
     };
-    // Contact-only scenes: the whole velocity solve as one dataflow launch (see k_contact_solve_df).
-    if (c->df_mode < 0) {
-        c->df_mode = 0;
-        const char *env = getenv("EDYNHIP_DATAFLOW");
-        int per_cu = 0, ncu = 0, coop = 0;
-        if (!(env && env[0] == '0') &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contact_solve_df, kDfBlock, 0) == hipSuccess &&
-            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
-            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
-            c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
-            int per_cu2 = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_contact_solve_df2, 64, 0) == hipSuccess && per_cu2 > 0)
-                c->df2_waves = (uint32_t)per_cu2 * (uint32_t)ncu;
-            int per_cu_p = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
-                c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
-            c->df_mode = 1;
-        }
-        (void)hipGetLastError();
-    }
     bool df_velocity = false;
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
@@ -2787,7 +2826,7 @@ int solve(edynhip_ctx *c) {
         const uint32_t per_wave = two_lane ? 32u : 64u;
         const uint32_t want_waves = env_waves ? env_waves : std::max(two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
         const uint32_t grid = std::min(blocks(na, per_wave), std::min(two_lane ? c->df2_waves : c->df_lanes, want_waves));
-        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr};
+        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
@@ -2808,6 +2847,9 @@ int solve(edynhip_ctx *c) {
         } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
             (void)hipGetLastError();
             c->df_mode = 0;
+            // the mixed schedule has no per-colour form for THIS step (the chains skip the jointed islands): give the step up,
+            // the next one takes the per-colour launches
+            if (mixed) return set_error(c, EDYNHIP_ERR_INTERNAL, "solve: the runtime refused the resident launch of the mixed schedule");
         }
         if (tracing && df_velocity) {
             std::vector<uint64_t> tr(trace_words); std::vector<uint32_t> keys(na);
@@ -2821,7 +2863,7 @@ int solve(edynhip_ctx *c) {
             (void)hipFree(a.trace);
         } else if (tracing) (void)hipFree(a.trace);
     }
-    if (!df_velocity && isl_fused) {
+    if ((!df_velocity && isl_fused) || (df_velocity && mixed)) {   // mixed: the islands with joints, beside the dataflow launch
         isl_args.iters = c->cfg.num_velocity_iterations;
         hipLaunchKernelGGL(k_island_velocity, dim3(kIslGrid), dim3(64), 0, s, isl_args);
         ++launches;
@@ -2862,12 +2904,12 @@ int solve(edynhip_ctx *c) {
     if (pos_df) {
         static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
-        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf);
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip);
         const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
-                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt};
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip};
             void *params[] = {&a};
             if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
@@ -2876,8 +2918,15 @@ int solve(edynhip_ctx *c) {
             }
         }
         // the bodies' transforms live in the hand-off slots while the dataflow launches run; k_finish picks them up
-        if (it == P) final_pslot = r.pslot;
-        else {   // a cooperative launch was refused: finish per colour (rare; never on an exclusive device)
+        if (it == P) {
+            final_pslot = r.pslot;
+            if (mixed) {   // the islands with joints, on the body records
+                isl_args.iters = P;
+                hipLaunchKernelGGL(k_island_position, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+            }
+        } else if (mixed) {
+            return set_error(c, EDYNHIP_ERR_INTERNAL, "solve: the runtime refused the resident launch of the mixed schedule (position)");
+        } else {   // a cooperative launch was refused: finish per colour (rare; never on an exclusive device)
             hipLaunchKernelGGL(k_pos_writeback, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, r.pslot, r.first_slot);
             if (it > 0) hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->pos_err + (size_t)(it - 1) * c->b.cap, c->isl_done);
             pos_per_colour(it);
@@ -2890,7 +2939,7 @@ int solve(edynhip_ctx *c) {
     }
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt,
-                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max});
+                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max}, c->isl_joint);
     rec(c, 9);
     ++c->step_index;
     EH_HIP(c, hipGetLastError());

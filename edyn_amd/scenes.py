@@ -263,6 +263,23 @@ def figures(template, nx, nz, pitch=2.2, hip_height=1.25, tumble=0.5, floor=True
     return s
 
 
+def merge(first, second):
+    """The bodies of `second` (e.g. figures(..., floor=False)) appended to `first`: joint, definition and exclusion indices shifted."""
+    n = len(first["kind"])
+    out = {}
+    for k, v in first.items():
+        if isinstance(v, np.ndarray) and len(v) == n and k in second:
+            out[k] = np.concatenate([v, second[k]], axis=0)
+    shift = lambda t: (t[0], t[1] + n, t[2] + n) + tuple(t[3:])
+    nj = len(first.get("joints") or [])
+    out["joints"] = list(first.get("joints") or []) + [shift(t) for t in second.get("joints", [])]
+    out["hinge_params"] = list(first.get("hinge_params", [])) + [(j + nj, p) for j, p in second.get("hinge_params", [])]
+    out["joint_defs"] = list(first.get("joint_defs", [])) + [(j + nj, fa, fb, p) for j, fa, fb, p in second.get("joint_defs", [])]
+    ex = [first["exclusions"]] if "exclusions" in first else []
+    out["exclusions"] = np.concatenate(ex + [second.get("exclusions", np.zeros((0, 2), np.uint32)) + np.uint32(n)])
+    return out
+
+
 def apply_figure_settings(world, scene):
     """What a figure scene needs after its bodies and joints are uploaded (any of the three world classes)."""
     for j, p in scene.get("hinge_params", []):

@@ -1283,3 +1283,30 @@ def test_joint_redefinition_is_applied_lazily_but_in_call_order():
             assert_state_equal(g, o)
             assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), s
     assert np.isfinite(g.get_state()[0]).all()
+
+
+def test_pile_beside_ragdolls_takes_the_mixed_schedule_bit_exact():
+    """A 1 152-box pile (one island, no joints) beside six of the reference's rag dolls: the dataflow launch keeps the pile - its
+    hand-off chains skip the manifolds of islands with joints - while the island-fused kernels solve the figures on the body
+    records, both in the same step (the "mixed" schedule; without it one joint anywhere put the whole scene on one launch per
+    colour and sweep). Pairs, manifolds, state and applied impulses against the oracle; the launch count shows the schedule."""
+    pile = scenes.box_pile(12, 8, 12)
+    figs = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 3, 2, pitch=1.6, floor=False)
+    figs["pos"][:, 0] += np.float32(25.0)
+    sc = scenes.merge(pile, figs)
+    g = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, timing=True))
+    g.set_scene(sc)
+    o = oracle_world(sc)
+    scenes.apply_figure_settings(g, sc); scenes.apply_figure_settings(o, sc)
+    launches = []
+    for step in range(1, 121):
+        g.step_simulation(1); o.step(1)
+        launches.append(g.get_timings()["solve_velocity_launches"])
+        if step % 20 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="pile beside rag dolls")
+    assert launches[0] > 20 and max(launches[5:]) == 2, launches[:8]     # first steps per colour, then: dataflow + island-fused
+    ji = g.get_joint_impulses()
+    assert np.isfinite(g.get_state()[0]).all() and np.abs(ji).max() > 0 and g.get_stats()["num_islands"] >= 2
