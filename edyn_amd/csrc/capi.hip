@@ -465,7 +465,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 6; }   // 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 7; }   // 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1107,6 +1107,13 @@ int edynhip_wake_all(edynhip_ctx *c) {
     hipLaunchKernelGGL(k_wake_all, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b.flags, c->sleep_since);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
+}
+int edynhip_wake_bodies(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
+    if (!c || (n && !indices)) return EDYNHIP_ERR_INVALID;
+    for (uint32_t k = 0; k < n; ++k) if (indices[k] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_wake_bodies: index out of range");
+    if (n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    return wake_islands_of(c, std::vector<uint32_t>(indices, indices + n));
 }
 int edynhip_get_asleep(edynhip_ctx *c, uint8_t *asleep) {
     if (!c || !asleep) return EDYNHIP_ERR_INVALID;

@@ -484,6 +484,11 @@ class World:
     def wake_all(self):
         self._check(self._L.edynhip_wake_all(self._h))
 
+    def wake_bodies(self, indices):
+        """edyn::wake_up_entity for the listed bodies: wakes their islands."""
+        idx = np.ascontiguousarray(indices, np.uint32)
+        self._check(self._L.edynhip_wake_bodies(self._h, len(idx), _ptr(idx)))
+
     def get_timings(self):
         t = _capi.Timings()
         self._check(self._L.edynhip_get_timings(self._h, C.byref(t)))

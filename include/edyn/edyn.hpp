@@ -210,6 +210,8 @@ struct gpu_stepper {
     void (*post_step)(entt::registry &){nullptr};
     struct mixing { uint32_t id0, id1; float v[6]; };
     std::vector<mixing> mixings;   // insert_material_mixing calls, replayed into a (re)created context
+    bool refresh_friction{false};  // set_rigidbody_friction: the carried contact points take the bodies' current materials (rigidbody.cpp:324-350)
+    bool recreate{false};          // a body's mass / inertia / material was edited: the next upload re-creates the context (contacts, joints and sleep state are carried)
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
@@ -286,12 +288,26 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     const uint32_t nj = (uint32_t)s.constraints.size();
     std::vector<edynhip_manifold> carried;   // contact state carried over a capacity growth (indices are stable)
     bool regrown = false;
-    if (!s.ctx || total > s.capacity || nj > s.joint_capacity) {
+    if (!s.ctx || total > s.capacity || nj > s.joint_capacity || s.recreate) {
+        s.recreate = false;
         if (s.ctx) {
             uint32_t m = 0;
             check(s, edynhip_num_manifolds(s.ctx, &m));
             carried.resize(m);
             if (m) check(s, edynhip_get_manifolds(s.ctx, carried.data(), m, &m));
+            if (s.refresh_friction) {   // set_rigidbody_friction: existing points take the mixed friction of the current materials, except
+                for (auto &rec : carried) {   // pairs combined through the material mix table (rigidbody.cpp:324-350)
+                    const entt::entity ea = s.bodies[rec.body[0]], eb = s.bodies[rec.body[1]];
+                    if (ea == entt::null || eb == entt::null) continue;
+                    const material *ma = registry.try_get<material>(ea), *mb = registry.try_get<material>(eb);
+                    if (!ma || !mb) continue;
+                    bool tabled = false;
+                    for (auto &mx : s.mixings) tabled = tabled || (mx.id0 == ma->id && mx.id1 == mb->id) || (mx.id0 == mb->id && mx.id1 == ma->id);
+                    if (tabled) continue;
+                    for (uint32_t k = 0; k < rec.num_points; ++k) rec.pt[k].friction = std::sqrt(ma->friction * mb->friction);
+                }
+                s.refresh_friction = false;
+            }
             edynhip_destroy(s.ctx); s.ctx = nullptr;
             regrown = true;
             s.contacts_resync = true; s.snapshot_pending = false;
@@ -839,6 +855,124 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
     registry.remove<detail::body_index>(entity);   // the stepper drops the body from the device world at the next update
+}
+
+// ---- util/rigidbody.hpp:105-260: edits of a body between updates. Velocity / transform edits go to the device with the next update
+// (they mark the state dirty like edyn::refresh); mass / inertia / friction edits re-create the device context at the next update,
+// carrying contacts (warm-start impulses), joints and sleep state over - rare operations, kept simple.
+namespace detail {
+inline matrix3x3 mat_mul(const matrix3x3 &a, const matrix3x3 &b) {
+    matrix3x3 r{};
+    auto el = [](const vector3 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; };
+    for (int i = 0; i < 3; ++i) {
+        scalar o[3];
+        for (int k = 0; k < 3; ++k) o[k] = el(a.row[i], 0) * el(b.row[0], k) + el(a.row[i], 1) * el(b.row[1], k) + el(a.row[i], 2) * el(b.row[2], k);
+        r.row[i] = {o[0], o[1], o[2]};
+    }
+    return r;
+}
+inline matrix3x3 transposed(const matrix3x3 &m) { return {{vector3{m.row[0].x, m.row[1].x, m.row[2].x}, vector3{m.row[0].y, m.row[1].y, m.row[2].y}, vector3{m.row[0].z, m.row[1].z, m.row[2].z}}}; }
+inline matrix3x3 rotation_matrix(const quaternion &q) {   // math/quaternion.hpp to_matrix3x3
+    const scalar d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = scalar(2) / d;
+    const scalar xs = q.x * s, ys = q.y * s, zs = q.z * s, wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    const scalar xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    return {{vector3{1 - (yy + zz), xy - wz, xz + wy}, vector3{xy + wz, 1 - (xx + zz), yz - wx}, vector3{xz - wy, yz + wx, 1 - (xx + yy)}}};
+}
+// inverse inertia tensor in world space of a dynamic body (zero for the others): the user's inertia component, or the solid
+// shape's (moment_of_inertia.cpp - the capsule as the reference computes it, see capi.hip k_init_bodies)
+inline matrix3x3 inertia_world_inv_of(entt::registry &registry, entt::entity e) {
+    matrix3x3 zero{};
+    if (!registry.all_of<dynamic_tag>(e)) return zero;
+    const scalar m = registry.get<mass>(e).s;
+    matrix3x3 I{};
+    if (auto *in = registry.try_get<inertia>(e)) I = *in;
+    else {
+        vector3 d{large_scalar, large_scalar, large_scalar};
+        if (auto *b = registry.try_get<box_shape>(e)) {
+            const vector3 x{b->half_extents.x * 2, b->half_extents.y * 2, b->half_extents.z * 2};
+            const scalar k = scalar(1) / scalar(12) * m;
+            d = {k * (x.y * x.y + x.z * x.z), k * (x.z * x.z + x.x * x.x), k * (x.x * x.x + x.y * x.y)};
+        } else if (auto *sp = registry.try_get<sphere_shape>(e)) {
+            const scalar v = scalar(0.4) * m * sp->radius * sp->radius; d = {v, v, v};
+        } else if (auto *c = registry.try_get<capsule_shape>(e)) {
+            const scalar pi = scalar(3.1415926535897932384626433832795029), len = c->half_length * 2, r = c->radius;
+            const scalar cv = pi * r * r * len, sv = pi * r * r * r * scalar(4) / scalar(3), cm = m * cv / (cv + sv), sm = m * sv / (cv + sv);
+            const scalar cxx = scalar(0.5) * cm * r * r, cyy = scalar(1) / scalar(12) * cm * (scalar(3) * r * r + len * len), si = scalar(0.4) * sm * r * r;
+            const int ax = (int)c->axis;
+            const scalar cyl_x = ax == 0 ? cxx : cyy, cyl_y = ax == 1 ? cxx : cyy, tt = scalar(4) * len + scalar(3) * r;
+            const scalar xx = si + cyl_x, yy = si + sm * tt * tt / scalar(64) + cyl_y;
+            d = {ax == 0 ? xx : yy, ax == 1 ? xx : yy, ax == 2 ? xx : yy};
+        }
+        I = {{vector3{d.x, 0, 0}, vector3{0, d.y, 0}, vector3{0, 0, d.z}}};
+    }
+    // inverse_matrix_symmetric (matrix3x3.hpp:190-218)
+    const vector3 &r0 = I.row[0], &r1 = I.row[1], &r2 = I.row[2];
+    const scalar det = r0.x * (r1.y * r2.z - r1.z * r2.y) + r0.y * (r1.z * r2.x - r1.x * r2.z) + r0.z * (r1.x * r2.y - r1.y * r2.x), di = scalar(1) / det;
+    const scalar a11 = r0.x, a12 = r0.y, a13 = r0.z, a22 = r1.y, a23 = r1.z, a33 = r2.z;
+    const scalar i11 = di * (a22 * a33 - a23 * a23), i12 = di * (a13 * a23 - a12 * a33), i13 = di * (a12 * a23 - a13 * a22);
+    const scalar i22 = di * (a11 * a33 - a13 * a13), i23 = di * (a12 * a13 - a11 * a23), i33 = di * (a11 * a22 - a12 * a12);
+    const matrix3x3 inv{{vector3{i11, i12, i13}, vector3{i12, i22, i23}, vector3{i13, i23, i33}}};
+    const matrix3x3 basis = rotation_matrix(registry.get<orientation>(e));
+    return mat_mul(mat_mul(basis, inv), transposed(basis));   // update_inertias.cpp:12-24
+}
+inline vector3 mat_vec(const matrix3x3 &m, const vector3 &v) {
+    return {m.row[0].x * v.x + m.row[0].y * v.y + m.row[0].z * v.z, m.row[1].x * v.x + m.row[1].y * v.y + m.row[1].z * v.z, m.row[2].x * v.x + m.row[2].y * v.y + m.row[2].z * v.z};
+}
+}  // namespace detail
+/// rigidbody.cpp:228-246
+inline void rigidbody_apply_impulse(entt::registry &registry, entt::entity entity, const vector3 &impulse, const vector3 &rel_location) {
+    if (!registry.all_of<dynamic_tag>(entity)) return;
+    const scalar m_inv = registry.get<mass_inv>(entity).s;
+    auto &v = registry.get<linvel>(entity); auto &w = registry.get<angvel>(entity);
+    v.x += impulse.x * m_inv; v.y += impulse.y * m_inv; v.z += impulse.z * m_inv;
+    const vector3 t{rel_location.y * impulse.z - rel_location.z * impulse.y, rel_location.z * impulse.x - rel_location.x * impulse.z, rel_location.x * impulse.y - rel_location.y * impulse.x};
+    const vector3 dw = detail::mat_vec(detail::inertia_world_inv_of(registry, entity), t);
+    w.x += dw.x; w.y += dw.y; w.z += dw.z;
+    registry.ctx().get<detail::gpu_stepper>().state_dirty = true;
+}
+inline void rigidbody_apply_torque_impulse(entt::registry &registry, entt::entity entity, const vector3 &torque_impulse) {
+    if (!registry.all_of<dynamic_tag>(entity)) return;
+    auto &w = registry.get<angvel>(entity);
+    const vector3 dw = detail::mat_vec(detail::inertia_world_inv_of(registry, entity), torque_impulse);
+    w.x += dw.x; w.y += dw.y; w.z += dw.z;
+    registry.ctx().get<detail::gpu_stepper>().state_dirty = true;
+}
+/// rigidbody.cpp:248-290: a kinematic body is moved by giving it the velocity that takes it there in `dt`
+inline void set_kinematic_position(entt::registry &registry, entt::entity entity, const vector3 &pos, scalar dt) {
+    auto &cur = registry.get<position>(entity); auto &vel = registry.get<linvel>(entity);
+    vel.x = (pos.x - cur.x) / dt; vel.y = (pos.y - cur.y) / dt; vel.z = (pos.z - cur.z) / dt;
+    cur.x = pos.x; cur.y = pos.y; cur.z = pos.z;
+    registry.ctx().get<detail::gpu_stepper>().state_dirty = true;
+}
+inline void set_kinematic_orientation(entt::registry &registry, entt::entity entity, const quaternion &orn, scalar dt) {
+    auto &cur = registry.get<orientation>(entity); auto &vel = registry.get<angvel>(entity);
+    const quaternion c{-cur.x, -cur.y, -cur.z, cur.w};   // r = orn * conjugate(cur): the rotation from the current orientation to the new one
+    const quaternion r{orn.w * c.x + orn.x * c.w + orn.y * c.z - orn.z * c.y, orn.w * c.y - orn.x * c.z + orn.y * c.w + orn.z * c.x,
+                       orn.w * c.z + orn.x * c.y - orn.y * c.x + orn.z * c.w, orn.w * c.w - orn.x * c.x - orn.y * c.y - orn.z * c.z};
+    const scalar ws = std::acos(r.w) / (scalar(0.5) * dt);   // the inverse of quaternion integrate (math/quaternion.cpp:7-22)
+    const scalar t = ws < scalar(0.001) ? scalar(0.5) * dt - dt * dt * dt * (scalar(1) / scalar(48)) * ws * ws : std::sin(scalar(0.5) * ws * dt) / ws;
+    vel.x = r.x / t; vel.y = r.y / t; vel.z = r.z / t;
+    cur.x = orn.x; cur.y = orn.y; cur.z = orn.z; cur.w = orn.w;
+    registry.ctx().get<detail::gpu_stepper>().state_dirty = true;
+}
+/// rigidbody.cpp:301-352
+inline void set_rigidbody_mass(entt::registry &registry, entt::entity entity, scalar m) {
+    registry.get<mass>(entity).s = m; registry.get<mass_inv>(entity).s = scalar(1) / m;
+    auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
+}
+inline void set_rigidbody_inertia(entt::registry &registry, entt::entity entity, const matrix3x3 &I) {
+    registry.emplace_or_replace<inertia>(entity, inertia{I});
+    auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
+}
+inline void set_rigidbody_friction(entt::registry &registry, entt::entity entity, scalar friction) {   // (existing contact points take the new value with the re-created context)
+    registry.get<material>(entity).friction = friction;
+    auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = s.refresh_friction = true;
+}
+/// rigidbody.cpp:409-415 -> island_manager wake_up_island
+inline void wake_up_entity(entt::registry &registry, entt::entity entity) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    if (auto *bi = registry.try_get<detail::body_index>(entity); bi && s.ctx && bi->value < s.uploaded_bodies && !s.scene_dirty)
+        detail::check(s, edynhip_wake_bodies(s.ctx, 1, &bi->value));
 }
 
 /// edyn::insert_material_mixing (util/insert_material_mixing.hpp:17): the material of contacts between bodies whose materials carry

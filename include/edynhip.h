@@ -321,6 +321,8 @@ int edynhip_debug_collide(edynhip_ctx *ctx, uint32_t n, const int32_t *shape_typ
  * everything (also implied by edynhip_set_state). island_manager.cpp:541-565, util/island_util.cpp:61-66. */
 int edynhip_get_asleep(edynhip_ctx *ctx, uint8_t *asleep);
 int edynhip_wake_all(edynhip_ctx *ctx);
+/* wake_up_entity (util/rigidbody.cpp:409-415 -> island_manager.cpp wake_up_island): wakes the islands of the listed bodies. */
+int edynhip_wake_bodies(edynhip_ctx *ctx, uint32_t n, const uint32_t *indices);
 
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);

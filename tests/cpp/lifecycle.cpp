@@ -115,6 +115,60 @@ int main() {
     edyn::set_pre_step_callback(registry, nullptr);
     edyn::set_post_step_callback(registry, nullptr);
 
+    // edits of a body between updates (util/rigidbody.hpp:105-260)
+    {
+        auto bdef = edyn::rigidbody_def{};
+        bdef.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}};
+        bdef.position = {20, 0.5f, 0};
+        const entt::entity puck = edyn::make_rigidbody(registry, bdef);   // sleeping enabled
+        run(30);
+        // an impulse through the centre of mass: dv = J / m; a torque impulse about y: dw = I^-1 L with I = m/6 for the unit cube
+        edyn::rigidbody_apply_impulse(registry, puck, {0, 3, 0}, {0, 0, 0});
+        CHECK(std::fabs(registry.get<edyn::linvel>(puck).y - 3.0f) < 1e-5f);
+        edyn::rigidbody_apply_torque_impulse(registry, puck, {0, 0.5f, 0});
+        CHECK(std::fabs(registry.get<edyn::angvel>(puck).y - 3.0f) < 1e-4f);
+        run(10);
+        CHECK(registry.get<edyn::position>(puck).y > 0.8f);                    // it took off ...
+        CHECK(std::fabs(registry.get<edyn::angvel>(puck).y - 3.0f) < 0.05f);   // ... spinning
+        run(240);   // lands, settles and falls asleep (the stack has sleeping disabled, this body not)
+        CHECK(std::fabs(registry.get<edyn::position>(puck).y - 0.5f) < 2e-2f);
+        CHECK(registry.all_of<edyn::sleeping_tag>(puck));
+        edyn::wake_up_entity(registry, puck);
+        run(1);
+        CHECK(!registry.all_of<edyn::sleeping_tag>(puck));
+        // a heavier body presses harder on the floor: the normal impulses follow the new mass, the contact itself survives the edit
+        edyn::set_rigidbody_mass(registry, puck, 4.0f);
+        run(30);
+        float weight = 0;
+        {
+            auto &s = registry.ctx().get<edyn::detail::gpu_stepper>();
+            uint32_t nm = 0; edynhip_num_manifolds(s.ctx, &nm);
+            std::vector<edynhip_manifold> recs(nm); edynhip_get_manifolds(s.ctx, recs.data(), nm, &nm);
+            const uint32_t pi = registry.get<edyn::detail::body_index>(puck).value;
+            for (auto &r : recs) if (r.body[0] == pi || r.body[1] == pi) for (uint32_t k = 0; k < r.num_points; ++k) weight += r.pt[k].normal_impulse;
+        }
+        CHECK(std::fabs(weight - 4.0f * 9.8f / 60.0f) < 0.02f);
+        // friction: pushed sideways with mu = 0.5 it stops within a metre; on ice (mu = 0) it keeps going
+        edyn::set_rigidbody_friction(registry, puck, 0.0f);
+        run(2);
+        edyn::rigidbody_apply_impulse(registry, puck, {8, 0, 0}, {0, 0, 0});   // 2 m/s
+        run(60);
+        CHECK(registry.get<edyn::position>(puck).x > 21.8f && std::fabs(registry.get<edyn::linvel>(puck).x - 2.0f) < 0.05f);
+        // a kinematic platform moved by the user: its velocity is what takes it there in dt
+        auto kdef = edyn::rigidbody_def{};
+        kdef.kind = edyn::rigidbody_kind::rb_kinematic;
+        kdef.shape = edyn::box_shape{{1, 0.1f, 1}};
+        kdef.position = {40, 1, 0};
+        const entt::entity lift = edyn::make_rigidbody(registry, kdef);
+        run(1);
+        edyn::set_kinematic_position(registry, lift, {40, 1.5f, 0}, 0.5f);
+        CHECK(std::fabs(registry.get<edyn::linvel>(lift).y - 1.0f) < 1e-6f && registry.get<edyn::position>(lift).y == 1.5f);
+        const float h = 0.5f * 0.3f;
+        edyn::set_kinematic_orientation(registry, lift, {0, std::sin(h), 0, std::cos(h)}, 0.1f);   // 0.3 rad in 0.1 s
+        CHECK(std::fabs(registry.get<edyn::angvel>(lift).y - 3.0f) < 1e-3f);
+        run(2);
+    }
+
     // update(registry) without a time: the monotonic clock drives the accumulator
     edyn::update(registry);
     edyn::update(registry);
