@@ -206,6 +206,7 @@ struct gpu_stepper {
     unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
     std::unordered_map<uint64_t, entt::entity> manifold_entities;   // (body index A << 32 | body index B) -> contact_manifold entity
     std::unordered_map<uint64_t, entt::entity> point_entities;      // device point id -> contact_point entity
+    double (*time_func)(){nullptr};                 // settings.time_func (edyn::set_time_source); nullptr = the monotonic clock
     void (*pre_step)(entt::registry &){nullptr};    // settings.pre_step_callback / post_step_callback (context/step_callback.hpp)
     void (*post_step)(entt::registry &){nullptr};
     struct mixing { uint32_t id0, id1; float v[6]; };
@@ -701,6 +702,8 @@ inline void detach(entt::registry &registry) { registry.ctx().erase<detail::gpu_
 inline scalar get_fixed_dt(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.fixed_dt; }
 inline void set_fixed_dt(entt::registry &registry, scalar dt) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.fixed_dt = dt; s.params_dirty = true; }
 inline void set_max_steps_per_update(entt::registry &registry, unsigned n) { registry.ctx().get<detail::gpu_stepper>().cfg.max_steps_per_update = n; }
+inline unsigned get_max_steps_per_update(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.max_steps_per_update; }
+inline execution_mode get_execution_mode(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.execution_mode; }
 inline bool is_paused(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().paused; }
 inline void set_paused(entt::registry &registry, bool paused) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.paused = paused; s.accumulated = 0; }
 inline vector3 get_gravity(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.gravity; }
@@ -750,9 +753,14 @@ inline double performance_time() {   // time/time.hpp performance_time(): second
 }
 }  // namespace detail
 /// edyn::update(registry) (edyn.hpp:124, edyn.cpp:234-238): the time comes from settings.time_func (a monotonic clock).
+inline double get_time(entt::registry &registry) {   // edyn.hpp:171, edyn.cpp:289-293
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    return s.time_func ? s.time_func() : detail::performance_time();
+}
+inline void set_time_source(entt::registry &registry, double (*time_func)(void)) { registry.ctx().get<detail::gpu_stepper>().time_func = time_func; }   // edyn.hpp:164
 inline void update(entt::registry &registry) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
-    const double now = detail::performance_time();
+    const double now = get_time(registry);
     if (s.last_time == 0 && s.accumulated == 0) s.last_time = now;   // attach() stamps the stepper with the current time
     update(registry, now);
 }
@@ -763,7 +771,7 @@ inline void step_simulation(entt::registry &registry, double time) {
     detail::run_steps(registry, s, 1, true, time, s.cfg.fixed_dt);
 }
 /// edyn::step_simulation(registry) (edyn.hpp:142).
-inline void step_simulation(entt::registry &registry) { step_simulation(registry, detail::performance_time()); }
+inline void step_simulation(entt::registry &registry) { step_simulation(registry, get_time(registry)); }
 
 // ---- util/rigidbody.hpp:84-93, rigidbody.cpp:47-191
 inline void make_rigidbody(entt::entity entity, entt::registry &registry, const rigidbody_def &def) {

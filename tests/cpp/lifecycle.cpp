@@ -169,9 +169,13 @@ int main() {
         run(2);
     }
 
-    // update(registry) without a time: the monotonic clock drives the accumulator
+    // update(registry) without a time: the monotonic clock drives the accumulator - or the user's time source
     edyn::update(registry);
     edyn::update(registry);
+    static double fake_now = 1000.0;
+    edyn::set_time_source(registry, [] { return fake_now; });
+    CHECK(edyn::get_time(registry) == 1000.0);
+    CHECK(edyn::get_execution_mode(registry) == edyn::execution_mode::sequential && edyn::get_max_steps_per_update(registry) >= 1);
     edyn::detach(registry);
     std::printf(failures == 0 ? "LIFECYCLE_OK\n" : "LIFECYCLE_FAIL\n");
     return failures == 0 ? 0 : 1;
