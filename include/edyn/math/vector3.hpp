@@ -1,0 +1,6 @@
+// Forwarding header of the MI355X stepper shim: the reference splits its API over many headers, the shim keeps it in one.
+// Code that includes <edyn/math/vector3.hpp> (as code written against the reference does) gets the shim's declarations.
+#ifndef EDYN_HIP_FWD_MATH_VECTOR3_HPP
+#define EDYN_HIP_FWD_MATH_VECTOR3_HPP
+#include <edyn/edyn.hpp>
+#endif

@@ -14,6 +14,14 @@ def test_shim_compiles_and_links():
     assert os.path.exists(os.path.join(CPP, "hello_world")) and os.path.exists(os.path.join(CPP, "lifecycle"))
 
 
+def test_reference_include_paths_resolve_to_the_shim():
+    """Code written against the reference includes <edyn/comp/...>, <edyn/constraints/...>, <edyn/util/...> piecemeal: the shim ships
+    forwarding headers for those paths (tests/cpp/includes.cpp builds and creates bodies / a constraint without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "includes"])
+    out = subprocess.run([os.path.join(CPP, "includes")], capture_output=True, text=True, timeout=60)
+    assert "INCLUDES_OK 1" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_shim_hello_world_runs():
     subprocess.check_call(["make", "-s", "-C", CPP, "hello_world"])
