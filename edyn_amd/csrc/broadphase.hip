@@ -36,7 +36,7 @@ __global__ void k_step_reset(Counters *cnt) {   // (inside edynhip_step the prev
     int t = threadIdx.x;
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0;
+        cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->pairs_differ = 0;
         cnt->unc_count = 0; cnt->df_abort = 0; cnt->bp_rebuild = 0;   // also the sticky ones: a stand-alone run follows set_* calls or a failed step
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
@@ -426,18 +426,28 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     own_count[i] = (uint32_t)em.n;
 }
 // After the scan of own_count: total pair count for the host, and the per-owner blocks copied to their final places.
+// Also compares the new key list with the previous step's manifold array (prev_skey[pm], sorted the same way): when nothing differs
+// the step keeps that array and works in place (Counters::pairs_differ, read by the host with the pair count).
 __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_keys, const uint32_t *__restrict__ own_count,
                              const uint32_t *__restrict__ own_offset, const uint64_t *__restrict__ extra, uint64_t *out, uint32_t cap,
-                             Counters *cnt) {
+                             Counters *cnt, const uint64_t *__restrict__ prev_skey, uint32_t pm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = own_offset[nbodies], nextra = min(cnt->num_extra, cap);
     if (i == 0) {
         cnt->num_pairs = total + nextra; if (total + nextra > cap) cnt->pair_overflow = 1;
         cnt->bp_rebuild = 0;   // consumed by k_bp_refit / k_bp_walk above; this step's k_finish decides for the next step
+        if (total + nextra != pm || nextra != 0) cnt->pairs_differ = 1;   // (surplus keys arrive unsorted: no comparison)
     }
     if (i < nbodies) {
         const uint32_t c = own_count[i], o = own_offset[i];
-        for (uint32_t a = 0; a < c; ++a) if (o + a < cap) out[o + a] = own_keys[(size_t)i * kOwnCap + a];
+        bool differ = false;
+        for (uint32_t a = 0; a < c; ++a)
+            if (o + a < cap) {
+                const uint64_t key = own_keys[(size_t)i * kOwnCap + a];
+                out[o + a] = key;
+                differ = differ || o + a >= pm || prev_skey[o + a] != key;
+            }
+        if (differ) cnt->pairs_differ = 1;
     }
     for (uint32_t e = i; e < nextra; e += gridDim.x * blockDim.x) if (total + e < cap) out[total + e] = extra[e];
 }
@@ -546,7 +556,7 @@ int broadphase(edynhip_ctx *c) {
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
-        hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt);
+        hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt, prev.skey, pm);
         // pair count is needed on the host to size the manifold kernels
         EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
@@ -556,6 +566,18 @@ int broadphase(edynhip_ctx *c) {
             int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb;
             EH_HIP(c, hipMemcpyAsync(c->pair_keys, c->pair_keys_sorted, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
             EH_TRY(sort_u64(c, c->pair_keys, c->pair_keys_sorted, M, 0, 33 + hb));
+        }
+        // Unchanged pair set (the common case once a scene has settled, and all that a sleeping world ever sees): the previous
+        // step's manifold array IS this step's - no rebuild, no copy of the contact points into the other array; the
+        // narrowphase works in place and sleeping manifolds cost nothing. (With contact events the build also keeps the
+        // created / destroyed bookkeeping, so it runs.)
+        static const bool inplace_env = !(getenv("EDYNHIP_INPLACE") && getenv("EDYNHIP_INPLACE")[0] == '0');
+        if (inplace_env && c->full_step && M > 0 && M == pm && !c->cnt_host->pairs_differ && !c->events && !c->force_islands) {
+            c->points_in_prev = false;
+            c->prev_num_manifolds = pm;
+            c->num_manifolds = M;
+            EH_HIP(c, hipGetLastError());
+            return EDYNHIP_OK;
         }
         if (!c->full_step) {   // inside edynhip_step the previous step's k_finish already cleared these
             EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));

@@ -232,6 +232,7 @@ struct Counters {
     uint32_t unc_count;          // edges k_col_prepare found uncoloured (listed in col_unc while they fit)
     uint32_t bp_rebuild;         // this step rebuilds the broadphase candidate lists (set by the previous step's k_finish, cleared by k_bp_compact)
     uint32_t df_abort;           // the dataflow solve kernel gave up waiting for a hand-off (never expected; reported as an error)
+    uint32_t pairs_differ;       // this step's sorted pair keys differ from the previous step's manifold array (k_bp_compact); 0 = the step runs in place
     uint32_t isl_num;            // island-fused schedule: islands that have constraints this step (solver.hip k_isl_fill)
     uint32_t isl_max_items;      //   and the largest of them, in constraints (read by the NEXT step's schedule decision)
     uint32_t isl_max_jitems;     //   the largest island that has joints

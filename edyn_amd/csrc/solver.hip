@@ -2511,7 +2511,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
         const int t = threadIdx.x;
         if (t == 0) {
             cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0; cnt->pairs_differ = 0;
         }
         if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
         for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
