@@ -753,7 +753,7 @@ static int append_host_joints(edynhip_ctx *c, uint32_t n, const edynhip_joints *
         HostJoint h;
         h.type = in->type[e]; h.body[0] = in->body[2 * e]; h.body[1] = in->body[2 * e + 1];
         if (h.body[0] >= c->b.n || h.body[1] >= c->b.n) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": body index out of range").c_str());
-        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_GENERIC) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
+        if (h.type < EDYNHIP_JOINT_POINT || h.type > EDYNHIP_JOINT_NULL) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": joint type").c_str());
         std::memcpy(h.pivot, in->pivot + 6 * e, sizeof(h.pivot));
         if (h.type == EDYNHIP_JOINT_HINGE) {
             if (!in->axis) return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": hinge needs axes").c_str());

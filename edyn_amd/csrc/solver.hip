@@ -1083,6 +1083,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt, uint32_t *__restrict
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;   // sleeping island: its joints are not prepared or solved
     if (is_dynamic(b.flags[ia])) isl_joint[b.island[ia]] = 1u;
     else if (is_dynamic(b.flags[ib])) isl_joint[b.island[ib]] = 1u;
+    if (j.type[i] == EDYNHIP_JOINT_NULL) { j.rmask[i] = 0; return; }   // null_constraint: an island-graph edge without rows
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;

@@ -132,6 +132,7 @@ struct generic_constraint : constraint_base {                                   
     std::array<linear_dof, 3> linear_dofs;
     std::array<angular_dof, 3> angular_dofs;
 };
+struct null_constraint : constraint_base {};                                                  // constraints/null_constraint.hpp: no rows, one island
 struct gravity_constraint : constraint_base {};                                               // constraints/gravity_constraint.hpp (Newtonian attraction)
 inline constexpr matrix3x3 matrix3x3_identity{{vector3{1, 0, 0}, vector3{0, 1, 0}, vector3{0, 0, 1}}};
 struct cone_constraint : constraint_base {                                                    // constraints/cone_constraint.hpp:19-49
@@ -226,6 +227,7 @@ template <typename T> constexpr int joint_kind_of() {
     else if constexpr (std::is_same_v<T, cone_constraint>) return EDYNHIP_JOINT_CONE;
     else if constexpr (std::is_same_v<T, cvjoint_constraint>) return EDYNHIP_JOINT_CVJOINT;
     else if constexpr (std::is_same_v<T, gravity_constraint>) return EDYNHIP_JOINT_GRAVITY;
+    else if constexpr (std::is_same_v<T, null_constraint>) return EDYNHIP_JOINT_NULL;
     else return EDYNHIP_JOINT_GENERIC;
 }
 // the constraint component of kind `kind` on `e`, or nullptr (also when the entity itself is gone)
@@ -239,6 +241,7 @@ inline constraint_base *constraint_of(entt::registry &registry, entt::entity e, 
     case EDYNHIP_JOINT_CONE: return registry.try_get<cone_constraint>(e);
     case EDYNHIP_JOINT_CVJOINT: return registry.try_get<cvjoint_constraint>(e);
     case EDYNHIP_JOINT_GRAVITY: return registry.try_get<gravity_constraint>(e);
+    case EDYNHIP_JOINT_NULL: return registry.try_get<null_constraint>(e);
     default: return registry.try_get<generic_constraint>(e);
     }
 }
@@ -270,6 +273,7 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
             auto *sc = &registry.get<soft_distance_constraint>(e);
             jt[j] = kind; fill(*sc, sc->pivot); jq[10 * j] = sc->distance; jq[10 * j + 1] = sc->stiffness; jq[10 * j + 2] = sc->damping;
         } else if (kind == EDYNHIP_JOINT_GRAVITY) { jt[j] = kind; fill(registry.get<gravity_constraint>(e), std::array<vector3, 2>{}); }
+        else if (kind == EDYNHIP_JOINT_NULL) { jt[j] = kind; fill(registry.get<null_constraint>(e), std::array<vector3, 2>{}); }
         else if (kind == EDYNHIP_JOINT_GENERIC) { auto *ge = &registry.get<generic_constraint>(e); jt[j] = kind; fill(*ge, ge->pivot); }   // (definition follows)
         else if (kind == EDYNHIP_JOINT_CONE) { auto *cc = &registry.get<cone_constraint>(e); jt[j] = kind; fill(*cc, cc->pivot); }      // frames / parameters follow
         else if (kind == EDYNHIP_JOINT_CVJOINT) { auto *cv = &registry.get<cvjoint_constraint>(e); jt[j] = kind; fill(*cv, cv->pivot); }  // (define_frames below)
@@ -820,7 +824,7 @@ template <typename T, typename... SetupFunc>
 void make_constraint(entt::registry &registry, entt::entity entity, entt::entity body0, entt::entity body1, SetupFunc... setup) {
     static_assert(std::is_same_v<T, point_constraint> || std::is_same_v<T, hinge_constraint> || std::is_same_v<T, distance_constraint> ||
                       std::is_same_v<T, soft_distance_constraint> || std::is_same_v<T, cone_constraint> || std::is_same_v<T, cvjoint_constraint> ||
-                      std::is_same_v<T, gravity_constraint> || std::is_same_v<T, generic_constraint>,
+                      std::is_same_v<T, gravity_constraint> || std::is_same_v<T, generic_constraint> || std::is_same_v<T, null_constraint>,
                   "unknown constraint type");
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     auto &con = registry.emplace<T>(entity);

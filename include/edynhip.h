@@ -56,7 +56,8 @@ enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_CONE = 4,           /* cone_constraint.cpp:12-104; frames + params through edynhip_set_joint_definition */
        EDYNHIP_JOINT_CVJOINT = 5,        /* cvjoint_constraint.cpp:12-302; frames + params through edynhip_set_joint_definition */
        EDYNHIP_JOINT_GRAVITY = 6,        /* gravity_constraint.cpp:6-34: Newtonian attraction between the two bodies; impulse slot 0 */
-       EDYNHIP_JOINT_GENERIC = 7         /* generic_constraint.cpp:10-330; frames + 6 x 10 parameters through edynhip_set_generic_definition */ };
+       EDYNHIP_JOINT_GENERIC = 7,        /* generic_constraint.cpp:10-330; frames + 6 x 10 parameters through edynhip_set_generic_definition */
+       EDYNHIP_JOINT_NULL = 8            /* null_constraint.hpp:12-17: no rows - an edge of the island graph that keeps two bodies in one island */ };
 /* contact_normal_attachment (include/edyn/collision/contact_normal_attachment.hpp:17-21) */
 enum { EDYNHIP_ATTACH_NONE = 0, EDYNHIP_ATTACH_ON_A = 1, EDYNHIP_ATTACH_ON_B = 2 };
 

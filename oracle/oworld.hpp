@@ -34,7 +34,7 @@
 namespace orc {
 
 enum body_kind : int { KIND_DYNAMIC = 0, KIND_KINEMATIC = 1, KIND_STATIC = 2 };
-enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5, JOINT_GRAVITY = 6, JOINT_GENERIC = 7 };
+enum joint_type : int { JOINT_POINT = 0, JOINT_HINGE = 1, JOINT_DISTANCE = 2, JOINT_SOFT_DISTANCE = 3, JOINT_CONE = 4, JOINT_CVJOINT = 5, JOINT_GRAVITY = 6, JOINT_GENERIC = 7, JOINT_NULL = 8 /* null_constraint.hpp: no rows, only an island-graph edge */ };
 constexpr int kJointSlotsO = 24, kJointParamsO = 64;
 // ORDER_EXTERNAL = ORDER_SEQUENTIAL with the visiting order inside each island supplied by the caller (ext_contact_order /
 // ext_joint_order): the order the REAL reference used for the same step (island.edges iteration order, which depends on
@@ -933,6 +933,7 @@ public:
         return a;
     }
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
+        if (j.type == JOINT_NULL) return 0;
         vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
         if (j.type == JOINT_GENERIC) {   // generic_constraint.cpp:10-258

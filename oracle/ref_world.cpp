@@ -25,6 +25,7 @@
 #include <edyn/util/gravity_util.hpp>
 #include <edyn/util/rigidbody.hpp>
 #include <edyn/util/ragdoll.hpp>
+#include <edyn/constraints/null_constraint.hpp>
 #include <edyn/comp/collision_exclusion.hpp>
 #include <edyn/comp/collision_filter.hpp>
 #include <entt/entity/registry.hpp>
@@ -187,6 +188,8 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
         e = edyn::make_constraint<edyn::generic_constraint>(w->registry, w->bodies[a], w->bodies[b], [&](edyn::generic_constraint &c) {
             c.pivot[0] = v3(pivotA); c.pivot[1] = v3(pivotB);
         });
+    } else if (type == 8) {
+        e = edyn::make_constraint<edyn::null_constraint>(w->registry, w->bodies[a], w->bodies[b]);
     } else if (type == 6) {
         e = edyn::make_constraint<edyn::gravity_constraint>(w->registry, w->bodies[a], w->bodies[b]);
     } else if (type == 4) {
@@ -213,7 +216,7 @@ uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *
         });
     }
     w->joints.push_back(e);
-    w->joint_type.push_back(type >= 0 && type <= 7 ? type : 1);
+    w->joint_type.push_back(type >= 0 && type <= 8 ? type : 1);
     return (uint32_t)w->joints.size() - 1;
 }
 

@@ -1310,3 +1310,21 @@ def test_pile_beside_ragdolls_takes_the_mixed_schedule_bit_exact():
     assert launches[0] > 20 and max(launches[5:]) == 2, launches[:8]     # first steps per colour, then: dataflow + island-fused
     ji = g.get_joint_impulses()
     assert np.isfinite(g.get_state()[0]).all() and np.abs(ji).max() > 0 and g.get_stats()["num_islands"] >= 2
+
+
+def test_null_constraint_bit_exact():
+    """null_constraint on the device: a joint without rows that only ties two bodies into one island (its island is marked as
+    jointed and takes the island-fused schedule with nothing to solve). The resting box stays awake until the box it is tied to has
+    landed and settled; the untied box falls asleep on time. Sleep flags and state against the oracle (pinned to the real engine in
+    tests/test_reference_engine.py::test_null_constraint_keeps_its_bodies_in_one_island_like_the_real_engine)."""
+    from test_reference_engine import _null_constraint_scene
+    sc = _null_constraint_scene()
+    g, o = _sleep_worlds(sc)
+    woke_late = False
+    for step in range(420):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+        a = g.get_asleep()
+        woke_late = woke_late or (a[3] and not a[1])
+    a = g.get_asleep()
+    assert woke_late and a[1] and a[2] and a[3] and g.get_stats()["num_islands"] == 2

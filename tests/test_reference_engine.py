@@ -818,3 +818,21 @@ def test_ragdolls_match_the_real_engine(shape):
     assert (np.abs(ji[kinds == scenes.JOINT_CVJOINT][:, [3, 4, 6, 7]]).max(axis=0) > 0).all()   # twist limit, bump stop, friction rows
     assert np.abs(ji[kinds == scenes.JOINT_HINGE][:, [6, 8]]).max() > 0      # knee / elbow bump stops and torque
     assert len(ref.get_manifolds()) > 40 and ref.get_state()[0][1:, 1].max() < 0.6   # everybody is lying on the floor
+
+
+def _null_constraint_scene():
+    """Two boxes far apart on the floor, one resting, one dropped from 6 m, tied by a null_constraint; a third box rests alone."""
+    sc = scenes.box_pile(3, 1, 1)
+    sc["pos"][1] = (0.0, 0.5, 0.0); sc["pos"][2] = (20.0, 6.0, 0.0); sc["pos"][3] = (40.0, 0.5, 0.0)
+    sc["joints"] = [(scenes.JOINT_NULL, 1, 2, (0, 0, 0), (0, 0, 0), (1, 0, 0), (1, 0, 0))]
+    return sc
+
+
+def test_null_constraint_keeps_its_bodies_in_one_island_like_the_real_engine():
+    """null_constraint (null_constraint.hpp:12-17): no rows, only an edge of the island graph - the resting box cannot fall asleep
+    before the one it is tied to has landed and settled, while the untied box sleeps on time. Sleep flags, islands and state
+    bit-identical with the real engine."""
+    ref, orc, first_sleep = _lockstep(_null_constraint_scene(), 420, sleeping=True)
+    assert first_sleep is not None
+    a = ref.get_asleep()
+    assert a[1] and a[2] and a[3] and ref.num_islands == 2 == orc.get_stats()["num_islands"]
