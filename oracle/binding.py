@@ -228,10 +228,12 @@ class World:
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
             grav = scene["gravity"][i] if scene.get("gravity") is not None else None
-            self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
-                          scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
-                          scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
-                          True, int(scene["group"][i]), int(scene["mask"][i]), grav)
+            b = self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
+                              scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
+                              scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
+                              True, int(scene["group"][i]), int(scene["mask"][i]), grav)
+            if scene.get("com") is not None and np.any(scene["com"][i] != 0):   # rigidbody_def::center_of_mass: `pos` was the origin
+                self.set_center_of_mass(b, scene["com"][i], float(scene["mass"][i]))
         joints = scene.get("joints")
         if joints is not None:
             for j in joints:
@@ -244,6 +246,11 @@ class World:
         if params is not None:
             self.set_joint_params(j, params)
         return j
+
+    def set_center_of_mass(self, body, com, mass):
+        """rigidbody_def::center_of_mass, right after add_body (the position given there is the origin)."""
+        f = self.L.orc_set_center_of_mass; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.c_float]; f.restype = None
+        f(self.h, body, _fp(_f32(com, 3)), mass)
 
     def exclude_collision(self, a, b):
         f = self.L.orc_exclude_collision; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
@@ -550,6 +557,11 @@ class RefWorld:
                                     _fp(_f32(angvel, 3)), mass, shape_type, _fp(_f32(shape_param, 4)), I,
                                     friction, restitution, int(has_material), group, mask, g, int(sleeping_disabled))
 
+    def next_center_of_mass(self, com):
+        """rigidbody_def::center_of_mass of the next add_body (whose position is then the origin)."""
+        f = self.L.refw_next_center_of_mass; f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, _fp(_f32(com, 3)))
+
     def add_bodies(self, scene, sleeping_disabled=True):
         n = len(scene["kind"])
         inertia = scene.get("inertia")
@@ -557,6 +569,8 @@ class RefWorld:
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
             grav = scene["gravity"][i] if scene.get("gravity") is not None else None
+            if scene.get("com") is not None and np.any(scene["com"][i] != 0):
+                self.next_center_of_mass(scene["com"][i])
             self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
                           scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
                           scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),

@@ -54,6 +54,7 @@ uint32_t orc_add_body(void *h, int kind, const float *pos, const float *orn, con
                        make_shape(shape_type, shape_param), inertia9 ? &I : nullptr, friction, restitution,
                        has_material != 0, group, mask, &g);
 }
+void orc_set_center_of_mass(void *h, uint32_t body, const float *com, float mass) { ((World *)h)->set_center_of_mass(body, v3(com), mass); }
 uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
                        const float *axisA, const float *axisB) {
     return ((World *)h)->add_joint(type, a, b, v3(pivotA), v3(pivotB), v3(axisA), v3(axisB));
@@ -107,6 +108,7 @@ void orc_set_state(void *h, const float *pos, const float *orn, const float *lin
         b.pos = v3(pos + 3 * i);
         b.orn = {orn[4 * i], orn[4 * i + 1], orn[4 * i + 2], orn[4 * i + 3]};
         b.linvel = v3(linvel + 3 * i); b.angvel = v3(angvel + 3 * i);
+        b.update_origin();
     }
 }
 void orc_refresh_derived(void *h) { ((World *)h)->refresh_derived(); }

@@ -65,6 +65,13 @@ struct Body {
     uint32_t leaf = DynTree::NIL;
     bool asleep = false;             // sleeping_tag (island_manager.cpp:541-565)
     bool sleeping_disabled = false;  // sleeping_disabled_tag
+    // center_of_mass / origin (comp/center_of_mass.hpp, comp/origin.hpp): `pos` is the centre of mass, shapes and every pivot live in the
+    // frame of `origin` = to_world(-com, pos, orn); bodies without an offset have neither component and use `pos`
+    vec3 com{0, 0, 0}, origin{0, 0, 0};
+    bool has_com = false;
+    mat3 I_body = kMat3Zero; bool inertia_from_shape = false;   // kept for rigidbody_def::center_of_mass (parallel-axis shift at creation)
+    vec3 org() const { return has_com ? origin : pos; }
+    void update_origin() { if (has_com) origin = to_world(-com, pos, orn); }   // update_origins.cpp:13-15
     bool procedural() const { return kind == KIND_DYNAMIC; }
     bool rolling() const { return kind == KIND_DYNAMIC && (sh.type == SHAPE_SPHERE || sh.type == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t, shapes.hpp:40-44
     vec3 roll_direction() const {   // roll_direction component: dynamic capsules roll about their axis (rigidbody.cpp:119-130, shapes.hpp:136-139)
@@ -280,6 +287,7 @@ public:
         if (kind == KIND_DYNAMIC) {
             b.mass_inv = 1.0f / mass;
             mat3 I = inertia ? *inertia : moment_of_inertia(sh, mass);
+            b.I_body = I; b.inertia_from_shape = inertia == nullptr;
             b.I_inv = inverse_symmetric(I);
             mat3 basis = to_mat3(orn);
             b.I_inv_world = basis * b.I_inv * transpose(basis);
@@ -343,6 +351,29 @@ public:
     void set_gravity(vec3 g) {   // gravity_util.cpp:12-20: the setting and every body that carries a gravity component
         gravity = g;
         for (auto &b : bodies) if (b.kind == KIND_DYNAMIC && !b.removed) b.gravity = g;
+    }
+    // rigidbody_def::center_of_mass right after add_body (rigidbody.cpp:56-87): an inertia derived from the shape is shifted by the
+    // parallel-axis theorem (moment_of_inertia.cpp:217-220), then apply_center_of_mass (rigidbody.cpp:517-548): the position given to
+    // add_body is the ORIGIN; position and linear velocity move to the centre of mass.
+    void set_center_of_mass(uint32_t i, vec3 com, float mass) {
+        Body &b = bodies[i];
+        if (b.kind == KIND_DYNAMIC && b.inertia_from_shape) {
+            const mat3 d = skew(com);
+            const mat3 dd = transpose(d) * d;
+            mat3 I;
+            for (int r = 0; r < 3; ++r) I.row[r] = b.I_body.row[r] + dd.row[r] * mass;
+            b.I_body = I;
+            b.I_inv = inverse_symmetric(I);
+            mat3 basis = to_mat3(b.orn);
+            b.I_inv_world = basis * b.I_inv * transpose(basis);
+        }
+        const vec3 origin = to_world(-b.com, b.pos, b.orn);
+        const vec3 com_world = to_world(com, origin, b.orn);
+        if (b.kind != KIND_STATIC) b.linvel += cross(b.angvel, com_world - b.pos);
+        b.pos = com_world;
+        b.has_com = !(com == vec3{0, 0, 0});
+        b.com = b.has_com ? com : vec3{0, 0, 0};
+        b.origin = origin;
     }
     uint32_t add_joint(int type, uint32_t a, uint32_t b, vec3 pivotA, vec3 pivotB, vec3 axisA, vec3 axisB) {
         Joint j;
@@ -478,7 +509,7 @@ public:
         const vec3 off = vec3{1, 1, 1} * -kContactBreakingThreshold;
         res.num_points = 0;
         if (!intersect(A.box.inset(off), B.box)) return;
-        coll_ctx ctx{A.pos, A.orn, B.pos, B.orn, kCollisionThreshold};
+        coll_ctx ctx{A.org(), A.orn, B.org(), B.orn, kCollisionThreshold};
         collide(A.sh, B.sh, ctx, res);
     }
     static size_t find_nearest(const ContactPoint &cp, const coll_result &res) {   // collision_util.cpp:233-255
@@ -539,7 +570,7 @@ public:
     }
     bool should_remove(const ContactPoint &cp, const Body &A, const Body &B) const {   // collision_util.cpp:397-413
         const float thr = kContactBreakingThreshold, thr2 = thr * thr;
-        vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+        vec3 pA = to_world(cp.pivotA, A.org(), A.orn), pB = to_world(cp.pivotB, B.org(), B.orn);
         vec3 d = pA - pB;
         float nd = dot(d, cp.normal);
         vec3 td = d - nd * cp.normal;
@@ -556,8 +587,8 @@ public:
             ContactPoint &cp = m.pt[i];
             ++cp.lifetime;
             size_t nearest = find_nearest(cp, res);
-            if (nearest == R && A.rolling()) nearest = find_nearest_rolling(res, cp.pivotA, A.pos, A.orn, A.angvel);
-            if (nearest == R && B.rolling()) nearest = find_nearest_rolling(res, cp.pivotB, B.pos, B.orn, B.angvel);
+            if (nearest == R && A.rolling()) nearest = find_nearest_rolling(res, cp.pivotA, A.org(), A.orn, A.angvel);
+            if (nearest == R && B.rolling()) nearest = find_nearest_rolling(res, cp.pivotB, B.org(), B.orn, B.angvel);
             if (nearest < R && !merged[nearest]) {
                 merge_point(m, res.point[nearest], cp);
                 merged[nearest] = true;
@@ -642,7 +673,7 @@ public:
             if (manifold_asleep(m)) continue;
             const Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
             for (int i = 0; i < m.num_points; ++i) {
-                vec3 pA = to_world(m.pt[i].pivotA, A.pos, A.orn), pB = to_world(m.pt[i].pivotB, B.pos, B.orn);
+                vec3 pA = to_world(m.pt[i].pivotA, A.org(), A.orn), pB = to_world(m.pt[i].pivotB, B.org(), B.orn);
                 m.pt[i].distance = dot(m.pt[i].normal, pA - pB);
             }
         }
@@ -819,11 +850,13 @@ public:
     struct BodyRef {   // solver.cpp:83-147: static => zero velocity; non-procedural => zero inverse mass, dummy deltas
         vec3 pos; quat orn; vec3 linvel, angvel; float inv_m; mat3 inv_I; vec3 *dv, *dw;
         vec3 roll_dir{0, 0, 0};
+        vec3 org_{0, 0, 0};
+        vec3 org() const { return org_; }   // constraint_body::origin (constraints/constraint_body.hpp:10-18)
     };
     BodyRef body_ref(uint32_t i) {
         Body &b = bodies[i];
         BodyRef r;
-        r.pos = b.pos; r.orn = b.orn; r.roll_dir = b.roll_direction();
+        r.pos = b.pos; r.orn = b.orn; r.roll_dir = b.roll_direction(); r.org_ = b.org();
         if (b.procedural()) { r.inv_m = b.mass_inv; r.inv_I = b.I_inv_world; r.dv = &b.dv; r.dw = &b.dw; }
         else { r.inv_m = 0; r.inv_I = kMat3Zero; r.dv = &dummy_dv_; r.dw = &dummy_dw_; }
         if (b.kind == KIND_STATIC) { r.linvel = {0, 0, 0}; r.angvel = {0, 0, 0}; }
@@ -838,7 +871,7 @@ public:
     // contact_constraint.cpp:15-56
     struct ExtraRows { bool roll = false, spin = false; FrictionRow rr; SpinRow sr; };
     void prepare_contact(const ContactPoint &cp, const BodyRef &A, const BodyRef &B, Row &nr, FrictionRow &fr, ExtraRows *ex = nullptr, int num_points = 1) {
-        vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
+        vec3 pAw = to_world(cp.pivotA, A.org(), A.orn), pBw = to_world(cp.pivotB, B.org(), B.orn);
         vec3 rA = pAw - A.pos, rB = pBw - B.pos;
         const vec3 n = cp.normal;
         nr.J[0] = n; nr.J[1] = cross(rA, n); nr.J[2] = -n; nr.J[3] = -cross(rB, n);
@@ -934,7 +967,7 @@ public:
     }
     int prepare_joint(Joint &j, const BodyRef &A, const BodyRef &B, Row *rows, int *slot) {
         if (j.type == JOINT_NULL) return 0;
-        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 pA = to_world(j.pivot[0], A.org(), A.orn), pB = to_world(j.pivot[1], B.org(), B.orn);
         vec3 rA = pA - A.pos, rB = pB - B.pos;
         if (j.type == JOINT_GENERIC) {   // generic_constraint.cpp:10-258
             const vec3 pivot_offset = pB - pA;
@@ -1036,7 +1069,7 @@ public:
         }
         if (j.type == JOINT_CONE) {   // cone_constraint.cpp:12-95
             const vec3 pivotB_world = pB;
-            const vec3 pivotB_in_A = to_object(pivotB_world, A.pos, A.orn);
+            const vec3 pivotB_in_A = to_object(pivotB_world, A.org(), A.orn);
             const vec3 pf = to_object(pivotB_in_A, j.pivot[0], j.frame[0]);
             const float scaling_y = 1.0f / j.params[0], scaling_z = 1.0f / j.params[1];
             const vec3 ps = pf * vec3{1, scaling_y, scaling_z};
@@ -1056,7 +1089,7 @@ public:
             const vec3 descale{1, 1 / scaling_y, 1 / scaling_z};
             const vec3 point_on_cone = point_on_cone_scaled * descale;
             const vec3 pivotA = to_world(point_on_cone, j.pivot[0], j.frame[0]);
-            const vec3 pivotA_world = to_world(pivotA, A.pos, A.orn);
+            const vec3 pivotA_world = to_world(pivotA, A.org(), A.orn);
             const vec3 tangent = normalize(tangent_scaled * descale);
             const vec3 normal = normalize(cross(tangent, point_on_cone));
             const vec3 nw = rotate(A.orn, j.frame[0] * normal);
@@ -1312,6 +1345,7 @@ public:
             float corr = error * kContactPositionCorrectionRate * em;
             if (A->procedural()) apply(*A, inv_mA, inv_IA, J[0], J[1], corr);
             if (B->procedural()) apply(*B, inv_mB, inv_IB, J[2], J[3], corr);
+            A->update_origin(); B->update_origin();   // position_solver.hpp:34-41: origins follow the corrected transforms
             max_error = std::max(std::fabs(error), max_error);
         }
         static void apply(Body &b, float inv_m, mat3 &inv_I, vec3 Jl, vec3 Ja, float corr) {
@@ -1328,7 +1362,7 @@ public:
         if (cp.extras() && cp.stiffness < kLarge) return;   // soft contacts take no position correction (contact_extras_constraint.cpp:81-86)
         Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
         ps.bind(A, B);
-        vec3 pAw = to_world(cp.pivotA, A.pos, A.orn), pBw = to_world(cp.pivotB, B.pos, B.orn);
+        vec3 pAw = to_world(cp.pivotA, A.org(), A.orn), pBw = to_world(cp.pivotB, B.org(), B.orn);
         if (cp.attachment == NA_ON_A) cp.normal = rotate(A.orn, cp.local_normal);
         else if (cp.attachment == NA_ON_B) cp.normal = rotate(B.orn, cp.local_normal);
         cp.distance = dot(pAw - pBw, cp.normal);
@@ -1344,7 +1378,7 @@ public:
         for (int i = 0; i < 3; ++i) {
             const float *P = j.params + 10 * i;
             if (P[0] == 0) continue;
-            const vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+            const vec3 pA = to_world(j.pivot[0], A.org(), A.orn), pB = to_world(j.pivot[1], B.org(), B.orn);
             const vec3 pivot_offset = pB - pA, rA = pA - A.pos, rB = pB - B.pos;
             const vec3 axisA = rotate(A.orn, j.frame[0].column(i));
             const float proj = dot(pivot_offset, axisA);
@@ -1370,7 +1404,7 @@ public:
             twist_error = angle;
         }
         { vec3 J[4] = {{0, 0, 0}, tA, {0, 0, 0}, -tB}; ps.solve(J, twist_error); }
-        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 pA = to_world(j.pivot[0], A.org(), A.orn), pB = to_world(j.pivot[1], B.org(), B.orn);
         vec3 dir = pA - pB;
         const float err = length(dir);
         if (err > kEps) {
@@ -1391,7 +1425,7 @@ public:
         if (std::fabs(e) > kEps) { vec3 J[4] = {{0, 0, 0}, p, {0, 0, 0}, -p}; ps.solve(J, e); }
         e = dot(u, q);
         if (std::fabs(e) > kEps) { vec3 J[4] = {{0, 0, 0}, q, {0, 0, 0}, -q}; ps.solve(J, e); }
-        vec3 pA = to_world(j.pivot[0], A.pos, A.orn), pB = to_world(j.pivot[1], B.pos, B.orn);
+        vec3 pA = to_world(j.pivot[0], A.org(), A.orn), pB = to_world(j.pivot[1], B.org(), B.orn);
         vec3 dir = pA - pB;
         float err = length(dir);
         if (err > kEps) {
@@ -1411,8 +1445,9 @@ public:
 
     void refresh_derived() {   // update_aabbs (dynamic + kinematic, update_aabbs.cpp:53-78), update_inertias (dynamic, update_inertias.cpp:12-24)
         for (auto &b : bodies) {
-            if (b.asleep) continue;   // update_aabbs / update_inertias views exclude sleeping entities
-            if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.pos, b.orn);
+            if (b.asleep) continue;   // update_origins / update_aabbs / update_inertias views exclude sleeping entities
+            b.update_origin();        // solver.cpp:453: before the AABBs (the position solve left the origins of untouched bodies where the integration found them)
+            if (b.sh.type != SHAPE_NONE && b.kind != KIND_STATIC) b.box = shape_aabb(b.sh, b.org(), b.orn);
             if (b.kind == KIND_DYNAMIC) {
                 mat3 basis = to_mat3(b.orn);
                 b.I_inv_world = basis * b.I_inv * transpose(basis);
@@ -1434,7 +1469,7 @@ public:
         float mn = kScalarMax;
         for (int i = 0; i < m.num_points; ++i) {
             const ContactPoint &cp = m.pt[i];
-            const vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+            const vec3 pA = to_world(cp.pivotA, A.org(), A.orn), pB = to_world(cp.pivotB, B.org(), B.orn);
             const vec3 rA = pA - A.pos, rB = pB - B.pos;
             const vec3 velA = vA + cross(wA, rA), velB = vB + cross(wB, rB);
             mn = std::min(dot(velA - velB, cp.normal), mn);
@@ -1449,7 +1484,7 @@ public:
             BodyRef A = body_ref(m->body[0]), B = body_ref(m->body[1]);
             for (int i = 0; i < m->num_points; ++i) {
                 ContactPoint &cp = m->pt[i];
-                const vec3 pA = to_world(cp.pivotA, A.pos, A.orn), pB = to_world(cp.pivotB, B.pos, B.orn);
+                const vec3 pA = to_world(cp.pivotA, A.org(), A.orn), pB = to_world(cp.pivotB, B.org(), B.orn);
                 const vec3 rA = pA - A.pos, rB = pB - B.pos, n = cp.normal;
                 Row r;
                 r.J[0] = n; r.J[1] = cross(rA, n); r.J[2] = -n; r.J[3] = -cross(rB, n);

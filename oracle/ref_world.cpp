@@ -59,6 +59,7 @@ struct ref_world {
     std::vector<entt::entity> bodies;
     std::unordered_map<uint32_t, uint32_t> index_of;   // entity id -> body index
     std::vector<entt::entity> joints;
+    edyn::vector3 next_com{0, 0, 0}; bool has_next_com = false;
     std::vector<int> joint_type;                       // edyn_amd JOINT_* code of joints[i] (one entity may hold a cone AND a cvjoint: ragdoll.cpp:643-657)
     double time = 0;
     float dt = 1.0f / 60;
@@ -168,12 +169,15 @@ uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, co
     if (grav) def.gravity = v3(grav);
     def.sleeping_disabled = sleeping_disabled != 0;
     def.presentation = false;
+    if (w->has_next_com) { def.center_of_mass = w->next_com; w->has_next_com = false; }
     auto e = edyn::make_rigidbody(w->registry, def);
     w->index_of[entt::to_integral(e)] = (uint32_t)w->bodies.size();
     w->bodies.push_back(e);
     return (uint32_t)w->bodies.size() - 1;
 }
 
+// rigidbody_def::center_of_mass for the NEXT refw_add_body call (the position passed there is then the origin).
+void refw_next_center_of_mass(void *h, const float *com) { auto *w = (ref_world *)h; w->next_com = v3(com); w->has_next_com = true; }
 // type 0 = point_constraint, 1 = hinge_constraint (set_axes(axisA, axisB)).
 uint32_t refw_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
                         const float *axisA, const float *axisB) {

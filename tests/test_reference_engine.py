@@ -836,3 +836,41 @@ def test_null_constraint_keeps_its_bodies_in_one_island_like_the_real_engine():
     assert first_sleep is not None
     a = ref.get_asleep()
     assert a[1] and a[2] and a[3] and ref.num_islands == 2 == orc.get_stats()["num_islands"]
+
+
+def _com_scene():
+    """Bodies whose centre of mass is not their shape's origin (rigidbody_def::center_of_mass): loaded boxes and a weighted sphere
+    tumbling onto the floor, two of them hinged together and one hanging from a static anchor by a point constraint."""
+    sc = scenes.box_pile(3, 2, 1)
+    n = len(sc["kind"])
+    sc["com"] = np.zeros((n, 3), np.float32)
+    sc["com"][1] = (0.2, -0.1, 0.05); sc["com"][3] = (-0.15, 0.2, 0.1); sc["com"][5] = (0.0, -0.3, 0.0)
+    sc["shape_type"][6] = scenes.SHAPE_SPHERE; sc["shape_param"][6] = (0.5, 0, 0, 0); sc["com"][6] = (0.0, -0.25, 0.0)
+    sc["angvel"][1:] = np.random.default_rng(3).normal(size=(n - 1, 3)).astype(np.float32)
+    sc["pos"][1:, 1] += 0.4
+    sc["joints"] = [(scenes.JOINT_HINGE, 1, 2, (0.51, 0.0, 0.0), (-0.51, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 0.0, 1.0)),
+                    (scenes.JOINT_POINT, 4, 5, (0.0, 0.6, 0.0), (0.0, -0.6, 0.0), (1.0, 0.0, 0.0), (1.0, 0.0, 0.0))]
+    return sc
+
+
+def test_center_of_mass_matches_the_real_engine():
+    """rigidbody_def::center_of_mass (rigidbody.cpp:56-87,517-548): the parallel-axis shift of the shape's inertia, position and
+    velocity moved to the centre of mass, shapes / contact pivots / joint pivots in the frame of the origin (update_origins.cpp,
+    position_solver.hpp:34-41: origins follow position corrections, and are otherwise refreshed once per step) - initial state,
+    AABBs and world inertias, then 300 steps bit-identical with the real engine."""
+    sc = _com_scene()
+    ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc)
+    orc = ob.World(vel_iters=10, order=ob.ORDER_EXTERNAL); orc.add_bodies(sc)
+    ad, od = ref.get_derived(), orc.get_derived()
+    assert np.array_equal(ad[0][1:].view(np.uint32), od[0][1:].view(np.uint32)) and np.array_equal(ad[1][1:].view(np.uint32), od[1][1:].view(np.uint32))
+    for s in range(1, 301):
+        ref.step(1)
+        orc.set_ext_order(*ref.get_solve_order()); orc.step(1)
+        assert not orc.ext_order_mismatch(), s
+        for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+            assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (s, name)
+    assert np.array_equal(ref.get_joint_impulses().view(np.uint32), orc.get_joint_impulses().view(np.uint32))
+    ad, od = ref.get_derived(), orc.get_derived()
+    assert np.array_equal(ad[0][1:].view(np.uint32), od[0][1:].view(np.uint32))
+    # the loaded bodies came to rest heavy side down: their centres of mass sit below their origins
+    assert ref.get_state()[0][6, 1] < 0.35
