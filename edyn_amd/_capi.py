@@ -28,7 +28,7 @@ class Bodies(C.Structure):
                 ("angvel", C.c_void_p), ("mass", C.c_void_p), ("inertia", C.c_void_p), ("has_inertia", C.c_void_p),
                 ("shape_type", C.c_void_p), ("shape_param", C.c_void_p), ("friction", C.c_void_p),
                 ("restitution", C.c_void_p), ("group", C.c_void_p), ("mask", C.c_void_p), ("gravity", C.c_void_p),
-                ("sleeping_disabled", C.c_void_p)]
+                ("sleeping_disabled", C.c_void_p), ("center_of_mass", C.c_void_p)]
 
 
 class Joints(C.Structure):

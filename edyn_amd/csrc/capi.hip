@@ -107,6 +107,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
+    EH_TRY(dalloc(c, c->com_store, nb)); EH_TRY(dalloc(c, c->origin_store, nb));
     EH_TRY(dalloc(c, c->isl_cnt, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_off, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_list, nb));
     EH_TRY(dalloc(c, c->isl_items, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_sorted, (size_t)M + nj)); EH_TRY(dalloc(c, c->isl_joint, nb));
     EH_TRY(dalloc(c, c->isl_err, nb)); EH_TRY(dalloc(c, c->isl_done, nb)); EH_TRY(dalloc(c, c->pos_err, (size_t)nb * kMaxDfPosIters));
@@ -136,7 +137,7 @@ static int allocate(edynhip_ctx *c) {
 // Scene upload: raw packed arrays -> float4 SoA + derived quantities (rigidbody.cpp:47-131).
 struct RawBodies {
     const int32_t *kind; const float *pos, *orn, *linvel, *angvel, *mass, *inertia; const uint8_t *has_inertia;
-    const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity; const uint8_t *sleeping_disabled;
+    const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity; const uint8_t *sleeping_disabled; const float *com;
 };
 __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b, float3 default_gravity) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;   // index into the caller's arrays
@@ -148,6 +149,8 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
     const float4 sp = make_float4(r.shape_param[4 * l], r.shape_param[4 * l + 1], r.shape_param[4 * l + 2], r.shape_param[4 * l + 3]);
     float inv_m = 0;
     m3 il = m3_zero(), iw = m3_zero();
+    const f3 com = r.com ? mk3(r.com[3 * l], r.com[3 * l + 1], r.com[3 * l + 2]) : mk3(0, 0, 0);
+    const bool has_com = !(com.x == 0 && com.y == 0 && com.z == 0);
     if (kind == EDYNHIP_KIND_DYNAMIC) {
         const float mass = r.mass[l];
         inv_m = 1.0f / mass;
@@ -182,6 +185,11 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         } else {
             I = {{kScalarMax, 0, 0}, {0, kScalarMax, 0}, {0, 0, kScalarMax}};
         }
+        if (has_com && !(r.has_inertia && r.has_inertia[l])) {   // shift_moment_of_inertia (moment_of_inertia.cpp:217-220): I + (d^T d) m, d = skew(com)
+            const m3 d = {{0, -com.z, com.y}, {com.z, 0, -com.x}, {-com.y, com.x, 0}};
+            const m3 dd = mul(transpose(d), d);
+            I = {I.r0 + dd.r0 * mass, I.r1 + dd.r1 * mass, I.r2 + dd.r2 * mass};
+        }
         // inverse_matrix_symmetric, matrix3x3.hpp:190-218
         float det = dot(I.r0, cross(I.r1, I.r2));
         float di = 1.0f / det;
@@ -198,11 +206,19 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         m3 basis = to_m3(orn);
         iw = mul(mul(basis, il), transpose(basis));
     }
-    B_POS(b, i) = to4(pos, inv_m);
-    B_ORN(b, i) = to4(orn);
     const bool moving = kind != EDYNHIP_KIND_STATIC;
-    b.linvel[i] = moving ? make_float4(r.linvel[3 * l], r.linvel[3 * l + 1], r.linvel[3 * l + 2], 0) : make_float4(0, 0, 0, 0);
-    b.angvel[i] = moving ? make_float4(r.angvel[3 * l], r.angvel[3 * l + 1], r.angvel[3 * l + 2], 0) : make_float4(0, 0, 0, 0);
+    f3 lv = moving ? mk3(r.linvel[3 * l], r.linvel[3 * l + 1], r.linvel[3 * l + 2]) : mk3(0, 0, 0);
+    const f3 av = moving ? mk3(r.angvel[3 * l], r.angvel[3 * l + 1], r.angvel[3 * l + 2]) : mk3(0, 0, 0);
+    f3 pos_com = pos;
+    if (has_com) {   // apply_center_of_mass (rigidbody.cpp:517-548): the given position is the origin
+        pos_com = to_world(com, pos, orn);
+        if (moving) lv += cross(av, pos_com - pos);
+    }
+    if (b.com) { b.com[i] = to4(com, has_com ? 1.0f : 0.0f); b.origin[i] = to4(pos, 0); }
+    B_POS(b, i) = to4(pos_com, inv_m);
+    B_ORN(b, i) = to4(orn);
+    b.linvel[i] = to4(lv, 0);
+    b.angvel[i] = to4(av, 0);
     B_DV(b, i) = make_float4(0, 0, 0, 0); B_DW(b, i) = make_float4(0, 0, 0, 0);
     B_IW(b, i, 0) = to4(iw.r0, 0); B_IW(b, i, 1) = to4(iw.r1, 0); B_IW(b, i, 2) = to4(iw.r2, 0);
     B_IL(b, i, 0) = to4(il.r0, 0); B_IL(b, i, 1) = to4(il.r1, 0); B_IL(b, i, 2) = to4(il.r2, 0);
@@ -465,7 +481,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 7; }   // 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 8; }   // 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -583,6 +599,16 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     up(in->friction, n, r.friction); up(in->restitution, n, r.restitution);
     up(in->group, n, r.group); up(in->mask, n, r.mask); up(in->gravity, (size_t)n * 3, r.gravity);
     up(in->sleeping_disabled, n, r.sleeping_disabled);
+    {   // centre-of-mass offsets: the origin arrays are attached to the body set with the first body that has one
+        bool any = false;
+        if (in->center_of_mass) for (size_t k = 0; k < (size_t)n * 3; ++k) any = any || in->center_of_mass[k] != 0.0f;
+        if (first == 0) { c->b.com = nullptr; c->b.origin = nullptr; }
+        if (any && !c->b.com) {
+            if (first != 0 && rc == EDYNHIP_OK && hipMemsetAsync(c->com_store, 0, (size_t)c->b.cap * sizeof(float4), c->stream) != hipSuccess) rc = EDYNHIP_ERR_HIP;
+            c->b.com = c->com_store; c->b.origin = c->origin_store;
+        }
+        if (c->b.com) up(in->center_of_mass, in->center_of_mass ? (size_t)n * 3 : 0, r.com);
+    }
     const uint32_t total = first + n;
     if (rc == EDYNHIP_OK) {
         c->b.n = total;

@@ -49,6 +49,9 @@ struct Bodies {
     float4 *amin = nullptr;     // AABB min
     float4 *amax = nullptr;     // AABB max
     float4 *shape = nullptr;    // box half extents | sphere radius | plane normal+constant
+    // center_of_mass / origin (comp/center_of_mass.hpp, comp/origin.hpp): nullptr while no body has an offset. `pos` is the centre of mass;
+    // shapes, contact pivots and joint pivots live in the frame of origin = to_world(-com, pos, orn) (com.w != 0 marks a body that has one)
+    float4 *com = nullptr, *origin = nullptr;
     float4 *grav = nullptr;     // per-body gravity
     float2 *mat = nullptr;      // friction, restitution
     float4 *mat2 = nullptr;     // contact_extras materials: spin_friction, roll_friction, stiffness, damping (comp/material.hpp:15-22)
@@ -256,6 +259,8 @@ struct StageTimer {
 #define B_ORN(b, i) ((b).xf[8 * (size_t)(i) + 1])
 #define B_IW(b, i, r) ((b).xf[8 * (size_t)(i) + 2 + (r)])
 #define B_IL(b, i, r) ((b).xf[8 * (size_t)(i) + 5 + (r)])
+// where a body's shape and pivots are anchored: its origin if it has a centre-of-mass offset, else its position
+#define B_ORG(b, i) (((b).origin && (b).com[(i)].w != 0.0f) ? from4((b).origin[(i)]) : from4(B_POS(b, i)))
 #define B_DV(b, i) ((b).dvw[2 * (size_t)(i)])
 #define B_DW(b, i) ((b).dvw[2 * (size_t)(i) + 1])
 
@@ -289,6 +294,7 @@ struct edynhip_ctx {
     uint64_t *used = nullptr;      // per body: colours in use
     uint64_t *best[2] = {nullptr, nullptr};
     float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
+    float4 *com_store = nullptr, *origin_store = nullptr;   // backing of Bodies::com / origin (attached to `b` once a body has an offset)
     uint32_t *isl_cnt = nullptr, *isl_off = nullptr, *isl_list = nullptr, *isl_items = nullptr, *isl_sorted = nullptr, *isl_joint = nullptr;   // island-fused schedule (solver.hip IslLists)
     uint32_t isl_prep_step = 0xFFFFFFF0u;   // step_index of the last step that bucketed its constraints by island (its isl_max_items reaches cnt_host with the next step's fetch)
     uint32_t last_fetch_step = 0xFFFFFFF0u; // step_index during which fetch_counters last ran

@@ -74,7 +74,7 @@ k_np_detect(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
     const box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
     if (intersect(inset(ba, -kBreakingThreshold), bbx)) {
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-        Ctx ctx{from4(B_POS(b, ia)), q_from4(B_ORN(b, ia)), from4(B_POS(b, ib)), q_from4(B_ORN(b, ib)), kCollisionThreshold};
+        Ctx ctx{B_ORG(b, ia), q_from4(B_ORN(b, ia)), B_ORG(b, ib), q_from4(B_ORN(b, ib)), kCollisionThreshold};   // shapes sit at the origin (collision_util.cpp:451-465)
         collide(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
     }
     st.rnum[m] = (uint32_t)res.num;
@@ -111,10 +111,10 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         }
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
         BodyIn A, B;
-        { float4 p = B_POS(b, ia); A.pos = from4(p); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
+        { A.pos = B_ORG(b, ia); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
           float2 mt = b.mat[ia]; A.friction = mt.x; A.restitution = mt.y;
           A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tA == SHAPE_SPHERE || tA == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t
-        { float4 p = B_POS(b, ib); B.pos = from4(p); B.orn = q_from4(B_ORN(b, ib)); B.angvel = from4(b.angvel[ib]);
+        { B.pos = B_ORG(b, ib); B.orn = q_from4(B_ORN(b, ib)); B.angvel = from4(b.angvel[ib]);
           float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
           B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tB == SHAPE_SPHERE || tB == SHAPE_CAPSULE); }
 

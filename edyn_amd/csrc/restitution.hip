@@ -25,12 +25,12 @@ inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
 DI bool dyn(uint32_t flags) { return (flags & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC; }
 constexpr float kRelvelThreshold = -0.005f;   // restitution_solver.cpp:138
 
-struct RBody { f3 pos; q4 orn; f3 v, w; float inv_m; m3 inv_I; };
+struct RBody { f3 pos, org; q4 orn; f3 v, w; float inv_m; m3 inv_I; };   // org: where pivots are anchored (the origin of a body with a centre-of-mass offset)
 DI RBody load_rbody(const Bodies &b, uint32_t i) {   // restitution_solver.cpp:166-220: kind decides velocity / mass / inertia
     RBody r;
     const float4 p = B_POS(b, i);
     const uint32_t fl = b.flags[i];
-    r.pos = from4(p); r.orn = q_from4(B_ORN(b, i));
+    r.pos = from4(p); r.org = B_ORG(b, i); r.orn = q_from4(B_ORN(b, i));
     if (dyn(fl)) { r.inv_m = p.w; r.inv_I = {from4(B_IW(b, i, 0)), from4(B_IW(b, i, 1)), from4(B_IW(b, i, 2))}; }
     else { r.inv_m = 0; r.inv_I = m3_zero(); }
     if ((fl & BF_KIND_MASK) == EDYNHIP_KIND_STATIC) { r.v = mk3(0, 0, 0); r.w = mk3(0, 0, 0); }
@@ -51,7 +51,7 @@ DI float manifold_min_relvel(const Manifolds &mf, const Bodies &b, uint32_t m) {
     float mn = kScalarMax;
     for (uint32_t k = 0; k < np; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
-        const f3 pA = to_world(from4(mf.pA[s]), A.pos, A.orn), pB = to_world(from4(mf.pB[s]), B.pos, B.orn);
+        const f3 pA = to_world(from4(mf.pA[s]), A.org, A.orn), pB = to_world(from4(mf.pB[s]), B.org, B.orn);
         const f3 rA = pA - A.pos, rB = pB - B.pos;
         const f3 velA = A.v + cross(A.w, rA), velB = B.v + cross(B.w, rB);
         mn = fminf(dot(velA - velB, from4(mf.nrm[s])), mn);
@@ -144,7 +144,7 @@ DI void solve_star(const RestArgs &a, uint32_t node) {
             for (uint32_t k = 0; k < np; ++k) {
                 const size_t s = (size_t)k * mf.cap + m;
                 const f3 n = from4(mf.nrm[s]);
-                const f3 pA = to_world(from4(mf.pA[s]), A.pos, A.orn), pB = to_world(from4(mf.pB[s]), B.pos, B.orn);
+                const f3 pA = to_world(from4(mf.pA[s]), A.org, A.orn), pB = to_world(from4(mf.pB[s]), B.org, B.orn);
                 const f3 rA = pA - A.pos, rB = pB - B.pos;
                 f3 dvA = from4(B_DV(b, ia)), dwA = from4(B_DW(b, ia)), dvB = from4(B_DV(b, ib)), dwB = from4(B_DW(b, ib));
                 if (!dyn(b.flags[ia])) { dvA = mk3(0, 0, 0); dwA = mk3(0, 0, 0); }   // dummy deltas of non-procedural bodies

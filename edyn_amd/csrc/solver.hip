@@ -411,12 +411,12 @@ __global__ void k_col_offsets(uint32_t M, const uint32_t *__restrict__ keys_sort
 }
 
 // ------------------------------------------------------------------ row math shared by prep / solve
-struct BRef { f3 pos; q4 orn; f3 v, w; float inv_m; m3 inv_I; };
+struct BRef { f3 pos, org; q4 orn; f3 v, w; float inv_m; m3 inv_I; };   // org: constraint_body::origin - the frame of every pivot (= pos without a centre-of-mass offset)
 DI BRef load_bref(const Bodies &b, uint32_t i) {
     BRef r;
     float4 p = B_POS(b, i);
     uint32_t fl = b.flags[i];
-    r.pos = from4(p); r.orn = q_from4(B_ORN(b, i));
+    r.pos = from4(p); r.org = B_ORG(b, i); r.orn = q_from4(B_ORN(b, i));
     if (is_dynamic(fl)) {
         r.inv_m = p.w;
         r.inv_I = {from4(B_IW(b, i, 0)), from4(B_IW(b, i, 1)), from4(B_IW(b, i, 2))};
@@ -483,7 +483,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
         const f3 n = from4(n4);
         const float distance = a4.w, mu = b4.w;
-        const f3 pAw = to_world(from4(a4), A.pos, A.orn), pBw = to_world(from4(b4), B.pos, B.orn);
+        const f3 pAw = to_world(from4(a4), A.org, A.orn), pBw = to_world(from4(b4), B.org, B.orn);
         const f3 rA = pAw - A.pos, rB = pBw - B.pos;
         // normal row
         const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
@@ -1085,7 +1085,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt, uint32_t *__restrict
     else if (is_dynamic(b.flags[ib])) isl_joint[b.island[ib]] = 1u;
     if (j.type[i] == EDYNHIP_JOINT_NULL) { j.rmask[i] = 0; return; }   // null_constraint: an island-graph edge without rows
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
-    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    const f3 pA = to_world(from4(j.pivA[i]), A.org, A.orn), pB = to_world(from4(j.pivB[i]), B.org, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
     const int type = j.type[i];
     const bool hinge = type == EDYNHIP_JOINT_HINGE;
@@ -1112,7 +1112,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt, uint32_t *__restrict
         const f3 fx = from4(j.axA[i]), fy = from4(j.pA[i]), fz = from4(j.qA[i]);   // columns of the frame in A
         const m3 frame = m3_columns(fx, fy, fz);
         const f3 pivA = from4(j.pivA[i]);
-        const f3 pivotB_in_A = to_object(pB, A.pos, A.orn);
+        const f3 pivotB_in_A = to_object(pB, A.org, A.orn);
         const f3 pf = to_object(pivotB_in_A, pivA, frame);
         const float scaling_y = 1.0f / P(0), scaling_z = 1.0f / P(1);
         const f3 ps = pf * mk3(1, scaling_y, scaling_z);
@@ -1130,7 +1130,7 @@ __global__ void k_prep_joints(Joints j, Bodies b, float dt, uint32_t *__restrict
         const float cone_proj = dot(ps, dir_on_cone);
         const f3 descale = mk3(1, 1 / scaling_y, 1 / scaling_z);
         const f3 point_on_cone = (dir_on_cone * cone_proj) * descale;
-        const f3 pivotA_world = to_world(pivA + mul(frame, point_on_cone), A.pos, A.orn);
+        const f3 pivotA_world = to_world(pivA + mul(frame, point_on_cone), A.org, A.orn);
         const f3 tangent = normalize(tangent_scaled * descale);
         const f3 normal = normalize(cross(tangent, point_on_cone));
         const f3 nw = rotate(A.orn, mul(frame, normal));
@@ -1333,7 +1333,7 @@ __global__ void k_prep_generic(Joints j, Bodies b, float dt) {
     const uint32_t ia = j.bodyA[i], ib = j.bodyB[i];
     if (edge_asleep(b.flags[ia], b.flags[ib])) return;
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
-    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    const f3 pA = to_world(from4(j.pivA[i]), A.org, A.orn), pB = to_world(from4(j.pivB[i]), B.org, B.orn);
     const f3 rA = pA - A.pos, rB = pB - B.pos;
     const f3 pivot_offset = pB - pA;
     const f3 colA[3] = {from4(j.axA[i]), from4(j.pA[i]), from4(j.qA[i])};
@@ -1569,11 +1569,14 @@ __global__ void k_integrate(uint32_t n, Bodies b, float dt, float *isl_err, uint
 }
 
 // ------------------------------------------------------------------ position solver
-struct PBody { f3 pos; q4 orn; float inv_m; m3 iw, il; bool proc; };
+struct PBody { f3 pos; q4 orn; float inv_m; m3 iw, il; bool proc; f3 org, com; bool has_com; };   // org: the frame of the pivots (position_solver.hpp:53-59)
 DI PBody load_pbody(const Bodies &b, uint32_t i) {
     PBody r;
     float4 p = B_POS(b, i);
     r.pos = from4(p); r.orn = q_from4(B_ORN(b, i));
+    r.has_com = b.origin && b.com[i].w != 0.0f;
+    r.com = r.has_com ? from4(b.com[i]) : mk3(0, 0, 0);
+    r.org = r.has_com ? from4(b.origin[i]) : r.pos;   // (the stored origin: after the integration it is the previous one until a correction or the end of the step refreshes it)
     r.proc = is_dynamic(b.flags[i]);
     if (r.proc) {
         r.inv_m = p.w;
@@ -1583,6 +1586,7 @@ DI PBody load_pbody(const Bodies &b, uint32_t i) {
     return r;
 }
 DI void store_pbody(const Bodies &b, uint32_t i, const PBody &r) {
+    if (r.has_com) b.origin[i] = to4(r.org, 0);
     if (!r.proc) return;
     B_POS(b, i) = to4(r.pos, r.inv_m); B_ORN(b, i) = to4(r.orn);
     B_IW(b, i, 0) = to4(r.iw.r0, 0); B_IW(b, i, 1) = to4(r.iw.r1, 0); B_IW(b, i, 2) = to4(r.iw.r2, 0);
@@ -1596,11 +1600,14 @@ DI void pos_apply(PBody &x, f3 Jl, f3 Ja, float corr) {
     m3 basis = to_m3(x.orn);
     x.iw = mul(mul(basis, x.il), transpose(basis));
 }
+// position_solver.hpp:34-41: after a correction the origins follow the new transforms (a body without an offset has none: its pivots use pos)
+DI void pos_origin(PBody &x) { if (x.has_com) x.org = to_world(-x.com, x.pos, x.orn); else x.org = x.pos; }
 DI void pos_solve(PBody &A, PBody &B, f3 J0, f3 J1, f3 J2, f3 J3, float error, float &max_err) {
     float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.iw, B.inv_m, B.iw);
     float corr = error * 0.2f * em;   // contact_position_correction_rate / error_correction_rate
     pos_apply(A, J0, J1, corr);
     pos_apply(B, J2, J3, corr);
+    pos_origin(A); pos_origin(B);
     max_err = fmaxf(fabsf(error), max_err);
 }
 // One atomic per wave when all its active lanes belong to one island (the common case: a pile is one
@@ -1834,7 +1841,7 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     for (int k = 0; k < NP; ++k) {
         if ((uint32_t)k < np && in_range && !soft[k]) {   // uniform within a lane pair
             const int attach = __float_as_int(n4[k].w);
-            const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
+            const f3 pXw = to_world(from4(piv[k]), X.org, X.orn);
             const f3 pOw = xchg1(pXw);
             const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
             // the normal rotates with the body it is attached to; that body's lane computes it and shares it
@@ -1859,6 +1866,7 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
                 const float error = -distance;
                 const float corr = error * 0.2f * em;
                 pos_apply(X, Jl, Ja, corr);
+                pos_origin(X);
                 max_err = fmaxf(fabsf(error), max_err);
             }
         }
@@ -1944,7 +1952,7 @@ DI void pos_joints_lane(uint32_t i, bool in_range, const Joints &j, const Bodies
     if (j.type[i] == EDYNHIP_JOINT_GENERIC) {   // generic_constraint.cpp:260-290: the limited linear degrees of freedom
         for (int k = 0; k < 3; ++k) {
             if (j.params[(size_t)(10 * k) * j.cap + i] == 0) continue;
-            const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+            const f3 pA = to_world(from4(j.pivA[i]), A.org, A.orn), pB = to_world(from4(j.pivB[i]), B.org, B.orn);
             const f3 off = pB - pA, rA = pA - A.pos, rB = pB - B.pos;
             const f3 axisA = rotate(A.orn, from4(k == 0 ? j.axA[i] : (k == 1 ? j.pA[i] : j.qA[i])));
             const float proj = dot(off, axisA), vmin = j.params[(size_t)(10 * k + 1) * j.cap + i], vmax = j.params[(size_t)(10 * k + 2) * j.cap + i];
@@ -1980,7 +1988,7 @@ DI void pos_joints_lane(uint32_t i, bool in_range, const Joints &j, const Bodies
     e = dot(u, qq);
     if (fabsf(e) > kEps) pos_solve(A, B, mk3(0, 0, 0), qq, mk3(0, 0, 0), -qq, e, max_err);
     }
-    const f3 pA = to_world(from4(j.pivA[i]), A.pos, A.orn), pB = to_world(from4(j.pivB[i]), B.pos, B.orn);
+    const f3 pA = to_world(from4(j.pivA[i]), A.org, A.orn), pB = to_world(from4(j.pivB[i]), B.org, B.orn);
     f3 dir = pA - pB;
     const float err = length(dir);
     if (err > kEps) {
@@ -2468,8 +2476,12 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
     const uint32_t kind = fl & BF_KIND_MASK;
     if (kind == EDYNHIP_KIND_STATIC || (fl & BF_ASLEEP)) return;   // update_aabbs / update_inertias exclude sleeping bodies
     const int st = (int)((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-    const f3 pos = from4(B_POS(b, i));
     const q4 orn = q_from4(B_ORN(b, i));
+    f3 pos = from4(B_POS(b, i));   // below: where the SHAPE sits
+    if (b.origin && b.com[i].w != 0.0f) {   // update_origins (update_origins.cpp:13-19, solver.cpp:453: before the AABBs)
+        pos = to_world(-from4(b.com[i]), pos, orn);
+        b.origin[i] = to4(pos, 0);
+    }
     const m3 basis = to_m3(orn);
     if (st == dc::SHAPE_BOX) {   // aabb_util.cpp:42-63
         const f3 h = from4(b.shape[i]);
@@ -2721,7 +2733,7 @@ int solve(edynhip_ctx *c) {
     }
     constexpr uint32_t kMixedMinFree = 1024;   // manifolds outside jointed islands that make the dataflow launch worth its fixed cost
     const bool mixed = isl_candidate && mixed_env && j.n > 0 && !c->extras && na > 0 && c->df_mode == 1 && c->cfg.num_position_iterations <= kMaxDfPosIters &&
-                       free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit;
+                       free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit && !c->b.com;
     const bool push = na > 0 && !serial && (contacts_only || mixed);
     if (na) {
         if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
@@ -2881,7 +2893,8 @@ int solve(edynhip_ctx *c) {
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
     const uint32_t P = c->cfg.num_position_iterations;
     // one error array per position iteration (DfPosArgs::err_out / err_prev): kMaxDfPosIters of them are allocated
-    const bool pos_df = P > 0 && P <= kMaxDfPosIters && push && c->df_mode == 1 && pos_df_env;
+    // (the dataflow position kernel hands positions and orientations over, not origins: worlds with centre-of-mass offsets solve positions per colour)
+    const bool pos_df = P > 0 && P <= kMaxDfPosIters && push && c->df_mode == 1 && pos_df_env && !c->b.com;
     hipLaunchKernelGGL(k_integrate, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->isl_err, c->isl_done, push ? c->rows.dslot : nullptr, c->rows.first_slot,
                        c->pos_err, pos_df ? P : 0u);
     if (na && !pos_df) hipLaunchKernelGGL(k_store_impulses, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, rcap, mf);

@@ -166,6 +166,8 @@ class World:
             a["gravity"] = np.ascontiguousarray(grav, np.float32).reshape(n, 3)
         if scene.get("sleeping_disabled") is not None:
             a["sleeping_disabled"] = np.ascontiguousarray(scene["sleeping_disabled"], np.uint8)
+        if scene.get("com") is not None:   # rigidbody_def::center_of_mass: `pos` is then the origin
+            a["center_of_mass"] = np.ascontiguousarray(scene["com"], np.float32).reshape(n, 3)
         b = _capi.Bodies()
         for f, _ in _capi.Bodies._fields_:
             setattr(b, f, _ptr(a.get(f)))

@@ -58,6 +58,8 @@ struct mass { scalar s; };
 struct mass_inv { scalar s; };
 struct inertia : matrix3x3 {};
 struct gravity : vector3 {};
+struct center_of_mass : vector3 {};   // comp/center_of_mass.hpp: offset of the centre of mass in the shape's frame
+struct origin : vector3 {};           // comp/origin.hpp: where the shape sits; `position` is the centre of mass (kept in sync after every update)
 inline constexpr scalar large_scalar = scalar(1e18);   // math/constants.hpp:17
 struct material_base {   // comp/material.hpp:15-22; the last four select contact_extras_constraint (rolling / spinning friction, soft contacts)
     scalar restitution{0}, friction{scalar(0.5)}, spin_friction{0}, roll_friction{0}, stiffness{large_scalar}, damping{large_scalar};
@@ -94,6 +96,7 @@ struct rigidbody_def {   // util/rigidbody.hpp:29-81 (hot-path fields)
     std::optional<matrix3x3> inertia;
     vector3 linvel{vector3_zero};
     vector3 angvel{vector3_zero};
+    std::optional<vector3> center_of_mass;   // (position is then the origin, as in the reference: util/rigidbody.cpp:85-87)
     std::optional<vector3> gravity;
     std::optional<shapes_variant_t> shape;
     std::optional<edyn::material> material{edyn::material{}};
@@ -339,6 +342,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     std::vector<int32_t> kind(n), stype(n);
     std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
     std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
+    std::vector<float> com(3 * n, 0.f); bool any_com = false;
     std::vector<float> xspin(n, 0.f), xroll(n, 0.f), xstiff(n, float(large_scalar)), xdamp(n, float(large_scalar));
     std::vector<uint32_t> mat_ids(n, 0xFFFFu);
     bool any_extras = false, any_ids = false;
@@ -356,6 +360,13 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
         if (auto *v = registry.try_get<linvel>(e)) { lv[3 * i] = v->x; lv[3 * i + 1] = v->y; lv[3 * i + 2] = v->z; }
         if (auto *w = registry.try_get<angvel>(e)) { av[3 * i] = w->x; av[3 * i + 1] = w->y; av[3 * i + 2] = w->z; }
+        if (auto *cm = registry.try_get<center_of_mass>(e)) {   // the device takes the ORIGIN and the offset, and moves position / velocity itself
+            const auto &o = registry.get<origin>(e);
+            const vector3 r{p.x - o.x, p.y - o.y, p.z - o.z};   // centre of mass - origin
+            pos[3 * i] = o.x; pos[3 * i + 1] = o.y; pos[3 * i + 2] = o.z;
+            lv[3 * i] -= av[3 * i + 1] * r.z - av[3 * i + 2] * r.y; lv[3 * i + 1] -= av[3 * i + 2] * r.x - av[3 * i] * r.z; lv[3 * i + 2] -= av[3 * i] * r.y - av[3 * i + 1] * r.x;
+            com[3 * i] = cm->x; com[3 * i + 1] = cm->y; com[3 * i + 2] = cm->z; any_com = true;
+        }
         if (auto *ms = registry.try_get<mass>(e)) m[i] = ms->s;
         if (auto *in = registry.try_get<inertia>(e)) {
             hasI[i] = 1;
@@ -377,7 +388,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
     }
     edynhip_bodies b{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
-                     fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data()};
+                     fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data(), any_com ? com.data() : nullptr};
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
     if (any_extras) check(s, edynhip_set_material_extras(s.ctx, first, n, xspin.data(), xroll.data(), xstiff.data(), xdamp.data()));
@@ -469,6 +480,12 @@ inline void write_back(entt::registry &registry, gpu_stepper &s) {
         auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
         auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
         auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
+        if (auto *cm = registry.try_get<center_of_mass>(e)) {   // update_origins.cpp:13-15: origin = to_world(-com, pos, orn)
+            const vector3 c{-cm->x, -cm->y, -cm->z}, u{q.x, q.y, q.z};
+            const vector3 t{2 * (u.y * c.z - u.z * c.y), 2 * (u.z * c.x - u.x * c.z), 2 * (u.x * c.y - u.y * c.x)};
+            auto &o = registry.get<origin>(e);
+            o.x = p.x + c.x + q.w * t.x + (u.y * t.z - u.z * t.y); o.y = p.y + c.y + q.w * t.y + (u.z * t.x - u.x * t.z); o.z = p.z + c.z + q.w * t.z + (u.x * t.y - u.y * t.x);
+        }
     }
     if (s.cfg.island_sleeping) {   // mirror sleeping_tag (island_manager.cpp:541-565, util/island_util.cpp:7-13)
         std::vector<uint8_t> asleep(n, 0);
@@ -795,6 +812,20 @@ inline void make_rigidbody(entt::entity entity, entt::registry &registry, const 
         registry.emplace<present_position>(entity, present_position{def.position});
         registry.emplace<present_orientation>(entity, present_orientation{def.orientation});
     }
+    if (def.center_of_mass && (def.center_of_mass->x != 0 || def.center_of_mass->y != 0 || def.center_of_mass->z != 0)) {   // apply_center_of_mass, rigidbody.cpp:517-548
+        const vector3 c = *def.center_of_mass;
+        const quaternion &q = def.orientation;
+        const vector3 u{q.x, q.y, q.z};
+        const vector3 t{2 * (u.y * c.z - u.z * c.y), 2 * (u.z * c.x - u.x * c.z), 2 * (u.x * c.y - u.y * c.x)};
+        const vector3 rc{c.x + q.w * t.x + (u.y * t.z - u.z * t.y), c.y + q.w * t.y + (u.z * t.x - u.x * t.z), c.z + q.w * t.z + (u.x * t.y - u.y * t.x)};   // rotate(orn, com)
+        registry.emplace<center_of_mass>(entity, center_of_mass{c});
+        registry.emplace<origin>(entity, origin{def.position});
+        auto &p = registry.get<position>(entity); p.x += rc.x; p.y += rc.y; p.z += rc.z;
+        if (def.kind != rigidbody_kind::rb_static) {
+            auto &v = registry.get<linvel>(entity); const auto &w = registry.get<angvel>(entity);
+            v.x += w.y * rc.z - w.z * rc.y; v.y += w.z * rc.x - w.x * rc.z; v.z += w.x * rc.y - w.y * rc.x;
+        }
+    }
     const vector3 g = def.gravity ? *def.gravity : s.cfg.gravity;
     if (def.kind == rigidbody_kind::rb_dynamic) registry.emplace<gravity>(entity, gravity{g});
     if (def.material) registry.emplace<material>(entity, *def.material);
@@ -863,7 +894,7 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<static_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<sleeping_disabled_tag>(entity);
     registry.remove<sleeping_tag>(entity); registry.remove<collision_filter>(entity); registry.remove<box_shape>(entity);
     registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<material>(entity);
-    registry.remove<gravity>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
+    registry.remove<gravity>(entity); registry.remove<center_of_mass>(entity); registry.remove<origin>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
     registry.remove<detail::body_index>(entity);   // the stepper drops the body from the device world at the next update
@@ -931,6 +962,11 @@ inline vector3 mat_vec(const matrix3x3 &m, const vector3 &v) {
     return {m.row[0].x * v.x + m.row[0].y * v.y + m.row[0].z * v.z, m.row[1].x * v.x + m.row[1].y * v.y + m.row[1].z * v.z, m.row[2].x * v.x + m.row[2].y * v.y + m.row[2].z * v.z};
 }
 }  // namespace detail
+/// util/rigidbody.hpp:191: where the body's shape sits (its position is the centre of mass)
+inline vector3 get_rigidbody_origin(entt::registry &registry, entt::entity entity) {
+    if (auto *o = registry.try_get<origin>(entity)) return *o;
+    return registry.get<position>(entity);
+}
 /// rigidbody.cpp:228-246
 inline void rigidbody_apply_impulse(entt::registry &registry, entt::entity entity, const vector3 &impulse, const vector3 &rel_location) {
     if (!registry.all_of<dynamic_tag>(entity)) return;

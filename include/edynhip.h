@@ -104,6 +104,9 @@ typedef struct {
     const uint64_t *mask;            /* [n] collision_filter.mask */
     const float *gravity;            /* [n][3] per-body gravity or NULL = config gravity */
     const uint8_t *sleeping_disabled;/* [n] or NULL: sleeping_disabled_tag (only meaningful with EDYNHIP_FLAG_SLEEPING) */
+    const float *center_of_mass;     /* [n][3] or NULL (ABI 8): rigidbody_def::center_of_mass in the shape's frame; `pos` is then the ORIGIN - the
+                                        stepper moves position / linear velocity to the centre of mass and shifts a shape-derived inertia
+                                        (util/rigidbody.cpp:56-87,517-548); edynhip_get_state returns the centre of mass, as the reference's position */
 } edynhip_bodies;
 
 typedef struct {

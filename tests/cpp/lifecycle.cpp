@@ -169,6 +169,31 @@ int main() {
         run(2);
     }
 
+    // rigidbody_def::center_of_mass: a sphere loaded at the bottom, laid on its side, rolls back upright and stays there
+    {
+        auto wdef = edyn::rigidbody_def{};
+        wdef.shape = edyn::sphere_shape{0.5f};
+        wdef.center_of_mass = edyn::vector3{0, -0.35f, 0};
+        wdef.material->friction = 1.0f;
+        wdef.material->roll_friction = 0.03f;   // rolling resistance damps the rocking
+        wdef.sleeping_disabled = true;
+        const float h = 0.5f * 1.2f;   // tilted 1.2 rad about z
+        wdef.orientation = {0, 0, std::sin(h), std::cos(h)};
+        wdef.position = {60, 0.5f, 0};   // the ORIGIN (centre of the sphere)
+        const entt::entity weeble = edyn::make_rigidbody(registry, wdef);
+        const auto com0 = registry.get<edyn::position>(weeble);
+        CHECK(std::fabs(com0.y - (0.5f - 0.35f * std::cos(1.2f))) < 1e-5f && std::fabs(com0.x - (60 + 0.35f * std::sin(1.2f))) < 1e-5f);
+        float lowest = 1, highest = 0;
+        for (int k = 0; k < 900; ++k) { run(1); const float y = registry.get<edyn::position>(weeble).y; lowest = std::fmin(lowest, y); highest = std::fmax(highest, y); }
+        std::printf("weeble: centre of mass y in [%.3f, %.3f], final %.3f, q.w %.4f\n", lowest, highest, registry.get<edyn::position>(weeble).y, registry.get<edyn::orientation>(weeble).w);
+        const auto q = registry.get<edyn::orientation>(weeble);
+        const auto o = edyn::get_rigidbody_origin(registry, weeble);
+        const auto p = registry.get<edyn::position>(weeble);
+        CHECK(highest < com0.y + 1e-3f && lowest < 0.16f);               // it never gained height, and swung through the upright pose
+        CHECK(std::fabs(q.w) > 0.98f || std::fabs(q.y) > 0.98f);         // upright again (it may have turned about the vertical)
+        CHECK(std::fabs(o.y - 0.5f) < 2e-2f && std::fabs(p.y - 0.15f) < 2e-2f);   // origin at the sphere's centre, centre of mass 0.35 below it
+    }
+
     // update(registry) without a time: the monotonic clock drives the accumulator - or the user's time source
     edyn::update(registry);
     edyn::update(registry);

@@ -1328,3 +1328,27 @@ def test_null_constraint_bit_exact():
         woke_late = woke_late or (a[3] and not a[1])
     a = g.get_asleep()
     assert woke_late and a[1] and a[2] and a[3] and g.get_stats()["num_islands"] == 2
+
+
+def test_center_of_mass_bit_exact():
+    """rigidbody_def::center_of_mass on the device (edynhip_bodies::center_of_mass): parallel-axis shift of the shape's inertia, position
+    and velocity moved to the centre of mass, shapes / contact pivots / joint pivots anchored at the origin, origins refreshed by the
+    position solver's corrections and once per step (`k_finish`) - loaded boxes and a weighted sphere tumbling onto the floor, a hinge
+    and a point constraint between them; initial derived state, then state / manifolds / joint impulses against the oracle, which is
+    pinned to the real engine on this scene (tests/test_reference_engine.py::test_center_of_mass_matches_the_real_engine)."""
+    from test_reference_engine import _com_scene
+    sc = _com_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    assert_state_equal(g, o)
+    gd, od = g.get_derived(), o.get_derived()
+    assert np.array_equal(gd[0][1:], od[0][1:]) and np.array_equal(gd[1][1:], od[1][1:])   # AABBs (around the origins), world inertias
+    for step in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if step % 20 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {step}")
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), step
+    gd, od = g.get_derived(), o.get_derived()
+    assert np.array_equal(gd[0][1:], od[0][1:])
+    assert np.isfinite(g.get_state()[0]).all() and g.get_state()[0][6, 1] < 0.35   # the weighted sphere rests heavy side down
