@@ -853,12 +853,16 @@ def _com_scene():
     return sc
 
 
-def test_center_of_mass_matches_the_real_engine():
+@pytest.mark.parametrize("bouncy", [False, True])
+def test_center_of_mass_matches_the_real_engine(bouncy):
     """rigidbody_def::center_of_mass (rigidbody.cpp:56-87,517-548): the parallel-axis shift of the shape's inertia, position and
     velocity moved to the centre of mass, shapes / contact pivots / joint pivots in the frame of the origin (update_origins.cpp,
     position_solver.hpp:34-41: origins follow position corrections, and are otherwise refreshed once per step) - initial state,
     AABBs and world inertias, then 300 steps bit-identical with the real engine."""
     sc = _com_scene()
+    if bouncy:   # the restitution solver anchors its pivots at the origins too (restitution_solver.cpp:166-220); bodies in islands of
+        sc["restitution"][:] = 0.6   # their own: with several manifolds the engine's graph-walk order is not reproduced (see above)
+        sc["joints"] = []; sc["pos"][1:, 0] += 5.0 * np.arange(len(sc["kind"]) - 1, dtype=np.float32)
     ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc)
     orc = ob.World(vel_iters=10, order=ob.ORDER_EXTERNAL); orc.add_bodies(sc)
     ad, od = ref.get_derived(), orc.get_derived()
@@ -873,4 +877,4 @@ def test_center_of_mass_matches_the_real_engine():
     ad, od = ref.get_derived(), orc.get_derived()
     assert np.array_equal(ad[0][1:].view(np.uint32), od[0][1:].view(np.uint32))
     # the loaded bodies came to rest heavy side down: their centres of mass sit below their origins
-    assert ref.get_state()[0][6, 1] < 0.35
+    assert bouncy or ref.get_state()[0][6, 1] < 0.35
