@@ -271,6 +271,13 @@ class World:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]; f.restype = None
         f(self.h, c.ctypes.data, len(c), j.ctypes.data, len(j))
 
+    def set_ext_restitution_walk(self, manifolds, adjacency):
+        """ORDER_EXTERNAL: the orders the real engine's restitution solver walks in (RefWorld.get_restitution_walk() of the same step)."""
+        m = np.ascontiguousarray(manifolds, np.uint32).reshape(-1, 2); a = np.ascontiguousarray(adjacency, np.uint32)
+        f = self.L.orc_set_ext_restitution_walk
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]; f.restype = None
+        f(self.h, m.ctypes.data, len(m), a.ctypes.data, len(a))
+
     def ext_order_mismatch(self):
         f = self.L.orc_ext_order_mismatch
         f.argtypes = [C.c_void_p]; f.restype = C.c_int
@@ -772,6 +779,14 @@ class RefWorld:
         g = self.L.refw_get_joint_order; g.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]; g.restype = C.c_uint32
         nc = f(self.h, c.ctypes.data, max_entries); nj = g(self.h, j.ctypes.data, len(j))
         return c[:nc].copy(), j[:nj].copy()
+
+    def get_restitution_walk(self, max_manifolds=1 << 20, max_words=1 << 23):
+        """(manifolds[n,2] in island edge order, adjacency words): what the last step's restitution solver walked by (ref_world.cpp)."""
+        m = np.zeros((max_manifolds, 2), np.uint32); a = np.zeros(max_words, np.uint32); nm = C.c_uint32(0)
+        f = self.L.refw_get_restitution_walk
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]; f.restype = C.c_uint32
+        na = f(self.h, m.ctypes.data, max_manifolds, C.byref(nm), a.ctypes.data, max_words)
+        return m[:nm.value].copy(), a[:na].copy()
 
     def get_joint_impulses(self):
         out = np.zeros((self.n_joints, 10), np.float32)

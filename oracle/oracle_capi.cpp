@@ -54,6 +54,18 @@ uint32_t orc_add_body(void *h, int kind, const float *pos, const float *orn, con
                        make_shape(shape_type, shape_param), inertia9 ? &I : nullptr, friction, restitution,
                        has_material != 0, group, mask, &g);
 }
+void orc_set_ext_restitution_walk(void *h, const uint32_t *manifolds2, uint32_t nm, const uint32_t *adj, uint32_t nwords) {
+    World *w = (World *)h;
+    w->ext_rest_manifolds.clear(); w->ext_adj.clear();
+    for (uint32_t i = 0; i < nm; ++i) w->ext_rest_manifolds.push_back({manifolds2[2 * i], manifolds2[2 * i + 1]});
+    for (uint32_t p = 0; p + 1 < nwords;) {
+        const uint32_t body = adj[p], count = adj[p + 1];
+        p += 2;
+        auto &lst = w->ext_adj[body];
+        for (uint32_t k = 0; k < count && p + 2 < nwords + 0u + 1u; ++k, p += 3) lst.push_back({adj[p], adj[p + 1], adj[p + 2]});
+    }
+    w->ext_walk_valid = true;
+}
 void orc_set_center_of_mass(void *h, uint32_t body, const float *com, float mass) { ((World *)h)->set_center_of_mass(body, v3(com), mass); }
 uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
                        const float *axisA, const float *axisB) {

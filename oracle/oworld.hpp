@@ -246,6 +246,12 @@ public:
     struct ExtContact { uint32_t a, b, slot; };
     std::vector<ExtContact> ext_contact_order;   // ORDER_EXTERNAL: every active contact point, in the reference's visiting order
     std::vector<uint32_t> ext_joint_order;       // ORDER_EXTERNAL: joint indices, in the reference's visiting order
+    // ORDER_EXTERNAL, restitution solver: the island edge-list order of the manifolds and every connecting body's adjacency in the real
+    // engine's entity graph (ref_world.cpp refw_get_restitution_walk) - one step's worth, consumed by the next solve_restitution()
+    struct ExtAdj { uint32_t other, ma, mb; };   // neighbour body; the edge's manifold (body[0], body[1]) or ~0 for a non-contact edge
+    std::vector<std::array<uint32_t, 2>> ext_rest_manifolds;
+    std::map<uint32_t, std::vector<ExtAdj>> ext_adj;
+    bool ext_walk_valid = false;
     std::vector<Body> bodies;
     std::vector<Joint> joints;
     std::map<uint64_t, Manifold> manifolds;
@@ -1534,11 +1540,22 @@ public:
         std::vector<std::vector<Manifold *>> adj(n);
         std::map<uint32_t, std::vector<Manifold *>> by_island;
         auto label_of = [&](uint32_t a, uint32_t b) { return bodies[a].procedural() ? island_label[a] : island_label[b]; };
+        const bool ext = order == ORDER_EXTERNAL && ext_walk_valid;
+        ext_walk_valid = false;
+        if (ext) {   // the island edge-list order of the real engine (the fastest-manifold search keeps the first minimum)
+            for (auto &ab : ext_rest_manifolds) {
+                auto it = manifolds.find(pair_key(ab[0], ab[1]));
+                if (it == manifolds.end()) { ext_order_mismatch = true; continue; }
+                Manifold &m = it->second;
+                if (manifold_asleep(m)) continue;
+                by_island[label_of(m.body[0], m.body[1])].push_back(&m);
+            }
+        }
         for (auto &kv : manifolds) {
             Manifold &m = kv.second;
             if (manifold_asleep(m)) continue;   // island_view excludes sleeping islands
             adj[m.body[0]].push_back(&m); adj[m.body[1]].push_back(&m);
-            by_island[label_of(m.body[0], m.body[1])].push_back(&m);
+            if (!ext) by_island[label_of(m.body[0], m.body[1])].push_back(&m);
         }
         const float threshold = -0.005f;
         std::vector<uint8_t> island_done(n, 0);
@@ -1561,6 +1578,29 @@ public:
                 uint32_t start;
                 if (sA > sB) start = FA.procedural() ? fastest->body[0] : fastest->body[1];
                 else start = FB.procedural() ? fastest->body[1] : fastest->body[0];
+                if (ext) {   // entity_graph::traverse (entity_graph.hpp:356-422) over the real engine's adjacency order
+                    std::vector<uint8_t> seen(n, 0);
+                    std::vector<uint32_t> to_visit{start};
+                    while (!to_visit.empty()) {
+                        const uint32_t node = to_visit.back();
+                        to_visit.pop_back();
+                        seen[node] = 1;
+                        if (!bodies[node].procedural()) continue;   // non-connecting: neither solved from nor walked through
+                        auto ait = ext_adj.find(node);
+                        if (ait == ext_adj.end()) continue;
+                        std::vector<Manifold *> star;
+                        for (const ExtAdj &e : ait->second) {   // graph.visit_edges(node): adjacency by adjacency, edge by edge
+                            if (e.ma == 0xFFFFFFFFu) continue;
+                            auto it = manifolds.find(pair_key(e.ma, e.mb));
+                            if (it == manifolds.end()) { ext_order_mismatch = true; continue; }
+                            if (manifold_min_relvel(it->second) < threshold) star.push_back(&it->second);
+                        }
+                        if (!star.empty()) restitution_solve_star(star);
+                        for (const ExtAdj &e : ait->second)   // neighbours in adjacency order, each put at the FRONT (breadth first)
+                            if (!seen[e.other]) { to_visit.insert(to_visit.begin(), e.other); seen[e.other] = 1; }
+                    }
+                    continue;
+                }
                 std::vector<uint8_t> visited(n, 0);
                 std::vector<uint32_t> queue{start};
                 visited[start] = 1;

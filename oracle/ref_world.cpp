@@ -26,6 +26,8 @@
 #include <edyn/util/rigidbody.hpp>
 #include <edyn/util/ragdoll.hpp>
 #include <edyn/constraints/null_constraint.hpp>
+#include <edyn/core/entity_graph.hpp>
+#include <edyn/comp/graph_node.hpp>
 #include <edyn/comp/collision_exclusion.hpp>
 #include <edyn/comp/collision_filter.hpp>
 #include <entt/entity/registry.hpp>
@@ -678,6 +680,51 @@ void refw_export_joint(void *h, uint32_t joint, int32_t *type, uint32_t *ab, flo
         p16[7] = cv->twist_stiffness; p16[8] = cv->twist_damping; p16[9] = cv->rest_direction[0]; p16[10] = cv->rest_direction[1]; p16[11] = cv->rest_direction[2];
         p16[12] = cv->bend_stiffness; p16[13] = cv->bend_friction_torque; p16[14] = cv->bend_damping;
     }
+}
+// What the restitution solver's walk depends on (restitution_solver.cpp:86-385): the order of the manifolds in each island's edge list
+// (the search for the fastest closing manifold keeps the FIRST minimum) and the entity graph's adjacency order (graph.traverse inserts
+// neighbours in adjacency order, graph.visit_edges lists a node's edges adjacency by adjacency). Exported after a step, they are the
+// orders that step's restitution solve used (the solver does not edit the graph).
+//   manifolds: 2 uint32 per manifold edge (body[0], body[1]) in island order.
+//   adjacency: per connecting node [body, n, n x (other body, manifold body[0] or ~0, manifold body[1] or ~0)] in visit_edges order.
+uint32_t refw_get_restitution_walk(void *h, uint32_t *manifolds2, uint32_t max_manifolds, uint32_t *num_manifolds, uint32_t *adj, uint32_t max_words) {
+    auto *w = (ref_world *)h;
+    auto &reg = w->registry;
+    auto manifold_view = reg.view<edyn::contact_manifold>();
+    uint32_t nm = 0;
+    for (auto [ie, isl] : reg.view<edyn::island>().each())
+        for (auto edge : isl.edges) {
+            if (!manifold_view.contains(edge)) continue;
+            auto &m = manifold_view.get<edyn::contact_manifold>(edge);
+            if (nm < max_manifolds) { manifolds2[2 * nm] = w->body_index(m.body[0]); manifolds2[2 * nm + 1] = w->body_index(m.body[1]); }
+            ++nm;
+        }
+    *num_manifolds = nm;
+    auto &graph = reg.ctx().get<edyn::entity_graph>();
+    uint32_t n = 0;
+    auto put = [&](uint32_t v) { if (n < max_words) adj[n] = v; ++n; };
+    for (uint32_t bi = 0; bi < w->bodies.size(); ++bi) {
+        const auto e = w->bodies[bi];
+        if (!reg.valid(e) || !reg.all_of<edyn::graph_node>(e)) continue;
+        const auto node_index = reg.get<edyn::graph_node>(e).node_index;
+        if (!graph.is_connecting_node(node_index)) continue;
+        put(bi);
+        const uint32_t count_at = n; put(0);
+        uint32_t count = 0;
+        graph.visit_edges(node_index, [&](auto edge_index) {
+            const auto ents = graph.edge_node_entities(edge_index);
+            const auto other = ents.first == e ? ents.second : ents.first;
+            const auto edge_entity = graph.edge_entity(edge_index);
+            put(w->body_index(other));
+            if (manifold_view.contains(edge_entity)) {
+                auto &m = manifold_view.get<edyn::contact_manifold>(edge_entity);
+                put(w->body_index(m.body[0])); put(w->body_index(m.body[1]));
+            } else { put(0xFFFFFFFFu); put(0xFFFFFFFFu); }
+            ++count;
+        });
+        if (count_at < max_words) adj[count_at] = count;
+    }
+    return n;
 }
 uint32_t refw_sizeof_manifold_rec() { return (uint32_t)sizeof(manifold_rec); }
 
