@@ -41,7 +41,7 @@ typedef enum {
     EDYNHIP_ERR_HIP = -3,           /* a HIP runtime call failed (see edynhip_last_error) */
     EDYNHIP_ERR_CAPACITY = -4,      /* pair / manifold capacity exceeded */
     EDYNHIP_ERR_COLOURS = -5,       /* a body has more joints than joint colours (64); contacts have no such limit */
-    EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope (e.g. a joint type other than point / hinge) */
+    EDYNHIP_ERR_UNSUPPORTED = -6,   /* feature outside the hot-path scope (e.g. a cylinder / polyhedron / mesh shape) */
     EDYNHIP_ERR_INTERNAL = -7       /* a device-side invariant failed (e.g. the dataflow solve timed out waiting for a hand-off) */
 } edynhip_status;
 
@@ -183,8 +183,8 @@ int edynhip_set_joints(edynhip_ctx *ctx, uint32_t n, const edynhip_joints *joint
 /* Append `n` bodies after the existing ones (indices num_bodies .. num_bodies+n-1). Existing bodies, their contact
  * manifolds (cached impulses, colours) and joints are untouched: this is registry.create + make_rigidbody on a running
  * world (src/edyn/util/rigidbody.cpp:18-161; the reference's island worker receives the new entities through
- * registry_operation insertions, src/edyn/simulation/simulation_worker.cpp). Removal is not supported without a
- * full edynhip_set_bodies (indices would shift) - or edynhip_remove_bodies, which keeps indices by leaving a tombstone. */
+ * registry_operation insertions, src/edyn/simulation/simulation_worker.cpp). To remove bodies: edynhip_remove_bodies, which keeps
+ * every other index by leaving a tombstone. */
 int edynhip_add_bodies(edynhip_ctx *ctx, uint32_t n, const edynhip_bodies *bodies);
 
 /* Joints on a running world: make_constraint / registry.destroy(constraint entity) (include/edyn/util/constraint_util.hpp:38-54,
