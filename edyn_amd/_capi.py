@@ -71,7 +71,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_joints", "edynhip_step", "edynhip_run_stages", "edynhip_synchronize", "edynhip_get_state",
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
-           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies",
+           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies", "edynhip_set_center_of_mass",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
            "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
@@ -114,6 +114,7 @@ def lib():
         L.edynhip_get_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_wake_all.argtypes = [C.c_void_p]
         L.edynhip_wake_bodies.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.edynhip_set_center_of_mass.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.edynhip_refresh_derived.argtypes = [C.c_void_p]
         L.edynhip_get_contact_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -481,7 +481,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 8; }   // 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 9; }   // 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1140,6 +1140,31 @@ int edynhip_wake_bodies(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
     if (n == 0) return EDYNHIP_OK;
     EH_HIP(c, hipSetDevice(c->device));
     return wake_islands_of(c, std::vector<uint32_t>(indices, indices + n));
+}
+__global__ void k_move_com(Bodies b, uint32_t i, float3 com_new) {
+    const f3 com = mk3(com_new.x, com_new.y, com_new.z);
+    const float4 p4 = B_POS(b, i);
+    const f3 pos = from4(p4);
+    const q4 orn = q_from4(B_ORN(b, i));
+    const f3 origin = b.com[i].w != 0.0f ? to_world(-from4(b.com[i]), pos, orn) : pos;
+    const f3 com_world = to_world(com, origin, orn);
+    if ((b.flags[i] & BF_KIND_MASK) != EDYNHIP_KIND_STATIC) b.linvel[i] = to4(from4(b.linvel[i]) + cross(from4(b.angvel[i]), com_world - pos), 0);
+    B_POS(b, i) = to4(com_world, p4.w);
+    const bool has = !(com.x == 0 && com.y == 0 && com.z == 0);
+    b.com[i] = to4(has ? com : mk3(0, 0, 0), has ? 1.0f : 0.0f);
+    b.origin[i] = to4(origin, 0);
+}
+int edynhip_set_center_of_mass(edynhip_ctx *c, uint32_t body, const float *com3) {
+    if (!c || !com3 || body >= c->b.n) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    if (!c->b.com) {   // the first offset of this world: attach the (zeroed) origin arrays
+        EH_HIP(c, hipMemsetAsync(c->com_store, 0, (size_t)c->b.cap * sizeof(float4), c->stream));
+        c->b.com = c->com_store; c->b.origin = c->origin_store;
+    }
+    hipLaunchKernelGGL(k_move_com, dim3(1), dim3(1), 0, c->stream, c->b, body, make_float3(com3[0], com3[1], com3[2]));
+    EH_HIP(c, hipGetLastError());
+    c->bvh.lists_dirty = true;   // (the reference does not wake the body's island either)
+    return EDYNHIP_OK;
 }
 int edynhip_get_asleep(edynhip_ctx *c, uint8_t *asleep) {
     if (!c || !asleep) return EDYNHIP_ERR_INVALID;

@@ -486,6 +486,12 @@ class World:
     def wake_all(self):
         self._check(self._L.edynhip_wake_all(self._h))
 
+    def move_center_of_mass(self, body, com):
+        """edyn::set_center_of_mass on a running world."""
+        self._flush_defs()
+        c3 = np.ascontiguousarray(com, np.float32)
+        self._check(self._L.edynhip_set_center_of_mass(self._h, int(body), _ptr(c3)))
+
     def wake_bodies(self, indices):
         """edyn::wake_up_entity for the listed bodies: wakes their islands."""
         idx = np.ascontiguousarray(indices, np.uint32)

@@ -967,6 +967,33 @@ inline vector3 get_rigidbody_origin(entt::registry &registry, entt::entity entit
     if (auto *o = registry.try_get<origin>(entity)) return *o;
     return registry.get<position>(entity);
 }
+/// util/rigidbody.hpp:182, rigidbody.cpp:364-370,517-548: the body's centre of mass moves (in the shape's frame); its origin stays
+inline void set_center_of_mass(entt::registry &registry, entt::entity entity, const vector3 &com) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const auto &q = registry.get<orientation>(entity);
+    auto rot = [&](vector3 c) {
+        const vector3 u{q.x, q.y, q.z};
+        const vector3 t{2 * (u.y * c.z - u.z * c.y), 2 * (u.z * c.x - u.x * c.z), 2 * (u.x * c.y - u.y * c.x)};
+        return vector3{c.x + q.w * t.x + (u.y * t.z - u.z * t.y), c.y + q.w * t.y + (u.z * t.x - u.x * t.z), c.z + q.w * t.z + (u.x * t.y - u.y * t.x)};
+    };
+    auto &p = registry.get<position>(entity);
+    vector3 org{p.x, p.y, p.z};
+    if (auto *old = registry.try_get<center_of_mass>(entity)) { const vector3 r = rot({-old->x, -old->y, -old->z}); org = {p.x + r.x, p.y + r.y, p.z + r.z}; }
+    const vector3 rc = rot(com), cw{org.x + rc.x, org.y + rc.y, org.z + rc.z}, d{cw.x - p.x, cw.y - p.y, cw.z - p.z};
+    if (auto *v = registry.try_get<linvel>(entity)) {
+        const auto &w = registry.get<angvel>(entity);
+        v->x += w.y * d.z - w.z * d.y; v->y += w.z * d.x - w.x * d.z; v->z += w.x * d.y - w.y * d.x;
+    }
+    p.x = cw.x; p.y = cw.y; p.z = cw.z;
+    const bool has = com.x != 0 || com.y != 0 || com.z != 0;
+    if (has) { registry.emplace_or_replace<center_of_mass>(entity, center_of_mass{com}); registry.emplace_or_replace<origin>(entity, origin{org}); }
+    else { registry.remove<center_of_mass>(entity); registry.remove<origin>(entity); }
+    const auto *bi = registry.try_get<detail::body_index>(entity);
+    if (bi && s.ctx && bi->value < s.uploaded_bodies && !s.scene_dirty) {
+        const float c3[3] = {com.x, com.y, com.z};
+        detail::check(s, edynhip_set_center_of_mass(s.ctx, bi->value, c3));   // the device does the same on its copy
+    }
+}
 /// rigidbody.cpp:228-246
 inline void rigidbody_apply_impulse(entt::registry &registry, entt::entity entity, const vector3 &impulse, const vector3 &rel_location) {
     if (!registry.all_of<dynamic_tag>(entity)) return;

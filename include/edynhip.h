@@ -327,6 +327,10 @@ int edynhip_get_asleep(edynhip_ctx *ctx, uint8_t *asleep);
 int edynhip_wake_all(edynhip_ctx *ctx);
 /* wake_up_entity (util/rigidbody.cpp:409-415 -> island_manager.cpp wake_up_island): wakes the islands of the listed bodies. */
 int edynhip_wake_bodies(edynhip_ctx *ctx, uint32_t n, const uint32_t *indices);
+/* edyn::set_center_of_mass on a running world (util/rigidbody.cpp:364-370, apply_center_of_mass :517-548): the body's position and linear
+ * velocity move to the new centre of mass (given in the shape's frame; zero removes the offset), its origin - shape, contact and joint
+ * pivots - stays where it is, its inertia is not changed. */
+int edynhip_set_center_of_mass(edynhip_ctx *ctx, uint32_t body, const float *com3);
 
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);

@@ -252,6 +252,11 @@ class World:
         f = self.L.orc_set_center_of_mass; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.c_float]; f.restype = None
         f(self.h, body, _fp(_f32(com, 3)), mass)
 
+    def move_center_of_mass(self, body, com):
+        """edyn::set_center_of_mass on a running world: position / linear velocity follow the new centre of mass, the inertia stays."""
+        f = self.L.orc_move_center_of_mass; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, body, _fp(_f32(com, 3)))
+
     def exclude_collision(self, a, b):
         f = self.L.orc_exclude_collision; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
         f(self.h, a, b)
@@ -563,6 +568,10 @@ class RefWorld:
         return self.L.refw_add_body(self.h, kind, _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), _fp(_f32(linvel, 3)),
                                     _fp(_f32(angvel, 3)), mass, shape_type, _fp(_f32(shape_param, 4)), I,
                                     friction, restitution, int(has_material), group, mask, g, int(sleeping_disabled))
+
+    def move_center_of_mass(self, body, com):
+        f = self.L.refw_set_center_of_mass; f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]; f.restype = None
+        f(self.h, body, _fp(_f32(com, 3)))
 
     def next_center_of_mass(self, com):
         """rigidbody_def::center_of_mass of the next add_body (whose position is then the origin)."""

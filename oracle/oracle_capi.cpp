@@ -67,6 +67,7 @@ void orc_set_ext_restitution_walk(void *h, const uint32_t *manifolds2, uint32_t 
     w->ext_walk_valid = true;
 }
 void orc_set_center_of_mass(void *h, uint32_t body, const float *com, float mass) { ((World *)h)->set_center_of_mass(body, v3(com), mass); }
+void orc_move_center_of_mass(void *h, uint32_t body, const float *com) { ((World *)h)->set_center_of_mass(body, v3(com), 0.0f, false); }
 uint32_t orc_add_joint(void *h, int type, uint32_t a, uint32_t b, const float *pivotA, const float *pivotB,
                        const float *axisA, const float *axisB) {
     return ((World *)h)->add_joint(type, a, b, v3(pivotA), v3(pivotB), v3(axisA), v3(axisB));

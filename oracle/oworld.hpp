@@ -361,9 +361,9 @@ public:
     // rigidbody_def::center_of_mass right after add_body (rigidbody.cpp:56-87): an inertia derived from the shape is shifted by the
     // parallel-axis theorem (moment_of_inertia.cpp:217-220), then apply_center_of_mass (rigidbody.cpp:517-548): the position given to
     // add_body is the ORIGIN; position and linear velocity move to the centre of mass.
-    void set_center_of_mass(uint32_t i, vec3 com, float mass) {
+    void set_center_of_mass(uint32_t i, vec3 com, float mass, bool at_creation = true) {   // at_creation = false: edyn::set_center_of_mass on a running world (rigidbody.cpp:364-370): apply_center_of_mass only
         Body &b = bodies[i];
-        if (b.kind == KIND_DYNAMIC && b.inertia_from_shape) {
+        if (at_creation && b.kind == KIND_DYNAMIC && b.inertia_from_shape) {
             const mat3 d = skew(com);
             const mat3 dd = transpose(d) * d;
             mat3 I;

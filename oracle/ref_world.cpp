@@ -178,6 +178,7 @@ uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, co
     return (uint32_t)w->bodies.size() - 1;
 }
 
+void refw_set_center_of_mass(void *h, uint32_t body, const float *com) { auto *w = (ref_world *)h; edyn::set_center_of_mass(w->registry, w->bodies[body], v3(com)); }
 // rigidbody_def::center_of_mass for the NEXT refw_add_body call (the position passed there is then the origin).
 void refw_next_center_of_mass(void *h, const float *com) { auto *w = (ref_world *)h; w->next_com = v3(com); w->has_next_com = true; }
 // type 0 = point_constraint, 1 = hinge_constraint (set_axes(axisA, axisB)).

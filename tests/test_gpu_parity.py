@@ -1355,3 +1355,27 @@ def test_center_of_mass_bit_exact(bouncy):
     gd, od = g.get_derived(), o.get_derived()
     assert np.array_equal(gd[0][1:], od[0][1:])
     assert np.isfinite(g.get_state()[0]).all() and (bouncy or g.get_state()[0][6, 1] < 0.35)   # the weighted sphere rests heavy side down
+
+
+def test_center_of_mass_moved_on_a_running_world_bit_exact():
+    """edynhip_set_center_of_mass (edyn::set_center_of_mass between steps): a first offset on a world that had none attached yet,
+    an offset changed and an offset removed - position / velocity follow, origins and pivots stay; against the oracle (pinned to the real
+    engine in tests/test_reference_engine.py::test_center_of_mass_moved_on_a_running_world_matches_the_real_engine)."""
+    from test_reference_engine import _com_scene
+    for start_without in (False, True):
+        sc = _com_scene()
+        if start_without:
+            sc["com"][:] = 0   # the origin arrays are attached by the first edit
+        g, o = gpu_world(sc), oracle_world(sc)
+        edits = {40: (2, (0.1, 0.2, 0.0)), 80: (1, (0.0, 0.0, 0.0)), 120: (6, (0.1, -0.1, 0.2))}
+        for step in range(1, 201):
+            if step in edits:
+                body, com = edits[step]
+                g.move_center_of_mass(body, com); o.move_center_of_mass(body, com)
+                assert_state_equal(g, o)
+            g.step_simulation(1); o.step(1)
+            if step % 20 == 0 or step in (41, 81, 121):
+                assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+                assert_state_equal(g, o)
+                assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {step}")
+        assert np.isfinite(g.get_state()[0]).all()

@@ -903,3 +903,26 @@ def test_center_of_mass_matches_the_real_engine(bouncy):
     assert np.array_equal(ad[0][1:].view(np.uint32), od[0][1:].view(np.uint32))
     # the loaded bodies came to rest heavy side down: their centres of mass sit below their origins
     assert bouncy or ref.get_state()[0][6, 1] < 0.35
+
+
+def test_center_of_mass_moved_on_a_running_world_matches_the_real_engine():
+    """edyn::set_center_of_mass between steps (rigidbody.cpp:364-370 -> apply_center_of_mass :517-548): position and linear velocity
+    follow the centre of mass, the origin - with every contact and joint pivot - stays, the inertia is not touched; giving a body its
+    first offset, changing one and removing one (offset zero drops the origin), each bit-identical with the real engine afterwards."""
+    sc = _com_scene()
+    ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc)
+    orc = ob.World(vel_iters=10, order=ob.ORDER_EXTERNAL); orc.add_bodies(sc)
+    edits = {40: (2, (0.1, 0.2, 0.0)), 80: (1, (0.0, 0.0, 0.0)), 120: (6, (0.1, -0.1, 0.2))}   # first offset, removal, change
+    for s in range(1, 241):
+        if s in edits:
+            body, com = edits[s]
+            ref.move_center_of_mass(body, com); orc.move_center_of_mass(body, com)
+            for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (s, "edit", name)
+        ref.step(1)
+        orc.set_ext_order(*ref.get_solve_order()); orc.set_ext_restitution_walk(*ref.get_restitution_walk()); orc.step(1)
+        assert not orc.ext_order_mismatch(), s
+        for name, a, b in zip(("pos", "orn", "linvel", "angvel"), ref.get_state(), orc.get_state()):
+            assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (s, name)
+    ad, od = ref.get_derived(), orc.get_derived()
+    assert np.array_equal(ad[0][1:].view(np.uint32), od[0][1:].view(np.uint32))
