@@ -216,6 +216,7 @@ struct gpu_stepper {
     struct mixing { uint32_t id0, id1; float v[6]; };
     std::vector<mixing> mixings;   // insert_material_mixing calls, replayed into a (re)created context
     bool refresh_friction{false};  // set_rigidbody_friction: the carried contact points take the bodies' current materials (rigidbody.cpp:324-350)
+    std::vector<uint32_t> reshaped;   // bodies whose shape / kind changed: their contacts are detected afresh by the re-created context
     bool recreate{false};          // a body's mass / inertia / material was edited: the next upload re-creates the context (contacts, joints and sleep state are carried)
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
@@ -303,6 +304,11 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             check(s, edynhip_num_manifolds(s.ctx, &m));
             carried.resize(m);
             if (m) check(s, edynhip_get_manifolds(s.ctx, carried.data(), m, &m));
+            if (!s.reshaped.empty()) {   // rigidbody_set_shape / set_kind: the old contacts of those bodies mean nothing to the new shape / kind
+                carried.erase(std::remove_if(carried.begin(), carried.end(), [&](const edynhip_manifold &rec) {
+                    return std::find(s.reshaped.begin(), s.reshaped.end(), rec.body[0]) != s.reshaped.end() || std::find(s.reshaped.begin(), s.reshaped.end(), rec.body[1]) != s.reshaped.end(); }), carried.end());
+                s.reshaped.clear();
+            }
             if (s.refresh_friction) {   // set_rigidbody_friction: existing points take the mixed friction of the current materials, except
                 for (auto &rec : carried) {   // pairs combined through the material mix table (rigidbody.cpp:324-350)
                     const entt::entity ea = s.bodies[rec.body[0]], eb = s.bodies[rec.body[1]];
@@ -1042,6 +1048,32 @@ inline void set_rigidbody_inertia(entt::registry &registry, entt::entity entity,
 inline void set_rigidbody_friction(entt::registry &registry, entt::entity entity, scalar friction) {   // (existing contact points take the new value with the re-created context)
     registry.get<material>(entity).friction = friction;
     auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = s.refresh_friction = true;
+}
+/// util/rigidbody.hpp:235-257 (rigidbody.cpp:417-515): another shape / no shape, another kind - through a re-created context like the edits above
+inline bool rigidbody_has_shape(entt::registry &registry, entt::entity entity) { return registry.any_of<box_shape, sphere_shape, plane_shape, capsule_shape>(entity); }
+inline void rigidbody_set_shape(entt::registry &registry, entt::entity entity, std::optional<shapes_variant_t> shape_opt) {
+    registry.remove<box_shape>(entity); registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity);
+    if (shape_opt) std::visit([&](auto &&sh) { registry.emplace<std::decay_t<decltype(sh)>>(entity, sh); }, *shape_opt);
+    auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
+    if (auto *bi = registry.try_get<detail::body_index>(entity)) s.reshaped.push_back(bi->value);
+}
+inline void rigidbody_set_kind(entt::registry &registry, entt::entity entity, rigidbody_kind kind) {
+    registry.remove<dynamic_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<kinematic_tag>(entity); registry.remove<static_tag>(entity);
+    if (kind == rigidbody_kind::rb_dynamic) {
+        registry.emplace<dynamic_tag>(entity); registry.emplace<procedural_tag>(entity);
+        if (!registry.all_of<mass>(entity)) { registry.emplace<mass>(entity, mass{1}); registry.emplace<mass_inv>(entity, mass_inv{1}); }
+        if (!registry.all_of<gravity>(entity)) registry.emplace<gravity>(entity, gravity{registry.ctx().get<detail::gpu_stepper>().cfg.gravity});
+    } else if (kind == rigidbody_kind::rb_kinematic) registry.emplace<kinematic_tag>(entity);
+    else registry.emplace<static_tag>(entity);
+    if (kind != rigidbody_kind::rb_static) {
+        if (!registry.all_of<linvel>(entity)) registry.emplace<linvel>(entity, linvel{});
+        if (!registry.all_of<angvel>(entity)) registry.emplace<angvel>(entity, angvel{});
+    } else {   // static bodies do not move (rigidbody.cpp:480-486 zeroes the velocities)
+        if (auto *v = registry.try_get<linvel>(entity)) *v = linvel{};
+        if (auto *w = registry.try_get<angvel>(entity)) *w = angvel{};
+    }
+    auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
+    if (auto *bi = registry.try_get<detail::body_index>(entity)) s.reshaped.push_back(bi->value);
 }
 /// rigidbody.cpp:409-415 -> island_manager wake_up_island
 inline void wake_up_entity(entt::registry &registry, entt::entity entity) {

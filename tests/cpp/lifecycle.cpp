@@ -154,6 +154,14 @@ int main() {
         edyn::rigidbody_apply_impulse(registry, puck, {8, 0, 0}, {0, 0, 0});   // 2 m/s
         run(60);
         CHECK(registry.get<edyn::position>(puck).x > 21.8f && std::fabs(registry.get<edyn::linvel>(puck).x - 2.0f) < 0.05f);
+        // another shape and another kind on a running world: the puck becomes a ball, then a static obstacle that no longer falls
+        edyn::rigidbody_set_shape(registry, puck, edyn::shapes_variant_t{edyn::sphere_shape{0.5f}});
+        run(30);
+        CHECK(edyn::rigidbody_has_shape(registry, puck) && registry.all_of<edyn::sphere_shape>(puck) && !registry.all_of<edyn::box_shape>(puck));
+        edyn::rigidbody_set_kind(registry, puck, edyn::rigidbody_kind::rb_static);
+        const float frozen_x = registry.get<edyn::position>(puck).x;
+        run(30);
+        CHECK(registry.all_of<edyn::static_tag>(puck) && registry.get<edyn::position>(puck).x == frozen_x);
         // a kinematic platform moved by the user: its velocity is what takes it there in dt
         auto kdef = edyn::rigidbody_def{};
         kdef.kind = edyn::rigidbody_kind::rb_kinematic;
