@@ -299,6 +299,7 @@ struct edynhip_ctx {
     uint32_t isl_prep_step = 0xFFFFFFF0u;   // step_index of the last step that bucketed its constraints by island (its isl_max_items reaches cnt_host with the next step's fetch)
     uint32_t last_fetch_step = 0xFFFFFFF0u; // step_index during which fetch_counters last ran
     uint32_t topology_epoch = 0;            // bumped when bodies or joints are added / removed / redefined
+    uint32_t isl_lists_epoch = 0xFFFFFFFFu;   // topology_epoch the island lists were built for, while they can be kept (joints only, no contacts, no sleeping)
     uint32_t isl_cache_epoch = 0xFFFFFFFFu, isl_cache_max = 0, isl_cache_free = 0, isl_cache_jmax = 0;   // largest island of a scene whose steps fetch no counters (no shapes, no contacts)
     float *isl_err = nullptr;      // per island label: max position error (as uint bits)
     uint32_t *isl_done = nullptr;
