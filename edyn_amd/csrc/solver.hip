@@ -2735,9 +2735,9 @@ int solve(edynhip_ctx *c) {
         }
     }
     constexpr uint32_t kMixedMinFree = 1024;   // manifolds outside jointed islands that make the dataflow launch worth its fixed cost
-    const bool mixed = isl_candidate && mixed_env && j.n > 0 && !c->extras && na > 0 && c->df_mode == 1 && c->cfg.num_position_iterations <= kMaxDfPosIters &&
+    bool mixed = isl_candidate && mixed_env && j.n > 0 && !c->extras && na > 0 && c->df_mode == 1 && c->cfg.num_position_iterations <= kMaxDfPosIters &&
                        free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit && !c->b.com;
-    const bool push = na > 0 && !serial && (contacts_only || mixed);
+    bool push = na > 0 && !serial && (contacts_only || mixed);
     if (na) {
         if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
         else hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
@@ -2767,6 +2767,17 @@ int solve(edynhip_ctx *c) {
         }
         c->isl_prep_step = c->step_index;
         isl_fused = !mixed && largest <= kIslFusedLimit;
+        // The decision above came from the PREVIOUS step's islands. Islands can merge in one step (a rag doll falls onto the pile), and
+        // a wave that finds itself with a 100 000-constraint island would need a large fraction of a second for it: confirm with this
+        // step's sizes (one more counter fetch, ~15 us, only on the fused / mixed schedules and only when the lists were rebuilt)
+        if ((isl_fused || mixed) && !keep_lists) {
+            EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
+            if (isl_fused && c->cnt_host->isl_max_items > kIslFusedLimit) isl_fused = false;
+            if (mixed && c->cnt_host->isl_max_jitems > kIslFusedLimit) {   // the jointed islands outgrew the fused kernels: the whole step per colour
+                mixed = false; push = false;
+                if (na) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, false);
+            }
+        }
     }
     if (push) {
         hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr);

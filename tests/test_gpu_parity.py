@@ -1379,3 +1379,33 @@ def test_center_of_mass_moved_on_a_running_world_bit_exact():
                 assert_state_equal(g, o)
                 assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {step}")
         assert np.isfinite(g.get_state()[0]).all()
+
+
+def test_ragdoll_landing_on_the_pile_leaves_the_mixed_schedule_in_the_same_step():
+    """Two rag dolls stand beside a 1 152-box pile, a third is dropped onto it: until it lands the step runs the mixed schedule (dataflow
+    for the pile, island-fused kernels for the figures); in the step the figure touches the pile the jointed island becomes the pile
+    itself - ~7 000 constraints, far beyond what one wave should solve - and the stepper, which confirms its choice with the CURRENT
+    step's island sizes, takes the per-colour launches from that very step on. Bit-exact against the oracle throughout."""
+    pile = scenes.box_pile(12, 8, 12)
+    tpl = scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz"))
+    beside = scenes.figures(tpl, 2, 1, pitch=1.6, floor=False)
+    beside["pos"][:, 0] += np.float32(25.0)
+    above = scenes.figures(tpl, 1, 1, floor=False, hip_height=float(pile["pos"][:, 1].max()) + 2.2)
+    above["pos"][:, 0] += np.float32(6.0); above["pos"][:, 2] += np.float32(6.0)
+    sc = scenes.merge(scenes.merge(pile, beside), above)
+    g = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, timing=True))
+    g.set_scene(sc)
+    o = oracle_world(sc)
+    scenes.apply_figure_settings(g, sc); scenes.apply_figure_settings(o, sc)
+    launches = []
+    for step in range(1, 91):
+        g.step_simulation(1); o.step(1)
+        launches.append(g.get_timings()["solve_velocity_launches"])
+        if step % 15 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+            assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32)), step
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="figure on the pile")
+    mixed_steps = [i for i, n in enumerate(launches) if n == 2]
+    assert len(mixed_steps) > 10 and launches[-1] > 20, launches        # mixed while the figure falls, per colour once it has landed
+    assert max(mixed_steps) < len(launches) - 10 and all(n > 20 for n in launches[max(mixed_steps) + 1:]), launches
