@@ -574,6 +574,7 @@ int broadphase(edynhip_ctx *c) {
         static const bool inplace_env = !(getenv("EDYNHIP_INPLACE") && getenv("EDYNHIP_INPLACE")[0] == '0');
         if (inplace_env && c->full_step && M > 0 && M == pm && !c->cnt_host->pairs_differ && !c->events && !c->force_islands) {
             c->points_in_prev = false;
+            c->inplace_step = true;
             c->prev_num_manifolds = pm;
             c->num_manifolds = M;
             EH_HIP(c, hipGetLastError());

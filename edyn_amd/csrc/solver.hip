@@ -2585,11 +2585,17 @@ int islands(edynhip_ctx *c) {
     // No manifold now or in the previous step, nothing edited, no sleep decisions to take: the labels stand and every kernel below would
     // return at once - not launched at all (a world of joints only: 4 of its ~20 launches per step)
     if (!force && M == 0 && pm == 0 && !c->sleeping && c->full_step) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.island, c->cnt, pm, force, mf, M, c->b.flags);
-    if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt, pm, force);
-    if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
-    hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
-    hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
+    // An in-place step (broadphase.hip: the pair set is last step's, read by the host with the pair count) leaves `pairs_changed` clear:
+    // all five kernels would take cc_mode's CC_SKIP exit - ~20 us of launches that a settled or sleeping world does not pay
+    const bool relabel = force || !c->inplace_step;
+    c->inplace_step = false;
+    if (relabel) {
+        hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.island, c->cnt, pm, force, mf, M, c->b.flags);
+        if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt, pm, force);
+        if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
+        hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
+        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
+    }
     if (c->sleeping) {
         hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
         hipLaunchKernelGGL(k_sleep_edges, dim3(32), dim3(256), 0, s, c->new_edges, c->cnt, c->b.island, c->sleep_state);
