@@ -548,7 +548,11 @@ int broadphase(edynhip_ctx *c) {
         // body has moved too far (checked on the device by the previous step's k_finish: Counters::bp_rebuild) or when the
         // host touched the bodies in between (lists_dirty), and always in a stand-alone stage run.
         const CandLists cl{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max};
-        const uint32_t force = (c->bvh.lists_dirty || !c->full_step || !bp_lists_enabled()) ? 1u : 0u;
+        // A new topology also needs its boxes: the node records (box + left child + rope) are only written by the refit, and a body
+        // whose list overflowed walks the tree in k_bp_pairs EVERY step - with last refit's records under this step's leaf order it
+        // would test the wrong bodies (found by the settled C3 scene: fast spheres, lists of > 64 candidates, pairs lost in the step
+        // after a topology rebuild). So a rebuild step refits and re-walks.
+        const uint32_t force = (c->bvh.lists_dirty || !c->full_step || !bp_lists_enabled() || rebuild) ? 1u : 0u;
         c->bvh.lists_dirty = false;
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
                            sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));

@@ -1248,6 +1248,10 @@ int edynhip_set_manifolds(edynhip_ctx *c, const edynhip_manifold *in, uint32_t n
     c->force_islands = true;
     c->all_asleep = false;
     c->clears_primed = false;
+    // colouring state that travels with the records: the number of colours in use (the next step releases the top one)
+    c->num_colours = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (in[i].colour != kNoColour && in[i].num_points > 0 && in[i].colour + 1 > c->num_colours) c->num_colours = in[i].colour + 1;
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     EH_HIP(c, hipMemsetAsync(c->m[c->cur].seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream));
     if (n == 0) return EDYNHIP_OK;

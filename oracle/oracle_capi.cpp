@@ -156,6 +156,11 @@ void orc_get_manifolds(void *h, orc_manifold_rec *out) {
 void orc_set_manifolds(void *h, const orc_manifold_rec *in, uint32_t n) {
     World *w = (World *)h;
     w->manifolds.clear();
+    // the colours come with the records; the number of colours in use (whose top one the next step releases, colour_contacts)
+    // is part of the colouring state and follows from them - edynhip_set_manifolds does the same
+    uint32_t nc = 0;
+    for (uint32_t k = 0; k < n; ++k) if (in[k].colour != kNoColour && in[k].num_points > 0) nc = std::max(nc, in[k].colour + 1);
+    w->stats.num_colours = nc;
     for (uint32_t k = 0; k < n; ++k) {
         const orc_manifold_rec &r = in[k];
         Manifold m;
