@@ -4,26 +4,34 @@
 Contract (one JSON line on rank 0):
   metric   steps/sec (whole node), 32k-box pile, 10 SI iters           (BASELINE.json)
   value    pile-steps per second over all ranks, scene resident in HBM before the timed region
+  state    the scene is SETTLED before anything is timed: `--settle` steps (default 120, SURVEY 8d "warm-up 120 steps") are part
+           of scene construction - untimed, not counted in `warmup` - so the number does not depend on the driver's --warmup;
+           `--warmup` steps then warm caches / clocks, `--steps` steps are timed.
   N = 1    the 32 768-box brick-offset pile on a static plane, 10 velocity / 3 position iterations
-  N > 1    the pile is ONE island and cannot be split: each rank steps its own replica of
-           the pile (N islands sharded one per GPU, no data-path collective) and the integrated state
-           (13 floats/body) is all-gathered over RCCL every step, as the registry write-back would need;
-           value counts pile-steps, scaling = "weak".
-  roofline the SI velocity-solve kernel (k_contact_solve_df2 / _df: ONE dataflow launch per step runs the warm start and
-           every iteration over every colour; scenes with joints use one k_contact_solve launch per colour):
-           algorithmic bytes (380 B per contact point per iteration) / time measured with HIP events
-           recorded on the stepper's stream around that launch inside the timed region.
+  N > 1    `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run on 127.0.0.1) when it was not launched by
+           torchrun. The pile is ONE island and cannot be split: each rank steps its own replica of the pile (N islands
+           sharded one per GPU, no data-path collective) and the integrated state (13 floats/body) is all-gathered over RCCL every
+           step, as the registry write-back would need; value counts pile-steps, scaling = "weak".
+  north_star  (second result in the same line) north_star's own target: 1 048 576 boxes in 16 384 islands, the islands sharded
+           over the N ranks (strong scaling of ONE scene, per-step RCCL gather of the state): bodies, steps/s, >= 60 Hz yes/no.
+  roofline the SI velocity-solve kernel actually launched (edynhip_stats::solve_schedule): algorithmic bytes
+           (380 B per contact point + 256 B per joint row, per iteration) / time measured with HIP events recorded
+           on the stepper's stream around that launch inside the timed region; beside the 8 TB/s spec peak the measured read
+           and copy ceilings of this GPU (edynhip_measure_bandwidth).
   cpu_baseline  Edyn's own multithreaded CPU path: the REAL reference engine (oracle/_ref/libedynref.so = the reference's
            translation units compiled where they lie, driven through edyn::attach / step_simulation in
-           execution_mode::sequential_multithreaded on all host cores) timed on a bounded sample of the same scene on rank 0
-           at N=1, in a subprocess with a wall-clock budget; next to it, in `sample`, the 1-thread restatement (oracle).
-           Falls back to the restatement (kind "port", cores 1) where oracle/_ref is not built or the budget is exceeded.
-           A reported baseline, not the target.
+           execution_mode::sequential_multithreaded on all host cores) timed on a bounded sample of the same scene IN THE SAME
+           (settled) STATE the GPU leg times, on rank 0 at N=1, in a subprocess with a wall-clock budget; next to it, in
+           `sample`, the 1-thread restatement (oracle). Falls back to the restatement (kind "port", cores 1) where oracle/_ref is
+           not built or the budget is exceeded. A reported baseline, not the target.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,55 +43,78 @@ import torch.distributed as dist
 
 import edyn_amd
 from edyn_amd import scenes
+from edyn_amd import _capi
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_POINT_ITER = 380.0   # algorithmic bytes per contact point per velocity iteration
+BYTES_PER_JOINT_ROW_ITER = 256.0   # per joint row per iteration
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+# parity statement that accompanies the number (tests/test_gpu_parity.py; the figures are asserted there)
+PARITY = ("bit-exact vs the oracle in this settled state at full size (pairs, state, manifolds, colours: "
+          "test_timed_regime_at_full_size_bit_exact); free-running vs the reference engine itself, C2 8000 boxes, 60 steps: "
+          "max |dpos| 0.23 m, mean 0.059 m, penetration <= 0.01 m, mean pile height within 2.6e-3 m - a Gauss-Seidel visiting-order "
+          "effect of the unconverged 10-iteration solve on a collapsing lattice, not fp rounding (lock-step: 2e-3 m per step, pair sets "
+          "and narrowphase bit-exact; test_free_running_c2_against_the_real_reference_engine, test_gpu_against_the_real_reference_engine)")
 WORKLOADS = {
-    "pile32k": dict(gen=lambda: scenes.box_pile(32, 32, 32), vel=10, pos=3, desc="32x32x32 = 32768-box brick-offset pile on a static plane"),
-    "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, desc="20x20x20 = 8000-box pile (config C2)"),
-    "mixed32k": dict(gen=lambda: scenes.box_pile(32, 32, 32, mixed=True), vel=20, pos=3, desc="32768 mixed box/sphere stack, 20 it (config C3)"),
-    "pile512": dict(gen=lambda: scenes.box_pile(8, 8, 8), vel=10, pos=3, desc="8x8x8 pile (smoke)"),
+    "pile32k": dict(gen=lambda: scenes.box_pile(32, 32, 32), vel=10, pos=3, settle=120, desc="32x32x32 = 32768-box brick-offset pile on a static plane"),
+    "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, settle=120, desc="20x20x20 = 8000-box pile (config C2)"),
+    "mixed32k": dict(gen=lambda: scenes.box_pile(32, 32, 32, mixed=True), vel=20, pos=3, settle=120, desc="32768 mixed box/sphere stack, 20 it (config C3)"),
+    "pile512": dict(gen=lambda: scenes.box_pile(8, 8, 8), vel=10, pos=3, settle=20, desc="8x8x8 pile (smoke)"),
     # C4 shards by islands: with N ranks each rank steps its contiguous block of the 4096 sites, no data-path
     # collective - strong scaling of ONE scene (value = scene-steps/s), unlike the single-island pile's replicas
-    "islands256k": dict(gen=lambda: scenes.c4_islands(), vel=10, pos=3, desc="262144 boxes in 4096 independent 4x4x4 mini-piles (config C4)",
+    "islands256k": dict(gen=lambda: scenes.c4_islands(), vel=10, pos=3, settle=120, desc="262144 boxes in 4096 independent 4x4x4 mini-piles (config C4)",
                         shard=lambda first, count: scenes.c4_islands(first_site=first, num_sites=count), shard_units=4096),
     # 1024 of the reference's own rag dolls (edyn::make_ragdoll, exported from the real engine: tests/golden/make_ragdoll.py)
     # collapsing on a plane: 22 529 bodies, 36 864 cone / cvjoint / hinge constraints, capsule contacts
-    "ragdolls1k": dict(gen=lambda: scenes.figures(scenes.load_figure(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ragdoll_capsule.npz")), 32, 32),
-                       vel=10, pos=3, desc="1024 rag dolls (22 bodies, 36 cone/cvjoint/hinge constraints each) falling on a plane"),
-    # north_star's body count on ONE GPU: 1 048 576 boxes in 16 384 islands (the C4 scene at 4x the sites)
-    "islands1m": dict(gen=lambda: scenes.mini_piles(128, 128), vel=10, pos=3, desc="1048576 boxes in 16384 independent 4x4x4 mini-piles",
+    "ragdolls1k": dict(gen=lambda: scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 32, 32),
+                       vel=10, pos=3, settle=120, desc="1024 rag dolls (22 bodies, 36 cone/cvjoint/hinge constraints each) falling on a plane"),
+    # north_star's body count: 1 048 576 boxes in 16 384 islands (the C4 scene at 4x the sites)
+    "islands1m": dict(gen=lambda: scenes.mini_piles(128, 128), vel=10, pos=3, settle=120, desc="1048576 boxes in 16384 independent 4x4x4 mini-piles",
                       shard=lambda first, count: scenes.mini_piles(128, 128, first_site=first, num_sites=count), shard_units=16384),
+    # a small scene of the same kind (functional tests of the north_star leg)
+    "islands4k": dict(gen=lambda: scenes.mini_piles(8, 8), vel=10, pos=3, settle=20, desc="4096 boxes in 64 independent 4x4x4 mini-piles (smoke)",
+                      shard=lambda first, count: scenes.mini_piles(8, 8, first_site=first, num_sites=count), shard_units=64),
     # the headline pile with 64 rag dolls standing beside it: islands with joints next to a large island without (mixed schedule)
-    "pile32k_ragdolls": dict(gen=lambda: _pile_and_ragdolls(), vel=10, pos=3, desc="the 32768-box pile beside 64 rag dolls (36 constraints each)"),
-    "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
+    "pile32k_ragdolls": dict(gen=lambda: _pile_and_ragdolls(), vel=10, pos=3, settle=120, desc="the 32768-box pile beside 64 rag dolls (36 constraints each)"),
+    "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, settle=120, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
 
 
 def _pile_and_ragdolls():
-    figs = scenes.figures(scenes.load_figure(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ragdoll_capsule.npz")), 8, 8, floor=False)
+    figs = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 8, 8, floor=False)
     figs["pos"][:, 0] += np.float32(60.0)
     return scenes.merge(scenes.box_pile(32, 32, 32), figs)
 
 
+# ------------------------------------------------------------------------------------------------ CPU legs (checker code, timed)
 def _cpu_scene(workload):
-    """The scene the CPU legs time: the workload itself, or - for the many-island scene, whose reference run would need
+    """The scene the CPU legs time: the workload itself, or - for the many-island scenes, whose reference run would need
     tens of GB - a block of its independent sites (steps/s then scale with the site count, stated in `sample`)."""
     wl = WORKLOADS[workload]
     if "shard" in wl:
-        sites = 256
-        return wl["shard"](0, sites), wl["shard_units"] / sites, f"sites 0..{sites - 1} of {wl['shard_units']} (independent islands; steps/s divided by {wl['shard_units'] // sites})"
-    return wl["gen"](), 1.0, "the whole scene"
+        sites = min(256, wl["shard_units"])
+        return wl["shard"](0, sites), wl["shard_units"] / sites, f"sites 0..{sites - 1} of {wl['shard_units']} (independent islands; steps/s divided by {wl['shard_units'] // sites})", sites
+    return wl["gen"](), 1.0, "the whole scene", None
 
 
-def cpu_reference_leg(workload, sample_steps, warm_steps):
+def _load_state(path, n):
+    if not path:
+        return None
+    z = np.load(path)
+    return tuple(np.ascontiguousarray(z[k][:n]) for k in ("pos", "orn", "linvel", "angvel"))
+
+
+def cpu_reference_leg(workload, sample_steps, warm_steps, state_path):
     """Child process (bench.py --cpu-reference-leg): time the real reference engine, multithreaded. Prints one JSON line."""
     from oracle import binding as ob
     wl = WORKLOADS[workload]
-    scene, scale, what = _cpu_scene(workload)
+    scene, scale, what, _ = _cpu_scene(workload)
     cores = os.cpu_count() or 1
     r = ob.RefWorld(vel_iters=wl["vel"], pos_iters=wl["pos"], mode=1, workers=0)   # sequential_multithreaded, hardware_concurrency - 1 workers + the caller
     r.add_bodies(scene); scenes.apply_figure_settings(r, scene)
+    st = _load_state(state_path, len(scene["kind"]))
+    if st is not None:
+        r.set_state(*st)
     t0 = time.perf_counter()
     r.step(warm_steps)
     warm_s = time.perf_counter() - t0
@@ -92,72 +123,167 @@ def cpu_reference_leg(workload, sample_steps, warm_steps):
                       "points": int(r.get_manifolds()["num_points"].sum())}))
 
 
-def cpu_baseline(workload, sample_steps, warm_steps, budget_s):
-    """CPU legs, timed on the host cores of the bench box. Checker code, timed - never shipped."""
-    import subprocess
+def cpu_baseline(workload, sample_steps, warm_steps, budget_s, state_path, settle):
+    """CPU legs, timed on the host cores of the bench box, started from the state the GPU leg times (the device's settled
+    transforms and velocities; `warm_steps` steps rebuild the contact manifolds there). Checker code, timed - never shipped."""
     from oracle import binding as ob
     wl = WORKLOADS[workload]
-    scene, scale, what = _cpu_scene(workload)
+    scene, scale, what, _ = _cpu_scene(workload)
     o = ob.World(vel_iters=wl["vel"], pos_iters=wl["pos"], order=ob.ORDER_SEQUENTIAL)
     o.add_bodies(scene); scenes.apply_figure_settings(o, scene)
+    st = _load_state(state_path, len(scene["kind"]))
+    if st is not None:
+        o.set_state(*st); o.refresh_derived()
     o.step(warm_steps)
     port = sample_steps / o.time_steps(sample_steps) / scale
+    state_note = (f"the device's state after its {settle} settle steps" if st is not None else "its initial state")
     port_note = (f"1-thread restatement (oracle, reference row order): {port:.3f} steps/s over {sample_steps} steps after {warm_steps} "
-                 f"warm-up steps of {what} from its initial state ({o.get_stats()['num_points']} contact points at the end)")
+                 f"contact-building steps of {what} from {state_note} ({o.get_stats()['num_points']} contact points at the end)")
     ref = None
     if ob.ref() is not None and budget_s > 0:
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-reference-leg", "--workload", workload,
-                                  "--cpu-sample-steps", str(sample_steps), "--cpu-warm-steps", str(warm_steps)],
-                                 capture_output=True, text=True, timeout=budget_s)
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-reference-leg", "--workload", workload,
+                   "--cpu-sample-steps", str(sample_steps), "--cpu-warm-steps", str(warm_steps)]
+            if state_path:
+                cmd += ["--cpu-state", state_path]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
             ref = json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else None
         except (subprocess.TimeoutExpired, ValueError):
             ref = None
     if ref is not None:
         return {"value": ref["value"], "unit": "steps/sec", "cores": ref["cores"], "kind": "reference",
                 "sample": f"the reference engine itself (edyn::attach, execution_mode::sequential_multithreaded, {ref['cores']} host threads): "
-                          f"{sample_steps} steps after {warm_steps} warm-up steps ({ref['warm_s']:.1f} s, they build ~{ref['points']} contact points "
-                          f"and their islands) of {ref['what']}; beside it the {port_note}"}
+                          f"{sample_steps} steps after {warm_steps} contact-building steps ({ref['warm_s']:.1f} s, ~{ref['points']} contact points) "
+                          f"of {ref['what']} from {state_note}; beside it the {port_note}"}
     return {"value": port, "unit": "steps/sec", "cores": 1, "kind": "port",
             "sample": port_note + "; the multithreaded reference-engine leg was unavailable (oracle/_ref not built or over its time budget)"}
 
 
-def copy_ceiling_gbs():
-    """Measured device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy, best of 5): SURVEY 8(d)'s
-    practical ceiling, reported beside the 8 TB/s spec peak."""
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
-    b.copy_(a); torch.cuda.synchronize()
-    best = 0.0
-    for _ in range(5):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
-        best = max(best, 2.0 * n / 1e9 / (e0.elapsed_time(e1) / 1e3))
-    del a, b
-    return best
+# ------------------------------------------------------------------------------------------------ launching N ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+    and pass their output through. Fails loudly when the box has fewer GPUs (unless the functional-test switch is set)."""
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ngpu < n and os.environ.get("EDYN_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: --gpus {n} but this box has {ngpu} GPU(s) (EDYN_BENCH_SHARE_GPU=1 shares devices, functional tests only)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------------------------------ one measured leg
+class Leg:
+    """One workload, built, settled, warmed and timed on this rank's GPU (all ranks call the same sequence)."""
+
+    def __init__(self, workload, args, rank, world_size, device_index, backend, stream):
+        from edyn_amd.parallel import shard_range, StateGather
+        self.name, self.wl = workload, WORKLOADS[workload]
+        wl = self.wl
+        self.rank, self.world_size, self.backend = rank, world_size, backend
+        self.distributed = world_size > 1
+        self.sharded = self.distributed and "shard" in wl
+        if self.sharded:
+            first, count = shard_range(wl["shard_units"], rank, world_size)
+            scene = wl["shard"](first, count)
+            per_site = (len(scene["kind"]) - 1) // count                          # bodies per site + the replicated static plane
+            counts = [1 + per_site * shard_range(wl["shard_units"], r, world_size)[1] for r in range(world_size)]
+            self.total_bodies = 1 + per_site * wl["shard_units"]
+        else:
+            scene = wl["gen"]()
+            counts = [len(scene["kind"])] * world_size
+            self.total_bodies = len(scene["kind"])
+        self.n_bodies = len(scene["kind"])
+        assert counts[rank] == self.n_bodies
+        cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
+                                   device=device_index, timing=args.stage_timing, timing_solve=not args.stage_timing,
+                                   # a single-rank run owns its GPU: plain launches for the resident-grid kernels;
+                                   # RCCL kernels share the GPU in multi-rank runs: cooperative launches there
+                                   exclusive_device=not self.distributed)
+        self.w = edyn_amd.World(cfg)
+        self.w.set_scene(scene)
+        scenes.apply_figure_settings(self.w, scene)
+        self.w.set_stream(stream.cuda_stream)
+        self.gath = StateGather(counts, "cuda", backend) if self.distributed else None   # edyn_amd.parallel: the registry write-back gather
+        self.settle = wl["settle"] if args.settle is None else args.settle
+
+    def one_step(self):
+        self.w.step_simulation(1)
+        if self.distributed:
+            self.w.pack_state_device(self.gath.local.data_ptr())   # same stream as the stepper and (through torch) the collective
+            self.gath.gather()
+
+    def run(self, steps, warmup):
+        """settle (scene construction) -> warm-up -> barrier + sync -> `steps` timed steps -> sync + barrier; max over ranks."""
+        self.w.step_simulation(self.settle)
+        for _ in range(warmup):
+            self.one_step()
+        if self.distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if self.distributed:
+            for _ in range(steps):
+                self.one_step()
+        else:
+            self.w.step_simulation(steps)   # K steps, stage events recorded per step on the stepper's stream
+        torch.cuda.synchronize()
+        if self.distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.distributed:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        self.elapsed, self.steps = elapsed, steps
+        # scene-steps per second: sharded = ONE scene stepped once per step by all ranks together; replicas = one scene per rank
+        self.value = (1 if self.sharded else self.world_size) * steps / elapsed
+        return self.value
+
+    def close(self):
+        self.w = None
+        self.gath = None
+        torch.cuda.empty_cache()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=None, help="settle steps before anything is timed (scene construction; default per workload: 120)")
     ap.add_argument("--workload", default="pile32k", choices=sorted(WORKLOADS))
+    ap.add_argument("--north-star", default="auto", help="workload of the north_star leg (sharded islands): a workload name, 'none', or 'auto' = islands1m on the default workload")
+    ap.add_argument("--north-star-steps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-timing", action="store_true",
                     help="HIP events around every stage (adds stages_ms_per_step; each event idles the GPU ~6 us, so the headline\n                    value is measured without it: only the two events around the velocity solve are recorded)")
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
-    ap.add_argument("--cpu-warm-steps", type=int, default=2)
+    ap.add_argument("--cpu-warm-steps", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock budget of the reference-engine CPU leg")
     ap.add_argument("--cpu-reference-leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-state", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_reference_leg:
-        cpu_reference_leg(args.workload, args.cpu_sample_steps, args.cpu_warm_steps)
+        cpu_reference_leg(args.workload, args.cpu_sample_steps, args.cpu_warm_steps, args.cpu_state)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)   # does not return
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus and rank == 0:
+        print(f"bench.py: launched with WORLD_SIZE={world_size} but --gpus {args.gpus}; measuring {world_size} ranks", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
     ngpu = torch.cuda.device_count()
@@ -177,77 +303,35 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
-    wl = WORKLOADS[args.workload]
-    sharded = distributed and "shard" in wl
-    from edyn_amd.parallel import shard_range, StateGather
-    if sharded:
-        first, count = shard_range(wl["shard_units"], rank, world_size)
-        scene = wl["shard"](first, count)
-        per_site = (len(scene["kind"]) - 1) // count                          # bodies per site + the replicated static plane
-        counts = [1 + per_site * shard_range(wl["shard_units"], r, world_size)[1] for r in range(world_size)]
-    else:
-        scene = wl["gen"]()
-        counts = [len(scene["kind"])] * world_size
-    n_bodies = len(scene["kind"])
-    assert counts[rank] == n_bodies
-    cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"],
-                               device=device_index, timing=args.stage_timing, timing_solve=not args.stage_timing,
-                               # a single-rank run owns its GPU: plain launches for the resident-grid kernels
-                               exclusive_device=not distributed)   # RCCL kernels share the GPU in multi-rank runs: cooperative launches there
-    w = edyn_amd.World(cfg)
-    w.set_scene(scene)
-    scenes.apply_figure_settings(w, scene)
     # The stepper, the pack kernel and the RCCL gather all run on ONE explicitly created torch stream (a non-zero
     # handle: edynhip_set_stream(NULL) would mean "a private stream"), entered for the whole run => ordered.
     stream = torch.cuda.Stream(device=device_index)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    w.set_stream(stream.cuda_stream)
 
-    gath = StateGather(counts, "cuda", backend) if distributed else None   # edyn_amd.parallel: the registry write-back gather
-
-    def one_step():
-        w.step_simulation(1)
-        if distributed:
-            w.pack_state_device(gath.local.data_ptr())   # same stream as the stepper and (through torch) the collective
-            gath.gather()
-
-    for _ in range(args.warmup):
-        one_step()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if distributed:
-        for _ in range(args.steps):
-            one_step()
-    else:
-        w.step_simulation(args.steps)   # K steps, stage events recorded per step on the stepper's stream
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
+    wl = WORKLOADS[args.workload]
+    leg = Leg(args.workload, args, rank, world_size, device_index, backend, stream)
+    leg.run(args.steps, args.warmup)
+    w = leg.w
     stats = w.get_stats()
     tm = w.get_timings()
-    pos = w.get_state()[0]
-    finite = bool(np.isfinite(pos).all())
+    state = w.get_state()
+    finite = bool(np.isfinite(state[0]).all())
+    read_gbs, copy_gbs = w.measure_bandwidth(1 << 30) if rank == 0 else (0.0, 0.0)
 
+    out = None
+    state_path = None
     if rank == 0:
         dist_note = ""
         if distributed:
             how = (f"sharded by islands over {world_size} ranks ({wl['shard_units']} sites, contiguous blocks), no data-path collective"
-                   if sharded else f"{world_size} replicas (one island per GPU)")
+                   if leg.sharded else f"{world_size} replicas (one island per GPU)")
             dist_note = f"; {how}, per-step {'RCCL' if backend == 'nccl' else 'gloo (shared-GPU functional test)'} all-gather of state"
-        value = (1 if sharded else world_size) * args.steps / elapsed   # sharded: one scene stepped once per step by all ranks together
         steps_timed = max(tm["steps"], 1)
         solve_ms = tm["solve_velocity_ms"] / steps_timed
         launches = tm["solve_velocity_launches"] / max(args.steps if not distributed else 1, 1)
-        alg_bytes_step = BYTES_PER_POINT_ITER * stats["num_points"] * (wl["vel"] + 1)   # +1: warm start sweep
+        sweeps = wl["vel"] + 1   # +1: the warm-start sweep
+        alg_bytes_step = (BYTES_PER_POINT_ITER * stats["num_points"] + BYTES_PER_JOINT_ROW_ITER * stats["num_joint_rows"]) * sweeps
         # measured fabric traffic per launch: a KEPT rocprofv3 PMC profile of this command (profiles/traffic.json, keyed
         # by workload; FETCH_SIZE/WRITE_SIZE cannot be read from inside the run) - null when no profile was kept
         traffic = None
@@ -263,27 +347,30 @@ def main():
         # achieved = min(algorithmic, measured) bytes / kernel time
         eff_bytes_step = min(alg_bytes_step, traffic * max(launches, 1)) if traffic else alg_bytes_step
         achieved = (eff_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
-        # The denominator stays the 8 TB/s spec peak: the measured device-to-device copy rate (reported beside it) is NOT a
-        # ceiling for this read-dominated kernel - on the many-island scene the solve streams rows faster than a copy moves
-        # bytes (a copy alternates reads and writes on every channel), which would put the fraction above 1.
-        ceiling = copy_ceiling_gbs()
+        # The denominator stays the 8 TB/s spec peak. Beside it: what this GPU streams when every CU reads 16 B per lane
+        # (the practical ceiling of a read-dominated kernel like the solve) and what a device-to-device copy moves (read +
+        # write bytes; a copy alternates reads and writes on every channel and is slower than a pure read stream).
         peak = HBM_PEAK_GBS
         out = {
             "metric": "steps/sec (whole node), 32k-box pile, 10 SI iters; HBM GB/s in solve",
-            "value": value, "unit": "steps/sec", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "value": leg.value, "unit": "steps/sec", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * leg.elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if leg.sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}; {wl['vel']} velocity / {wl['pos']} position iterations, dt 1/60, "
-                                   f"friction 0.5, restitution 0" + dist_note,
-                       "bodies": n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
-                       "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite},
+                                   f"friction 0.5, restitution 0; settled for {leg.settle} steps before warm-up and timing" + dist_note,
+                       "settle_steps": leg.settle, "bodies": leg.n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
+                       "joint_rows": stats["num_joint_rows"],
+                       "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite,
+                       "parity": PARITY},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": "kept rocprofv3 PMC profile (profiles/traffic.json), not measured in this run",
-                         "measured_copy_ceiling": ceiling, "frac_of_measured_copy_ceiling": achieved / ceiling if ceiling > 0 else None,
-                         "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = HBM3E spec; the measured device-to-device copy rate (read + write bytes) is reported beside it",
-                         "kernel": ("k_contact_solve_df2 (one dataflow launch per step: warm start + every iteration over every colour; two lanes per manifold - k_contact_solve_df, one lane, on bandwidth-bound scenes)" if launches < 1.5
-                                    else "k_contact_solve<WARM,PUSH> (+ _tail): one launch per colour, every iteration + warm start"),
-                         "algorithmic_bytes_per_launch": per_launch_alg, "launches_per_step": launches,
+                         "measured_read_ceiling": read_gbs, "frac_of_measured_read_ceiling": achieved / read_gbs if read_gbs > 0 else None,
+                         "measured_copy_ceiling": copy_gbs, "frac_of_measured_copy_ceiling": achieved / copy_gbs if copy_gbs > 0 else None,
+                         "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = HBM3E spec; the measured read-stream and device-to-device copy rates of this GPU are reported beside it",
+                         "kernel": _capi.SCHEDULE_NAMES.get(stats["solve_schedule"], str(stats["solve_schedule"])),
+                         "algorithmic_bytes_per_launch": per_launch_alg,
+                         "algorithmic_bytes_rule": "(380 B x contact points + 256 B x joint rows) x (velocity iterations + 1 warm-start sweep)",
+                         "launches_per_step": launches,
                          "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
         }
         if args.stage_timing:
@@ -291,7 +378,41 @@ def main():
                                                                          "prepare_ms", "solve_velocity_ms", "integrate_ms", "solve_position_ms",
                                                                          "finish_ms", "step_ms")}
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_steps, args.cpu_warm_steps, args.cpu_budget_s)
+            # the CPU legs start from the state the GPU leg was timed in (the first bodies of a sharded scene: its first sites)
+            fd, state_path = tempfile.mkstemp(suffix=".npz", prefix="edyn_bench_state_")
+            os.close(fd)
+            np.savez(state_path, pos=state[0], orn=state[1], linvel=state[2], angvel=state[3])
+    leg.close()
+    del w
+
+    # ---- north_star: 1M bodies in 16k islands, sharded over the ranks (strong scaling), >= 60 Hz?
+    ns_name = args.north_star
+    if ns_name == "auto":
+        ns_name = "islands1m" if args.workload == "pile32k" else "none"
+    if ns_name != "none":
+        if ns_name not in WORKLOADS or "shard" not in WORKLOADS[ns_name]:
+            raise SystemExit(f"bench.py: --north-star {ns_name}: not a shardable workload")
+        ns = Leg(ns_name, args, rank, world_size, device_index, backend, stream)
+        ns.run(args.north_star_steps, min(args.warmup, 10))
+        ns_stats = ns.w.get_stats()
+        ns_finite = bool(np.isfinite(ns.w.get_state()[0]).all())
+        if rank == 0:
+            out["north_star"] = {
+                "workload": f"{ns_name}: {WORKLOADS[ns_name]['desc']}; islands sharded over {world_size} rank(s) in contiguous site blocks, no data-path "
+                            f"collective" + (f", per-step {'RCCL' if backend == 'nccl' else 'gloo'} all-gather of the state" if distributed else "")
+                            + f"; settled {ns.settle} steps",
+                "bodies": ns.total_bodies, "n_gpus": world_size, "scaling": "strong", "steps": args.north_star_steps,
+                "steps_per_sec": ns.value, "ms_per_step": 1e3 * ns.elapsed / args.north_star_steps,
+                "target_hz": 60.0, "meets_60hz": bool(ns.value >= 60.0),
+                "bodies_this_rank": ns.n_bodies, "contact_points_this_rank": ns_stats["num_points"], "finite": ns_finite}
+        ns.close()
+
+    if rank == 0:
+        if state_path is not None:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_steps, args.cpu_warm_steps, args.cpu_budget_s, state_path, leg.settle)
+            finally:
+                os.unlink(state_path)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

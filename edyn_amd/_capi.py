@@ -50,7 +50,14 @@ class Timings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("num_bodies", "num_manifolds", "num_points", "num_active_manifolds",
                                           "num_islands", "num_colours", "num_joint_colours", "colour_rounds",
-                                          "num_joints", "num_joint_rows")] + [("colour_size", C.c_uint32 * 64)]
+                                          "num_joints", "num_joint_rows", "solve_schedule")] + [("colour_size", C.c_uint32 * 64)]
+
+
+SCHEDULE_NAMES = {0: "none", 1: "k_contact_solve_df2 (dataflow, one launch per step, two lanes per manifold)",
+                  2: "k_contact_solve_df (dataflow, one launch per step, one lane per manifold)",
+                  3: "k_island_velocity (island-fused: one wave per island)",
+                  4: "k_contact_solve_df2 + k_island_velocity (mixed: dataflow launch for islands without joints, one wave per jointed island)",
+                  5: "k_contact_solve<WARM,PUSH> / k_joint_solve (one launch per colour and sweep)"}
 
 
 POINT_DTYPE = np.dtype([
@@ -76,7 +83,8 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
            "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
-           "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing"]
+           "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing",
+           "edynhip_measure_bandwidth"]
 
 _lib = None
 
@@ -136,6 +144,7 @@ def lib():
         L.edynhip_step_timed.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
         L.edynhip_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_remove_collision_exclusion.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.edynhip_measure_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L
     return _lib

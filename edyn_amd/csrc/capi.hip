@@ -481,7 +481,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 9; }   // 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 10; }   // 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1531,6 +1531,58 @@ int edynhip_get_stats(edynhip_ctx *c, edynhip_stats *out) {
     c->stats.num_colours = c->num_colours;
     for (uint32_t k = 0; k < kMaxColours; ++k) c->stats.colour_size[k] = k < c->num_colours ? c->colour_end[k] - c->colour_start[k] : 0;
     *out = c->stats;
+    return EDYNHIP_OK;
+}
+
+// ---- measurement aid: what this chip streams (the practical denominator printed next to the HBM spec peak)
+__global__ void __launch_bounds__(256) k_bw_read(const float4 *__restrict__ src, size_t n, float4 *sink) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 v = src[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x == 12345.678f) sink[0] = acc;   // never true for the zero-filled buffer: keeps the loads alive
+}
+__global__ void __launch_bounds__(256) k_bw_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+int edynhip_measure_bandwidth(edynhip_ctx *c, uint64_t bytes, float *read_gbs, float *copy_gbs) {
+    if (!c || bytes < (1u << 20)) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)(bytes / sizeof(float4));
+    float4 *a = nullptr, *b = nullptr;
+    if (hipMalloc((void **)&a, n * sizeof(float4)) != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_measure_bandwidth: hipMalloc");
+    if (hipMalloc((void **)&b, n * sizeof(float4)) != hipSuccess) { (void)hipFree(a); return set_error(c, EDYNHIP_ERR_HIP, "edynhip_measure_bandwidth: hipMalloc"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    if (err == hipSuccess) err = hipMemsetAsync(a, 0, n * sizeof(float4), c->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(b, 0, n * sizeof(float4), c->stream);
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const dim3 grid((unsigned)ncu * 8u), block(256);
+    float best_r = 0, best_c = 0;
+    for (int rep = 0; rep < 6 && err == hipSuccess; ++rep) {   // the first pass of each is a warm-up
+        float ms = 0;
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k_bw_read, grid, block, 0, c->stream, a, n, b);
+        (void)hipEventRecord(e1, c->stream);
+        err = hipEventSynchronize(e1);
+        if (err == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0 && rep > 0) best_r = std::max(best_r, (float)(n * sizeof(float4) / 1e6 / ms));
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k_bw_copy, grid, block, 0, c->stream, a, b, n);
+        (void)hipEventRecord(e1, c->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        if (err == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0 && rep > 0) best_c = std::max(best_c, (float)(2.0 * n * sizeof(float4) / 1e6 / ms));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (err != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_measure_bandwidth", err);
+    if (read_gbs) *read_gbs = best_r;
+    if (copy_gbs) *copy_gbs = best_c;
     return EDYNHIP_OK;
 }
 

@@ -2851,7 +2851,7 @@ int solve(edynhip_ctx *c) {
             ++launches;
         }
     };
-    bool df_velocity = false;
+    bool df_velocity = false, df_two_lane = false;
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
         // Two lanes per manifold (k_contact_solve_df2) unless disabled; resident waves (measured on MI355X): enough for
@@ -2862,6 +2862,7 @@ int solve(edynhip_ctx *c) {
         // (the two-lane form reads J_lin on both lanes: ~20 % more row traffic, which only matters once the sweep is
         // bandwidth-bound - then the one-lane kernel is the better one)
         const bool two_lane = two_lane_env && c->df2_waves > 0 && na <= 16u * 32u * c->df2_waves;
+        df_two_lane = two_lane;
         const uint32_t per_wave = two_lane ? 32u : 64u;
         const uint32_t want_waves = env_waves ? env_waves : std::max(two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
         const uint32_t grid = std::min(blocks(na, per_wave), std::min(two_lane ? c->df2_waves : c->df_lanes, want_waves));
@@ -2915,6 +2916,9 @@ int solve(edynhip_ctx *c) {
         }
     }
     c->timings.solve_velocity_launches += launches;
+    c->stats.solve_schedule = (na + j.n) == 0 ? EDYNHIP_SCHEDULE_NONE
+                              : df_velocity ? (mixed ? EDYNHIP_SCHEDULE_MIXED : df_two_lane ? EDYNHIP_SCHEDULE_DATAFLOW2 : EDYNHIP_SCHEDULE_DATAFLOW1)
+                              : isl_fused ? EDYNHIP_SCHEDULE_ISLAND_FUSED : EDYNHIP_SCHEDULE_PER_COLOUR;
     rec(c, 6);
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');
     const uint32_t P = c->cfg.num_position_iterations;

@@ -502,6 +502,12 @@ class World:
         self._check(self._L.edynhip_get_timings(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in _capi.Timings._fields_}
 
+    def measure_bandwidth(self, nbytes=1 << 30):
+        """(read GB/s, copy GB/s) of this GPU: the measured ceilings bench.py prints beside the HBM spec peak."""
+        r, c = C.c_float(0), C.c_float(0)
+        self._check(self._L.edynhip_measure_bandwidth(self._h, int(nbytes), C.byref(r), C.byref(c)))
+        return float(r.value), float(c.value)
+
     def get_stats(self):
         s = _capi.Stats()
         self._check(self._L.edynhip_get_stats(self._h, C.byref(s)))

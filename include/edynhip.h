@@ -168,8 +168,19 @@ typedef struct {
 typedef struct {
     uint32_t num_bodies, num_manifolds, num_points, num_active_manifolds, num_islands, num_colours,
              num_joint_colours, colour_rounds, num_joints, num_joint_rows;
+    uint32_t solve_schedule;         /* EDYNHIP_SCHEDULE_*: which velocity-solve kernels the last step launched */
     uint32_t colour_size[64];        /* manifolds per solver colour in the last step */
 } edynhip_stats;
+
+/* Velocity-solve schedules (edynhip_stats::solve_schedule). The results are bit-identical across them. */
+enum {
+    EDYNHIP_SCHEDULE_NONE = 0,          /* nothing to solve */
+    EDYNHIP_SCHEDULE_DATAFLOW2 = 1,     /* k_contact_solve_df2: one launch per step, two lanes per manifold */
+    EDYNHIP_SCHEDULE_DATAFLOW1 = 2,     /* k_contact_solve_df: one launch per step, one lane per manifold */
+    EDYNHIP_SCHEDULE_ISLAND_FUSED = 3,  /* k_island_velocity: one wave per island (scenes with joints / contact_extras rows) */
+    EDYNHIP_SCHEDULE_MIXED = 4,         /* dataflow launch for the islands without joints + k_island_velocity for the others */
+    EDYNHIP_SCHEDULE_PER_COLOUR = 5     /* k_contact_solve / k_joint_solve: one launch per colour and sweep */
+};
 
 edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out);
 void edynhip_destroy(edynhip_ctx *ctx);
@@ -335,6 +346,11 @@ int edynhip_set_center_of_mass(edynhip_ctx *ctx, uint32_t body, const float *com
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);
 uint32_t edynhip_abi_version(void);
+
+/* Measurement aid for the roofline report (bench.py): streams `bytes` of device memory with 16-byte loads from every CU (read_gbs)
+ * and copies them device-to-device (copy_gbs, read + write bytes counted), best of five runs each, on the context's stream.
+ * Not part of the step path. */
+int edynhip_measure_bandwidth(edynhip_ctx *ctx, uint64_t bytes, float *read_gbs, float *copy_gbs);
 
 #ifdef __cplusplus
 }

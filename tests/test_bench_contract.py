@@ -22,24 +22,43 @@ def test_bench_json_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True
     assert d["unit"] == "steps/sec" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
+    assert d["config"]["settle_steps"] == 20 and d["config"]["colours"] >= 1 and "parity" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"].startswith("k_contact_solve_df") and r["measured_read_ceiling"] > 1000 and r["measured_copy_ceiling"] > 1000
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     if c["kind"] == "reference":   # the real engine, multithreaded: both thread counts are in the sample text
         assert c["cores"] > 1 and "1-thread" in c["sample"] and "sequential_multithreaded" in c["sample"]
 
 
-def test_bench_two_ranks_on_one_gpu_functional():
-    """The N>1 code path (rendezvous, per-step pack + all-gather, max-over-ranks timing) on a 1-GPU box: two ranks share
-    cuda:0 and gather through gloo. The 8-GPU RCCL run itself is the driver's; this guards everything around it."""
-    env = dict(os.environ, EDYN_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pile512",
-           "--steps", "8", "--warmup", "4"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+def _two_rank_checks(out):
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    ns = d["north_star"]   # the sharded-islands leg: ONE scene over both ranks
+    assert ns["n_gpus"] == 2 and ns["scaling"] == "strong" and ns["bodies"] == 64 * 64 + 1 and ns["bodies_this_rank"] == 32 * 64 + 1
+    assert ns["steps_per_sec"] > 0 and ns["finite"] is True and isinstance(ns["meets_60hz"], bool)
+
+
+def test_bench_two_ranks_on_one_gpu_functional():
+    """The N>1 code path (rendezvous, per-step pack + all-gather, max-over-ranks timing, the sharded north_star leg) on a 1-GPU
+    box: two ranks share cuda:0 and gather through gloo. The 8-GPU RCCL run itself is the driver's; this guards everything
+    around it. Launched the way the driver launches it (torch.distributed.run) ..."""
+    env = dict(os.environ, EDYN_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pile512",
+           "--steps", "8", "--warmup", "4", "--north-star", "islands4k", "--north-star-steps", "6"]
+    _two_rank_checks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """... and as plain `python bench.py --gpus 2`: without torchrun's environment bench.py starts the two ranks itself
+    (--gpus used to be parsed and ignored)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EDYN_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pile512", "--steps", "8", "--warmup", "4",
+           "--north-star", "islands4k", "--north-star-steps", "6"]
+    _two_rank_checks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
