@@ -57,7 +57,8 @@ SCHEDULE_NAMES = {0: "none", 1: "k_contact_solve_df2 (dataflow, one launch per s
                   2: "k_contact_solve_df (dataflow, one launch per step, one lane per manifold)",
                   3: "k_island_velocity (island-fused: one wave per island)",
                   4: "k_contact_solve_df2 + k_island_velocity (mixed: dataflow launch for islands without joints, one wave per jointed island)",
-                  5: "k_contact_solve<WARM,PUSH> / k_joint_solve (one launch per colour and sweep)"}
+                  5: "k_contact_solve<WARM,PUSH> / k_joint_solve (one launch per colour and sweep)",
+                  6: "k_contact_solve_df4 (dataflow, one launch per step, four lanes per manifold)"}
 
 
 POINT_DTYPE = np.dtype([

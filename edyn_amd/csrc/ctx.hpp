@@ -355,6 +355,7 @@ struct edynhip_ctx {
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel
     uint32_t df2_waves = 0;        // resident waves of the two-lane dataflow velocity kernel
+    uint32_t df4_waves = 0;        // resident waves of the four-lane dataflow velocity kernel
     bool inplace_step = false;     // broadphase found last step's pair set again and kept the manifold array: islands() has nothing to relabel
     bool points_in_prev = false;   // this step's manifold array holds no copied points yet (see Manifolds::prev_idx)
     bool force_islands = true;     // recompute island labels even if the pair set did not change

@@ -1818,6 +1818,177 @@ __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
             else df2_dispatch<false>(a, p, valid, sideB, np, col, sweep, tr);
         }
 }
+
+// ---- dataflow velocity sweep, FOUR lanes per manifold ---------------------------------------------------------------
+// Measured on the two-lane kernel (profiles/r02_dftrace_pile32k.txt and its ISA): the section between "inputs arrived" and
+// "deltas published" is ~630 VALU instructions for a four-point manifold and takes 1.65 us - 5.5 cycles per instruction with one
+// wave per SIMD: it is ISSUE-bound (a wave64 instruction occupies its SIMD for 4 cycles however few lanes are live), not
+// latency-bound. Every hop of every body's chain pays it, 18 colours x 11 sweeps deep. The work of one row is four 3-vector
+// dot products (J_linA.dvA, J_angA.dwA, J_linB.dvB, J_angB.dwB) and four 3-vector updates: here each of FOUR lanes owns one
+// of the four 3-vectors of a manifold (role = lane & 3: 0 = A linear, 1 = A angular, 2 = B linear, 3 = B angular): its piece of
+// the body deltas, its J and its I^-1 J^T (or inv_mass * J) per row. A row then costs one dot product, a quad reduction through
+// DPP broadcasts in rel_speed()'s order ((d0 + d1) + d2) + d3, the scalar impulse update (computed redundantly by the four
+// lanes: no exchange) and one 3-vector update - about 40 % of the two-lane kernel's instructions - and the wave holds 16
+// manifolds. Same operations in the same order on the same values: bit-identical to the one- and two-lane kernels
+// (tests/test_gpu_parity.py::test_per_colour_and_dataflow_schedules_are_bit_identical). The hand-off slots are already laid out
+// in 16-byte pieces (side, half) with their own tags: each lane polls and publishes exactly its own piece.
+struct Row4 { f3 j, ij; float eff, rhs, imp; };
+DI float qb0(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00 /* quad_perm:[0,0,0,0] */, 0xF, 0xF, true)); }
+DI float qb1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55 /* quad_perm:[1,1,1,1] */, 0xF, 0xF, true)); }
+DI float qb2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA /* quad_perm:[2,2,2,2] */, 0xF, 0xF, true)); }
+DI float qb3(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF /* quad_perm:[3,3,3,3] */, 0xF, 0xF, true)); }
+DI void df4_poll(const float4 *piece, v4f &h) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(h) : "v"(piece) : "memory");
+}
+DI void df4_publish(float4 *piece, f3 d, uint32_t tag) {
+    const v4f v = {d.x, d.y, d.z, __uint_as_float(tag)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(piece), "v"(v) : "memory");
+}
+DI float df4_relspeed(const f3 &x, const Row4 &r) {
+    const float t = dot(r.j, x);
+    return qb0(t) + qb1(t) + qb2(t) + qb3(t);
+}
+template <bool WARM>
+DI void df4_normal(f3 &x, Row4 &rn) {
+    if (WARM) { x += rn.ij * rn.imp; return; }
+    float dimp = (rn.rhs - df4_relspeed(x, rn)) * rn.eff;
+    const float imp = rn.imp + dimp;
+    if (imp < 0.0f) { dimp = 0.0f - rn.imp; rn.imp = 0.0f; }
+    else if (imp > kLarge) { dimp = kLarge - rn.imp; rn.imp = kLarge; }
+    else rn.imp = imp;
+    x += rn.ij * dimp;
+}
+template <bool WARM>
+DI void df4_friction(f3 &x, Row4 (&R)[kRowsPerPoint], float mu) {
+    Row4 &ra = R[1], &rb = R[2];
+    if (WARM) {   // warm_start(constraint_row_friction&)
+        x += ra.ij * ra.imp;
+        x += rb.ij * rb.imp;
+        return;
+    }
+    const float c0 = ra.imp, c1 = rb.imp;
+    float di0 = (ra.rhs - df4_relspeed(x, ra)) * ra.eff;
+    float i0 = c0 + di0;
+    float di1 = (rb.rhs - df4_relspeed(x, rb)) * rb.eff;
+    float i1 = c1 + di1;
+    const float len2 = i0 * i0 + i1 * i1;
+    const float max_len = mu * R[0].imp;   // mu * current normal impulse
+    if (len2 > square(max_len)) {
+        const float len = sqrtf(len2);
+        if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+        else { i0 = 0; i1 = 0; }
+        di0 = i0 - c0; di1 = i1 - c1;
+    }
+    ra.imp = i0; rb.imp = i1;
+    x += ra.ij * di0;
+    x += rb.ij * di1;
+}
+template <bool WARM, int NP, bool EXACT>
+DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
+    Row4 R[NP][kRowsPerPoint];
+    float mu[NP];
+    const uint64_t w0 = a.trace ? wall_clock64() : 0;
+    const uint32_t side = role >> 1;
+    const bool ang = role & 1u;
+    const uint32_t slot = 2 * p + side;
+    const uint32_t nx = a.next[slot];
+    const float im = a.im[slot];
+    const size_t off_a = (size_t)(ang ? 1u + side : 0u) * a.rcap, off_i = (size_t)(3u + side) * a.rcap;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int r = 0; r < kRowsPerPoint; ++r) {
+            const size_t base = (size_t)((k * kRowsPerPoint + r) * kRowF) * a.rcap + p;
+            const float4 fa = a.rw[base + off_a];     // role 0, 2: (J_lin, eff)   1: (J_angA, rhs)   3: (J_angB, impulse)
+            float4 fi = fa;
+            if (ang) fi = a.rw[base + off_i];         // role 1: (I_A^-1 J_angA, mu)   3: (I_B^-1 J_angB, -)
+            Row4 &q = R[k][r];
+            const f3 Ja = from4(fa);
+            q.j = role == 2u ? -Ja : Ja;              // body B's linear Jacobian is -J_lin
+            const f3 lin = im * q.j;
+            q.ij = ang ? from4(fi) : lin;
+            q.eff = qb0(fa.w); q.rhs = qb1(fa.w); q.imp = qb3(fa.w);
+            if (r == 0) mu[k] = qb1(fi.w);
+        }
+    }
+    f3 x = mk3(0, 0, 0);
+    const uint32_t want = (nx & kHeadBit) ? sweep : sweep + 1;
+    bool got = im == 0;   // read-only bodies hand nothing over: their deltas stay zero
+    bool done = !valid;
+    const float4 *mine = a.dslot + dslot_at(slot, ang ? 1u : 0u);
+    uint64_t w1 = 0, w2 = 0;
+    for (uint32_t spin = 0;; ++spin) {
+        if (!done && !got) {
+            v4f h;
+            df4_poll(mine, h);
+            if (__float_as_uint(h.w) == want) { x = mk3(h.x, h.y, h.z); got = true; }
+        }
+        if (a.trace && w1 == 0) w1 = wall_clock64();
+        const uint64_t pending = __ballot(!done);
+        if (pending == 0) {
+            if (trace_slot && (threadIdx.x & 63) == 0) { trace_slot[0] = w0; trace_slot[1] = w1; trace_slot[2] = w2; trace_slot[3] = wall_clock64(); }
+            break;
+        }
+        const uint32_t minc = __shfl(col, __ffsll((long long)pending) - 1);   // lanes are in colour order
+        const bool mine_now = !done && col == minc;                           // the four lanes of a manifold share p, hence colour
+        if (__ballot(mine_now && !got) == 0) {
+            if (a.trace && w2 == 0) w2 = wall_clock64();
+            // the DPP reads need all four lanes of a manifold: `mine_now` is uniform within a quad
+            if (mine_now) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (EXACT || (uint32_t)k < np) df4_normal<WARM>(x, R[k][0]);
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (EXACT || (uint32_t)k < np) df4_friction<WARM>(x, R[k], mu[k]);
+                // hand the deltas over first (the next manifold of this body is waiting for them), then store the impulses
+                if (im != 0) df4_publish(a.dslot + dslot_at(nx & kSlotMask, ang ? 1u : 0u), x, sweep + 1);
+                if (!WARM && role == 3u) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if (!EXACT && (uint32_t)k >= np) continue;
+#pragma unroll
+                        for (int r = 0; r < kRowsPerPoint; ++r)
+                            a.rw[(size_t)((k * kRowsPerPoint + r) * kRowF + 2) * a.rcap + p] = to4(R[k][r].j, R[k][r].imp);
+                    }
+                }
+                done = true;
+            }
+        } else {
+            if (spin > kDfSpinLimit || ((spin & 1023u) == 1023u && __hip_atomic_load(&a.cnt->df_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+template <bool WARM>
+DI void df4_dispatch(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
+    if (!WARM && __all(!valid || np == 4u)) df4_task<WARM, 4, true>(a, p, valid, role, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 2u)) df4_task<WARM, 2, true>(a, p, valid, role, np, col, sweep, tr);
+    else if (__any(np > 2u)) df4_task<WARM, 4, false>(a, p, valid, role, np, col, sweep, tr);
+    else df4_task<WARM, 2, false>(a, p, valid, role, np, col, sweep, tr);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_contact_solve_df4(DfArgs a) {
+    const uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 2);   // 16 manifolds per wave, four lanes each
+    const uint32_t role = threadIdx.x & 3u;
+    const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 4;
+    for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
+        for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
+            const uint32_t pt = base + t;
+            const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
+            if (!__any(valid)) continue;              // whole wave beyond the end (wave-uniform)
+            const uint32_t p = valid ? pt : a.na - 1;
+            const uint32_t key = a.keys_sorted[p];
+            const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
+            uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
+            if (sweep == 0) df4_dispatch<true>(a, p, valid, role, np, col, sweep, tr);
+            else df4_dispatch<false>(a, p, valid, role, np, col, sweep, tr);
+        }
+}
 template <int NP>
 DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, const Rows &rows, const Manifolds &mf, const Bodies &b,
                         float *isl_err, const uint32_t *isl_done, uint32_t m, uint32_t ia, uint32_t ib, uint32_t label) {
@@ -2710,6 +2881,9 @@ int solve(edynhip_ctx *c) {
             int per_cu2 = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_contact_solve_df2, 64, 0) == hipSuccess && per_cu2 > 0)
                 c->df2_waves = (uint32_t)per_cu2 * (uint32_t)ncu;
+            int per_cu4 = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_contact_solve_df4, 64, 0) == hipSuccess && per_cu4 > 0)
+                c->df4_waves = (uint32_t)per_cu4 * (uint32_t)ncu;
             int per_cu_p = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
                 c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
@@ -2851,21 +3025,35 @@ int solve(edynhip_ctx *c) {
             ++launches;
         }
     };
-    bool df_velocity = false, df_two_lane = false;
+    bool df_velocity = false, df_two_lane = false, df_four_lane = false;
     if (push && c->df_mode == 1) {
         const Rows &r = c->rows;
         // Two lanes per manifold (k_contact_solve_df2) unless disabled; resident waves (measured on MI355X): enough for
         // ~4-5 tasks per wave and sweep while the sweep is latency-bound - more only add polling traffic - and up to every
         // resident slot once the row stream dominates (many islands, millions of points).
+        // Lanes per manifold: 4 (k_contact_solve_df4: shortest hop; the default while the sweep is latency-bound), 2 (k_contact_solve_df2)
+        // or 1 (k_contact_solve_df: least row traffic, for bandwidth-bound scenes - many islands, millions of points). EDYNHIP_DF_LANES forces one.
+        static const uint32_t env_lanes = getenv("EDYNHIP_DF_LANES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_LANES")) : 0u;
         static const bool two_lane_env = !(getenv("EDYNHIP_DF_TWOLANE") && getenv("EDYNHIP_DF_TWOLANE")[0] == '0');
         static const uint32_t env_waves = getenv("EDYNHIP_DF_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DF_WAVES")) : 0u;
-        // (the two-lane form reads J_lin on both lanes: ~20 % more row traffic, which only matters once the sweep is
+        // (the multi-lane forms read J_lin on two lanes: ~20 % more row traffic, which only matters once the sweep is
         // bandwidth-bound - then the one-lane kernel is the better one)
-        const bool two_lane = two_lane_env && c->df2_waves > 0 && na <= 16u * 32u * c->df2_waves;
-        df_two_lane = two_lane;
-        const uint32_t per_wave = two_lane ? 32u : 64u;
-        const uint32_t want_waves = env_waves ? env_waves : std::max(two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
-        const uint32_t grid = std::min(blocks(na, per_wave), std::min(two_lane ? c->df2_waves : c->df_lanes, want_waves));
+        const bool latency_bound = c->df2_waves > 0 && na <= 16u * 32u * c->df2_waves;
+        // Four lanes were measured on the settled headline pile (r03): 541 instead of 633 instructions between "inputs arrived" and
+        // "published" (1.50 vs 1.66 us per wave-task), but 16 manifolds per wave need two waves per SIMD for the same ~4.5 tasks per
+        // wave and sweep, and the two contend for the issue slots exactly while the critical chain runs: 0.60 vs 0.564 ms per solve.
+        // Two lanes stay the default; EDYNHIP_DF_LANES=4 selects the four-lane kernel (bit-identical).
+        uint32_t lanes = latency_bound ? 2u : 1u;
+        if (env_lanes == 1u || env_lanes == 2u || env_lanes == 4u) lanes = env_lanes;
+        if (!two_lane_env && lanes > 1u) lanes = 1u;
+        if (lanes == 4u && c->df4_waves == 0) lanes = 2u;
+        if (lanes == 2u && c->df2_waves == 0) lanes = 1u;
+        const bool two_lane = lanes == 2u, four_lane = lanes == 4u;
+        df_two_lane = two_lane; df_four_lane = four_lane;
+        const uint32_t per_wave = 64u / lanes;
+        const uint32_t resident = four_lane ? c->df4_waves : two_lane ? c->df2_waves : c->df_lanes;
+        const uint32_t want_waves = env_waves ? env_waves : std::max(four_lane ? 2048u : two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
+        const uint32_t grid = std::min(blocks(na, per_wave), std::min(resident, want_waves));
         DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
@@ -2881,7 +3069,7 @@ int solve(edynhip_ctx *c) {
         void *params[] = {&a};
         // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
         // hand-off polling relies on
-        if (launch_resident(c, two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, grid, 64, params) == hipSuccess) {
+        if (launch_resident(c, four_lane ? (const void *)k_contact_solve_df4 : two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, grid, 64, params) == hipSuccess) {
             df_velocity = true;
             ++launches;
         } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
@@ -2917,7 +3105,7 @@ int solve(edynhip_ctx *c) {
     }
     c->timings.solve_velocity_launches += launches;
     c->stats.solve_schedule = (na + j.n) == 0 ? EDYNHIP_SCHEDULE_NONE
-                              : df_velocity ? (mixed ? EDYNHIP_SCHEDULE_MIXED : df_two_lane ? EDYNHIP_SCHEDULE_DATAFLOW2 : EDYNHIP_SCHEDULE_DATAFLOW1)
+                              : df_velocity ? (mixed ? EDYNHIP_SCHEDULE_MIXED : df_four_lane ? EDYNHIP_SCHEDULE_DATAFLOW4 : df_two_lane ? EDYNHIP_SCHEDULE_DATAFLOW2 : EDYNHIP_SCHEDULE_DATAFLOW1)
                               : isl_fused ? EDYNHIP_SCHEDULE_ISLAND_FUSED : EDYNHIP_SCHEDULE_PER_COLOUR;
     rec(c, 6);
     static const bool pos_df_env = !(getenv("EDYNHIP_DATAFLOW_POS") && getenv("EDYNHIP_DATAFLOW_POS")[0] == '0');

@@ -179,7 +179,8 @@ enum {
     EDYNHIP_SCHEDULE_DATAFLOW1 = 2,     /* k_contact_solve_df: one launch per step, one lane per manifold */
     EDYNHIP_SCHEDULE_ISLAND_FUSED = 3,  /* k_island_velocity: one wave per island (scenes with joints / contact_extras rows) */
     EDYNHIP_SCHEDULE_MIXED = 4,         /* dataflow launch for the islands without joints + k_island_velocity for the others */
-    EDYNHIP_SCHEDULE_PER_COLOUR = 5     /* k_contact_solve / k_joint_solve: one launch per colour and sweep */
+    EDYNHIP_SCHEDULE_PER_COLOUR = 5,    /* k_contact_solve / k_joint_solve: one launch per colour and sweep */
+    EDYNHIP_SCHEDULE_DATAFLOW4 = 6      /* k_contact_solve_df4: one launch per step, four lanes per manifold */
 };
 
 edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out);

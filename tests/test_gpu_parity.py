@@ -420,13 +420,17 @@ def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
         "p, q, v, a = w.get_state(); m = w.get_manifolds()\n"
         "np.savez(sys.argv[1], p=p, q=q, v=v, a=a, m=m.view(np.uint8))\n" % root)
     outs = []
-    for mode in ("1", "0"):
-        out = str(tmp_path / f"state_{mode}.npz")
+    # the default (two lanes per manifold), the four- and one-lane dataflow kernels, and one launch per colour
+    for mode, lanes in (("1", None), ("1", "4"), ("1", "1"), ("0", None)):
+        out = str(tmp_path / f"state_{mode}_{lanes}.npz")
         env = dict(os.environ, EDYNHIP_DATAFLOW=mode)
+        if lanes:
+            env["EDYNHIP_DF_LANES"] = lanes
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
         outs.append(np.load(out))
-    for k in ("p", "q", "v", "a", "m"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+    for other in outs[1:]:
+        for k in ("p", "q", "v", "a", "m"):
+            assert np.array_equal(outs[0][k], other[k]), k
     # and the default schedule against the oracle on the same scene
     o = oracle_world(scenes.box_pile(6, 6, 6, mixed=True)); o.step(80)
     for a, b in zip((outs[0]["p"], outs[0]["q"], outs[0]["v"], outs[0]["a"]), o.get_state()):
