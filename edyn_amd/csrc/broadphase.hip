@@ -525,6 +525,7 @@ int broadphase(edynhip_ctx *c) {
     const uint32_t np = c->bvh.num_proc;
     Manifolds &prev = c->m[c->cur], &cur = c->m[c->cur ^ 1];
     const uint32_t pm = c->num_manifolds;
+    c->inplace_step = false;   // set below when this step keeps last step's manifold array; read (and cleared) by islands()
     if (!c->full_step) hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, c->cnt);
     uint32_t M = 0;
     if (np > 0) {

@@ -460,16 +460,28 @@ __global__ void k_wake_marked(uint32_t n, Bodies b, uint32_t *wake, double *sinc
     if (wake[l]) { b.flags[i] = fl & ~BF_ASLEEP; if (l == i) since[i] = -1.0; }
 }
 // wake the islands of the listed bodies (wake_up_island, island_manager.cpp:541-571)
+// Index lists handed to small kernels (bodies to wake, bodies to remove): one persistent device buffer that grows on demand
+// and is released with the context - no hipMalloc / hipFree per call, nothing to leak on an error path.
+static int index_scratch(edynhip_ctx *c, size_t count, uint32_t *&out) {
+    if (count > c->idx_scratch_cap) {
+        if (c->idx_scratch) (void)hipFree(c->idx_scratch);
+        c->idx_scratch = nullptr; c->idx_scratch_cap = 0;
+        const size_t cap = std::max<size_t>(count * 2, 1024);
+        EH_HIP(c, hipMalloc((void **)&c->idx_scratch, cap * sizeof(uint32_t)));
+        c->idx_scratch_cap = cap;
+    }
+    out = c->idx_scratch;
+    return EDYNHIP_OK;
+}
 int wake_islands_of(edynhip_ctx *c, const std::vector<uint32_t> &bodies) {
     if (!c->sleeping || bodies.empty() || c->b.n == 0) { c->all_asleep = false; return EDYNHIP_OK; }
     uint32_t *list = nullptr;
-    EH_HIP(c, hipMalloc((void **)&list, bodies.size() * sizeof(uint32_t)));
+    EH_TRY(index_scratch(c, bodies.size(), list));
     EH_HIP(c, hipMemcpyAsync(list, bodies.data(), bodies.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     EH_HIP(c, hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.n * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_mark_touching, dim3(((uint32_t)bodies.size() + 127) / 128), dim3(128), 0, c->stream, (uint32_t)bodies.size(), list, c->b, c->sleep_action);
     hipLaunchKernelGGL(k_wake_marked, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, c->sleep_action, c->sleep_since);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    (void)hipFree(list);
+    hipError_t e = hipStreamSynchronize(c->stream);   // the scratch list may be refilled by the next call
     c->all_asleep = false;
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "wake_islands_of", e);
     return EDYNHIP_OK;
@@ -522,6 +534,7 @@ void edynhip_destroy(edynhip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->idx_scratch) (void)hipFree(c->idx_scratch);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
     if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
     if (c->state_host) (void)hipHostFree(c->state_host);
@@ -875,6 +888,43 @@ int edynhip_set_generic_definition(edynhip_ctx *c, uint32_t joint, const float *
         if (dof60[10 * d] != 0 && dof60[10 * d + 1] > dof60[10 * d + 2]) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_generic_definition: a limit's minimum exceeds its maximum");
     return redefine_joint(c, joint, dof60, 60, frameA, frameB);
 }
+int edynhip_set_joint_warm_start(edynhip_ctx *c, const float *impulses24, const float *angles) {
+    if (!c || !impulses24) return EDYNHIP_ERR_INVALID;
+    const uint32_t total = (uint32_t)c->host_joints.size();
+    if (total == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_TRY(flush_joint_redefs(c));
+    for (uint32_t e = 0; e < total; ++e) {
+        HostJoint &h = c->host_joints[e];
+        if (!h.alive) continue;
+        std::memcpy(h.impulse, impulses24 + (size_t)kJointSlots * e, sizeof(h.impulse));
+        if (angles) h.angle = angles[e];
+    }
+    return rebuild_joints(c, false);   // host copies -> device (colouring unchanged: same joints)
+}
+__global__ void k_set_asleep(uint32_t n, Bodies b, const uint8_t *__restrict__ asleep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t fl = b.flags[i];
+    if ((fl & BF_KIND_MASK) != EDYNHIP_KIND_DYNAMIC || (fl & (BF_REMOVED | BF_NOSLEEP))) return;
+    if (asleep[i]) {   // put_to_sleep (island_manager.cpp:553-565): tag + zero velocities
+        b.flags[i] = fl | BF_ASLEEP;
+        b.linvel[i] = make_float4(0, 0, 0, 0); b.angvel[i] = make_float4(0, 0, 0, 0);
+    } else b.flags[i] = fl & ~BF_ASLEEP;
+}
+int edynhip_set_asleep(edynhip_ctx *c, const uint8_t *asleep) {
+    if (!c || !asleep) return EDYNHIP_ERR_INVALID;
+    if (!c->sleeping || c->b.n == 0) return EDYNHIP_OK;
+    EH_HIP(c, hipSetDevice(c->device));
+    uint32_t *buf = nullptr;
+    EH_TRY(index_scratch(c, (c->b.n + 3) / 4, buf));
+    EH_HIP(c, hipMemcpyAsync(buf, asleep, c->b.n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_asleep, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, (const uint8_t *)buf);
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    c->all_asleep = false;   // decided again by the next step
+    c->force_islands = true;
+    return EDYNHIP_OK;
+}
 int edynhip_get_joint_slot_impulses(edynhip_ctx *c, float *out) {
     if (!c || !out) return EDYNHIP_ERR_INVALID;
     const uint32_t total = (uint32_t)c->host_joints.size();
@@ -1009,14 +1059,13 @@ int edynhip_remove_bodies(edynhip_ctx *c, uint32_t n, const uint32_t *indices) {
             if (h.alive && (gone[h.body[0]] || gone[h.body[1]])) { h.alive = false; joints_changed = true; partners.push_back(h.body[0]); partners.push_back(h.body[1]); }
     }
     uint32_t *list = nullptr;
-    EH_HIP(c, hipMalloc((void **)&list, (size_t)n * sizeof(uint32_t)));
+    EH_TRY(index_scratch(c, n, list));
     EH_HIP(c, hipMemcpyAsync(list, indices, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     EH_HIP(c, hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.n * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_mark_removed, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, list, c->b, c->sleep_action);
     if (c->num_manifolds) hipLaunchKernelGGL(k_wake_partners, dim3((c->num_manifolds + 255) / 256), dim3(256), 0, c->stream, c->num_manifolds, c->m[c->cur], c->b, c->sleep_action);
     hipLaunchKernelGGL(k_wake_marked, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, c->sleep_action, c->sleep_since);
     hipError_t e = hipStreamSynchronize(c->stream);
-    (void)hipFree(list);
     if (e != hipSuccess) return set_error(c, EDYNHIP_ERR_HIP, "edynhip_remove_bodies", e);
     for (uint32_t k = 0; k < n; ++k) { c->host_kind[indices[k]] = EDYNHIP_KIND_STATIC; c->host_shape[indices[k]] = EDYNHIP_SHAPE_NONE; }
     if (!c->host_excl.empty())

@@ -317,6 +317,7 @@ struct edynhip_ctx {
     uint32_t colour_split[eh::kMaxColours][3] = {{0}};   // ends of the 4-, 3- and 2-point groups inside each colour's range
     uint32_t num_active = 0;
     std::vector<void *> allocs;
+    uint32_t *idx_scratch = nullptr; size_t idx_scratch_cap = 0;   // index lists of the editing entry points (capi.hip index_scratch)
     bool clears_primed = false;    // the previous call ended with k_finish, which pre-clears the next step's scratch
     bool full_step = false;        // inside edynhip_step (all stages back to back): per-step clears are folded into kernels
     float *state_dev = nullptr;    // [max_bodies][13] staging of the packed state (get/set_state run every update in the C++ shim)

@@ -127,14 +127,22 @@ class ShardedWorld:
     all non-dynamic bodies and steps them with its own stepper - NO collective inside a step. Once per step the integrated
     state is gathered (StateGather: RCCL on GPUs, gloo on CPU) so that every rank - and the host registry - sees the whole
     world; the gathered AABBs also tell when islands of different ranks come close (island_boxes_overlap), and then the
-    islands are re-partitioned with their contact manifolds (warm-start impulses, colours) carried to their new owner.
+    islands are re-partitioned, carrying to their new owner: the contact manifolds (warm-start impulses, colours), the joints'
+    applied impulses and tracked angles, the sleeping tags, the collision exclusions and joint definitions of the scene.
+    step() runs the approach check itself after every gather (auto_repartition=True) - from the gathered positions and a
+    conservative reach per body, with the island labels of the last partition (islands that merged inside a rank since then
+    are still owned by one rank; islands that split only make the test more conservative) - and re-partitions when it fires.
+    The gather of THIS class goes through a host copy of the state (get_state -> numpy -> torch -> all_gather): it serves the
+    registry write-back of a sharded world; bench.py's timed loop packs on the device (edynhip_pack_state_device) and gathers
+    device buffers over RCCL.
 
     make_world(scene) -> a stepper with the World interface (edyn_amd.World on a GPU; the CPU tests pass the checker).
     Body order inside a shard is ascending global index, so canonical pair keys, island labels (lowest index) and the
     colouring keep their relative order: a shard computes exactly what the unsharded world computes for those islands."""
 
-    def __init__(self, scene, make_world, rank, world_size, backend="nccl", device="cuda", labels=None, weights=None):
+    def __init__(self, scene, make_world, rank, world_size, backend="nccl", device="cuda", labels=None, weights=None, auto_repartition=True):
         self.scene, self.make_world = scene, make_world
+        self.auto_repartition = auto_repartition
         self.rank, self.world_size, self.backend, self.device = rank, world_size, backend, device
         self.kind = np.asarray(scene["kind"])
         self.n = len(self.kind)
@@ -152,10 +160,16 @@ class ShardedWorld:
         if weights is None:
             weights = np.ones(self.n)
         self.repartitions = 0
+        # conservative reach of every body around its position (no point of the shape is further away), for the per-step approach check
+        sp, st = np.asarray(scene["shape_param"], np.float64), np.asarray(scene["shape_type"])
+        self.reach = np.where(st == 1, np.linalg.norm(sp[:, :3], axis=1), np.where(st == 2, sp[:, 0], np.where(st == 4, sp[:, 0] + sp[:, 1], 0.0)))
+        if "center_of_mass" in scene:
+            self.reach = self.reach + np.linalg.norm(np.asarray(scene["center_of_mass"], np.float64), axis=1)
+        self.part_labels = np.asarray(labels).copy()
         self._build(partition_islands(labels, self.kind, weights, world_size), scene, manifolds=None)
 
     # -- shard construction
-    def _build(self, rank_of, scene, manifolds):
+    def _build(self, rank_of, scene, manifolds, carry=None):
         self.rank_of = rank_of
         mine = (rank_of == self.rank) | (rank_of < 0)
         self.local_ids = np.nonzero(mine)[0].astype(np.int64)            # ascending global indices
@@ -164,16 +178,31 @@ class ShardedWorld:
         counts = [int((rank_of == r).sum()) for r in range(self.world_size)]
         self.owners = [np.nonzero(rank_of == r)[0] for r in range(self.world_size)]
         local_scene = subset(scene, self.local_ids)
-        local_scene["joints"] = [(j[0], int(self.to_local[j[1]]), int(self.to_local[j[2]])) + tuple(j[3:])
-                                 for j in scene.get("joints") or [] if self.to_local[j[1]] >= 0 and self.to_local[j[2]] >= 0
-                                 and (rank_of[j[1]] == self.rank or rank_of[j[2]] == self.rank)]
+        # joints whose bodies are here and of which this rank owns one (a joint to a replicated static anchor lives on one rank)
+        self.local_joints = [g for g, j in enumerate(scene.get("joints") or []) if self.to_local[j[1]] >= 0 and self.to_local[j[2]] >= 0
+                             and (rank_of[j[1]] == self.rank or rank_of[j[2]] == self.rank)]
+        jl = {g: l for l, g in enumerate(self.local_joints)}
+        local_scene["joints"] = [(scene["joints"][g][0], int(self.to_local[scene["joints"][g][1]]), int(self.to_local[scene["joints"][g][2]])) + tuple(scene["joints"][g][3:])
+                                 for g in self.local_joints]
+        # what apply_figure_settings needs, in local indices: joint parameter blocks / definitions and collision exclusions
+        local_scene["hinge_params"] = [(jl[j], p) for j, p in scene.get("hinge_params", []) if j in jl]
+        local_scene["joint_defs"] = [(jl[j], fa, fb, p) for j, fa, fb, p in scene.get("joint_defs", []) if j in jl]
+        local_scene["exclusions"] = [(int(self.to_local[a]), int(self.to_local[b])) for a, b in scene.get("exclusions", [])
+                                     if self.to_local[a] >= 0 and self.to_local[b] >= 0 and (rank_of[a] == self.rank or rank_of[b] == self.rank)]
         self.world = self.make_world(local_scene)
+        from .scenes import apply_figure_settings
+        apply_figure_settings(self.world, local_scene)
         if manifolds is not None and len(manifolds):
             a, b = manifolds["body"][:, 0], manifolds["body"][:, 1]
             keep = ((rank_of[a] == self.rank) | (rank_of[b] == self.rank))
             rec = manifolds[keep].copy()
             rec["body"] = self.to_local[rec["body"]]
             self.world.set_manifolds(rec)                                  # relative order = canonical order (monotone index map)
+        if carry is not None:
+            if self.local_joints and carry.get("joint_imp") is not None and hasattr(self.world, "set_joint_warm_start"):
+                self.world.set_joint_warm_start(carry["joint_imp"][self.local_joints], carry["joint_angle"][self.local_joints])
+            if carry.get("asleep") is not None and carry["asleep"].any() and hasattr(self.world, "set_asleep"):
+                self.world.set_asleep(carry["asleep"][self.local_ids])
         self.gather = StateGather(counts, self.device, self.backend)
         self.state = np.zeros((self.n, 13), np.float32)
 
@@ -182,6 +211,16 @@ class ShardedWorld:
         for _ in range(n):
             self.world.step_simulation(1) if hasattr(self.world, "step_simulation") else self.world.step(1)
             self._gather_state()
+            if self.auto_repartition and self.world_size > 1 and self._islands_close():
+                self.maybe_repartition()
+
+    def _islands_close(self):
+        """Conservative, collective-free approach test on the gathered state (identical on every rank, so every rank takes the
+        same decision): body boxes = position +- reach, islands = those of the last partition."""
+        pos = self.state[:, 0:3].astype(np.float64)
+        r = self.reach[:, None]
+        aabb = np.concatenate([pos - r, pos + r], axis=1)
+        return bool(island_boxes_overlap(aabb, self.part_labels, self.kind, self.rank_of))
 
     def _gather_state(self):
         pos, orn, lv, av = self.world.get_state()
@@ -259,10 +298,26 @@ class ShardedWorld:
             da, db = self.kind[manifolds["body"][:, 0]] == KIND_DYNAMIC, self.kind[manifolds["body"][:, 1]] == KIND_DYNAMIC
             owner = np.where(da & db, np.maximum(a, b), np.where(da, a, b)); other = np.where(owner == a, b, a)
             manifolds = manifolds[np.argsort((owner << np.uint64(32)) | other, kind="stable")]
+        # joints (applied impulses of all 24 slots + tracked angles) and sleeping tags travel with their islands
+        carry = {"joint_imp": None, "joint_angle": None, "asleep": None}
+        nj = len(self.scene.get("joints") or [])
+        if nj and hasattr(self.world, "get_joint_impulses24"):
+            imp = self.world.get_joint_impulses24() if self.local_joints else np.zeros((0, 24), np.float32)
+            ang = self.world.get_joint_impulses()[:, 9] if self.local_joints else np.zeros(0, np.float32)
+            carry["joint_imp"] = np.zeros((nj, 24), np.float32); carry["joint_angle"] = np.zeros(nj, np.float32)
+            for ids, i24, a in self._all_gather_object((np.asarray(self.local_joints, np.int64), imp, ang)):
+                if len(ids):
+                    carry["joint_imp"][ids] = i24; carry["joint_angle"][ids] = a
+        if hasattr(self.world, "get_asleep"):
+            asl = np.asarray(self.world.get_asleep(), bool)[self.to_local[self.owned]]
+            carry["asleep"] = np.zeros(self.n, bool)
+            for ids, a in self._all_gather_object((self.owned, asl)):
+                carry["asleep"][ids] = a
         scene = dict(self.scene)
         pos, orn, lv, av = self.get_state()
         scene["pos"], scene["orn"], scene["linvel"], scene["angvel"] = pos, orn, lv, av
-        self._build(rank_of, scene, manifolds)
+        self.part_labels = welded
+        self._build(rank_of, scene, manifolds, carry)
         self.repartitions += 1
         self._gather_state_without_step()
         return True

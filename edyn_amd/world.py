@@ -477,6 +477,20 @@ class World:
         self._check(self._L.edynhip_debug_collide(self._h, n, _ptr(st), _ptr(sp), _ptr(ps), _ptr(qs), threshold, _ptr(out), _ptr(cnt)))
         return out, cnt
 
+    def set_joint_warm_start(self, impulses24, angles=None):
+        """Applied impulses ([nj, 24], the layout of get_joint_impulses24) and tracked angles of the joints, by caller index: what a
+        world carries into another (edynhip_set_joint_warm_start)."""
+        self._flush_defs()
+        imp = np.ascontiguousarray(impulses24, np.float32).reshape(self.nj, 24)
+        ang = None if angles is None else np.ascontiguousarray(angles, np.float32).reshape(self.nj)
+        self._check(self._L.edynhip_set_joint_warm_start(self._h, _ptr(imp), _ptr(ang) if ang is not None else None))
+
+    def set_asleep(self, flags):
+        """Sleeping tags by body (edynhip_set_asleep): sleeping bodies get zero velocities."""
+        f = np.ascontiguousarray(np.asarray(flags).astype(np.uint8))
+        assert len(f) == self.n
+        self._check(self._L.edynhip_set_asleep(self._h, _ptr(f)))
+
     def get_asleep(self):
         out = np.zeros(self.n, np.uint8)
         if self.n:

@@ -203,7 +203,10 @@ struct gpu_stepper {
     std::vector<entt::entity> bodies;          // body index -> entity (creation order); entt::null = destroyed (the index stays reserved)
     std::vector<entt::entity> constraints;     // joint index -> entity, same convention
     std::vector<uint8_t> constraint_kind;      // joint index -> EDYNHIP_JOINT_*: one entity may carry several constraint types (make_ragdoll: cone + cvjoint)
-    std::vector<std::array<uint32_t, 2>> pending_exclusions;   // exclude_collision calls made before the bodies were uploaded
+    std::vector<std::array<uint32_t, 2>> exclusions;   // every active exclude_collision pair (body indices): replayed into a re-created context
+    size_t exclusions_uploaded{0};                     // how many of them the current device context already holds (a prefix)
+    std::vector<float> shadow;                         // asynchronous mode: the state this shim last wrote into the registry (13 floats per body) - what differs was edited by the user
+    unsigned snapshot_bodies{0};                       // bodies the snapshot in flight covers
     bool scene_dirty{true}, state_dirty{false}, paused{false}, params_dirty{false};
     double accumulated{0}, last_time{0};
     unsigned capacity{0}, joint_capacity{0};
@@ -296,6 +299,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     const uint32_t total = (uint32_t)s.bodies.size();
     const uint32_t nj = (uint32_t)s.constraints.size();
     std::vector<edynhip_manifold> carried;   // contact state carried over a capacity growth (indices are stable)
+    std::vector<float> carried_impulses, carried_angles;   // joints: 24 applied-impulse slots + the tracked angle, by joint index
+    std::vector<uint8_t> carried_asleep;                   // sleeping tags by body index
     bool regrown = false;
     if (!s.ctx || total > s.capacity || nj > s.joint_capacity || s.recreate) {
         s.recreate = false;
@@ -322,7 +327,21 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
                 }
                 s.refresh_friction = false;
             }
+            // joints' applied impulses (warm start) and tracked angles, and the sleeping tags, travel too (by index: both are stable)
+            if (s.uploaded_constraints) {
+                carried_impulses.assign((size_t)24 * s.uploaded_constraints, 0.f);
+                std::vector<float> imp10((size_t)10 * s.uploaded_constraints, 0.f);
+                check(s, edynhip_get_joint_slot_impulses(s.ctx, carried_impulses.data()));
+                check(s, edynhip_get_joint_impulses(s.ctx, imp10.data()));
+                carried_angles.resize(s.uploaded_constraints);
+                for (uint32_t j = 0; j < s.uploaded_constraints; ++j) carried_angles[j] = imp10[(size_t)10 * j + 9];
+            }
+            if (s.cfg.island_sleeping && s.uploaded_bodies) {
+                carried_asleep.assign(s.uploaded_bodies, 0);
+                check(s, edynhip_get_asleep(s.ctx, carried_asleep.data()));
+            }
             edynhip_destroy(s.ctx); s.ctx = nullptr;
+            s.exclusions_uploaded = 0;
             regrown = true;
             s.contacts_resync = true; s.snapshot_pending = false;
         }
@@ -401,6 +420,18 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     if (first == 0) for (auto &m : s.mixings) check(s, edynhip_insert_material_mixing(s.ctx, m.id0, m.id1, m.v));   // a (re)created context
     if (any_ids) check(s, edynhip_set_material_ids(s.ctx, first, n, mat_ids.data()));
     if (!dead.empty()) check(s, edynhip_remove_bodies(s.ctx, (uint32_t)dead.size(), dead.data()));
+    if (s.cfg.execution_mode == execution_mode::asynchronous) {   // the registry state these bodies went up with is what "unedited" means for them
+        if (s.shadow.size() < (size_t)13 * total) s.shadow.resize((size_t)13 * total, 0.f);
+        for (uint32_t i = first; i < total; ++i) {
+            const entt::entity e = s.bodies[i];
+            if (e == entt::null) continue;
+            float *sh = &s.shadow[(size_t)13 * i];
+            const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
+            sh[0] = p.x; sh[1] = p.y; sh[2] = p.z; sh[3] = q.x; sh[4] = q.y; sh[5] = q.z; sh[6] = q.w;
+            if (auto *v = registry.try_get<linvel>(e)) { sh[7] = v->x; sh[8] = v->y; sh[9] = v->z; }
+            if (auto *w = registry.try_get<angvel>(e)) { sh[10] = w->x; sh[11] = w->y; sh[12] = w->z; }
+        }
+    }
     s.uploaded_bodies = total;
     if (regrown && !carried.empty()) check(s, edynhip_set_manifolds(s.ctx, carried.data(), (uint32_t)carried.size()));
     // joints: everything after a (re)creation of the context, otherwise only the ones made since the last upload
@@ -451,10 +482,24 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
         }
     }
+    if (regrown && !carried_impulses.empty()) {   // joints created since then start from zero impulses, like any new joint
+        // (a joint made just now keeps the angle reset_angle gave it: its carried slot is not applied)
+        const uint32_t had = (uint32_t)std::min<size_t>(carried_angles.size(), nj);
+        carried_impulses.resize((size_t)24 * nj, 0.f); carried_angles.resize(nj, 0.f);
+        std::vector<float> now10((size_t)10 * nj, 0.f);
+        check(s, edynhip_get_joint_impulses(s.ctx, now10.data()));
+        for (uint32_t j = 0; j < nj; ++j) if (j >= had || s.constraints[j] == entt::null) carried_angles[j] = now10[(size_t)10 * j + 9];
+        check(s, edynhip_set_joint_warm_start(s.ctx, carried_impulses.data(), carried_angles.data()));
+    }
     if (!dead_joints.empty()) check(s, edynhip_remove_joints(s.ctx, (uint32_t)dead_joints.size(), dead_joints.data()));
     s.uploaded_constraints = nj;
-    for (auto &ex : s.pending_exclusions) check(s, edynhip_exclude_collision(s.ctx, ex[0], ex[1]));
-    s.pending_exclusions.clear();
+    // collision exclusions: the whole list into a (re)created context, the new ones otherwise
+    for (size_t k = s.exclusions_uploaded; k < s.exclusions.size(); ++k) check(s, edynhip_exclude_collision(s.ctx, s.exclusions[k][0], s.exclusions[k][1]));
+    s.exclusions_uploaded = s.exclusions.size();
+    if (regrown && !carried_asleep.empty()) {
+        carried_asleep.resize(total, 0);
+        check(s, edynhip_set_asleep(s.ctx, carried_asleep.data()));
+    }
     s.scene_dirty = false;
     if (first == 0) s.state_dirty = false;
 }
@@ -638,16 +683,47 @@ inline void sync_contacts(entt::registry &registry, gpu_stepper &s) {
     if (s.cfg.contact_point_data) refresh_contact_points(registry, s);
 }
 inline void import_state(entt::registry &registry, gpu_stepper &s, const std::vector<float> &pos, const std::vector<float> &orn,
-                         const std::vector<float> &lv, const std::vector<float> &av) {
-    const uint32_t n = (uint32_t)std::min(s.bodies.size(), pos.size() / 3);
+                         const std::vector<float> &lv, const std::vector<float> &av, uint32_t count) {
+    // `count` = the bodies the arrays cover (a snapshot taken before bodies were appended covers fewer than exist now)
+    const uint32_t n = (uint32_t)std::min<size_t>(s.bodies.size(), count);
+    if (s.shadow.size() < (size_t)13 * s.bodies.size()) s.shadow.resize((size_t)13 * s.bodies.size(), 0.f);
     for (uint32_t i = 0; i < n; ++i) {
         const entt::entity e = s.bodies[i];
-        if (e == entt::null || !registry.all_of<dynamic_tag>(e)) continue;
+        if (e == entt::null || !registry.valid(e) || !registry.all_of<dynamic_tag>(e)) continue;
         auto &p = registry.get<position>(e); p.x = pos[3 * i]; p.y = pos[3 * i + 1]; p.z = pos[3 * i + 2];
         auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
         auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
         auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
+        float *sh = &s.shadow[(size_t)13 * i];
+        sh[0] = p.x; sh[1] = p.y; sh[2] = p.z; sh[3] = q.x; sh[4] = q.y; sh[5] = q.z; sh[6] = q.w;
+        sh[7] = v.x; sh[8] = v.y; sh[9] = v.z; sh[10] = w.x; sh[11] = w.y; sh[12] = w.z;
     }
+}
+// Asynchronous mode with user edits pending (edyn::refresh, rigidbody_apply_impulse, set_kinematic_* between two updates): the
+// registry is one update behind the device, so neither "import the snapshot" (the edits would be overwritten) nor "upload the
+// registry" (every other body would be rewound by an update) is right. The reference sends such edits to the simulation worker,
+// which applies them to ITS current state (simulation_worker.cpp, registry operations). Here: fetch the device's current state
+// (this one update waits for the GPU), find the bodies whose registry state differs from what this shim last wrote there (the
+// shadow) - those were edited -, carry a velocity edit over as an increment on the current velocity (an impulse stays an
+// impulse) and a transform edit as the new transform, bring the registry up to date, and let upload_state push the result.
+inline void merge_user_edits(entt::registry &registry, gpu_stepper &s) {
+    const uint32_t n = std::min<uint32_t>((uint32_t)s.bodies.size(), s.uploaded_bodies);
+    if (n == 0) return;
+    std::vector<float> pos(3 * (size_t)s.uploaded_bodies), orn(4 * (size_t)s.uploaded_bodies), lv(3 * (size_t)s.uploaded_bodies), av(3 * (size_t)s.uploaded_bodies);
+    check(s, edynhip_get_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
+    if (s.shadow.size() < (size_t)13 * s.bodies.size()) s.shadow.resize((size_t)13 * s.bodies.size(), 0.f);
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[i];
+        if (e == entt::null || !registry.valid(e) || !registry.all_of<dynamic_tag>(e)) continue;   // static / kinematic: the registry is the authority
+        const float *sh = &s.shadow[(size_t)13 * i];
+        auto &p = registry.get<position>(e); auto &q = registry.get<orientation>(e);
+        auto &v = registry.get<linvel>(e); auto &w = registry.get<angvel>(e);
+        const bool moved = p.x != sh[0] || p.y != sh[1] || p.z != sh[2] || q.x != sh[3] || q.y != sh[4] || q.z != sh[5] || q.w != sh[6];
+        if (moved) { pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z; orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w; }
+        lv[3 * i] += v.x - sh[7]; lv[3 * i + 1] += v.y - sh[8]; lv[3 * i + 2] += v.z - sh[9];
+        av[3 * i] += w.x - sh[10]; av[3 * i + 1] += w.y - sh[11]; av[3 * i + 2] += w.z - sh[12];
+    }
+    import_state(registry, s, pos, orn, lv, av, n);   // the registry (and the shadow) now hold the current state plus the edits
 }
 inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, bool timed = false, double first_time = 0, double step_dt = 0) {
     const bool async = s.cfg.execution_mode == execution_mode::asynchronous;
@@ -655,10 +731,13 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
         // execution_mode::asynchronous: the registry receives the PREVIOUS update's result (handed over while this update's
         // steps run, like the simulation worker's snapshots, simulation_worker.cpp:406-444) - contact entities and sleeping
         // tags of that update too, all read before the next steps are enqueued.
-        const uint32_t n = (uint32_t)s.bodies.size();
-        std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n);
-        check(s, edynhip_snapshot_read(s.ctx, pos.data(), orn.data(), lv.data(), av.data(), nullptr));
-        import_state(registry, s, pos, orn, lv, av);
+        if (s.state_dirty) merge_user_edits(registry, s);   // the snapshot is superseded by the current state + the edits
+        else {
+            const uint32_t n = std::max<uint32_t>(s.snapshot_bodies, 1u);   // what the snapshot covers: bodies appended since are not in it
+            std::vector<float> pos(3 * (size_t)n), orn(4 * (size_t)n), lv(3 * (size_t)n), av(3 * (size_t)n);
+            check(s, edynhip_snapshot_read(s.ctx, pos.data(), orn.data(), lv.data(), av.data(), nullptr));
+            import_state(registry, s, pos, orn, lv, av, s.snapshot_bodies);
+        }
         sync_contacts(registry, s);
         s.snapshot_pending = false;
     }
@@ -684,6 +763,7 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
     if (async) {
         check(s, edynhip_snapshot(s.ctx));   // returns at once; read at the next update
         s.snapshot_pending = true;
+        s.snapshot_bodies = s.uploaded_bodies;
         return;
     }
     write_back(registry, s);
@@ -708,6 +788,7 @@ inline void update_presentation(entt::registry &registry, gpu_stepper &s, double
     const double sim_time = s.last_time - s.accumulated;
     const scalar idt = std::min(static_cast<scalar>(time - s.cfg.fixed_dt - sim_time), s.cfg.fixed_dt);
     for (const entt::entity e : s.bodies) {
+        if (e == entt::null || !registry.valid(e)) continue;   // destroyed bodies keep their index
         if (!registry.all_of<present_position>(e) || registry.all_of<sleeping_tag>(e)) continue;
         const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
         const auto &v = registry.get<linvel>(e); const auto &w = registry.get<angvel>(e);
@@ -882,17 +963,26 @@ entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt:
 inline void exclude_collision(entt::registry &registry, entt::entity first, entt::entity second) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     const uint32_t a = registry.get<detail::body_index>(first).value, b = registry.get<detail::body_index>(second).value;
-    if (s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies && !s.scene_dirty) detail::check(s, edynhip_exclude_collision(s.ctx, a, b));
-    else { s.pending_exclusions.push_back({a, b}); s.scene_dirty = true; }
+    // recorded for good (a re-created context gets the whole list again); sent at once when the device already holds everything
+    // recorded before it, else with the next upload
+    s.exclusions.push_back({a, b});
+    if (s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies && !s.scene_dirty && s.exclusions_uploaded + 1 == s.exclusions.size()) {
+        detail::check(s, edynhip_exclude_collision(s.ctx, a, b));
+        s.exclusions_uploaded = s.exclusions.size();
+    } else s.scene_dirty = true;
 }
 inline void remove_collision_exclusion(entt::registry &registry, entt::entity first, entt::entity second) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     const uint32_t a = registry.get<detail::body_index>(first).value, b = registry.get<detail::body_index>(second).value;
-    for (size_t k = s.pending_exclusions.size(); k; --k) {
-        auto &ex = s.pending_exclusions[k - 1];
-        if ((ex[0] == a && ex[1] == b) || (ex[0] == b && ex[1] == a)) s.pending_exclusions.erase(s.pending_exclusions.begin() + (k - 1));
+    bool on_device = false;
+    for (size_t k = s.exclusions.size(); k; --k) {
+        auto &ex = s.exclusions[k - 1];
+        if ((ex[0] == a && ex[1] == b) || (ex[0] == b && ex[1] == a)) {
+            if (k - 1 < s.exclusions_uploaded) { on_device = true; --s.exclusions_uploaded; }
+            s.exclusions.erase(s.exclusions.begin() + (k - 1));
+        }
     }
-    if (s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies) detail::check(s, edynhip_remove_collision_exclusion(s.ctx, a, b));
+    if (on_device && s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies) detail::check(s, edynhip_remove_collision_exclusion(s.ctx, a, b));
 }
 /// util/rigidbody.hpp:95-103, rigidbody.cpp:193-226: strips everything make_rigidbody assigned; the entity itself lives on.
 inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
@@ -908,7 +998,8 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
 
 // ---- util/rigidbody.hpp:105-260: edits of a body between updates. Velocity / transform edits go to the device with the next update
 // (they mark the state dirty like edyn::refresh); mass / inertia / friction edits re-create the device context at the next update,
-// carrying contacts (warm-start impulses), joints and sleep state over - rare operations, kept simple.
+// carrying contacts (warm-start impulses), joints (applied impulses, tracked angles), collision exclusions and sleeping tags over (island
+// sleep timers of awake islands restart) - rare operations, kept simple.
 namespace detail {
 inline matrix3x3 mat_mul(const matrix3x3 &a, const matrix3x3 &b) {
     matrix3x3 r{};

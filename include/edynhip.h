@@ -346,6 +346,13 @@ int edynhip_set_center_of_mass(edynhip_ctx *ctx, uint32_t body, const float *com
 
 int edynhip_get_timings(edynhip_ctx *ctx, edynhip_timings *out);
 int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);
+/* State a caller carries from one context into another (the C++ shim re-creates a context to grow it): the joints' applied
+ * impulses - all 24 slots per joint, the layout of edynhip_get_joint_slot_impulses - and tracked angles (the 10th value of
+ * edynhip_get_joint_impulses; NULL keeps the angles), by caller joint index; and the sleeping tags of the bodies (as
+ * edynhip_get_asleep returns them; sleeping bodies get zero velocities, island timers of awake islands restart). */
+int edynhip_set_joint_warm_start(edynhip_ctx *ctx, const float *impulses24, const float *angles);
+int edynhip_set_asleep(edynhip_ctx *ctx, const uint8_t *asleep);
+
 uint32_t edynhip_abi_version(void);
 
 /* Measurement aid for the roofline report (bench.py): streams `bytes` of device memory with 16-byte loads from every CU (read_gbs)

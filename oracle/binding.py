@@ -69,6 +69,8 @@ def lib():
         L.orc_set_sleeping_disabled.argtypes = [C.c_void_p, C.c_uint32, C.c_int]; L.orc_set_sleeping_disabled.restype = None
         L.orc_wake_all.argtypes = [C.c_void_p]; L.orc_wake_all.restype = None
         L.orc_get_asleep.argtypes = [C.c_void_p, C.c_void_p]; L.orc_get_asleep.restype = None
+        L.orc_set_asleep.argtypes = [C.c_void_p, C.c_void_p]; L.orc_set_asleep.restype = None
+        L.orc_set_joint_warm_start.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]; L.orc_set_joint_warm_start.restype = None
         L.orc_step.argtypes = [C.c_void_p, C.c_int]
         L.orc_run_stage.argtypes = [C.c_void_p, C.c_int]
         L.orc_num_bodies.restype = C.c_uint32
@@ -296,6 +298,15 @@ class World:
 
     def wake_all(self):
         self.L.orc_wake_all(self.h)
+
+    def set_joint_warm_start(self, impulses24, angles=None):
+        imp = np.ascontiguousarray(impulses24, np.float32)
+        ang = None if angles is None else np.ascontiguousarray(angles, np.float32)
+        self.L.orc_set_joint_warm_start(self.h, _fp(imp), _fp(ang) if ang is not None else None)
+
+    def set_asleep(self, flags):
+        f = np.ascontiguousarray(np.asarray(flags).astype(np.uint8))
+        self.L.orc_set_asleep(self.h, f.ctypes.data_as(C.c_void_p))
 
     def get_asleep(self):
         out = np.zeros(self.num_bodies, np.uint8)

@@ -310,6 +310,24 @@ void orc_get_joint_impulses24(void *h, float *out24) {
     for (size_t i = 0; i < w->joints.size(); ++i)
         for (int k = 0; k < 24; ++k) out24[24 * i + k] = w->joints[i].alive ? w->joints[i].impulse[k] : 0.0f;
 }
+// what a world carries into another (edynhip_set_joint_warm_start / edynhip_set_asleep do the same on the device)
+void orc_set_joint_warm_start(void *h, const float *imp24, const float *angles) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->joints.size(); ++i) {
+        if (!w->joints[i].alive) continue;
+        for (int k = 0; k < 24; ++k) w->joints[i].impulse[k] = imp24[24 * i + k];
+        if (angles) w->joints[i].angle = angles[i];
+    }
+}
+void orc_set_asleep(void *h, const uint8_t *flags) {
+    World *w = (World *)h;
+    for (size_t i = 0; i < w->bodies.size(); ++i) {
+        Body &b = w->bodies[i];
+        if (b.kind != KIND_DYNAMIC || b.removed || b.sleeping_disabled) continue;
+        b.asleep = flags[i] != 0;
+        if (b.asleep) { b.linvel = {0, 0, 0}; b.angvel = {0, 0, 0}; }
+    }
+}
 // material ids and the mix table (edyn::insert_material_mixing)
 void orc_set_material_id(void *h, uint32_t body, uint32_t id) { ((World *)h)->bodies[body].material_id = id; }
 void orc_insert_material_mixing(void *h, uint32_t id0, uint32_t id1, const float *m6) {

@@ -88,6 +88,43 @@ int main() {
         }
     }
     REQUIRE(count<edyn::contact_manifold>(async_reg) > 0);
+    // ---- asynchronous mode with the user editing between updates: a body made mid-run and an impulse applied mid-run
+    // must reach the device as they would in synchronous mode - the registry lags one update, the simulation does not
+    {
+        entt::registry sreg, areg;
+        auto c2 = edyn::init_config{};
+        edyn::attach(sreg, c2);
+        c2.execution_mode = edyn::execution_mode::asynchronous;
+        edyn::attach(areg, c2);
+        std::vector<entt::entity> s2, a2;
+        build(sreg, s2); build(areg, a2);
+        entt::entity s_new = entt::null, a_new = entt::null;
+        std::vector<edyn::position> hist13, hist_new;
+        double t2 = 0;
+        for (int i = 0; i < 60; ++i) {
+            t2 += 1.0 / 60;
+            edyn::update(sreg, t2); edyn::update(areg, t2);
+            hist13.push_back(sreg.get<edyn::position>(s2[13]));
+            if (s_new != entt::null) hist_new.push_back(sreg.get<edyn::position>(s_new));
+            if (i == 20) {   // between two updates: a new box above the pile, an impulse on box 13 (both worlds alike)
+                auto def = edyn::rigidbody_def{};
+                def.mass = 1; def.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}}; def.position = {1.02f, 6.0f, 1.02f}; def.sleeping_disabled = true;
+                s_new = edyn::make_rigidbody(sreg, def); a_new = edyn::make_rigidbody(areg, def);
+                edyn::rigidbody_apply_impulse(sreg, s2[13], {0, 0, 3.0f}, {0, 0, 0});
+                edyn::rigidbody_apply_impulse(areg, a2[13], {0, 0, 3.0f}, {0, 0, 0});
+            }
+            if (i >= 22) {   // one update late again (the velocity edit is carried as an increment: equal up to its rounding)
+                const auto &p = areg.get<edyn::position>(a2[13]);
+                REQUIRE(std::fabs(p.x - hist13[i - 1].x) < 1e-4f && std::fabs(p.y - hist13[i - 1].y) < 1e-4f && std::fabs(p.z - hist13[i - 1].z) < 1e-4f);
+                const auto &pn = areg.get<edyn::position>(a_new);
+                const auto &hn = hist_new[hist_new.size() - 2];
+                REQUIRE(std::isfinite(pn.y) && std::fabs(pn.x - hn.x) < 1e-4f && std::fabs(pn.y - hn.y) < 1e-4f && std::fabs(pn.z - hn.z) < 1e-4f);
+            }
+        }
+        REQUIRE(std::fabs(sreg.get<edyn::position>(s2[13]).z - 1.02f) > 0.05f);   // the impulse did move it
+        const auto &qn = areg.get<edyn::orientation>(a_new);
+        REQUIRE(std::fabs(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w - 1.0f) < 1e-4f);   // never a zero quaternion
+    }
     // ---- contact_extras through the shim: material::roll_friction stops a rolling sphere, the default lets it roll on
     entt::registry roll_reg;
     edyn::attach(roll_reg, edyn::init_config{});

@@ -6,6 +6,7 @@
 //   exclude_collision                                                                   util/exclude_collision.hpp:20-47
 //   capacity growth while running (contacts carried over), update(registry) without a time argument
 #include <edyn/edyn.hpp>
+#include <edyn/util/ragdoll.hpp>
 #include <cmath>
 #include <cstdio>
 
@@ -210,6 +211,59 @@ int main() {
     CHECK(edyn::get_time(registry) == 1000.0);
     CHECK(edyn::get_execution_mode(registry) == edyn::execution_mode::sequential && edyn::get_max_steps_per_update(registry) >= 1);
     edyn::detach(registry);
+    // ---- a rag doll (21 collision exclusions between its limbs, 36 constraints) in a world that outgrows its capacity and then has
+    // a body's friction edited (both re-create the device context): the exclusions, the joints' warm-start impulses and tracked
+    // angles must travel - no manifold may ever appear between two bodies of the figure (they used to be dropped)
+    {
+        entt::registry world;
+        auto cfg = edyn::init_config{};
+        cfg.max_bodies = 32;   // the figure fits; the crowd added below does not
+        edyn::attach(world, cfg);
+        auto ground = edyn::rigidbody_def{};
+        ground.kind = edyn::rigidbody_kind::rb_static;
+        ground.shape = edyn::plane_shape{{0, 1, 0}, 0};
+        edyn::make_rigidbody(world, ground);
+        edyn::ragdoll_simple_def rd;
+        rd.position = {0, 1.2f, 0};
+        const edyn::ragdoll_entities rag = edyn::make_ragdoll(world, rd);
+        (void)rag;
+        auto &st = world.ctx().get<edyn::detail::gpu_stepper>();
+        const size_t figure_first = 1, figure_end = st.bodies.size();
+        auto is_limb = [&](entt::entity e) {
+            for (size_t i = figure_first; i < figure_end; ++i) if (st.bodies[i] == e) return true;
+            return false;
+        };
+        auto excluded_pair_touching = [&]() {   // a manifold between two limbs that exclude each other
+            int bad = 0;
+            for (auto &m : edyn::get_contact_manifolds(world)) {
+                if (!is_limb(m.body[0]) || !is_limb(m.body[1])) continue;
+                const uint32_t a = world.get<edyn::detail::body_index>(m.body[0]).value, b = world.get<edyn::detail::body_index>(m.body[1]).value;
+                for (auto &ex : st.exclusions) if ((ex[0] == a && ex[1] == b) || (ex[0] == b && ex[1] == a)) ++bad;
+            }
+            return bad;
+        };
+        double tw = 0;
+        auto step = [&](int frames) { for (int i = 0; i < frames; ++i) { tw += 1.0 / 60; edyn::update(world, tw); } };
+        step(45);   // the figure collapses onto the floor: its limbs fold over each other
+        CHECK(st.exclusions.size() >= 20);
+        CHECK(excluded_pair_touching() == 0);
+        auto crowd = edyn::rigidbody_def{};
+        crowd.shape = edyn::box_shape{{0.25f, 0.25f, 0.25f}};
+        for (int i = 0; i < 40; ++i) { crowd.position = {4.0f + 0.7f * (i % 8), 0.25f + 0.6f * (i / 8), 3.0f}; edyn::make_rigidbody(world, crowd); }
+        step(45);   // capacity growth happened in the first of these updates
+        CHECK(st.capacity > 32);
+        CHECK(excluded_pair_touching() == 0);
+        edyn::set_rigidbody_friction(world, st.bodies[figure_first], 0.9f);   // re-creates the context once more
+        step(45);
+        CHECK(excluded_pair_touching() == 0);
+        const auto &pelvis = world.get<edyn::position>(st.bodies[figure_first]);
+        CHECK(std::isfinite(pelvis.x) && std::isfinite(pelvis.y) && pelvis.y > 0.0f && pelvis.y < 1.5f);   // lying on the floor, in one piece
+        // removing an exclusion takes it off the list for good (it is not replayed into the next context)
+        const size_t before = st.exclusions.size();
+        edyn::remove_collision_exclusion(world, st.bodies[st.exclusions[0][0]], st.bodies[st.exclusions[0][1]]);
+        CHECK(st.exclusions.size() == before - 1);
+        step(2);
+    }
     std::printf(failures == 0 ? "LIFECYCLE_OK\n" : "LIFECYCLE_FAIL\n");
     return failures == 0 ? 0 : 1;
 }

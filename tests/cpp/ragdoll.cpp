@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
             }
             std::printf("\n");
         }
-        for (auto &x : s.pending_exclusions) std::printf("exclude %u %u\n", x[0] - first, x[1] - first);
+        for (auto &x : s.exclusions) std::printf("exclude %u %u\n", x[0] - first, x[1] - first);
         std::printf("entities %d %d\n", (int)(rag.head != rag.hand_right), (int)(rag.wrist_right_constraint != rag.hip_torso_lower_constraint));
         std::printf("RAGDOLL_DUMP_OK\n");
         return 0;

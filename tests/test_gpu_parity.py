@@ -1494,3 +1494,33 @@ def test_ragdoll_landing_on_the_pile_leaves_the_mixed_schedule_in_the_same_step(
     mixed_steps = [i for i, n in enumerate(launches) if n == 2]
     assert len(mixed_steps) > 10 and launches[-1] > 20, launches        # mixed while the figure falls, per colour once it has landed
     assert max(mixed_steps) < len(launches) - 10 and all(n > 20 for n in launches[max(mixed_steps) + 1:]), launches
+
+
+def test_joint_warm_start_and_sleep_tags_carried_into_a_new_context():
+    """edynhip_set_joint_warm_start / edynhip_set_asleep (ABI v10): a second context that receives the first one's state, manifolds,
+    joint impulses + tracked angles and sleeping tags continues bit for bit like the first (what the C++ shim does when it grows a
+    context or a mass / friction edit re-creates it)."""
+    chains = scenes.c5_chains(3, 5)
+    chains["hinge_params"] = [(j, [-0.5, 0.5, 0.2, 0.2, 15.0, 0.05, 0.0, 0.1, 1.5, 0.01]) for j, t in enumerate(chains["joints"]) if t[0] == scenes.JOINT_HINGE]
+    chains["pos"][:, 0] += 20.0
+    sc = scenes.merge(scenes.mini_piles(2, 1), chains)
+    def make(sleeping):
+        w = gpu_world(sc, sleeping=sleeping); scenes.apply_figure_settings(w, sc); return w
+    for sleeping, steps in ((False, 50), (True, 200)):
+        a = make(sleeping)
+        a.step_simulation(steps)
+        if sleeping:
+            assert a.get_asleep().any()   # the mini-piles have settled and gone to sleep (the chains still swing)
+        b = make(sleeping)
+        b.set_state(*a.get_state()); b.refresh_derived()
+        b.set_manifolds(a.get_manifolds())
+        b.set_joint_warm_start(a.get_joint_impulses24(), a.get_joint_impulses()[:, 9])
+        if sleeping:
+            b.set_asleep(a.get_asleep())
+            assert np.array_equal(a.get_asleep(), b.get_asleep())
+        assert np.array_equal(a.get_joint_impulses24().view(np.uint32), b.get_joint_impulses24().view(np.uint32))
+        assert np.array_equal(a.get_joint_impulses()[:, 9], b.get_joint_impulses()[:, 9])
+        if not sleeping:   # (island sleep timers restart in the new context: the continuation is compared without sleeping)
+            a.step_simulation(20); b.step_simulation(20)
+            assert_state_equal(a, b)
+            assert np.array_equal(a.get_joint_impulses24().view(np.uint32), b.get_joint_impulses24().view(np.uint32))

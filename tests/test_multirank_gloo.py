@@ -74,6 +74,58 @@ def _bridge_scene():
     return ext
 
 
+def _jointed_bridge_scene():
+    """The bridge scene plus two pendulum chains (point + hinge joints, one hinge with angle limits, a bump stop and friction
+    torque: tracked angle and four optional row slots) hanging from static anchors, and an excluded pair of overlapping spheres:
+    what a re-partition has to carry besides the manifolds."""
+    from edyn_amd import scenes
+    chains = scenes.c5_chains(2, 4)
+    chains["pos"][:, 0] += 30.0; chains["pos"][:, 2] += 6.0
+    # every hinge: limits (+-0.6 rad, restitution 0.3), a bump stop, friction torque and a soft spring
+    chains["hinge_params"] = [(j, [-0.6, 0.6, 0.3, 0.2, 20.0, 0.05, 0.0, 0.1, 2.0, 0.01]) for j, t in enumerate(chains["joints"]) if t[0] == scenes.JOINT_HINGE]
+    sc = scenes.merge(_bridge_scene(), chains)
+    n = len(sc["kind"])
+    two = scenes._empty(2)
+    two["pos"][:] = [(40.0, 0.5, 0.0), (40.3, 0.5, 0.0)]        # overlapping spheres that must keep ignoring each other
+    two["shape_type"][:] = scenes.SHAPE_SPHERE; two["shape_param"][:, 0] = 0.5
+    two["exclusions"] = np.array([[0, 1]], np.uint32)
+    sc = scenes.merge(sc, two)
+    assert len(sc["kind"]) == n + 2 and len(sc["exclusions"]) == 1 and len(sc["hinge_params"]) >= 2
+    return sc
+
+
+def _make_world_fn(use_gpu):
+    from edyn_amd import scenes
+    if use_gpu:
+        import edyn_amd
+        def make_world(sc):
+            w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10)); w.set_scene(sc); return w
+    else:
+        from oracle import binding as ob
+        def make_world(sc):
+            w = ob.World(vel_iters=10, order=ob.ORDER_COLOURED); w.add_bodies(sc); return w
+    return make_world
+
+
+def _jointed_worker(rank, world_size, port, steps, out_path, use_gpu):
+    """ShardedWorld.step() alone: the approach check runs inside it (auto_repartition)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from edyn_amd.parallel import ShardedWorld
+    sw = ShardedWorld(_jointed_bridge_scene(), _make_world_fn(use_gpu), rank, world_size, backend="gloo", device="cpu")
+    states = []
+    for k in range(steps):
+        sw.step(1)
+        states.append(np.concatenate(sw.get_state(), axis=1))
+        if k in (30, 60):
+            sw.maybe_repartition(force=True)   # every shard is rebuilt: the chains swing with warm-started joints mid-motion
+    if rank == 0:
+        np.savez(out_path, states=np.stack(states), reparts=sw.repartitions)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _sharded_worker(rank, world_size, port, steps, out_path, use_gpu):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -89,11 +141,11 @@ def _sharded_worker(rank, world_size, port, steps, out_path, use_gpu):
         def make_world(sc):
             w = ob.World(vel_iters=10, order=ob.ORDER_COLOURED); w.add_bodies(sc); return w
     sw = ShardedWorld(scene, make_world, rank, world_size, backend="gloo", device="cpu")
-    states, reparts = [], 0
+    states = []
     for _ in range(steps):
-        sw.step(1)
+        sw.step(1)     # the approach check (and the re-partition it asks for) happens inside
         states.append(np.concatenate(sw.get_state(), axis=1))
-        reparts += int(sw.maybe_repartition())
+    reparts = sw.repartitions
     owners = np.bincount(sw.rank_of[sw.rank_of >= 0], minlength=world_size)
     if rank == 0:
         np.savez(out_path, states=np.stack(states), reparts=reparts, owners=owners)
@@ -153,3 +205,25 @@ def test_sharded_world_repartitions_and_matches_the_unsharded_world(tmp_path):
     assert int(got["reparts"]) >= 1, "the rolling sphere must have triggered a re-partition"
     assert got["owners"].min() > 0
     assert np.array_equal(got["states"], ref)
+
+
+def test_sharded_world_carries_joints_and_exclusions_across_a_repartition(tmp_path):
+    """a re-partition rebuilds every shard; besides the manifolds it must carry the joints' applied impulses and
+    tracked angles (warm start, angle-limit rows) and apply the scene's joint parameters and collision exclusions in the new
+    local indices - and step() must notice the approaching islands by itself. Two pendulum chains with limited, sprung hinges
+    and an excluded pair ride along with the bridge scene; the trajectory equals the unsharded world bit for bit."""
+    from edyn_amd import scenes
+    from oracle import binding as ob
+    steps = 90
+    out = str(tmp_path / "jointed.npz")
+    port = 29500 + (os.getpid() % 2000) + 13
+    mp.spawn(_jointed_worker, args=(2, port, steps, out, False), nprocs=2, join=True)
+    got = np.load(out)
+    sc = _jointed_bridge_scene()
+    w = ob.World(vel_iters=10, order=ob.ORDER_COLOURED); w.add_bodies(sc); scenes.apply_figure_settings(w, sc)
+    ref = []
+    for _ in range(steps):
+        w.step(1)
+        ref.append(np.concatenate(w.get_state(), axis=1))
+    assert int(got["reparts"]) >= 2
+    assert np.array_equal(got["states"], np.stack(ref))
