@@ -1505,8 +1505,11 @@ def test_joint_warm_start_and_sleep_tags_carried_into_a_new_context():
     chains["pos"][:, 0] += 20.0
     sc = scenes.merge(scenes.mini_piles(2, 1), chains)
     def make(sleeping):
-        w = gpu_world(sc, sleeping=sleeping); scenes.apply_figure_settings(w, sc); return w
-    for sleeping, steps in ((False, 50), (True, 200)):
+        scn = dict(sc)
+        if sleeping:
+            scn["sleeping_disabled"] = np.zeros(len(sc["kind"]), np.uint8)   # (the benchmark scenes disable sleeping body by body)
+        w = gpu_world(scn, sleeping=sleeping); scenes.apply_figure_settings(w, scn); return w
+    for sleeping, steps in ((False, 50), (True, 400)):
         a = make(sleeping)
         a.step_simulation(steps)
         if sleeping:
