@@ -37,6 +37,7 @@ __global__ void k_step_reset(Counters *cnt) {   // (inside edynhip_step the prev
     if (t == 0) {
         cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
         cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->pairs_differ = 0;
+        cnt->tree_found = 0; cnt->tree_marks = 0;
         cnt->unc_count = 0; cnt->df_abort = 0; cnt->bp_rebuild = 0;   // also the sticky ones: a stand-alone run follows set_* calls or a failed step
     }
     if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
@@ -255,7 +256,7 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
 constexpr int kOwnCap = 32;   // partners kept in the per-lane list; more go through the sorted fallback path
 constexpr int kBpBlock = 64;  // one wave per workgroup: LDS per block stays small, so many blocks share a CU
 // The lane's own keys all start with the same owner: LDS keeps only the low half, (other << 1 | swapped), 4 bytes a key.
-struct Emit { uint32_t (*mine)[kBpBlock]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; };
+struct Emit { uint32_t (*mine)[kBpBlock]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; uint32_t tree; };   // tree: kept forest-certificate manifolds
 DI void emit_pair(uint64_t skey, Emit &e) {
     if (e.n < kOwnCap) { e.mine[e.n++][e.tx] = (uint32_t)skey; return; }
     const uint32_t g = atomicAdd(&e.cnt->num_extra, 1u);   // rare: an owner with more than kOwnCap partners
@@ -271,7 +272,7 @@ DI void consider_pair(uint32_t i, uint32_t j, const box3 &bi, const float4 *amin
         const uint64_t ps = prev.skey[pidx];
         const bool swapped = ps & 1;                      // body[0] == j
         const box3 &x0 = swapped ? bj : bi, &x1 = swapped ? bi : bj;
-        if (intersect(inset(x0, -separation_threshold()), x1)) emit_pair(ps, em);
+        if (intersect(inset(x0, -separation_threshold()), x1)) { emit_pair(ps, em); em.tree += prev.tree[pidx]; }
         return;
     }
     if (!filter_ok(f, i, j)) return;
@@ -361,20 +362,24 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
            const uint32_t *__restrict__ flags, bool sleeping) {
     __shared__ uint32_t cand[kCandCap][kBpBlock];     // tree-walk path only: candidate bodies per lane, [slot][thread]
     __shared__ uint32_t mine[kOwnCap][kBpBlock];      // this lane's (= this owner's) pair keys, low halves
+    __shared__ uint32_t tree_kept;                    // forest-certificate manifolds this block's owners keep (Counters::tree_found)
     const int tx = threadIdx.x;
+    tree_kept = 0;                                    // (one wave per block: every lane stores the same value before any lane adds)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    Emit em{mine, tx, 0, extra, cap, cnt};
+    Emit em{mine, tx, 0, extra, cap, cnt, 0u};
     const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
     if (sleeping && (flags[i] & BF_ASLEEP)) {
         // a sleeping owner keeps its manifolds as they are (destroy_separated_manifolds excludes them): its previous
         // segment is already in ascending order
-        uint32_t c = 0;
+        uint32_t c = 0, kept = 0;
         if (pm) for (uint32_t s = prev.seg_start[i], e = prev.seg_end[i]; s < e; ++s, ++c) {
             if (c < (uint32_t)kOwnCap) own_keys[(size_t)i * kOwnCap + c] = prev.skey[s];
             else { const uint32_t g = atomicAdd(&cnt->num_extra, 1u); if (g < cap) extra[g] = prev.skey[s]; else cnt->pair_overflow = 1; }
+            kept += prev.tree[s];
         }
         own_count[i] = min(c, (uint32_t)kOwnCap);
+        if (kept) atomicAdd(&cnt->tree_found, kept);   // (sleeping worlds: rare path, no block reduction)
         return;
     }
     const box3 bi = body_box(amin, amax, i);
@@ -424,6 +429,11 @@ k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ 
     }
     for (int a = 0; a < em.n; ++a) own_keys[(size_t)i * kOwnCap + a] = ((uint64_t)i << 33) | mine[a][tx];
     own_count[i] = (uint32_t)em.n;
+    // one atomic per block for the kept certificate manifolds (the lanes still here are converged again: one wave per block)
+    if (em.tree) atomicAdd(&tree_kept, em.tree);
+    __threadfence_block();
+    const uint64_t alive = __ballot(1);
+    if ((uint32_t)tx == (uint32_t)__ffsll((long long)alive) - 1u && tree_kept) atomicAdd(&cnt->tree_found, tree_kept);
 }
 // After the scan of own_count: total pair count for the host, and the per-owner blocks copied to their final places.
 // Also compares the new key list with the previous step's manifold array (prev_skey[pm], sorted the same way): when nothing differs
@@ -454,7 +464,7 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
 __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
-                                     Counters *cnt, uint2 *new_edges, bool copy_points, EventSink ev, uint8_t *prev_matched) {
+                                     Counters *cnt, uint2 *new_edges, uint32_t *new_edge_m, bool copy_points, EventSink ev, uint8_t *prev_matched) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t found = 0;
     if (m < M) {
@@ -476,10 +486,12 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     uint32_t info = kNoColour << 8;
     if (p == 0xFFFFFFFFu) {
         cnt->pairs_changed = 1;
-        new_edges[atomicAdd(&cnt->num_new, 1u)] = make_uint2(hi, lo);
+        const uint32_t slot = atomicAdd(&cnt->num_new, 1u);
+        new_edges[slot] = make_uint2(hi, lo); new_edge_m[slot] = m;
         if (ev.buf) emit_event(ev, EDYNHIP_EVENT_MANIFOLD_CREATED, swapped ? lo : hi, swapped ? hi : lo, 0);
     }
     cur.prev_idx[m] = p;
+    cur.tree[m] = p != 0xFFFFFFFFu ? prev.tree[p] : (uint8_t)0;
     if (p != 0xFFFFFFFFu) {
         found = 1;
         info = prev.info[p];
@@ -591,7 +603,7 @@ int broadphase(edynhip_ctx *c) {
         }
         const EventSink ev = event_sink(c);
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, !c->full_step, ev, c->prev_matched);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, !c->full_step, ev, c->prev_matched);
         else if (pm != 0) c->force_islands = true;
         if (ev.buf && pm > 0) hipLaunchKernelGGL(k_ev_destroyed, dim3(blocks(pm, 256)), dim3(256), 0, s, pm, prev, c->prev_matched, ev);
     }

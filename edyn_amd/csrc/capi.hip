@@ -64,7 +64,7 @@ static int dalloc(edynhip_ctx *c, T *&p, size_t count) {
 static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap, uint32_t nb) {
     m.cap = cap;
     if (c->cfg.flags & EDYNHIP_FLAG_CONTACT_EVENTS) EH_TRY(dalloc(c, m.pid, (size_t)cap * kMaxPts));
-    EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb)); EH_TRY(dalloc(c, m.prev_idx, cap));
+    EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb)); EH_TRY(dalloc(c, m.prev_idx, cap)); EH_TRY(dalloc(c, m.tree, cap));
     EH_TRY(dalloc(c, m.skey, cap)); EH_TRY(dalloc(c, m.bodyA, cap)); EH_TRY(dalloc(c, m.bodyB, cap)); EH_TRY(dalloc(c, m.info, cap));
     EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
     EH_TRY(dalloc(c, m.nrm, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.lnrm, (size_t)cap * kMaxPts));
@@ -101,7 +101,7 @@ static int allocate(edynhip_ctx *c) {
         c->event_cap = 5u * M + 1024u;
         EH_TRY(dalloc(c, c->events, c->event_cap)); EH_TRY(dalloc(c, c->event_count, 4)); EH_TRY(dalloc(c, c->prev_matched, M));
     }
-    EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M));
+    EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M)); EH_TRY(dalloc(c, c->new_edge_m, M));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
@@ -321,6 +321,7 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
         if (nh != hi) mf.seg_end[hi] = m + 1;
     }
     mf.info[m] = (r.num_points & 0xFF) | ((r.colour & 0xFF) << 8);
+    mf.tree[m] = 0;   // (set_manifolds forces a full island update, which rebuilds the certificate)
     for (uint32_t k = 0; k < r.num_points; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
         const edynhip_point &p = r.pt[k];

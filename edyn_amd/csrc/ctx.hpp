@@ -74,6 +74,9 @@ struct Manifolds {
     uint32_t *seg_start = nullptr, *seg_end = nullptr;   // per body b: the manifolds it owns
     uint32_t *prev_idx = nullptr; // inside a full step: index of the same pair in the previous array (~0u = created now);
                                   // the narrowphase then reads the old points from there instead of a copy
+    uint8_t *tree = nullptr;      // 1 = the island union-find hooked on this manifold: the marked manifolds (with the joints) are a
+                                  // spanning forest of the contact graph, i.e. a certificate for the island labels - while none of
+                                  // them disappears, no island can have split and the labels are updated incrementally (solver.hip)
     // per point slot k (list order, newest first): index k*cap + m
     float4 *pA = nullptr;         // pivotA xyz, w = distance
     float4 *pB = nullptr;         // pivotB xyz, w = friction
@@ -240,6 +243,9 @@ struct Counters {
     uint32_t isl_max_items;      //   and the largest of them, in constraints (read by the NEXT step's schedule decision)
     uint32_t isl_max_jitems;     //   the largest island that has joints
     uint32_t isl_free;           //   active manifolds in islands without joints (mixed schedule: those go to the dataflow launch)
+    uint32_t tree_found;         // forest-certificate manifolds (Manifolds::tree) of the previous array that this step's pair set keeps (k_bp_pairs)
+    uint32_t tree_marks;         // manifolds marked by this step's island update
+    uint32_t tree_total;         // marked manifolds in the current array (NOT reset per step): tree_found == tree_total <=> no island can have split
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
     uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];
@@ -287,6 +293,7 @@ struct edynhip_ctx {
     uint64_t *own_keys = nullptr;                                  // [body][kOwnCap] sorted pair keys of each owner (broadphase.hip)
     uint32_t *own_count = nullptr, *own_offset = nullptr;          // [bodies + 1]
     uint2 *new_edges = nullptr;    // body pairs of manifolds created this step (incremental island update)
+    uint32_t *new_edge_m = nullptr; //   and their manifold indices
     uint32_t prev_num_manifolds = 0;
     uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr;   // colour sort (counting sort, solver.hip k_cs_*)
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]

@@ -56,80 +56,94 @@ DI uint32_t cc_find(uint32_t *parent, uint32_t x) {
     }
     return x;
 }
-DI void cc_union(uint32_t *parent, uint32_t a, uint32_t b) {
+DI bool cc_union(uint32_t *parent, uint32_t a, uint32_t b) {   // true: this call joined two trees (the edge certifies the union)
     uint32_t ra = cc_find(parent, a), rb = cc_find(parent, b);
     while (ra != rb) {
         if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }   // hook the larger root under the smaller
         const uint32_t seen = atomicCAS(&parent[ra], ra, rb);
-        if (seen == ra) return;
+        if (seen == ra) return true;
         ra = cc_find(parent, seen);   // ra was no longer a root: continue from what it points to now
         rb = cc_find(parent, rb);
     }
+    return false;
 }
-// Island labels are maintained incrementally; the mode is decided ON THE DEVICE from the broadphase counters
-// (no host sync):  unchanged pair set -> nothing to do;  only additions -> start from last step's labels and
-// hook the new edges;  any removal (or a scene edit, `force`) -> full recompute over all manifolds and joints.
+// Island labels are maintained incrementally, and the HOST picks the mode from counters it fetched with the pair count:
+//   CC_SKIP         unchanged pair set (in-place step): nothing is launched;
+//   CC_INCREMENTAL  no island can have split: start from last step's labels (roots = a depth-1 forest), hook the new edges;
+//   CC_FULL         recompute over all joints and manifolds (scene edits, or a certificate manifold disappeared).
+// "No island can have split" is decided with a CERTIFICATE: every union the forest ever performed was made on a particular
+// edge - a joint, or a manifold, which is then marked (Manifolds::tree). The marked edges form a spanning forest of the
+// contact graph, so as long as every marked manifold of the previous array is still in this step's pair set
+// (Counters::tree_found == tree_total, counted by k_bp_pairs while it re-tests the existing pairs) the components are intact,
+// whatever other pairs went away. Manifolds that carry contact points are hooked first and separated AABBs almost always
+// belong to manifolds without points, so on a settled pile the full recompute (~100 us: its cost is the depth of the
+// initial forest) went from most steps to almost none. (Round 2 recomputed whenever ANY pair disappeared.)
 enum { CC_SKIP = 0, CC_INCREMENTAL = 1, CC_FULL = 2 };
-DI int cc_mode(const Counters *cnt, uint32_t prev_m, uint32_t force) {
-    if (force) return CC_FULL;
-    if (!cnt->pairs_changed) return CC_SKIP;
-    return cnt->num_found == prev_m ? CC_INCREMENTAL : CC_FULL;
+DI void cc_count_marks(uint32_t marks, Counters *cnt) {   // every lane of the wave calls this
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) marks += __shfl_xor(marks, off);
+    if ((threadIdx.x & 63) == 0 && marks) atomicAdd(&cnt->tree_marks, marks);
 }
-__global__ void k_cc_init(uint32_t n, uint32_t *forest, const uint32_t *__restrict__ label, Counters *cnt, uint32_t prev_m, uint32_t force,
-                          Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags) {
-    const int mode = cc_mode(cnt, prev_m, force);
-    if (mode == CC_SKIP) return;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// CC_FULL only: every body starts at its smallest dynamic lower-index neighbour it has CONTACT POINTS with (its manifolds
+// with lower-index partners are the contiguous segment [seg_start, seg_end) of the sorted array). Links point to smaller
+// indices, so this is a valid forest and most unions below find their roots already merged. Clears the segment's marks.
+__global__ void k_cc_init(uint32_t n, uint32_t *forest, Counters *cnt, Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->num_islands = 0;
-    if (i >= n) return;
-    if (mode == CC_INCREMENTAL) { forest[i] = label[i]; return; }   // labels are roots (min index): a valid depth-1 forest
-    // full recompute: start every body at its smallest dynamic neighbour with a lower index (its manifolds with
-    // lower-index partners are the contiguous segment [seg_start, seg_end) of the sorted array). Links point to
-    // smaller indices, so this is a valid forest and most unions below find their roots already merged.
-    uint32_t parent = i;
-    if (M && is_dynamic(flags[i])) {
-        for (uint32_t s = mf.seg_start[i], e = mf.seg_end[i]; s < e; ++s) {
-            const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
-            if (is_dynamic(flags[lo])) { parent = lo; break; }
+    uint32_t marks = 0;
+    if (i < n) {
+        uint32_t parent = i;
+        if (M && is_dynamic(flags[i])) {
+            for (uint32_t s = mf.seg_start[i], e = mf.seg_end[i]; s < e; ++s) {
+                const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
+                uint8_t mark = 0;
+                if (parent == i && (mf.info[s] & 0xFF) != 0 && is_dynamic(flags[lo])) { parent = lo; mark = 1; marks = 1; }
+                mf.tree[s] = mark;
+            }
         }
+        forest[i] = parent;
     }
-    forest[i] = parent;
+    cc_count_marks(marks, cnt);
 }
 __global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                          const uint32_t *__restrict__ flags, uint32_t *island, const Counters *cnt, uint32_t prev_m, uint32_t force) {
-    if (cc_mode(cnt, prev_m, force) != CC_FULL) return;
+                          const uint32_t *__restrict__ flags, uint32_t *island) {   // joints (CC_FULL): edges that only an edit removes
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M) return;
     uint32_t a = bA[e], b = bB[e];
-    if (is_dynamic(flags[a]) && is_dynamic(flags[b])) cc_union(island, a, b);
+    if (is_dynamic(flags[a]) && is_dynamic(flags[b])) (void)cc_union(island, a, b);
 }
 // Vertex-centric hooking for the full recompute: one lane per body walks the contiguous run of manifolds in which it
 // is the higher-index partner. All unions of one body are issued by one lane in sequence, so lanes do not fight over
-// the same root the way one-lane-per-edge does when a body has 6-12 partners.
-__global__ void k_cc_hook_bodies(uint32_t n, Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags, uint32_t *island,
-                                 const Counters *cnt, uint32_t prev_m, uint32_t force) {
-    if (cc_mode(cnt, prev_m, force) != CC_FULL) return;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || M == 0 || !is_dynamic(flags[i])) return;
-    const uint32_t s0 = mf.seg_start[i], s1 = mf.seg_end[i];
-    for (uint32_t s = s0; s < s1; ++s) {
-        const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
-        if (is_dynamic(flags[lo])) cc_union(island, i, lo);
+// the same root the way one-lane-per-edge does when a body has 6-12 partners. Manifolds with contact points first.
+__global__ void k_cc_hook_bodies(uint32_t n, Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags, uint32_t *island, Counters *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t marks = 0;
+    if (i < n && M != 0 && is_dynamic(flags[i])) {
+        const uint32_t s0 = mf.seg_start[i], s1 = mf.seg_end[i];
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass)
+            for (uint32_t s = s0; s < s1; ++s) {
+                if (((mf.info[s] & 0xFF) != 0) != (pass == 0)) continue;
+                const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
+                if (is_dynamic(flags[lo]) && cc_union(island, i, lo)) { mf.tree[s] = 1; ++marks; }
+            }
     }
+    cc_count_marks(marks, cnt);
 }
-__global__ void k_cc_hook_new(const uint2 *__restrict__ edges, const uint32_t *__restrict__ flags, uint32_t *island,
-                              const Counters *cnt, uint32_t prev_m, uint32_t force) {
-    if (cc_mode(cnt, prev_m, force) != CC_INCREMENTAL) return;
+__global__ void k_cc_hook_new(const uint2 *__restrict__ edges, const uint32_t *__restrict__ edge_m, uint8_t *tree, const uint32_t *__restrict__ flags,
+                              uint32_t *island, Counters *cnt) {   // CC_INCREMENTAL: `island` holds last step's labels
     const uint32_t n = cnt->num_new;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->num_islands = 0;
+    uint32_t marks = 0;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         uint2 ed = edges[e];
-        if (is_dynamic(flags[ed.x]) && is_dynamic(flags[ed.y])) cc_union(island, ed.x, ed.y);
+        if (is_dynamic(flags[ed.x]) && is_dynamic(flags[ed.y]) && cc_union(island, ed.x, ed.y)) { tree[edge_m[e]] = 1; ++marks; }
     }
+    cc_count_marks(marks, cnt);
 }
-__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt,
-                             uint32_t prev_m, uint32_t force) {
-    if (cc_mode(cnt, prev_m, force) == CC_SKIP) return;
+__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt, int mode) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cnt->tree_total = (mode == CC_FULL ? 0u : cnt->tree_total) + cnt->tree_marks;   // the hooks are done (kernel boundary)
     uint32_t root = 0;
     if (i < n) {
         uint32_t r = cc_find(island, i);
@@ -2695,7 +2709,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
         const int t = threadIdx.x;
         if (t == 0) {
             cnt->num_pairs = 0; cnt->pair_overflow = 0; cnt->num_points = 0; cnt->num_active = 0;
-            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0; cnt->pairs_differ = 0;
+            cnt->uncoloured = 0; cnt->colour_overflow = 0; cnt->pairs_changed = 0; cnt->num_found = 0; cnt->num_new = 0; cnt->num_extra = 0; cnt->num_awake = 0; cnt->unc_count = 0; cnt->pairs_differ = 0; cnt->tree_found = 0; cnt->tree_marks = 0;
         }
         if (t < 3) { cnt->bounds_min[t] = 0x7FFFFFFF; cnt->bounds_max[t] = (int)0x80000000; }
         for (int k = t; k < 4 * (int)kMaxColours; k += (int)blockDim.x) { cnt->colour_start[k] = 0; cnt->colour_end[k] = 0; }
@@ -2756,16 +2770,21 @@ int islands(edynhip_ctx *c) {
     // No manifold now or in the previous step, nothing edited, no sleep decisions to take: the labels stand and every kernel below would
     // return at once - not launched at all (a world of joints only: 4 of its ~20 launches per step)
     if (!force && M == 0 && pm == 0 && !c->sleeping && c->full_step) return EDYNHIP_OK;
-    // An in-place step (broadphase.hip: the pair set is last step's, read by the host with the pair count) leaves `pairs_changed` clear:
-    // all five kernels would take cc_mode's CC_SKIP exit - ~20 us of launches that a settled or sleeping world does not pay
-    const bool relabel = force || !c->inplace_step;
+    // An in-place step (broadphase.hip: the pair set is last step's) has nothing to relabel. Otherwise the counters fetched with
+    // the pair count say whether every certificate manifold is still there (see CC_INCREMENTAL above).
+    const bool inplace = c->inplace_step;
     c->inplace_step = false;
-    if (relabel) {
-        hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.island, c->cnt, pm, force, mf, M, c->b.flags);
-        if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt, pm, force);
-        if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest, c->cnt, pm, force);
-        hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->b.flags, forest, c->cnt, pm, force);
-        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, pm, force);
+    const int mode = force ? CC_FULL : inplace ? CC_SKIP
+                     : (c->full_step && c->cnt_host->tree_found == c->cnt_host->tree_total) ? CC_INCREMENTAL : CC_FULL;
+    (void)pm;
+    if (mode == CC_FULL) {
+        hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->cnt, mf, M, c->b.flags);
+        if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest);
+        if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt);
+        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, mode);
+    } else if (mode == CC_INCREMENTAL) {   // the labels themselves are the forest (roots = lowest index: depth 1)
+        hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->new_edge_m, mf.tree, c->b.flags, c->b.island, c->cnt);
+        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, c->b.island, c->b.island, c->cnt, mode);
     }
     if (c->sleeping) {
         hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
