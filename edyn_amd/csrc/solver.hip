@@ -2831,7 +2831,7 @@ static int colour_contacts(edynhip_ctx *c) {
     };
     // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
     // could not finish (a long list, or more rounds than it runs) is left to the multi-block rounds below.
-    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), 0, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->used, c->cnt, c->col_unc, 16u);
+    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), 0, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->used, c->cnt, c->col_unc, 64u);
     EH_TRY(sort_and_fetch());
     if (c->cnt_host->uncoloured != 0) {
         uint32_t batch = 4;

@@ -12,19 +12,21 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 for WL in $WLS; do
   W=/tmp/prof_${R}_$WL; rm -rf $W; mkdir -p $W
-  case $WL in islands256k) STEPS=60; WARM=60;; *) STEPS=300; WARM=120;; esac
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline > $OUT/${R}_bench_under_rocprof_$WL.json 2> $W/kt.log )
+  # bench.py settles the scene (120 steps) before the warm-up and the timed steps: SETTLE + WARM + STEPS steps are profiled
+  SETTLE=120
+  case $WL in islands256k|islands1m) STEPS=60; WARM=10;; *) STEPS=300; WARM=20;; esac
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --workload $WL --steps $STEPS --warmup $WARM --north-star none --no-cpu-baseline > $OUT/${R}_bench_under_rocprof_$WL.json 2> $W/kt.log )
   case $WL in chains16k|ragdolls1k) KN=k_island_velocity;; *) KN=k_contact_solve;; esac
-  python scripts/prof_summary.py $W/kt $((STEPS + WARM)) $KN $STEPS > $OUT/${R}_kernel_stats_$WL.txt
+  python scripts/prof_summary.py $W/kt $((SETTLE + STEPS + WARM)) $KN $STEPS > $OUT/${R}_kernel_stats_$WL.txt
   case $WL in chains16k|ragdolls1k) continue;; esac   # joint scenes: kernel statistics only (the traffic model is the contact solve's)
   for C in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps 40 --warmup 5 --no-cpu-baseline > /dev/null 2> $W/$C.log )
+    ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps 40 --warmup 5 --north-star none --no-cpu-baseline > /dev/null 2> $W/$C.log )
   done
   python scripts/pmc_traffic.py $W/FETCH_SIZE $W/WRITE_SIZE $WL > $OUT/${R}_traffic_$WL.json
   if [ $WL = pile32k ]; then
-    python scripts/prof_timeline.py $W/kt $((STEPS + WARM - 50)) > $OUT/${R}_timeline_$WL.txt 2>&1 || true
-    python bench.py --stage-timing --no-cpu-baseline > $OUT/${R}_bench_stage_timing.json 2> /dev/null || true
-    ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $W/sq -o r -- python $OLDPWD/bench.py --steps 60 --warmup 5 --no-cpu-baseline > /dev/null 2> $W/sq.log )
+    python scripts/prof_timeline.py $W/kt $((SETTLE + STEPS + WARM - 50)) > $OUT/${R}_timeline_$WL.txt 2>&1 || true
+    python bench.py --stage-timing --north-star none --no-cpu-baseline > $OUT/${R}_bench_stage_timing.json 2> /dev/null || true
+    ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $W/sq -o r -- python $OLDPWD/bench.py --steps 60 --warmup 5 --north-star none --no-cpu-baseline > /dev/null 2> $W/sq.log )
     python scripts/pmc_summary.py $W/sq > $OUT/${R}_pmc_sq_counters_$WL.txt 2>&1 || true
   fi
 done
