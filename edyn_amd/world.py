@@ -16,7 +16,7 @@ from . import _capi
 from ._capi import EdynHipError, MANIFOLD_DTYPE
 
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2          # rigidbody_kind
-SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE = 0, 1, 2, 3, 4
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER = 0, 1, 2, 3, 4, 5
 JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY, JOINT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 ALL_GROUPS = 2**64 - 1                                       # collision_filter::all_groups
 

@@ -482,6 +482,10 @@ inline void collide_capsule_box(const shape &shA, vec3 hB, const coll_ctx &ctx, 
     }
 }
 
+}  // namespace orc
+#include "ocylinder.hpp"
+namespace orc {
+
 // Dispatch on the shape pair; mirrored overloads go through swap_collide (collide.hpp:369-374).
 inline void collide(const shape &shA, const shape &shB, const coll_ctx &ctx, coll_result &r) {
     const int a = shA.type, b = shB.type;
@@ -503,6 +507,15 @@ inline void collide(const shape &shA, const shape &shB, const coll_ctx &ctx, col
     else if (a == SHAPE_CAPSULE && b == SHAPE_CAPSULE) collide_capsule_capsule(shA, shB, ctx, r);
     else if (a == SHAPE_CAPSULE && b == SHAPE_BOX) collide_capsule_box(shA, shB.half_extents, ctx, r);
     else if (a == SHAPE_BOX && b == SHAPE_CAPSULE) { collide_capsule_box(shB, shA.half_extents, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CYLINDER && b == SHAPE_PLANE) collide_cylinder_plane(shA, shB.normal, shB.constant, ctx, r);
+    else if (a == SHAPE_PLANE && b == SHAPE_CYLINDER) { collide_cylinder_plane(shB, shA.normal, shA.constant, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CYLINDER && b == SHAPE_SPHERE) collide_cylinder_sphere(shA, shB.radius, ctx, r);
+    else if (a == SHAPE_SPHERE && b == SHAPE_CYLINDER) { collide_cylinder_sphere(shB, shA.radius, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CYLINDER && b == SHAPE_CYLINDER) collide_cylinder_cylinder(shA, shB, ctx, r);
+    else if (a == SHAPE_CYLINDER && b == SHAPE_BOX) collide_cylinder_box(shA, shB.half_extents, ctx, r);
+    else if (a == SHAPE_BOX && b == SHAPE_CYLINDER) { collide_cylinder_box(shB, shA.half_extents, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_CAPSULE && b == SHAPE_CYLINDER) collide_capsule_cylinder(shA, shB, ctx, r);
+    else if (a == SHAPE_CYLINDER && b == SHAPE_CAPSULE) { collide_capsule_cylinder(shB, shA, ctx.swapped(), r); r.swap(); }
     // plane-plane: both static, never paired (only procedural bodies query the broadphase).
 }
 

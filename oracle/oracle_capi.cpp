@@ -39,7 +39,7 @@ static shape make_shape(int type, const float *p) {
     if (type == SHAPE_BOX) s.half_extents = v3(p);
     else if (type == SHAPE_SPHERE) s.radius = p[0];
     else if (type == SHAPE_PLANE) { s.normal = v3(p); s.constant = p[3]; }
-    else if (type == SHAPE_CAPSULE) { s.radius = p[0]; s.half_length = p[1]; s.axis = (int)p[2]; }
+    else if (type == SHAPE_CAPSULE || type == SHAPE_CYLINDER) { s.radius = p[0]; s.half_length = p[1]; s.axis = (int)p[2]; }
     return s;
 }
 

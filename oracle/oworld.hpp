@@ -73,9 +73,9 @@ struct Body {
     vec3 org() const { return has_com ? origin : pos; }
     void update_origin() { if (has_com) origin = to_world(-com, pos, orn); }   // update_origins.cpp:13-15
     bool procedural() const { return kind == KIND_DYNAMIC; }
-    bool rolling() const { return kind == KIND_DYNAMIC && (sh.type == SHAPE_SPHERE || sh.type == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t, shapes.hpp:40-44
+    bool rolling() const { return kind == KIND_DYNAMIC && (sh.type == SHAPE_SPHERE || sh.type == SHAPE_CAPSULE || sh.type == SHAPE_CYLINDER); }   // rolling_shapes_tuple_t, shapes.hpp:40-44
     vec3 roll_direction() const {   // roll_direction component: dynamic capsules roll about their axis (rigidbody.cpp:119-130, shapes.hpp:136-139)
-        return kind == KIND_DYNAMIC && sh.type == SHAPE_CAPSULE ? coordinate_axis_vector(sh.axis) : vec3{0, 0, 0};
+        return kind == KIND_DYNAMIC && (sh.type == SHAPE_CAPSULE || sh.type == SHAPE_CYLINDER) ? coordinate_axis_vector(sh.axis) : vec3{0, 0, 0};
     }
 };
 

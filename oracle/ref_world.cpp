@@ -153,6 +153,7 @@ uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, co
     else if (shape_type == 2) def.shape = edyn::sphere_shape{sp[0]};
     else if (shape_type == 3) def.shape = edyn::plane_shape{v3(sp), sp[3]};
     else if (shape_type == 4) def.shape = edyn::capsule_shape{sp[0], sp[1], (edyn::coordinate_axis)(int)sp[2]};
+    else if (shape_type == 5) def.shape = edyn::cylinder_shape{sp[0], sp[1], (edyn::coordinate_axis)(int)sp[2]};
     if (inertia9) {
         def.inertia = edyn::matrix3x3{{edyn::vector3{inertia9[0], inertia9[1], inertia9[2]},
                                        edyn::vector3{inertia9[3], inertia9[4], inertia9[5]},
@@ -591,7 +592,7 @@ uint32_t refw_make_ragdoll(void *h, int shape, const float *pos, const float *or
     def.position = v3(pos);
     def.orientation = edyn::quaternion{orn[0], orn[1], orn[2], orn[3]};
     def.height = height; def.weight = weight; def.friction = friction; def.restitution = restitution;
-    def.shape_type = shape == 0 ? edyn::ragdoll_shape_type::box : edyn::ragdoll_shape_type::capsule;
+    def.shape_type = shape == 0 ? edyn::ragdoll_shape_type::box : shape == 2 ? edyn::ragdoll_shape_type::cylinder : edyn::ragdoll_shape_type::capsule;
     edyn::make_ragdoll(reg, def);
     std::vector<uint32_t> fresh;
     for (auto e : reg.view<edyn::rigidbody_tag>())
@@ -635,6 +636,7 @@ void refw_export_body(void *h, uint32_t body, int32_t *kind, float *pos, float *
     else if (auto *s = reg.try_get<edyn::sphere_shape>(e)) { *shape_type = 2; sp4[0] = s->radius; }
     else if (auto *p = reg.try_get<edyn::plane_shape>(e)) { *shape_type = 3; put3(sp4, p->normal); sp4[3] = p->constant; }
     else if (auto *c = reg.try_get<edyn::capsule_shape>(e)) { *shape_type = 4; sp4[0] = c->radius; sp4[1] = c->half_length; sp4[2] = (float)(int)c->axis; }
+    else if (auto *cy = reg.try_get<edyn::cylinder_shape>(e)) { *shape_type = 5; sp4[0] = cy->radius; sp4[1] = cy->half_length; sp4[2] = (float)(int)cy->axis; }
     *has_material = 0; *friction = 0; *restitution = 0;
     if (auto *m = reg.try_get<edyn::material>(e)) { *has_material = 1; *friction = m->friction; *restitution = m->restitution; }
     *group = ~0ull; *mask = ~0ull;

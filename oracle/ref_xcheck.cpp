@@ -89,12 +89,13 @@ void ref_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
 #include <vector>
 
 namespace {
-using ref_shape = std::variant<std::monostate, box_shape, sphere_shape, plane_shape, capsule_shape>;
+using ref_shape = std::variant<std::monostate, box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>;
 ref_shape make_ref_shape(int type, const float *p) {
     if (type == 1) return box_shape{v3(p)};
     if (type == 2) return sphere_shape{p[0]};
     if (type == 3) return plane_shape{v3(p), p[3]};
     if (type == 4) return capsule_shape{p[0], p[1], (coordinate_axis)(int)p[2]};
+    if (type == 5) return cylinder_shape{p[0], p[1], (coordinate_axis)(int)p[2]};
     return std::monostate{};
 }
 }  // namespace

@@ -39,6 +39,12 @@ def pair_batch(rng, n, tA, tB):
             sp[:, side, 1] = rng.uniform(0.05, 0.6, size=n)
             sp[:, side, 2] = rng.integers(0, 3, n)
             reach[:, side] = sp[:, side, 0] + rng.random(n).astype(np.float32) * sp[:, side, 1]
+        elif t == getattr(scenes, "SHAPE_CYLINDER", 5):   # (radius, half_length, axis): flat discs and long rods alike
+            sp[:, side, 0] = rng.uniform(0.1, 0.5, size=n)
+            sp[:, side, 1] = rng.uniform(0.05, 0.6, size=n)
+            sp[:, side, 2] = rng.integers(0, 3, n)
+            r, hl = sp[:, side, 0], sp[:, side, 1]
+            reach[:, side] = np.minimum(r, hl) + rng.random(n).astype(np.float32) * (np.sqrt(r * r + hl * hl) - np.minimum(r, hl))
         else:   # plane through a random offset with a random (or +Y) normal
             nrm = rng.normal(size=(n, 3)).astype(np.float32)
             nrm[rng.random(n) < 0.5] = (0, 1, 0)

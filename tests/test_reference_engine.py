@@ -44,7 +44,11 @@ def _libm_trig():
     (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE),
     (scenes.SHAPE_CAPSULE, scenes.SHAPE_CAPSULE), (scenes.SHAPE_CAPSULE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE),
     (scenes.SHAPE_CAPSULE, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CAPSULE),
-    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE)])
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_CYLINDER), (scenes.SHAPE_CYLINDER, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_CYLINDER), (scenes.SHAPE_CYLINDER, scenes.SHAPE_CAPSULE)])
 def test_collide_matches_the_reference_routines(tA, tB):
     """collide_box_box.cpp:14-266, collide_box_plane.cpp, collide_sphere_{sphere,plane,box}.cpp, swap_collide
     (collide.hpp:369-374), collision_result.cpp: counts, pivots, normals, distances, attachments — the same 200k random
@@ -607,6 +611,31 @@ def test_capsules_whole_steps_bit_exact_against_the_real_engine():
     four capsule pair routines and rolling_tag matching in the narrowphase - a tumbling heap of capsules, boxes and spheres
     stays bit-identical to the real engine for 250 steps."""
     _lockstep(_capsule_scene(), 250, 10)
+
+
+def _cylinder_scene():
+    """A tumbling heap of cylinders (flat discs and rods, all three axes), capsules, boxes and spheres."""
+    sc = scenes.box_pile(3, 3, 4, mixed=True)
+    n = len(sc["kind"])
+    for i in range(1, n):
+        if i % 3 == 0:
+            sc["shape_type"][i] = scenes.SHAPE_CYLINDER
+            sc["shape_param"][i] = (0.25 + 0.05 * (i % 5), 0.1 + 0.08 * (i % 4), float(i % 3), 0)
+        elif i % 7 == 1:
+            sc["shape_type"][i] = scenes.SHAPE_CAPSULE
+            sc["shape_param"][i] = (0.3, 0.2 + 0.05 * (i % 4), float(i % 3), 0)
+    rng = np.random.default_rng(11)
+    sc["angvel"][1:] = (rng.normal(size=(n - 1, 3)) * 2).astype(np.float32)
+    sc["linvel"][1:] = (rng.normal(size=(n - 1, 3)) * (0.8, 0.1, 0.8)).astype(np.float32)
+    return sc
+
+
+def test_cylinders_whole_steps_bit_exact_against_the_real_engine():
+    """cylinder_shape: AABB (aabb_util.cpp:72-79), solid-cylinder inertia (moment_of_inertia.cpp:27-44), its five
+    pair routines (cylinder-plane / sphere / cylinder / box, capsule-cylinder) with the circle-line and circle-circle Newton
+    iterations, and rolling_tag matching in the narrowphase: a tumbling heap of cylinders, capsules, boxes and spheres stays
+    bit-identical to the real engine for 250 steps."""
+    _lockstep(_cylinder_scene(), 250, 10)
 
 
 def test_capsule_rolling_friction_uses_the_roll_direction():
