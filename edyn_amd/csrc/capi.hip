@@ -2,7 +2,7 @@
 // state read-back. Host-side logic only; every simulation stage runs in the HIP kernels of
 // broadphase.hip / narrowphase.hip / solver.hip. There is no CPU fallback.
 #include "ctx.hpp"
-#include "dcollide.hpp"
+#include "dcylinder.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -182,6 +182,9 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
             const float yy_zz = sph_inertia + sph_mass * square(4.0f * len + 3.0f * radius) / 64.0f + cyl.y;
             const f3 d = sp.z == 0.0f ? mk3(xx, yy_zz, yy_zz) : (sp.z == 1.0f ? mk3(yy_zz, xx, yy_zz) : mk3(yy_zz, yy_zz, xx));
             I = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}};
+        } else if (st == dc::SHAPE_CYLINDER) {   // moment_of_inertia.cpp:27-44,167-169
+            const f3 d = dc::cylinder_inertia_diag(dc::cyl_of(sp), mass);
+            I = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}};
         } else {
             I = {{kScalarMax, 0, 0}, {0, kScalarMax, 0}, {0, 0, kScalarMax}};
         }
@@ -252,6 +255,9 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         const f3 p0 = pos - v, p1 = pos + v;
         mn = mk3(fminf(p0.x, p1.x) - sp.x, fminf(p0.y, p1.y) - sp.x, fminf(p0.z, p1.z) - sp.x);
         mx = mk3(fmaxf(p0.x, p1.x) + sp.x, fmaxf(p0.y, p1.y) + sp.x, fmaxf(p0.z, p1.z) + sp.x);
+    } else if (st == dc::SHAPE_CYLINDER) {   // aabb_util.cpp:72-79
+        const box3 bb = dc::cylinder_aabb(dc::cyl_of(sp), pos, orn);
+        mn = bb.mn; mx = bb.mx;
     } else if (st == dc::SHAPE_PLANE) {
         const f3 nrm = from4(sp);
         f3 umin = mk3(-1, -1, -1), umax = mk3(1, 1, 1);
@@ -595,8 +601,10 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
               !in->friction || !in->restitution))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
     for (uint32_t i = 0; i < n; ++i)
-        if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_CAPSULE)
-            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule)").c_str());
+        if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_CYLINDER)
+            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule, cylinder)").c_str());
+    if (first == 0) c->has_cylinder = false;
+    for (uint32_t i = 0; i < n; ++i) if (in->shape_type[i] == EDYNHIP_SHAPE_CYLINDER) c->has_cylinder = true;   // narrowphase.hip launches k_np_detect_ext
     if (first == 0) { c->has_restitution = false; c->extras = false; c->host_mat_id.clear(); c->b.mix_K = 0; for (auto &kv : c->host_mix) if (kv.second[0] > 0) c->has_restitution = true; }
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)

@@ -332,6 +332,7 @@ struct edynhip_ctx {
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     bool has_generic = false;      // some joint is a generic_constraint (k_prep_generic runs)
+    bool has_cylinder = false;     // some body is a cylinder_shape (narrowphase.hip k_np_detect_ext runs)
     // material mix table, host side: the reference's container (std::map under unordered_pair's comparator) so that lookups behave
     // exactly like its own; ids by body; device buffers are rebuilt on every change (rebuild_mix_table, capi.hip)
     struct MixIdPair { uint32_t first, second; };

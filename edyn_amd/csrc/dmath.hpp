@@ -18,7 +18,11 @@ constexpr float kPi = 3.1415926535897932384626433832795029f;   // math/constants
 constexpr float kPi2 = kPi * 2.0f;
 constexpr float kHalfSqrt2 = 0.7071067811865475244008443621048490f;
 
-struct f3 { float x, y, z; };
+struct f3 {
+    float x, y, z;
+    DI float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }          // (used by the cylinder routines, dcylinder.hpp)
+    DI float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
 struct f2 { float x, y; };
 struct q4 { float x, y, z, w; };
 struct m3 { f3 r0, r1, r2; };

@@ -8,7 +8,7 @@
 // manifold owns four fixed slots kept in that same list order, so creation/destruction is a register
 // shuffle instead of entity churn.
 #include "ctx.hpp"
-#include "dcollide.hpp"
+#include "dcylinder.hpp"
 
 namespace eh {
 using namespace dc;
@@ -88,6 +88,32 @@ k_np_detect(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
     }
 }
 
+// The same for the manifolds that involve a cylinder (dcylinder.hpp): launched after k_np_detect - which leaves such pairs
+// without points - and only in worlds that have a cylinder; every other lane returns at once.
+__global__ void __launch_bounds__(64)
+k_np_detect_ext(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+    const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+    const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+    if (tA != SHAPE_CYLINDER && tB != SHAPE_CYLINDER) return;
+    if (sleeping && edge_asleep(fa, fb)) return;
+    const box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
+    if (!intersect(inset(ba, -kBreakingThreshold), bbx)) return;
+    CResult res;
+    res.num = 0;
+    Ctx ctx{B_ORG(b, ia), q_from4(B_ORN(b, ia)), B_ORG(b, ib), q_from4(B_ORN(b, ib)), kCollisionThreshold};
+    collide_ext(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
+    st.rnum[m] = (uint32_t)res.num;
+    for (int k = 0; k < res.num; ++k) {
+        const size_t d = (size_t)k * mf.cap + m;
+        st.ra[d] = to4(res.pt[k].pivotA, res.pt[k].distance);
+        st.rb[d] = to4(res.pt[k].pivotB, __int_as_float(res.pt[k].attachment));
+        st.rn[d] = to4(res.pt[k].normal, 0.0f);
+    }
+}
+
 __global__ void __launch_bounds__(64, 2)
 k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifolds old, bool points_in_old, Staging st, EventSink ev) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,10 +139,10 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         BodyIn A, B;
         { A.pos = B_ORG(b, ia); A.orn = q_from4(B_ORN(b, ia)); A.angvel = from4(b.angvel[ia]);
           float2 mt = b.mat[ia]; A.friction = mt.x; A.restitution = mt.y;
-          A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tA == SHAPE_SPHERE || tA == SHAPE_CAPSULE); }   // rolling_shapes_tuple_t
+          A.rolling = (fa & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tA == SHAPE_SPHERE || tA == SHAPE_CAPSULE || tA == SHAPE_CYLINDER); }   // rolling_shapes_tuple_t
         { B.pos = B_ORG(b, ib); B.orn = q_from4(B_ORN(b, ib)); B.angvel = from4(b.angvel[ib]);
           float2 mt = b.mat[ib]; B.friction = mt.x; B.restitution = mt.y;
-          B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tB == SHAPE_SPHERE || tB == SHAPE_CAPSULE); }
+          B.rolling = (fb & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC && (tB == SHAPE_SPHERE || tB == SHAPE_CAPSULE || tB == SHAPE_CYLINDER); }
 
         // Old points: only what the matching needs is held across it (pivots, normal, distance); friction, restitution, the
         // local normal, the warm-start impulses and the lifetime are re-read just before the stores.
@@ -326,14 +352,16 @@ int count_points(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
-__global__ void __launch_bounds__(64, 2) k_debug_collide(uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
+template <bool EXT>
+__global__ void __launch_bounds__(64, EXT ? 1 : 2) k_debug_collide(uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
                                 const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ctx ctx{mk3(pos[6 * i], pos[6 * i + 1], pos[6 * i + 2]), q_from4(orn[2 * i]), mk3(pos[6 * i + 3], pos[6 * i + 4], pos[6 * i + 5]),
             q_from4(orn[2 * i + 1]), threshold};
     CResult r;
-    collide(st[2 * i], sp[2 * i], st[2 * i + 1], sp[2 * i + 1], ctx, r);
+    if (EXT) { r.num = 0; if (!collide_ext(st[2 * i], sp[2 * i], st[2 * i + 1], sp[2 * i + 1], ctx, r)) return; }   // (the plain kernel wrote this pair's zero count)
+    else collide(st[2 * i], sp[2 * i], st[2 * i + 1], sp[2 * i + 1], ctx, r);
     count[i] = (uint32_t)r.num;
     for (int k = 0; k < r.num; ++k) {
         float *o = out + ((size_t)i * 4 + k) * 11;
@@ -359,8 +387,13 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_orn, orn, b_orn, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d + o_out, 0, b_out, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_collide, dim3((n + 63) / 64), dim3(64), 0, s, n, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
+        hipLaunchKernelGGL(k_debug_collide<false>, dim3((n + 63) / 64), dim3(64), 0, s, n, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
                            (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt));
+        bool any_cyl = false;
+        for (uint32_t i = 0; i < 2 * n && !any_cyl; ++i) any_cyl = st[i] == EDYNHIP_SHAPE_CYLINDER;
+        if (any_cyl)
+            hipLaunchKernelGGL(k_debug_collide<true>, dim3((n + 63) / 64), dim3(64), 0, s, n, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
+                               (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt));
         e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(count, d + o_cnt, b_cnt, hipMemcpyDeviceToHost, s);
@@ -375,6 +408,7 @@ int narrowphase(edynhip_ctx *c) {
     if (M == 0) return EDYNHIP_OK;
     const Staging st{c->np_ra, c->np_rb, c->np_rn, c->np_rnum};
     hipLaunchKernelGGL(k_np_detect, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
+    if (c->has_cylinder) hipLaunchKernelGGL(k_np_detect_ext, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
     hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st, event_sink(c));
     c->points_in_prev = false;
     EH_HIP(c, hipGetLastError());

@@ -28,7 +28,7 @@
 //   * per colour (scenes with joints, or when the resident-grid launch is refused): one launch per colour with one
 //     manifold per lane (k_contact_solve, k_joint_solve, k_pos_contacts, k_pos_joints).
 #include "ctx.hpp"
-#include "dcollide.hpp"
+#include "dcylinder.hpp"
 
 namespace eh {
 using namespace dm;
@@ -549,7 +549,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const uint32_t fl = side ? fb : fa;
-                    if (is_dynamic(fl) && ((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == (uint32_t)dc::SHAPE_CAPSULE) {
+                    if (is_dynamic(fl) && (((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == (uint32_t)dc::SHAPE_CAPSULE || ((fl & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == (uint32_t)dc::SHAPE_CYLINDER)) {   // shape_rolling_direction, shapes.hpp:127-139
                         const f3 rdw = rotate(A.orn, dc::axis_vector(b.shape[side ? ib : ia].z));
                         ax0 *= dot(rdw, ax0); ax1 *= dot(rdw, ax1);
                     }
@@ -2692,6 +2692,9 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
         const f3 p0 = pos - v, p1 = pos + v;
         b.amin[i] = make_float4(fminf(p0.x, p1.x) - sh.x, fminf(p0.y, p1.y) - sh.x, fminf(p0.z, p1.z) - sh.x, 0);
         b.amax[i] = make_float4(fmaxf(p0.x, p1.x) + sh.x, fmaxf(p0.y, p1.y) + sh.x, fmaxf(p0.z, p1.z) + sh.x, 0);
+    } else if (st == dc::SHAPE_CYLINDER) {   // aabb_util.cpp:72-79
+        const box3 bb = dc::cylinder_aabb(dc::cyl_of(b.shape[i]), pos, orn);
+        b.amin[i] = to4(bb.mn, 0); b.amax[i] = to4(bb.mx, 0);
     }
     if (kind == EDYNHIP_KIND_DYNAMIC) {   // update_inertias.cpp:12-24
         const m3 il = {from4(B_IL(b, i, 0)), from4(B_IL(b, i, 1)), from4(B_IL(b, i, 2))};

@@ -84,7 +84,8 @@ struct sphere_shape { scalar radius; };
 struct plane_shape { vector3 normal; scalar constant; };
 enum class coordinate_axis : unsigned char { x, y, z };                                       // math/coordinate_axis.hpp
 struct capsule_shape { scalar radius; scalar half_length; coordinate_axis axis{coordinate_axis::x}; };   // shapes/capsule_shape.hpp:17-30
-using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape, capsule_shape>;
+struct cylinder_shape { scalar radius; scalar half_length; coordinate_axis axis{coordinate_axis::x}; };  // shapes/cylinder_shape.hpp:22-25
+using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>;
 
 enum class rigidbody_kind : uint8_t { rb_dynamic, rb_kinematic, rb_static };   // util/rigidbody.hpp:22-27
 
@@ -400,6 +401,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         if (auto *b = registry.try_get<box_shape>(e)) { stype[i] = EDYNHIP_SHAPE_BOX; sp[4 * i] = b->half_extents.x; sp[4 * i + 1] = b->half_extents.y; sp[4 * i + 2] = b->half_extents.z; }
         else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
         else if (auto *cs = registry.try_get<capsule_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CAPSULE; sp[4 * i] = cs->radius; sp[4 * i + 1] = cs->half_length; sp[4 * i + 2] = (float)(int)cs->axis; }
+        else if (auto *cy = registry.try_get<cylinder_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CYLINDER; sp[4 * i] = cy->radius; sp[4 * i + 1] = cy->half_length; sp[4 * i + 2] = (float)(int)cy->axis; }
         else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
         else stype[i] = EDYNHIP_SHAPE_NONE;
         if (auto *mt = registry.try_get<material>(e)) {
@@ -989,7 +991,7 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<rigidbody_tag>(entity); registry.remove<dynamic_tag>(entity); registry.remove<kinematic_tag>(entity);
     registry.remove<static_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<sleeping_disabled_tag>(entity);
     registry.remove<sleeping_tag>(entity); registry.remove<collision_filter>(entity); registry.remove<box_shape>(entity);
-    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<material>(entity);
+    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity); registry.remove<material>(entity);
     registry.remove<gravity>(entity); registry.remove<center_of_mass>(entity); registry.remove<origin>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
@@ -1041,6 +1043,11 @@ inline matrix3x3 inertia_world_inv_of(entt::registry &registry, entt::entity e) 
             const int ax = (int)c->axis;
             const scalar cyl_x = ax == 0 ? cxx : cyy, cyl_y = ax == 1 ? cxx : cyy, tt = scalar(4) * len + scalar(3) * r;
             const scalar xx = si + cyl_x, yy = si + sm * tt * tt / scalar(64) + cyl_y;
+            d = {ax == 0 ? xx : yy, ax == 1 ? xx : yy, ax == 2 ? xx : yy};
+        } else if (auto *cy = registry.try_get<cylinder_shape>(e)) {   // moment_of_inertia.cpp:27-44
+            const scalar len = cy->half_length * 2, r = cy->radius;
+            const scalar xx = scalar(0.5) * m * r * r, yy = scalar(1) / scalar(12) * m * (scalar(3) * r * r + len * len);
+            const int ax = (int)cy->axis;
             d = {ax == 0 ? xx : yy, ax == 1 ? xx : yy, ax == 2 ? xx : yy};
         }
         I = {{vector3{d.x, 0, 0}, vector3{0, d.y, 0}, vector3{0, 0, d.z}}};
@@ -1141,9 +1148,9 @@ inline void set_rigidbody_friction(entt::registry &registry, entt::entity entity
     auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = s.refresh_friction = true;
 }
 /// util/rigidbody.hpp:235-257 (rigidbody.cpp:417-515): another shape / no shape, another kind - through a re-created context like the edits above
-inline bool rigidbody_has_shape(entt::registry &registry, entt::entity entity) { return registry.any_of<box_shape, sphere_shape, plane_shape, capsule_shape>(entity); }
+inline bool rigidbody_has_shape(entt::registry &registry, entt::entity entity) { return registry.any_of<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>(entity); }
 inline void rigidbody_set_shape(entt::registry &registry, entt::entity entity, std::optional<shapes_variant_t> shape_opt) {
-    registry.remove<box_shape>(entity); registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity);
+    registry.remove<box_shape>(entity); registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity);
     if (shape_opt) std::visit([&](auto &&sh) { registry.emplace<std::decay_t<decltype(sh)>>(entity, sh); }, *shape_opt);
     auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
     if (auto *bi = registry.try_get<detail::body_index>(entity)) s.reshaped.push_back(bi->value);

@@ -3,7 +3,7 @@
 // exclude_collision. The figure it builds is the reference's: 22 bodies (two shapeless fore-arm twist bodies, two shapeless
 // shoulders), 36 constraints (cone + cvjoint pairs sharing an entity, hinges), 21 collision exclusions - checked field by field
 // against the real engine's own rag doll (tests/golden/ragdoll_*.npz, exported from the engine) by tests/test_cpp_shim.py.
-// ragdoll_shape_type::cylinder is declared but rejected: cylinder_shape is not on the device path.
+// box, capsule and cylinder figures (ragdoll_shape_type), as the reference builds them.
 #ifndef EDYN_HIP_UTIL_RAGDOLL_HPP
 #define EDYN_HIP_UTIL_RAGDOLL_HPP
 
@@ -80,6 +80,11 @@ inline vector3 box_inertia(scalar mass, vector3 extents) {   // moment_of_inerti
 }
 // solid capsule, as the reference computes it (moment_of_inertia.cpp:65-90: the cylinder term arrives permuted for the axis and is
 // read as (axial, transverse) - reproduced, the device does the same: capi.hip k_init_bodies)
+inline vector3 cylinder_inertia(scalar mass, scalar radius, scalar half_length, coordinate_axis axis) {   // moment_of_inertia.cpp:27-44
+    const scalar len = half_length * 2;
+    const scalar xx = scalar(0.5) * mass * radius * radius, yy = scalar(1) / scalar(12) * mass * (scalar(3) * radius * radius + len * len);
+    return axis == coordinate_axis::x ? vector3{xx, yy, yy} : axis == coordinate_axis::y ? vector3{yy, xx, yy} : vector3{yy, yy, xx};
+}
 inline vector3 capsule_inertia(scalar mass, scalar radius, scalar half_length, coordinate_axis axis) {
     const scalar len = half_length * 2;
     const scalar cyl_vol = kPi * radius * radius * len, sph_vol = kPi * radius * radius * radius * scalar(4) / scalar(3);
@@ -125,10 +130,8 @@ inline ragdoll_def make_ragdoll_def_from_simple(const ragdoll_simple_def &simple
 
 inline ragdoll_entities make_ragdoll(entt::registry &registry, const ragdoll_def &r) {   // ragdoll.cpp:69-914
     using namespace detail::rag;
-    if (r.shape_type == ragdoll_shape_type::cylinder)
-        throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "edyn::make_ragdoll: cylinder_shape is not on the device path (box and capsule are)");
     ragdoll_entities e{};
-    const bool capsules = r.shape_type == ragdoll_shape_type::capsule;
+    const bool capsules = r.shape_type == ragdoll_shape_type::capsule, cylinders = r.shape_type == ragdoll_shape_type::cylinder;
     const quaternion turned = mul(r.orientation, axis_angle({0, 0, 1}, kPi));   // right arm: the same parts turned about z
     const vector3 X{1, 0, 0}, Y{0, 1, 0}, Z{0, 0, 1};
 
@@ -144,8 +147,10 @@ inline ragdoll_entities make_ragdoll(entt::registry &registry, const ragdoll_def
         const scalar length = along == coordinate_axis::y ? size.y : along == coordinate_axis::x ? size.x : size.z;
         if (mode == shape_mode::shapeless_box) def.inertia = diagonal(box_inertia(mass, size));
         else if (mode == shape_mode::shapeless_like_shape)
-            def.inertia = diagonal(capsules ? capsule_inertia(mass, across / 2, (length - across) / 2, along) : box_inertia(mass, size));
+            def.inertia = diagonal(capsules ? capsule_inertia(mass, across / 2, (length - across) / 2, along)
+                                   : cylinders ? cylinder_inertia(mass, across / 2, length / 2, along) : box_inertia(mass, size));
         else if (capsules) def.shape = capsule_shape{across / 2, (length - across) / 2, along};
+        else if (cylinders) def.shape = cylinder_shape{across / 2, length / 2, along};   // ragdoll.cpp:94-96 and the like
         else def.shape = box_shape{size * scalar(0.5)};
         return make_rigidbody(registry, def);
     };

@@ -49,7 +49,8 @@ typedef enum {
 enum { EDYNHIP_KIND_DYNAMIC = 0, EDYNHIP_KIND_KINEMATIC = 1, EDYNHIP_KIND_STATIC = 2 };
 /* shapes on the hot path; NONE = amorphous body */
 enum { EDYNHIP_SHAPE_NONE = 0, EDYNHIP_SHAPE_BOX = 1, EDYNHIP_SHAPE_SPHERE = 2, EDYNHIP_SHAPE_PLANE = 3,
-       EDYNHIP_SHAPE_CAPSULE = 4 /* shape_param = radius, half_length, axis (0 x, 1 y, 2 z): shapes/capsule_shape.hpp:17-30 */ };
+       EDYNHIP_SHAPE_CAPSULE = 4, /* shape_param = radius, half_length, axis (0 x, 1 y, 2 z): shapes/capsule_shape.hpp:17-30 */
+       EDYNHIP_SHAPE_CYLINDER = 5 /* shape_param = radius, half_length, axis: shapes/cylinder_shape.hpp:22-25 */ };
 enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_DISTANCE = 2,       /* distance_constraint.cpp:7-31; params[0] = distance; impulse slot 0 */
        EDYNHIP_JOINT_SOFT_DISTANCE = 3,  /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */

@@ -647,7 +647,7 @@ class RefWorld:
         f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)] + [C.c_float] * 4
         g = self.L.refw_num_joints; g.argtypes = [C.c_void_p]; g.restype = C.c_uint32
         first_body, first_joint = self.num_bodies, self.n_joints
-        f(self.h, {"box": 0, "capsule": 1}[shape], _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), height, weight, friction, restitution)
+        f(self.h, {"box": 0, "capsule": 1, "cylinder": 2}[shape], _fp(_f32(pos, 3)), _fp(_f32(orn, 4)), height, weight, friction, restitution)
         self.n_joints = g(self.h)
         return first_body, first_joint
 

@@ -1,6 +1,6 @@
 // edyn::make_ragdoll through the shim: dumps the figure it builds (every body and constraint as registry components) for
 // tests/test_cpp_shim.py to compare with the real engine's own rag doll (tests/golden/ragdoll_*.npz), and - with a GPU
-// (argument "run") - drops it on a floor. Usage: ragdoll capsule|box [run]
+// (argument "run") - drops it on a floor. Usage: ragdoll capsule|box|cylinder [run]
 #include <edyn/util/ragdoll.hpp>
 #include <cstdio>
 #include <cstring>
@@ -14,6 +14,7 @@ static void m3(const char *tag, const edyn::matrix3x3 &m) {
 
 int main(int argc, char **argv) {
     const bool box = argc > 1 && !std::strcmp(argv[1], "box");
+    const bool cyl = argc > 1 && !std::strcmp(argv[1], "cylinder");
     const bool run = argc > 2 && !std::strcmp(argv[2], "run");
     entt::registry registry;
     edyn::attach(registry);
@@ -24,7 +25,7 @@ int main(int argc, char **argv) {
         edyn::make_rigidbody(registry, floor);
     }
     edyn::ragdoll_simple_def def;
-    def.shape_type = box ? edyn::ragdoll_shape_type::box : edyn::ragdoll_shape_type::capsule;
+    def.shape_type = box ? edyn::ragdoll_shape_type::box : cyl ? edyn::ragdoll_shape_type::cylinder : edyn::ragdoll_shape_type::capsule;
     if (run) def.position = {0, 1.3f, 0};
     const edyn::ragdoll_entities rag = edyn::make_ragdoll(registry, def);
     auto &s = registry.ctx().get<edyn::detail::gpu_stepper>();
@@ -38,6 +39,7 @@ int main(int argc, char **argv) {
             std::printf(" orn %.9g %.9g %.9g %.9g", q.x, q.y, q.z, q.w);
             if (auto *b = registry.try_get<edyn::box_shape>(e)) { std::printf(" shape 1"); v3("param", b->half_extents); }
             else if (auto *c = registry.try_get<edyn::capsule_shape>(e)) std::printf(" shape 4 param %.9g %.9g %d", c->radius, c->half_length, (int)c->axis);
+            else if (auto *y = registry.try_get<edyn::cylinder_shape>(e)) std::printf(" shape 5 param %.9g %.9g %d", y->radius, y->half_length, (int)y->axis);
             else { std::printf(" shape 0 param 0 0 0"); m3("inertia", registry.get<edyn::inertia>(e)); }
             const auto &mat = registry.get<edyn::material>(e);
             std::printf(" friction %.9g restitution %.9g\n", mat.friction, mat.restitution);

@@ -1,4 +1,4 @@
-"""Generates tests/golden/ragdoll_{capsule,box}.npz: the reference's own rag doll (edyn::make_ragdoll,
+"""Generates tests/golden/ragdoll_{capsule,box,cylinder}.npz: the reference's own rag doll (edyn::make_ragdoll,
 util/ragdoll.cpp:65-914 - 22 bodies, 36 cone / cvjoint / hinge constraints, 21 collision exclusions) built by the REAL
 engine (oracle/_ref/libedynref.so) with its hip at the origin, exported body by body and constraint by constraint
 (RefWorld.export_figure). edyn_amd.scenes.figures() replicates the template into scenes for the parity tests and the
@@ -24,7 +24,7 @@ def build(shape):
 
 
 def main():
-    for shape in ("capsule", "box"):
+    for shape in ("capsule", "box", "cylinder"):
         fig = build(shape)
         np.savez_compressed(os.path.join(HERE, f"ragdoll_{shape}.npz"), **fig)
         print(shape, "bodies", len(fig["kind"]), "constraints", len(fig["joint_type"]), "exclusions", len(fig["exclusions"]))

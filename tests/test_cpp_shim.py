@@ -66,7 +66,7 @@ def _parse_dump(text):
     return bodies, joints, excl
 
 
-@pytest.mark.parametrize("shape", ["capsule", "box"])
+@pytest.mark.parametrize("shape", ["capsule", "box", "cylinder"])
 def test_shim_make_ragdoll_builds_the_reference_figure(shape):
     """edyn::make_ragdoll of the shim (include/edyn/util/ragdoll.hpp, tables of parts and joints) against the real engine's own
     rag doll (tests/golden/ragdoll_*.npz: edyn::make_ragdoll run by the reference and exported): every body - mass, transform,
@@ -101,7 +101,7 @@ def test_shim_make_ragdoll_builds_the_reference_figure(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["capsule", "box"])
+@pytest.mark.parametrize("shape", ["capsule", "box", "cylinder"])
 def test_shim_ragdoll_falls_on_the_floor(shape):
     """The shim's rag doll dropped on a plane: cone + cvjoint on one constraint entity, shapeless parts, exclusions - one second of
     simulation leaves a finite, connected figure lying on the floor."""

@@ -334,7 +334,11 @@ from pairgen import pair_batch as _pair_batch  # noqa: E402
     (scenes.SHAPE_SPHERE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE),
     (scenes.SHAPE_CAPSULE, scenes.SHAPE_CAPSULE), (scenes.SHAPE_CAPSULE, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE),
     (scenes.SHAPE_CAPSULE, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CAPSULE),
-    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE)])
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CAPSULE),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_PLANE), (scenes.SHAPE_PLANE, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_SPHERE), (scenes.SHAPE_SPHERE, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CYLINDER, scenes.SHAPE_CYLINDER), (scenes.SHAPE_CYLINDER, scenes.SHAPE_BOX), (scenes.SHAPE_BOX, scenes.SHAPE_CYLINDER),
+    (scenes.SHAPE_CAPSULE, scenes.SHAPE_CYLINDER), (scenes.SHAPE_CYLINDER, scenes.SHAPE_CAPSULE)])
 def test_collide_routines_bit_exact_on_random_pairs(tA, tB):
     """200k random pairs per shape combination through the device collide() (edynhip_debug_collide) and the oracle's:
     point counts, pivots, normals, distances and normal attachments must be identical bit for bit."""
@@ -1149,6 +1153,35 @@ def test_capsules_bit_exact():
     sc = _capsule_scene()
     g, o = gpu_world(sc), oracle_world(sc)
     for s in range(1, 201):
+        g.step_simulation(1); o.step(1)
+        if s % 25 == 0 or s < 3:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            gd, od = g.get_derived(), o.get_derived()
+            assert np.array_equal(gd[0], od[0]) and np.array_equal(gd[1], od[1]), s   # AABBs, world inertias
+    g2, o2 = gpu_world(sc), oracle_world(sc)
+    n = len(sc["kind"])
+    g2.set_material_extras(0, np.full(n, 0.01, np.float32), np.full(n, 0.05, np.float32))
+    for i in range(n):
+        o2.set_material_extras(i, spin=0.01, roll=0.05)
+    for s in range(1, 151):
+        g2.step_simulation(1); o2.step(1)
+        if s % 25 == 0:
+            assert_state_equal(g2, o2)
+            assert np.array_equal(g2.get_point_extras().view(np.uint32), o2.get_point_extras().view(np.uint32)), s
+    assert_state_equal(g2, o2)
+
+
+def test_cylinders_bit_exact():
+    """cylinder_shape on the device (AABB, inertia, the five pair routines of dcylinder.hpp in k_np_detect_ext,
+    rolling-shape matching, roll_direction in the rolling rows): a tumbling heap of cylinders, capsules, boxes and spheres against
+    the oracle - pairs, state, manifolds, AABBs and world inertias - then with rolling / spinning friction materials; the oracle's
+    cylinders are pinned to the real engine in tests/test_reference_engine.py."""
+    from test_reference_engine import _cylinder_scene
+    sc = _cylinder_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for s in range(1, 251):
         g.step_simulation(1); o.step(1)
         if s % 25 == 0 or s < 3:
             assert np.array_equal(g.get_pairs(), o.get_pairs()), s

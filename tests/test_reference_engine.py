@@ -847,7 +847,7 @@ def test_material_mix_table_matches_the_real_engine():
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("shape", ["capsule", "box"])
+@pytest.mark.parametrize("shape", ["capsule", "box", "cylinder"])
 def test_ragdoll_template_is_what_the_engine_builds(shape):
     """tests/golden/ragdoll_*.npz (what the -m gpu tests and the bench build their figures from) against edyn::make_ragdoll
     (util/ragdoll.cpp:65-914) run by the real engine now: every body and constraint field bit for bit."""
@@ -860,7 +860,7 @@ def test_ragdoll_template_is_what_the_engine_builds(shape):
     assert len(fig["kind"]) == 22 and len(fig["joint_type"]) == 36 and len(fig["exclusions"]) == 21
 
 
-@pytest.mark.parametrize("shape", ["capsule", "box"])
+@pytest.mark.parametrize("shape", ["capsule", "box", "cylinder"])
 def test_ragdolls_match_the_real_engine(shape):
     """Four of the reference's rag dolls (22 bodies on 36 cone / cvjoint / hinge constraints with bump stops, twist limits,
     friction and damping; shapeless twist bodies with explicit inertia; 21 collision exclusions) collapse onto the floor:
