@@ -9,7 +9,7 @@ import math
 import numpy as np
 
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
-SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER = 0, 1, 2, 3, 4, 5
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_POLYHEDRON = 0, 1, 2, 3, 4, 5, 6
 JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY, JOINT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 JOINT_NULL = 8   # null_constraint: no rows, keeps two bodies in one island
 ALL = np.uint64(2**64 - 1)

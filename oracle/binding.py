@@ -21,7 +21,7 @@ POINT_DTYPE = np.dtype([
 MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
-SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE = 0, 1, 2, 3
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_POLYHEDRON = 0, 1, 2, 3, 4, 5, 6
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2
 JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY, JOINT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 ORDER_SEQUENTIAL, ORDER_COLOURED, ORDER_EXTERNAL = 0, 1, 2
@@ -190,6 +190,40 @@ def collide(typeA, paramA, posA, ornA, typeB, paramB, posB, ornB, threshold):
     n = f(typeA, _fp(_f32(paramA, 4)), _fp(_f32(posA, 3)), _fp(_f32(ornA, 4)), typeB, _fp(_f32(paramB, 4)),
           _fp(_f32(posB, 3)), _fp(_f32(ornB, 4)), threshold, _fp(out))
     return out.reshape(4, 11)[:n].copy()
+
+
+MESH_FIELDS = ("vertices", "normals", "relevant_normals", "edge_vertices", "edge_normals", "edges", "edge_faces", "relevant_faces",
+               "relevant_edges", "neighbors_start", "neighbor_indices")
+
+
+def create_mesh(mesh, real=False):
+    """Register a convex mesh (tests/meshes.py dict) with the oracle (or the reference driver); returns its id = shape_param[0]."""
+    L = ref() if real else lib()
+    f = getattr(L, "ref_create_mesh" if real else "orc_create_mesh")
+    f.restype = C.c_int; f.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    v = np.ascontiguousarray(mesh["vertices"], np.float32); i = np.ascontiguousarray(mesh["indices"], np.uint32)
+    fc = np.ascontiguousarray(mesh["faces"], np.uint32)
+    return f(len(v), v.ctypes.data, len(i), i.ctypes.data, len(fc), fc.ctypes.data)
+
+
+def mesh_get(mesh_id, field, real=False):
+    L = ref() if real else lib()
+    f = getattr(L, "ref_mesh_get" if real else "orc_mesh_get")
+    f.restype = C.c_uint32; f.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    what = MESH_FIELDS.index(field)
+    n = f(mesh_id, what, None)
+    out = np.zeros((n, 3), np.float32) if what < 5 else np.zeros(n, np.uint32)
+    f(mesh_id, what, out.ctypes.data)
+    return out
+
+
+def mesh_inertia(mesh_id, mass, real=False):
+    L = ref() if real else lib()
+    f = getattr(L, "ref_mesh_inertia" if real else "orc_mesh_inertia")
+    f.restype = None; f.argtypes = [C.c_int, C.c_float, C.c_void_p]
+    out = np.zeros((3, 3), np.float32)
+    f(mesh_id, mass, out.ctypes.data)
+    return out
 
 
 def should_collide(groupA, maskA, groupB, maskB):
@@ -482,6 +516,14 @@ def collide_batch(shape_type, shape_param, pos, orn, threshold=0.01):
     f.restype = None
     f(n, st.ctypes.data, sp.ctypes.data, ps.ctypes.data, qs.ctypes.data, threshold, out.ctypes.data, cnt.ctypes.data)
     return out, cnt
+
+
+def last_batch_flags(n):
+    """Per pair of the last collide_batch: bit 0 = a configuration on which the reference's routine has undefined behaviour."""
+    out = np.zeros(n, np.uint8)
+    f = lib().orc_last_batch_flags; f.argtypes = [C.c_void_p]; f.restype = None
+    f(out.ctypes.data)
+    return out
 
 
 def _batch(fn, shape_type, shape_param, pos, orn, threshold):

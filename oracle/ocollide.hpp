@@ -484,6 +484,7 @@ inline void collide_capsule_box(const shape &shA, vec3 hB, const coll_ctx &ctx, 
 
 }  // namespace orc
 #include "ocylinder.hpp"
+#include "opolyhedron.hpp"
 namespace orc {
 
 // Dispatch on the shape pair; mirrored overloads go through swap_collide (collide.hpp:369-374).
@@ -516,6 +517,28 @@ inline void collide(const shape &shA, const shape &shB, const coll_ctx &ctx, col
     else if (a == SHAPE_BOX && b == SHAPE_CYLINDER) { collide_cylinder_box(shB, shA.half_extents, ctx.swapped(), r); r.swap(); }
     else if (a == SHAPE_CAPSULE && b == SHAPE_CYLINDER) collide_capsule_cylinder(shA, shB, ctx, r);
     else if (a == SHAPE_CYLINDER && b == SHAPE_CAPSULE) { collide_capsule_cylinder(shB, shA, ctx.swapped(), r); r.swap(); }
+    else if (a == SHAPE_POLYHEDRON || b == SHAPE_POLYHEDRON) {
+        // the rotated mesh is what update_rotated_meshes left after the last integration: rotate(orn * rotated_mesh_list::orientation)
+        // with that orientation the identity for a polyhedron that is not part of a compound (update_rotated_meshes.cpp:62)
+        const bool first = a == SHAPE_POLYHEDRON;
+        const shape &P = first ? shA : shB, &Q = first ? shB : shA;
+        const coll_ctx c = first ? ctx : ctx.swapped();
+        const ConvexMesh &mP = *mesh_registry()[P.mesh];
+        RotatedMesh rP, rQ;
+        PolySh pP{MeshView{&mP}, RotView{&rP}};
+        const int q = Q.type;
+        if (q == SHAPE_PLANE) { rP.update(mP, c.ornA * quat{0, 0, 0, 1}); collide_polyhedron_plane(pP, Q.normal, Q.constant, c, r); }
+        else if (q == SHAPE_SPHERE) collide_polyhedron_sphere(pP, Q.radius, c, r);
+        else if (q == SHAPE_BOX) collide_polyhedron_box(pP, Q.half_extents, c, r);
+        else if (q == SHAPE_CAPSULE) collide_polyhedron_capsule(pP, Q, c, r);
+        else if (q == SHAPE_CYLINDER) collide_polyhedron_cylinder(pP, Q, c, r);
+        else if (q == SHAPE_POLYHEDRON) {
+            const ConvexMesh &mQ = *mesh_registry()[Q.mesh];
+            rP.update(mP, c.ornA * quat{0, 0, 0, 1}); rQ.update(mQ, c.ornB * quat{0, 0, 0, 1});
+            collide_polyhedron_polyhedron(pP, PolySh{MeshView{&mQ}, RotView{&rQ}}, c, r);
+        }
+        if (!first) r.swap();
+    }
     // plane-plane: both static, never paired (only procedural bodies query the broadphase).
 }
 

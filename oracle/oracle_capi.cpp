@@ -40,7 +40,35 @@ static shape make_shape(int type, const float *p) {
     else if (type == SHAPE_SPHERE) s.radius = p[0];
     else if (type == SHAPE_PLANE) { s.normal = v3(p); s.constant = p[3]; }
     else if (type == SHAPE_CAPSULE || type == SHAPE_CYLINDER) { s.radius = p[0]; s.half_length = p[1]; s.axis = (int)p[2]; }
+    else if (type == SHAPE_POLYHEDRON) s.mesh = (int)p[0];
     return s;
+}
+// convex meshes live in a process-wide registry (a polyhedron_shape holds a shared_ptr<convex_mesh>); shape_param[0] = the id
+int orc_create_mesh(uint32_t nv, const float *verts, uint32_t nidx, const uint32_t *indices, uint32_t nfaces, const uint32_t *faces) {
+    auto m = std::make_shared<ConvexMesh>();
+    for (uint32_t i = 0; i < nv; ++i) m->vertices.push_back(v3(verts + 3 * i));
+    m->indices.assign(indices, indices + nidx);
+    m->faces.assign(faces, faces + 2 * nfaces);
+    m->initialize();
+    mesh_registry().push_back(m);
+    return (int)mesh_registry().size() - 1;
+}
+// what: 0 vertices, 1 normals, 2 relevant_normals, 3 edge_vertices, 4 edge_normals (floats x3); 5 edges, 6 edge_faces, 7 relevant_faces,
+// 8 relevant_edges, 9 neighbors_start, 10 neighbor_indices (uint32). out == nullptr: returns the element count.
+static uint32_t mesh_field(const ConvexMesh &m, int what, void *out) {
+    const std::vector<vec3> *fv[5] = {&m.vertices, &m.normals, &m.relevant_normals, &m.edge_vertices, &m.edge_normals};
+    const std::vector<uint32_t> *uv[6] = {&m.edges, &m.edge_faces, &m.relevant_faces, &m.relevant_edges, &m.neighbors_start, &m.neighbor_indices};
+    if (what < 5) {
+        if (out) for (size_t i = 0; i < fv[what]->size(); ++i) put3((float *)out + 3 * i, (*fv[what])[i]);
+        return (uint32_t)fv[what]->size();
+    }
+    if (out) std::copy(uv[what - 5]->begin(), uv[what - 5]->end(), (uint32_t *)out);
+    return (uint32_t)uv[what - 5]->size();
+}
+uint32_t orc_mesh_get(int id, int what, void *out) { return mesh_field(*mesh_registry()[id], what, out); }
+void orc_mesh_inertia(int id, float mass, float *out9) {
+    const mat3 I = mesh_registry()[id]->inertia(mass);
+    for (int r = 0; r < 3; ++r) put3(out9 + 3 * r, I.row[r]);
 }
 
 uint32_t orc_add_body(void *h, int kind, const float *pos, const float *orn, const float *linvel, const float *angvel,
@@ -375,12 +403,20 @@ uint32_t orc_sizeof_manifold_rec() { return (uint32_t)sizeof(orc_manifold_rec); 
 }  // extern "C"
 
 // Batch form of orc_collide for the randomized device-vs-oracle narrowphase test.
+static std::vector<uint8_t> g_batch_flags;
 extern "C" void orc_collide_batch(uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                                   float *out, uint32_t *count) {
-    for (uint32_t i = 0; i < n; ++i)
+    g_batch_flags.assign(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        g_poly_flags = 0;
         count[i] = (uint32_t)orc_collide(st[2 * i], sp + 8 * i, pos + 6 * i, orn + 8 * i, st[2 * i + 1], sp + 8 * i + 4, pos + 6 * i + 3,
                                          orn + 8 * i + 4, threshold, out + (size_t)i * 44);
+        g_batch_flags[i] = (uint8_t)g_poly_flags;
+    }
 }
+// per pair of the last orc_collide_batch: bit 0 = the pair took a path on which the reference reads uninitialised variables
+// (collide_polyhedron_polyhedron.cpp:98-100 when no edge pair spans a Minkowski face) - those pairs cannot be compared with it
+extern "C" void orc_last_batch_flags(uint8_t *out) { std::copy(g_batch_flags.begin(), g_batch_flags.end(), out); }
 
 // Twins of oracle/ref_xcheck.cpp's ref_tree_run / ref_friction_solve over the restatement (same argument layouts).
 extern "C" uint32_t orc_tree_run(uint32_t nops, const int32_t *ops, const float *boxes, uint32_t *hits, uint32_t max_hits, uint8_t *moved) {

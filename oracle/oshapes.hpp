@@ -9,7 +9,7 @@
 
 namespace orc {
 
-enum shape_type : int { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4, SHAPE_CYLINDER = 5 };
+enum shape_type : int { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4, SHAPE_CYLINDER = 5, SHAPE_POLYHEDRON = 6 };
 enum box_feature : int { BF_VERTEX = 0, BF_EDGE = 1, BF_FACE = 2 };
 
 struct shape {
@@ -20,6 +20,7 @@ struct shape {
     float constant = 0;           // plane
     float half_length = 0;        // capsule, cylinder (radius above); shapes/capsule_shape.hpp:17-30, cylinder_shape.hpp:22-25
     int axis = 0;                 // capsule, cylinder: coordinate_axis x, y, z
+    int mesh = -1;                // polyhedron: index into mesh_registry() (opolyhedron.hpp); shapes/polyhedron_shape.hpp:11-43
 };
 inline vec3 coordinate_axis_vector(int axis) { return axis == 0 ? vec3{1, 0, 0} : (axis == 1 ? vec3{0, 1, 0} : vec3{0, 0, 1}); }   // math/coordinate_axis.hpp:23-44
 inline void capsule_vertices(const shape &s, vec3 pos, quat orn, vec3 out[2]) {   // capsule_shape::get_vertices
@@ -157,9 +158,12 @@ inline aabb sphere_aabb(float radius, vec3 pos) {
 }
 inline aabb cylinder_aabb(const shape &s, vec3 pos, quat orn);   // ocylinder.hpp
 inline mat3 cylinder_inertia(const shape &s, float mass);
+inline aabb polyhedron_aabb(const shape &s, vec3 pos, quat orn);   // opolyhedron.hpp
+inline mat3 polyhedron_inertia(const shape &s, float mass);
 inline aabb shape_aabb(const shape &s, vec3 pos, quat orn) {
     switch (s.type) {
     case SHAPE_CYLINDER: return cylinder_aabb(s, pos, orn);
+    case SHAPE_POLYHEDRON: return polyhedron_aabb(s, pos, orn);
     case SHAPE_BOX: return box_aabb(s.half_extents, pos, orn);
     case SHAPE_SPHERE: return sphere_aabb(s.radius, pos);
     case SHAPE_PLANE: return plane_aabb(s.normal, s.constant);
@@ -175,6 +179,7 @@ inline aabb shape_aabb(const shape &s, vec3 pos, quat orn) {
 
 inline mat3 moment_of_inertia(const shape &s, float mass) {
     if (s.type == SHAPE_CYLINDER) return cylinder_inertia(s, mass);
+    if (s.type == SHAPE_POLYHEDRON) return polyhedron_inertia(s, mass);
     if (s.type == SHAPE_BOX) {
         vec3 ext = s.half_extents * 2.0f;
         vec3 d = 1.0f / 12.0f * mass * vec3{ext.y * ext.y + ext.z * ext.z, ext.z * ext.z + ext.x * ext.x,

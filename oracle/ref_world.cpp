@@ -39,6 +39,7 @@
 #include <unordered_map>
 #include <vector>
 
+std::shared_ptr<edyn::convex_mesh> ref_mesh(int id);   // ref_xcheck.cpp: the mesh registry shared with the leaf cross-checks
 namespace {
 
 // Same record layout as oracle_capi.cpp / include/edynhip.h (one numpy dtype describes all three).
@@ -154,6 +155,7 @@ uint32_t refw_add_body(void *h, int kind, const float *pos, const float *orn, co
     else if (shape_type == 3) def.shape = edyn::plane_shape{v3(sp), sp[3]};
     else if (shape_type == 4) def.shape = edyn::capsule_shape{sp[0], sp[1], (edyn::coordinate_axis)(int)sp[2]};
     else if (shape_type == 5) def.shape = edyn::cylinder_shape{sp[0], sp[1], (edyn::coordinate_axis)(int)sp[2]};
+    else if (shape_type == 6) def.shape = edyn::polyhedron_shape{ref_mesh((int)sp[0])};
     if (inertia9) {
         def.inertia = edyn::matrix3x3{{edyn::vector3{inertia9[0], inertia9[1], inertia9[2]},
                                        edyn::vector3{inertia9[3], inertia9[4], inertia9[5]},

@@ -85,12 +85,18 @@ void ref_row_prepare_solve(const float *rd, const float *vel, float *delta, floa
 #include <edyn/collision/dynamic_tree.hpp>
 #include <edyn/constraints/constraint_row_friction.hpp>
 #include <edyn/util/aabb_util.hpp>
+#include <edyn/shapes/polyhedron_shape.hpp>
+#include <edyn/shapes/convex_mesh.hpp>
+#include <edyn/dynamics/moment_of_inertia.hpp>
+#include <memory>
 #include <variant>
 #include <vector>
 
 namespace {
-using ref_shape = std::variant<std::monostate, box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>;
+using ref_shape = std::variant<std::monostate, box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape, polyhedron_shape>;
+std::vector<std::shared_ptr<convex_mesh>> g_ref_meshes;
 ref_shape make_ref_shape(int type, const float *p) {
+    if (type == 6) return polyhedron_shape{g_ref_meshes[(int)p[0]]};
     if (type == 1) return box_shape{v3(p)};
     if (type == 2) return sphere_shape{p[0]};
     if (type == 3) return plane_shape{v3(p), p[3]};
@@ -100,7 +106,36 @@ ref_shape make_ref_shape(int type, const float *p) {
 }
 }  // namespace
 
+std::shared_ptr<edyn::convex_mesh> ref_mesh(int id) { return g_ref_meshes[id]; }
 extern "C" {
+int ref_create_mesh(uint32_t nv, const float *verts, uint32_t nidx, const uint32_t *indices, uint32_t nfaces, const uint32_t *faces) {
+    auto m = std::make_shared<convex_mesh>();
+    for (uint32_t i = 0; i < nv; ++i) m->vertices.push_back(v3(verts + 3 * i));
+    m->indices.assign(indices, indices + nidx);
+    m->faces.assign(faces, faces + 2 * nfaces);
+    m->initialize();
+    g_ref_meshes.push_back(m);
+    return (int)g_ref_meshes.size() - 1;
+}
+uint32_t ref_mesh_get(int id, int what, void *out) {   // fields as orc_mesh_get
+    const convex_mesh &m = *g_ref_meshes[id];
+    const std::vector<vector3> *fv[5] = {&m.vertices, &m.normals, nullptr, &m.edge_vertices, &m.edge_normals};
+    const std::vector<uint32_t> *uv[6] = {&m.edges, &m.edge_faces, &m.relevant_faces, &m.relevant_edges, &m.neighbors_start, &m.neighbor_indices};
+    if (what == 2) {
+        if (out) for (size_t i = 0; i < m.relevant_faces.size(); ++i) put3((float *)out + 3 * i, m.relevant_normals[i]);
+        return (uint32_t)m.relevant_faces.size();
+    }
+    if (what < 5) {
+        if (out) for (size_t i = 0; i < fv[what]->size(); ++i) put3((float *)out + 3 * i, (*fv[what])[i]);
+        return (uint32_t)fv[what]->size();
+    }
+    if (out) std::copy(uv[what - 5]->begin(), uv[what - 5]->end(), (uint32_t *)out);
+    return (uint32_t)uv[what - 5]->size();
+}
+void ref_mesh_inertia(int id, float mass, float *out9) {
+    const auto I = moment_of_inertia(polyhedron_shape{g_ref_meshes[id]}, mass);
+    for (int r = 0; r < 3; ++r) put3(out9 + 3 * r, I.row[r]);
+}
 // Same signature as orc_collide_batch: per pair shape types st[2], shape params sp[2][4], pos[2][3], orn[2][4];
 // out per point 11 floats (pivotA, pivotB, normal, distance, normal_attachment). collide.hpp:43-330 overloads.
 void ref_collide_batch(uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
@@ -109,6 +144,10 @@ void ref_collide_batch(uint32_t n, const int32_t *st, const float *sp, const flo
         auto shA = make_ref_shape(st[2 * i], sp + 8 * i), shB = make_ref_shape(st[2 * i + 1], sp + 8 * i + 4);
         const float *pa = pos + 6 * i, *pb = pa + 3, *qa = orn + 8 * i, *qb = qa + 4;
         collision_result result;
+        // the rotated mesh as update_rotated_meshes leaves it: orientation * rotated_mesh_list::orientation (identity)
+        rotated_mesh rotA, rotB;
+        if (auto *pa_ = std::get_if<polyhedron_shape>(&shA)) { rotA = make_rotated_mesh(*pa_->mesh, quaternion{qa[0], qa[1], qa[2], qa[3]} * quaternion_identity); pa_->rotated = &rotA; }
+        if (auto *pb_ = std::get_if<polyhedron_shape>(&shB)) { rotB = make_rotated_mesh(*pb_->mesh, quaternion{qb[0], qb[1], qb[2], qb[3]} * quaternion_identity); pb_->rotated = &rotB; }
         std::visit([&](auto &&a) {
             std::visit([&](auto &&b) {
                 using A = std::decay_t<decltype(a)>;

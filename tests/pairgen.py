@@ -16,7 +16,7 @@ def random_quats(rng, n, snap_fraction=0.3):
     return q.astype(np.float32)
 
 
-def pair_batch(rng, n, tA, tB):
+def pair_batch(rng, n, tA, tB, mesh_radii=None):
     """n shape pairs placed so that a good share are within the contact threshold of each other."""
     st = np.empty((n, 2), np.int32); st[:, 0] = tA; st[:, 1] = tB
     sp = np.zeros((n, 2, 4), np.float32)
@@ -45,6 +45,11 @@ def pair_batch(rng, n, tA, tB):
             sp[:, side, 2] = rng.integers(0, 3, n)
             r, hl = sp[:, side, 0], sp[:, side, 1]
             reach[:, side] = np.minimum(r, hl) + rng.random(n).astype(np.float32) * (np.sqrt(r * r + hl * hl) - np.minimum(r, hl))
+        elif t == getattr(scenes, "SHAPE_POLYHEDRON", 6):   # shape_param[0] = mesh id; mesh_radii[id] = (inner, outer) about the centroid
+            ids = rng.integers(0, len(mesh_radii), n)
+            sp[:, side, 0] = ids
+            rr = np.asarray(mesh_radii, np.float32)[ids]
+            reach[:, side] = rr[:, 0] + rng.random(n).astype(np.float32) ** 2 * (rr[:, 1] - rr[:, 0])
         else:   # plane through a random offset with a random (or +Y) normal
             nrm = rng.normal(size=(n, 3)).astype(np.float32)
             nrm[rng.random(n) < 0.5] = (0, 1, 0)

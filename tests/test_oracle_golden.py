@@ -33,6 +33,38 @@ def test_collide_box_box_face_edge():
     _set_equal(r[:, 3:6], [(0.5, -0.5, 0.5), (-0.5, -0.5, 0.5)])
 
 
+def test_collide_polyhedron_sphere():
+    # test/edyn/collision/test_collision.cpp:92-147: the unit box as a convex mesh against a sphere of radius 0.5, both argument orders
+    import meshes
+    meshes.registered()   # id 0 = make_box_mesh({0.5, 0.5, 0.5})
+    P, S = ob.SHAPE_POLYHEDRON, ob.SHAPE_SPHERE
+    r = ob.collide(P, [0, 0, 0, 0], [0.5, 0.5, 0.5], IDENT, S, [0.5, 0, 0, 0], [0.5, 1.4, 0.5], IDENT, 1e18)
+    assert len(r) == 1
+    np.testing.assert_allclose(r[0, 6:9], (0, -1, 0), atol=1e-6)
+    np.testing.assert_allclose(r[0, 0:3], (0, 0.5, 0), atol=1e-6)
+    np.testing.assert_allclose(r[0, 3:6], (0, -0.5, 0), atol=1e-6)
+    assert abs(r[0, 9] + 0.1) < 1e-6
+    r = ob.collide(S, [0.5, 0, 0, 0], [1.5, 1.5, 0.5], IDENT, P, [0, 0, 0, 0], [0.5, 0.5, 0.5], IDENT, 1e18)
+    assert len(r) == 1
+    h = 0.707107
+    np.testing.assert_allclose(r[0, 6:9], (h, h, 0), atol=1e-5)
+    np.testing.assert_allclose(r[0, 0:3], (-h / 2, -h / 2, 0), atol=1e-5)
+    np.testing.assert_allclose(r[0, 3:6], (0.5, 0.5, 0), atol=1e-5)
+    assert abs(r[0, 9] - 0.2071067812) < 1e-5
+
+
+def test_mesh_centroid_and_volume():
+    # test/edyn/shapes/test_centroid.cpp:4-51, test_shape_volume.cpp:5-13: initialize() leaves the centroid of the unit box mesh at the
+    # origin; an off-centre prism is moved there
+    import meshes
+    lib, _ = meshes.registered()
+    v = ob.mesh_get(0, "vertices")
+    assert np.array_equal(np.abs(v), np.full((8, 3), 0.5, np.float32))
+    v4 = ob.mesh_get(4, "vertices")   # prism(6) built at offset (0.2, -0.1, 0.05)
+    np.testing.assert_allclose(v4.mean(axis=0), 0, atol=1e-6)
+    np.testing.assert_allclose(lib[4]["vertices"].mean(axis=0), (0.2, -0.1, 0.05), atol=1e-6)
+
+
 @pytest.mark.parametrize("p0,p1,bmin,bmax,n,s", [
     ((0, 0.5), (1, 1.5), (-1, -0.5), (2, 1), 2, (-1, 0.5)),      # test_geom.cpp:3-13
     ((2, 1), (1, 1.5), (-1, -0.5), (2, 1), 1, (0,)),             # :15-24

@@ -26,6 +26,7 @@ import pytest
 from edyn_amd import scenes
 from oracle import binding as ob
 from pairgen import pair_batch
+import meshes
 
 pytestmark = pytest.mark.skipif(ob.ref() is None, reason="oracle/_ref/libedynref.so not built (needs /root/reference at build time)")
 
@@ -62,6 +63,41 @@ def test_collide_matches_the_reference_routines(tA, tB):
     if tA == scenes.SHAPE_BOX and tB == scenes.SHAPE_BOX:
         assert set(np.unique(rc)) == {0, 1, 2, 3, 4}
     assert np.array_equal(op.view(np.uint32), rp.view(np.uint32))
+
+
+def test_convex_mesh_initialisation_matches_the_reference():
+    """convex_mesh::initialize (convex_mesh.cpp:10-230: centroid shift, face normals, unique edges with their two faces, vertex
+    adjacency, relevant faces / edges) and moment_of_inertia_polyhedron, every derived array bit for bit."""
+    lib, _ = meshes.registered()
+    for k in range(len(lib)):
+        for f in ob.MESH_FIELDS:
+            x, y = ob.mesh_get(k, f, False), ob.mesh_get(k, f, True)
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), (k, f)
+        assert np.array_equal(ob.mesh_inertia(k, 2.5).view(np.uint32), ob.mesh_inertia(k, 2.5, True).view(np.uint32))
+    assert len(ob.mesh_get(9, "relevant_edges")) < len(ob.mesh_get(9, "edges")) // 2   # the 12-gon prism: parallel edges folded
+
+
+@pytest.mark.parametrize("other", [scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE, scenes.SHAPE_POLYHEDRON, scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE,
+                                   scenes.SHAPE_CYLINDER])
+def test_polyhedron_collide_matches_the_reference_routines(other):
+    """collide_polyhedron_{plane,sphere,polyhedron,box,capsule,cylinder}.cpp in both argument orders over ten convex meshes (boxes,
+    tetrahedron, octahedron, prisms with 5/6/12-gon faces, a wedge, two random hulls): hill-climbing support projection, support
+    polygons and their quickhull, Minkowski-face edge pruning, segment intersections - bit for bit.
+    Pairs of polyhedra with only parallel edges are left out of the comparison: the reference reads uninitialised variables there
+    (collide_polyhedron_polyhedron.cpp:98-100,150) - the oracle reports which pairs took that path."""
+    _, rad = meshes.registered()
+    P = scenes.SHAPE_POLYHEDRON
+    for tA, tB in ((P, other), (other, P)) if other != P else ((P, P),):
+        rng = np.random.default_rng(1000 + 10 * tA + tB)
+        n = 100_000
+        st, sp, pos, orn = pair_batch(rng, n, tA, tB, rad)
+        op, oc = ob.collide_batch(st, sp, pos, orn, threshold=0.02)
+        ok = ob.last_batch_flags(n) == 0
+        assert (other == P and 0 < (~ok).sum() < n // 50) or ok.all()
+        rp, rc = ob.ref_collide_batch(st[ok], sp[ok], pos[ok], orn[ok], threshold=0.02)
+        assert np.array_equal(oc[ok], rc)
+        assert (rc > 0).mean() > 0.5 and (other in (scenes.SHAPE_SPHERE, scenes.SHAPE_CAPSULE) or (rc == 4).sum() > 100)
+        assert np.array_equal(op[ok].view(np.uint32), rp.view(np.uint32))
 
 
 def test_dynamic_tree_matches_the_reference_tree():
@@ -636,6 +672,37 @@ def test_cylinders_whole_steps_bit_exact_against_the_real_engine():
     iterations, and rolling_tag matching in the narrowphase: a tumbling heap of cylinders, capsules, boxes and spheres stays
     bit-identical to the real engine for 250 steps."""
     _lockstep(_cylinder_scene(), 250, 10)
+
+
+def _polyhedron_scene():
+    """A tumbling heap of convex polyhedra (the ten meshes of tests/meshes.py) among cylinders, capsules, boxes and spheres."""
+    lib, _ = meshes.registered()
+    sc = scenes.box_pile(3, 3, 5, mixed=True)
+    n = len(sc["kind"])
+    rng = np.random.default_rng(12)
+    for i in range(1, n):
+        if i % 2 == 0:
+            sc["shape_type"][i] = scenes.SHAPE_POLYHEDRON
+            sc["shape_param"][i] = (float(i // 2 % len(lib)), 0, 0, 0)
+        elif i % 7 == 1:
+            sc["shape_type"][i] = scenes.SHAPE_CYLINDER
+            sc["shape_param"][i] = (0.25 + 0.05 * (i % 5), 0.1 + 0.08 * (i % 4), float(i % 3), 0)
+        elif i % 7 == 3:
+            sc["shape_type"][i] = scenes.SHAPE_CAPSULE
+            sc["shape_param"][i] = (0.3, 0.2 + 0.05 * (i % 4), float(i % 3), 0)
+    q = rng.normal(size=(n - 1, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    sc["orn"][1:] = q.astype(np.float32)
+    sc["angvel"][1:] = (rng.normal(size=(n - 1, 3)) * 2).astype(np.float32)
+    sc["linvel"][1:] = (rng.normal(size=(n - 1, 3)) * (0.8, 0.1, 0.8)).astype(np.float32)
+    sc["meshes"] = lib
+    return sc
+
+
+def test_polyhedra_whole_steps_bit_exact_against_the_real_engine():
+    """polyhedron_shape (SURVEY 8f rank 3): convex_mesh::initialize, mesh inertia, the rotated mesh refreshed after every integration
+    (update_rotated_meshes.cpp, solver.cpp:458), its AABB (update_aabbs.cpp:22-32), and the six pair routines: a tumbling heap of
+    polyhedra, cylinders, capsules, boxes and spheres stays bit-identical to the real engine for 300 steps."""
+    _lockstep(_polyhedron_scene(), 300, 10)
 
 
 def test_capsule_rolling_friction_uses_the_roll_direction():
