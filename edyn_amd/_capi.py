@@ -85,7 +85,8 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
            "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing",
-           "edynhip_measure_bandwidth", "edynhip_set_joint_warm_start", "edynhip_set_asleep"]
+           "edynhip_measure_bandwidth", "edynhip_set_joint_warm_start", "edynhip_set_asleep", "edynhip_create_convex_mesh",
+           "edynhip_get_convex_mesh"]
 
 _lib = None
 
@@ -148,6 +149,8 @@ def lib():
         L.edynhip_set_joint_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_measure_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.edynhip_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.edynhip_get_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L
     return _lib

@@ -2,7 +2,7 @@
 // state read-back. Host-side logic only; every simulation stage runs in the HIP kernels of
 // broadphase.hip / narrowphase.hip / solver.hip. There is no CPU fallback.
 #include "ctx.hpp"
-#include "dcylinder.hpp"
+#include "dpolyhedron.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -102,6 +102,7 @@ static int allocate(edynhip_ctx *c) {
         EH_TRY(dalloc(c, c->events, c->event_cap)); EH_TRY(dalloc(c, c->event_count, 4)); EH_TRY(dalloc(c, c->prev_matched, M));
     }
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M)); EH_TRY(dalloc(c, c->new_edge_m, M));
+    EH_TRY(dalloc(c, c->rot_off, nb)); EH_HIP(c, hipMemsetAsync(c->rot_off, 0xFF, (size_t)nb * sizeof(uint32_t), c->stream));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
@@ -139,7 +140,7 @@ struct RawBodies {
     const int32_t *kind; const float *pos, *orn, *linvel, *angvel, *mass, *inertia; const uint8_t *has_inertia;
     const int32_t *shape_type; const float *shape_param, *friction, *restitution; const uint64_t *group, *mask; const float *gravity; const uint8_t *sleeping_disabled; const float *com;
 };
-__global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b, float3 default_gravity) {
+__global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b, float3 default_gravity, dc::Meshes meshes) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;   // index into the caller's arrays
     if (l >= n) return;
     const uint32_t i = first + l;                                // body index
@@ -185,6 +186,8 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         } else if (st == dc::SHAPE_CYLINDER) {   // moment_of_inertia.cpp:27-44,167-169
             const f3 d = dc::cylinder_inertia_diag(dc::cyl_of(sp), mass);
             I = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}};
+        } else if (st == dc::SHAPE_POLYHEDRON) {   // moment_of_inertia.cpp:93-157,183-185
+            I = dc::polyhedron_inertia(meshes, sp, mass);
         } else {
             I = {{kScalarMax, 0, 0}, {0, kScalarMax, 0}, {0, 0, kScalarMax}};
         }
@@ -257,6 +260,9 @@ __global__ void k_init_bodies(uint32_t first, uint32_t n, RawBodies r, Bodies b,
         mx = mk3(fmaxf(p0.x, p1.x) + sp.x, fmaxf(p0.y, p1.y) + sp.x, fmaxf(p0.z, p1.z) + sp.x);
     } else if (st == dc::SHAPE_CYLINDER) {   // aabb_util.cpp:72-79
         const box3 bb = dc::cylinder_aabb(dc::cyl_of(sp), pos, orn);
+        mn = bb.mn; mx = bb.mx;
+    } else if (st == dc::SHAPE_POLYHEDRON) {   // aabb_util.cpp:141-164,195-197
+        const box3 bb = dc::polyhedron_aabb(meshes, sp, pos, orn);
         mn = bb.mn; mx = bb.mx;
     } else if (st == dc::SHAPE_PLANE) {
         const f3 nrm = from4(sp);
@@ -472,6 +478,8 @@ __global__ void k_wake_marked(uint32_t n, Bodies b, uint32_t *wake, double *sinc
 static int index_scratch(edynhip_ctx *c, size_t count, uint32_t *&out) {
     if (count > c->idx_scratch_cap) {
         if (c->idx_scratch) (void)hipFree(c->idx_scratch);
+    for (void *p : c->mesh_allocs) (void)hipFree(p);
+    if (c->rot) (void)hipFree(c->rot);
         c->idx_scratch = nullptr; c->idx_scratch_cap = 0;
         const size_t cap = std::max<size_t>(count * 2, 1024);
         EH_HIP(c, hipMalloc((void **)&c->idx_scratch, cap * sizeof(uint32_t)));
@@ -500,7 +508,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 10; }   // 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 11; }   // 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -601,8 +609,9 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
               !in->friction || !in->restitution))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string(who) + ": missing array").c_str());
     for (uint32_t i = 0; i < n; ++i)
-        if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_CYLINDER)
-            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule, cylinder)").c_str());
+        if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_POLYHEDRON)
+            return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule, cylinder, polyhedron)").c_str());
+    EH_TRY(mesh_bind_bodies(c, first, n, in->shape_type, in->shape_param));
     if (first == 0) c->has_cylinder = false;
     for (uint32_t i = 0; i < n; ++i) if (in->shape_type[i] == EDYNHIP_SHAPE_CYLINDER) c->has_cylinder = true;   // narrowphase.hip launches k_np_detect_ext
     if (first == 0) { c->has_restitution = false; c->extras = false; c->host_mat_id.clear(); c->b.mix_K = 0; for (auto &kv : c->host_mix) if (kv.second[0] > 0) c->has_restitution = true; }
@@ -636,7 +645,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         c->b.n = total;
         if (n)
             hipLaunchKernelGGL(k_init_bodies, dim3((n + 255) / 256), dim3(256), 0, c->stream, first, n, r, c->b,
-                               make_float3(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]));
+                               make_float3(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]), c->meshes);
         c->host_kind.resize(first); c->host_shape.resize(first);
         c->host_kind.insert(c->host_kind.end(), in->kind, in->kind + n);
         c->host_shape.insert(c->host_shape.end(), in->shape_type, in->shape_type + n);

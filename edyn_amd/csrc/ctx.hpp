@@ -10,6 +10,7 @@
 #include <map>
 #include <vector>
 #include "../../include/edynhip.h"
+#include "dmesh.hpp"
 
 namespace eh {
 
@@ -333,6 +334,19 @@ struct edynhip_ctx {
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
     bool has_generic = false;      // some joint is a generic_constraint (k_prep_generic runs)
     bool has_cylinder = false;     // some body is a cylinder_shape (narrowphase.hip k_np_detect_ext runs)
+    // convex meshes and polyhedron bodies (mesh.hip)
+    bool has_polyhedron = false;   // some body is a polyhedron_shape (k_update_rotated + k_np_detect_poly run)
+    struct HostMeshes {
+        std::vector<dc::MeshDesc> desc;
+        std::vector<float4> vertices, normals, edge_vertices, edge_normals, relevant_normals;
+        std::vector<uint32_t> face_first, edge_vidx, edge_faces, relevant_faces, relevant_edges, nb_start, nb_idx;
+        void swap(HostMeshes &o) { std::swap(*this, o); }
+    } host_meshes;
+    dc::Meshes meshes;                       // the same tables on the device (+ the rotated-mesh buffer)
+    std::vector<void *> mesh_allocs;
+    float4 *rot = nullptr; size_t rot_cap = 0, rot_used = 0;   // rotated meshes of the polyhedron bodies
+    uint32_t *rot_off = nullptr;             // per body: its slice of `rot` (~0u: none)
+    std::vector<uint32_t> host_rot_off;
     // material mix table, host side: the reference's container (std::map under unordered_pair's comparator) so that lookups behave
     // exactly like its own; ids by body; device buffers are rebuilt on every change (rebuild_mix_table, capi.hip)
     struct MixIdPair { uint32_t first, second; };
@@ -400,6 +414,8 @@ int wake_islands_of(edynhip_ctx *c, const std::vector<uint32_t> &bodies);   // c
 size_t sort_temp_bytes(uint32_t max_items);
 int sort_u64(edynhip_ctx *c, const uint64_t *in, uint64_t *out, uint32_t n, int begin_bit, int end_bit);
 int set_error(edynhip_ctx *c, int code, const char *what, hipError_t e = hipSuccess);
+int mesh_bind_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const int32_t *shape_type, const float *shape_param);   // mesh.hip
+int update_rotated(edynhip_ctx *c);
 }  // namespace eh
 
 #define EH_HIP(c, call)                                                          \

@@ -15,7 +15,7 @@ constexpr float kMergingThreshold = 0.01f;          // :27
 constexpr float kCachingThreshold = 0.04f;          // :34
 constexpr float kSupportTolerance = 0.005f;         // :56
 
-enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4, SHAPE_CYLINDER = 5 };
+enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_SPHERE = 2, SHAPE_PLANE = 3, SHAPE_CAPSULE = 4, SHAPE_CYLINDER = 5, SHAPE_POLYHEDRON = 6 };
 enum { BF_VERTEX = 0, BF_EDGE = 1, BF_FACE = 2 };
 enum { NA_NONE = 0, NA_ON_A = 1, NA_ON_B = 2 };
 enum { INS_NONE = 0, INS_APPEND = 1, INS_SIMILAR = 2, INS_REPLACE = 3 };

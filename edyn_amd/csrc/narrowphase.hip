@@ -8,7 +8,7 @@
 // manifold owns four fixed slots kept in that same list order, so creation/destruction is a register
 // shuffle instead of entity churn.
 #include "ctx.hpp"
-#include "dcylinder.hpp"
+#include "dpolyhedron.hpp"
 
 namespace eh {
 using namespace dc;
@@ -105,6 +105,32 @@ k_np_detect_ext(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
     res.num = 0;
     Ctx ctx{B_ORG(b, ia), q_from4(B_ORN(b, ia)), B_ORG(b, ib), q_from4(B_ORN(b, ib)), kCollisionThreshold};
     collide_ext(tA, b.shape[ia], tB, b.shape[ib], ctx, res);
+    st.rnum[m] = (uint32_t)res.num;
+    for (int k = 0; k < res.num; ++k) {
+        const size_t d = (size_t)k * mf.cap + m;
+        st.ra[d] = to4(res.pt[k].pivotA, res.pt[k].distance);
+        st.rb[d] = to4(res.pt[k].pivotB, __int_as_float(res.pt[k].attachment));
+        st.rn[d] = to4(res.pt[k].normal, 0.0f);
+    }
+}
+
+// The same for the manifolds that involve a polyhedron (dpolyhedron.hpp), in worlds that have one; k_update_rotated ran before.
+__global__ void __launch_bounds__(64)
+k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st, Meshes meshes) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+    const uint32_t fa = b.flags[ia], fb = b.flags[ib];
+    const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+    if (tA != SHAPE_POLYHEDRON && tB != SHAPE_POLYHEDRON) return;
+    if (sleeping && edge_asleep(fa, fb)) return;
+    const box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
+    if (!intersect(inset(ba, -kBreakingThreshold), bbx)) return;
+    CResult res;
+    res.num = 0;
+    Ctx ctx{B_ORG(b, ia), q_from4(B_ORN(b, ia)), B_ORG(b, ib), q_from4(B_ORN(b, ib)), kCollisionThreshold};
+    collide_poly(meshes, tA, b.shape[ia], tA == SHAPE_POLYHEDRON ? meshes.rot + meshes.rot_off[ia] : nullptr, tB, b.shape[ib],
+                 tB == SHAPE_POLYHEDRON ? meshes.rot + meshes.rot_off[ib] : nullptr, ctx, res);
     st.rnum[m] = (uint32_t)res.num;
     for (int k = 0; k < res.num; ++k) {
         const size_t d = (size_t)k * mf.cap + m;
@@ -371,6 +397,37 @@ __global__ void __launch_bounds__(64, EXT ? 1 : 2) k_debug_collide(uint32_t n, c
         o[9] = r.pt[k].distance; o[10] = (float)r.pt[k].attachment;
     }
 }
+// Pairs with a polyhedron: one workgroup per pair - its lanes rotate the pair's meshes into scratch (update_rotated_mesh), lane 0 collides.
+__global__ void __launch_bounds__(64)
+k_debug_collide_poly(uint32_t first, uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
+                     const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count, Meshes meshes, float4 *scratch, uint32_t stride) {
+    const uint32_t i = first + blockIdx.x;
+    if (blockIdx.x >= n) return;
+    const int tA = st[2 * i], tB = st[2 * i + 1];
+    if (tA != SHAPE_POLYHEDRON && tB != SHAPE_POLYHEDRON) return;
+    float4 *rot[2] = {scratch + (size_t)(2 * blockIdx.x) * stride, scratch + (size_t)(2 * blockIdx.x + 1) * stride};
+    for (int side = 0; side < 2; ++side) {
+        if (st[2 * i + side] != SHAPE_POLYHEDRON) continue;
+        const MeshDesc d = meshes.desc[(uint32_t)sp[2 * i + side].x];
+        const q4 q = q_from4(orn[2 * i + side]) * q4{0, 0, 0, 1};
+        for (uint32_t k = threadIdx.x; k < d.rot_size; k += 64) rotate_mesh_item(meshes, d, q, rot[side], k);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    Ctx ctx{mk3(pos[6 * i], pos[6 * i + 1], pos[6 * i + 2]), q_from4(orn[2 * i]), mk3(pos[6 * i + 3], pos[6 * i + 4], pos[6 * i + 5]),
+            q_from4(orn[2 * i + 1]), threshold};
+    CResult r;
+    r.num = 0;
+    collide_poly(meshes, tA, sp[2 * i], rot[0], tB, sp[2 * i + 1], rot[1], ctx, r);
+    count[i] = (uint32_t)r.num;
+    for (int k = 0; k < r.num; ++k) {
+        float *o = out + ((size_t)i * 4 + k) * 11;
+        o[0] = r.pt[k].pivotA.x; o[1] = r.pt[k].pivotA.y; o[2] = r.pt[k].pivotA.z;
+        o[3] = r.pt[k].pivotB.x; o[4] = r.pt[k].pivotB.y; o[5] = r.pt[k].pivotB.z;
+        o[6] = r.pt[k].normal.x; o[7] = r.pt[k].normal.y; o[8] = r.pt[k].normal.z;
+        o[9] = r.pt[k].distance; o[10] = (float)r.pt[k].attachment;
+    }
+}
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count) {
     if (n == 0) return EDYNHIP_OK;
@@ -394,7 +451,28 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
         if (any_cyl)
             hipLaunchKernelGGL(k_debug_collide<true>, dim3((n + 63) / 64), dim3(64), 0, s, n, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
                                (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt));
-        e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, s);
+        bool any_poly = false;
+        for (uint32_t i = 0; i < 2 * n; ++i)
+            if (st[i] == EDYNHIP_SHAPE_POLYHEDRON) {
+                any_poly = true;
+                const float id = sp[4 * i];
+                if (!(id >= 0) || id >= (float)c->host_meshes.desc.size()) { (void)hipStreamSynchronize(s); (void)hipFree(d); return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_debug_collide: unknown mesh id"); }
+            }
+        if (any_poly) {
+            uint32_t stride = 0;
+            for (const MeshDesc &md : c->host_meshes.desc) stride = std::max(stride, md.rot_size);
+            const uint32_t chunk = 16384;
+            float4 *scratch = nullptr;
+            e = hipMalloc((void **)&scratch, (size_t)chunk * 2 * stride * sizeof(float4));
+            for (uint32_t first = 0; first < n && e == hipSuccess; first += chunk) {
+                const uint32_t cnt = std::min(chunk, n - first);
+                hipLaunchKernelGGL(k_debug_collide_poly, dim3(cnt), dim3(64), 0, s, first, cnt, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
+                                   (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt), c->meshes, scratch, stride);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (scratch) (void)hipFree(scratch);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(count, d + o_cnt, b_cnt, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -409,6 +487,10 @@ int narrowphase(edynhip_ctx *c) {
     const Staging st{c->np_ra, c->np_rb, c->np_rn, c->np_rnum};
     hipLaunchKernelGGL(k_np_detect, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
     if (c->has_cylinder) hipLaunchKernelGGL(k_np_detect_ext, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
+    if (c->has_polyhedron) {
+        EH_TRY(update_rotated(c));
+        hipLaunchKernelGGL(k_np_detect_poly, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st, c->meshes);
+    }
     hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st, event_sink(c));
     c->points_in_prev = false;
     EH_HIP(c, hipGetLastError());

@@ -28,7 +28,7 @@
 //   * per colour (scenes with joints, or when the resident-grid launch is refused): one launch per colour with one
 //     manifold per lane (k_contact_solve, k_joint_solve, k_pos_contacts, k_pos_joints).
 #include "ctx.hpp"
-#include "dcylinder.hpp"
+#include "dpolyhedron.hpp"
 
 namespace eh {
 using namespace dm;
@@ -2656,7 +2656,7 @@ __global__ void k_pos_flags(uint32_t n, float *isl_err, uint32_t *isl_done) {
 
 // ------------------------------------------------------------------ derived state
 // update_aabbs (update_aabbs.cpp:53-78 -> aabb_util.cpp:42-70) and update_inertias (update_inertias.cpp:12-24) of one body.
-__device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
+__device__ __forceinline__ void derive_body(Bodies &b, uint32_t i, const dc::Meshes &meshes) {
     const uint32_t fl = b.flags[i];
     const uint32_t kind = fl & BF_KIND_MASK;
     if (kind == EDYNHIP_KIND_STATIC || (fl & BF_ASLEEP)) return;   // update_aabbs / update_inertias exclude sleeping bodies
@@ -2695,6 +2695,9 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
     } else if (st == dc::SHAPE_CYLINDER) {   // aabb_util.cpp:72-79
         const box3 bb = dc::cylinder_aabb(dc::cyl_of(b.shape[i]), pos, orn);
         b.amin[i] = to4(bb.mn, 0); b.amax[i] = to4(bb.mx, 0);
+    } else if (st == dc::SHAPE_POLYHEDRON) {   // update_aabbs.cpp:22-32: the point cloud of the rotated mesh, moved to the position
+        const box3 bb = dc::polyhedron_aabb(meshes, b.shape[i], pos, orn);
+        b.amin[i] = to4(bb.mn, 0); b.amax[i] = to4(bb.mx, 0);
     }
     if (kind == EDYNHIP_KIND_DYNAMIC) {   // update_inertias.cpp:12-24
         const m3 il = {from4(B_IL(b, i, 0)), from4(B_IL(b, i, 1)), from4(B_IL(b, i, 2))};
@@ -2706,7 +2709,7 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i) {
 // until now), the derived state (AABB, world inertia), the next step's scratch, and the broadphase's question for the next
 // step - has this body left the slack box its candidate list was built for? (Counters::bp_rebuild, see broadphase.hip.)
 __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt,
-                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint) {
+                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint, dc::Meshes meshes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
         const int t = threadIdx.x;
@@ -2723,7 +2726,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
         used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0;
         const uint32_t fl = b.flags[i];
         if (pslot && is_dynamic(fl)) pos_writeback(b, i, pslot, first_slot);
-        derive_body(b, i);
+        derive_body(b, i, meshes);
         if (cl.count && is_dynamic(fl) && !(fl & BF_REMOVED)) {
             const float4 a = b.amin[i], c = b.amax[i], ra = cl.ref_min[i], rc = cl.ref_max[i];
             const float d = fmaxf(fmaxf(fmaxf(fabsf(a.x - ra.x), fabsf(a.y - ra.y)), fabsf(a.z - ra.z)),
@@ -2734,13 +2737,13 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
     }
     if (__any(moved) && (threadIdx.x & 63) == 0) cnt->bp_rebuild = 1u;
 }
-__global__ void k_refresh_derived(uint32_t n, Bodies b) {
+__global__ void k_refresh_derived(uint32_t n, Bodies b, dc::Meshes meshes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) derive_body(b, i);
+    if (i < n) derive_body(b, i, meshes);
 }
 int refresh_derived(edynhip_ctx *c) {
     if (c->b.n == 0) return EDYNHIP_OK;
-    hipLaunchKernelGGL(k_refresh_derived, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b);
+    hipLaunchKernelGGL(k_refresh_derived, dim3((c->b.n + 255) / 256), dim3(256), 0, c->stream, c->b.n, c->b, c->meshes);
     EH_HIP(c, hipGetLastError());
     return EDYNHIP_OK;
 }
@@ -3193,7 +3196,7 @@ int solve(edynhip_ctx *c) {
     }
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt,
-                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max}, c->isl_joint);
+                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max}, c->isl_joint, c->meshes);
     rec(c, 9);
     ++c->step_index;
     EH_HIP(c, hipGetLastError());

@@ -16,7 +16,7 @@ from . import _capi
 from ._capi import EdynHipError, MANIFOLD_DTYPE
 
 KIND_DYNAMIC, KIND_KINEMATIC, KIND_STATIC = 0, 1, 2          # rigidbody_kind
-SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER = 0, 1, 2, 3, 4, 5
+SHAPE_NONE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_PLANE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_POLYHEDRON = 0, 1, 2, 3, 4, 5, 6
 JOINT_POINT, JOINT_HINGE, JOINT_DISTANCE, JOINT_SOFT_DISTANCE, JOINT_CONE, JOINT_CVJOINT, JOINT_GRAVITY, JOINT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 ALL_GROUPS = 2**64 - 1                                       # collision_filter::all_groups
 
@@ -93,6 +93,7 @@ class World:
         self._last_time = 0.0
         self.n = 0
         self.nj = 0
+        self.num_meshes = 0
         self._L = _capi.lib()
 
     # ---- edyn::attach / detach
@@ -116,6 +117,7 @@ class World:
         if not h:
             raise EdynHipError(st.value, self._L.edynhip_last_error(None).decode())
         self._h = C.c_void_p(h)
+        self.num_meshes = 0   # meshes belong to the context
 
     def detach(self):
         if self._h:
@@ -270,6 +272,9 @@ class World:
         n, keep, b = self._body_arrays(scene)
         if self._h is None:
             self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
+        for k, mesh in enumerate(scene.get("meshes") or []):   # polyhedron bodies refer to these by position (shape_param[0])
+            if k >= self.num_meshes:
+                assert self.create_convex_mesh(mesh["vertices"], mesh["indices"], mesh["faces"]) == k
         self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
         self.n = n
         self._upload_joints(joints)
@@ -515,6 +520,31 @@ class World:
         t = _capi.Timings()
         self._check(self._L.edynhip_get_timings(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in _capi.Timings._fields_}
+
+    MESH_FIELDS = ("vertices", "normals", "relevant_normals", "edge_vertices", "edge_normals", "edges", "edge_faces", "relevant_faces",
+                   "relevant_edges", "neighbors_start", "neighbor_indices", "inertia_sums")
+
+    def create_convex_mesh(self, vertices, indices, faces):
+        """polyhedron_shape's convex_mesh (convex_mesh.hpp:17-70) + initialize(): vertices [nv, 3], the faces' vertex indices and
+        faces [nf, 2] = (first index, vertex count). Returns the mesh id a SHAPE_POLYHEDRON body puts in shape_param[0]."""
+        if self._h is None:
+            self.attach(self.cfg.max_bodies or 1, self.cfg.max_joints)
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 2)
+        out = C.c_uint32(0)
+        self._check(self._L.edynhip_create_convex_mesh(self._h, len(v), _ptr(v), len(i), _ptr(i), len(f), _ptr(f), C.byref(out)))
+        self.num_meshes = int(out.value) + 1
+        return int(out.value)
+
+    def get_convex_mesh(self, mesh_id, field):
+        """One derived array of a mesh (MESH_FIELDS): float fields [count, 3], index fields uint32."""
+        what = self.MESH_FIELDS.index(field)
+        n = C.c_uint32(0)
+        self._check(self._L.edynhip_get_convex_mesh(self._h, mesh_id, what, None, 0, C.byref(n)))
+        out = np.zeros(7, np.float32) if what == 11 else (np.zeros((n.value, 3), np.float32) if what < 5 else np.zeros(n.value, np.uint32))
+        self._check(self._L.edynhip_get_convex_mesh(self._h, mesh_id, what, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def measure_bandwidth(self, nbytes=1 << 30):
         """(read GB/s, copy GB/s) of this GPU: the measured ceilings bench.py prints beside the HBM spec peak."""

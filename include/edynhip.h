@@ -50,7 +50,8 @@ enum { EDYNHIP_KIND_DYNAMIC = 0, EDYNHIP_KIND_KINEMATIC = 1, EDYNHIP_KIND_STATIC
 /* shapes on the hot path; NONE = amorphous body */
 enum { EDYNHIP_SHAPE_NONE = 0, EDYNHIP_SHAPE_BOX = 1, EDYNHIP_SHAPE_SPHERE = 2, EDYNHIP_SHAPE_PLANE = 3,
        EDYNHIP_SHAPE_CAPSULE = 4, /* shape_param = radius, half_length, axis (0 x, 1 y, 2 z): shapes/capsule_shape.hpp:17-30 */
-       EDYNHIP_SHAPE_CYLINDER = 5 /* shape_param = radius, half_length, axis: shapes/cylinder_shape.hpp:22-25 */ };
+       EDYNHIP_SHAPE_CYLINDER = 5, /* shape_param = radius, half_length, axis: shapes/cylinder_shape.hpp:22-25 */
+       EDYNHIP_SHAPE_POLYHEDRON = 6 /* shape_param[0] = id of a mesh made with edynhip_create_convex_mesh: shapes/polyhedron_shape.hpp:11-43 */ };
 enum { EDYNHIP_JOINT_POINT = 0, EDYNHIP_JOINT_HINGE = 1,
        EDYNHIP_JOINT_DISTANCE = 2,       /* distance_constraint.cpp:7-31; params[0] = distance; impulse slot 0 */
        EDYNHIP_JOINT_SOFT_DISTANCE = 3,  /* soft_distance_constraint.cpp:8-62; params = distance, stiffness, damping; slots 0 spring, 1 damping */
@@ -355,6 +356,22 @@ int edynhip_set_joint_warm_start(edynhip_ctx *ctx, const float *impulses24, cons
 int edynhip_set_asleep(edynhip_ctx *ctx, const uint8_t *asleep);
 
 uint32_t edynhip_abi_version(void);
+
+/* polyhedron_shape's convex_mesh (include/edyn/shapes/convex_mesh.hpp:17-70): vertices[num_vertices][3], the faces' vertex indices
+ * (counter-clockwise seen from outside) and faces[num_faces][2] = (first index, vertex count). Does what convex_mesh::initialize does
+ * (src/edyn/shapes/convex_mesh.cpp:10-30): moves the vertices so that the centroid is the origin, derives face normals, unique edges,
+ * vertex adjacency and the relevant (direction-unique) faces and edges. The mesh belongs to the context and is shared by every body
+ * whose shape is EDYNHIP_SHAPE_POLYHEDRON with shape_param[0] = *mesh_id (the shared_ptr<convex_mesh> of the reference); meshes are
+ * created before the bodies that use them. Limits: closed mesh of positive volume, at most 32 vertices per face (support polygons
+ * are held in fixed storage on the device). */
+int edynhip_create_convex_mesh(edynhip_ctx *ctx, uint32_t num_vertices, const float *vertices, uint32_t num_indices, const uint32_t *indices,
+                               uint32_t num_faces, const uint32_t *faces, uint32_t *mesh_id);
+/* The derived arrays of a mesh (parity tests; out == NULL returns the element count): float fields [count][3], index fields uint32. */
+enum { EDYNHIP_MESH_VERTICES = 0, EDYNHIP_MESH_NORMALS = 1, EDYNHIP_MESH_RELEVANT_NORMALS = 2, EDYNHIP_MESH_EDGE_VERTICES = 3,
+       EDYNHIP_MESH_EDGE_NORMALS = 4, EDYNHIP_MESH_EDGES = 5, EDYNHIP_MESH_EDGE_FACES = 6, EDYNHIP_MESH_RELEVANT_FACES = 7,
+       EDYNHIP_MESH_RELEVANT_EDGES = 8, EDYNHIP_MESH_NEIGHBORS_START = 9, EDYNHIP_MESH_NEIGHBOR_INDICES = 10,
+       EDYNHIP_MESH_INERTIA_SUMS = 11 /* 7 floats: the face sums of moment_of_inertia_polyhedron (volume, xx, yy, zz, yz, zx, xy) */ };
+int edynhip_get_convex_mesh(edynhip_ctx *ctx, uint32_t mesh_id, int field, void *out, uint32_t capacity, uint32_t *count);
 
 /* Measurement aid for the roofline report (bench.py): streams `bytes` of device memory with 16-byte loads from every CU (read_gbs)
  * and copies them device-to-device (copy_gbs, read + write bytes counted), best of five runs each, on the context's stream.

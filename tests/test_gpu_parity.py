@@ -355,6 +355,91 @@ def test_collide_routines_bit_exact_on_random_pairs(tA, tB):
     assert np.array_equal(gp.view(np.uint32), op.view(np.uint32))
 
 
+def _mesh_world():
+    import meshes
+    lib, rad = meshes.registered()
+    w = edyn_amd.World(edyn_amd.init_config())
+    for k, m in enumerate(lib):
+        assert w.create_convex_mesh(m["vertices"], m["indices"], m["faces"]) == k
+    return w, lib, rad
+
+
+def test_convex_mesh_initialisation_bit_exact():
+    """edynhip_create_convex_mesh (mesh.hip: centroid shift, face normals, unique edges and their faces, vertex adjacency, relevant
+    faces / edges, inertia sums) against the oracle's convex_mesh::initialize, array by array; malformed meshes are rejected."""
+    w, lib, _ = _mesh_world()
+    for k in range(len(lib)):
+        for f in ob.MESH_FIELDS:
+            x, y = w.get_convex_mesh(k, f), ob.mesh_get(k, f)
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), (k, f)
+    m = lib[0]
+    with pytest.raises(edyn_amd.EdynHipError):
+        w.create_convex_mesh(m["vertices"], m["indices"], m["faces"][:-1])        # open: an edge with one face
+    with pytest.raises(edyn_amd.EdynHipError):
+        w.create_convex_mesh(m["vertices"], m["indices"][::-1].copy(), m["faces"])   # inside out: negative volume
+    assert w.create_convex_mesh(m["vertices"], m["indices"], m["faces"]) == len(lib)   # the rejected ones left no trace
+    sc = scenes.box_pile(1, 1, 1)
+    sc["shape_type"][1] = scenes.SHAPE_POLYHEDRON; sc["shape_param"][1] = (99, 0, 0, 0)
+    with pytest.raises(edyn_amd.EdynHipError):
+        w.set_scene(sc)
+
+
+@pytest.mark.parametrize("other", [scenes.SHAPE_PLANE, scenes.SHAPE_SPHERE, scenes.SHAPE_POLYHEDRON, scenes.SHAPE_BOX, scenes.SHAPE_CAPSULE,
+                                   scenes.SHAPE_CYLINDER])
+def test_polyhedron_collide_routines_bit_exact_on_random_pairs(other):
+    """100k random pairs per combination and argument order through the device routines of dpolyhedron.hpp (hill-climbing support,
+    support polygons + quickhull in fixed storage, Minkowski-face pruning) and the oracle's, over the ten meshes of tests/meshes.py:
+    counts, pivots, normals, distances, attachments bit for bit - including the parallel-edge polyhedron pairs on which the
+    reference itself is undefined and the oracle's definition is the specification."""
+    w, lib, rad = _mesh_world()
+    P = scenes.SHAPE_POLYHEDRON
+    for tA, tB in ((P, other), (other, P)) if other != P else ((P, P),):
+        rng = np.random.default_rng(1000 + 10 * tA + tB)
+        n = 100_000
+        st, sp, pos, orn = _pair_batch(rng, n, tA, tB, rad)
+        gp, gc = w.debug_collide(st, sp, pos, orn, threshold=0.02)
+        op, oc = ob.collide_batch(st, sp, pos, orn, threshold=0.02)
+        assert np.array_equal(gc, oc)
+        assert (gc > 0).mean() > 0.5
+        assert np.array_equal(gp.view(np.uint32), op.view(np.uint32))
+
+
+def test_polyhedra_bit_exact():
+    """polyhedron_shape on the device: mesh inertia, AABB from the mesh's point cloud, the rotated meshes refreshed
+    before every narrowphase, the six pair routines in k_np_detect_poly - a tumbling heap of polyhedra, cylinders, capsules, boxes and
+    spheres against the oracle: pairs, state, manifolds, AABBs and world inertias; the oracle's polyhedra are pinned to the real engine
+    in tests/test_reference_engine.py. Then bodies appended to the running world, and a state edit between steps."""
+    from test_reference_engine import _polyhedron_scene
+    sc = _polyhedron_scene()
+    g, o = gpu_world(sc), oracle_world(sc)
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        if s % 25 == 0 or s < 3:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+            gd, od = g.get_derived(), o.get_derived()
+            assert np.array_equal(gd[0], od[0]) and np.array_equal(gd[1], od[1]), s   # AABBs, world inertias
+    # turn every body a quarter about x between two steps: the rotated meshes follow the edit
+    p, q, v, wv = g.get_state()
+    r = np.float32([0.70710678, 0, 0, 0.70710678])
+    q2 = np.stack([r[3] * q[:, 0] + r[0] * q[:, 3] + r[1] * q[:, 2] - r[2] * q[:, 1],
+                   r[3] * q[:, 1] - r[0] * q[:, 2] + r[1] * q[:, 3] + r[2] * q[:, 0],
+                   r[3] * q[:, 2] + r[0] * q[:, 1] - r[1] * q[:, 0] + r[2] * q[:, 3],
+                   r[3] * q[:, 3] - r[0] * q[:, 0] - r[1] * q[:, 1] - r[2] * q[:, 2]], axis=1).astype(np.float32)
+    q2 /= np.linalg.norm(q2, axis=1, keepdims=True).astype(np.float32)
+    q2[0] = q[0]
+    p2 = p + np.float32([0, 0.5, 0]); p2[0] = p[0]
+    g.set_state(p2, q2, v, wv); o.set_state(p2, q2, v, wv)
+    g.refresh_derived(); o.refresh_derived()
+    for s in range(1, 101):
+        g.step_simulation(1); o.step(1)
+        if s % 25 == 0 or s < 3:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"after the edit, step {s}")
+
+
 # ------------------------------------------------------------------ bodies appended to a running world
 def _shifted(scene, dy, keep_static=False):
     s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
