@@ -149,7 +149,7 @@ def lib():
         L.edynhip_set_joint_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_measure_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.edynhip_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.edynhip_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_abi_version.restype = C.c_uint32
         _lib = L

@@ -102,7 +102,7 @@ static int allocate(edynhip_ctx *c) {
         EH_TRY(dalloc(c, c->events, c->event_cap)); EH_TRY(dalloc(c, c->event_count, 4)); EH_TRY(dalloc(c, c->prev_matched, M));
     }
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M)); EH_TRY(dalloc(c, c->new_edge_m, M));
-    EH_TRY(dalloc(c, c->rot_off, nb)); EH_HIP(c, hipMemsetAsync(c->rot_off, 0xFF, (size_t)nb * sizeof(uint32_t), c->stream));
+    EH_TRY(dalloc(c, c->isl_top, nb)); EH_TRY(dalloc(c, c->rot_off, nb)); EH_HIP(c, hipMemsetAsync(c->rot_off, 0xFF, (size_t)nb * sizeof(uint32_t), c->stream));
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
@@ -478,8 +478,6 @@ __global__ void k_wake_marked(uint32_t n, Bodies b, uint32_t *wake, double *sinc
 static int index_scratch(edynhip_ctx *c, size_t count, uint32_t *&out) {
     if (count > c->idx_scratch_cap) {
         if (c->idx_scratch) (void)hipFree(c->idx_scratch);
-    for (void *p : c->mesh_allocs) (void)hipFree(p);
-    if (c->rot) (void)hipFree(c->rot);
         c->idx_scratch = nullptr; c->idx_scratch_cap = 0;
         const size_t cap = std::max<size_t>(count * 2, 1024);
         EH_HIP(c, hipMalloc((void **)&c->idx_scratch, cap * sizeof(uint32_t)));
@@ -550,6 +548,8 @@ void edynhip_destroy(edynhip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->idx_scratch) (void)hipFree(c->idx_scratch);
+    for (void *p : c->mesh_allocs) (void)hipFree(p);
+    if (c->rot) (void)hipFree(c->rot);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
     if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
     if (c->state_host) (void)hipHostFree(c->state_host);

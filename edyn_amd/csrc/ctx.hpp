@@ -300,6 +300,7 @@ struct edynhip_ctx {
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
+    uint32_t *isl_top = nullptr;   // per island label: highest colour carried into this step + 1 (k_col_tops; cleared like `used`)
     uint64_t *best[2] = {nullptr, nullptr};
     float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
     float4 *com_store = nullptr, *origin_store = nullptr;   // backing of Bodies::com / origin (attached to `b` once a body has an offset)

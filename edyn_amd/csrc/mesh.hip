@@ -34,7 +34,7 @@ constexpr float kRelevantDirectionTolerance = 0.0006f;   // convex_mesh_relevant
 }  // namespace
 
 // Appends one mesh to the host tables. Returns an error text or nullptr.
-static const char *append_mesh(edynhip_ctx::HostMeshes &t, uint32_t nv, const float *verts, uint32_t nidx, const uint32_t *indices, uint32_t nfaces, const uint32_t *faces) {
+static const char *append_mesh(edynhip_ctx::HostMeshes &t, uint32_t nv, const float *verts, uint32_t nidx, const uint32_t *indices, uint32_t nfaces, const uint32_t *faces, bool centred) {
     if (nv < 4 || nfaces < 4 || !verts || !indices || !faces) return "a convex mesh needs at least 4 vertices and 4 faces";
     for (uint32_t f = 0; f < nfaces; ++f) {
         const uint32_t first = faces[2 * f], count = faces[2 * f + 1];
@@ -45,7 +45,7 @@ static const char *append_mesh(edynhip_ctx::HostMeshes &t, uint32_t nv, const fl
     std::vector<H3> v(nv);
     for (uint32_t i = 0; i < nv; ++i) v[i] = {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
     auto face_vertex = [&](uint32_t f, uint32_t k) { return indices[faces[2 * f] + k]; };
-    {   // shift_to_centroid: mesh_centroid (shape_util.cpp:351-391), then every vertex minus it
+    if (!centred) {   // shift_to_centroid: mesh_centroid (shape_util.cpp:351-391), then every vertex minus it
         H3 center{0, 0, 0};
         float volume = 0;
         for (uint32_t f = 0; f < nfaces; ++f) {
@@ -252,11 +252,11 @@ using namespace eh;
 extern "C" {
 
 int edynhip_create_convex_mesh(edynhip_ctx *c, uint32_t num_vertices, const float *vertices, uint32_t num_indices, const uint32_t *indices,
-                               uint32_t num_faces, const uint32_t *faces, uint32_t *mesh_id) {
-    if (!c || !mesh_id) return EDYNHIP_ERR_INVALID;
+                               uint32_t num_faces, const uint32_t *faces, uint32_t flags, uint32_t *mesh_id) {
+    if (!c || !mesh_id || (flags & ~(uint32_t)EDYNHIP_MESH_INITIALIZED)) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
     edynhip_ctx::HostMeshes trial = c->host_meshes;   // a rejected mesh leaves the tables as they were
-    if (const char *why = append_mesh(trial, num_vertices, vertices, num_indices, indices, num_faces, faces))
+    if (const char *why = append_mesh(trial, num_vertices, vertices, num_indices, indices, num_faces, faces, (flags & EDYNHIP_MESH_INITIALIZED) != 0))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string("edynhip_create_convex_mesh: ") + why).c_str());
     c->host_meshes.swap(trial);
     EH_TRY(upload_meshes(c));

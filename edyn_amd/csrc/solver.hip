@@ -216,11 +216,34 @@ __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ colouring
-// `reinsert` = last step's top colour: its edges are released and first-fit again, so colour classes freed by
-// vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards.
+// In every island the top colour carried over from the last step is released and first-fit again, so colour classes freed by
+// vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards. Per ISLAND, not per
+// world: an island is coloured - and therefore solved - the same way whatever else the world holds, so a shard of the world
+// (edyn_amd/parallel.py) steps exactly like the whole. k_col_tops finds each island's top colour (+ 1), k_col_prepare releases it.
+__device__ __forceinline__ uint32_t manifold_label(uint32_t a, uint32_t b, uint32_t fa, const uint32_t *__restrict__ island) { return island[is_dynamic(fa) ? a : b]; }
+__global__ void k_col_tops(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                           const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint32_t *isl_top) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t label = 0xFFFFFFFFu, top = 0;
+    if (m < M) {
+        const uint32_t in = info[m], np = in & 0xFF, col = in >> 8;
+        const uint32_t a = bA[m], b = bB[m], fa = flags[a], fb = flags[b];
+        if (np > 0 && col != kNoColour && !edge_asleep(fa, fb)) { label = manifold_label(a, b, fa, island); top = col + 1; }
+    }
+    // neighbours in the canonical order mostly share their island: one atomic per wave when they all do
+    const uint32_t first = __shfl(label, __ffsll((long long)__ballot(top != 0)) - 1);
+    if (__all(top == 0 || label == first)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) top = max(top, (uint32_t)__shfl_xor(top, off));
+        // (a plain look first: once the island's top colour has landed, the other waves have nothing to add - a big island would
+        // otherwise serialise thousands of atomics on one address)
+        if ((threadIdx.x & 63) == 0 && top && __atomic_load_n(&isl_top[first], __ATOMIC_RELAXED) < top) atomicMax(&isl_top[first], top);
+    } else if (top && __atomic_load_n(&isl_top[label], __ATOMIC_RELAXED) < top) atomicMax(&isl_top[label], top);
+}
 __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
-                              uint64_t *best0, uint64_t *best1, Counters *cnt, uint32_t reinsert, uint32_t *unc_list) {
+                              uint64_t *best0, uint64_t *best1, Counters *cnt, const uint32_t *__restrict__ island, const uint32_t *__restrict__ isl_top,
+                              uint32_t *unc_list) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t unc = 0;
     if (m < M) {
@@ -230,7 +253,10 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
         const uint32_t fa = flags[a], fb = flags[b];
         // a sleeping manifold is out of the solve but keeps (and blocks) its colour for when its island wakes
         const bool asleep = edge_asleep(fa, fb);
-        if (np > 0 && col == reinsert && !asleep) { col = kNoColour; info[m] = np | (kNoColour << 8); }
+        if (np > 0 && col != kNoColour && !asleep) {
+            const uint32_t top = isl_top[manifold_label(a, b, fa, island)];
+            if (top >= 2 && col + 1 == top) { col = kNoColour; info[m] = np | (kNoColour << 8); }
+        }
         if (np > 0) {
             bool da = is_dynamic(fa), db = is_dynamic(fb);
             if (col != kNoColour) {
@@ -2709,7 +2735,7 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i, const dc::Mes
 // until now), the derived state (AABB, world inertia), the next step's scratch, and the broadphase's question for the next
 // step - has this body left the slack box its candidate list was built for? (Counters::bp_rebuild, see broadphase.hip.)
 __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt,
-                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint, dc::Meshes meshes) {
+                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint, uint32_t *__restrict__ isl_top, dc::Meshes meshes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
         const int t = threadIdx.x;
@@ -2723,7 +2749,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
     // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
     bool moved = false;
     if (i < n) {
-        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0;
+        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0; isl_top[i] = 0;
         const uint32_t fl = b.flags[i];
         if (pslot && is_dynamic(fl)) pos_writeback(b, i, pslot, first_slot);
         derive_body(b, i, meshes);
@@ -2810,11 +2836,12 @@ static int colour_contacts(edynhip_ctx *c) {
     if (M == 0) { c->num_colours = 0; return EDYNHIP_OK; }
     if (!c->full_step) {   // inside edynhip_step: `used` was cleared by the previous k_finish, the counters by k_step_reset
         EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
+        EH_HIP(c, hipMemsetAsync(c->isl_top, 0, (size_t)n * sizeof(uint32_t), s));
         EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }
-    const uint32_t reinsert = c->num_colours >= 2 ? c->num_colours - 1 : kNoColour;
-    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, reinsert, c->col_unc);
+    hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top);
+    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, c->b.island, c->isl_top, c->col_unc);
     uint32_t round = 0, total_rounds = 0;
     auto run_rounds = [&](uint32_t count) {
         for (uint32_t r = 0; r < count; ++r, ++round) {
@@ -3196,7 +3223,7 @@ int solve(edynhip_ctx *c) {
     }
     rec(c, 8);
     hipLaunchKernelGGL(k_finish, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->used, c->m[c->cur ^ 1].seg_start, c->m[c->cur ^ 1].seg_end, c->cnt,
-                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max}, c->isl_joint, c->meshes);
+                       final_pslot, c->rows.first_slot, CandLists{c->bvh.cand_list, c->bvh.cand_count, c->bvh.ref_min, c->bvh.ref_max}, c->isl_joint, c->isl_top, c->meshes);
     rec(c, 9);
     ++c->step_index;
     EH_HIP(c, hipGetLastError());

@@ -95,11 +95,13 @@ def partition_islands(labels, kind, weights, world_size):
     return rank_of
 
 
-def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026):
+def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026, any_owner=False):
     """Cross-shard merge detection ("re-partition only when an island merge crosses shards"): island bounding
     boxes (union of the body AABBs, grown by the manifold separation threshold) of islands owned by DIFFERENT ranks that
     overlap. Returns the list of (label_a, label_b) pairs; empty = the partition is still valid. Conservative: overlapping
-    island boxes do not yet touch, but no contact between two shards can appear without it."""
+    island boxes do not yet touch, but no contact between two shards can appear without it. any_owner = also the pairs that
+    live on ONE rank: what a new partition has to keep together (two islands about to touch that were co-located by the last
+    partition have no manifold between them yet - the partitioner would be free to split them again)."""
     kind = np.asarray(kind); labels = np.asarray(labels); rank_of = np.asarray(rank_of)
     dyn = kind == KIND_DYNAMIC
     isl, inv = np.unique(labels[dyn], return_inverse=True)
@@ -115,7 +117,7 @@ def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026):
     for k in order:
         active = [a for a in active if hi[a, 0] >= lo[k, 0]]
         for a in active:
-            if owner[a] != owner[k] and np.all(lo[a] <= hi[k]) and np.all(lo[k] <= hi[a]):
+            if (any_owner or owner[a] != owner[k]) and np.all(lo[a] <= hi[k]) and np.all(lo[k] <= hi[a]):
                 out.append((int(min(isl[a], isl[k])), int(max(isl[a], isl[k]))))
         active.append(k)
     return sorted(set(out))
@@ -162,7 +164,14 @@ class ShardedWorld:
         self.repartitions = 0
         # conservative reach of every body around its position (no point of the shape is further away), for the per-step approach check
         sp, st = np.asarray(scene["shape_param"], np.float64), np.asarray(scene["shape_type"])
-        self.reach = np.where(st == 1, np.linalg.norm(sp[:, :3], axis=1), np.where(st == 2, sp[:, 0], np.where(st == 4, sp[:, 0] + sp[:, 1], 0.0)))
+        self.reach = np.where(st == 1, np.linalg.norm(sp[:, :3], axis=1), np.where(st == 2, sp[:, 0], np.where(st == 4, sp[:, 0] + sp[:, 1],
+                              np.where(st == 5, np.hypot(sp[:, 0], sp[:, 1]), 0.0))))
+        if (st == 6).any():   # polyhedra: the mesh's diameter bounds the distance from its centroid to any vertex
+            diam = []
+            for m in scene["meshes"]:
+                v = np.asarray(m["vertices"], np.float64)
+                diam.append(float(np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2).max()))
+            self.reach = np.where(st == 6, np.asarray(diam)[np.clip(sp[:, 0].astype(np.int64), 0, len(diam) - 1)], self.reach)
         if "center_of_mass" in scene:
             self.reach = self.reach + np.linalg.norm(np.asarray(scene["center_of_mass"], np.float64), axis=1)
         self.part_labels = np.asarray(labels).copy()
@@ -273,7 +282,9 @@ class ShardedWorld:
         close = island_boxes_overlap(aabb, labels, self.kind, self.rank_of)
         if not close and not force:
             return False
-        # islands whose boxes overlap must end up on one rank: weld them for the partitioner
+        # islands whose boxes overlap must end up on one rank: weld them for the partitioner - all of them, also the pairs an earlier
+        # partition already co-located (they may still be separate islands)
+        close = island_boxes_overlap(aabb, labels, self.kind, self.rank_of, any_owner=True)
         parent = {}
         def find(x):
             while parent.get(x, x) != x:

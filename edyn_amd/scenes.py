@@ -330,6 +330,8 @@ def subset(scene, idx):
     for k, v in scene.items():
         if k in ("joints", "hinge_params", "joint_defs", "exclusions"):
             out[k] = []
+        elif k == "meshes":   # convex meshes are referred to by position (shape_param[0] of a polyhedron): every subset keeps the list
+            out[k] = v
         else:
             out[k] = np.ascontiguousarray(v[idx])
     return out

@@ -524,16 +524,17 @@ class World:
     MESH_FIELDS = ("vertices", "normals", "relevant_normals", "edge_vertices", "edge_normals", "edges", "edge_faces", "relevant_faces",
                    "relevant_edges", "neighbors_start", "neighbor_indices", "inertia_sums")
 
-    def create_convex_mesh(self, vertices, indices, faces):
+    def create_convex_mesh(self, vertices, indices, faces, initialized=False):
         """polyhedron_shape's convex_mesh (convex_mesh.hpp:17-70) + initialize(): vertices [nv, 3], the faces' vertex indices and
-        faces [nf, 2] = (first index, vertex count). Returns the mesh id a SHAPE_POLYHEDRON body puts in shape_param[0]."""
+        faces [nf, 2] = (first index, vertex count); initialized = the vertices are already relative to the centroid (initialize() ran
+        on them). Returns the mesh id a SHAPE_POLYHEDRON body puts in shape_param[0]."""
         if self._h is None:
             self.attach(self.cfg.max_bodies or 1, self.cfg.max_joints)
         v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
         f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 2)
         out = C.c_uint32(0)
-        self._check(self._L.edynhip_create_convex_mesh(self._h, len(v), _ptr(v), len(i), _ptr(i), len(f), _ptr(f), C.byref(out)))
+        self._check(self._L.edynhip_create_convex_mesh(self._h, len(v), _ptr(v), len(i), _ptr(i), len(f), _ptr(f), 1 if initialized else 0, C.byref(out)))
         self.num_meshes = int(out.value) + 1
         return int(out.value)
 

@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -85,7 +86,54 @@ struct plane_shape { vector3 normal; scalar constant; };
 enum class coordinate_axis : unsigned char { x, y, z };                                       // math/coordinate_axis.hpp
 struct capsule_shape { scalar radius; scalar half_length; coordinate_axis axis{coordinate_axis::x}; };   // shapes/capsule_shape.hpp:17-30
 struct cylinder_shape { scalar radius; scalar half_length; coordinate_axis axis{coordinate_axis::x}; };  // shapes/cylinder_shape.hpp:22-25
-using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>;
+/// shapes/convex_mesh.hpp:17-70: vertices, the faces' vertex indices (counter-clockwise seen from outside), faces = (first index, count)
+/// pairs. initialize() moves the vertices so that the centroid is the origin (convex_mesh.cpp:32-38, shape_util.cpp:351-391); face normals,
+/// edges, adjacency and the relevant faces / edges are derived on upload (edynhip_create_convex_mesh) and live with the device context.
+struct convex_mesh {
+    std::vector<vector3> vertices;
+    std::vector<uint32_t> indices, faces;
+    bool initialized{false};
+    size_t num_faces() const { return faces.size() / 2; }
+    void initialize() {
+        if (initialized) return;
+        vector3 c{0, 0, 0};
+        scalar volume = 0;
+        for (size_t f = 0; f < num_faces(); ++f) {
+            const uint32_t first = faces[2 * f], count = faces[2 * f + 1];
+            const vector3 v0 = vertices[indices[first]];
+            for (uint32_t j = 1; j + 1 < count; ++j) {
+                const vector3 v1 = vertices[indices[first + j]], v2 = vertices[indices[first + j + 1]];
+                const vector3 a{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, b{v2.x - v1.x, v2.y - v1.y, v2.z - v1.z};
+                const vector3 n{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+                volume += v0.x * n.x + v0.y * n.y + v0.z * n.z;
+                const vector3 vx{v0.x + v1.x, v1.x + v2.x, v2.x + v0.x}, vy{v0.y + v1.y, v1.y + v2.y, v2.y + v0.y}, vz{v0.z + v1.z, v1.z + v2.z, v2.z + v0.z};
+                c.x += n.x * (vx.x * vx.x + vx.y * vx.y + vx.z * vx.z);
+                c.y += n.y * (vy.x * vy.x + vy.y * vy.y + vy.z * vy.z);
+                c.z += n.z * (vz.x * vz.x + vz.y * vz.y + vz.z * vz.z);
+            }
+        }
+        volume /= 6;
+        const scalar z = scalar(1) / (24 * 2 * volume);
+        c = {c.x * z, c.y * z, c.z * z};
+        for (auto &v : vertices) v = {v.x - c.x, v.y - c.y, v.z - c.z};
+        initialized = true;
+    }
+};
+struct polyhedron_shape {   // shapes/polyhedron_shape.hpp:11-43 (the rotated mesh is the device's business)
+    std::shared_ptr<convex_mesh> mesh;
+    polyhedron_shape() = default;
+    polyhedron_shape(std::shared_ptr<convex_mesh> m) : mesh(std::move(m)) {}
+};
+/// util/shape_util.hpp make_box_mesh (shape_util.cpp:12-38)
+inline void make_box_mesh(const vector3 &he, std::vector<vector3> &vertices, std::vector<uint32_t> &indices, std::vector<uint32_t> &faces) {
+    const scalar x = he.x, y = he.y, z = he.z;
+    const vector3 v[8] = {{-x, -y, -z}, {x, -y, -z}, {x, -y, z}, {-x, -y, z}, {-x, y, -z}, {x, y, -z}, {x, y, z}, {-x, y, z}};
+    vertices.insert(vertices.end(), v, v + 8);
+    const uint32_t idx[24] = {0, 1, 2, 3, 7, 6, 5, 4, 4, 5, 1, 0, 6, 7, 3, 2, 7, 4, 0, 3, 5, 6, 2, 1};
+    indices.insert(indices.end(), idx, idx + 24);
+    for (uint32_t f = 0; f < 6; ++f) { faces.push_back(4 * f); faces.push_back(4); }
+}
+using shapes_variant_t = std::variant<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape, polyhedron_shape>;
 
 enum class rigidbody_kind : uint8_t { rb_dynamic, rb_kinematic, rb_static };   // util/rigidbody.hpp:22-27
 
@@ -220,6 +268,7 @@ struct gpu_stepper {
     struct mixing { uint32_t id0, id1; float v[6]; };
     std::vector<mixing> mixings;   // insert_material_mixing calls, replayed into a (re)created context
     bool refresh_friction{false};  // set_rigidbody_friction: the carried contact points take the bodies' current materials (rigidbody.cpp:324-350)
+    std::vector<std::pair<std::shared_ptr<convex_mesh>, uint32_t>> meshes;   // convex meshes the current device context holds, with their ids
     std::vector<uint32_t> reshaped;   // bodies whose shape / kind changed: their contacts are detected afresh by the re-created context
     bool recreate{false};          // a body's mass / inertia / material was edited: the next upload re-creates the context (contacts, joints and sleep state are carried)
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
@@ -359,6 +408,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.materialize_contacts ? EDYNHIP_FLAG_CONTACT_EVENTS : 0u);
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
+        s.meshes.clear();   // meshes belong to the context
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
         s.params_dirty = false;
@@ -402,6 +452,19 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
         else if (auto *cs = registry.try_get<capsule_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CAPSULE; sp[4 * i] = cs->radius; sp[4 * i + 1] = cs->half_length; sp[4 * i + 2] = (float)(int)cs->axis; }
         else if (auto *cy = registry.try_get<cylinder_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CYLINDER; sp[4 * i] = cy->radius; sp[4 * i + 1] = cy->half_length; sp[4 * i + 2] = (float)(int)cy->axis; }
+        else if (auto *ph = registry.try_get<polyhedron_shape>(e)) {   // the mesh goes up once per context, however many bodies share it
+            uint32_t id = ~0u;
+            for (auto &known : s.meshes) if (known.first == ph->mesh) id = known.second;
+            if (id == ~0u) {
+                const convex_mesh &cm = *ph->mesh;
+                std::vector<float> mv(3 * cm.vertices.size());
+                for (size_t k = 0; k < cm.vertices.size(); ++k) { mv[3 * k] = cm.vertices[k].x; mv[3 * k + 1] = cm.vertices[k].y; mv[3 * k + 2] = cm.vertices[k].z; }
+                check(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)cm.vertices.size(), mv.data(), (uint32_t)cm.indices.size(), cm.indices.data(),
+                                                    (uint32_t)cm.num_faces(), cm.faces.data(), cm.initialized ? EDYNHIP_MESH_INITIALIZED : 0u, &id));
+                s.meshes.emplace_back(ph->mesh, id);
+            }
+            stype[i] = EDYNHIP_SHAPE_POLYHEDRON; sp[4 * i] = (float)id;
+        }
         else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
         else stype[i] = EDYNHIP_SHAPE_NONE;
         if (auto *mt = registry.try_get<material>(e)) {
@@ -991,7 +1054,7 @@ inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<rigidbody_tag>(entity); registry.remove<dynamic_tag>(entity); registry.remove<kinematic_tag>(entity);
     registry.remove<static_tag>(entity); registry.remove<procedural_tag>(entity); registry.remove<sleeping_disabled_tag>(entity);
     registry.remove<sleeping_tag>(entity); registry.remove<collision_filter>(entity); registry.remove<box_shape>(entity);
-    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity); registry.remove<material>(entity);
+    registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity); registry.remove<polyhedron_shape>(entity); registry.remove<material>(entity);
     registry.remove<gravity>(entity); registry.remove<center_of_mass>(entity); registry.remove<origin>(entity); registry.remove<linvel>(entity); registry.remove<angvel>(entity); registry.remove<mass>(entity);
     registry.remove<mass_inv>(entity); registry.remove<inertia>(entity); registry.remove<present_position>(entity);
     registry.remove<present_orientation>(entity); registry.remove<position>(entity); registry.remove<orientation>(entity);
@@ -1051,6 +1114,28 @@ inline matrix3x3 inertia_world_inv_of(entt::registry &registry, entt::entity e) 
             d = {ax == 0 ? xx : yy, ax == 1 ? xx : yy, ax == 2 ? xx : yy};
         }
         I = {{vector3{d.x, 0, 0}, vector3{0, d.y, 0}, vector3{0, 0, d.z}}};
+        if (auto *ph = registry.try_get<polyhedron_shape>(e)) {   // moment_of_inertia_polyhedron (moment_of_inertia.cpp:93-157)
+            const convex_mesh &cm = *ph->mesh;
+            scalar vol = 0, xx = 0, yy = 0, zz = 0, yz = 0, zx = 0, xy = 0;
+            for (size_t f = 0; f < cm.num_faces(); ++f) {
+                const uint32_t first = cm.faces[2 * f], count = cm.faces[2 * f + 1];
+                const vector3 v0 = cm.vertices[cm.indices[first]];
+                for (uint32_t j = 1; j + 1 < count; ++j) {
+                    const vector3 v1 = cm.vertices[cm.indices[first + j]], v2 = cm.vertices[cm.indices[first + j + 1]];
+                    const scalar pd = v0.x * (v1.y * v2.z - v1.z * v2.y) + v0.y * (v1.z * v2.x - v1.x * v2.z) + v0.z * (v1.x * v2.y - v1.y * v2.x);
+                    vol += pd;
+                    const vector3 v3{v0.x + v1.x + v2.x, v0.y + v1.y + v2.y, v0.z + v1.z + v2.z};
+                    xx += pd * (v0.x * v0.x + v1.x * v1.x + v2.x * v2.x + v3.x * v3.x);
+                    yy += pd * (v0.y * v0.y + v1.y * v1.y + v2.y * v2.y + v3.y * v3.y);
+                    zz += pd * (v0.z * v0.z + v1.z * v1.z + v2.z * v2.z + v3.z * v3.z);
+                    yz += pd * (v0.y * v0.z + v1.y * v1.z + v2.y * v2.z + v3.y * v3.z);
+                    zx += pd * (v0.z * v0.x + v1.z * v1.x + v2.z * v2.x + v3.z * v3.x);
+                    xy += pd * (v0.x * v0.y + v1.x * v1.y + v2.x * v2.y + v3.x * v3.y);
+                }
+            }
+            const scalar r = m / (vol / scalar(6)) / scalar(120);
+            I = {{vector3{(yy + zz) * r, xy * r, zx * r}, vector3{xy * r, (zz + xx) * r, yz * r}, vector3{zx * r, yz * r, (xx + yy) * r}}};
+        }
     }
     // inverse_matrix_symmetric (matrix3x3.hpp:190-218)
     const vector3 &r0 = I.row[0], &r1 = I.row[1], &r2 = I.row[2];
@@ -1148,9 +1233,9 @@ inline void set_rigidbody_friction(entt::registry &registry, entt::entity entity
     auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = s.refresh_friction = true;
 }
 /// util/rigidbody.hpp:235-257 (rigidbody.cpp:417-515): another shape / no shape, another kind - through a re-created context like the edits above
-inline bool rigidbody_has_shape(entt::registry &registry, entt::entity entity) { return registry.any_of<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape>(entity); }
+inline bool rigidbody_has_shape(entt::registry &registry, entt::entity entity) { return registry.any_of<box_shape, sphere_shape, plane_shape, capsule_shape, cylinder_shape, polyhedron_shape>(entity); }
 inline void rigidbody_set_shape(entt::registry &registry, entt::entity entity, std::optional<shapes_variant_t> shape_opt) {
-    registry.remove<box_shape>(entity); registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity);
+    registry.remove<box_shape>(entity); registry.remove<sphere_shape>(entity); registry.remove<plane_shape>(entity); registry.remove<capsule_shape>(entity); registry.remove<cylinder_shape>(entity); registry.remove<polyhedron_shape>(entity);
     if (shape_opt) std::visit([&](auto &&sh) { registry.emplace<std::decay_t<decltype(sh)>>(entity, sh); }, *shape_opt);
     auto &s = registry.ctx().get<detail::gpu_stepper>(); s.recreate = s.scene_dirty = true;
     if (auto *bi = registry.try_get<detail::body_index>(entity)) s.reshaped.push_back(bi->value);

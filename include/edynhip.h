@@ -362,10 +362,12 @@ uint32_t edynhip_abi_version(void);
  * (src/edyn/shapes/convex_mesh.cpp:10-30): moves the vertices so that the centroid is the origin, derives face normals, unique edges,
  * vertex adjacency and the relevant (direction-unique) faces and edges. The mesh belongs to the context and is shared by every body
  * whose shape is EDYNHIP_SHAPE_POLYHEDRON with shape_param[0] = *mesh_id (the shared_ptr<convex_mesh> of the reference); meshes are
- * created before the bodies that use them. Limits: closed mesh of positive volume, at most 32 vertices per face (support polygons
- * are held in fixed storage on the device). */
+ * created before the bodies that use them. flags: EDYNHIP_MESH_INITIALIZED = the vertices come from a convex_mesh on which
+ * initialize() already ran (they are relative to the centroid): they are taken as they are and only the derived arrays are built.
+ * Limits: closed mesh of positive volume, at most 32 vertices per face (support polygons are held in fixed storage on the device). */
+enum { EDYNHIP_MESH_INITIALIZED = 1u };
 int edynhip_create_convex_mesh(edynhip_ctx *ctx, uint32_t num_vertices, const float *vertices, uint32_t num_indices, const uint32_t *indices,
-                               uint32_t num_faces, const uint32_t *faces, uint32_t *mesh_id);
+                               uint32_t num_faces, const uint32_t *faces, uint32_t flags, uint32_t *mesh_id);
 /* The derived arrays of a mesh (parity tests; out == NULL returns the element count): float fields [count][3], index fields uint32. */
 enum { EDYNHIP_MESH_VERTICES = 0, EDYNHIP_MESH_NORMALS = 1, EDYNHIP_MESH_RELEVANT_NORMALS = 2, EDYNHIP_MESH_EDGE_VERTICES = 3,
        EDYNHIP_MESH_EDGE_NORMALS = 4, EDYNHIP_MESH_EDGES = 5, EDYNHIP_MESH_EDGE_FACES = 6, EDYNHIP_MESH_RELEVANT_FACES = 7,

@@ -47,6 +47,53 @@ def test_shim_contact_entities_and_asynchronous_mode():
     assert "contacts OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_shim_polyhedra():
+    """convex_mesh / polyhedron_shape / make_box_mesh through the shim - tests/cpp/polyhedra.cpp: meshes shared between bodies, created
+    once per context and again when the context is re-created; polyhedral cubes rest like boxes. The final transforms agree with
+    the same scene driven through the C ABI from Python (where the mesh is initialised by the library and the late bodies are
+    appended instead of the context being re-created: same physics, not the same rounding)."""
+    import numpy as np
+    import edyn_amd
+    from edyn_amd import scenes
+    subprocess.check_call(["make", "-s", "-C", CPP, "polyhedra"])
+    out = subprocess.run([os.path.join(CPP, "polyhedra")], capture_output=True, text=True, timeout=300)
+    assert "POLYHEDRA_OK" in out.stdout, out.stdout + out.stderr
+    got = np.array([[float(x) for x in (ln.split()[3:6] + ln.split()[7:11])] for ln in out.stdout.splitlines() if ln.startswith("body ")], np.float32)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import meshes
+    cube, wedge = meshes.box_mesh((0.5, 0.5, 0.5)), meshes.wedge()
+    P, B, S = scenes.SHAPE_POLYHEDRON, scenes.SHAPE_BOX, scenes.SHAPE_SPHERE
+    first = [(scenes.SHAPE_PLANE, (0, 1, 0, 0), (0, 0, 0))]
+    first += [(P, (0, 0, 0, 0), (0.0, 0.52 + 1.03 * i, 0.0)) for i in range(3)]
+    first += [(B, (0.5, 0.5, 0.5, 0), (3.0, 0.52 + 1.03 * i, 0.0)) for i in range(3)]
+    first += [(P, (1, 0, 0, 0), (-2.0, 0.6, 0.5)), (S, (0.3, 0, 0, 0), (-2.2, 1.4, 0.5)), (P, (1, 0, 0, 0), (0.1, 3.8, 0.05))]
+    later = [(P, (0, 0, 0, 0), (6.0 + 1.2 * (i % 8), 0.6 + 1.1 * (i // 8), 2.0)) for i in range(40)]
+
+    def scene(items, meshes_=None):
+        n = len(items)
+        sc = dict(kind=np.full(n, scenes.KIND_DYNAMIC, np.int32), pos=np.float32([it[2] for it in items]), orn=np.tile(np.float32([0, 0, 0, 1]), (n, 1)),
+                  linvel=np.zeros((n, 3), np.float32), angvel=np.zeros((n, 3), np.float32), mass=np.full(n, 2, np.float32),
+                  shape_type=np.int32([it[0] for it in items]), shape_param=np.float32([it[1] for it in items]),
+                  friction=np.full(n, 0.5, np.float32), restitution=np.zeros(n, np.float32), group=np.full(n, 2**64 - 1, np.uint64),
+                  mask=np.full(n, 2**64 - 1, np.uint64), sleeping_disabled=np.ones(n, np.uint8))
+        sc["kind"][np.int32([it[0] for it in items]) == scenes.SHAPE_PLANE] = scenes.KIND_STATIC
+        if meshes_:
+            sc["meshes"] = meshes_
+        return sc
+
+    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, max_bodies=64))
+    w.set_scene(scene(first, [cube, wedge]))
+    w.step_simulation(120)
+    w.add_scene(scene(later))
+    w.step_simulation(120)
+    pos, orn, _, _ = w.get_state()
+    want = np.concatenate([pos, orn], axis=1)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 0.02, float(np.abs(got - want).max())
+
+
 def _parse_dump(text):
     bodies, joints, excl = [], [], []
     for line in text.splitlines():

@@ -378,6 +378,10 @@ def test_convex_mesh_initialisation_bit_exact():
     with pytest.raises(edyn_amd.EdynHipError):
         w.create_convex_mesh(m["vertices"], m["indices"][::-1].copy(), m["faces"])   # inside out: negative volume
     assert w.create_convex_mesh(m["vertices"], m["indices"], m["faces"]) == len(lib)   # the rejected ones left no trace
+    # EDYNHIP_MESH_INITIALIZED: vertices of a mesh on which initialize() already ran are taken as they are
+    k2 = w.create_convex_mesh(ob.mesh_get(4, "vertices"), lib[4]["indices"], lib[4]["faces"], initialized=True)
+    for f in w.MESH_FIELDS:
+        assert np.array_equal(w.get_convex_mesh(k2, f).view(np.uint32), w.get_convex_mesh(4, f).view(np.uint32)), f
     sc = scenes.box_pile(1, 1, 1)
     sc["shape_type"][1] = scenes.SHAPE_POLYHEDRON; sc["shape_param"][1] = (99, 0, 0, 0)
     with pytest.raises(edyn_amd.EdynHipError):

@@ -74,6 +74,23 @@ def _bridge_scene():
     return ext
 
 
+def _poly_bridge_scene():
+    """The bridge scene with every second box a convex polyhedron (meshes of tests/meshes.py; their ids are positions in the scene's
+    mesh list, which every shard keeps whole) and some cylinders: the shards create the meshes in their own worlds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import meshes
+    from edyn_amd import scenes
+    lib, _ = meshes.registered()
+    sc = _bridge_scene()
+    for i in range(1, len(sc["kind"]) - 1):
+        if i % 2 == 0:
+            sc["shape_type"][i] = scenes.SHAPE_POLYHEDRON; sc["shape_param"][i] = (float((i // 2) % 2 * 4), 0, 0, 0)   # the unit cube or the hexagonal prism
+        elif i % 7 == 1:
+            sc["shape_type"][i] = scenes.SHAPE_CYLINDER; sc["shape_param"][i] = (0.5, 0.5, 1.0, 0)
+    sc["meshes"] = lib
+    return sc
+
+
 def _jointed_bridge_scene():
     """The bridge scene plus two pendulum chains (point + hinge joints, one hinge with angle limits, a bump stop and friction
     torque: tracked angle and four optional row slots) hanging from static anchors, and an excluded pair of overlapping spheres:
@@ -126,12 +143,12 @@ def _jointed_worker(rank, world_size, port, steps, out_path, use_gpu):
     dist.destroy_process_group()
 
 
-def _sharded_worker(rank, world_size, port, steps, out_path, use_gpu):
+def _sharded_worker(rank, world_size, port, steps, out_path, use_gpu, poly=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     from edyn_amd.parallel import ShardedWorld
-    scene = _bridge_scene()
+    scene = _poly_bridge_scene() if poly else _bridge_scene()
     if use_gpu:
         import edyn_amd
         def make_world(sc):
@@ -153,8 +170,8 @@ def _sharded_worker(rank, world_size, port, steps, out_path, use_gpu):
     dist.destroy_process_group()
 
 
-def _unsharded_states(steps, use_gpu):
-    scene = _bridge_scene()
+def _unsharded_states(steps, use_gpu, poly=False):
+    scene = _poly_bridge_scene() if poly else _bridge_scene()
     if use_gpu:
         import edyn_amd
         w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10)); w.set_scene(scene)
@@ -204,6 +221,19 @@ def test_sharded_world_repartitions_and_matches_the_unsharded_world(tmp_path):
     assert got["states"].shape == ref.shape
     assert int(got["reparts"]) >= 1, "the rolling sphere must have triggered a re-partition"
     assert got["owners"].min() > 0
+    assert np.array_equal(got["states"], ref)
+
+
+def test_sharded_world_with_polyhedra_matches_the_unsharded_world(tmp_path):
+    """Polyhedra and cylinders in the sharded scene: every shard holds the scene's mesh list (ids are positions in it), the approach check
+    knows their reach, and the re-partitioned trajectory equals the unsharded world bit for bit."""
+    steps = 90
+    out = str(tmp_path / "sharded_poly.npz")
+    port = 29500 + (os.getpid() % 2000) + 23
+    mp.spawn(_sharded_worker, args=(2, port, steps, out, False, True), nprocs=2, join=True)
+    got = np.load(out)
+    ref = _unsharded_states(steps, False, True)
+    assert int(got["reparts"]) >= 1 and got["owners"].min() > 0
     assert np.array_equal(got["states"], ref)
 
 
