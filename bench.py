@@ -76,6 +76,8 @@ WORKLOADS = {
                       shard=lambda first, count: scenes.mini_piles(8, 8, first_site=first, num_sites=count), shard_units=64),
     # the headline pile with 64 rag dolls standing beside it: islands with joints next to a large island without (mixed schedule)
     "pile32k_ragdolls": dict(gen=lambda: _pile_and_ragdolls(), vel=10, pos=3, settle=120, desc="the 32768-box pile beside 64 rag dolls (36 constraints each)"),
+    # every polyhedron pair routine at work: 32768 convex polyhedra (six meshes, random orientations) collapsing into a heap
+    "polyheap32k": dict(gen=lambda: scenes.polyhedron_heap(32, 32, 32), vel=10, pos=3, settle=240, desc="32768 convex polyhedra (cubes, tetrahedra, octahedra, prisms, wedges) in a heap"),
     "chains16k": dict(gen=lambda: scenes.c5_chains(1024, 16), vel=10, pos=3, settle=120, desc="1024 chains x 16 links, hinge + point joints, no contacts (config C5)"),
 }
 

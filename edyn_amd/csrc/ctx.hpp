@@ -298,6 +298,7 @@ struct edynhip_ctx {
     uint32_t prev_num_manifolds = 0;
     uint32_t *col_keys = nullptr, *col_keys_sorted = nullptr;   // colour sort (counting sort, solver.hip k_cs_*)
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
+    uint32_t col_lds_edges = 0;   // listed edges k_col_rounds holds in LDS (set at the first colouring)
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
     uint32_t *isl_top = nullptr;   // per island label: highest colour carried into this step + 1 (k_col_tops; cleared like `used`)

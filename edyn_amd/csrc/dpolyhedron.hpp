@@ -361,6 +361,9 @@ DI void collide_polyhedron_polyhedron(const PolySh &shA, const PolySh &shB, cons
             distance = dist; projectionA = projA; projectionB = projB; sep_axis = dir;
         }
     }
+    // (device only: the separation found so far can only grow with further axes, so a pair already beyond the threshold ends up with no
+    // points whatever the remaining - expensive - axes say: same result as the reference, which tests once after all of them)
+    if (distance > threshold) return;
     float min_edge_dist = -kScalarMax;
     // The reference declares edge_projectionA / edge_projectionB / edge_dir without initialisers (:98-100) and reads them even when no
     // edge pair spanned a Minkowski face (parallel edges only: axis-aligned prisms and boxes) - undefined behaviour that, with the
@@ -468,6 +471,9 @@ DI void collide_polyhedron_box(const PolySh &shA, f3 hB, const Ctx &ctx, CResult
         const float dist = projA - projB;
         if (dist > distance) { distance = dist; projection_poly = projA; sep_axis = dir; }
     }
+    // (device only: the separation found so far can only grow with further axes, so a pair already beyond the threshold ends up with no
+    // points whatever the remaining - expensive - axes say: same result as the reference, which tests once after all of them)
+    if (distance > threshold) return;
     float min_edge_dist = -kScalarMax, edge_projectionA = 0, edge_projectionB = 0;
     f3 edge_dir{0, 0, 0};
     for (int eA = 0; eA < meshA.ne(); ++eA) {
@@ -616,6 +622,7 @@ DI void collide_polyhedron_capsule(const PolySh &shA, const CylSh &shB, const Ct
         const float dist = projA - projB;
         if (dist > distance) { distance = dist; projection_poly = projA; sep_axis = normalA; }
     }
+    if (distance > threshold) return;   // (device only, see collide_polyhedron_polyhedron)
     for (int i = 0; i < meshA.ne(); ++i) {
         const f3 vertexA0 = meshA.edge_vertex(2 * i), vertexA1 = meshA.edge_vertex(2 * i + 1);
         f3 closestA, closestB;
@@ -708,6 +715,7 @@ DI void collide_polyhedron_cylinder(const PolySh &shA, const CylSh &shB, const C
         const float dist = projA - projB;
         if (dist > distance) { distance = dist; projection_poly = projA; sep_axis = dir; }
     }
+    if (distance > threshold) return;   // (device only, see collide_polyhedron_polyhedron)
     for (int k = 0; k < meshA.nre(); ++k) {
         const int edge_idx = meshA.relevant_edge(k);
         const f3 poly_edge = meshA.edge_vertex(2 * edge_idx + 1) - meshA.edge_vertex(2 * edge_idx);
@@ -731,6 +739,7 @@ DI void collide_polyhedron_cylinder(const PolySh &shA, const CylSh &shB, const C
         const float dist = projA - projB;
         if (dist > distance) { distance = dist; projection_poly = projA; sep_axis = dir; }
     }
+    if (distance > threshold) return;   // (device only, see collide_polyhedron_polyhedron)
     for (int i = 0; i < meshA.ne(); ++i) {
         const f3 vertexA0 = meshA.edge_vertex(2 * i), vertexA1 = meshA.edge_vertex(2 * i + 1);
         for (int j = 0; j < 2; ++j) {

@@ -284,58 +284,84 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
     for (int off = 32; off > 0; off >>= 1) unc += __shfl_xor(unc, off);
     if ((threadIdx.x & 63) == 0 && unc) atomicAdd(&cnt->uncoloured, unc);
 }
-// The rounds for a SHORT list of uncoloured edges - the steady state: a few hundred new contacts per step - run in one
-// workgroup with workgroup barriers between the phases instead of two launches per round; same rule, same result as
-// k_col_best / k_col_assign. Longer lists are left to those (the host sees cnt->uncoloured != 0).
+// The rounds for a list of uncoloured edges that one workgroup can hold - the steady state: some hundred (a restless heap: some
+// thousand) new contacts per step - run in one workgroup with workgroup barriers between the phases instead of two launches per
+// round; same rule, same result as k_col_best / k_col_assign. The edges' endpoints sit in LDS (index | dynamic << 31), the list is
+// compacted as edges take their colour (a round only visits what is still uncoloured), and the endpoint marks alternate between the
+// two `best` arrays like the multi-block rounds' (a round zeroes the next round's marks while it sets its own). Longer lists, and
+// what is left after max_rounds, go to the multi-block rounds (the host sees cnt->uncoloured != 0).
 __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                                                     const uint32_t *__restrict__ flags, uint64_t *best, uint64_t *used, Counters *cnt,
-                                                     const uint32_t *__restrict__ list, uint32_t max_rounds) {
-    __shared__ uint32_t remaining;
-    const uint32_t n = cnt->unc_count;
-    if (n == 0 || n > kColUncCap) return;
-    if (threadIdx.x == 0) remaining = n;
-    __syncthreads();
-    auto ld = [](const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto ld32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // other waves' stores: not through a stale L1 line
-    for (uint32_t round = 0; round < max_rounds; ++round) {
-        if (remaining == 0) break;
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 1: every endpoint learns its best uncoloured edge
-            const uint32_t m = list[e];
-            if ((ld32(&info[m]) >> 8) != kNoColour) continue;
-            const uint32_t a = bA[m], b = bB[m];
-            const uint64_t pr = edge_prio(m);
-            if (is_dynamic(flags[a])) atomicMax((unsigned long long *)&best[a], pr);
-            if (is_dynamic(flags[b])) atomicMax((unsigned long long *)&best[b], pr);
-        }
-        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
-        uint32_t done = 0;
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 2: edges that are best at both ends take a colour
-            const uint32_t m = list[e];
-            const uint32_t in = ld32(&info[m]);
-            if ((in >> 8) != kNoColour) continue;
-            const uint32_t a = bA[m], b = bB[m];
-            const bool da = is_dynamic(flags[a]), db = is_dynamic(flags[b]);
-            const uint64_t pr = edge_prio(m);
-            if ((da && ld(&best[a]) != pr) || (db && ld(&best[b]) != pr)) continue;
-            const uint64_t busy = (da ? ld(&used[a]) : 0ull) | (db ? ld(&used[b]) : 0ull);
-            const uint64_t avail = ~busy & ((1ull << kSerialColour) - 1ull);
-            const uint32_t c = avail ? (uint32_t)__ffsll((long long)avail) - 1 : kSerialColour;   // nothing free: the serial bucket
-            info[m] = (in & 0xFF) | (c << 8);
-            if (da) atomicOr((unsigned long long *)&used[a], 1ull << c);
-            if (db) atomicOr((unsigned long long *)&used[b], 1ull << c);
-            ++done;
-        }
-        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 3: clear the marks for the next round
-            const uint32_t m = list[e];
-            const uint32_t a = bA[m], b = bB[m];
-            if (is_dynamic(flags[a])) best[a] = 0;
-            if (is_dynamic(flags[b])) best[b] = 0;
-        }
-        if (done) atomicSub(&remaining, done);
-        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
+                                                     const uint32_t *__restrict__ flags, uint64_t *best0, uint64_t *best1, uint64_t *used, Counters *cnt,
+                                                     uint32_t *list, uint32_t cap, uint32_t max_rounds) {
+    extern __shared__ uint32_t col_lds[];   // ea[cap], eb[cap]
+    uint32_t *ea = col_lds, *eb = col_lds + cap;
+    __shared__ uint32_t live, wr;
+    const uint32_t n0 = cnt->unc_count;
+    if (n0 == 0 || n0 > cap) return;
+    for (uint32_t e = threadIdx.x; e < n0; e += blockDim.x) {
+        const uint32_t m = list[e], a = bA[m], b = bB[m];
+        ea[e] = a | (is_dynamic(flags[a]) ? 0x80000000u : 0u);
+        eb[e] = b | (is_dynamic(flags[b]) ? 0x80000000u : 0u);
     }
-    if (threadIdx.x == 0) cnt->uncoloured = remaining;
+    if (threadIdx.x == 0) live = n0;
+    __syncthreads();
+    auto ld = [](const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // other waves' stores: not through a stale L1 line
+    auto ld32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    uint32_t round = 0;
+    for (; round < max_rounds; ++round) {
+        const uint32_t n = live;
+        if (n == 0) break;
+        uint64_t *cur = (round & 1u) ? best1 : best0, *nxt = (round & 1u) ? best0 : best1;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 1: every endpoint learns its best uncoloured edge
+            const uint64_t pr = edge_prio(list[e]);
+            const uint32_t a = ea[e], b = eb[e];
+            if (a >> 31) { atomicMax((unsigned long long *)&cur[a & 0x7FFFFFFFu], pr); nxt[a & 0x7FFFFFFFu] = 0; }
+            if (b >> 31) { atomicMax((unsigned long long *)&cur[b & 0x7FFFFFFFu], pr); nxt[b & 0x7FFFFFFFu] = 0; }
+        }
+        if (threadIdx.x == 0) wr = 0;
+        __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
+        for (uint32_t base = 0; base < n; base += blockDim.x) {           // phase 2: edges that are best at both ends take a colour, the others stay listed
+            const uint32_t e = base + threadIdx.x;
+            bool keep = false;
+            uint32_t m = 0, a = 0, b = 0;
+            if (e < n) {
+                m = list[e]; a = ea[e]; b = eb[e];
+                const bool da = a >> 31, db = b >> 31;
+                const uint32_t ia = a & 0x7FFFFFFFu, ib = b & 0x7FFFFFFFu;
+                const uint64_t pr = edge_prio(m);
+                if ((da && ld(&cur[ia]) != pr) || (db && ld(&cur[ib]) != pr)) keep = true;
+                else {
+                    const uint64_t busy = (da ? ld(&used[ia]) : 0ull) | (db ? ld(&used[ib]) : 0ull);
+                    const uint64_t avail = ~busy & ((1ull << kSerialColour) - 1ull);
+                    const uint32_t c = avail ? (uint32_t)__ffsll((long long)avail) - 1 : kSerialColour;   // nothing free: the serial bucket
+                    info[m] = (ld32(&info[m]) & 0xFF) | (c << 8);
+                    if (da) atomicOr((unsigned long long *)&used[ia], 1ull << c);
+                    if (db) atomicOr((unsigned long long *)&used[ib], 1ull << c);
+                }
+            }
+            __syncthreads();   // this block of the list has been read: its survivors may now be written over the front of it
+            const uint64_t mask = __ballot(keep);
+            if (mask) {
+                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&wr, (uint32_t)__popcll(mask));
+                at = __shfl(at, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (keep) { list[at] = m; ea[at] = a; eb[at] = b; }
+            }
+        }
+        __threadfence_block(); __syncthreads();
+        if (threadIdx.x == 0) live = wr;
+        __syncthreads();
+    }
+    const uint32_t left = live;
+    if (left) {   // handed to the multi-block rounds, which start from clean marks in both arrays
+        for (uint32_t e = threadIdx.x; e < left; e += blockDim.x) {
+            const uint32_t a = ea[e], b = eb[e];
+            if (a >> 31) { best0[a & 0x7FFFFFFFu] = 0; best1[a & 0x7FFFFFFFu] = 0; }
+            if (b >> 31) { best0[b & 0x7FFFFFFFu] = 0; best1[b & 0x7FFFFFFFu] = 0; }
+        }
+    }
+    if (threadIdx.x == 0) cnt->uncoloured = left;
 }
 __global__ void k_col_best(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                            const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *best_cur,
@@ -2864,7 +2890,18 @@ static int colour_contacts(edynhip_ctx *c) {
     };
     // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
     // could not finish (a long list, or more rounds than it runs) is left to the multi-block rounds below.
-    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), 0, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->used, c->cnt, c->col_unc, 64u);
+    if (c->col_lds_edges == 0) {   // endpoints of the listed edges live in LDS: as many as one workgroup may have (8 bytes each)
+        int max_lds = 0;
+        (void)hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
+        uint32_t edges = std::min<uint32_t>(kColUncCap, max_lds > 2048 ? (uint32_t)(max_lds - 1024) / 8u : 4096u);
+        if (edges * 8u > 48u * 1024u && hipFuncSetAttribute((const void *)k_col_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(edges * 8u)) != hipSuccess) {
+            (void)hipGetLastError();
+            edges = 48u * 1024u / 8u;
+        }
+        c->col_lds_edges = edges;
+    }
+    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
+                       c->col_unc, c->col_lds_edges, 256u);
     EH_TRY(sort_and_fetch());
     if (c->cnt_host->uncoloured != 0) {
         uint32_t batch = 4;

@@ -100,6 +100,55 @@ def box_pile(nx, ny, nz, mixed=False):
     return s
 
 
+def _convex_mesh(verts, face_lists):
+    """(vertices, indices, faces) as edyn::convex_mesh takes them; every face is wound counter-clockwise seen from outside."""
+    v = np.asarray(verts, np.float64)
+    c = v.mean(axis=0)
+    indices, faces = [], []
+    for f in face_lists:
+        p = v[list(f)]
+        f = list(f) if np.dot(np.cross(p[1] - p[0], p[2] - p[1]), p[0] - c) > 0 else list(reversed(f))
+        faces.append((len(indices), len(f))); indices += f
+    return dict(vertices=np.asarray(verts, np.float32), indices=np.asarray(indices, np.uint32), faces=np.asarray(faces, np.uint32))
+
+
+def convex_library():
+    """Six convex meshes of roughly unit size for the polyhedron scenes: the unit cube (the reference's make_box_mesh,
+    shape_util.cpp:12-38), a tetrahedron, an octahedron, a hexagonal and a pentagonal prism, a wedge."""
+    def prism(n, r, h):
+        ang = np.arange(n) * 2 * np.pi / n
+        top = [(r * np.cos(a), h, r * np.sin(a)) for a in ang]; bot = [(r * np.cos(a), -h, r * np.sin(a)) for a in ang]
+        return _convex_mesh(top + bot, [tuple(range(n)), tuple(range(n, 2 * n))] + [(i, (i + 1) % n, n + (i + 1) % n, n + i) for i in range(n)])
+    h = 0.5
+    cube = dict(vertices=np.float32([(-h, -h, -h), (h, -h, -h), (h, -h, h), (-h, -h, h), (-h, h, -h), (h, h, -h), (h, h, h), (-h, h, h)]),
+                indices=np.uint32([0, 1, 2, 3, 7, 6, 5, 4, 4, 5, 1, 0, 6, 7, 3, 2, 7, 4, 0, 3, 5, 6, 2, 1]),
+                faces=np.uint32([(4 * f, 4) for f in range(6)]))
+    tet = _convex_mesh([(h, h, h), (h, -h, -h), (-h, h, -h), (-h, -h, h)], [(0, 1, 2), (0, 3, 1), (0, 2, 3), (1, 3, 2)])
+    octa = _convex_mesh([(0.6, 0, 0), (-0.6, 0, 0), (0, 0.5, 0), (0, -0.5, 0), (0, 0, 0.6), (0, 0, -0.6)],
+                        [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)])
+    wedge = _convex_mesh([(-0.5, -0.3, -0.4), (0.5, -0.3, -0.4), (0.5, -0.3, 0.4), (-0.5, -0.3, 0.4), (-0.5, 0.3, -0.4), (-0.5, 0.3, 0.4)],
+                         [(0, 1, 2, 3), (0, 4, 1), (3, 2, 5), (0, 3, 5, 4), (1, 4, 5, 2)])
+    return [cube, tet, octa, prism(6, 0.5, 0.4), prism(5, 0.45, 0.5), wedge]
+
+
+def polyhedron_heap(nx, ny, nz, pitch=1.3):
+    """A lattice of convex polyhedra (convex_library, cycled through) with pseudo-random orientations, falling into a heap on a
+    static plane: every polyhedron pair routine at work, plus polyhedron-plane."""
+    n = nx * ny * nz + 1
+    s = _empty(n)
+    _add_plane(s)
+    pos, _ = _lattice(nx, ny, nz, pitch_h=pitch, pitch_v=pitch, y0=0.9, brick=False)
+    s["pos"][1:] = pos
+    s["shape_type"][1:] = SHAPE_POLYHEDRON
+    lib = convex_library()
+    s["shape_param"][1:, 0] = np.arange(n - 1) % len(lib)
+    u = splitmix64_uniform(4 * (n - 1), stream=7).reshape(n - 1, 4).astype(np.float64) * 2 - 1
+    q = u / np.linalg.norm(u, axis=1, keepdims=True)
+    s["orn"][1:] = q.astype(np.float32)
+    s["meshes"] = lib
+    return s
+
+
 def pyramid(n):
     """Stable test scene: square pyramid, layer k has (n-k)^2 unit boxes, each resting on four below."""
     pts = []

@@ -206,6 +206,30 @@ def create_mesh(mesh, real=False):
     return f(len(v), v.ctypes.data, len(i), i.ctypes.data, len(fc), fc.ctypes.data)
 
 
+_mesh_ids = ({}, {})   # content -> registry id, for the oracle and for the reference driver
+
+
+def scene_mesh_ids(scene, real=False):
+    """The registry ids of a scene's convex meshes (scene["meshes"], referred to by position in shape_param[0] of its polyhedra):
+    each distinct mesh is registered once per process."""
+    ids = []
+    for m in scene.get("meshes") or []:
+        key = (np.ascontiguousarray(m["vertices"], np.float32).tobytes(), np.ascontiguousarray(m["indices"], np.uint32).tobytes(),
+               np.ascontiguousarray(m["faces"], np.uint32).tobytes())
+        cache = _mesh_ids[1 if real else 0]
+        if key not in cache:
+            cache[key] = create_mesh(m, real)
+        ids.append(cache[key])
+    return ids
+
+
+def _shape_param(scene, i, ids):
+    sp = scene["shape_param"][i]
+    if ids and int(scene["shape_type"][i]) == SHAPE_POLYHEDRON:
+        sp = np.array(sp, np.float32); sp[0] = ids[int(sp[0])]
+    return sp
+
+
 def mesh_get(mesh_id, field, real=False):
     L = ref() if real else lib()
     f = getattr(L, "ref_mesh_get" if real else "orc_mesh_get")
@@ -261,12 +285,13 @@ class World:
         n = len(scene["kind"])
         inertia = scene.get("inertia")
         has_inertia = scene.get("has_inertia")
+        mesh_ids = scene_mesh_ids(scene, real=False)
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
             grav = scene["gravity"][i] if scene.get("gravity") is not None else None
             b = self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
                               scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
-                              scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
+                              _shape_param(scene, i, mesh_ids), I, float(scene["friction"][i]), float(scene["restitution"][i]),
                               True, int(scene["group"][i]), int(scene["mask"][i]), grav)
             if scene.get("com") is not None and np.any(scene["com"][i] != 0):   # rigidbody_def::center_of_mass: `pos` was the origin
                 self.set_center_of_mass(b, scene["com"][i], float(scene["mass"][i]))
@@ -635,6 +660,7 @@ class RefWorld:
         n = len(scene["kind"])
         inertia = scene.get("inertia")
         has_inertia = scene.get("has_inertia")
+        mesh_ids = scene_mesh_ids(scene, real=True)
         for i in range(n):
             I = inertia[i] if (inertia is not None and has_inertia is not None and has_inertia[i]) else None
             grav = scene["gravity"][i] if scene.get("gravity") is not None else None
@@ -642,7 +668,7 @@ class RefWorld:
                 self.next_center_of_mass(scene["com"][i])
             self.add_body(int(scene["kind"][i]), scene["pos"][i], scene["orn"][i], scene["linvel"][i],
                           scene["angvel"][i], float(scene["mass"][i]), int(scene["shape_type"][i]),
-                          scene["shape_param"][i], I, float(scene["friction"][i]), float(scene["restitution"][i]),
+                          _shape_param(scene, i, mesh_ids), I, float(scene["friction"][i]), float(scene["restitution"][i]),
                           True, int(scene["group"][i]), int(scene["mask"][i]), grav, sleeping_disabled)
         for j in scene.get("joints") or []:
             self.add_joint(*j)

@@ -38,4 +38,8 @@ def build_native():
         subprocess.call(["make", "-s", "-j%d" % max(2, os.cpu_count() or 2), "-C", os.path.join(ROOT, "oracle"), "ref"])
     if not os.path.exists(os.path.join(ROOT, "edyn_amd", "libedynhip.so")):
         subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "edyn_amd", "csrc")])
+    # the test meshes take the first ids of the process-wide mesh registries (tests/meshes.py), whatever test runs first
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import meshes
+    meshes.registered()
     yield

@@ -105,9 +105,9 @@ def registered():
     if _registered is None:
         from oracle import binding as ob
         lib = library()
-        for k, m in enumerate(lib):
-            assert ob.create_mesh(m, real=False) == k
-            if ob.ref() is not None:
-                assert ob.create_mesh(m, real=True) == k
+        # (through the binding's content cache, so that scenes carrying these meshes map to the same ids)
+        assert ob.scene_mesh_ids({"meshes": lib}, real=False) == list(range(len(lib))), "register the library before any other mesh"
+        if ob.ref() is not None:
+            assert ob.scene_mesh_ids({"meshes": lib}, real=True) == list(range(len(lib)))
         _registered = (lib, [radii(m) for m in lib])
     return _registered

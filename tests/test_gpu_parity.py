@@ -444,6 +444,23 @@ def test_polyhedra_bit_exact():
             assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"after the edit, step {s}")
 
 
+def test_polyhedron_heap_at_size_bit_exact():
+    """4096 convex polyhedra (edyn_amd.scenes.polyhedron_heap: cubes, tetrahedra, octahedra, prisms, wedges, random orientations)
+    collapsing into a heap: pairs, state, manifolds (points in list order, impulses, colours) and AABBs equal the oracle's bit for bit
+    after 50, 100 and 150 steps - 10k+ polyhedron-polyhedron manifolds through k_np_detect_poly every step."""
+    sc = scenes.polyhedron_heap(16, 16, 16)
+    g, o = gpu_world(sc), oracle_world(sc)
+    for s in range(1, 151):
+        g.step_simulation(1); o.step(1)
+        if s % 50 == 0:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+            assert_state_equal(g, o)
+            gm = g.get_manifolds()
+            assert_manifolds_equal(gm, o.get_manifolds(), what=f"step {s}")
+            assert np.array_equal(g.get_derived()[0], o.get_derived()[0]), s
+    assert (gm["num_points"] > 0).sum() > 8000 and np.isfinite(g.get_state()[0]).all()
+
+
 # ------------------------------------------------------------------ bodies appended to a running world
 def _shifted(scene, dy, keep_static=False):
     s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}

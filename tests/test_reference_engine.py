@@ -705,6 +705,12 @@ def test_polyhedra_whole_steps_bit_exact_against_the_real_engine():
     _lockstep(_polyhedron_scene(), 300, 10)
 
 
+def test_polyhedron_heap_whole_steps_bit_exact_against_the_real_engine():
+    """The product's own polyhedron scene (edyn_amd.scenes.polyhedron_heap, 256 bodies: the six meshes of convex_library in random
+    orientations falling into a heap) stays bit-identical to the real engine for 250 steps."""
+    _lockstep(scenes.polyhedron_heap(8, 4, 8), 250, 10)
+
+
 def test_capsule_rolling_friction_uses_the_roll_direction():
     """contact_extras rolling rows of bodies with a roll_direction (dynamic capsules: their axis, shapes.hpp:136-139): the
     tangent axes are scaled by the projection of the rolling direction (contact_extras_constraint.cpp:44-55)."""
