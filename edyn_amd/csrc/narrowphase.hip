@@ -115,7 +115,8 @@ k_np_detect_ext(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
 }
 
 // The same for the manifolds that involve a polyhedron (dpolyhedron.hpp), in worlds that have one; k_update_rotated ran before.
-__global__ void __launch_bounds__(64)
+// (more resident waves per SIMD - fewer registers - were measured slower: 4 / 8 / 16 workgroups per CU gave 172 / 169 / 158 steps/s on polyheap32k)
+__global__ void __launch_bounds__(64, 4)
 k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st, Meshes meshes) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;

@@ -221,24 +221,54 @@ __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__
 // world: an island is coloured - and therefore solved - the same way whatever else the world holds, so a shard of the world
 // (edyn_amd/parallel.py) steps exactly like the whole. k_col_tops finds each island's top colour (+ 1), k_col_prepare releases it.
 __device__ __forceinline__ uint32_t manifold_label(uint32_t a, uint32_t b, uint32_t fa, const uint32_t *__restrict__ island) { return island[is_dynamic(fa) ? a : b]; }
-__global__ void k_col_tops(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                           const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint32_t *isl_top) {
+__global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                                                   const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint32_t *isl_top) {
+    __shared__ uint32_t s_label[16], s_top[16];
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t label = 0xFFFFFFFFu, top = 0;
     if (m < M) {
         const uint32_t in = info[m], np = in & 0xFF, col = in >> 8;
         const uint32_t a = bA[m], b = bB[m], fa = flags[a], fb = flags[b];
         if (np > 0 && col != kNoColour && !edge_asleep(fa, fb)) { label = manifold_label(a, b, fa, island); top = col + 1; }
     }
-    // neighbours in the canonical order mostly share their island: one atomic per wave when they all do
-    const uint32_t first = __shfl(label, __ffsll((long long)__ballot(top != 0)) - 1);
-    if (__all(top == 0 || label == first)) {
+    // Neighbours in the canonical order mostly share their island. A wave of one island hands its maximum to the workgroup, which
+    // issues one atomic per run of equal labels (a big island: one per 1024 manifolds instead of thousands on one address); a wave
+    // that spans islands issues one atomic per island it touches. A plain look comes first: once an island's top colour has landed
+    // the others have nothing to add.
+    auto post = [&](uint32_t l, uint32_t t) { if (__atomic_load_n(&isl_top[l], __ATOMIC_RELAXED) < t) atomicMax(&isl_top[l], t); };
+    uint64_t todo = __ballot(top != 0);
+    uint32_t w_label = 0xFFFFFFFFu, w_top = 0;
+    if (todo) {
+        const uint32_t l0 = __shfl(label, __ffsll((long long)todo) - 1);
+        if (__ballot(top != 0 && label == l0) == todo) {   // one island
+            uint32_t t = top;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) top = max(top, (uint32_t)__shfl_xor(top, off));
-        // (a plain look first: once the island's top colour has landed, the other waves have nothing to add - a big island would
-        // otherwise serialise thousands of atomics on one address)
-        if ((threadIdx.x & 63) == 0 && top && __atomic_load_n(&isl_top[first], __ATOMIC_RELAXED) < top) atomicMax(&isl_top[first], top);
-    } else if (top && __atomic_load_n(&isl_top[label], __ATOMIC_RELAXED) < top) atomicMax(&isl_top[label], top);
+            for (int off = 32; off > 0; off >>= 1) t = max(t, (uint32_t)__shfl_xor(t, off));
+            w_label = l0; w_top = t;
+        } else {
+            while (todo) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1, l = __shfl(label, leader);
+                const bool mine = top != 0 && label == l;
+                uint32_t t = mine ? top : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t = max(t, (uint32_t)__shfl_xor(t, off));
+                if (lane == leader) post(l, t);
+                todo &= ~__ballot(mine);
+            }
+        }
+    }
+    if (lane == 0) { s_label[wave] = w_label; s_top[wave] = w_top; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t l = 0xFFFFFFFFu, t = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (s_top[w] == 0) continue;
+            if (s_label[w] != l) { if (t) post(l, t); l = s_label[w]; t = 0; }
+            t = max(t, s_top[w]);
+        }
+        if (t) post(l, t);
+    }
 }
 __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
@@ -2866,7 +2896,7 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }
-    hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top);
+    hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top);
     hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, c->b.island, c->isl_top, c->col_unc);
     uint32_t round = 0, total_rounds = 0;
     auto run_rounds = [&](uint32_t count) {
