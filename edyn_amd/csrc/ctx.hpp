@@ -301,7 +301,7 @@ struct edynhip_ctx {
     uint32_t col_lds_edges = 0;   // listed edges k_col_rounds holds in LDS (set at the first colouring)
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
-    uint32_t *isl_top = nullptr;   // per island label: highest colour carried into this step + 1 (k_col_tops; cleared like `used`)
+    uint2 *isl_top = nullptr;      // per island label: (highest colour carried into this step + 1, has an edge to colour) - k_col_tops; cleared like `used`
     uint64_t *best[2] = {nullptr, nullptr};
     float *pos_err = nullptr;      // dataflow position solve: [iteration][island label] max error of that iteration (zeroed by k_integrate)
     float4 *com_store = nullptr, *origin_store = nullptr;   // backing of Bodies::com / origin (attached to `b` once a body has an offset)

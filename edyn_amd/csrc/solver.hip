@@ -216,13 +216,15 @@ __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ colouring
-// In every island the top colour carried over from the last step is released and first-fit again, so colour classes freed by
-// vanished contacts are reclaimed and the colour count (= dependent launches per sweep) does not drift upwards. Per ISLAND, not per
-// world: an island is coloured - and therefore solved - the same way whatever else the world holds, so a shard of the world
-// (edyn_amd/parallel.py) steps exactly like the whole. k_col_tops finds each island's top colour (+ 1), k_col_prepare releases it.
+// In every island that has an edge to colour in this step (a new or re-activated contact) the top colour carried over from the last
+// step is released and first-fit again, so colour classes freed by vanished contacts are reclaimed when the island next changes and
+// the colour count (= dependent hops per sweep) does not drift upwards - while an island in which nothing happened keeps its
+// colouring untouched (4096 settled mini-piles: nothing to recolour). Per ISLAND, not per world: an island is coloured - and
+// therefore solved - the same way whatever else the world holds, so a shard of the world (edyn_amd/parallel.py) steps exactly like
+// the whole. k_col_tops finds each island's top colour (+ 1; .x) and whether it has an uncoloured active edge (.y), k_col_prepare releases.
 __device__ __forceinline__ uint32_t manifold_label(uint32_t a, uint32_t b, uint32_t fa, const uint32_t *__restrict__ island) { return island[is_dynamic(fa) ? a : b]; }
 __global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                                                   const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint32_t *isl_top) {
+                                                   const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint2 *isl_top) {
     __shared__ uint32_t s_label[16], s_top[16];
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -230,13 +232,17 @@ __global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *_
     if (m < M) {
         const uint32_t in = info[m], np = in & 0xFF, col = in >> 8;
         const uint32_t a = bA[m], b = bB[m], fa = flags[a], fb = flags[b];
-        if (np > 0 && col != kNoColour && !edge_asleep(fa, fb)) { label = manifold_label(a, b, fa, island); top = col + 1; }
+        if (np > 0 && !edge_asleep(fa, fb)) {
+            const uint32_t l = manifold_label(a, b, fa, island);
+            if (col != kNoColour) { label = l; top = col + 1; }
+            else isl_top[l].y = 1u;   // the island has something to colour in this step (identical plain stores)
+        }
     }
     // Neighbours in the canonical order mostly share their island. A wave of one island hands its maximum to the workgroup, which
     // issues one atomic per run of equal labels (a big island: one per 1024 manifolds instead of thousands on one address); a wave
     // that spans islands issues one atomic per island it touches. A plain look comes first: once an island's top colour has landed
     // the others have nothing to add.
-    auto post = [&](uint32_t l, uint32_t t) { if (__atomic_load_n(&isl_top[l], __ATOMIC_RELAXED) < t) atomicMax(&isl_top[l], t); };
+    auto post = [&](uint32_t l, uint32_t t) { if (__atomic_load_n(&isl_top[l].x, __ATOMIC_RELAXED) < t) atomicMax(&isl_top[l].x, t); };
     uint64_t todo = __ballot(top != 0);
     uint32_t w_label = 0xFFFFFFFFu, w_top = 0;
     if (todo) {
@@ -272,7 +278,7 @@ __global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *_
 }
 __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
-                              uint64_t *best0, uint64_t *best1, Counters *cnt, const uint32_t *__restrict__ island, const uint32_t *__restrict__ isl_top,
+                              uint64_t *best0, uint64_t *best1, Counters *cnt, const uint32_t *__restrict__ island, const uint2 *__restrict__ isl_top,
                               uint32_t *unc_list) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t unc = 0;
@@ -284,8 +290,8 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
         // a sleeping manifold is out of the solve but keeps (and blocks) its colour for when its island wakes
         const bool asleep = edge_asleep(fa, fb);
         if (np > 0 && col != kNoColour && !asleep) {
-            const uint32_t top = isl_top[manifold_label(a, b, fa, island)];
-            if (top >= 2 && col + 1 == top) { col = kNoColour; info[m] = np | (kNoColour << 8); }
+            const uint2 top = isl_top[manifold_label(a, b, fa, island)];
+            if (top.y && top.x >= 2 && col + 1 == top.x) { col = kNoColour; info[m] = np | (kNoColour << 8); }
         }
         if (np > 0) {
             bool da = is_dynamic(fa), db = is_dynamic(fb);
@@ -2355,6 +2361,10 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = !X.proc;                                // read-only bodies: the record is the truth
     bool corrected = false;
+    // The world inertia follows the orientation (position_solver::solve rebuilds it after every correction). Here it is rebuilt -
+    // same operations, same value - just before the next correction that reads it instead of right after the previous one: the
+    // rebuild after a task's last correction would be thrown away (the next task rebuilds from the handed-over orientation).
+    bool iw_stale = false;
     // An island that met the error threshold in an earlier iteration takes no part in this one (island_solver.cpp:350-353):
     // its lanes neither wait for nor publish hand-offs - every consumer of its bodies is in the same island, equally
     // finished - and each body's chain-head slot keeps the transform of the island's last iteration for k_pos_writeback.
@@ -2369,7 +2379,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             if (__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want && __float_as_uint(h2.w) == want) {
                 X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
                 corrected = h2.y != 0.0f;
-                if (corrected) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); }
+                iw_stale = corrected;   // rebuilt from the orientation when (if) a correction needs it
                 got = true;
             }
         }
@@ -2398,6 +2408,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
                     n4[k] = to4(n, n4[k].w);
                     piv[k].w = distance;
                     if (!(distance > -kEps)) {
+                        if (iw_stale) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); iw_stale = false; }
                         const f3 Jl = sideB ? -n : n;
                         const f3 cx = cross(rX, n);
                         const f3 Ja = sideB ? -cx : cx;
@@ -2407,7 +2418,12 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
                         const float em = 1.0f / (a1 + a2 + b1 + b2);
                         const float error = -distance;
                         const float corr = error * 0.2f * em;
-                        pos_apply(X, Jl, Ja, corr);
+                        if (X.proc) {   // pos_apply without its closing inertia rebuild (see iw_stale)
+                            X.pos += X.inv_m * Jl * corr;
+                            const f3 ang = mul(X.iw, Ja) * corr;
+                            X.orn = normalize(X.orn + quaternion_derivative(X.orn, ang));
+                            iw_stale = true;
+                        }
                         applied = applied || X.proc;
                         max_err = fmaxf(fabsf(error), max_err);
                     }
@@ -2791,7 +2807,7 @@ __device__ __forceinline__ void derive_body(Bodies &b, uint32_t i, const dc::Mes
 // until now), the derived state (AABB, world inertia), the next step's scratch, and the broadphase's question for the next
 // step - has this body left the slack box its candidate list was built for? (Counters::bp_rebuild, see broadphase.hip.)
 __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_seg_start, uint32_t *next_seg_end, Counters *cnt,
-                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint, uint32_t *__restrict__ isl_top, dc::Meshes meshes) {
+                         const float4 *__restrict__ pslot, const uint32_t *__restrict__ first_slot, CandLists cl, uint32_t *__restrict__ isl_joint, uint2 *__restrict__ isl_top, dc::Meshes meshes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {   // the next step's counters (what k_step_reset does for a stand-alone stage run)
         const int t = threadIdx.x;
@@ -2805,7 +2821,7 @@ __global__ void k_finish(uint32_t n, Bodies b, uint64_t *used, uint32_t *next_se
     // pre-clear the next step's per-body scratch (colour masks, segment index of the manifold buffer it will fill)
     bool moved = false;
     if (i < n) {
-        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0; isl_top[i] = 0;
+        used[i] = 0; next_seg_start[i] = 0; next_seg_end[i] = 0; isl_joint[i] = 0; isl_top[i] = make_uint2(0u, 0u);
         const uint32_t fl = b.flags[i];
         if (pslot && is_dynamic(fl)) pos_writeback(b, i, pslot, first_slot);
         derive_body(b, i, meshes);
@@ -2892,7 +2908,7 @@ static int colour_contacts(edynhip_ctx *c) {
     if (M == 0) { c->num_colours = 0; return EDYNHIP_OK; }
     if (!c->full_step) {   // inside edynhip_step: `used` was cleared by the previous k_finish, the counters by k_step_reset
         EH_HIP(c, hipMemsetAsync(c->used, 0, (size_t)n * sizeof(uint64_t), s));
-        EH_HIP(c, hipMemsetAsync(c->isl_top, 0, (size_t)n * sizeof(uint32_t), s));
+        EH_HIP(c, hipMemsetAsync(c->isl_top, 0, (size_t)n * sizeof(uint2), s));
         EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }

@@ -816,20 +816,26 @@ public:
         ms.reserve(manifolds.size());
         for (auto &kv : manifolds) ms.push_back(&kv.second);
         std::vector<uint64_t> used(bodies.size(), 0);
-        // In every island the top colour carried over from the last step is released and first-fit again (keeps the colour count from
-        // drifting up). Per island, not per world: an island is coloured - and therefore solved - the same way whatever else the world
-        // holds, so a shard of the world steps exactly like the whole (edyn_amd/parallel.py).
+        // In every island that has an edge to colour in this step (a new or re-activated contact) the top colour carried over from
+        // the last step is released and first-fit again: colour classes freed by vanished contacts are reclaimed when the island next
+        // changes, so the colour count does not drift up - and an island in which nothing happened keeps its colouring untouched.
+        // Per island, not per world: an island is coloured - and therefore solved - the same way whatever else the world holds, so a
+        // shard of the world steps exactly like the whole (edyn_amd/parallel.py).
         std::vector<uint32_t> top(bodies.size(), 0);   // per island label: its highest carried colour + 1
+        std::vector<uint8_t> changed(bodies.size(), 0);
         auto label_of = [&](const Manifold &m) { return bodies[m.body[0]].procedural() ? island_label[m.body[0]] : island_label[m.body[1]]; };
-        for (Manifold *m : ms)
-            if (!manifold_asleep(*m) && m->num_points > 0 && m->colour != kNoColour) top[label_of(*m)] = std::max(top[label_of(*m)], m->colour + 1);
+        for (Manifold *m : ms) {
+            if (manifold_asleep(*m) || m->num_points == 0) continue;
+            if (m->colour != kNoColour) top[label_of(*m)] = std::max(top[label_of(*m)], m->colour + 1);
+            else changed[label_of(*m)] = 1;
+        }
         for (Manifold *m : ms) {
             if (manifold_asleep(*m)) {   // out of the solve, but it keeps its colour for when the island wakes
                 if (m->colour != kNoColour) for (int s = 0; s < 2; ++s) if (bodies[m->body[s]].procedural()) used[m->body[s]] |= 1ull << m->colour;
                 continue;
             }
             if (m->num_points == 0) { m->colour = kNoColour; continue; }   // inactive edges hold no colour
-            if (m->colour != kNoColour && top[label_of(*m)] >= 2 && m->colour + 1 == top[label_of(*m)]) m->colour = kNoColour;
+            if (m->colour != kNoColour && changed[label_of(*m)] && top[label_of(*m)] >= 2 && m->colour + 1 == top[label_of(*m)]) m->colour = kNoColour;
             if (m->colour != kNoColour) {
                 for (int s = 0; s < 2; ++s) if (bodies[m->body[s]].procedural()) used[m->body[s]] |= 1ull << m->colour;
             }

@@ -14,11 +14,11 @@ for WL in $WLS; do
   W=/tmp/prof_${R}_$WL; rm -rf $W; mkdir -p $W
   # bench.py settles the scene (120 steps) before the warm-up and the timed steps: SETTLE + WARM + STEPS steps are profiled
   SETTLE=120
-  case $WL in islands256k|islands1m) STEPS=60; WARM=10;; *) STEPS=300; WARM=20;; esac
+  case $WL in islands256k|islands1m) STEPS=60; WARM=10;; polyheap32k) STEPS=100; WARM=10; SETTLE=240;; *) STEPS=300; WARM=20;; esac
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --workload $WL --steps $STEPS --warmup $WARM --north-star none --no-cpu-baseline > $OUT/${R}_bench_under_rocprof_$WL.json 2> $W/kt.log )
   case $WL in chains16k|ragdolls1k) KN=k_island_velocity;; *) KN=k_contact_solve;; esac
   python scripts/prof_summary.py $W/kt $((SETTLE + STEPS + WARM)) $KN $STEPS > $OUT/${R}_kernel_stats_$WL.txt
-  case $WL in chains16k|ragdolls1k) continue;; esac   # joint scenes: kernel statistics only (the traffic model is the contact solve's)
+  case $WL in chains16k|ragdolls1k|polyheap32k) continue;; esac   # joint scenes / the polyhedron heap: kernel statistics only (the traffic model is the contact solve's)
   for C in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps 40 --warmup 5 --north-star none --no-cpu-baseline > /dev/null 2> $W/$C.log )
   done
