@@ -550,6 +550,7 @@ void edynhip_destroy(edynhip_ctx *c) {
     if (c->idx_scratch) (void)hipFree(c->idx_scratch);
     for (void *p : c->mesh_allocs) (void)hipFree(p);
     if (c->rot) (void)hipFree(c->rot);
+    if (c->poly_work) (void)hipFree(c->poly_work);
     if (c->cnt_host) (void)hipHostFree(c->cnt_host);
     if (c->cnt_seq) (void)hipHostFree((void *)c->cnt_seq);
     if (c->state_host) (void)hipHostFree(c->state_host);

@@ -349,6 +349,7 @@ struct edynhip_ctx {
     float4 *rot = nullptr; size_t rot_cap = 0, rot_used = 0;   // rotated meshes of the polyhedron bodies
     uint32_t *rot_off = nullptr;             // per body: its slice of `rot` (~0u: none)
     std::vector<uint32_t> host_rot_off;
+    uint32_t *poly_work = nullptr;           // narrowphase.hip PolyBins: bin counters + per-manifold keys + the binned manifold list
     // material mix table, host side: the reference's container (std::map under unordered_pair's comparator) so that lookups behave
     // exactly like its own; ids by body; device buffers are rebuilt on every change (rebuild_mix_table, capi.hip)
     struct MixIdPair { uint32_t first, second; };
