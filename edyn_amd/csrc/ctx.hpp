@@ -334,6 +334,7 @@ struct edynhip_ctx {
     float *state_host = nullptr;   // pinned mirror
     bool sleeping = false;         // EDYNHIP_FLAG_SLEEPING
     bool all_asleep = false;       // the last step left every procedural body asleep and nothing was edited since: steps are no-ops
+    bool solve_begin_done = false; // this step's k_cc_flatten already did k_solve_begin's work (solver.hip islands())
     bool has_generic = false;      // some joint is a generic_constraint (k_prep_generic runs)
     bool has_cylinder = false;     // some body is a cylinder_shape (narrowphase.hip k_np_detect_ext runs)
     // convex meshes and polyhedron bodies (mesh.hip)

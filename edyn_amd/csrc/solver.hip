@@ -141,7 +141,26 @@ __global__ void k_cc_hook_new(const uint2 *__restrict__ edges, const uint32_t *_
     }
     cc_count_marks(marks, cnt);
 }
-__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt, int mode) {
+// The per-body start of the solve (k_solve_begin: gravity, zeroed deltas, hand-off chain heads) - also folded into k_cc_flatten, the
+// per-body kernel that precedes it, when nothing that runs in between reads velocities or sleep flags (no island sleeping, no restitution).
+DI void solve_begin_body(uint32_t i, Bodies &b, float dt, uint32_t *first_slot) {
+    first_slot[i] = 0xFFFFFFFFu;
+    uint32_t fl = b.flags[i];
+    float inv_m = 0;
+    if (is_dynamic(fl)) {
+        inv_m = B_POS(b, i).w;
+        f3 g = from4(b.grav[i]);
+        if (!(g.x == 0 && g.y == 0 && g.z == 0) && !(fl & BF_ASLEEP)) {   // apply_gravity.hpp:13 excludes sleeping bodies
+            f3 v = from4(b.linvel[i]);
+            v += g * dt;
+            b.linvel[i] = to4(v, 0);
+        }
+    }
+    B_DV(b, i) = make_float4(0, 0, 0, inv_m);
+    B_DW(b, i) = make_float4(0, 0, 0, 0);
+}
+template <bool BEGIN>
+__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt, int mode, Bodies b, float dt, uint32_t *first_slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->tree_total = (mode == CC_FULL ? 0u : cnt->tree_total) + cnt->tree_marks;   // the hooks are done (kernel boundary)
     uint32_t root = 0;
@@ -149,6 +168,7 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
         uint32_t r = cc_find(island, i);
         label[i] = r;
         root = (r == i && is_dynamic(flags[i])) ? 1u : 0u;
+        if (BEGIN) solve_begin_body(i, b, dt, first_slot);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) root += __shfl_xor(root, off);
@@ -537,21 +557,7 @@ DI float rel_speed(f3 J0, f3 J1, f3 J2, f3 J3, f3 vA, f3 wA, f3 vB, f3 wB) {
 
 __global__ void k_solve_begin(uint32_t n, Bodies b, float dt, uint32_t *first_slot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    first_slot[i] = 0xFFFFFFFFu;
-    uint32_t fl = b.flags[i];
-    float inv_m = 0;
-    if (is_dynamic(fl)) {
-        inv_m = B_POS(b, i).w;
-        f3 g = from4(b.grav[i]);
-        if (!(g.x == 0 && g.y == 0 && g.z == 0) && !(fl & BF_ASLEEP)) {   // apply_gravity.hpp:13 excludes sleeping bodies
-            f3 v = from4(b.linvel[i]);
-            v += g * dt;
-            b.linvel[i] = to4(v, 0);
-        }
-    }
-    B_DV(b, i) = make_float4(0, 0, 0, inv_m);
-    B_DW(b, i) = make_float4(0, 0, 0, 0);
+    if (i < n) solve_begin_body(i, b, dt, first_slot);
 }
 
 DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, float eff, float rhs, float imp, float mu,
@@ -2868,6 +2874,7 @@ int islands(edynhip_ctx *c) {
     const Manifolds &mf = c->m[c->cur];
     // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
     uint32_t *forest = c->isl_done;
+    c->solve_begin_done = false;
     const uint32_t force = c->force_islands ? 1u : 0u;
     const uint32_t pm = c->prev_num_manifolds;
     c->force_islands = false;
@@ -2881,14 +2888,21 @@ int islands(edynhip_ctx *c) {
     const int mode = force ? CC_FULL : inplace ? CC_SKIP
                      : (c->full_step && c->cnt_host->tree_found == c->cnt_host->tree_total) ? CC_INCREMENTAL : CC_FULL;
     (void)pm;
+    // the solve's per-body start rides on the flatten kernel when nothing in between looks at velocities or sleep flags
+    const bool begin = c->full_step && !c->sleeping && !c->has_restitution;
+    auto flatten = [&](uint32_t *forest_or_labels) {
+        if (begin) hipLaunchKernelGGL(k_cc_flatten<true>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot);
+        else hipLaunchKernelGGL(k_cc_flatten<false>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot);
+        c->solve_begin_done = begin;
+    };
     if (mode == CC_FULL) {
         hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->cnt, mf, M, c->b.flags);
         if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest);
         if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt);
-        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest, c->b.island, c->cnt, mode);
+        flatten(forest);
     } else if (mode == CC_INCREMENTAL) {   // the labels themselves are the forest (roots = lowest index: depth 1)
         hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->new_edge_m, mf.tree, c->b.flags, c->b.island, c->cnt);
-        hipLaunchKernelGGL(k_cc_flatten, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, c->b.island, c->b.island, c->cnt, mode);
+        flatten(c->b.island);
     }
     if (c->sleeping) {
         hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
@@ -2994,7 +3008,8 @@ int solve(edynhip_ctx *c) {
     rec(c, 3);
     EH_TRY(restitution(c));   // solve_restitution comes first in solver::update (solver.cpp:397); a no-op without bouncy materials
     // gravity / zeroed deltas do not depend on the colouring: enqueued first, they run while the host waits for the counters
-    hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
+    if (!c->solve_begin_done) hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
+    c->solve_begin_done = false;
     EH_TRY(colour_contacts(c));
     // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
     c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
