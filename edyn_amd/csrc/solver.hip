@@ -159,13 +159,26 @@ DI void solve_begin_body(uint32_t i, Bodies &b, float dt, uint32_t *first_slot) 
     B_DV(b, i) = make_float4(0, 0, 0, inv_m);
     B_DW(b, i) = make_float4(0, 0, 0, 0);
 }
+enum { SL_FAST = 1, SL_DISABLED = 2, SL_HAS_ASLEEP = 4, SL_HAS_AWAKE = 8, SL_WAKE = 16, SL_SPLIT = 32 };   // island state bits (k_sleep_*)
+enum { SLA_KEEP = 0, SLA_AWAKE = 1, SLA_SLEEP = 2 };
+// split_state (island sleeping, full relabel only): a body whose root differs from the root of last step's root of its island is a
+// part of an island that fell apart - both parts are marked, k_sleep_decide starts their timers again (split_islands,
+// island_manager.cpp:411-447: every part of a split island ends up with an empty sleep_timestamp).
 template <bool BEGIN>
-__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt, int mode, Bodies b, float dt, uint32_t *first_slot) {
+__global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uint32_t *island, uint32_t *label, Counters *cnt, int mode, Bodies b, float dt, uint32_t *first_slot,
+                             uint32_t *split_state) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->tree_total = (mode == CC_FULL ? 0u : cnt->tree_total) + cnt->tree_marks;   // the hooks are done (kernel boundary)
     uint32_t root = 0;
     if (i < n) {
         uint32_t r = cc_find(island, i);
+        if (split_state && is_dynamic(flags[i]) && !(flags[i] & BF_REMOVED)) {
+            const uint32_t o = label[i];   // last step's root of this body's island (a full relabel works on a scratch forest: `label` is still last step's here)
+            if (o < n && is_dynamic(flags[o]) && !(flags[o] & BF_REMOVED)) {
+                const uint32_t ro = cc_find(island, o);
+                if (ro != r) { atomicOr(&split_state[r], (uint32_t)SL_SPLIT); atomicOr(&split_state[ro], (uint32_t)SL_SPLIT); }
+            }
+        }
         label[i] = r;
         root = (r == i && is_dynamic(flags[i])) ? 1u : 0u;
         if (BEGIN) solve_begin_body(i, b, dt, first_slot);
@@ -180,8 +193,6 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
 // bodies into state bits, (2) mark the islands that received a manifold created this step, (3) one lane per island
 // decides - wake (new edge, or sleeping and awake bodies merged), keep sleeping, run / restart the timer, go to sleep
 // once the timer has run for more than island_time_to_sleep (measured on the step time stamps, ctx.hpp sim_clock) - (4) every body applies its island's decision (put_to_sleep zeroes velocities).
-enum { SL_FAST = 1, SL_DISABLED = 2, SL_HAS_ASLEEP = 4, SL_HAS_AWAKE = 8, SL_WAKE = 16 };
-enum { SLA_KEEP = 0, SLA_AWAKE = 1, SLA_SLEEP = 2 };
 __global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -205,6 +216,7 @@ __global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *
     const uint32_t s = state[i];
     state[i] = 0;
     if (!is_dynamic(b.flags[i]) || b.island[i] != i) { since[i] = -1.0; return; }
+    if (s & SL_SPLIT) since[i] = -1.0;   // a part of an island that split: the timer starts again
     const bool wake = (s & SL_WAKE) || ((s & SL_HAS_ASLEEP) && (s & SL_HAS_AWAKE));
     if ((s & SL_HAS_ASLEEP) && !(s & SL_HAS_AWAKE) && !wake) { action[i] = SLA_KEEP; return; }
     uint32_t a = SLA_AWAKE;
@@ -2891,8 +2903,9 @@ int islands(edynhip_ctx *c) {
     // the solve's per-body start rides on the flatten kernel when nothing in between looks at velocities or sleep flags
     const bool begin = c->full_step && !c->sleeping && !c->has_restitution;
     auto flatten = [&](uint32_t *forest_or_labels) {
-        if (begin) hipLaunchKernelGGL(k_cc_flatten<true>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot);
-        else hipLaunchKernelGGL(k_cc_flatten<false>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot);
+        uint32_t *split = (c->sleeping && mode == CC_FULL) ? c->sleep_state : nullptr;
+        if (begin) hipLaunchKernelGGL(k_cc_flatten<true>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot, split);
+        else hipLaunchKernelGGL(k_cc_flatten<false>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot, split);
         c->solve_begin_done = begin;
     };
     if (mode == CC_FULL) {

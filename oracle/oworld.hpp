@@ -275,6 +275,7 @@ public:
     // island_manager.cpp:605-623): sim_clock is the stamp of the step being run; step() advances it by fixed dt, step_timed()
     // by the caller's stretched step_dt (the max_steps_per_update clamp scales the stamps, not the integration dt).
     double sim_clock = 0;   // the island manager's m_last_time: the stamp of the last step whose island update has run
+    std::vector<uint8_t> split_reset_;     // per label: the island is a part of an island that split in this step
     std::vector<double> sleep_since;       // per label: time stamp at which the island first qualified for sleep, < 0 = not counting
     std::vector<uint64_t> new_keys;        // manifolds created by this step's broadphase (they wake their island)
 
@@ -696,6 +697,7 @@ public:
     // ---------------- islands (connected components over procedural bodies) ----------------
     void update_islands() {
         const uint32_t n = (uint32_t)bodies.size();
+        const std::vector<uint32_t> prev_label = island_label;   // last step's partition (split detection below)
         island_label.resize(n);
         for (uint32_t i = 0; i < n; ++i) island_label[i] = i;
         auto find = [&](uint32_t x) {
@@ -716,6 +718,16 @@ public:
             if (bodies[i].procedural() && island_label[i] == i) ++count;
         }
         stats.num_islands = count;
+        // split_islands (island_manager.cpp:411-447): when an island falls apart, the largest component is MOVED into the island entity
+        // - a move assignment of a freshly built `island`, whose sleep_timestamp is empty - and the others become new islands: every part
+        // starts its sleep timer again. (An island that merely merges keeps a timer: island_manager.cpp:297-350 keeps the larger island's;
+        // here the lower label's - the one deviation that is left, oracle/README.md.)
+        split_reset_.assign(n, 0);
+        for (uint32_t i = 0; i < n && i < prev_label.size(); ++i) {
+            if (!bodies[i].procedural() || bodies[i].removed) continue;
+            const uint32_t r = prev_label[i];   // last step's root of this body: a body of the same old island
+            if (r < n && bodies[r].procedural() && !bodies[r].removed && island_label[r] != island_label[i]) { split_reset_[island_label[i]] = 1; split_reset_[island_label[r]] = 1; }
+        }
         if (sleeping) update_sleep();   // island_manager::update: put_islands_to_sleep() still sees the PREVIOUS step's stamp ...
         sim_clock = pending_stamp_;     // ... and only then m_last_time = timestamp (island_manager.cpp:533-539)
     }
@@ -746,6 +758,7 @@ public:
         std::vector<uint8_t> action(n, 0);   // 0 keep, 1 awake, 2 sleep
         for (uint32_t i = 0; i < n; ++i) {
             if (!bodies[i].procedural() || island_label[i] != i) { sleep_since[i] = -1; continue; }
+            if (i < split_reset_.size() && split_reset_[i]) sleep_since[i] = -1;   // a part of an island that split: its timer starts again
             const uint8_t s = st[i];
             const bool wake = (s & WAKE) || ((s & HAS_ASLEEP) && (s & HAS_AWAKE));
             if ((s & HAS_ASLEEP) && !(s & HAS_AWAKE) && !wake) { action[i] = 0; continue; }   // stays asleep

@@ -444,6 +444,22 @@ def test_polyhedra_bit_exact():
             assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"after the edit, step {s}")
 
 
+def test_island_split_restarts_the_sleep_timers():
+    """An island that falls apart while its sleep timer runs: every part starts again (split_islands, island_manager.cpp:411-447;
+    pinned to the real engine in tests/test_reference_engine.py::test_island_split_restarts_the_sleep_timers_like_the_real_engine)."""
+    from test_reference_engine import _drift_apart_scene
+    sc = _drift_apart_scene()
+    g = gpu_world(sc, sleeping=True)
+    o = oracle_world(sc); o.set_sleeping(True)
+    seen = []
+    for s in range(1, 301):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_asleep(), o.get_asleep()), s
+        seen.append(g.get_asleep().tolist())
+    assert_state_equal(g, o)
+    assert seen[199] == [False, False, True] and seen[-1] == [True, True, True]
+
+
 def test_polyhedron_heap_at_size_bit_exact():
     """4096 convex polyhedra (edyn_amd.scenes.polyhedron_heap: cubes, tetrahedra, octahedra, prisms, wedges, random orientations)
     collapsing into a heap: pairs, state, manifolds (points in list order, impulses, colours) and AABBs equal the oracle's bit for bit

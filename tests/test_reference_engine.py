@@ -249,6 +249,31 @@ def test_island_sleeping_matches_the_real_engine(name, make, steps):
     assert ref.get_asleep()[1:].mean() > 0.5
 
 
+def _drift_apart_scene():
+    """Weightless boxes: two whose boxes overlap (one manifold without points: one island) while one drifts away at 0.004 m/s - below the
+    sleep thresholds -, and a third far away. After 1.75 s the manifold is destroyed and the island splits, its sleep timer running."""
+    s = scenes._empty(3)
+    s["kind"][:] = scenes.KIND_DYNAMIC
+    s["shape_type"][:] = scenes.SHAPE_BOX; s["shape_param"][:, :3] = 0.5
+    s["pos"][0] = (0, 0, 0); s["pos"][1] = (1.019, 0, 0); s["pos"][2] = (10, 0, 0)
+    s["linvel"][1] = (0.004, 0, 0)
+    s["gravity"] = np.zeros((3, 3), np.float32)
+    return s
+
+
+def test_island_split_restarts_the_sleep_timers_like_the_real_engine():
+    """split_islands (island_manager.cpp:411-447) move-assigns the largest component into the island entity - a freshly built `island`
+    whose sleep_timestamp is empty - and creates new islands for the rest: every part of a split island starts its 2 s timer again.
+    The far box falls asleep after 2 s, the two parts only 2 s after the split (the split half)."""
+    ref, orc, first_sleep = _lockstep(_drift_apart_scene(), 300, sleeping=True)
+    assert 120 < first_sleep < 125
+    ref2 = ob.RefWorld(vel_iters=10); ref2.add_bodies(_drift_apart_scene(), sleeping_disabled=False)
+    ref2.step(200)
+    assert ref2.get_asleep().tolist() == [False, False, True] and len(ref2.get_manifolds()) == 0
+    ref2.step(60)
+    assert ref2.get_asleep().all()
+
+
 def test_reference_order_is_a_permutation_of_the_canonical_order():
     """ORDER_EXTERNAL only permutes: same multiset of (pair, slot) as the canonical sequence of ORDER_SEQUENTIAL."""
     sc = scenes.box_pile(3, 3, 3)
