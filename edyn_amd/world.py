@@ -94,6 +94,7 @@ class World:
         self.n = 0
         self.nj = 0
         self.num_meshes = 0
+        self._mesh_sig = []   # content hashes of the meshes created through set_scene, in id order
         self._L = _capi.lib()
 
     # ---- edyn::attach / detach
@@ -118,6 +119,7 @@ class World:
             raise EdynHipError(st.value, self._L.edynhip_last_error(None).decode())
         self._h = C.c_void_p(h)
         self.num_meshes = 0   # meshes belong to the context
+        self._mesh_sig = []
 
     def detach(self):
         if self._h:
@@ -272,9 +274,16 @@ class World:
         n, keep, b = self._body_arrays(scene)
         if self._h is None:
             self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
-        for k, mesh in enumerate(scene.get("meshes") or []):   # polyhedron bodies refer to these by position (shape_param[0])
+        # polyhedron bodies refer to the scene's meshes by position (shape_param[0]): the context must hold exactly that list as its
+        # first meshes - a context that holds other meshes is replaced
+        sig = [hash((np.ascontiguousarray(m["vertices"], np.float32).tobytes(), np.ascontiguousarray(m["indices"], np.uint32).tobytes(),
+                     np.ascontiguousarray(m["faces"], np.uint32).tobytes())) for m in scene.get("meshes") or []]
+        if sig and self._mesh_sig[:len(sig)] != sig[:len(self._mesh_sig)]:
+            self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
+        for k, mesh in enumerate(scene.get("meshes") or []):
             if k >= self.num_meshes:
                 assert self.create_convex_mesh(mesh["vertices"], mesh["indices"], mesh["faces"]) == k
+                self._mesh_sig.append(sig[k])
         self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
         self.n = n
         self._upload_joints(joints)
@@ -536,6 +545,8 @@ class World:
         out = C.c_uint32(0)
         self._check(self._L.edynhip_create_convex_mesh(self._h, len(v), _ptr(v), len(i), _ptr(i), len(f), _ptr(f), 1 if initialized else 0, C.byref(out)))
         self.num_meshes = int(out.value) + 1
+        if len(self._mesh_sig) < int(out.value):   # created directly, ahead of a scene's list: no signature to compare with
+            self._mesh_sig += [None] * (int(out.value) - len(self._mesh_sig))
         return int(out.value)
 
     def get_convex_mesh(self, mesh_id, field):
