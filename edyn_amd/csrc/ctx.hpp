@@ -218,7 +218,7 @@ struct LBVH {
 // Device counters / flags block, mirrored to pinned host memory once or twice per step.
 // Broadphase candidate lists (broadphase.hip); k_finish checks them at the end of a step.
 struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };   // ref_min.w = the body's slack
-constexpr uint32_t kListCap = 64;                 // candidates kept per body (broadphase.hip); a body with more walks the tree every step
+constexpr uint32_t kListCap = 128;                // candidates kept per body (broadphase.hip); a body with more walks the tree every step
 constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of a body with more candidates than a list holds
 
 constexpr uint32_t kMaxDfPosIters = 8;   // more position iterations than this run on the per-colour schedule
