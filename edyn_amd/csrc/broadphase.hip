@@ -253,7 +253,6 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
 // owners in ascending order": each lane sorts its few keys in LDS, a scan over the per-owner counts gives the
 // offsets, a compaction kernel writes the list. No global sort (it used to be 7 radix passes, ~150 us per step).
 // swapped = the manifold's body[0] is `other` (the querying body is body[0], broadphase.cpp:151,171).
-constexpr int kOwnCap = 32;   // partners kept in the per-lane list; more go through the sorted fallback path
 constexpr int kBpBlock = 64;  // one wave per workgroup: LDS per block stays small, so many blocks share a CU
 // The lane's own keys all start with the same owner: LDS keeps only the low half, (other << 1 | swapped), 4 bytes a key.
 struct Emit { uint32_t (*mine)[kBpBlock]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; uint32_t tree; };   // tree: kept forest-certificate manifolds

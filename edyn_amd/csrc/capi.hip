@@ -103,7 +103,7 @@ static int allocate(edynhip_ctx *c) {
     }
     EH_TRY(dalloc(c, c->pair_keys, M)); EH_TRY(dalloc(c, c->pair_keys_sorted, M)); EH_TRY(dalloc(c, c->new_edges, M)); EH_TRY(dalloc(c, c->new_edge_m, M));
     EH_TRY(dalloc(c, c->isl_top, nb)); EH_TRY(dalloc(c, c->rot_off, nb)); EH_HIP(c, hipMemsetAsync(c->rot_off, 0xFF, (size_t)nb * sizeof(uint32_t), c->stream));
-    EH_TRY(dalloc(c, c->own_keys, (size_t)nb * 32)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
+    EH_TRY(dalloc(c, c->own_keys, (size_t)nb * kOwnCap)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
     { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }

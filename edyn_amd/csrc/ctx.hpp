@@ -219,6 +219,7 @@ struct LBVH {
 // Broadphase candidate lists (broadphase.hip); k_finish checks them at the end of a step.
 struct CandLists { uint32_t *list; uint32_t *count; float4 *ref_min, *ref_max; };   // ref_min.w = the body's slack
 constexpr uint32_t kListCap = 128;                // candidates kept per body (broadphase.hip); a body with more walks the tree every step
+constexpr int kOwnCap = 64;                       // pair partners an owner keeps in its in-kernel list (broadphase.hip k_bp_pairs); more go through the sorted fallback path
 constexpr uint32_t kListOverflow = 0xFFFFFFFFu;   // cand_count value of a body with more candidates than a list holds
 
 constexpr uint32_t kMaxDfPosIters = 8;   // more position iterations than this run on the per-colour schedule

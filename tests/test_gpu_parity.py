@@ -636,12 +636,12 @@ def test_static_body_with_the_highest_index():
 
 
 def test_owner_with_more_partners_than_the_in_kernel_list():
-    """One wide plate, created last, rests on 49 bricks: it owns more pairs than the per-lane list holds (32), so the
+    """One wide plate, created last, rests on 81 bricks: it owns more pairs than the per-lane list holds (64), so the
     surplus takes the sorted fallback path. Pair sets, manifolds and trajectories must still match the oracle exactly."""
-    s = scenes.box_pile(7, 1, 7)
+    s = scenes.box_pile(9, 1, 9)
     top = float(s["pos"][:, 1].max()) + 0.5
     xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
-    s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(4.1, 0.25, 4.1, 0), mass=20.0)
+    s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(5.2, 0.25, 5.2, 0), mass=30.0)
     g = gpu_world(s); o = oracle_world(s)
     plate = len(s["kind"]) - 1
     most = 0
@@ -652,18 +652,18 @@ def test_owner_with_more_partners_than_the_in_kernel_list():
             assert np.array_equal(a, b), step
         m = g.get_manifolds()
         most = max(most, int(((m["body"] == plate).any(axis=1)).sum()))
-    assert most > 40, most
+    assert most > 70, most
     assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="plate")
 
 
 def test_body_with_more_neighbours_than_a_candidate_list_holds():
-    """The broadphase keeps per-body candidate lists (64 entries) between tree walks; a body with more neighbours inside its
-    list margin walks the tree every step instead. A weightless plate hovering 6 cm above 81 bricks (inside the list margin,
+    """The broadphase keeps per-body candidate lists (128 entries) between tree walks; a body with more neighbours inside its
+    list margin walks the tree every step instead. A weightless plate hovering 6 cm above 169 bricks (inside the list margin,
     outside the 2.6 cm contact margin) is such a body; two boxes land on it and push it slowly down."""
-    s = scenes.box_pile(9, 1, 9)
+    s = scenes.box_pile(13, 1, 13)
     top = float(s["pos"][:, 1].max()) + 0.5
     xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
-    s = _append_body(s, pos=(xc, top + 0.06 + 0.05, zc), shape_param=(5.2, 0.05, 5.2, 0), mass=1000.0)
+    s = _append_body(s, pos=(xc, top + 0.06 + 0.05, zc), shape_param=(7.3, 0.05, 7.3, 0), mass=1000.0)
     plate = len(s["kind"]) - 1
     s = _append_body(s, pos=(xc - 1.0, top + 0.16 + 0.8, zc), shape_param=(0.5, 0.5, 0.5, 0), mass=1.0)
     s = _append_body(s, pos=(xc + 1.5, top + 0.16 + 1.1, zc + 0.7), shape_param=(0.5, 0.5, 0.5, 0), mass=1.0)
