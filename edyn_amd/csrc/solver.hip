@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *_
         if (t) post(l, t);
     }
 }
-__global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
+__global__ void __launch_bounds__(1024) k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                               const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *used,
                               uint64_t *best0, uint64_t *best1, Counters *cnt, const uint32_t *__restrict__ island, const uint2 *__restrict__ isl_top,
                               uint32_t *unc_list) {
@@ -337,20 +337,25 @@ __global__ void k_col_prepare(uint32_t M, uint32_t *__restrict__ info, const uin
             }
         }
     }
-    {   // list the uncoloured edges (one atomic per wave) for k_col_rounds; beyond its capacity only the count matters
-        const uint64_t mask = __ballot(unc != 0);
-        if (mask) {
-            const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&cnt->unc_count, (uint32_t)__popcll(mask));
-            base = __shfl(base, leader);
-            const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (unc && at < kColUncCap) unc_list[at] = m;
-        }
+    // list the uncoloured edges for k_col_rounds (beyond its capacity only the count matters): one pair of atomics per WORKGROUP - a
+    // restless scene has an uncoloured edge in almost every wave, and thousands of atomics on one cache line cost more than the kernel
+    __shared__ uint32_t wcount[16], wbase;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t mask = __ballot(unc != 0);
+    if (lane == 0) wcount[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) total += wcount[w];
+        wbase = total ? atomicAdd(&cnt->unc_count, total) : 0u;
+        if (total) atomicAdd(&cnt->uncoloured, total);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) unc += __shfl_xor(unc, off);
-    if ((threadIdx.x & 63) == 0 && unc) atomicAdd(&cnt->uncoloured, unc);
+    __syncthreads();
+    if (unc) {
+        uint32_t at = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) at += wcount[w];
+        if (at < kColUncCap) unc_list[at] = m;
+    }
 }
 // The rounds for a list of uncoloured edges that one workgroup can hold - the steady state: some hundred (a restless heap: some
 // thousand) new contacts per step - run in one workgroup with workgroup barriers between the phases instead of two launches per
@@ -2940,7 +2945,7 @@ static int colour_contacts(edynhip_ctx *c) {
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }
     hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top);
-    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 256)), dim3(256), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, c->b.island, c->isl_top, c->col_unc);
+    hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, c->b.island, c->isl_top, c->col_unc);
     uint32_t round = 0, total_rounds = 0;
     auto run_rounds = [&](uint32_t count) {
         for (uint32_t r = 0; r < count; ++r, ++round) {
