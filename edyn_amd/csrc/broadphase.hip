@@ -466,6 +466,8 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
                                      Counters *cnt, uint2 *new_edges, uint32_t *new_edge_m, bool copy_points, EventSink ev, uint8_t *prev_matched) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t found = 0;
+    bool is_new = false;
+    uint32_t new_hi = 0, new_lo = 0;
     if (m < M) {
     if (m == 0 && M != pm) cnt->pairs_changed = 1;
     const uint64_t sk = skeys[m];
@@ -484,9 +486,7 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     uint32_t p = find_prev(prev, pm, hi, lo);
     uint32_t info = kNoColour << 8;
     if (p == 0xFFFFFFFFu) {
-        cnt->pairs_changed = 1;
-        const uint32_t slot = atomicAdd(&cnt->num_new, 1u);
-        new_edges[slot] = make_uint2(hi, lo); new_edge_m[slot] = m;
+        is_new = true; new_hi = hi; new_lo = lo;   // listed below, one counter atomic per workgroup
         if (ev.buf) emit_event(ev, EDYNHIP_EVENT_MANIFOLD_CREATED, swapped ? lo : hi, swapped ? hi : lo, 0);
     }
     cur.prev_idx[m] = p;
@@ -507,9 +507,28 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
     }
     cur.info[m] = info;
     }
+    // the new manifolds' list slots and the found count: one atomic each per WORKGROUP (a scene in motion creates thousands of
+    // manifolds per step; one atomic per manifold on one address made this kernel 10x slower there than on the settled pile)
+    __shared__ uint32_t w_new[16], w_found[16], base_new;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t mask = __ballot(is_new);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off);
-    if ((threadIdx.x & 63) == 0 && found) atomicAdd(&cnt->num_found, found);
+    if (lane == 0) { w_new[wave] = (uint32_t)__popcll(mask); w_found[wave] = found; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tn = 0, tf = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { tn += w_new[w]; tf += w_found[w]; }
+        base_new = tn ? atomicAdd(&cnt->num_new, tn) : 0u;
+        if (tn) cnt->pairs_changed = 1;
+        if (tf) atomicAdd(&cnt->num_found, tf);
+    }
+    __syncthreads();
+    if (is_new) {
+        uint32_t slot = base_new + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) slot += w_new[w];
+        new_edges[slot] = make_uint2(new_hi, new_lo); new_edge_m[slot] = m;
+    }
 }
 
 static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
@@ -602,7 +621,7 @@ int broadphase(edynhip_ctx *c) {
         }
         const EventSink ev = event_sink(c);
         if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, !c->full_step, ev, c->prev_matched);
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 512)), dim3(512), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, !c->full_step, ev, c->prev_matched);
         else if (pm != 0) c->force_islands = true;
         if (ev.buf && pm > 0) hipLaunchKernelGGL(k_ev_destroyed, dim3(blocks(pm, 256)), dim3(256), 0, s, pm, prev, c->prev_matched, ev);
     }
