@@ -318,40 +318,65 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // how long the lists live, not whether they are right.)
 constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
                                                   // sleeping is on: it matters only while that body sleeps, see below)
-// The tree walk, only in the steps that rebuild the lists: one lane per body, stackless (ropes), fat query box.
+// The tree walk, only in the steps that rebuild the lists: stackless (ropes), fat query box, kWalkSplit lanes per body - lane s walks the
+// s-th of the subtrees three levels below the root (k_bp_split, with the topology) and stops at that subtree's rope. One lane per body
+// left half of the SIMDs without a wave on a 32k-body scene and made the walk a single chain of ~300 dependent node loads (0.52 ms per
+// step on a heap whose every step rebuilds the lists). The order of a list's entries is arbitrary: the pairs are sorted later.
+constexpr uint32_t kWalkSplit = 8;
+__global__ void k_bp_split(int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, uint32_t *split) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t cur[kWalkSplit], nxt[kWalkSplit];
+    uint32_t nc = 0;
+    if (n > 1) cur[nc++] = 0;   // the root (internal node 0)
+    for (int level = 0; level < 3; ++level) {
+        uint32_t nn = 0;
+        for (uint32_t e = 0; e < nc; ++e) {
+            const uint32_t x = cur[e];
+            if (x < (uint32_t)(n - 1)) { nxt[nn++] = left[x]; nxt[nn++] = right[x]; } else nxt[nn++] = x;
+        }
+        nc = nn;
+        for (uint32_t e = 0; e < nc; ++e) cur[e] = nxt[e];
+    }
+    for (uint32_t e = 0; e < kWalkSplit; ++e) split[e] = e < nc ? cur[e] : kRopeEnd;
+}
 __global__ void __launch_bounds__(256)
 k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
-          const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways, uint32_t force) {
+          const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways, uint32_t force,
+          const uint32_t *__restrict__ split, const uint32_t *__restrict__ rope) {
     if (!(cnt->bp_rebuild | force)) return;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n - 1) visit[k] = 0;   // arm the refit counters for the next refit
-    if (k >= n) return;
-    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-    const float4 a4 = cl.ref_min[i], c4 = cl.ref_max[i];          // written by this step's refit: the current AABB and the slack
-    const box3 q = inset(box3{from4(a4), from4(c4)}, -(kListTest + a4.w));
-    uint32_t *row = cl.list + (size_t)i * kListCap;
-    uint32_t nc = 0;
-    if (n > 1) {
-        uint32_t node = 0;
-        const uint32_t first_leaf = (uint32_t)(n - 1);
-        while (node != kRopeEnd) {   // descend left while the box overlaps, else follow the rope past this subtree
-            const float4 lo4 = nmin[node], hi4 = nmax[node];
-            const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
-            if (hit && node >= first_leaf) {
-                const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
-                if (j < i || (both_ways && j > i)) {
-                    if (nc < kListCap) row[nc] = j < i ? j : (j | kHigherBit);
-                    ++nc;
+    __shared__ uint32_t found[256 / kWalkSplit];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t / (int)kWalkSplit;
+    const uint32_t s = (uint32_t)t % kWalkSplit, kl = threadIdx.x / kWalkSplit;
+    if (s == 0) { found[kl] = 0; if (k < n - 1) visit[k] = 0; }   // (visit: arm the refit counters for the next refit)
+    __syncthreads();
+    uint32_t i = 0;
+    if (k < n) {
+        i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+        const uint32_t start = split[s];
+        if (n > 1 && start != kRopeEnd) {
+            const float4 a4 = cl.ref_min[i], c4 = cl.ref_max[i];          // written by this step's refit: the current AABB and the slack
+            const box3 q = inset(box3{from4(a4), from4(c4)}, -(kListTest + a4.w));
+            uint32_t *row = cl.list + (size_t)i * kListCap;
+            const uint32_t stop = rope[start], first_leaf = (uint32_t)(n - 1);
+            uint32_t node = start;
+            while (node != stop) {   // descend left while the box overlaps, else follow the rope past this subtree
+                const float4 lo4 = nmin[node], hi4 = nmax[node];
+                const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
+                if (hit && node >= first_leaf) {
+                    const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
+                    if (j < i || (both_ways && j > i)) {
+                        const uint32_t at = atomicAdd(&found[kl], 1u);
+                        if (at < kListCap) row[at] = j < i ? j : (j | kHigherBit);
+                    }
                 }
+                node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
             }
-            node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
         }
     }
-    cl.count[i] = nc <= kListCap ? nc : kListOverflow;
+    __syncthreads();
+    if (s == 0 && k < n) cl.count[i] = found[kl] <= kListCap ? found[kl] : kListOverflow;
 }
-
-// Every step: the exact predicates over each body's candidates (or, for a body whose list overflowed, over a fresh tree
-// walk - the check in k_finish forces the refit in that case), then the static / kinematic bodies, then the owner's keys in order.
 constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
@@ -573,6 +598,7 @@ int broadphase(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_bp_build, dim3(blocks(np - 1, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.visit);
         if (np > 1)
             hipLaunchKernelGGL(k_bp_ropes, dim3(blocks(2 * np - 1, 256)), dim3(256), 0, s, (int)np, c->bvh.parent, c->bvh.right, c->bvh.rope);
+        hipLaunchKernelGGL(k_bp_split, dim3(1), dim3(64), 0, s, (int)np, c->bvh.left, c->bvh.right, c->bvh.split);
         }
         // candidate lists: (refit -> walk, both no-ops while the lists are valid) -> exact predicates over the lists.
         // A new topology re-sorts the leaves but the lists are indexed by body, so they survive it; they are rebuilt when a
@@ -587,7 +613,7 @@ int broadphase(edynhip_ctx *c) {
         c->bvh.lists_dirty = false;
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
                            sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
-        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force);
+        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkSplit, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.split, c->bvh.rope);
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));

@@ -93,7 +93,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));
     EH_TRY(dalloc(c, t.parent, (size_t)2 * nb)); EH_TRY(dalloc(c, t.left, nb)); EH_TRY(dalloc(c, t.right, nb));
     EH_TRY(dalloc(c, t.nmin, (size_t)2 * nb)); EH_TRY(dalloc(c, t.nmax, (size_t)2 * nb)); EH_TRY(dalloc(c, t.visit, nb));
-    EH_TRY(dalloc(c, t.np_list, nb)); EH_TRY(dalloc(c, t.rope, (size_t)2 * nb));
+    EH_TRY(dalloc(c, t.np_list, nb)); EH_TRY(dalloc(c, t.rope, (size_t)2 * nb)); EH_TRY(dalloc(c, t.split, 8));
     EH_TRY(dalloc(c, t.cand_list, (size_t)nb * kListCap)); EH_TRY(dalloc(c, t.cand_count, nb)); EH_TRY(dalloc(c, t.ref_min, nb)); EH_TRY(dalloc(c, t.ref_max, nb));
     EH_TRY(dalloc(c, c->np_ra, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rb, (size_t)M * kMaxPts)); EH_TRY(dalloc(c, c->np_rn, (size_t)M * kMaxPts));
     EH_TRY(dalloc(c, c->np_rnum, M));

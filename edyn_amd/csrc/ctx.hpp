@@ -203,6 +203,7 @@ struct LBVH {
     uint32_t *parent = nullptr;     // [2n-1]: internal 0..n-2, leaves n-1..2n-2
     uint32_t *left = nullptr, *right = nullptr;   // internal nodes
     uint32_t *rope = nullptr;       // [2n-1] stackless traversal: the node that follows this subtree in a depth-first walk
+    uint32_t *split = nullptr;      // [8] the subtrees three levels below the root: the walk's lanes per body (broadphase.hip k_bp_split)
     // candidate lists (broadphase.hip "Verlet lists"): per body its possible partners within a fat margin, and the AABBs
     // they were built from; valid until a body strays from its ref box
     uint32_t *cand_list = nullptr, *cand_count = nullptr;
