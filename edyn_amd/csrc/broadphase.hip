@@ -242,9 +242,13 @@ DI bool filter_ok(const Filt &f, uint32_t a, uint32_t b) {
 // the candidates are the short contiguous run of manifolds whose higher body is `hi`.
 DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t lo) {
     if (pm == 0) return 0xFFFFFFFFu;
-    const uint32_t s0 = prev.seg_start[hi], s1 = prev.seg_end[hi];
-    for (uint32_t s = s0; s < s1; ++s)
-        if ((uint32_t)(prev.skey[s] >> 1) == lo) return s;
+    // the owner's segment of the previous array is in ascending order of `other` (the array is sorted by canonical key): binary search
+    uint32_t a = prev.seg_start[hi], b = prev.seg_end[hi];
+    while (a < b) {
+        const uint32_t mid = (a + b) >> 1, o = (uint32_t)(prev.skey[mid] >> 1);
+        if (o == lo) return mid;
+        if (o < lo) a = mid + 1; else b = mid;
+    }
     return 0xFFFFFFFFu;
 }
 // Canonical pair key: (owner << 32 | other) << 1 | swapped. The OWNER is the procedural body whose query reports the
