@@ -259,9 +259,12 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
 // swapped = the manifold's body[0] is `other` (the querying body is body[0], broadphase.cpp:151,171).
 constexpr int kBpBlock = 64;  // one wave per workgroup: LDS per block stays small, so many blocks share a CU
 // The lane's own keys all start with the same owner: LDS keeps only the low half, (other << 1 | swapped), 4 bytes a key.
-struct Emit { uint32_t (*mine)[kBpBlock]; int tx; int n; uint64_t *extra; uint32_t cap; Counters *cnt; uint32_t tree; };   // tree: kept forest-certificate manifolds
+// kPairLanes lanes share an owner (each takes every kPairLanes-th candidate): they append to the owner's list through an LDS counter.
+constexpr int kPairLanes = 4, kOwnersPerBlock = kBpBlock / kPairLanes;
+struct Emit { uint32_t (*mine)[kOwnersPerBlock]; uint32_t *count; int ol; uint64_t *extra; uint32_t cap; Counters *cnt; uint32_t tree; };   // tree: kept forest-certificate manifolds
 DI void emit_pair(uint64_t skey, Emit &e) {
-    if (e.n < kOwnCap) { e.mine[e.n++][e.tx] = (uint32_t)skey; return; }
+    const uint32_t slot = atomicAdd(&e.count[e.ol], 1u);
+    if (slot < (uint32_t)kOwnCap) { e.mine[slot][e.ol] = (uint32_t)skey; return; }
     const uint32_t g = atomicAdd(&e.cnt->num_extra, 1u);   // rare: an owner with more than kOwnCap partners
     if (g < e.cap) e.extra[g] = skey; else e.cnt->pair_overflow = 1;
 }
@@ -381,87 +384,92 @@ k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ n
     __syncthreads();
     if (s == 0 && k < n) cl.count[i] = found[kl] <= kListCap ? found[kl] : kListOverflow;
 }
-constexpr int kCandCap = 40;
 __global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
            const float4 *__restrict__ amin, const float4 *__restrict__ amax, Filt f,
            const uint32_t *__restrict__ np_list, uint32_t num_np, Manifolds prev, uint32_t pm,
            uint64_t *own_keys, uint32_t *own_count, uint64_t *extra, uint32_t cap, Counters *cnt, CandLists cl,
-           const uint32_t *__restrict__ flags, bool sleeping) {
-    __shared__ uint32_t cand[kCandCap][kBpBlock];     // tree-walk path only: candidate bodies per lane, [slot][thread]
-    __shared__ uint32_t mine[kOwnCap][kBpBlock];      // this lane's (= this owner's) pair keys, low halves
-    __shared__ uint32_t tree_kept;                    // forest-certificate manifolds this block's owners keep (Counters::tree_found)
-    const int tx = threadIdx.x;
-    tree_kept = 0;                                    // (one wave per block: every lane stores the same value before any lane adds)
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    Emit em{mine, tx, 0, extra, cap, cnt, 0u};
-    const uint32_t i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-    if (sleeping && (flags[i] & BF_ASLEEP)) {
+           const uint32_t *__restrict__ flags, bool sleeping, const uint32_t *__restrict__ split, const uint32_t *__restrict__ rope) {
+    __shared__ uint32_t mine[kOwnCap][kOwnersPerBlock];   // each owner's pair keys, low halves
+    __shared__ uint32_t mine_n[kOwnersPerBlock];          // ... and how many its lanes have emitted (may exceed kOwnCap: the surplus went to `extra`)
+    __shared__ uint32_t tree_kept;                        // forest-certificate manifolds this block's owners keep (Counters::tree_found)
+    const int tx = threadIdx.x, ol = tx / kPairLanes;
+    const uint32_t s = (uint32_t)(tx % kPairLanes);
+    if (tx < kOwnersPerBlock) mine_n[tx] = 0;
+    if (tx == 0) tree_kept = 0;
+    __syncthreads();
+    const int k = blockIdx.x * kOwnersPerBlock + ol;
+    const bool valid = k < n;
+    const uint32_t i = valid ? (uint32_t)(keys[k] & 0xFFFFFFFFu) : 0u;
+    const bool asleep_owner = valid && sleeping && (flags[i] & BF_ASLEEP);
+    if (asleep_owner) {
         // a sleeping owner keeps its manifolds as they are (destroy_separated_manifolds excludes them): its previous
         // segment is already in ascending order
-        uint32_t c = 0, kept = 0;
-        if (pm) for (uint32_t s = prev.seg_start[i], e = prev.seg_end[i]; s < e; ++s, ++c) {
-            if (c < (uint32_t)kOwnCap) own_keys[(size_t)i * kOwnCap + c] = prev.skey[s];
-            else { const uint32_t g = atomicAdd(&cnt->num_extra, 1u); if (g < cap) extra[g] = prev.skey[s]; else cnt->pair_overflow = 1; }
-            kept += prev.tree[s];
+        if (s == 0) {
+            uint32_t c = 0, kept = 0;
+            if (pm) for (uint32_t p0 = prev.seg_start[i], e = prev.seg_end[i]; p0 < e; ++p0, ++c) {
+                if (c < (uint32_t)kOwnCap) own_keys[(size_t)i * kOwnCap + c] = prev.skey[p0];
+                else { const uint32_t g = atomicAdd(&cnt->num_extra, 1u); if (g < cap) extra[g] = prev.skey[p0]; else cnt->pair_overflow = 1; }
+                kept += prev.tree[p0];
+            }
+            own_count[i] = min(c, (uint32_t)kOwnCap);
+            if (kept) atomicAdd(&cnt->tree_found, kept);   // (sleeping worlds: rare path, no block reduction)
         }
-        own_count[i] = min(c, (uint32_t)kOwnCap);
-        if (kept) atomicAdd(&cnt->tree_found, kept);   // (sleeping worlds: rare path, no block reduction)
-        return;
-    }
-    const box3 bi = body_box(amin, amax, i);
-    const uint32_t lc = cl.count[i];
-    if (lc != kListOverflow) {
-        const uint32_t *row = cl.list + (size_t)i * kListCap;
-        for (uint32_t t = 0; t < lc; ++t) {
-            const uint32_t e = row[t], j = e & ~kHigherBit;
-            if (!(e & kHigherBit)) consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
-            else if (sleeping && (flags[j] & BF_ASLEEP)) consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
-        }
-    } else if (n > 1) {   // more than kListCap bodies around this one: walk the (freshly refitted) tree
-        const box3 q = inset(bi, -kQueryGrow);
-        int nc = 0;
-        uint32_t node = 0;
-        const uint32_t first_leaf = (uint32_t)(n - 1);
-        while (node != kRopeEnd) {
-            const float4 lo4 = nmin[node], hi4 = nmax[node];
-            const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
-            if (hit && node >= first_leaf) {
-                const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
-                if (j < i) {
-                    if (nc < kCandCap) cand[nc++][tx] = j;
-                    else consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
-                } else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) {
-                    consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
+    } else if (valid) {
+        Emit em{mine, mine_n, ol, extra, cap, cnt, 0u};
+        const box3 bi = body_box(amin, amax, i);
+        const uint32_t lc = cl.count[i];
+        if (lc != kListOverflow) {
+            const uint32_t *row = cl.list + (size_t)i * kListCap;
+            for (uint32_t t = s; t < lc; t += kPairLanes) {
+                const uint32_t e = row[t], j = e & ~kHigherBit;
+                if (!(e & kHigherBit)) consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
+                else if (sleeping && (flags[j] & BF_ASLEEP)) consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
+            }
+        } else if (n > 1) {   // more than kListCap bodies around this one: walk the (freshly refitted) tree, a subtree per lane
+            const box3 q = inset(bi, -kQueryGrow);
+            const uint32_t first_leaf = (uint32_t)(n - 1);
+            for (uint32_t sub = s; sub < kWalkSplit; sub += kPairLanes) {
+                const uint32_t start = split[sub];
+                if (start == kRopeEnd) continue;
+                const uint32_t stop = rope[start];
+                uint32_t node = start;
+                while (node != stop) {
+                    const float4 lo4 = nmin[node], hi4 = nmax[node];
+                    const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
+                    if (hit && node >= first_leaf) {
+                        const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
+                        if (j < i) consider_pair(i, j, bi, amin, amax, f, true, prev, pm, em);
+                        else if (sleeping && j > i && (flags[j] & BF_ASLEEP)) consider_sleeping_owner(i, j, bi, amin, amax, f, prev, pm, em);
+                    }
+                    node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
                 }
             }
-            node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
         }
-        for (int t = 0; t < nc; ++t) consider_pair(i, cand[t][tx], bi, amin, amax, f, true, prev, pm, em);
-    }
-    {
-        const box3 q = inset(bi, -kQueryGrow);
-        for (uint32_t t = 0; t < num_np; ++t) {
-            uint32_t j = np_list[t];
-            box3 bj = body_box(amin, amax, j);
-            if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, f, false, prev, pm, em);
+        {
+            const box3 q = inset(bi, -kQueryGrow);
+            for (uint32_t t = s; t < num_np; t += kPairLanes) {
+                uint32_t j = np_list[t];
+                box3 bj = body_box(amin, amax, j);
+                if (intersect(bj, q)) consider_pair(i, j, bi, amin, amax, f, false, prev, pm, em);
+            }
         }
+        if (em.tree) atomicAdd(&tree_kept, em.tree);
     }
-    // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
-    for (int a = 1; a < em.n; ++a) {
-        const uint32_t v = mine[a][tx];
-        int b = a - 1;
-        while (b >= 0 && mine[b][tx] > v) { mine[b + 1][tx] = mine[b][tx]; --b; }
-        mine[b + 1][tx] = v;
+    __syncthreads();
+    if (valid && !asleep_owner && s == 0) {
+        // ascending by `other` (insertion sort: a handful of keys), then out to this owner's slot block
+        const int cnt_i = (int)min(mine_n[ol], (uint32_t)kOwnCap);
+        for (int a = 1; a < cnt_i; ++a) {
+            const uint32_t v = mine[a][ol];
+            int b = a - 1;
+            while (b >= 0 && mine[b][ol] > v) { mine[b + 1][ol] = mine[b][ol]; --b; }
+            mine[b + 1][ol] = v;
+        }
+        for (int a = 0; a < cnt_i; ++a) own_keys[(size_t)i * kOwnCap + a] = ((uint64_t)i << 33) | mine[a][ol];
+        own_count[i] = (uint32_t)cnt_i;
     }
-    for (int a = 0; a < em.n; ++a) own_keys[(size_t)i * kOwnCap + a] = ((uint64_t)i << 33) | mine[a][tx];
-    own_count[i] = (uint32_t)em.n;
-    // one atomic per block for the kept certificate manifolds (the lanes still here are converged again: one wave per block)
-    if (em.tree) atomicAdd(&tree_kept, em.tree);
-    __threadfence_block();
-    const uint64_t alive = __ballot(1);
-    if ((uint32_t)tx == (uint32_t)__ffsll((long long)alive) - 1u && tree_kept) atomicAdd(&cnt->tree_found, tree_kept);
+    if (tx == 0 && tree_kept) atomicAdd(&cnt->tree_found, tree_kept);   // one atomic per block for the kept certificate manifolds
 }
 // After the scan of own_count: total pair count for the host, and the per-owner blocks copied to their final places.
 // Also compares the new key list with the previous step's manifold array (prev_skey[pm], sorted the same way): when nothing differs
@@ -618,7 +626,7 @@ int broadphase(edynhip_ctx *c) {
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
                            sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
         hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkSplit, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.split, c->bvh.rope);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kBpBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kOwnersPerBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping, c->bvh.split, c->bvh.rope);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt, prev.skey, pm);
