@@ -175,8 +175,9 @@ __global__ void __launch_bounds__(256) k_poly_scatter(uint32_t M, PolyBins pb) {
     __syncthreads();
     if (key != 0xFFFFFFFFu) pb.list[hist[key] + rank] = m;
 }
-// (more resident waves per SIMD - fewer registers - were measured slower: 4 / 8 / 16 workgroups per CU gave 172 / 169 / 158 steps/s on polyheap32k)
-__global__ void __launch_bounds__(64, 4)
+// (register budget: 1 / 2 / 4 / 8 / 16 workgroups per CU as the launch bound gave 231 / 251 / 240 / 235 / 220 steps/s on polyheap32k -
+// two leaves the allocator enough registers to keep the polygons' scalars out of scratch and still lets a second wave hide latency)
+__global__ void __launch_bounds__(64, 2)
 k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, Staging st, Meshes meshes, PolyBins pb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M || i >= *pb.total) return;
