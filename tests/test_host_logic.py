@@ -53,3 +53,37 @@ def test_fixed_step_accumulator():
     assert steps == 10 and acc < dt
     steps, acc, sdt = fixed_step_plan(0.0, -5.0, dt, 10)          # negative elapsed clamps to 0
     assert steps == 0 and acc == 0.0
+
+
+def test_convex_library_meshes_are_closed_and_wound_outwards():
+    """edyn_amd.scenes.convex_library: every mesh is a closed 2-manifold (each edge shared by exactly two faces, once in each
+    direction), its faces wind counter-clockwise seen from outside (positive volume), no face has more vertices than a support
+    polygon holds (32) - what edynhip_create_convex_mesh insists on."""
+    from edyn_amd import scenes
+    for m in scenes.convex_library():
+        v, idx, faces = m["vertices"].astype(np.float64), m["indices"], m["faces"]
+        directed = {}
+        vol = 0.0
+        for first, count in faces:
+            f = idx[first:first + count]
+            assert 3 <= count <= 32
+            for k in range(count):
+                e = (int(f[k]), int(f[(k + 1) % count]))
+                assert e not in directed
+                directed[e] = 1
+            for k in range(1, count - 1):
+                vol += np.dot(v[f[0]], np.cross(v[f[k]], v[f[k + 1]])) / 6
+        assert all((b, a) in directed for a, b in directed)   # every edge has its opposite: closed, consistently oriented
+        assert vol > 0.01
+        assert len(np.unique(idx)) == len(v)                  # no unused vertex
+
+
+def test_polyhedron_heap_scene_and_its_subsets_carry_the_mesh_list():
+    from edyn_amd import scenes
+    a, b = scenes.polyhedron_heap(4, 3, 4), scenes.polyhedron_heap(4, 3, 4)
+    assert all(np.array_equal(a[k], b[k]) for k in a if k != "meshes")                    # deterministic
+    assert (a["shape_type"][1:] == scenes.SHAPE_POLYHEDRON).all() and a["shape_type"][0] == scenes.SHAPE_PLANE
+    assert set(a["shape_param"][1:, 0].astype(int)) == set(range(len(a["meshes"])))      # every mesh is used
+    assert np.allclose(np.linalg.norm(a["orn"], axis=1), 1.0, atol=1e-6)
+    sub = scenes.subset(a, np.array([0, 3, 7, 11]))
+    assert sub["meshes"] is a["meshes"] and len(sub["kind"]) == 4                         # ids stay positions in the same list
