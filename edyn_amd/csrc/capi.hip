@@ -612,6 +612,7 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     for (uint32_t i = 0; i < n; ++i)
         if (in->shape_type[i] < EDYNHIP_SHAPE_NONE || in->shape_type[i] > EDYNHIP_SHAPE_POLYHEDRON)
             return set_error(c, EDYNHIP_ERR_UNSUPPORTED, (std::string(who) + ": shape type not on this path (box, sphere, plane, capsule, cylinder, polyhedron)").c_str());
+    EH_HIP(c, hipSetDevice(c->device));   // before anything allocates: a process may hold contexts on several GPUs
     EH_TRY(mesh_bind_bodies(c, first, n, in->shape_type, in->shape_param));
     if (first == 0) c->has_cylinder = false;
     for (uint32_t i = 0; i < n; ++i) if (in->shape_type[i] == EDYNHIP_SHAPE_CYLINDER) c->has_cylinder = true;   // narrowphase.hip launches k_np_detect_ext
@@ -619,7 +620,6 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     for (uint32_t i = 0; i < n; ++i)
         if (in->restitution[i] > 0.0f) c->has_restitution = true;   // turns the restitution solver on (restitution.hip)
     if (first == 0) { c->host_joints.clear(); c->j.n = 0; c->j.num_colours = 0; c->j.rows = 0; c->host_excl.clear(); if (c->excl) (void)hipMemsetAsync(c->excl, 0xFF, (size_t)c->b.cap * 16 * sizeof(uint32_t), c->stream); }
-    EH_HIP(c, hipSetDevice(c->device));
     std::vector<void *> tmp;
     RawBodies r{};
     int rc = EDYNHIP_OK;

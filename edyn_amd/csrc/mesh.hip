@@ -161,34 +161,67 @@ static const char *append_mesh(edynhip_ctx::HostMeshes &t, uint32_t nv, const fl
         for (int k = 0; k < 7; ++k) d.isum[k] = s[k];
         if (!(volume > 0)) return "the mesh has no positive volume (faces must wind counter-clockwise seen from outside)";
     }
+    if (nv > (uint32_t)kPolyMax) {
+        // A support polygon (dpolyhedron.hpp point_cloud_support_polygon) gathers EVERY vertex within support_feature_tolerance of
+        // the supporting plane of a direction - across coplanar faces (a triangulated cap) and across facets narrower than the
+        // tolerance. Its arrays hold kPolyMax vertices (std::vector in the reference), so a mesh that could put more than that
+        // into one of them is refused here instead of being clipped silently: checked for every face normal and for the
+        // direction between the two faces of every edge, with a margin on the tolerance.
+        const float tol = 0.005f + 1e-4f;   // support_feature_tolerance, config/constants.hpp:56
+        auto crowded = [&](H3 dir) {
+            float top = -3.0e38f;
+            for (const H3 &p : v) top = std::max(top, hdot(p, dir));
+            uint32_t within = 0;
+            for (const H3 &p : v) if (hdot(p, dir) > top - tol) ++within;
+            return within > (uint32_t)kPolyMax;
+        };
+        for (uint32_t f = 0; f < nfaces; ++f)
+            if (crowded(normals[f])) return "more than 32 vertices lie within the support tolerance of one face plane (a support polygon holds 32)";
+        for (uint32_t e = 0; e < ne; ++e) {
+            H3 mid = e_n[2 * e] + e_n[2 * e + 1];
+            if (htry_normalize(mid) && crowded(mid)) return "more than 32 vertices lie within the support tolerance of one supporting plane (a support polygon holds 32)";
+        }
+    }
     d.rot_size = d.nv + d.nrf + 4 * d.ne;
     t.desc.push_back(d);
     return nullptr;
 }
 
 template <typename T>
-static int put(edynhip_ctx *c, const std::vector<T> &h, const T *&dev) {
+static int put(edynhip_ctx *c, const std::vector<T> &h, const T *&dev, std::vector<void *> &allocs) {
     void *q = nullptr;
     EH_HIP(c, hipMalloc(&q, std::max<size_t>(1, h.size()) * sizeof(T)));
-    c->mesh_allocs.push_back(q);
+    allocs.push_back(q);
     if (!h.empty()) EH_HIP(c, hipMemcpyAsync(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
     dev = (const T *)q;
     return EDYNHIP_OK;
 }
-static int upload_meshes(edynhip_ctx *c) {
-    EH_HIP(c, hipStreamSynchronize(c->stream));
-    for (void *p : c->mesh_allocs) (void)hipFree(p);
-    c->mesh_allocs.clear();
-    const auto &t = c->host_meshes;
-    Meshes &m = c->meshes;
-    EH_TRY(put(c, t.desc, m.desc));
-    EH_TRY(put(c, t.vertices, m.vertices)); EH_TRY(put(c, t.normals, m.normals)); EH_TRY(put(c, t.edge_vertices, m.edge_vertices));
-    EH_TRY(put(c, t.edge_normals, m.edge_normals)); EH_TRY(put(c, t.relevant_normals, m.relevant_normals));
-    EH_TRY(put(c, t.face_first, m.face_first)); EH_TRY(put(c, t.edge_vidx, m.edge_vidx)); EH_TRY(put(c, t.edge_faces, m.edge_faces));
-    EH_TRY(put(c, t.relevant_faces, m.relevant_faces)); EH_TRY(put(c, t.relevant_edges, m.relevant_edges));
-    EH_TRY(put(c, t.nb_start, m.nb_start)); EH_TRY(put(c, t.nb_idx, m.nb_idx));
+// Uploads the tables `t` into FRESH allocations; only when every copy has succeeded do they replace the context's tables (and the
+// old allocations go). A failure leaves the context exactly as it was - device tables, host tables, registered meshes.
+static int upload_meshes(edynhip_ctx *c, edynhip_ctx::HostMeshes &t) {
+    std::vector<void *> fresh;
+    Meshes m = c->meshes;
+    auto all = [&]() -> int {
+        EH_TRY(put(c, t.desc, m.desc, fresh));
+        EH_TRY(put(c, t.vertices, m.vertices, fresh)); EH_TRY(put(c, t.normals, m.normals, fresh)); EH_TRY(put(c, t.edge_vertices, m.edge_vertices, fresh));
+        EH_TRY(put(c, t.edge_normals, m.edge_normals, fresh)); EH_TRY(put(c, t.relevant_normals, m.relevant_normals, fresh));
+        EH_TRY(put(c, t.face_first, m.face_first, fresh)); EH_TRY(put(c, t.edge_vidx, m.edge_vidx, fresh)); EH_TRY(put(c, t.edge_faces, m.edge_faces, fresh));
+        EH_TRY(put(c, t.relevant_faces, m.relevant_faces, fresh)); EH_TRY(put(c, t.relevant_edges, m.relevant_edges, fresh));
+        EH_TRY(put(c, t.nb_start, m.nb_start, fresh)); EH_TRY(put(c, t.nb_idx, m.nb_idx, fresh));
+        EH_HIP(c, hipStreamSynchronize(c->stream));   // the copies read t: done before anybody may touch it; also drains the steps that read the old tables
+        return EDYNHIP_OK;
+    };
+    const int rc = all();
+    if (rc != EDYNHIP_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        for (void *p : fresh) (void)hipFree(p);
+        return rc;
+    }
     m.num = (uint32_t)t.desc.size();
-    EH_HIP(c, hipStreamSynchronize(c->stream));
+    for (void *p : c->mesh_allocs) (void)hipFree(p);
+    c->mesh_allocs.swap(fresh);
+    c->meshes = m;
+    c->host_meshes.swap(t);
     return EDYNHIP_OK;
 }
 
@@ -263,8 +296,7 @@ int edynhip_create_convex_mesh(edynhip_ctx *c, uint32_t num_vertices, const floa
     edynhip_ctx::HostMeshes trial = c->host_meshes;   // a rejected mesh leaves the tables as they were
     if (const char *why = append_mesh(trial, num_vertices, vertices, num_indices, indices, num_faces, faces, (flags & EDYNHIP_MESH_INITIALIZED) != 0))
         return set_error(c, EDYNHIP_ERR_INVALID, (std::string("edynhip_create_convex_mesh: ") + why).c_str());
-    c->host_meshes.swap(trial);
-    EH_TRY(upload_meshes(c));
+    EH_TRY(upload_meshes(c, trial));   // swaps the tables in on success only
     *mesh_id = (uint32_t)c->host_meshes.desc.size() - 1;
     return EDYNHIP_OK;
 }

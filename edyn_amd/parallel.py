@@ -172,8 +172,9 @@ class ShardedWorld:
                 v = np.asarray(m["vertices"], np.float64)
                 diam.append(float(np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2).max()))
             self.reach = np.where(st == 6, np.asarray(diam)[np.clip(sp[:, 0].astype(np.int64), 0, len(diam) - 1)], self.reach)
-        if "center_of_mass" in scene:
-            self.reach = self.reach + np.linalg.norm(np.asarray(scene["center_of_mass"], np.float64), axis=1)
+        com = scene.get("com", scene.get("center_of_mass"))   # scenes carry the offsets as "com" (world.py)
+        if com is not None:
+            self.reach = self.reach + np.linalg.norm(np.asarray(com, np.float64).reshape(-1, 3), axis=1)
         self.part_labels = np.asarray(labels).copy()
         self._build(partition_islands(labels, self.kind, weights, world_size), scene, manifolds=None)
 

@@ -282,7 +282,9 @@ class World:
             self.attach(self.cfg.max_bodies or n, self.cfg.max_joints or len(joints))
         for k, mesh in enumerate(scene.get("meshes") or []):
             if k >= self.num_meshes:
-                assert self.create_convex_mesh(mesh["vertices"], mesh["indices"], mesh["faces"]) == k
+                mid = self.create_convex_mesh(mesh["vertices"], mesh["indices"], mesh["faces"])
+                if mid != k:
+                    raise RuntimeError(f"convex mesh {k} of the scene was registered as mesh {mid}")
                 self._mesh_sig.append(sig[k])
         self._check(self._L.edynhip_set_bodies(self._h, n, C.byref(b)))
         self.n = n

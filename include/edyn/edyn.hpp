@@ -871,7 +871,14 @@ inline void attach(entt::registry &registry, const init_config &config = {}) {
     auto &s = registry.ctx().emplace<detail::gpu_stepper>();
     s.cfg = config;
 }
-inline void detach(entt::registry &registry) { registry.ctx().erase<detail::gpu_stepper>(); }
+inline void detach(entt::registry &registry) {   // edyn.cpp:148-197: the stepper goes, and every entity the engine created with it
+    if (auto *s = registry.ctx().find<detail::gpu_stepper>()) {
+        for (auto &kv : s->point_entities) if (registry.valid(kv.second)) registry.destroy(kv.second);
+        for (auto &kv : s->manifold_entities) if (registry.valid(kv.second)) registry.destroy(kv.second);
+        s->point_entities.clear(); s->manifold_entities.clear();
+    }
+    registry.ctx().erase<detail::gpu_stepper>();
+}
 inline scalar get_fixed_dt(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().cfg.fixed_dt; }
 inline void set_fixed_dt(entt::registry &registry, scalar dt) { auto &s = registry.ctx().get<detail::gpu_stepper>(); s.cfg.fixed_dt = dt; s.params_dirty = true; }
 inline void set_max_steps_per_update(entt::registry &registry, unsigned n) { registry.ctx().get<detail::gpu_stepper>().cfg.max_steps_per_update = n; }

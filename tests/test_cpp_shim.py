@@ -155,3 +155,44 @@ def test_shim_ragdoll_falls_on_the_floor(shape):
     subprocess.check_call(["make", "-s", "-C", CPP, "ragdoll"])
     out = subprocess.run([os.path.join(CPP, "ragdoll"), shape, "run"], capture_output=True, text=True, timeout=300)
     assert "RAGDOLL_RUN_OK" in out.stdout, out.stdout + out.stderr
+
+
+# ---- the shim's EnTT branch -------------------------------------------------------------------------------
+# `make entt` builds every program a second time with -I oracle/entt_min, so that <entt/entt.hpp> resolves and the
+# `__has_include(<entt/entt.hpp>)` branch of include/edyn/edyn.hpp:22-26 is what compiles and runs: an EnTT-API registry with
+# sparse-set pools, signals and scoped connections instead of the bundled 144-line mini registry. oracle/entt_min is the checker's
+# from-scratch EnTT subset (EnTT 3.15 is not in this image); this is test-only use of oracle/.
+def test_shim_compiles_against_an_entt_api_registry():
+    subprocess.check_call(["make", "-s", "-C", CPP, "entt"])
+    out = subprocess.run([os.path.join(CPP, "includes_entt")], capture_output=True, text=True, timeout=60)
+    assert "INCLUDES_OK 1" in out.stdout, out.stdout + out.stderr
+    # the EnTT branch really is what was compiled: the mini registry has no signals, listeners.cpp needs them
+    syms = subprocess.run(["nm", "-C", os.path.join(CPP, "listeners_entt")], capture_output=True, text=True).stdout
+    assert "sigh" in syms or "sink" in syms, "listeners_entt does not contain EnTT signal code"
+
+
+@pytest.mark.gpu
+def test_shim_entt_listeners_see_contact_points_and_destroy_hooks():
+    """registry.on_construct / on_destroy<contact_point | contact_manifold> listeners, registry.destroy(body) hooks, a scoped
+    connection, detach destroying the engine's entities - tests/cpp/listeners.cpp, EnTT branch only."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "listeners_entt"])
+    out = subprocess.run([os.path.join(CPP, "listeners_entt")], capture_output=True, text=True, timeout=300)
+    assert "LISTENERS_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,ok", [("hello_world", "HELLO_WORLD_OK"), ("lifecycle", "LIFECYCLE_OK"), ("contacts", "contacts OK"),
+                                     ("polyhedra", "POLYHEDRA_OK")])
+def test_shim_programs_run_over_the_entt_api_registry(prog, ok):
+    """The same programs as above, through the shim's EnTT branch (EnTT's reverse iteration, swap-and-pop pools, entity recycling
+    with versions - what the mini registry only approximates)."""
+    subprocess.check_call(["make", "-s", "-C", CPP, prog + "_entt"])
+    out = subprocess.run([os.path.join(CPP, prog + "_entt")], capture_output=True, text=True, timeout=300)
+    assert ok in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_ragdoll_over_the_entt_api_registry():
+    subprocess.check_call(["make", "-s", "-C", CPP, "ragdoll_entt"])
+    out = subprocess.run([os.path.join(CPP, "ragdoll_entt"), "capsule", "run"], capture_output=True, text=True, timeout=300)
+    assert "RAGDOLL_RUN_OK" in out.stdout, out.stdout + out.stderr
