@@ -257,6 +257,42 @@ class Leg:
         torch.cuda.empty_cache()
 
 
+def per_rank_proxy(workload, args, device_index, stream, ranks):
+    from edyn_amd.parallel import shard_range
+    wl = WORKLOADS[workload]
+    first, count = shard_range(wl["shard_units"], 0, ranks)
+    scene = wl["shard"](first, count)
+    cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"], device=device_index,
+                               exclusive_device=True)
+    w = edyn_amd.World(cfg)
+    w.set_scene(scene)
+    w.set_stream(stream.cuda_stream)
+    n = len(scene["kind"])
+    buf = torch.zeros((n, 13), dtype=torch.float32, device="cuda")
+    settle = wl["settle"] if args.settle is None else args.settle
+    w.step_simulation(settle)
+    def one():
+        w.step_simulation(1)
+        w.pack_state_device(buf.data_ptr())
+    for _ in range(min(args.warmup, 10)):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.north_star_steps):
+        one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = w.get_stats()
+    finite = bool(torch.isfinite(buf).all().item())
+    rate = args.north_star_steps / el
+    return {"what": f"rank 0's block of a {ranks}-rank run of {workload} (sites {first}..{first + count - 1}) stepped on ONE GPU with the per-step state pack "
+                    f"(the send buffer of the all-gather) in the loop; settled {settle} steps",
+            "bodies": n, "contact_points": st["num_points"], "islands": st["num_islands"], "steps": args.north_star_steps,
+            "steps_per_sec": rate, "ms_per_step": 1e3 * el / args.north_star_steps, "target_hz": 60.0, "meets_60hz": bool(rate >= 60.0), "finite": finite,
+            "reading": f"measured upper bound of the {ranks}-GPU rate of {workload}: no data-path collective exists between islands; the state gather over xGMI "
+                       f"(13 floats per body) and the slowest of the {ranks} ranks come on top - not a {ranks}-GPU measurement"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,21 +370,30 @@ def main():
         launches = tm["solve_velocity_launches"] / max(args.steps if not distributed else 1, 1)
         sweeps = wl["vel"] + 1   # +1: the warm-start sweep
         alg_bytes_step = (BYTES_PER_POINT_ITER * stats["num_points"] + BYTES_PER_JOINT_ROW_ITER * stats["num_joint_rows"]) * sweeps
-        # measured fabric traffic per launch: a KEPT rocprofv3 PMC profile of this command (profiles/traffic.json, keyed
-        # by workload; FETCH_SIZE/WRITE_SIZE cannot be read from inside the run) - null when no profile was kept
+        # Measured fabric traffic: a KEPT rocprofv3 PMC profile of this workload (profiles/traffic.json, keyed by workload, made by
+        # scripts/profile_round.sh; FETCH_SIZE / WRITE_SIZE cannot be read from inside the run). The profile stores the traffic of its
+        # timed steps PER ALGORITHMIC BYTE, so it scales to this run's own contact-point / joint-row counts; it only counts for the
+        # schedule (the kernels) it was measured on. No profile for the schedule that ran => traffic, achieved and frac are null.
+        schedule = _capi.SCHEDULE_NAMES.get(stats["solve_schedule"], str(stats["solve_schedule"]))
         traffic = None
+        traffic_note = "no kept rocprofv3 PMC profile of this workload on this solve schedule (profiles/traffic.json): traffic, achieved and frac are null"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get(args.workload) if isinstance(tj.get(args.workload), dict) else (tj if tj.get("workload") == args.workload else None)
-                traffic = ent.get("hbm_bytes_per_launch") if ent else None
+                ent = json.load(open(tpath)).get(args.workload)
+                if isinstance(ent, dict) and ent.get("schedule") == schedule and ent.get("traffic_per_algorithmic_byte"):
+                    traffic = float(ent["traffic_per_algorithmic_byte"]) * alg_bytes_step / max(launches, 1)
+                    traffic_note = (f"kept rocprofv3 PMC profile (profiles/traffic.json: {ent['traffic_per_algorithmic_byte']:.3f} fabric bytes per algorithmic byte over "
+                                    f"the timed steps of a run with {ent['contact_points']} contact points / {ent['joint_rows']} joint rows on the same schedule), scaled to this "
+                                    f"run's counts; not measured in this run")
             except Exception:
                 traffic = None
         per_launch_alg = alg_bytes_step / max(launches, 1)
         # achieved = min(algorithmic, measured) bytes / kernel time
-        eff_bytes_step = min(alg_bytes_step, traffic * max(launches, 1)) if traffic else alg_bytes_step
-        achieved = (eff_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
+        achieved = None
+        if traffic is not None and solve_ms > 0:
+            achieved = (min(alg_bytes_step, traffic * max(launches, 1)) / 1e9) / (solve_ms / 1e3)
+        achieved_alg = (alg_bytes_step / 1e9) / (solve_ms / 1e3) if solve_ms > 0 else 0.0
         # The denominator stays the 8 TB/s spec peak. Beside it: what this GPU streams when every CU reads 16 B per lane
         # (the practical ceiling of a read-dominated kernel like the solve) and what a device-to-device copy moves (read +
         # write bytes; a copy alternates reads and writes on every channel and is slower than a pure read stream).
@@ -364,12 +409,13 @@ def main():
                        "joint_rows": stats["num_joint_rows"],
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite,
                        "parity": PARITY},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": "kept rocprofv3 PMC profile (profiles/traffic.json), not measured in this run",
-                         "measured_read_ceiling": read_gbs, "frac_of_measured_read_ceiling": achieved / read_gbs if read_gbs > 0 else None,
-                         "measured_copy_ceiling": copy_gbs, "frac_of_measured_copy_ceiling": achieved / copy_gbs if copy_gbs > 0 else None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": (achieved / peak) if achieved is not None else None,
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "achieved_from_algorithmic_bytes_only": achieved_alg, "frac_from_algorithmic_bytes_only": achieved_alg / peak,
+                         "measured_read_ceiling": read_gbs, "frac_of_measured_read_ceiling": (achieved / read_gbs) if achieved is not None and read_gbs > 0 else None,
+                         "measured_copy_ceiling": copy_gbs, "frac_of_measured_copy_ceiling": (achieved / copy_gbs) if achieved is not None and copy_gbs > 0 else None,
                          "achieved_rule": "min(algorithmic bytes, measured traffic) / kernel time; peak = HBM3E spec; the measured read-stream and device-to-device copy rates of this GPU are reported beside it",
-                         "kernel": _capi.SCHEDULE_NAMES.get(stats["solve_schedule"], str(stats["solve_schedule"])),
+                         "kernel": schedule,
                          "algorithmic_bytes_per_launch": per_launch_alg,
                          "algorithmic_bytes_rule": "(380 B x contact points + 256 B x joint rows) x (velocity iterations + 1 warm-start sweep)",
                          "launches_per_step": launches,
@@ -408,6 +454,12 @@ def main():
                 "target_hz": 60.0, "meets_60hz": bool(ns.value >= 60.0),
                 "bodies_this_rank": ns.n_bodies, "contact_points_this_rank": ns_stats["num_points"], "finite": ns_finite}
         ns.close()
+        # north_star.per_rank_proxy: what ONE rank of an 8-GPU run has to do - its 1/8 block of the sites
+        # (131 072 boxes, 2 048 islands) stepped on this GPU with the per-step state pack (edynhip_pack_state_device into the buffer
+        # an RCCL all-gather would send) in the loop. Islands need no data-path collective, so this is a MEASURED UPPER BOUND of the
+        # 8-GPU rate (the gather over xGMI and the slowest of eight ranks come on top), stated as such.
+        if rank == 0 and world_size == 1 and "shard" in WORKLOADS[ns_name] and WORKLOADS[ns_name]["shard_units"] >= 8:
+            out["north_star"]["per_rank_proxy"] = per_rank_proxy(ns_name, args, device_index, stream, 8)
 
     if rank == 0:
         if state_path is not None:

@@ -9,6 +9,7 @@ from .world import (World, init_config, rigidbody_def, attach, detach, make_rigi
                     JOINT_POINT, JOINT_HINGE, ALL_GROUPS)
 from ._capi import EdynHipError, MANIFOLD_DTYPE, POINT_DTYPE
 from . import scenes
+from .multi import MultiWorld
 
 __all__ = ["World", "init_config", "rigidbody_def", "attach", "detach", "make_rigidbody", "update",
-           "step_simulation", "EdynHipError", "scenes"]
+           "step_simulation", "EdynHipError", "scenes", "MultiWorld"]

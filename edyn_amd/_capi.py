@@ -53,6 +53,10 @@ class Stats(C.Structure):
                                           "num_joints", "num_joint_rows", "solve_schedule")] + [("colour_size", C.c_uint32 * 64)]
 
 
+class WorldStats(C.Structure):   # edynhip_world_stats
+    _fields_ = [(n, C.c_uint32) for n in ("num_shards", "num_bodies", "steps", "approach_checks", "repartitions")] + [("bodies_per_shard", C.c_uint32 * 16)]
+
+
 SCHEDULE_NAMES = {0: "none", 1: "k_contact_solve_df2 (dataflow, one launch per step, two lanes per manifold)",
                   2: "k_contact_solve_df (dataflow, one launch per step, one lane per manifold)",
                   3: "k_island_velocity (island-fused: one wave per island)",
@@ -86,7 +90,13 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
            "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing",
            "edynhip_measure_bandwidth", "edynhip_set_joint_warm_start", "edynhip_set_asleep", "edynhip_create_convex_mesh",
-           "edynhip_get_convex_mesh"]
+           "edynhip_get_convex_mesh",
+           # multi-GPU world (ABI 12)
+           "edynhip_world_create", "edynhip_world_destroy", "edynhip_world_last_error", "edynhip_world_create_convex_mesh",
+           "edynhip_world_set_bodies", "edynhip_world_set_joints", "edynhip_world_set_joint_definition", "edynhip_world_exclude_collision",
+           "edynhip_world_step", "edynhip_world_get_state", "edynhip_world_get_partition", "edynhip_world_repartition",
+           "edynhip_world_get_manifolds", "edynhip_world_get_stats", "edynhip_world_context", "edynhip_partition_islands",
+           "edynhip_island_boxes_overlap", "edynhip_get_island_boxes"]
 
 _lib = None
 
@@ -152,5 +162,26 @@ def lib():
         L.edynhip_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_abi_version.restype = C.c_uint32
+        L.edynhip_world_create.restype = C.c_void_p
+        L.edynhip_world_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+        L.edynhip_world_destroy.argtypes = [C.c_void_p]
+        L.edynhip_world_last_error.restype = C.c_char_p
+        L.edynhip_world_last_error.argtypes = [C.c_void_p]
+        L.edynhip_world_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_world_set_bodies.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Bodies)]
+        L.edynhip_world_set_joints.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Joints)]
+        L.edynhip_world_set_joint_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.edynhip_world_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.edynhip_world_step.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_world_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.edynhip_world_get_partition.argtypes = [C.c_void_p, C.c_void_p]
+        L.edynhip_world_repartition.argtypes = [C.c_void_p]
+        L.edynhip_world_get_manifolds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_world_get_stats.argtypes = [C.c_void_p, C.POINTER(WorldStats)]
+        L.edynhip_world_context.restype = C.c_void_p
+        L.edynhip_world_context.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_partition_islands.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.edynhip_island_boxes_overlap.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.edynhip_get_island_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib

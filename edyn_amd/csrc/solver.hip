@@ -709,6 +709,39 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
     const f3 Jl = from4(r.f[0]);
     return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
 }
+// solve_friction's clamp to the friction circle (constraint_row_friction.cpp:26-42), shared by every velocity-solve kernel:
+//     if (len2 > max_len^2) { len = sqrt(len2); if (len > eps) { i0 = i0 / len * max_len; i1 = ... } else i0 = i1 = 0; d = i - c; }
+// Same result bit for bit, but the square root and the two divisions (about 45 of a task's ~160 instructions per point: they are
+// IEEE-correct sequences) are only executed when a lane has a SLIDING contact, i.e. max_len != 0. A point whose normal row carries
+// no impulse - every speculative (distance > 0) contact of a pile and the unloaded corners of a resting face - has max_len == 0 and
+// takes this clamp on every visit; there (i / len) * 0 is a zero with the sign of i (|i / len| <= 1: finite), and the test
+// sqrt(len2) > FLT_EPSILON is equivalent to len2 > 0x1.000002p-46f for a correctly rounded square root (checked exhaustively
+// around the boundary). A wave therefore skips the slow path unless one of its lanes slides.
+constexpr float kLen2AboveEps = 0x1.000002p-46f;
+DI void friction_circle(float &i0, float &i1, float &di0, float &di1, float c0, float c1, float max_len) {
+    const float len2 = i0 * i0 + i1 * i1;
+    const bool over = len2 > square(max_len);
+    const bool slow = over && (max_len != 0.0f || !(len2 < 3.0e38f));
+    if (slow) {
+        const float len = sqrtf(len2);
+        if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
+        else { i0 = 0; i1 = 0; }
+    } else if (over) {
+        const uint32_t sm = __float_as_uint(max_len) & 0x80000000u;
+        const bool big = len2 > kLen2AboveEps;
+        i0 = big ? __uint_as_float((__float_as_uint(i0) & 0x80000000u) ^ sm) : 0.0f;
+        i1 = big ? __uint_as_float((__float_as_uint(i1) & 0x80000000u) ^ sm) : 0.0f;
+    }
+    if (over) { di0 = i0 - c0; di1 = i1 - c1; }
+}
+// solve(constraint_row&)'s clamp (constraint_row.cpp:38-50) as selects: dimp keeps its computed value unless a limit cuts in
+DI void normal_clamp(float &cur, float &dimp, float upper) {
+    const float imp = cur + dimp;
+    const bool lt = imp < 0.0f, gt = !lt && imp > upper;
+    const float nw = lt ? 0.0f : (gt ? upper : imp);
+    dimp = (lt || gt) ? nw - cur : dimp;
+    cur = nw;
+}
 // NP (points of the manifold) is a template parameter: lanes are grouped by point count inside a colour, so a wave
 // runs one instantiation, every loop is fully unrolled without predication and the compiler can issue all
 // 15*NP row loads plus the body loads back to back before the first use (one memory round trip after the indices).
@@ -739,11 +772,7 @@ DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
             float drel = row_relspeed(d, r);
             float dimp = (r.f[1].w - drel) * r.f[0].w;
             float cur = r.f[2].w;
-            float imp = cur + dimp;
-            const float upper = r.f[4].w;   // large_scalar, or a soft contact's force limit
-            if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
-            else if (imp > upper) { dimp = upper - cur; cur = upper; }
-            else cur = imp;
+            normal_clamp(cur, dimp, r.f[4].w);   // upper = large_scalar, or a soft contact's force limit
             r.f[2].w = cur;
             row_apply(d, r, dimp);
         }
@@ -760,14 +789,7 @@ DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
             float i0 = ra.f[2].w + di0;
             float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
             float i1 = rb.f[2].w + di1;
-            float len2 = i0 * i0 + i1 * i1;
-            float max_len = R[k][0].f[3].w * R[k][0].f[2].w;   // mu * current normal impulse
-            if (len2 > square(max_len)) {
-                float len = sqrtf(len2);
-                if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-                else { i0 = 0; i1 = 0; }
-                di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
-            }
+            friction_circle(i0, i1, di0, di1, ra.f[2].w, rb.f[2].w, R[k][0].f[3].w * R[k][0].f[2].w);   // mu * current normal impulse
             ra.f[2].w = i0; rb.f[2].w = i1;
             row_apply(d, ra, di0);
             row_apply(d, rb, di1);
@@ -801,10 +823,7 @@ DI void rows_solve_normals(Delta &d, RowReg (&Rn)[NP], uint32_t np) {
             float drel = row_relspeed(d, r);
             float dimp = (r.f[1].w - drel) * r.f[0].w;
             float cur = r.f[2].w;
-            float imp = cur + dimp;
-            if (imp < 0.0f) { dimp = 0.0f - cur; cur = 0.0f; }
-            else if (imp > kLarge) { dimp = kLarge - cur; cur = kLarge; }
-            else cur = imp;
+            normal_clamp(cur, dimp, kLarge);
             r.f[2].w = cur;
             row_apply(d, r, dimp);
         }
@@ -820,14 +839,7 @@ DI void rows_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) 
         float i0 = ra.f[2].w + di0;
         float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
         float i1 = rb.f[2].w + di1;
-        float len2 = i0 * i0 + i1 * i1;
-        float max_len = rn.f[3].w * rn.f[2].w;   // mu * current normal impulse
-        if (len2 > square(max_len)) {
-            float len = sqrtf(len2);
-            if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-            else { i0 = 0; i1 = 0; }
-            di0 = i0 - ra.f[2].w; di1 = i1 - rb.f[2].w;
-        }
+        friction_circle(i0, i1, di0, di1, ra.f[2].w, rb.f[2].w, rn.f[3].w * rn.f[2].w);   // mu * current normal impulse
         ra.f[2].w = i0; rb.f[2].w = i1;
         row_apply(d, ra, di0);
         row_apply(d, rb, di1);
@@ -1802,10 +1814,7 @@ DI void df2_point(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
         return;
     }
     float dimp = (rn.rhs - df2_relspeed(x, rn)) * rn.eff;
-    const float imp = rn.imp + dimp;
-    if (imp < 0.0f) { dimp = 0.0f - rn.imp; rn.imp = 0.0f; }
-    else if (imp > kLarge) { dimp = kLarge - rn.imp; rn.imp = kLarge; }
-    else rn.imp = imp;
+    normal_clamp(rn.imp, dimp, kLarge);
     df2_apply(x, rn, dimp);
     (void)ra; (void)rb; (void)mu;
 }
@@ -1822,14 +1831,7 @@ DI void df2_friction(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
     float i0 = c0 + di0;
     float di1 = (rb.rhs - df2_relspeed(x, rb)) * rb.eff;
     float i1 = c1 + di1;
-    const float len2 = i0 * i0 + i1 * i1;
-    const float max_len = mu * R[0].imp;   // mu * current normal impulse
-    if (len2 > square(max_len)) {
-        const float len = sqrtf(len2);
-        if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-        else { i0 = 0; i1 = 0; }
-        di0 = i0 - c0; di1 = i1 - c1;
-    }
+    friction_circle(i0, i1, di0, di1, c0, c1, mu * R[0].imp);   // mu * current normal impulse
     ra.imp = i0; rb.imp = i1;
     df2_apply(x, ra, di0);
     df2_apply(x, rb, di1);

@@ -76,23 +76,28 @@ def partition_islands(labels, kind, weights, world_size):
     kind    [n] body kinds; non-dynamic bodies belong to no island and are replicated on every rank
     weights [n] per-body cost (e.g. contact points the body takes part in; 1 = balance body counts)
     Deterministic: islands by descending weight, ties by ascending label, each to the currently lightest rank (ties to
-    the lowest rank) - longest-processing-time-first. Returns rank_of_body [n] (-1 = replicated)."""
-    labels = np.asarray(labels); kind = np.asarray(kind); weights = np.asarray(weights, np.float64)
-    dyn = kind == KIND_DYNAMIC
+    the lowest rank) - longest-processing-time-first. Returns rank_of_body [n] (-1 = replicated).
+    The partitioner itself is the library's (edynhip_partition_islands, edyn_amd/csrc/multi.hip - host code, no GPU needed):
+    the single-process multi-GPU world (edynhip_world_*) and this multi-process one partition alike."""
+    from . import _capi
+    labels = np.ascontiguousarray(labels, np.uint32); kind = np.ascontiguousarray(kind, np.int32)
+    weights = np.ascontiguousarray(weights, np.float64)
     rank_of = np.full(len(kind), -1, np.int32)
-    if not dyn.any():
-        return rank_of
-    isl, inv = np.unique(labels[dyn], return_inverse=True)
-    w = np.bincount(inv, weights=weights[dyn], minlength=len(isl))
-    order = np.lexsort((isl, -w))
-    load = np.zeros(world_size)
-    owner = np.zeros(len(isl), np.int32)
-    for k in order:
-        r = int(np.argmin(load))          # first minimum = lowest rank on ties
-        owner[k] = r
-        load[r] += w[k]
-    rank_of[dyn] = owner[inv]
+    rc = _capi.lib().edynhip_partition_islands(len(kind), labels.ctypes.data, kind.ctypes.data, weights.ctypes.data, int(world_size), rank_of.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"edynhip_partition_islands: {rc}")
     return rank_of
+
+
+def island_boxes(aabb, labels, kind):
+    """(labels [k], boxes [k, 6]) - per island the union of its dynamic bodies' AABBs."""
+    kind = np.asarray(kind); labels = np.asarray(labels)
+    dyn = kind == KIND_DYNAMIC
+    isl, inv = np.unique(labels[dyn], return_inverse=True)
+    lo = np.full((len(isl), 3), np.inf); hi = np.full((len(isl), 3), -np.inf)
+    if len(isl):
+        np.minimum.at(lo, inv, aabb[dyn][:, :3]); np.maximum.at(hi, inv, aabb[dyn][:, 3:])
+    return isl, np.concatenate([lo, hi], axis=1).astype(np.float32), inv
 
 
 def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026, any_owner=False):
@@ -101,26 +106,24 @@ def island_boxes_overlap(aabb, labels, kind, rank_of, margin=0.026, any_owner=Fa
     overlap. Returns the list of (label_a, label_b) pairs; empty = the partition is still valid. Conservative: overlapping
     island boxes do not yet touch, but no contact between two shards can appear without it. any_owner = also the pairs that
     live on ONE rank: what a new partition has to keep together (two islands about to touch that were co-located by the last
-    partition have no manifold between them yet - the partitioner would be free to split them again)."""
-    kind = np.asarray(kind); labels = np.asarray(labels); rank_of = np.asarray(rank_of)
-    dyn = kind == KIND_DYNAMIC
-    isl, inv = np.unique(labels[dyn], return_inverse=True)
+    partition have no manifold between them yet - the partitioner would be free to split them again).
+    The sweep is the library's (edynhip_island_boxes_overlap, host code)."""
+    from . import _capi
+    rank_of = np.asarray(rank_of)
+    isl, boxes, inv = island_boxes(np.asarray(aabb, np.float64), labels, kind)
     if len(isl) < 2:
         return []
-    lo = np.full((len(isl), 3), np.inf); hi = np.full((len(isl), 3), -np.inf)
-    np.minimum.at(lo, inv, aabb[dyn][:, :3]); np.maximum.at(hi, inv, aabb[dyn][:, 3:])
-    lo -= margin; hi += margin
+    dyn = np.asarray(kind) == KIND_DYNAMIC
     owner = np.zeros(len(isl), np.int32); owner[inv] = rank_of[dyn]
-    out = []
-    order = np.argsort(lo[:, 0], kind="stable")       # sweep along x
-    active = []
-    for k in order:
-        active = [a for a in active if hi[a, 0] >= lo[k, 0]]
-        for a in active:
-            if (any_owner or owner[a] != owner[k]) and np.all(lo[a] <= hi[k]) and np.all(lo[k] <= hi[a]):
-                out.append((int(min(isl[a], isl[k])), int(max(isl[a], isl[k]))))
-        active.append(k)
-    return sorted(set(out))
+    lab = np.ascontiguousarray(isl, np.uint32); boxes = np.ascontiguousarray(boxes, np.float32)
+    n = _capi.C.c_uint32(0)
+    L = _capi.lib()
+    L.edynhip_island_boxes_overlap(len(lab), boxes.ctypes.data, lab.ctypes.data, owner.ctypes.data, float(margin), int(any_owner), None, 0, _capi.C.byref(n))
+    pairs = np.zeros((max(n.value, 1), 2), np.uint32)
+    rc = L.edynhip_island_boxes_overlap(len(lab), boxes.ctypes.data, lab.ctypes.data, owner.ctypes.data, float(margin), int(any_owner), pairs.ctypes.data, len(pairs), _capi.C.byref(n))
+    if rc != 0:
+        raise ValueError(f"edynhip_island_boxes_overlap: {rc}")
+    return [(int(a), int(b)) for a, b in pairs[:n.value]]
 
 
 class ShardedWorld:

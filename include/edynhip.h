@@ -380,6 +380,63 @@ int edynhip_get_convex_mesh(edynhip_ctx *ctx, uint32_t mesh_id, int field, void 
  * Not part of the step path. */
 int edynhip_measure_bandwidth(edynhip_ctx *ctx, uint64_t bytes, float *read_gbs, float *copy_gbs);
 
+/* ------------------------------------------------------------------------------------------------ Multi-GPU world (ABI 12)
+ * ONE simulation over several GPUs of a node at island granularity - the reference's own unit of parallelism
+ * (src/edyn/dynamics/solver.cpp:408-428 runs every island as its own task; islands share only non-procedural bodies, which a
+ * step never writes: include/edyn/comp/island.hpp:34-41). An application reaches it through edyn::attach with
+ * init_config::devices (include/edyn/edyn.hpp of this repository; the reference's attach: include/edyn/edyn.hpp:66-70).
+ * Every device gets one edynhip_ctx (a "shard") that owns the dynamic bodies of its islands plus a replica of every non-dynamic
+ * body; shards step concurrently (one private host thread each) with NO exchange inside a step; after each step the integrated
+ * state of every shard is copied into pinned host memory and from there into the world's arrays (edynhip_world_get_state) - the
+ * registry write-back. Islands of different shards that approach each other are noticed from island bounding boxes reduced ON
+ * THE DEVICE (edyn_amd/csrc/multi.hip), and the world re-partitions, carrying contact manifolds (warm-start impulses, colours),
+ * joint impulses / angles, sleeping tags, exclusions, joint definitions and meshes to the islands' new owners. A shard computes
+ * for its islands bit for bit what one context computes for the whole world (tests/cpp/multi.cpp).
+ * Body / joint indices of this interface are GLOBAL (the caller's order). `devices` may name a device more than once (several
+ * shards on one GPU: functional tests). Scene description calls (meshes, bodies, joints, definitions, exclusions - in this order)
+ * come before the first step; a later edynhip_world_set_bodies starts a new world. */
+typedef struct edynhip_world edynhip_world;
+typedef struct {
+    uint32_t num_shards, num_bodies;
+    uint32_t steps;                  /* steps taken since creation */
+    uint32_t approach_checks;        /* island-box sweeps (device reduction + host sweep) */
+    uint32_t repartitions;           /* times the shards were rebuilt because islands of different shards met (or on request) */
+    uint32_t bodies_per_shard[16];   /* bodies whose state each shard reports (shard 0 also reports the replicated ones) */
+} edynhip_world_stats;
+edynhip_world *edynhip_world_create(const edynhip_config *cfg /* .device is ignored; capacities 0 = sized per shard */,
+                                    const int32_t *devices, uint32_t num_devices, int *status_out);
+void edynhip_world_destroy(edynhip_world *w);
+const char *edynhip_world_last_error(const edynhip_world *w);   /* w may be NULL: error of the last failed create */
+int edynhip_world_create_convex_mesh(edynhip_world *w, uint32_t num_vertices, const float *vertices, uint32_t num_indices, const uint32_t *indices,
+                                     uint32_t num_faces, const uint32_t *faces, uint32_t flags, uint32_t *mesh_id);
+int edynhip_world_set_bodies(edynhip_world *w, uint32_t n, const edynhip_bodies *bodies);
+int edynhip_world_set_joints(edynhip_world *w, uint32_t n, const edynhip_joints *joints);
+/* edynhip_set_joint_definition (generic = 0: params[16]) / edynhip_set_generic_definition (generic = 1: params[60]) by global joint index */
+int edynhip_world_set_joint_definition(edynhip_world *w, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params, int generic);
+int edynhip_world_exclude_collision(edynhip_world *w, uint32_t body_a, uint32_t body_b);
+/* edyn::step_simulation on every shard, then the gather, the approach test and - when islands of different shards have met - the
+ * re-partition. Returns when the state of the last step is in the world's arrays. */
+int edynhip_world_step(edynhip_world *w, uint32_t nsteps);
+int edynhip_world_get_state(edynhip_world *w, float *pos, float *orn, float *linvel, float *angvel);   /* any may be NULL */
+int edynhip_world_get_partition(edynhip_world *w, int32_t *shard_of_body);   /* -1 = replicated (not dynamic) */
+int edynhip_world_repartition(edynhip_world *w);                             /* re-partition now (load balance / tests) */
+int edynhip_world_get_manifolds(edynhip_world *w, edynhip_manifold *out, uint32_t capacity, uint32_t *n);   /* global indices, canonical order */
+int edynhip_world_get_stats(edynhip_world *w, edynhip_world_stats *out);
+edynhip_ctx *edynhip_world_context(edynhip_world *w, uint32_t shard);        /* a shard's context (read-only use: statistics, timings) */
+
+/* The pieces of the above that processes owning ONE GPU each use (edyn_amd/parallel.py ShardedWorld over torch.distributed / RCCL):
+ * the island partitioner - longest-processing-time-first over the summed weights, deterministic (islands by descending weight, ties
+ * by ascending label, each to the lightest rank, ties to the lowest rank); rank_of[i] = -1 for non-dynamic bodies. weights may be
+ * NULL (1 per body). Host only: no GPU needed. */
+int edynhip_partition_islands(uint32_t n, const uint32_t *island_label, const int32_t *kind, const double *weights, uint32_t world_size, int32_t *rank_of);
+/* island boxes [num][6] (min, max) grown by `margin` on every side that overlap: pairs (label_a < label_b), sorted, without
+ * duplicates; any_owner = 0: only pairs of different owners. pairs may be NULL (count only). Host only. */
+int edynhip_island_boxes_overlap(uint32_t num_islands, const float *boxes6, const uint32_t *labels, const int32_t *owner, float margin, int any_owner,
+                                 uint32_t *pairs, uint32_t capacity, uint32_t *num_pairs);
+/* per island of the context (label = its lowest body index, as edynhip_get_derived returns them) the union of the AABBs of its
+ * shaped dynamic bodies, reduced on the device after the last step. labels / boxes6 may be NULL (count only). */
+int edynhip_get_island_boxes(edynhip_ctx *ctx, uint32_t *labels, float *boxes6, uint32_t capacity, uint32_t *num_islands);
+
 #ifdef __cplusplus
 }
 #endif

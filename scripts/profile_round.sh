@@ -18,11 +18,12 @@ for WL in $WLS; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --workload $WL --steps $STEPS --warmup $WARM --north-star none --no-cpu-baseline > $OUT/${R}_bench_under_rocprof_$WL.json 2> $W/kt.log )
   case $WL in chains16k|ragdolls1k) KN=k_island_velocity;; *) KN=k_contact_solve;; esac
   python scripts/prof_summary.py $W/kt $((SETTLE + STEPS + WARM)) $KN $STEPS > $OUT/${R}_kernel_stats_$WL.txt
-  case $WL in chains16k|ragdolls1k|polyheap32k) continue;; esac   # joint scenes / the polyhedron heap: kernel statistics only (the traffic model is the contact solve's)
+  # HBM-side traffic of the velocity-solve kernels of EVERY workload (r04): two PMC passes, timed region only, scaled per algorithmic byte
+  case $WL in islands256k|islands1m) PS=20;; *) PS=40;; esac
   for C in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps 40 --warmup 5 --north-star none --no-cpu-baseline > /dev/null 2> $W/$C.log )
+    ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps $PS --warmup 5 --north-star none --no-cpu-baseline > $W/$C.json 2> $W/$C.log )
   done
-  python scripts/pmc_traffic.py $W/FETCH_SIZE $W/WRITE_SIZE $WL > $OUT/${R}_traffic_$WL.json
+  python scripts/pmc_traffic.py $W/FETCH_SIZE $W/WRITE_SIZE $WL $W/FETCH_SIZE.json > $OUT/${R}_traffic_$WL.json 2> $OUT/${R}_traffic_$WL.err || true
   if [ $WL = pile32k ]; then
     python scripts/prof_timeline.py $W/kt $((SETTLE + STEPS + WARM - 50)) > $OUT/${R}_timeline_$WL.txt 2>&1 || true
     python bench.py --stage-timing --north-star none --no-cpu-baseline > $OUT/${R}_bench_stage_timing.json 2> /dev/null || true
@@ -31,10 +32,10 @@ for WL in $WLS; do
   fi
 done
 # one traffic.json keyed by workload (what bench.py reads as roofline.traffic)
-python - <<'PY'
+ROUND_TAG=$R python - <<'PY'
 import glob, json, os
 out = {}
-for f in sorted(glob.glob("gpurun_out/*_traffic_*.json")):
+for f in sorted(glob.glob("gpurun_out/%s_traffic_*.json" % os.environ.get("ROUND_TAG", "r04"))):
     try:
         j = json.load(open(f)); out[j["workload"]] = j
     except Exception:

@@ -1,0 +1,103 @@
+// The multi-GPU world of the C-ABI (include/edynhip.h "Multi-GPU world", edyn_amd/csrc/multi.hip) next to ONE context stepping the
+// same scene: six mini-piles (six islands) and a sphere that rolls from the first pile into the second - its island meets an
+// island that lives on the other shard, which forces a re-partition with the contact manifolds carried along; later a forced
+// re-partition. Positions, orientations and velocities must be bit-equal after every step. Two shards on one physical GPU
+// (the reference's island parallelism: src/edyn/dynamics/solver.cpp:408-428).
+#include <edynhip.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s (%s | %s)\n", __FILE__, __LINE__, #c, edynhip_world_last_error(world), one ? edynhip_last_error(one) : ""); return 1; } } while (0)
+
+struct Scene {
+    std::vector<int32_t> kind, shape;
+    std::vector<float> pos, orn, lv, av, mass, param, fric, rest;
+    std::vector<uint64_t> group, mask;
+    std::vector<uint8_t> nosleep;
+    void add(int k, int s, float x, float y, float z, float p0, float p1, float p2, float p3, float vx = 0) {
+        kind.push_back(k); shape.push_back(s);
+        pos.insert(pos.end(), {x, y, z}); orn.insert(orn.end(), {0, 0, 0, 1}); lv.insert(lv.end(), {vx, 0, 0}); av.insert(av.end(), {0, 0, 0});
+        mass.push_back(1); param.insert(param.end(), {p0, p1, p2, p3}); fric.push_back(0.5f); rest.push_back(0);
+        group.push_back(~0ull); mask.push_back(~0ull); nosleep.push_back(1);
+    }
+    edynhip_bodies view() const {
+        edynhip_bodies b{};
+        b.kind = kind.data(); b.pos = pos.data(); b.orn = orn.data(); b.linvel = lv.data(); b.angvel = av.data(); b.mass = mass.data();
+        b.shape_type = shape.data(); b.shape_param = param.data(); b.friction = fric.data(); b.restitution = rest.data();
+        b.group = group.data(); b.mask = mask.data(); b.sleeping_disabled = nosleep.data();
+        return b;
+    }
+    uint32_t n() const { return (uint32_t)kind.size(); }
+};
+
+int main() {
+    edynhip_world *world = nullptr;
+    edynhip_ctx *one = nullptr;
+    Scene sc;
+    sc.add(EDYNHIP_KIND_STATIC, EDYNHIP_SHAPE_PLANE, 0, 0, 0, 0, 1, 0, 0);
+    for (int site = 0; site < 6; ++site)                 // 3 x 2 sites, 8 m apart, a brick-offset 3 x 3 x 3 pile on each
+        for (int k = 0; k < 27; ++k) {
+            const int i = k % 3, j = (k / 3) % 3, l = k / 9;
+            const float off = (j & 1) ? 0.5f : 0.0f;
+            sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_BOX, 8.0f * (site % 3) + 1.02f * i + off + 0.003f * k, 0.505f + 1.005f * j, 8.0f * (site / 3) + 1.02f * l + off, 0.5f, 0.5f, 0.5f, 0);
+        }
+    sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 4.3f, 0.5f, 1.0f, 0.5f, 0, 0, 0, 4.0f);   // between site 0 and site 1, rolling towards +x
+    const uint32_t n = sc.n();
+
+    edynhip_config cfg{};
+    cfg.device = 0; cfg.max_bodies = n + 16; cfg.fixed_dt = 1.0f / 60; cfg.num_velocity_iterations = 10; cfg.num_position_iterations = 3;
+    cfg.gravity[1] = -9.8f;
+    int status = 0;
+    one = edynhip_create(&cfg, &status);
+    REQUIRE(one != nullptr);
+    const edynhip_bodies b = sc.view();
+    REQUIRE(edynhip_set_bodies(one, n, &b) == EDYNHIP_OK);
+
+    const int32_t devices[2] = {0, 0};
+    cfg.max_bodies = 0;
+    world = edynhip_world_create(&cfg, devices, 2, &status);
+    REQUIRE(world != nullptr);
+    REQUIRE(edynhip_world_set_bodies(world, n, &b) == EDYNHIP_OK);
+
+    std::vector<int32_t> part(n), part2(n);
+    REQUIRE(edynhip_world_get_partition(world, part.data()) == EDYNHIP_OK);
+    int on[2] = {0, 0};
+    for (uint32_t i = 1; i < n; ++i) { REQUIRE(part[i] == 0 || part[i] == 1); ++on[part[i]]; }
+    REQUIRE(part[0] == -1 && on[0] > 27 && on[1] > 27);
+    for (int site = 0; site < 6; ++site)                 // an island is never split
+        for (int k = 1; k < 27; ++k) REQUIRE(part[1 + 27 * site + k] == part[1 + 27 * site]);
+
+    std::vector<float> p1(3 * n), q1(4 * n), v1(3 * n), w1(3 * n), p2(3 * n), q2(4 * n), v2(3 * n), w2(3 * n);
+    for (int step = 0; step < 120; ++step) {
+        REQUIRE(edynhip_step(one, 1) == EDYNHIP_OK);
+        REQUIRE(edynhip_world_step(world, 1) == EDYNHIP_OK);
+        REQUIRE(edynhip_get_state(one, p1.data(), q1.data(), v1.data(), w1.data()) == EDYNHIP_OK);
+        REQUIRE(edynhip_world_get_state(world, p2.data(), q2.data(), v2.data(), w2.data()) == EDYNHIP_OK);
+        if (std::memcmp(p1.data(), p2.data(), p1.size() * 4) || std::memcmp(q1.data(), q2.data(), q1.size() * 4) ||
+            std::memcmp(v1.data(), v2.data(), v1.size() * 4) || std::memcmp(w1.data(), w2.data(), w1.size() * 4)) {
+            std::printf("FAILED: the sharded world left the single context's trajectory at step %d\n", step);
+            return 1;
+        }
+        if (step == 80) REQUIRE(edynhip_world_repartition(world) == EDYNHIP_OK);   // forced: every shard rebuilt mid-run
+    }
+    edynhip_world_stats st{};
+    REQUIRE(edynhip_world_get_stats(world, &st) == EDYNHIP_OK);
+    REQUIRE(st.repartitions >= 2);                       // the sphere's approach + the forced one
+    REQUIRE(st.approach_checks < st.steps);              // the growth budget spares most steps the box sweep
+    REQUIRE(st.bodies_per_shard[0] + st.bodies_per_shard[1] == n);
+    REQUIRE(edynhip_world_get_partition(world, part2.data()) == EDYNHIP_OK);
+    REQUIRE(part2[n - 1] == part2[1 + 27]);              // the sphere now lives with the pile it ran into
+    uint32_t m1 = 0, m2 = 0;
+    REQUIRE(edynhip_num_manifolds(one, &m1) == EDYNHIP_OK);
+    REQUIRE(edynhip_world_get_manifolds(world, nullptr, 0, &m2) == EDYNHIP_OK && m1 == m2);
+    std::vector<edynhip_manifold> a(m1), c(m2);
+    REQUIRE(edynhip_get_manifolds(one, a.data(), m1, &m1) == EDYNHIP_OK && edynhip_world_get_manifolds(world, c.data(), m2, &m2) == EDYNHIP_OK);
+    REQUIRE(std::memcmp(a.data(), c.data(), (size_t)m1 * sizeof(edynhip_manifold)) == 0);
+    std::printf("MULTI_OK %u bodies, %u steps, %u approach checks, %u re-partitions, shards %u + %u bodies, %u manifolds identical\n", n, st.steps,
+                st.approach_checks, st.repartitions, st.bodies_per_shard[0], st.bodies_per_shard[1], m1);
+    edynhip_world_destroy(world);
+    edynhip_destroy(one);
+    return 0;
+}

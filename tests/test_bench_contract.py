@@ -24,7 +24,12 @@ def test_bench_json_contract():
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
     assert d["config"]["settle_steps"] == 20 and d["config"]["colours"] >= 1 and "parity" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    if r["traffic"] is None:   # no kept counter profile for this workload / schedule (pile512 has none): nothing is claimed
+        assert r["achieved"] is None and r["frac"] is None and "no kept" in r["traffic_source"]
+    else:
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["frac_from_algorithmic_bytes_only"] > 0 and r["algorithmic_bytes_per_launch"] > 0
     assert r["kernel"].startswith("k_contact_solve_df") and r["measured_read_ceiling"] > 1000 and r["measured_copy_ceiling"] > 1000
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

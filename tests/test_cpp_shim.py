@@ -196,3 +196,12 @@ def test_shim_ragdoll_over_the_entt_api_registry():
     subprocess.check_call(["make", "-s", "-C", CPP, "ragdoll_entt"])
     out = subprocess.run([os.path.join(CPP, "ragdoll_entt"), "capsule", "run"], capture_output=True, text=True, timeout=300)
     assert "RAGDOLL_RUN_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_world_through_the_c_abi():
+    """tests/cpp/multi.cpp: edynhip_world_* with two shards (on the one GPU of the test box) against one context, bit-equal through
+    an approach-triggered and a forced re-partition; manifolds identical at the end."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "multi"])
+    out = subprocess.run([os.path.join(CPP, "multi")], capture_output=True, text=True, timeout=300)
+    assert "MULTI_OK" in out.stdout, out.stdout + out.stderr

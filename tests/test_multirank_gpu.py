@@ -20,3 +20,87 @@ def test_sharded_hip_worlds_match_the_unsharded_gpu_world(tmp_path):
     ref = _unsharded_states(steps, True)
     assert int(got["reparts"]) >= 1
     assert np.array_equal(got["states"], ref)
+
+
+# ---- the multi-GPU world BEHIND the C-ABI (edynhip_world_*, edyn_amd/csrc/multi.hip) ----------------------
+# Two shards on the one physical GPU of the test box: one process, one host thread per shard, island boxes reduced on the device,
+# re-partitions inside edynhip_world_step. The trajectory must equal ONE context stepping the whole scene, bit for bit.
+def _single_world_states(scene, steps):
+    import edyn_amd
+    from edyn_amd import scenes
+    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10)); w.set_scene(scene); scenes.apply_figure_settings(w, scene)
+    out = []
+    for _ in range(steps):
+        w.step_simulation(1)
+        out.append(np.concatenate(w.get_state(), axis=1))
+    return np.stack(out), w
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_multi_world_matches_one_context_through_an_approach_triggered_repartition(shards):
+    import edyn_amd
+    from test_multirank_gloo import _bridge_scene
+    scene = _bridge_scene()
+    steps = 90
+    ref, single = _single_world_states(scene, steps)
+    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0] * shards)
+    mw.set_scene(scene)
+    part0 = mw.get_partition()
+    assert part0[0] == -1 and set(part0[1:]) == set(range(shards))
+    for k in range(steps):
+        mw.step_simulation(1)
+        assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[k]), k
+    st = mw.get_stats()
+    assert st["repartitions"] >= 1, "the rolling sphere must have forced a re-partition"
+    assert st["approach_checks"] < steps, "a check every step means the growth budget is not working"
+    assert sum(st["bodies_per_shard"]) == len(scene["kind"])
+    gm, sm = mw.get_manifolds(), single.get_manifolds()
+    assert len(gm) == len(sm) and gm.tobytes() == sm.tobytes()     # manifolds incl. impulses and colours, global indices, canonical order
+
+
+def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
+    import edyn_amd
+    from test_multirank_gloo import _jointed_bridge_scene
+    scene = _jointed_bridge_scene()
+    steps = 90
+    ref, _ = _single_world_states(scene, steps)
+    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0])
+    mw.set_scene(scene)
+    for k in range(steps):
+        mw.step_simulation(1)
+        assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[k]), k
+        if k in (30, 60):
+            mw.repartition()   # every shard is rebuilt: the chains swing on with warm-started joints and tracked angles
+    assert mw.get_stats()["repartitions"] >= 3
+
+
+def test_multi_world_with_polyhedra_and_cylinders():
+    import edyn_amd
+    from test_multirank_gloo import _poly_bridge_scene
+    scene = _poly_bridge_scene()
+    steps = 90
+    ref, _ = _single_world_states(scene, steps)
+    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0])
+    mw.set_scene(scene)
+    mw.step_simulation(steps)
+    assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[-1])
+    assert mw.get_stats()["repartitions"] >= 1
+
+
+def test_island_boxes_reduced_on_the_device():
+    """edynhip_get_island_boxes: per island the union of its bodies' AABBs - against numpy on the read-back AABBs and labels."""
+    import ctypes as C
+    import edyn_amd
+    from edyn_amd import scenes, _capi
+    from edyn_amd.parallel import island_boxes
+    scene = scenes.mini_piles(3, 3)
+    w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10)); w.set_scene(scene)
+    w.step_simulation(40)
+    aabb, _, labels = w.get_derived()[:3]
+    isl, boxes, _ = island_boxes(np.asarray(aabb, np.float64), labels, scene["kind"])
+    n = C.c_uint32(0)
+    lab = np.zeros(len(scene["kind"]), np.uint32); bx = np.zeros((len(scene["kind"]), 6), np.float32)
+    assert w._L.edynhip_get_island_boxes(w._h, lab.ctypes.data, bx.ctypes.data, len(lab), C.byref(n)) == 0
+    order = np.argsort(lab[:n.value])
+    assert np.array_equal(lab[:n.value][order], isl.astype(np.uint32))
+    assert np.array_equal(bx[:n.value][order], boxes)
