@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libedynhip.so")
+LIB_PATH = os.environ.get("EDYNHIP_LIB") or os.path.join(_HERE, "libedynhip.so")   # EDYNHIP_LIB: developer A/B runs of two builds on one box
 
 
 class EdynHipError(RuntimeError):

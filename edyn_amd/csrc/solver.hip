@@ -709,30 +709,19 @@ DI float row_relspeed(const Delta &d, const RowReg &r) {
     const f3 Jl = from4(r.f[0]);
     return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
 }
-// solve_friction's clamp to the friction circle (constraint_row_friction.cpp:26-42), shared by every velocity-solve kernel:
-//     if (len2 > max_len^2) { len = sqrt(len2); if (len > eps) { i0 = i0 / len * max_len; i1 = ... } else i0 = i1 = 0; d = i - c; }
-// Same result bit for bit, but the square root and the two divisions (about 45 of a task's ~160 instructions per point: they are
-// IEEE-correct sequences) are only executed when a lane has a SLIDING contact, i.e. max_len != 0. A point whose normal row carries
-// no impulse - every speculative (distance > 0) contact of a pile and the unloaded corners of a resting face - has max_len == 0 and
-// takes this clamp on every visit; there (i / len) * 0 is a zero with the sign of i (|i / len| <= 1: finite), and the test
-// sqrt(len2) > FLT_EPSILON is equivalent to len2 > 0x1.000002p-46f for a correctly rounded square root (checked exhaustively
-// around the boundary). A wave therefore skips the slow path unless one of its lanes slides.
-constexpr float kLen2AboveEps = 0x1.000002p-46f;
+// solve_friction's clamp to the friction circle (constraint_row_friction.cpp:26-42), shared by every velocity-solve kernel.
+// (Round 4, measured and dropped: a branch that spares the square root and the two divisions - a third of a point's instructions -
+// for points without normal impulse, where the result is a signed zero. Bit-identical, but a wave only skips the slow path when
+// none of its 32 manifolds slides in that point slot, and on the settled bench piles 17-28 % of the loaded points sit ON the
+// friction circle: ~90 % of the wave-tasks have a slider in every slot (scripts/sliding_fraction.py). 1.69 vs 1.66 us per task.)
 DI void friction_circle(float &i0, float &i1, float &di0, float &di1, float c0, float c1, float max_len) {
     const float len2 = i0 * i0 + i1 * i1;
-    const bool over = len2 > square(max_len);
-    const bool slow = over && (max_len != 0.0f || !(len2 < 3.0e38f));
-    if (slow) {
+    if (len2 > square(max_len)) {
         const float len = sqrtf(len2);
         if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
         else { i0 = 0; i1 = 0; }
-    } else if (over) {
-        const uint32_t sm = __float_as_uint(max_len) & 0x80000000u;
-        const bool big = len2 > kLen2AboveEps;
-        i0 = big ? __uint_as_float((__float_as_uint(i0) & 0x80000000u) ^ sm) : 0.0f;
-        i1 = big ? __uint_as_float((__float_as_uint(i1) & 0x80000000u) ^ sm) : 0.0f;
+        di0 = i0 - c0; di1 = i1 - c1;
     }
-    if (over) { di0 = i0 - c0; di1 = i1 - c1; }
 }
 // solve(constraint_row&)'s clamp (constraint_row.cpp:38-50) as selects: dimp keeps its computed value unless a limit cuts in
 DI void normal_clamp(float &cur, float &dimp, float upper) {
@@ -1923,8 +1912,11 @@ template <bool WARM>
 DI void df2_dispatch(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
     // lanes are grouped by point count: np is uniform over a wave except at a group boundary. The warm-start sweep runs
     // once and keeps the predicated form only (fewer instantiations: the kernel has to stay within the instruction cache).
+    // Waves of one-point manifolds (sphere contacts: the majority of a mixed scene) get their own instantiation: the NP = 2 form
+    // fetched a second point slot in vain for each of them (round 3: 1.30x the algorithmic traffic on mixed32k) and ran its code.
     if (!WARM && __all(!valid || np == 4u)) df2_task<WARM, 4, true>(a, p, valid, sideB, np, col, sweep, tr);
     else if (!WARM && __all(!valid || np == 2u)) df2_task<WARM, 2, true>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 1u)) df2_task<WARM, 1, true>(a, p, valid, sideB, np, col, sweep, tr);
     else if (__any(np > 2u)) df2_task<WARM, 4, false>(a, p, valid, sideB, np, col, sweep, tr);
     else df2_task<WARM, 2, false>(a, p, valid, sideB, np, col, sweep, tr);
 }
@@ -2493,7 +2485,8 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
         const uint32_t key = a.keys_sorted[p];
         const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
         if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col);
-        else dfp_task<2>(a, p, valid, sideB, np, col);
+        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col);
+        else dfp_task<1>(a, p, valid, sideB, np, col);
     }
 }
 

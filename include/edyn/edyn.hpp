@@ -228,6 +228,13 @@ struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
     unsigned max_steps_per_update{10};
     vector3 gravity{gravity_earth};
     int device{0};
+    // More than one entry: ONE simulation over these GPUs at island granularity (edynhip.h "Multi-GPU world": one shard per device,
+    // islands partitioned by load, re-partitioned when islands of different shards meet) - the reference's island parallelism
+    // (solver.cpp:408-428) across devices. Bodies of every shape, every constraint type, exclusions and settings are supported;
+    // contact entities, contact_extras materials / the mix table, asynchronous mode and step callbacks are single-device features
+    // (attach throws stepper_error EDYNHIP_ERR_UNSUPPORTED when combined); an edit of a running multi-device world (bodies made or
+    // destroyed, edyn::refresh) rebuilds the world from the registry - correct, but the contacts' warm start is lost.
+    std::vector<int> devices{};
     unsigned max_bodies{0};      // 0 = sized at the first upload (count + 25 % head-room)
     unsigned max_manifolds{0};
     bool island_sleeping{true};  // the reference always sleeps islands (bodies opt out with sleeping_disabled)
@@ -249,6 +256,8 @@ namespace detail {
 struct gpu_stepper {
     init_config cfg;
     edynhip_ctx *ctx{nullptr};
+    edynhip_world *world{nullptr};             // init_config::devices names more than one GPU: the multi-GPU world instead of `ctx`
+    bool multi() const { return cfg.devices.size() > 1; }
     std::vector<entt::entity> bodies;          // body index -> entity (creation order); entt::null = destroyed (the index stays reserved)
     std::vector<entt::entity> constraints;     // joint index -> entity, same convention
     std::vector<uint8_t> constraint_kind;      // joint index -> EDYNHIP_JOINT_*: one entity may carry several constraint types (make_ragdoll: cone + cvjoint)
@@ -273,7 +282,7 @@ struct gpu_stepper {
     bool recreate{false};          // a body's mass / inertia / material was edited: the next upload re-creates the context (contacts, joints and sleep state are carried)
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
-    ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); }
+    ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); if (world) edynhip_world_destroy(world); }
 };
 struct body_index { uint32_t value; };
 template <typename T> constexpr int joint_kind_of() {
@@ -304,7 +313,7 @@ inline constraint_base *constraint_of(entt::registry &registry, entt::entity e, 
 }
 
 inline void check(gpu_stepper &s, int rc) {
-    if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + edynhip_last_error(s.ctx));
+    if (rc != EDYNHIP_OK) throw stepper_error(rc, std::string("edynhip: ") + (s.world ? edynhip_world_last_error(s.world) : edynhip_last_error(s.ctx)));
 }
 
 // Joint definitions [first, end) for edynhip_set_joints / edynhip_add_joints. A constraint destroyed before it was ever
@@ -343,6 +352,164 @@ inline void joint_arrays(entt::registry &registry, gpu_stepper &s, uint32_t firs
             for (int k = 0; k < 10; ++k) jq[10 * j + k] = q[k];
         }
     }
+}
+
+// The per-body arrays of edynhip_bodies for bodies [first, first + n) of the stepper's list, from the registry's components.
+struct body_arrays {
+    std::vector<int32_t> kind, stype;
+    std::vector<float> pos, orn, lv, av, m, I, sp, fr, re, g, com, xspin, xroll, xstiff, xdamp;
+    std::vector<uint8_t> hasI, nosleep;
+    std::vector<uint32_t> mat_ids, dead;
+    std::vector<uint64_t> grp, msk;
+    bool any_com{false}, any_extras{false}, any_ids{false};
+    explicit body_arrays(uint32_t n)
+        : kind(n), stype(n), pos(3 * (size_t)n), orn(4 * (size_t)n), lv(3 * (size_t)n), av(3 * (size_t)n), m(n, 1.f), I(9 * (size_t)n, 0.f), sp(4 * (size_t)n, 0.f), fr(n, 0.5f),
+          re(n, 0.f), g(3 * (size_t)n, 0.f), com(3 * (size_t)n, 0.f), xspin(n, 0.f), xroll(n, 0.f), xstiff(n, float(large_scalar)), xdamp(n, float(large_scalar)), hasI(n, 0),
+          nosleep(n, 0), mat_ids(n, 0xFFFFu), grp(n, ~0ull), msk(n, ~0ull) {}
+    edynhip_bodies view() const {
+        return edynhip_bodies{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
+                              fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data(), any_com ? com.data() : nullptr};
+    }
+};
+// mesh_id(polyhedron_shape) -> the id of its mesh in the device context (created there on first sight)
+template <typename MeshId>
+inline void fill_body_arrays(entt::registry &registry, gpu_stepper &s, uint32_t first, uint32_t n, body_arrays &A, MeshId &&mesh_id) {
+    auto &kind = A.kind; auto &stype = A.stype; auto &pos = A.pos; auto &orn = A.orn; auto &lv = A.lv; auto &av = A.av; auto &m = A.m; auto &I = A.I;
+    auto &sp = A.sp; auto &fr = A.fr; auto &re = A.re; auto &g = A.g; auto &com = A.com; auto &xspin = A.xspin; auto &xroll = A.xroll; auto &xstiff = A.xstiff;
+    auto &xdamp = A.xdamp; auto &hasI = A.hasI; auto &nosleep = A.nosleep; auto &mat_ids = A.mat_ids; auto &dead = A.dead; auto &grp = A.grp; auto &msk = A.msk;
+    bool &any_com = A.any_com; bool &any_extras = A.any_extras; bool &any_ids = A.any_ids;
+    for (uint32_t i = 0; i < n; ++i) {
+        const entt::entity e = s.bodies[first + i];
+        if (e == entt::null) {   // destroyed before it was ever uploaded (or before a re-upload): a shapeless static placeholder
+            kind[i] = EDYNHIP_KIND_STATIC; stype[i] = EDYNHIP_SHAPE_NONE; orn[4 * i + 3] = 1.f; dead.push_back(first + i);
+            continue;
+        }
+        kind[i] = registry.all_of<dynamic_tag>(e) ? EDYNHIP_KIND_DYNAMIC : registry.all_of<kinematic_tag>(e) ? EDYNHIP_KIND_KINEMATIC : EDYNHIP_KIND_STATIC;
+        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+        orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
+        if (auto *v = registry.try_get<linvel>(e)) { lv[3 * i] = v->x; lv[3 * i + 1] = v->y; lv[3 * i + 2] = v->z; }
+        if (auto *w = registry.try_get<angvel>(e)) { av[3 * i] = w->x; av[3 * i + 1] = w->y; av[3 * i + 2] = w->z; }
+        if (auto *cm = registry.try_get<center_of_mass>(e)) {   // the device takes the ORIGIN and the offset, and moves position / velocity itself
+            const auto &o = registry.get<origin>(e);
+            const vector3 r{p.x - o.x, p.y - o.y, p.z - o.z};   // centre of mass - origin
+            pos[3 * i] = o.x; pos[3 * i + 1] = o.y; pos[3 * i + 2] = o.z;
+            lv[3 * i] -= av[3 * i + 1] * r.z - av[3 * i + 2] * r.y; lv[3 * i + 1] -= av[3 * i + 2] * r.x - av[3 * i] * r.z; lv[3 * i + 2] -= av[3 * i] * r.y - av[3 * i + 1] * r.x;
+            com[3 * i] = cm->x; com[3 * i + 1] = cm->y; com[3 * i + 2] = cm->z; any_com = true;
+        }
+        if (auto *ms = registry.try_get<mass>(e)) m[i] = ms->s;
+        if (auto *in = registry.try_get<inertia>(e)) {
+            hasI[i] = 1;
+            for (int r = 0; r < 3; ++r) { I[9 * i + 3 * r] = in->row[r].x; I[9 * i + 3 * r + 1] = in->row[r].y; I[9 * i + 3 * r + 2] = in->row[r].z; }
+        }
+        if (auto *b = registry.try_get<box_shape>(e)) { stype[i] = EDYNHIP_SHAPE_BOX; sp[4 * i] = b->half_extents.x; sp[4 * i + 1] = b->half_extents.y; sp[4 * i + 2] = b->half_extents.z; }
+        else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
+        else if (auto *cs = registry.try_get<capsule_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CAPSULE; sp[4 * i] = cs->radius; sp[4 * i + 1] = cs->half_length; sp[4 * i + 2] = (float)(int)cs->axis; }
+        else if (auto *cy = registry.try_get<cylinder_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CYLINDER; sp[4 * i] = cy->radius; sp[4 * i + 1] = cy->half_length; sp[4 * i + 2] = (float)(int)cy->axis; }
+        else if (auto *ph = registry.try_get<polyhedron_shape>(e)) {   // the mesh goes up once per context, however many bodies share it
+            const uint32_t id = mesh_id(*ph);
+            stype[i] = EDYNHIP_SHAPE_POLYHEDRON; sp[4 * i] = (float)id;
+        }
+        else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
+        else stype[i] = EDYNHIP_SHAPE_NONE;
+        if (auto *mt = registry.try_get<material>(e)) {
+            fr[i] = mt->friction; re[i] = mt->restitution;
+            xspin[i] = mt->spin_friction; xroll[i] = mt->roll_friction; xstiff[i] = mt->stiffness; xdamp[i] = mt->damping;
+            any_extras = any_extras || mt->spin_friction > 0 || mt->roll_friction > 0 || mt->stiffness < large_scalar || mt->damping < large_scalar;
+            mat_ids[i] = mt->id; any_ids = any_ids || mt->id != material::UnassignedID;
+        }
+        if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
+        if (registry.all_of<sleeping_disabled_tag>(e)) nosleep[i] = 1;
+        if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
+    }
+}
+
+// frames and parameter blocks of the cone / cvjoint / generic constraints [first_joint, nj): set_def(joint, frame_a, frame_b, params, generic)
+template <typename SetDef>
+inline void upload_joint_defs(entt::registry &registry, gpu_stepper &s, uint32_t first_joint, uint32_t nj, SetDef &&set_def) {
+    for (uint32_t j = first_joint; j < nj; ++j) {
+        const entt::entity e = s.constraints[j];
+        if (e == entt::null) continue;
+        auto rows9 = [](const matrix3x3 &m, float *o) { for (int r = 0; r < 3; ++r) { o[3 * r] = m.row[r].x; o[3 * r + 1] = m.row[r].y; o[3 * r + 2] = m.row[r].z; } };
+        float fa[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, fb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, q[16] = {0};
+        const int kind = s.constraint_kind[j];
+        if (kind == EDYNHIP_JOINT_CONE) {
+            auto *cc = &registry.get<cone_constraint>(e);
+            rows9(cc->frame, fa);
+            q[0] = cc->span_tan[0]; q[1] = cc->span_tan[1]; q[2] = cc->restitution; q[3] = cc->bump_stop_stiffness; q[4] = cc->bump_stop_length;
+            set_def(j, fa, fb, q, false);
+        } else if (kind == EDYNHIP_JOINT_GENERIC) {
+            auto *ge = &registry.get<generic_constraint>(e);
+            rows9(ge->frame[0], fa); rows9(ge->frame[1], fb);
+            float dof[60];
+            for (int d = 0; d < 3; ++d) {
+                const auto &l = ge->linear_dofs[d]; const auto &a = ge->angular_dofs[d];
+                const float lv[10] = {l.limit_enabled ? 1.f : 0.f, l.offset_min, l.offset_max, l.limit_restitution, l.bump_stop_length, l.bump_stop_stiffness,
+                                      l.friction_force, l.rest_offset, l.spring_stiffness, l.damping};
+                const float av[10] = {a.limit_enabled ? 1.f : 0.f, a.angle_min, a.angle_max, a.limit_restitution, a.bump_stop_angle, a.bump_stop_stiffness,
+                                      a.friction_torque, a.rest_angle, a.spring_stiffness, a.damping};
+                for (int k = 0; k < 10; ++k) { dof[10 * d + k] = lv[k]; dof[10 * (3 + d) + k] = av[k]; }
+            }
+            set_def(j, fa, fb, dof, true);
+        } else if (kind == EDYNHIP_JOINT_CVJOINT) {
+            auto *cv = &registry.get<cvjoint_constraint>(e);
+            rows9(cv->frame[0], fa); rows9(cv->frame[1], fb);
+            const float v[15] = {cv->twist_min, cv->twist_max, cv->twist_restitution, cv->twist_bump_stop_angle, cv->twist_bump_stop_stiffness,
+                                 cv->twist_friction_torque, cv->twist_rest_angle, cv->twist_stiffness, cv->twist_damping,
+                                 cv->rest_direction.x, cv->rest_direction.y, cv->rest_direction.z, cv->bend_stiffness, cv->bend_friction_torque, cv->bend_damping};
+            for (int k = 0; k < 15; ++k) q[k] = v[k];
+            set_def(j, fa, fb, q, false);
+        }
+    }
+}
+
+// init_config::devices names several GPUs: the whole scene goes to the multi-GPU world (edynhip_world_*), which takes a scene once -
+// so every (re)upload builds a new world from the registry's current components.
+inline void upload_scene_multi(entt::registry &registry, gpu_stepper &s) {
+    const uint32_t total = (uint32_t)s.bodies.size(), nj = (uint32_t)s.constraints.size();
+    if (s.world) { edynhip_world_destroy(s.world); s.world = nullptr; }
+    if (!s.mixings.empty()) throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "edyn: the material mix table is a single-device feature (init_config::devices)");
+    edynhip_config c{};
+    c.max_manifolds = s.cfg.max_manifolds;
+    c.fixed_dt = s.cfg.fixed_dt;
+    c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
+    c.num_position_iterations = s.cfg.num_solver_position_iterations;
+    c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
+    c.flags = s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u;
+    std::vector<int32_t> devs(s.cfg.devices.begin(), s.cfg.devices.end());
+    int st = 0;
+    s.world = edynhip_world_create(&c, devs.data(), (uint32_t)devs.size(), &st);
+    if (!s.world) throw stepper_error(st, std::string("edynhip_world_create: ") + edynhip_world_last_error(nullptr));
+    s.meshes.clear();
+    body_arrays A(total);
+    fill_body_arrays(registry, s, 0, total, A, [&](const polyhedron_shape &ph) {
+        uint32_t id = ~0u;
+        for (auto &known : s.meshes) if (known.first == ph.mesh) id = known.second;
+        if (id == ~0u) {
+            const convex_mesh &cm = *ph.mesh;
+            std::vector<float> mv(3 * cm.vertices.size());
+            for (size_t k = 0; k < cm.vertices.size(); ++k) { mv[3 * k] = cm.vertices[k].x; mv[3 * k + 1] = cm.vertices[k].y; mv[3 * k + 2] = cm.vertices[k].z; }
+            check(s, edynhip_world_create_convex_mesh(s.world, (uint32_t)cm.vertices.size(), mv.data(), (uint32_t)cm.indices.size(), cm.indices.data(),
+                                                      (uint32_t)cm.num_faces(), cm.faces.data(), cm.initialized ? EDYNHIP_MESH_INITIALIZED : 0u, &id));
+            s.meshes.emplace_back(ph.mesh, id);
+        }
+        return id;
+    });
+    if (A.any_extras || A.any_ids) throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "edyn: contact_extras materials and material ids are single-device features (init_config::devices)");
+    const edynhip_bodies b = A.view();   // destroyed bodies went up as shapeless static placeholders: they take part in nothing
+    check(s, edynhip_world_set_bodies(s.world, total, &b));
+    std::vector<int32_t> jt; std::vector<uint32_t> jb; std::vector<float> jp, ja, jq;
+    std::vector<uint32_t> dead_joints;
+    joint_arrays(registry, s, 0, jt, jb, jp, ja, jq, dead_joints);
+    for (uint32_t j : dead_joints) { jt[j] = EDYNHIP_JOINT_NULL; jb[2 * j] = jb[2 * j + 1] = 0; }   // a destroyed constraint keeps its index: a rowless self-edge
+    edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
+    check(s, edynhip_world_set_joints(s.world, nj, nj ? &js : nullptr));
+    upload_joint_defs(registry, s, 0, nj, [&](uint32_t j, const float *fa, const float *fb, const float *q, bool generic) {
+        check(s, edynhip_world_set_joint_definition(s.world, j, fa, fb, q, generic ? 1 : 0));
+    });
+    for (const auto &e : s.exclusions) check(s, edynhip_world_exclude_collision(s.world, e[0], e[1]));
+    s.uploaded_bodies = total; s.uploaded_constraints = nj; s.exclusions_uploaded = s.exclusions.size();
+    s.scene_dirty = false; s.state_dirty = false;
 }
 
 inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
@@ -415,70 +582,23 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     }
     // Bodies created since the last upload are appended (edynhip_add_bodies): the running contact state of the others stays.
     const uint32_t first = s.uploaded_bodies, n = total - first;
-    std::vector<int32_t> kind(n), stype(n);
-    std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n), m(n, 1.f), I(9 * n, 0.f), sp(4 * n, 0.f), fr(n, 0.5f), re(n, 0.f), g(3 * n, 0.f);
-    std::vector<uint8_t> hasI(n, 0), nosleep(n, 0);
-    std::vector<float> com(3 * n, 0.f); bool any_com = false;
-    std::vector<float> xspin(n, 0.f), xroll(n, 0.f), xstiff(n, float(large_scalar)), xdamp(n, float(large_scalar));
-    std::vector<uint32_t> mat_ids(n, 0xFFFFu);
-    bool any_extras = false, any_ids = false;
-    std::vector<uint64_t> grp(n, ~0ull), msk(n, ~0ull);
-    std::vector<uint32_t> dead;
-    for (uint32_t i = 0; i < n; ++i) {
-        const entt::entity e = s.bodies[first + i];
-        if (e == entt::null) {   // destroyed before it was ever uploaded (or before a re-upload): a shapeless static placeholder
-            kind[i] = EDYNHIP_KIND_STATIC; stype[i] = EDYNHIP_SHAPE_NONE; orn[4 * i + 3] = 1.f; dead.push_back(first + i);
-            continue;
+    body_arrays A(n);
+    fill_body_arrays(registry, s, first, n, A, [&](const polyhedron_shape &ph) {   // the mesh goes up once per context, however many bodies share it
+        uint32_t id = ~0u;
+        for (auto &known : s.meshes) if (known.first == ph.mesh) id = known.second;
+        if (id == ~0u) {
+            const convex_mesh &cm = *ph.mesh;
+            std::vector<float> mv(3 * cm.vertices.size());
+            for (size_t k = 0; k < cm.vertices.size(); ++k) { mv[3 * k] = cm.vertices[k].x; mv[3 * k + 1] = cm.vertices[k].y; mv[3 * k + 2] = cm.vertices[k].z; }
+            check(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)cm.vertices.size(), mv.data(), (uint32_t)cm.indices.size(), cm.indices.data(),
+                                                (uint32_t)cm.num_faces(), cm.faces.data(), cm.initialized ? EDYNHIP_MESH_INITIALIZED : 0u, &id));
+            s.meshes.emplace_back(ph.mesh, id);
         }
-        kind[i] = registry.all_of<dynamic_tag>(e) ? EDYNHIP_KIND_DYNAMIC : registry.all_of<kinematic_tag>(e) ? EDYNHIP_KIND_KINEMATIC : EDYNHIP_KIND_STATIC;
-        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
-        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
-        orn[4 * i] = q.x; orn[4 * i + 1] = q.y; orn[4 * i + 2] = q.z; orn[4 * i + 3] = q.w;
-        if (auto *v = registry.try_get<linvel>(e)) { lv[3 * i] = v->x; lv[3 * i + 1] = v->y; lv[3 * i + 2] = v->z; }
-        if (auto *w = registry.try_get<angvel>(e)) { av[3 * i] = w->x; av[3 * i + 1] = w->y; av[3 * i + 2] = w->z; }
-        if (auto *cm = registry.try_get<center_of_mass>(e)) {   // the device takes the ORIGIN and the offset, and moves position / velocity itself
-            const auto &o = registry.get<origin>(e);
-            const vector3 r{p.x - o.x, p.y - o.y, p.z - o.z};   // centre of mass - origin
-            pos[3 * i] = o.x; pos[3 * i + 1] = o.y; pos[3 * i + 2] = o.z;
-            lv[3 * i] -= av[3 * i + 1] * r.z - av[3 * i + 2] * r.y; lv[3 * i + 1] -= av[3 * i + 2] * r.x - av[3 * i] * r.z; lv[3 * i + 2] -= av[3 * i] * r.y - av[3 * i + 1] * r.x;
-            com[3 * i] = cm->x; com[3 * i + 1] = cm->y; com[3 * i + 2] = cm->z; any_com = true;
-        }
-        if (auto *ms = registry.try_get<mass>(e)) m[i] = ms->s;
-        if (auto *in = registry.try_get<inertia>(e)) {
-            hasI[i] = 1;
-            for (int r = 0; r < 3; ++r) { I[9 * i + 3 * r] = in->row[r].x; I[9 * i + 3 * r + 1] = in->row[r].y; I[9 * i + 3 * r + 2] = in->row[r].z; }
-        }
-        if (auto *b = registry.try_get<box_shape>(e)) { stype[i] = EDYNHIP_SHAPE_BOX; sp[4 * i] = b->half_extents.x; sp[4 * i + 1] = b->half_extents.y; sp[4 * i + 2] = b->half_extents.z; }
-        else if (auto *sh = registry.try_get<sphere_shape>(e)) { stype[i] = EDYNHIP_SHAPE_SPHERE; sp[4 * i] = sh->radius; }
-        else if (auto *cs = registry.try_get<capsule_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CAPSULE; sp[4 * i] = cs->radius; sp[4 * i + 1] = cs->half_length; sp[4 * i + 2] = (float)(int)cs->axis; }
-        else if (auto *cy = registry.try_get<cylinder_shape>(e)) { stype[i] = EDYNHIP_SHAPE_CYLINDER; sp[4 * i] = cy->radius; sp[4 * i + 1] = cy->half_length; sp[4 * i + 2] = (float)(int)cy->axis; }
-        else if (auto *ph = registry.try_get<polyhedron_shape>(e)) {   // the mesh goes up once per context, however many bodies share it
-            uint32_t id = ~0u;
-            for (auto &known : s.meshes) if (known.first == ph->mesh) id = known.second;
-            if (id == ~0u) {
-                const convex_mesh &cm = *ph->mesh;
-                std::vector<float> mv(3 * cm.vertices.size());
-                for (size_t k = 0; k < cm.vertices.size(); ++k) { mv[3 * k] = cm.vertices[k].x; mv[3 * k + 1] = cm.vertices[k].y; mv[3 * k + 2] = cm.vertices[k].z; }
-                check(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)cm.vertices.size(), mv.data(), (uint32_t)cm.indices.size(), cm.indices.data(),
-                                                    (uint32_t)cm.num_faces(), cm.faces.data(), cm.initialized ? EDYNHIP_MESH_INITIALIZED : 0u, &id));
-                s.meshes.emplace_back(ph->mesh, id);
-            }
-            stype[i] = EDYNHIP_SHAPE_POLYHEDRON; sp[4 * i] = (float)id;
-        }
-        else if (auto *pl = registry.try_get<plane_shape>(e)) { stype[i] = EDYNHIP_SHAPE_PLANE; sp[4 * i] = pl->normal.x; sp[4 * i + 1] = pl->normal.y; sp[4 * i + 2] = pl->normal.z; sp[4 * i + 3] = pl->constant; }
-        else stype[i] = EDYNHIP_SHAPE_NONE;
-        if (auto *mt = registry.try_get<material>(e)) {
-            fr[i] = mt->friction; re[i] = mt->restitution;
-            xspin[i] = mt->spin_friction; xroll[i] = mt->roll_friction; xstiff[i] = mt->stiffness; xdamp[i] = mt->damping;
-            any_extras = any_extras || mt->spin_friction > 0 || mt->roll_friction > 0 || mt->stiffness < large_scalar || mt->damping < large_scalar;
-            mat_ids[i] = mt->id; any_ids = any_ids || mt->id != material::UnassignedID;
-        }
-        if (auto *f = registry.try_get<collision_filter>(e)) { grp[i] = f->group; msk[i] = f->mask; }
-        if (registry.all_of<sleeping_disabled_tag>(e)) nosleep[i] = 1;
-        if (auto *gr = registry.try_get<gravity>(e)) { g[3 * i] = gr->x; g[3 * i + 1] = gr->y; g[3 * i + 2] = gr->z; }
-    }
-    edynhip_bodies b{kind.data(), pos.data(), orn.data(), lv.data(), av.data(), m.data(), I.data(), hasI.data(), stype.data(), sp.data(),
-                     fr.data(), re.data(), grp.data(), msk.data(), g.data(), nosleep.data(), any_com ? com.data() : nullptr};
+        return id;
+    });
+    const edynhip_bodies b = A.view();
+    auto &xspin = A.xspin; auto &xroll = A.xroll; auto &xstiff = A.xstiff; auto &xdamp = A.xdamp; auto &mat_ids = A.mat_ids; auto &dead = A.dead;
+    const bool any_extras = A.any_extras, any_ids = A.any_ids;
     if (first == 0) check(s, edynhip_set_bodies(s.ctx, n, &b));
     else if (n) check(s, edynhip_add_bodies(s.ctx, n, &b));
     if (any_extras) check(s, edynhip_set_material_extras(s.ctx, first, n, xspin.data(), xroll.data(), xstiff.data(), xdamp.data()));
@@ -512,41 +632,9 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         uint32_t first_joint = 0;
         check(s, edynhip_add_joints(s.ctx, nj - s.uploaded_constraints, &js, &first_joint));
     }
-    // frames and parameter blocks of the cone / cvjoint constraints that went up just now
-    for (uint32_t j = (first == 0 ? 0u : s.uploaded_constraints); j < nj; ++j) {
-        const entt::entity e = s.constraints[j];
-        if (e == entt::null) continue;
-        auto rows9 = [](const matrix3x3 &m, float *o) { for (int r = 0; r < 3; ++r) { o[3 * r] = m.row[r].x; o[3 * r + 1] = m.row[r].y; o[3 * r + 2] = m.row[r].z; } };
-        float fa[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, fb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, q[16] = {0};
-        const int kind = s.constraint_kind[j];
-        if (kind == EDYNHIP_JOINT_CONE) {
-            auto *cc = &registry.get<cone_constraint>(e);
-            rows9(cc->frame, fa);
-            q[0] = cc->span_tan[0]; q[1] = cc->span_tan[1]; q[2] = cc->restitution; q[3] = cc->bump_stop_stiffness; q[4] = cc->bump_stop_length;
-            check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
-        } else if (kind == EDYNHIP_JOINT_GENERIC) {
-            auto *ge = &registry.get<generic_constraint>(e);
-            rows9(ge->frame[0], fa); rows9(ge->frame[1], fb);
-            float dof[60];
-            for (int d = 0; d < 3; ++d) {
-                const auto &l = ge->linear_dofs[d]; const auto &a = ge->angular_dofs[d];
-                const float lv[10] = {l.limit_enabled ? 1.f : 0.f, l.offset_min, l.offset_max, l.limit_restitution, l.bump_stop_length, l.bump_stop_stiffness,
-                                      l.friction_force, l.rest_offset, l.spring_stiffness, l.damping};
-                const float av[10] = {a.limit_enabled ? 1.f : 0.f, a.angle_min, a.angle_max, a.limit_restitution, a.bump_stop_angle, a.bump_stop_stiffness,
-                                      a.friction_torque, a.rest_angle, a.spring_stiffness, a.damping};
-                for (int k = 0; k < 10; ++k) { dof[10 * d + k] = lv[k]; dof[10 * (3 + d) + k] = av[k]; }
-            }
-            check(s, edynhip_set_generic_definition(s.ctx, j, fa, fb, dof));
-        } else if (kind == EDYNHIP_JOINT_CVJOINT) {
-            auto *cv = &registry.get<cvjoint_constraint>(e);
-            rows9(cv->frame[0], fa); rows9(cv->frame[1], fb);
-            const float v[15] = {cv->twist_min, cv->twist_max, cv->twist_restitution, cv->twist_bump_stop_angle, cv->twist_bump_stop_stiffness,
-                                 cv->twist_friction_torque, cv->twist_rest_angle, cv->twist_stiffness, cv->twist_damping,
-                                 cv->rest_direction.x, cv->rest_direction.y, cv->rest_direction.z, cv->bend_stiffness, cv->bend_friction_torque, cv->bend_damping};
-            for (int k = 0; k < 15; ++k) q[k] = v[k];
-            check(s, edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
-        }
-    }
+    upload_joint_defs(registry, s, first == 0 ? 0u : s.uploaded_constraints, nj, [&](uint32_t j, const float *fa, const float *fb, const float *q, bool generic) {
+        check(s, generic ? edynhip_set_generic_definition(s.ctx, j, fa, fb, q) : edynhip_set_joint_definition(s.ctx, j, fa, fb, q));
+    });
     if (regrown && !carried_impulses.empty()) {   // joints created since then start from zero impulses, like any new joint
         // (a joint made just now keeps the angle reset_angle gave it: its carried slot is not applied)
         const uint32_t had = (uint32_t)std::min<size_t>(carried_angles.size(), nj);
@@ -805,6 +893,24 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
         }
         sync_contacts(registry, s);
         s.snapshot_pending = false;
+    }
+    if (s.multi()) {   // init_config::devices: the multi-GPU world (see upload_scene_multi)
+        if (async || s.pre_step || s.post_step || s.cfg.contact_point_data)
+            throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "edyn: asynchronous mode, step callbacks and contact entities are single-device features (init_config::devices)");
+        const size_t gone_before = (size_t)std::count(s.bodies.begin(), s.bodies.end(), entt::entity{entt::null}) + (size_t)std::count(s.constraints.begin(), s.constraints.end(), entt::entity{entt::null});
+        sync_removed(registry, s);
+        const size_t gone_after = (size_t)std::count(s.bodies.begin(), s.bodies.end(), entt::entity{entt::null}) + (size_t)std::count(s.constraints.begin(), s.constraints.end(), entt::entity{entt::null});
+        if (gone_after != gone_before || s.params_dirty) s.scene_dirty = true;   // settings travel with the world's creation
+        s.params_dirty = false;
+        if (s.bodies.empty()) return;
+        if (s.scene_dirty || s.state_dirty || !s.world) upload_scene_multi(registry, s);
+        if (steps == 0) return;
+        check(s, edynhip_world_step(s.world, steps));
+        const uint32_t n = (uint32_t)s.bodies.size();
+        std::vector<float> pos(3 * (size_t)n), orn(4 * (size_t)n), lv(3 * (size_t)n), av(3 * (size_t)n);
+        check(s, edynhip_world_get_state(s.world, pos.data(), orn.data(), lv.data(), av.data()));
+        import_state(registry, s, pos, orn, lv, av, n);
+        return;
     }
     sync_removed(registry, s);
     if (s.scene_dirty) upload_scene(registry, s);

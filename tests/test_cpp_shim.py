@@ -205,3 +205,12 @@ def test_multi_gpu_world_through_the_c_abi():
     subprocess.check_call(["make", "-s", "-C", CPP, "multi"])
     out = subprocess.run([os.path.join(CPP, "multi")], capture_output=True, text=True, timeout=300)
     assert "MULTI_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_attach_with_several_devices():
+    """edyn::attach with init_config::devices = {0, 0}: the registry program of the reference over the multi-GPU world - bit-equal to the
+    single-device stepper until the running world is edited, rebuilt from the registry afterwards (tests/cpp/multi_shim.cpp)."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "multi_shim"])
+    out = subprocess.run([os.path.join(CPP, "multi_shim")], capture_output=True, text=True, timeout=300)
+    assert "MULTI_SHIM_OK" in out.stdout, out.stdout + out.stderr

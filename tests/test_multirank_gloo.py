@@ -257,3 +257,18 @@ def test_sharded_world_carries_joints_and_exclusions_across_a_repartition(tmp_pa
         ref.append(np.concatenate(w.get_state(), axis=1))
     assert int(got["reparts"]) >= 2
     assert np.array_equal(got["states"], np.stack(ref))
+
+
+def test_sharded_world_over_eight_gloo_ranks(tmp_path):
+    """world_size 8: the bridge scene has seven islands - one rank owns nothing but the replicated plane, the
+    partition (the library's edynhip_partition_islands) is identical on every rank, the approach check and the re-partition run on
+    all eight - and the trajectory equals the unsharded world bit for bit."""
+    steps = 60
+    out = str(tmp_path / "sharded8.npz")
+    port = 29500 + (os.getpid() % 2000) + 31
+    mp.spawn(_sharded_worker, args=(8, port, steps, out, False), nprocs=8, join=True)
+    got = np.load(out)
+    ref = _unsharded_states(steps, False)
+    assert int(got["reparts"]) >= 1
+    assert got["owners"].sum() == ref.shape[1] - 1 and (got["owners"] == 0).sum() >= 1    # more ranks than islands: some own nothing
+    assert np.array_equal(got["states"], ref)
