@@ -698,16 +698,46 @@ DI void apply_impulse(Delta &d, f3 J0, f3 J1, f3 J2, f3 J3, float imp) {   // ap
 // (solve(constraint_row&) + apply_row_impulse, then solve_friction, per point in list order).
 // Loads are all issued up front: indices -> {body deltas, every row of every point} -> arithmetic -> stores.
 struct RowReg { float4 f[kRowF]; };
+// ---- the arithmetic of a contact's normal and friction rows ("fused rows", round 4) -------------------------------------------------
+// The velocity solve is a dependency chain: what bounds a step is the number of instructions between "a body's deltas arrived" and
+// "its deltas are handed on" (DESIGN.md section 3). These rows therefore use the row equations of constraint_row.cpp:24-57 and
+// constraint_row_friction.cpp:11-54 written with fused multiply-adds and fewer operations - 385 instead of 619 instructions for a
+// four-point manifold in the two-lane kernel. The specification is the checker's coloured order (its header states the same rules);
+// every velocity-solve kernel of this file - per colour, island-fused, one / two / four lanes per manifold - computes it bit for bit:
+//   dot(a, b)      = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x))
+//   relative speed = (lin_A + ang_A) + (lin_B + ang_B)
+//   delta          = fma(-relative speed, eff, rhs * eff)
+//   normal row     : new = min(max(impulse + delta, 0), upper), applied = new - impulse
+//   friction pair  : both impulses times max_len / len (ONE correctly rounded division) when outside the circle, applied = new - old
+//   apply          : delta_v = fma(M^-1 J, applied, delta_v) per component
+// Joint rows, contact_extras rows and the restitution solver keep the reference's operation order.
+DI float dot3_fma(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+DI f3 fma3(f3 w, float s, f3 acc) { return mk3(__builtin_fmaf(w.x, s, acc.x), __builtin_fmaf(w.y, s, acc.y), __builtin_fmaf(w.z, s, acc.z)); }
+DI float fused_delta(float rel, float eff, float rhs_eff) { return __builtin_fmaf(-rel, eff, rhs_eff); }
+DI float fused_normal(float &cur, float dimp, float upper) {   // returns the applied impulse
+    const float nw = __builtin_fminf(__builtin_fmaxf(cur + dimp, 0.0f), upper);
+    const float applied = nw - cur;
+    cur = nw;
+    return applied;
+}
+DI void fused_circle(float &i0, float &i1, float max_len) {
+    const float len2 = __builtin_fmaf(i1, i1, i0 * i0);
+    if (len2 > max_len * max_len) {
+        const float len = sqrtf(len2);
+        const float sc = len > kEps ? max_len / len : 0.0f;
+        i0 *= sc; i1 *= sc;
+    }
+}
 DI void row_apply(Delta &d, const RowReg &r, float imp) {   // apply_row_impulse with precomputed I^-1 J^T
     const f3 Jl = from4(r.f[0]);
-    d.dvA += d.imA * Jl * imp;
-    d.dvB += d.imB * (-Jl) * imp;
-    d.dwA += from4(r.f[3]) * imp;
-    d.dwB += from4(r.f[4]) * imp;
+    d.dvA = fma3(d.imA * Jl, imp, d.dvA);
+    d.dvB = fma3(d.imB * (-Jl), imp, d.dvB);
+    d.dwA = fma3(from4(r.f[3]), imp, d.dwA);
+    d.dwB = fma3(from4(r.f[4]), imp, d.dwB);
 }
 DI float row_relspeed(const Delta &d, const RowReg &r) {
     const f3 Jl = from4(r.f[0]);
-    return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
+    return (dot3_fma(Jl, d.dvA) + dot3_fma(from4(r.f[1]), d.dwA)) + (dot3_fma(-Jl, d.dvB) + dot3_fma(from4(r.f[2]), d.dwB));
 }
 // solve_friction's clamp to the friction circle (constraint_row_friction.cpp:26-42), shared by every velocity-solve kernel.
 // (Round 4, measured and dropped: a branch that spares the square root and the two divisions - a third of a point's instructions -
@@ -758,12 +788,10 @@ DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
         if (WARM) {
             row_apply(d, r, r.f[2].w);
         } else {
-            float drel = row_relspeed(d, r);
-            float dimp = (r.f[1].w - drel) * r.f[0].w;
             float cur = r.f[2].w;
-            normal_clamp(cur, dimp, r.f[4].w);   // upper = large_scalar, or a soft contact's force limit
+            const float applied = fused_normal(cur, fused_delta(row_relspeed(d, r), r.f[0].w, r.f[1].w * r.f[0].w), r.f[4].w);   // upper = large_scalar, or a soft contact's force limit
             r.f[2].w = cur;
-            row_apply(d, r, dimp);
+            row_apply(d, r, applied);
         }
     }
 #pragma unroll
@@ -774,14 +802,13 @@ DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
             row_apply(d, ra, ra.f[2].w);
             row_apply(d, rb, rb.f[2].w);
         } else {
-            float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
-            float i0 = ra.f[2].w + di0;
-            float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
-            float i1 = rb.f[2].w + di1;
-            friction_circle(i0, i1, di0, di1, ra.f[2].w, rb.f[2].w, R[k][0].f[3].w * R[k][0].f[2].w);   // mu * current normal impulse
+            const float c0 = ra.f[2].w, c1 = rb.f[2].w;
+            float i0 = c0 + fused_delta(row_relspeed(d, ra), ra.f[0].w, ra.f[1].w * ra.f[0].w);
+            float i1 = c1 + fused_delta(row_relspeed(d, rb), rb.f[0].w, rb.f[1].w * rb.f[0].w);
+            fused_circle(i0, i1, R[k][0].f[3].w * R[k][0].f[2].w);   // mu * current normal impulse
             ra.f[2].w = i0; rb.f[2].w = i1;
-            row_apply(d, ra, di0);
-            row_apply(d, rb, di1);
+            row_apply(d, ra, i0 - c0);
+            row_apply(d, rb, i1 - c1);
         }
     }
 }
@@ -809,12 +836,10 @@ DI void rows_solve_normals(Delta &d, RowReg (&Rn)[NP], uint32_t np) {
         if (WARM) {
             row_apply(d, r, r.f[2].w);
         } else {
-            float drel = row_relspeed(d, r);
-            float dimp = (r.f[1].w - drel) * r.f[0].w;
             float cur = r.f[2].w;
-            normal_clamp(cur, dimp, kLarge);
+            const float applied = fused_normal(cur, fused_delta(row_relspeed(d, r), r.f[0].w, r.f[1].w * r.f[0].w), kLarge);
             r.f[2].w = cur;
-            row_apply(d, r, dimp);
+            row_apply(d, r, applied);
         }
     }
 }
@@ -824,14 +849,13 @@ DI void rows_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) 
         row_apply(d, ra, ra.f[2].w);
         row_apply(d, rb, rb.f[2].w);
     } else {
-        float di0 = (ra.f[1].w - row_relspeed(d, ra)) * ra.f[0].w;
-        float i0 = ra.f[2].w + di0;
-        float di1 = (rb.f[1].w - row_relspeed(d, rb)) * rb.f[0].w;
-        float i1 = rb.f[2].w + di1;
-        friction_circle(i0, i1, di0, di1, ra.f[2].w, rb.f[2].w, rn.f[3].w * rn.f[2].w);   // mu * current normal impulse
+        const float c0 = ra.f[2].w, c1 = rb.f[2].w;
+        float i0 = c0 + fused_delta(row_relspeed(d, ra), ra.f[0].w, ra.f[1].w * ra.f[0].w);
+        float i1 = c1 + fused_delta(row_relspeed(d, rb), rb.f[0].w, rb.f[1].w * rb.f[0].w);
+        fused_circle(i0, i1, rn.f[3].w * rn.f[2].w);   // mu * current normal impulse
         ra.f[2].w = i0; rb.f[2].w = i1;
-        row_apply(d, ra, di0);
-        row_apply(d, rb, di1);
+        row_apply(d, ra, i0 - c0);
+        row_apply(d, rb, i1 - c1);
     }
 }
 // contact_extras rows of one manifold after its normal and friction rows: the rolling pairs of all points, then the
@@ -1726,6 +1750,74 @@ DI void pos_apply(PBody &x, f3 Jl, f3 Ja, float corr) {
     m3 basis = to_m3(x.orn);
     x.iw = mul(mul(basis, x.il), transpose(basis));
 }
+DI float xchg1(float v) {   // value held by the partner lane (lane ^ 1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+}
+DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
+// ---- position correction of one contact point, one body per lane: the coloured order's own arithmetic ("fused", round 4) -----------
+// The position solve walks the same dependency chains as the velocity solve with 2.2x the work per task - per point a quaternion
+// rotation of the pivot and the normal, the product I_w Ja through a freshly rebuilt world inertia (two 3x3 products), five correctly
+// rounded divisions. Like the velocity rows it therefore has its own arithmetic in the coloured order (specified by the checker's
+// coloured order, reproduced here bit for bit, within SURVEY 8(d)'s tolerances of the reference's): the same correction
+// (contact_constraint.cpp:58-90, position_solver.hpp:16-51) written with
+//   * R = the rotation matrix of the (unit) orientation, built without the renormalising division, used for the pivot, the normal
+//     and the inertia product I_w Ja = R (I_l (R^T Ja)) - three matrix-vector products instead of two matrix-matrix ones;
+//   * every dot product as an fma chain; 1 / ((t1 + t2) + (o1 + o2)) for the effective mass;
+//   * the re-normalisation of the orientation as ONE division, q * (1 / |q|).
+// The body record's world inertia is not read by contacts any more; it is rebuilt (reference arithmetic) from the final orientation
+// by whoever stores the body, for the joints' position solve and the next step.
+DI m3 basis_unit(q4 q) {
+    const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+    const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    const float xx = q.x * xs, yy = q.y * ys, zz = q.z * zs;
+    return {{1.0f - (yy + zz), __builtin_fmaf(q.x, ys, -wz), __builtin_fmaf(q.x, zs, wy)},
+            {__builtin_fmaf(q.x, ys, wz), 1.0f - (xx + zz), __builtin_fmaf(q.y, zs, -wx)},
+            {__builtin_fmaf(q.x, zs, -wy), __builtin_fmaf(q.y, zs, wx), 1.0f - (xx + yy)}};
+}
+DI f3 mv_fma(const m3 &m, f3 v) { return mk3(dot3_fma(m.r0, v), dot3_fma(m.r1, v), dot3_fma(m.r2, v)); }
+DI f3 mtv_fma(const m3 &m, f3 v) {   // transpose(m) * v
+    return mk3(__builtin_fmaf(m.r2.x, v.z, __builtin_fmaf(m.r1.x, v.y, m.r0.x * v.x)), __builtin_fmaf(m.r2.y, v.z, __builtin_fmaf(m.r1.y, v.y, m.r0.y * v.x)),
+               __builtin_fmaf(m.r2.z, v.z, __builtin_fmaf(m.r1.z, v.y, m.r0.z * v.x)));
+}
+DI f3 cross_fma(f3 a, f3 b) { return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))); }
+// One point, this lane's body X (sideB: X is body[1]); piv = (pivot of X, .w: distance on side A), l4 = local normal, n4 = (normal, attachment).
+// Both lanes of the pair must execute it together (DPP exchanges). Returns true when X was corrected.
+DI bool pos_point_fused(PBody &X, bool sideB, float4 &piv, const float4 &l4, float4 &n4, float &max_err) {
+    const int attach = __float_as_int(n4.w);
+    const m3 R = basis_unit(X.orn);
+    const f3 pXw = mv_fma(R, from4(piv)) + X.org;
+    const f3 pOw = xchg1(pXw);
+    const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
+    // the normal rotates with the body it is attached to; that body's lane computes it and shares it
+    const f3 nrot = mv_fma(R, from4(l4));
+    const f3 nother = xchg1(nrot);
+    f3 n = from4(n4);
+    if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
+    else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
+    const float distance = dot3_fma(pAw - pBw, n);
+    const f3 rX = pXw - X.pos;
+    n4 = to4(n, n4.w);
+    piv.w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
+    if (distance > -kEps) return false;
+    // J = {n, rA x n, -n, -(rB x n)}
+    const f3 Jl = sideB ? -n : n;
+    const f3 cx = cross_fma(rX, n);
+    const f3 Ja = sideB ? -cx : cx;
+    const f3 w = mv_fma(R, mv_fma(X.il, mtv_fma(R, Ja)));   // I_w Ja
+    const float mine = dot3_fma(Jl, Jl) * X.inv_m + dot3_fma(w, Ja);
+    const float em = 1.0f / (mine + xchg1(mine));
+    const float corr = (-distance * 0.2f) * em;
+    max_err = fmaxf(fabsf(distance), max_err);
+    if (!X.proc) return false;
+    X.pos = fma3(X.inv_m * Jl, corr, X.pos);
+    const q4 q = X.orn + quaternion_derivative(X.orn, w * corr);
+    const float l2 = __builtin_fmaf(q.w, q.w, __builtin_fmaf(q.z, q.z, __builtin_fmaf(q.y, q.y, q.x * q.x)));
+    const float rl = 1.0f / sqrtf(l2);
+    X.orn = q4{q.x * rl, q.y * rl, q.z * rl, q.w * rl};
+    if (X.has_com) X.org = to_world(-X.com, X.pos, X.orn); else X.org = X.pos;   // position_solver.hpp:34-41
+    return true;
+}
+DI void pos_rebuild_inertia(PBody &X) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); }   // update_inertia, reference arithmetic
 // position_solver.hpp:34-41: after a correction the origins follow the new transforms (a body without an offset has none: its pivots use pos)
 DI void pos_origin(PBody &x) { if (x.has_com) x.org = to_world(-x.com, x.pos, x.orn); else x.org = x.pos; }
 DI void pos_solve(PBody &A, PBody &B, f3 J0, f3 J1, f3 J2, f3 J3, float error, float &max_err) {
@@ -1757,10 +1849,6 @@ DI void publish_error(bool active, float max_err, uint32_t label, float *isl_err
 // position_solver::solve does), and the two bodies' updates are independent, so each lane owns one body. The few
 // shared scalars (world pivots, normal, effective-mass terms) are swapped with the partner lane through DPP.
 // Every quantity is computed by exactly the same fp32 operations in the same order as the one-lane formulation.
-DI float xchg1(float v) {   // value held by the partner lane (lane ^ 1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
-}
-DI f3 xchg1(f3 v) { return {xchg1(v.x), xchg1(v.y), xchg1(v.z)}; }
 
 // ---- dataflow velocity sweep, two lanes per manifold (even lane = body A's side, odd lane = body B's side) ----
 // The per-hop cost of k_contact_solve_df is "notice the hand-off" + the manifold's arithmetic, and the arithmetic is a
@@ -1788,12 +1876,12 @@ DI void df2_poll(const float4 *slot, v4f &h0, v4f &h1) {
 }
 struct Side { f3 dv, dw; };
 DI float df2_relspeed(const Side &x, const Row2 &r) {
-    const float lin = dot(r.jl, x.dv), ang = dot(r.ja, x.dw);
-    return dppA(lin) + dppA(ang) + dppB(lin) + dppB(ang);
+    const float p = dot3_fma(r.jl, x.dv) + dot3_fma(r.ja, x.dw);   // this side's half
+    return p + xchg1(p);                                            // (A's half) + (B's half): the same bits in both lanes
 }
 DI void df2_apply(Side &x, const Row2 &r, float imp) {
-    x.dv += r.ijl * imp;
-    x.dw += r.ija * imp;
+    x.dv = fma3(r.ijl, imp, x.dv);
+    x.dw = fma3(r.ija, imp, x.dw);
 }
 template <bool WARM>
 DI void df2_point(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
@@ -1802,9 +1890,8 @@ DI void df2_point(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
         df2_apply(x, rn, rn.imp);
         return;
     }
-    float dimp = (rn.rhs - df2_relspeed(x, rn)) * rn.eff;
-    normal_clamp(rn.imp, dimp, kLarge);
-    df2_apply(x, rn, dimp);
+    const float applied = fused_normal(rn.imp, fused_delta(df2_relspeed(x, rn), rn.eff, rn.rhs), kLarge);   // Row2::rhs holds rhs * eff (prepared before the wait)
+    df2_apply(x, rn, applied);
     (void)ra; (void)rb; (void)mu;
 }
 template <bool WARM>
@@ -1816,14 +1903,12 @@ DI void df2_friction(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
         return;
     }
     const float c0 = ra.imp, c1 = rb.imp;
-    float di0 = (ra.rhs - df2_relspeed(x, ra)) * ra.eff;
-    float i0 = c0 + di0;
-    float di1 = (rb.rhs - df2_relspeed(x, rb)) * rb.eff;
-    float i1 = c1 + di1;
-    friction_circle(i0, i1, di0, di1, c0, c1, mu * R[0].imp);   // mu * current normal impulse
+    float i0 = c0 + fused_delta(df2_relspeed(x, ra), ra.eff, ra.rhs);
+    float i1 = c1 + fused_delta(df2_relspeed(x, rb), rb.eff, rb.rhs);
+    fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
     ra.imp = i0; rb.imp = i1;
-    df2_apply(x, ra, di0);
-    df2_apply(x, rb, di1);
+    df2_apply(x, ra, i0 - c0);
+    df2_apply(x, rb, i1 - c1);
 }
 // EXACT: every live lane of the wave has exactly NP points (the common case: lanes are grouped by point count), so the
 // rows need no per-lane point-count predicate.
@@ -1849,7 +1934,7 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
             q.ijl = im * q.jl;
             q.ja = from4(fa); q.ija = from4(fi);
             q.eff = f0.w;
-            q.rhs = dppA(fa.w); q.imp = dppB(fa.w);
+            q.rhs = dppA(fa.w) * f0.w; q.imp = dppB(fa.w);
             if (r == 0) mu[k] = dppA(fi.w);
         }
     }
@@ -1965,44 +2050,35 @@ DI void df4_publish(float4 *piece, f3 d, uint32_t tag) {
     const v4f v = {d.x, d.y, d.z, __uint_as_float(tag)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(piece), "v"(v) : "memory");
 }
-DI float df4_relspeed(const f3 &x, const Row4 &r) {
-    const float t = dot(r.j, x);
-    return qb0(t) + qb1(t) + qb2(t) + qb3(t);
+DI float xchg2(float v) {   // value held by the lane two away inside the quad (lane ^ 2)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
+}
+DI float df4_relspeed(const f3 &x, const Row4 &r) {   // (lin_A + ang_A) + (lin_B + ang_B): roles 0..3 = A linear, A angular, B linear, B angular
+    const float t = dot3_fma(r.j, x);
+    const float side = t + xchg1(t);
+    return side + xchg2(side);
 }
 template <bool WARM>
-DI void df4_normal(f3 &x, Row4 &rn) {
-    if (WARM) { x += rn.ij * rn.imp; return; }
-    float dimp = (rn.rhs - df4_relspeed(x, rn)) * rn.eff;
-    const float imp = rn.imp + dimp;
-    if (imp < 0.0f) { dimp = 0.0f - rn.imp; rn.imp = 0.0f; }
-    else if (imp > kLarge) { dimp = kLarge - rn.imp; rn.imp = kLarge; }
-    else rn.imp = imp;
-    x += rn.ij * dimp;
+DI void df4_normal(f3 &x, Row4 &rn) {   // Row4::rhs holds rhs * eff
+    if (WARM) { x = fma3(rn.ij, rn.imp, x); return; }
+    const float applied = fused_normal(rn.imp, fused_delta(df4_relspeed(x, rn), rn.eff, rn.rhs), kLarge);
+    x = fma3(rn.ij, applied, x);
 }
 template <bool WARM>
 DI void df4_friction(f3 &x, Row4 (&R)[kRowsPerPoint], float mu) {
     Row4 &ra = R[1], &rb = R[2];
     if (WARM) {   // warm_start(constraint_row_friction&)
-        x += ra.ij * ra.imp;
-        x += rb.ij * rb.imp;
+        x = fma3(ra.ij, ra.imp, x);
+        x = fma3(rb.ij, rb.imp, x);
         return;
     }
     const float c0 = ra.imp, c1 = rb.imp;
-    float di0 = (ra.rhs - df4_relspeed(x, ra)) * ra.eff;
-    float i0 = c0 + di0;
-    float di1 = (rb.rhs - df4_relspeed(x, rb)) * rb.eff;
-    float i1 = c1 + di1;
-    const float len2 = i0 * i0 + i1 * i1;
-    const float max_len = mu * R[0].imp;   // mu * current normal impulse
-    if (len2 > square(max_len)) {
-        const float len = sqrtf(len2);
-        if (len > kEps) { i0 = i0 / len * max_len; i1 = i1 / len * max_len; }
-        else { i0 = 0; i1 = 0; }
-        di0 = i0 - c0; di1 = i1 - c1;
-    }
+    float i0 = c0 + fused_delta(df4_relspeed(x, ra), ra.eff, ra.rhs);
+    float i1 = c1 + fused_delta(df4_relspeed(x, rb), rb.eff, rb.rhs);
+    fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
     ra.imp = i0; rb.imp = i1;
-    x += ra.ij * di0;
-    x += rb.ij * di1;
+    x = fma3(ra.ij, i0 - c0, x);
+    x = fma3(rb.ij, i1 - c1, x);
 }
 template <bool WARM, int NP, bool EXACT>
 DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
@@ -2028,7 +2104,7 @@ DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_
             q.j = role == 2u ? -Ja : Ja;              // body B's linear Jacobian is -J_lin
             const f3 lin = im * q.j;
             q.ij = ang ? from4(fi) : lin;
-            q.eff = qb0(fa.w); q.rhs = qb1(fa.w); q.imp = qb3(fa.w);
+            q.eff = qb0(fa.w); q.rhs = qb1(fa.w) * q.eff; q.imp = qb3(fa.w);   // rhs * eff, as fused_delta takes it
             if (r == 0) mu[k] = qb1(fi.w);
         }
     }
@@ -2127,40 +2203,12 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     bool soft[NP];   // soft contacts take no position correction (contact_extras_constraint.cpp:81-86)
 #pragma unroll
     for (int k = 0; k < NP; ++k) soft[k] = mf.xmat != nullptr && mf.xmat[(size_t)k * mf.cap + m].z < kLarge;
+    bool corrected = false;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        if ((uint32_t)k < np && in_range && !soft[k]) {   // uniform within a lane pair
-            const int attach = __float_as_int(n4[k].w);
-            const f3 pXw = to_world(from4(piv[k]), X.org, X.orn);
-            const f3 pOw = xchg1(pXw);
-            const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
-            // the normal rotates with the body it is attached to; that body's lane computes it and shares it
-            const f3 nrot = rotate(X.orn, from4(l4[k]));
-            const f3 nother = xchg1(nrot);
-            f3 n = from4(n4[k]);
-            if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
-            else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
-            const float distance = dot(pAw - pBw, n);
-            const f3 rX = pXw - X.pos;
-            n4[k] = to4(n, n4[k].w);
-            piv[k].w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
-            if (!(distance > -kEps)) {
-                // J = {n, rA x n, -n, -(rB x n)}
-                const f3 Jl = sideB ? -n : n;
-                const f3 cx = cross(rX, n);
-                const f3 Ja = sideB ? -cx : cx;
-                const float t1 = dot(Jl, Jl) * X.inv_m, t2 = dot(mul(X.iw, Ja), Ja);
-                const float o1 = xchg1(t1), o2 = xchg1(t2);
-                const float a1 = sideB ? o1 : t1, a2 = sideB ? o2 : t2, b1 = sideB ? t1 : o1, b2 = sideB ? t2 : o2;
-                const float em = 1.0f / (a1 + a2 + b1 + b2);
-                const float error = -distance;
-                const float corr = error * 0.2f * em;
-                pos_apply(X, Jl, Ja, corr);
-                pos_origin(X);
-                max_err = fmaxf(fabsf(error), max_err);
-            }
-        }
-    }
+    for (int k = 0; k < NP; ++k)
+        if ((uint32_t)k < np && in_range && !soft[k])   // uniform within a lane pair
+            corrected = pos_point_fused(X, sideB, piv[k], l4[k], n4[k], max_err) || corrected;
+    if (corrected) pos_rebuild_inertia(X);   // what store_pbody leaves for the joints' position solve and the next step
     const bool active = in_range && done == 0;
     if (active) {
 #pragma unroll
@@ -2378,10 +2426,8 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = !X.proc;                                // read-only bodies: the record is the truth
     bool corrected = false;
-    // The world inertia follows the orientation (position_solver::solve rebuilds it after every correction). Here it is rebuilt -
-    // same operations, same value - just before the next correction that reads it instead of right after the previous one: the
-    // rebuild after a task's last correction would be thrown away (the next task rebuilds from the handed-over orientation).
-    bool iw_stale = false;
+    // (the world inertia is not part of the hand-off: contacts do not read it - pos_point_fused - and k_pos_writeback rebuilds it
+    //  from the final orientation)
     // An island that met the error threshold in an earlier iteration takes no part in this one (island_solver.cpp:350-353):
     // its lanes neither wait for nor publish hand-offs - every consumer of its bodies is in the same island, equally
     // finished - and each body's chain-head slot keeps the transform of the island's last iteration for k_pos_writeback.
@@ -2395,8 +2441,8 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             dfp_poll(mine, h0, h1, h2);
             if (__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want && __float_as_uint(h2.w) == want) {
                 X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
+                X.org = X.pos;   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
                 corrected = h2.y != 0.0f;
-                iw_stale = corrected;   // rebuilt from the orientation when (if) a correction needs it
                 got = true;
             }
         }
@@ -2409,43 +2455,8 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             act = mine_now && done_isl == 0;
             bool applied = false;
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if ((uint32_t)k < np && act) {
-                    const int attach = __float_as_int(n4[k].w);
-                    const f3 pXw = to_world(from4(piv[k]), X.pos, X.orn);
-                    const f3 pOw = xchg1(pXw);
-                    const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
-                    const f3 nrot = rotate(X.orn, from4(l4[k]));
-                    const f3 nother = xchg1(nrot);
-                    f3 n = from4(n4[k]);
-                    if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
-                    else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
-                    const float distance = dot(pAw - pBw, n);
-                    const f3 rX = pXw - X.pos;
-                    n4[k] = to4(n, n4[k].w);
-                    piv[k].w = distance;
-                    if (!(distance > -kEps)) {
-                        if (iw_stale) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); iw_stale = false; }
-                        const f3 Jl = sideB ? -n : n;
-                        const f3 cx = cross(rX, n);
-                        const f3 Ja = sideB ? -cx : cx;
-                        const float t1 = dot(Jl, Jl) * X.inv_m, t2 = dot(mul(X.iw, Ja), Ja);
-                        const float o1 = xchg1(t1), o2 = xchg1(t2);
-                        const float a1 = sideB ? o1 : t1, a2 = sideB ? o2 : t2, b1 = sideB ? t1 : o1, b2 = sideB ? t2 : o2;
-                        const float em = 1.0f / (a1 + a2 + b1 + b2);
-                        const float error = -distance;
-                        const float corr = error * 0.2f * em;
-                        if (X.proc) {   // pos_apply without its closing inertia rebuild (see iw_stale)
-                            X.pos += X.inv_m * Jl * corr;
-                            const f3 ang = mul(X.iw, Ja) * corr;
-                            X.orn = normalize(X.orn + quaternion_derivative(X.orn, ang));
-                            iw_stale = true;
-                        }
-                        applied = applied || X.proc;
-                        max_err = fmaxf(fabsf(error), max_err);
-                    }
-                }
-            }
+            for (int k = 0; k < NP; ++k)
+                if ((uint32_t)k < np && act) applied = pos_point_fused(X, sideB, piv[k], l4[k], n4[k], max_err) || applied;
             if (act) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {

@@ -173,6 +173,13 @@ def set_libm_trig(on):
     f(int(bool(on)))
 
 
+def set_fused_rows(on):
+    """The coloured order's contact rows: its own fused arithmetic (default, what the device computes) or the reference's."""
+    f = lib().orc_set_fused_rows
+    f.argtypes = [C.c_int]; f.restype = None
+    f(int(bool(on)))
+
+
 def leaf():
     return _Leaf(lib(), "orc_")
 

@@ -206,6 +206,59 @@ inline void solve_friction(FrictionRow &f, Row &n) {
         *n.dwB += n.inv_IB * f.row[i].J[3] * dimp[i];
     }
 }
+// ---- the coloured order's own contact-row arithmetic ("fused rows", round 4) ------------------------------------------------------
+// The device's velocity solve is a dependency chain: what bounds a step is the number of instructions between
+// "a body's deltas arrived" and "its deltas are handed on". The coloured order therefore has its own arithmetic for the normal and
+// friction rows of contacts - the same row equations (constraint_row.cpp:24-57, constraint_row_friction.cpp:11-54) written with
+// fused multiply-adds and fewer operations; this header is its specification and the device reproduces it bit for bit:
+//   * a 3-vector dot product is fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); a relative speed is (lin_A + ang_A) + (lin_B + ang_B);
+//   * delta = fma(-relative_speed, eff_mass, rhs * eff_mass);
+//   * a normal row clamps the new impulse, min(max(impulse + delta, lower), upper), and applies new - old;
+//   * a friction pair scales both impulses by max_len / len (ONE correctly rounded division) when they leave the circle and
+//     applies new - old;
+//   * an impulse is applied as delta_v = fma(M^-1 J, delta, delta_v) per component.
+// The sequential and external orders keep the reference's arithmetic operation for operation (they are what is pinned to the engine
+// bit for bit); the coloured order differs from them in the Gauss-Seidel visiting order anyway, and agrees with them - and with the
+// engine - within the tolerances of SURVEY 8(d) (tests/test_oracle_physics.py, tests/test_reference_engine.py, lock-step tests).
+inline bool g_fused_rows = true;   // test switch (orc_set_fused_rows): false = the reference's arithmetic in the coloured order too
+inline float dot3_fma(vec3 a, vec3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
+inline vec3 fma3(vec3 w, float s, vec3 acc) { return {std::fmaf(w.x, s, acc.x), std::fmaf(w.y, s, acc.y), std::fmaf(w.z, s, acc.z)}; }
+inline float relative_speed_fused(const vec3 J[4], vec3 vA, vec3 wA, vec3 vB, vec3 wB) {
+    return (dot3_fma(J[0], vA) + dot3_fma(J[1], wA)) + (dot3_fma(J[2], vB) + dot3_fma(J[3], wB));
+}
+inline void apply_impulse_fused(float imp, const vec3 J[4], Row &n) {
+    *n.dvA = fma3(n.inv_mA * J[0], imp, *n.dvA);
+    *n.dwA = fma3(n.inv_IA * J[1], imp, *n.dwA);
+    *n.dvB = fma3(n.inv_mB * J[2], imp, *n.dvB);
+    *n.dwB = fma3(n.inv_IB * J[3], imp, *n.dwB);
+}
+inline void solve_normal_fused(Row &r) {
+    const float rel = relative_speed_fused(r.J, *r.dvA, *r.dwA, *r.dvB, *r.dwB);
+    const float dimp = std::fmaf(-rel, r.eff_mass, r.rhs * r.eff_mass);
+    const float nw = std::fmin(std::fmax(r.impulse + dimp, r.lower), r.upper);
+    const float applied = nw - r.impulse;
+    r.impulse = nw;
+    apply_impulse_fused(applied, r.J, r);
+}
+inline void solve_friction_fused(FrictionRow &f, Row &n) {
+    float imp[2];
+    for (int i = 0; i < 2; ++i) {
+        const float rel = relative_speed_fused(f.row[i].J, *n.dvA, *n.dwA, *n.dvB, *n.dwB);
+        imp[i] = f.row[i].impulse + std::fmaf(-rel, f.row[i].eff_mass, f.row[i].rhs * f.row[i].eff_mass);
+    }
+    const float len2 = std::fmaf(imp[1], imp[1], imp[0] * imp[0]);
+    const float max_len = f.mu * n.impulse;
+    if (len2 > max_len * max_len) {
+        const float len = std::sqrt(len2);
+        const float scale = len > kEps ? max_len / len : 0.0f;
+        imp[0] *= scale; imp[1] *= scale;
+    }
+    for (int i = 0; i < 2; ++i) {
+        const float applied = imp[i] - f.row[i].impulse;
+        f.row[i].impulse = imp[i];
+        apply_impulse_fused(applied, f.row[i].J, n);
+    }
+}
 inline void solve_spin_friction(SpinRow &r, Row &n) {   // constraint_row_spin_friction.cpp:5-29
     const float max_len = r.mu * n.impulse;
     const float drel = dot(r.J[0], *n.dwA) + dot(r.J[1], *n.dwB);
@@ -1402,6 +1455,59 @@ public:
         vec3 J[4] = {cp.normal, cross(rA, cp.normal), -cp.normal, -cross(rB, cp.normal)};
         ps.solve(J, error);
     }
+    // The coloured order's own arithmetic for the position correction of a contact point (see "fused rows" above; the device's
+    // pos_point_fused computes exactly this): the correction of contact_constraint.cpp:58-90 / position_solver.hpp:16-51 with
+    //   R = the rotation matrix of the unit orientation, built without to_mat3's renormalising division, used for the pivot, the normal
+    //       and the inertia product I_w Ja = R (I_l (R^T Ja)); every dot product an fma chain;
+    //   effective mass 1 / ((lin_A + ang_A) + (lin_B + ang_B)); the orientation re-normalised with ONE division, q * (1 / |q|).
+    // The bodies' world inertia is not read; it is rebuilt (reference arithmetic) after each correction for the joints' position solve.
+    static mat3 basis_unit(quat q) {
+        const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+        const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+        const float xx = q.x * xs, yy = q.y * ys, zz = q.z * zs;
+        return {{{1.0f - (yy + zz), std::fmaf(q.x, ys, -wz), std::fmaf(q.x, zs, wy)},
+                 {std::fmaf(q.x, ys, wz), 1.0f - (xx + zz), std::fmaf(q.y, zs, -wx)},
+                 {std::fmaf(q.x, zs, -wy), std::fmaf(q.y, zs, wx), 1.0f - (xx + yy)}}};
+    }
+    static vec3 mv_fma(const mat3 &m, vec3 v) { return {dot3_fma(m.row[0], v), dot3_fma(m.row[1], v), dot3_fma(m.row[2], v)}; }
+    static vec3 mtv_fma(const mat3 &m, vec3 v) {
+        return {std::fmaf(m.row[2].x, v.z, std::fmaf(m.row[1].x, v.y, m.row[0].x * v.x)), std::fmaf(m.row[2].y, v.z, std::fmaf(m.row[1].y, v.y, m.row[0].y * v.x)),
+                std::fmaf(m.row[2].z, v.z, std::fmaf(m.row[1].z, v.y, m.row[0].z * v.x))};
+    }
+    static vec3 cross_fma(vec3 a, vec3 b) { return {std::fmaf(a.y, b.z, -(a.z * b.y)), std::fmaf(a.z, b.x, -(a.x * b.z)), std::fmaf(a.x, b.y, -(a.y * b.x))}; }
+    void contact_solve_position_fused(Manifold &m, ContactPoint &cp, PosSolver &ps) {
+        if (cp.extras() && cp.stiffness < kLarge) return;   // soft contacts take no position correction
+        Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
+        const mat3 RA = basis_unit(A.orn), RB = basis_unit(B.orn);
+        const vec3 pAw = mv_fma(RA, cp.pivotA) + A.org(), pBw = mv_fma(RB, cp.pivotB) + B.org();
+        if (cp.attachment == NA_ON_A) cp.normal = mv_fma(RA, cp.local_normal);
+        else if (cp.attachment == NA_ON_B) cp.normal = mv_fma(RB, cp.local_normal);
+        const vec3 n = cp.normal;
+        cp.distance = dot3_fma(pAw - pBw, n);
+        if (cp.distance > -kEps) return;
+        const vec3 rA = pAw - A.pos, rB = pBw - B.pos;
+        const vec3 JlA = n, JaA = cross_fma(rA, n), JlB = -n, JaB = -cross_fma(rB, n);
+        const float imA = A.procedural() ? A.mass_inv : 0.0f, imB = B.procedural() ? B.mass_inv : 0.0f;
+        const mat3 IlA = A.procedural() ? A.I_inv : kMat3Zero, IlB = B.procedural() ? B.I_inv : kMat3Zero;
+        const vec3 wA = mv_fma(RA, mv_fma(IlA, mtv_fma(RA, JaA))), wB = mv_fma(RB, mv_fma(IlB, mtv_fma(RB, JaB)));
+        const float sA = dot3_fma(JlA, JlA) * imA + dot3_fma(wA, JaA), sB = dot3_fma(JlB, JlB) * imB + dot3_fma(wB, JaB);
+        const float em = 1.0f / (sA + sB);
+        const float corr = (-cp.distance * 0.2f) * em;
+        ps.max_error = std::max(std::fabs(cp.distance), ps.max_error);
+        auto apply = [&](Body &b, float im, vec3 Jl, vec3 w) {
+            if (!b.procedural()) return;
+            b.pos = fma3(im * Jl, corr, b.pos);
+            const quat q = b.orn + quaternion_derivative(b.orn, w * corr);
+            const float l2 = std::fmaf(q.w, q.w, std::fmaf(q.z, q.z, std::fmaf(q.y, q.y, q.x * q.x)));
+            const float rl = 1.0f / std::sqrt(l2);
+            b.orn = quat{q.x * rl, q.y * rl, q.z * rl, q.w * rl};
+            const mat3 basis = to_mat3(b.orn);
+            b.I_inv_world = basis * b.I_inv * transpose(basis);   // update_inertia (reference arithmetic): what the joints' position solve reads
+            b.update_origin();
+        };
+        apply(A, imA, JlA, wA);
+        apply(B, imB, JlB, wB);
+    }
     void generic_solve_position(Joint &j, PosSolver &ps) {   // generic_constraint.cpp:260-290: the limited linear degrees of freedom
         Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
         ps.bind(A, B);
@@ -1786,17 +1892,28 @@ public:
             cc[m.colour].push_back(cr);
         }
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) apply_row_impulse(jr.r[i].impulse, jr.r[i]);
+        const bool fused = g_fused_rows;
         for (auto &col : cc) for (auto &cr : col) {
-            for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
-            for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+            if (fused) {
+                for (int i = 0; i < cr.m->num_points; ++i) apply_impulse_fused(cr.nr[i].impulse, cr.nr[i].J, cr.nr[i]);
+                for (int i = 0; i < cr.m->num_points; ++i) for (int t = 0; t < 2; ++t) apply_impulse_fused(cr.fr[i].row[t].impulse, cr.fr[i].row[t].J, cr.nr[i]);
+            } else {
+                for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
+                for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+            }
             for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) warm_start_friction(cr.ex[i].rr, cr.nr[i]);
             for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) warm_start_spin(cr.ex[i].sr, cr.nr[i]);
         }
         for (int it = 0; it < vel_iters; ++it) {
             for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) { float d = solve_row(jr.r[i]); apply_row_impulse(d, jr.r[i]); }
             for (auto &col : cc) for (auto &cr : col) {
-                for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
-                for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+                if (fused) {
+                    for (int i = 0; i < cr.m->num_points; ++i) solve_normal_fused(cr.nr[i]);
+                    for (int i = 0; i < cr.m->num_points; ++i) solve_friction_fused(cr.fr[i], cr.nr[i]);
+                } else {
+                    for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
+                    for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+                }
                 // inside a manifold the reference's order of row kinds: normals, friction, rolling, spinning
                 for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) solve_friction(cr.ex[i].rr, cr.nr[i]);
                 for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) solve_spin_friction(cr.ex[i].sr, cr.nr[i]);
@@ -1831,7 +1948,10 @@ public:
                 uint32_t l = label_of(cr.m->body[0], cr.m->body[1]);
                 if (done[l]) continue;
                 PosSolver ps;
-                for (int i = 0; i < cr.m->num_points; ++i) contact_solve_position(*cr.m, cr.m->pt[i], ps);
+                for (int i = 0; i < cr.m->num_points; ++i) {
+                    if (fused) contact_solve_position_fused(*cr.m, cr.m->pt[i], ps);
+                    else contact_solve_position(*cr.m, cr.m->pt[i], ps);
+                }
                 err[l] = std::max(err[l], ps.max_error);
             }
             for (size_t l = 0; l < done.size(); ++l) if (err[l] < 0.005f) done[l] = 1;
