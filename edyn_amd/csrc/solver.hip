@@ -1000,7 +1000,9 @@ struct DfArgs {
     Counters *cnt;
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
     const uint8_t *skip;              // mixed schedule: [p] != 0 = the manifold's island has joints and is solved by k_island_velocity; else nullptr
+    uint32_t nap;                     // pause between two polls of a wave that found nothing: 0 none, 1 s_sleep 1, else s_sleep 4 (EDYNHIP_DF_NAP, developer knob)
 };
+DI void df_nap(uint32_t nap) { if (nap == 0) return; if (nap == 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }
 DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): pieces 1 KiB apart (dslot_at)
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                  "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
@@ -1989,7 +1991,7 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
                 if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);   // ~0.1 us between polls
+            df_nap(a.nap);   // ~0.1 us between polls by default
         }
     }
 }
@@ -3228,7 +3230,8 @@ int solve(edynhip_ctx *c) {
         const uint32_t resident = four_lane ? c->df4_waves : two_lane ? c->df2_waves : c->df_lanes;
         const uint32_t want_waves = env_waves ? env_waves : std::max(four_lane ? 2048u : two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
         const uint32_t grid = std::min(blocks(na, per_wave), std::min(resident, want_waves));
-        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip};
+        static const uint32_t env_nap = getenv("EDYNHIP_DF_NAP") ? (uint32_t)atoi(getenv("EDYNHIP_DF_NAP")) : 1u;   // (r04 sweep on one box: 4 -> 1: +0.6 %, 0: the same)
+        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip, env_nap};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
