@@ -50,11 +50,14 @@ BYTES_PER_POINT_ITER = 380.0   # algorithmic bytes per contact
 BYTES_PER_JOINT_ROW_ITER = 256.0   # per joint row per iteration
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # parity statement that accompanies the number (tests/test_gpu_parity.py; the figures are asserted there)
-PARITY = ("bit-exact vs the oracle in this settled state at full size (pairs, state, manifolds, colours: "
-          "test_timed_regime_at_full_size_bit_exact); free-running vs the reference engine itself, C2 8000 boxes, 60 steps: "
-          "max |dpos| 0.23 m, mean 0.059 m, penetration <= 0.01 m, mean pile height within 2.6e-3 m - a Gauss-Seidel visiting-order "
-          "effect of the unconverged 10-iteration solve on a collapsing lattice, not fp rounding (lock-step: 2e-3 m per step, pair sets "
-          "and narrowphase bit-exact; test_free_running_c2_against_the_real_reference_engine, test_gpu_against_the_real_reference_engine)")
+PARITY = ("bit-exact vs the oracle's coloured order in this settled state at full size (pairs, state, manifolds, colours: "
+          "test_timed_regime_at_full_size_bit_exact; islands1m: test_islands1m_at_full_size_bit_exact) - the coloured order has its own "
+          "row arithmetic (fused multiply-adds, DESIGN.md section 3), the oracle's reference order is pinned to the reference engine bit for bit; "
+          "free-running vs the reference engine itself, C2 8000 boxes: 60 steps max |dpos| 0.23 m, mean 0.059 m; 300 steps (SURVEY 8(d)(4)): "
+          "mean resting height within 6.4e-4 m, penetration of the resting pile 0.0036 / 0.0018 m, kinetic energy of the resting set 1.2e-5 J per "
+          "body on both sides - a Gauss-Seidel visiting-order effect of the unconverged 10-iteration solve on a collapsing lattice, not fp "
+          "rounding (lock-step: 2e-3 m per step, pair sets and narrowphase bit-exact, also on C3 at full size: 1.6e-3 m; "
+          "test_c2_300_steps_survey_invariants_*, test_free_running_c2_*, test_c3_full_size_lock_step_*, test_gpu_against_the_real_reference_engine)")
 WORKLOADS = {
     "pile32k": dict(gen=lambda: scenes.box_pile(32, 32, 32), vel=10, pos=3, settle=120, desc="32x32x32 = 32768-box brick-offset pile on a static plane"),
     "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, settle=120, desc="20x20x20 = 8000-box pile (config C2)"),
