@@ -499,9 +499,18 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
 }
 
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
+// `speculative`: the launch was enqueued before the host read the pair count (broadphase(), below) - M is then taken from the device
+// counters, and the launch does nothing when the host is going to take another path (capacity error, an unsorted surplus that needs the
+// extra sort first, an unchanged pair set that keeps last step's array); `first` = the first manifold of this launch (the host covers
+// what a speculative grid was too small for with a second launch).
 __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds cur, Manifolds prev, uint32_t pm,
-                                     Counters *cnt, uint2 *new_edges, uint32_t *new_edge_m, bool copy_points, EventSink ev, uint8_t *prev_matched) {
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+                                     Counters *cnt, uint2 *new_edges, uint32_t *new_edge_m, bool copy_points, EventSink ev, uint8_t *prev_matched,
+                                     uint32_t first, bool speculative, bool inplace_allowed) {
+    if (speculative) {
+        M = cnt->num_pairs;
+        if (cnt->pair_overflow || cnt->num_extra || M > cur.cap || (inplace_allowed && M > 0 && M == pm && !cnt->pairs_differ)) return;
+    }
+    uint32_t m = first + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t found = 0;
     bool is_new = false;
     uint32_t new_hi = 0, new_lo = 0;
@@ -630,8 +639,24 @@ int broadphase(edynhip_ctx *c) {
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt, prev.skey, pm);
-        // pair count is needed on the host to size the manifold kernels
-        EH_TRY(fetch_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours));
+        // The pair count is needed on the host to size the manifold kernels - but the first of them need not wait for it: inside a full
+        // step the build is enqueued right behind the counter publish, over a grid sized from last step's count, reads the count on the
+        // device and stands down by itself in the cases decided below (speculative launch; what its grid did not cover is launched
+        // after the fetch). The GPU builds while the answer travels to the host (11 us of idle GPU per step on the headline pile).
+        static const bool spec_env = !(getenv("EDYNHIP_SPECULATE") && getenv("EDYNHIP_SPECULATE")[0] == '0');
+        static const bool inplace_env = !(getenv("EDYNHIP_INPLACE") && getenv("EDYNHIP_INPLACE")[0] == '0');
+        const bool inplace_allowed = inplace_env && c->full_step && !c->events && !c->force_islands;
+        const EventSink ev = event_sink(c);
+        uint32_t covered = 0;
+        uint32_t ticket = 0;
+        EH_TRY(publish_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours, &ticket));
+        const uint32_t spec_grid = std::min<uint32_t>(cur.cap / 512u, blocks(pm + pm / 16 + 2048, 512));
+        if (spec_env && c->full_step && pm > 0 && spec_grid > 0) {
+            covered = spec_grid * 512u;
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(spec_grid), dim3(512), 0, s, c->pair_keys_sorted, 0u, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, false, ev, c->prev_matched,
+                               0u, true, inplace_allowed);
+        }
+        EH_TRY(wait_counters(c, ticket));
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         if (c->cnt_host->df_abort) return set_error(c, EDYNHIP_ERR_INTERNAL, "dataflow solve: a hand-off never arrived in the previous step (workgroups not co-resident?)");
         M = c->cnt_host->num_pairs;
@@ -644,8 +669,7 @@ int broadphase(edynhip_ctx *c) {
         // step's manifold array IS this step's - no rebuild, no copy of the contact points into the other array; the
         // narrowphase works in place and sleeping manifolds cost nothing. (With contact events the build also keeps the
         // created / destroyed bookkeeping, so it runs.)
-        static const bool inplace_env = !(getenv("EDYNHIP_INPLACE") && getenv("EDYNHIP_INPLACE")[0] == '0');
-        if (inplace_env && c->full_step && M > 0 && M == pm && !c->cnt_host->pairs_differ && !c->events && !c->force_islands) {
+        if (inplace_allowed && M > 0 && M == pm && !c->cnt_host->pairs_differ) {
             c->points_in_prev = false;
             c->inplace_step = true;
             c->prev_num_manifolds = pm;
@@ -657,10 +681,11 @@ int broadphase(edynhip_ctx *c) {
             EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
             EH_HIP(c, hipMemsetAsync(cur.seg_end, 0, (size_t)c->b.cap * sizeof(uint32_t), s));
         }
-        const EventSink ev = event_sink(c);
-        if (M > 0)
-            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M, 512)), dim3(512), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, !c->full_step, ev, c->prev_matched);
-        else if (pm != 0) c->force_islands = true;
+        if (c->cnt_host->num_extra) covered = 0;   // the speculative launch stood down: the keys were not sorted yet
+        if (M > covered)
+            hipLaunchKernelGGL(k_bp_build_manifolds, dim3(blocks(M - covered, 512)), dim3(512), 0, s, c->pair_keys_sorted, M, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, !c->full_step, ev, c->prev_matched,
+                               covered, false, false);
+        if (M == 0 && pm != 0) c->force_islands = true;
         if (ev.buf && pm > 0) hipLaunchKernelGGL(k_ev_destroyed, dim3(blocks(pm, 256)), dim3(256), 0, s, pm, prev, c->prev_matched, ev);
     }
     c->points_in_prev = c->full_step && M > 0 && np > 0;

@@ -31,12 +31,19 @@ __global__ void k_publish_counters(const uint32_t *__restrict__ src, uint32_t *d
     __syncthreads();
     if (threadIdx.x == 0) { __hip_atomic_store((uint32_t *)seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
-int fetch_counters(edynhip_ctx *c, size_t bytes) {
+// The two halves of a fetch: the publish kernel is enqueued, then the caller may enqueue work that does not need the host's answer
+// (speculative launches whose kernels read their element counts from device memory) before it waits - the GPU then runs that work
+// while the sequence number travels to the host and the next launches travel back, instead of idling (~11-14 us per fetch).
+int publish_counters(edynhip_ctx *c, size_t bytes, uint32_t *ticket) {
     const uint32_t value = ++c->cnt_seq_next;
     c->last_fetch_step = c->step_index;
     hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->cnt, (uint32_t *)c->cnt_host,
                        (uint32_t)(bytes / sizeof(uint32_t)), c->cnt_seq, value);
     EH_HIP(c, hipGetLastError());
+    *ticket = value;
+    return EDYNHIP_OK;
+}
+int wait_counters(edynhip_ctx *c, uint32_t value) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *c->cnt_seq != value; ++spins) {
         __builtin_ia32_pause();
@@ -48,6 +55,11 @@ int fetch_counters(edynhip_ctx *c, size_t bytes) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return EDYNHIP_OK;
+}
+int fetch_counters(edynhip_ctx *c, size_t bytes) {
+    uint32_t ticket = 0;
+    EH_TRY(publish_counters(c, bytes, &ticket));
+    return wait_counters(c, ticket);
 }
 
 template <typename T>
@@ -88,6 +100,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, r.dslot, ((size_t)M + 64) * 4));   // whole 64-lane blocks (dslot_at)
     EH_TRY(dalloc(c, r.pslot, ((size_t)M + 32) * 6));   // whole 32-lane blocks (pslot_at)
     EH_TRY(dalloc(c, r.next, (size_t)M * 2)); EH_TRY(dalloc(c, r.im, (size_t)M * 2));
+    EH_TRY(dalloc(c, r.pw, (size_t)M * kMaxPts * kPosF)); EH_TRY(dalloc(c, r.pil, (size_t)M * 2 * 3));
     EH_TRY(dalloc(c, r.slot_of, (size_t)nb * kMaxColours)); EH_TRY(dalloc(c, r.first_slot, nb)); EH_TRY(dalloc(c, r.skip, M));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));

@@ -178,11 +178,15 @@ struct Rows {
                                   // bit 31 (kHeadBit) marks THIS slot as the head of its body's chain
     float4 *pslot = nullptr;      // position-solve hand-off slots, 3 float4 per (lane, side): see k_pos_contacts_df
     float *im = nullptr;          // [2p + side] inverse mass of that side's body (0 = read-only body: no hand-off)
+    // what the dataflow position solve reads, indexed by the lane like the rows (written by k_prep_contacts / k_push_links): with them
+    // a position task needs no gather through the manifold or body index - every load address follows from p
+    float4 *pw = nullptr;         // [(k * kPosF + f) * cap + p]: point k's pivot on A, pivot on B, local normal, (normal, attachment)
+    float4 *pil = nullptr;        // [f * 2 cap + 2p + side], f < 3: the rows of that side's body's local inverse inertia (zero: read-only body)
     uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
     uint8_t *skip = nullptr;          // [p] mixed schedule: the manifold's island has joints (solved by the island-fused kernels, not on the chains)
 };
-constexpr int kRowF = 5, kRowsPerPoint = 3;
+constexpr int kRowF = 5, kRowsPerPoint = 3, kPosF = 4;
 constexpr uint32_t kColUncCap = 16384;   // uncoloured edges one workgroup colours by itself (more: the multi-block rounds)
 constexpr uint32_t kHeadBit = 0x80000000u, kSlotMask = 0x7FFFFFFFu;
 // Hand-off slot addressing (float4 units). A slot is (lane p, side); its pieces are laid out so that ONE vector load of a
@@ -406,6 +410,8 @@ int broadphase(edynhip_ctx *c);
 int narrowphase(edynhip_ctx *c);
 int count_points(edynhip_ctx *c);
 int fetch_counters(edynhip_ctx *c, size_t bytes);   // device counters -> cnt_host, waits for them (capi.hip)
+int publish_counters(edynhip_ctx *c, size_t bytes, uint32_t *ticket);   // the same in two halves: enqueue the copy ...
+int wait_counters(edynhip_ctx *c, uint32_t ticket);                      // ... and wait for it (speculative launches go in between)
 int scan_u32(edynhip_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);   // exclusive prefix sum
 int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp, const float *pos, const float *orn, float threshold,
                   float *out, uint32_t *count);

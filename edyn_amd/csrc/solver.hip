@@ -589,21 +589,31 @@ DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, fl
 // headline path and carries none of that code.
 template <bool EXTRAS>
 __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt,
-                                const uint32_t *__restrict__ keys_sorted, bool push) {
+                                const uint32_t *__restrict__ keys_sorted, bool push, bool by_key) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
+    // speculative launch (solve(): enqueued before the host has read the colouring's counters): n_active is the number of ALL
+    // manifolds; the active ones are the prefix of the sorted order whose keys name a colour
+    if (by_key && keys_sorted[p] >= 4u * kMaxContactColours) return;
     const uint32_t m = rows.order[p];
-    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
     const uint32_t np = mf.info[m] & 0xFF;
-    rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
-    rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
-    if (push) {   // hand-off slot of (body, colour): k_push_links turns these into each body's chain
-        const uint32_t col = keys_sorted[p] >> 2;
-        if (is_dynamic(b.flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
-        if (is_dynamic(b.flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
+    // gridDim.y > 1: one lane per contact POINT (blockIdx.y = the point's slot; lanes are sorted by point count inside a colour, so the
+    // waves of slots a manifold does not have leave together) - the points of a manifold are independent here, and a lane that walks
+    // four of them one after the other is a four times longer dependent chain for a quarter of the lanes (72 -> us on the headline pile)
+    const uint32_t k_begin = gridDim.y > 1 ? blockIdx.y : 0u, k_end = gridDim.y > 1 ? min(np, blockIdx.y + 1u) : np;
+    if (k_begin >= np && k_begin != 0u) return;
+    const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+    if (k_begin == 0u) {
+        rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
+        rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
+        if (push) {   // hand-off slot of (body, colour): k_push_links turns these into each body's chain
+            const uint32_t col = keys_sorted[p] >> 2;
+            if (is_dynamic(b.flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
+            if (is_dynamic(b.flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
+        }
     }
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
-    for (uint32_t k = 0; k < np; ++k) {
+    for (uint32_t k = k_begin; k < k_end; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
         const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
         const f3 n = from4(n4);
@@ -638,6 +648,10 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
         const size_t base = (size_t)(k * kRowsPerPoint) * kRowF * rcap + p, rstride = (size_t)kRowF * rcap;
         store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
+        if (!EXTRAS && push) {   // the dataflow position solve's copy of the point, indexed by the lane (Rows::pw)
+            const size_t pb = (size_t)(k * kPosF) * rcap + p;
+            rows.pw[pb] = a4; rows.pw[pb + rcap] = b4; rows.pw[pb + 2 * (size_t)rcap] = mf.lnrm[s]; rows.pw[pb + 3 * (size_t)rcap] = n4;
+        }
         if (EXTRAS && upper != kLarge) rows.rw[base + 4 * (size_t)rcap].w = upper;
         if (EXTRAS) {   // rolling pair and spinning row (:37-78); roll_direction components do not exist on this path
             const size_t xb = (size_t)(k * kXPoint) * rcap + p;
@@ -1113,7 +1127,7 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 // `isl_joint` (mixed schedule, else nullptr): islands with joints take no part in the hand-off chains - their manifolds are marked in
 // Rows::skip and their bodies keep first_slot = none (k_island_velocity / k_island_position solve them on the body records).
 __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used,
-                             const uint32_t *__restrict__ isl_joint) {
+                             const uint32_t *__restrict__ isl_joint, uint32_t rcap) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
     if (isl_joint) {
@@ -1128,12 +1142,15 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
         const uint32_t slot = 2 * p + side;
         // every slot starts a step as (0,0,0 | tag 0): the chain head's seed, and "nothing handed over yet" elsewhere
         rows.dslot[dslot_at(slot, 0)] = make_float4(0, 0, 0, 0); rows.dslot[dslot_at(slot, 1)] = make_float4(0, 0, 0, 0);
+        const size_t cap2 = 2 * (size_t)rcap;
         if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
             rows.next[slot] = slot;
             rows.im[slot] = 0.0f;
+            rows.pil[slot] = make_float4(0, 0, 0, 0); rows.pil[cap2 + slot] = make_float4(0, 0, 0, 0); rows.pil[2 * cap2 + slot] = make_float4(0, 0, 0, 0);
             continue;
         }
         rows.im[slot] = B_POS(b, body).w;
+        rows.pil[slot] = B_IL(b, body, 0); rows.pil[cap2 + slot] = B_IL(b, body, 1); rows.pil[2 * cap2 + slot] = B_IL(b, body, 2);
         const uint64_t mask = used[body];                         // colours of this body's active manifolds
         const uint64_t above = col >= 63 ? 0ull : mask & ~((2ull << col) - 1ull);
         const uint32_t nextc = (uint32_t)__ffsll((long long)(above ? above : mask)) - 1;
@@ -1782,37 +1799,53 @@ DI f3 mtv_fma(const m3 &m, f3 v) {   // transpose(m) * v
                __builtin_fmaf(m.r2.z, v.z, __builtin_fmaf(m.r1.z, v.y, m.r0.z * v.x)));
 }
 DI f3 cross_fma(f3 a, f3 b) { return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))); }
-// One point, this lane's body X (sideB: X is body[1]); piv = (pivot of X, .w: distance on side A), l4 = local normal, n4 = (normal, attachment).
-// Both lanes of the pair must execute it together (DPP exchanges). Returns true when X was corrected.
-DI bool pos_point_fused(PBody &X, bool sideB, float4 &piv, const float4 &l4, float4 &n4, float &max_err) {
-    const int attach = __float_as_int(n4.w);
+// The unit of the coloured order's position solve is the MANIFOLD (block correction, round 4; specified by the checker's
+// coloured order, contact_solve_position_block): the corrections of its <= 4 points are evaluated from the transforms the manifold was entered with,
+// each body's translation / rotation vector is the sum, in list order, of the rounded products (inv_m Jl) corr_i / (I_w Ja_i) corr_i,
+// and the body is moved once - one rotation matrix, one quaternion update, one square root and one division per body and manifold
+// instead of one per point (a four-point task: ~1 200 -> ~520 instructions between "transforms arrived" and "transforms handed on").
+// This lane's body is X (sideB: X is body[1]); piv[k] = (pivot of X, .w: distance on side A), l4 = local normal, n4 = (normal, attachment);
+// live[k]: point k takes part (uniform within the lane pair). Both lanes of the pair execute it together (DPP exchanges).
+// Returns true when X was corrected.
+template <int NP>
+DI bool pos_manifold_block(PBody &X, bool sideB, float4 (&piv)[NP], const float4 (&l4)[NP], float4 (&n4)[NP], const bool (&live)[NP], float &max_err) {
     const m3 R = basis_unit(X.orn);
-    const f3 pXw = mv_fma(R, from4(piv)) + X.org;
-    const f3 pOw = xchg1(pXw);
-    const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
-    // the normal rotates with the body it is attached to; that body's lane computes it and shares it
-    const f3 nrot = mv_fma(R, from4(l4));
-    const f3 nother = xchg1(nrot);
-    f3 n = from4(n4);
-    if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
-    else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
-    const float distance = dot3_fma(pAw - pBw, n);
-    const f3 rX = pXw - X.pos;
-    n4 = to4(n, n4.w);
-    piv.w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
-    if (distance > -kEps) return false;
-    // J = {n, rA x n, -n, -(rB x n)}
-    const f3 Jl = sideB ? -n : n;
-    const f3 cx = cross_fma(rX, n);
-    const f3 Ja = sideB ? -cx : cx;
-    const f3 w = mv_fma(R, mv_fma(X.il, mtv_fma(R, Ja)));   // I_w Ja
-    const float mine = dot3_fma(Jl, Jl) * X.inv_m + dot3_fma(w, Ja);
-    const float em = 1.0f / (mine + xchg1(mine));
-    const float corr = (-distance * 0.2f) * em;
-    max_err = fmaxf(fabsf(distance), max_err);
-    if (!X.proc) return false;
-    X.pos = fma3(X.inv_m * Jl, corr, X.pos);
-    const q4 q = X.orn + quaternion_derivative(X.orn, w * corr);
+    f3 t = mk3(0, 0, 0), rot = mk3(0, 0, 0);
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (!live[k]) continue;
+        const int attach = __float_as_int(n4[k].w);
+        const f3 pXw = mv_fma(R, from4(piv[k])) + X.org;
+        const f3 pOw = xchg1(pXw);
+        const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
+        // the normal rotates with the body it is attached to; that body's lane computes it and shares it
+        const f3 nrot = mv_fma(R, from4(l4[k]));
+        const f3 nother = xchg1(nrot);
+        f3 n = from4(n4[k]);
+        if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
+        else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
+        const float distance = dot3_fma(pAw - pBw, n);
+        n4[k] = to4(n, n4[k].w);
+        piv[k].w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
+        if (distance > -kEps) continue;   // (the same bits in both lanes of the pair)
+        // J = {n, rA x n, -n, -(rB x n)}
+        const f3 rX = pXw - X.pos;
+        const f3 Jl = sideB ? -n : n;
+        const f3 cx = cross_fma(rX, n);
+        const f3 Ja = sideB ? -cx : cx;
+        const f3 w = mv_fma(R, mv_fma(X.il, mtv_fma(R, Ja)));   // I_w Ja
+        const float mine = dot3_fma(Jl, Jl) * X.inv_m + dot3_fma(w, Ja);
+        const float em = 1.0f / (mine + xchg1(mine));
+        const float corr = (-distance * 0.2f) * em;
+        max_err = fmaxf(fabsf(distance), max_err);
+        t = t + (X.inv_m * Jl) * corr;
+        rot = rot + w * corr;
+        any = true;
+    }
+    if (!any || !X.proc) return false;
+    X.pos = X.pos + t;
+    const q4 q = X.orn + quaternion_derivative(X.orn, rot);
     const float l2 = __builtin_fmaf(q.w, q.w, __builtin_fmaf(q.z, q.z, __builtin_fmaf(q.y, q.y, q.x * q.x)));
     const float rl = 1.0f / sqrtf(l2);
     X.orn = q4{q.x * rl, q.y * rl, q.z * rl, q.w * rl};
@@ -2205,11 +2238,10 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     bool soft[NP];   // soft contacts take no position correction (contact_extras_constraint.cpp:81-86)
 #pragma unroll
     for (int k = 0; k < NP; ++k) soft[k] = mf.xmat != nullptr && mf.xmat[(size_t)k * mf.cap + m].z < kLarge;
-    bool corrected = false;
+    bool live[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
-        if ((uint32_t)k < np && in_range && !soft[k])   // uniform within a lane pair
-            corrected = pos_point_fused(X, sideB, piv[k], l4[k], n4[k], max_err) || corrected;
+    for (int k = 0; k < NP; ++k) live[k] = (uint32_t)k < np && in_range && !soft[k];   // uniform within a lane pair
+    const bool corrected = pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err);
     if (corrected) pos_rebuild_inertia(X);   // what store_pbody leaves for the joints' position solve and the next step
     const bool active = in_range && done == 0;
     if (active) {
@@ -2364,6 +2396,7 @@ struct DfPosArgs {
                                     // no error, so its entry stays 0 and it stays finished - no separate flag pass is needed
     Counters *cnt;
     const uint8_t *skip;            // mixed schedule: manifolds of islands with joints (k_island_position solves those), else nullptr
+    uint64_t *trace;                // developer aid (EDYNHIP_DFP_TRACE): 4 timestamps per (round, wave) of this iteration, else nullptr
 };
 constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
@@ -2389,7 +2422,9 @@ __global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot
     if (!(slot & 1u)) store_impulses_of(p, rows, rcap, mf);
     if (skip && skip[p]) return;   // an island with joints: not on the hand-off chains
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
-    if ((rows.next[slot] & kHeadBit) && is_dynamic(b.flags[body])) {   // the chain head starts from the integrated transform
+    // the chain head starts from the integrated transform; the slot of a read-only body (static, kinematic) holds that body's transform
+    // for the whole solve - its lane takes it from there without looking at the tag (no gather through the body index in the solve)
+    if (((rows.next[slot] & kHeadBit) && is_dynamic(b.flags[body])) || !is_dynamic(b.flags[body])) {
         const float4 ps = B_POS(b, body), q = B_ORN(b, body);
         h0 = make_float4(ps.x, ps.y, ps.z, 0); h1 = make_float4(q.x, q.y, q.z, 0); h2 = make_float4(q.w, 0, 0, 0);
     }
@@ -2410,25 +2445,36 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && is_dynamic(b.flags[i])) pos_writeback(b, i, pslot, first_slot);
 }
+// What a position task needs besides its points, none of it depending on the point count: loaded (with the first look at the task's
+// own hand-off slot) before the kernel branches on the point count, so that a task's loads are two dependent levels - (key, head,
+// first poll), then (points, the island's error of the previous iteration) - instead of four (key -> order / bodies / next -> the
+// manifold's points and the body records -> poll): the trace showed 3.5 us from "task begins" to "first poll back" against 1.5 us of
+// arithmetic and 1.3 us of waiting per task (profiles/r04_dftrace_position_*.txt).
+struct DfpHead { uint32_t m, label, nx; float im; float4 il0, il1, il2; v4f h0, h1, h2; };
 template <int NP>
-DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col) {
-    const Manifolds &mf = a.mf; const Bodies &b = a.b;
-    const uint32_t m = a.rows.order[p], ix = sideB ? a.rows.bB[p] : a.rows.bA[p], label = a.rows.label[p];
+DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, const DfpHead &hd, uint64_t w0, uint64_t *trace_slot) {
+    const Manifolds &mf = a.mf;
+    uint64_t w1 = 0, w2 = 0;
+    const uint32_t m = hd.m, label = hd.label;
     const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
-    const uint32_t nx = a.next[slot];
-    const float4 *__restrict__ pvsrc = sideB ? mf.pB : mf.pA;
+    const uint32_t nx = hd.nx;
+    const size_t rcap = mf.cap;
     float4 piv[NP], l4[NP], n4[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
-        piv[k] = pvsrc[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s];
+        const size_t pb = (size_t)(k * kPosF) * rcap + p;
+        piv[k] = a.rows.pw[pb + (sideB ? rcap : 0)]; l4[k] = a.rows.pw[pb + 2 * rcap]; n4[k] = a.rows.pw[pb + 3 * rcap];
     }
-    PBody X = load_pbody(b, ix);                       // pos/orn/iw of a procedural body are replaced by the hand-off
+    PBody X;   // the transform comes with the hand-off (a read-only body's: from its seeded slot); pivots are anchored at the position
+    X.inv_m = hd.im; X.proc = hd.im != 0.0f;
+    X.il = {from4(hd.il0), from4(hd.il1), from4(hd.il2)};
+    X.has_com = false; X.com = mk3(0, 0, 0);   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
+    X.pos = X.org = mk3(0, 0, 0); X.orn = q4{0, 0, 0, 1};
     const uint32_t done_isl = (a.err_prev && a.err_prev[label] < kPosErrorThreshold) ? 1u : 0u;
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
-    bool got = !X.proc;                                // read-only bodies: the record is the truth
+    bool got = false;
     bool corrected = false;
-    // (the world inertia is not part of the hand-off: contacts do not read it - pos_point_fused - and k_pos_writeback rebuilds it
+    // (the world inertia is not part of the hand-off: contacts do not read it - pos_manifold_block - and k_pos_writeback rebuilds it
     //  from the final orientation)
     // An island that met the error threshold in an earlier iteration takes no part in this one (island_solver.cpp:350-353):
     // its lanes neither wait for nor publish hand-offs - every consumer of its bodies is in the same island, equally
@@ -2437,28 +2483,42 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const float4 *mine = a.pslot + pslot_at(slot, 0);
     float max_err = 0;
     bool act = false;
+    auto accept = [&](const v4f &h0, const v4f &h1, const v4f &h2) {
+        if ((__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want && __float_as_uint(h2.w) == want) || !X.proc) {
+            X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
+            X.org = X.pos;
+            corrected = h2.y != 0.0f;
+            got = true;
+        }
+    };
+    if (!done) accept(hd.h0, hd.h1, hd.h2);   // the look taken with the head loads
     for (uint32_t spin = 0;; ++spin) {
-        if (!done && !got) {
+        if (!done && !got && spin > 0) {
             v4f h0, h1, h2;
             dfp_poll(mine, h0, h1, h2);
-            if (__float_as_uint(h0.w) == want && __float_as_uint(h1.w) == want && __float_as_uint(h2.w) == want) {
-                X.pos = mk3(h0.x, h0.y, h0.z); X.orn = q4{h1.x, h1.y, h1.z, h2.x};
-                X.org = X.pos;   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
-                corrected = h2.y != 0.0f;
-                got = true;
-            }
+            accept(h0, h1, h2);
         }
+        if (a.trace && w1 == 0) w1 = wall_clock64();
         const uint64_t pending = __ballot(!done);
-        if (pending == 0) break;
+        if (pending == 0) {
+            if (trace_slot && (threadIdx.x & 63) == 0) { trace_slot[0] = w0; trace_slot[1] = w1; trace_slot[2] = w2; trace_slot[3] = wall_clock64(); }
+            break;
+        }
         const uint32_t minc = __shfl(col, __ffsll((long long)pending) - 1);
         const bool mine_now = !done && col == minc;            // both lanes of a pair share p, hence colour
         if (__ballot(mine_now && !got) == 0) {
+            if (a.trace && w2 == 0) w2 = wall_clock64();
             // the arithmetic below is pos_contacts_np's; `act` is uniform within a lane pair (DPP exchanges)
             act = mine_now && done_isl == 0;
-            bool applied = false;
+            bool live[NP];
 #pragma unroll
-            for (int k = 0; k < NP; ++k)
-                if ((uint32_t)k < np && act) applied = pos_point_fused(X, sideB, piv[k], l4[k], n4[k], max_err) || applied;
+            for (int k = 0; k < NP; ++k) live[k] = (uint32_t)k < np && act;
+            const bool applied = pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err);
+            // hand the transform on first (the body's next manifold is waiting for it), then store the points' distances / normals
+            if (mine_now) {
+                if (X.proc) dfp_publish(a.pslot + pslot_at(nx & kSlotMask, 0), X.pos, X.orn, corrected || applied, a.iter + 1);
+                done = true;
+            }
             if (act) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
@@ -2471,35 +2531,38 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
                 // the body record is NOT written here: two waves on different XCDs would leave the same line dirty in
                 // two L2s; k_pos_writeback stores each body's final transform once, from its chain head's slot
             }
-            if (mine_now) {
-                if (X.proc) dfp_publish(a.pslot + pslot_at(nx & kSlotMask, 0), X.pos, X.orn, corrected || applied, a.iter + 1);
-                done = true;
-            }
         } else {
             if (spin > kDfSpinLimit || ((spin & 1023u) == 1023u && __hip_atomic_load(&a.cnt->df_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 if (spin > kDfSpinLimit) atomicExch(&a.cnt->df_abort, 1u);
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            if (spin > 0) __builtin_amdgcn_s_sleep(4);
         }
     }
     publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.err_out);
 }
-// (Requesting a wave's next task's indices or point data one task ahead was measured and is slower: a wave's vector
-// memory operations complete in order, so anything issued before a poll delays noticing the hand-off.)
 __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
-    for (uint32_t base = 0; base < a.na; base += a.stride) {
+    const uint32_t nwaves = a.stride >> 5;
+    const size_t cap2 = 2 * (size_t)a.mf.cap;
+    for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
         const uint32_t pt = base + t;
         const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
         if (!__any(valid)) continue;
+        const uint64_t w0 = a.trace ? wall_clock64() : 0;
         const uint32_t p = valid ? pt : a.na - 1;
+        const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
         const uint32_t key = a.keys_sorted[p];
+        DfpHead hd;
+        hd.m = a.rows.order[p]; hd.label = a.rows.label[p]; hd.nx = a.next[slot]; hd.im = a.rows.im[slot];
+        hd.il0 = a.rows.pil[slot]; hd.il1 = a.rows.pil[cap2 + slot]; hd.il2 = a.rows.pil[2 * cap2 + slot];
+        dfp_poll(a.pslot + pslot_at(slot, 0), hd.h0, hd.h1, hd.h2);   // (waits for the loads above with it)
         const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
-        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col);
-        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col);
-        else dfp_task<1>(a, p, valid, sideB, np, col);
+        uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)round * nwaves + blockIdx.x) : nullptr;
+        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col, hd, w0, tr);
+        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col, hd, w0, tr);
+        else dfp_task<1>(a, p, valid, sideB, np, col, hd, w0, tr);
     }
 }
 
@@ -2940,7 +3003,12 @@ int islands(edynhip_ctx *c) {
     return EDYNHIP_OK;
 }
 
-static int colour_contacts(edynhip_ctx *c) {
+// `between`: called once, after the steady-state colouring and its counter publish are enqueued and before the host waits for the
+// counters - what it enqueues runs while the answer travels (it must not depend on the answer). *first_final tells the caller whether
+// the counters of that first publish were the final ones (no multi-block colouring rounds, no second sort).
+template <typename Between>
+static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
+    *first_final = false;
     hipStream_t s = c->stream;
     const uint32_t M = c->num_manifolds, n = c->b.n;
     Manifolds &mf = c->m[c->cur];
@@ -2963,6 +3031,7 @@ static int colour_contacts(edynhip_ctx *c) {
         }
         total_rounds += count;
     };
+    bool first = true;
     auto sort_and_fetch = [&]() -> int {
         {
             const uint32_t nb = blocks(M, kCsBlock);
@@ -2971,7 +3040,11 @@ static int colour_contacts(edynhip_ctx *c) {
             hipLaunchKernelGGL(k_cs_scatter, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order);
         }
         hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
-        EH_TRY(fetch_counters(c, sizeof(Counters)));
+        uint32_t ticket = 0;
+        EH_TRY(publish_counters(c, sizeof(Counters), &ticket));
+        if (first) between();
+        first = false;
+        EH_TRY(wait_counters(c, ticket));
         return EDYNHIP_OK;
     };
     // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
@@ -2989,6 +3062,7 @@ static int colour_contacts(edynhip_ctx *c) {
     hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
                        c->col_unc, c->col_lds_edges, 256u);
     EH_TRY(sort_and_fetch());
+    *first_final = c->cnt_host->uncoloured == 0;
     if (c->cnt_host->uncoloured != 0) {
         uint32_t batch = 4;
         while (c->cnt_host->uncoloured != 0) {
@@ -3036,14 +3110,6 @@ int solve(edynhip_ctx *c) {
     // gravity / zeroed deltas do not depend on the colouring: enqueued first, they run while the host waits for the counters
     if (!c->solve_begin_done) hipLaunchKernelGGL(k_solve_begin, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, dt, c->rows.first_slot);
     c->solve_begin_done = false;
-    EH_TRY(colour_contacts(c));
-    // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
-    c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
-    rec(c, 4);
-    const uint32_t na = c->num_active, nc = c->num_colours;
-    const Joints &j = c->j;
-    if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt, c->isl_joint);
-    if (j.n && c->has_generic) hipLaunchKernelGGL(k_prep_generic, dim3(blocks(j.n, 64)), dim3(64), 0, s, j, c->b, dt);
     // Contact-only scenes: the whole velocity solve as one dataflow launch (see k_contact_solve_df).
     if (c->df_mode < 0) {
         c->df_mode = 0;
@@ -3067,6 +3133,32 @@ int solve(edynhip_ctx *c) {
         }
         (void)hipGetLastError();
     }
+    const Joints &j = c->j;
+    // Contact-only worlds on the dataflow schedule: the row preparation does not wait for the host to read the colouring's counters.
+    // It is enqueued right behind the counter publish over ALL manifolds - the active ones are the prefix of the sorted order whose
+    // keys name a colour (k_prep_contacts by_key) - and runs while the answer travels to the host and the next launches travel back
+    // (14 us of idle GPU per step on the headline pile, profiles/r04_timeline_pile32k.txt). If the colouring turns out unfinished
+    // (uncoloured edges left for the multi-block rounds: a scene coloured from scratch) the rows are prepared again after the second sort;
+    // a non-empty serial bucket only drops `push` - the slot table written for it is read through the bodies' colour masks alone.
+    static const bool spec_env = !(getenv("EDYNHIP_SPECULATE") && getenv("EDYNHIP_SPECULATE")[0] == '0');
+    static const uint32_t kPrepY = (getenv("EDYNHIP_PREP_PER_POINT") && getenv("EDYNHIP_PREP_PER_POINT")[0] == '0') ? 1u : 4u;   // lanes per manifold of k_prep_contacts<false>
+    bool spec_prep = false;
+    auto speculative_prep = [&]() {
+        rec(c, 4);
+        if (!(spec_env && j.n == 0 && !c->extras && c->df_mode == 1 && c->full_step && c->num_manifolds > 0)) return;
+        const uint32_t M = c->num_manifolds;
+        hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(M, 128), kPrepY), dim3(128), 0, s, M, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, true, true);
+        spec_prep = true;
+    };
+    bool first_final = false;
+    EH_TRY(colour_contacts(c, speculative_prep, &first_final));
+    if (!first_final) spec_prep = false;   // the sorted order changed after the speculative launch: prepare again
+    // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
+    c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
+    if (c->num_manifolds == 0) rec(c, 4);
+    const uint32_t na = c->num_active, nc = c->num_colours;
+    if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt, c->isl_joint);
+    if (j.n && c->has_generic) hipLaunchKernelGGL(k_prep_generic, dim3(blocks(j.n, 64)), dim3(64), 0, s, j, c->b, dt);
     // without joints every delta hand-off stays inside the contact sweeps; contact_extras rows exist on the per-colour schedule only
     // a non-empty serial bucket (a body with more than 62 coloured contacts) also needs the per-colour schedule
     const bool serial = nc == kSerialColour + 1 && c->colour_end[kSerialColour] > c->colour_start[kSerialColour];
@@ -3095,8 +3187,8 @@ int solve(edynhip_ctx *c) {
                        free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit && !c->b.com;
     bool push = na > 0 && !serial && (contacts_only || mixed);
     if (na) {
-        if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
-        else hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push);
+        if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false);
+        else if (!spec_prep) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128), kPrepY), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false);
     }
     bool isl_fused = false;
     if (isl_candidate) {
@@ -3131,12 +3223,12 @@ int solve(edynhip_ctx *c) {
             if (isl_fused && c->cnt_host->isl_max_items > kIslFusedLimit) isl_fused = false;
             if (mixed && c->cnt_host->isl_max_jitems > kIslFusedLimit) {   // the jointed islands outgrew the fused kernels: the whole step per colour
                 mixed = false; push = false;
-                if (na) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, false);
+                if (na) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128), kPrepY), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, false, false);
             }
         }
     }
     if (push) {
-        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr);
+        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr, rcap);
     }
     const uint8_t *df_skip = mixed ? c->rows.skip : nullptr;
     IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done, mixed ? 1u : 0u};
@@ -3315,16 +3407,39 @@ int solve(edynhip_ctx *c) {
         const Rows &r = c->rows;
         hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip);
         const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
+        // developer aid: EDYNHIP_DFP_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th position solve
+        // (same file format as EDYNHIP_DF_TRACE with "sweeps" = position iterations: scripts/df_trace.py reads both)
+        static const char *ptrace_path = getenv("EDYNHIP_DFP_TRACE");
+        static long ptrace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, pos_calls = 0;
+        const bool ptracing = ptrace_path && pos_calls++ == ptrace_step;
+        const uint32_t prounds = blocks(na, grid * 32u);
+        const size_t ptrace_words = 4 * (size_t)prounds * grid;
+        uint64_t *ptrace = nullptr;
+        if (ptracing) {
+            EH_HIP(c, hipMalloc((void **)&ptrace, ptrace_words * P * 8));
+            EH_HIP(c, hipMemsetAsync(ptrace, 0, ptrace_words * P * 8, s));
+        }
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
-                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip};
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr};
             void *params[] = {&a};
             if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
                 c->df_mode = 0;
                 break;
             }
+        }
+        if (ptrace) {
+            std::vector<uint64_t> tr(ptrace_words * P); std::vector<uint32_t> keys(na);
+            EH_HIP(c, hipStreamSynchronize(s));
+            EH_HIP(c, hipMemcpy(tr.data(), ptrace, tr.size() * 8, hipMemcpyDeviceToHost));
+            EH_HIP(c, hipMemcpy(keys.data(), c->col_keys_sorted, (size_t)na * 4, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(ptrace_path, "wb")) {
+                const uint32_t hdr[4] = {na, grid * 32u, P, 32u};
+                fwrite(hdr, 4, 4, f); fwrite(keys.data(), 4, na, f); fwrite(tr.data(), 8, tr.size(), f); fclose(f);
+            }
+            (void)hipFree(ptrace);
         }
         // the bodies' transforms live in the hand-off slots while the dataflow launches run; k_finish picks them up
         if (it == P) {

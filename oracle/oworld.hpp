@@ -1455,8 +1455,8 @@ public:
         vec3 J[4] = {cp.normal, cross(rA, cp.normal), -cp.normal, -cross(rB, cp.normal)};
         ps.solve(J, error);
     }
-    // The coloured order's own arithmetic for the position correction of a contact point (see "fused rows" above; the device's
-    // pos_point_fused computes exactly this): the correction of contact_constraint.cpp:58-90 / position_solver.hpp:16-51 with
+    // The coloured order's own arithmetic for the position correction of a contact point (see "fused rows" above): the correction of
+    // contact_constraint.cpp:58-90 / position_solver.hpp:16-51 with
     //   R = the rotation matrix of the unit orientation, built without to_mat3's renormalising division, used for the pivot, the normal
     //       and the inertia product I_w Ja = R (I_l (R^T Ja)); every dot product an fma chain;
     //   effective mass 1 / ((lin_A + ang_A) + (lin_B + ang_B)); the orientation re-normalised with ONE division, q * (1 / |q|).
@@ -1475,29 +1475,50 @@ public:
                 std::fmaf(m.row[2].z, v.z, std::fmaf(m.row[1].z, v.y, m.row[0].z * v.x))};
     }
     static vec3 cross_fma(vec3 a, vec3 b) { return {std::fmaf(a.y, b.z, -(a.z * b.y)), std::fmaf(a.z, b.x, -(a.x * b.z)), std::fmaf(a.x, b.y, -(a.y * b.x))}; }
-    void contact_solve_position_fused(Manifold &m, ContactPoint &cp, PosSolver &ps) {
-        if (cp.extras() && cp.stiffness < kLarge) return;   // soft contacts take no position correction
+    // The unit of the coloured order's position solve is the MANIFOLD ("block correction", round 4): the corrections of its <= 4 points
+    // are all evaluated from the transforms the manifold was entered with and applied together - one translation and one orientation
+    // update (one re-normalisation) per body and manifold instead of one per point. Between two points of one manifold the reference's
+    // Gauss-Seidel lets the second see the first's correction (contact_constraint.cpp:58-90 called point after point); with the 0.2
+    // correction rate that coupling is a second-order term (< 0.2^2 of the penetration), well inside SURVEY 8(d)'s lock-step bound, and
+    // it is what makes a position task a short dependency chain on the device: a point costs one rotation of pivot and normal and the
+    // inertia product; the quaternion update, its square root and division are paid once per manifold. Specification (the device's
+    // pos_manifold_block computes exactly this, bit for bit):
+    //   RA, RB = basis_unit of the entry orientations; per point, in list order: world pivots, normal, distance, Jacobian, I_w Ja,
+    //   effective mass and correction exactly as in the per-point form above; each body's translation is the sum, in list order, of the
+    //   ROUNDED products (inv_m Jl) corr_i, its rotation vector the sum of the rounded products (I_w Ja_i) corr_i; then
+    //   pos += sum, q = orn + quaternion_derivative(orn, rotation sum), q * (1 / |q|). A manifold without a penetrating point changes nothing.
+    void contact_solve_position_block(Manifold &m, PosSolver &ps) {
         Body &A = bodies[m.body[0]], &B = bodies[m.body[1]];
         const mat3 RA = basis_unit(A.orn), RB = basis_unit(B.orn);
-        const vec3 pAw = mv_fma(RA, cp.pivotA) + A.org(), pBw = mv_fma(RB, cp.pivotB) + B.org();
-        if (cp.attachment == NA_ON_A) cp.normal = mv_fma(RA, cp.local_normal);
-        else if (cp.attachment == NA_ON_B) cp.normal = mv_fma(RB, cp.local_normal);
-        const vec3 n = cp.normal;
-        cp.distance = dot3_fma(pAw - pBw, n);
-        if (cp.distance > -kEps) return;
-        const vec3 rA = pAw - A.pos, rB = pBw - B.pos;
-        const vec3 JlA = n, JaA = cross_fma(rA, n), JlB = -n, JaB = -cross_fma(rB, n);
         const float imA = A.procedural() ? A.mass_inv : 0.0f, imB = B.procedural() ? B.mass_inv : 0.0f;
         const mat3 IlA = A.procedural() ? A.I_inv : kMat3Zero, IlB = B.procedural() ? B.I_inv : kMat3Zero;
-        const vec3 wA = mv_fma(RA, mv_fma(IlA, mtv_fma(RA, JaA))), wB = mv_fma(RB, mv_fma(IlB, mtv_fma(RB, JaB)));
-        const float sA = dot3_fma(JlA, JlA) * imA + dot3_fma(wA, JaA), sB = dot3_fma(JlB, JlB) * imB + dot3_fma(wB, JaB);
-        const float em = 1.0f / (sA + sB);
-        const float corr = (-cp.distance * 0.2f) * em;
-        ps.max_error = std::max(std::fabs(cp.distance), ps.max_error);
-        auto apply = [&](Body &b, float im, vec3 Jl, vec3 w) {
+        vec3 tA{0, 0, 0}, rotA{0, 0, 0}, tB{0, 0, 0}, rotB{0, 0, 0};
+        bool any = false;
+        for (int i = 0; i < m.num_points; ++i) {
+            ContactPoint &cp = m.pt[i];
+            if (cp.extras() && cp.stiffness < kLarge) continue;   // soft contacts take no position correction
+            const vec3 pAw = mv_fma(RA, cp.pivotA) + A.org(), pBw = mv_fma(RB, cp.pivotB) + B.org();
+            if (cp.attachment == NA_ON_A) cp.normal = mv_fma(RA, cp.local_normal);
+            else if (cp.attachment == NA_ON_B) cp.normal = mv_fma(RB, cp.local_normal);
+            const vec3 n = cp.normal;
+            cp.distance = dot3_fma(pAw - pBw, n);
+            if (cp.distance > -kEps) continue;
+            const vec3 rA = pAw - A.pos, rB = pBw - B.pos;
+            const vec3 JlA = n, JaA = cross_fma(rA, n), JlB = -n, JaB = -cross_fma(rB, n);
+            const vec3 wA = mv_fma(RA, mv_fma(IlA, mtv_fma(RA, JaA))), wB = mv_fma(RB, mv_fma(IlB, mtv_fma(RB, JaB)));
+            const float sA = dot3_fma(JlA, JlA) * imA + dot3_fma(wA, JaA), sB = dot3_fma(JlB, JlB) * imB + dot3_fma(wB, JaB);
+            const float em = 1.0f / (sA + sB);
+            const float corr = (-cp.distance * 0.2f) * em;
+            ps.max_error = std::max(std::fabs(cp.distance), ps.max_error);
+            tA = tA + (imA * JlA) * corr; rotA = rotA + wA * corr;
+            tB = tB + (imB * JlB) * corr; rotB = rotB + wB * corr;
+            any = true;
+        }
+        if (!any) return;
+        auto apply = [&](Body &b, vec3 t, vec3 rot) {
             if (!b.procedural()) return;
-            b.pos = fma3(im * Jl, corr, b.pos);
-            const quat q = b.orn + quaternion_derivative(b.orn, w * corr);
+            b.pos = b.pos + t;
+            const quat q = b.orn + quaternion_derivative(b.orn, rot);
             const float l2 = std::fmaf(q.w, q.w, std::fmaf(q.z, q.z, std::fmaf(q.y, q.y, q.x * q.x)));
             const float rl = 1.0f / std::sqrt(l2);
             b.orn = quat{q.x * rl, q.y * rl, q.z * rl, q.w * rl};
@@ -1505,8 +1526,8 @@ public:
             b.I_inv_world = basis * b.I_inv * transpose(basis);   // update_inertia (reference arithmetic): what the joints' position solve reads
             b.update_origin();
         };
-        apply(A, imA, JlA, wA);
-        apply(B, imB, JlB, wB);
+        apply(A, tA, rotA);
+        apply(B, tB, rotB);
     }
     void generic_solve_position(Joint &j, PosSolver &ps) {   // generic_constraint.cpp:260-290: the limited linear degrees of freedom
         Body &A = bodies[j.body[0]], &B = bodies[j.body[1]];
@@ -1948,10 +1969,8 @@ public:
                 uint32_t l = label_of(cr.m->body[0], cr.m->body[1]);
                 if (done[l]) continue;
                 PosSolver ps;
-                for (int i = 0; i < cr.m->num_points; ++i) {
-                    if (fused) contact_solve_position_fused(*cr.m, cr.m->pt[i], ps);
-                    else contact_solve_position(*cr.m, cr.m->pt[i], ps);
-                }
+                if (fused) contact_solve_position_block(*cr.m, ps);
+                else for (int i = 0; i < cr.m->num_points; ++i) contact_solve_position(*cr.m, cr.m->pt[i], ps);
                 err[l] = std::max(err[l], ps.max_error);
             }
             for (size_t l = 0; l < done.size(); ++l) if (err[l] < 0.005f) done[l] = 1;
