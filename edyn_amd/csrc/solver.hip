@@ -589,7 +589,7 @@ DI void store_row(float4 *rw, size_t base, size_t cap, f3 Jl, f3 JaA, f3 JaB, fl
 // headline path and carries none of that code.
 template <bool EXTRAS>
 __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Manifolds mf, Bodies b, float dt,
-                                const uint32_t *__restrict__ keys_sorted, bool push, bool by_key) {
+                                const uint32_t *__restrict__ keys_sorted, bool push, bool by_key, bool write_pw) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
     // speculative launch (solve(): enqueued before the host has read the colouring's counters): n_active is the number of ALL
@@ -597,23 +597,18 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
     if (by_key && keys_sorted[p] >= 4u * kMaxContactColours) return;
     const uint32_t m = rows.order[p];
     const uint32_t np = mf.info[m] & 0xFF;
-    // gridDim.y > 1: one lane per contact POINT (blockIdx.y = the point's slot; lanes are sorted by point count inside a colour, so the
-    // waves of slots a manifold does not have leave together) - the points of a manifold are independent here, and a lane that walks
-    // four of them one after the other is a four times longer dependent chain for a quarter of the lanes (72 -> us on the headline pile)
-    const uint32_t k_begin = gridDim.y > 1 ? blockIdx.y : 0u, k_end = gridDim.y > 1 ? min(np, blockIdx.y + 1u) : np;
-    if (k_begin >= np && k_begin != 0u) return;
     const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
-    if (k_begin == 0u) {
-        rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
-        rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
-        if (push) {   // hand-off slot of (body, colour): k_push_links turns these into each body's chain
-            const uint32_t col = keys_sorted[p] >> 2;
-            if (is_dynamic(b.flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
-            if (is_dynamic(b.flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
-        }
+    rows.bA[p] = ia; rows.bB[p] = ib; rows.np[p] = np;
+    rows.label[p] = b.island[is_dynamic(b.flags[ia]) ? ia : ib];
+    if (push) {   // hand-off slot of (body, colour): k_push_links turns these into each body's chain
+        const uint32_t col = keys_sorted[p] >> 2;
+        if (is_dynamic(b.flags[ia])) rows.slot_of[(size_t)ia * kMaxColours + col] = 2 * p;
+        if (is_dynamic(b.flags[ib])) rows.slot_of[(size_t)ib * kMaxColours + col] = 2 * p + 1;
     }
+    // (One lane per contact POINT instead of per manifold was measured - the points of a manifold are independent here - and is slower,
+    //  103 against 71 us on the headline pile: every lane then loads both bodies for a single point.)
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
-    for (uint32_t k = k_begin; k < k_end; ++k) {
+    for (uint32_t k = 0; k < np; ++k) {
         const size_t s = (size_t)k * mf.cap + m;
         const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
         const f3 n = from4(n4);
@@ -648,7 +643,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         const float rhs1 = -rel_speed(t1, L1, -t1, L3, A.v, A.w, B.v, B.w);
         const size_t base = (size_t)(k * kRowsPerPoint) * kRowF * rcap + p, rstride = (size_t)kRowF * rcap;
         store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
-        if (!EXTRAS && push) {   // the dataflow position solve's copy of the point, indexed by the lane (Rows::pw)
+        if (!EXTRAS && push && write_pw) {   // the dataflow position solve's copy of the point, indexed by the lane (Rows::pw)
             const size_t pb = (size_t)(k * kPosF) * rcap + p;
             rows.pw[pb] = a4; rows.pw[pb + rcap] = b4; rows.pw[pb + 2 * (size_t)rcap] = mf.lnrm[s]; rows.pw[pb + 3 * (size_t)rcap] = n4;
         }
@@ -1127,7 +1122,7 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 // `isl_joint` (mixed schedule, else nullptr): islands with joints take no part in the hand-off chains - their manifolds are marked in
 // Rows::skip and their bodies keep first_slot = none (k_island_velocity / k_island_position solve them on the body records).
 __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used,
-                             const uint32_t *__restrict__ isl_joint, uint32_t rcap) {
+                             const uint32_t *__restrict__ isl_joint, uint32_t rcap, bool write_pil) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
     if (isl_joint) {
@@ -1146,11 +1141,11 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
         if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
             rows.next[slot] = slot;
             rows.im[slot] = 0.0f;
-            rows.pil[slot] = make_float4(0, 0, 0, 0); rows.pil[cap2 + slot] = make_float4(0, 0, 0, 0); rows.pil[2 * cap2 + slot] = make_float4(0, 0, 0, 0);
+            if (write_pil) { rows.pil[slot] = make_float4(0, 0, 0, 0); rows.pil[cap2 + slot] = make_float4(0, 0, 0, 0); rows.pil[2 * cap2 + slot] = make_float4(0, 0, 0, 0); }
             continue;
         }
         rows.im[slot] = B_POS(b, body).w;
-        rows.pil[slot] = B_IL(b, body, 0); rows.pil[cap2 + slot] = B_IL(b, body, 1); rows.pil[2 * cap2 + slot] = B_IL(b, body, 2);
+        if (write_pil) { rows.pil[slot] = B_IL(b, body, 0); rows.pil[cap2 + slot] = B_IL(b, body, 1); rows.pil[2 * cap2 + slot] = B_IL(b, body, 2); }
         const uint64_t mask = used[body];                         // colours of this body's active manifolds
         const uint64_t above = col >= 63 ? 0ull : mask & ~((2ull << col) - 1ull);
         const uint32_t nextc = (uint32_t)__ffsll((long long)(above ? above : mask)) - 1;
@@ -2397,6 +2392,7 @@ struct DfPosArgs {
     Counters *cnt;
     const uint8_t *skip;            // mixed schedule: manifolds of islands with joints (k_island_position solves those), else nullptr
     uint64_t *trace;                // developer aid (EDYNHIP_DFP_TRACE): 4 timestamps per (round, wave) of this iteration, else nullptr
+    bool use_pw, use_pil;           // points from the lane-indexed copy Rows::pw / inertia rows from Rows::pil (else gathered through the manifold / body index)
 };
 constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
@@ -2415,12 +2411,22 @@ DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) 
 }
 // Seeds the position hand-off chains from the integrated transforms; the side-A lane also copies its manifold's solved
 // impulses back to the contact points (what k_store_impulses does when the position solve runs per colour).
-__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf, const uint8_t *__restrict__ skip) {
+__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf, const uint8_t *__restrict__ skip, bool write_pw) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= 2 * n_active) return;
     const uint32_t p = slot >> 1, body = (slot & 1u) ? rows.bB[p] : rows.bA[p];
     if (!(slot & 1u)) store_impulses_of(p, rows, rcap, mf);
     if (skip && skip[p]) return;   // an island with joints: not on the hand-off chains
+    if (write_pw) {   // the position solve's lane-indexed copy of the manifold's points (Rows::pw): side A's lane copies pivot A and the
+                      // local normal, side B's pivot B and the normal
+        const uint32_t m = rows.order[p], np = rows.np[p];
+        const float4 *__restrict__ s0 = (slot & 1u) ? mf.pB : mf.pA, *__restrict__ s1 = (slot & 1u) ? mf.nrm : mf.lnrm;
+        const size_t f0 = (slot & 1u) ? 1 : 0, f1 = (slot & 1u) ? 3 : 2;
+        for (uint32_t k = 0; k < np; ++k) {
+            const size_t sidx = (size_t)k * mf.cap + m, pb = (size_t)(k * kPosF) * rcap + p;
+            rows.pw[pb + f0 * rcap] = s0[sidx]; rows.pw[pb + f1 * rcap] = s1[sidx];
+        }
+    }
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
     // the chain head starts from the integrated transform; the slot of a read-only body (static, kinematic) holds that body's transform
     // for the whole solve - its lane takes it from there without looking at the tag (no gather through the body index in the solve)
@@ -2450,7 +2456,7 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
 // first poll), then (points, the island's error of the previous iteration) - instead of four (key -> order / bodies / next -> the
 // manifold's points and the body records -> poll): the trace showed 3.5 us from "task begins" to "first poll back" against 1.5 us of
 // arithmetic and 1.3 us of waiting per task (profiles/r04_dftrace_position_*.txt).
-struct DfpHead { uint32_t m, label, nx; float im; float4 il0, il1, il2; v4f h0, h1, h2; };
+struct DfpHead { uint32_t m, ix, label, nx; float im; float4 il0, il1, il2; v4f h0, h1, h2; };
 template <int NP>
 DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, const DfpHead &hd, uint64_t w0, uint64_t *trace_slot) {
     const Manifolds &mf = a.mf;
@@ -2460,14 +2466,25 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     const uint32_t nx = hd.nx;
     const size_t rcap = mf.cap;
     float4 piv[NP], l4[NP], n4[NP];
+    if (a.use_pw) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const size_t pb = (size_t)(k * kPosF) * rcap + p;
-        piv[k] = a.rows.pw[pb + (sideB ? rcap : 0)]; l4[k] = a.rows.pw[pb + 2 * rcap]; n4[k] = a.rows.pw[pb + 3 * rcap];
+        for (int k = 0; k < NP; ++k) {
+            const size_t pb = (size_t)(k * kPosF) * rcap + p;
+            piv[k] = a.rows.pw[pb + (sideB ? rcap : 0)]; l4[k] = a.rows.pw[pb + 2 * rcap]; n4[k] = a.rows.pw[pb + 3 * rcap];
+        }
+    } else {
+        const float4 *__restrict__ pvsrc = sideB ? mf.pB : mf.pA;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const size_t sidx = (size_t)k * rcap + m;
+            piv[k] = pvsrc[sidx]; l4[k] = mf.lnrm[sidx]; n4[k] = mf.nrm[sidx];
+        }
     }
     PBody X;   // the transform comes with the hand-off (a read-only body's: from its seeded slot); pivots are anchored at the position
     X.inv_m = hd.im; X.proc = hd.im != 0.0f;
-    X.il = {from4(hd.il0), from4(hd.il1), from4(hd.il2)};
+    if (a.use_pil) X.il = {from4(hd.il0), from4(hd.il1), from4(hd.il2)};
+    else if (X.proc) X.il = {from4(B_IL(a.b, hd.ix, 0)), from4(B_IL(a.b, hd.ix, 1)), from4(B_IL(a.b, hd.ix, 2))};
+    else X.il = m3_zero();
     X.has_com = false; X.com = mk3(0, 0, 0);   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
     X.pos = X.org = mk3(0, 0, 0); X.orn = q4{0, 0, 0, 1};
     const uint32_t done_isl = (a.err_prev && a.err_prev[label] < kPosErrorThreshold) ? 1u : 0u;
@@ -2555,8 +2572,9 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
         const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
         const uint32_t key = a.keys_sorted[p];
         DfpHead hd;
-        hd.m = a.rows.order[p]; hd.label = a.rows.label[p]; hd.nx = a.next[slot]; hd.im = a.rows.im[slot];
-        hd.il0 = a.rows.pil[slot]; hd.il1 = a.rows.pil[cap2 + slot]; hd.il2 = a.rows.pil[2 * cap2 + slot];
+        hd.m = a.rows.order[p]; hd.ix = sideB ? a.rows.bB[p] : a.rows.bA[p]; hd.label = a.rows.label[p]; hd.nx = a.next[slot]; hd.im = a.rows.im[slot];
+        if (a.use_pil) { hd.il0 = a.rows.pil[slot]; hd.il1 = a.rows.pil[cap2 + slot]; hd.il2 = a.rows.pil[2 * cap2 + slot]; }
+        else hd.il0 = hd.il1 = hd.il2 = make_float4(0, 0, 0, 0);
         dfp_poll(a.pslot + pslot_at(slot, 0), hd.h0, hd.h1, hd.h2);   // (waits for the loads above with it)
         const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
         uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)round * nwaves + blockIdx.x) : nullptr;
@@ -3141,13 +3159,18 @@ int solve(edynhip_ctx *c) {
     // (uncoloured edges left for the multi-block rounds: a scene coloured from scratch) the rows are prepared again after the second sort;
     // a non-empty serial bucket only drops `push` - the slot table written for it is read through the bodies' colour masks alone.
     static const bool spec_env = !(getenv("EDYNHIP_SPECULATE") && getenv("EDYNHIP_SPECULATE")[0] == '0');
-    static const uint32_t kPrepY = (getenv("EDYNHIP_PREP_PER_POINT") && getenv("EDYNHIP_PREP_PER_POINT")[0] == '0') ? 1u : 4u;   // lanes per manifold of k_prep_contacts<false>
+    // developer knobs of the dataflow position solve's inputs: EDYNHIP_POS_PW=0 gathers the points through the manifold index instead of
+    // reading the lane-indexed copy k_prep_contacts writes (Rows::pw); EDYNHIP_POS_PIL=1 reads the inertia rows from a lane-indexed copy
+    // written by k_push_links (Rows::pil) instead of gathering them through the body index
+    static const bool kUsePw = !(getenv("EDYNHIP_POS_PW") && getenv("EDYNHIP_POS_PW")[0] == '0');
+    static const bool kUsePil = getenv("EDYNHIP_POS_PIL") && getenv("EDYNHIP_POS_PIL")[0] == '1';
+    const bool kPwInPrep = kUsePw;
     bool spec_prep = false;
     auto speculative_prep = [&]() {
         rec(c, 4);
         if (!(spec_env && j.n == 0 && !c->extras && c->df_mode == 1 && c->full_step && c->num_manifolds > 0)) return;
         const uint32_t M = c->num_manifolds;
-        hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(M, 128), kPrepY), dim3(128), 0, s, M, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, true, true);
+        hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(M, 128)), dim3(128), 0, s, M, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, true, true, kPwInPrep);
         spec_prep = true;
     };
     bool first_final = false;
@@ -3187,8 +3210,8 @@ int solve(edynhip_ctx *c) {
                        free_manifolds >= kMixedMinFree && largest_jointed <= kIslFusedLimit && !c->b.com;
     bool push = na > 0 && !serial && (contacts_only || mixed);
     if (na) {
-        if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false);
-        else if (!spec_prep) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128), kPrepY), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false);
+        if (c->extras) hipLaunchKernelGGL(k_prep_contacts<true>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false, false);
+        else if (!spec_prep) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, push, false, kPwInPrep);
     }
     bool isl_fused = false;
     if (isl_candidate) {
@@ -3223,12 +3246,12 @@ int solve(edynhip_ctx *c) {
             if (isl_fused && c->cnt_host->isl_max_items > kIslFusedLimit) isl_fused = false;
             if (mixed && c->cnt_host->isl_max_jitems > kIslFusedLimit) {   // the jointed islands outgrew the fused kernels: the whole step per colour
                 mixed = false; push = false;
-                if (na) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128), kPrepY), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, false, false);
+                if (na) hipLaunchKernelGGL(k_prep_contacts<false>, dim3(blocks(na, 128)), dim3(128), 0, s, na, c->rows, rcap, mf, c->b, dt, c->col_keys_sorted, false, false, false);
             }
         }
     }
     if (push) {
-        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr, rcap);
+        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr, rcap, kUsePil);
     }
     const uint8_t *df_skip = mixed ? c->rows.skip : nullptr;
     IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done, mixed ? 1u : 0u};
@@ -3405,7 +3428,7 @@ int solve(edynhip_ctx *c) {
     if (pos_df) {
         static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
-        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip);
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip, false);
         const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
         // developer aid: EDYNHIP_DFP_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th position solve
         // (same file format as EDYNHIP_DF_TRACE with "sweeps" = position iterations: scripts/df_trace.py reads both)
@@ -3422,7 +3445,7 @@ int solve(edynhip_ctx *c) {
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
-                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr};
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr, kUsePw, kUsePil};
             void *params[] = {&a};
             if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();

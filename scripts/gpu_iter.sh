@@ -1,6 +1,6 @@
 #!/bin/bash
 # One short gpurun call of an optimisation iteration: a chosen subset of the GPU tests, A/B against libedynhip_base.so, knob runs,
-# optional dataflow traces. usage: scripts/gpu_iter.sh <tag> "<pytest -k expression or ''>" [extra "NAME WORKLOAD ENV=.." runs via RUNS file]
+# optional dataflow traces. usage: scripts/gpu_iter.sh <tag> "<pytest -k expression or ''>" (then sources scripts/runs/<tag>.sh: the run / trace lines of this iteration)
 TAG=${1:-it}; KEXPR=${2:-}; mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp
 line() { python - "$1" "$2" <<'PY'
 import json, sys
@@ -24,8 +24,15 @@ trace() {  # trace <name> [ENV=..]...
   python scripts/df_trace.py /tmp/dfp_$name.bin > gpurun_out/$TAG/dftrace_position_$name.txt 2>&1
   echo "--- trace $name $*"; sed -n '1p;9p' gpurun_out/$TAG/dftrace_velocity_$name.txt; head -4 gpurun_out/$TAG/dftrace_position_$name.txt
 }
+prof() {  # prof <name> [ENV=..]... : rocprofv3 kernel statistics of the default bench command (per-step averages)
+  local name=$1; shift
+  local W=/tmp/prof_$name; rm -rf $W; mkdir -p $W
+  ( cd /tmp && env "$@" rocprofv3 --kernel-trace --stats -d $W/kt -o r -- python $OLDPWD/bench.py --steps 300 --warmup 20 --north-star none --no-cpu-baseline > /dev/null 2> $W/kt.log )
+  python scripts/prof_summary.py $W/kt 440 k_contact_solve 300 > gpurun_out/$TAG/kernel_stats_$name.txt 2>&1
+  echo "--- prof $name $*"; head -${PROF_LINES:-22} gpurun_out/$TAG/kernel_stats_$name.txt | cut -c1-118
+}
 if [ -n "$KEXPR" ]; then
   timeout 900 python -m pytest tests -m gpu -x -q --durations=30 -k "$KEXPR" > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 gpurun_out/$TAG/pytest_gpu.log
 fi
 BASE=$PWD/edyn_amd/libedynhip_base.so
-[ -f gpurun_out_runs_$TAG.sh ] && source gpurun_out_runs_$TAG.sh
+[ -f scripts/runs/$TAG.sh ] && source scripts/runs/$TAG.sh
