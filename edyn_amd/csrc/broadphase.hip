@@ -325,10 +325,9 @@ DI void consider_sleeping_owner(uint32_t i, uint32_t j, const box3 &bi, const fl
 // how long the lists live, not whether they are right.)
 constexpr uint32_t kHigherBit = 0x80000000u;      // list entry flag: the candidate has a HIGHER index (recorded when island
                                                   // sleeping is on: it matters only while that body sleeps, see below)
-// The tree walk, only in the steps that rebuild the lists: stackless (ropes), fat query box, kWalkSplit lanes per body - lane s walks the
-// s-th of the subtrees three levels below the root (k_bp_split, with the topology) and stops at that subtree's rope. One lane per body
-// left half of the SIMDs without a wave on a 32k-body scene and made the walk a single chain of ~300 dependent node loads (0.52 ms per
-// step on a heap whose every step rebuilds the lists). The order of a list's entries is arbitrary: the pairs are sorted later.
+// The subtrees three levels below the root (k_bp_split, computed with the topology): a body whose candidate list overflowed walks the
+// tree in k_bp_pairs every step, stackless (ropes), one of these subtrees per lane - each walk ends at its subtree's rope. (Until round
+// 4 the list-building walk k_bp_walk ran the same way, kWalkSplit lanes per body; it is group-cooperative now, below.)
 constexpr uint32_t kWalkSplit = 8;
 __global__ void k_bp_split(int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, uint32_t *split) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -346,43 +345,76 @@ __global__ void k_bp_split(int n, const uint32_t *__restrict__ left, const uint3
     }
     for (uint32_t e = 0; e < kWalkSplit; ++e) split[e] = e < nc ? cur[e] : kRopeEnd;
 }
+// Round 4: a GROUP of kWalkLanes lanes walks the tree for one body together. The walk used to be a chain of dependent node loads per
+// lane (~0.25 us each, 150-300 of them on a pile, far more for the fat boxes of a heap in motion: 0.55 ms per step on the polyhedron
+// heap); now the group keeps a stack of pending nodes in LDS, pops up to kWalkLanes of them per round, tests them in parallel and pushes
+// the children of the internal nodes that overlap (wave prefix sums place them): a walk of N node tests takes ~N / kWalkLanes + depth
+// dependent rounds. A stack that would overflow marks the body's list as overflowed - the same safe fallback as a list with more than
+// kListCap entries (the body then walks the tree in k_bp_pairs every step).
+constexpr uint32_t kWalkLanes = 16, kWalkStack = 192;
 __global__ void __launch_bounds__(256)
 k_bp_walk(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
           const float4 *__restrict__ amin, const float4 *__restrict__ amax, CandLists cl, const Counters *cnt, uint32_t *visit, bool both_ways, uint32_t force,
-          const uint32_t *__restrict__ split, const uint32_t *__restrict__ rope) {
+          const uint32_t *__restrict__ right) {
     if (!(cnt->bp_rebuild | force)) return;
-    __shared__ uint32_t found[256 / kWalkSplit];
+    __shared__ uint32_t stack_mem[256 / kWalkLanes][kWalkStack];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = t / (int)kWalkSplit;
-    const uint32_t s = (uint32_t)t % kWalkSplit, kl = threadIdx.x / kWalkSplit;
-    if (s == 0) { found[kl] = 0; if (k < n - 1) visit[k] = 0; }   // (visit: arm the refit counters for the next refit)
-    __syncthreads();
-    uint32_t i = 0;
+    const int k = t / (int)kWalkLanes;
+    const uint32_t s = threadIdx.x % kWalkLanes, g = threadIdx.x / kWalkLanes;
+    volatile uint32_t *stack = stack_mem[g];
+    if (s == 0 && k < n - 1) visit[k] = 0;   // (visit: arm the refit counters for the next refit)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t group_mask = ((1ull << kWalkLanes) - 1ull) << (lane & ~(kWalkLanes - 1u)), lower = (1ull << lane) - 1ull;
+    const uint32_t first_leaf = (uint32_t)(n - 1);
+    uint32_t i = 0, top = 0, found = 0;
+    bool overflow = false;
+    box3 q{mk3(0, 0, 0), mk3(0, 0, 0)};
+    uint32_t *row = nullptr;
     if (k < n) {
         i = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-        const uint32_t start = split[s];
-        if (n > 1 && start != kRopeEnd) {
-            const float4 a4 = cl.ref_min[i], c4 = cl.ref_max[i];          // written by this step's refit: the current AABB and the slack
-            const box3 q = inset(box3{from4(a4), from4(c4)}, -(kListTest + a4.w));
-            uint32_t *row = cl.list + (size_t)i * kListCap;
-            const uint32_t stop = rope[start], first_leaf = (uint32_t)(n - 1);
-            uint32_t node = start;
-            while (node != stop) {   // descend left while the box overlaps, else follow the rope past this subtree
-                const float4 lo4 = nmin[node], hi4 = nmax[node];
-                const bool hit = intersect(box3{from4(lo4), from4(hi4)}, q);
-                if (hit && node >= first_leaf) {
-                    const uint32_t j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
-                    if (j < i || (both_ways && j > i)) {
-                        const uint32_t at = atomicAdd(&found[kl], 1u);
-                        if (at < kListCap) row[at] = j < i ? j : (j | kHigherBit);
-                    }
-                }
-                node = (hit && node < first_leaf) ? __float_as_uint(lo4.w) : __float_as_uint(hi4.w);
+        const float4 a4 = cl.ref_min[i], c4 = cl.ref_max[i];          // written by this step's refit: the current AABB and the slack
+        q = inset(box3{from4(a4), from4(c4)}, -(kListTest + a4.w));
+        row = cl.list + (size_t)i * kListCap;
+        if (n > 1) { if (s == 0) stack[0] = 0u; top = 1; }           // the root (internal node 0)
+    }
+    while (__any(top > 0)) {   // (every lane of the wave stays in the loop: the ballots below need them; a finished group idles)
+        const uint32_t take = min(top, kWalkLanes);
+        const bool has = s < take;
+        const uint32_t node = has ? stack[top - 1 - s] : 0u;
+        top -= take;
+        const bool leaf = node >= first_leaf;
+        bool hit = false;
+        uint32_t lc = 0, rc = 0;
+        if (has) {
+            const float4 lo4 = nmin[node], hi4 = nmax[node];
+            if (!leaf) rc = right[node];
+            hit = intersect(box3{from4(lo4), from4(hi4)}, q);
+            lc = __float_as_uint(lo4.w);
+        }
+        bool cand = false;
+        uint32_t j = 0;
+        if (hit && leaf) {
+            j = (uint32_t)(keys[node - first_leaf] & 0xFFFFFFFFu);
+            cand = j < i || (both_ways && j > i);
+        }
+        const bool inner = hit && !leaf;
+        const uint64_t bc = __ballot(cand) & group_mask, bi = __ballot(inner) & group_mask;
+        if (cand) {
+            const uint32_t at = found + (uint32_t)__popcll(bc & lower);
+            if (at < kListCap) row[at] = j < i ? j : (j | kHigherBit);
+        }
+        found += (uint32_t)__popcll(bc);
+        const uint32_t pushes = 2u * (uint32_t)__popcll(bi);
+        if (top + pushes > kWalkStack) { overflow = true; top = 0; }   // (uniform within the group)
+        else {
+            if (inner) {
+                const uint32_t at = top + 2u * (uint32_t)__popcll(bi & lower);
+                stack[at] = lc; stack[at + 1] = rc;
             }
+            top += pushes;
         }
     }
-    __syncthreads();
-    if (s == 0 && k < n) cl.count[i] = found[kl] <= kListCap ? found[kl] : kListOverflow;
+    if (s == 0 && k < n) cl.count[i] = (overflow || found > kListCap) ? kListOverflow : found;
 }
 __global__ void __launch_bounds__(kBpBlock)
 k_bp_pairs(const uint64_t *__restrict__ keys, int n, const float4 *__restrict__ nmin, const float4 *__restrict__ nmax,
@@ -634,7 +666,7 @@ int broadphase(edynhip_ctx *c) {
         c->bvh.lists_dirty = false;
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
                            sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
-        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkSplit, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.split, c->bvh.rope);
+        hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkLanes, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.right);
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kOwnersPerBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping, c->bvh.split, c->bvh.rope);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));

@@ -100,7 +100,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, r.dslot, ((size_t)M + 64) * 4));   // whole 64-lane blocks (dslot_at)
     EH_TRY(dalloc(c, r.pslot, ((size_t)M + 32) * 6));   // whole 32-lane blocks (pslot_at)
     EH_TRY(dalloc(c, r.next, (size_t)M * 2)); EH_TRY(dalloc(c, r.im, (size_t)M * 2));
-    EH_TRY(dalloc(c, r.pw, (size_t)M * kMaxPts * kPosF)); EH_TRY(dalloc(c, r.pil, (size_t)M * 2 * 3));
+    EH_TRY(dalloc(c, r.pw, (size_t)M * kMaxPts * kPosF));
     EH_TRY(dalloc(c, r.slot_of, (size_t)nb * kMaxColours)); EH_TRY(dalloc(c, r.first_slot, nb)); EH_TRY(dalloc(c, r.skip, M));
     LBVH &t = c->bvh;
     EH_TRY(dalloc(c, t.keys, nb)); EH_TRY(dalloc(c, t.keys_sorted, nb));

@@ -178,10 +178,9 @@ struct Rows {
                                   // bit 31 (kHeadBit) marks THIS slot as the head of its body's chain
     float4 *pslot = nullptr;      // position-solve hand-off slots, 3 float4 per (lane, side): see k_pos_contacts_df
     float *im = nullptr;          // [2p + side] inverse mass of that side's body (0 = read-only body: no hand-off)
-    // what the dataflow position solve reads, indexed by the lane like the rows (written by k_prep_contacts / k_push_links): with them
-    // a position task needs no gather through the manifold or body index - every load address follows from p
+    // what the dataflow position solve reads, indexed by the lane like the rows (written by k_prep_contacts): with it the points of a
+    // position task need no gather through the manifold index - their addresses follow from p
     float4 *pw = nullptr;         // [(k * kPosF + f) * cap + p]: point k's pivot on A, pivot on B, local normal, (normal, attachment)
-    float4 *pil = nullptr;        // [f * 2 cap + 2p + side], f < 3: the rows of that side's body's local inverse inertia (zero: read-only body)
     uint32_t *slot_of = nullptr;  // [body * 64 + colour] -> slot, scratch for building `next`
     uint32_t *first_slot = nullptr;   // per body: slot of its lowest-colour manifold (where a sweep leaves its deltas), or ~0
     uint8_t *skip = nullptr;          // [p] mixed schedule: the manifold's island has joints (solved by the island-fused kernels, not on the chains)

@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 // `isl_joint` (mixed schedule, else nullptr): islands with joints take no part in the hand-off chains - their manifolds are marked in
 // Rows::skip and their bodies keep first_slot = none (k_island_velocity / k_island_position solve them on the body records).
 __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used,
-                             const uint32_t *__restrict__ isl_joint, uint32_t rcap, bool write_pil) {
+                             const uint32_t *__restrict__ isl_joint) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_active) return;
     if (isl_joint) {
@@ -1137,15 +1137,12 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
         const uint32_t slot = 2 * p + side;
         // every slot starts a step as (0,0,0 | tag 0): the chain head's seed, and "nothing handed over yet" elsewhere
         rows.dslot[dslot_at(slot, 0)] = make_float4(0, 0, 0, 0); rows.dslot[dslot_at(slot, 1)] = make_float4(0, 0, 0, 0);
-        const size_t cap2 = 2 * (size_t)rcap;
         if (!is_dynamic(b.flags[body])) {   // read-only partner: permanent zero deltas, never written
             rows.next[slot] = slot;
             rows.im[slot] = 0.0f;
-            if (write_pil) { rows.pil[slot] = make_float4(0, 0, 0, 0); rows.pil[cap2 + slot] = make_float4(0, 0, 0, 0); rows.pil[2 * cap2 + slot] = make_float4(0, 0, 0, 0); }
             continue;
         }
         rows.im[slot] = B_POS(b, body).w;
-        if (write_pil) { rows.pil[slot] = B_IL(b, body, 0); rows.pil[cap2 + slot] = B_IL(b, body, 1); rows.pil[2 * cap2 + slot] = B_IL(b, body, 2); }
         const uint64_t mask = used[body];                         // colours of this body's active manifolds
         const uint64_t above = col >= 63 ? 0ull : mask & ~((2ull << col) - 1ull);
         const uint32_t nextc = (uint32_t)__ffsll((long long)(above ? above : mask)) - 1;
@@ -2392,7 +2389,6 @@ struct DfPosArgs {
     Counters *cnt;
     const uint8_t *skip;            // mixed schedule: manifolds of islands with joints (k_island_position solves those), else nullptr
     uint64_t *trace;                // developer aid (EDYNHIP_DFP_TRACE): 4 timestamps per (round, wave) of this iteration, else nullptr
-    bool use_pw, use_pil;           // points from the lane-indexed copy Rows::pw / inertia rows from Rows::pil (else gathered through the manifold / body index)
 };
 constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
@@ -2411,22 +2407,12 @@ DI void dfp_publish(float4 *slot, f3 pos, q4 orn, bool corrected, uint32_t tag) 
 }
 // Seeds the position hand-off chains from the integrated transforms; the side-A lane also copies its manifold's solved
 // impulses back to the contact points (what k_store_impulses does when the position solve runs per colour).
-__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf, const uint8_t *__restrict__ skip, bool write_pw) {
+__global__ void k_pos_seed(uint32_t n_active, Rows rows, Bodies b, float4 *pslot, uint32_t rcap, Manifolds mf, const uint8_t *__restrict__ skip) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= 2 * n_active) return;
     const uint32_t p = slot >> 1, body = (slot & 1u) ? rows.bB[p] : rows.bA[p];
     if (!(slot & 1u)) store_impulses_of(p, rows, rcap, mf);
     if (skip && skip[p]) return;   // an island with joints: not on the hand-off chains
-    if (write_pw) {   // the position solve's lane-indexed copy of the manifold's points (Rows::pw): side A's lane copies pivot A and the
-                      // local normal, side B's pivot B and the normal
-        const uint32_t m = rows.order[p], np = rows.np[p];
-        const float4 *__restrict__ s0 = (slot & 1u) ? mf.pB : mf.pA, *__restrict__ s1 = (slot & 1u) ? mf.nrm : mf.lnrm;
-        const size_t f0 = (slot & 1u) ? 1 : 0, f1 = (slot & 1u) ? 3 : 2;
-        for (uint32_t k = 0; k < np; ++k) {
-            const size_t sidx = (size_t)k * mf.cap + m, pb = (size_t)(k * kPosF) * rcap + p;
-            rows.pw[pb + f0 * rcap] = s0[sidx]; rows.pw[pb + f1 * rcap] = s1[sidx];
-        }
-    }
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0, h2 = h0;
     // the chain head starts from the integrated transform; the slot of a read-only body (static, kinematic) holds that body's transform
     // for the whole solve - its lane takes it from there without looking at the tag (no gather through the body index in the solve)
@@ -2451,43 +2437,52 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && is_dynamic(b.flags[i])) pos_writeback(b, i, pslot, first_slot);
 }
-// What a position task needs besides its points, none of it depending on the point count: loaded (with the first look at the task's
-// own hand-off slot) before the kernel branches on the point count, so that a task's loads are two dependent levels - (key, head,
-// first poll), then (points, the island's error of the previous iteration) - instead of four (key -> order / bodies / next -> the
-// manifold's points and the body records -> poll): the trace showed 3.5 us from "task begins" to "first poll back" against 1.5 us of
-// arithmetic and 1.3 us of waiting per task (profiles/r04_dftrace_position_*.txt).
-struct DfpHead { uint32_t m, ix, label, nx; float im; float4 il0, il1, il2; v4f h0, h1, h2; };
+// A position task's inputs, in the two dependent load levels they take: everything whose address follows from the lane's sorted
+// position p (key, manifold and body index, island label, next slot, inverse mass, the points' lane-indexed copies Rows::pw, and the
+// first look at the own hand-off slot), then what needs one of those (the body's local inverse inertia through the body index, the
+// island's error of the previous iteration through its label). Round 3's kernel took four levels (key -> order / bodies / next -> the
+// manifold's points and the body record -> poll): its trace showed 3.5 us from "task begins" to "first poll back" against 1.5 us of
+// arithmetic and 1.3 us of waiting per task. Measured and dropped (round 4): requesting the wave's NEXT task's inputs while the current
+// one runs (software pipelining, 256 VGPRs): no gain - what a task then waits for at its first poll is the prefetch itself; the inertia
+// rows as a lane-indexed copy too (costs k_push_links what it saves here); gathering the points through the manifold index one level
+// earlier instead of copying them (position kernel 84 instead of 71 us per iteration).
+struct DfpIn { uint32_t key, m, ix, label, nx; float im; float4 pw0[3]; };   // pw0 = the first point's (own pivot, local normal, (normal, attachment))
+struct DfpIn2 { float4 il[3]; float err; };
+DI void dfp_load1(const DfPosArgs &a, uint32_t p, bool sideB, DfpIn &in) {
+    const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
+    const size_t rcap = a.mf.cap;
+    in.key = a.keys_sorted[p];
+    in.m = a.rows.order[p]; in.ix = sideB ? a.rows.bB[p] : a.rows.bA[p]; in.label = a.rows.label[p]; in.nx = a.next[slot]; in.im = a.rows.im[slot];
+    // the first point (every task has one); the others follow with the second level, once the key has told how many there are
+    in.pw0[0] = a.rows.pw[p + (sideB ? rcap : 0)]; in.pw0[1] = a.rows.pw[p + 2 * rcap]; in.pw0[2] = a.rows.pw[p + 3 * rcap];
+}
+DI void dfp_load2(const DfPosArgs &a, const DfpIn &in, DfpIn2 &in2) {
+    const bool proc = in.im != 0.0f;
+    const float4 z = make_float4(0, 0, 0, 0);
+    in2.il[0] = proc ? B_IL(a.b, in.ix, 0) : z; in2.il[1] = proc ? B_IL(a.b, in.ix, 1) : z; in2.il[2] = proc ? B_IL(a.b, in.ix, 2) : z;
+    in2.err = a.err_prev ? a.err_prev[in.label] : 1.0f;
+}
 template <int NP>
-DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, const DfpHead &hd, uint64_t w0, uint64_t *trace_slot) {
+DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, const DfpIn &in, const DfpIn2 &in2,
+                 const v4f &f0, const v4f &f1, const v4f &f2, uint64_t w0, uint64_t *trace_slot) {
     const Manifolds &mf = a.mf;
     uint64_t w1 = 0, w2 = 0;
-    const uint32_t m = hd.m, label = hd.label;
+    const uint32_t m = in.m, label = in.label;
     const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
-    const uint32_t nx = hd.nx;
-    const size_t rcap = mf.cap;
+    const uint32_t nx = in.nx;
     float4 piv[NP], l4[NP], n4[NP];
-    if (a.use_pw) {
+    piv[0] = in.pw0[0]; l4[0] = in.pw0[1]; n4[0] = in.pw0[2];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const size_t pb = (size_t)(k * kPosF) * rcap + p;
-            piv[k] = a.rows.pw[pb + (sideB ? rcap : 0)]; l4[k] = a.rows.pw[pb + 2 * rcap]; n4[k] = a.rows.pw[pb + 3 * rcap];
-        }
-    } else {
-        const float4 *__restrict__ pvsrc = sideB ? mf.pB : mf.pA;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const size_t sidx = (size_t)k * rcap + m;
-            piv[k] = pvsrc[sidx]; l4[k] = mf.lnrm[sidx]; n4[k] = mf.nrm[sidx];
-        }
+    for (int k = 1; k < NP; ++k) {
+        const size_t rcap = mf.cap, pb = (size_t)(k * kPosF) * rcap + p;
+        piv[k] = a.rows.pw[pb + (sideB ? rcap : 0)]; l4[k] = a.rows.pw[pb + 2 * rcap]; n4[k] = a.rows.pw[pb + 3 * rcap];
     }
     PBody X;   // the transform comes with the hand-off (a read-only body's: from its seeded slot); pivots are anchored at the position
-    X.inv_m = hd.im; X.proc = hd.im != 0.0f;
-    if (a.use_pil) X.il = {from4(hd.il0), from4(hd.il1), from4(hd.il2)};
-    else if (X.proc) X.il = {from4(B_IL(a.b, hd.ix, 0)), from4(B_IL(a.b, hd.ix, 1)), from4(B_IL(a.b, hd.ix, 2))};
-    else X.il = m3_zero();
+    X.inv_m = in.im; X.proc = in.im != 0.0f;
+    X.il = {from4(in2.il[0]), from4(in2.il[1]), from4(in2.il[2])};
     X.has_com = false; X.com = mk3(0, 0, 0);   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
     X.pos = X.org = mk3(0, 0, 0); X.orn = q4{0, 0, 0, 1};
-    const uint32_t done_isl = (a.err_prev && a.err_prev[label] < kPosErrorThreshold) ? 1u : 0u;
+    const uint32_t done_isl = in2.err < kPosErrorThreshold ? 1u : 0u;
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = false;
     bool corrected = false;
@@ -2508,7 +2503,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             got = true;
         }
     };
-    if (!done) accept(hd.h0, hd.h1, hd.h2);   // the look taken with the head loads
+    if (!done) accept(f0, f1, f2);   // the look the kernel loop took before it requested the next task's second level
     for (uint32_t spin = 0;; ++spin) {
         if (!done && !got && spin > 0) {
             v4f h0, h1, h2;
@@ -2562,25 +2557,22 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
     const uint32_t nwaves = a.stride >> 5;
-    const size_t cap2 = 2 * (size_t)a.mf.cap;
     for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
         const uint32_t pt = base + t;
         const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
         if (!__any(valid)) continue;
         const uint64_t w0 = a.trace ? wall_clock64() : 0;
-        const uint32_t p = valid ? pt : a.na - 1;
-        const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
-        const uint32_t key = a.keys_sorted[p];
-        DfpHead hd;
-        hd.m = a.rows.order[p]; hd.ix = sideB ? a.rows.bB[p] : a.rows.bA[p]; hd.label = a.rows.label[p]; hd.nx = a.next[slot]; hd.im = a.rows.im[slot];
-        if (a.use_pil) { hd.il0 = a.rows.pil[slot]; hd.il1 = a.rows.pil[cap2 + slot]; hd.il2 = a.rows.pil[2 * cap2 + slot]; }
-        else hd.il0 = hd.il1 = hd.il2 = make_float4(0, 0, 0, 0);
-        dfp_poll(a.pslot + pslot_at(slot, 0), hd.h0, hd.h1, hd.h2);   // (waits for the loads above with it)
-        const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
+        const uint32_t p = pt < a.na ? pt : a.na - 1;
+        DfpIn in; DfpIn2 in2;
+        dfp_load1(a, p, sideB, in);
+        v4f f0, f1, f2;
+        dfp_poll(a.pslot + pslot_at(2 * p + (sideB ? 1u : 0u), 0), f0, f1, f2);   // the first look at the own slot travels with level 1
+        dfp_load2(a, in, in2);
+        const uint32_t np = valid ? 4u - (in.key & 3u) : 0u, col = in.key >> 2;
         uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)round * nwaves + blockIdx.x) : nullptr;
-        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col, hd, w0, tr);
-        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col, hd, w0, tr);
-        else dfp_task<1>(a, p, valid, sideB, np, col, hd, w0, tr);
+        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
+        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
+        else dfp_task<1>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
     }
 }
 
@@ -3159,12 +3151,7 @@ int solve(edynhip_ctx *c) {
     // (uncoloured edges left for the multi-block rounds: a scene coloured from scratch) the rows are prepared again after the second sort;
     // a non-empty serial bucket only drops `push` - the slot table written for it is read through the bodies' colour masks alone.
     static const bool spec_env = !(getenv("EDYNHIP_SPECULATE") && getenv("EDYNHIP_SPECULATE")[0] == '0');
-    // developer knobs of the dataflow position solve's inputs: EDYNHIP_POS_PW=0 gathers the points through the manifold index instead of
-    // reading the lane-indexed copy k_prep_contacts writes (Rows::pw); EDYNHIP_POS_PIL=1 reads the inertia rows from a lane-indexed copy
-    // written by k_push_links (Rows::pil) instead of gathering them through the body index
-    static const bool kUsePw = !(getenv("EDYNHIP_POS_PW") && getenv("EDYNHIP_POS_PW")[0] == '0');
-    static const bool kUsePil = getenv("EDYNHIP_POS_PIL") && getenv("EDYNHIP_POS_PIL")[0] == '1';
-    const bool kPwInPrep = kUsePw;
+    const bool kPwInPrep = true;   // k_prep_contacts also writes the position solve's lane-indexed copy of the points (Rows::pw) on the push schedules
     bool spec_prep = false;
     auto speculative_prep = [&]() {
         rec(c, 4);
@@ -3251,7 +3238,7 @@ int solve(edynhip_ctx *c) {
         }
     }
     if (push) {
-        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr, rcap, kUsePil);
+        hipLaunchKernelGGL(k_push_links, dim3(blocks(na, 256)), dim3(256), 0, s, na, c->rows, c->col_keys_sorted, c->b, c->used, mixed ? c->isl_joint : nullptr);
     }
     const uint8_t *df_skip = mixed ? c->rows.skip : nullptr;
     IslSolveArgs isl_args{isl, c->cnt, j, c->b, c->rows, mf, rcap, c->extras ? c->rows.rwx : nullptr, 0u, c->isl_err, c->isl_done, mixed ? 1u : 0u};
@@ -3428,7 +3415,7 @@ int solve(edynhip_ctx *c) {
     if (pos_df) {
         static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
-        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip, false);
+        hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip);
         const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
         // developer aid: EDYNHIP_DFP_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th position solve
         // (same file format as EDYNHIP_DF_TRACE with "sweeps" = position iterations: scripts/df_trace.py reads both)
@@ -3445,7 +3432,7 @@ int solve(edynhip_ctx *c) {
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
-                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr, kUsePw, kUsePil};
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr};
             void *params[] = {&a};
             if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
