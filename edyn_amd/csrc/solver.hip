@@ -2442,8 +2442,11 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
 // first look at the own hand-off slot), then what needs one of those (the body's local inverse inertia through the body index, the
 // island's error of the previous iteration through its label). Round 3's kernel took four levels (key -> order / bodies / next -> the
 // manifold's points and the body record -> poll): its trace showed 3.5 us from "task begins" to "first poll back" against 1.5 us of
-// arithmetic and 1.3 us of waiting per task. Measured and dropped (round 4): requesting the wave's NEXT task's inputs while the current
-// one runs (software pipelining, 256 VGPRs): no gain - what a task then waits for at its first poll is the prefetch itself; the inertia
+// arithmetic and 1.3 us of waiting per task. Measured and dropped (round 4, scripts/runs/c5-c9.sh): requesting the wave's NEXT task's
+// inputs while the current one runs - before its polls, or at the moment its hand-offs have arrived, with the island's error looked at
+// only after the arithmetic (256 VGPRs): the time to the first poll falls from 2.3 to 1.3 us and the arithmetic section grows by as
+// much; leaving out the scattered point stores (experiment): no difference - a launch is one sweep over 16-18 colours that advances
+// round by round at the pace of each round's slowest wave, ~4 us per colour whatever a single task saves; the inertia
 // rows as a lane-indexed copy too (costs k_push_links what it saves here); gathering the points through the manifold index one level
 // earlier instead of copying them (position kernel 84 instead of 71 us per iteration).
 struct DfpIn { uint32_t key, m, ix, label, nx; float im; float4 pw0[3]; };   // pw0 = the first point's (own pivot, local normal, (normal, attachment))
