@@ -260,6 +260,8 @@ DI uint32_t find_prev(const Manifolds &prev, uint32_t pm, uint32_t hi, uint32_t 
 constexpr int kBpBlock = 64;  // one wave per workgroup: LDS per block stays small, so many blocks share a CU
 // The lane's own keys all start with the same owner: LDS keeps only the low half, (other << 1 | swapped), 4 bytes a key.
 // kPairLanes lanes share an owner (each takes every kPairLanes-th candidate): they append to the owner's list through an LDS counter.
+// (Sixteen lanes per owner, also only for scenes with many pairs per body, were measured in round 4 and are slower everywhere: pile32k 836
+// against 888 steps/s, the polyhedron heap 299 against 303 - the kernel is not bound by a lane's chain of candidates.)
 constexpr int kPairLanes = 4, kOwnersPerBlock = kBpBlock / kPairLanes;
 struct Emit { uint32_t (*mine)[kOwnersPerBlock]; uint32_t *count; int ol; uint64_t *extra; uint32_t cap; Counters *cnt; uint32_t tree; };   // tree: kept forest-certificate manifolds
 DI void emit_pair(uint64_t skey, Emit &e) {
