@@ -128,6 +128,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->state_dev, (size_t)nb * 13));
     EH_HIP(c, hipHostMalloc((void **)&c->state_host, (size_t)nb * 13 * sizeof(float), hipHostMallocDefault));
     EH_TRY(dalloc(c, c->sleep_state, nb)); EH_TRY(dalloc(c, c->sleep_action, nb)); EH_TRY(dalloc(c, c->sleep_since, nb));
+    EH_TRY(dalloc(c, c->sleep_old_label, nb)); EH_TRY(dalloc(c, c->sleep_size, nb)); EH_TRY(dalloc(c, c->sleep_best, nb)); EH_TRY(dalloc(c, c->sleep_carried, nb));
     EH_HIP(c, hipMemsetAsync(c->sleep_since, 0xFF, (size_t)nb * sizeof(double), c->stream));   // all ones (a NaN): no timer running
     Joints &j = c->j;
     j.cap = nj;
@@ -677,6 +678,9 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         c->sim_clock = 0;
         (void)hipMemsetAsync(c->sleep_state, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
         (void)hipMemsetAsync(c->sleep_action, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->sleep_size, 0, (size_t)c->b.cap * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->sleep_best, 0, (size_t)c->b.cap * sizeof(unsigned long long), c->stream);
+        c->sleep_prev_n = 0;   // no islands of a previous step
         (void)hipStreamSynchronize(c->stream);
     }
     c->force_islands = true;

@@ -383,6 +383,11 @@ struct edynhip_ctx {
     double sim_clock = 0;
     uint32_t *sleep_state = nullptr, *sleep_action = nullptr;   // per island label: reduction bits / decision
     double *sleep_since = nullptr;                              // per island label: stamp at which its timer started, < 0 = not running
+    // the timer that survives an island merge (solver.hip k_sleep_sizes / k_sleep_carry): last step's labels and body count, sizes of last
+    // step's islands, the biggest candidate per new label (size << 32 | ~old label), the carried stamps
+    uint32_t *sleep_old_label = nullptr, *sleep_size = nullptr, sleep_prev_n = 0;
+    unsigned long long *sleep_best = nullptr;
+    double *sleep_carried = nullptr;
     int df_mode = -1;              // dataflow velocity solve: -1 = not probed yet, 0 = unavailable/disabled, 1 = in use
     uint32_t df_lanes = 0;         // resident waves of the dataflow velocity kernel
     uint32_t dfp_waves = 0;        // resident waves of the dataflow position kernel

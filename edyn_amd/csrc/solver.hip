@@ -193,11 +193,57 @@ __global__ void k_cc_flatten(uint32_t n, const uint32_t *__restrict__ flags, uin
 // bodies into state bits, (2) mark the islands that received a manifold created this step, (3) one lane per island
 // decides - wake (new edge, or sleeping and awake bodies merged), keep sleeping, run / restart the timer, go to sleep
 // once the timer has run for more than island_time_to_sleep (measured on the step time stamps, ctx.hpp sim_clock) - (4) every body applies its island's decision (put_to_sleep zeroes velocities).
-__global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state) {
+// merge_islands (island_manager.cpp:297-350): the BIGGEST of the islands that merge - nodes + edges - survives with its sleep timer.
+// Labels are lowest body indices, so the surviving timer is carried to the merged island's label: per new island, the timer of the biggest
+// of last step's islands it consists of; size = its procedural bodies + the edges it had before this step (manifolds that persist from
+// the previous array, joints), ties: the lowest old label (the checker's coloured order counts the same; pinned to the engine by
+// tests/test_reference_engine.py::test_island_merge_keeps_the_bigger_islands_sleep_timer_like_the_real_engine). Three small passes
+// in the steps of a world with island sleeping that relabel: k_sleep_sizes (sizes of last step's islands, keyed by last step's labels -
+// a copy taken before the hooks, the union-find halves paths in place), the candidate maximum in k_sleep_scan, k_sleep_carry.
+struct SleepMerge { const uint32_t *old_label; uint32_t prev_n; uint32_t *size; unsigned long long *best; double *carried; };
+DI void add_by_label(uint32_t label, uint32_t amount, uint32_t *dst) {   // every lane of the wave calls this (amount 0 = nothing): one atomic per distinct label and wave
+    uint64_t todo = __ballot(amount != 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t l = (uint32_t)__shfl((int)label, leader);
+        const bool mine = amount != 0 && label == l;
+        uint32_t sum = mine ? amount : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&dst[l], sum);
+        todo &= ~__ballot(mine);
+    }
+}
+__global__ void k_sleep_sizes(uint32_t n, Bodies b, Manifolds mf, uint32_t M, Joints j, SleepMerge sm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t label = 0, amount = 0;
+    if (i < n && i < sm.prev_n && is_dynamic(b.flags[i]) && !(b.flags[i] & BF_REMOVED)) {
+        label = sm.old_label[i];
+        amount = 1;
+        if (M) for (uint32_t s = mf.seg_start[i], e = mf.seg_end[i]; s < e; ++s) amount += mf.prev_idx[s] != 0xFFFFFFFFu ? 1u : 0u;   // this body's manifolds (it is their owner) that existed before this step
+        if (label >= n) amount = 0;
+    }
+    add_by_label(label, amount, sm.size);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < j.n; e += gridDim.x * blockDim.x) {   // joints (few): plain atomics
+        const uint32_t a = j.bodyA[e], bb = j.bodyB[e], x = is_dynamic(b.flags[a]) ? a : bb;
+        if (x < sm.prev_n && is_dynamic(b.flags[x]) && sm.old_label[x] < n) atomicAdd(&sm.size[sm.old_label[x]], 1u);
+    }
+}
+__global__ void k_sleep_carry(uint32_t n, Bodies b, SleepMerge sm, const double *__restrict__ since) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = sm.best[i];
+    sm.best[i] = 0ull; sm.size[i] = 0u;   // armed for the next relabelling step
+    sm.carried[i] = key ? since[~(uint32_t)key] : -1.0;
+}
+__global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state, SleepMerge sm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t fl = b.flags[i];
     if (!is_dynamic(fl)) return;
+    // one of last step's island roots: a candidate for the timer of the island it is in now
+    if (sm.best && i < sm.prev_n && !(fl & BF_REMOVED) && sm.old_label[i] == i)
+        atomicMax(&sm.best[b.island[i]], ((unsigned long long)sm.size[i] << 32) | (unsigned long long)(~i));
     const f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
     const float lin = 0.005f, ang = 3.1415926535897932384626433832795029f / 48.0f;   // config/constants.hpp:41-42
     uint32_t bits = (fl & BF_ASLEEP) ? SL_HAS_ASLEEP : SL_HAS_AWAKE;
@@ -210,12 +256,13 @@ __global__ void k_sleep_edges(const uint2 *__restrict__ edges, const Counters *c
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
         atomicOr(&state[label[edges[e].x]], (uint32_t)SL_WAKE);   // .x = the pair's owner: always procedural
 }
-__global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *action, double *since, double now) {
+__global__ void k_sleep_decide(uint32_t n, Bodies b, uint32_t *state, uint32_t *action, double *since, double now, const double *__restrict__ carried) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = state[i];
     state[i] = 0;
     if (!is_dynamic(b.flags[i]) || b.island[i] != i) { since[i] = -1.0; return; }
+    if (carried) since[i] = carried[i];   // a relabelling step: the timer of the biggest island this one is made of (k_sleep_carry)
     if (s & SL_SPLIT) since[i] = -1.0;   // a part of an island that split: the timer starts again
     const bool wake = (s & SL_WAKE) || ((s & SL_HAS_ASLEEP) && (s & SL_HAS_AWAKE));
     if ((s & SL_HAS_ASLEEP) && !(s & SL_HAS_AWAKE) && !wake) { action[i] = SLA_KEEP; return; }
@@ -2989,6 +3036,9 @@ int islands(edynhip_ctx *c) {
     const int mode = force ? CC_FULL : inplace ? CC_SKIP
                      : (c->full_step && c->cnt_host->tree_found == c->cnt_host->tree_total) ? CC_INCREMENTAL : CC_FULL;
     (void)pm;
+    // island sleeping: last step's labels, before the hooks rewrite them (the merge rule of k_sleep_sizes / k_sleep_carry reads them)
+    if (c->sleeping && mode != CC_SKIP && c->sleep_old_label)
+        EH_HIP(c, hipMemcpyAsync(c->sleep_old_label, c->b.island, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     // the solve's per-body start rides on the flatten kernel when nothing in between looks at velocities or sleep flags
     const bool begin = c->full_step && !c->sleeping && !c->has_restitution;
     auto flatten = [&](uint32_t *forest_or_labels) {
@@ -3007,9 +3057,16 @@ int islands(edynhip_ctx *c) {
         flatten(c->b.island);
     }
     if (c->sleeping) {
-        hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state);
+        const bool relabelled = mode != CC_SKIP && c->sleep_old_label != nullptr;
+        SleepMerge sm{c->sleep_old_label, c->sleep_prev_n, c->sleep_size, c->sleep_best, c->sleep_carried};
+        if (!relabelled) sm.best = nullptr;
+        if (relabelled) hipLaunchKernelGGL(k_sleep_sizes, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, mf, M, c->j, sm);
+        hipLaunchKernelGGL(k_sleep_scan, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, sm);
+        if (relabelled) hipLaunchKernelGGL(k_sleep_carry, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, sm, c->sleep_since);
+        c->sleep_prev_n = n;
         hipLaunchKernelGGL(k_sleep_edges, dim3(32), dim3(256), 0, s, c->new_edges, c->cnt, c->b.island, c->sleep_state);
-        hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->sim_clock);
+        hipLaunchKernelGGL(k_sleep_decide, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_state, c->sleep_action, c->sleep_since, c->sim_clock,
+                           relabelled ? c->sleep_carried : (const double *)nullptr);
         hipLaunchKernelGGL(k_sleep_apply, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b, c->sleep_action, c->cnt);
     }
     EH_HIP(c, hipGetLastError());

@@ -771,10 +771,39 @@ public:
             if (bodies[i].procedural() && island_label[i] == i) ++count;
         }
         stats.num_islands = count;
+        // merge_islands (island_manager.cpp:297-350): when islands merge, the BIGGEST of them - nodes + edges - survives with its
+        // sleep_timestamp and takes the others in. Labels here are lowest body indices, so the surviving timer has to be carried to the
+        // merged island's label: per new island, the timer of the biggest of last step's islands it is made of, size = procedural bodies
+        // + edges (manifolds that existed before this step, joints); ties: the lowest old label. (The engine's count also has each
+        // island's non-procedural nodes - a set with history: a static body stays in it after its last edge is gone, until a split
+        // rebuilds it - and among equals it keeps the first in an ECS iteration order; both only matter between islands of nearly the same
+        // size. Demonstrated against the engine with a four-box scene: tests/test_reference_engine.py::test_island_merge_keeps_the_bigger_*.)
+        if (sleeping) {
+            sleep_since.resize(n, -1.0);
+            std::vector<uint32_t> size_old(n, 0);
+            auto old_label = [&](uint32_t i) { return i < prev_label.size() ? prev_label[i] : i; };
+            for (uint32_t i = 0; i < n && i < prev_label.size(); ++i) if (bodies[i].procedural() && !bodies[i].removed && prev_label[i] < n) ++size_old[prev_label[i]];
+            std::vector<uint64_t> fresh(new_keys);
+            std::sort(fresh.begin(), fresh.end());
+            for (auto &kv : manifolds) {
+                if (std::binary_search(fresh.begin(), fresh.end(), kv.first)) continue;   // created this step: in no island yet
+                const uint32_t a = kv.second.body[0], b = kv.second.body[1];
+                const uint32_t l = old_label(bodies[a].procedural() ? a : b);
+                if (l < n) ++size_old[l];
+            }
+            for (auto &j : joints) if (j.alive) { const uint32_t l = old_label(bodies[j.body[0]].procedural() ? j.body[0] : j.body[1]); if (l < n) ++size_old[l]; }
+            std::vector<double> carried(n, -1.0);
+            std::vector<uint32_t> best(n, 0xFFFFFFFFu);
+            for (uint32_t r = 0; r < n && r < prev_label.size(); ++r) {
+                if (prev_label[r] != r || !bodies[r].procedural() || bodies[r].removed) continue;   // last step's roots
+                const uint32_t L = island_label[r];
+                if (best[L] == 0xFFFFFFFFu || size_old[r] > size_old[best[L]]) { best[L] = r; carried[L] = sleep_since[r]; }
+            }
+            for (uint32_t i = 0; i < n; ++i) sleep_since[i] = (bodies[i].procedural() && island_label[i] == i) ? carried[i] : -1.0;
+        }
         // split_islands (island_manager.cpp:411-447): when an island falls apart, the largest component is MOVED into the island entity
         // - a move assignment of a freshly built `island`, whose sleep_timestamp is empty - and the others become new islands: every part
-        // starts its sleep timer again. (An island that merely merges keeps a timer: island_manager.cpp:297-350 keeps the larger island's;
-        // here the lower label's - the one deviation that is left, oracle/README.md.)
+        // starts its sleep timer again.
         split_reset_.assign(n, 0);
         for (uint32_t i = 0; i < n && i < prev_label.size(); ++i) {
             if (!bodies[i].procedural() || bodies[i].removed) continue;

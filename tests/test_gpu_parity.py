@@ -460,6 +460,26 @@ def test_island_split_restarts_the_sleep_timers():
     assert seen[199] == [False, False, True] and seen[-1] == [True, True, True]
 
 
+@pytest.mark.parametrize("mirror", [False, True])
+def test_island_merge_keeps_the_bigger_islands_sleep_timer(mirror):
+    """Two islands that merge while both sleep timers run: the merged island continues with the timer of the BIGGER one (merge_islands,
+    island_manager.cpp:297-350; pinned to the real engine in
+    tests/test_reference_engine.py::test_island_merge_keeps_the_bigger_islands_sleep_timer_like_the_real_engine): asleep 2 s after the
+    split that restarted the bigger island's timer (step 226), not 2 s after the start. Device == checker, every step."""
+    from test_reference_engine import _drift_together_scene
+    sc = _drift_together_scene(mirror)
+    g = gpu_world(sc, sleeping=True)
+    o = oracle_world(sc); o.set_sleeping(True)
+    first = None
+    for s in range(1, 261):
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_asleep(), o.get_asleep()), s
+        if first is None and g.get_asleep().any():
+            first = s
+    assert_state_equal(g, o)
+    assert first == 226 and g.get_asleep().all()
+
+
 def test_polyhedron_heap_at_size_bit_exact():
     """4096 convex polyhedra (edyn_amd.scenes.polyhedron_heap: cubes, tetrahedra, octahedra, prisms, wedges, random orientations)
     collapsing into a heap: pairs, state, manifolds (points in list order, impulses, colours) and AABBs equal the oracle's bit for bit
