@@ -123,8 +123,10 @@ def cpu_reference_leg(workload, sample_steps, warm_steps, state_path):
     t0 = time.perf_counter()
     r.step(warm_steps)
     warm_s = time.perf_counter() - t0
-    t = r.time_steps(sample_steps)
+    per_step = [r.time_steps(1) for _ in range(sample_steps)]   # one by one: the spread of the sample is reported beside its mean
+    t = sum(per_step)
     print(json.dumps({"value": sample_steps / t / scale, "cores": cores, "warm_s": warm_s, "what": what,
+                      "slowest": 1.0 / max(per_step) / scale, "fastest": 1.0 / min(per_step) / scale,
                       "points": int(r.get_manifolds()["num_points"].sum())}))
 
 
@@ -157,6 +159,9 @@ def cpu_baseline(workload, sample_steps, warm_steps, budget_s, state_path, settl
             ref = None
     if ref is not None:
         return {"value": ref["value"], "unit": "steps/sec", "cores": ref["cores"], "kind": "reference",
+                # the spread: over the steps of this sample, and what kept driver runs of earlier rounds recorded on the headline scene
+                # (box and state dependent: BENCH_r01..r03 1.29 / 1.88 / 1.13, profiles/r04 1.17) - a baseline, not a precise figure
+                "spread": {"slowest_step": ref.get("slowest"), "fastest_step": ref.get("fastest"), "earlier_rounds_pile32k": [1.29, 1.88, 1.13, 1.17]},
                 "sample": f"the reference engine itself (edyn::attach, execution_mode::sequential_multithreaded, {ref['cores']} host threads): "
                           f"{sample_steps} steps after {warm_steps} contact-building steps ({ref['warm_s']:.1f} s, ~{ref['points']} contact points) "
                           f"of {ref['what']} from {state_note}; beside it the {port_note}"}
