@@ -52,10 +52,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # parity statement that accompanies the number (tests/test_gpu_parity.py; the figures are asserted there)
 PARITY = ("bit-exact vs the oracle's coloured order in this settled state at full size (pairs, state, manifolds, colours: "
           "test_timed_regime_at_full_size_bit_exact; islands1m: test_islands1m_at_full_size_bit_exact) - the coloured order has its own "
-          "row arithmetic (fused multiply-adds, DESIGN.md section 3), the oracle's reference order is pinned to the reference engine bit for bit; "
+          "arithmetic for contact rows and position corrections (fused multiply-adds, the position correction per manifold, DESIGN.md section 3), "
+          "the oracle's reference order is pinned to the reference engine bit for bit; "
           "free-running vs the reference engine itself, C2 8000 boxes: 60 steps max |dpos| 0.23 m, mean 0.059 m; 300 steps (SURVEY 8(d)(4)): "
-          "mean resting height within 6.4e-4 m, penetration of the resting pile 0.0036 / 0.0018 m, kinetic energy of the resting set 1.2e-5 J per "
-          "body on both sides - a Gauss-Seidel visiting-order effect of the unconverged 10-iteration solve on a collapsing lattice, not fp "
+          "mean resting height within 3.4e-4 m, penetration of the resting pile 0.0036 / 0.0018 m, kinetic energy of the resting set 1.1e-5 / 1.2e-5 J per "
+          "body - a Gauss-Seidel visiting-order effect of the unconverged 10-iteration solve on a collapsing lattice, not fp "
           "rounding (lock-step: 2e-3 m per step, pair sets and narrowphase bit-exact, also on C3 at full size: 1.6e-3 m; "
           "test_c2_300_steps_survey_invariants_*, test_free_running_c2_*, test_c3_full_size_lock_step_*, test_gpu_against_the_real_reference_engine)")
 WORKLOADS = {
