@@ -74,6 +74,7 @@ MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
 FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE, FLAG_TIMING_SOLVE, FLAG_CONTACT_EVENTS = 1, 4, 8, 16, 32
+PAIR_FILTER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)   # edynhip_pair_filter: int filter(void *user, uint32_t body, uint32_t other)
 EVENT_DTYPE = np.dtype([("type", np.uint32), ("step", np.uint32), ("body", np.uint32, 2), ("point_id", np.uint64)])
 EVENT_MANIFOLD_CREATED, EVENT_MANIFOLD_DESTROYED, EVENT_POINT_CREATED, EVENT_POINT_DESTROYED = 1, 2, 3, 4
 STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
@@ -83,7 +84,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_set_joints", "edynhip_step", "edynhip_run_stages", "edynhip_synchronize", "edynhip_get_state",
            "edynhip_set_state", "edynhip_pack_state_device", "edynhip_get_derived", "edynhip_num_manifolds",
            "edynhip_get_manifolds", "edynhip_set_manifolds", "edynhip_get_pairs", "edynhip_get_joint_impulses",
-           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies", "edynhip_set_center_of_mass",
+           "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_set_pair_filter", "edynhip_default_should_collide", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies", "edynhip_set_center_of_mass",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
            "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
@@ -156,6 +157,8 @@ def lib():
         L.edynhip_step_timed.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
         L.edynhip_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_remove_collision_exclusion.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.edynhip_set_pair_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edynhip_default_should_collide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_set_joint_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_asleep.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_measure_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]

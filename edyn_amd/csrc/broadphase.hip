@@ -223,7 +223,7 @@ DI box3 body_box(const float4 *amin, const float4 *amax, uint32_t b) { return {f
 // (collision_exclusion: <= 16 entities per body, comp/collision_exclusion.hpp:16-31). It gates the CREATION of a manifold
 // only (broadphase.cpp:145,165); an existing manifold lives until its AABBs separate.
 constexpr uint32_t kMaxExclusions = 16;
-struct Filt { const uint64_t *group, *mask; const uint32_t *excl; };   // excl: [body][16], ~0u-terminated, or nullptr (no lists)
+struct Filt { const uint64_t *group, *mask; const uint32_t *excl; bool bypass; };   // excl: [body][16], ~0u-terminated, or nullptr (no lists); bypass: the host's pair filter decides (edynhip_set_pair_filter)
 DI bool excluded_one_way(const uint32_t *excl, uint32_t a, uint32_t b) {
     const uint32_t *l = excl + (size_t)a * kMaxExclusions;
     for (uint32_t k = 0; k < kMaxExclusions; ++k) {
@@ -234,6 +234,7 @@ DI bool excluded_one_way(const uint32_t *excl, uint32_t a, uint32_t b) {
     return false;
 }
 DI bool filter_ok(const Filt &f, uint32_t a, uint32_t b) {
+    if (f.bypass) return true;
     if ((f.group[a] & f.mask[b]) == 0 || (f.group[b] & f.mask[a]) == 0) return false;
     if (f.excl && (excluded_one_way(f.excl, a, b) || excluded_one_way(f.excl, b, a))) return false;
     return true;
@@ -532,6 +533,24 @@ __global__ void k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_
     for (uint32_t e = i; e < nextra; e += gridDim.x * blockDim.x) if (total + e < cap) out[total + e] = extra[e];
 }
 
+// ---- the host's pair filter (edynhip_set_pair_filter: settings.should_collide_func, broadphase.cpp:143-153) ---------------------------
+// k_bp_list_new: the positions, in the step's sorted pair list, of the candidates that have no manifold yet (order arbitrary).
+// k_bp_drop_rejected: the list without the pairs the host rejected (`rejected`: their positions, ascending).
+__global__ void k_bp_list_new(const uint64_t *__restrict__ skeys, uint32_t M, Manifolds prev, uint32_t pm, uint32_t *list, uint32_t *count) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint64_t key = skeys[m] >> 1;
+    if (find_prev(prev, pm, (uint32_t)(key >> 32), (uint32_t)key) == 0xFFFFFFFFu) list[atomicAdd(count, 1u)] = m;
+}
+__global__ void k_bp_drop_rejected(const uint64_t *__restrict__ in, uint64_t *out, uint32_t M, const uint32_t *__restrict__ rejected, uint32_t nrej) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    uint32_t a = 0, b = nrej;   // number of rejected positions below m
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if (rejected[mid] < m) a = mid + 1; else b = mid; }
+    if (a < nrej && rejected[a] == m) return;
+    out[m - a] = in[m];
+}
+
 // New manifold array from the sorted pair keys; contact points persist from the previous array.
 // `speculative`: the launch was enqueued before the host read the pair count (broadphase(), below) - M is then taken from the device
 // counters, and the launch does nothing when the host is going to take another path (capacity error, an unsorted surplus that needs the
@@ -669,7 +688,7 @@ int broadphase(edynhip_ctx *c) {
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
                            sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
         hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkLanes, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.right);
-        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kOwnersPerBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping, c->bvh.split, c->bvh.rope);
+        hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kOwnersPerBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl, c->pair_filter != nullptr}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping, c->bvh.split, c->bvh.rope);
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         EH_TRY(scan_u32(c, c->own_count, c->own_offset, c->b.n + 1));
         hipLaunchKernelGGL(k_bp_compact, dim3(blocks(c->b.n, 256)), dim3(256), 0, s, c->b.n, c->own_keys, c->own_count, c->own_offset, c->pair_keys, c->pair_keys_sorted, cur.cap, c->cnt, prev.skey, pm);
@@ -685,7 +704,7 @@ int broadphase(edynhip_ctx *c) {
         uint32_t ticket = 0;
         EH_TRY(publish_counters(c, sizeof(Counters) - sizeof(uint32_t) * 8 * kMaxColours, &ticket));
         const uint32_t spec_grid = std::min<uint32_t>(cur.cap / 512u, blocks(pm + pm / 16 + 2048, 512));
-        if (spec_env && c->full_step && pm > 0 && spec_grid > 0) {
+        if (spec_env && c->full_step && pm > 0 && spec_grid > 0 && !c->pair_filter) {   // (a host pair filter may shorten the list first)
             covered = spec_grid * 512u;
             hipLaunchKernelGGL(k_bp_build_manifolds, dim3(spec_grid), dim3(512), 0, s, c->pair_keys_sorted, 0u, cur, prev, pm, c->cnt, c->new_edges, c->new_edge_m, false, ev, c->prev_matched,
                                0u, true, inplace_allowed);
@@ -710,6 +729,38 @@ int broadphase(edynhip_ctx *c) {
             c->num_manifolds = M;
             EH_HIP(c, hipGetLastError());
             return EDYNHIP_OK;
+        }
+        // The host's pair filter: the step's new candidates go to the host, the rejected ones leave the list (slow path, see edynhip.h).
+        if (c->pair_filter && M > 0) {
+            uint32_t *count = &c->cnt->num_new;   // (free until the build counts the new manifolds; k_step_reset zeroed it)
+            EH_HIP(c, hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_bp_list_new, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, M, prev, pm, c->filter_new_idx, count);
+            uint32_t nnew = 0;
+            EH_HIP(c, hipMemcpyAsync(&nnew, count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            EH_HIP(c, hipStreamSynchronize(s));
+            if (nnew > 0) {
+                std::vector<uint32_t> idx(nnew);
+                EH_HIP(c, hipMemcpy(idx.data(), c->filter_new_idx, (size_t)nnew * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::sort(idx.begin(), idx.end());
+                std::vector<uint64_t> keys(M);   // (the whole list: one contiguous copy instead of nnew gathers)
+                EH_HIP(c, hipMemcpy(keys.data(), c->pair_keys_sorted, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                std::vector<uint32_t> rejected;
+                for (uint32_t m : idx) {
+                    const uint64_t sk = keys[m], key = sk >> 1;
+                    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+                    const bool swapped = sk & 1;   // body[0] - the querying body - is `lo`
+                    if (!c->pair_filter(c->pair_filter_user, swapped ? lo : hi, swapped ? hi : lo)) rejected.push_back(m);
+                }
+                if (!rejected.empty()) {
+                    EH_HIP(c, hipMemcpyAsync(c->filter_new_idx, rejected.data(), rejected.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(k_bp_drop_rejected, dim3(blocks(M, 256)), dim3(256), 0, s, c->pair_keys_sorted, c->pair_keys, M, c->filter_new_idx, (uint32_t)rejected.size());
+                    M -= (uint32_t)rejected.size();
+                    EH_HIP(c, hipMemcpyAsync(c->pair_keys_sorted, c->pair_keys, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+                    EH_HIP(c, hipMemcpyAsync(&c->cnt->num_pairs, &M, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    EH_HIP(c, hipStreamSynchronize(s));   // (`rejected` and M are host memory that must outlive the copies)
+                }
+            }
+            EH_HIP(c, hipMemsetAsync(count, 0, sizeof(uint32_t), s));
         }
         if (!c->full_step) {   // inside edynhip_step the previous step's k_finish already cleared these
             EH_HIP(c, hipMemsetAsync(cur.seg_start, 0, (size_t)c->b.cap * sizeof(uint32_t), s));

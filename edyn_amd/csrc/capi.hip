@@ -520,7 +520,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 12; }   // 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 13; }   // 13: edynhip_set_pair_filter (settings.should_collide_func); 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -644,6 +644,10 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
     up(in->shape_type, n, r.shape_type); up(in->shape_param, (size_t)n * 4, r.shape_param);
     up(in->friction, n, r.friction); up(in->restitution, n, r.restitution);
     up(in->group, n, r.group); up(in->mask, n, r.mask); up(in->gravity, (size_t)n * 3, r.gravity);
+    {   // host mirror of the collision groups / masks (edynhip_default_should_collide)
+        c->host_group.resize((size_t)first + n, ~0ull); c->host_mask.resize((size_t)first + n, ~0ull);
+        for (uint32_t i = 0; i < n; ++i) { c->host_group[first + i] = in->group ? in->group[i] : ~0ull; c->host_mask[first + i] = in->mask ? in->mask[i] : ~0ull; }
+    }
     up(in->sleeping_disabled, n, r.sleeping_disabled);
     {   // centre-of-mass offsets: the origin arrays are attached to the body set with the first body that has one
         bool any = false;
@@ -1181,6 +1185,29 @@ int edynhip_exclude_collision(edynhip_ctx *c, uint32_t a, uint32_t b) {
     };
     EH_TRY(add(a, b)); EH_TRY(add(b, a));
     return upload_exclusion_rows(c, a, b);
+}
+int edynhip_set_pair_filter(edynhip_ctx *c, edynhip_pair_filter filter, void *user) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    c->pair_filter = filter; c->pair_filter_user = user;
+    if (filter && !c->filter_new_idx) {
+        EH_HIP(c, hipSetDevice(c->device));
+        EH_TRY(dalloc(c, c->filter_new_idx, c->cfg.max_manifolds));
+    }
+    return EDYNHIP_OK;
+}
+int edynhip_default_should_collide(edynhip_ctx *c, uint32_t a, uint32_t b) {   // should_collide_default, should_collide.cpp:11-57
+    if (!c || a >= c->b.n || b >= c->b.n) return EDYNHIP_ERR_INVALID;
+    if (a == b) return 0;
+    if (a < c->host_group.size() && b < c->host_group.size() && ((c->host_group[a] & c->host_mask[b]) == 0 || (c->host_group[b] & c->host_mask[a]) == 0)) return 0;
+    if (!c->host_excl.empty()) {
+        auto listed = [&](uint32_t x, uint32_t y) {
+            const uint32_t *l = &c->host_excl[(size_t)x * 16];
+            for (uint32_t k = 0; k < 16 && l[k] != 0xFFFFFFFFu; ++k) if (l[k] == y) return true;
+            return false;
+        };
+        if (listed(a, b) || listed(b, a)) return 0;
+    }
+    return 1;
 }
 int edynhip_remove_collision_exclusion(edynhip_ctx *c, uint32_t a, uint32_t b) {
     if (!c || a >= c->b.n || b >= c->b.n) return EDYNHIP_ERR_INVALID;

@@ -381,6 +381,12 @@ struct edynhip_ctx {
     // a step runs - advanced by fixed_dt per edynhip_step step, set by the caller in edynhip_step_timed (the
     // max_steps_per_update clamp stretches the stamps, not the integration dt).
     double sim_clock = 0;
+    // edynhip_set_pair_filter: the user's should_collide predicate (host callback, asked for new candidate pairs: broadphase.hip) and
+    // host mirrors of the collision groups / masks for edynhip_default_should_collide
+    int (*pair_filter)(void *, uint32_t, uint32_t) = nullptr;
+    void *pair_filter_user = nullptr;
+    uint32_t *filter_new_idx = nullptr;            // [max_manifolds] positions in the sorted pair list of this step's new candidates / of the rejected ones
+    std::vector<uint64_t> host_group, host_mask;
     uint32_t *sleep_state = nullptr, *sleep_action = nullptr;   // per island label: reduction bits / decision
     double *sleep_since = nullptr;                              // per island label: stamp at which its timer started, < 0 = not running
     // the timer that survives an island merge (solver.hip k_sleep_sizes / k_sleep_carry): last step's labels and body count, sizes of last

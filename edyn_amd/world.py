@@ -380,6 +380,19 @@ class World:
         self._flush_defs()
         self._check(self._L.edynhip_remove_collision_exclusion(self._h, int(a), int(b)))
 
+    def set_should_collide(self, func):
+        """edyn::set_should_collide: func(body, other) -> bool replaces should_collide_default for NEW manifolds (None restores the device
+        test). A host callback: steps with new candidate pairs take the slow path described in include/edynhip.h."""
+        self._filter_cb = _capi.PAIR_FILTER(lambda user, a, b: 1 if func(int(a), int(b)) else 0) if func else None
+        self._check(self._L.edynhip_set_pair_filter(self._h, C.cast(self._filter_cb, C.c_void_p) if func else None, None))
+
+    def default_should_collide(self, a, b):
+        """should_collide_default (collision groups / masks, exclusion lists) - for predicates that extend it."""
+        r = self._L.edynhip_default_should_collide(self._h, int(a), int(b))
+        if r < 0:
+            self._check(r)
+        return bool(r)
+
     def set_material_extras(self, first, spin=None, roll=None, stiffness=None, damping=None):
         """material::{spin_friction, roll_friction, stiffness, damping} of bodies [first, first + n) - contact_extras_constraint
         (rolling / spinning friction, soft contacts). Arrays of equal length; None = the reference's default."""

@@ -68,6 +68,7 @@ public:
             return *static_cast<T *>(slot.get());
         }
         template <typename T> T &get() { return *static_cast<T *>(vars_.at(std::type_index(typeid(T))).get()); }
+        template <typename T> const T &get() const { return *static_cast<const T *>(vars_.at(std::type_index(typeid(T))).get()); }
         template <typename T> T *find() {
             auto it = vars_.find(std::type_index(typeid(T)));
             return it == vars_.end() ? nullptr : static_cast<T *>(it->second.get());
@@ -98,6 +99,13 @@ public:
     template <typename... T> bool any_of(entity e) { return (assure<T>().contains(e) || ...); }
     template <typename T> void remove(entity e) { assure<T>().remove(e); }
     context &ctx() { return ctx_; }
+    // read-only access through a const registry (what a should_collide predicate is handed): same pools, nothing is created that a
+    // non-const call would not create
+    template <typename T> const T &get(entity e) const { return const_cast<registry *>(this)->template get<T>(e); }
+    template <typename T> const T *try_get(entity e) const { return const_cast<registry *>(this)->template try_get<T>(e); }
+    template <typename... T> bool all_of(entity e) const { return const_cast<registry *>(this)->template all_of<T...>(e); }
+    template <typename... T> bool any_of(entity e) const { return const_cast<registry *>(this)->template any_of<T...>(e); }
+    const context &ctx() const { return ctx_; }
 
     template <typename First, typename... Rest>
     class basic_view {

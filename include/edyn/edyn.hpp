@@ -7,6 +7,7 @@
 //   edyn::rigidbody_def, rigidbody_kind, make_rigidbody                                include/edyn/util/rigidbody.hpp:22-93
 //   edyn::make_constraint<point_constraint|hinge_constraint>(registry, [entity,] body0, body1, setup...)   include/edyn/util/constraint_util.hpp:38-54
 //   edyn::exclude_collision, remove_collision_exclusion, clear_rigidbody                include/edyn/util/exclude_collision.hpp:20-47, util/rigidbody.hpp:95-103
+//   edyn::set_should_collide, should_collide_default                                   include/edyn/collision/should_collide.hpp:8-18 (host predicate: slow path)
 //   registry.destroy(body / constraint entity) on a running world                      noticed at the next update (island_manager.cpp:47-115 semantics)
 //   components: position, orientation, linvel, angvel, mass, mass_inv, inertia, material, box_shape, sphere_shape,
 //               plane_shape, AABB, dynamic_tag / kinematic_tag / static_tag, rigidbody_tag, contact_manifold (read-only view)
@@ -262,6 +263,8 @@ struct gpu_stepper {
     std::vector<entt::entity> constraints;     // joint index -> entity, same convention
     std::vector<uint8_t> constraint_kind;      // joint index -> EDYNHIP_JOINT_*: one entity may carry several constraint types (make_ragdoll: cone + cvjoint)
     std::vector<std::array<uint32_t, 2>> exclusions;   // every active exclude_collision pair (body indices): replayed into a re-created context
+    bool (*should_collide)(const entt::registry &, entt::entity, entt::entity){nullptr};   // edyn::set_should_collide: the user's predicate (nullptr = should_collide_default on the device)
+    entt::registry *filter_registry{nullptr};        // what the predicate is called with
     size_t exclusions_uploaded{0};                     // how many of them the current device context already holds (a prefix)
     std::vector<float> shadow;                         // asynchronous mode: the state this shim last wrote into the registry (13 floats per body) - what differs was edited by the user
     unsigned snapshot_bodies{0};                       // bodies the snapshot in flight covers
@@ -285,6 +288,12 @@ struct gpu_stepper {
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); if (world) edynhip_world_destroy(world); }
 };
 struct body_index { uint32_t value; };
+/// edynhip_pair_filter -> the user's should_collide_func: body indices back to the entities they were made from
+inline int pair_filter_trampoline(void *user, uint32_t body, uint32_t other) {
+    auto &s = *static_cast<gpu_stepper *>(user);
+    if (!s.should_collide || !s.filter_registry || body >= s.bodies.size() || other >= s.bodies.size()) return 1;
+    return s.should_collide(*s.filter_registry, s.bodies[body], s.bodies[other]) ? 1 : 0;
+}
 template <typename T> constexpr int joint_kind_of() {
     if constexpr (std::is_same_v<T, point_constraint>) return EDYNHIP_JOINT_POINT;
     else if constexpr (std::is_same_v<T, hinge_constraint>) return EDYNHIP_JOINT_HINGE;
@@ -577,6 +586,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         s.ctx = edynhip_create(&c, &st);
         s.meshes.clear();   // meshes belong to the context
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
+        if (s.should_collide) check(s, edynhip_set_pair_filter(s.ctx, &pair_filter_trampoline, &s));   // a re-created context asks the same predicate
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
         s.params_dirty = false;
     }
@@ -1135,6 +1145,28 @@ entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt:
     auto e = registry.create();
     make_constraint<T>(registry, e, body0, body1, setup...);
     return e;
+}
+
+// ---- collision/should_collide.hpp:8-18: the user's predicate that replaces should_collide_default for NEW manifolds (a host callback:
+// steps that have new candidate pairs take the slow path of edynhip_set_pair_filter). Multi-device worlds keep the default.
+using should_collide_func_t = bool (*)(const entt::registry &, entt::entity, entt::entity);
+/// collision groups / masks and exclusion lists, evaluated on the host (should_collide.cpp:11-57) - for predicates that extend the default
+inline bool should_collide_default(const entt::registry &registry, entt::entity first, entt::entity second) {
+    if (first == second) return false;
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const uint32_t a = registry.get<detail::body_index>(first).value, b = registry.get<detail::body_index>(second).value;
+    uint64_t ga = ~0ull, ma = ~0ull, gb = ~0ull, mb = ~0ull;
+    if (auto *f = registry.try_get<collision_filter>(first)) { ga = f->group; ma = f->mask; }
+    if (auto *f = registry.try_get<collision_filter>(second)) { gb = f->group; mb = f->mask; }
+    if ((ga & mb) == 0 || (gb & ma) == 0) return false;
+    for (auto &ex : s.exclusions) if ((ex[0] == a && ex[1] == b) || (ex[0] == b && ex[1] == a)) return false;
+    return true;
+}
+inline void set_should_collide(entt::registry &registry, should_collide_func_t func) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    if (func == &should_collide_default) func = nullptr;   // the device's own test
+    s.should_collide = func; s.filter_registry = &registry;
+    if (s.ctx) detail::check(s, edynhip_set_pair_filter(s.ctx, func ? &detail::pair_filter_trampoline : nullptr, &s));
 }
 
 // ---- util/exclude_collision.hpp:20-47

@@ -238,6 +238,21 @@ int edynhip_set_state(edynhip_ctx *ctx, const float *pos, const float *orn, cons
  * lives on until its AABBs separate, as in the reference. */
 int edynhip_exclude_collision(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);
 int edynhip_remove_collision_exclusion(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);
+/* settings.should_collide_func / edyn::set_should_collide (include/edyn/collision/should_collide.hpp:8-18, include/edyn/context/settings.hpp:43):
+ * the user's predicate that REPLACES should_collide_default - the reference calls it for every candidate of a body's tree query
+ * (src/edyn/collision/broadphase.cpp:143-153) and creates a manifold only when it says yes. A host callback cannot run inside the
+ * device broadphase, so a context with a filter takes a slow path in every step that has candidates for NEW manifolds: the device
+ * broadphase runs WITHOUT its group / mask / exclusion test, the new candidate pairs (AABBs already found overlapping, no manifold yet)
+ * travel to the host, `filter(user, body, other)` is asked once per pair - body = the querying (procedural) body, body[0] of the
+ * manifold that would be made - the rejected pairs are taken out of the step's pair list, and the step goes on. A rejected pair is
+ * asked about again in every step in which it is still a candidate, an existing manifold lives on until its AABBs separate - both as
+ * in the reference. The predicate must be a function of the pair (the reference asks more often - also for pairs that have a
+ * manifold or whose boxes then do not overlap - and in another order). edynhip_default_should_collide evaluates what the device would
+ * have (collision groups / masks, exclusion lists) for callbacks that extend the default. filter = NULL restores the device test.
+ * Costs one device-to-host copy and a stream synchronisation per step that has new candidates. Not available on edynhip_world_*. */
+typedef int (*edynhip_pair_filter)(void *user, uint32_t body, uint32_t other);
+int edynhip_set_pair_filter(edynhip_ctx *ctx, edynhip_pair_filter filter, void *user);
+int edynhip_default_should_collide(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);   /* 1 / 0, negative = error */
 /* Recompute every awake body's AABB and world-space inverse inertia from its current transform: the reference's public
  * update_aabbs(registry) / update_inertias(registry) (include/edyn/sys/update_aabbs.hpp:18-25, update_inertias.hpp:18-28).
  * A step does this at its end (solver.cpp:456-465); after edynhip_set_state the derived state is stale until then -

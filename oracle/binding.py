@@ -7,6 +7,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 product package (edyn_amd/) never does.
 """
 import ctypes as C
+PAIR_FILTER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)   # int filter(void *user, uint32_t body, uint32_t other)
 import os
 import subprocess
 import numpy as np
@@ -328,6 +329,16 @@ class World:
     def exclude_collision(self, a, b):
         f = self.L.orc_exclude_collision; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
         f(self.h, a, b)
+
+    def set_should_collide(self, func):
+        """settings.should_collide_func: func(body, other) -> bool replaces should_collide_default (None restores it)."""
+        self._filter_cb = PAIR_FILTER(lambda user, a, b: 1 if func(int(a), int(b)) else 0) if func else None
+        f = self.L.orc_set_should_collide; f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = None
+        f(self.h, C.cast(self._filter_cb, C.c_void_p) if func else None, None)
+
+    def default_should_collide(self, a, b):
+        f = self.L.orc_default_should_collide; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = C.c_int
+        return bool(f(self.h, a, b))
 
     def remove_collision_exclusion(self, a, b):
         f = self.L.orc_remove_collision_exclusion; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = None
@@ -694,6 +705,16 @@ class RefWorld:
 
     def exclude_collision(self, a, b):
         self.L.refw_exclude_collision(self.h, a, b)
+
+    def set_should_collide(self, func):
+        """edyn::set_should_collide on the real engine: func(body, other) -> bool (None restores should_collide_default)."""
+        self._filter_cb = PAIR_FILTER(lambda user, a, b: 1 if func(int(a), int(b)) else 0) if func else None
+        f = self.L.refw_set_should_collide; f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = None
+        f(self.h, C.cast(self._filter_cb, C.c_void_p) if func else None, None)
+
+    def default_should_collide(self, a, b):
+        f = self.L.refw_default_should_collide; f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]; f.restype = C.c_int
+        return bool(f(self.h, a, b))
 
     def remove_body(self, body):
         f = self.L.refw_remove_body; f.argtypes = [C.c_void_p, C.c_uint32]; f.restype = None

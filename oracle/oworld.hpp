@@ -474,6 +474,9 @@ public:
     void wake_all() { for (auto &b : bodies) b.asleep = false; std::fill(sleep_since.begin(), sleep_since.end(), -1.0); }
 
     // ---------------- broadphase ----------------
+    // settings.should_collide_func (settings.hpp:43, set_should_collide): a user predicate that replaces should_collide_default
+    int (*collide_filter)(void *, uint32_t, uint32_t) = nullptr;
+    void *collide_filter_user = nullptr;
     bool should_collide(uint32_t a, uint32_t b) const {   // should_collide.cpp:11-57
         if (a == b) return false;
         const Body &A = bodies[a], &B = bodies[b];
@@ -547,7 +550,7 @@ public:
             auto visit_tree = [&](const DynTree &t) {
                 t.query(q, [&](uint32_t leaf) {
                     uint32_t other = t.payload(leaf);
-                    if (!should_collide(k, other)) return;
+                    if (collide_filter ? !collide_filter(collide_filter_user, k, other) : !should_collide(k, other)) return;   // broadphase.cpp:145
                     uint64_t key = pair_key(k, other);
                     if (manifolds.count(key)) return;
                     if (!intersect(q, bodies[other].box)) return;

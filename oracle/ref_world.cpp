@@ -325,6 +325,23 @@ void refw_exclude_collision(void *h, uint32_t a, uint32_t b) {
     auto *w = (ref_world *)h;
     edyn::exclude_collision(w->registry, w->bodies[a], w->bodies[b]);
 }
+// settings.should_collide_func (edyn::set_should_collide, should_collide.hpp:18): a plain function pointer without user data, so the
+// world that installed a predicate is kept in a static (one filtered reference world at a time - checker use)
+static ref_world *g_filter_world = nullptr;
+static int (*g_filter_fn)(void *, uint32_t, uint32_t) = nullptr;
+static void *g_filter_user = nullptr;
+static bool filter_trampoline(const entt::registry &, entt::entity a, entt::entity b) {
+    return g_filter_fn(g_filter_user, g_filter_world->body_index(a), g_filter_world->body_index(b)) != 0;
+}
+void refw_set_should_collide(void *h, int (*fn)(void *, uint32_t, uint32_t), void *user) {
+    auto *w = (ref_world *)h;
+    g_filter_world = fn ? w : nullptr; g_filter_fn = fn; g_filter_user = user;
+    edyn::set_should_collide(w->registry, fn ? &filter_trampoline : &edyn::should_collide_default);
+}
+int refw_default_should_collide(void *h, uint32_t a, uint32_t b) {
+    auto *w = (ref_world *)h;
+    return edyn::should_collide_default(w->registry, w->bodies[a], w->bodies[b]) ? 1 : 0;
+}
 
 void refw_step(void *h, int n) {
     auto *w = (ref_world *)h;

@@ -97,6 +97,29 @@ int main() {
     run(90);
     CHECK(std::fabs(registry.get<edyn::position>(upper).y - 0.5f) < 3e-2f);
 
+    // set_should_collide (collision/should_collide.hpp:18): a user predicate decides about NEW manifolds - a ghost box falls through a
+    // solid one although nothing excludes the pair; with the default back, the next ghost lands on it
+    {
+        static entt::entity ghost;
+        def.position = {-14, 0.5f, 0}; auto solid = edyn::make_rigidbody(registry, def);
+        def.position = {-14, 1.6f, 0}; ghost = edyn::make_rigidbody(registry, def);
+        static int asked = 0;
+        edyn::set_should_collide(registry, [](const entt::registry &r, entt::entity a, entt::entity b) {
+            ++asked;
+            const bool floor = !r.all_of<edyn::dynamic_tag>(a) || !r.all_of<edyn::dynamic_tag>(b);
+            return edyn::should_collide_default(r, a, b) && (floor || (a != ghost && b != ghost));
+        });
+        run(90);
+        CHECK(asked > 0);
+        CHECK(std::fabs(registry.get<edyn::position>(ghost).y - 0.5f) < 3e-2f);      // through the solid box, onto the floor
+        CHECK(std::fabs(registry.get<edyn::position>(solid).y - 0.5f) < 3e-2f);
+        edyn::set_should_collide(registry, &edyn::should_collide_default);
+        def.position = {-18, 0.5f, 0}; edyn::make_rigidbody(registry, def);
+        def.position = {-18, 1.6f, 0}; auto lands = edyn::make_rigidbody(registry, def);
+        run(90);
+        CHECK(std::fabs(registry.get<edyn::position>(lands).y - 1.5f) < 3e-2f);
+    }
+
     // clear_rigidbody keeps the entity but takes the body out of the world
     edyn::clear_rigidbody(registry, lower);
     CHECK(registry.valid(lower));

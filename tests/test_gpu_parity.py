@@ -480,6 +480,36 @@ def test_island_merge_keeps_the_bigger_islands_sleep_timer(mirror):
     assert first == 226 and g.get_asleep().all()
 
 
+def test_user_should_collide_predicate_bit_exact():
+    """edynhip_set_pair_filter (settings.should_collide_func / edyn::set_should_collide): a host predicate - the default AND "index
+    parities differ" - decides about new manifolds; the device's slow path (new candidates to the host, rejected pairs out of the
+    step's list) against the checker with the same predicate: pair sets, state and manifolds bit for bit over a collapsing pile;
+    switched off after 80 steps. Pinned to the real engine in
+    tests/test_reference_engine.py::test_user_should_collide_predicate_matches_the_real_engine."""
+    from test_reference_engine import _checkerboard_filter, _pair_bodies
+    sc = scenes.box_pile(4, 4, 4)
+    g, o = gpu_world(sc), oracle_world(sc)
+    asked = []
+    g.set_should_collide(lambda a, b: (asked.append((a, b)) or True) and _checkerboard_filter(g.default_should_collide)(a, b))
+    o.set_should_collide(_checkerboard_filter(o.default_should_collide))
+    for s in range(1, 141):
+        if s == 81:
+            g.set_should_collide(None); o.set_should_collide(None)
+        g.step_simulation(1); o.step(1)
+        assert np.array_equal(g.get_pairs(), o.get_pairs()), s
+        if s % 20 == 0 or s == 81:
+            assert_state_equal(g, o)
+            assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"step {s}")
+        if s == 80:
+            hi, lo = _pair_bodies(g.get_pairs())
+            boxes = (hi != 0) & (lo != 0)
+            assert boxes.sum() > 20 and ((hi[boxes] + lo[boxes]) % 2 == 1).all()
+    assert len(asked) > 50 and len(set(asked)) < len(asked)   # rejected pairs are asked about again, step after step
+    hi, lo = _pair_bodies(g.get_pairs())
+    boxes = (hi != 0) & (lo != 0)
+    assert ((hi[boxes] + lo[boxes]) % 2 == 0).any()
+
+
 def test_polyhedron_heap_at_size_bit_exact():
     """4096 convex polyhedra (edyn_amd.scenes.polyhedron_heap: cubes, tetrahedra, octahedra, prisms, wedges, random orientations)
     collapsing into a heap: pairs, state, manifolds (points in list order, impulses, colours) and AABBs equal the oracle's bit for bit

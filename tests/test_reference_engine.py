@@ -340,6 +340,44 @@ def test_canonical_and_coloured_orders_agree_with_the_reference_order_within_tol
     assert np.abs(ref.get_state()[0][:, 1] - orc.get_state()[0][:, 1]).max() < 1e-3
 
 
+def _pair_bodies(keys):
+    keys = np.asarray(keys, np.uint64)
+    return (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+
+
+def _checkerboard_filter(default):
+    """A user predicate on top of the default: boxes whose indices have the same parity pass through each other."""
+    return lambda a, b: default(a, b) and (a == 0 or b == 0 or (a + b) % 2 == 1)
+
+
+def test_user_should_collide_predicate_matches_the_real_engine():
+    """settings.should_collide_func (settings.hpp:43, edyn::set_should_collide, called at broadphase.cpp:145): a user predicate that
+    replaces should_collide_default - here the default AND "index parities differ" - in the real engine and in the restatement:
+    same pair sets, bit-identical state over 150 steps of a collapsing pile in which half of the box pairs never get a manifold;
+    switched off again after 80 steps (existing manifolds live on, new ones follow the default)."""
+    sc = scenes.box_pile(3, 3, 3)
+    ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc)
+    orc = ob.World(vel_iters=10, order=ob.ORDER_EXTERNAL); orc.add_bodies(sc)
+    ref.set_should_collide(_checkerboard_filter(ref.default_should_collide))
+    orc.set_should_collide(_checkerboard_filter(orc.default_should_collide))
+    for s in range(1, 151):
+        if s == 81:
+            ref.set_should_collide(None); orc.set_should_collide(None)
+        ref.step(1)
+        orc.set_ext_order(*ref.get_solve_order())
+        orc.step(1)
+        assert np.array_equal(ref.get_pairs(), orc.get_pairs()), s
+        for a, b in zip(ref.get_state(), orc.get_state()):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), s
+        if s == 80:
+            hi, lo = _pair_bodies(ref.get_pairs())
+            boxes = (hi != 0) & (lo != 0)
+            assert boxes.sum() > 10 and ((hi[boxes] + lo[boxes]) % 2 == 1).all()
+    hi, lo = _pair_bodies(ref.get_pairs())
+    boxes = (hi != 0) & (lo != 0)
+    assert ((hi[boxes] + lo[boxes]) % 2 == 0).any()   # after the switch-off same-parity pairs appear
+
+
 def test_collision_filter_and_exclusion_lists_match_the_real_engine():
     """should_collide_default (should_collide.cpp:11-57) inside whole steps: group/mask bits and exclude_collision lists decide
     which manifolds get created. A 3x3x3 pile where one column of boxes ignores its neighbours (filter) and six pairs are
