@@ -13,6 +13,7 @@
 #include <edyn/constraints/hinge_constraint.hpp>
 #include <edyn/constraints/cvjoint_constraint.hpp>
 #include <edyn/collision/contact_manifold.hpp>
+#include <edyn/collision/should_collide.hpp>
 #include <edyn/util/rigidbody.hpp>
 #include <edyn/util/constraint_util.hpp>
 #include <edyn/util/exclude_collision.hpp>
