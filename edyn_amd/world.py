@@ -120,6 +120,8 @@ class World:
         self._h = C.c_void_p(h)
         self.num_meshes = 0   # meshes belong to the context
         self._mesh_sig = []
+        if getattr(self, "_filter_cb", None) is not None:   # the user's should_collide predicate belongs to the world, not to one context
+            self._check(self._L.edynhip_set_pair_filter(self._h, C.cast(self._filter_cb, C.c_void_p), None))
 
     def detach(self):
         if self._h:
@@ -384,7 +386,8 @@ class World:
         """edyn::set_should_collide: func(body, other) -> bool replaces should_collide_default for NEW manifolds (None restores the device
         test). A host callback: steps with new candidate pairs take the slow path described in include/edynhip.h."""
         self._filter_cb = _capi.PAIR_FILTER(lambda user, a, b: 1 if func(int(a), int(b)) else 0) if func else None
-        self._check(self._L.edynhip_set_pair_filter(self._h, C.cast(self._filter_cb, C.c_void_p) if func else None, None))
+        if self._h is not None:   # (before attach: installed when the context is created)
+            self._check(self._L.edynhip_set_pair_filter(self._h, C.cast(self._filter_cb, C.c_void_p) if func else None, None))
 
     def default_should_collide(self, a, b):
         """should_collide_default (collision groups / masks, exclusion lists) - for predicates that extend it."""

@@ -1165,6 +1165,7 @@ inline bool should_collide_default(const entt::registry &registry, entt::entity 
 inline void set_should_collide(entt::registry &registry, should_collide_func_t func) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     if (func == &should_collide_default) func = nullptr;   // the device's own test
+    if (func && s.multi()) throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "set_should_collide: a world over several devices (init_config::devices) keeps should_collide_default");
     s.should_collide = func; s.filter_registry = &registry;
     if (s.ctx) detail::check(s, edynhip_set_pair_filter(s.ctx, func ? &detail::pair_filter_trampoline : nullptr, &s));
 }
