@@ -50,9 +50,25 @@ BYTES_PER_POINT_ITER = 380.0   # algorithmic bytes per contact
 BYTES_PER_JOINT_ROW_ITER = 256.0   # per joint row per iteration
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # parity statement that accompanies the number (tests/test_gpu_parity.py; the figures are asserted there)
+# Contact arithmetic (edynhip.h EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION): the headline is quoted on "reference" - every
+# contact row and position correction with the reference's operations in the reference's order; the other two are opt-in and reported beside it.
+ARITHMETIC = {
+    "reference": dict(),
+    "fused_velocity_rows": dict(fused_velocity_rows=True),
+    "fused_rows_block_position": dict(fused_velocity_rows=True, block_position=True),
+}
+# what each mode costs in parity, measured on the CPU checker and asserted by tests/test_arithmetic_fork.py (coloured order, against the coloured
+# order with the reference's arithmetic): worst of box_pile(6,6,6) 10 it / mixed pile 20 it / c1_columns
+ARITHMETIC_FORK = {
+    "reference": "the reference's row arithmetic (constraint_row.cpp:24-57, constraint_row_friction.cpp:11-54, contact_constraint.cpp:58-90, position_solver.hpp:16-51) in the coloured "
+                 "visiting order: SURVEY 8(d)(3) holds with zero error (device bit-exact vs the checker's coloured order with ARITH_REFERENCE)",
+    "fused_velocity_rows": "fp-level deviation: lock-step <= 9.5e-7 m (1 ulp at 9.5 m) / 7.2e-7 m/s per step; 60 free-running steps <= 9.0e-5 m / 6.7e-4 m/s - inside SURVEY 8(d)(3) (1e-4 m / 1e-3)",
+    "fused_rows_block_position": "algorithmic deviation: lock-step up to 5.1e-4 m per step; 60 free-running steps 4.7e-4 m (box pile) / 2.1e-4 m (mixed pile) / 4.8e-2 m (straight "
+                                 "columns) - SURVEY 8(d)(3) is NOT met in this mode",
+}
 PARITY = ("bit-exact vs the oracle's coloured order in this settled state at full size (pairs, state, manifolds, colours: "
-          "test_timed_regime_at_full_size_bit_exact; islands1m: test_islands1m_at_full_size_bit_exact) - the coloured order has its own "
-          "arithmetic for contact rows and position corrections (fused multiply-adds, the position correction per manifold, DESIGN.md section 3), "
+          "test_timed_regime_at_full_size_bit_exact; islands1m: test_islands1m_at_full_size_bit_exact) - the coloured order evaluates every row with the "
+          "REFERENCE's arithmetic (round 5 default; only the Gauss-Seidel visiting order differs from the reference), "
           "the oracle's reference order is pinned to the reference engine bit for bit; "
           "free-running vs the reference engine itself, C2 8000 boxes: 60 steps max |dpos| 0.23 m, mean 0.059 m; 300 steps (SURVEY 8(d)(4)): "
           "mean resting height within 3.4e-4 m, penetration of the resting pile 0.0036 / 0.0018 m, kinetic energy of the resting set 1.1e-5 / 1.2e-5 J per "
@@ -196,7 +212,7 @@ def spawn_ranks(n):
 class Leg:
     """One workload, built, settled, warmed and timed on this rank's GPU (all ranks call the same sequence)."""
 
-    def __init__(self, workload, args, rank, world_size, device_index, backend, stream):
+    def __init__(self, workload, args, rank, world_size, device_index, backend, stream, arithmetic=None):
         from edyn_amd.parallel import shard_range, StateGather
         self.name, self.wl = workload, WORKLOADS[workload]
         wl = self.wl
@@ -219,7 +235,7 @@ class Leg:
                                    device=device_index, timing=args.stage_timing, timing_solve=not args.stage_timing,
                                    # a single-rank run owns its GPU: plain launches for the resident-grid kernels;
                                    # RCCL kernels share the GPU in multi-rank runs: cooperative launches there
-                                   exclusive_device=not self.distributed)
+                                   exclusive_device=not self.distributed, **ARITHMETIC[arithmetic or args.arithmetic])
         self.w = edyn_amd.World(cfg)
         self.w.set_scene(scene)
         scenes.apply_figure_settings(self.w, scene)
@@ -272,7 +288,7 @@ def per_rank_proxy(workload, args, device_index, stream, ranks):
     first, count = shard_range(wl["shard_units"], 0, ranks)
     scene = wl["shard"](first, count)
     cfg = edyn_amd.init_config(num_solver_velocity_iterations=wl["vel"], num_solver_position_iterations=wl["pos"], device=device_index,
-                               exclusive_device=True)
+                               exclusive_device=True, **ARITHMETIC[args.arithmetic])
     w = edyn_amd.World(cfg)
     w.set_scene(scene)
     w.set_stream(stream.cuda_stream)
@@ -312,6 +328,10 @@ def main():
     ap.add_argument("--north-star", default="auto", help="workload of the north_star leg (sharded islands): a workload name, 'none', or 'auto' = islands1m on the default workload")
     ap.add_argument("--north-star-steps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arithmetic", default="reference", choices=sorted(ARITHMETIC),
+                    help="contact arithmetic of the measured run (default: the reference's operations; the others are the opt-in faster forms)")
+    ap.add_argument("--other-arithmetic-steps", type=int, default=None,
+                    help="timed steps of the two short legs in the OTHER contact arithmetics (config.arithmetic.steps_per_sec; default: --steps on the default workload at N=1, else 0)")
     ap.add_argument("--stage-timing", action="store_true",
                     help="HIP events around every stage (adds stages_ms_per_step; each event idles the GPU ~6 us, so the headline\n                    value is measured without it: only the two events around the velocity solve are recorded)")
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
@@ -417,6 +437,7 @@ def main():
                        "settle_steps": leg.settle, "bodies": leg.n_bodies, "contact_points": stats["num_points"], "manifolds": stats["num_manifolds"],
                        "joint_rows": stats["num_joint_rows"],
                        "colours": stats["num_colours"], "colour_sizes": stats["colour_size"], "islands": stats["num_islands"], "finite": finite,
+                       "arithmetic": {"mode": args.arithmetic, "parity": ARITHMETIC_FORK[args.arithmetic], "steps_per_sec": {args.arithmetic: leg.value}},
                        "parity": PARITY},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": (achieved / peak) if achieved is not None else None,
                          "traffic": traffic, "traffic_source": traffic_note,
@@ -441,6 +462,22 @@ def main():
             np.savez(state_path, pos=state[0], orn=state[1], linvel=state[2], angvel=state[3])
     leg.close()
     del w
+
+    # ---- the same workload in the other contact arithmetics (single rank): both numbers beside the headline
+    other_steps = args.other_arithmetic_steps
+    if other_steps is None:
+        other_steps = args.steps if (args.workload == "pile32k" and world_size == 1) else 0
+    if other_steps > 0 and world_size == 1:
+        for mode in ARITHMETIC:
+            if mode == args.arithmetic:
+                continue
+            other = Leg(args.workload, args, rank, world_size, device_index, backend, stream, arithmetic=mode)
+            other.run(other_steps, args.warmup)
+            otm = other.w.get_timings()
+            out["config"]["arithmetic"]["steps_per_sec"][mode] = other.value
+            out["config"]["arithmetic"].setdefault("solve_ms_per_step", {args.arithmetic: out["roofline"]["solve_ms_per_step"]})[mode] = otm["solve_velocity_ms"] / max(otm["steps"], 1)
+            out["config"]["arithmetic"].setdefault("other_modes", {})[mode] = ARITHMETIC_FORK[mode]
+            other.close()
 
     # ---- north_star: 1M bodies in 16k islands, sharded over the ranks (strong scaling), >= 60 Hz?
     ns_name = args.north_star

@@ -74,6 +74,7 @@ MANIFOLD_DTYPE = np.dtype([
     ("body", np.uint32, 2), ("num_points", np.uint32), ("colour", np.uint32), ("pt", POINT_DTYPE, 4)])
 
 FLAG_TIMING, FLAG_SLEEPING, FLAG_EXCLUSIVE_DEVICE, FLAG_TIMING_SOLVE, FLAG_CONTACT_EVENTS = 1, 4, 8, 16, 32
+FLAG_FUSED_VELOCITY_ROWS, FLAG_BLOCK_POSITION = 64, 128   # opt-in contact arithmetic (edynhip.h); default: the reference's operations
 PAIR_FILTER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)   # edynhip_pair_filter: int filter(void *user, uint32_t body, uint32_t other)
 EVENT_DTYPE = np.dtype([("type", np.uint32), ("step", np.uint32), ("body", np.uint32, 2), ("point_id", np.uint64)])
 EVENT_MANIFOLD_CREATED, EVENT_MANIFOLD_DESTROYED, EVENT_POINT_CREATED, EVENT_POINT_DESTROYED = 1, 2, 3, 4

@@ -225,6 +225,7 @@ struct edynhip_world {
     std::vector<int32_t> rank_of;
     std::vector<float> pos, orn, linvel, angvel;   // the gathered state, global order
     bool built = false;
+    bool stepped = false;                          // stepped since the scene was last described (set_bodies): scene-description calls are refused then
     float budget = 0.0f;                           // how much two islands of different shards may still approach before a check is due
     edynhip_world_stats stats{};
     std::string err;
@@ -298,6 +299,11 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     s.local_joints.clear();
     for (uint32_t g = 0; g < sc.nj; ++g) {
         const uint32_t a = sc.jbody[2 * g], b = sc.jbody[2 * g + 1];
+        // a joint is an island edge: a partition that puts its two dynamic bodies on different shards is wrong - never drop it silently
+        if (w->rank_of[a] >= 0 && w->rank_of[b] >= 0 && w->rank_of[a] != w->rank_of[b]) {
+            s.rc = EDYNHIP_ERR_INTERNAL; s.err = "partition splits joint " + std::to_string(g) + " (bodies " + std::to_string(a) + ", " + std::to_string(b) + ") over two shards";
+            return;
+        }
         if (s.to_local[a] >= 0 && s.to_local[b] >= 0 && (w->rank_of[a] == (int32_t)r || w->rank_of[b] == (int32_t)r)) s.local_joints.push_back(g);
     }
     edynhip_config cfg = w->cfg;
@@ -329,8 +335,13 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     b.gravity = gr.empty() ? nullptr : gr.data(); b.sleeping_disabled = sd.empty() ? nullptr : sd.data();
     b.center_of_mass = com.empty() ? nullptr : com.data();
     SH_TRY(s, edynhip_set_bodies(s.ctx, nl, &b));
-    if (from_state && !com.empty())   // set_bodies read `pos` as the origin of bodies with an offset: put the centre-of-mass state back
+    if (from_state && !com.empty()) {   // set_bodies read `pos` as the origin of bodies with an offset: put the centre-of-mass state back ...
         SH_TRY(s, edynhip_set_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
+        // ... and with it what set_bodies derived from the misread position: origins, AABBs (displaced by R com otherwise - the first
+        // broadphase / narrowphase after a re-partition would place those shapes wrong) and world inertias. Before the sleep tags below:
+        // the derivation skips sleeping bodies
+        SH_TRY(s, edynhip_refresh_derived(s.ctx));
+    }
     // joints, in local indices
     const uint32_t njl = (uint32_t)s.local_joints.size();
     if (njl) {
@@ -568,6 +579,18 @@ int repartition(edynhip_world *w) {
     std::vector<uint32_t> parent(n);
     std::iota(parent.begin(), parent.end(), 0u);
     auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    // The device labels are those of the shards' LAST island stage: a shard that has not stepped since it was built (a re-partition
+    // before the first step, or right after a step that re-partitioned by itself) still has identity labels. The edges the island
+    // manager connects bodies through are known on the host - every joint and every carried manifold between two dynamic bodies
+    // (island_manager.cpp:117-247) - so they are united here, whatever the labels say: cheap, and a joint or a carried manifold can
+    // never end up with its bodies on two shards.
+    auto unite = [&](uint32_t a, uint32_t b) {
+        if (sc.kind[a] != EDYNHIP_KIND_DYNAMIC || sc.kind[b] != EDYNHIP_KIND_DYNAMIC) return;
+        const uint32_t ra = find(labels[a]), rb = find(labels[b]);
+        if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+    };
+    for (uint32_t g = 0; g < sc.nj; ++g) unite(sc.jbody[2 * g], sc.jbody[2 * g + 1]);
+    for (const edynhip_manifold &m : carry.manifolds) unite(m.body[0], m.body[1]);
     sweep_boxes(boxes, kCreationMargin, false, [&](const IslandBox &a, const IslandBox &b, float) {
         const uint32_t ra = find(a.label), rb = find(b.label);
         if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
@@ -735,13 +758,17 @@ int edynhip_world_set_bodies(edynhip_world *w, uint32_t n, const edynhip_bodies 
     copy_in(sc.group, in->group, n); copy_in(sc.mask, in->mask, n); copy_in(sc.gravity, in->gravity, 3 * (size_t)n);
     copy_in(sc.sleeping_disabled, in->sleeping_disabled, n); copy_in(sc.com, in->center_of_mass, 3 * (size_t)n);
     sc.nj = 0; sc.jtype.clear(); sc.jbody.clear(); sc.jpivot.clear(); sc.jaxis.clear(); sc.jparams.clear(); sc.defs.clear(); sc.exclusions.clear();
-    w->built = false;
+    w->built = false; w->stepped = false;
     w->stats.num_bodies = n;
     return EDYNHIP_OK;
 }
 
 int edynhip_world_set_joints(edynhip_world *w, uint32_t n, const edynhip_joints *in) {
     if (!w || (n && (!in || !in->type || !in->body || !in->pivot))) return EDYNHIP_ERR_INVALID;
+    // The scene description is what the world is (re)built from - with the INITIAL state of edynhip_world_set_bodies. Once the world has
+    // stepped, such a rebuild would silently reset the simulation: refused (describe the scene again with edynhip_world_set_bodies -
+    // which takes the current state - as the C++ shim does for an edit of a running multi-device world)
+    if (w->stepped) return w->fail(EDYNHIP_ERR_UNSUPPORTED, "edynhip_world_set_joints: the world has been stepped; describe the scene again (edynhip_world_set_bodies with the current state) before editing it");
     HostScene &sc = w->scene;
     for (uint32_t k = 0; k < 2 * n; ++k) if (in->body[k] >= sc.n) return w->fail(EDYNHIP_ERR_INVALID, "edynhip_world_set_joints: body index out of range");
     sc.nj = n;
@@ -755,6 +782,7 @@ int edynhip_world_set_joints(edynhip_world *w, uint32_t n, const edynhip_joints 
 
 int edynhip_world_set_joint_definition(edynhip_world *w, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params, int generic) {
     if (!w || !frame_a9 || !frame_b9 || !params || joint >= w->scene.nj) return EDYNHIP_ERR_INVALID;
+    if (w->stepped) return w->fail(EDYNHIP_ERR_UNSUPPORTED, "edynhip_world_set_joint_definition: the world has been stepped; describe the scene again first (see edynhip_world_set_joints)");
     HostScene::Def d;
     d.joint = joint; d.generic = generic != 0;
     d.fa.assign(frame_a9, frame_a9 + 9); d.fb.assign(frame_b9, frame_b9 + 9); d.p.assign(params, params + (generic ? 60 : 16));
@@ -765,6 +793,7 @@ int edynhip_world_set_joint_definition(edynhip_world *w, uint32_t joint, const f
 
 int edynhip_world_exclude_collision(edynhip_world *w, uint32_t a, uint32_t b) {
     if (!w || a >= w->scene.n || b >= w->scene.n) return EDYNHIP_ERR_INVALID;
+    if (w->stepped) return w->fail(EDYNHIP_ERR_UNSUPPORTED, "edynhip_world_exclude_collision: the world has been stepped; describe the scene again first (see edynhip_world_set_joints)");
     w->scene.exclusions.push_back({a, b});
     w->built = false;
     return EDYNHIP_OK;
@@ -783,6 +812,7 @@ int edynhip_world_step(edynhip_world *w, uint32_t nsteps) {
         });
         EH_TRY(shard_error(w));
         ++w->stats.steps;
+        w->stepped = true;
         if (w->shards.size() < 2) continue;
         float growth = 0.0f;
         for (Shard &s : w->shards) if (!s.local_ids.empty()) { float g; std::memcpy(&g, s.mon_host, 4); growth = std::max(growth, g); }

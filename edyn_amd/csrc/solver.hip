@@ -754,12 +754,15 @@ DI void apply_impulse(Delta &d, f3 J0, f3 J1, f3 J2, f3 J3, float imp) {   // ap
 // (solve(constraint_row&) + apply_row_impulse, then solve_friction, per point in list order).
 // Loads are all issued up front: indices -> {body deltas, every row of every point} -> arithmetic -> stores.
 struct RowReg { float4 f[kRowF]; };
-// ---- the arithmetic of a contact's normal and friction rows ("fused rows", round 4) -------------------------------------------------
-// The velocity solve is a dependency chain: what bounds a step is the number of instructions between "a body's deltas arrived" and
-// "its deltas are handed on" (DESIGN.md section 3). These rows therefore use the row equations of constraint_row.cpp:24-57 and
-// constraint_row_friction.cpp:11-54 written with fused multiply-adds and fewer operations - 385 instead of 619 instructions for a
-// four-point manifold in the two-lane kernel. The specification is the checker's coloured order (its header states the same rules);
-// every velocity-solve kernel of this file - per colour, island-fused, one / two / four lanes per manifold - computes it bit for bit:
+// ---- the arithmetic of a contact's normal and friction rows: two forms, selected per context (ctx.hpp Arith) ------------------------
+// FUSED = false (the default): the reference's operations in the reference's order - solve(constraint_row&) + apply_row_impulse
+// (constraint_row.cpp:24-57), solve_friction (constraint_row_friction.cpp:11-54): the coloured order then differs from the reference
+// in the Gauss-Seidel visiting order ONLY (checker: ORDER_COLOURED with ARITH_REFERENCE, bit for bit).
+// FUSED = true (EDYNHIP_FLAG_FUSED_VELOCITY_ROWS, opt-in): the velocity solve is a dependency chain - what bounds a step is the number
+// of instructions between "a body's deltas arrived" and "its deltas are handed on"  - so this form writes the same
+// row equations with fused multiply-adds and fewer operations, 385 instead of 619 instructions for a four-point manifold in the
+// two-lane kernel; an fp-level deviation (1e-7 m/s per step, tests/test_arithmetic_fork.py), specified by the checker's
+// ARITH_FUSED_VELOCITY and computed bit for bit by every velocity-solve kernel of this file:
 //   dot(a, b)      = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x))
 //   relative speed = (lin_A + ang_A) + (lin_B + ang_B)
 //   delta          = fma(-relative speed, eff, rhs * eff)
@@ -784,16 +787,26 @@ DI void fused_circle(float &i0, float &i1, float max_len) {
         i0 *= sc; i1 *= sc;
     }
 }
+template <bool FUSED>
 DI void row_apply(Delta &d, const RowReg &r, float imp) {   // apply_row_impulse with precomputed I^-1 J^T
     const f3 Jl = from4(r.f[0]);
-    d.dvA = fma3(d.imA * Jl, imp, d.dvA);
-    d.dvB = fma3(d.imB * (-Jl), imp, d.dvB);
-    d.dwA = fma3(from4(r.f[3]), imp, d.dwA);
-    d.dwB = fma3(from4(r.f[4]), imp, d.dwB);
+    if (FUSED) {
+        d.dvA = fma3(d.imA * Jl, imp, d.dvA);
+        d.dvB = fma3(d.imB * (-Jl), imp, d.dvB);
+        d.dwA = fma3(from4(r.f[3]), imp, d.dwA);
+        d.dwB = fma3(from4(r.f[4]), imp, d.dwB);
+    } else {
+        d.dvA += d.imA * Jl * imp;
+        d.dvB += d.imB * (-Jl) * imp;
+        d.dwA += from4(r.f[3]) * imp;
+        d.dwB += from4(r.f[4]) * imp;
+    }
 }
+template <bool FUSED>
 DI float row_relspeed(const Delta &d, const RowReg &r) {
     const f3 Jl = from4(r.f[0]);
-    return (dot3_fma(Jl, d.dvA) + dot3_fma(from4(r.f[1]), d.dwA)) + (dot3_fma(-Jl, d.dvB) + dot3_fma(from4(r.f[2]), d.dwB));
+    if (FUSED) return (dot3_fma(Jl, d.dvA) + dot3_fma(from4(r.f[1]), d.dwA)) + (dot3_fma(-Jl, d.dvB) + dot3_fma(from4(r.f[2]), d.dwB));
+    return rel_speed(Jl, from4(r.f[1]), -Jl, from4(r.f[2]), d.dvA, d.dwA, d.dvB, d.dwB);
 }
 // solve_friction's clamp to the friction circle (constraint_row_friction.cpp:26-42), shared by every velocity-solve kernel.
 // (Round 4, measured and dropped: a branch that spares the square root and the two divisions - a third of a point's instructions -
@@ -817,6 +830,44 @@ DI void normal_clamp(float &cur, float &dimp, float upper) {
     dimp = (lt || gt) ? nw - cur : dimp;
     cur = nw;
 }
+// One normal row (solve(constraint_row&) + apply_row_impulse) and one friction pair (solve_friction) in either arithmetic.
+template <bool FUSED>
+DI void row_solve_normal(Delta &d, RowReg &r, float upper) {
+    float cur = r.f[2].w;
+    if (FUSED) {
+        const float applied = fused_normal(cur, fused_delta(row_relspeed<true>(d, r), r.f[0].w, r.f[1].w * r.f[0].w), upper);
+        r.f[2].w = cur;
+        row_apply<true>(d, r, applied);
+    } else {
+        const float drel = row_relspeed<false>(d, r);
+        float dimp = (r.f[1].w - drel) * r.f[0].w;
+        normal_clamp(cur, dimp, upper);
+        r.f[2].w = cur;
+        row_apply<false>(d, r, dimp);
+    }
+}
+template <bool FUSED>
+DI void row_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) {
+    const float max_len = rn.f[3].w * rn.f[2].w;   // mu * current normal impulse
+    if (FUSED) {
+        const float c0 = ra.f[2].w, c1 = rb.f[2].w;
+        float i0 = c0 + fused_delta(row_relspeed<true>(d, ra), ra.f[0].w, ra.f[1].w * ra.f[0].w);
+        float i1 = c1 + fused_delta(row_relspeed<true>(d, rb), rb.f[0].w, rb.f[1].w * rb.f[0].w);
+        fused_circle(i0, i1, max_len);
+        ra.f[2].w = i0; rb.f[2].w = i1;
+        row_apply<true>(d, ra, i0 - c0);
+        row_apply<true>(d, rb, i1 - c1);
+    } else {
+        float di0 = (ra.f[1].w - row_relspeed<false>(d, ra)) * ra.f[0].w;
+        float i0 = ra.f[2].w + di0;
+        float di1 = (rb.f[1].w - row_relspeed<false>(d, rb)) * rb.f[0].w;
+        float i1 = rb.f[2].w + di1;
+        friction_circle(i0, i1, di0, di1, ra.f[2].w, rb.f[2].w, max_len);
+        ra.f[2].w = i0; rb.f[2].w = i1;
+        row_apply<false>(d, ra, di0);
+        row_apply<false>(d, rb, di1);
+    }
+}
 // NP (points of the manifold) is a template parameter: lanes are grouped by point count inside a colour, so a wave
 // runs one instantiation, every loop is fully unrolled without predication and the compiler can issue all
 // 15*NP row loads plus the body loads back to back before the first use (one memory round trip after the indices).
@@ -835,37 +886,23 @@ DI void rows_load(RowReg (&R)[NP][kRowsPerPoint], const float4 *__restrict__ rw,
             for (int f = 0; f < kRowF; ++f) R[k][r].f[f] = rw[(size_t)((k * kRowsPerPoint + r) * kRowF + f) * rcap + p];
 }
 // One manifold's share of a sweep: its normal rows, then its friction pairs, in contact-list order.
-template <bool WARM, int NP>
+template <bool WARM, int NP, bool FUSED>
 DI void rows_solve(Delta &d, RowReg (&R)[NP][kRowsPerPoint], uint32_t np) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if ((uint32_t)k >= np) continue;
         RowReg &r = R[k][0];
-        if (WARM) {
-            row_apply(d, r, r.f[2].w);
-        } else {
-            float cur = r.f[2].w;
-            const float applied = fused_normal(cur, fused_delta(row_relspeed(d, r), r.f[0].w, r.f[1].w * r.f[0].w), r.f[4].w);   // upper = large_scalar, or a soft contact's force limit
-            r.f[2].w = cur;
-            row_apply(d, r, applied);
-        }
+        if (WARM) row_apply<FUSED>(d, r, r.f[2].w);
+        else row_solve_normal<FUSED>(d, r, r.f[4].w);   // upper = large_scalar, or a soft contact's force limit
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if ((uint32_t)k >= np) continue;
         RowReg &ra = R[k][1], &rb = R[k][2];
         if (WARM) {   // warm_start(constraint_row_friction&)
-            row_apply(d, ra, ra.f[2].w);
-            row_apply(d, rb, rb.f[2].w);
-        } else {
-            const float c0 = ra.f[2].w, c1 = rb.f[2].w;
-            float i0 = c0 + fused_delta(row_relspeed(d, ra), ra.f[0].w, ra.f[1].w * ra.f[0].w);
-            float i1 = c1 + fused_delta(row_relspeed(d, rb), rb.f[0].w, rb.f[1].w * rb.f[0].w);
-            fused_circle(i0, i1, R[k][0].f[3].w * R[k][0].f[2].w);   // mu * current normal impulse
-            ra.f[2].w = i0; rb.f[2].w = i1;
-            row_apply(d, ra, i0 - c0);
-            row_apply(d, rb, i1 - c1);
-        }
+            row_apply<FUSED>(d, ra, ra.f[2].w);
+            row_apply<FUSED>(d, rb, rb.f[2].w);
+        } else row_solve_friction<FUSED>(d, R[k][0], ra, rb);
     }
 }
 template <int NP>
@@ -883,36 +920,21 @@ DI void row_load(RowReg &r, const float4 *__restrict__ rw, uint32_t rcap, uint32
 #pragma unroll
     for (int f = 0; f < kRowF; ++f) r.f[f] = rw[(size_t)((k * kRowsPerPoint + row) * kRowF + f) * rcap + p];
 }
-template <bool WARM, int NP>
+template <bool WARM, int NP, bool FUSED>
 DI void rows_solve_normals(Delta &d, RowReg (&Rn)[NP], uint32_t np) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if ((uint32_t)k >= np) continue;
-        RowReg &r = Rn[k];
-        if (WARM) {
-            row_apply(d, r, r.f[2].w);
-        } else {
-            float cur = r.f[2].w;
-            const float applied = fused_normal(cur, fused_delta(row_relspeed(d, r), r.f[0].w, r.f[1].w * r.f[0].w), kLarge);
-            r.f[2].w = cur;
-            row_apply(d, r, applied);
-        }
+        if (WARM) row_apply<FUSED>(d, Rn[k], Rn[k].f[2].w);
+        else row_solve_normal<FUSED>(d, Rn[k], kLarge);
     }
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void rows_solve_friction(Delta &d, const RowReg &rn, RowReg &ra, RowReg &rb) {
     if (WARM) {   // warm_start(constraint_row_friction&)
-        row_apply(d, ra, ra.f[2].w);
-        row_apply(d, rb, rb.f[2].w);
-    } else {
-        const float c0 = ra.f[2].w, c1 = rb.f[2].w;
-        float i0 = c0 + fused_delta(row_relspeed(d, ra), ra.f[0].w, ra.f[1].w * ra.f[0].w);
-        float i1 = c1 + fused_delta(row_relspeed(d, rb), rb.f[0].w, rb.f[1].w * rb.f[0].w);
-        fused_circle(i0, i1, rn.f[3].w * rn.f[2].w);   // mu * current normal impulse
-        ra.f[2].w = i0; rb.f[2].w = i1;
-        row_apply(d, ra, i0 - c0);
-        row_apply(d, rb, i1 - c1);
-    }
+        row_apply<FUSED>(d, ra, ra.f[2].w);
+        row_apply<FUSED>(d, rb, rb.f[2].w);
+    } else row_solve_friction<FUSED>(d, rn, ra, rb);
 }
 // contact_extras rows of one manifold after its normal and friction rows: the rolling pairs of all points, then the
 // spinning rows (island_solver.cpp:76-111 keeps the row kinds in this order). Rolling is solve_friction with the roll
@@ -969,7 +991,7 @@ DI void extras_solve(Delta &d, const RowReg (&R)[NP][kRowsPerPoint], uint32_t np
         xrow_apply(d, r, dimp);
     }
 }
-template <bool WARM, int NP, bool PUSH>
+template <bool WARM, int NP, bool PUSH, bool FUSED>
 DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                          float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im,
                          float4 *__restrict__ rwx = nullptr) {
@@ -988,7 +1010,7 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
         if (PUSH) { d.imA = im[2 * (size_t)p]; d.imB = im[2 * (size_t)p + 1]; }   // slot .w lanes carry hand-off tags
         else { d.imA = va.w; d.imB = vb.w; }
     }
-    rows_solve<WARM, NP>(d, R, np);
+    rows_solve<WARM, NP, FUSED>(d, R, np);
     if (rwx) extras_solve<WARM, NP>(d, R, np, rwx, rcap, p);
     if (!WARM) rows_store_impulses<NP>(R, rw, rcap, p, np);
     const float wA = PUSH ? 0.0f : d.imA, wB = PUSH ? 0.0f : d.imB;
@@ -997,32 +1019,32 @@ DI void contact_solve_np(uint32_t p, uint32_t np, const uint32_t *__restrict__ r
     if (d.imA != 0) { bdvw[oa0] = to4(d.dvA, wA); bdvw[oa1] = to4(d.dwA, 0); }   // non-procedural bodies keep zero deltas
     if (d.imB != 0) { bdvw[ob0] = to4(d.dvB, wB); bdvw[ob1] = to4(d.dwB, 0); }
 }
-template <bool WARM, bool PUSH>
+template <bool WARM, bool PUSH, bool FUSED>
 DI void contact_solve_lane(uint32_t p, uint32_t np, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                            float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im,
                            float4 *__restrict__ rwx = nullptr) {
-    if (np > 2) contact_solve_np<WARM, 4, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
-    else contact_solve_np<WARM, 2, PUSH>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
+    if (np > 2) contact_solve_np<WARM, 4, PUSH, FUSED>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
+    else contact_solve_np<WARM, 2, PUSH, FUSED>(p, np, rbA, rbB, rw, rcap, bdvw, im, rwx);
 }
 struct Split { uint32_t e4, e3, e2; };   // ends of the 4-, 3-, 2-point groups of a colour's sorted range
 DI uint32_t np_of(uint32_t p, const Split &sp) { return p < sp.e4 ? 4u : (p < sp.e3 ? 3u : (p < sp.e2 ? 2u : 1u)); }
-template <bool WARM, bool PUSH>
+template <bool WARM, bool PUSH, bool FUSED>
 __global__ void __launch_bounds__(64)
 k_contact_solve(uint32_t start, uint32_t end, Split sp, const uint32_t *__restrict__ rbA, const uint32_t *__restrict__ rbB,
                 float4 *__restrict__ rw, uint32_t rcap, float4 *__restrict__ bdvw, const float *__restrict__ im, float4 *__restrict__ rwx) {
     const uint32_t p = start + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < end) contact_solve_lane<WARM, PUSH>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, im, rwx);
+    if (p < end) contact_solve_lane<WARM, PUSH, FUSED>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, im, rwx);
 }
 // Tail colours are tiny (tens to hundreds of manifolds) yet would each cost a full dependent launch; ONE
 // workgroup sweeps them in colour order instead, separated by workgroup barriers (same CU, same L1).
 struct TailRanges { uint32_t n; uint32_t start[kMaxColours]; uint32_t end[kMaxColours]; Split split[kMaxColours]; };
 constexpr uint32_t kTailThreads = 256, kTailMax = 512;   // one wave per SIMD keeps the full register budget
-template <bool WARM, bool PUSH>
+template <bool WARM, bool PUSH, bool FUSED>
 __global__ void __launch_bounds__(256)
 k_contact_solve_tail(TailRanges tr, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, const float *im, float4 *rwx) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t p = tr.start[c] + threadIdx.x; p < tr.end[c]; p += kTailThreads)
-            contact_solve_lane<WARM, PUSH>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw, im, rwx);
+            contact_solve_lane<WARM, PUSH, FUSED>(p, np_of(p, tr.split[c]), rbA, rbB, rw, rcap, bdvw, im, rwx);
         __threadfence_block();
         __syncthreads();
     }
@@ -1074,7 +1096,7 @@ DI void df_publish(float4 *slot, f3 dv, f3 dw, uint32_t tag) {   // slot = &dslo
                  "global_store_dwordx4 %0, %2, off offset:1024 sc1" : : "v"(slot), "v"(v), "v"(w) : "memory");
 }
 constexpr uint32_t kDfSpinLimit = 1u << 22;   // ~seconds; a hand-off normally arrives within microseconds
-template <bool WARM, int NP>
+template <bool WARM, int NP, bool FUSED>
 DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
     // Rows fetched before the wait: every normal row and the friction rows of the first two points. The friction rows
     // of points 2 and 3 are fetched when the hand-offs have arrived and land while the normal rows are being solved;
@@ -1119,10 +1141,10 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
             if (mine_now) {
 #pragma unroll
                 for (int k = kEarly; k < NP; ++k) { row_load(Rf[k][0], a.rw, a.rcap, p, k, 1); row_load(Rf[k][1], a.rw, a.rcap, p, k, 2); }
-                rows_solve_normals<WARM, NP>(d, Rn, np);
+                rows_solve_normals<WARM, NP, FUSED>(d, Rn, np);
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if ((uint32_t)k < np) rows_solve_friction<WARM>(d, Rn[k], Rf[k][0], Rf[k][1]);
+                    if ((uint32_t)k < np) rows_solve_friction<WARM, FUSED>(d, Rn[k], Rf[k][0], Rf[k][1]);
                 // hand the deltas over first (the next manifolds are waiting for them), then store the impulses
                 if (d.imA != 0) df_publish(a.dslot + dslot_at(nA & kSlotMask, 0), d.dvA, d.dwA, sweep + 1);
                 if (d.imB != 0) df_publish(a.dslot + dslot_at(nB & kSlotMask, 0), d.dvB, d.dwB, sweep + 1);
@@ -1147,6 +1169,7 @@ DI void df_task(const DfArgs &a, uint32_t p, bool valid, uint32_t np, uint32_t c
     }
 }
 constexpr uint32_t kDfBlock = 64;   // one wave per workgroup: the dispatcher spreads the waves over all CUs
+template <bool FUSED>
 __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 6;
@@ -1160,8 +1183,8 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
             const uint32_t np = 4u - (key & 3u), col = key >> 2;
             const bool big = __any(valid && np > 2);  // lanes are grouped by point count: uniform except at a group boundary
             uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
-            if (sweep == 0) { if (big) df_task<true, 4>(a, p, valid, np, col, sweep, tr); else df_task<true, 2>(a, p, valid, np, col, sweep, tr); }
-            else { if (big) df_task<false, 4>(a, p, valid, np, col, sweep, tr); else df_task<false, 2>(a, p, valid, np, col, sweep, tr); }
+            if (sweep == 0) { if (big) df_task<true, 4, FUSED>(a, p, valid, np, col, sweep, tr); else df_task<true, 2, FUSED>(a, p, valid, np, col, sweep, tr); }
+            else { if (big) df_task<false, 4, FUSED>(a, p, valid, np, col, sweep, tr); else df_task<false, 2, FUSED>(a, p, valid, np, col, sweep, tr); }
         }
 }
 
@@ -1894,6 +1917,56 @@ DI bool pos_manifold_block(PBody &X, bool sideB, float4 (&piv)[NP], const float4
 DI void pos_rebuild_inertia(PBody &X) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); }   // update_inertia, reference arithmetic
 // position_solver.hpp:34-41: after a correction the origins follow the new transforms (a body without an offset has none: its pivots use pos)
 DI void pos_origin(PBody &x) { if (x.has_com) x.org = to_world(-x.com, x.pos, x.orn); else x.org = x.pos; }
+// The contacts of a manifold corrected the reference's way (the default; ctx.hpp Arith): contact_constraint::solve_position
+// (contact_constraint.cpp:58-90) point after point in list order, each through position_solver::solve (position_solver.hpp:16-51) - a
+// point sees the transforms the previous point left, every correction re-normalises the orientation and is followed by a rebuilt
+// world inertia. One body per lane (X; sideB: X is body[1]), the partner's terms cross over with DPP: every quantity is computed by
+// exactly the reference's fp32 operations in the reference's order. The world inertia follows the orientation lazily: `iw_stale` says
+// that X.iw has to be rebuilt (same operations, same value as the reference's rebuild right after the correction) before it is read.
+// live[k]: point k takes part (uniform within the lane pair). Returns true when X was corrected.
+template <int NP>
+DI bool pos_manifold_points(PBody &X, bool sideB, float4 (&piv)[NP], const float4 (&l4)[NP], float4 (&n4)[NP], const bool (&live)[NP], float &max_err, bool &iw_stale) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (!live[k]) continue;
+        const int attach = __float_as_int(n4[k].w);
+        const f3 pXw = to_world(from4(piv[k]), X.org, X.orn);
+        const f3 pOw = xchg1(pXw);
+        const f3 pAw = sideB ? pOw : pXw, pBw = sideB ? pXw : pOw;
+        // the normal rotates with the body it is attached to; that body's lane computes it and shares it
+        const f3 nrot = rotate(X.orn, from4(l4[k]));
+        const f3 nother = xchg1(nrot);
+        f3 n = from4(n4[k]);
+        if (attach == dc::NA_ON_A) n = sideB ? nother : nrot;
+        else if (attach == dc::NA_ON_B) n = sideB ? nrot : nother;
+        const float distance = dot(pAw - pBw, n);
+        const f3 rX = pXw - X.pos;
+        n4[k] = to4(n, n4[k].w);
+        piv[k].w = distance;   // meaningful on side A only (pA.w = distance, pB.w = friction)
+        if (distance > -kEps) continue;   // (the same bits in both lanes of the pair)
+        if (iw_stale) { const m3 basis = to_m3(X.orn); X.iw = mul(mul(basis, X.il), transpose(basis)); iw_stale = false; }
+        // J = {n, rA x n, -n, -(rB x n)}
+        const f3 Jl = sideB ? -n : n;
+        const f3 cx = cross(rX, n);
+        const f3 Ja = sideB ? -cx : cx;
+        const f3 iwJa = mul(X.iw, Ja);
+        const float t1 = dot(Jl, Jl) * X.inv_m, t2 = dot(iwJa, Ja);
+        const float o1 = xchg1(t1), o2 = xchg1(t2);
+        const float a1 = sideB ? o1 : t1, a2 = sideB ? o2 : t2, b1 = sideB ? t1 : o1, b2 = sideB ? t2 : o2;
+        const float em = 1.0f / (a1 + a2 + b1 + b2);   // get_effective_mass's order
+        const float error = -distance;
+        const float corr = error * 0.2f * em;           // contact_position_correction_rate
+        max_err = fmaxf(fabsf(error), max_err);
+        if (!X.proc) continue;
+        X.pos += X.inv_m * Jl * corr;
+        X.orn = normalize(X.orn + quaternion_derivative(X.orn, iwJa * corr));
+        iw_stale = true;
+        if (X.has_com) X.org = to_world(-X.com, X.pos, X.orn); else X.org = X.pos;   // position_solver.hpp:34-41
+        any = true;
+    }
+    return any;
+}
 DI void pos_solve(PBody &A, PBody &B, f3 J0, f3 J1, f3 J2, f3 J3, float error, float &max_err) {
     float em = eff_mass(J0, J1, J2, J3, A.inv_m, A.iw, B.inv_m, B.iw);
     float corr = error * 0.2f * em;   // contact_position_correction_rate / error_correction_rate
@@ -1949,44 +2022,68 @@ DI void df2_poll(const float4 *slot, v4f &h0, v4f &h1) {
                  : "=&v"(h0), "=&v"(h1) : "v"(slot) : "memory");
 }
 struct Side { f3 dv, dw; };
+// (Row2::rhs: the row's rhs in the reference arithmetic, rhs * eff - prepared before the wait - in the fused one)
+template <bool FUSED>
 DI float df2_relspeed(const Side &x, const Row2 &r) {
-    const float p = dot3_fma(r.jl, x.dv) + dot3_fma(r.ja, x.dw);   // this side's half
-    return p + xchg1(p);                                            // (A's half) + (B's half): the same bits in both lanes
+    if (FUSED) {
+        const float p = dot3_fma(r.jl, x.dv) + dot3_fma(r.ja, x.dw);   // this side's half
+        return p + xchg1(p);                                            // (A's half) + (B's half): the same bits in both lanes
+    }
+    const float lin = dot(r.jl, x.dv), ang = dot(r.ja, x.dw);          // rel_speed()'s order: ((JlA.dvA + JaA.dwA) + JlB.dvB) + JaB.dwB
+    return dppA(lin) + dppA(ang) + dppB(lin) + dppB(ang);
 }
+template <bool FUSED>
 DI void df2_apply(Side &x, const Row2 &r, float imp) {
-    x.dv = fma3(r.ijl, imp, x.dv);
-    x.dw = fma3(r.ija, imp, x.dw);
+    if (FUSED) { x.dv = fma3(r.ijl, imp, x.dv); x.dw = fma3(r.ija, imp, x.dw); }
+    else { x.dv += r.ijl * imp; x.dw += r.ija * imp; }
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void df2_point(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
-    Row2 &rn = R[0], &ra = R[1], &rb = R[2];
+    Row2 &rn = R[0];
     if (WARM) {   // warm_start: the normal row, then the friction pair
-        df2_apply(x, rn, rn.imp);
+        df2_apply<FUSED>(x, rn, rn.imp);
         return;
     }
-    const float applied = fused_normal(rn.imp, fused_delta(df2_relspeed(x, rn), rn.eff, rn.rhs), kLarge);   // Row2::rhs holds rhs * eff (prepared before the wait)
-    df2_apply(x, rn, applied);
-    (void)ra; (void)rb; (void)mu;
+    if (FUSED) {
+        const float applied = fused_normal(rn.imp, fused_delta(df2_relspeed<true>(x, rn), rn.eff, rn.rhs), kLarge);
+        df2_apply<true>(x, rn, applied);
+    } else {
+        float dimp = (rn.rhs - df2_relspeed<false>(x, rn)) * rn.eff;
+        normal_clamp(rn.imp, dimp, kLarge);
+        df2_apply<false>(x, rn, dimp);
+    }
+    (void)mu;
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void df2_friction(Side &x, Row2 (&R)[kRowsPerPoint], float mu) {
     Row2 &ra = R[1], &rb = R[2];
     if (WARM) {   // warm_start(constraint_row_friction&)
-        df2_apply(x, ra, ra.imp);
-        df2_apply(x, rb, rb.imp);
+        df2_apply<FUSED>(x, ra, ra.imp);
+        df2_apply<FUSED>(x, rb, rb.imp);
         return;
     }
     const float c0 = ra.imp, c1 = rb.imp;
-    float i0 = c0 + fused_delta(df2_relspeed(x, ra), ra.eff, ra.rhs);
-    float i1 = c1 + fused_delta(df2_relspeed(x, rb), rb.eff, rb.rhs);
-    fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
-    ra.imp = i0; rb.imp = i1;
-    df2_apply(x, ra, i0 - c0);
-    df2_apply(x, rb, i1 - c1);
+    if (FUSED) {
+        float i0 = c0 + fused_delta(df2_relspeed<true>(x, ra), ra.eff, ra.rhs);
+        float i1 = c1 + fused_delta(df2_relspeed<true>(x, rb), rb.eff, rb.rhs);
+        fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
+        ra.imp = i0; rb.imp = i1;
+        df2_apply<true>(x, ra, i0 - c0);
+        df2_apply<true>(x, rb, i1 - c1);
+    } else {
+        float di0 = (ra.rhs - df2_relspeed<false>(x, ra)) * ra.eff;
+        float i0 = c0 + di0;
+        float di1 = (rb.rhs - df2_relspeed<false>(x, rb)) * rb.eff;
+        float i1 = c1 + di1;
+        friction_circle(i0, i1, di0, di1, c0, c1, mu * R[0].imp);   // mu * current normal impulse
+        ra.imp = i0; rb.imp = i1;
+        df2_apply<false>(x, ra, di0);
+        df2_apply<false>(x, rb, di1);
+    }
 }
 // EXACT: every live lane of the wave has exactly NP points (the common case: lanes are grouped by point count), so the
 // rows need no per-lane point-count predicate.
-template <bool WARM, int NP, bool EXACT>
+template <bool WARM, int NP, bool EXACT, bool FUSED>
 DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
     Row2 R[NP][kRowsPerPoint];
     float mu[NP];
@@ -2008,7 +2105,7 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
             q.ijl = im * q.jl;
             q.ja = from4(fa); q.ija = from4(fi);
             q.eff = f0.w;
-            q.rhs = dppA(fa.w) * f0.w; q.imp = dppB(fa.w);
+            q.rhs = FUSED ? dppA(fa.w) * f0.w : dppA(fa.w); q.imp = dppB(fa.w);
             if (r == 0) mu[k] = dppA(fi.w);
         }
     }
@@ -2041,10 +2138,10 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
             if (mine_now) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if (EXACT || (uint32_t)k < np) df2_point<WARM>(x, R[k], mu[k]);
+                    if (EXACT || (uint32_t)k < np) df2_point<WARM, FUSED>(x, R[k], mu[k]);
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if (EXACT || (uint32_t)k < np) df2_friction<WARM>(x, R[k], mu[k]);
+                    if (EXACT || (uint32_t)k < np) df2_friction<WARM, FUSED>(x, R[k], mu[k]);
                 // hand the deltas over first (the next manifold of this body is waiting for them), then store the impulses
                 if (im != 0) df_publish(a.dslot + dslot_at(nx & kSlotMask, 0), x.dv, x.dw, sweep + 1);
                 if (!WARM && sideB) {
@@ -2067,18 +2164,19 @@ DI void df2_task(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t n
         }
     }
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void df2_dispatch(const DfArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
     // lanes are grouped by point count: np is uniform over a wave except at a group boundary. The warm-start sweep runs
     // once and keeps the predicated form only (fewer instantiations: the kernel has to stay within the instruction cache).
     // Waves of one-point manifolds (sphere contacts: the majority of a mixed scene) get their own instantiation: the NP = 2 form
     // fetched a second point slot in vain for each of them (round 3: 1.30x the algorithmic traffic on mixed32k) and ran its code.
-    if (!WARM && __all(!valid || np == 4u)) df2_task<WARM, 4, true>(a, p, valid, sideB, np, col, sweep, tr);
-    else if (!WARM && __all(!valid || np == 2u)) df2_task<WARM, 2, true>(a, p, valid, sideB, np, col, sweep, tr);
-    else if (!WARM && __all(!valid || np == 1u)) df2_task<WARM, 1, true>(a, p, valid, sideB, np, col, sweep, tr);
-    else if (__any(np > 2u)) df2_task<WARM, 4, false>(a, p, valid, sideB, np, col, sweep, tr);
-    else df2_task<WARM, 2, false>(a, p, valid, sideB, np, col, sweep, tr);
+    if (!WARM && __all(!valid || np == 4u)) df2_task<WARM, 4, true, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 2u)) df2_task<WARM, 2, true, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 1u)) df2_task<WARM, 1, true, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
+    else if (__any(np > 2u)) df2_task<WARM, 4, false, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
+    else df2_task<WARM, 2, false, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
 }
+template <bool FUSED>
 __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
@@ -2092,8 +2190,8 @@ __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
             const uint32_t key = a.keys_sorted[p];
             const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
             uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
-            if (sweep == 0) df2_dispatch<true>(a, p, valid, sideB, np, col, sweep, tr);
-            else df2_dispatch<false>(a, p, valid, sideB, np, col, sweep, tr);
+            if (sweep == 0) df2_dispatch<true, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
+            else df2_dispatch<false, FUSED>(a, p, valid, sideB, np, col, sweep, tr);
         }
 }
 
@@ -2127,34 +2225,58 @@ DI void df4_publish(float4 *piece, f3 d, uint32_t tag) {
 DI float xchg2(float v) {   // value held by the lane two away inside the quad (lane ^ 2)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
 }
-DI float df4_relspeed(const f3 &x, const Row4 &r) {   // (lin_A + ang_A) + (lin_B + ang_B): roles 0..3 = A linear, A angular, B linear, B angular
-    const float t = dot3_fma(r.j, x);
-    const float side = t + xchg1(t);
-    return side + xchg2(side);
+template <bool FUSED>
+DI float df4_relspeed(const f3 &x, const Row4 &r) {   // roles 0..3 = A linear, A angular, B linear, B angular
+    if (FUSED) {   // (lin_A + ang_A) + (lin_B + ang_B)
+        const float t = dot3_fma(r.j, x);
+        const float side = t + xchg1(t);
+        return side + xchg2(side);
+    }
+    const float t = dot(r.j, x);   // rel_speed()'s order: ((d0 + d1) + d2) + d3
+    return qb0(t) + qb1(t) + qb2(t) + qb3(t);
 }
-template <bool WARM>
-DI void df4_normal(f3 &x, Row4 &rn) {   // Row4::rhs holds rhs * eff
-    if (WARM) { x = fma3(rn.ij, rn.imp, x); return; }
-    const float applied = fused_normal(rn.imp, fused_delta(df4_relspeed(x, rn), rn.eff, rn.rhs), kLarge);
-    x = fma3(rn.ij, applied, x);
+template <bool FUSED>
+DI void df4_apply(f3 &x, const Row4 &r, float imp) { if (FUSED) x = fma3(r.ij, imp, x); else x += r.ij * imp; }
+template <bool WARM, bool FUSED>
+DI void df4_normal(f3 &x, Row4 &rn) {   // Row4::rhs: the row's rhs (reference arithmetic) or rhs * eff (fused)
+    if (WARM) { df4_apply<FUSED>(x, rn, rn.imp); return; }
+    if (FUSED) {
+        const float applied = fused_normal(rn.imp, fused_delta(df4_relspeed<true>(x, rn), rn.eff, rn.rhs), kLarge);
+        df4_apply<true>(x, rn, applied);
+    } else {
+        float dimp = (rn.rhs - df4_relspeed<false>(x, rn)) * rn.eff;
+        normal_clamp(rn.imp, dimp, kLarge);
+        df4_apply<false>(x, rn, dimp);
+    }
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void df4_friction(f3 &x, Row4 (&R)[kRowsPerPoint], float mu) {
     Row4 &ra = R[1], &rb = R[2];
     if (WARM) {   // warm_start(constraint_row_friction&)
-        x = fma3(ra.ij, ra.imp, x);
-        x = fma3(rb.ij, rb.imp, x);
+        df4_apply<FUSED>(x, ra, ra.imp);
+        df4_apply<FUSED>(x, rb, rb.imp);
         return;
     }
     const float c0 = ra.imp, c1 = rb.imp;
-    float i0 = c0 + fused_delta(df4_relspeed(x, ra), ra.eff, ra.rhs);
-    float i1 = c1 + fused_delta(df4_relspeed(x, rb), rb.eff, rb.rhs);
-    fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
-    ra.imp = i0; rb.imp = i1;
-    x = fma3(ra.ij, i0 - c0, x);
-    x = fma3(rb.ij, i1 - c1, x);
+    if (FUSED) {
+        float i0 = c0 + fused_delta(df4_relspeed<true>(x, ra), ra.eff, ra.rhs);
+        float i1 = c1 + fused_delta(df4_relspeed<true>(x, rb), rb.eff, rb.rhs);
+        fused_circle(i0, i1, mu * R[0].imp);   // mu * current normal impulse
+        ra.imp = i0; rb.imp = i1;
+        df4_apply<true>(x, ra, i0 - c0);
+        df4_apply<true>(x, rb, i1 - c1);
+    } else {
+        float di0 = (ra.rhs - df4_relspeed<false>(x, ra)) * ra.eff;
+        float i0 = c0 + di0;
+        float di1 = (rb.rhs - df4_relspeed<false>(x, rb)) * rb.eff;
+        float i1 = c1 + di1;
+        friction_circle(i0, i1, di0, di1, c0, c1, mu * R[0].imp);
+        ra.imp = i0; rb.imp = i1;
+        df4_apply<false>(x, ra, di0);
+        df4_apply<false>(x, rb, di1);
+    }
 }
-template <bool WARM, int NP, bool EXACT>
+template <bool WARM, int NP, bool EXACT, bool FUSED>
 DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *trace_slot) {
     Row4 R[NP][kRowsPerPoint];
     float mu[NP];
@@ -2178,7 +2300,7 @@ DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_
             q.j = role == 2u ? -Ja : Ja;              // body B's linear Jacobian is -J_lin
             const f3 lin = im * q.j;
             q.ij = ang ? from4(fi) : lin;
-            q.eff = qb0(fa.w); q.rhs = qb1(fa.w) * q.eff; q.imp = qb3(fa.w);   // rhs * eff, as fused_delta takes it
+            q.eff = qb0(fa.w); q.rhs = FUSED ? qb1(fa.w) * q.eff : qb1(fa.w); q.imp = qb3(fa.w);   // rhs * eff, as fused_delta takes it
             if (r == 0) mu[k] = qb1(fi.w);
         }
     }
@@ -2208,10 +2330,10 @@ DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_
             if (mine_now) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if (EXACT || (uint32_t)k < np) df4_normal<WARM>(x, R[k][0]);
+                    if (EXACT || (uint32_t)k < np) df4_normal<WARM, FUSED>(x, R[k][0]);
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if (EXACT || (uint32_t)k < np) df4_friction<WARM>(x, R[k], mu[k]);
+                    if (EXACT || (uint32_t)k < np) df4_friction<WARM, FUSED>(x, R[k], mu[k]);
                 // hand the deltas over first (the next manifold of this body is waiting for them), then store the impulses
                 if (im != 0) df4_publish(a.dslot + dslot_at(nx & kSlotMask, ang ? 1u : 0u), x, sweep + 1);
                 if (!WARM && role == 3u) {
@@ -2234,13 +2356,14 @@ DI void df4_task(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_
         }
     }
 }
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void df4_dispatch(const DfArgs &a, uint32_t p, bool valid, uint32_t role, uint32_t np, uint32_t col, uint32_t sweep, uint64_t *tr) {
-    if (!WARM && __all(!valid || np == 4u)) df4_task<WARM, 4, true>(a, p, valid, role, np, col, sweep, tr);
-    else if (!WARM && __all(!valid || np == 2u)) df4_task<WARM, 2, true>(a, p, valid, role, np, col, sweep, tr);
-    else if (__any(np > 2u)) df4_task<WARM, 4, false>(a, p, valid, role, np, col, sweep, tr);
-    else df4_task<WARM, 2, false>(a, p, valid, role, np, col, sweep, tr);
+    if (!WARM && __all(!valid || np == 4u)) df4_task<WARM, 4, true, FUSED>(a, p, valid, role, np, col, sweep, tr);
+    else if (!WARM && __all(!valid || np == 2u)) df4_task<WARM, 2, true, FUSED>(a, p, valid, role, np, col, sweep, tr);
+    else if (__any(np > 2u)) df4_task<WARM, 4, false, FUSED>(a, p, valid, role, np, col, sweep, tr);
+    else df4_task<WARM, 2, false, FUSED>(a, p, valid, role, np, col, sweep, tr);
 }
+template <bool FUSED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_contact_solve_df4(DfArgs a) {
     const uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 2);   // 16 manifolds per wave, four lanes each
     const uint32_t role = threadIdx.x & 3u;
@@ -2254,11 +2377,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const uint32_t key = a.keys_sorted[p];
             const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
             uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)(sweep * rounds + round) * nwaves + blockIdx.x) : nullptr;
-            if (sweep == 0) df4_dispatch<true>(a, p, valid, role, np, col, sweep, tr);
-            else df4_dispatch<false>(a, p, valid, role, np, col, sweep, tr);
+            if (sweep == 0) df4_dispatch<true, FUSED>(a, p, valid, role, np, col, sweep, tr);
+            else df4_dispatch<false, FUSED>(a, p, valid, role, np, col, sweep, tr);
         }
 }
-template <int NP>
+template <int NP, bool BLOCK>
 DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, const Rows &rows, const Manifolds &mf, const Bodies &b,
                         float *isl_err, const uint32_t *isl_done, uint32_t m, uint32_t ia, uint32_t ib, uint32_t label) {
     const uint32_t ix = sideB ? ib : ia;
@@ -2280,8 +2403,9 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     bool live[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) live[k] = (uint32_t)k < np && in_range && !soft[k];   // uniform within a lane pair
-    const bool corrected = pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err);
-    if (corrected) pos_rebuild_inertia(X);   // what store_pbody leaves for the joints' position solve and the next step
+    bool iw_stale = false;
+    const bool corrected = BLOCK ? pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err) : pos_manifold_points<NP>(X, sideB, piv, l4, n4, live, max_err, iw_stale);
+    if (BLOCK ? corrected : iw_stale) pos_rebuild_inertia(X);   // what store_pbody leaves for the joints' position solve and the next step
     const bool active = in_range && done == 0;
     if (active) {
 #pragma unroll
@@ -2298,31 +2422,35 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
 }
 // one (manifold, side) lane of the position solve; `pc` must be a valid sorted position even when !in_range
 // all lanes stay in the code below (no early exit): DPP exchanges and wave reductions need every lane executing
+template <bool BLOCK>
 DI void pos_contacts_item(bool in_range, uint32_t pc, bool sideB, const Rows &rows, const Manifolds &mf, const Bodies &b,
                           float *isl_err, const uint32_t *isl_done) {
     const uint32_t m = rows.order[pc];
     const uint32_t ia = rows.bA[pc], ib = rows.bB[pc], np = in_range ? rows.np[pc] : 0;
     const uint32_t label = rows.label[pc];
     // lanes are grouped by point count inside a colour, so a wave takes one branch (except at a group boundary)
-    if (__any(np > 2)) pos_contacts_np<4>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
-    else pos_contacts_np<2>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
+    if (__any(np > 2)) pos_contacts_np<4, BLOCK>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
+    else pos_contacts_np<2, BLOCK>(in_range, pc, sideB, np, rows, mf, b, isl_err, isl_done, m, ia, ib, label);
 }
+template <bool BLOCK>
 DI void pos_contacts_lane(uint32_t start, uint32_t end, uint32_t t, const Rows &rows, const Manifolds &mf, const Bodies &b,
                           float *isl_err, const uint32_t *isl_done) {
     const uint32_t p = start + (t >> 1);
-    pos_contacts_item(p < end, p < end ? p : start, t & 1, rows, mf, b, isl_err, isl_done);
+    pos_contacts_item<BLOCK>(p < end, p < end ? p : start, t & 1, rows, mf, b, isl_err, isl_done);
 }
+template <bool BLOCK>
 __global__ void __launch_bounds__(128)
 k_pos_contacts(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *__restrict__ isl_done) {
-    pos_contacts_lane(start, end, blockIdx.x * blockDim.x + threadIdx.x, rows, mf, b, isl_err, isl_done);
+    pos_contacts_lane<BLOCK>(start, end, blockIdx.x * blockDim.x + threadIdx.x, rows, mf, b, isl_err, isl_done);
 }
 // Tail colours of the position solve in ONE workgroup (see k_contact_solve_tail); uniform trip counts so that every
 // lane reaches the wave-level reductions.
+template <bool BLOCK>
 __global__ void __launch_bounds__(256)
 k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *isl_done) {
     for (uint32_t c = 0; c < tr.n; ++c) {
         for (uint32_t base = tr.start[c]; base < tr.end[c]; base += 128) {
-            pos_contacts_lane(base, tr.end[c], threadIdx.x, rows, mf, b, isl_err, isl_done);
+            pos_contacts_lane<BLOCK>(base, tr.end[c], threadIdx.x, rows, mf, b, isl_err, isl_done);
         }
         __threadfence_block();
         __syncthreads();
@@ -2330,19 +2458,20 @@ k_pos_contacts_tail(TailRanges tr, Rows rows, Manifolds mf, Bodies b, float *isl
 }
 // The serial bucket (ctx.hpp kSerialColour): its manifolds may share bodies, so one lane (velocity) / one lane pair (position)
 // takes them one after the other, in sorted order; the fence makes each manifold's stores visible to the next one's loads.
-template <bool WARM>
+template <bool WARM, bool FUSED>
 __global__ void __launch_bounds__(64)
 k_contact_solve_serial(uint32_t start, uint32_t end, Split sp, const uint32_t *rbA, const uint32_t *rbB, float4 *rw, uint32_t rcap, float4 *bdvw, float4 *rwx) {
     if (threadIdx.x != 0) return;
     for (uint32_t p = start; p < end; ++p) {
-        contact_solve_lane<WARM, false>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, nullptr, rwx);
+        contact_solve_lane<WARM, false, FUSED>(p, np_of(p, sp), rbA, rbB, rw, rcap, bdvw, nullptr, rwx);
         __threadfence();
     }
 }
+template <bool BLOCK>
 __global__ void __launch_bounds__(64)
 k_pos_contacts_serial(uint32_t start, uint32_t end, Rows rows, Manifolds mf, Bodies b, float *isl_err, const uint32_t *isl_done) {
     for (uint32_t p = start; p < end; ++p) {
-        pos_contacts_lane(p, p + 1, threadIdx.x, rows, mf, b, isl_err, isl_done);
+        pos_contacts_lane<BLOCK>(p, p + 1, threadIdx.x, rows, mf, b, isl_err, isl_done);
         __threadfence();
     }
 }
@@ -2497,7 +2626,7 @@ __global__ void k_pos_writeback(uint32_t n, Bodies b, const float4 *__restrict__
 // rows as a lane-indexed copy too (costs k_push_links what it saves here); gathering the points through the manifold index one level
 // earlier instead of copying them (position kernel 84 instead of 71 us per iteration).
 struct DfpIn { uint32_t key, m, ix, label, nx; float im; float4 pw0[3]; };   // pw0 = the first point's (own pivot, local normal, (normal, attachment))
-struct DfpIn2 { float4 il[3]; float err; };
+struct DfpIn2 { float4 il[3]; float4 iw[3]; float err; };   // iw: the record's world inertia - what a body not yet corrected in this solve carries (point-by-point form only)
 DI void dfp_load1(const DfPosArgs &a, uint32_t p, bool sideB, DfpIn &in) {
     const uint32_t slot = 2 * p + (sideB ? 1u : 0u);
     const size_t rcap = a.mf.cap;
@@ -2506,13 +2635,15 @@ DI void dfp_load1(const DfPosArgs &a, uint32_t p, bool sideB, DfpIn &in) {
     // the first point (every task has one); the others follow with the second level, once the key has told how many there are
     in.pw0[0] = a.rows.pw[p + (sideB ? rcap : 0)]; in.pw0[1] = a.rows.pw[p + 2 * rcap]; in.pw0[2] = a.rows.pw[p + 3 * rcap];
 }
+template <bool BLOCK>
 DI void dfp_load2(const DfPosArgs &a, const DfpIn &in, DfpIn2 &in2) {
     const bool proc = in.im != 0.0f;
     const float4 z = make_float4(0, 0, 0, 0);
     in2.il[0] = proc ? B_IL(a.b, in.ix, 0) : z; in2.il[1] = proc ? B_IL(a.b, in.ix, 1) : z; in2.il[2] = proc ? B_IL(a.b, in.ix, 2) : z;
+    if (!BLOCK) { in2.iw[0] = proc ? B_IW(a.b, in.ix, 0) : z; in2.iw[1] = proc ? B_IW(a.b, in.ix, 1) : z; in2.iw[2] = proc ? B_IW(a.b, in.ix, 2) : z; }   // the same 128-byte record
     in2.err = a.err_prev ? a.err_prev[in.label] : 1.0f;
 }
-template <int NP>
+template <int NP, bool BLOCK>
 DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_t np, uint32_t col, const DfpIn &in, const DfpIn2 &in2,
                  const v4f &f0, const v4f &f1, const v4f &f2, uint64_t w0, uint64_t *trace_slot) {
     const Manifolds &mf = a.mf;
@@ -2530,14 +2661,18 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     PBody X;   // the transform comes with the hand-off (a read-only body's: from its seeded slot); pivots are anchored at the position
     X.inv_m = in.im; X.proc = in.im != 0.0f;
     X.il = {from4(in2.il[0]), from4(in2.il[1]), from4(in2.il[2])};
+    if (!BLOCK) X.iw = {from4(in2.iw[0]), from4(in2.iw[1]), from4(in2.iw[2])};
     X.has_com = false; X.com = mk3(0, 0, 0);   // (worlds with centre-of-mass offsets do not take the dataflow position solve)
     X.pos = X.org = mk3(0, 0, 0); X.orn = q4{0, 0, 0, 1};
     const uint32_t done_isl = in2.err < kPosErrorThreshold ? 1u : 0u;
     const uint32_t want = (nx & kHeadBit) ? a.iter : a.iter + 1;
     bool got = false;
     bool corrected = false;
-    // (the world inertia is not part of the hand-off: contacts do not read it - pos_manifold_block - and k_pos_writeback rebuilds it
-    //  from the final orientation)
+    // The world inertia is not part of the hand-off. Block form: contacts do not read it (pos_manifold_block). Point-by-point form:
+    // position_solver::solve rebuilds it after every correction - here it is rebuilt from the handed-over orientation, same operations,
+    // same value, just before the first correction that reads it (`iw_stale`: the body was corrected earlier in this solve; an
+    // uncorrected body still carries the inertia of its record); the rebuild after a task's last correction would be thrown away.
+    // k_pos_writeback rebuilds it from the final orientation.
     // An island that met the error threshold in an earlier iteration takes no part in this one (island_solver.cpp:350-353):
     // its lanes neither wait for nor publish hand-offs - every consumer of its bodies is in the same island, equally
     // finished - and each body's chain-head slot keeps the transform of the island's last iteration for k_pos_writeback.
@@ -2575,7 +2710,8 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             bool live[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) live[k] = (uint32_t)k < np && act;
-            const bool applied = pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err);
+            bool iw_stale = corrected;
+            const bool applied = BLOCK ? pos_manifold_block<NP>(X, sideB, piv, l4, n4, live, max_err) : pos_manifold_points<NP>(X, sideB, piv, l4, n4, live, max_err, iw_stale);
             // hand the transform on first (the body's next manifold is waiting for it), then store the points' distances / normals
             if (mine_now) {
                 if (X.proc) dfp_publish(a.pslot + pslot_at(nx & kSlotMask, 0), X.pos, X.orn, corrected || applied, a.iter + 1);
@@ -2603,6 +2739,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
     }
     publish_error(valid && done_isl == 0 && !sideB, max_err, label, a.err_out);
 }
+template <bool BLOCK>
 __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
@@ -2617,12 +2754,12 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
         dfp_load1(a, p, sideB, in);
         v4f f0, f1, f2;
         dfp_poll(a.pslot + pslot_at(2 * p + (sideB ? 1u : 0u), 0), f0, f1, f2);   // the first look at the own slot travels with level 1
-        dfp_load2(a, in, in2);
+        dfp_load2<BLOCK>(a, in, in2);
         const uint32_t np = valid ? 4u - (in.key & 3u) : 0u, col = in.key >> 2;
         uint64_t *tr = a.trace ? a.trace + 4 * ((size_t)round * nwaves + blockIdx.x) : nullptr;
-        if (__any(np > 2)) dfp_task<4>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
-        else if (__any(np > 1)) dfp_task<2>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
-        else dfp_task<1>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
+        if (__any(np > 2)) dfp_task<4, BLOCK>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
+        else if (__any(np > 1)) dfp_task<2, BLOCK>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
+        else dfp_task<1, BLOCK>(a, p, valid, sideB, np, col, in, in2, f0, f1, f2, w0, tr);
     }
 }
 
@@ -2755,7 +2892,7 @@ struct IslSolveArgs {
     float *isl_err; uint32_t *isl_done;
     uint32_t only_jointed;          // mixed schedule: islands without joints belong to the dataflow launch - skip them here
 };
-template <bool WARM>
+template <bool WARM, bool FUSED>
 DI void isl_velocity_sweep(const IslSolveArgs &a, const IslShared &S, const uint32_t *lst) {
     const uint32_t nph = S.nph;
     for (uint32_t k = 0; k < nph; ++k) {
@@ -2765,8 +2902,8 @@ DI void isl_velocity_sweep(const IslSolveArgs &a, const IslShared &S, const uint
         } else {
             for (uint32_t q = q0 + threadIdx.x; q < q1; q += 64) {
                 const uint32_t p = lst[q] & kIslIdMask, np = a.rows.np[p];
-                if (__any(np > 2)) contact_solve_np<WARM, 4, false>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
-                else contact_solve_np<WARM, 2, false>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
+                if (__any(np > 2)) contact_solve_np<WARM, 4, false, FUSED>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
+                else contact_solve_np<WARM, 2, false, FUSED>(p, np, a.rows.bA, a.rows.bB, a.rows.rw, a.rcap, a.b.dvw, nullptr, a.rwx);
             }
         }
         __threadfence_block();
@@ -2779,6 +2916,7 @@ DI void isl_velocity_sweep(const IslSolveArgs &a, const IslShared &S, const uint
 // dependent trips to memory. Same operations in the same order as the lane functions above.
 constexpr uint32_t kIslBodySlots = 256, kIslNoSlot = 0xFFFFFFFFu;
 struct IslFast { float4 dv[kIslBodySlots], dw[kIslBodySlots]; };
+template <bool FUSED>
 DI void isl_velocity_fast(const IslSolveArgs &a, const IslShared &S, IslFast &F, bool has, uint32_t item, uint32_t ia, uint32_t ib, uint32_t base) {
     const uint32_t ph = item >> kIslPhaseShift, id = item & kIslIdMask;
     const bool is_joint = ph < kIslContactPhase;
@@ -2807,7 +2945,7 @@ DI void isl_velocity_fast(const IslSolveArgs &a, const IslShared &S, IslFast &F,
                 if (sa != kIslNoSlot) { d.dvA = from4(F.dv[sa]); d.dwA = from4(F.dw[sa]); } else { d.dvA = d.dwA = mk3(0, 0, 0); }
                 if (sb != kIslNoSlot) { d.dvB = from4(F.dv[sb]); d.dwB = from4(F.dw[sb]); } else { d.dvB = d.dwB = mk3(0, 0, 0); }
                 if (is_joint) { if (sweep == 0) jlane_solve<true>(R, d); else jlane_solve<false>(R, d); }
-                else { if (sweep == 0) rows_solve<true, 4>(d, R, np); else rows_solve<false, 4>(d, R, np); }
+                else { if (sweep == 0) rows_solve<true, 4, FUSED>(d, R, np); else rows_solve<false, 4, FUSED>(d, R, np); }
                 if (sa != kIslNoSlot) { F.dv[sa] = to4(d.dvA, d.imA); F.dw[sa] = to4(d.dwA, 0); }
                 if (sb != kIslNoSlot) { F.dv[sb] = to4(d.dvB, d.imB); F.dw[sb] = to4(d.dwB, 0); }
             }
@@ -2821,6 +2959,7 @@ DI void isl_velocity_fast(const IslSolveArgs &a, const IslShared &S, IslFast &F,
         else if (a.iters) rows_store_impulses<4>(R, a.rows.rw, a.rcap, id, np);
     }
 }
+template <bool FUSED>
 __global__ void __launch_bounds__(64) k_island_velocity(IslSolveArgs a) {
     __shared__ IslShared S;
     __shared__ IslFast F;
@@ -2849,13 +2988,14 @@ __global__ void __launch_bounds__(64) k_island_velocity(IslSolveArgs a) {
             base = lo;
         }
         if (fast) {
-            isl_velocity_fast(a, S, F, has, item, ia, ib, base);
+            isl_velocity_fast<FUSED>(a, S, F, has, item, ia, ib, base);
         } else {
-            isl_velocity_sweep<true>(a, S, lst);
-            for (uint32_t it = 0; it < a.iters; ++it) isl_velocity_sweep<false>(a, S, lst);
+            isl_velocity_sweep<true, FUSED>(a, S, lst);
+            for (uint32_t it = 0; it < a.iters; ++it) isl_velocity_sweep<false, FUSED>(a, S, lst);
         }
     }
 }
+template <bool BLOCK>
 __global__ void __launch_bounds__(64) k_island_position(IslSolveArgs a) {
     __shared__ IslShared S;
     __shared__ uint32_t s_done;
@@ -2878,7 +3018,7 @@ __global__ void __launch_bounds__(64) k_island_position(IslSolveArgs a) {
                     for (uint32_t base = q0; base < q1; base += 32) {
                         const uint32_t q = base + (t >> 1);
                         const bool in = q < q1;
-                        pos_contacts_item(in, lst[in ? q : q0] & kIslIdMask, t & 1u, a.rows, a.mf, a.b, a.isl_err, a.isl_done);
+                        pos_contacts_item<BLOCK>(in, lst[in ? q : q0] & kIslIdMask, t & 1u, a.rows, a.mf, a.b, a.isl_err, a.isl_done);
                     }
                 }
                 __threadfence_block();
@@ -3168,8 +3308,35 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
     return EDYNHIP_OK;
 }
 
+// Kernel instantiations by (warm start, push hand-offs) and the context's contact arithmetic (ctx.hpp Arith: the reference's operations
+// by default, EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION opt in to the coloured order's own forms).
+using ContactSolveFn = void (*)(uint32_t, uint32_t, Split, const uint32_t *, const uint32_t *, float4 *, uint32_t, float4 *, const float *, float4 *);
+using ContactTailFn = void (*)(TailRanges, const uint32_t *, const uint32_t *, float4 *, uint32_t, float4 *, const float *, float4 *);
+using ContactSerialFn = void (*)(uint32_t, uint32_t, Split, const uint32_t *, const uint32_t *, float4 *, uint32_t, float4 *, float4 *);
+static ContactSolveFn contact_solve_fn(bool warm, bool push, bool fused) {
+    static const ContactSolveFn t[2][2][2] = {{{k_contact_solve<false, false, false>, k_contact_solve<false, false, true>}, {k_contact_solve<false, true, false>, k_contact_solve<false, true, true>}},
+                                              {{k_contact_solve<true, false, false>, k_contact_solve<true, false, true>}, {k_contact_solve<true, true, false>, k_contact_solve<true, true, true>}}};
+    return t[warm][push][fused];
+}
+static ContactTailFn contact_tail_fn(bool warm, bool push, bool fused) {
+    static const ContactTailFn t[2][2][2] = {{{k_contact_solve_tail<false, false, false>, k_contact_solve_tail<false, false, true>}, {k_contact_solve_tail<false, true, false>, k_contact_solve_tail<false, true, true>}},
+                                             {{k_contact_solve_tail<true, false, false>, k_contact_solve_tail<true, false, true>}, {k_contact_solve_tail<true, true, false>, k_contact_solve_tail<true, true, true>}}};
+    return t[warm][push][fused];
+}
+static ContactSerialFn contact_serial_fn(bool warm, bool fused) {
+    static const ContactSerialFn t[2][2] = {{k_contact_solve_serial<false, false>, k_contact_solve_serial<false, true>}, {k_contact_solve_serial<true, false>, k_contact_solve_serial<true, true>}};
+    return t[warm][fused];
+}
+static const void *df_velocity_fn(uint32_t lanes, bool fused) {
+    if (lanes == 4u) return fused ? (const void *)k_contact_solve_df4<true> : (const void *)k_contact_solve_df4<false>;
+    if (lanes == 2u) return fused ? (const void *)k_contact_solve_df2<true> : (const void *)k_contact_solve_df2<false>;
+    return fused ? (const void *)k_contact_solve_df<true> : (const void *)k_contact_solve_df<false>;
+}
+static const void *df_position_fn(bool block) { return block ? (const void *)k_pos_contacts_df<true> : (const void *)k_pos_contacts_df<false>; }
+
 int solve(edynhip_ctx *c) {
     hipStream_t s = c->stream;
+    const bool fused_rows = (c->cfg.flags & EDYNHIP_FLAG_FUSED_VELOCITY_ROWS) != 0, block_pos = (c->cfg.flags & EDYNHIP_FLAG_BLOCK_POSITION) != 0;
     const uint32_t n = c->b.n;
     if (n == 0) return EDYNHIP_OK;
     Manifolds &mf = c->m[c->cur];
@@ -3186,18 +3353,18 @@ int solve(edynhip_ctx *c) {
         const char *env = getenv("EDYNHIP_DATAFLOW");
         int per_cu = 0, ncu = 0, coop = 0;
         if (!(env && env[0] == '0') &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contact_solve_df, kDfBlock, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, df_velocity_fn(1u, fused_rows), kDfBlock, 0) == hipSuccess &&
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess &&
             hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && per_cu > 0 && ncu > 0 && coop) {
             c->df_lanes = (uint32_t)per_cu * (uint32_t)ncu;   // resident waves (one per workgroup)
             int per_cu2 = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_contact_solve_df2, 64, 0) == hipSuccess && per_cu2 > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, df_velocity_fn(2u, fused_rows), 64, 0) == hipSuccess && per_cu2 > 0)
                 c->df2_waves = (uint32_t)per_cu2 * (uint32_t)ncu;
             int per_cu4 = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_contact_solve_df4, 64, 0) == hipSuccess && per_cu4 > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, df_velocity_fn(4u, fused_rows), 64, 0) == hipSuccess && per_cu4 > 0)
                 c->df4_waves = (uint32_t)per_cu4 * (uint32_t)ncu;
             int per_cu_p = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_pos_contacts_df, 64, 0) == hipSuccess && per_cu_p > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, df_position_fn(block_pos), 64, 0) == hipSuccess && per_cu_p > 0)
                 c->dfp_waves = (uint32_t)per_cu_p * (uint32_t)ncu;
             c->df_mode = 1;
         }
@@ -3333,33 +3500,22 @@ int solve(edynhip_ctx *c) {
             const Rows &r = c->rows;
             const Split sp{c->colour_split[k][0], c->colour_split[k][1], c->colour_split[k][2]};
             const dim3 g(blocks(e - a, 64)), bl(64);
-            if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
-                else hipLaunchKernelGGL((k_contact_solve<false, true>), g, bl, 0, s, a, e, sp, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
-            } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve<true, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
-                else hipLaunchKernelGGL((k_contact_solve<false, false>), g, bl, 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
-            }
+            if (push) hipLaunchKernelGGL(contact_solve_fn(warm, true, fused_rows), g, bl, 0, s, a, e, sp, (const uint32_t *)r.next, (const uint32_t *)nullptr, r.rw, rcap, r.dslot, (const float *)r.im, (float4 *)nullptr);
+            else hipLaunchKernelGGL(contact_solve_fn(warm, false, fused_rows), g, bl, 0, s, a, e, sp, (const uint32_t *)r.bA, (const uint32_t *)r.bB, r.rw, rcap, c->b.dvw, (const float *)nullptr, c->extras ? r.rwx : (float4 *)nullptr);
             ++launches;
         }
         if (tail.n) {
             const Rows &r = c->rows;
             const dim3 g(1), bl(kTailThreads);
-            if (push) {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, true>), g, bl, 0, s, tail, r.next, nullptr, r.rw, rcap, r.dslot, r.im, (float4 *)nullptr);
-            } else {
-                if (warm) hipLaunchKernelGGL((k_contact_solve_tail<true, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
-                else hipLaunchKernelGGL((k_contact_solve_tail<false, false>), g, bl, 0, s, tail, r.bA, r.bB, r.rw, rcap, c->b.dvw, nullptr, c->extras ? r.rwx : nullptr);
-            }
+            if (push) hipLaunchKernelGGL(contact_tail_fn(warm, true, fused_rows), g, bl, 0, s, tail, (const uint32_t *)r.next, (const uint32_t *)nullptr, r.rw, rcap, r.dslot, (const float *)r.im, (float4 *)nullptr);
+            else hipLaunchKernelGGL(contact_tail_fn(warm, false, fused_rows), g, bl, 0, s, tail, (const uint32_t *)r.bA, (const uint32_t *)r.bB, r.rw, rcap, c->b.dvw, (const float *)nullptr, c->extras ? r.rwx : (float4 *)nullptr);
             ++launches;
         }
         if (serial) {
             const Rows &r = c->rows;
             const uint32_t a = c->colour_start[kSerialColour], e = c->colour_end[kSerialColour];
             const Split sp{c->colour_split[kSerialColour][0], c->colour_split[kSerialColour][1], c->colour_split[kSerialColour][2]};
-            if (warm) hipLaunchKernelGGL(k_contact_solve_serial<true>, dim3(1), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, c->extras ? r.rwx : nullptr);
-            else hipLaunchKernelGGL(k_contact_solve_serial<false>, dim3(1), dim3(64), 0, s, a, e, sp, r.bA, r.bB, r.rw, rcap, c->b.dvw, c->extras ? r.rwx : nullptr);
+            hipLaunchKernelGGL(contact_serial_fn(warm, fused_rows), dim3(1), dim3(64), 0, s, a, e, sp, (const uint32_t *)r.bA, (const uint32_t *)r.bB, r.rw, rcap, c->b.dvw, c->extras ? r.rwx : (float4 *)nullptr);
             ++launches;
         }
     };
@@ -3408,7 +3564,7 @@ int solve(edynhip_ctx *c) {
         void *params[] = {&a};
         // cooperative launch: the runtime guarantees that all `grid` workgroups are resident together, which the
         // hand-off polling relies on
-        if (launch_resident(c, four_lane ? (const void *)k_contact_solve_df4 : two_lane ? (const void *)k_contact_solve_df2 : (const void *)k_contact_solve_df, grid, 64, params) == hipSuccess) {
+        if (launch_resident(c, df_velocity_fn(lanes, fused_rows), grid, 64, params) == hipSuccess) {
             df_velocity = true;
             ++launches;
         } else {   // e.g. the device is shared and cannot hold the grid: use the per-colour schedule from now on
@@ -3432,7 +3588,8 @@ int solve(edynhip_ctx *c) {
     }
     if ((!df_velocity && isl_fused) || (df_velocity && mixed)) {   // mixed: the islands with joints, beside the dataflow launch
         isl_args.iters = c->cfg.num_velocity_iterations;
-        hipLaunchKernelGGL(k_island_velocity, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+        if (fused_rows) hipLaunchKernelGGL(k_island_velocity<true>, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+        else hipLaunchKernelGGL(k_island_velocity<false>, dim3(kIslGrid), dim3(64), 0, s, isl_args);
         ++launches;
     } else if (!df_velocity) {
         joints_pass(true);
@@ -3465,10 +3622,10 @@ int solve(edynhip_ctx *c) {
             }
             for (uint32_t k = 0; k < first_tail; ++k) {
                 uint32_t a = c->colour_start[k], e = c->colour_end[k];
-                if (e > a) hipLaunchKernelGGL(k_pos_contacts, dim3(blocks(2 * (e - a), 128)), dim3(128), 0, s, a, e, c->rows, mf, c->b, c->isl_err, c->isl_done);
+                if (e > a) hipLaunchKernelGGL(block_pos ? k_pos_contacts<true> : k_pos_contacts<false>, dim3(blocks(2 * (e - a), 128)), dim3(128), 0, s, a, e, c->rows, mf, c->b, c->isl_err, (const uint32_t *)c->isl_done);
             }
-            if (tail.n) hipLaunchKernelGGL(k_pos_contacts_tail, dim3(1), dim3(256), 0, s, tail, c->rows, mf, c->b, c->isl_err, c->isl_done);
-            if (serial) hipLaunchKernelGGL(k_pos_contacts_serial, dim3(1), dim3(64), 0, s, c->colour_start[kSerialColour], c->colour_end[kSerialColour], c->rows, mf, c->b, c->isl_err, c->isl_done);
+            if (tail.n) hipLaunchKernelGGL(block_pos ? k_pos_contacts_tail<true> : k_pos_contacts_tail<false>, dim3(1), dim3(256), 0, s, tail, c->rows, mf, c->b, c->isl_err, (const uint32_t *)c->isl_done);
+            if (serial) hipLaunchKernelGGL(block_pos ? k_pos_contacts_serial<true> : k_pos_contacts_serial<false>, dim3(1), dim3(64), 0, s, c->colour_start[kSerialColour], c->colour_end[kSerialColour], c->rows, mf, c->b, c->isl_err, (const uint32_t *)c->isl_done);
             hipLaunchKernelGGL(k_pos_flags, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->isl_err, c->isl_done);
         }
     };
@@ -3494,7 +3651,7 @@ int solve(edynhip_ctx *c) {
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
                         it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr};
             void *params[] = {&a};
-            if (launch_resident(c, (const void *)k_pos_contacts_df, grid, 64, params) != hipSuccess) {
+            if (launch_resident(c, df_position_fn(block_pos), grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();
                 c->df_mode = 0;
                 break;
@@ -3516,7 +3673,7 @@ int solve(edynhip_ctx *c) {
             final_pslot = r.pslot;
             if (mixed) {   // the islands with joints, on the body records
                 isl_args.iters = P;
-                hipLaunchKernelGGL(k_island_position, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+                hipLaunchKernelGGL(block_pos ? k_island_position<true> : k_island_position<false>, dim3(kIslGrid), dim3(64), 0, s, isl_args);
             }
         } else if (mixed) {
             return set_error(c, EDYNHIP_ERR_INTERNAL, "solve: the runtime refused the resident launch of the mixed schedule (position)");
@@ -3528,7 +3685,7 @@ int solve(edynhip_ctx *c) {
     } else if (P > 0 && (na || j.n)) {
         if (isl_fused) {
             isl_args.iters = P;
-            hipLaunchKernelGGL(k_island_position, dim3(kIslGrid), dim3(64), 0, s, isl_args);
+            hipLaunchKernelGGL(block_pos ? k_island_position<true> : k_island_position<false>, dim3(kIslGrid), dim3(64), 0, s, isl_args);
         } else pos_per_colour(0);
     }
     rec(c, 8);

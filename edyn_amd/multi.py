@@ -24,7 +24,8 @@ class MultiWorld:
         cfg.num_position_iterations = self.cfg.num_solver_position_iterations
         cfg.gravity = (C.c_float * 3)(*[float(x) for x in self.cfg.gravity])
         cfg.flags = ((_capi.FLAG_SLEEPING if self.cfg.sleeping else 0) | (_capi.FLAG_EXCLUSIVE_DEVICE if self.cfg.exclusive_device else 0)
-                     | (_capi.FLAG_TIMING_SOLVE if self.cfg.timing_solve else 0))
+                     | (_capi.FLAG_TIMING_SOLVE if self.cfg.timing_solve else 0)
+                     | (_capi.FLAG_FUSED_VELOCITY_ROWS if self.cfg.fused_velocity_rows else 0) | (_capi.FLAG_BLOCK_POSITION if self.cfg.block_position else 0))
         dev = np.ascontiguousarray(devices, np.int32)
         st = C.c_int(0)
         h = self._L.edynhip_world_create(C.byref(cfg), dev.ctypes.data, len(dev), C.byref(st))

@@ -38,6 +38,10 @@ class init_config:
     sleeping: bool = False       # island sleeping (off = every body sleeping_disabled, as the benchmark scenes are)
     contact_events: bool = False # record manifold / contact point creation and destruction (get_contact_events)
     exclusive_device: bool = False   # promise that this stepper is the only user of its GPU while it steps (see edynhip.h)
+    # Contact arithmetic (edynhip.h EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / _BLOCK_POSITION). Default: every contact row and position
+    # correction with the reference's operations in the reference's order; the two switches opt in to faster forms of the same equations.
+    fused_velocity_rows: bool = False
+    block_position: bool = False
 
 
 @dataclass
@@ -112,7 +116,9 @@ class World:
         cfg.flags = ((_capi.FLAG_TIMING if self.cfg.timing else 0) | (_capi.FLAG_TIMING_SOLVE if self.cfg.timing_solve else 0)
                      | (_capi.FLAG_SLEEPING if self.cfg.sleeping else 0)
                      | (_capi.FLAG_CONTACT_EVENTS if self.cfg.contact_events else 0)
-                     | (_capi.FLAG_EXCLUSIVE_DEVICE if self.cfg.exclusive_device else 0))
+                     | (_capi.FLAG_EXCLUSIVE_DEVICE if self.cfg.exclusive_device else 0)
+                     | (_capi.FLAG_FUSED_VELOCITY_ROWS if self.cfg.fused_velocity_rows else 0)
+                     | (_capi.FLAG_BLOCK_POSITION if self.cfg.block_position else 0))
         st = C.c_int(0)
         h = self._L.edynhip_create(C.byref(cfg), C.byref(st))
         if not h:

@@ -244,6 +244,11 @@ struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
     // read-back of the manifolds; off = call edyn::refresh_contact_points(registry) when the data is needed).
     bool materialize_contacts{true};
     bool contact_point_data{false};
+    // Contact arithmetic (edynhip.h EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION). Default: every contact row and every
+    // contact position correction with the reference's operations in the reference's order; the two switches opt in to faster forms
+    // of the same equations (stated deviations: DESIGN.md section 4).
+    bool fused_velocity_rows{false};
+    bool block_position{false};
 };
 
 class stepper_error : public std::runtime_error {
@@ -484,7 +489,7 @@ inline void upload_scene_multi(entt::registry &registry, gpu_stepper &s) {
     c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
     c.num_position_iterations = s.cfg.num_solver_position_iterations;
     c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
-    c.flags = s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u;
+    c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.fused_velocity_rows ? EDYNHIP_FLAG_FUSED_VELOCITY_ROWS : 0u) | (s.cfg.block_position ? EDYNHIP_FLAG_BLOCK_POSITION : 0u);
     std::vector<int32_t> devs(s.cfg.devices.begin(), s.cfg.devices.end());
     int st = 0;
     s.world = edynhip_world_create(&c, devs.data(), (uint32_t)devs.size(), &st);
@@ -581,7 +586,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         c.num_velocity_iterations = s.cfg.num_solver_velocity_iterations;
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
         c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
-        c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.materialize_contacts ? EDYNHIP_FLAG_CONTACT_EVENTS : 0u);
+        c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.materialize_contacts ? EDYNHIP_FLAG_CONTACT_EVENTS : 0u) |
+                  (s.cfg.fused_velocity_rows ? EDYNHIP_FLAG_FUSED_VELOCITY_ROWS : 0u) | (s.cfg.block_position ? EDYNHIP_FLAG_BLOCK_POSITION : 0u);
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
         s.meshes.clear();   // meshes belong to the context

@@ -80,6 +80,15 @@ enum {
     EDYNHIP_FLAG_TIMING_SOLVE = 16u, /* record only the two events around the velocity solve (solve_velocity_ms) */
     EDYNHIP_FLAG_SLEEPING = 4u,      /* island sleeping / waking (island_manager.cpp:524-623); off = every body sleeping_disabled */
     EDYNHIP_FLAG_CONTACT_EVENTS = 32u, /* record manifold / contact point creation and destruction (edynhip_get_contact_events) */
+    /* Contact arithmetic of the solve. Default (neither flag): every contact row and every contact position correction is evaluated with the
+       reference's operations in the reference's order (constraint_row.cpp:24-57, constraint_row_friction.cpp:11-54, contact_constraint.cpp:58-90,
+       position_solver.hpp:16-51) - the stepper then differs from the reference in the Gauss-Seidel VISITING order only. The two flags opt in
+       to faster forms of the same equations; each is a stated deviation (tests/test_arithmetic_fork.py):
+         FUSED_VELOCITY_ROWS  fused multiply-adds, one division per friction-circle clamp (an fp-level change: ~1e-7 m/s per step);
+         BLOCK_POSITION       the <= 4 points of a manifold corrected as one block from the transforms the manifold was entered with
+                              (an algorithmic change: up to ~3e-4 m per step; SURVEY 8(d)(3) is NOT met in this mode). */
+    EDYNHIP_FLAG_FUSED_VELOCITY_ROWS = 64u,
+    EDYNHIP_FLAG_BLOCK_POSITION = 128u,
     EDYNHIP_FLAG_EXCLUSIVE_DEVICE = 8u /* promise: nothing else launches work on this device while a step runs (one stepper per
                                         GPU). The resident-grid solver kernels are then launched plainly instead of
                                         cooperatively (~0.1 ms per step less idle GPU). Without the promise the default,
@@ -425,6 +434,10 @@ const char *edynhip_world_last_error(const edynhip_world *w);   /* w may be NULL
 int edynhip_world_create_convex_mesh(edynhip_world *w, uint32_t num_vertices, const float *vertices, uint32_t num_indices, const uint32_t *indices,
                                      uint32_t num_faces, const uint32_t *faces, uint32_t flags, uint32_t *mesh_id);
 int edynhip_world_set_bodies(edynhip_world *w, uint32_t n, const edynhip_bodies *bodies);
+/* The scene description (joints, joint definitions, exclusions) is what the shards are (re)built from, with the state of
+ * edynhip_world_set_bodies: these three calls come before the first step. On a world that has been stepped they return EDYNHIP_ERR_UNSUPPORTED
+ * (a rebuild would reset the simulation to its initial state); describe the scene again - edynhip_world_set_bodies with the current state -
+ * to edit a running world. The initial island probe loads the whole scene onto devices[0]: a scene must fit one GPU's memory once. */
 int edynhip_world_set_joints(edynhip_world *w, uint32_t n, const edynhip_joints *joints);
 /* edynhip_set_joint_definition (generic = 0: params[16]) / edynhip_set_generic_definition (generic = 1: params[60]) by global joint index */
 int edynhip_world_set_joint_definition(edynhip_world *w, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params, int generic);

@@ -181,6 +181,23 @@ def set_fused_rows(on):
     f(int(bool(on)))
 
 
+ARITH_REFERENCE, ARITH_FUSED_VELOCITY, ARITH_BLOCK_POSITION = 0, 1, 2
+
+
+def set_arithmetic(mode):
+    """Contact arithmetic of the coloured order: ARITH_REFERENCE (the reference's operations, default), | ARITH_FUSED_VELOCITY
+    (fma velocity rows), | ARITH_BLOCK_POSITION (per-manifold block position correction). Process-wide."""
+    f = lib().orc_set_arithmetic
+    f.argtypes = [C.c_int]; f.restype = None
+    f(int(mode))
+
+
+def get_arithmetic():
+    f = lib().orc_get_arithmetic
+    f.argtypes = []; f.restype = C.c_int
+    return int(f())
+
+
 def leaf():
     return _Leaf(lib(), "orc_")
 

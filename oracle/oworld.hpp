@@ -220,7 +220,10 @@ inline void solve_friction(FrictionRow &f, Row &n) {
 // The sequential and external orders keep the reference's arithmetic operation for operation (they are what is pinned to the engine
 // bit for bit); the coloured order differs from them in the Gauss-Seidel visiting order anyway, and agrees with them - and with the
 // engine - within the tolerances of SURVEY 8(d) (tests/test_oracle_physics.py, tests/test_reference_engine.py, lock-step tests).
-inline bool g_fused_rows = true;   // test switch (orc_set_fused_rows): false = the reference's arithmetic in the coloured order too
+// Test / mode switch of the coloured order (orc_set_arithmetic): bit 0 = fused velocity rows (above), bit 1 = the per-manifold block
+// position correction (contact_solve_position_block below). 0 = the reference's arithmetic in the coloured order too.
+enum : int { ARITH_REFERENCE = 0, ARITH_FUSED_VELOCITY = 1, ARITH_BLOCK_POSITION = 2 };
+inline int g_arith = ARITH_REFERENCE;
 inline float dot3_fma(vec3 a, vec3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
 inline vec3 fma3(vec3 w, float s, vec3 acc) { return {std::fmaf(w.x, s, acc.x), std::fmaf(w.y, s, acc.y), std::fmaf(w.z, s, acc.z)}; }
 inline float relative_speed_fused(const vec3 J[4], vec3 vA, vec3 wA, vec3 vB, vec3 wB) {
@@ -1945,7 +1948,7 @@ public:
             cc[m.colour].push_back(cr);
         }
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) apply_row_impulse(jr.r[i].impulse, jr.r[i]);
-        const bool fused = g_fused_rows;
+        const bool fused = (g_arith & ARITH_FUSED_VELOCITY) != 0, block = (g_arith & ARITH_BLOCK_POSITION) != 0;
         for (auto &col : cc) for (auto &cr : col) {
             if (fused) {
                 for (int i = 0; i < cr.m->num_points; ++i) apply_impulse_fused(cr.nr[i].impulse, cr.nr[i].J, cr.nr[i]);
@@ -2001,7 +2004,7 @@ public:
                 uint32_t l = label_of(cr.m->body[0], cr.m->body[1]);
                 if (done[l]) continue;
                 PosSolver ps;
-                if (fused) contact_solve_position_block(*cr.m, ps);
+                if (block) contact_solve_position_block(*cr.m, ps);
                 else for (int i = 0; i < cr.m->num_points; ++i) contact_solve_position(*cr.m, cr.m->pt[i], ps);
                 err[l] = std::max(err[l], ps.max_error);
             }

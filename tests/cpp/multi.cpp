@@ -16,7 +16,9 @@ struct Scene {
     std::vector<float> pos, orn, lv, av, mass, param, fric, rest;
     std::vector<uint64_t> group, mask;
     std::vector<uint8_t> nosleep;
-    void add(int k, int s, float x, float y, float z, float p0, float p1, float p2, float p3, float vx = 0) {
+    std::vector<float> com;
+    void add(int k, int s, float x, float y, float z, float p0, float p1, float p2, float p3, float vx = 0, float cx = 0, float cy = 0, float cz = 0) {
+        com.insert(com.end(), {cx, cy, cz});
         kind.push_back(k); shape.push_back(s);
         pos.insert(pos.end(), {x, y, z}); orn.insert(orn.end(), {0, 0, 0, 1}); lv.insert(lv.end(), {vx, 0, 0}); av.insert(av.end(), {0, 0, 0});
         mass.push_back(1); param.insert(param.end(), {p0, p1, p2, p3}); fric.push_back(0.5f); rest.push_back(0);
@@ -27,12 +29,68 @@ struct Scene {
         b.kind = kind.data(); b.pos = pos.data(); b.orn = orn.data(); b.linvel = lv.data(); b.angvel = av.data(); b.mass = mass.data();
         b.shape_type = shape.data(); b.shape_param = param.data(); b.friction = fric.data(); b.restitution = rest.data();
         b.group = group.data(); b.mask = mask.data(); b.sleeping_disabled = nosleep.data();
+        b.center_of_mass = com.data();
         return b;
     }
     uint32_t n() const { return (uint32_t)kind.size(); }
 };
 
+// Joints are island edges the host knows: a re-partition BEFORE the first step (the shards' device labels are still the identity) must
+// keep two far-apart bodies tied by a joint on one shard (they were split and the joint silently dropped), and the
+// scene-description calls are refused once the world has stepped.
+static int jointed_pairs() {
+    edynhip_world *world = nullptr;
+    edynhip_ctx *one = nullptr;
+    Scene sc;
+    sc.add(EDYNHIP_KIND_STATIC, EDYNHIP_SHAPE_PLANE, 0, 0, 0, 0, 1, 0, 0);
+    for (int k = 0; k < 8; ++k) {   // eight pairs of spheres 3 m apart, each pair tied by a distance constraint, swinging sideways
+        sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 10.0f * k, 4.0f, 0, 0.4f, 0, 0, 0, 0.5f);
+        sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 10.0f * k + 3.0f, 4.0f, 0, 0.4f, 0, 0, 0, -0.5f);
+    }
+    const uint32_t n = sc.n(), nj = 8;
+    std::vector<int32_t> jt(nj, EDYNHIP_JOINT_DISTANCE);
+    std::vector<uint32_t> jb; std::vector<float> jp(6 * nj, 0.0f), ja(6 * nj, 0.0f), jq(10 * nj, 0.0f);
+    for (uint32_t k = 0; k < nj; ++k) { jb.push_back(1 + 2 * k); jb.push_back(2 + 2 * k); jq[10 * k] = 3.0f; }
+    edynhip_joints js{jt.data(), jb.data(), jp.data(), ja.data(), jq.data()};
+    edynhip_config cfg{};
+    cfg.device = 0; cfg.max_bodies = n + 16; cfg.max_joints = nj + 4; cfg.fixed_dt = 1.0f / 60; cfg.num_velocity_iterations = 10; cfg.num_position_iterations = 3;
+    cfg.gravity[1] = -9.8f;
+    int status = 0;
+    one = edynhip_create(&cfg, &status);
+    REQUIRE(one != nullptr);
+    const edynhip_bodies b = sc.view();
+    REQUIRE(edynhip_set_bodies(one, n, &b) == EDYNHIP_OK && edynhip_set_joints(one, nj, &js) == EDYNHIP_OK);
+    const int32_t devices[2] = {0, 0};
+    cfg.max_bodies = 0; cfg.max_joints = 0;
+    world = edynhip_world_create(&cfg, devices, 2, &status);
+    REQUIRE(world != nullptr);
+    REQUIRE(edynhip_world_set_bodies(world, n, &b) == EDYNHIP_OK && edynhip_world_set_joints(world, nj, &js) == EDYNHIP_OK);
+    REQUIRE(edynhip_world_repartition(world) == EDYNHIP_OK);   // before the first step: no device labels yet
+    std::vector<int32_t> part(n);
+    REQUIRE(edynhip_world_get_partition(world, part.data()) == EDYNHIP_OK);
+    for (uint32_t k = 0; k < nj; ++k) REQUIRE(part[1 + 2 * k] == part[2 + 2 * k] && part[1 + 2 * k] >= 0);
+    std::vector<float> p1(3 * n), p2(3 * n), v1(3 * n), v2(3 * n);
+    for (int step = 0; step < 90; ++step) {
+        REQUIRE(edynhip_step(one, 1) == EDYNHIP_OK && edynhip_world_step(world, 1) == EDYNHIP_OK);
+        if (step == 30) REQUIRE(edynhip_world_repartition(world) == EDYNHIP_OK);   // and right after a step
+        REQUIRE(edynhip_get_state(one, p1.data(), nullptr, v1.data(), nullptr) == EDYNHIP_OK);
+        REQUIRE(edynhip_world_get_state(world, p2.data(), nullptr, v2.data(), nullptr) == EDYNHIP_OK);
+        if (std::memcmp(p1.data(), p2.data(), p1.size() * 4) || std::memcmp(v1.data(), v2.data(), v1.size() * 4)) {
+            std::printf("FAILED: jointed pairs: the sharded world left the single context's trajectory at step %d\n", step);
+            return 1;
+        }
+    }
+    const float d0 = p2[3] - p2[6], d1 = p2[4] - p2[7], d2 = p2[5] - p2[8];
+    REQUIRE(std::fabs(std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) - 3.0f) < 0.05f);   // the constraint is alive
+    REQUIRE(edynhip_world_exclude_collision(world, 1, 2) == EDYNHIP_ERR_UNSUPPORTED);   // a stepped world is not silently reset
+    REQUIRE(edynhip_world_set_joints(world, nj, &js) == EDYNHIP_ERR_UNSUPPORTED);
+    edynhip_world_destroy(world);
+    edynhip_destroy(one);
+    return 0;
+}
+
 int main() {
+    if (jointed_pairs() != 0) return 1;
     edynhip_world *world = nullptr;
     edynhip_ctx *one = nullptr;
     Scene sc;
@@ -41,7 +99,11 @@ int main() {
         for (int k = 0; k < 27; ++k) {
             const int i = k % 3, j = (k / 3) % 3, l = k / 9;
             const float off = (j & 1) ? 0.5f : 0.0f;
-            sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_BOX, 8.0f * (site % 3) + 1.02f * i + off + 0.003f * k, 0.505f + 1.005f * j, 8.0f * (site / 3) + 1.02f * l + off, 0.5f, 0.5f, 0.5f, 0);
+            // every fifth box carries a centre-of-mass offset (rigidbody_def::center_of_mass): a re-partition hands the CENTRE-OF-MASS state
+            // back to freshly built shards, whose origins / AABBs must follow it (they were displaced by R com)
+            const bool offset = k % 5 == 2;
+            sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_BOX, 8.0f * (site % 3) + 1.02f * i + off + 0.003f * k, 0.505f + 1.005f * j, 8.0f * (site / 3) + 1.02f * l + off, 0.5f, 0.5f, 0.5f, 0,
+                   0, offset ? 0.12f : 0.0f, offset ? -0.08f : 0.0f, offset ? 0.05f : 0.0f);
         }
     sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 4.3f, 0.5f, 1.0f, 0.5f, 0, 0, 0, 4.0f);   // between site 0 and site 1, rolling towards +x
     const uint32_t n = sc.n();

@@ -1,5 +1,11 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle and the committed golden fixtures.
 
+Contact arithmetic: device and oracle both default to the REFERENCE's operations in the reference's order (round 5; oracle:
+ARITH_REFERENCE) - every test of this file that does not say otherwise therefore holds the device to "the reference's row arithmetic in
+the coloured visiting order", bit for bit. The two opt-in forms (EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION) are
+held to the oracle's matching modes by test_opt_in_contact_arithmetic_* below; what the fork costs is pinned on the CPU by
+tests/test_arithmetic_fork.py.
+
 Bars (stated per check):
   * broadphase pair sets: bit-exact every step (canonical sorted (hi,lo) keys);
   * contact manifolds (body order, point count, list order, pivots, normals, impulses), island labels, colours:
@@ -22,6 +28,20 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 POINT_FIELDS = ("pivotA", "pivotB", "normal", "local_normal", "distance", "friction", "attachment", "lifetime",
                 "normal_impulse", "friction_impulse")
+
+
+@pytest.fixture(autouse=True)
+def _oracle_back_to_reference_arithmetic():
+    yield
+    ob.set_arithmetic(ob.ARITH_REFERENCE)   # process-wide switch of the checker
+
+
+# opt-in contact arithmetic: init_config switches of the device and the checker's matching mode
+ARITH_MODES = {
+    "fused_velocity_rows": (dict(fused_velocity_rows=True), ob.ARITH_FUSED_VELOCITY),
+    "block_position": (dict(block_position=True), ob.ARITH_BLOCK_POSITION),
+    "fused_rows_and_block_position": (dict(fused_velocity_rows=True, block_position=True), ob.ARITH_FUSED_VELOCITY | ob.ARITH_BLOCK_POSITION),
+}
 
 
 def gpu_world(scene, vel=10, pos=3, **kw):
@@ -581,7 +601,8 @@ def test_make_rigidbody_after_update_appends():
 
 
 # ------------------------------------------------------------------ both solver schedules
-def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
+@pytest.mark.parametrize("arith", ["reference", "fused_rows_and_block_position"])
+def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path, arith):
     """Contact-only scenes run the velocity and position solves as dataflow launches (tagged hand-offs between
     manifolds); scenes with joints, or EDYNHIP_DATAFLOW=0, run one launch per colour. Both visit every body's manifolds
     in colour order, so they must agree bit for bit (and both with the oracle, which the other tests check for the
@@ -591,7 +612,8 @@ def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
     script = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "import edyn_amd; from edyn_amd import scenes\n"
-        "w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3))\n"
+        "kw = dict(fused_velocity_rows=True, block_position=True) if sys.argv[2] != 'reference' else {}\n"
+        "w = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, **kw))\n"
         "w.set_scene(scenes.box_pile(6, 6, 6, mixed=True)); w.step_simulation(80)\n"
         "p, q, v, a = w.get_state(); m = w.get_manifolds()\n"
         "np.savez(sys.argv[1], p=p, q=q, v=v, a=a, m=m.view(np.uint8))\n" % root)
@@ -602,15 +624,87 @@ def test_per_colour_and_dataflow_schedules_are_bit_identical(tmp_path):
         env = dict(os.environ, EDYNHIP_DATAFLOW=mode)
         if lanes:
             env["EDYNHIP_DF_LANES"] = lanes
-        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
+        subprocess.run([sys.executable, "-c", script, out, arith], check=True, env=env, timeout=300)
         outs.append(np.load(out))
     for other in outs[1:]:
         for k in ("p", "q", "v", "a", "m"):
             assert np.array_equal(outs[0][k], other[k]), k
     # and the default schedule against the oracle on the same scene
+    ob.set_arithmetic(ob.ARITH_REFERENCE if arith == "reference" else ARITH_MODES[arith][1])
     o = oracle_world(scenes.box_pile(6, 6, 6, mixed=True)); o.step(80)
     for a, b in zip((outs[0]["p"], outs[0]["q"], outs[0]["v"], outs[0]["a"]), o.get_state()):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", list(ARITH_MODES))
+def test_opt_in_contact_arithmetic_bit_exact_vs_the_checkers_mode(mode):
+    """EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION (the faster forms of the contact rows / position corrections, off by
+    default): every solve kernel computes the checker's matching arithmetic bit for bit - the dataflow launches (a collapsing box pile:
+    4-, 3-, 2- and 1-point instantiations; a box/sphere mix at 20 iterations), the per-colour launches with the serial bucket (a plate on
+    100 bricks), the island-fused kernels beside the dataflow launch (rag dolls next to a pile: mixed schedule)."""
+    kw, omode = ARITH_MODES[mode]
+    ob.set_arithmetic(omode)
+    for name, scene, vel, steps in (("pile", scenes.box_pile(6, 6, 6), 10, 60), ("mixed", scenes.box_pile(5, 5, 5, mixed=True), 20, 40)):
+        g, o = gpu_world(scene, vel=vel, **kw), oracle_world(scene, vel=vel)
+        for step in range(steps):
+            g.step_simulation(1); o.step(1)
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), (name, step)
+            for a, b, f in zip(g.get_state(), o.get_state(), ("pos", "orn", "linvel", "angvel")):
+                assert np.array_equal(a, b), (name, step, f, float(np.abs(a - b).max()))
+        assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"{mode} {name}")
+        assert np.array_equal(g.get_derived()[1], o.get_derived()[1]), (name, "world inertia")
+    # per-colour launches + serial bucket
+    s = scenes.box_pile(10, 1, 10)
+    top = float(s["pos"][:, 1].max()) + 0.5
+    xc, zc = float(s["pos"][1:, 0].mean()), float(s["pos"][1:, 2].mean())
+    s = _append_body(s, pos=(xc, top + 0.26, zc), shape_param=(5.6, 0.25, 5.6, 0), mass=50.0)
+    g, o = gpu_world(s, **kw), oracle_world(s)
+    for step in range(40):
+        g.step_simulation(1); o.step(1)
+    assert np.array_equal(g.get_pairs(), o.get_pairs())
+    assert_state_equal(g, o)
+    gm = g.get_manifolds()
+    assert_manifolds_equal(gm, o.get_manifolds(), what=f"{mode} plate")
+    assert int((gm["colour"] == 62).sum()) > 0
+    # mixed schedule: island-fused kernels (figures) + dataflow (pile)
+    pile = scenes.box_pile(12, 8, 12)
+    figs = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 2, 2, pitch=1.6, floor=False)
+    figs["pos"][:, 0] += np.float32(25.0)
+    sc = scenes.merge(pile, figs)
+    g = edyn_amd.World(edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_position_iterations=3, **kw))
+    g.set_scene(sc)
+    o = oracle_world(sc)
+    scenes.apply_figure_settings(g, sc); scenes.apply_figure_settings(o, sc)
+    for step in range(1, 61):
+        g.step_simulation(1); o.step(1)
+        if step % 20 == 0 or step < 4:
+            assert np.array_equal(g.get_pairs(), o.get_pairs()), step
+            assert_state_equal(g, o)
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what=f"{mode} pile beside rag dolls")
+    assert np.array_equal(g.get_joint_impulses().view(np.uint32), o.get_joint_impulses().view(np.uint32))
+
+
+def test_the_default_contact_arithmetic_is_the_references_and_the_modes_differ():
+    """A world created without the opt-in flags is bit-exact against the checker's ARITH_REFERENCE and NOT against its other modes -
+    the flags really select different kernels - on a collapsing pile (device vs the coloured order with the reference's
+    arithmetic after 60 steps: zero error, bound 1e-4 m / 1e-3)."""
+    scene = scenes.box_pile(6, 6, 6)
+    g = gpu_world(scene); g.step_simulation(60)
+    states = {}
+    for omode in (ob.ARITH_REFERENCE, ob.ARITH_FUSED_VELOCITY, ob.ARITH_FUSED_VELOCITY | ob.ARITH_BLOCK_POSITION):
+        ob.set_arithmetic(omode)
+        o = oracle_world(scene); o.step(60)
+        states[omode] = o.get_state()
+    for a, b in zip(g.get_state(), states[ob.ARITH_REFERENCE]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(g.get_state()[0], states[ob.ARITH_FUSED_VELOCITY][0])
+    assert not np.array_equal(g.get_state()[0], states[ob.ARITH_FUSED_VELOCITY | ob.ARITH_BLOCK_POSITION][0])
+    # and the opt-in modes' distance from the default on the device itself, against the figures tests/test_arithmetic_fork.py asserts on the CPU
+    f = gpu_world(scene, fused_velocity_rows=True); f.step_simulation(60)
+    b = gpu_world(scene, fused_velocity_rows=True, block_position=True); b.step_simulation(60)
+    dp_f = float(np.abs(f.get_state()[0] - g.get_state()[0]).max()); dp_b = float(np.abs(b.get_state()[0] - g.get_state()[0]).max())
+    print(f"\n[figures] device, box_pile(6,6,6), 60 free-running steps vs the default arithmetic: fused velocity rows dpos {dp_f:.2e} m, + block position {dp_b:.2e} m")
+    assert dp_f <= 1e-4 and 1e-4 < dp_b < 1e-3, (dp_f, dp_b)
 
 
 def test_island_fused_and_per_colour_schedules_are_bit_identical(tmp_path):
