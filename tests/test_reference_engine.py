@@ -340,6 +340,72 @@ def test_canonical_and_coloured_orders_agree_with_the_reference_order_within_tol
     assert np.abs(ref.get_state()[0][:, 1] - orc.get_state()[0][:, 1]).max() < 1e-3
 
 
+def test_solver_residual_and_penetration_of_the_coloured_order_against_the_real_engine():
+    """SURVEY section 7 hard-part 1 (VERDICT r04 missing #4): the solver-residual invariant. After the last velocity iteration of a step,
+    |J v - rhs| over the active normal rows (tests/invariants.py: the relative normal velocity the unconverged Gauss-Seidel sweep leaves at
+    loaded, touching contacts) in the coloured order - the device's specification, with the reference's row arithmetic - against the real
+    engine running its own order, free-running from the same start on a box pile (10 iterations) and a box / sphere mix (20 iterations), while
+    the piles settle (steps 120, 240). The coloured order must not leave more than TWICE the engine's residual (measured: it leaves LESS -
+    0.3-0.5x the maximum, 0.05-0.3x the mean: a body meets its contacts in colour order, bottom-up through the lattice, instead of in
+    EnTT creation order), and the pile sits no deeper than the engine's (99th percentile and mean penetration within 2x). The device is bit-exact against this coloured
+    order; the same invariant is taken on the device at BASELINE size in tests/test_gpu_parity.py."""
+    from invariants import normal_row_residual, penetration_stats
+    for name, sc, vel, height in (("pile_8x8x8", scenes.box_pile(8, 8, 8), 10, 8.0), ("mixed_7x7x7", scenes.box_pile(7, 7, 7, mixed=True), 20, 7.0)):
+        ref = ob.RefWorld(vel_iters=vel); ref.add_bodies(sc)
+        orc = ob.World(vel_iters=vel, order=ob.ORDER_COLOURED); orc.add_bodies(sc)
+        for upto in (120, 240):
+            ref.step(120); orc.step(120)
+            (em, ea, en), (cm, ca, cn) = normal_row_residual(ref.get_state(), ref.get_manifolds()), normal_row_residual(orc.get_state(), orc.get_manifolds())
+            (pe, pe99, pea), (pc, pc99, pca) = penetration_stats(ref.get_manifolds()), penetration_stats(orc.get_manifolds())
+            print(f"\n[residual] {name} step {upto} [coloured / engine]: max {cm:.3e} / {em:.3e} m/s, mean {ca:.3e} / {ea:.3e} m/s over {cn} / {en} active rows; "
+                  f"penetration deepest {pc:.4f} / {pe:.4f} m, 99th percentile {pc99:.5f} / {pe99:.5f} m, mean {pca:.2e} / {pea:.2e} m")
+            assert cn > 100 and en > 100
+            assert cm <= 2.0 * em and ca <= 2.0 * ea, (name, upto, cm, em, ca, ea)
+            # the pile as a whole sits no deeper than the engine's (percentile and mean within 2x + 0.2 mm); the single deepest point is a
+            # faller's transient on either side (see penetration_stats), bounded by one step of free fall from the pile's height
+            assert pc99 <= 2.0 * pe99 + 2e-4 and pca <= 2.0 * pea + 2e-4, (name, upto, pc99, pe99, pca, pea)
+            assert max(pc, pe) <= float(np.sqrt(2 * 9.8 * height)) / 60.0, (name, upto, pc, pe)
+
+
+def test_jointed_scenes_in_lock_step_with_the_real_engine():
+    """VERDICT r04 missing #3: how far the COLOURED joint order lands from the engine per step on the jointed configurations - C5-style
+    chains (hinge_constraint.cpp:26-213, point_constraint.cpp:9-58) and a heap of the reference's rag dolls (cone / cvjoint / hinge, capsule
+    contacts) - with every step restarted from the engine's own state: bodies, manifolds and the joints' applied impulses and tracked
+    angles (set_joint_warm_start). Two statements:
+      * the engine's own row order replayed (ORDER_EXTERNAL): ZERO difference for every step - the hand-over of an engine state (incl. the
+        joint warm start) into another stepper is exact, so whatever the coloured order differs by below is its visiting order alone;
+      * the coloured order (the device's; the device is bit-exact against it): pair sets and narrowphase output identical, the solved state
+        within the bounds asserted here per step. Measured: chains 3.0e-3 m / 0.24 m/s; the collapsing rag-doll heap 2.9e-2 m / 1.7 m/s
+        (limbs hitting the floor at 5-10 m/s, 36 stiff constraints per figure with bump stops, 10 iterations: the joints are far from
+        converged in either order) - mean over the bodies 2.9e-3 m / 0.18 m/s in the worst step, median step 5e-3 m / 0.32 m/s."""
+    from invariants import resync_lockstep_jointed
+    chains = scenes.c5_chains(64, 16)
+    dolls = scenes.figures(scenes.load_figure(os.path.join(GOLDEN, "ragdoll_capsule.npz")), 3, 2, pitch=1.0, ny=3, pitch_v=1.9)
+    for name, sc, steps, contacts, tol_p, tol_v in (("chains_64x16", chains, 90, False, 1e-2, 0.6), ("ragdoll_heap_18", dolls, 90, True, 8e-2, 4.0)):
+        # (a) the engine's order replayed: exact
+        ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc); scenes.apply_figure_settings(ref, sc)
+        orc = ob.World(vel_iters=10, order=ob.ORDER_EXTERNAL); orc.add_bodies(sc); scenes.apply_figure_settings(orc, sc)
+        from invariants import canonical_records
+        for step in range(1, 41):
+            orc.set_state(*ref.get_state()); orc.refresh_derived()
+            if contacts:
+                orc.set_manifolds(canonical_records(ref.get_manifolds(), sc["kind"]))
+            orc.set_joint_warm_start(ref.get_joint_impulses24(), ref.get_joint_impulses()[:, 9])
+            ref.step(1)
+            orc.set_ext_order(*ref.get_solve_order())
+            orc.step(1)
+            assert not orc.ext_order_mismatch(), (name, step)
+            for a, b, f in zip(orc.get_state(), ref.get_state(), ("pos", "orn", "linvel", "angvel")):
+                assert np.array_equal(a, b), (name, step, f)
+        # (b) the coloured order: bounded per step
+        ref = ob.RefWorld(vel_iters=10); ref.add_bodies(sc); scenes.apply_figure_settings(ref, sc)
+        orc = ob.World(vel_iters=10, order=ob.ORDER_COLOURED); orc.add_bodies(sc); scenes.apply_figure_settings(orc, sc)
+        wp, wv, ww = resync_lockstep_jointed(orc, ref, sc["kind"], steps, tol_p, tol_v, contacts)
+        vmax = float(np.abs(ref.get_state()[2]).max())
+        print(f"\n[lock-step] {name}, coloured order vs engine, {steps} steps: worst per step |dpos| {wp:.3e} m, |dvel| {wv:.3e} m/s, |dangvel| {ww:.3e} rad/s "
+              f"(bounds {tol_p} m / {tol_v} m/s; fastest body at the end {vmax:.2f} m/s)")
+
+
 def _pair_bodies(keys):
     keys = np.asarray(keys, np.uint64)
     return (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
