@@ -98,7 +98,8 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_world_set_bodies", "edynhip_world_set_joints", "edynhip_world_set_joint_definition", "edynhip_world_exclude_collision",
            "edynhip_world_step", "edynhip_world_get_state", "edynhip_world_get_partition", "edynhip_world_repartition",
            "edynhip_world_get_manifolds", "edynhip_world_get_stats", "edynhip_world_context", "edynhip_partition_islands",
-           "edynhip_island_boxes_overlap", "edynhip_get_island_boxes"]
+           "edynhip_island_boxes_overlap", "edynhip_get_island_boxes",
+           "edynhip_world_set_pair_filter", "edynhip_world_default_should_collide"]
 
 _lib = None
 
@@ -177,6 +178,8 @@ def lib():
         L.edynhip_world_set_joint_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.edynhip_world_exclude_collision.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_world_step.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_world_set_pair_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edynhip_world_default_should_collide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_world_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.edynhip_world_get_partition.argtypes = [C.c_void_p, C.c_void_p]
         L.edynhip_world_repartition.argtypes = [C.c_void_p]

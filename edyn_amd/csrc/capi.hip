@@ -119,7 +119,7 @@ static int allocate(edynhip_ctx *c) {
     EH_TRY(dalloc(c, c->own_keys, (size_t)nb * kOwnCap)); EH_TRY(dalloc(c, c->own_count, (size_t)nb + 1)); EH_TRY(dalloc(c, c->own_offset, (size_t)nb + 1));
     EH_TRY(dalloc(c, c->col_keys, M)); EH_TRY(dalloc(c, c->col_keys_sorted, M));
     EH_TRY(dalloc(c, c->col_unc, kColUncCap));
-    { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); }
+    { const size_t cs = 256 * (((size_t)M + 1023) / 1024) + 1; EH_TRY(dalloc(c, c->cs_hist, cs)); EH_TRY(dalloc(c, c->cs_start, cs)); EH_TRY(dalloc(c, c->cs_sup, 16 * 256)); EH_HIP(c, hipMemset(c->cs_sup, 0, 16 * 256 * sizeof(uint32_t))); }
     EH_TRY(dalloc(c, c->used, nb)); EH_TRY(dalloc(c, c->best[0], nb)); EH_TRY(dalloc(c, c->best[1], nb));
     EH_TRY(dalloc(c, c->com_store, nb)); EH_TRY(dalloc(c, c->origin_store, nb));
     EH_TRY(dalloc(c, c->isl_cnt, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_off, (size_t)nb + 1)); EH_TRY(dalloc(c, c->isl_list, nb));

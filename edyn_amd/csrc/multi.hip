@@ -224,6 +224,15 @@ struct edynhip_world {
     HostScene scene;
     std::vector<int32_t> rank_of;
     std::vector<float> pos, orn, linvel, angvel;   // the gathered state, global order
+    // settings.should_collide_func on a world over several devices (broadphase.cpp:143-153): the user's predicate speaks GLOBAL body
+    // indices; every shard's context asks it through a thunk that maps its local indices back (ShardFilter, one per shard, stable
+    // across re-partitions). The shards step on their own host threads: the calls are serialised (the reference's sequential stepper
+    // asks from one thread).
+    edynhip_pair_filter filter = nullptr;
+    void *filter_user = nullptr;
+    std::mutex filter_mutex;
+    struct ShardFilter { edynhip_world *w; uint32_t shard; };
+    std::vector<ShardFilter> shard_filters;
     bool built = false;
     bool stepped = false;                          // stepped since the scene was last described (set_bodies): scene-description calls are refused then
     float budget = 0.0f;                           // how much two islands of different shards may still approach before a check is due
@@ -277,6 +286,14 @@ struct Carry {   // what travels with the islands through a re-partition (global
     std::vector<uint8_t> asleep;               // per global body
     bool any = false;
 };
+
+int shard_filter_thunk(void *user, uint32_t body, uint32_t other) {
+    auto *sf = static_cast<edynhip_world::ShardFilter *>(user);
+    edynhip_world *w = sf->w;
+    const Shard &s = w->shards[sf->shard];
+    std::lock_guard<std::mutex> lock(w->filter_mutex);
+    return w->filter(w->filter_user, s.local_ids[body], s.local_ids[other]);
+}
 
 // (Re)builds shard r for the partition w->rank_of from the scene, the current global state and what the islands carry.
 void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_state) {
@@ -363,6 +380,7 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     for (const auto &e : sc.exclusions)
         if (s.to_local[e[0]] >= 0 && s.to_local[e[1]] >= 0 && (w->rank_of[e[0]] == (int32_t)r || w->rank_of[e[1]] == (int32_t)r))
             SH_TRY(s, edynhip_exclude_collision(s.ctx, (uint32_t)s.to_local[e[0]], (uint32_t)s.to_local[e[1]]));
+    if (w->filter) SH_TRY(s, edynhip_set_pair_filter(s.ctx, &shard_filter_thunk, &w->shard_filters[r]));
     if (carry.any) {
         std::vector<edynhip_manifold> mine;
         for (const edynhip_manifold &m : carry.manifolds)
@@ -721,6 +739,8 @@ edynhip_world *edynhip_world_create(const edynhip_config *cfg, const int32_t *de
     // several shards on ONE device (functional tests) must not promise that device to each of them
     for (uint32_t r = 0; r < num_devices; ++r) for (uint32_t q = 0; q < r; ++q) if (devices[q] == devices[r]) w->cfg.flags &= ~(uint32_t)EDYNHIP_FLAG_EXCLUSIVE_DEVICE;
     w->pool.reset(new Pool(num_devices));
+    w->shard_filters.resize(num_devices);
+    for (uint32_t r = 0; r < num_devices; ++r) w->shard_filters[r] = edynhip_world::ShardFilter{w, r};
     w->stats.num_shards = num_devices;
     if (status_out) *status_out = EDYNHIP_OK;
     return w;
@@ -797,6 +817,30 @@ int edynhip_world_exclude_collision(edynhip_world *w, uint32_t a, uint32_t b) {
     w->scene.exclusions.push_back({a, b});
     w->built = false;
     return EDYNHIP_OK;
+}
+
+int edynhip_world_set_pair_filter(edynhip_world *w, edynhip_pair_filter filter, void *user) {
+    if (!w) return EDYNHIP_ERR_INVALID;
+    w->filter = filter; w->filter_user = user;
+    if (!w->built) return EDYNHIP_OK;   // installed when the shards are built
+    for (uint32_t r = 0; r < w->shards.size(); ++r) {
+        Shard &s = w->shards[r];
+        if (!s.ctx) continue;
+        const int rc = edynhip_set_pair_filter(s.ctx, filter ? &shard_filter_thunk : nullptr, &w->shard_filters[r]);
+        if (rc != EDYNHIP_OK) return w->fail(rc, std::string("edynhip_world_set_pair_filter: shard ") + std::to_string(r) + ": " + edynhip_last_error(s.ctx));
+    }
+    return EDYNHIP_OK;
+}
+
+int edynhip_world_default_should_collide(edynhip_world *w, uint32_t a, uint32_t b) {   // should_collide_default in global indices
+    if (!w || a >= w->scene.n || b >= w->scene.n) return EDYNHIP_ERR_INVALID;
+    if (a == b) return 0;
+    const HostScene &sc = w->scene;
+    const uint64_t ga = sc.group.empty() ? ~0ull : sc.group[a], gb = sc.group.empty() ? ~0ull : sc.group[b];
+    const uint64_t ma = sc.mask.empty() ? ~0ull : sc.mask[a], mb = sc.mask.empty() ? ~0ull : sc.mask[b];
+    if ((ga & mb) == 0 || (gb & ma) == 0) return 0;
+    for (const auto &e : sc.exclusions) if ((e[0] == a && e[1] == b) || (e[0] == b && e[1] == a)) return 0;
+    return 1;
 }
 
 int edynhip_world_step(edynhip_world *w, uint32_t nsteps) {

@@ -36,6 +36,7 @@ using namespace dm;
 static inline uint32_t blocks(uint32_t n, uint32_t bs) { return (n + bs - 1) / bs; }
 
 DI bool is_dynamic(uint32_t flags) { return (flags & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC; }
+constexpr uint32_t kCsBlock = 1024, kCsKeys = 256, kCsDirectBlocks = 256, kCsSuper = 16;   // the colour sort (k_cs_*)
 // Edge priority for the colouring rounds: lower edge index wins, which reproduces sequential first-fit
 // colouring in canonical pair order (near-optimal colour counts on stacked scenes: max degree or +1) at the
 // price of more rounds when a whole scene is coloured from scratch; steady state only colours new edges.
@@ -104,6 +105,13 @@ __global__ void k_cc_init(uint32_t n, uint32_t *forest, Counters *cnt, Manifolds
         forest[i] = parent;
     }
     cc_count_marks(marks, cnt);
+}
+// CC_FULL, between the initial forest and the unions (round 5): every body's link goes straight to its root. The initial forest of a pile
+// is a set of chains ~100 links deep (each body under its lowest lower-index partner); without this pass every union of k_cc_hook_bodies
+// walks such a chain twice. The walks halve the paths they pass, so a second pass costs little where the first has been.
+__global__ void k_cc_compress(uint32_t n, uint32_t *forest, const uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && is_dynamic(flags[i])) forest[i] = cc_find(forest, i);   // (a racing hook cannot exist here: only finds run in this launch)
 }
 __global__ void k_cc_hook(uint32_t M, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
                           const uint32_t *__restrict__ flags, uint32_t *island) {   // joints (CC_FULL): edges that only an edit removes
@@ -303,9 +311,11 @@ __global__ void k_sleep_apply(uint32_t n, Bodies b, const uint32_t *__restrict__
 // the whole. k_col_tops finds each island's top colour (+ 1; .x) and whether it has an uncoloured active edge (.y), k_col_prepare releases.
 __device__ __forceinline__ uint32_t manifold_label(uint32_t a, uint32_t b, uint32_t fa, const uint32_t *__restrict__ island) { return island[is_dynamic(fa) ? a : b]; }
 __global__ void __launch_bounds__(1024) k_col_tops(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                                                   const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint2 *isl_top) {
+                                                   const uint32_t *__restrict__ flags, const uint32_t *__restrict__ island, uint2 *isl_top, uint32_t *cs_sup) {
     __shared__ uint32_t s_label[16], s_top[16];
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    // (first kernel of the colouring chain: also clears the colour sort's super-block key counts, k_cs_hist<true>)
+    for (uint32_t g = m; g < (kCsDirectBlocks / kCsSuper) * kCsKeys; g += gridDim.x * blockDim.x) cs_sup[g] = 0u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t label = 0xFFFFFFFFu, top = 0;
     if (m < M) {
@@ -538,10 +548,14 @@ DI uint32_t colour_key(uint32_t m, const uint32_t *__restrict__ info, const uint
 //  k_cs_hist:    per 1024-element block, the count of every key          -> hist[key * nblocks + block]
 //  scan_u32:     exclusive scan of that key-major table                   -> where each (key, block) run starts
 //  k_cs_scatter: every element's slot = its run's start + its rank among the block's earlier elements with its key
-constexpr uint32_t kCsBlock = 1024, kCsKeys = 256;
+//  Scenes of up to kCsDirectBlocks blocks (the headline pile: 174) take two launches instead of five (round 5): the
+//  histogram table is block-major there and k_cs_hist<true> also accumulates the key counts of every kCsSuper blocks (`sup`, integer
+//  sums: the same values whatever the order); k_cs_scatter<true> gets the run starts of its block from at most 16 + 15 table rows,
+//  builds the key starts from the totals, and block 0 publishes the colour ranges (k_col_offsets' work). No library scan on the hot path.
+template <bool DIRECT>
 __global__ void __launch_bounds__(kCsBlock) k_cs_hist(uint32_t M, uint32_t *keys, uint32_t *hist, uint32_t nblocks, const uint32_t *__restrict__ info,
                                                       const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
-                                                      const uint32_t *__restrict__ flags, bool sleeping) {
+                                                      const uint32_t *__restrict__ flags, bool sleeping, uint32_t *sup) {
     __shared__ uint32_t h[kCsKeys];
     if (threadIdx.x < kCsKeys) h[threadIdx.x] = 0;
     __syncthreads();
@@ -552,12 +566,54 @@ __global__ void __launch_bounds__(kCsBlock) k_cs_hist(uint32_t M, uint32_t *keys
         atomicAdd(&h[key & 0xFFu], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kCsKeys) hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < kCsKeys) {
+        hist[DIRECT ? blockIdx.x * kCsKeys + threadIdx.x : threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+        if (DIRECT && h[threadIdx.x]) atomicAdd(&sup[(blockIdx.x / kCsSuper) * kCsKeys + threadIdx.x], h[threadIdx.x]);
+    }
 }
+template <bool DIRECT>
 __global__ void __launch_bounds__(kCsBlock) k_cs_scatter(uint32_t M, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ start,
-                                                         uint32_t nblocks, uint32_t *keys_sorted, uint32_t *order) {
+                                                         uint32_t nblocks, uint32_t *keys_sorted, uint32_t *order, Counters *cnt, const uint32_t *__restrict__ sup) {
     __shared__ uint32_t base[kCsKeys];
-    if (threadIdx.x < kCsKeys) base[threadIdx.x] = start[threadIdx.x * nblocks + blockIdx.x];
+    if (DIRECT) {   // `start` is the block-major histogram table
+        __shared__ uint32_t wsum[4], part[kCsKeys];
+        uint32_t before = 0, total = 0;
+        {   // lanes 0..255: the super-block rows (key totals; what lies before this block's super-block); lanes 256..511: the rows of
+            // the blocks before this one inside its super-block - at most 16 + 15 independent loads per key
+            const uint32_t k = threadIdx.x & (kCsKeys - 1), q = threadIdx.x >> 8, sb = blockIdx.x / kCsSuper, nsup = (nblocks + kCsSuper - 1) / kCsSuper;
+            if (q == 0) {
+                uint32_t v[kCsDirectBlocks / kCsSuper];
+#pragma unroll
+                for (uint32_t u = 0; u < kCsDirectBlocks / kCsSuper; ++u) v[u] = u < nsup ? sup[u * kCsKeys + k] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < kCsDirectBlocks / kCsSuper; ++u) { total += v[u]; before += u < sb ? v[u] : 0u; }
+            } else if (q == 1) {
+                uint32_t v[kCsSuper], inner = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < kCsSuper; ++u) { const uint32_t b = sb * kCsSuper + u; v[u] = b < blockIdx.x ? start[b * kCsKeys + k] : 0u; }
+#pragma unroll
+                for (uint32_t u = 0; u < kCsSuper; ++u) inner += v[u];
+                part[k] = inner;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kCsKeys) before += part[threadIdx.x];
+        // exclusive scan of the 256 key totals (lanes 0..255 = waves 0..3)
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        uint32_t inc = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+        if (wave < 4 && lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x < kCsKeys) {
+            uint32_t key_start = inc - total;
+            for (uint32_t w = 0; w < wave; ++w) key_start += wsum[w];
+            base[threadIdx.x] = key_start + before;
+            if (blockIdx.x == 0 && threadIdx.x < 4 * kMaxContactColours && total) {   // what k_col_offsets reads off the sorted keys
+                cnt->colour_start[threadIdx.x] = key_start; cnt->colour_end[threadIdx.x] = key_start + total;
+            }
+        }
+    } else if (threadIdx.x < kCsKeys) base[threadIdx.x] = start[threadIdx.x * nblocks + blockIdx.x];
     __syncthreads();
     const uint32_t m = blockIdx.x * kCsBlock + threadIdx.x;
     const bool valid = m < M;
@@ -1191,6 +1247,10 @@ __global__ void __launch_bounds__(kDfBlock) k_contact_solve_df(DfArgs a) {
 // ---- push hand-off: link every (lane, side) to the same body's next manifold in colour order (cyclic) ----
 // `isl_joint` (mixed schedule, else nullptr): islands with joints take no part in the hand-off chains - their manifolds are marked in
 // Rows::skip and their bodies keep first_slot = none (k_island_velocity / k_island_position solve them on the body records).
+// (Round 5, measured and dropped: the links computed inside k_prep_contacts, the slot table written by the colour sort's scatter - one
+//  launch less, and no gain: the scatter grows by what the table costs (+7 us), and the velocity solve that then follows the row
+//  preparation directly starts 10-25 us slower - it meets the row stores of the preparation still on their way out of the L2s, which this
+//  small kernel otherwise absorbs. A/B on one box: 769 against 783 steps/s.)
 __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__restrict__ keys_sorted, Bodies b, const uint64_t *__restrict__ used,
                              const uint32_t *__restrict__ isl_joint) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3190,6 +3250,10 @@ int islands(edynhip_ctx *c) {
     if (mode == CC_FULL) {
         hipLaunchKernelGGL(k_cc_init, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->cnt, mf, M, c->b.flags);
         if (c->j.n) hipLaunchKernelGGL(k_cc_hook, dim3(blocks(c->j.n, 256)), dim3(256), 0, s, c->j.n, c->j.bodyA, c->j.bodyB, c->b.flags, forest);
+        static const int compress_env = getenv("EDYNHIP_CC_COMPRESS") ? atoi(getenv("EDYNHIP_CC_COMPRESS")) : 1;   // developer knob: passes of k_cc_compress
+        if (M) for (int pass = 0; pass < compress_env; ++pass) hipLaunchKernelGGL(k_cc_compress, dim3(blocks(n, 256)), dim3(256), 0, s, n, forest, c->b.flags);
+        // (round 5, measured and dropped: one lane per EDGE on the compressed forest instead of the per-body walks - 2 x 67 us against 57:
+        //  what costs is not the depth of the finds any more but the unions themselves, thousands of trees hooking into one root)
         if (M) hipLaunchKernelGGL(k_cc_hook_bodies, dim3(blocks(n, 256)), dim3(256), 0, s, n, mf, M, c->b.flags, forest, c->cnt);
         flatten(forest);
     } else if (mode == CC_INCREMENTAL) {   // the labels themselves are the forest (roots = lowest index: depth 1)
@@ -3230,7 +3294,7 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
         EH_HIP(c, hipMemsetAsync(&c->cnt->uncoloured, 0, 2 * sizeof(uint32_t), s));   // uncoloured, colour_overflow
         EH_HIP(c, hipMemsetAsync(c->cnt->colour_start, 0, 8 * kMaxColours * sizeof(uint32_t), s));
     }
-    hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top);
+    hipLaunchKernelGGL(k_col_tops, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->b.island, c->isl_top, c->cs_sup);
     hipLaunchKernelGGL(k_col_prepare, dim3(blocks(M, 1024)), dim3(1024), 0, s, M, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->best[0], c->best[1], c->cnt, c->b.island, c->isl_top, c->col_unc);
     uint32_t round = 0, total_rounds = 0;
     auto run_rounds = [&](uint32_t count) {
@@ -3245,11 +3309,18 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
     auto sort_and_fetch = [&]() -> int {
         {
             const uint32_t nb = blocks(M, kCsBlock);
-            hipLaunchKernelGGL(k_cs_hist, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping);
-            EH_TRY(scan_u32(c, c->cs_hist, c->cs_start, kCsKeys * nb));
-            hipLaunchKernelGGL(k_cs_scatter, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order);
+            static const bool direct_env = !(getenv("EDYNHIP_DIRECT_SORT") && getenv("EDYNHIP_DIRECT_SORT")[0] == '0');   // developer knob (A/B)
+            if (nb <= kCsDirectBlocks && direct_env) {
+                if (!first) EH_HIP(c, hipMemsetAsync(c->cs_sup, 0, (size_t)(kCsDirectBlocks / kCsSuper) * kCsKeys * sizeof(uint32_t), s));   // (the step's first sort: cleared by k_col_tops)
+                hipLaunchKernelGGL(k_cs_hist<true>, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping, c->cs_sup);
+                hipLaunchKernelGGL(k_cs_scatter<true>, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb, c->col_keys_sorted, c->rows.order, c->cnt, c->cs_sup);
+            } else {
+                hipLaunchKernelGGL(k_cs_hist<false>, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_hist, nb, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->sleeping, (uint32_t *)nullptr);
+                EH_TRY(scan_u32(c, c->cs_hist, c->cs_start, kCsKeys * nb));
+                hipLaunchKernelGGL(k_cs_scatter<false>, dim3(nb), dim3(kCsBlock), 0, s, M, c->col_keys, c->cs_start, nb, c->col_keys_sorted, c->rows.order, c->cnt, (const uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
+            }
         }
-        hipLaunchKernelGGL(k_col_offsets, dim3(blocks(M, 256)), dim3(256), 0, s, M, c->col_keys_sorted, c->cnt);
         uint32_t ticket = 0;
         EH_TRY(publish_counters(c, sizeof(Counters), &ticket));
         if (first) between();

@@ -75,6 +75,15 @@ class MultiWorld:
         for a, bb in scene.get("exclusions", []):
             self._check(self._L.edynhip_world_exclude_collision(self._h, int(a), int(bb)))
 
+    def set_should_collide(self, func):
+        """edyn::set_should_collide on a world over several devices: func(body, other) -> bool with GLOBAL body indices replaces
+        should_collide_default for new manifolds (None restores the device test); edynhip_world_set_pair_filter."""
+        self._filter_cb = _capi.PAIR_FILTER(lambda user, a, b: 1 if func(int(a), int(b)) else 0) if func else None
+        self._check(self._L.edynhip_world_set_pair_filter(self._h, C.cast(self._filter_cb, C.c_void_p) if func else None, None))
+
+    def default_should_collide(self, a, b):
+        return self._L.edynhip_world_default_should_collide(self._h, int(a), int(b)) == 1
+
     def step_simulation(self, n=1):
         self._check(self._L.edynhip_world_step(self._h, int(n)))
 

@@ -494,6 +494,7 @@ inline void upload_scene_multi(entt::registry &registry, gpu_stepper &s) {
     int st = 0;
     s.world = edynhip_world_create(&c, devs.data(), (uint32_t)devs.size(), &st);
     if (!s.world) throw stepper_error(st, std::string("edynhip_world_create: ") + edynhip_world_last_error(nullptr));
+    if (s.should_collide) check(s, edynhip_world_set_pair_filter(s.world, &pair_filter_trampoline, &s));   // a rebuilt world asks the same predicate
     s.meshes.clear();
     body_arrays A(total);
     fill_body_arrays(registry, s, 0, total, A, [&](const polyhedron_shape &ph) {
@@ -1154,7 +1155,7 @@ entt::entity make_constraint(entt::registry &registry, entt::entity body0, entt:
 }
 
 // ---- collision/should_collide.hpp:8-18: the user's predicate that replaces should_collide_default for NEW manifolds (a host callback:
-// steps that have new candidate pairs take the slow path of edynhip_set_pair_filter). Multi-device worlds keep the default.
+// steps that have new candidate pairs take the slow path of edynhip_set_pair_filter; worlds over several devices: edynhip_world_set_pair_filter).
 using should_collide_func_t = bool (*)(const entt::registry &, entt::entity, entt::entity);
 /// collision groups / masks and exclusion lists, evaluated on the host (should_collide.cpp:11-57) - for predicates that extend the default
 inline bool should_collide_default(const entt::registry &registry, entt::entity first, entt::entity second) {
@@ -1171,9 +1172,9 @@ inline bool should_collide_default(const entt::registry &registry, entt::entity 
 inline void set_should_collide(entt::registry &registry, should_collide_func_t func) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     if (func == &should_collide_default) func = nullptr;   // the device's own test
-    if (func && s.multi()) throw stepper_error(EDYNHIP_ERR_UNSUPPORTED, "set_should_collide: a world over several devices (init_config::devices) keeps should_collide_default");
     s.should_collide = func; s.filter_registry = &registry;
     if (s.ctx) detail::check(s, edynhip_set_pair_filter(s.ctx, func ? &detail::pair_filter_trampoline : nullptr, &s));
+    if (s.world) detail::check(s, edynhip_world_set_pair_filter(s.world, func ? &detail::pair_filter_trampoline : nullptr, &s));   // global body indices = the shim's
 }
 
 // ---- util/exclude_collision.hpp:20-47

@@ -258,7 +258,8 @@ int edynhip_remove_collision_exclusion(edynhip_ctx *ctx, uint32_t body_a, uint32
  * in the reference. The predicate must be a function of the pair (the reference asks more often - also for pairs that have a
  * manifold or whose boxes then do not overlap - and in another order). edynhip_default_should_collide evaluates what the device would
  * have (collision groups / masks, exclusion lists) for callbacks that extend the default. filter = NULL restores the device test.
- * Costs one device-to-host copy and a stream synchronisation per step that has new candidates. Not available on edynhip_world_*. */
+ * Costs one device-to-host copy and a stream synchronisation per step that has new candidates. Worlds over several devices:
+ * edynhip_world_set_pair_filter (global body indices). */
 typedef int (*edynhip_pair_filter)(void *user, uint32_t body, uint32_t other);
 int edynhip_set_pair_filter(edynhip_ctx *ctx, edynhip_pair_filter filter, void *user);
 int edynhip_default_should_collide(edynhip_ctx *ctx, uint32_t body_a, uint32_t body_b);   /* 1 / 0, negative = error */
@@ -442,6 +443,12 @@ int edynhip_world_set_joints(edynhip_world *w, uint32_t n, const edynhip_joints 
 /* edynhip_set_joint_definition (generic = 0: params[16]) / edynhip_set_generic_definition (generic = 1: params[60]) by global joint index */
 int edynhip_world_set_joint_definition(edynhip_world *w, uint32_t joint, const float *frame_a9, const float *frame_b9, const float *params, int generic);
 int edynhip_world_exclude_collision(edynhip_world *w, uint32_t body_a, uint32_t body_b);
+/* settings.should_collide_func on a world over several devices (ABI 14): `filter(user, body, other)` is asked with GLOBAL body indices by
+ * whichever shard holds the candidate pair (see edynhip_set_pair_filter for when and how often); the shards step on their own host
+ * threads, the calls are serialised. May be set before or after the shards exist; filter = NULL restores the device test.
+ * edynhip_world_default_should_collide: collision groups / masks and exclusion lists of the scene, in global indices. */
+int edynhip_world_set_pair_filter(edynhip_world *w, edynhip_pair_filter filter, void *user);
+int edynhip_world_default_should_collide(edynhip_world *w, uint32_t body_a, uint32_t body_b);
 /* edyn::step_simulation on every shard, then the gather, the approach test and - when islands of different shards have met - the
  * re-partition. Returns when the state of the last step is in the world's arrays. */
 int edynhip_world_step(edynhip_world *w, uint32_t nsteps);

@@ -10,7 +10,7 @@ for WL in $WLS; do
   for REP in 1 2; do
     for B in base new; do
       if [ $B = base ]; then export EDYNHIP_LIB=$PWD/edyn_amd/libedynhip_base.so; else unset EDYNHIP_LIB; fi
-      timeout 600 python bench.py --workload $WL $A --north-star none --no-cpu-baseline > gpurun_out/$TAG/${WL}_${B}_$REP.json 2> gpurun_out/$TAG/${WL}_${B}_$REP.err
+      timeout 600 python bench.py --workload $WL $A --north-star none --other-arithmetic-steps 0 --no-cpu-baseline > gpurun_out/$TAG/${WL}_${B}_$REP.json 2> gpurun_out/$TAG/${WL}_${B}_$REP.err
       python - <<PY
 import json
 try:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer sweep over the dataflow kernels' launch knobs on one box: steps/s and solve ms of the default bench command per setting
-run() { env "$@" timeout 300 python bench.py --north-star none --no-cpu-baseline ${WLARGS:-} 2>/dev/null | python -c "
+run() { env "$@" timeout 300 python bench.py --north-star none --other-arithmetic-steps 0 --no-cpu-baseline ${WLARGS:-} 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().splitlines()[-1]); print('%-44s %.1f steps/s  solve %.3f ms  %s' % ('$*', j['value'], j['roofline']['solve_ms_per_step'], j['roofline']['kernel'][:22]))"; }
 run A=0

@@ -10,10 +10,10 @@ grep -a "free-running C2\|C2 free-running\|C3 full size" gpurun_out/${R}_pytest_
 timeout 900 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/${R}_bench_default.json
 for WL in pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k; do
   case $WL in islands256k) A="--steps 60 --warmup 10";; polyheap32k) A="--steps 100 --warmup 10";; *) A="";; esac
-  timeout 600 python bench.py --workload $WL $A --north-star none --no-cpu-baseline > gpurun_out/${R}_bench_$WL.json 2> gpurun_out/${R}_bench_$WL.err; echo "$WL rc=$?"; cut -c1-260 gpurun_out/${R}_bench_$WL.json
+  timeout 600 python bench.py --workload $WL $A --north-star none --other-arithmetic-steps 0 --no-cpu-baseline > gpurun_out/${R}_bench_$WL.json 2> gpurun_out/${R}_bench_$WL.err; echo "$WL rc=$?"; cut -c1-260 gpurun_out/${R}_bench_$WL.json
 done
 timeout 2400 bash scripts/profile_round.sh $R pile32k pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k > gpurun_out/${R}_profile.log 2>&1; echo "profile rc=$?"
-EDYNHIP_DF_TRACE=/tmp/df.bin EDYNHIP_DFP_TRACE=/tmp/dfp.bin EDYNHIP_DF_TRACE_STEP=200 timeout 200 python bench.py --steps 150 --warmup 100 --no-cpu-baseline --north-star none > /dev/null 2>&1
+EDYNHIP_DF_TRACE=/tmp/df.bin EDYNHIP_DFP_TRACE=/tmp/dfp.bin EDYNHIP_DF_TRACE_STEP=200 timeout 200 python bench.py --steps 150 --warmup 100 --no-cpu-baseline --north-star none --other-arithmetic-steps 0 > /dev/null 2>&1
 python scripts/df_trace.py /tmp/df.bin > gpurun_out/${R}_dftrace_velocity_pile32k.txt 2>&1
 python scripts/df_trace.py /tmp/dfp.bin > gpurun_out/${R}_dftrace_position_pile32k.txt 2>&1
 head -12 gpurun_out/${R}_kernel_stats_pile32k.txt | cut -c1-118; cat gpurun_out/${R}_timeline_pile32k.txt | tail -36

@@ -10,6 +10,6 @@ fi
 timeout 900 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; echo "bench rc=$?"; cat gpurun_out/${R}_bench_default.json | cut -c1-1500
 for WL in pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k; do
   case $WL in islands256k) A="--steps 60 --warmup 10";; polyheap32k) A="--steps 100 --warmup 10";; *) A="";; esac
-  timeout 600 python bench.py --workload $WL $A --north-star none --no-cpu-baseline > gpurun_out/${R}_bench_$WL.json 2> gpurun_out/${R}_bench_$WL.err; echo "$WL rc=$?"; cut -c1-400 gpurun_out/${R}_bench_$WL.json
+  timeout 600 python bench.py --workload $WL $A --north-star none --other-arithmetic-steps 0 --no-cpu-baseline > gpurun_out/${R}_bench_$WL.json 2> gpurun_out/${R}_bench_$WL.err; echo "$WL rc=$?"; cut -c1-400 gpurun_out/${R}_bench_$WL.json
 done
 timeout 2400 bash scripts/profile_round.sh $R pile32k pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k > gpurun_out/${R}_profile.log 2>&1; echo "profile rc=$?"
