@@ -99,7 +99,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_world_step", "edynhip_world_get_state", "edynhip_world_get_partition", "edynhip_world_repartition",
            "edynhip_world_get_manifolds", "edynhip_world_get_stats", "edynhip_world_context", "edynhip_partition_islands",
            "edynhip_island_boxes_overlap", "edynhip_get_island_boxes",
-           "edynhip_world_set_pair_filter", "edynhip_world_default_should_collide"]
+           "edynhip_world_set_pair_filter", "edynhip_world_default_should_collide", "edynhip_get_sleep_timers", "edynhip_set_sleep_timers"]
 
 _lib = None
 
@@ -163,6 +163,8 @@ def lib():
         L.edynhip_default_should_collide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.edynhip_set_joint_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_asleep.argtypes = [C.c_void_p, C.c_void_p]
+        L.edynhip_get_sleep_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.edynhip_set_sleep_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         L.edynhip_measure_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.edynhip_create_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_convex_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]

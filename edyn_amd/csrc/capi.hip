@@ -965,6 +965,34 @@ int edynhip_set_asleep(edynhip_ctx *c, const uint8_t *asleep) {
     c->force_islands = true;
     return EDYNHIP_OK;
 }
+int edynhip_get_sleep_timers(edynhip_ctx *c, uint32_t *island_label, double *since, double *clock) {
+    if (!c || !island_label || !since || !clock) return EDYNHIP_ERR_INVALID;
+    *clock = c->sim_clock;
+    const uint32_t n = c->b.n;
+    if (n == 0) return EDYNHIP_OK;
+    if (!c->sleeping) { for (uint32_t i = 0; i < n; ++i) { island_label[i] = i; since[i] = -1.0; } return EDYNHIP_OK; }
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_HIP(c, hipMemcpyAsync(island_label, c->b.island, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipMemcpyAsync(since, c->sleep_since, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    return EDYNHIP_OK;
+}
+int edynhip_set_sleep_timers(edynhip_ctx *c, const uint32_t *island_label, const double *since, double clock) {
+    if (!c || !island_label || !since) return EDYNHIP_ERR_INVALID;
+    const uint32_t n = c->b.n;
+    if (!c->sleeping || n == 0) return EDYNHIP_OK;
+    for (uint32_t i = 0; i < n; ++i) if (island_label[i] >= n) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_set_sleep_timers: island label out of range");
+    EH_HIP(c, hipSetDevice(c->device));
+    // The labels become "last step's labels": the next step's relabel (forced below) starts from them, so its merge / split rules
+    // (k_sleep_sizes / k_sleep_carry, k_cc_flatten's split marks) see the islands the timers belong to.
+    EH_HIP(c, hipMemcpyAsync(c->b.island, island_label, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipMemcpyAsync(c->sleep_since, since, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    c->sim_clock = clock;
+    c->sleep_prev_n = n;
+    c->force_islands = true;
+    return EDYNHIP_OK;
+}
 int edynhip_get_joint_slot_impulses(edynhip_ctx *c, float *out) {
     if (!c || !out) return EDYNHIP_ERR_INVALID;
     const uint32_t total = (uint32_t)c->host_joints.size();

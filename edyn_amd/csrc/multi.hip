@@ -166,6 +166,7 @@ struct Shard {
     std::string err;
     // collected for a re-partition
     std::vector<uint32_t> labels; std::vector<float> aabb; std::vector<edynhip_manifold> manifolds; std::vector<float> imp24, imp10; std::vector<uint8_t> asleep;
+    std::vector<uint32_t> sleep_label; std::vector<double> sleep_since; double sleep_clock = 0;
 };
 
 class Pool {   // one persistent host thread per shard (a context is single-threaded; its step spins on its own counters)
@@ -284,6 +285,9 @@ struct Carry {   // what travels with the islands through a re-partition (global
     std::vector<edynhip_manifold> manifolds;   // canonical order
     std::vector<float> imp24, angle;           // per global joint
     std::vector<uint8_t> asleep;               // per global body
+    std::vector<uint32_t> label;               // per global body: its island (global index of the island's lowest body) - with
+    std::vector<double> since;                 // ... the islands' sleep timers by that label, and the clock they are measured on (ADVICE r04:
+    double clock = 0;                          //     every re-partition used to restart every island's timer)
     bool any = false;
 };
 
@@ -397,6 +401,17 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
             auto as = take(carry.asleep, s.local_ids, 1);
             SH_TRY(s, edynhip_set_asleep(s.ctx, as.data()));
         }
+        if (!carry.label.empty()) {   // the islands' sleep timers go on where they were (edynhip_set_sleep_timers), in local indices
+            std::vector<uint32_t> lab(nl);
+            std::vector<double> since(nl, -1.0);
+            for (uint32_t l = 0; l < nl; ++l) {
+                const uint32_t g = s.local_ids[l], root = carry.label[g];
+                const int32_t lr = w->rank_of[g] == (int32_t)r && root < n ? s.to_local[root] : -1;   // an island lives on one shard: its root is local
+                lab[l] = lr >= 0 ? (uint32_t)lr : l;
+                if (lr >= 0 && root == g) since[l] = carry.since[g];
+            }
+            SH_TRY(s, edynhip_set_sleep_timers(s.ctx, lab.data(), since.data(), carry.clock));
+        }
     }
     // gather and monitor buffers
     SH_HIP(s, hipMalloc((void **)&s.pack_dev, (size_t)std::max<uint32_t>(nl, 1) * 13 * sizeof(float)));
@@ -509,7 +524,11 @@ void collect_shard(edynhip_world *w, uint32_t r) {
         SH_TRY(s, edynhip_get_joint_slot_impulses(s.ctx, s.imp24.data()));
         SH_TRY(s, edynhip_get_joint_impulses(s.ctx, s.imp10.data()));
     }
-    if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) SH_TRY(s, edynhip_get_asleep(s.ctx, s.asleep.data()));
+    if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) {
+        SH_TRY(s, edynhip_get_asleep(s.ctx, s.asleep.data()));
+        s.sleep_label.assign(nl, 0); s.sleep_since.assign(nl, -1.0);
+        SH_TRY(s, edynhip_get_sleep_timers(s.ctx, s.sleep_label.data(), s.sleep_since.data(), &s.sleep_clock));
+    }
 }
 
 inline uint64_t canonical_key(const HostScene &sc, uint32_t a, uint32_t b) {   // (owner << 32) | other: the owner is the dynamic body, the higher index of two
@@ -557,15 +576,20 @@ int repartition(edynhip_world *w) {
     Carry carry;
     carry.any = true;
     if (sc.nj) { carry.imp24.assign((size_t)sc.nj * 24, 0.f); carry.angle.assign(sc.nj, 0.f); }
-    if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) carry.asleep.assign(n, 0);
+    if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) { carry.asleep.assign(n, 0); carry.label.resize(n); std::iota(carry.label.begin(), carry.label.end(), 0u); carry.since.assign(n, -1.0); }
     for (uint32_t r = 0; r < W; ++r) {
         Shard &s = w->shards[r];
+        if (!carry.label.empty() && !s.local_ids.empty()) carry.clock = std::max(carry.clock, s.sleep_clock);   // (every shard has taken the same steps)
         for (uint32_t l = 0; l < s.local_ids.size(); ++l) {
             const uint32_t g = s.local_ids[l];
             if (w->rank_of[g] != (int32_t)r) continue;
             labels[g] = s.local_ids[s.labels[l]];
             std::memcpy(&aabb[6 * (size_t)g], &s.aabb[6 * (size_t)l], 24);
             if (!carry.asleep.empty()) carry.asleep[g] = s.asleep[l];
+            if (!carry.label.empty() && s.sleep_label[l] < s.local_ids.size()) {
+                carry.label[g] = s.local_ids[s.sleep_label[l]];
+                if (s.sleep_label[l] == l) carry.since[g] = s.sleep_since[l];
+            }
         }
         for (const edynhip_manifold &m : s.manifolds) {   // weight = 1 + the contact points the body takes part in (balance the rows)
             const uint32_t a = s.local_ids[m.body[0]], b = s.local_ids[m.body[1]];

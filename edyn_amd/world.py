@@ -523,6 +523,19 @@ class World:
         ang = None if angles is None else np.ascontiguousarray(angles, np.float32).reshape(self.nj)
         self._check(self._L.edynhip_set_joint_warm_start(self._h, _ptr(imp), _ptr(ang) if ang is not None else None))
 
+    def get_sleep_timers(self):
+        """(island label per body, time stamp since which each island - by label - meets the sleep thresholds, clock of the last step):
+        edynhip_get_sleep_timers."""
+        lab = np.zeros(self.n, np.uint32); since = np.zeros(self.n, np.float64); clock = C.c_double(0)
+        self._check(self._L.edynhip_get_sleep_timers(self._h, _ptr(lab), _ptr(since), C.byref(clock)))
+        return lab, since, clock.value
+
+    def set_sleep_timers(self, labels, since, clock):
+        """Continue another world's island sleep timers (edynhip_set_sleep_timers): after set_state / set_manifolds / set_asleep."""
+        lab = np.ascontiguousarray(labels, np.uint32); sn = np.ascontiguousarray(since, np.float64)
+        assert len(lab) == self.n and len(sn) == self.n
+        self._check(self._L.edynhip_set_sleep_timers(self._h, _ptr(lab), _ptr(sn), float(clock)))
+
     def set_asleep(self, flags):
         """Sleeping tags by body (edynhip_set_asleep): sleeping bodies get zero velocities."""
         f = np.ascontiguousarray(np.asarray(flags).astype(np.uint8))

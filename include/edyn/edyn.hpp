@@ -533,6 +533,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     std::vector<edynhip_manifold> carried;   // contact state carried over a capacity growth (indices are stable)
     std::vector<float> carried_impulses, carried_angles;   // joints: 24 applied-impulse slots + the tracked angle, by joint index
     std::vector<uint8_t> carried_asleep;                   // sleeping tags by body index
+    std::vector<uint32_t> carried_labels; std::vector<double> carried_since; double carried_clock = 0;   // island labels + sleep timers by label + their clock
     bool regrown = false;
     if (!s.ctx || total > s.capacity || nj > s.joint_capacity || s.recreate) {
         s.recreate = false;
@@ -571,6 +572,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             if (s.cfg.island_sleeping && s.uploaded_bodies) {
                 carried_asleep.assign(s.uploaded_bodies, 0);
                 check(s, edynhip_get_asleep(s.ctx, carried_asleep.data()));
+                carried_labels.assign(s.uploaded_bodies, 0); carried_since.assign(s.uploaded_bodies, -1.0);   // the islands' sleep timers go on in the new context
+                check(s, edynhip_get_sleep_timers(s.ctx, carried_labels.data(), carried_since.data(), &carried_clock));
             }
             edynhip_destroy(s.ctx); s.ctx = nullptr;
             s.exclusions_uploaded = 0;
@@ -669,6 +672,10 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     if (regrown && !carried_asleep.empty()) {
         carried_asleep.resize(total, 0);
         check(s, edynhip_set_asleep(s.ctx, carried_asleep.data()));
+        const uint32_t had = (uint32_t)carried_labels.size();
+        carried_labels.resize(total); carried_since.resize(total, -1.0);
+        for (uint32_t i = had; i < total; ++i) carried_labels[i] = i;   // bodies made since: islands of their own, no timer
+        check(s, edynhip_set_sleep_timers(s.ctx, carried_labels.data(), carried_since.data(), carried_clock));
     }
     s.scene_dirty = false;
     if (first == 0) s.state_dirty = false;

@@ -379,6 +379,14 @@ int edynhip_get_stats(edynhip_ctx *ctx, edynhip_stats *out);
  * edynhip_get_asleep returns them; sleeping bodies get zero velocities, island timers of awake islands restart). */
 int edynhip_set_joint_warm_start(edynhip_ctx *ctx, const float *impulses24, const float *angles);
 int edynhip_set_asleep(edynhip_ctx *ctx, const uint8_t *asleep);
+/* ... and the island sleep TIMERS (island::sleep_timestamp, island_manager.cpp:605-623; ABI 14): island_label[n] = every body's island (the
+ * lowest body index of the island, as edynhip_get_derived returns it), since[n] = by island label, the time stamp at which the island first
+ * met the sleep thresholds (negative or NaN: no timer running; entries that are not labels are ignored), clock = the stamp of the last step.
+ * A context that receives them (after its bodies, manifolds and sleeping tags) continues the timers where the other context left them - its
+ * first step relabels from the given labels, so an island that merges or splits in that very step follows the rules of a running world -
+ * instead of starting every timer again. A no-op without EDYNHIP_FLAG_SLEEPING. */
+int edynhip_get_sleep_timers(edynhip_ctx *ctx, uint32_t *island_label, double *since, double *clock);
+int edynhip_set_sleep_timers(edynhip_ctx *ctx, const uint32_t *island_label, const double *since, double clock);
 
 uint32_t edynhip_abi_version(void);
 

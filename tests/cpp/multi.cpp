@@ -4,6 +4,7 @@
 // re-partition. Positions, orientations and velocities must be bit-equal after every step. Two shards on one physical GPU
 // (the reference's island parallelism: src/edyn/dynamics/solver.cpp:408-428).
 #include <edynhip.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -154,9 +155,65 @@ static int filtered_piles() {
     return 0;
 }
 
+// Island sleeping on a world over several devices: a re-partition rebuilds every shard, and the islands' sleep timers
+// (island::sleep_timestamp) travel with them (edynhip_get / set_sleep_timers) - four piles settle and fall asleep at the same steps as in ONE
+// context although the shards are rebuilt four times on the way (each rebuild used to start every timer again: nothing fell asleep while
+// re-partitions came more often than island_time_to_sleep).
+static int sleeping_piles() {
+    edynhip_world *world = nullptr;
+    edynhip_ctx *one = nullptr;
+    Scene sc;
+    sc.add(EDYNHIP_KIND_STATIC, EDYNHIP_SHAPE_PLANE, 0, 0, 0, 0, 1, 0, 0);
+    for (int site = 0; site < 4; ++site)
+        for (int k = 0; k < 27; ++k) {
+            const int i = k % 3, j = (k / 3) % 3, l = k / 9;
+            const float off = (j & 1) ? 0.5f : 0.0f;
+            sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_BOX, 8.0f * site + 1.02f * i + off + 0.003f * k, 0.505f + 1.005f * j, 1.02f * l + off, 0.5f, 0.5f, 0.5f, 0);
+        }
+    std::fill(sc.nosleep.begin(), sc.nosleep.end(), (uint8_t)0);
+    const uint32_t n = sc.n();
+    edynhip_config cfg{};
+    cfg.device = 0; cfg.max_bodies = n + 16; cfg.fixed_dt = 1.0f / 60; cfg.num_velocity_iterations = 10; cfg.num_position_iterations = 3;
+    cfg.gravity[1] = -9.8f; cfg.flags = EDYNHIP_FLAG_SLEEPING;
+    int status = 0;
+    one = edynhip_create(&cfg, &status);
+    REQUIRE(one != nullptr);
+    const edynhip_bodies b = sc.view();
+    REQUIRE(edynhip_set_bodies(one, n, &b) == EDYNHIP_OK);
+    const int32_t devices[2] = {0, 0};
+    cfg.max_bodies = 0;
+    world = edynhip_world_create(&cfg, devices, 2, &status);
+    REQUIRE(world != nullptr);
+    REQUIRE(edynhip_world_set_bodies(world, n, &b) == EDYNHIP_OK);
+    std::vector<float> p1(3 * n), p2(3 * n), v1(3 * n), v2(3 * n), w1(3 * n), w2(3 * n);
+    std::vector<uint8_t> asleep(n);
+    int first_sleep = -1, all_asleep = -1;
+    for (int step = 0; step < 480; ++step) {
+        if (step == 100 || step == 180 || step == 250 || step == 330) REQUIRE(edynhip_world_repartition(world) == EDYNHIP_OK);
+        REQUIRE(edynhip_step(one, 1) == EDYNHIP_OK && edynhip_world_step(world, 1) == EDYNHIP_OK);
+        REQUIRE(edynhip_get_state(one, p1.data(), nullptr, v1.data(), w1.data()) == EDYNHIP_OK);
+        REQUIRE(edynhip_world_get_state(world, p2.data(), nullptr, v2.data(), w2.data()) == EDYNHIP_OK);
+        if (std::memcmp(p1.data(), p2.data(), p1.size() * 4) || std::memcmp(v1.data(), v2.data(), v1.size() * 4) || std::memcmp(w1.data(), w2.data(), w1.size() * 4)) {
+            std::printf("FAILED: sleeping piles: the sharded world left the single context's trajectory at step %d (first sleep in the single context at step %d)\n", step, first_sleep);
+            return 1;
+        }
+        REQUIRE(edynhip_get_asleep(one, asleep.data()) == EDYNHIP_OK);
+        uint32_t count = 0;
+        for (uint32_t i = 1; i < n; ++i) count += asleep[i];
+        if (count && first_sleep < 0) first_sleep = step;
+        if (count == n - 1 && all_asleep < 0) all_asleep = step;
+    }
+    REQUIRE(first_sleep > 130 && all_asleep > 0);   // the piles did fall asleep - later than one island_time_to_sleep (120 steps) after the start
+    std::printf("sleeping piles: first island asleep at step %d, all asleep at step %d, four re-partitions on the way\n", first_sleep, all_asleep);
+    edynhip_world_destroy(world);
+    edynhip_destroy(one);
+    return 0;
+}
+
 int main() {
     if (jointed_pairs() != 0) return 1;
     if (filtered_piles() != 0) return 1;
+    if (sleeping_piles() != 0) return 1;
     edynhip_world *world = nullptr;
     edynhip_ctx *one = nullptr;
     Scene sc;

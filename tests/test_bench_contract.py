@@ -23,6 +23,9 @@ def test_bench_json_contract():
     assert d["unit"] == "steps/sec" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
     assert d["config"]["settle_steps"] == 20 and d["config"]["colours"] >= 1 and "parity" in d["config"]
+    # the headline is quoted on the reference's contact arithmetic; the opt-in forms are separate legs (default workload only)
+    a = d["config"]["arithmetic"]
+    assert a["mode"] == "reference" and list(a["steps_per_sec"]) == ["reference"] and abs(a["steps_per_sec"]["reference"] - d["value"]) < 1e-9
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     if r["traffic"] is None:   # no kept counter profile for this workload / schedule (pile512 has none): nothing is claimed
@@ -67,3 +70,32 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "pile512", "--steps", "8", "--warmup", "4",
            "--north-star", "islands4k", "--north-star-steps", "6"]
     _two_rank_checks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
+
+
+def test_bench_reports_every_contact_arithmetic_beside_the_headline():
+    """the line carries steps/s of the headline workload in all three contact arithmetics - the default (the
+    reference's operations) is `value`, the two opt-in forms are measured beside it with what each costs in parity."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pile512", "--steps", "10", "--warmup", "5", "--north-star", "none",
+                          "--other-arithmetic-steps", "10", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    a = d["config"]["arithmetic"]
+    assert a["mode"] == "reference" and set(a["steps_per_sec"]) == {"reference", "fused_velocity_rows", "fused_rows_block_position"}
+    assert all(v > 0 for v in a["steps_per_sec"].values()) and a["steps_per_sec"]["reference"] == d["value"]
+    assert "NOT met" in a["other_modes"]["fused_rows_block_position"] and "zero error" in a["parity"]
+
+
+def test_bench_eight_ranks_on_one_gpu_functional():
+    """the north_star leg at the world size it is meant for - 8 ranks, the islands sharded in contiguous site blocks, the
+    per-step pack + all-gather of every rank's state - as a functional run on the one GPU of the test box (ranks share cuda:0, the gather goes
+    through gloo). The 8-GPU RCCL measurement itself is the driver's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EDYN_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "islands4k", "--steps", "6", "--warmup", "2",
+           "--north-star", "islands4k", "--north-star-steps", "6"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["finite"] is True
+    ns = d["north_star"]
+    assert ns["n_gpus"] == 8 and ns["scaling"] == "strong" and ns["bodies"] == 64 * 64 + 1 and ns["bodies_this_rank"] == 8 * 64 + 1 and ns["finite"] is True
