@@ -504,15 +504,26 @@ int approach_check(edynhip_world *w, bool &close, bool per_body = false) {
     return EDYNHIP_OK;
 }
 
-// everything the islands carry, from every shard, in global indices
-void collect_shard(edynhip_world *w, uint32_t r) {
+// What the islands carry, per shard, in two parts: LIGHT - island labels, AABBs, sleeping tags and timers (28-45 bytes per body: what a
+// re-partition decides on) - and HEAVY - the manifolds with their warm-start impulses and the joints' applied impulses (336 bytes per
+// manifold: only worth reading from the shards that are rebuilt).
+void collect_shard(edynhip_world *w, uint32_t r, bool light, bool heavy) {
     Shard &s = w->shards[r];
     if (s.rc != EDYNHIP_OK) return;
     const uint32_t nl = (uint32_t)s.local_ids.size();
-    s.labels.assign(nl, 0); s.aabb.assign((size_t)nl * 6, 0.f); s.manifolds.clear(); s.imp24.clear(); s.imp10.clear(); s.asleep.assign(nl, 0);
+    if (light) { s.labels.assign(nl, 0); s.aabb.assign((size_t)nl * 6, 0.f); s.asleep.assign(nl, 0); }
+    s.manifolds.clear(); s.imp24.clear(); s.imp10.clear();
     if (nl == 0) return;
     SH_HIP(s, hipSetDevice(s.device));
-    SH_TRY(s, edynhip_get_derived(s.ctx, s.aabb.data(), nullptr, s.labels.data()));
+    if (light) {
+        SH_TRY(s, edynhip_get_derived(s.ctx, s.aabb.data(), nullptr, s.labels.data()));
+        if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) {
+            SH_TRY(s, edynhip_get_asleep(s.ctx, s.asleep.data()));
+            s.sleep_label.assign(nl, 0); s.sleep_since.assign(nl, -1.0);
+            SH_TRY(s, edynhip_get_sleep_timers(s.ctx, s.sleep_label.data(), s.sleep_since.data(), &s.sleep_clock));
+        }
+    }
+    if (!heavy) return;
     uint32_t nm = 0;
     SH_TRY(s, edynhip_num_manifolds(s.ctx, &nm));
     s.manifolds.resize(nm);
@@ -523,11 +534,6 @@ void collect_shard(edynhip_world *w, uint32_t r) {
         s.imp24.assign((size_t)njl * 24, 0.f); s.imp10.assign((size_t)njl * 10, 0.f);
         SH_TRY(s, edynhip_get_joint_slot_impulses(s.ctx, s.imp24.data()));
         SH_TRY(s, edynhip_get_joint_impulses(s.ctx, s.imp10.data()));
-    }
-    if (w->cfg.flags & EDYNHIP_FLAG_SLEEPING) {
-        SH_TRY(s, edynhip_get_asleep(s.ctx, s.asleep.data()));
-        s.sleep_label.assign(nl, 0); s.sleep_since.assign(nl, -1.0);
-        SH_TRY(s, edynhip_get_sleep_timers(s.ctx, s.sleep_label.data(), s.sleep_since.data(), &s.sleep_clock));
     }
 }
 
@@ -553,8 +559,9 @@ void merge_manifolds(edynhip_world *w, std::vector<edynhip_manifold> &out) {
     });
 }
 
-int rebuild(edynhip_world *w, const Carry &carry, bool from_state) {
-    w->pool->run([&](uint32_t r) { build_shard(w, r, carry, from_state); });
+// `only` (or nullptr = all): the shards to build; the others keep their contexts - their bodies, and therefore their local indices, are unchanged.
+int rebuild(edynhip_world *w, const Carry &carry, bool from_state, const std::vector<uint8_t> *only = nullptr) {
+    w->pool->run([&](uint32_t r) { if (!only || (*only)[r]) build_shard(w, r, carry, from_state); });
     EH_TRY(shard_error(w));
     w->pool->run([w](uint32_t r) { gather_shard(w, r, false); });
     EH_TRY(shard_error(w));
@@ -564,10 +571,17 @@ int rebuild(edynhip_world *w, const Carry &carry, bool from_state) {
     return approach_check(w, close, true);   // a fresh partition keeps close islands together: sets the budget, records the reference boxes
 }
 
-int repartition(edynhip_world *w) {
+// Re-partition. FULL (edynhip_world_repartition, on request): everything the islands carry is read from every shard, the islands are
+// balanced afresh (longest processing time first over their contact rows) and every shard is rebuilt. STICKY (the approach check found
+// islands of different shards within the creation margin of each other - what a step does by itself): the islands stay where they are, a
+// group of islands that has to live together moves to the shard that already holds most of it, and only the shards that gain or lose a
+// body are read in full and rebuilt - the cost of an island meeting its neighbour follows the two shards involved, not the world
+// (round 5: a collapsing 262 144-box scene re-partitioned 18 times in 160 steps at 8 s each when every meeting rebuilt all shards from an
+// unrelated partition; scripts/multi_overhead.py).
+int repartition(edynhip_world *w, bool sticky) {
     const HostScene &sc = w->scene;
     const uint32_t n = sc.n, W = (uint32_t)w->shards.size();
-    w->pool->run([w](uint32_t r) { collect_shard(w, r); });
+    w->pool->run([w, sticky](uint32_t r) { collect_shard(w, r, true, !sticky); });
     EH_TRY(shard_error(w));
     std::vector<uint32_t> labels(n);
     std::iota(labels.begin(), labels.end(), 0u);
@@ -591,18 +605,26 @@ int repartition(edynhip_world *w) {
                 if (s.sleep_label[l] == l) carry.since[g] = s.sleep_since[l];
             }
         }
-        for (const edynhip_manifold &m : s.manifolds) {   // weight = 1 + the contact points the body takes part in (balance the rows)
-            const uint32_t a = s.local_ids[m.body[0]], b = s.local_ids[m.body[1]];
-            if (w->rank_of[a] == (int32_t)r) weights[a] += m.num_points;
-            if (w->rank_of[b] == (int32_t)r) weights[b] += m.num_points;
-        }
-        for (uint32_t lj = 0; lj < s.local_joints.size(); ++lj) {
-            const uint32_t g = s.local_joints[lj];
-            std::memcpy(&carry.imp24[(size_t)g * 24], &s.imp24[(size_t)lj * 24], 24 * sizeof(float));
-            carry.angle[g] = s.imp10[(size_t)lj * 10 + 9];
-        }
     }
-    merge_manifolds(w, carry.manifolds);
+    // what travels with the bodies of the shards read in full (all of them / later: the ones that change)
+    auto take_heavy = [&](const std::vector<uint8_t> *only) {
+        for (uint32_t r = 0; r < W; ++r) {
+            Shard &s = w->shards[r];
+            if (only && !(*only)[r]) { s.manifolds.clear(); continue; }
+            for (const edynhip_manifold &m : s.manifolds) {   // weight = 1 + the contact points the body takes part in (balance the rows)
+                const uint32_t a = s.local_ids[m.body[0]], b = s.local_ids[m.body[1]];
+                if (w->rank_of[a] == (int32_t)r) weights[a] += m.num_points;
+                if (w->rank_of[b] == (int32_t)r) weights[b] += m.num_points;
+            }
+            for (uint32_t lj = 0; lj < s.local_joints.size() && !s.imp24.empty(); ++lj) {
+                const uint32_t g = s.local_joints[lj];
+                std::memcpy(&carry.imp24[(size_t)g * 24], &s.imp24[(size_t)lj * 24], 24 * sizeof(float));
+                carry.angle[g] = s.imp10[(size_t)lj * 10 + 9];
+            }
+        }
+        merge_manifolds(w, carry.manifolds);
+    };
+    if (!sticky) take_heavy(nullptr);
     // islands whose boxes overlap (grown by the creation margin) must end up on one shard: weld them - all such pairs, also those the
     // last partition had co-located (they may still be separate islands, and the partitioner would be free to split them)
     std::vector<IslandBox> boxes;
@@ -622,10 +644,10 @@ int repartition(edynhip_world *w) {
     std::iota(parent.begin(), parent.end(), 0u);
     auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     // The device labels are those of the shards' LAST island stage: a shard that has not stepped since it was built (a re-partition
-    // before the first step, or right after a step that re-partitioned by itself) still has identity labels. The edges the island
-    // manager connects bodies through are known on the host - every joint and every carried manifold between two dynamic bodies
+    // before the first step, or right after a step that re-partitioned by itself) still has the labels it was built with. The edges the
+    // island manager connects bodies through are known on the host - every joint and every carried manifold between two dynamic bodies
     // (island_manager.cpp:117-247) - so they are united here, whatever the labels say: cheap, and a joint or a carried manifold can
-    // never end up with its bodies on two shards.
+    // never end up with its bodies on two shards. (A sticky re-partition follows a step of every shard: labels are current.)
     auto unite = [&](uint32_t a, uint32_t b) {
         if (sc.kind[a] != EDYNHIP_KIND_DYNAMIC || sc.kind[b] != EDYNHIP_KIND_DYNAMIC) return;
         const uint32_t ra = find(labels[a]), rb = find(labels[b]);
@@ -639,10 +661,42 @@ int repartition(edynhip_world *w) {
     });
     std::vector<uint32_t> welded(n);
     for (uint32_t i = 0; i < n; ++i) welded[i] = find(labels[i]);
-    w->rank_of.assign(n, -1);
-    partition_islands(n, welded.data(), sc.kind.data(), weights.data(), W, w->rank_of.data());
     ++w->stats.repartitions;
-    return rebuild(w, carry, true);
+    if (!sticky) {
+        w->rank_of.assign(n, -1);
+        partition_islands(n, welded.data(), sc.kind.data(), weights.data(), W, w->rank_of.data());
+        return rebuild(w, carry, true);
+    }
+    // sticky: a group that spans shards goes to the shard holding most of its bodies (ties: the lower shard); everybody else stays
+    std::vector<int32_t> next = w->rank_of;
+    {
+        std::vector<uint32_t> order;
+        for (uint32_t i = 0; i < n; ++i) if (sc.kind[i] == EDYNHIP_KIND_DYNAMIC) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return welded[a] != welded[b] ? welded[a] < welded[b] : a < b; });
+        std::vector<uint32_t> count(W);
+        for (size_t a = 0; a < order.size();) {
+            size_t e = a;
+            std::fill(count.begin(), count.end(), 0u);
+            while (e < order.size() && welded[order[e]] == welded[order[a]]) { ++count[(uint32_t)w->rank_of[order[e]]]; ++e; }
+            uint32_t target = 0, spans = 0;
+            for (uint32_t r = 0; r < W; ++r) { if (count[r]) ++spans; if (count[r] > count[target]) target = r; }
+            if (spans > 1) for (size_t k = a; k < e; ++k) next[order[k]] = (int32_t)target;
+            a = e;
+        }
+    }
+    std::vector<uint8_t> changed(W, 0);
+    for (uint32_t i = 0; i < n; ++i) if (next[i] != w->rank_of[i]) { changed[(uint32_t)next[i]] = 1; changed[(uint32_t)w->rank_of[i]] = 1; }
+    if (std::none_of(changed.begin(), changed.end(), [](uint8_t c) { return c != 0; })) {
+        // nothing has to move (the close islands already share a shard): only the budget is taken again
+        bool close = false;
+        EH_TRY(approach_check(w, close, true));
+        return EDYNHIP_OK;
+    }
+    w->pool->run([w, &changed](uint32_t r) { if (changed[r]) collect_shard(w, r, false, true); });
+    EH_TRY(shard_error(w));
+    take_heavy(&changed);
+    w->rank_of = next;
+    return rebuild(w, carry, true, &changed);
 }
 
 int ensure_built(edynhip_world *w) {
@@ -887,7 +941,7 @@ int edynhip_world_step(edynhip_world *w, uint32_t nsteps) {
         if (2 * growth < w->budget) continue;   // nobody has moved far enough out of the boxes of the last check
         bool close = false;
         EH_TRY(approach_check(w, close));
-        if (close) EH_TRY(repartition(w));
+        if (close) EH_TRY(repartition(w, true));
     }
     return EDYNHIP_OK;
 }
@@ -895,7 +949,7 @@ int edynhip_world_step(edynhip_world *w, uint32_t nsteps) {
 int edynhip_world_repartition(edynhip_world *w) {
     if (!w) return EDYNHIP_ERR_INVALID;
     EH_TRY(ensure_built(w));
-    return repartition(w);
+    return repartition(w, false);
 }
 
 int edynhip_world_get_state(edynhip_world *w, float *pos, float *orn, float *linvel, float *angvel) {
@@ -919,7 +973,7 @@ int edynhip_world_get_partition(edynhip_world *w, int32_t *rank_of) {
 int edynhip_world_get_manifolds(edynhip_world *w, edynhip_manifold *out, uint32_t capacity, uint32_t *n) {
     if (!w || !n) return EDYNHIP_ERR_INVALID;
     EH_TRY(ensure_built(w));
-    w->pool->run([w](uint32_t r) { collect_shard(w, r); });
+    w->pool->run([w](uint32_t r) { collect_shard(w, r, false, true); });
     EH_TRY(shard_error(w));
     std::vector<edynhip_manifold> all;
     merge_manifolds(w, all);

@@ -19,22 +19,30 @@ cfg = edyn_amd.init_config(num_solver_velocity_iterations=10, num_solver_positio
 settle = 120
 
 
-def timed(step, sync):
+def timed(step, sync, stats=None):
+    """per-step wall times of `steps` steps after the settle; with `stats`: the steps in which the world re-partitioned are told apart"""
     step(settle); sync()
-    t0 = time.perf_counter(); step(steps); sync()
-    return 1e3 * (time.perf_counter() - t0) / steps
+    plain, repart = [], []
+    for _ in range(steps):
+        before = stats()["repartitions"] if stats else 0
+        t0 = time.perf_counter(); step(1); sync()
+        dt = 1e3 * (time.perf_counter() - t0)
+        (repart if stats and stats()["repartitions"] != before else plain).append(dt)
+    return plain, repart
 
 
 one = edyn_amd.World(cfg); one.set_scene(scene)
-t_one = timed(one.step_simulation, lambda: one.get_state())
+t_one, _ = timed(one.step_simulation, lambda: one.get_state())
 p_one = one.get_state()[0]
 del one
 mw = edyn_amd.MultiWorld(cfg, devices=[0] * shards); mw.set_scene(scene)
-t_multi = timed(mw.step_simulation, lambda: None)   # edynhip_world_step returns with the state gathered
+t_multi, t_repart = timed(mw.step_simulation, lambda: mw.get_state(), mw.get_stats)   # edynhip_world_step returns with the state gathered
 same = bool(np.array_equal(mw.get_state()[0], p_one))
 st = mw.get_stats()
-# the same shards stepped WITHOUT the world (one context per shard, no gather, no pool): what the GPU work alone costs when it is cut into S pieces
-print(json.dumps({"workload": wl, "bodies": len(scene["kind"]), "shards_on_one_gpu": shards, "steps": steps,
-                  "single_context_ms_per_step": t_one, "world_ms_per_step": t_multi, "difference_us_per_step": 1e3 * (t_multi - t_one),
-                  "bit_identical_to_single_context": same, "approach_checks": st["approach_checks"], "repartitions": st["repartitions"],
+med = lambda v: float(np.median(v)) if len(v) else None
+print(json.dumps({"workload": wl, "bodies": len(scene["kind"]), "shards_on_one_gpu": shards, "settle_steps": settle, "timed_steps": steps,
+                  "single_context_ms_per_step_median_incl_state_readback": med(t_one), "world_ms_per_step_median_without_repartition": med(t_multi),
+                  "difference_us_per_step": 1e3 * (med(t_multi) - med(t_one)) if t_multi else None,
+                  "steps_with_a_repartition": len(t_repart), "ms_per_repartitioning_step_median": med(t_repart),
+                  "bit_identical_to_single_context": same, "approach_checks_total": st["approach_checks"], "repartitions_total": st["repartitions"],
                   "bodies_per_shard": st["bodies_per_shard"]}))

@@ -9,7 +9,7 @@ def _rotate(q, v):
     return v + w * t + np.cross(u, t)
 
 
-def normal_row_residual(state, manifolds):
+def normal_row_residual(state, manifolds, rest_speed=0.05):
     """The solver residual of SURVEY section 7 hard-part 1: |J v - rhs| of the ACTIVE normal rows after the last velocity iteration.
 
     A contact's normal row asks for J (v + dv) = -(error erp) with J = {n, rA x n, -n, -(rB x n)} (contact_constraint.cpp:15-56,
@@ -17,11 +17,14 @@ def normal_row_residual(state, manifolds):
     SURVEY 8(g)(3)), so what the unconverged Gauss-Seidel sweep leaves behind is the relative normal velocity of the two contact points at
     the end of the step, n . ((vA + wA x rA) - (vB + wB x rB)) - evaluated for every point whose row is active (applied normal impulse > 0) and
     whose distance is <= 0, from the post-step state (the lever arms move by O(dt |v|) during the step: the same on every side).
-    Returns (max, mean, count) in m/s."""
+    Returns (max over the rows whose two bodies are at rest, mean over all active rows, count, 99th percentile, max over all active rows)
+    in m/s. The unrestricted maximum is an extreme statistic of a collapsing scene - the contact a faller has just landed on - like the
+    deepest penetration (penetration_stats); comparisons between steppers use the resting-set maximum, the percentile and the mean."""
     pos, orn, v, w = (np.asarray(a) for a in state)
     v, w = v.astype(np.float64), w.astype(np.float64)
+    slow = (np.linalg.norm(v, axis=1) <= rest_speed) & (np.linalg.norm(w, axis=1) <= 2.0 * rest_speed)   # the same surface speed at half a box
     m = manifolds
-    out = []
+    out, rest = [], []
     for k in range(4):
         sel = m["num_points"] > k
         if not sel.any():
@@ -33,9 +36,12 @@ def normal_row_residual(state, manifolds):
         rA, rB = _rotate(orn[a], pt["pivotA"][sel, k].astype(np.float64)), _rotate(orn[b], pt["pivotB"][sel, k].astype(np.float64))
         vn = ((v[a] + np.cross(w[a], rA) - v[b] - np.cross(w[b], rB)) * n).sum(axis=1)
         act = (lam > 0) & (dist <= 0)
-        out.append(np.abs(vn[act]))
+        out.append(np.abs(vn[act])); rest.append(np.abs(vn[act & slow[a] & slow[b]]))
     r = np.concatenate(out) if out else np.zeros(0)
-    return (float(r.max()), float(r.mean()), int(len(r))) if len(r) else (0.0, 0.0, 0)
+    q = np.concatenate(rest) if rest else np.zeros(0)
+    if not len(r):
+        return 0.0, 0.0, 0, 0.0, 0.0
+    return (float(q.max()) if len(q) else 0.0), float(r.mean()), int(len(r)), float(np.percentile(r, 99)), float(r.max())
 
 
 def max_penetration(manifolds):

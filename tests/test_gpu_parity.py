@@ -1073,12 +1073,12 @@ def test_c2_300_steps_survey_invariants_device_and_reference_engine():
     # engine's residual - and the penetration of the pile as a distribution (99th percentile, mean) instead of its single deepest point,
     # which is a faller's transient on either side (tests/test_reference_engine.py::test_solver_residual_* takes both on the CPU)
     from invariants import normal_row_residual, penetration_stats
-    (gm_, ga_, gn_), (rm_, ra_, rn_) = normal_row_residual(g.get_state(), g.get_manifolds()), normal_row_residual(r.get_state(), r.get_manifolds())
+    (gm_, ga_, gn_, g99_, gx_), (rm_, ra_, rn_, r99_, rx_) = normal_row_residual(g.get_state(), g.get_manifolds()), normal_row_residual(r.get_state(), r.get_manifolds())
     (pg, pg99, pga), (pr, pr99, pra) = penetration_stats(g.get_manifolds()), penetration_stats(r.get_manifolds())
-    print(f"[figures] C2 step {T['steps']} solver residual |Jv - rhs| over active normal rows [device / engine]: max {gm_:.3e} / {rm_:.3e} m/s, mean {ga_:.3e} / {ra_:.3e} m/s "
-          f"({gn_} / {rn_} rows); penetration 99th percentile {pg99:.5f} / {pr99:.5f} m, mean {pga:.2e} / {pra:.2e} m, deepest {pg:.4f} / {pr:.4f} m")
+    print(f"[figures] C2 step {T['steps']} solver residual |Jv - rhs| over active normal rows [device / engine]: max among resting bodies {gm_:.3e} / {rm_:.3e} m/s, 99th percentile {g99_:.3e} / {r99_:.3e}, "
+          f"mean {ga_:.3e} / {ra_:.3e} m/s, max over all rows (fallers' landings) {gx_:.3e} / {rx_:.3e} ({gn_} / {rn_} rows); penetration 99th percentile {pg99:.5f} / {pr99:.5f} m, mean {pga:.2e} / {pra:.2e} m, deepest {pg:.4f} / {pr:.4f} m")
     assert gn_ > 10000 and rn_ > 10000
-    assert gm_ <= 2.0 * rm_ and ga_ <= 2.0 * ra_, (gm_, rm_, ga_, ra_)
+    assert gm_ <= 2.0 * rm_ + 1e-3 and g99_ <= 2.0 * r99_ + 1e-4 and ga_ <= 2.0 * ra_, (gm_, rm_, g99_, r99_, ga_, ra_)
     assert pg99 <= 2.0 * pr99 + 2e-4 and pga <= 2.0 * pra + 2e-4, (pg99, pr99, pga, pra)
 
 
