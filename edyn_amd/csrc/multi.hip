@@ -22,6 +22,7 @@
 #include "ctx.hpp"
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -55,6 +56,56 @@ static void partition_islands(uint32_t n, const uint32_t *labels, const int32_t 
         for (uint32_t q = 1; q < world_size; ++q) if (load[q] < load[r]) r = q;
         owner[k] = (int32_t)r;
         load[r] += w[k];
+    }
+    for (uint32_t i = 0; i < n; ++i) if (kind[i] == EDYNHIP_KIND_DYNAMIC) rank_of[i] = owner[index_of(labels[i])];
+}
+
+// The world's own placement rule (round 5): islands in the order of a space-filling curve through their box centres (30-bit Morton
+// keys over the scene's bounds), cut into world_size runs of equal weight. Neighbours in space mostly share a shard, so islands that
+// meet later mostly meet inside a shard - the longest-processing-time rule above scatters neighbours over the shards, and every meeting
+// of two of them then costs a re-partition (a field of collapsing piles: 18 in 40 steps). A shard's load is within one island of the mean.
+// aabb6[n][6]: the bodies' boxes; shapeless bodies count with a point at the origin of their island's other bodies (or 0).
+static void partition_islands_spatial(uint32_t n, const uint32_t *labels, const int32_t *kind, const double *weights, const float *aabb6, uint32_t world_size, int32_t *rank_of) {
+    std::vector<uint32_t> isl;
+    for (uint32_t i = 0; i < n; ++i) { rank_of[i] = -1; if (kind[i] == EDYNHIP_KIND_DYNAMIC) isl.push_back(labels[i]); }
+    std::sort(isl.begin(), isl.end());
+    isl.erase(std::unique(isl.begin(), isl.end()), isl.end());
+    const uint32_t m = (uint32_t)isl.size();
+    if (m == 0) return;
+    auto index_of = [&](uint32_t label) { return (uint32_t)(std::lower_bound(isl.begin(), isl.end(), label) - isl.begin()); };
+    std::vector<double> w(m, 0.0), cx(3 * (size_t)m, 0.0), cw(m, 0.0);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < n; ++i) {
+        if (kind[i] != EDYNHIP_KIND_DYNAMIC) continue;
+        const uint32_t k = index_of(labels[i]);
+        w[k] += weights ? weights[i] : 1.0;
+        const float *b = aabb6 + 6 * (size_t)i;
+        bool finite = true;
+        for (int d = 0; d < 6; ++d) finite = finite && std::isfinite(b[d]) && std::fabs(b[d]) < 1.0e30f;
+        if (!finite || (b[0] == 0 && b[3] == 0 && b[1] == 0 && b[4] == 0 && b[2] == 0 && b[5] == 0)) continue;   // no shape: no place of its own
+        for (int d = 0; d < 3; ++d) { cx[3 * (size_t)k + d] += 0.5 * ((double)b[d] + (double)b[3 + d]); }
+        cw[k] += 1.0;
+    }
+    for (uint32_t k = 0; k < m; ++k) for (int d = 0; d < 3; ++d) {
+        if (cw[k] > 0) cx[3 * (size_t)k + d] /= cw[k];
+        lo[d] = std::min(lo[d], cx[3 * (size_t)k + d]); hi[d] = std::max(hi[d], cx[3 * (size_t)k + d]);
+    }
+    auto spread = [](uint32_t v) { v &= 0x3FFu; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; };
+    std::vector<uint32_t> key(m), order(m);
+    for (uint32_t k = 0; k < m; ++k) {
+        uint32_t q[3];
+        for (int d = 0; d < 3; ++d) { const double ext = hi[d] - lo[d]; q[d] = ext > 0 ? (uint32_t)std::min(1023.0, (cx[3 * (size_t)k + d] - lo[d]) / ext * 1024.0) : 0u; }
+        key[k] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+    }
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : isl[a] < isl[b]; });
+    double total = 0, before = 0;
+    for (double x : w) total += x;
+    std::vector<int32_t> owner(m, 0);
+    for (uint32_t k : order) {   // the run an island falls into is decided by the middle of its own weight interval
+        const double mid = before + 0.5 * w[k];
+        owner[k] = (int32_t)std::min<double>(world_size - 1, std::floor(mid / total * world_size));
+        before += w[k];
     }
     for (uint32_t i = 0; i < n; ++i) if (kind[i] == EDYNHIP_KIND_DYNAMIC) rank_of[i] = owner[index_of(labels[i])];
 }
@@ -664,7 +715,7 @@ int repartition(edynhip_world *w, bool sticky) {
     ++w->stats.repartitions;
     if (!sticky) {
         w->rank_of.assign(n, -1);
-        partition_islands(n, welded.data(), sc.kind.data(), weights.data(), W, w->rank_of.data());
+        partition_islands_spatial(n, welded.data(), sc.kind.data(), weights.data(), aabb.data(), W, w->rank_of.data());
         return rebuild(w, carry, true);
     }
     // sticky: a group that spans shards goes to the shard holding most of its bodies (ties: the lower shard); everybody else stays
@@ -707,6 +758,7 @@ int ensure_built(edynhip_world *w) {
     // The islands of the initial state, from the stepper itself: one probe context holds the whole scene and runs broadphase,
     // narrowphase and the island stage - exactly the graph the island manager partitions (island_manager.cpp:117-247).
     std::vector<uint32_t> labels(n);
+    std::vector<float> aabb0((size_t)n * 6, 0.f);
     {
         w->rank_of.assign(n, -1);
         for (uint32_t i = 0; i < n; ++i) if (sc.kind[i] == EDYNHIP_KIND_DYNAMIC) w->rank_of[i] = 0;
@@ -720,7 +772,7 @@ int ensure_built(edynhip_world *w) {
         if (rc == EDYNHIP_OK) {
             Shard &p = w->shards[0];
             rc = edynhip_run_stages(p.ctx, EDYNHIP_STAGE_BROADPHASE | EDYNHIP_STAGE_NARROWPHASE | EDYNHIP_STAGE_ISLANDS);
-            if (rc == EDYNHIP_OK) rc = edynhip_get_derived(p.ctx, nullptr, nullptr, labels.data());
+            if (rc == EDYNHIP_OK) rc = edynhip_get_derived(p.ctx, aabb0.data(), nullptr, labels.data());
             if (rc != EDYNHIP_OK) w->fail(rc, std::string("probe: ") + edynhip_last_error(p.ctx));
         }
         free_shard(w->shards[0]);
@@ -728,7 +780,7 @@ int ensure_built(edynhip_world *w) {
         if (rc != EDYNHIP_OK) return rc;
     }
     w->rank_of.assign(n, -1);
-    partition_islands(n, labels.data(), sc.kind.data(), nullptr, W, w->rank_of.data());
+    partition_islands_spatial(n, labels.data(), sc.kind.data(), nullptr, aabb0.data(), W, w->rank_of.data());
     w->pos = sc.pos; w->orn = sc.orn; w->linvel = sc.linvel; w->angvel = sc.angvel;
     Carry none;
     return rebuild(w, none, false);

@@ -1,5 +1,5 @@
 // The multi-GPU world of the C-ABI (include/edynhip.h "Multi-GPU world", edyn_amd/csrc/multi.hip) next to ONE context stepping the
-// same scene: six mini-piles (six islands) and a sphere that rolls from the first pile into the second - its island meets an
+// same scene: six mini-piles (six islands) and a sphere that rolls from the first pile into the fourth - its island meets an
 // island that lives on the other shard, which forces a re-partition with the contact manifolds carried along; later a forced
 // re-partition. Positions, orientations and velocities must be bit-equal after every step. Two shards on one physical GPU
 // (the reference's island parallelism: src/edyn/dynamics/solver.cpp:408-428).
@@ -228,7 +228,10 @@ int main() {
             sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_BOX, 8.0f * (site % 3) + 1.02f * i + off + 0.003f * k, 0.505f + 1.005f * j, 8.0f * (site / 3) + 1.02f * l + off, 0.5f, 0.5f, 0.5f, 0,
                    0, offset ? 0.12f : 0.0f, offset ? -0.08f : 0.0f, offset ? 0.05f : 0.0f);
         }
-    sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 4.3f, 0.5f, 1.0f, 0.5f, 0, 0, 0, 4.0f);   // between site 0 and site 1, rolling towards +x
+    // between site 0 and site 3, rolling towards +z: the world places islands along a space-filling curve (neighbours mostly share a shard);
+    // with two shards the cut runs between the z = 0 row and the z = 8 row of sites, so this sphere's island has to change shards
+    sc.add(EDYNHIP_KIND_DYNAMIC, EDYNHIP_SHAPE_SPHERE, 1.0f, 0.5f, 4.3f, 0.5f, 0, 0, 0, 0.0f);
+    sc.lv[sc.lv.size() - 1] = 4.0f;
     const uint32_t n = sc.n();
 
     edynhip_config cfg{};
@@ -273,7 +276,8 @@ int main() {
     REQUIRE(st.approach_checks < st.steps);              // the growth budget spares most steps the box sweep
     REQUIRE(st.bodies_per_shard[0] + st.bodies_per_shard[1] == n);
     REQUIRE(edynhip_world_get_partition(world, part2.data()) == EDYNHIP_OK);
-    REQUIRE(part2[n - 1] == part2[1 + 27]);              // the sphere now lives with the pile it ran into
+    REQUIRE(part[1] != part[1 + 27 * 3]);                // (site 0 and site 3 started on different shards)
+    REQUIRE(part2[n - 1] == part2[1 + 27 * 3]);          // the sphere now lives with the pile it ran into
     uint32_t m1 = 0, m2 = 0;
     REQUIRE(edynhip_num_manifolds(one, &m1) == EDYNHIP_OK);
     REQUIRE(edynhip_world_get_manifolds(world, nullptr, 0, &m2) == EDYNHIP_OK && m1 == m2);

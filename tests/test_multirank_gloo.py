@@ -57,9 +57,11 @@ def test_sharded_islands_match_single_world(tmp_path):
 
 
 # ------------------------------------------------------------------ the product's ShardedWorld (edyn_amd.parallel)
-def _bridge_scene():
+def _bridge_scene(along="x"):
     """Six mini-piles (six islands) plus a sphere that rolls from the first site into the second: its island meets an
-    island that may live on another rank, which forces a re-partition with the contact manifolds carried along."""
+    island that may live on another rank, which forces a re-partition with the contact manifolds carried along.
+    along = "z": the sphere rolls from site 0 into site 3 instead (the row behind it) - the library's multi-device world places islands
+    along a space-filling curve, whose cuts run between the two rows of sites for 2 and 3 shards (tests/test_multirank_gpu.py)."""
     from edyn_amd import scenes
     sc = scenes.mini_piles(3, 2)
     n = len(sc["kind"])
@@ -68,20 +70,24 @@ def _bridge_scene():
         if k != "joints":
             ext[k][:n] = v
     ext["kind"][n] = scenes.KIND_DYNAMIC
-    ext["pos"][n] = (-3.4, 0.5, -4.0)                # between site 0 (x = -8) and site 1 (x = 0), rolling towards +x
-    ext["linvel"][n] = (4.0, 0, 0)
+    if along == "x":
+        ext["pos"][n] = (-3.4, 0.5, -4.0)            # between site 0 (x = -8) and site 1 (x = 0), rolling towards +x
+        ext["linvel"][n] = (4.0, 0, 0)
+    else:
+        ext["pos"][n] = (-7.7, 0.5, -0.4)            # between site 0 (z = -4) and site 3 (z = +4), rolling towards +z
+        ext["linvel"][n] = (0, 0, 4.0)
     ext["shape_type"][n] = scenes.SHAPE_SPHERE; ext["shape_param"][n] = (0.5, 0, 0, 0)
     return ext
 
 
-def _poly_bridge_scene():
+def _poly_bridge_scene(along="x"):
     """The bridge scene with every second box a convex polyhedron (meshes of tests/meshes.py; their ids are positions in the scene's
     mesh list, which every shard keeps whole) and some cylinders: the shards create the meshes in their own worlds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import meshes
     from edyn_amd import scenes
     lib, _ = meshes.registered()
-    sc = _bridge_scene()
+    sc = _bridge_scene(along)
     for i in range(1, len(sc["kind"]) - 1):
         if i % 2 == 0:
             sc["shape_type"][i] = scenes.SHAPE_POLYHEDRON; sc["shape_param"][i] = (float((i // 2) % 2 * 4), 0, 0, 0)   # the unit cube or the hexagonal prism
@@ -91,7 +97,7 @@ def _poly_bridge_scene():
     return sc
 
 
-def _jointed_bridge_scene():
+def _jointed_bridge_scene(along="x"):
     """The bridge scene plus two pendulum chains (point + hinge joints, one hinge with angle limits, a bump stop and friction
     torque: tracked angle and four optional row slots) hanging from static anchors, and an excluded pair of overlapping spheres:
     what a re-partition has to carry besides the manifolds."""
@@ -100,7 +106,7 @@ def _jointed_bridge_scene():
     chains["pos"][:, 0] += 30.0; chains["pos"][:, 2] += 6.0
     # every hinge: limits (+-0.6 rad, restitution 0.3), a bump stop, friction torque and a soft spring
     chains["hinge_params"] = [(j, [-0.6, 0.6, 0.3, 0.2, 20.0, 0.05, 0.0, 0.1, 2.0, 0.01]) for j, t in enumerate(chains["joints"]) if t[0] == scenes.JOINT_HINGE]
-    sc = scenes.merge(_bridge_scene(), chains)
+    sc = scenes.merge(_bridge_scene(along), chains)
     n = len(sc["kind"])
     two = scenes._empty(2)
     two["pos"][:] = [(40.0, 0.5, 0.0), (40.3, 0.5, 0.0)]        # overlapping spheres that must keep ignoring each other

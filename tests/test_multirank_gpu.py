@@ -40,7 +40,7 @@ def _single_world_states(scene, steps):
 def test_multi_world_matches_one_context_through_an_approach_triggered_repartition(shards):
     import edyn_amd
     from test_multirank_gloo import _bridge_scene
-    scene = _bridge_scene()
+    scene = _bridge_scene(along="z")   # the sphere crosses the world's cut (islands are placed along a space-filling curve)
     steps = 90
     ref, single = _single_world_states(scene, steps)
     mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0] * shards)
@@ -61,7 +61,7 @@ def test_multi_world_matches_one_context_through_an_approach_triggered_repartiti
 def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
     import edyn_amd
     from test_multirank_gloo import _jointed_bridge_scene
-    scene = _jointed_bridge_scene()
+    scene = _jointed_bridge_scene(along="z")
     steps = 90
     ref, _ = _single_world_states(scene, steps)
     mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0])
@@ -71,13 +71,13 @@ def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
         assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[k]), k
         if k in (30, 60):
             mw.repartition()   # every shard is rebuilt: the chains swing on with warm-started joints and tracked angles
-    assert mw.get_stats()["repartitions"] >= 3
+    assert mw.get_stats()["repartitions"] >= 2   # the two forced ones (whether the sphere also crosses a cut depends on where the chains put it)
 
 
 def test_multi_world_with_polyhedra_and_cylinders():
     import edyn_amd
     from test_multirank_gloo import _poly_bridge_scene
-    scene = _poly_bridge_scene()
+    scene = _poly_bridge_scene(along="z")
     steps = 90
     ref, _ = _single_world_states(scene, steps)
     mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0])
