@@ -24,6 +24,8 @@ for WL in $WLS; do
     ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $W/$C -o r -- python $OLDPWD/bench.py --workload $WL --steps $PS --warmup 5 --north-star none --other-arithmetic-steps 0 --no-cpu-baseline > $W/$C.json 2> $W/$C.log )
   done
   python scripts/pmc_traffic.py $W/FETCH_SIZE $W/WRITE_SIZE $WL $W/FETCH_SIZE.json > $OUT/${R}_traffic_$WL.json 2> $OUT/${R}_traffic_$WL.err || true
+  # ... and of the other bandwidth kernels of the step (the row preparation had no counter profile), last $PS timed steps
+  python scripts/pmc_kernel_traffic.py $W/FETCH_SIZE $W/WRITE_SIZE $PS k_prep_contacts k_np_merge k_np_detect k_pos_seed k_push_links k_bp_pairs > $OUT/${R}_traffic_other_kernels_$WL.json 2> /dev/null || true
   if [ $WL = pile32k ]; then
     python scripts/prof_timeline.py $W/kt $((SETTLE + STEPS + WARM - 50)) > $OUT/${R}_timeline_$WL.txt 2>&1 || true
     python bench.py --stage-timing --north-star none --other-arithmetic-steps 0 --no-cpu-baseline > $OUT/${R}_bench_stage_timing.json 2> /dev/null || true
