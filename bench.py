@@ -74,7 +74,11 @@ PARITY = ("bit-exact vs the oracle's coloured order in this settled state at ful
           "mean resting height within 3.4e-4 m, penetration of the resting pile 0.0036 / 0.0018 m, kinetic energy of the resting set 1.1e-5 / 1.2e-5 J per "
           "body - a Gauss-Seidel visiting-order effect of the unconverged 10-iteration solve on a collapsing lattice, not fp "
           "rounding (lock-step: 2e-3 m per step, pair sets and narrowphase bit-exact, also on C3 at full size: 1.6e-3 m; "
-          "test_c2_300_steps_survey_invariants_*, test_free_running_c2_*, test_c3_full_size_lock_step_*, test_gpu_against_the_real_reference_engine)")
+          "test_c2_300_steps_survey_invariants_*, test_free_running_c2_*, test_c3_full_size_lock_step_*, test_gpu_against_the_real_reference_engine); "
+          "solver residual |Jv - rhs| over active normal rows, coloured order vs engine: it leaves less than the engine does (0.3-0.7x the mean, "
+          "test_solver_residual_*; the device on C2 after 300 steps: profiles/r05_parity_figures.txt); jointed configurations in lock-step with the engine: "
+          "exact with the engine's order replayed, 3.0e-3 m / 0.24 m/s per step on chains and 2.9e-2 m / 1.7 m/s on a collapsing rag-doll heap in the coloured order "
+          "(test_jointed_*)")
 WORKLOADS = {
     "pile32k": dict(gen=lambda: scenes.box_pile(32, 32, 32), vel=10, pos=3, settle=120, desc="32x32x32 = 32768-box brick-offset pile on a static plane"),
     "pile8k": dict(gen=lambda: scenes.box_pile(20, 20, 20), vel=10, pos=3, settle=120, desc="20x20x20 = 8000-box pile (config C2)"),
