@@ -3704,7 +3704,9 @@ int solve(edynhip_ctx *c) {
         static const uint32_t env_pw = getenv("EDYNHIP_DFP_WAVES") ? (uint32_t)atoi(getenv("EDYNHIP_DFP_WAVES")) : 0u;
         const Rows &r = c->rows;
         hipLaunchKernelGGL(k_pos_seed, dim3(blocks(2 * na, 256)), dim3(256), 0, s, na, r, c->b, r.pslot, rcap, mf, df_skip);
-        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(512u, blocks(na, 32 * 9))));
+        // resident waves: 512 for the block form (round 4: 256 / 768 / 1024 / 2048 within 1 %), 1024 - every SIMD - for the point-by-point form, whose tasks
+        // are longer (round 5, one box: 785-791 -> 796-797 steps/s; 384: 743)
+        const uint32_t grid = std::min(blocks(na, 32), std::min(c->dfp_waves, env_pw ? env_pw : std::max(block_pos ? 512u : 1024u, blocks(na, 32 * 9))));
         // developer aid: EDYNHIP_DFP_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th position solve
         // (same file format as EDYNHIP_DF_TRACE with "sweeps" = position iterations: scripts/df_trace.py reads both)
         static const char *ptrace_path = getenv("EDYNHIP_DFP_TRACE");
