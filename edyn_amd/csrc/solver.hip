@@ -1135,7 +1135,56 @@ struct DfArgs {
     uint64_t *trace;                  // developer aid (EDYNHIP_DF_TRACE): 4 timestamps per (sweep, round, wave), else nullptr
     const uint8_t *skip;              // mixed schedule: [p] != 0 = the manifold's island has joints and is solved by k_island_velocity; else nullptr
     uint32_t nap;                     // pause between two polls of a wave that found nothing: 0 none, 1 s_sleep 1, else s_sleep 4 (EDYNHIP_DF_NAP, developer knob)
+    uint32_t xcd_lists;               // two-lane kernel: tasks are handed out per XCD (XcdLists below) instead of by p alone
 };
+// ---- XCD-local task lists (round 5) ---------------------------------------------------------------------------------------------------
+// A hand-off between two waves of the SAME XCD is noticed ~0.2 us sooner than one that crosses XCDs (scripts/ubench/pingpong.hip: 280 against
+// 460-530 ns per hop on an idle chip, same sc1 stores and polls: the poll is served by the XCD's own L2), and workgroup b of a launch runs
+// on XCD (b + const) mod 8. The sorted order p is (colour, point count)-major and, inside such a class, in manifold order - which follows
+// the bodies' indices, i.e. where they sit in the scene. So every class is cut into EIGHTHS, and the waves with blockIdx = g (mod 8) take
+// the g-th eighth of every class: a body's manifolds - in whatever colour - mostly lie in the same eighth of their classes, so most of
+// its hand-offs stay inside one XCD. Nothing but speed depends on the placement (every hand-off stays an sc1 store and an sc1 poll),
+// and nothing but the ORDER IN WHICH WAVES PICK TASKS changes: every array stays indexed by p. List g = the g-th eighths of all classes
+// in class (= colour) order, so a wave still meets its tasks in colour order and every dependency points to an earlier task.
+constexpr uint32_t kXcds = 8, kCls = 4 * kMaxColours;
+// The eighths are cut at multiples of 32 in p and every class starts a new wave-task in its list (the unused lanes of a class's last
+// task idle): a wave's 32 manifolds are then 32-aligned in p exactly like in the plain assignment - one contiguous piece of the hand-off
+// slot layout per poll (dslot_at / pslot_at) - and never straddle two classes (first version, unpadded: 576 instead of 72 class
+// boundaries fell inside wave-tasks, which then run colour after colour and in the predicated form: velocity solve 0.55 -> 0.64 ms).
+struct XcdLists { uint32_t pre[kCls + 1]; uint32_t first[kCls], lo[kCls], hi[kCls]; };   // list g: pre[c] = task slots before class c; first[c] = p of slot 0 of the class (32-aligned); [lo, hi) = the class's g-th eighth
+DI void xcd_lists_build(XcdLists &L, const Counters *cnt, uint32_t g) {   // one wave (64 lanes); ends with a barrier
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n[4], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t c = 4 * lane + k, a = cnt->colour_start[c], e = cnt->colour_end[c], size = e > a && c < 4 * kMaxContactColours ? e - a : 0u;
+        auto cut = [&](uint32_t i) {   // boundary i of the class's eighths: 0 = start, 8 = end, between: the nearest multiple of 32 inside the class
+            if (i == 0) return a;
+            if (i >= kXcds) return a + size;
+            const uint32_t b = (a + (uint32_t)(((uint64_t)size * i) / kXcds) + 16u) & ~31u;
+            return b < a ? a : (b > a + size ? a + size : b);
+        };
+        const uint32_t lo = cut(g), hi = cut(g + 1), v = lo & ~31u;
+        L.first[c] = v; L.lo[c] = lo; L.hi[c] = hi;
+        n[k] = hi > lo ? ((hi - v) + 31u) & ~31u : 0u;
+        sum += n[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if ((int)lane >= d) inc += u; }
+    uint32_t at = inc - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) { L.pre[4 * lane + k] = at; at += n[k]; }
+    if (lane == 63) L.pre[kCls] = at;
+    __syncthreads();
+}
+DI uint32_t xcd_lists_p(const XcdLists &L, uint32_t q, uint32_t none) {   // q < L.pre[kCls]: the manifold in task slot q of the list, or `none` for an idle slot
+    uint32_t lo = 0, hi = kCls;
+#pragma unroll 1
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.pre[mid] <= q) lo = mid; else hi = mid; }
+    const uint32_t p = L.first[lo] + (q - L.pre[lo]);
+    return p >= L.lo[lo] && p < L.hi[lo] ? p : none;
+}
 DI void df_nap(uint32_t nap) { if (nap == 0) return; if (nap == 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }
 DI void df_poll(const float4 *slot, v4f &a0, v4f &a1, v4f &b0, v4f &b1) {   // both sides' (dv|tag, dw|tag): pieces 1 KiB apart (dslot_at)
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -2240,6 +2289,24 @@ template <bool FUSED>
 __global__ void __launch_bounds__(64) k_contact_solve_df2(DfArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
+    if (a.xcd_lists) {   // (gridDim.x is a multiple of 8: solve())
+        __shared__ XcdLists L;
+        xcd_lists_build(L, a.cnt, blockIdx.x % kXcds);
+        const uint32_t count = L.pre[kCls], step = (gridDim.x / kXcds) * 32u, mine = (blockIdx.x / kXcds) * 32u + (threadIdx.x >> 1);
+        for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
+            for (uint32_t base = 0; base < count; base += step) {
+                const uint32_t q = base + mine;
+                const uint32_t pt = q < count ? xcd_lists_p(L, q, a.na) : a.na;
+                const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
+                if (!__any(valid)) continue;
+                const uint32_t p = pt < a.na ? pt : a.na - 1;
+                const uint32_t key = a.keys_sorted[p];
+                const uint32_t np = valid ? 4u - (key & 3u) : 0u, col = key >> 2;
+                if (sweep == 0) df2_dispatch<true, FUSED>(a, p, valid, sideB, np, col, sweep, nullptr);
+                else df2_dispatch<false, FUSED>(a, p, valid, sideB, np, col, sweep, nullptr);
+            }
+        return;
+    }
     const uint32_t rounds = (a.na + a.stride - 1) / a.stride, nwaves = a.stride >> 5;
     for (uint32_t sweep = 0; sweep < a.sweeps; ++sweep)
         for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
@@ -2625,6 +2692,7 @@ struct DfPosArgs {
     Counters *cnt;
     const uint8_t *skip;            // mixed schedule: manifolds of islands with joints (k_island_position solves those), else nullptr
     uint64_t *trace;                // developer aid (EDYNHIP_DFP_TRACE): 4 timestamps per (round, wave) of this iteration, else nullptr
+    uint32_t xcd_lists;             // tasks are handed out per XCD (XcdLists, see the velocity kernel)
 };
 constexpr float kPosErrorThreshold = 0.005f;
 DI void dfp_poll(const float4 *slot, v4f &h0, v4f &h1, v4f &h2) {
@@ -2804,8 +2872,15 @@ __global__ void __launch_bounds__(64) k_pos_contacts_df(DfPosArgs a) {
     const uint32_t t = blockIdx.x * 32u + (threadIdx.x >> 1);   // 32 manifolds per wave, two lanes each
     const bool sideB = threadIdx.x & 1u;
     const uint32_t nwaves = a.stride >> 5;
-    for (uint32_t base = 0, round = 0; base < a.na; base += a.stride, ++round) {
-        const uint32_t pt = base + t;
+    __shared__ XcdLists L;
+    uint32_t count = a.na, step = a.stride, mine = t;
+    if (a.xcd_lists) {
+        xcd_lists_build(L, a.cnt, blockIdx.x % kXcds);
+        count = L.pre[kCls]; step = (gridDim.x / kXcds) * 32u; mine = (blockIdx.x / kXcds) * 32u + (threadIdx.x >> 1);
+    }
+    for (uint32_t base = 0, round = 0; base < count; base += step, ++round) {
+        const uint32_t q = base + mine;
+        const uint32_t pt = a.xcd_lists ? (q < count ? xcd_lists_p(L, q, a.na) : a.na) : q;
         const bool valid = pt < a.na && !(a.skip && a.skip[pt]);
         if (!__any(valid)) continue;
         const uint64_t w0 = a.trace ? wall_clock64() : 0;
@@ -3620,12 +3695,17 @@ int solve(edynhip_ctx *c) {
         const uint32_t want_waves = env_waves ? env_waves : std::max(four_lane ? 2048u : two_lane ? 1024u : 512u, blocks(na, per_wave * 9));
         const uint32_t grid = std::min(blocks(na, per_wave), std::min(resident, want_waves));
         static const uint32_t env_nap = getenv("EDYNHIP_DF_NAP") ? (uint32_t)atoi(getenv("EDYNHIP_DF_NAP")) : 1u;   // (r04 sweep on one box: 4 -> 1: +0.6 %, 0: the same)
-        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip, env_nap};
+        // (measured, round 5, A/B on one box: the headline pile LOSES - velocity solve 0.553 -> 0.597 ms: the class padding adds 6 % task slots to waves
+        //  that were exactly as busy as the chains are long - mixed32k and pile8k win 1.5-3 % of their solves: off by default, EDYNHIP_DF_XCD=1 turns it on)
+        static const bool xcd_env = getenv("EDYNHIP_DF_XCD") && getenv("EDYNHIP_DF_XCD")[0] == '1';
+        const uint32_t xcd_lists = (xcd_env && two_lane && grid % kXcds == 0 && grid >= 8 * kXcds) ? 1u : 0u;
+        DfArgs a{na, grid * per_wave, c->cfg.num_velocity_iterations + 1, c->col_keys_sorted, r.next, r.im, r.rw, rcap, r.dslot, c->cnt, nullptr, df_skip, env_nap, xcd_lists};
         // developer aid: EDYNHIP_DF_TRACE=<file> EDYNHIP_DF_TRACE_STEP=<n> dumps per-task timestamps of the n-th solve
         static const char *trace_path = getenv("EDYNHIP_DF_TRACE");
         static long trace_step = getenv("EDYNHIP_DF_TRACE_STEP") ? atol(getenv("EDYNHIP_DF_TRACE_STEP")) : 100, solve_calls = 0;
         const bool tracing = trace_path && solve_calls++ == trace_step;
         size_t trace_words = 0;
+        if (tracing) a.xcd_lists = 0;   // (the trace is laid out by (sweep, round, wave) of the plain assignment)
         if (tracing) {
             const uint32_t rounds = (na + a.stride - 1) / a.stride;
             trace_words = 4 * (size_t)a.sweeps * rounds * (a.stride / per_wave);
@@ -3721,8 +3801,10 @@ int solve(edynhip_ctx *c) {
         }
         uint32_t it = 0;
         for (; it < c->cfg.num_position_iterations; ++it) {
+            static const bool xcd_env = getenv("EDYNHIP_DF_XCD") && getenv("EDYNHIP_DF_XCD")[0] == '1';
+            const uint32_t xcd_lists = (xcd_env && !ptrace && grid % kXcds == 0 && grid >= 8 * kXcds) ? 1u : 0u;
             DfPosArgs a{na, grid * 32u, it, c->col_keys_sorted, r.next, r.pslot, r, mf, c->b, c->pos_err + (size_t)it * c->b.cap,
-                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr};
+                        it ? c->pos_err + (size_t)(it - 1) * c->b.cap : nullptr, c->cnt, df_skip, ptrace ? ptrace + ptrace_words * it : nullptr, xcd_lists};
             void *params[] = {&a};
             if (launch_resident(c, df_position_fn(block_pos), grid, 64, params) != hipSuccess) {
                 (void)hipGetLastError();

@@ -77,6 +77,38 @@ __global__ void k_pp_16(float4 *fa, float4 *fb, int n, int who0, int who1) {
         }
     }
 }
+// (d) round 5: would a hand-off that stays inside one XCD be faster if the producer left the line in that XCD's L2? Producer: PLAIN (or sc0)
+// 16-byte store instead of the write-through sc1 store; consumer: sc1 (or sc0) polls. A poll that never sees the value gives up after
+// `limit` tries and the pair reports the failure (cross-XCD pairs are expected to: a plain store is not visible outside its XCD's L2).
+__device__ __forceinline__ void store16_plain(float4 *p, float4 f) {
+    v4f v = {f.x, f.y, f.z, f.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float4 load16_sc0(const float4 *p) {
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <int STORE, int LOAD>   // STORE 0 plain, 1 sc1; LOAD 0 sc0, 1 sc1
+__global__ void k_pp_16x(float4 *fa, float4 *fb, int n, int who0, int who1, uint32_t limit, uint32_t *fail) {
+    if (threadIdx.x != 0) return;
+    auto st = [](float4 *p, float4 f) { if (STORE) store16_sc1(p, f); else store16_plain(p, f); };
+    auto ld = [](const float4 *p) { return LOAD ? load16_sc1(p) : load16_sc0(p); };
+    if ((int)blockIdx.x == who0) {
+        for (int i = 1; i <= n; ++i) {
+            st(fa, make_float4(1.f, 2.f, 3.f, __int_as_float(i)));
+            uint32_t tries = 0;
+            while (__float_as_int(ld(fb).w) != i) if (++tries > limit) { fail[0] = (uint32_t)i; return; }
+        }
+    } else if ((int)blockIdx.x == who1) {
+        for (int i = 1; i <= n; ++i) {
+            float4 v; uint32_t tries = 0;
+            do { v = ld(fa); if (++tries > limit) { fail[1] = (uint32_t)i; return; } } while (__float_as_int(v.w) != i);
+            v.x += 1.f;
+            st(fb, v);
+        }
+    }
+}
 // chain: block k waits for block k-1's tag then publishes its own; measures the per-hop cost over many XCD crossings
 __global__ void k_chain_16(float4 *slots, int n_iter, int nblocks) {
     if (threadIdx.x != 0) return;
@@ -153,6 +185,23 @@ int main() {
         printf("blocks 0<->%d             : volatile on uncached  %.0f ns/hop\n", other, 1e6 * ms / N / 2);
         ms = timeit([&] { hipLaunchKernelGGL(k_pp_16, dim3(16), dim3(64), 0, s, slots, slots + 16, N, 0, other); return 0; });
         printf("blocks 0<->%d             : 16-B tagged sc1       %.0f ns/hop\n", other, 1e6 * ms / N / 2);
+    }
+    {   // (d): same-XCD pair (blocks 0 and 8) and cross-XCD pair (0 and 1), every store / load flavour, with a give-up limit
+        uint32_t *fail; CK(hipMalloc(&fail, 64));
+        for (int other : {8, 1}) {
+            auto run = [&](const char *what, auto kern) {
+                CK(hipMemset(fail, 0, 64));
+                float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(16), dim3(64), 0, s, slots, slots + 16, N, 0, other, 200000u, fail); return 0; });
+                uint32_t hf[2]; CK(hipMemcpy(hf, fail, 8, hipMemcpyDeviceToHost));
+                if (hf[0] || hf[1]) printf("blocks 0<->%d: %-28s NOT VISIBLE (gave up at hand-off %u / %u)\n", other, what, hf[0], hf[1]);
+                else printf("blocks 0<->%d: %-28s %.0f ns/hop\n", other, what, 1e6 * ms / N / 2);
+                return 0;
+            };
+            run("sc1 store, sc1 poll", k_pp_16x<1, 1>);
+            run("plain store, sc1 poll", k_pp_16x<0, 1>);
+            run("plain store, sc0 poll", k_pp_16x<0, 0>);
+            run("sc1 store, sc0 poll", k_pp_16x<1, 0>);
+        }
     }
     for (int nb : {8, 64, 256}) {
         const int it = 2000;
