@@ -144,13 +144,13 @@ DI void hull_insert(SupportPolygon &p, int at, int idx) {
     for (int k = p.nhull; k > at; --k) p.hull[k] = p.hull[k - 1];
     p.hull[at] = idx; ++p.nhull;
 }
-DI int split_hull_edge(SupportPolygon &p, int i0_in, int i1_in, float tolerance) {
-    struct Frame { int i0, i1, stage, n1; };
-    Frame stack[kPolyMax + 2];
+struct HullFrame { unsigned char i0, i1, stage, n1; };   // (indices and counts <= kPolyMax + 1)
+DI HullFrame hull_frame(int i0, int i1) { return HullFrame{(unsigned char)i0, (unsigned char)i1, 0, 0}; }
+DI int split_hull_edge(SupportPolygon &p, int i0_in, int i1_in, float tolerance, HullFrame *stack) {   // stack: kPolyMax + 2 frames
     int sp = 0, ret = 0;
-    stack[sp++] = Frame{i0_in, i1_in, 0, 0};
+    stack[sp++] = hull_frame(i0_in, i1_in);
     while (sp > 0) {
-        Frame &f = stack[sp - 1];
+        HullFrame &f = stack[sp - 1];
         if (f.stage == 0) {
             const f2 v0 = p.plane_vertices[p.hull[f.i0]], v1 = p.plane_vertices[p.hull[f.i1]];
             const f2 dir = -orthogonal(v1 - v0);
@@ -162,14 +162,13 @@ DI int split_hull_edge(SupportPolygon &p, int i0_in, int i1_in, float tolerance)
             if (dot(p.plane_vertices[idx] - v0, dir) > tolerance && p.nhull <= kPolyMax && sp < kPolyMax + 1) {
                 hull_insert(p, f.i1, idx);
                 f.stage = 1;
-                stack[sp++] = Frame{f.i0, f.i1, 0, 0};
+                stack[sp] = hull_frame(f.i0, f.i1); ++sp;
             } else { ret = 0; --sp; }
         } else if (f.stage == 1) {
-            f.n1 = ret;
-            f.i1 += f.n1;
+            f.n1 = (unsigned char)ret;
+            f.i1 = (unsigned char)(f.i1 + f.n1);
             f.stage = 2;
-            const int a = f.i1, b = f.i1 + 1;
-            stack[sp++] = Frame{a, b, 0, 0};
+            stack[sp] = hull_frame(f.i1, f.i1 + 1); ++sp;
         } else {
             ret = 1 + f.n1 + ret;
             --sp;
@@ -177,7 +176,7 @@ DI int split_hull_edge(SupportPolygon &p, int i0_in, int i1_in, float tolerance)
     }
     return ret;
 }
-DI void calculate_convex_hull(SupportPolygon &p, float tolerance) {   // shape_util.cpp:126-190
+DI void calculate_convex_hull(SupportPolygon &p, float tolerance, HullFrame *stack) {   // shape_util.cpp:126-190
     const int n = p.nverts;
     p.nhull = 0;
     if (n <= 3) {
@@ -208,11 +207,12 @@ DI void calculate_convex_hull(SupportPolygon &p, float tolerance) {   // shape_u
     }
     p.hull[0] = pt_max_idx; p.hull[1] = pt_min_idx; p.hull[2] = pt_max_idx; p.nhull = 3;
     int i1 = 1;
-    const int num_splits = split_hull_edge(p, 0, i1, tolerance);
+    const int num_splits = split_hull_edge(p, 0, i1, tolerance, stack);
     i1 += num_splits;
-    split_hull_edge(p, i1, i1 + 1, tolerance);
+    split_hull_edge(p, i1, i1 + 1, tolerance, stack);
     --p.nhull;   // hull.pop_back()
 }
+DI void calculate_convex_hull(SupportPolygon &p, float tolerance) { HullFrame stack[kPolyMax + 2]; calculate_convex_hull(p, tolerance, stack); }
 template <class V>
 DI void point_cloud_support_polygon(SupportPolygon &polygon, const V &verts, int count, f3 offset, f3 dir, float projection, bool positive_side, float tolerance) {
     polygon.origin = dir * projection;
@@ -331,6 +331,49 @@ DI void collide_polyhedron_sphere(const PolySh &shA, float radiusB, const Ctx &c
 }
 
 // ---- collide(polyhedron, polyhedron)   collide_polyhedron_polyhedron.cpp:13-241 (A at the origin, rotated meshes)
+// the contact points of two support polygons along the separating axis (collide_polyhedron_polyhedron.cpp:152-241)
+DI void polygon_polygon_contacts(const SupportPolygon &polygonA, const SupportPolygon &polygonB, f3 posA, q4 ornA, f3 posB, q4 ornB, f3 sep_axis, float distance, CResult &result) {
+    int normal_attachment = NA_NONE;
+    if (polygonB.nhull > 2) normal_attachment = NA_ON_B;
+    else if (polygonA.nhull > 2) normal_attachment = NA_ON_A;
+    if (polygonB.nhull > 2)
+        for (int h = 0; h < polygonA.nhull; ++h) {
+            const f3 pointA = polygonA.vertices[polygonA.hull[h]];
+            if (point_in_polygonal_prism(polygonB, sep_axis, pointA)) {
+                const f3 pivotA = to_object(pointA, posA, ornA);
+                const f3 pivotB = to_object(project_plane(pointA, polygonB.origin, sep_axis), posB, ornB);
+                res_maybe_add(result, {pivotA, pivotB, sep_axis, distance, normal_attachment});
+            }
+        }
+    if (polygonA.nhull > 2)
+        for (int h = 0; h < polygonB.nhull; ++h) {
+            const f3 pointB = polygonB.vertices[polygonB.hull[h]];
+            if (point_in_polygonal_prism(polygonA, sep_axis, pointB)) {
+                const f3 pivotB = to_object(pointB, posB, ornB);
+                const f3 pivotA = to_object(project_plane(pointB, polygonA.origin, sep_axis), posA, ornA);
+                res_maybe_add(result, {pivotA, pivotB, sep_axis, distance, normal_attachment});
+            }
+        }
+    if (polygonA.nhull > 1 && polygonB.nhull > 1) {
+        const int sizeA = polygonA.nhull, sizeB = polygonB.nhull;
+        const int limitA = sizeA == 2 ? 1 : sizeA, limitB = sizeB == 2 ? 1 : sizeB;
+        float s[2], t[2];
+        for (int i = 0; i < limitA; ++i) {
+            const int idx0A = polygonA.hull[i], idx1A = polygonA.hull[(i + 1) % sizeA];
+            const f2 v0A = polygonA.plane_vertices[idx0A], v1A = polygonA.plane_vertices[idx1A];
+            for (int j = 0; j < limitB; ++j) {
+                const int idx0B = polygonB.hull[j], idx1B = polygonB.hull[(j + 1) % sizeB];
+                const f2 v0B = polygonB.plane_vertices[idx0B], v1B = polygonB.plane_vertices[idx1B];
+                const int num_points = intersect_segments(v0A, v1A, v0B, v1B, s[0], t[0], s[1], t[1]);
+                for (int k = 0; k < num_points; ++k) {
+                    const f3 pivotA_world = lerp(polygonA.vertices[idx0A], polygonA.vertices[idx1A], s[k]);
+                    const f3 pivotB_world = lerp(polygonB.vertices[idx0B], polygonB.vertices[idx1B], t[k]);
+                    res_maybe_add(result, {to_object(pivotA_world, posA, ornA), to_object(pivotB_world, posB, ornB), sep_axis, distance, normal_attachment});
+                }
+            }
+        }
+    }
+}
 DI void poly_max_support_direction(const PolySh &shA, f3 posA, const PolySh &shB, f3 posB, f3 &dir, float &distance, float &projectionA, float &projectionB) {
     float max_proj_A = kScalarMax, max_proj_B = -kScalarMax, max_distance = -kScalarMax;
     f3 best_dir{0, 0, 0};
@@ -402,46 +445,232 @@ DI void collide_polyhedron_polyhedron(const PolySh &shA, const PolySh &shB, cons
     SupportPolygon polygonA, polygonB;
     point_cloud_support_polygon(polygonA, shA.rot, shA.mesh.nv(), posA, sep_axis, projectionA, true, kSupportTolerance);
     point_cloud_support_polygon(polygonB, shB.rot, shB.mesh.nv(), posB, sep_axis, projectionB, false, kSupportTolerance);
-    int normal_attachment = NA_NONE;
-    if (polygonB.nhull > 2) normal_attachment = NA_ON_B;
-    else if (polygonA.nhull > 2) normal_attachment = NA_ON_A;
-    if (polygonB.nhull > 2)
-        for (int h = 0; h < polygonA.nhull; ++h) {
-            const f3 pointA = polygonA.vertices[polygonA.hull[h]];
-            if (point_in_polygonal_prism(polygonB, sep_axis, pointA)) {
-                const f3 pivotA = to_object(pointA, posA, ornA);
-                const f3 pivotB = to_object(project_plane(pointA, polygonB.origin, sep_axis), posB, ornB);
-                res_maybe_add(result, {pivotA, pivotB, sep_axis, distance, normal_attachment});
-            }
+    polygon_polygon_contacts(polygonA, polygonB, posA, ornA, posB, ornB, sep_axis, distance, result);
+}
+
+// ---- collide(polyhedron, polyhedron) by a GROUP of G lanes (narrowphase.hip k_np_pp_axes, k_np_pp_contacts) -------------------------------------------
+// The routine above is one lane's serial walk: (faces of A + faces of B) hill climbs, edges of A x edges of B Minkowski tests, two support
+// polygons, their hulls, the clipping - ~10k instructions of dependent loads with one wave per SIMD (245 VGPRs, 2.4 KB of scratch per lane
+// for the polygons and the hull's stack). Here G lanes share one pair:
+//   * every candidate separating axis is one lane's work - the face axes of both polyhedra in one round, the edge pairs G at a time - and
+//     the winner is found by a group reduction on (distance, index in the serial order): "the first axis with the largest distance", which
+//     is what the serial loops' strict `>` keeps;
+//   * the support polygons are collected G vertices at a time (the in-boundary vertices take consecutive slots in vertex order: a ballot
+//     and a prefix count) into LDS, lanes 0 and 1 run the two quickhulls side by side on LDS (the hull stack is LDS too), lane 0 clips.
+// Same operations on the same values in the same order wherever order matters: bit-identical to collide_polyhedron_polyhedron
+// (tests/test_gpu_parity.py: 100k random pairs per mesh combination through this routine, the heaps through the kernel).
+constexpr int kNoAxis = 0x7fffffff;
+// What the group routines read of one polyhedron: the body's rotated mesh (k_update_rotated ran) and the offsets into the shared tables.
+// (Measured and dropped: rotating the table entries where they are used instead - rotate(orn, entry), what k_update_rotated stores, so the
+// same bits - to keep the 0.8 GB per step of rotated-mesh reads of the 32k heap out of the L2s: the kernel is bound by instruction issue,
+// not by those reads, and the rotations made it 12 % slower.)
+struct PPSide {
+    const float4 *rot; int nv, nrf, ne; uint32_t rf_off, f_off, nb_off, ni_off;
+    DI f3 vertex(int i) const { return from4(rot[i]); }
+    DI f3 relevant_normal(int k) const { return from4(rot[nv + k]); }
+    DI f3 edge_vertex(int k) const { return from4(rot[nv + nrf + k]); }
+    DI f3 edge_normal(int k) const { return from4(rot[nv + nrf + 2 * ne + k]); }
+};
+DI PPSide pp_side(const Meshes &t, float4 shape, const float4 *rot) {
+    const MeshDesc d = t.desc[(uint32_t)shape.x];
+    return PPSide{rot, (int)d.nv, (int)d.nrf, (int)d.ne, d.rf_off, d.f_off, d.nb_off, d.ni_off};
+}
+DI float pp_support_projection(const Meshes &t, const PPSide &Y, f3 dir) {   // polyhedron_support_projection
+    int v_idx = 0;
+    float max_proj = dot(Y.vertex(0), dir);
+    for (;;) {
+        const int n0 = (int)t.nb_start[Y.nb_off + v_idx], n1 = (int)t.nb_start[Y.nb_off + v_idx + 1];
+        bool done = true;
+        for (int i = n0; i < n1; ++i) {
+            const int nv_idx = (int)t.nb_idx[Y.ni_off + i];
+            const float proj = dot(Y.vertex(nv_idx), dir);
+            if (proj > max_proj) { max_proj = proj; v_idx = nv_idx; done = false; }
         }
-    if (polygonA.nhull > 2)
-        for (int h = 0; h < polygonB.nhull; ++h) {
-            const f3 pointB = polygonB.vertices[polygonB.hull[h]];
-            if (point_in_polygonal_prism(polygonA, sep_axis, pointB)) {
-                const f3 pivotB = to_object(pointB, posB, ornB);
-                const f3 pivotA = to_object(project_plane(pointB, polygonA.origin, sep_axis), posA, ornA);
-                res_maybe_add(result, {pivotA, pivotB, sep_axis, distance, normal_attachment});
-            }
+        if (done) break;
+    }
+    return max_proj;
+}
+struct PPAxis { float dist, projX, projY; f3 dir; int idx; };
+DI PPAxis pp_no_axis(float projX, float projY) { return PPAxis{-kScalarMax, projX, projY, mk3(0, 0, 0), kNoAxis}; }
+// one iteration of poly_max_support_direction: face axis `idx` of X against Y
+DI void pp_face_axis(const Meshes &t, const PPSide &X, f3 posX, const PPSide &Y, f3 posY, int idx, PPAxis &best) {
+    const f3 normal_world = -X.relevant_normal(idx);
+    const int face_idx = (int)t.relevant_faces[X.rf_off + idx];
+    const f3 vertexX = X.vertex((int)t.face_first[X.f_off + face_idx]);
+    const f3 vertex_world = vertexX + posX;
+    const float projX = dot(vertex_world, normal_world);
+    const float projY = pp_support_projection(t, Y, normal_world) + dot(posY, normal_world);
+    const float dist = projX - projY;
+    if (dist > best.dist) best = PPAxis{dist, projX, projY, normal_world, idx};
+}
+template <int G> DI float gshfl(float v, int src) { return __shfl(v, src, G); }
+template <int G> DI PPAxis pp_group_best(PPAxis a) {   // the largest distance, the lowest index among equals: every lane gets the winner
+    int who = (int)(threadIdx.x % G);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const float od = __shfl_xor(a.dist, off, G);
+        const int oi = __shfl_xor(a.idx, off, G), ow = __shfl_xor(who, off, G);
+        if (od > a.dist || (od == a.dist && oi < a.idx)) { a.dist = od; a.idx = oi; who = ow; }
+    }
+    a.projX = gshfl<G>(a.projX, who); a.projY = gshfl<G>(a.projY, who);
+    a.dir = mk3(gshfl<G>(a.dir.x, who), gshfl<G>(a.dir.y, who), gshfl<G>(a.dir.z, who));
+    return a;
+}
+template <int G> DI uint32_t pp_group_ballot(bool pred) {
+    const uint64_t b = __ballot(pred);
+    return (uint32_t)(b >> (((threadIdx.x & 63u) / G) * G)) & (uint32_t)((1ull << G) - 1ull);
+}
+DI void pp_group_sync() {   // LDS written by one lane of the wave, read by another
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+struct PPLds { SupportPolygon poly[2]; HullFrame stack[2][kPolyMax + 2]; };   // one per group, in LDS
+// point_cloud_support_polygon without its hull, G vertices at a time
+template <int G>
+DI void pp_group_polygon(SupportPolygon &polygon, const PPSide &S, f3 offset, f3 dir, float projection, bool positive_side, float tolerance) {
+    const int j = (int)(threadIdx.x % G);
+    const f3 origin = dir * projection;
+    const m3 basis = make_tangent_basis(dir);
+    const bool zero_offset = eq(offset, mk3(0, 0, 0));
+    int n = 0;
+    for (int base = 0; base < S.nv; base += G) {
+        const int i = base + j;
+        bool in_boundary = false;
+        f3 vertex_world = mk3(0, 0, 0);
+        if (i < S.nv) {
+            vertex_world = zero_offset ? S.vertex(i) : S.vertex(i) + offset;
+            in_boundary = positive_side ? dot(vertex_world, dir) < projection + tolerance : dot(vertex_world, dir) > projection - tolerance;
         }
-    if (polygonA.nhull > 1 && polygonB.nhull > 1) {
-        const int sizeA = polygonA.nhull, sizeB = polygonB.nhull;
-        const int limitA = sizeA == 2 ? 1 : sizeA, limitB = sizeB == 2 ? 1 : sizeB;
-        float s[2], t[2];
-        for (int i = 0; i < limitA; ++i) {
-            const int idx0A = polygonA.hull[i], idx1A = polygonA.hull[(i + 1) % sizeA];
-            const f2 v0A = polygonA.plane_vertices[idx0A], v1A = polygonA.plane_vertices[idx1A];
-            for (int j = 0; j < limitB; ++j) {
-                const int idx0B = polygonB.hull[j], idx1B = polygonB.hull[(j + 1) % sizeB];
-                const f2 v0B = polygonB.plane_vertices[idx0B], v1B = polygonB.plane_vertices[idx1B];
-                const int num_points = intersect_segments(v0A, v1A, v0B, v1B, s[0], t[0], s[1], t[1]);
-                for (int k = 0; k < num_points; ++k) {
-                    const f3 pivotA_world = lerp(polygonA.vertices[idx0A], polygonA.vertices[idx1A], s[k]);
-                    const f3 pivotB_world = lerp(polygonB.vertices[idx0B], polygonB.vertices[idx1B], t[k]);
-                    res_maybe_add(result, {to_object(pivotA_world, posA, ornA), to_object(pivotB_world, posB, ornB), sep_axis, distance, normal_attachment});
+        const uint32_t mask = pp_group_ballot<G>(in_boundary);
+        const int slot = n + __popc(mask & ((1u << j) - 1u));
+        if (in_boundary && slot < kPolyMax) {
+            polygon.vertices[slot] = vertex_world;
+            polygon.plane_vertices[slot] = to_vector2_xz(to_object(vertex_world, origin, basis));
+        }
+        n = min(n + (int)__popc(mask), kPolyMax);
+    }
+    if (j == 0) { polygon.nverts = n; polygon.origin = origin; polygon.basis = basis; }
+}
+// All G lanes of the group call this together (group-uniform arguments); lane 0 of the group holds the result.
+// developer profile (EDYNHIP_PP_PROF=1): every phase boundary adds the 100 MHz clock to its sum; differences of the sums = ticks per phase
+template <bool ON> struct PPProf { uint64_t t[8]; DI void stamp(int k) { if (ON) t[k] += wall_clock64(); } };
+struct PPSeparation { f3 axis; float distance, projectionA, projectionB; uint32_t hint; };
+// The axis that decided a pair, as a hint for the next step: 0 = none, else kind << 28 | index (kind 1 = face axis `index` of A, 2 = of B,
+// 3 = edge pair eA * ne(B) + eB). pp_hint_separates tries that one axis before anything else: the final distance of the routine is the
+// maximum over its axes, so ONE axis of the routine's own set beyond the threshold means "no points" whatever the others say - the same
+// argument as the routine's early return after the face axes. (An axis from outside the set would not do: between a vertex and a vertex
+// the set's maximum is smaller than the true distance.) A face axis is evaluated exactly as the loop evaluates it; an edge pair must span
+// a Minkowski face now, like in the loop, and - its final projection difference is rounded differently from the distance that selects
+// it - must clear the threshold by 1e-3 (rounding: ~1e-6). A stale or meaningless hint costs one wasted axis, never a result.
+constexpr uint32_t kHintFaceA = 1u << 28, kHintFaceB = 2u << 28, kHintEdge = 3u << 28, kHintIndex = (1u << 28) - 1u;
+DI bool pp_hint_separates(const Meshes &t, const PPSide &A, const PPSide &B, f3 posB, float threshold, uint32_t hint) {
+    const f3 posA{0, 0, 0};
+    const uint32_t kind = hint & ~kHintIndex;
+    const int idx = (int)(hint & kHintIndex);
+    if (kind == kHintFaceA || kind == kHintFaceB) {
+        const bool second = kind == kHintFaceB;
+        if (idx >= (second ? B.nrf : A.nrf)) return false;
+        PPAxis a = pp_no_axis(0, 0);
+        if (second) pp_face_axis(t, B, posB, A, posA, idx, a); else pp_face_axis(t, A, posA, B, posB, idx, a);
+        return a.dist > threshold;
+    }
+    if (kind != kHintEdge || B.ne <= 0 || idx >= A.ne * B.ne) return false;
+    const int eA = idx / B.ne, eB = idx % B.ne;
+    const f3 normalsA[2] = {A.edge_normal(2 * eA), A.edge_normal(2 * eA + 1)};
+    f3 verticesA[2] = {A.edge_vertex(2 * eA), A.edge_vertex(2 * eA + 1)};
+    verticesA[0] += posA; verticesA[1] += posA;
+    const f3 edge_dirA = verticesA[0] - verticesA[1];
+    const f3 normalsB[2] = {B.edge_normal(2 * eB), B.edge_normal(2 * eB + 1)};
+    f3 verticesB[2] = {B.edge_vertex(2 * eB), B.edge_vertex(2 * eB + 1)};
+    verticesB[0] += posB; verticesB[1] += posB;
+    const f3 edge_dirB = verticesB[0] - verticesB[1];
+    if (!edges_generate_minkowski_face(normalsA[0], normalsA[1], normalsB[0], normalsB[1], edge_dirA, edge_dirB)) return false;
+    f3 dir = cross(edge_dirA, edge_dirB);
+    if (!try_normalize(dir)) return false;
+    if (dot(verticesA[0] - posA, dir) < 0) dir *= -1.0f;
+    return dot(verticesB[0] - verticesA[0], dir) > threshold + 1e-3f;
+}
+// The separating-axis half: all G lanes of the group call this together (group-uniform arguments) and get the same answer - false when the
+// polyhedra are further apart than the threshold along some axis (no contact points, as the serial routine's early returns).
+template <int G, class Prof>
+DI bool pp_group_axes(const Meshes &t, const PPSide &A, const PPSide &B, f3 posB, float threshold, PPSeparation &sep, Prof &prof) {
+    const int j = (int)(threadIdx.x % G);
+    const f3 posA{0, 0, 0};
+    // face axes of A (poly_max_support_direction(A, B)) and of B ((B, A)): one lane each
+    PPAxis bestA = pp_no_axis(kScalarMax, -kScalarMax), bestB = pp_no_axis(kScalarMax, -kScalarMax);
+    for (int k = j; k < A.nrf + B.nrf; k += G) {
+        if (k < A.nrf) pp_face_axis(t, A, posA, B, posB, k, bestA);
+        else pp_face_axis(t, B, posB, A, posA, k - A.nrf, bestB);
+    }
+    bestA = pp_group_best<G>(bestA);
+    bestB = pp_group_best<G>(bestB);
+    prof.stamp(1);
+    float distance = bestA.dist, projectionA = bestA.projX, projectionB = bestA.projY;
+    f3 sep_axis = bestA.dir;
+    uint32_t hint = bestA.idx != kNoAxis ? kHintFaceA | (uint32_t)bestA.idx : 0u;
+    if (bestB.dist > distance) {   // (the second call's X is B: projX is B's projection)
+        distance = bestB.dist; projectionA = bestB.projY * -1.0f; projectionB = bestB.projX * -1.0f; sep_axis = bestB.dir * -1.0f;
+        hint = kHintFaceB | (uint32_t)bestB.idx;
+    }
+    sep.hint = hint;
+    if (distance > threshold) { prof.stamp(2); return false; }
+    // edge pairs in the serial order eA * ne(B) + eB, G at a time (ascending per lane: the strict `>` keeps a lane's first; the group
+    // reduction keeps the lowest index among equal distances)
+    PPAxis edge = pp_no_axis(-kScalarMax, 0);
+    if (A.ne > 0 && B.ne > 0) {
+        const int pairs = A.ne * B.ne;
+        int eA = j / B.ne, eB = j % B.ne;
+        for (int k = j; k < pairs; k += G) {
+            const f3 normalsA[2] = {A.edge_normal(2 * eA), A.edge_normal(2 * eA + 1)};
+            f3 verticesA[2] = {A.edge_vertex(2 * eA), A.edge_vertex(2 * eA + 1)};
+            verticesA[0] += posA; verticesA[1] += posA;
+            const f3 edge_dirA = verticesA[0] - verticesA[1];
+            const f3 normalsB[2] = {B.edge_normal(2 * eB), B.edge_normal(2 * eB + 1)};
+            f3 verticesB[2] = {B.edge_vertex(2 * eB), B.edge_vertex(2 * eB + 1)};
+            verticesB[0] += posB; verticesB[1] += posB;
+            const f3 edge_dirB = verticesB[0] - verticesB[1];
+            if (edges_generate_minkowski_face(normalsA[0], normalsA[1], normalsB[0], normalsB[1], edge_dirA, edge_dirB)) {
+                f3 dir = cross(edge_dirA, edge_dirB);
+                if (try_normalize(dir)) {
+                    if (dot(verticesA[0] - posA, dir) < 0) dir *= -1.0f;
+                    const float edge_dist = dot(verticesB[0] - verticesA[0], dir);
+                    if (edge_dist > edge.dist) {
+                        dir *= -1.0f;
+                        edge = PPAxis{edge_dist, dot(verticesA[0], dir), dot(verticesB[0], dir), dir, k};
+                    }
                 }
             }
+            eB += G;
+            while (eB >= B.ne) { eB -= B.ne; ++eA; }
         }
     }
+    edge = pp_group_best<G>(edge);
+    const float edge_distance = edge.projX - edge.projY;
+    if (edge_distance > distance) {
+        distance = edge_distance; projectionA = edge.projX; projectionB = edge.projY; sep_axis = edge.dir;
+        if (edge.idx != kNoAxis && (uint32_t)edge.idx <= kHintIndex) hint = kHintEdge | (uint32_t)edge.idx;
+    }
+    prof.stamp(2);
+    sep = PPSeparation{sep_axis, distance, projectionA, projectionB, hint};
+    return !(distance > threshold);
+}
+// The contact half, for a pair pp_group_axes let through: the two support polygons along the axis, their hulls, the clipping. Lane 0 of the
+// group holds the result.
+template <int G, class Prof>
+DI void pp_group_contacts(const PPSide &A, const PPSide &B, const Ctx &ctx, const PPSeparation &sep, PPLds &lds, CResult &result, Prof &prof) {
+    const int j = (int)(threadIdx.x % G);
+    const f3 posA{0, 0, 0};
+    const f3 posB = ctx.posB - ctx.posA;
+    pp_group_polygon<G>(lds.poly[0], A, posA, sep.axis, sep.projectionA, true, kSupportTolerance);
+    pp_group_polygon<G>(lds.poly[1], B, posB, sep.axis, sep.projectionB, false, kSupportTolerance);
+    pp_group_sync();
+    prof.stamp(3);
+    if (j < 2) calculate_convex_hull(lds.poly[j], 0.001f, lds.stack[j]);
+    pp_group_sync();
+    prof.stamp(4);
+    if (j == 0) polygon_polygon_contacts(lds.poly[0], lds.poly[1], posA, ctx.ornA, posB, ctx.ornB, sep.axis, sep.distance, result);
+    prof.stamp(5);
 }
 
 // ---- collide(polyhedron, box)   collide_polyhedron_box.cpp:14-290 (in the polyhedron's space)

@@ -246,9 +246,10 @@ int mesh_bind_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const int32_t *
     if (!any && !c->has_polyhedron) return EDYNHIP_OK;
     c->has_polyhedron = c->has_polyhedron || any;
     if (!c->poly_work) {   // the polyhedron narrowphase's binning scratch (narrowphase.hip PolyBins), with the first polyhedron of the context
-        const size_t words = 3 * 1024 + 1 + 2 * (size_t)c->m[0].cap;
+        const size_t cap = c->m[0].cap, words = 3 * 1024 + 1 + 4 * cap;   // bins, total, keys, list, two hint arrays
         EH_HIP(c, hipMalloc((void **)&c->poly_work, words * sizeof(uint32_t)));
         EH_HIP(c, hipMemsetAsync(c->poly_work, 0, (3 * 1024 + 1) * sizeof(uint32_t), c->stream));
+        EH_HIP(c, hipMemsetAsync(c->poly_work + 3 * 1024 + 1 + 2 * cap, 0, 2 * cap * sizeof(uint32_t), c->stream));   // no hints yet
     }
     if (c->rot_used > c->rot_cap) {   // contents are recomputed before every use: nothing to carry over
         EH_HIP(c, hipStreamSynchronize(c->stream));

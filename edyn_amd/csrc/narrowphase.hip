@@ -123,10 +123,19 @@ k_np_detect_ext(uint32_t M, Manifolds mf, Bodies b, bool sleeping, Staging st) {
 // 2.01 -> 1.20 ms on the 32k-polyhedron heap (+0.055 ms for the three binning kernels). Measured and dropped: a first pass that tries only
 // the cheap separating axes and compacts the survivors (56 % of the listed pairs are separated along a face normal) so that the full
 // routine runs in full waves - 0.25 + 1.10 ms: the survivors' waves diverge more (support polygons, clipping cases) and run one per SIMD.
-constexpr uint32_t kPolyBins = 1024;   // 32 x 32: a mesh id mod 24, or 24 + the shape type of the other body
-struct PolyBins { uint32_t *count, *start, *cursor, *total, *key, *list; };   // count / start / cursor: [kPolyBins]; key, list: [max_manifolds]
-DI uint32_t poly_class(int t, float4 s) { return t == SHAPE_POLYHEDRON ? (uint32_t)s.x % 24u : 24u + (uint32_t)t; }
-__global__ void __launch_bounds__(256) k_poly_count(uint32_t M, Manifolds mf, Bodies b, bool sleeping, PolyBins pb) {
+// Round 5: the bins of polyhedron-polyhedron pairs come first in the list (keys below kPolyPairBins) and are walked by their own kernel,
+// k_np_detect_pp, a GROUP of lanes per pair (dpolyhedron.hpp collide_polyhedron_polyhedron_group); the other pairs keep one lane each.
+constexpr uint32_t kPolyBins = 1024;
+constexpr uint32_t kPolyPairBins = 24 * 24;   // (mesh id mod 24) x (mesh id mod 24); then 2 x 24 x 8: (which side holds the polyhedron, its class, the other body's shape type)
+struct PolyBins { uint32_t *count, *start, *cursor, *total, *key, *list, *hint; };   // count / start / cursor: [kPolyBins]; key, list, hint: [max_manifolds]
+// hint: per manifold of THIS manifold array, the separating axis that decided the pair last time (dpolyhedron.hpp pp_hint_separates); one
+// array per manifold array, carried over by k_poly_count through prev_idx when the broadphase rebuilt the manifolds.
+DI uint32_t poly_bin(int tA, float4 sA, int tB, float4 sB) {
+    const uint32_t cA = (uint32_t)sA.x % 24u, cB = (uint32_t)sB.x % 24u;
+    if (tA == SHAPE_POLYHEDRON && tB == SHAPE_POLYHEDRON) return cA * 24u + cB;
+    return tA == SHAPE_POLYHEDRON ? kPolyPairBins + cA * 8u + ((uint32_t)tB & 7u) : kPolyPairBins + 192u + cB * 8u + ((uint32_t)tA & 7u);
+}
+__global__ void __launch_bounds__(256) k_poly_count(uint32_t M, Manifolds mf, Bodies b, bool sleeping, PolyBins pb, Meshes meshes, const uint32_t *hint_prev, bool rebuilt, bool use_hints) {
     __shared__ uint32_t hist[kPolyBins];
     for (uint32_t k = threadIdx.x; k < kPolyBins; k += 256) hist[k] = 0;
     __syncthreads();
@@ -138,8 +147,16 @@ __global__ void __launch_bounds__(256) k_poly_count(uint32_t M, Manifolds mf, Bo
         const int tA = (int)((fa & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT), tB = (int)((fb & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
         if ((tA == SHAPE_POLYHEDRON || tB == SHAPE_POLYHEDRON) && !(sleeping && edge_asleep(fa, fb))) {
             const box3 ba{from4(b.amin[ia]), from4(b.amax[ia])}, bbx{from4(b.amin[ib]), from4(b.amax[ib])};
-            if (intersect(inset(ba, -kBreakingThreshold), bbx)) key = poly_class(tA, b.shape[ia]) * 32u + poly_class(tB, b.shape[ib]);
+            if (intersect(inset(ba, -kBreakingThreshold), bbx)) key = poly_bin(tA, b.shape[ia], tB, b.shape[ib]);
         }
+        // the pair's hint follows it into a rebuilt manifold array; a polyhedron pair that its hinted axis still separates is done (k_np_detect
+        // left it without points) and stays out of the list
+        uint32_t hint = 0;
+        if (rebuilt) { const uint32_t p = mf.prev_idx[m]; if (p < mf.cap) hint = hint_prev[p]; } else hint = pb.hint[m];
+        pb.hint[m] = hint;
+        if (use_hints && hint != 0 && key < kPolyPairBins &&
+            pp_hint_separates(meshes, pp_side(meshes, b.shape[ia], meshes.rot + meshes.rot_off[ia]), pp_side(meshes, b.shape[ib], meshes.rot + meshes.rot_off[ib]),
+                              B_ORG(b, ib) - B_ORG(b, ia), kCollisionThreshold, hint)) key = 0xFFFFFFFFu;
         pb.key[m] = key;
     }
     if (key != 0xFFFFFFFFu) atomicAdd(&hist[key], 1u);
@@ -178,8 +195,8 @@ __global__ void __launch_bounds__(256) k_poly_scatter(uint32_t M, PolyBins pb) {
 // (register budget: 1 / 2 / 4 / 8 / 16 workgroups per CU as the launch bound gave 231 / 251 / 240 / 235 / 220 steps/s on polyheap32k -
 // two leaves the allocator enough registers to keep the polygons' scalars out of scratch and still lets a second wave hide latency)
 __global__ void __launch_bounds__(64, 2)
-k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, Staging st, Meshes meshes, PolyBins pb) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, Staging st, Meshes meshes, PolyBins pb, bool pp_elsewhere) {
+    const uint32_t i = (pp_elsewhere ? pb.start[kPolyPairBins] : 0u) + blockIdx.x * blockDim.x + threadIdx.x;   // polyhedron pairs: k_np_detect_pp
     if (i >= M || i >= *pb.total) return;
     const uint32_t m = pb.list[i];
     const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
@@ -196,6 +213,89 @@ k_np_detect_poly(uint32_t M, Manifolds mf, Bodies b, Staging st, Meshes meshes, 
         st.ra[d] = to4(res.pt[k].pivotA, res.pt[k].distance);
         st.rb[d] = to4(res.pt[k].pivotB, __int_as_float(res.pt[k].attachment));
         st.rn[d] = to4(res.pt[k].normal, 0.0f);
+    }
+}
+
+// Polyhedron-polyhedron pairs, G lanes per pair, in two kernels (round 5). The binned list's first pb.start[kPolyPairBins] entries are such pairs
+// (the count lives on the device: fixed grids stride over them).
+//   k_np_pp_axes      the separating axes (dpolyhedron.hpp pp_group_axes): no LDS, few registers - many waves per SIMD hide its dependent
+//                     loads (list -> bodies -> mesh tables -> rotated vertices). A pair within the threshold leaves its axis in its staging
+//                     slot and its manifold index in the survivor list (the key array, free once the scatter ran; counter: the cursor of
+//                     the unused bin 1023, zeroed by k_poly_scan); a separated pair is done (no points).
+//   k_np_pp_contacts  support polygons, hulls, clipping of the survivors (pp_group_contacts), polygons in LDS.
+// Profile that decided the split (one kernel, G = 16, polyheap32k: 300-400k pairs per step): faces 8.8 us + edges 8.1 us of dependent-load
+// latency per pair-iteration at two waves per SIMD (251 VGPRs, the contact half's), polygons + hulls + contacts 3.3 us, 38 % of the pairs survive.
+DI PPSide pp_side_of(const Meshes &meshes, const Bodies &b, uint32_t body) { return pp_side(meshes, b.shape[body], meshes.rot + meshes.rot_off[body]); }
+template <int G, bool PROF>
+__global__ void __launch_bounds__(64)
+k_np_pp_axes(Manifolds mf, Bodies b, Staging st, Meshes meshes, PolyBins pb, unsigned long long *prof_out) {
+    constexpr uint32_t kGroups = 64u / G;
+    const uint32_t g = threadIdx.x / G;
+    const uint32_t n = pb.start[kPolyPairBins];
+    PPProf<PROF> prof;
+    if (PROF) for (int k = 0; k < 8; ++k) prof.t[k] = 0;
+    uint32_t iters = 0;
+    for (uint32_t i = blockIdx.x * kGroups + g; i < n; i += gridDim.x * kGroups) {
+        prof.stamp(0);
+        const uint32_t m = pb.list[i];
+        const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+        PPSeparation sep;
+        const bool touching = pp_group_axes<G>(meshes, pp_side_of(meshes, b, ia), pp_side_of(meshes, b, ib), B_ORG(b, ib) - B_ORG(b, ia), kCollisionThreshold, sep, prof);
+        if (threadIdx.x % G == 0) {
+            pb.hint[m] = sep.hint;
+            if (touching) {
+                pb.key[atomicAdd(&pb.cursor[kPolyBins - 1], 1u)] = m;
+                st.ra[m] = to4(sep.axis, sep.distance);
+                st.rb[m] = make_float4(sep.projectionA, sep.projectionB, 0.0f, 0.0f);
+            } else {
+                st.rnum[m] = 0;
+            }
+        }
+        prof.stamp(3);
+        ++iters;
+    }
+    if (PROF && threadIdx.x % G == 0) {   // [0]: pairs; [1..3]: ticks of setup + faces, edges, stores + waiting for the wave's other groups
+        atomicAdd(&prof_out[0], (unsigned long long)iters);
+        for (int k = 1; k < 4; ++k) atomicAdd(&prof_out[k], (unsigned long long)(prof.t[k] - prof.t[k - 1]));
+    }
+}
+template <int G, bool PROF>
+__global__ void __launch_bounds__(64)
+k_np_pp_contacts(Manifolds mf, Bodies b, Staging st, Meshes meshes, PolyBins pb, unsigned long long *prof_out) {
+    constexpr uint32_t kGroups = 64u / G;
+    __shared__ __align__(16) unsigned char lds_raw[kGroups * sizeof(PPLds)];
+    const uint32_t g = threadIdx.x / G;
+    PPLds &lds = reinterpret_cast<PPLds *>(lds_raw)[g];
+    const uint32_t n = pb.cursor[kPolyBins - 1];
+    PPProf<PROF> prof;
+    if (PROF) for (int k = 0; k < 8; ++k) prof.t[k] = 0;
+    uint32_t iters = 0;
+    for (uint32_t i = blockIdx.x * kGroups + g; i < n; i += gridDim.x * kGroups) {
+        prof.stamp(2);
+        const uint32_t m = pb.key[i];
+        const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
+        const float4 r0 = st.ra[m], r1 = st.rb[m];
+        const PPSeparation sep{from4(r0), r0.w, r1.x, r1.y};
+        CResult res;
+        res.num = 0;
+        const Ctx ctx{B_ORG(b, ia), q_from4(B_ORN(b, ia)), B_ORG(b, ib), q_from4(B_ORN(b, ib)), kCollisionThreshold};
+        pp_group_contacts<G>(pp_side_of(meshes, b, ia), pp_side_of(meshes, b, ib), ctx, sep, lds, res, prof);
+        if (threadIdx.x % G == 0) {
+            st.rnum[m] = (uint32_t)res.num;
+            for (int k = 0; k < res.num; ++k) {
+                const size_t d = (size_t)k * mf.cap + m;
+                st.ra[d] = to4(res.pt[k].pivotA, res.pt[k].distance);
+                st.rb[d] = to4(res.pt[k].pivotB, __int_as_float(res.pt[k].attachment));
+                st.rn[d] = to4(res.pt[k].normal, 0.0f);
+            }
+        }
+        pp_group_sync();   // the next pair's polygons overwrite this one's
+        prof.stamp(6);
+        ++iters;
+    }
+    if (PROF && threadIdx.x % G == 0) {   // [4]: survivors; [5..8]: ticks of setup + polygons, hulls, contacts, stores + waiting
+        atomicAdd(&prof_out[4], (unsigned long long)iters);
+        for (int k = 3; k < 7; ++k) atomicAdd(&prof_out[k + 2], (unsigned long long)(prof.t[k] - prof.t[k - 1]));
     }
 }
 
@@ -459,7 +559,7 @@ __global__ void __launch_bounds__(64, EXT ? 1 : 2) k_debug_collide(uint32_t n, c
 // Pairs with a polyhedron: one workgroup per pair - its lanes rotate the pair's meshes into scratch (update_rotated_mesh), lane 0 collides.
 __global__ void __launch_bounds__(64)
 k_debug_collide_poly(uint32_t first, uint32_t n, const int32_t *__restrict__ st, const float4 *__restrict__ sp, const float *__restrict__ pos,
-                     const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count, Meshes meshes, float4 *scratch, uint32_t stride) {
+                     const float4 *__restrict__ orn, float threshold, float *out, uint32_t *count, Meshes meshes, float4 *scratch, uint32_t stride, int group) {
     const uint32_t i = first + blockIdx.x;
     if (blockIdx.x >= n) return;
     const int tA = st[2 * i], tB = st[2 * i + 1];
@@ -472,12 +572,25 @@ k_debug_collide_poly(uint32_t first, uint32_t n, const int32_t *__restrict__ st,
         for (uint32_t k = threadIdx.x; k < d.rot_size; k += 64) rotate_mesh_item(meshes, d, q, rot[side], k);
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
     Ctx ctx{mk3(pos[6 * i], pos[6 * i + 1], pos[6 * i + 2]), q_from4(orn[2 * i]), mk3(pos[6 * i + 3], pos[6 * i + 4], pos[6 * i + 5]),
             q_from4(orn[2 * i + 1]), threshold};
     CResult r;
     r.num = 0;
-    collide_poly(meshes, tA, sp[2 * i], rot[0], tB, sp[2 * i + 1], rot[1], ctx, r);
+    if (group != 0 && tA == SHAPE_POLYHEDRON && tB == SHAPE_POLYHEDRON) {   // the first `group` lanes of the workgroup: what k_np_pp_axes + k_np_pp_contacts run
+        __shared__ __align__(16) unsigned char lds_raw[sizeof(PPLds)];
+        PPLds &lds = *reinterpret_cast<PPLds *>(lds_raw);
+        if ((int)threadIdx.x >= group) return;
+        PPProf<false> noprof;
+        const PPSide A = pp_side(meshes, sp[2 * i], rot[0]), B = pp_side(meshes, sp[2 * i + 1], rot[1]);
+        PPSeparation sep;
+        if (group == 16) { if (pp_group_axes<16>(meshes, A, B, ctx.posB - ctx.posA, ctx.threshold, sep, noprof)) pp_group_contacts<16>(A, B, ctx, sep, lds, r, noprof); }
+        else if (group == 4) { if (pp_group_axes<4>(meshes, A, B, ctx.posB - ctx.posA, ctx.threshold, sep, noprof)) pp_group_contacts<4>(A, B, ctx, sep, lds, r, noprof); }
+        else if (pp_group_axes<8>(meshes, A, B, ctx.posB - ctx.posA, ctx.threshold, sep, noprof)) pp_group_contacts<8>(A, B, ctx, sep, lds, r, noprof);
+        if (threadIdx.x != 0) return;
+    } else {
+        if (threadIdx.x != 0) return;
+        collide_poly(meshes, tA, sp[2 * i], rot[0], tB, sp[2 * i + 1], rot[1], ctx, r);
+    }
     count[i] = (uint32_t)r.num;
     for (int k = 0; k < r.num; ++k) {
         float *o = out + ((size_t)i * 4 + k) * 11;
@@ -521,12 +634,13 @@ int debug_collide(edynhip_ctx *c, uint32_t n, const int32_t *st, const float *sp
             uint32_t stride = 0;
             for (const MeshDesc &md : c->host_meshes.desc) stride = std::max(stride, md.rot_size);
             const uint32_t chunk = 16384;
+            const int group = getenv("EDYNHIP_POLY_GROUP") ? atoi(getenv("EDYNHIP_POLY_GROUP")) : 8;   // (as narrowphase() below)
             float4 *scratch = nullptr;
             e = hipMalloc((void **)&scratch, (size_t)chunk * 2 * stride * sizeof(float4));
             for (uint32_t first = 0; first < n && e == hipSuccess; first += chunk) {
                 const uint32_t cnt = std::min(chunk, n - first);
                 hipLaunchKernelGGL(k_debug_collide_poly, dim3(cnt), dim3(64), 0, s, first, cnt, (const int32_t *)d, (const float4 *)(d + o_sp), (const float *)(d + o_pos),
-                                   (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt), c->meshes, scratch, stride);
+                                   (const float4 *)(d + o_orn), threshold, (float *)(d + o_out), (uint32_t *)(d + o_cnt), c->meshes, scratch, stride, group);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (scratch) (void)hipFree(scratch);
@@ -548,12 +662,50 @@ int narrowphase(edynhip_ctx *c) {
     if (c->has_cylinder) hipLaunchKernelGGL(k_np_detect_ext, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, st);
     if (c->has_polyhedron) {
         EH_TRY(update_rotated(c));
-        uint32_t *pw = c->poly_work;   // [count | start | cursor : kPolyBins each][total][key : cap][list : cap], allocated with the first polyhedron (mesh.hip)
-        const PolyBins pb{pw, pw + kPolyBins, pw + 2 * kPolyBins, pw + 3 * kPolyBins, pw + 3 * kPolyBins + 1, pw + 3 * kPolyBins + 1 + c->m[0].cap};
-        hipLaunchKernelGGL(k_poly_count, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, pb);
+        uint32_t *pw = c->poly_work;   // [count | start | cursor : kPolyBins each][total][key : cap][list : cap][hint : 2 x cap], allocated with the first polyhedron (mesh.hip)
+        const size_t cap = c->m[0].cap;
+        uint32_t *const hints = pw + 3 * kPolyBins + 1 + 2 * cap;   // [2][cap]: one hint array per manifold array
+        const PolyBins pb{pw, pw + kPolyBins, pw + 2 * kPolyBins, pw + 3 * kPolyBins, pw + 3 * kPolyBins + 1, pw + 3 * kPolyBins + 1 + cap, hints + (size_t)c->cur * cap};
+        static const bool use_hints = !(getenv("EDYNHIP_POLY_HINT") && getenv("EDYNHIP_POLY_HINT")[0] == '0');   // developer knob (A/B)
+        hipLaunchKernelGGL(k_poly_count, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, c->m[c->cur], c->b, c->sleeping, pb, c->meshes, hints + (size_t)(c->cur ^ 1) * cap,
+                           !c->inplace_step, use_hints);
         hipLaunchKernelGGL(k_poly_scan, dim3(1), dim3(1024), 0, c->stream, pb);
         hipLaunchKernelGGL(k_poly_scatter, dim3((M + 255) / 256), dim3(256), 0, c->stream, M, pb);
-        hipLaunchKernelGGL(k_np_detect_poly, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, st, c->meshes, pb);
+        // developer knobs (A/B): EDYNHIP_POLY_GROUP=0 the round-4 form (k_np_detect_poly for polyhedron pairs too), =8 / 16 lanes per pair in the separating-axis kernel (default 8)
+        static const int group = getenv("EDYNHIP_POLY_GROUP") ? atoi(getenv("EDYNHIP_POLY_GROUP")) : 8;
+        if (group != 0) {
+            const uint32_t waves = 5120;   // 20 per CU of an MI355X (the axes kernel runs five per SIMD): the grids stride over the pairs
+            static const int group2 = getenv("EDYNHIP_POLY_GROUP2") ? atoi(getenv("EDYNHIP_POLY_GROUP2")) : 4;   // lanes per surviving pair: 4 (default: 16 pairs per wave), 8 or 16
+            static const bool prof = getenv("EDYNHIP_PP_PROF") != nullptr;   // developer profile of the phases: printed every 100th step
+            static unsigned long long *prof_dev = nullptr;
+            static int prof_calls = 0;
+            if (prof && !prof_dev) { EH_HIP(c, hipMalloc((void **)&prof_dev, 128)); EH_HIP(c, hipMemsetAsync(prof_dev, 0, 128, c->stream)); }
+            const Manifolds &mfc = c->m[c->cur];
+            unsigned long long *const pd = prof ? prof_dev : nullptr;
+            // (measured and dropped: the contact kernel compiled for three waves per SIMD - 168 VGPRs and 260 B of spills - 324 -> 304 steps/s on polyheap32k)
+            if (prof) {
+                if (group == 16) hipLaunchKernelGGL((k_np_pp_axes<16, true>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                else hipLaunchKernelGGL((k_np_pp_axes<8, true>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                if (group2 == 8) hipLaunchKernelGGL((k_np_pp_contacts<8, true>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                else hipLaunchKernelGGL((k_np_pp_contacts<4, true>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+            } else {
+                if (group == 16) hipLaunchKernelGGL((k_np_pp_axes<16, false>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                else hipLaunchKernelGGL((k_np_pp_axes<8, false>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                if (group2 == 8) hipLaunchKernelGGL((k_np_pp_contacts<8, false>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                else if (group2 == 16) hipLaunchKernelGGL((k_np_pp_contacts<16, false>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+                else hipLaunchKernelGGL((k_np_pp_contacts<4, false>), dim3(waves), dim3(64), 0, c->stream, mfc, c->b, st, c->meshes, pb, pd);
+            }
+            if (prof && ++prof_calls % 100 == 0) {
+                unsigned long long h[16];
+                EH_HIP(c, hipMemcpyAsync(h, prof_dev, 128, hipMemcpyDeviceToHost, c->stream));
+                EH_HIP(c, hipStreamSynchronize(c->stream));
+                EH_HIP(c, hipMemsetAsync(prof_dev, 0, 128, c->stream));
+                const double p = 100.0 * (double)std::max<unsigned long long>(h[0], 1), q = 100.0 * (double)std::max<unsigned long long>(h[4], 1);
+                fprintf(stderr, "[pp prof, G=%d/%d] pairs/step %.0f, us per pair-iteration: setup+faces %.2f edges %.2f stores+wait %.2f; survivors/step %.0f: setup+polygons %.2f hulls %.2f contacts %.2f stores+wait %.2f\n",
+                        group, group2, h[0] / 100.0, h[1] / p, h[2] / p, h[3] / p, h[4] / 100.0, h[5] / q, h[6] / q, h[7] / q, h[8] / q);
+            }
+        }
+        hipLaunchKernelGGL(k_np_detect_poly, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, st, c->meshes, pb, group != 0);
     }
     hipLaunchKernelGGL(k_np_merge, dim3((M + 63) / 64), dim3(64), 0, c->stream, M, c->m[c->cur], c->b, c->cfg.fixed_dt, c->sleeping, c->m[c->cur ^ 1], c->points_in_prev, st, event_sink(c));
     c->points_in_prev = false;
