@@ -430,7 +430,7 @@ def test_polyhedron_collide_routines_bit_exact_on_random_pairs(other):
 
 def test_polyhedra_bit_exact():
     """polyhedron_shape on the device: mesh inertia, AABB from the mesh's point cloud, the rotated meshes refreshed
-    before every narrowphase, the six pair routines in k_np_detect_poly - a tumbling heap of polyhedra, cylinders, capsules, boxes and
+    before every narrowphase, the six pair routines in k_np_detect_poly / k_np_pp_axes + k_np_pp_contacts - a tumbling heap of polyhedra, cylinders, capsules, boxes and
     spheres against the oracle: pairs, state, manifolds, AABBs and world inertias; the oracle's polyhedra are pinned to the real engine
     in tests/test_reference_engine.py. Then bodies appended to the running world, and a state edit between steps."""
     from test_reference_engine import _polyhedron_scene
@@ -533,7 +533,8 @@ def test_user_should_collide_predicate_bit_exact():
 def test_polyhedron_heap_at_size_bit_exact():
     """4096 convex polyhedra (edyn_amd.scenes.polyhedron_heap: cubes, tetrahedra, octahedra, prisms, wedges, random orientations)
     collapsing into a heap: pairs, state, manifolds (points in list order, impulses, colours) and AABBs equal the oracle's bit for bit
-    after 50, 100 and 150 steps - 10k+ polyhedron-polyhedron manifolds through k_np_detect_poly every step."""
+    after 50, 100 and 150 steps - 10k+ polyhedron-polyhedron manifolds through k_np_pp_axes / k_np_pp_contacts every step, most of the separated ones
+    through the separating-axis hints of k_poly_count."""
     sc = scenes.polyhedron_heap(16, 16, 16)
     g, o = gpu_world(sc), oracle_world(sc)
     for s in range(1, 151):
