@@ -417,9 +417,11 @@ __global__ void __launch_bounds__(1024) k_col_prepare(uint32_t M, uint32_t *__re
 // The rounds for a list of uncoloured edges that one workgroup can hold - the steady state: some hundred (a restless heap: some
 // thousand) new contacts per step - run in one workgroup with workgroup barriers between the phases instead of two launches per
 // round; same rule, same result as k_col_best / k_col_assign. The edges' endpoints sit in LDS (index | dynamic << 31), the list is
-// compacted as edges take their colour (a round only visits what is still uncoloured), and the endpoint marks alternate between the
-// two `best` arrays like the multi-block rounds' (a round zeroes the next round's marks while it sets its own). Longer lists, and
-// what is left after max_rounds, go to the multi-block rounds (the host sees cnt->uncoloured != 0).
+// compacted as edges take their colour (a round only visits what is still uncoloured). The endpoint marks carry the round in their upper
+// half - (round + 1) << 32 | priority - so a mark of an earlier round loses against any mark of this one and nothing has to be zeroed
+// between rounds (round 5: the workgroup is bound by the memory requests one CU can issue - a restless heap of polyhedra lists 15 000
+// edges per step and still has two thirds of them after three rounds; the zeroing stores were two of six requests per edge and round).
+// Longer lists, and what is left after max_rounds, go to the multi-block rounds (the host sees cnt->uncoloured != 0).
 __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
                                                      const uint32_t *__restrict__ flags, uint64_t *best0, uint64_t *best1, uint64_t *used, Counters *cnt,
                                                      uint32_t *list, uint32_t cap, uint32_t max_rounds) {
@@ -441,12 +443,13 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
     for (; round < max_rounds; ++round) {
         const uint32_t n = live;
         if (n == 0) break;
-        uint64_t *cur = (round & 1u) ? best1 : best0, *nxt = (round & 1u) ? best0 : best1;
+        uint64_t *cur = best0;
+        const uint64_t stamp = (uint64_t)(round + 1u) << 32;   // (edge_prio fits the lower half)
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {           // phase 1: every endpoint learns its best uncoloured edge
-            const uint64_t pr = edge_prio(list[e]);
+            const uint64_t pr = stamp | edge_prio(list[e]);
             const uint32_t a = ea[e], b = eb[e];
-            if (a >> 31) { atomicMax((unsigned long long *)&cur[a & 0x7FFFFFFFu], pr); nxt[a & 0x7FFFFFFFu] = 0; }
-            if (b >> 31) { atomicMax((unsigned long long *)&cur[b & 0x7FFFFFFFu], pr); nxt[b & 0x7FFFFFFFu] = 0; }
+            if (a >> 31) atomicMax((unsigned long long *)&cur[a & 0x7FFFFFFFu], pr);
+            if (b >> 31) atomicMax((unsigned long long *)&cur[b & 0x7FFFFFFFu], pr);
         }
         if (threadIdx.x == 0) wr = 0;
         __threadfence_block(); __syncthreads();   // one workgroup, one CU: its stores only have to reach L2 before the other waves' (atomic) loads
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
                 m = list[e]; a = ea[e]; b = eb[e];
                 const bool da = a >> 31, db = b >> 31;
                 const uint32_t ia = a & 0x7FFFFFFFu, ib = b & 0x7FFFFFFFu;
-                const uint64_t pr = edge_prio(m);
+                const uint64_t pr = stamp | edge_prio(m);
                 if ((da && ld(&cur[ia]) != pr) || (db && ld(&cur[ib]) != pr)) keep = true;
                 else {
                     const uint64_t busy = (da ? ld(&used[ia]) : 0ull) | (db ? ld(&used[ib]) : 0ull);
