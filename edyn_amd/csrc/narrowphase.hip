@@ -676,7 +676,7 @@ int narrowphase(edynhip_ctx *c) {
         if (group != 0) {
             const uint32_t waves = 5120;   // 20 per CU of an MI355X (the axes kernel runs five per SIMD): the grids stride over the pairs
             static const int group2 = getenv("EDYNHIP_POLY_GROUP2") ? atoi(getenv("EDYNHIP_POLY_GROUP2")) : 4;   // lanes per surviving pair: 4 (default: 16 pairs per wave), 8 or 16
-            static const bool prof = getenv("EDYNHIP_PP_PROF") != nullptr;   // developer profile of the phases: printed every 100th step
+            static const bool prof = getenv("EDYNHIP_PP_PROF") != nullptr;   // developer profile of the phases: printed every 100th step (one context, one device: its counters are process-wide)
             static unsigned long long *prof_dev = nullptr;
             static int prof_calls = 0;
             if (prof && !prof_dev) { EH_HIP(c, hipMalloc((void **)&prof_dev, 128)); EH_HIP(c, hipMemsetAsync(prof_dev, 0, 128, c->stream)); }
