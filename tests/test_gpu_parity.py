@@ -886,6 +886,31 @@ def test_sleeping_island_wakes_when_hit_bit_exact():
     assert not g.get_asleep().any()
 
 
+def test_sleeping_polyhedra_fall_asleep_and_wake_bit_exact():
+    """Eighteen polyhedra tumble, settle and fall asleep; a nineteenth, appended later, lands on them and wakes most of the heap while
+    three islands sleep on: sleeping flags and state against the oracle at every step, manifolds when everything sleeps and at the end.
+    The polyhedron pairs run through the separating-axis hints, the axis kernel and the contact kernel (narrowphase.hip) all the way:
+    hints carried while their pairs sleep, through rebuilt manifold arrays and into pairs that touch again."""
+    scene = scenes.polyhedron_heap(3, 3, 2)
+    g, o = _sleep_worlds(scene, max_bodies=32)
+    for step in range(420):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, step)
+    assert g.get_asleep()[1:].all()
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="asleep")
+    extra = _shifted(scenes.polyhedron_heap(1, 1, 1), 4.0)
+    extra["pos"][:, 0] += 0.2
+    g.add_scene(extra); o.add_bodies(extra)
+    fewest = 19
+    for step in range(300):
+        g.step_simulation(1); o.step(1)
+        _assert_same(g, o, ("after the drop", step))
+        fewest = min(fewest, int(g.get_asleep().sum()))
+    assert fewest <= 8                       # the heap woke ...
+    assert 0 < int(g.get_asleep().sum()) < 19   # ... not all of it, and the last mover is still awake or just came to rest
+    assert_manifolds_equal(g.get_manifolds(), o.get_manifolds(), what="after the wake")
+
+
 def test_sleeping_off_by_default_and_flag_does_not_change_awake_physics():
     scene = scenes.box_pile(4, 4, 4)
     g0 = gpu_world(scene)
