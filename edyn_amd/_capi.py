@@ -78,6 +78,15 @@ FLAG_FUSED_VELOCITY_ROWS, FLAG_BLOCK_POSITION = 64, 128   # opt-in contact arith
 PAIR_FILTER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)   # edynhip_pair_filter: int filter(void *user, uint32_t body, uint32_t other)
 EVENT_DTYPE = np.dtype([("type", np.uint32), ("step", np.uint32), ("body", np.uint32, 2), ("point_id", np.uint64)])
 EVENT_MANIFOLD_CREATED, EVENT_MANIFOLD_DESTROYED, EVENT_POINT_CREATED, EVENT_POINT_DESTROYED = 1, 2, 3, 4
+# edynhip_body_record (96 B) and edynhip_record_view: the registry write-back read in place (edynhip_snapshot_records / _map)
+RECORD_DTYPE = np.dtype([("pos", np.float32, 3), ("orn", np.float32, 4), ("linvel", np.float32, 3), ("angvel", np.float32, 3),
+                         ("present_pos", np.float32, 3), ("present_orn", np.float32, 4), ("origin", np.float32, 3), ("flags", np.uint32)])
+RECORD_DYNAMIC, RECORD_ASLEEP, RECORD_HAS_ORIGIN, RECORD_REMOVED = 1, 2, 4, 8
+
+
+class RecordView(C.Structure):
+    _fields_ = [("records", C.c_void_p), ("num_bodies", C.c_uint32), ("step_index", C.c_uint32), ("events", C.c_void_p),
+                ("num_events", C.c_uint32), ("total_events", C.c_uint32)]
 STAGE_BROADPHASE, STAGE_NARROWPHASE, STAGE_ISLANDS, STAGE_SOLVE, STAGE_ALL = 1, 2, 4, 8, 15
 
 # every symbol include/edynhip.h declares (checked by tests/test_abi.py)
@@ -88,7 +97,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_set_pair_filter", "edynhip_default_should_collide", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies", "edynhip_set_center_of_mass",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
-           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read",
+           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read", "edynhip_snapshot_records", "edynhip_snapshot_map",
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
            "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing",
            "edynhip_measure_bandwidth", "edynhip_set_joint_warm_start", "edynhip_set_asleep", "edynhip_create_convex_mesh",
@@ -142,6 +151,8 @@ def lib():
         L.edynhip_get_contact_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_snapshot.argtypes = [C.c_void_p]
+        L.edynhip_snapshot_records.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+        L.edynhip_snapshot_map.argtypes = [C.c_void_p, C.POINTER(RecordView)]
         L.edynhip_set_joint_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_material_ids.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.edynhip_insert_material_mixing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]

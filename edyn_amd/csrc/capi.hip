@@ -520,7 +520,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 14; }   // 14: EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION (the default contact arithmetic is the reference's); 13: edynhip_set_pair_filter (settings.should_collide_func); 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 15; }   // 15: edynhip_snapshot_records / edynhip_snapshot_map (the registry write-back read in place); 14: EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION (the default contact arithmetic is the reference's); 13: edynhip_set_pair_filter (settings.should_collide_func); 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -571,6 +571,10 @@ void edynhip_destroy(edynhip_ctx *c) {
     for (int k = 0; k < 2; ++k) {
         if (c->snap_host[k]) (void)hipHostFree(c->snap_host[k]);
         if (c->snap_event[k]) (void)hipEventDestroy(c->snap_event[k]);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (c->rec_host[k]) (void)hipHostFree(c->rec_host[k]);
+        if (c->rec_event[k]) (void)hipEventDestroy(c->rec_event[k]);
     }
     if (c->snap_ready) (void)hipEventDestroy(c->snap_ready);
     if (c->snap_stream) (void)hipStreamDestroy(c->snap_stream);
@@ -1601,6 +1605,93 @@ int edynhip_snapshot_read(edynhip_ctx *c, float *pos, float *orn, float *linvel,
         if (angvel) std::memcpy(angvel + 3 * i, o + 10, 12);
     }
     if (step_index) *step_index = c->snap_step[slot];
+    return EDYNHIP_OK;
+}
+
+// ---- record snapshots: the registry write-back read in place (edynhip.h, ABI 15)
+static_assert(sizeof(edynhip_body_record) == 96, "record layout");
+constexpr size_t kRecHeader = 64;   // [0] = events that occurred, [1] = events copied into this block
+__global__ void k_pack_records(uint32_t n, Bodies b, float present_dt, float4 *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p4 = B_POS(b, i), q4v = B_ORN(b, i), v4 = b.linvel[i], w4 = b.angvel[i];
+    const uint32_t fl = b.flags[i];
+    const f3 p = from4(p4), v = from4(v4), w = from4(w4);
+    const q4 q{q4v.x, q4v.y, q4v.z, q4v.w};
+    // update_presentation.cpp:73-79: pre = pos + vel * interpolation_dt; pre = integrate(orn, vel, interpolation_dt)
+    const f3 pp = p + v * present_dt;
+    const q4 po = integrate(q, w, present_dt);
+    const bool has_origin = b.origin && b.com[i].w != 0.0f;
+    const f3 org = has_origin ? from4(b.origin[i]) : p;
+    uint32_t rf = 0;
+    if ((fl & BF_KIND_MASK) == EDYNHIP_KIND_DYNAMIC) rf |= EDYNHIP_RECORD_DYNAMIC;
+    if (fl & BF_ASLEEP) rf |= EDYNHIP_RECORD_ASLEEP;
+    if (has_origin) rf |= EDYNHIP_RECORD_HAS_ORIGIN;
+    if (fl & BF_REMOVED) rf |= EDYNHIP_RECORD_REMOVED;
+    float4 *o = dst + (size_t)i * 6;
+    o[0] = make_float4(p.x, p.y, p.z, q.x);
+    o[1] = make_float4(q.y, q.z, q.w, v.x);
+    o[2] = make_float4(v.y, v.z, w.x, w.y);
+    o[3] = make_float4(w.z, pp.x, pp.y, pp.z);
+    o[4] = make_float4(po.x, po.y, po.z, po.w);
+    o[5] = make_float4(org.x, org.y, org.z, __uint_as_float(rf));
+}
+__global__ void k_pack_events(const eh::ContactEvent *__restrict__ events, const uint32_t *__restrict__ count, uint32_t cap, uint32_t max_copy,
+                              uint32_t *__restrict__ header, eh::ContactEvent *__restrict__ dst) {
+    const uint32_t total = events ? *count : 0u;
+    const uint32_t held = min(min(total, cap), max_copy);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { header[0] = total; header[1] = held; }
+    for (uint32_t k = t; k < held; k += gridDim.x * blockDim.x) dst[k] = events[k];
+}
+int edynhip_snapshot_records(edynhip_ctx *c, float present_dt, uint32_t max_events) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    EH_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = c->b.n;
+    const int slot = (c->rec_last + 1) & 1;
+    if (!c->snap_stream) {
+        EH_HIP(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+        EH_HIP(c, hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
+    }
+    if (!c->rec_dev[0]) {
+        c->rec_event_cap = c->events ? std::min<uint32_t>(c->event_cap, std::max<uint32_t>(4096u, 2u * c->b.cap)) : 0u;
+        const size_t bytes = kRecHeader + (size_t)c->rec_event_cap * sizeof(eh::ContactEvent) + (size_t)c->b.cap * sizeof(edynhip_body_record);
+        for (int k = 0; k < 2; ++k) {
+            EH_HIP(c, hipEventCreateWithFlags(&c->rec_event[k], hipEventDisableTiming));
+            EH_HIP(c, hipHostMalloc((void **)&c->rec_host[k], bytes, hipHostMallocDefault));
+            EH_TRY(dalloc(c, c->rec_dev[k], bytes));
+        }
+    }
+    const uint32_t copy_events = std::min(max_events, c->rec_event_cap);
+    const size_t ev_bytes = (size_t)c->rec_event_cap * sizeof(eh::ContactEvent);
+    uint8_t *d = c->rec_dev[slot], *h = c->rec_host[slot];
+    // pack on the stepper's stream (it must see the finished steps), copy on the side stream: the copy engine moves the bytes
+    // while the stepper's next kernels already run
+    if (n) hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->b, present_dt, (float4 *)(d + kRecHeader + ev_bytes));
+    hipLaunchKernelGGL(k_pack_events, dim3(copy_events > 4096 ? 64 : 4), dim3(256), 0, c->stream, (const eh::ContactEvent *)c->events, (const uint32_t *)c->event_count,
+                       c->event_cap, copy_events, (uint32_t *)d, (eh::ContactEvent *)(d + kRecHeader));
+    EH_HIP(c, hipEventRecord(c->snap_ready, c->stream));
+    EH_HIP(c, hipStreamWaitEvent(c->snap_stream, c->snap_ready, 0));
+    EH_HIP(c, hipMemcpyAsync(h, d, kRecHeader + (size_t)copy_events * sizeof(eh::ContactEvent), hipMemcpyDeviceToHost, c->snap_stream));
+    if (n) EH_HIP(c, hipMemcpyAsync(h + kRecHeader + ev_bytes, d + kRecHeader + ev_bytes, (size_t)n * sizeof(edynhip_body_record), hipMemcpyDeviceToHost, c->snap_stream));
+    EH_HIP(c, hipEventRecord(c->rec_event[slot], c->snap_stream));
+    c->rec_step[slot] = c->step_index; c->rec_bodies[slot] = n; c->rec_events_copied[slot] = copy_events; c->rec_last = slot;
+    return EDYNHIP_OK;
+}
+int edynhip_snapshot_map(edynhip_ctx *c, edynhip_record_view *view) {
+    if (!c || !view) return EDYNHIP_ERR_INVALID;
+    if (c->rec_last < 0) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_snapshot_map: no record snapshot was taken");
+    EH_HIP(c, hipSetDevice(c->device));
+    const int slot = c->rec_last;
+    EH_HIP(c, hipEventSynchronize(c->rec_event[slot]));   // that copy only - not the steps enqueued after it
+    const uint8_t *h = c->rec_host[slot];
+    const uint32_t *header = (const uint32_t *)h;
+    view->records = (const edynhip_body_record *)(h + kRecHeader + (size_t)c->rec_event_cap * sizeof(eh::ContactEvent));
+    view->num_bodies = c->rec_bodies[slot];
+    view->step_index = c->rec_step[slot];
+    view->events = c->events ? (const edynhip_contact_event *)(h + kRecHeader) : nullptr;
+    view->total_events = header[0];
+    view->num_events = header[1];
     return EDYNHIP_OK;
 }
 

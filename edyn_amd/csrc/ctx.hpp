@@ -377,6 +377,10 @@ struct edynhip_ctx {
     // double-buffered read-back (edynhip_snapshot): pinned host copies of the packed state, the event that completes each
     float *snap_host[2] = {nullptr, nullptr}; float *snap_dev[2] = {nullptr, nullptr}; hipEvent_t snap_event[2] = {nullptr, nullptr};
     uint32_t snap_step[2] = {0, 0}, snap_bodies[2] = {0, 0}; int snap_last = -1; hipStream_t snap_stream = nullptr; hipEvent_t snap_ready = nullptr;
+    // record snapshots (edynhip_snapshot_records, ABI 15): per slot one device block and its pinned host copy, laid out as
+    // [header 64 B | events: rec_event_cap x 24 B | records: bodies x 96 B]; the registry write-back reads the pinned copy in place
+    uint8_t *rec_host[2] = {nullptr, nullptr}; uint8_t *rec_dev[2] = {nullptr, nullptr}; hipEvent_t rec_event[2] = {nullptr, nullptr};
+    uint32_t rec_step[2] = {0, 0}, rec_bodies[2] = {0, 0}, rec_events_copied[2] = {0, 0}; int rec_last = -1; uint32_t rec_event_cap = 0;
     // Island sleep timers run on the step time stamps the stepper hands to the island manager (stepper_sequential.cpp:60-75,
     // island_manager.cpp:533-539,605-623): sim_clock is the island manager's m_last_time, i.e. the stamp of the PREVIOUS step while
     // a step runs - advanced by fixed_dt per edynhip_step step, set by the caller in edynhip_step_timed (the

@@ -222,6 +222,21 @@ DI void add_by_label(uint32_t label, uint32_t amount, uint32_t *dst) {   // ever
         todo &= ~__ballot(mine);
     }
 }
+DI void or_by_label(uint32_t label, uint32_t bits, uint32_t *dst) {   // every lane of the wave calls this (bits 0 = nothing): one atomic per distinct label and wave
+    // (one lane per body OR-ing into its island's word serialises on that word: a 32k-body pile - one island - spent 0.4 ms per step here)
+    uint64_t todo = __ballot(bits != 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t l = (uint32_t)__shfl((int)label, leader);
+        const bool mine = bits != 0 && label == l;
+        uint32_t all = mine ? bits : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) all |= (uint32_t)__shfl_xor((int)all, off);
+        // the word only gains bits while this kernel runs (k_sleep_decide zeroed it): a stale read can cost a redundant atomic, never a lost bit
+        if ((int)(threadIdx.x & 63) == leader && (__hip_atomic_load(&dst[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & all) != all) atomicOr(&dst[l], all);
+        todo &= ~__ballot(mine);
+    }
+}
 __global__ void k_sleep_sizes(uint32_t n, Bodies b, Manifolds mf, uint32_t M, Joints j, SleepMerge sm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t label = 0, amount = 0;
@@ -246,18 +261,22 @@ __global__ void k_sleep_carry(uint32_t n, Bodies b, SleepMerge sm, const double 
 }
 __global__ void k_sleep_scan(uint32_t n, Bodies b, uint32_t *state, SleepMerge sm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t fl = b.flags[i];
-    if (!is_dynamic(fl)) return;
-    // one of last step's island roots: a candidate for the timer of the island it is in now
-    if (sm.best && i < sm.prev_n && !(fl & BF_REMOVED) && sm.old_label[i] == i)
-        atomicMax(&sm.best[b.island[i]], ((unsigned long long)sm.size[i] << 32) | (unsigned long long)(~i));
-    const f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
-    const float lin = 0.005f, ang = 3.1415926535897932384626433832795029f / 48.0f;   // config/constants.hpp:41-42
-    uint32_t bits = (fl & BF_ASLEEP) ? SL_HAS_ASLEEP : SL_HAS_AWAKE;
-    if (length_sqr(v) > lin * lin || length_sqr(w) > ang * ang) bits |= SL_FAST;
-    if (fl & BF_NOSLEEP) bits |= SL_DISABLED;
-    atomicOr(&state[b.island[i]], bits);
+    uint32_t label = 0, bits = 0;
+    if (i < n) {
+        const uint32_t fl = b.flags[i];
+        if (is_dynamic(fl)) {
+            label = b.island[i];
+            // one of last step's island roots: a candidate for the timer of the island it is in now
+            if (sm.best && i < sm.prev_n && !(fl & BF_REMOVED) && sm.old_label[i] == i)
+                atomicMax(&sm.best[label], ((unsigned long long)sm.size[i] << 32) | (unsigned long long)(~i));
+            const f3 v = from4(b.linvel[i]), w = from4(b.angvel[i]);
+            const float lin = 0.005f, ang = 3.1415926535897932384626433832795029f / 48.0f;   // config/constants.hpp:41-42
+            bits = (fl & BF_ASLEEP) ? SL_HAS_ASLEEP : SL_HAS_AWAKE;
+            if (length_sqr(v) > lin * lin || length_sqr(w) > ang * ang) bits |= SL_FAST;
+            if (fl & BF_NOSLEEP) bits |= SL_DISABLED;
+        }
+    }
+    or_by_label(label, bits, state);
 }
 __global__ void k_sleep_edges(const uint2 *__restrict__ edges, const Counters *cnt, const uint32_t *__restrict__ label, uint32_t *state) {
     const uint32_t n = cnt->num_new;

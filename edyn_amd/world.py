@@ -483,6 +483,21 @@ class World:
         self._check(self._L.edynhip_snapshot_read(self._h, _ptr(pos), _ptr(orn), _ptr(lin), _ptr(ang), C.byref(step)))
         return (pos, orn, lin, ang), step.value
 
+    # ---- the registry write-back read in place: 96-byte records (state, presentation transforms, origin, flags) + the contact events
+    def snapshot_records(self, present_dt=0.0, max_events=4096):
+        self._check(self._L.edynhip_snapshot_records(self._h, float(present_dt), int(max_events)))
+
+    def snapshot_map(self):
+        """(records, events, total_events, step_index): structured COPIES of the pinned slot (the C caller reads it in place)."""
+        v = _capi.RecordView()
+        self._check(self._L.edynhip_snapshot_map(self._h, C.byref(v)))
+        rec = np.ctypeslib.as_array((C.c_uint8 * (v.num_bodies * _capi.RECORD_DTYPE.itemsize)).from_address(v.records)).view(_capi.RECORD_DTYPE).copy() \
+            if v.num_bodies else np.zeros(0, _capi.RECORD_DTYPE)
+        ev = np.zeros(0, _capi.EVENT_DTYPE)
+        if v.events and v.num_events:
+            ev = np.ctypeslib.as_array((C.c_uint8 * (v.num_events * _capi.EVENT_DTYPE.itemsize)).from_address(v.events)).view(_capi.EVENT_DTYPE).copy()
+        return rec, ev, int(v.total_events), int(v.step_index)
+
     def set_manifolds(self, recs):
         recs = np.ascontiguousarray(recs, MANIFOLD_DTYPE)
         self._check(self._L.edynhip_set_manifolds(self._h, _ptr(recs), len(recs)))

@@ -4,6 +4,7 @@
 // view<Ts...>().each(fn) (+ begin/end over entities), ctx().emplace / get / find / erase / contains.
 // With EnTT 3.15 installed this header is never included and the caller's own registry type is used.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <memory>
 #include <tuple>
@@ -17,11 +18,32 @@ namespace entt {
 enum class entity : std::uint32_t {};
 inline constexpr entity null{static_cast<entity>(0xFFFFFFFFu)};
 
+class registry;
 namespace detail {
+// on_destroy listeners (the subset of entt::sigh / entt::sink the shim uses): free functions with a payload,
+// registry.on_destroy<T>().connect<&fn>(payload) with fn(Payload &, registry &, entity), called BEFORE the component goes away.
+struct listener { void (*call)(void *payload, registry &, entity); void *payload; const void *id; };
+template <auto Candidate> struct candidate_id { static inline const char tag = 0; };
 struct pool_base {
     virtual ~pool_base() = default;
     virtual void remove(entity e) = 0;
     virtual bool contains(entity e) const = 0;
+    std::vector<listener> on_destroy;
+    registry *owner{nullptr};
+};
+class destroy_sink {
+public:
+    explicit destroy_sink(pool_base &p) : p_(p) {}
+    template <auto Candidate, typename Payload> void connect(Payload &payload) {
+        disconnect<Candidate>(payload);
+        p_.on_destroy.push_back({[](void *pl, registry &r, entity e) { Candidate(*static_cast<Payload *>(pl), r, e); }, &payload, &candidate_id<Candidate>::tag});
+    }
+    template <auto Candidate, typename Payload> void disconnect(Payload &payload) {
+        for (std::size_t k = p_.on_destroy.size(); k-- > 0;)
+            if (p_.on_destroy[k].payload == &payload && p_.on_destroy[k].id == &candidate_id<Candidate>::tag) p_.on_destroy.erase(p_.on_destroy.begin() + (std::ptrdiff_t)k);
+    }
+private:
+    pool_base &p_;
 };
 template <typename T>
 struct pool final : pool_base {
@@ -45,6 +67,7 @@ struct pool final : pool_base {
     T &get(entity e) { return data[sparse[static_cast<std::uint32_t>(e)] - 1]; }
     void remove(entity e) override {   // swap-and-pop, like entt::sparse_set
         if (!contains(e)) return;
+        for (std::size_t k = 0; k < on_destroy.size(); ++k) on_destroy[k].call(on_destroy[k].payload, *owner, e);
         auto i = static_cast<std::uint32_t>(e);
         std::uint32_t at = sparse[i] - 1, last = static_cast<std::uint32_t>(packed.size() - 1);
         if (at != last) {
@@ -98,6 +121,8 @@ public:
     template <typename... T> bool all_of(entity e) { return (assure<T>().contains(e) && ...); }
     template <typename... T> bool any_of(entity e) { return (assure<T>().contains(e) || ...); }
     template <typename T> void remove(entity e) { assure<T>().remove(e); }
+    template <typename T> detail::pool<T> &storage() { return assure<T>(); }             // direct pool handle: contains(e) / get(e)
+    template <typename T> detail::destroy_sink on_destroy() { return detail::destroy_sink(assure<T>()); }
     context &ctx() { return ctx_; }
     // read-only access through a const registry (what a should_collide predicate is handed): same pools, nothing is created that a
     // non-const call would not create
@@ -140,7 +165,7 @@ private:
     template <typename T>
     detail::pool<T> &assure() {
         auto &slot = pools_[std::type_index(typeid(T))];
-        if (!slot) slot = std::make_unique<detail::pool<T>>();
+        if (!slot) { slot = std::make_unique<detail::pool<T>>(); slot->owner = this; }
         return *static_cast<detail::pool<T> *>(slot.get());
     }
     std::unordered_map<std::type_index, std::unique_ptr<detail::pool_base>> pools_;

@@ -27,13 +27,19 @@
 #endif
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <variant>
 #include <vector>
@@ -222,7 +228,11 @@ struct contact_point_list { entt::entity parent; uint64_t id; };   // parent man
 
 enum class execution_mode : uint8_t { sequential, sequential_multithreaded, asynchronous };
 struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
-    edyn::execution_mode execution_mode{execution_mode::sequential};   // every mode maps to the synchronous GPU stepper
+    // Host threads that carry the device's results into the registry (the write-back of position / orientation / linvel / angvel /
+    // present_* / origin is a parallel loop over the bodies). The reference's field of the same name sizes its job dispatcher
+    // (edyn.hpp:39-42: 0 = hardware_concurrency); here 0 = min(16, hardware_concurrency / 2), 1 = no threads are started.
+    size_t num_worker_threads{0};
+    edyn::execution_mode execution_mode{execution_mode::sequential};   // asynchronous: the registry receives each update's result during the next one (below)
     scalar fixed_dt{scalar(1.0 / 60)};
     unsigned num_solver_velocity_iterations{8};
     unsigned num_solver_position_iterations{3};
@@ -249,6 +259,17 @@ struct init_config {   // edyn.hpp:39-60 + settings.hpp:21-57
     // of the same equations (stated deviations: DESIGN.md section 4).
     bool fused_velocity_rows{false};
     bool block_position{false};
+    // EDYNHIP_FLAG_EXCLUSIVE_DEVICE: a promise that this stepper is the only user of its GPU while it steps - the resident-grid
+    // solver kernels are then launched plainly instead of cooperatively (edynhip.h). Off = always safe.
+    bool exclusive_device{false};
+};
+
+/// Host time the shim itself spent around the device calls, accumulated over updates (edyn::get_shim_timings / reset_shim_timings):
+/// what edyn::update costs beyond edynhip_step. Milliseconds; `step_call` is the host time inside edynhip_step(_timed) - the part
+/// of the GPU step during which the host waits for the step's counters -, `state_wait` the wait for the rest of the step + the copy.
+struct shim_timings {
+    double sync_removed{0}, upload{0}, step_call{0}, state_wait{0}, write_back{0}, contacts{0}, presentation{0}, total{0};
+    uint64_t updates{0}, steps{0}, contact_events{0};   // contact_events: manifold / point creations and destructions carried into the registry
 };
 
 class stepper_error : public std::runtime_error {
@@ -258,6 +279,100 @@ public:
 };
 
 namespace detail {
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+// A small fork-join pool for the registry write-back (the reference's counterpart: the job dispatcher's parallel_for, which its
+// multithreaded stepper uses for the same kind of per-entity loops). parallel_for cuts [0, count) into chunks of `grain`; the
+// caller and the workers take chunks from one atomic ticket until none is left, so a worker that wakes up late costs nothing -
+// the others have done its share. Workers spin briefly for the next job, then sleep; prewake() tells sleeping workers that a job
+// is about to follow (they then spin for it for up to ~3 ms instead of being woken when it is already there).
+class worker_pool {
+public:
+    explicit worker_pool(unsigned threads) {
+        for (unsigned k = 1; k < threads; ++k) workers_.emplace_back([this, k] { loop(k); });
+    }
+    ~worker_pool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    worker_pool(const worker_pool &) = delete;
+    worker_pool &operator=(const worker_pool &) = delete;
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    void prewake() {
+        if (workers_.empty()) return;
+        hint_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
+    }
+    /// f(begin, end, worker) for every chunk; worker in [0, size()); returns when every chunk is done
+    template <typename F>
+    void parallel_for(uint32_t count, uint32_t grain, F &&f) {
+        if (count == 0) return;
+        const uint32_t chunks = (count + grain - 1) / grain;
+        if (workers_.empty() || chunks == 1) { f(0u, count, 0u); return; }
+        using Fn = std::remove_reference_t<F>;
+        run_ = [](void *ctx, uint32_t b, uint32_t e, unsigned w) { (*static_cast<Fn *>(ctx))(b, e, w); };
+        ctx_ = &f; count_ = count; grain_ = grain; chunks_.store(chunks, std::memory_order_relaxed);
+        remaining_.store(chunks, std::memory_order_relaxed);
+        const uint64_t seq = ++seq_;
+        ticket_.store(seq << 32, std::memory_order_release);   // opens the job: (sequence, next chunk)
+        if (sleepers_.load(std::memory_order_acquire)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
+        take_chunks(seq, 0u);
+        while (remaining_.load(std::memory_order_acquire) != 0) cpu_relax();
+        ticket_.store((seq << 32) | 0xFFFFFFFFull, std::memory_order_release);   // closed: a straggler finds no chunk and no stale field is read
+    }
+private:
+    void take_chunks(uint64_t seq, unsigned worker) {
+        uint64_t t = ticket_.load(std::memory_order_acquire);
+        for (;;) {
+            if ((t >> 32) != seq) return;
+            const uint32_t c = (uint32_t)t;
+            if (c == 0xFFFFFFFFu || c >= chunks_.load(std::memory_order_relaxed)) return;   // (the job's fields change only between a close and the next open)
+            if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+            const uint32_t b = c * grain_;
+            run_(ctx_, b, std::min(count_, b + grain_), worker);
+            remaining_.fetch_sub(1, std::memory_order_acq_rel);
+            t = ticket_.load(std::memory_order_acquire);
+        }
+    }
+    void loop(unsigned worker) {
+        uint64_t seen = 0, seen_hint = 0;
+        auto spin_until = std::chrono::steady_clock::now();
+        for (;;) {
+            const uint64_t t = ticket_.load(std::memory_order_acquire);
+            if ((t >> 32) != seen && (uint32_t)t != 0xFFFFFFFFu) {
+                seen = t >> 32;
+                take_chunks(seen, worker);
+                spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(50);
+                continue;
+            }
+            const uint64_t h = hint_.load(std::memory_order_acquire);
+            if (h != seen_hint) { seen_hint = h; spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(3000); }
+            if (std::chrono::steady_clock::now() < spin_until) { for (int k = 0; k < 32; ++k) cpu_relax(); continue; }
+            std::unique_lock<std::mutex> l(m_);
+            if (stop_) return;
+            sleepers_.fetch_add(1, std::memory_order_acq_rel);
+            cv_.wait(l, [&] {
+                const uint64_t now = ticket_.load(std::memory_order_acquire);
+                return stop_ || ((now >> 32) != seen && (uint32_t)now != 0xFFFFFFFFu) || hint_.load(std::memory_order_acquire) != seen_hint;
+            });
+            sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            if (stop_) return;
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_; std::condition_variable cv_; bool stop_{false};
+    std::atomic<uint64_t> ticket_{0xFFFFFFFFull}, hint_{0};
+    std::atomic<uint32_t> remaining_{0}, sleepers_{0};
+    uint64_t seq_{0};
+    void (*run_)(void *, uint32_t, uint32_t, unsigned){nullptr}; void *ctx_{nullptr}; uint32_t count_{0}, grain_{1}; std::atomic<uint32_t> chunks_{0};
+};
+
 // The analogue of stepper_sequential in registry.ctx() (edyn.cpp:117-123).
 struct gpu_stepper {
     init_config cfg;
@@ -290,9 +405,25 @@ struct gpu_stepper {
     bool recreate{false};          // a body's mass / inertia / material was edited: the next upload re-creates the context (contacts, joints and sleep state are carried)
     bool contacts_resync{false};   // the context was re-created (capacity growth): point ids changed, rebuild the contact entities
     bool snapshot_pending{false};                                   // asynchronous mode: a snapshot of the previous update is in flight
+    shim_timings tm;                                                // host time per phase (edyn::get_shim_timings)
+    std::unique_ptr<worker_pool> pool;                              // the write-back's host threads (init_config::num_worker_threads)
+    std::vector<std::vector<uint32_t>> sleep_changes;               // per worker: bodies whose sleeping flag differs from the registry's tag
+    std::vector<uint8_t> asleep_shadow;                             // body index -> the registry carries sleeping_tag (as this shim left it)
+    bool removal_pending{true};                                     // an on_destroy hook fired (or nothing is known yet): sync_removed has work
+    bool records_pending{false};                                    // a record snapshot of the previous update is in flight (asynchronous mode)
+    float present_dt{0};                                            // update_presentation's interpolation_dt of the update in progress
+    bool hooks_connected{false};
+    bool host_presentation{false};                                  // this update's presentation transforms were not part of a write-back: compute them on the host
+    uint32_t events_stale_through{0};                               // asynchronous mode: snapshots up to this step index carry events a rebuild already covered
     ~gpu_stepper() { if (ctx) edynhip_destroy(ctx); if (world) edynhip_world_destroy(world); }
 };
 struct body_index { uint32_t value; };
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct phase_timer {   // adds the time between construction and destruction to one field of shim_timings
+    double &acc; double t0;
+    explicit phase_timer(double &a) : acc(a), t0(now_ms()) {}
+    ~phase_timer() { acc += now_ms() - t0; }
+};
 /// edynhip_pair_filter -> the user's should_collide_func: body indices back to the entities they were made from
 inline int pair_filter_trampoline(void *user, uint32_t body, uint32_t other) {
     auto &s = *static_cast<gpu_stepper *>(user);
@@ -578,7 +709,7 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
             edynhip_destroy(s.ctx); s.ctx = nullptr;
             s.exclusions_uploaded = 0;
             regrown = true;
-            s.contacts_resync = true; s.snapshot_pending = false;
+            s.contacts_resync = true; s.snapshot_pending = false; s.records_pending = false; s.events_stale_through = 0;
         }
         s.uploaded_bodies = s.uploaded_constraints = 0;
         edynhip_config c{};
@@ -591,7 +722,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         c.num_position_iterations = s.cfg.num_solver_position_iterations;
         c.gravity[0] = s.cfg.gravity.x; c.gravity[1] = s.cfg.gravity.y; c.gravity[2] = s.cfg.gravity.z;
         c.flags = (s.cfg.island_sleeping ? EDYNHIP_FLAG_SLEEPING : 0u) | (s.cfg.materialize_contacts ? EDYNHIP_FLAG_CONTACT_EVENTS : 0u) |
-                  (s.cfg.fused_velocity_rows ? EDYNHIP_FLAG_FUSED_VELOCITY_ROWS : 0u) | (s.cfg.block_position ? EDYNHIP_FLAG_BLOCK_POSITION : 0u);
+                  (s.cfg.fused_velocity_rows ? EDYNHIP_FLAG_FUSED_VELOCITY_ROWS : 0u) | (s.cfg.block_position ? EDYNHIP_FLAG_BLOCK_POSITION : 0u) |
+                  (s.cfg.exclusive_device ? EDYNHIP_FLAG_EXCLUSIVE_DEVICE : 0u);
         int st = 0;
         s.ctx = edynhip_create(&c, &st);
         s.meshes.clear();   // meshes belong to the context
@@ -697,41 +829,108 @@ inline void upload_state(entt::registry &registry, gpu_stepper &s) {
     s.state_dirty = false;
 }
 
-inline void write_back(entt::registry &registry, gpu_stepper &s) {
-    const uint32_t n = (uint32_t)s.bodies.size();
-    std::vector<float> pos(3 * n), orn(4 * n), lv(3 * n), av(3 * n);
-    check(s, edynhip_get_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
-    for (uint32_t i = 0; i < n; ++i) {
-        const entt::entity e = s.bodies[i];
-        if (e == entt::null || !registry.all_of<dynamic_tag>(e)) continue;
-        auto &p = registry.get<position>(e); p.x = pos[3 * i]; p.y = pos[3 * i + 1]; p.z = pos[3 * i + 2];
-        auto &q = registry.get<orientation>(e); q.x = orn[4 * i]; q.y = orn[4 * i + 1]; q.z = orn[4 * i + 2]; q.w = orn[4 * i + 3];
-        auto &v = registry.get<linvel>(e); v.x = lv[3 * i]; v.y = lv[3 * i + 1]; v.z = lv[3 * i + 2];
-        auto &w = registry.get<angvel>(e); w.x = av[3 * i]; w.y = av[3 * i + 1]; w.z = av[3 * i + 2];
-        if (auto *cm = registry.try_get<center_of_mass>(e)) {   // update_origins.cpp:13-15: origin = to_world(-com, pos, orn)
-            const vector3 c{-cm->x, -cm->y, -cm->z}, u{q.x, q.y, q.z};
-            const vector3 t{2 * (u.y * c.z - u.z * c.y), 2 * (u.z * c.x - u.x * c.z), 2 * (u.x * c.y - u.y * c.x)};
-            auto &o = registry.get<origin>(e);
-            o.x = p.x + c.x + q.w * t.x + (u.y * t.z - u.z * t.y); o.y = p.y + c.y + q.w * t.y + (u.z * t.x - u.x * t.z); o.z = p.z + c.z + q.w * t.z + (u.x * t.y - u.y * t.x);
-        }
+// ---- the registry write-back. The device hands over one 96-byte record per body in pinned host memory (edynhip_snapshot_records /
+// edynhip_snapshot_map): state, presentation transforms (update_presentation.cpp:56-84 evaluated on the device), origin
+// (update_origins.cpp:13-15) and flags. The loop below is all the host does: it reads the records in place and writes the
+// components through direct pool handles (registry.storage<T>(): one sparse look-up per component instead of a type-indexed
+// registry.get), in parallel over the bodies; sleeping_tag changes (island_manager.cpp:541-565) are collected per worker and
+// applied serially afterwards - emplace / remove are the only operations that change a pool's layout.
+inline worker_pool &pool_of(gpu_stepper &s) {
+    if (!s.pool) {
+        size_t n = s.cfg.num_worker_threads;
+        if (const char *e = std::getenv("EDYN_NUM_WORKER_THREADS")) n = (size_t)std::atoi(e);
+        if (n == 0) n = std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency() / 2));
+        s.pool = std::make_unique<worker_pool>((unsigned)n);
+        s.sleep_changes.assign(s.pool->size(), {});
     }
-    if (s.cfg.island_sleeping) {   // mirror sleeping_tag (island_manager.cpp:541-565, util/island_util.cpp:7-13)
-        std::vector<uint8_t> asleep(n, 0);
-        check(s, edynhip_get_asleep(s.ctx, asleep.data()));
-        for (uint32_t i = 0; i < n; ++i) {
+    return *s.pool;
+}
+constexpr uint32_t write_back_grain = 512;   // bodies per chunk of the parallel loops
+inline void import_records(entt::registry &registry, gpu_stepper &s, const edynhip_record_view &view, bool presentation) {
+    const uint32_t n = (uint32_t)std::min<size_t>(s.bodies.size(), view.num_bodies);
+    if (n == 0) return;
+    const bool async = s.cfg.execution_mode == execution_mode::asynchronous;
+    if (async && s.shadow.size() < (size_t)13 * s.bodies.size()) s.shadow.resize((size_t)13 * s.bodies.size(), 0.f);
+    if (s.asleep_shadow.size() < s.bodies.size()) s.asleep_shadow.resize(s.bodies.size(), 0);
+    auto &sp = registry.storage<position>(); auto &sq = registry.storage<orientation>();
+    auto &sv = registry.storage<linvel>(); auto &sw = registry.storage<angvel>();
+    auto &spp = registry.storage<present_position>(); auto &spo = registry.storage<present_orientation>();
+    auto &sorg = registry.storage<origin>();
+    worker_pool &pool = pool_of(s);
+    const edynhip_body_record *recs = view.records;
+    pool.parallel_for(n, write_back_grain, [&](uint32_t begin, uint32_t end, unsigned worker) {
+        auto &changes = s.sleep_changes[worker];
+        for (uint32_t i = begin; i < end; ++i) {
             const entt::entity e = s.bodies[i];
-            if (e == entt::null) continue;
-            const bool tagged = registry.all_of<sleeping_tag>(e);
-            if (asleep[i] && !tagged) registry.emplace<sleeping_tag>(e);
-            else if (!asleep[i] && tagged) registry.remove<sleeping_tag>(e);
+            const edynhip_body_record &r = recs[i];
+            if (e == entt::null || !(r.flags & EDYNHIP_RECORD_DYNAMIC) || (r.flags & EDYNHIP_RECORD_REMOVED)) continue;   // static / kinematic: the registry is the authority
+            if (!sp.contains(e) || !sv.contains(e)) continue;   // stripped by the user since the last update (noticed by sync_removed next time)
+            auto &p = sp.get(e); p.x = r.pos[0]; p.y = r.pos[1]; p.z = r.pos[2];
+            auto &q = sq.get(e); q.x = r.orn[0]; q.y = r.orn[1]; q.z = r.orn[2]; q.w = r.orn[3];
+            auto &v = sv.get(e); v.x = r.linvel[0]; v.y = r.linvel[1]; v.z = r.linvel[2];
+            auto &w = sw.get(e); w.x = r.angvel[0]; w.y = r.angvel[1]; w.z = r.angvel[2];
+            if ((r.flags & EDYNHIP_RECORD_HAS_ORIGIN) && sorg.contains(e)) { auto &o = sorg.get(e); o.x = r.origin[0]; o.y = r.origin[1]; o.z = r.origin[2]; }
+            const uint8_t asleep = (r.flags & EDYNHIP_RECORD_ASLEEP) ? 1 : 0;
+            if (presentation && !asleep && spp.contains(e) && spo.contains(e)) {   // update_presentation's views exclude sleeping entities
+                auto &pp = spp.get(e); pp.x = r.present_pos[0]; pp.y = r.present_pos[1]; pp.z = r.present_pos[2];
+                auto &po = spo.get(e); po.x = r.present_orn[0]; po.y = r.present_orn[1]; po.z = r.present_orn[2]; po.w = r.present_orn[3];
+            }
+            if (asleep != s.asleep_shadow[i]) changes.push_back(i);
+            if (async) std::memcpy(&s.shadow[(size_t)13 * i], r.pos, 13 * sizeof(float));   // pos orn linvel angvel are the record's first 13 floats
         }
+    });
+    if (s.cfg.island_sleeping)
+        for (auto &changes : s.sleep_changes) {
+            for (uint32_t i : changes) {
+                const entt::entity e = s.bodies[i];
+                const bool asleep = (recs[i].flags & EDYNHIP_RECORD_ASLEEP) != 0, tagged = registry.all_of<sleeping_tag>(e);
+                if (asleep && !tagged) registry.emplace<sleeping_tag>(e);
+                else if (!asleep && tagged) registry.remove<sleeping_tag>(e);
+                s.asleep_shadow[i] = asleep ? 1 : 0;
+            }
+            changes.clear();
+        }
+    else for (auto &changes : s.sleep_changes) changes.clear();
+}
+// Contact events that travelled with a record snapshot -> contact entities (sync_contacts below applies them).
+inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::vector<edynhip_contact_event> &ev, int rc);
+// sequential write-back: enqueue the pack + copy behind the step, wait for it, import. `events_max`: how many contact events travel along.
+inline void write_back(entt::registry &registry, gpu_stepper &s, bool presentation) {
+    { phase_timer t(s.tm.state_wait);
+      check(s, edynhip_snapshot_records(s.ctx, s.present_dt, s.cfg.materialize_contacts ? 4096u : 0u));
+      pool_of(s).prewake(); }
+    edynhip_record_view view{};
+    { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_map(s.ctx, &view)); }
+    { phase_timer t(s.tm.write_back); import_records(registry, s, view, presentation); }
+    if (s.cfg.materialize_contacts) {
+        phase_timer t(s.tm.contacts);
+        std::vector<edynhip_contact_event> ev;
+        int rc = EDYNHIP_OK;
+        if (view.total_events > view.num_events) {   // more than travelled along: the device still holds the whole list (no step was enqueued since)
+            uint32_t cnt = 0;
+            ev.resize(view.total_events);
+            rc = edynhip_get_contact_events(s.ctx, ev.data(), (uint32_t)ev.size(), &cnt);
+            ev.resize(rc == EDYNHIP_OK ? cnt : 0);
+        } else if (view.num_events) ev.assign(view.events, view.events + view.num_events);
+        apply_contact_events(registry, s, ev, rc);
     }
 }
 
 // registry.destroy(entity) / clear_rigidbody on bodies and constraints since the last update: the reference reacts through
 // on_destroy hooks (island_manager.cpp:24-27); this shim notices at the next update that the entity is gone (or no longer
 // carries the component that made it a body / a joint) and removes it from the device world, keeping every other index.
+inline void on_stepper_entity_gone(gpu_stepper &s, entt::registry &, entt::entity) { s.removal_pending = true; }
+template <typename... T> inline void connect_removal_hooks(entt::registry &registry, gpu_stepper &s) {
+    (registry.template on_destroy<T>().template connect<&on_stepper_entity_gone>(s), ...);
+}
+template <typename... T> inline void disconnect_removal_hooks(entt::registry &registry, gpu_stepper &s) {
+    (registry.template on_destroy<T>().template disconnect<&on_stepper_entity_gone>(s), ...);
+}
 inline void sync_removed(entt::registry &registry, gpu_stepper &s) {
+    // The reference reacts to destroyed bodies / constraints through on_destroy hooks (island_manager.cpp:24-27); so does this shim:
+    // the hooks (attach) raise `removal_pending`, and only then is the list of bodies and constraints walked.
+    if (s.hooks_connected && !s.removal_pending) return;
+    s.removal_pending = false;
     std::vector<uint32_t> gone_bodies, gone_joints;
     for (uint32_t i = 0; i < (uint32_t)s.bodies.size(); ++i) {
         const entt::entity e = s.bodies[i];
@@ -788,12 +987,10 @@ inline void refresh_contact_points(entt::registry &registry, gpu_stepper &s) {
             registry.get<contact_point_impulse>(it->second) = {p.normal_impulse, {p.friction_impulse[0], p.friction_impulse[1]}};
         }
 }
-inline void sync_contacts(entt::registry &registry, gpu_stepper &s) {
+inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::vector<edynhip_contact_event> &ev, int rc) {
     if (!s.cfg.materialize_contacts || !s.ctx) return;
-    uint32_t n = 0;
-    int rc = edynhip_get_contact_events(s.ctx, nullptr, 0, &n);
-    std::vector<edynhip_contact_event> ev(n);
-    if (rc == EDYNHIP_OK && n) rc = edynhip_get_contact_events(s.ctx, ev.data(), n, &n);
+    s.tm.contact_events += ev.size();
+    if (ev.empty() && rc == EDYNHIP_OK && !s.contacts_resync) { if (s.cfg.contact_point_data) refresh_contact_points(registry, s); return; }
     auto body_of = [&](uint32_t i) { return i < s.bodies.size() ? s.bodies[i] : entt::entity{entt::null}; };
     auto make_manifold = [&](uint32_t a, uint32_t b) {
         const entt::entity e = registry.create();
@@ -859,6 +1056,14 @@ inline void sync_contacts(entt::registry &registry, gpu_stepper &s) {
     }
     if (s.cfg.contact_point_data) refresh_contact_points(registry, s);
 }
+inline void sync_contacts(entt::registry &registry, gpu_stepper &s) {   // the events straight from the device (no record snapshot at hand)
+    if (!s.cfg.materialize_contacts || !s.ctx) return;
+    uint32_t n = 0;
+    int rc = edynhip_get_contact_events(s.ctx, nullptr, 0, &n);
+    std::vector<edynhip_contact_event> ev(n);
+    if (rc == EDYNHIP_OK && n) rc = edynhip_get_contact_events(s.ctx, ev.data(), n, &n);
+    apply_contact_events(registry, s, ev, rc);
+}
 inline void import_state(entt::registry &registry, gpu_stepper &s, const std::vector<float> &pos, const std::vector<float> &orn,
                          const std::vector<float> &lv, const std::vector<float> &av, uint32_t count) {
     // `count` = the bodies the arrays cover (a snapshot taken before bodies were appended covers fewer than exist now)
@@ -902,21 +1107,37 @@ inline void merge_user_edits(entt::registry &registry, gpu_stepper &s) {
     }
     import_state(registry, s, pos, orn, lv, av, n);   // the registry (and the shadow) now hold the current state plus the edits
 }
+// asynchronous mode: the record snapshot of the previous update -> registry (state, presentation, sleeping tags, contact entities)
+inline void import_pending_records(entt::registry &registry, gpu_stepper &s, const edynhip_record_view &view, uint32_t steps_in_flight) {
+    { phase_timer t(s.tm.write_back); import_records(registry, s, view, true); }
+    if (!s.cfg.materialize_contacts) return;
+    phase_timer t(s.tm.contacts);
+    std::vector<edynhip_contact_event> ev;
+    if (view.step_index <= s.events_stale_through) {
+        // a rebuild from the manifolds (below) already covered these steps: their events would be applied twice
+    } else if (view.total_events > view.num_events) {
+        // more events than travel with a snapshot (a pile hitting the ground): the device's list has been reset by the steps enqueued
+        // since, so the contact entities are rebuilt from the CURRENT manifolds - which include the steps in flight, whose events are
+        // then skipped when their snapshot arrives
+        s.contacts_resync = true;
+        s.events_stale_through = view.step_index + steps_in_flight;
+    } else if (view.num_events) ev.assign(view.events, view.events + view.num_events);
+    apply_contact_events(registry, s, ev, EDYNHIP_OK);
+}
 inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, bool timed = false, double first_time = 0, double step_dt = 0) {
     const bool async = s.cfg.execution_mode == execution_mode::asynchronous;
-    if (async && s.snapshot_pending) {
-        // execution_mode::asynchronous: the registry receives the PREVIOUS update's result (handed over while this update's
-        // steps run, like the simulation worker's snapshots, simulation_worker.cpp:406-444) - contact entities and sleeping
-        // tags of that update too, all read before the next steps are enqueued.
-        if (s.state_dirty) merge_user_edits(registry, s);   // the snapshot is superseded by the current state + the edits
-        else {
-            const uint32_t n = std::max<uint32_t>(s.snapshot_bodies, 1u);   // what the snapshot covers: bodies appended since are not in it
-            std::vector<float> pos(3 * (size_t)n), orn(4 * (size_t)n), lv(3 * (size_t)n), av(3 * (size_t)n);
-            check(s, edynhip_snapshot_read(s.ctx, pos.data(), orn.data(), lv.data(), av.data(), nullptr));
-            import_state(registry, s, pos, orn, lv, av, s.snapshot_bodies);
+    if (async && s.records_pending && (s.state_dirty || s.scene_dirty || steps == 0 || s.pre_step || s.post_step)) {
+        // execution_mode::asynchronous, the cases that cannot overlap: user edits pending (the snapshot is superseded by the device's
+        // current state + the edits), a scene change (the context may be re-created), no step to overlap with
+        if (s.state_dirty) {
+            { phase_timer t(s.tm.write_back); merge_user_edits(registry, s); }
+            { phase_timer t(s.tm.contacts); sync_contacts(registry, s); }
+        } else {
+            edynhip_record_view view{};
+            { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_map(s.ctx, &view)); }
+            import_pending_records(registry, s, view, 0u);
         }
-        sync_contacts(registry, s);
-        s.snapshot_pending = false;
+        s.records_pending = false;
     }
     if (s.multi()) {   // init_config::devices: the multi-GPU world (see upload_scene_multi)
         if (async || s.pre_step || s.post_step || s.cfg.contact_point_data)
@@ -934,13 +1155,18 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
         std::vector<float> pos(3 * (size_t)n), orn(4 * (size_t)n), lv(3 * (size_t)n), av(3 * (size_t)n);
         check(s, edynhip_world_get_state(s.world, pos.data(), orn.data(), lv.data(), av.data()));
         import_state(registry, s, pos, orn, lv, av, n);
+        s.host_presentation = true;   // (the multi-GPU world hands back plain state arrays)
         return;
     }
-    sync_removed(registry, s);
-    if (s.scene_dirty) upload_scene(registry, s);
-    if (s.state_dirty) upload_state(registry, s);   // also after an append: edits made in the same frame are not lost
-    apply_params(s);
-    if (steps == 0 || s.bodies.empty()) return;
+    { phase_timer t(s.tm.sync_removed); sync_removed(registry, s); }
+    {
+        phase_timer t(s.tm.upload);
+        if (s.scene_dirty) upload_scene(registry, s);
+        if (s.state_dirty) upload_state(registry, s);   // also after an append: edits made in the same frame are not lost
+        apply_params(s);
+    }
+    if (steps == 0 || s.bodies.empty()) { s.host_presentation = true; return; }   // time went on without a step: presentation from the registry's state
+    s.tm.steps += steps;
     if (s.pre_step || s.post_step) {
         // step callbacks (stepper_sequential.cpp:76-78,97-99) see the registry between steps: one step per launch, the state
         // written back after each, edits made by a callback (followed by edyn::refresh) uploaded before the next
@@ -948,21 +1174,26 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
             if (s.pre_step) s.pre_step(registry);
             if (s.state_dirty) upload_state(registry, s);
             check(s, timed ? edynhip_step_timed(s.ctx, 1, first_time + step_dt * k, step_dt) : edynhip_step(s.ctx, 1));
-            write_back(registry, s);
-            sync_contacts(registry, s);
+            write_back(registry, s, k + 1 == steps);
             if (s.post_step) s.post_step(registry);
         }
         return;
     }
-    check(s, timed ? edynhip_step_timed(s.ctx, steps, first_time, step_dt) : edynhip_step(s.ctx, steps));
+    { phase_timer t(s.tm.step_call); check(s, timed ? edynhip_step_timed(s.ctx, steps, first_time, step_dt) : edynhip_step(s.ctx, steps)); }
     if (async) {
-        check(s, edynhip_snapshot(s.ctx));   // returns at once; read at the next update
-        s.snapshot_pending = true;
-        s.snapshot_bodies = s.uploaded_bodies;
+        // The registry receives the PREVIOUS update's result while this update's steps run on the device (the simulation worker's
+        // snapshots, simulation_worker.cpp:406-444): its copy finished long ago - it was enqueued before these steps -, so nothing
+        // here waits for the GPU, and the GPU does not wait for the host loop below.
+        edynhip_record_view prev{};
+        const bool have_prev = s.records_pending;
+        if (have_prev) { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_map(s.ctx, &prev)); }
+        // every contact event of these steps travels with the snapshot (as many as a slot holds)
+        check(s, edynhip_snapshot_records(s.ctx, s.present_dt, s.cfg.materialize_contacts ? 0xFFFFFFFFu : 0u));
+        s.records_pending = true;
+        if (have_prev) { pool_of(s).prewake(); import_pending_records(registry, s, prev, steps); }
         return;
     }
-    write_back(registry, s);
-    sync_contacts(registry, s);
+    write_back(registry, s, true);
 }
 // update_presentation (src/edyn/sys/update_presentation.cpp:56-84), local simulation (no discontinuities): transforms are
 // extrapolated from the last simulated state to `presentation_delay` = fixed_dt behind the current time.
@@ -971,28 +1202,54 @@ inline quaternion integrate(const quaternion &q, const vector3 &w, scalar dt) { 
     const scalar half = scalar(0.5);
     scalar t;
     if (ws < scalar(0.001)) t = half * dt - dt * dt * dt * (scalar(1) / scalar(48)) * ws * ws;
-    else t = std::sin(half * ws * dt) / ws;
-    const quaternion r{w.x * t, w.y * t, w.z * t, std::cos(half * ws * dt)};
+    else t = (scalar)std::sin((double)(half * ws * dt)) / ws;   // sin / cos through double, rounded once: what the device's integrate() computes
+    const quaternion r{w.x * t, w.y * t, w.z * t, (scalar)std::cos((double)(half * ws * dt))};
     quaternion o{r.w * q.x + r.x * q.w + r.y * q.z - r.z * q.y, r.w * q.y + r.y * q.w + r.z * q.x - r.x * q.z,
                  r.w * q.z + r.z * q.w + r.x * q.y - r.y * q.x, r.w * q.w - r.x * q.x - r.y * q.y - r.z * q.z};
     const scalar l = std::sqrt(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
     o.x /= l; o.y /= l; o.z /= l; o.w /= l;
     return o;
 }
-inline void update_presentation(entt::registry &registry, gpu_stepper &s, double time) {
-    const double sim_time = s.last_time - s.accumulated;
-    const scalar idt = std::min(static_cast<scalar>(time - s.cfg.fixed_dt - sim_time), s.cfg.fixed_dt);
-    for (const entt::entity e : s.bodies) {
-        if (e == entt::null || !registry.valid(e)) continue;   // destroyed bodies keep their index
-        if (!registry.all_of<present_position>(e) || registry.all_of<sleeping_tag>(e)) continue;
-        const auto &p = registry.get<position>(e); const auto &q = registry.get<orientation>(e);
-        const auto &v = registry.get<linvel>(e); const auto &w = registry.get<angvel>(e);
-        auto &pp = registry.get<present_position>(e);
-        pp.x = p.x + v.x * idt; pp.y = p.y + v.y * idt; pp.z = p.z + v.z * idt;
-        const quaternion o = integrate(q, w, idt);
-        auto &po = registry.get<present_orientation>(e);
-        po.x = o.x; po.y = o.y; po.z = o.z; po.w = o.w;
-    }
+/// interpolation_dt of update_presentation (update_presentation.cpp:70-71) for the state the registry will hold after this update
+inline scalar presentation_dt(const gpu_stepper &s, double time) {
+    const double sim_time = time - s.accumulated;   // get_simulation_timestamp() once m_last_time = time
+    return std::min(static_cast<scalar>(time - s.cfg.fixed_dt - sim_time), s.cfg.fixed_dt);
+}
+// The host form of update_presentation: used when the update ran no step (time went on, the state did not) and by the multi-GPU
+// world; an update that steps gets the same transforms from the device with the state (edynhip_body_record::present_*).
+inline void update_presentation(entt::registry &registry, gpu_stepper &s, scalar idt) {
+    const uint32_t n = (uint32_t)s.bodies.size();
+    auto &sp = registry.storage<position>(); auto &sq = registry.storage<orientation>();
+    auto &sv = registry.storage<linvel>(); auto &sw = registry.storage<angvel>();
+    auto &spp = registry.storage<present_position>(); auto &spo = registry.storage<present_orientation>();
+    auto &sleeping = registry.storage<sleeping_tag>();
+    pool_of(s).parallel_for(n, write_back_grain, [&](uint32_t begin, uint32_t end, unsigned) {
+        for (uint32_t i = begin; i < end; ++i) {
+            const entt::entity e = s.bodies[i];
+            if (e == entt::null || !spp.contains(e) || !spo.contains(e) || sleeping.contains(e)) continue;   // destroyed bodies keep their index
+            if (!sp.contains(e) || !sq.contains(e) || !sv.contains(e) || !sw.contains(e)) continue;
+            const auto &p = sp.get(e); const auto &q = sq.get(e); const auto &v = sv.get(e); const auto &w = sw.get(e);
+            auto &pp = spp.get(e);
+            pp.x = p.x + v.x * idt; pp.y = p.y + v.y * idt; pp.z = p.z + v.z * idt;
+            const quaternion o = integrate(q, w, idt);
+            auto &po = spo.get(e);
+            po.x = o.x; po.y = o.y; po.z = o.z; po.w = o.w;
+        }
+    });
+}
+/// snap_presentation (update_presentation.cpp:86-92): what a paused stepper does instead (stepper_sequential.cpp:38-43)
+inline void snap_presentation(entt::registry &registry, gpu_stepper &s) {
+    auto &sp = registry.storage<position>(); auto &sq = registry.storage<orientation>();
+    auto &spp = registry.storage<present_position>(); auto &spo = registry.storage<present_orientation>();
+    pool_of(s).parallel_for((uint32_t)s.bodies.size(), write_back_grain, [&](uint32_t begin, uint32_t end, unsigned) {
+        for (uint32_t i = begin; i < end; ++i) {
+            const entt::entity e = s.bodies[i];
+            if (e == entt::null || !spp.contains(e) || !spo.contains(e) || !sp.contains(e) || !sq.contains(e)) continue;
+            const auto &p = sp.get(e); const auto &q = sq.get(e);
+            auto &pp = spp.get(e); pp.x = p.x; pp.y = p.y; pp.z = p.z;
+            auto &po = spo.get(e); po.x = q.x; po.y = q.y; po.z = q.z; po.w = q.w;
+        }
+    });
 }
 }  // namespace detail
 
@@ -1000,9 +1257,17 @@ inline void update_presentation(entt::registry &registry, gpu_stepper &s, double
 inline void attach(entt::registry &registry, const init_config &config = {}) {
     auto &s = registry.ctx().emplace<detail::gpu_stepper>();
     s.cfg = config;
+    // destroyed bodies / constraints are noticed through on_destroy hooks, like the reference's island manager (island_manager.cpp:24-27)
+    detail::connect_removal_hooks<rigidbody_tag, detail::body_index, point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint,
+                                  generic_constraint, null_constraint, gravity_constraint, cone_constraint, cvjoint_constraint>(registry, s);
+    s.hooks_connected = true;
 }
 inline void detach(entt::registry &registry) {   // edyn.cpp:148-197: the stepper goes, and every entity the engine created with it
     if (auto *s = registry.ctx().find<detail::gpu_stepper>()) {
+        if (s->hooks_connected)
+            detail::disconnect_removal_hooks<rigidbody_tag, detail::body_index, point_constraint, hinge_constraint, distance_constraint, soft_distance_constraint,
+                                             generic_constraint, null_constraint, gravity_constraint, cone_constraint, cvjoint_constraint>(registry, *s);
+        s->hooks_connected = false;
         for (auto &kv : s->point_entities) if (registry.valid(kv.second)) registry.destroy(kv.second);
         for (auto &kv : s->manifold_entities) if (registry.valid(kv.second)) registry.destroy(kv.second);
         s->point_entities.clear(); s->manifold_entities.clear();
@@ -1038,7 +1303,9 @@ inline void refresh(entt::registry &registry) { registry.ctx().get<detail::gpu_s
 /// solver always integrates with fixed_dt).
 inline void update(entt::registry &registry, double time) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
-    if (s.paused) { detail::run_steps(registry, s, 0); return; }
+    if (s.paused) { detail::run_steps(registry, s, 0); detail::snap_presentation(registry, s); return; }
+    detail::phase_timer whole(s.tm.total);
+    ++s.tm.updates;
     const double sim_time = s.last_time - s.accumulated;   // get_simulation_timestamp() before this update
     const double elapsed = std::max(time - s.last_time, 0.0);
     s.accumulated += elapsed;
@@ -1052,10 +1319,15 @@ inline void update(entt::registry &registry, double time) {
         effective_steps = s.cfg.max_steps_per_update;
         step_dt = advance_dt / static_cast<double>(effective_steps);
     }
+    s.present_dt = detail::presentation_dt(s, time);   // travels to the device with the write-back request
+    s.host_presentation = false;
     detail::run_steps(registry, s, (unsigned)effective_steps, true, sim_time, step_dt);
     s.last_time = time;
-    detail::update_presentation(registry, s, time);
+    if (s.host_presentation) { detail::phase_timer t(s.tm.presentation); detail::update_presentation(registry, s, s.present_dt); }
 }
+/// Host-side cost of the shim per phase since attach / the last reset (shim_timings above).
+inline shim_timings get_shim_timings(entt::registry &registry) { return registry.ctx().get<detail::gpu_stepper>().tm; }
+inline void reset_shim_timings(entt::registry &registry) { registry.ctx().get<detail::gpu_stepper>().tm = shim_timings{}; }
 namespace detail {
 inline double performance_time() {   // time/time.hpp performance_time(): seconds on a monotonic clock
     using namespace std::chrono;

@@ -353,6 +353,38 @@ int edynhip_get_point_ids(edynhip_ctx *ctx, uint64_t *ids, uint32_t capacity_man
 int edynhip_snapshot(edynhip_ctx *ctx);
 int edynhip_snapshot_read(edynhip_ctx *ctx, float *pos, float *orn, float *linvel, float *angvel, uint32_t *step_index);
 
+/* The registry write-back, read in place (ABI 15). The reference has no write-back - the registry IS its storage
+ * (stepper_sequential.cpp:28-119) - so what a registry-facing caller pays per update beyond the step is this copy. One packed
+ * 96-byte record per body, written by the device into pinned host memory the context owns (two slots, alternating): no
+ * per-call staging arrays, no second scatter, and everything a per-body host loop would otherwise compute or fetch separately:
+ *   pos orn linvel angvel   the simulated state (what solver::update leaves in the components, solver.cpp:331-339)
+ *   present_pos/orn         update_presentation.cpp:56-84 evaluated at `present_dt` from that state: pos + linvel * dt and
+ *                           integrate(orn, angvel, dt) (math/quaternion.cpp:7-22) with the stepper's own integrate()
+ *   origin                  update_origins.cpp:13-15 (meaningful when EDYNHIP_RECORD_HAS_ORIGIN is set)
+ *   flags                   EDYNHIP_RECORD_*: dynamic body / sleeping_tag (island_manager.cpp:541-565) / has a centre-of-mass offset / removed
+ * and the contact events of the last step call (edynhip_get_contact_events' list), the first `max_events` of them.
+ * edynhip_snapshot_records enqueues, behind the steps issued so far, the pack and the copy (on a side stream) and returns at once;
+ * edynhip_snapshot_map waits for THAT copy only and hands out pointers into the pinned slot, valid until the next-but-one
+ * edynhip_snapshot_records call. step -> snapshot_records -> step -> snapshot_map hands over the first step's result while the
+ * second one runs (simulation_worker.cpp:406-444). `total_events` > `num_events`: the list was cut - in a synchronous caller
+ * edynhip_get_contact_events still returns all of them (until the next step call), otherwise resynchronise from the manifolds. */
+enum { EDYNHIP_RECORD_DYNAMIC = 1u, EDYNHIP_RECORD_ASLEEP = 2u, EDYNHIP_RECORD_HAS_ORIGIN = 4u, EDYNHIP_RECORD_REMOVED = 8u };
+typedef struct {
+    float pos[3], orn[4], linvel[3], angvel[3];
+    float present_pos[3], present_orn[4];
+    float origin[3];
+    uint32_t flags;
+} edynhip_body_record;
+typedef struct {
+    const edynhip_body_record *records;    /* [num_bodies], index = body id */
+    uint32_t num_bodies;
+    uint32_t step_index;                   /* steps completed when the snapshot was taken */
+    const edynhip_contact_event *events;   /* [num_events]; NULL when the context records no events */
+    uint32_t num_events, total_events;
+} edynhip_record_view;
+int edynhip_snapshot_records(edynhip_ctx *ctx, float present_dt, uint32_t max_events);
+int edynhip_snapshot_map(edynhip_ctx *ctx, edynhip_record_view *view);
+
 /* Test hook: run the device closest-feature routine on `n` independent shape pairs (no world state involved).
  * shape_type[n][2], shape_param[n][2][4], pos[n][2][3], orn[n][2][4]; out_points[n][4][11] =
  * (pivotA3, pivotB3, normal3, distance, attachment) per point, out_count[n]. Replaces nothing in the reference: it

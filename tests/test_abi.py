@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in edynhip.h but not exported"
     assert sorted(_capi.SYMBOLS) == syms, "edyn_amd/_capi.py SYMBOLS out of sync with include/edynhip.h"
-    assert lib.edynhip_abi_version() == 14
+    assert lib.edynhip_abi_version() == 15
 
 
 def test_record_layouts_match():

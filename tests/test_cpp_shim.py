@@ -22,6 +22,32 @@ def test_reference_include_paths_resolve_to_the_shim():
     assert "INCLUDES_OK 1" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("prog", ["host_logic", "host_logic_entt"])
+def test_shim_host_logic(prog):
+    """No GPU: the write-back's fork-join pool visits every index exactly once (1-8 threads, sleeping and pre-woken workers), the
+    on_destroy hooks that replace the per-update scan for destroyed bodies / constraints, the host form of update_presentation /
+    snap_presentation - tests/cpp/host_logic.cpp on both registry branches."""
+    subprocess.check_call(["make", "-s", "-C", CPP, prog])
+    out = subprocess.run([os.path.join(CPP, prog)], capture_output=True, text=True, timeout=300)
+    assert "HOST_LOGIC_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["bench_update", "bench_update_entt"])
+def test_shim_update_bench_small(prog):
+    """tests/cpp/bench_update.cpp on a 10^3 pile: edyn::update in sequential / asynchronous mode, default / exclusive launches, with and
+    without contact entities - every run steps exactly once per update, stays finite, rests at the right height and keeps its
+    contact entities in step with the device (the program's own checks); the timing lines are printed for the log."""
+    import json
+    subprocess.check_call(["make", "-s", "-C", CPP, prog])
+    out = subprocess.run([os.path.join(CPP, prog), "10", "90", "60"], capture_output=True, text=True, timeout=600)
+    assert "BENCH_UPDATE_OK" in out.stdout, out.stdout + out.stderr
+    runs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(runs) == 5
+    seq = [r for r in runs if r["run"] == "sequential"][0]
+    assert seq["contact_point_entities"] == seq["contact_points"] > 1000   # the registry mirrors the device's contact points
+
+
 @pytest.mark.gpu
 def test_shim_hello_world_runs():
     subprocess.check_call(["make", "-s", "-C", CPP, "hello_world"])

@@ -1573,6 +1573,73 @@ def test_double_buffered_snapshots_deliver_the_previous_step():
     assert_state_equal(a, b)
 
 
+def _integrate_f32(q, w, dt):
+    """math/quaternion.cpp:7-22 in float32 with sin / cos through double (what dmath.hpp integrate() computes)."""
+    f = np.float32
+    dt = f(dt)
+    ws = np.sqrt((w[:, 0] * w[:, 0] + w[:, 1] * w[:, 1] + w[:, 2] * w[:, 2]).astype(f)).astype(f)
+    small = ws < f(0.001)
+    t_small = (f(0.5) * dt - dt * dt * dt * (f(1) / f(48)) * ws * ws).astype(f)
+    arg = (f(0.5) * ws * dt).astype(f)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_big = (np.sin(arg.astype(np.float64)).astype(f) / ws).astype(f)
+    t = np.where(small, t_small, t_big).astype(f)
+    r = np.stack([w[:, 0] * t, w[:, 1] * t, w[:, 2] * t, np.cos(arg.astype(np.float64)).astype(f)], 1).astype(f)
+    x, y, z, ww = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    o = np.stack([r[:, 3] * x + r[:, 0] * ww + r[:, 1] * z - r[:, 2] * y, r[:, 3] * y + r[:, 1] * ww + r[:, 2] * x - r[:, 0] * z,
+                  r[:, 3] * z + r[:, 2] * ww + r[:, 0] * y - r[:, 1] * x, r[:, 3] * ww - r[:, 0] * x - r[:, 1] * y - r[:, 2] * z], 1).astype(f)
+    n = np.sqrt((o[:, 0] * o[:, 0] + o[:, 1] * o[:, 1] + o[:, 2] * o[:, 2] + o[:, 3] * o[:, 3]).astype(f)).astype(f)
+    return (o / n[:, None]).astype(f)
+
+
+def test_record_snapshots_are_the_write_back_in_place():
+    """edynhip_snapshot_records / edynhip_snapshot_map (ABI 15): the 96-byte records a registry write-back reads in place.
+    State fields bit-identical to edynhip_get_state at the same point (and therefore to the oracle, held by every other test);
+    present_pos / present_orn = update_presentation.cpp:56-84 evaluated from that state (pos + linvel dt bit for bit; the orientation
+    within 1 ulp of the float32 formula: numpy may fuse differently); flags = kind / sleeping_tag / centre-of-mass offset; origin =
+    update_origins.cpp:13-15 for the bodies that have an offset; the contact events of the last step call travel along, cut at
+    max_events with the true total reported; two snapshots in flight deliver the older state while newer steps run."""
+    scene = scenes.box_pile(5, 5, 5, mixed=True)
+    scene["com"] = np.zeros((len(scene["kind"]), 3), np.float32); scene["com"][7] = (0.1, -0.05, 0.2); scene["com"][11] = (0, 0.2, 0)
+    g = gpu_world(scene, contact_events=True, sleeping=True)
+    total_seen = 0
+    for call in range(30):
+        g.step_simulation(1 + call % 2)
+        dt = np.float32(-1.0 / 60 + 0.001 * call)
+        g.snapshot_records(present_dt=float(dt), max_events=64)
+        rec, ev, total, step = g.snapshot_map()
+        p, q, v, w = g.get_state()
+        assert np.array_equal(rec["pos"], p) and np.array_equal(rec["orn"], q) and np.array_equal(rec["linvel"], v) and np.array_equal(rec["angvel"], w), call
+        assert np.array_equal(rec["present_pos"], (p + v * dt).astype(np.float32)), call
+        want = _integrate_f32(q, w, dt)
+        assert np.abs(rec["present_orn"] - want).max() <= 1.2e-7, (call, float(np.abs(rec["present_orn"] - want).max()))
+        dyn = np.asarray(scene["kind"]) == scenes.KIND_DYNAMIC
+        assert np.array_equal((rec["flags"] & 1) != 0, dyn)
+        assert np.array_equal((rec["flags"] & 2) != 0, g.get_asleep().astype(bool))
+        has_org = (rec["flags"] & 4) != 0
+        assert has_org[7] and has_org[11] and has_org.sum() == 2
+        # origin = to_world(-com, pos, orn) (update_origins.cpp:13-15), for the bodies that have one; the others report their position
+        assert np.array_equal(rec["origin"][~has_org], p[~has_org])
+        for i in (7, 11):
+            c = -scene["com"][i].astype(np.float64); u = q[i, :3].astype(np.float64)
+            t = 2 * np.cross(u, c); o = p[i] + c + q[i, 3] * t + np.cross(u, t)
+            assert np.abs(rec["origin"][i] - o).max() < 2e-6, (i, rec["origin"][i], o)
+        all_ev = g.get_contact_events()
+        assert total == len(all_ev) and len(ev) == min(total, 64)
+        assert np.array_equal(ev, all_ev[:len(ev)]), call
+        total_seen += total
+    assert total_seen > 200
+    # two snapshots in flight: the older one is delivered although newer steps are enqueued behind it
+    a, b = gpu_world(scenes.box_pile(6, 6, 6)), gpu_world(scenes.box_pile(6, 6, 6))
+    for i in range(1, 13):
+        a.step_simulation(1); a.snapshot_records(); a.step_simulation(1)
+        rec, _, _, idx = a.snapshot_map()
+        b.step_simulation(1)
+        bp, bq, bv, bw = b.get_state()
+        assert idx == 2 * i - 1 and np.array_equal(rec["pos"], bp) and np.array_equal(rec["orn"], bq) and np.array_equal(rec["linvel"], bv) and np.array_equal(rec["angvel"], bw), i
+        b.step_simulation(1)
+
+
 @pytest.mark.parametrize("kind", ["roll_spin", "soft", "both"])
 def test_contact_extras_bit_exact(kind):
     """contact_extras_constraint on the device (rolling / spinning friction rows, soft normal rows, material mixing, no
