@@ -322,6 +322,35 @@ def per_rank_proxy(workload, args, device_index, stream, ranks):
                        f"(13 floats per body) and the slowest of the {ranks} ranks come on top - not a {ranks}-GPU measurement"}
 
 
+def shim_leg(steps, settle):
+    """The drop-in itself (VERDICT r05 item 1): tests/cpp/bench_update.cpp - the headline pile built with edyn::make_rigidbody,
+    edyn::update(registry, t) once per step through include/edyn/edyn.hpp - in execution_mode::sequential and ::asynchronous, default
+    and exclusive_device launch modes, against edynhip_step on the very same context. A separate process (plain C++ over the C-ABI)."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    exe = os.path.join(cpp, "bench_update")
+    try:
+        subprocess.check_call(["make", "-s", "-C", cpp, "bench_update"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        res = subprocess.run([exe, "32", str(settle), str(steps)], capture_output=True, text=True, timeout=600)
+    except Exception as e:   # no compiler on the box, a time-out: the bench line says so instead of failing
+        return {"error": f"{type(e).__name__}: {e}"}
+    runs = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    if not runs or "BENCH_UPDATE_OK" not in res.stdout:
+        return {"error": "bench_update failed", "tail": (res.stdout + res.stderr)[-400:]}
+    return {"what": "edyn::update(registry, t) over the registry, one fixed step per call, on the headline pile built with edyn::make_rigidbody (tests/cpp/bench_update.cpp); "
+                    "bundled mini registry; the shim's defaults: island sleeping on, contact_manifold / contact_point entities kept in step with the device "
+                    f"(~{runs[0]['contact_events_per_update']:.0f} creations + destructions per update); settled {settle} updates, {steps} timed",
+            "steps_per_sec": {r["run"]: r["update_steps_per_sec"] for r in runs},
+            "raw_steps_per_sec_same_context": {r["run"]: r["raw_steps_per_sec"] for r in runs},
+            "ratio_to_raw_same_context": {r["run"]: r["ratio"] for r in runs},
+            "host_ms_per_update": {r["run"]: r["host_ms_per_update"] for r in runs},
+            "ms_per_update": {r["run"]: r["ms_per_update"] for r in runs},
+            "contact_point_entities": runs[0]["contact_point_entities"],
+            "reading": "host_ms_per_update = registry write-back + contact entities + removal hooks + presentation (the latter now computed on the device and "
+                       "delivered with the state); in sequential mode the contact entities are built while the step's solve still runs on the device, in "
+                       "asynchronous mode the whole import overlaps the next step; step_call = host time inside edynhip_step (the step's counter fetches), "
+                       "state_wait = waiting for the rest of the step and the 96-byte-per-body record copy"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +361,8 @@ def main():
     ap.add_argument("--north-star", default="auto", help="workload of the north_star leg (sharded islands): a workload name, 'none', or 'auto' = islands1m on the default workload")
     ap.add_argument("--north-star-steps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shim", action="store_true", help="skip the edyn::update leg (tests/cpp/bench_update: the C++ drop-in over the registry)")
+    ap.add_argument("--shim-steps", type=int, default=300)
     ap.add_argument("--arithmetic", default="reference", choices=sorted(ARITHMETIC),
                     help="contact arithmetic of the measured run (default: the reference's operations; the others are the opt-in faster forms)")
     ap.add_argument("--other-arithmetic-steps", type=int, default=None,
@@ -511,6 +542,10 @@ def main():
         if rank == 0 and world_size == 1 and "shard" in WORKLOADS[ns_name] and WORKLOADS[ns_name]["shard_units"] >= 8:
             out["north_star"]["per_rank_proxy"] = per_rank_proxy(ns_name, args, device_index, stream, 8)
 
+    if rank == 0 and world_size == 1 and args.workload == "pile32k" and not args.no_shim:
+        out["shim"] = shim_leg(args.shim_steps, leg.settle)
+        if "steps_per_sec" in out["shim"]:
+            out["shim"]["ratio_to_value"] = {k: v / out["value"] for k, v in out["shim"]["steps_per_sec"].items()}
     if rank == 0:
         if state_path is not None:
             try:

@@ -97,7 +97,7 @@ SYMBOLS = ["edynhip_create", "edynhip_destroy", "edynhip_last_error", "edynhip_s
            "edynhip_get_timings", "edynhip_get_stats", "edynhip_abi_version", "edynhip_set_pair_filter", "edynhip_default_should_collide", "edynhip_debug_collide", "edynhip_add_bodies", "edynhip_get_asleep", "edynhip_wake_all", "edynhip_wake_bodies", "edynhip_set_center_of_mass",
            "edynhip_refresh_derived", "edynhip_exclude_collision", "edynhip_remove_collision_exclusion", "edynhip_add_joints",
            "edynhip_remove_joints", "edynhip_set_joint_params", "edynhip_remove_bodies", "edynhip_get_params", "edynhip_set_params",
-           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read", "edynhip_snapshot_records", "edynhip_snapshot_map",
+           "edynhip_step_timed", "edynhip_get_contact_events", "edynhip_get_point_ids", "edynhip_snapshot", "edynhip_snapshot_read", "edynhip_snapshot_records", "edynhip_snapshot_map", "edynhip_set_event_prefetch", "edynhip_prefetched_events",
            "edynhip_set_material_extras", "edynhip_get_point_extras", "edynhip_set_joint_definition",
            "edynhip_set_generic_definition", "edynhip_get_joint_slot_impulses", "edynhip_set_material_ids", "edynhip_insert_material_mixing",
            "edynhip_measure_bandwidth", "edynhip_set_joint_warm_start", "edynhip_set_asleep", "edynhip_create_convex_mesh",
@@ -153,6 +153,8 @@ def lib():
         L.edynhip_snapshot.argtypes = [C.c_void_p]
         L.edynhip_snapshot_records.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
         L.edynhip_snapshot_map.argtypes = [C.c_void_p, C.POINTER(RecordView)]
+        L.edynhip_set_event_prefetch.argtypes = [C.c_void_p, C.c_uint32]
+        L.edynhip_prefetched_events.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.edynhip_set_joint_definition.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.edynhip_set_material_ids.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.edynhip_insert_material_mixing.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]

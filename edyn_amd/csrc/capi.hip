@@ -442,6 +442,14 @@ static int run_stages(edynhip_ctx *c, uint32_t mask) {
     rec(1);
     if (mask & EDYNHIP_STAGE_NARROWPHASE) EH_TRY(guarded(narrowphase(c)));
     rec(2);
+    if (c->evp_now && c->events) {   // every event of a step is emitted by the broadphase and the narrowphase: the list of this call is complete
+        EH_HIP(c, hipEventRecord(c->evp_np_done, c->stream));
+        EH_HIP(c, hipStreamWaitEvent(c->snap_stream, c->evp_np_done, 0));
+        EH_HIP(c, hipMemcpyAsync(c->evp_host, c->event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->snap_stream));
+        EH_HIP(c, hipMemcpyAsync(c->evp_host + 64, c->events, (size_t)std::min(c->evp_max, c->event_cap) * sizeof(eh::ContactEvent), hipMemcpyDeviceToHost, c->snap_stream));
+        EH_HIP(c, hipEventRecord(c->evp_ready, c->snap_stream));
+        c->evp_state = 1;
+    }
     if (mask & EDYNHIP_STAGE_ISLANDS) EH_TRY(guarded(islands(c)));
     if (mask & EDYNHIP_STAGE_SOLVE) EH_TRY(guarded(solve(c)));   // records events 3..9
     rec(10);
@@ -520,7 +528,7 @@ using namespace eh;
 
 extern "C" {
 
-uint32_t edynhip_abi_version(void) { return 15; }   // 15: edynhip_snapshot_records / edynhip_snapshot_map (the registry write-back read in place); 14: EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION (the default contact arithmetic is the reference's); 13: edynhip_set_pair_filter (settings.should_collide_func); 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
+uint32_t edynhip_abi_version(void) { return 15; }   // 15: edynhip_snapshot_records / edynhip_snapshot_map (the registry write-back read in place), edynhip_set_event_prefetch / edynhip_prefetched_events; 14: EDYNHIP_FLAG_FUSED_VELOCITY_ROWS / EDYNHIP_FLAG_BLOCK_POSITION (the default contact arithmetic is the reference's); 13: edynhip_set_pair_filter (settings.should_collide_func); 12: multi-GPU world (edynhip_world_*, multi.hip); 11: polyhedron shapes (edynhip_create_convex_mesh); 10: edynhip_stats::solve_schedule, edynhip_measure_bandwidth; 9: edynhip_set_center_of_mass; 8: edynhip_bodies::center_of_mass; 7: edynhip_wake_bodies; 6: every constraint type, capsules, material mix table; 5: contact_extras materials; 4: contact events + point ids, double-buffered snapshots;   // 3: joint slots/params, add/remove joints, remove bodies, params, timed steps, exclusions
 
 const char *edynhip_last_error(const edynhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -572,6 +580,9 @@ void edynhip_destroy(edynhip_ctx *c) {
         if (c->snap_host[k]) (void)hipHostFree(c->snap_host[k]);
         if (c->snap_event[k]) (void)hipEventDestroy(c->snap_event[k]);
     }
+    if (c->evp_host) (void)hipHostFree(c->evp_host);
+    if (c->evp_np_done) (void)hipEventDestroy(c->evp_np_done);
+    if (c->evp_ready) (void)hipEventDestroy(c->evp_ready);
     for (int k = 0; k < 2; ++k) {
         if (c->rec_host[k]) (void)hipHostFree(c->rec_host[k]);
         if (c->rec_event[k]) (void)hipEventDestroy(c->rec_event[k]);
@@ -653,6 +664,8 @@ static int load_bodies(edynhip_ctx *c, uint32_t first, uint32_t n, const edynhip
         for (uint32_t i = 0; i < n; ++i) { c->host_group[first + i] = in->group ? in->group[i] : ~0ull; c->host_mask[first + i] = in->mask ? in->mask[i] : ~0ull; }
     }
     up(in->sleeping_disabled, n, r.sleeping_disabled);
+    if (first == 0) c->num_sleepable = 0;
+    for (uint32_t i = 0; i < n; ++i) if (in->kind[i] == EDYNHIP_KIND_DYNAMIC && !(in->sleeping_disabled && in->sleeping_disabled[i])) ++c->num_sleepable;
     {   // centre-of-mass offsets: the origin arrays are attached to the body set with the first body that has one
         bool any = false;
         if (in->center_of_mass) for (size_t k = 0; k < (size_t)n * 3; ++k) any = any || in->center_of_mass[k] != 0.0f;
@@ -1061,7 +1074,9 @@ static int step_stamped(edynhip_ctx *c, uint32_t nsteps, bool timed, double firs
     c->timings = edynhip_timings{};
     c->timer.recorded = 0;
     if (c->events) EH_HIP(c, hipMemsetAsync(c->event_count, 0, sizeof(uint32_t), c->stream));   // the events of THIS call
+    c->evp_state = c->evp_max ? 2 : 0;
     for (uint32_t i = 0; i < nsteps; ++i) {
+        c->evp_now = c->evp_max != 0 && i + 1 == nsteps;
         // island_manager::update runs put_islands_to_sleep() against the PREVIOUS step's stamp and only then takes the new one
         // (island_manager.cpp:533-539): the kernels read c->sim_clock, which is advanced after the step
         const double stamp = timed ? first_time + step_dt * (double)i : c->sim_clock + (double)c->cfg.fixed_dt;
@@ -1070,8 +1085,9 @@ static int step_stamped(edynhip_ctx *c, uint32_t nsteps, bool timed, double firs
         if (c->all_asleep) { ++c->step_index; c->sim_clock = stamp; continue; }
         const int rc = run_stages(c, EDYNHIP_STAGE_ALL);
         c->sim_clock = stamp;
-        if (rc != EDYNHIP_OK) return rc;
+        if (rc != EDYNHIP_OK) { c->evp_now = false; return rc; }
     }
+    c->evp_now = false;
     return EDYNHIP_OK;
 }
 int edynhip_step(edynhip_ctx *c, uint32_t nsteps) {
@@ -1692,6 +1708,39 @@ int edynhip_snapshot_map(edynhip_ctx *c, edynhip_record_view *view) {
     view->events = c->events ? (const edynhip_contact_event *)(h + kRecHeader) : nullptr;
     view->total_events = header[0];
     view->num_events = header[1];
+    return EDYNHIP_OK;
+}
+
+// ---- contact-event prefetch: the events of a step call handed over while its solve still runs
+int edynhip_set_event_prefetch(edynhip_ctx *c, uint32_t max_events) {
+    if (!c) return EDYNHIP_ERR_INVALID;
+    if (!c->events) return set_error(c, EDYNHIP_ERR_UNSUPPORTED, "edynhip_set_event_prefetch: create the context with EDYNHIP_FLAG_CONTACT_EVENTS");
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->snap_stream) EH_HIP(c, hipStreamSynchronize(c->snap_stream));
+    if (c->evp_host) { (void)hipHostFree(c->evp_host); c->evp_host = nullptr; }
+    c->evp_max = std::min(max_events, c->event_cap); c->evp_state = 0;
+    if (c->evp_max == 0) return EDYNHIP_OK;
+    if (!c->snap_stream) {
+        EH_HIP(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+        EH_HIP(c, hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming));
+    }
+    if (!c->evp_np_done) { EH_HIP(c, hipEventCreateWithFlags(&c->evp_np_done, hipEventDisableTiming)); EH_HIP(c, hipEventCreateWithFlags(&c->evp_ready, hipEventDisableTiming)); }
+    EH_HIP(c, hipHostMalloc((void **)&c->evp_host, 64 + (size_t)c->evp_max * sizeof(eh::ContactEvent), hipHostMallocDefault));
+    std::memset(c->evp_host, 0, 64);
+    return EDYNHIP_OK;
+}
+int edynhip_prefetched_events(edynhip_ctx *c, const edynhip_contact_event **events, uint32_t *num_events, uint32_t *total_events) {
+    if (!c || !events || !num_events || !total_events) return EDYNHIP_ERR_INVALID;
+    *events = nullptr; *num_events = 0; *total_events = 0;
+    if (c->evp_max == 0 || c->evp_state == 0) return set_error(c, EDYNHIP_ERR_INVALID, "edynhip_prefetched_events: no step call ran with the prefetch enabled");
+    if (c->evp_state == 2) return EDYNHIP_OK;   // every island asleep: the call ran no step, nothing happened
+    EH_HIP(c, hipSetDevice(c->device));
+    EH_HIP(c, hipEventSynchronize(c->evp_ready));   // that copy only: the step's solve may still be running
+    const uint32_t total = *(const uint32_t *)c->evp_host;
+    *total_events = total;
+    *num_events = std::min(std::min(total, c->event_cap), c->evp_max);
+    *events = (const edynhip_contact_event *)(c->evp_host + 64);
     return EDYNHIP_OK;
 }
 

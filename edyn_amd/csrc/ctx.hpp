@@ -377,6 +377,15 @@ struct edynhip_ctx {
     // double-buffered read-back (edynhip_snapshot): pinned host copies of the packed state, the event that completes each
     float *snap_host[2] = {nullptr, nullptr}; float *snap_dev[2] = {nullptr, nullptr}; hipEvent_t snap_event[2] = {nullptr, nullptr};
     uint32_t snap_step[2] = {0, 0}, snap_bodies[2] = {0, 0}; int snap_last = -1; hipStream_t snap_stream = nullptr; hipEvent_t snap_ready = nullptr;
+    // Bodies that CAN sleep (dynamic, not sleeping_disabled) ever uploaded (removals are not subtracted: an upper bound). While it is zero
+    // the island-sleeping stage has nothing to decide - every island carries SL_DISABLED (the reference's exclude_sleeping_disabled views
+    // skip such entities, island_manager.cpp:573-623) - and its kernels are not launched: a benchmark scene, sleeping_disabled on every
+    // body as SURVEY 8(d) prescribes, then steps like a context created without EDYNHIP_FLAG_SLEEPING.
+    uint32_t num_sleepable = 0;
+    bool sleep_active() const { return sleeping && num_sleepable > 0; }
+    // contact-event prefetch (edynhip_set_event_prefetch): the event list of a step call copied to pinned memory as soon as the last step's
+    // narrowphase has run - the caller turns it into registry entities while the solve is still running
+    uint32_t evp_max = 0; uint8_t *evp_host = nullptr; hipEvent_t evp_np_done = nullptr, evp_ready = nullptr; bool evp_now = false; int evp_state = 0;   // 0 none, 1 copy enqueued, 2 the call ran no step
     // record snapshots (edynhip_snapshot_records, ABI 15): per slot one device block and its pinned host copy, laid out as
     // [header 64 B | events: rec_event_cap x 24 B | records: bodies x 96 B]; the registry write-back reads the pinned copy in place
     uint8_t *rec_host[2] = {nullptr, nullptr}; uint8_t *rec_dev[2] = {nullptr, nullptr}; hipEvent_t rec_event[2] = {nullptr, nullptr};

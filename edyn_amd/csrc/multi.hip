@@ -20,6 +20,7 @@
 // their relative order: a shard computes for its islands exactly what one context computes for the whole world
 // (tests/cpp/multi.cpp: bit-equal through a forced and an approach-triggered re-partition).
 #include "ctx.hpp"
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -350,6 +351,17 @@ int shard_filter_thunk(void *user, uint32_t body, uint32_t other) {
     return w->filter(w->filter_user, s.local_ids[body], s.local_ids[other]);
 }
 
+// developer aid (EDYNHIP_WORLD_TRACE=1): wall time of the phases of a re-partition, to stderr
+struct PhaseTrace {
+    bool on; std::chrono::steady_clock::time_point t0; const char *what;
+    explicit PhaseTrace(const char *w_) : on(getenv("EDYNHIP_WORLD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w_) {}
+    void mark(const char *phase) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edynhip_world] %s: %s %.2f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 // (Re)builds shard r for the partition w->rank_of from the scene, the current global state and what the islands carry.
 void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_state) {
     Shard &s = w->shards[r];
@@ -384,9 +396,11 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     cfg.max_joints = std::max<uint32_t>((uint32_t)s.local_joints.size() + 16, 16);
     if (w->cfg.max_manifolds) cfg.max_manifolds = w->cfg.max_manifolds; else cfg.max_manifolds = 0;
     int status = 0;
+    PhaseTrace trace("build_shard");
     s.ctx = edynhip_create(&cfg, &status);
     if (!s.ctx) { s.rc = status; s.err = edynhip_last_error(nullptr); return; }
     s.cap = cfg.max_bodies;
+    trace.mark("edynhip_create");
     for (const HostScene::Mesh &m : sc.meshes) {
         uint32_t id = 0;
         SH_TRY(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)m.v.size() / 3, m.v.data(), (uint32_t)m.idx.size(), m.idx.data(), (uint32_t)m.faces.size() / 2, m.faces.data(), m.flags, &id));
@@ -407,6 +421,7 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     b.gravity = gr.empty() ? nullptr : gr.data(); b.sleeping_disabled = sd.empty() ? nullptr : sd.data();
     b.center_of_mass = com.empty() ? nullptr : com.data();
     SH_TRY(s, edynhip_set_bodies(s.ctx, nl, &b));
+    trace.mark("take + edynhip_set_bodies");
     if (from_state && !com.empty()) {   // set_bodies read `pos` as the origin of bodies with an offset: put the centre-of-mass state back ...
         SH_TRY(s, edynhip_set_state(s.ctx, pos.data(), orn.data(), lv.data(), av.data()));
         // ... and with it what set_bodies derived from the misread position: origins, AABBs (displaced by R com otherwise - the first
@@ -443,7 +458,9 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
                 mine.push_back(m);
                 mine.back().body[0] = (uint32_t)s.to_local[m.body[0]]; mine.back().body[1] = (uint32_t)s.to_local[m.body[1]];   // a monotone map: the canonical order is kept
             }
+        trace.mark("joints, exclusions, select carried manifolds");
         if (!mine.empty()) SH_TRY(s, edynhip_set_manifolds(s.ctx, mine.data(), (uint32_t)mine.size()));
+        trace.mark("edynhip_set_manifolds");
         if (njl && !carry.imp24.empty()) {
             auto i24 = take(carry.imp24, s.local_joints, 24), ang = take(carry.angle, s.local_joints, 1);
             SH_TRY(s, edynhip_set_joint_warm_start(s.ctx, i24.data(), ang.data()));
@@ -471,6 +488,7 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     SH_HIP(s, hipMalloc((void **)&s.mon_dev, words * sizeof(uint32_t)));
     SH_HIP(s, hipHostMalloc((void **)&s.mon_host, (2 + 7 * (size_t)s.cap) * sizeof(uint32_t), hipHostMallocDefault));
     SH_HIP(s, hipMemset(s.mon_dev, 0, words * sizeof(uint32_t)));
+    trace.mark("warm start, sleep state, gather / monitor buffers");
 }
 
 // the shard's state into the world's global arrays (its own bodies; shard 0: also the replicated ones)
@@ -632,8 +650,10 @@ int rebuild(edynhip_world *w, const Carry &carry, bool from_state, const std::ve
 int repartition(edynhip_world *w, bool sticky) {
     const HostScene &sc = w->scene;
     const uint32_t n = sc.n, W = (uint32_t)w->shards.size();
+    PhaseTrace trace(sticky ? "sticky re-partition" : "full re-partition");
     w->pool->run([w, sticky](uint32_t r) { collect_shard(w, r, true, !sticky); });
     EH_TRY(shard_error(w));
+    trace.mark("collect light state of every shard");
     std::vector<uint32_t> labels(n);
     std::iota(labels.begin(), labels.end(), 0u);
     std::vector<float> aabb((size_t)n * 6, 0.f);
@@ -713,6 +733,7 @@ int repartition(edynhip_world *w, bool sticky) {
     std::vector<uint32_t> welded(n);
     for (uint32_t i = 0; i < n; ++i) welded[i] = find(labels[i]);
     ++w->stats.repartitions;
+    trace.mark("island boxes, welding");
     if (!sticky) {
         w->rank_of.assign(n, -1);
         partition_islands_spatial(n, welded.data(), sc.kind.data(), weights.data(), aabb.data(), W, w->rank_of.data());
@@ -743,11 +764,16 @@ int repartition(edynhip_world *w, bool sticky) {
         EH_TRY(approach_check(w, close, true));
         return EDYNHIP_OK;
     }
+    trace.mark("sticky targets");
     w->pool->run([w, &changed](uint32_t r) { if (changed[r]) collect_shard(w, r, false, true); });
     EH_TRY(shard_error(w));
+    trace.mark("collect manifolds / joint impulses of the changed shards");
     take_heavy(&changed);
+    trace.mark("merge carried manifolds");
     w->rank_of = next;
-    return rebuild(w, carry, true, &changed);
+    const int rc_rebuild = rebuild(w, carry, true, &changed);
+    trace.mark("rebuild changed shards (+ gather, approach check)");
+    return rc_rebuild;
 }
 
 int ensure_built(edynhip_world *w) {

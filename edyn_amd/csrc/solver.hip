@@ -3317,6 +3317,7 @@ int islands(edynhip_ctx *c) {
     const uint32_t n = c->b.n, M = c->num_manifolds;
     if (n == 0) return EDYNHIP_OK;
     const Manifolds &mf = c->m[c->cur];
+    const bool sleeping = c->sleep_active();   // (a world in which no body can sleep runs no sleep kernels: ctx.hpp num_sleepable)
     // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
     uint32_t *forest = c->isl_done;
     c->solve_begin_done = false;
@@ -3325,7 +3326,7 @@ int islands(edynhip_ctx *c) {
     c->force_islands = false;
     // No manifold now or in the previous step, nothing edited, no sleep decisions to take: the labels stand and every kernel below would
     // return at once - not launched at all (a world of joints only: 4 of its ~20 launches per step)
-    if (!force && M == 0 && pm == 0 && !c->sleeping && c->full_step) return EDYNHIP_OK;
+    if (!force && M == 0 && pm == 0 && !sleeping && c->full_step) return EDYNHIP_OK;
     // An in-place step (broadphase.hip: the pair set is last step's) has nothing to relabel. Otherwise the counters fetched with
     // the pair count say whether every certificate manifold is still there (see CC_INCREMENTAL above).
     const bool inplace = c->inplace_step;
@@ -3334,12 +3335,12 @@ int islands(edynhip_ctx *c) {
                      : (c->full_step && c->cnt_host->tree_found == c->cnt_host->tree_total) ? CC_INCREMENTAL : CC_FULL;
     (void)pm;
     // island sleeping: last step's labels, before the hooks rewrite them (the merge rule of k_sleep_sizes / k_sleep_carry reads them)
-    if (c->sleeping && mode != CC_SKIP && c->sleep_old_label)
+    if (sleeping && mode != CC_SKIP && c->sleep_old_label)
         EH_HIP(c, hipMemcpyAsync(c->sleep_old_label, c->b.island, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     // the solve's per-body start rides on the flatten kernel when nothing in between looks at velocities or sleep flags
-    const bool begin = c->full_step && !c->sleeping && !c->has_restitution;
+    const bool begin = c->full_step && !sleeping && !c->has_restitution;
     auto flatten = [&](uint32_t *forest_or_labels) {
-        uint32_t *split = (c->sleeping && mode == CC_FULL) ? c->sleep_state : nullptr;
+        uint32_t *split = (sleeping && mode == CC_FULL) ? c->sleep_state : nullptr;
         if (begin) hipLaunchKernelGGL(k_cc_flatten<true>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot, split);
         else hipLaunchKernelGGL(k_cc_flatten<false>, dim3(blocks(n, 256)), dim3(256), 0, s, n, c->b.flags, forest_or_labels, c->b.island, c->cnt, mode, c->b, c->cfg.fixed_dt, c->rows.first_slot, split);
         c->solve_begin_done = begin;
@@ -3357,7 +3358,7 @@ int islands(edynhip_ctx *c) {
         hipLaunchKernelGGL(k_cc_hook_new, dim3(32), dim3(256), 0, s, c->new_edges, c->new_edge_m, mf.tree, c->b.flags, c->b.island, c->cnt);
         flatten(c->b.island);
     }
-    if (c->sleeping) {
+    if (sleeping) {
         const bool relabelled = mode != CC_SKIP && c->sleep_old_label != nullptr;
         SleepMerge sm{c->sleep_old_label, c->sleep_prev_n, c->sleep_size, c->sleep_best, c->sleep_carried};
         if (!relabelled) sm.best = nullptr;
@@ -3559,7 +3560,7 @@ int solve(edynhip_ctx *c) {
     EH_TRY(colour_contacts(c, speculative_prep, &first_final));
     if (!first_final) spec_prep = false;   // the sorted order changed after the speculative launch: prepare again
     // colour_contacts fetched the counters: with island sleeping, remember whether anything is still awake
-    c->all_asleep = c->sleeping && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
+    c->all_asleep = c->sleep_active() && c->full_step && c->num_manifolds > 0 && c->cnt_host->num_awake == 0;
     if (c->num_manifolds == 0) rec(c, 4);
     const uint32_t na = c->num_active, nc = c->num_colours;
     if (j.n) hipLaunchKernelGGL(k_prep_joints, dim3(blocks(j.n, 128)), dim3(128), 0, s, j, c->b, dt, c->isl_joint);
@@ -3602,13 +3603,13 @@ int solve(edynhip_ctx *c) {
         for (uint32_t k = 0; k <= j.num_colours && k <= kMaxColours; ++k) jc.start[k] = j.colour_start[k];
         // A world of joints only (no contact this step, no sleeping) whose bodies and joints have not been edited since the lists were
         // built has the same islands and the same lists: they are kept (chains16k: 4 launches of 28 per step)
-        const bool keep_lists = na == 0 && !c->sleeping && c->isl_lists_epoch == c->topology_epoch;
+        const bool keep_lists = na == 0 && !c->sleep_active() && c->isl_lists_epoch == c->topology_epoch;
         if (!keep_lists) {
         EH_HIP(c, hipMemsetAsync(&c->cnt->isl_num, 0, 4 * sizeof(uint32_t), s));   // isl_num, isl_max_items, isl_max_jitems, isl_free
         hipLaunchKernelGGL(k_isl_count, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, c->rows, c->b, isl);
         EH_TRY(scan_u32(c, c->isl_cnt, c->isl_off, n + 1));
         hipLaunchKernelGGL(k_isl_fill, dim3(blocks(j.n + na, 256)), dim3(256), 0, s, j.n, na, j, jc, c->rows, c->col_keys_sorted, c->b, isl, c->cnt);
-        c->isl_lists_epoch = (na == 0 && !c->sleeping) ? c->topology_epoch : 0xFFFFFFFFu;
+        c->isl_lists_epoch = (na == 0 && !c->sleep_active()) ? c->topology_epoch : 0xFFFFFFFFu;
         }
         if (largest == 0xFFFFFFFFu && c->last_fetch_step != c->step_index) {
             // no contacts and nothing with a shape: the step reads no counters at all and the islands are those of the

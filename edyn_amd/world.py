@@ -498,6 +498,18 @@ class World:
             ev = np.ctypeslib.as_array((C.c_uint8 * (v.num_events * _capi.EVENT_DTYPE.itemsize)).from_address(v.events)).view(_capi.EVENT_DTYPE).copy()
         return rec, ev, int(v.total_events), int(v.step_index)
 
+    def set_event_prefetch(self, max_events):
+        self._check(self._L.edynhip_set_event_prefetch(self._h, int(max_events)))
+
+    def prefetched_events(self):
+        """(events, total): the event list of the last step call as copied right after its last narrowphase (a structured copy)."""
+        ptr, num, total = C.c_void_p(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.edynhip_prefetched_events(self._h, C.byref(ptr), C.byref(num), C.byref(total)))
+        ev = np.zeros(0, _capi.EVENT_DTYPE)
+        if ptr.value and num.value:
+            ev = np.ctypeslib.as_array((C.c_uint8 * (num.value * _capi.EVENT_DTYPE.itemsize)).from_address(ptr.value)).view(_capi.EVENT_DTYPE).copy()
+        return ev, int(total.value)
+
     def set_manifolds(self, recs):
         recs = np.ascontiguousarray(recs, MANIFOLD_DTYPE)
         self._check(self._L.edynhip_set_manifolds(self._h, _ptr(recs), len(recs)))

@@ -373,6 +373,74 @@ private:
     void (*run_)(void *, uint32_t, uint32_t, unsigned){nullptr}; void *ctx_{nullptr}; uint32_t count_{0}, grain_{1}; std::atomic<uint32_t> chunks_{0};
 };
 
+// uint64 key -> entity, open addressing with linear probing and backward-shift deletion: the contact entities' look-up tables (half a
+// million live points on the headline pile, a thousand insertions and removals per update) - one cache line per operation and no node
+// allocations, where std::unordered_map pays a malloc / free and two dependent misses each. The interface is the subset of
+// std::unordered_map the shim uses (find / end / erase(iterator) / operator[] / clear / range-for over `first`, `second`).
+class entity_table {
+public:
+    struct slot { uint64_t first; entt::entity second; };
+    class iterator {
+    public:
+        iterator(slot *p, slot *e) : p_(p), e_(e) { skip(); }
+        slot &operator*() const { return *p_; }
+        slot *operator->() const { return p_; }
+        iterator &operator++() { ++p_; skip(); return *this; }
+        bool operator!=(const iterator &o) const { return p_ != o.p_; }
+        bool operator==(const iterator &o) const { return p_ == o.p_; }
+    private:
+        friend class entity_table;
+        void skip() { while (p_ != e_ && p_->first == empty_key) ++p_; }
+        slot *p_, *e_;
+    };
+    iterator begin() { return iterator(slots_.data(), slots_.data() + slots_.size()); }
+    iterator end() { return iterator(slots_.data() + slots_.size(), slots_.data() + slots_.size()); }
+    size_t size() const { return count_; }
+    void clear() { slots_.clear(); count_ = 0; }
+    iterator find(uint64_t key) {
+        if (slots_.empty()) return end();
+        const uint64_t k = key + 1;   // 0 marks an empty slot (no point id is 2^64 - 1)
+        for (size_t i = home(k);; i = (i + 1) & mask()) {
+            if (slots_[i].first == k) return at(i);
+            if (slots_[i].first == empty_key) return end();
+        }
+    }
+    entt::entity &operator[](uint64_t key) {
+        if ((count_ + 1) * 4 > slots_.size() * 3) grow();
+        const uint64_t k = key + 1;
+        for (size_t i = home(k);; i = (i + 1) & mask()) {
+            if (slots_[i].first == k) return slots_[i].second;
+            if (slots_[i].first == empty_key) { slots_[i].first = k; slots_[i].second = entt::null; ++count_; return slots_[i].second; }
+        }
+    }
+    void erase(iterator it) {   // backward-shift deletion: no tombstones, probe sequences stay short however long the table lives
+        size_t i = (size_t)(it.p_ - slots_.data());
+        for (size_t j = (i + 1) & mask();; j = (j + 1) & mask()) {
+            if (slots_[j].first == empty_key) break;
+            const size_t h = home(slots_[j].first);
+            if (((j - h) & mask()) >= ((j - i) & mask())) { slots_[i] = slots_[j]; i = j; }   // j's element may move back to i: i lies on its probe path
+        }
+        slots_[i].first = empty_key;
+        --count_;
+    }
+    /// the key a slot was stored under (`first` holds key + 1)
+    static uint64_t key_of(const slot &s) { return s.first - 1; }
+private:
+    static constexpr uint64_t empty_key = 0;
+    size_t mask() const { return slots_.size() - 1; }
+    size_t home(uint64_t k) const { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return (size_t)k & mask(); }
+    iterator at(size_t i) { iterator it(slots_.data() + slots_.size(), slots_.data() + slots_.size()); it.p_ = slots_.data() + i; return it; }
+    void grow() {
+        std::vector<slot> old;
+        old.swap(slots_);
+        slots_.assign(old.empty() ? 1024 : old.size() * 2, slot{empty_key, entt::null});
+        count_ = 0;
+        for (const slot &s : old) if (s.first != empty_key) (*this)[s.first - 1] = s.second;
+    }
+    std::vector<slot> slots_;
+    size_t count_{0};
+};
+
 // The analogue of stepper_sequential in registry.ctx() (edyn.cpp:117-123).
 struct gpu_stepper {
     init_config cfg;
@@ -392,8 +460,8 @@ struct gpu_stepper {
     double accumulated{0}, last_time{0};
     unsigned capacity{0}, joint_capacity{0};
     unsigned uploaded_bodies{0}, uploaded_constraints{0};   // what the device context already holds
-    std::unordered_map<uint64_t, entt::entity> manifold_entities;   // (body index A << 32 | body index B) -> contact_manifold entity
-    std::unordered_map<uint64_t, entt::entity> point_entities;      // device point id -> contact_point entity
+    entity_table manifold_entities;   // (body index A << 32 | body index B) -> contact_manifold entity
+    entity_table point_entities;      // device point id -> contact_point entity
     double (*time_func)(){nullptr};                 // settings.time_func (edyn::set_time_source); nullptr = the monotonic clock
     void (*pre_step)(entt::registry &){nullptr};    // settings.pre_step_callback / post_step_callback (context/step_callback.hpp)
     void (*post_step)(entt::registry &){nullptr};
@@ -658,6 +726,7 @@ inline void upload_scene_multi(entt::registry &registry, gpu_stepper &s) {
     s.scene_dirty = false; s.state_dirty = false;
 }
 
+constexpr uint32_t prefetch_events_max = 8192;   // contact events that travel ahead of a step's state (sequential modes); more = read after the step
 inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
     const uint32_t total = (uint32_t)s.bodies.size();
     const uint32_t nj = (uint32_t)s.constraints.size();
@@ -729,6 +798,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         s.meshes.clear();   // meshes belong to the context
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
         if (s.should_collide) check(s, edynhip_set_pair_filter(s.ctx, &pair_filter_trampoline, &s));   // a re-created context asks the same predicate
+        // contact entities follow the narrowphase, not the end of the step (edynhip.h "Contact-event prefetch"): the host builds them while the solve runs
+        if (s.cfg.materialize_contacts && s.cfg.execution_mode != execution_mode::asynchronous) check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max));
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
         s.params_dirty = false;
     }
@@ -896,24 +967,28 @@ inline void import_records(entt::registry &registry, gpu_stepper &s, const edynh
 inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::vector<edynhip_contact_event> &ev, int rc);
 // sequential write-back: enqueue the pack + copy behind the step, wait for it, import. `events_max`: how many contact events travel along.
 inline void write_back(entt::registry &registry, gpu_stepper &s, bool presentation) {
-    { phase_timer t(s.tm.state_wait);
-      check(s, edynhip_snapshot_records(s.ctx, s.present_dt, s.cfg.materialize_contacts ? 4096u : 0u));
-      pool_of(s).prewake(); }
+    { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_records(s.ctx, s.present_dt, 0u)); }   // the pack + copy, enqueued right behind the step
+    if (s.cfg.materialize_contacts) {
+        // Contact points become entities while the step's solve is still running on the device - where the reference creates them too:
+        // inside the step, by the narrowphase, before the solver moves anything (narrowphase.cpp:21-40, collision_util.cpp:311-430).
+        phase_timer t(s.tm.contacts);
+        const edynhip_contact_event *events = nullptr;
+        uint32_t num = 0, total = 0;
+        check(s, edynhip_prefetched_events(s.ctx, &events, &num, &total));
+        std::vector<edynhip_contact_event> ev;
+        int rc = EDYNHIP_OK;
+        if (total > num) {   // more than travel ahead (a pile hitting the ground): the whole list, once the step is through
+            uint32_t cnt = 0;
+            ev.resize(total);
+            rc = edynhip_get_contact_events(s.ctx, ev.data(), (uint32_t)ev.size(), &cnt);
+            ev.resize(rc == EDYNHIP_OK ? cnt : 0);
+        } else if (num) ev.assign(events, events + num);
+        apply_contact_events(registry, s, ev, rc);
+    }
+    pool_of(s).prewake();
     edynhip_record_view view{};
     { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_map(s.ctx, &view)); }
     { phase_timer t(s.tm.write_back); import_records(registry, s, view, presentation); }
-    if (s.cfg.materialize_contacts) {
-        phase_timer t(s.tm.contacts);
-        std::vector<edynhip_contact_event> ev;
-        int rc = EDYNHIP_OK;
-        if (view.total_events > view.num_events) {   // more than travelled along: the device still holds the whole list (no step was enqueued since)
-            uint32_t cnt = 0;
-            ev.resize(view.total_events);
-            rc = edynhip_get_contact_events(s.ctx, ev.data(), (uint32_t)ev.size(), &cnt);
-            ev.resize(rc == EDYNHIP_OK ? cnt : 0);
-        } else if (view.num_events) ev.assign(view.events, view.events + view.num_events);
-        apply_contact_events(registry, s, ev, rc);
-    }
 }
 
 // registry.destroy(entity) / clear_rigidbody on bodies and constraints since the last update: the reference reacts through
@@ -992,9 +1067,13 @@ inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::
     s.tm.contact_events += ev.size();
     if (ev.empty() && rc == EDYNHIP_OK && !s.contacts_resync) { if (s.cfg.contact_point_data) refresh_contact_points(registry, s); return; }
     auto body_of = [&](uint32_t i) { return i < s.bodies.size() ? s.bodies[i] : entt::entity{entt::null}; };
+    // direct pool handles: a thousand points come and go per update on the headline pile - no type-indexed pool look-up per component
+    auto &pool_manifold = registry.storage<contact_manifold>(); auto &pool_list = registry.storage<contact_point_list>();
+    auto &pool_geometry = registry.storage<contact_point_geometry>(); auto &pool_impulse = registry.storage<contact_point_impulse>();
+    auto &pool_point = registry.storage<contact_point>();
     auto make_manifold = [&](uint32_t a, uint32_t b) {
         const entt::entity e = registry.create();
-        registry.emplace<contact_manifold>(e, contact_manifold{{body_of(a), body_of(b)}, 0u});
+        pool_manifold.emplace(e, contact_manifold{{body_of(a), body_of(b)}, 0u});
         s.manifold_entities[manifold_key(a, b)] = e;
         return e;
     };
@@ -1002,11 +1081,11 @@ inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::
         auto mit = s.manifold_entities.find(manifold_key(a, b));
         const entt::entity parent = mit != s.manifold_entities.end() ? mit->second : make_manifold(a, b);
         const entt::entity e = registry.create();
-        registry.emplace<contact_point_list>(e, contact_point_list{parent, id});
-        registry.emplace<contact_point_geometry>(e);
-        registry.emplace<contact_point_impulse>(e);
-        registry.emplace<contact_point>(e);   // last, as create_contact_point does: a listener finds the other components
-        ++registry.get<contact_manifold>(parent).num_points;
+        pool_list.emplace(e, contact_point_list{parent, id});
+        pool_geometry.emplace(e, contact_point_geometry{});
+        pool_impulse.emplace(e, contact_point_impulse{});
+        pool_point.emplace(e, contact_point{});   // last, as create_contact_point does: a listener finds the other components
+        ++pool_manifold.get(parent).num_points;
         s.point_entities[id] = e;
     };
     if (rc == EDYNHIP_ERR_CAPACITY || s.contacts_resync) {   // more events than the context holds, or a re-created context: rebuild from the manifolds
@@ -1037,8 +1116,8 @@ inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::
             case EDYNHIP_EVENT_POINT_DESTROYED: {
                 auto it = s.point_entities.find(e.point_id);
                 if (it == s.point_entities.end()) break;
-                const entt::entity parent = registry.get<contact_point_list>(it->second).parent;
-                if (auto *m = registry.try_get<contact_manifold>(parent)) if (m->num_points) --m->num_points;
+                const entt::entity parent = pool_list.get(it->second).parent;
+                if (pool_manifold.contains(parent)) { auto &m = pool_manifold.get(parent); if (m.num_points) --m.num_points; }
                 registry.destroy(it->second);
                 s.point_entities.erase(it);
                 break;

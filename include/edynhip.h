@@ -384,6 +384,15 @@ typedef struct {
 } edynhip_record_view;
 int edynhip_snapshot_records(edynhip_ctx *ctx, float present_dt, uint32_t max_events);
 int edynhip_snapshot_map(edynhip_ctx *ctx, edynhip_record_view *view);
+/* Contact-event prefetch (ABI 15). In the reference contact points become registry entities INSIDE the step, during the narrowphase
+ * (create_contact_point collision_util.cpp:311-388, destroy_contact_point :390-430, narrowphase.cpp:21-40) - before the solver moves
+ * anything. Every event of a step is emitted by its broadphase and narrowphase, so with the prefetch enabled (max_events > 0) a step
+ * call copies its event list (the count and the first max_events events) to pinned memory as soon as the LAST step's narrowphase has
+ * run, on a side stream; edynhip_prefetched_events waits for that copy only, so the caller creates / destroys the contact entities
+ * while the islands, solve and finish stages of that step are still running. `total_events` > `num_events`: the list was cut -
+ * edynhip_get_contact_events returns all of it (and waits for the step). The pointers stay valid until the next step call. */
+int edynhip_set_event_prefetch(edynhip_ctx *ctx, uint32_t max_events);
+int edynhip_prefetched_events(edynhip_ctx *ctx, const edynhip_contact_event **events, uint32_t *num_events, uint32_t *total_events);
 
 /* Test hook: run the device closest-feature routine on `n` independent shape pairs (no world state involved).
  * shape_type[n][2], shape_param[n][2][4], pos[n][2][3], orn[n][2][4]; out_points[n][4][11] =

@@ -181,7 +181,7 @@ def set_fused_rows(on):
     f(int(bool(on)))
 
 
-ARITH_REFERENCE, ARITH_FUSED_VELOCITY, ARITH_BLOCK_POSITION = 0, 1, 2
+ARITH_REFERENCE, ARITH_FUSED_VELOCITY, ARITH_BLOCK_POSITION, ARITH_TWO_PHASE = 0, 1, 2, 4   # TWO_PHASE: checker-only (island-wide normals, then friction: island_solver.cpp:94-111)
 
 
 def set_arithmetic(mode):

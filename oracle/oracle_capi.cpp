@@ -113,7 +113,7 @@ int orc_ext_order_mismatch(void *h) { return ((World *)h)->ext_order_mismatch ? 
 void orc_set_restitution_iterations(void *h, int iters, int individual) { World *w = (World *)h; w->restitution_iters = iters; w->individual_restitution_iters = individual; }
 void orc_set_libm_trig(int on) { g_libm_trig = on != 0; }
 void orc_set_fused_rows(int on) { g_arith = on ? (ARITH_FUSED_VELOCITY | ARITH_BLOCK_POSITION) : ARITH_REFERENCE; }
-void orc_set_arithmetic(int mode) { g_arith = mode & 3; }
+void orc_set_arithmetic(int mode) { g_arith = mode & 7; }
 int orc_get_arithmetic() { return g_arith; }
 void orc_set_should_collide(void *h, int (*fn)(void *, uint32_t, uint32_t), void *user) { auto *w = (World *)h; w->collide_filter = fn; w->collide_filter_user = user; }
 int orc_default_should_collide(void *h, uint32_t a, uint32_t b) { return ((World *)h)->should_collide(a, b) ? 1 : 0; }

@@ -222,7 +222,13 @@ inline void solve_friction(FrictionRow &f, Row &n) {
 // engine - within the tolerances of SURVEY 8(d) (tests/test_oracle_physics.py, tests/test_reference_engine.py, lock-step tests).
 // Test / mode switch of the coloured order (orc_set_arithmetic): bit 0 = fused velocity rows (above), bit 1 = the per-manifold block
 // position correction (contact_solve_position_block below). 0 = the reference's arithmetic in the coloured order too.
-enum : int { ARITH_REFERENCE = 0, ARITH_FUSED_VELOCITY = 1, ARITH_BLOCK_POSITION = 2 };
+// bit 2 (checker-only, no device counterpart): the coloured order keeps the reference's TWO PHASES per iteration over the whole island -
+// every normal row (colour after colour), then every friction row, then rolling, then spinning (island_solver.cpp:76-111) - instead of
+// finishing each manifold (normals, then its friction rows) before the next. Inside ONE colour the two forms are the same thing (its
+// manifolds share no dynamic body), so "two phases per colour" would change nothing; what can be measured is the island-wide form, which
+// a device would pay for with two passes over every body's chain per iteration. tests/test_reference_engine.py uses it to put a number on
+// how much of the coloured order's distance to the engine comes from this choice (VERDICT r05 missing #5).
+enum : int { ARITH_REFERENCE = 0, ARITH_FUSED_VELOCITY = 1, ARITH_BLOCK_POSITION = 2, ARITH_TWO_PHASE = 4 };
 inline int g_arith = ARITH_REFERENCE;
 inline float dot3_fma(vec3 a, vec3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
 inline vec3 fma3(vec3 w, float s, vec3 acc) { return {std::fmaf(w.x, s, acc.x), std::fmaf(w.y, s, acc.y), std::fmaf(w.z, s, acc.z)}; }
@@ -1948,7 +1954,13 @@ public:
             cc[m.colour].push_back(cr);
         }
         for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) apply_row_impulse(jr.r[i].impulse, jr.r[i]);
-        const bool fused = (g_arith & ARITH_FUSED_VELOCITY) != 0, block = (g_arith & ARITH_BLOCK_POSITION) != 0;
+        const bool fused = (g_arith & ARITH_FUSED_VELOCITY) != 0, block = (g_arith & ARITH_BLOCK_POSITION) != 0, two_phase = (g_arith & ARITH_TWO_PHASE) != 0;
+        if (two_phase) {   // warm_start(row_cache&) and solve(row_cache&) of the reference, the rows of each kind in colour order
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) apply_row_impulse(cr.nr[i].impulse, cr.nr[i]);
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) warm_start_friction(cr.fr[i], cr.nr[i]);
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) warm_start_friction(cr.ex[i].rr, cr.nr[i]);
+            for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) warm_start_spin(cr.ex[i].sr, cr.nr[i]);
+        } else
         for (auto &col : cc) for (auto &cr : col) {
             if (fused) {
                 for (int i = 0; i < cr.m->num_points; ++i) apply_impulse_fused(cr.nr[i].impulse, cr.nr[i].J, cr.nr[i]);
@@ -1962,6 +1974,13 @@ public:
         }
         for (int it = 0; it < vel_iters; ++it) {
             for (auto &col : jc) for (auto &jr : col) for (int i = 0; i < jr.n; ++i) { float d = solve_row(jr.r[i]); apply_row_impulse(d, jr.r[i]); }
+            if (two_phase) {
+                for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) { float d = solve_row(cr.nr[i]); apply_row_impulse(d, cr.nr[i]); }
+                for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) solve_friction(cr.fr[i], cr.nr[i]);
+                for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].roll) solve_friction(cr.ex[i].rr, cr.nr[i]);
+                for (auto &col : cc) for (auto &cr : col) for (int i = 0; i < cr.m->num_points; ++i) if (cr.ex[i].spin) solve_spin_friction(cr.ex[i].sr, cr.nr[i]);
+                continue;
+            }
             for (auto &col : cc) for (auto &cr : col) {
                 if (fused) {
                     for (int i = 0; i < cr.m->num_points; ++i) solve_normal_fused(cr.nr[i]);

@@ -70,7 +70,13 @@ def simulate_owner(compute, handoff, rule, sweeps=11, local=0.0):
         own_a = (da & ~db) | (da & db & ((deg_a > deg_b) | ((deg_a == deg_b) & (body[:, 0] > body[:, 1]))))
     elif rule == "none":
         own_a = np.zeros(na, bool); 
-    owner = np.where(own_a, body[:, 0], body[:, 1]) if rule != "none" else np.full(na, -1)
+    if not isinstance(rule, tuple): owner = np.where(own_a, body[:, 0], body[:, 1]) if rule != "none" else np.full(na, -1)
+    if isinstance(rule, tuple):   # ("hot", H): only bodies with at least H active manifolds own their chains
+        H = rule[1]
+        ha, hb = da & (deg_a >= H), db & (deg_b >= H)
+        own_a = ha & (~hb | (deg_a > deg_b) | ((deg_a == deg_b) & (body[:, 0] > body[:, 1])))
+        own_b = hb & ~own_a
+        owner = np.where(own_a, body[:, 0].astype(np.int64), np.where(own_b, body[:, 1].astype(np.int64), np.int64(-1)))
     bt = np.zeros(nb); last_owned = np.zeros(nb, bool)   # was the body's previous task owned by the body itself?
     cstart = np.r_[0, np.flatnonzero(np.diff(col)) + 1, na]
     ends = []
@@ -89,6 +95,16 @@ def simulate_owner(compute, handoff, rule, sweeps=11, local=0.0):
         ends.append(bt[dyn].max())
     return ends[-1], np.diff(ends)[-3:].mean(), owner
 
+# round 6: the judge's proposal - the hottest bodies' chains each inside one wave (intra-wave hand-off 0.1 us), with this round's measured
+# figures: 1.55 us of arithmetic per four-point task, 1.4 us per fabric hand-off
+c_r5 = lambda n: 0.23 + 0.33 * n
+print("degree histogram of the dynamic bodies (active manifolds):", dict(zip(*np.unique(deg_d, return_counts=True))))
+for H in (16, 15, 14, 13, 12, 11, 10, 8, 1):
+    total, period, owner = simulate_owner(c_r5, 1.4, ("hot", H), local=0.1)
+    nh = int((deg_d >= H).sum())
+    print(f"hot chains, degree >= {H:2d} ({nh:5d} bodies, {int((owner >= 0).sum()):6d} manifolds in hot waves): total {total:7.1f} us  sweep period {period:6.2f} us")
+total, period, _ = simulate_owner(c_r5, 1.4, "none")
+print(f"{'r05 figures, no ownership':45s} total {total:7.1f} us  sweep period {period:6.2f} us")
 for name, rule in [("no ownership", "none"), ("owner = higher degree", "degree")]:
     total, period, owner = simulate_owner(c_df2, 1.1, rule)
     print(f"{name:45s} total {total:7.1f} us  sweep period {period:6.2f} us")
@@ -96,6 +112,7 @@ for name, rule in [("no ownership", "none"), ("owner = higher degree", "degree")
         cnt = np.bincount(owner[owner >= 0], minlength=nb)[dyn]
         print("   owned manifolds per body: mean %.2f max %d; bodies owning none: %d" % (cnt.mean(), cnt.max(), (cnt == 0).sum()))
 
+if "--clusters" not in sys.argv: sys.exit(0)
 # ---- cluster model: one wave owns a spatial cluster of manifolds and walks it colour by colour; hand-offs inside the cluster
 # are free (LDS), hand-offs between clusters cost `handoff` (slot through the fabric)
 pos = f["pos"]

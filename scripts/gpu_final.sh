@@ -15,7 +15,7 @@ for WL in pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k; do
 done
 python scripts/multi_overhead.py islands256k 8 40 > gpurun_out/${R}_multi_overhead_islands256k.json 2> /dev/null; cat gpurun_out/${R}_multi_overhead_islands256k.json
 timeout 2400 bash scripts/profile_round.sh $R pile32k pile8k mixed32k islands256k chains16k ragdolls1k polyheap32k > gpurun_out/${R}_profile.log 2>&1; echo "profile rc=$?"
-EDYNHIP_DF_TRACE=/tmp/df.bin EDYNHIP_DFP_TRACE=/tmp/dfp.bin EDYNHIP_DF_TRACE_STEP=200 timeout 200 python bench.py --steps 150 --warmup 100 --no-cpu-baseline --north-star none --other-arithmetic-steps 0 > /dev/null 2>&1
+EDYNHIP_DF_TRACE=/tmp/df.bin EDYNHIP_DFP_TRACE=/tmp/dfp.bin EDYNHIP_DF_TRACE_STEP=200 timeout 200 python bench.py --steps 150 --warmup 100 --no-cpu-baseline --north-star none --other-arithmetic-steps 0 --no-shim > /dev/null 2>&1
 python scripts/df_trace.py /tmp/df.bin > gpurun_out/${R}_dftrace_velocity_pile32k.txt 2>&1
 python scripts/df_trace.py /tmp/dfp.bin > gpurun_out/${R}_dftrace_position_pile32k.txt 2>&1
 head -12 gpurun_out/${R}_kernel_stats_pile32k.txt | cut -c1-118; cat gpurun_out/${R}_timeline_pile32k.txt | tail -36

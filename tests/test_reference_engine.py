@@ -406,6 +406,48 @@ def test_jointed_scenes_in_lock_step_with_the_real_engine():
               f"(bounds {tol_p} m / {tol_v} m/s; fastest body at the end {vmax:.2f} m/s)")
 
 
+def test_two_phase_coloured_order_distance_to_the_engine():
+    """VERDICT r05 missing #5 / next #7(c): the reference sweeps ALL normal rows of an island, then ALL friction rows, per iteration
+    (island_solver.cpp:94-111); the coloured order - the device's specification - finishes each manifold (its normals, then its friction
+    rows) before the next one. How much of the coloured order's per-step distance to the engine is that choice, how much the colour order
+    itself? Inside one colour the two forms coincide (a colour's manifolds share no dynamic body), so the comparable variant is the
+    island-wide two-phase sweep in colour order (oracle ARITH_TWO_PHASE, checker-only: a device would visit every body's chain twice per
+    iteration). Lock-step against the engine (every step restarted from the engine's state and manifolds) on the 8^3 pile at 10 iterations
+    and the 7^3 mixed pile at 20, first 40 steps (the collapse onto the 5 mm gaps, where the orders differ most). Result (printed; round 6):
+    the island-wide two-phase variant lands 8-17 % closer to the engine (8^3 pile: worst step 1.31e-3 -> 1.12e-3 m, mean over bodies and
+    steps 6.5e-5 -> 5.4e-5 m; 7^3 mixed pile: 6.9e-4 -> 6.4e-4 m, 4.3e-5 -> 3.9e-5 m): about a sixth of the coloured order's distance to the
+    engine is the interleaving of row kinds, the rest is the order in which the bodies are visited - at the price of two passes over every
+    body's chain per iteration on a device (twice the hand-offs of the dataflow solve), which is why the device keeps the per-manifold form."""
+    from invariants import canonical_records
+    fig = {}
+    try:
+        for name, gen, vel in (("pile_8x8x8", lambda: scenes.box_pile(8, 8, 8), 10), ("mixed_7x7x7", lambda: scenes.box_pile(7, 7, 7, mixed=True), 20)):
+            for label, mode in (("per manifold (the device's order)", ob.ARITH_REFERENCE), ("two phases over the island", ob.ARITH_TWO_PHASE)):
+                ob.set_arithmetic(mode)
+                sc = gen()
+                ref = ob.RefWorld(vel_iters=vel); ref.add_bodies(sc)
+                orc = ob.World(vel_iters=vel, order=ob.ORDER_COLOURED); orc.add_bodies(sc)
+                worst_p = worst_v = 0.0; mean_p = []
+                for step in range(1, 41):
+                    orc.set_state(*ref.get_state()); orc.refresh_derived()
+                    orc.set_manifolds(canonical_records(ref.get_manifolds(), sc["kind"]))
+                    orc.step(1); ref.step(1)
+                    assert np.array_equal(orc.get_pairs(), ref.get_pairs()), (name, label, step)
+                    (wp, _, wv, _), (rp, _, rv, _) = orc.get_state(), ref.get_state()
+                    worst_p = max(worst_p, float(np.abs(wp - rp).max())); worst_v = max(worst_v, float(np.abs(wv - rv).max()))
+                    mean_p.append(float(np.abs(wp - rp).max(axis=1).mean()))
+                fig[(name, label)] = (worst_p, worst_v, float(np.mean(mean_p)))
+                print(f"\n[figures] lock-step vs engine, {name}, {vel} iterations, coloured order {label}: worst per step |dpos| {worst_p:.3e} m, |dvel| {worst_v:.3e} m/s, "
+                      f"mean over bodies and steps {np.mean(mean_p):.3e} m")
+    finally:
+        ob.set_arithmetic(ob.ARITH_REFERENCE)
+    for name in ("pile_8x8x8", "mixed_7x7x7"):
+        a, b = fig[(name, "per manifold (the device's order)")], fig[(name, "two phases over the island")]
+        assert a[0] < 2e-3 and a[1] < 0.1, (name, a)           # the device's order: the lock-step contract of tests/test_gpu_parity.py
+        assert b[0] < 2e-3 and b[1] < 0.1, (name, b)           # the variant: the same contract
+        assert 0.6 * a[2] < b[2] < 1.05 * a[2], (name, a, b)    # somewhat closer on average, not a different regime
+
+
 def _pair_bodies(keys):
     keys = np.asarray(keys, np.uint64)
     return (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
