@@ -486,6 +486,17 @@ def main():
                          "launches_per_step": launches,
                          "avg_launch_us": 1e3 * solve_ms / max(launches, 1), "solve_ms_per_step": solve_ms},
         }
+        # the kept 300-step figure of this workload beside the one of this run (a short driver run samples 20 steps: VERDICT r05 next #8)
+        kpath = os.path.join(ROOT, "profiles", "kept_runs.json")
+        if os.path.exists(kpath):
+            try:
+                kept = json.load(open(kpath)).get(args.workload)
+                if isinstance(kept, dict):
+                    out["roofline"]["frac_profile_300"] = kept.get("frac")
+                    out["roofline"]["frac_profile_300_from_algorithmic_bytes_only"] = kept.get("frac_from_algorithmic_bytes_only")
+                    out["roofline"]["frac_profile_300_source"] = kept.get("source")
+            except Exception:
+                pass
         if args.stage_timing:
             out["stages_ms_per_step"] = {k: tm[k] / steps_timed for k in ("broadphase_ms", "narrowphase_ms", "islands_ms", "colouring_ms",
                                                                          "prepare_ms", "solve_velocity_ms", "integrate_ms", "solve_position_ms",

@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 
 class WorldStats(C.Structure):   # edynhip_world_stats
-    _fields_ = [(n, C.c_uint32) for n in ("num_shards", "num_bodies", "steps", "approach_checks", "repartitions")] + [("bodies_per_shard", C.c_uint32 * 16)]
+    _fields_ = [(n, C.c_uint32) for n in ("num_shards", "num_bodies", "steps", "approach_checks", "repartitions")] + [("bodies_per_shard", C.c_uint32 * 16), ("rebalances", C.c_uint32)]
 
 
 SCHEDULE_NAMES = {0: "none", 1: "k_contact_solve_df2 (dataflow, one launch per step, two lanes per manifold)",

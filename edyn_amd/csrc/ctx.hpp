@@ -383,6 +383,9 @@ struct edynhip_ctx {
     // body as SURVEY 8(d) prescribes, then steps like a context created without EDYNHIP_FLAG_SLEEPING.
     uint32_t num_sleepable = 0;
     bool sleep_active() const { return sleeping && num_sleepable > 0; }
+    unsigned long long *pp_prof_dev = nullptr; int pp_prof_calls = 0;   // EDYNHIP_PP_PROF (narrowphase.hip): phase ticks of the polyhedron-pair kernels
+    bool island_labels_valid = false;   // b.island / sleep_since hold what an island stage (or edynhip_set_sleep_timers) wrote - not before the first step of a new scene
+    uint32_t excl_dirty_lo = 0xFFFFFFFFu, excl_dirty_hi = 0;   // body rows of host_excl edited since the last upload (capi.hip flush_exclusions)
     // contact-event prefetch (edynhip_set_event_prefetch): the event list of a step call copied to pinned memory as soon as the last step's
     // narrowphase has run - the caller turns it into registry entities while the solve is still running
     uint32_t evp_max = 0; uint8_t *evp_host = nullptr; hipEvent_t evp_np_done = nullptr, evp_ready = nullptr; bool evp_now = false; int evp_state = 0;   // 0 none, 1 copy enqueued, 2 the call ran no step

@@ -87,10 +87,15 @@ static void partition_islands_spatial(uint32_t n, const uint32_t *labels, const 
         for (int d = 0; d < 3; ++d) { cx[3 * (size_t)k + d] += 0.5 * ((double)b[d] + (double)b[3 + d]); }
         cw[k] += 1.0;
     }
+    // islands without any shaped body have no place: they stay out of the bounds the Morton keys are quantised over (a scene far from the
+    // origin would otherwise lose its resolution to a phantom island at 0,0,0) and take the key of the scene's lower corner
     for (uint32_t k = 0; k < m; ++k) for (int d = 0; d < 3; ++d) {
-        if (cw[k] > 0) cx[3 * (size_t)k + d] /= cw[k];
+        if (cw[k] <= 0) continue;
+        cx[3 * (size_t)k + d] /= cw[k];
         lo[d] = std::min(lo[d], cx[3 * (size_t)k + d]); hi[d] = std::max(hi[d], cx[3 * (size_t)k + d]);
     }
+    for (uint32_t k = 0; k < m; ++k) if (cw[k] <= 0) for (int d = 0; d < 3; ++d) cx[3 * (size_t)k + d] = lo[d] <= hi[d] ? lo[d] : 0.0;
+    for (int d = 0; d < 3; ++d) if (lo[d] > hi[d]) lo[d] = hi[d] = 0.0;
     auto spread = [](uint32_t v) { v &= 0x3FFu; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; };
     std::vector<uint32_t> key(m), order(m);
     for (uint32_t k = 0; k < m; ++k) {
@@ -754,6 +759,19 @@ int repartition(edynhip_world *w, bool sticky) {
             for (uint32_t r = 0; r < W; ++r) { if (count[r]) ++spans; if (count[r] > count[target]) target = r; }
             if (spans > 1) for (size_t k = a; k < e; ++k) next[order[k]] = (int32_t)target;
             a = e;
+        }
+    }
+    // Sticky moves only ever add to the shard that holds most of a group: a collapsing or merging scene would drift onto a few shards.
+    // Once the heaviest shard carries more than 1.5 x the mean, this meeting takes the full, spatially balanced re-partition instead
+    // (the price is one rebuild of every shard, the gain every later step of the slowest shard).
+    if (W > 1) {
+        std::vector<uint32_t> load(W, 0);
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < n; ++i) if (next[i] >= 0) { ++load[(uint32_t)next[i]]; ++total; }
+        const uint32_t heaviest = *std::max_element(load.begin(), load.end());
+        if (total >= 8 * W && (double)heaviest * W > 1.5 * (double)total) {
+            ++w->stats.rebalances; --w->stats.repartitions;   // (counted again by the full pass)
+            return repartition(w, false);
         }
     }
     std::vector<uint8_t> changed(W, 0);

@@ -676,10 +676,10 @@ int narrowphase(edynhip_ctx *c) {
         if (group != 0) {
             const uint32_t waves = 5120;   // 20 per CU of an MI355X (the axes kernel runs five per SIMD): the grids stride over the pairs
             static const int group2 = getenv("EDYNHIP_POLY_GROUP2") ? atoi(getenv("EDYNHIP_POLY_GROUP2")) : 4;   // lanes per surviving pair: 4 (default: 16 pairs per wave), 8 or 16
-            static const bool prof = getenv("EDYNHIP_PP_PROF") != nullptr;   // developer profile of the phases: printed every 100th step (one context, one device: its counters are process-wide)
-            static unsigned long long *prof_dev = nullptr;
-            static int prof_calls = 0;
-            if (prof && !prof_dev) { EH_HIP(c, hipMalloc((void **)&prof_dev, 128)); EH_HIP(c, hipMemsetAsync(prof_dev, 0, 128, c->stream)); }
+            static const bool prof = getenv("EDYNHIP_PP_PROF") != nullptr;   // developer profile of the phases: printed every 100th step, per context (its counters live with the context: the shards of a multi-device world step on their own threads and devices)
+            unsigned long long *&prof_dev = c->pp_prof_dev;
+            int &prof_calls = c->pp_prof_calls;
+            if (prof && !prof_dev) { void *q = nullptr; EH_HIP(c, hipMalloc(&q, 128)); c->allocs.push_back(q); prof_dev = (unsigned long long *)q; EH_HIP(c, hipMemsetAsync(prof_dev, 0, 128, c->stream)); }
             const Manifolds &mfc = c->m[c->cur];
             unsigned long long *const pd = prof ? prof_dev : nullptr;
             // (measured and dropped: the contact kernel compiled for three waves per SIMD - 168 VGPRs and 260 B of spills - 324 -> 304 steps/s on polyheap32k)

@@ -3318,6 +3318,7 @@ int islands(edynhip_ctx *c) {
     if (n == 0) return EDYNHIP_OK;
     const Manifolds &mf = c->m[c->cur];
     const bool sleeping = c->sleep_active();   // (a world in which no body can sleep runs no sleep kernels: ctx.hpp num_sleepable)
+    c->island_labels_valid = true;
     // union-find forest lives in isl_done (scratch until the position solver) to keep b.island stable for readers
     uint32_t *forest = c->isl_done;
     c->solve_begin_done = false;

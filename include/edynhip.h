@@ -476,6 +476,7 @@ typedef struct {
     uint32_t approach_checks;        /* island-box sweeps (device reduction + host sweep) */
     uint32_t repartitions;           /* times the shards were rebuilt because islands of different shards met (or on request) */
     uint32_t bodies_per_shard[16];   /* bodies whose state each shard reports (shard 0 also reports the replicated ones) */
+    uint32_t rebalances;             /* meetings that took the full, load-balanced re-partition because the heaviest shard exceeded 1.5 x the mean (ABI 15) */
 } edynhip_world_stats;
 edynhip_world *edynhip_world_create(const edynhip_config *cfg /* .device is ignored; capacities 0 = sized per shard */,
                                     const int32_t *devices, uint32_t num_devices, int *status_out);

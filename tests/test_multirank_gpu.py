@@ -59,19 +59,49 @@ def test_multi_world_matches_one_context_through_an_approach_triggered_repartiti
 
 
 def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
+    """Three shards, the jointed bridge scene: (1) the APPROACH-TRIGGERED sticky path with joints in the world - the sphere rolls into a
+    site that lives on another shard (the variant of the scene in which that is so is picked from the initial partition, so the
+    crossing does not depend on where the chains happen to put the cuts: ADVICE r05), the two islands end up on one shard and every
+    body of a shard that was not involved stays where it was; (2) two forced full re-partitions - every shard rebuilt: the chains
+    swing on with warm-started joints and tracked angles. Bit-equal to one context at every step."""
     import edyn_amd
     from test_multirank_gloo import _jointed_bridge_scene
-    scene = _jointed_bridge_scene(along="z")
+    sphere, per_site = 1 + 6 * 64, 64                      # _bridge_scene: six 4x4x4 sites, then the sphere
+    target_site = {"z": 3, "x": 1}                          # the site the sphere rolls into
+    picked = None
+    for along in ("z", "x"):
+        scene = _jointed_bridge_scene(along=along)
+        probe = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0, 0])
+        probe.set_scene(scene)
+        part = probe.get_partition()
+        first_of_target = 1 + target_site[along] * per_site
+        del probe
+        if part[sphere] != part[first_of_target]:
+            picked = (along, scene, part, first_of_target)
+            break
+    assert picked is not None, "in neither variant does the sphere cross a shard boundary"
+    along, scene, part0, first_of_target = picked
     steps = 90
     ref, _ = _single_world_states(scene, steps)
-    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0])
+    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0, 0])
     mw.set_scene(scene)
+    assert np.array_equal(mw.get_partition(), part0)
+    involved = {int(part0[sphere]), int(part0[first_of_target])}
+    sticky_seen = False
     for k in range(steps):
+        before = mw.get_stats()["repartitions"]
         mw.step_simulation(1)
         assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[k]), k
+        if not sticky_seen and mw.get_stats()["repartitions"] > before:   # the approach-triggered one (no forced one has happened yet)
+            sticky_seen = True
+            assert k < 30
+            part1 = mw.get_partition()
+            assert part1[sphere] == part1[first_of_target], "the sphere's island and the site it rolls into share a shard now"
+            bystanders = [i for i in range(len(part0)) if part0[i] >= 0 and int(part0[i]) not in involved]
+            assert bystanders and all(part1[i] == part0[i] for i in bystanders), "a sticky re-partition moves nothing but the meeting islands"
         if k in (30, 60):
-            mw.repartition()   # every shard is rebuilt: the chains swing on with warm-started joints and tracked angles
-    assert mw.get_stats()["repartitions"] >= 2   # the two forced ones (whether the sphere also crosses a cut depends on where the chains put it)
+            mw.repartition()
+    assert sticky_seen and mw.get_stats()["repartitions"] >= 3   # one approach-triggered + the two forced ones
 
 
 def test_multi_world_with_polyhedra_and_cylinders():
