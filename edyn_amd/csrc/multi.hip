@@ -121,21 +121,49 @@ struct IslandBox { float lo[3], hi[3]; uint32_t label; int32_t owner; };
 // largest per-axis distance between the ORIGINAL boxes (0 when they overlap). cross_only: pairs of different owners only.
 template <typename Hit>
 static void sweep_boxes(std::vector<IslandBox> &boxes, float reach, bool cross_only, Hit &&hit) {
+    // Sweep along x; the boxes still open at the sweep front are kept in BUCKETS along z, so a box only meets the open boxes of the z
+    // cells it reaches. (Round 6: with one list of open boxes a field of piles on a 64 x 64 grid - 262 144 body boxes, every pile of a
+    // column open at once - cost ~260 M pair tests, 0.8 s of every re-partition's 1.2 s.) A pair that shares several cells is tested in
+    // the first of them only.
     std::sort(boxes.begin(), boxes.end(), [](const IslandBox &a, const IslandBox &b) { return a.lo[0] != b.lo[0] ? a.lo[0] < b.lo[0] : a.label < b.label; });
-    std::vector<uint32_t> active;
-    for (uint32_t k = 0; k < boxes.size(); ++k) {
+    const uint32_t nb = (uint32_t)boxes.size();
+    if (nb < 2) return;
+    float zlo = 3.0e38f, zhi = -3.0e38f;
+    double ext = 0;
+    uint32_t finite = 0;
+    for (const IslandBox &b : boxes) {
+        if (!(b.lo[2] <= b.hi[2]) || !std::isfinite(b.lo[2]) || !std::isfinite(b.hi[2])) continue;
+        zlo = std::min(zlo, b.lo[2]); zhi = std::max(zhi, b.hi[2]); ext += (double)b.hi[2] - (double)b.lo[2]; ++finite;
+    }
+    const float mean_ext = finite ? (float)(ext / finite) : 0.0f;
+    const float span = finite ? zhi - zlo : 0.0f;
+    const uint32_t cells = span > 0 ? (uint32_t)std::min(4096.0f, std::max(1.0f, span / std::max(mean_ext + 2 * reach, 1e-3f))) : 1u;
+    const float inv = cells > 1 ? (float)cells / span : 0.0f;
+    auto cell_of = [&](float z) { if (!(z > zlo)) return 0u; const float c = (z - zlo) * inv; return c >= (float)(cells - 1) ? cells - 1 : (uint32_t)c; };   // (NaN and -inf land in cell 0, +inf in the last)
+    std::vector<std::vector<uint32_t>> open(cells);
+    std::vector<uint32_t> first_cell(nb);
+    for (uint32_t k = 0; k < nb; ++k) {
         const IslandBox &bk = boxes[k];
-        size_t keep = 0;
-        for (uint32_t a : active) if (boxes[a].hi[0] + 2 * reach >= bk.lo[0]) active[keep++] = a;
-        active.resize(keep);
-        for (uint32_t a : active) {
-            const IslandBox &ba = boxes[a];
-            if (cross_only && ba.owner == bk.owner) continue;
-            float gap = 0;
-            for (int d = 0; d < 3; ++d) gap = std::max(gap, std::max(bk.lo[d] - ba.hi[d], ba.lo[d] - bk.hi[d]));
-            if (gap < 2 * reach) hit(ba, bk, gap);
+        const bool sane = bk.lo[2] <= bk.hi[2];
+        const uint32_t q0 = sane ? cell_of(bk.lo[2] - 2 * reach) : 0u, q1 = sane ? cell_of(bk.hi[2] + 2 * reach) : cells - 1;
+        for (uint32_t c = q0; c <= q1; ++c) {
+            std::vector<uint32_t> &bucket = open[c];
+            size_t keep = 0;
+            for (uint32_t a : bucket) {
+                const IslandBox &ba = boxes[a];
+                if (!(ba.hi[0] + 2 * reach >= bk.lo[0])) continue;   // the sweep front has passed it: drop it from this bucket
+                bucket[keep++] = a;
+                if (c != std::max(first_cell[a], q0)) continue;       // this pair is tested in the first cell the two share
+                if (cross_only && ba.owner == bk.owner) continue;
+                float gap = 0;
+                for (int d = 0; d < 3; ++d) gap = std::max(gap, std::max(bk.lo[d] - ba.hi[d], ba.lo[d] - bk.hi[d]));
+                if (gap < 2 * reach) hit(ba, bk, gap);
+            }
+            bucket.resize(keep);
         }
-        active.push_back(k);
+        const uint32_t i0 = sane ? cell_of(bk.lo[2]) : 0u, i1 = sane ? cell_of(bk.hi[2]) : cells - 1;
+        first_cell[k] = i0;
+        for (uint32_t c = i0; c <= i1; ++c) open[c].push_back(k);
     }
 }
 
@@ -218,7 +246,7 @@ struct Shard {
     float *pack_dev = nullptr, *pack_host = nullptr;   // [n_local][13]
     // monitor scratch on the device: [0] growth bits, [1] island count | per label 3 lo + 3 hi ordered bits | out labels | out boxes | amin0 | amax0
     uint32_t *mon_dev = nullptr, *mon_host = nullptr;
-    uint32_t cap = 0;
+    uint32_t cap = 0, joint_cap = 0, meshes_created = 0;
     int rc = EDYNHIP_OK;
     std::string err;
     // collected for a re-partition
@@ -317,6 +345,7 @@ void free_shard(Shard &s) {
     if (s.mon_host) (void)hipHostFree(s.mon_host);
     if (s.ctx) edynhip_destroy(s.ctx);
     s.ctx = nullptr; s.pack_dev = s.pack_host = nullptr; s.mon_dev = s.mon_host = nullptr;
+    s.cap = s.joint_cap = s.meshes_created = 0;
 }
 
 template <typename T>
@@ -346,6 +375,13 @@ struct Carry {   // what travels with the islands through a re-partition (global
     std::vector<double> since;                 // ... the islands' sleep timers by that label, and the clock they are measured on (ADVICE r04:
     double clock = 0;                          //     every re-partition used to restart every island's timer)
     bool any = false;
+    // sticky re-partitions: the manifolds already sorted out per NEW shard (global indices, canonical order) - the bodies of a shard that
+    // stay keep their relative order, so their manifolds are taken over in place and only the few that arrive are merged in; `manifolds`
+    // above (one merged, sorted list of everything) is then empty. Consumed (moved from) by build_shard.
+    mutable std::vector<std::vector<edynhip_manifold>> per_shard;
+    // island boxes of the state the shards are built from, owners = the new partition: the approach check after the rebuild sweeps these
+    // (thousands) instead of every body's box (hundreds of thousands)
+    std::vector<IslandBox> island_boxes;
 };
 
 int shard_filter_thunk(void *user, uint32_t body, uint32_t other) {
@@ -372,7 +408,7 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     Shard &s = w->shards[r];
     const HostScene &sc = w->scene;
     s.rc = EDYNHIP_OK; s.err.clear();
-    free_shard(s);
+    PhaseTrace trace("build_shard");
     SH_HIP(s, hipSetDevice(s.device));
     const uint32_t n = sc.n;
     s.local_ids.clear(); s.owned_local.clear();
@@ -397,18 +433,29 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     }
     edynhip_config cfg = w->cfg;
     cfg.device = s.device;
-    cfg.max_bodies = std::max<uint32_t>(nl + nl / 8 + 16, 64);
-    cfg.max_joints = std::max<uint32_t>((uint32_t)s.local_joints.size() + 16, 16);
     if (w->cfg.max_manifolds) cfg.max_manifolds = w->cfg.max_manifolds; else cfg.max_manifolds = 0;
-    int status = 0;
-    PhaseTrace trace("build_shard");
-    s.ctx = edynhip_create(&cfg, &status);
-    if (!s.ctx) { s.rc = status; s.err = edynhip_last_error(nullptr); return; }
-    s.cap = cfg.max_bodies;
-    trace.mark("edynhip_create");
-    for (const HostScene::Mesh &m : sc.meshes) {
-        uint32_t id = 0;
-        SH_TRY(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)m.v.size() / 3, m.v.data(), (uint32_t)m.idx.size(), m.idx.data(), (uint32_t)m.faces.size() / 2, m.faces.data(), m.flags, &id));
+    // A shard that is rebuilt keeps its context when the new body / joint set fits the old capacities: edynhip_set_bodies starts a new
+    // world on an existing context (manifolds, joints, exclusions, sleep state, clocks - everything but the meshes, which are the scene's
+    // and stay), and a context's ~100 device allocations - over a gigabyte for a 32k-body shard - are neither freed nor made again
+    // (round 6: the frees and allocations were ~0.1 s of every re-partition). A context that is too small is replaced with head-room.
+    const bool reuse = s.ctx != nullptr && nl <= s.cap && (uint32_t)s.local_joints.size() <= s.joint_cap && (uint32_t)sc.meshes.size() == s.meshes_created;
+    if (!reuse) {
+        free_shard(s);
+        trace.mark("free the old context");
+        cfg.max_bodies = std::max<uint32_t>(nl + nl / 4 + 64, 64);
+        cfg.max_joints = std::max<uint32_t>((uint32_t)s.local_joints.size() + (uint32_t)s.local_joints.size() / 4 + 16, 16);
+        int status = 0;
+        s.ctx = edynhip_create(&cfg, &status);
+        if (!s.ctx) { s.rc = status; s.err = edynhip_last_error(nullptr); return; }
+        s.cap = cfg.max_bodies; s.joint_cap = cfg.max_joints;
+        trace.mark("edynhip_create");
+        for (const HostScene::Mesh &m : sc.meshes) {
+            uint32_t id = 0;
+            SH_TRY(s, edynhip_create_convex_mesh(s.ctx, (uint32_t)m.v.size() / 3, m.v.data(), (uint32_t)m.idx.size(), m.idx.data(), (uint32_t)m.faces.size() / 2, m.faces.data(), m.flags, &id));
+        }
+        s.meshes_created = (uint32_t)sc.meshes.size();
+    } else {
+        SH_TRY(s, edynhip_synchronize(s.ctx));
     }
     // bodies: the scene's definitions with the CURRENT state
     const std::vector<float> &P = from_state ? w->pos : sc.pos, &Q = from_state ? w->orn : sc.orn, &V = from_state ? w->linvel : sc.linvel, &W = from_state ? w->angvel : sc.angvel;
@@ -458,6 +505,10 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
     if (w->filter) SH_TRY(s, edynhip_set_pair_filter(s.ctx, &shard_filter_thunk, &w->shard_filters[r]));
     if (carry.any) {
         std::vector<edynhip_manifold> mine;
+        if (!carry.per_shard.empty()) {
+            mine.swap(carry.per_shard[r]);
+            for (edynhip_manifold &m : mine) { m.body[0] = (uint32_t)s.to_local[m.body[0]]; m.body[1] = (uint32_t)s.to_local[m.body[1]]; }
+        } else
         for (const edynhip_manifold &m : carry.manifolds)
             if (w->rank_of[m.body[0]] == (int32_t)r || w->rank_of[m.body[1]] == (int32_t)r) {
                 mine.push_back(m);
@@ -486,12 +537,14 @@ void build_shard(edynhip_world *w, uint32_t r, const Carry &carry, bool from_sta
             SH_TRY(s, edynhip_set_sleep_timers(s.ctx, lab.data(), since.data(), carry.clock));
         }
     }
-    // gather and monitor buffers
-    SH_HIP(s, hipMalloc((void **)&s.pack_dev, (size_t)std::max<uint32_t>(nl, 1) * 13 * sizeof(float)));
-    SH_HIP(s, hipHostMalloc((void **)&s.pack_host, (size_t)std::max<uint32_t>(nl, 1) * 13 * sizeof(float), hipHostMallocDefault));
+    // gather and monitor buffers (sized by the context's capacity: they live as long as the context does)
     const size_t words = MonLayout(s.cap).words;
-    SH_HIP(s, hipMalloc((void **)&s.mon_dev, words * sizeof(uint32_t)));
-    SH_HIP(s, hipHostMalloc((void **)&s.mon_host, (2 + 7 * (size_t)s.cap) * sizeof(uint32_t), hipHostMallocDefault));
+    if (!s.pack_dev) {
+        SH_HIP(s, hipMalloc((void **)&s.pack_dev, (size_t)std::max<uint32_t>(s.cap, 1) * 13 * sizeof(float)));
+        SH_HIP(s, hipHostMalloc((void **)&s.pack_host, (size_t)std::max<uint32_t>(s.cap, 1) * 13 * sizeof(float), hipHostMallocDefault));
+        SH_HIP(s, hipMalloc((void **)&s.mon_dev, words * sizeof(uint32_t)));
+        SH_HIP(s, hipHostMalloc((void **)&s.mon_host, (2 + 7 * (size_t)s.cap) * sizeof(uint32_t), hipHostMallocDefault));
+    }
     SH_HIP(s, hipMemset(s.mon_dev, 0, words * sizeof(uint32_t)));
     trace.mark("warm start, sleep state, gather / monitor buffers");
 }
@@ -553,10 +606,14 @@ void island_boxes_shard(edynhip_world *w, uint32_t r, bool per_body) {
 
 // The approach check on the device-reduced island boxes. Returns true when islands of different shards are within the creation
 // margin of each other; otherwise w->budget = how far they may still approach.
-int approach_check(edynhip_world *w, bool &close, bool per_body = false) {
+int approach_check(edynhip_world *w, bool &close, bool per_body = false, const std::vector<IslandBox> *host_boxes = nullptr) {
     w->pool->run([w, per_body](uint32_t r) { island_boxes_shard(w, r, per_body); });
     EH_TRY(shard_error(w));
     std::vector<IslandBox> boxes;
+    if (host_boxes) {   // the caller knows the islands of this state (a re-partition): their boxes, owned by the shard their bodies went to
+        boxes = *host_boxes;
+        for (IslandBox &b : boxes) b.owner = b.label < w->rank_of.size() ? w->rank_of[b.label] : -1;
+    } else
     for (uint32_t r = 0; r < w->shards.size(); ++r) {
         Shard &s = w->shards[r];
         const uint32_t k = s.local_ids.empty() ? 0 : s.mon_host[1];
@@ -628,21 +685,32 @@ void merge_manifolds(edynhip_world *w, std::vector<edynhip_manifold> &out) {
             if (ra == (int32_t)r || (ra < 0 && rb == (int32_t)r)) out.push_back(m);
         }
     }
-    std::stable_sort(out.begin(), out.end(), [&](const edynhip_manifold &x, const edynhip_manifold &y) {
-        return canonical_key(w->scene, x.body[0], x.body[1]) < canonical_key(w->scene, y.body[0], y.body[1]);
-    });
+    // canonical order: sort (key, position) pairs and move every 336-byte record once (a stable sort of the records themselves, with
+    // the key recomputed in every comparison, was 0.15-0.3 s of a re-partition)
+    std::vector<std::pair<uint64_t, uint32_t>> order(out.size());
+    for (uint32_t k = 0; k < out.size(); ++k) order[k] = {canonical_key(w->scene, out[k].body[0], out[k].body[1]), k};
+    std::sort(order.begin(), order.end());   // (ties keep their gathering order: the position is the second key)
+    std::vector<edynhip_manifold> sorted(out.size());
+    for (uint32_t k = 0; k < out.size(); ++k) sorted[k] = out[order[k].second];
+    out.swap(sorted);
 }
 
 // `only` (or nullptr = all): the shards to build; the others keep their contexts - their bodies, and therefore their local indices, are unchanged.
 int rebuild(edynhip_world *w, const Carry &carry, bool from_state, const std::vector<uint8_t> *only = nullptr) {
+    PhaseTrace trace("rebuild");
     w->pool->run([&](uint32_t r) { if (!only || (*only)[r]) build_shard(w, r, carry, from_state); });
     EH_TRY(shard_error(w));
+    trace.mark("build the shards (in parallel)");
     w->pool->run([w](uint32_t r) { gather_shard(w, r, false); });
     EH_TRY(shard_error(w));
+    trace.mark("gather");
     for (uint32_t r = 0; r < w->shards.size(); ++r) w->stats.bodies_per_shard[r < 16 ? r : 15] = (uint32_t)w->shards[r].owned_local.size();
     w->built = true;
     bool close = false;
-    return approach_check(w, close, true);   // a fresh partition keeps close islands together: sets the budget, records the reference boxes
+    // a fresh partition keeps close islands together: the check sets the budget and records the reference boxes the growth is measured against
+    const int rc_check = approach_check(w, close, true, carry.island_boxes.empty() ? nullptr : &carry.island_boxes);
+    trace.mark(carry.island_boxes.empty() ? "approach check on body boxes" : "approach check (reference boxes on the devices, island boxes from the host)");
+    return rc_check;
 }
 
 // Re-partition. FULL (edynhip_world_repartition, on request): everything the islands carry is read from every shard, the islands are
@@ -786,8 +854,53 @@ int repartition(edynhip_world *w, bool sticky) {
     w->pool->run([w, &changed](uint32_t r) { if (changed[r]) collect_shard(w, r, false, true); });
     EH_TRY(shard_error(w));
     trace.mark("collect manifolds / joint impulses of the changed shards");
-    take_heavy(&changed);
-    trace.mark("merge carried manifolds");
+    // joints' applied impulses and angles of the changed shards
+    for (uint32_t r = 0; r < W; ++r) {
+        Shard &s = w->shards[r];
+        if (!changed[r]) continue;
+        for (uint32_t lj = 0; lj < s.local_joints.size() && !s.imp24.empty(); ++lj) {
+            const uint32_t g = s.local_joints[lj];
+            std::memcpy(&carry.imp24[(size_t)g * 24], &s.imp24[(size_t)lj * 24], 24 * sizeof(float));
+            carry.angle[g] = s.imp10[(size_t)lj * 10 + 9];
+        }
+    }
+    // Manifolds: a body that stays in its shard keeps its place among the others that stay (local indices ascend with the global ones), so
+    // the manifolds that stay ARE in canonical order already; only those whose island moves are taken out, sorted among themselves and
+    // merged into their new shard's list. No global sort, one copy per record at most (the merged, sorted list of every changed shard's
+    // manifolds was 0.1-0.3 s of a re-partition).
+    std::vector<std::vector<edynhip_manifold>> leaving(W);
+    w->pool->run([&](uint32_t q) {
+        if (!changed[q]) return;
+        Shard &s = w->shards[q];
+        size_t keep = 0;
+        for (size_t k = 0; k < s.manifolds.size(); ++k) {
+            edynhip_manifold m = s.manifolds[k];
+            m.body[0] = s.local_ids[m.body[0]]; m.body[1] = s.local_ids[m.body[1]];
+            const uint32_t dyn = w->rank_of[m.body[0]] >= 0 ? m.body[0] : m.body[1];
+            if (w->rank_of[dyn] != (int32_t)q) continue;          // (not this shard's to report: cannot happen - a manifold lives where its dynamic body does)
+            if (next[dyn] == (int32_t)q) s.manifolds[keep++] = m; else leaving[q].push_back(m);
+        }
+        s.manifolds.resize(keep);
+    });
+    std::vector<std::vector<edynhip_manifold>> incoming(W);
+    for (uint32_t q = 0; q < W; ++q)
+        for (const edynhip_manifold &m : leaving[q]) {
+            const uint32_t dyn = w->rank_of[m.body[0]] >= 0 ? m.body[0] : m.body[1];
+            incoming[(uint32_t)next[dyn]].push_back(m);
+        }
+    carry.per_shard.assign(W, {});
+    w->pool->run([&](uint32_t r) {
+        if (!changed[r]) return;
+        Shard &s = w->shards[r];
+        auto key_less = [&](const edynhip_manifold &x, const edynhip_manifold &y) { return canonical_key(sc, x.body[0], x.body[1]) < canonical_key(sc, y.body[0], y.body[1]); };
+        if (incoming[r].empty()) { carry.per_shard[r].swap(s.manifolds); return; }
+        std::sort(incoming[r].begin(), incoming[r].end(), key_less);
+        carry.per_shard[r].resize(s.manifolds.size() + incoming[r].size());
+        std::merge(s.manifolds.begin(), s.manifolds.end(), incoming[r].begin(), incoming[r].end(), carry.per_shard[r].begin(), key_less);
+        s.manifolds.clear(); s.manifolds.shrink_to_fit();
+    });
+    trace.mark("sort out the carried manifolds per new shard");
+    carry.island_boxes = boxes;
     w->rank_of = next;
     const int rc_rebuild = rebuild(w, carry, true, &changed);
     trace.mark("rebuild changed shards (+ gather, approach check)");

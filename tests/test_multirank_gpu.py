@@ -59,7 +59,7 @@ def test_multi_world_matches_one_context_through_an_approach_triggered_repartiti
 
 
 def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
-    """Three shards, the jointed bridge scene: (1) the APPROACH-TRIGGERED sticky path with joints in the world - the sphere rolls into a
+    """Several shards (4, else 3 or 5), the jointed bridge scene: (1) the APPROACH-TRIGGERED sticky path with joints in the world - the sphere rolls into a
     site that lives on another shard (the variant of the scene in which that is so is picked from the initial partition, so the
     crossing does not depend on where the chains happen to put the cuts: ADVICE r05), the two islands end up on one shard and every
     body of a shard that was not involved stays where it was; (2) two forced full re-partitions - every shard rebuilt: the chains
@@ -69,21 +69,21 @@ def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
     sphere, per_site = 1 + 6 * 64, 64                      # _bridge_scene: six 4x4x4 sites, then the sphere
     target_site = {"z": 3, "x": 1}                          # the site the sphere rolls into
     picked = None
-    for along in ("z", "x"):
-        scene = _jointed_bridge_scene(along=along)
-        probe = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0, 0])
-        probe.set_scene(scene)
-        part = probe.get_partition()
-        first_of_target = 1 + target_site[along] * per_site
-        del probe
-        if part[sphere] != part[first_of_target]:
-            picked = (along, scene, part, first_of_target)
-            break
-    assert picked is not None, "in neither variant does the sphere cross a shard boundary"
-    along, scene, part0, first_of_target = picked
+    for shards in (4, 3, 5):                                # (islands are placed along a space-filling curve: where its cuts fall depends on the count)
+        for along in ("z", "x"):
+            scene = _jointed_bridge_scene(along=along)
+            probe = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0] * shards)
+            probe.set_scene(scene)
+            part = probe.get_partition()
+            first_of_target = 1 + target_site[along] * per_site
+            del probe
+            if part[sphere] != part[first_of_target] and picked is None:
+                picked = (shards, along, scene, part, first_of_target)
+    assert picked is not None, "in no variant does the sphere cross a shard boundary"
+    shards, along, scene, part0, first_of_target = picked
     steps = 90
     ref, _ = _single_world_states(scene, steps)
-    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0, 0, 0])
+    mw = edyn_amd.MultiWorld(edyn_amd.init_config(num_solver_velocity_iterations=10), devices=[0] * shards)
     mw.set_scene(scene)
     assert np.array_equal(mw.get_partition(), part0)
     involved = {int(part0[sphere]), int(part0[first_of_target])}
