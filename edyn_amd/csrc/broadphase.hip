@@ -630,9 +630,10 @@ __global__ void k_bp_build_manifolds(const uint64_t *__restrict__ skeys, uint32_
         // inside a full step the narrowphase reads the old points straight from the previous array (no copy here)
         const uint32_t np = copy_points ? (info & 0xFF) : 0u;
         for (uint32_t k = 0; k < np; ++k) {
-            const size_t s = (size_t)k * prev.cap + p, d = (size_t)k * cur.cap + m;
-            cur.pA[d] = prev.pA[s]; cur.pB[d] = prev.pB[s]; cur.nrm[d] = prev.nrm[s];
-            cur.lnrm[d] = prev.lnrm[s]; cur.imp[d] = prev.imp[s];
+            const size_t ts = pt_at(prev.cap, k, p), td = pt_at(cur.cap, k, m);
+            cur.pA[td] = prev.pA[ts]; cur.pB[td] = prev.pB[ts]; cur.nrm[td] = prev.nrm[ts];
+            cur.lnrm[td] = prev.lnrm[ts]; cur.imp[td] = prev.imp[ts];
+            const size_t s = slot_at(prev.cap, k, p), d = slot_at(cur.cap, k, m);
             if (cur.pid) cur.pid[d] = prev.pid[s];
             if (cur.xmat) { cur.xmat[d] = prev.xmat[s]; cur.ximp[d] = prev.ximp[s]; }
         }

@@ -78,9 +78,15 @@ static int alloc_manifolds(edynhip_ctx *c, Manifolds &m, uint32_t cap, uint32_t 
     if (c->cfg.flags & EDYNHIP_FLAG_CONTACT_EVENTS) EH_TRY(dalloc(c, m.pid, (size_t)cap * kMaxPts));
     EH_TRY(dalloc(c, m.seg_start, nb)); EH_TRY(dalloc(c, m.seg_end, nb)); EH_TRY(dalloc(c, m.prev_idx, cap)); EH_TRY(dalloc(c, m.tree, cap));
     EH_TRY(dalloc(c, m.skey, cap)); EH_TRY(dalloc(c, m.bodyA, cap)); EH_TRY(dalloc(c, m.bodyB, cap)); EH_TRY(dalloc(c, m.info, cap));
-    EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
-    EH_TRY(dalloc(c, m.nrm, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.lnrm, (size_t)cap * kMaxPts));
-    EH_TRY(dalloc(c, m.imp, (size_t)cap * kMaxPts));
+    if (kPointRecords) {   // one allocation, five interleaved base pointers: element pt_at(cap, k, m) of each is a field of point k of manifold m
+        float4 *pts = nullptr;
+        EH_TRY(dalloc(c, pts, (size_t)cap * kMaxPts * kPointF));
+        m.pA = pts; m.pB = pts + 1; m.nrm = pts + 2; m.lnrm = pts + 3; m.imp = pts + 4;
+    } else {
+        EH_TRY(dalloc(c, m.pA, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.pB, (size_t)cap * kMaxPts));
+        EH_TRY(dalloc(c, m.nrm, (size_t)cap * kMaxPts)); EH_TRY(dalloc(c, m.lnrm, (size_t)cap * kMaxPts));
+        EH_TRY(dalloc(c, m.imp, (size_t)cap * kMaxPts));
+    }
     return EDYNHIP_OK;
 }
 
@@ -314,7 +320,7 @@ __global__ void k_manifolds_to_records(uint32_t M, Manifolds mf, edynhip_manifol
     const uint32_t info = mf.info[m];
     r.num_points = info & 0xFF; r.colour = info >> 8;
     for (uint32_t k = 0; k < r.num_points; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
+        const size_t s = pt_at(mf.cap, k, m);
         float4 a = mf.pA[s], b = mf.pB[s], n = mf.nrm[s], l = mf.lnrm[s], im = mf.imp[s];
         edynhip_point &p = r.pt[k];
         p.pivotA[0] = a.x; p.pivotA[1] = a.y; p.pivotA[2] = a.z; p.distance = a.w;
@@ -349,13 +355,13 @@ __global__ void k_records_to_manifolds(uint32_t M, const edynhip_manifold *in, M
     mf.info[m] = (r.num_points & 0xFF) | ((r.colour & 0xFF) << 8);
     mf.tree[m] = 0;   // (set_manifolds forces a full island update, which rebuilds the certificate)
     for (uint32_t k = 0; k < r.num_points; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
+        const size_t t = pt_at(mf.cap, k, m), s = slot_at(mf.cap, k, m);
         const edynhip_point &p = r.pt[k];
-        mf.pA[s] = make_float4(p.pivotA[0], p.pivotA[1], p.pivotA[2], p.distance);
-        mf.pB[s] = make_float4(p.pivotB[0], p.pivotB[1], p.pivotB[2], p.friction);
-        mf.nrm[s] = make_float4(p.normal[0], p.normal[1], p.normal[2], __int_as_float(p.attachment));
-        mf.lnrm[s] = make_float4(p.local_normal[0], p.local_normal[1], p.local_normal[2], p.restitution);
-        mf.imp[s] = make_float4(p.normal_impulse, p.friction_impulse[0], p.friction_impulse[1], __uint_as_float(p.lifetime));
+        mf.pA[t] = make_float4(p.pivotA[0], p.pivotA[1], p.pivotA[2], p.distance);
+        mf.pB[t] = make_float4(p.pivotB[0], p.pivotB[1], p.pivotB[2], p.friction);
+        mf.nrm[t] = make_float4(p.normal[0], p.normal[1], p.normal[2], __int_as_float(p.attachment));
+        mf.lnrm[t] = make_float4(p.local_normal[0], p.local_normal[1], p.local_normal[2], p.restitution);
+        mf.imp[t] = make_float4(p.normal_impulse, p.friction_impulse[0], p.friction_impulse[1], __uint_as_float(p.lifetime));
         if (mf.pid) mf.pid[s] = ((uint64_t)m << 2) | k;   // injected points: high word 0
         if (mf.xmat) {   // the record carries no extras: the materials are mixed as for a new point, the extras impulses start at 0
             const float4 ma = mat2[a], mb = mat2[b];

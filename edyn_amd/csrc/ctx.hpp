@@ -78,17 +78,27 @@ struct Manifolds {
     uint8_t *tree = nullptr;      // 1 = the island union-find hooked on this manifold: the marked manifolds (with the joints) are a
                                   // spanning forest of the contact graph, i.e. a certificate for the island labels - while none of
                                   // them disappears, no island can have split and the labels are updated incrementally (solver.hip)
-    // per point slot k (list order, newest first): index k*cap + m
+    // per point slot k (list order, newest first), five float4 at index pt_at(cap, k, m) of five INTERLEAVED base pointers (round 6: one
+    // 320-byte record per manifold - pA pB nrm lnrm imp of point 0, then of point 1, ... - so a lane that reaches a manifold through an index
+    // (the row preparation through the colour-sorted order, the narrowphase through prev_idx) pulls 3 lines instead of 20: a 16-byte gather
+    // costs a whole 128-byte line, scripts/ubench/gather.hip, points.hip)
     float4 *pA = nullptr;         // pivotA xyz, w = distance
     float4 *pB = nullptr;         // pivotB xyz, w = friction
     float4 *nrm = nullptr;        // normal xyz, w = bitcast(attachment)
     float4 *lnrm = nullptr;       // local_normal xyz, w = restitution
     float4 *imp = nullptr;        // normal_impulse, friction_impulse[0], [1], bitcast(lifetime)
+    // slot-major, index slot_at(cap, k, m) = k*cap + m:
     uint64_t *pid = nullptr;      // contact events only (else nullptr): the point's id from creation to destruction
     // contact_extras only (else nullptr; allocated when a body gets such a material, edynhip_set_material_extras)
     float4 *xmat = nullptr;       // mixed at creation: roll_friction, spin_friction, stiffness, damping (contact_point_material)
     float4 *ximp = nullptr;       // rolling_friction_impulse[0], [1], spin_friction_impulse, -
 };
+constexpr bool kPointRecords = true;   // false: the slot-major layout of rounds 1-5 (pA[k*cap + m], ...), kept for A/B runs
+constexpr int kPointF = 5;             // float4 per contact point: pA pB nrm lnrm imp
+__host__ __device__ __forceinline__ size_t pt_at(uint32_t cap, uint32_t k, uint32_t m) {
+    return kPointRecords ? ((size_t)m * 4 + k) * kPointF : (size_t)k * cap + m;
+}
+__host__ __device__ __forceinline__ size_t slot_at(uint32_t cap, uint32_t k, uint32_t m) { return (size_t)k * cap + m; }
 // Extras rows of a point (contact_extras_constraint.cpp:37-78), angular only: J = {0, axis, 0, -axis}. Per point 10 float4 at
 // rwx[(k * kXPoint + slot) * cap + p]: rows roll0, roll1, spin as (axis, eff) (I_A^-1 axis, rhs) (I_B^-1 (-axis), impulse) in
 // slots 3r..3r+2, and slot 9 = (roll mu, spin mu, -, -); mu = 0: the row does not exist.

@@ -912,29 +912,57 @@ int ensure_built(edynhip_world *w) {
     const HostScene &sc = w->scene;
     const uint32_t n = sc.n, W = (uint32_t)w->shards.size();
     if (n == 0) return w->fail(EDYNHIP_ERR_INVALID, "edynhip_world: no bodies");
-    // The islands of the initial state, from the stepper itself: one probe context holds the whole scene and runs broadphase,
-    // narrowphase and the island stage - exactly the graph the island manager partitions (island_manager.cpp:117-247).
+    // The islands of the initial state, estimated on the HOST (round 6; until round 5 a probe context on devices[0] held the WHOLE scene and
+    // ran broadphase, narrowphase and the island stage - a sharded scene had to fit one GPU, and a quarter-million-body probe cost seconds).
+    // An island edge exists once a manifold exists (constraint_util.cpp:76-78: every manifold owns a null_constraint edge), i.e. once two
+    // AABBs come within the creation margin (broadphase.hpp:15-18), or through a joint (island_manager.cpp:117-247). The partition only
+    // has to keep every TRUE island on one shard, so a conservative edge set is as good as the exact one - it merely co-locates islands
+    // that are about to meet anyway: every dynamic shaped body gets the box of its bounding sphere (no collision filters, no exclusions
+    // applied), boxes within the margin and jointed bodies are united, the label of a component is its lowest body index, as on the device.
     std::vector<uint32_t> labels(n);
     std::vector<float> aabb0((size_t)n * 6, 0.f);
     {
-        w->rank_of.assign(n, -1);
-        for (uint32_t i = 0; i < n; ++i) if (sc.kind[i] == EDYNHIP_KIND_DYNAMIC) w->rank_of[i] = 0;
-        std::vector<Shard> keep;
-        keep.swap(w->shards);
-        w->shards.resize(1);
-        w->shards[0].device = keep[0].device;
-        Carry none;
-        build_shard(w, 0, none, false);
-        int rc = shard_error(w);
-        if (rc == EDYNHIP_OK) {
-            Shard &p = w->shards[0];
-            rc = edynhip_run_stages(p.ctx, EDYNHIP_STAGE_BROADPHASE | EDYNHIP_STAGE_NARROWPHASE | EDYNHIP_STAGE_ISLANDS);
-            if (rc == EDYNHIP_OK) rc = edynhip_get_derived(p.ctx, aabb0.data(), nullptr, labels.data());
-            if (rc != EDYNHIP_OK) w->fail(rc, std::string("probe: ") + edynhip_last_error(p.ctx));
+        std::vector<float> mesh_radius(sc.meshes.size(), 0.f);
+        for (size_t k = 0; k < sc.meshes.size(); ++k) {
+            const std::vector<float> &v = sc.meshes[k].v;
+            double c[3] = {0, 0, 0};
+            const size_t nv = v.size() / 3;
+            for (size_t i = 0; i < nv; ++i) for (int d = 0; d < 3; ++d) c[d] += v[3 * i + d];
+            for (int d = 0; d < 3; ++d) c[d] /= (double)std::max<size_t>(nv, 1);
+            double r2 = 0;
+            for (size_t i = 0; i < nv; ++i) { double q = 0; for (int d = 0; d < 3; ++d) q += (v[3 * i + d] - c[d]) * (v[3 * i + d] - c[d]); r2 = std::max(r2, q); }
+            mesh_radius[k] = 2.0f * (float)std::sqrt(r2);   // (the centroid the library shifts to lies inside the hull: twice the radius about the mean covers it)
         }
-        free_shard(w->shards[0]);
-        w->shards.swap(keep);
-        if (rc != EDYNHIP_OK) return rc;
+        std::vector<IslandBox> boxes;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (sc.kind[i] != EDYNHIP_KIND_DYNAMIC) continue;
+            const float *p = &sc.shape_param[4 * (size_t)i];
+            float r = -1.0f;
+            switch (sc.shape_type[i]) {
+            case EDYNHIP_SHAPE_BOX: r = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); break;
+            case EDYNHIP_SHAPE_SPHERE: r = p[0]; break;
+            case EDYNHIP_SHAPE_CAPSULE: r = p[0] + p[1]; break;
+            case EDYNHIP_SHAPE_CYLINDER: r = std::sqrt(p[0] * p[0] + p[1] * p[1]); break;
+            case EDYNHIP_SHAPE_POLYHEDRON: { const size_t id = (size_t)p[0]; r = id < mesh_radius.size() ? mesh_radius[id] : 0.0f; break; }
+            default: break;   // no shape (or a plane, which is never dynamic in a sensible scene): touches nothing
+            }
+            if (r < 0) continue;
+            if (!sc.com.empty()) r += std::sqrt(sc.com[3 * (size_t)i] * sc.com[3 * (size_t)i] + sc.com[3 * (size_t)i + 1] * sc.com[3 * (size_t)i + 1] + sc.com[3 * (size_t)i + 2] * sc.com[3 * (size_t)i + 2]);
+            IslandBox b;
+            for (int d = 0; d < 3; ++d) { b.lo[d] = sc.pos[3 * (size_t)i + d] - r; b.hi[d] = sc.pos[3 * (size_t)i + d] + r; aabb0[6 * (size_t)i + d] = b.lo[d]; aabb0[6 * (size_t)i + 3 + d] = b.hi[d]; }
+            b.label = i; b.owner = 0;
+            boxes.push_back(b);
+        }
+        std::vector<uint32_t> parent(n);
+        std::iota(parent.begin(), parent.end(), 0u);
+        auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        auto unite = [&](uint32_t a, uint32_t b) { const uint32_t ra = find(a), rb = find(b); if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); };
+        sweep_boxes(boxes, kCreationMargin, false, [&](const IslandBox &a, const IslandBox &b, float) { unite(a.label, b.label); });
+        for (uint32_t g = 0; g < sc.nj; ++g) {
+            const uint32_t a = sc.jbody[2 * g], b = sc.jbody[2 * g + 1];
+            if (sc.kind[a] == EDYNHIP_KIND_DYNAMIC && sc.kind[b] == EDYNHIP_KIND_DYNAMIC) unite(a, b);
+        }
+        for (uint32_t i = 0; i < n; ++i) labels[i] = find(i);
     }
     w->rank_of.assign(n, -1);
     partition_islands_spatial(n, labels.data(), sc.kind.data(), nullptr, aabb0.data(), W, w->rank_of.data());

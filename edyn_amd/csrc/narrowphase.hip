@@ -313,8 +313,9 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         if (sleeping && edge_asleep(fa, fb)) {   // narrowphase.cpp:31: sleeping manifolds are left as they are
             if (points_in_old)
                 for (int k = 0; k < n_old; ++k) {
-                    const size_t s = (size_t)k * src.cap + sidx, d = (size_t)k * mf.cap + m;
-                    mf.pA[d] = src.pA[s]; mf.pB[d] = src.pB[s]; mf.nrm[d] = src.nrm[s]; mf.lnrm[d] = src.lnrm[s]; mf.imp[d] = src.imp[s];
+                    const size_t ts = pt_at(src.cap, (uint32_t)k, sidx), td = pt_at(mf.cap, (uint32_t)k, m);
+                    mf.pA[td] = src.pA[ts]; mf.pB[td] = src.pB[ts]; mf.nrm[td] = src.nrm[ts]; mf.lnrm[td] = src.lnrm[ts]; mf.imp[td] = src.imp[ts];
+                    const size_t s = slot_at(src.cap, (uint32_t)k, sidx), d = slot_at(mf.cap, (uint32_t)k, m);
                     if (mf.pid) mf.pid[d] = src.pid[s];
                     if (mf.xmat) { mf.xmat[d] = src.xmat[s]; mf.ximp[d] = src.ximp[s]; }
                 }
@@ -335,7 +336,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
 #pragma unroll
         for (int k = 0; k < kMaxPts; ++k) {
             if (k < n_old) {
-                const size_t s = (size_t)k * src.cap + sidx;
+                const size_t s = pt_at(src.cap, (uint32_t)k, sidx);
                 const float4 a = src.pA[s], bb = src.pB[s], n = src.nrm[s];
                 CPoint &p = pts[k];
                 p.pivotA = from4(a); p.pivotB = from4(bb); p.normal = from4(n); p.attachment = __float_as_int(n.w);
@@ -449,7 +450,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
 #pragma unroll
         for (int i = 0; i < kMaxPts; ++i) {
             if (i < n_old && !((dead >> i) & 1u)) {
-                const size_t s = (size_t)i * src.cap + sidx;
+                const size_t s = pt_at(src.cap, (uint32_t)i, sidx);
                 ext_l[i] = src.lnrm[s]; ext_i[i] = src.imp[s]; ext_f[i] = src.pB[s].w;
             } else {
                 ext_l[i] = ext_i[i] = make_float4(0, 0, 0, 0); ext_f[i] = 0;
@@ -464,7 +465,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
             for (int i = kMaxPts - 1; i >= 0; --i) {
                 if ((create >> i) & 1u) {
                     const CPoint &p = lp[i];
-                    const size_t d = (size_t)n_out * mf.cap + m;
+                    const size_t d = pt_at(mf.cap, (uint32_t)n_out, m);
                     mf.pA[d] = to4(p.pivotA, p.distance);
                     mf.pB[d] = to4(p.pivotB, friction);
                     mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
@@ -472,7 +473,7 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
                     mf.imp[d] = make_float4(0, 0, 0, __uint_as_float(0u));
                     if (mf.pid) {   // id = (step of creation + 1) << 32 | manifold index << 2 | local slot
                         const uint64_t id = ((uint64_t)(ev.step + 1u) << 32) | ((uint64_t)m << 2) | (uint64_t)i;
-                        mf.pid[d] = id;
+                        mf.pid[slot_at(mf.cap, (uint32_t)n_out, m)] = id;
                         emit_event(ev, EDYNHIP_EVENT_POINT_CREATED, ia, ib, id);
                     }
                     ++n_out;
@@ -483,14 +484,14 @@ k_np_merge(uint32_t M, Manifolds mf, Bodies b, float dt, bool sleeping, Manifold
         for (int i = 0; i < kMaxPts; ++i) {
             if (i < n_old && !((dead >> i) & 1u)) {
                 const CPoint &p = pts[i];
-                const size_t d = (size_t)n_out * mf.cap + m;
+                const size_t d = pt_at(mf.cap, (uint32_t)n_out, m);
                 const f3 ln = ((changed >> i) & 1u) ? local_normal(p, A, B) : from4(ext_l[i]);
                 mf.pA[d] = to4(p.pivotA, p.distance);
                 mf.pB[d] = to4(p.pivotB, ext_f[i]);
                 mf.nrm[d] = to4(p.normal, __int_as_float(p.attachment));
                 mf.lnrm[d] = to4(ln, ext_l[i].w);
                 mf.imp[d] = make_float4(ext_i[i].x, ext_i[i].y, ext_i[i].z, __uint_as_float(__float_as_uint(ext_i[i].w) + 1u));
-                if (mf.pid) mf.pid[d] = ext_id[i];
+                if (mf.pid) mf.pid[slot_at(mf.cap, (uint32_t)n_out, m)] = ext_id[i];
                 ++n_out;
             }
         }

@@ -50,11 +50,11 @@ DI float manifold_min_relvel(const Manifolds &mf, const Bodies &b, uint32_t m) {
     const RBody A = load_rbody(b, mf.bodyA[m]), B = load_rbody(b, mf.bodyB[m]);
     float mn = kScalarMax;
     for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
-        const f3 pA = to_world(from4(mf.pA[s]), A.org, A.orn), pB = to_world(from4(mf.pB[s]), B.org, B.orn);
+        const size_t pt = pt_at(mf.cap, k, m);
+        const f3 pA = to_world(from4(mf.pA[pt]), A.org, A.orn), pB = to_world(from4(mf.pB[pt]), B.org, B.orn);
         const f3 rA = pA - A.pos, rB = pB - B.pos;
         const f3 velA = A.v + cross(A.w, rA), velB = B.v + cross(B.w, rB);
-        mn = fminf(dot(velA - velB, from4(mf.nrm[s])), mn);
+        mn = fminf(dot(velA - velB, from4(mf.nrm[pt])), mn);
     }
     return mn;
 }
@@ -142,9 +142,9 @@ DI void solve_star(const RestArgs &a, uint32_t node) {
             const uint32_t ia = mf.bodyA[m], ib = mf.bodyB[m];
             const RBody A = load_rbody(b, ia), B = load_rbody(b, ib);   // velocities do not change until the star is done
             for (uint32_t k = 0; k < np; ++k) {
-                const size_t s = (size_t)k * mf.cap + m;
-                const f3 n = from4(mf.nrm[s]);
-                const f3 pA = to_world(from4(mf.pA[s]), A.org, A.orn), pB = to_world(from4(mf.pB[s]), B.org, B.orn);
+                const size_t s = slot_at(mf.cap, k, m), pt = pt_at(mf.cap, k, m);   // (s: the solver's own slot-major scratch; pt: the manifold's point record)
+                const f3 n = from4(mf.nrm[pt]);
+                const f3 pA = to_world(from4(mf.pA[pt]), A.org, A.orn), pB = to_world(from4(mf.pB[pt]), B.org, B.orn);
                 const f3 rA = pA - A.pos, rB = pB - B.pos;
                 f3 dvA = from4(B_DV(b, ia)), dwA = from4(B_DW(b, ia)), dvB = from4(B_DV(b, ib)), dwB = from4(B_DW(b, ib));
                 if (!dyn(b.flags[ia])) { dvA = mk3(0, 0, 0); dwA = mk3(0, 0, 0); }   // dummy deltas of non-procedural bodies
@@ -155,7 +155,7 @@ DI void solve_star(const RestArgs &a, uint32_t node) {
                     const f3 J0 = n, J1 = cross(rA, n), J2 = -n, J3 = -cross(rB, n);
                     const float em = eff_mass4(J0, J1, J2, J3, A, B);
                     const float relvel = rel_speed4(J0, J1, J2, J3, A.v, A.w, B.v, B.w);
-                    const float restitution = mf.lnrm[s].w;
+                    const float restitution = mf.lnrm[pt].w;
                     const float rhs = -(0.0f * 0.2f + relvel * (1 + restitution));
                     const float drel = rel_speed4(J0, J1, J2, J3, dvA, dwA, dvB, dwB);
                     float dimp = (rhs - drel) * em;
@@ -170,7 +170,7 @@ DI void solve_star(const RestArgs &a, uint32_t node) {
                 {
                     f3 t[2];
                     plane_space(n, t[0], t[1]);
-                    const float mu = mf.pB[s].w;
+                    const float mu = mf.pB[pt].w;
                     float di[2], ni[2];
                     f3 K1[2], K3[2];
 #pragma unroll

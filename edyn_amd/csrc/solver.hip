@@ -734,8 +734,8 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
     //  103 against 71 us on the headline pile: every lane then loads both bodies for a single point.)
     const BRef A = load_bref(b, ia), B = load_bref(b, ib);
     for (uint32_t k = 0; k < np; ++k) {
-        const size_t s = (size_t)k * mf.cap + m;
-        const float4 a4 = mf.pA[s], b4 = mf.pB[s], n4 = mf.nrm[s], im = mf.imp[s];
+        const size_t s = slot_at(mf.cap, k, m), t = pt_at(mf.cap, k, m);   // (s: the slot-major extras arrays; t: the manifold's point record)
+        const float4 a4 = mf.pA[t], b4 = mf.pB[t], n4 = mf.nrm[t], im = mf.imp[t];
         const f3 n = from4(n4);
         const float distance = a4.w, mu = b4.w;
         const f3 pAw = to_world(from4(a4), A.org, A.orn), pBw = to_world(from4(b4), B.org, B.orn);
@@ -770,7 +770,7 @@ __global__ void k_prep_contacts(uint32_t n_active, Rows rows, uint32_t rcap, Man
         store_row(rows.rw, base, rcap, n, J1, J3, effn, rhsn, im.x, mu, A, B);
         if (!EXTRAS && push && write_pw) {   // the dataflow position solve's copy of the point, indexed by the lane (Rows::pw)
             const size_t pb = (size_t)(k * kPosF) * rcap + p;
-            rows.pw[pb] = a4; rows.pw[pb + rcap] = b4; rows.pw[pb + 2 * (size_t)rcap] = mf.lnrm[s]; rows.pw[pb + 3 * (size_t)rcap] = n4;
+            rows.pw[pb] = a4; rows.pw[pb + rcap] = b4; rows.pw[pb + 2 * (size_t)rcap] = mf.lnrm[t]; rows.pw[pb + 3 * (size_t)rcap] = n4;
         }
         if (EXTRAS && upper != kLarge) rows.rw[base + 4 * (size_t)rcap].w = upper;
         if (EXTRAS) {   // rolling pair and spinning row (:37-78); roll_direction components do not exist on this path
@@ -1356,12 +1356,12 @@ __global__ void k_push_links(uint32_t n_active, Rows rows, const uint32_t *__res
 DI void store_impulses_of(uint32_t p, const Rows &rows, uint32_t rcap, const Manifolds &mf) {
     const uint32_t m = rows.order[p], np = rows.np[p];
     for (uint32_t k = 0; k < np; ++k) {
-        const size_t d = (size_t)k * mf.cap + m;
-        float4 im = mf.imp[d];
+        const size_t d = slot_at(mf.cap, k, m), td = pt_at(mf.cap, k, m);
+        float4 im = mf.imp[td];
         im.x = rows.rw[(size_t)((k * kRowsPerPoint + 0) * kRowF + 2) * rcap + p].w;
         im.y = rows.rw[(size_t)((k * kRowsPerPoint + 1) * kRowF + 2) * rcap + p].w;
         im.z = rows.rw[(size_t)((k * kRowsPerPoint + 2) * kRowF + 2) * rcap + p].w;
-        mf.imp[d] = im;
+        mf.imp[td] = im;
         if (rows.rwx && mf.ximp) {   // contact_extras_constraint::store_applied_impulses (contact_extras_constraint.cpp:88-107)
             const size_t xb = (size_t)(k * kXPoint) * rcap + p;
             const float4 mu = rows.rwx[xb + 9 * (size_t)rcap];
@@ -2538,7 +2538,7 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     float4 piv[NP], l4[NP], n4[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {   // unconditional: slots >= np hold finite stale data that is never used or stored
-        const size_t s = (size_t)k * mf.cap + m;
+        const size_t s = pt_at(mf.cap, (uint32_t)k, m);
         piv[k] = pvsrc[s]; l4[k] = mf.lnrm[s]; n4[k] = mf.nrm[s];
     }
     PBody X = load_pbody(b, ix);
@@ -2559,7 +2559,7 @@ DI void pos_contacts_np(bool in_range, uint32_t pc, bool sideB, uint32_t np, con
     if (active) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const size_t s = (size_t)k * mf.cap + m;
+            const size_t s = pt_at(mf.cap, (uint32_t)k, m);
             if ((uint32_t)k < np && !soft[k]) {
                 if (!sideB) mf.pA[s] = piv[k];
                 else mf.nrm[s] = n4[k];
@@ -2870,7 +2870,7 @@ DI void dfp_task(const DfPosArgs &a, uint32_t p, bool valid, bool sideB, uint32_
             if (act) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    const size_t s = (size_t)k * mf.cap + m;
+                    const size_t s = pt_at(mf.cap, (uint32_t)k, m);
                     if ((uint32_t)k < np) {
                         if (!sideB) mf.pA[s] = piv[k];
                         else mf.nrm[s] = n4[k];

@@ -94,12 +94,12 @@ def test_multi_world_carries_joints_exclusions_and_a_forced_repartition():
         assert np.array_equal(np.concatenate(mw.get_state(), axis=1), ref[k]), k
         if not sticky_seen and mw.get_stats()["repartitions"] > before:   # the approach-triggered one (no forced one has happened yet)
             sticky_seen = True
-            assert k < 30
+            assert k < 55
             part1 = mw.get_partition()
             assert part1[sphere] == part1[first_of_target], "the sphere's island and the site it rolls into share a shard now"
             bystanders = [i for i in range(len(part0)) if part0[i] >= 0 and int(part0[i]) not in involved]
             assert bystanders and all(part1[i] == part0[i] for i in bystanders), "a sticky re-partition moves nothing but the meeting islands"
-        if k in (30, 60):
+        if k in (55, 75):   # (after the sphere has arrived: 14 steps along x, 35 along z)
             mw.repartition()
     assert sticky_seen and mw.get_stats()["repartitions"] >= 3   # one approach-triggered + the two forced ones
 
