@@ -23,7 +23,7 @@ constexpr float kQueryGrow = 0.03f;              // conservative candidate margi
 constexpr float kBreaking = 0.02f;               // broadphase.hpp:15 (m_aabb_offset)
 // candidate lists (see "candidate lists" below)
 constexpr float kListSlack = 0.035f;     // base slack
-constexpr float kListLookahead = 6.0f;   // + this many steps of motion at the current velocity
+constexpr float kListLookaheadMax = 6.0f, kListLookaheadMin = 1.5f;   // + this many steps of motion at the current velocity (LBVH::lookahead adapts between the two)
 constexpr float kListTest = 0.026f;      // the widest margin any exact predicate uses (separation threshold 0.02 * 1.3)
 static_assert(kListTest >= 0.02f * 1.3f - 1e-6f && kListTest <= kQueryGrow, "list margin must cover every exact predicate");
 // broadphase.hpp:18: contact_breaking_threshold * scalar(1.3), evaluated in fp32 like the reference
@@ -182,7 +182,7 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
                            const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ rope,
                            const float4 *__restrict__ amin, const float4 *__restrict__ amax, float4 *nmin, float4 *nmax,
                            uint32_t *visit, const Counters *cnt, float4 *ref_min, float4 *ref_max, const float4 *__restrict__ linvel,
-                           const float4 *__restrict__ angvel, float dt, uint32_t force, float gacc) {
+                           const float4 *__restrict__ angvel, float dt, uint32_t force, float gacc, float lookahead) {
     if (!(cnt->bp_rebuild | force)) return;   // the candidate lists are still valid: nobody walks the tree this step
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -192,8 +192,8 @@ __global__ void k_bp_refit(const uint64_t *__restrict__ keys, int n, const uint3
         const f3 v = from4(linvel[body]), w = from4(angvel[body]);
         const f3 ext = mx - mn;
         const float reach = 0.5f * sqrtf(ext.x * ext.x + ext.y * ext.y + ext.z * ext.z);   // no point of the body is further from its centre
-        // the motion of the next kListLookahead steps at the current velocity, plus what gravity adds to it
-        const float horizon = kListLookahead * dt;
+        // the motion of the next `lookahead` steps at the current velocity, plus what gravity adds to it
+        const float horizon = lookahead * dt;
         float slack = kListSlack + horizon * (sqrtf(length_sqr(v)) + sqrtf(length_sqr(w)) * reach) + 0.5f * gacc * horizon * horizon;
         if (!(slack < 4.0f)) slack = 4.0f;   // also catches NaN / inf velocities
         ref_min[body] = to4(mn, slack); ref_max[body] = to4(mx, 0.0f);
@@ -549,6 +549,7 @@ k_bp_compact(uint32_t nbodies, const uint64_t *__restrict__ own_keys, const uint
     const uint32_t nextra = min(cnt->num_extra, cap);
     if (i == 0) {
         cnt->num_pairs = total + nextra; if (total + nextra > cap) cnt->pair_overflow = 1;
+        cnt->bp_rebuilt = cnt->bp_rebuild;
         cnt->bp_rebuild = 0;   // consumed by k_bp_refit / k_bp_walk above; this step's k_finish decides for the next step
         if (total + nextra != pm || nextra != 0) cnt->pairs_differ = 1;   // (surplus keys arrive unsorted: no comparison)
     }
@@ -720,9 +721,30 @@ int broadphase(edynhip_ctx *c) {
         const uint32_t force = (c->bvh.lists_dirty || !c->full_step || !bp_lists_enabled() || rebuild) ? 1u : 0u;
         c->bvh.lists_dirty = false;
         hipLaunchKernelGGL(k_bp_refit, dim3(blocks(np, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.parent, c->bvh.left, c->bvh.right, c->bvh.rope, c->b.amin, c->b.amax, c->bvh.nmin, c->bvh.nmax, c->bvh.visit, c->cnt, c->bvh.ref_min, c->bvh.ref_max, c->b.linvel, c->b.angvel, c->cfg.fixed_dt, force,
-                           sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]));
+                           sqrtf(c->cfg.gravity[0] * c->cfg.gravity[0] + c->cfg.gravity[1] * c->cfg.gravity[1] + c->cfg.gravity[2] * c->cfg.gravity[2]), c->bvh.lookahead);
         hipLaunchKernelGGL(k_bp_walk, dim3(blocks(np * kWalkLanes, 256)), dim3(256), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, cl, c->cnt, c->bvh.visit, c->sleeping, force, c->bvh.right);
         hipLaunchKernelGGL(k_bp_pairs, dim3(blocks(np, kOwnersPerBlock)), dim3(kBpBlock), 0, s, c->bvh.keys_sorted, (int)np, c->bvh.nmin, c->bvh.nmax, c->b.amin, c->b.amax, Filt{c->b.group, c->b.mask, c->excl, c->pair_filter != nullptr}, c->bvh.np_list, c->bvh.num_np, prev, pm, c->own_keys, c->own_count, c->pair_keys, cur.cap, c->cnt, cl, c->b.flags, c->sleeping, c->bvh.split, c->bvh.rope);
+        {   // developer knob EDYNHIP_BP_STATS=1: what k_bp_pairs had to do, every 100th step (candidate-list lengths, owners that walked the tree, pairs kept)
+            static const bool bp_stats = getenv("EDYNHIP_BP_STATS") != nullptr;
+            if (bp_stats && c->step_index % 100 == 50) {
+                std::vector<uint32_t> cnt(c->b.n), own(c->b.n);
+                EH_HIP(c, hipMemcpyAsync(cnt.data(), c->bvh.cand_count, (size_t)c->b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                EH_HIP(c, hipMemcpyAsync(own.data(), c->own_count, (size_t)c->b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                EH_HIP(c, hipStreamSynchronize(s));
+                uint64_t sum = 0, pairs = 0; uint32_t mx = 0, over = 0, listed = 0;
+                uint32_t hist[9] = {0};
+                for (uint32_t i = 0; i < c->b.n; ++i) {
+                    pairs += own[i];
+                    if (cnt[i] == kListOverflow) { ++over; continue; }
+                    sum += cnt[i]; mx = std::max(mx, cnt[i]); ++listed;
+                    ++hist[std::min<uint32_t>(cnt[i] / 16, 8)];
+                }
+                fprintf(stderr, "[bp stats] step %u: bodies %u, candidates per body mean %.1f max %u, owners walking the tree %u, pairs kept %llu (%.2f per body); candidates/16 histogram:",
+                        c->step_index, c->b.n, listed ? (double)sum / listed : 0.0, mx, over, (unsigned long long)pairs, (double)pairs / std::max(c->b.n, 1u));
+                for (int k = 0; k < 9; ++k) fprintf(stderr, " %u", hist[k]);
+                fprintf(stderr, "; look-ahead %.2f steps, rebuild history %04x\n", c->bvh.lookahead, c->bvh.rebuild_hist & 0xFFFFu);
+            }
+        }
         // owners in index order: offsets = exclusive scan of the per-owner counts (own_count[n] = 0 -> own_offset[n] = total)
         static const bool direct_env = !(getenv("EDYNHIP_DIRECT_COMPACT") && getenv("EDYNHIP_DIRECT_COMPACT")[0] == '0');   // developer knob (A/B)
         if (c->b.n <= kCompactScanBodies && direct_env) {
@@ -752,6 +774,15 @@ int broadphase(edynhip_ctx *c) {
         if (c->cnt_host->pair_overflow) return set_error(c, EDYNHIP_ERR_CAPACITY, c->cnt_host->pair_overflow == 2 ? "broadphase: BVH traversal stack exhausted" : "broadphase: pair capacity (max_manifolds) exceeded");
         if (c->cnt_host->df_abort) return set_error(c, EDYNHIP_ERR_INTERNAL, "dataflow solve: a hand-off never arrived in the previous step (workgroups not co-resident?)");
         M = c->cnt_host->num_pairs;
+        {   // adapt the lists' look-ahead (ctx.hpp LBVH::lookahead): rebuilt in each of the last 4 steps -> halve; at most twice in the last 8 -> double
+            static const bool adapt = !(getenv("EDYNHIP_BP_ADAPT") && getenv("EDYNHIP_BP_ADAPT")[0] == '0');   // developer knob (A/B)
+            const bool rebuilt = force != 0 || c->cnt_host->bp_rebuilt != 0;
+            c->bvh.rebuild_hist = (c->bvh.rebuild_hist << 1) | (rebuilt ? 1u : 0u);
+            if (adapt && c->full_step) {
+                if ((c->bvh.rebuild_hist & 0xFu) == 0xFu) c->bvh.lookahead = std::max(kListLookaheadMin, 0.5f * c->bvh.lookahead);
+                else if (__builtin_popcount(c->bvh.rebuild_hist & 0xFFu) <= 2) c->bvh.lookahead = std::min(kListLookaheadMax, 2.0f * c->bvh.lookahead);
+            }
+        }
         if (c->cnt_host->num_extra) {   // some owner had more than kOwnCap partners: its surplus sits unsorted at the end
             int hb = 1; while ((1u << hb) < c->b.n && hb < 31) ++hb;
             EH_HIP(c, hipMemcpyAsync(c->pair_keys, c->pair_keys_sorted, (size_t)M * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));

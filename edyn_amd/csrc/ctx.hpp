@@ -222,6 +222,12 @@ struct LBVH {
     uint32_t *cand_list = nullptr, *cand_count = nullptr;
     float4 *ref_min = nullptr, *ref_max = nullptr;
     bool lists_dirty = true;        // the host changed the set of bodies: rebuild at the next step
+    // The lists' look-ahead in steps (the slack a body's list is built with = kListSlack + look-ahead x dt x speed + gravity's share): 6 for
+    // scenes whose lists live for many steps; halved (down to 1.5) while the lists are rebuilt in almost every step anyway - a heap in free
+    // fall: the slack then only makes every list longer (round 6: polyheap32k, 58 candidates per body and a quarter of the bodies beyond a
+    // list's 128 entries at look-ahead 6) - and doubled again once they survive. Any value keeps the pair set exact (k_finish's check).
+    float lookahead = 6.0f;
+    uint32_t rebuild_hist = 0;      // bit k: the lists were rebuilt k steps ago
     float4 *nmin = nullptr, *nmax = nullptr;      // node boxes [2n-1]
     uint32_t *visit = nullptr;      // refit counters
     uint32_t *np_list = nullptr;    // shaped non-procedural bodies
@@ -262,6 +268,7 @@ struct Counters {
     uint32_t tree_found;         // forest-certificate manifolds (Manifolds::tree) of the previous array that this step's pair set keeps (k_bp_pairs)
     uint32_t tree_marks;         // manifolds marked by this step's island update
     uint32_t tree_total;         // marked manifolds in the current array (NOT reset per step): tree_found == tree_total <=> no island can have split
+    uint32_t bp_rebuilt;         // the candidate lists were rebuilt in this step on the device's own flag (k_bp_compact copies bp_rebuild here before clearing it): the host adapts the lists' look-ahead to it
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
     uint32_t colour_start[4 * kMaxColours], colour_end[4 * kMaxColours];

@@ -88,6 +88,11 @@ DI void cc_count_marks(uint32_t marks, Counters *cnt) {   // every lane of the w
 // CC_FULL only: every body starts at its smallest dynamic lower-index neighbour it has CONTACT POINTS with (its manifolds
 // with lower-index partners are the contiguous segment [seg_start, seg_end) of the sorted array). Links point to smaller
 // indices, so this is a valid forest and most unions below find their roots already merged. Clears the segment's marks.
+// (Round 6, measured and dropped: offering the edges in classes of decreasing STABILITY - manifolds whose oldest point has lived for 32 steps,
+//  then the other manifolds with points, then the pointless ones - so that the certificate consists of long-lived contacts. The number of
+//  steps that relabel in full did not move (mixed32k 372 against 373 of 440, pile32k 127 / 128, islands256k 277 / 277, the polyhedron heap
+//  every step either way) and the two kernels got slower (k_cc_hook_bodies 55 -> 70 us): what breaks a certificate on these scenes is not
+//  a young contact flickering but some long-lived pair of 32 768 bodies separating, in nearly every step. scripts/runs/r6k.sh.)
 __global__ void k_cc_init(uint32_t n, uint32_t *forest, Counters *cnt, Manifolds mf, uint32_t M, const uint32_t *__restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->num_islands = 0;
