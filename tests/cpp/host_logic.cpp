@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <unordered_map>
 #include <vector>
 
 #define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
@@ -32,6 +33,33 @@ int main() {
         uint64_t total = 0;
         for (auto &h : hits) total += h.load();
         REQUIRE(total == expect);
+    }
+    // ---- entity_table (the contact entities' look-up tables): open addressing with backward-shift deletion against std::unordered_map
+    {
+        edyn::detail::entity_table table;
+        std::unordered_map<uint64_t, entt::entity> ref;
+        uint64_t x = 88172645463325252ull;
+        auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        for (int round = 0; round < 200000; ++round) {
+            const uint64_t key = (rnd() % 5000) * 0x100000004ull + (rnd() % 3 == 0 ? 0 : (rnd() & 3));   // clustered keys, key 0 included
+            const int op = (int)(rnd() % 3);
+            if (op == 0) { const auto e = static_cast<entt::entity>((uint32_t)(rnd() % 100000)); table[key] = e; ref[key] = e; }
+            else if (op == 1) {
+                auto it = table.find(key); auto rt = ref.find(key);
+                REQUIRE((it == table.end()) == (rt == ref.end()));
+                if (rt != ref.end()) { REQUIRE(it->second == rt->second && edyn::detail::entity_table::key_of(*it) == key); table.erase(it); ref.erase(rt); }
+            } else {
+                auto it = table.find(key); auto rt = ref.find(key);
+                REQUIRE((it == table.end()) == (rt == ref.end()));
+                if (rt != ref.end()) REQUIRE(it->second == rt->second);
+            }
+            REQUIRE(table.size() == ref.size());
+        }
+        size_t seen = 0;
+        for (auto &kv : table) { auto rt = ref.find(edyn::detail::entity_table::key_of(kv)); REQUIRE(rt != ref.end() && rt->second == kv.second); ++seen; }
+        REQUIRE(seen == ref.size());
+        table.clear();
+        REQUIRE(table.size() == 0 && table.find(1) == table.end());
     }
     // ---- removal hooks: nothing is walked while nothing was destroyed
     entt::registry registry;
