@@ -1560,6 +1560,77 @@ inline void remove_collision_exclusion(entt::registry &registry, entt::entity fi
     }
     if (on_device && s.ctx && a < s.uploaded_bodies && b < s.uploaded_bodies) detail::check(s, edynhip_remove_collision_exclusion(s.ctx, a, b));
 }
+/// util/exclude_collision.hpp:23 (entity_pair form) and :38 clear_collision_exclusion (exclude_collision.cpp:59-69): every exclusion `entity` takes part in
+using entity_pair = std::pair<entt::entity, entt::entity>;   // core/entity_pair.hpp
+inline void exclude_collision(entt::registry &registry, entity_pair entities) { exclude_collision(registry, entities.first, entities.second); }
+inline void clear_collision_exclusion(entt::registry &registry, entt::entity entity) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const auto *bi = registry.try_get<detail::body_index>(entity);
+    if (!bi) return;
+    std::vector<entt::entity> others;
+    for (const auto &ex : s.exclusions) if (ex[0] == bi->value || ex[1] == bi->value) others.push_back(s.bodies[ex[0] == bi->value ? ex[1] : ex[0]]);
+    for (const entt::entity o : others) if (o != entt::null) remove_collision_exclusion(registry, entity, o);
+}
+/// util/constraint_util.hpp:61 (constraint_util.cpp:53-58): the entity stops being a constraint (it lives on); the stepper drops the joint at the next update
+inline void clear_constraint(entt::registry &registry, entt::entity entity) {
+    registry.remove<point_constraint>(entity); registry.remove<hinge_constraint>(entity); registry.remove<distance_constraint>(entity);
+    registry.remove<soft_distance_constraint>(entity); registry.remove<generic_constraint>(entity); registry.remove<null_constraint>(entity);
+    registry.remove<gravity_constraint>(entity); registry.remove<cone_constraint>(entity); registry.remove<cvjoint_constraint>(entity);
+    registry.ctx().get<detail::gpu_stepper>().removal_pending = true;   // (also without signals: the bundled registry's sinks cover destroy / remove alike)
+}
+/// util/rigidbody.hpp:140 (rigidbody.cpp:289-298): does the entity carry what a rigid body of this stepper needs?
+inline bool validate_rigidbody(entt::registry &registry, entt::entity &entity) {
+    if (!registry.valid(entity) || !registry.all_of<rigidbody_tag, detail::body_index>(entity)) return false;
+    if (!registry.any_of<dynamic_tag, kinematic_tag, static_tag>(entity)) return false;
+    if (!registry.all_of<position, orientation>(entity)) return false;
+    if (!registry.all_of<static_tag>(entity) && !registry.all_of<linvel, angvel>(entity)) return false;
+    if (registry.all_of<dynamic_tag>(entity) && !registry.all_of<mass, mass_inv>(entity)) return false;
+    return true;
+}
+/// util/contact_manifold_util.hpp:19-35: is there a contact manifold between the two bodies / which entity is it (init_config::materialize_contacts)
+inline entt::entity get_manifold_entity(entt::registry &registry, entt::entity first, entt::entity second) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    const auto *a = registry.try_get<detail::body_index>(first), *b = registry.try_get<detail::body_index>(second);
+    if (!a || !b) return entt::null;
+    for (const uint64_t key : {detail::manifold_key(a->value, b->value), detail::manifold_key(b->value, a->value)}) {
+        auto it = s.manifold_entities.find(key);
+        if (it != s.manifold_entities.end()) return it->second;
+    }
+    return entt::null;
+}
+inline entt::entity get_manifold_entity(entt::registry &registry, entity_pair entities) { return get_manifold_entity(registry, entities.first, entities.second); }
+inline bool manifold_exists(entt::registry &registry, entt::entity first, entt::entity second) { return get_manifold_entity(registry, first, second) != entt::null; }
+inline bool manifold_exists(entt::registry &registry, entity_pair entities) { return manifold_exists(registry, entities.first, entities.second); }
+/// util/constraint_util.hpp:73-105: the edges of a body in the island graph - its constraint entities and (with materialize_contacts) its contact manifold
+/// entities - and the bodies at their other ends. func(entity), or bool func(entity) returning false to stop.
+template <typename Func> void visit_edges(entt::registry &registry, entt::entity entity, Func func) {
+    auto &s = registry.ctx().get<detail::gpu_stepper>();
+    auto call = [&](entt::entity e) { if constexpr (std::is_invocable_r_v<bool, Func, entt::entity>) return func(e); else { func(e); return true; } };
+    for (uint32_t j = 0; j < (uint32_t)s.constraints.size(); ++j) {
+        const entt::entity c = s.constraints[j];
+        if (c == entt::null) continue;
+        const constraint_base *cb = detail::constraint_of(registry, c, s.constraint_kind[j]);
+        if (cb && (cb->body[0] == entity || cb->body[1] == entity) && !call(c)) return;
+    }
+    const auto *bi = registry.try_get<detail::body_index>(entity);
+    if (!bi) return;
+    for (auto &kv : s.manifold_entities) {
+        const uint64_t key = detail::entity_table::key_of(kv);
+        if (((uint32_t)(key >> 32) == bi->value || (uint32_t)key == bi->value) && !call(kv.second)) return;
+    }
+}
+template <typename Func> void visit_neighbors(entt::registry &registry, entt::entity entity, Func func) {
+    visit_edges(registry, entity, [&](entt::entity edge) {
+        entt::entity other = entt::null;
+        if (auto *m = registry.try_get<contact_manifold>(edge)) other = m->body[0] == entity ? m->body[1] : m->body[0];
+        else {
+            auto &s = registry.ctx().get<detail::gpu_stepper>();
+            for (uint32_t j = 0; j < (uint32_t)s.constraints.size() && other == entt::null; ++j)
+                if (s.constraints[j] == edge) if (const constraint_base *cb = detail::constraint_of(registry, edge, s.constraint_kind[j])) other = cb->body[0] == entity ? cb->body[1] : cb->body[0];
+        }
+        if (other != entt::null) func(other);
+    });
+}
 /// util/rigidbody.hpp:95-103, rigidbody.cpp:193-226: strips everything make_rigidbody assigned; the entity itself lives on.
 inline void clear_rigidbody(entt::registry &registry, entt::entity entity) {
     registry.remove<rigidbody_tag>(entity); registry.remove<dynamic_tag>(entity); registry.remove<kinematic_tag>(entity);
@@ -1666,6 +1737,35 @@ inline vector3 mat_vec(const matrix3x3 &m, const vector3 &v) {
 inline vector3 get_rigidbody_origin(entt::registry &registry, entt::entity entity) {
     if (auto *o = registry.try_get<origin>(entity)) return *o;
     return registry.get<position>(entity);
+}
+namespace detail {
+inline vector3 to_world_space(const vector3 &c, const vector3 &p, const quaternion &q) {   // math/transform.hpp: p + rotate(q, c)
+    const vector3 u{q.x, q.y, q.z};
+    const vector3 t{2 * (u.y * c.z - u.z * c.y), 2 * (u.z * c.x - u.x * c.z), 2 * (u.x * c.y - u.y * c.x)};
+    return {p.x + c.x + q.w * t.x + (u.y * t.z - u.z * t.y), p.y + c.y + q.w * t.y + (u.z * t.x - u.x * t.z), p.z + c.z + q.w * t.z + (u.x * t.y - u.y * t.x)};
+}
+}  // namespace detail
+/// util/rigidbody.hpp:201 (rigidbody.cpp:382-391): move the body so that its ORIGIN is at `origin` (edyn::refresh is implied: the device takes the edit at the next update)
+inline void set_rigidbody_origin(entt::registry &registry, entt::entity entity, const vector3 &org) {
+    auto &p = registry.get<position>(entity);
+    if (auto *cm = registry.try_get<center_of_mass>(entity)) {
+        const vector3 w = detail::to_world_space(*cm, org, registry.get<orientation>(entity));
+        p.x = w.x; p.y = w.y; p.z = w.z;
+        auto &o = registry.get<origin>(entity); o.x = org.x; o.y = org.y; o.z = org.z;
+    } else { p.x = org.x; p.y = org.y; p.z = org.z; }
+    registry.ctx().get<detail::gpu_stepper>().state_dirty = true;
+}
+/// util/rigidbody.hpp:219 (rigidbody.cpp:403-407): recompute `origin` from position / orientation / centre of mass after an edit of the transform
+inline void rigidbody_update_origin(entt::registry &registry, entt::entity entity) {
+    const auto &cm = registry.get<center_of_mass>(entity);
+    const vector3 w = detail::to_world_space(vector3{-cm.x, -cm.y, -cm.z}, registry.get<position>(entity), registry.get<orientation>(entity));
+    auto &o = registry.get<origin>(entity); o.x = w.x; o.y = w.y; o.z = w.z;
+}
+/// util/rigidbody.hpp:198 (rigidbody.cpp:393-401): where a renderer draws the body's shape
+inline vector3 get_rigidbody_present_origin(entt::registry &registry, entt::entity entity) {
+    const auto &pp = registry.get<present_position>(entity);
+    if (auto *cm = registry.try_get<center_of_mass>(entity)) return detail::to_world_space(vector3{-cm->x, -cm->y, -cm->z}, pp, registry.get<present_orientation>(entity));
+    return pp;
 }
 /// util/rigidbody.hpp:182, rigidbody.cpp:364-370,517-548: the body's centre of mass moves (in the shape's frame); its origin stays
 inline void set_center_of_mass(entt::registry &registry, entt::entity entity, const vector3 &com) {
@@ -1775,6 +1875,10 @@ inline void wake_up_entity(entt::registry &registry, entt::entity entity) {
     if (auto *bi = registry.try_get<detail::body_index>(entity); bi && s.ctx && bi->value < s.uploaded_bodies && !s.scene_dirty)
         detail::check(s, edynhip_wake_bodies(s.ctx, 1, &bi->value));
 }
+
+/// util/island_util.hpp:20-26: in the sequential stepper wake_up_entity IS wake_up_island_resident (rigidbody.cpp:409-415)
+inline void wake_up_island_resident(entt::registry &registry, entt::entity entity) { wake_up_entity(registry, entity); }
+inline void wake_up_island_residents(entt::registry &registry, const std::vector<entt::entity> &entities) { for (const entt::entity e : entities) wake_up_entity(registry, e); }
 
 /// edyn::insert_material_mixing (util/insert_material_mixing.hpp:17): the material of contacts between bodies whose materials carry
 /// these ids. As in the reference the lookup is sensitive to the order in which the two bodies meet (edynhip.h).

@@ -59,6 +59,13 @@ int main() {
         if (registry.get<edyn::contact_point_geometry>(e).distance < 0.02f) ++penetrating;
     });
     REQUIRE(parents_ok && data_ok && penetrating > 0);
+    // util/contact_manifold_util.hpp, util/constraint_util.hpp visit_*: box 3 rests on box 0 (same column, one layer up)
+    REQUIRE(edyn::manifold_exists(registry, boxes[3], boxes[0]) && edyn::manifold_exists(registry, boxes[0], boxes[3]));
+    REQUIRE(registry.all_of<edyn::contact_manifold>(edyn::get_manifold_entity(registry, boxes[3], boxes[0])));
+    REQUIRE(!edyn::manifold_exists(registry, boxes[0], boxes[26]));
+    bool below_seen = false; size_t neighbours = 0;
+    edyn::visit_neighbors(registry, boxes[3], [&](entt::entity o) { ++neighbours; below_seen = below_seen || o == boxes[0]; });
+    REQUIRE(below_seen && neighbours >= 2);
     // destroying a body takes its manifolds and points with it (at the next update)
     registry.destroy(boxes.back());
     t += 1.0 / 60; edyn::update(registry, t);

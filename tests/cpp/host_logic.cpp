@@ -5,10 +5,12 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
 #define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+#define REQUIRE_VOID(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
 
 int main() {
     // ---- worker_pool
@@ -95,6 +97,50 @@ int main() {
     edyn::detail::sync_removed(registry, s);
     REQUIRE(s.constraints[1] == entt::null && !registry.valid(con2));
 
+    // ---- registry-side helpers of the reference's util headers (no device needed: the stepper uploads lazily)
+    {
+        entt::entity b50 = bodies[50];
+        REQUIRE(edyn::validate_rigidbody(registry, b50));
+        entt::entity plain = registry.create();
+        REQUIRE(!edyn::validate_rigidbody(registry, plain));
+        auto c1 = edyn::make_constraint<edyn::point_constraint>(registry, bodies[50], bodies[51]);
+        auto c2 = edyn::make_constraint<edyn::distance_constraint>(registry, bodies[50], bodies[52]);
+        int edges = 0; std::vector<entt::entity> nb;
+        edyn::visit_edges(registry, bodies[50], [&](entt::entity) { ++edges; });
+        edyn::visit_neighbors(registry, bodies[50], [&](entt::entity o) { nb.push_back(o); });
+        REQUIRE(edges == 2 && nb.size() == 2 && ((nb[0] == bodies[51] && nb[1] == bodies[52]) || (nb[0] == bodies[52] && nb[1] == bodies[51])));
+        int first_only = 0;
+        edyn::visit_edges(registry, bodies[50], [&](entt::entity) { ++first_only; return false; });   // a bool functor stops the walk
+        REQUIRE(first_only == 1);
+        s.removal_pending = false;
+        edyn::clear_constraint(registry, c1);
+        REQUIRE(s.removal_pending && registry.valid(c1) && !registry.all_of<edyn::point_constraint>(c1));
+        edyn::detail::sync_removed(registry, s);
+        edges = 0; edyn::visit_edges(registry, bodies[50], [&](entt::entity e) { ++edges; REQUIRE_VOID(e == c2); });
+        REQUIRE(edges == 1);
+        edyn::exclude_collision(registry, bodies[60], bodies[61]);
+        edyn::exclude_collision(registry, edyn::entity_pair{bodies[60], bodies[62]});
+        edyn::exclude_collision(registry, bodies[63], bodies[64]);
+        REQUIRE(s.exclusions.size() == 3);
+        edyn::clear_collision_exclusion(registry, bodies[60]);
+        REQUIRE(s.exclusions.size() == 1 && s.exclusions[0][0] == registry.get<edyn::detail::body_index>(bodies[63]).value);
+        REQUIRE(!edyn::manifold_exists(registry, bodies[60], bodies[61]) && edyn::get_manifold_entity(registry, edyn::entity_pair{bodies[60], bodies[61]}) == entt::null);
+        // origin helpers on a body with a centre-of-mass offset
+        auto od = edyn::rigidbody_def{};
+        od.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}};
+        od.position = {1, 2, 3};
+        od.center_of_mass = edyn::vector3{0.25f, 0, 0};
+        const auto ob = edyn::make_rigidbody(registry, od);
+        const auto o0 = edyn::get_rigidbody_origin(registry, ob);
+        REQUIRE(o0.x == 1 && o0.y == 2 && o0.z == 3 && registry.get<edyn::position>(ob).x == 1.25f);
+        edyn::set_rigidbody_origin(registry, ob, {5, 2, 3});
+        REQUIRE(registry.get<edyn::position>(ob).x == 5.25f && edyn::get_rigidbody_origin(registry, ob).x == 5 && s.state_dirty);
+        registry.get<edyn::position>(ob).x = 7.25f;
+        edyn::rigidbody_update_origin(registry, ob);
+        REQUIRE(edyn::get_rigidbody_origin(registry, ob).x == 7);
+        registry.get<edyn::present_position>(ob) = edyn::present_position{{9.25f, 2, 3}};
+        REQUIRE(edyn::get_rigidbody_present_origin(registry, ob).x == 9);
+    }
     // ---- host presentation: pos + v dt, integrate(orn, w, dt); sleeping bodies and bodies without present_* are left alone
     registry.emplace<edyn::sleeping_tag>(bodies[30]);
     registry.get<edyn::present_position>(bodies[30]).x = -99;
