@@ -1704,6 +1704,17 @@ int edynhip_snapshot_records(edynhip_ctx *c, float present_dt, uint32_t max_even
     const uint32_t copy_events = std::min(max_events, c->rec_event_cap);
     const size_t ev_bytes = (size_t)c->rec_event_cap * sizeof(eh::ContactEvent);
     uint8_t *d = c->rec_dev[slot], *h = c->rec_host[slot];
+    // developer knob EDYNHIP_RECORDS_DIRECT=1 (A/B): the pack kernels store straight into the pinned host slot (it is mapped into the device's
+    // address space) on the stepper's stream - no copy engine, no second stream, no event between the two
+    static const bool direct = getenv("EDYNHIP_RECORDS_DIRECT") && getenv("EDYNHIP_RECORDS_DIRECT")[0] == '1';
+    if (direct) {
+        if (n) hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->b, present_dt, (float4 *)(h + kRecHeader + ev_bytes));
+        hipLaunchKernelGGL(k_pack_events, dim3(copy_events > 4096 ? 64 : 4), dim3(256), 0, c->stream, (const eh::ContactEvent *)c->events, (const uint32_t *)c->event_count,
+                           c->event_cap, copy_events, (uint32_t *)h, (eh::ContactEvent *)(h + kRecHeader));
+        EH_HIP(c, hipEventRecord(c->rec_event[slot], c->stream));
+        c->rec_step[slot] = c->step_index; c->rec_bodies[slot] = n; c->rec_events_copied[slot] = copy_events; c->rec_last = slot;
+        return EDYNHIP_OK;
+    }
     // pack on the stepper's stream (it must see the finished steps), copy on the side stream: the copy engine moves the bytes
     // while the stepper's next kernels already run
     if (n) hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->b, present_dt, (float4 *)(d + kRecHeader + ev_bytes));
