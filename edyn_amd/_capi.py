@@ -151,7 +151,7 @@ def lib():
         L.edynhip_get_contact_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_get_point_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.edynhip_snapshot.argtypes = [C.c_void_p]
-        L.edynhip_snapshot_records.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+        L.edynhip_snapshot_records.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32]
         L.edynhip_snapshot_map.argtypes = [C.c_void_p, C.POINTER(RecordView)]
         L.edynhip_set_event_prefetch.argtypes = [C.c_void_p, C.c_uint32]
         L.edynhip_prefetched_events.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

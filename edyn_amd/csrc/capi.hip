@@ -1683,7 +1683,7 @@ __global__ void k_pack_events(const eh::ContactEvent *__restrict__ events, const
     if (t == 0) { header[0] = total; header[1] = held; }
     for (uint32_t k = t; k < held; k += gridDim.x * blockDim.x) dst[k] = events[k];
 }
-int edynhip_snapshot_records(edynhip_ctx *c, float present_dt, uint32_t max_events) {
+int edynhip_snapshot_records(edynhip_ctx *c, float present_dt, uint32_t max_events, uint32_t flags) {
     if (!c) return EDYNHIP_ERR_INVALID;
     EH_HIP(c, hipSetDevice(c->device));
     const uint32_t n = c->b.n;
@@ -1704,9 +1704,12 @@ int edynhip_snapshot_records(edynhip_ctx *c, float present_dt, uint32_t max_even
     const uint32_t copy_events = std::min(max_events, c->rec_event_cap);
     const size_t ev_bytes = (size_t)c->rec_event_cap * sizeof(eh::ContactEvent);
     uint8_t *d = c->rec_dev[slot], *h = c->rec_host[slot];
-    // developer knob EDYNHIP_RECORDS_DIRECT=1 (A/B): the pack kernels store straight into the pinned host slot (it is mapped into the device's
-    // address space) on the stepper's stream - no copy engine, no second stream, no event between the two
-    static const bool direct = getenv("EDYNHIP_RECORDS_DIRECT") && getenv("EDYNHIP_RECORDS_DIRECT")[0] == '1';
+    // EDYNHIP_SNAPSHOT_DIRECT: the pack kernels store straight into the pinned host slot (it is mapped into the device's address space) on the
+    // stepper's stream - no copy engine, no second stream, no event between the two. A/B on one box (scripts/runs/r6l.sh): edyn::update in
+    // sequential mode 705 -> 727 steps/s; in asynchronous mode, where nobody waits for the snapshot, the copy engine's overlap is worth as much
+    // (785 / 759 against 764 / 765): the shim asks for it in its synchronous write-back only. (developer knob EDYNHIP_RECORDS_DIRECT=0 / 1 overrides)
+    static const int direct_env = getenv("EDYNHIP_RECORDS_DIRECT") ? atoi(getenv("EDYNHIP_RECORDS_DIRECT")) : -1;
+    const bool direct = direct_env >= 0 ? direct_env != 0 : (flags & EDYNHIP_SNAPSHOT_DIRECT) != 0;
     if (direct) {
         if (n) hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->b, present_dt, (float4 *)(h + kRecHeader + ev_bytes));
         hipLaunchKernelGGL(k_pack_events, dim3(copy_events > 4096 ? 64 : 4), dim3(256), 0, c->stream, (const eh::ContactEvent *)c->events, (const uint32_t *)c->event_count,

@@ -484,8 +484,8 @@ class World:
         return (pos, orn, lin, ang), step.value
 
     # ---- the registry write-back read in place: 96-byte records (state, presentation transforms, origin, flags) + the contact events
-    def snapshot_records(self, present_dt=0.0, max_events=4096):
-        self._check(self._L.edynhip_snapshot_records(self._h, float(present_dt), int(max_events)))
+    def snapshot_records(self, present_dt=0.0, max_events=4096, direct=False):
+        self._check(self._L.edynhip_snapshot_records(self._h, float(present_dt), int(max_events), 1 if direct else 0))
 
     def snapshot_map(self):
         """(records, events, total_events, step_index): structured COPIES of the pinned slot (the C caller reads it in place)."""

@@ -967,7 +967,7 @@ inline void import_records(entt::registry &registry, gpu_stepper &s, const edynh
 inline void apply_contact_events(entt::registry &registry, gpu_stepper &s, std::vector<edynhip_contact_event> &ev, int rc);
 // sequential write-back: enqueue the pack + copy behind the step, wait for it, import. `events_max`: how many contact events travel along.
 inline void write_back(entt::registry &registry, gpu_stepper &s, bool presentation) {
-    { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_records(s.ctx, s.present_dt, 0u)); }   // the pack + copy, enqueued right behind the step
+    { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_records(s.ctx, s.present_dt, 0u, EDYNHIP_SNAPSHOT_DIRECT)); }   // the pack, enqueued right behind the step, straight into pinned memory: this update waits for it
     if (s.cfg.materialize_contacts) {
         // Contact points become entities while the step's solve is still running on the device - where the reference creates them too:
         // inside the step, by the narrowphase, before the solver moves anything (narrowphase.cpp:21-40, collision_util.cpp:311-430).
@@ -1267,7 +1267,7 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
         const bool have_prev = s.records_pending;
         if (have_prev) { phase_timer t(s.tm.state_wait); check(s, edynhip_snapshot_map(s.ctx, &prev)); }
         // every contact event of these steps travels with the snapshot (as many as a slot holds)
-        check(s, edynhip_snapshot_records(s.ctx, s.present_dt, s.cfg.materialize_contacts ? 0xFFFFFFFFu : 0u));
+        check(s, edynhip_snapshot_records(s.ctx, s.present_dt, s.cfg.materialize_contacts ? 0xFFFFFFFFu : 0u, 0u));   // (copy engine, side stream: nobody waits for it)
         s.records_pending = true;
         if (have_prev) { pool_of(s).prewake(); import_pending_records(registry, s, prev, steps); }
         return;

@@ -382,7 +382,11 @@ typedef struct {
     const edynhip_contact_event *events;   /* [num_events]; NULL when the context records no events */
     uint32_t num_events, total_events;
 } edynhip_record_view;
-int edynhip_snapshot_records(edynhip_ctx *ctx, float present_dt, uint32_t max_events);
+/* flags: EDYNHIP_SNAPSHOT_DIRECT - the caller is going to wait for THIS snapshot right away (a synchronous write-back): the pack kernels store
+ * straight into the pinned slot on the stepper's stream instead of handing a device buffer to the copy engine on the side stream (no
+ * second stream, no event between the two: ~0.04 ms sooner on the headline pile); without it the copy overlaps whatever is enqueued next. */
+enum { EDYNHIP_SNAPSHOT_DIRECT = 1u };
+int edynhip_snapshot_records(edynhip_ctx *ctx, float present_dt, uint32_t max_events, uint32_t flags);
 int edynhip_snapshot_map(edynhip_ctx *ctx, edynhip_record_view *view);
 /* Contact-event prefetch (ABI 15). In the reference contact points become registry entities INSIDE the step, during the narrowphase
  * (create_contact_point collision_util.cpp:311-388, destroy_contact_point :390-430, narrowphase.cpp:21-40) - before the solver moves

@@ -1650,7 +1650,7 @@ def test_record_snapshots_are_the_write_back_in_place():
         g.step_simulation(1 + call % 2)
         early, early_total = g.prefetched_events()
         dt = np.float32(-1.0 / 60 + 0.001 * call)
-        g.snapshot_records(present_dt=float(dt), max_events=64)
+        g.snapshot_records(present_dt=float(dt), max_events=64, direct=bool(call & 1))   # alternating: copy engine / stored straight into the pinned slot
         rec, ev, total, step = g.snapshot_map()
         p, q, v, w = g.get_state()
         assert np.array_equal(rec["pos"], p) and np.array_equal(rec["orn"], q) and np.array_equal(rec["linvel"], v) and np.array_equal(rec["angvel"], w), call
