@@ -480,6 +480,7 @@ struct gpu_stepper {
     bool removal_pending{true};                                     // an on_destroy hook fired (or nothing is known yet): sync_removed has work
     bool records_pending{false};                                    // a record snapshot of the previous update is in flight (asynchronous mode)
     float present_dt{0};                                            // update_presentation's interpolation_dt of the update in progress
+    bool present_this_call{true};                                   // edyn::update refreshes present_*; edyn::step_simulation does not (stepper_sequential.cpp:121-147 never calls update_presentation)
     bool hooks_connected{false};
     bool host_presentation{false};                                  // this update's presentation transforms were not part of a write-back: compute them on the host
     uint32_t events_stale_through{0};                               // asynchronous mode: snapshots up to this step index carry events a rebuild already covered
@@ -799,7 +800,8 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
         if (s.should_collide) check(s, edynhip_set_pair_filter(s.ctx, &pair_filter_trampoline, &s));   // a re-created context asks the same predicate
         // contact entities follow the narrowphase, not the end of the step (edynhip.h "Contact-event prefetch"): the host builds them while the solve runs
-        if (s.cfg.materialize_contacts && s.cfg.execution_mode != execution_mode::asynchronous) check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max));
+        // (also in asynchronous mode, whose step callbacks and edits take the synchronous write-back: the prefetch is 200 KB of copy per step call)
+        if (s.cfg.materialize_contacts) check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max));
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
         s.params_dirty = false;
     }
@@ -1188,7 +1190,7 @@ inline void merge_user_edits(entt::registry &registry, gpu_stepper &s) {
 }
 // asynchronous mode: the record snapshot of the previous update -> registry (state, presentation, sleeping tags, contact entities)
 inline void import_pending_records(entt::registry &registry, gpu_stepper &s, const edynhip_record_view &view, uint32_t steps_in_flight) {
-    { phase_timer t(s.tm.write_back); import_records(registry, s, view, true); }
+    { phase_timer t(s.tm.write_back); import_records(registry, s, view, s.present_this_call); }
     if (!s.cfg.materialize_contacts) return;
     phase_timer t(s.tm.contacts);
     std::vector<edynhip_contact_event> ev;
@@ -1253,7 +1255,7 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
             if (s.pre_step) s.pre_step(registry);
             if (s.state_dirty) upload_state(registry, s);
             check(s, timed ? edynhip_step_timed(s.ctx, 1, first_time + step_dt * k, step_dt) : edynhip_step(s.ctx, 1));
-            write_back(registry, s, k + 1 == steps);
+            write_back(registry, s, s.present_this_call && k + 1 == steps);
             if (s.post_step) s.post_step(registry);
         }
         return;
@@ -1272,7 +1274,7 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
         if (have_prev) { pool_of(s).prewake(); import_pending_records(registry, s, prev, steps); }
         return;
     }
-    write_back(registry, s, true);
+    write_back(registry, s, s.present_this_call);
 }
 // update_presentation (src/edyn/sys/update_presentation.cpp:56-84), local simulation (no discontinuities): transforms are
 // extrapolated from the last simulated state to `presentation_delay` = fixed_dt behind the current time.
@@ -1429,6 +1431,8 @@ inline void update(entt::registry &registry) {
 inline void step_simulation(entt::registry &registry, double time) {
     auto &s = registry.ctx().get<detail::gpu_stepper>();
     s.last_time = time;
+    struct restore { bool &flag; ~restore() { flag = true; } } guard{s.present_this_call};   // (also when a step throws)
+    s.present_this_call = false;
     detail::run_steps(registry, s, 1, true, time, s.cfg.fixed_dt);
 }
 /// edyn::step_simulation(registry) (edyn.hpp:142).

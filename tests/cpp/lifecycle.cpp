@@ -287,6 +287,47 @@ int main() {
         CHECK(st.exclusions.size() == before - 1);
         step(2);
     }
+    // --- a paused stepper: update() snaps the presentation to the state (stepper_sequential.cpp:38-43), step_simulation() takes exactly one
+    //     step and leaves the presentation alone (:121-147); step callbacks in asynchronous mode take the synchronous write-back, contact
+    //     entities included (round 6: the event prefetch is on in every mode)
+    {
+        entt::registry world;
+        auto cfg = edyn::init_config{};
+        cfg.execution_mode = edyn::execution_mode::asynchronous;
+        edyn::attach(world, cfg);
+        auto floor_def = edyn::rigidbody_def{};
+        floor_def.kind = edyn::rigidbody_kind::rb_static;
+        floor_def.shape = edyn::plane_shape{{0, 1, 0}, 0};
+        edyn::make_rigidbody(world, floor_def);
+        auto def = edyn::rigidbody_def{};
+        def.shape = edyn::box_shape{{0.5f, 0.5f, 0.5f}};
+        def.position = {0, 0.6f, 0};
+        const auto box = edyn::make_rigidbody(world, def);
+        static int pre_calls = 0, post_calls = 0;
+        pre_calls = post_calls = 0;
+        edyn::set_pre_step_callback(world, [](entt::registry &) { ++pre_calls; });
+        edyn::set_post_step_callback(world, [](entt::registry &) { ++post_calls; });
+        double tw = 0;
+        for (int i = 0; i < 30; ++i) { tw += 1.0 / 60; edyn::update(world, tw); }
+        CHECK(pre_calls == post_calls && pre_calls >= 29);
+        size_t points = 0;
+        world.view<edyn::contact_point>().each([&](auto, auto &) { ++points; });
+        CHECK(points >= 1);   // the callbacks' synchronous write-back built the contact entities
+        CHECK(std::fabs(world.get<edyn::position>(box).y - 0.5f) < 0.02f);
+        edyn::set_pre_step_callback(world, nullptr); edyn::set_post_step_callback(world, nullptr);
+        edyn::set_paused(world, true);
+        world.get<edyn::present_position>(box).y = 42.0f;
+        edyn::update(world, tw + 1.0);   // paused: no step, the presentation snaps to the state
+        CHECK(world.get<edyn::present_position>(box).y == world.get<edyn::position>(box).y);
+        edyn::rigidbody_apply_impulse(world, box, {0, 3.0f, 0}, {0, 0, 0});
+        world.get<edyn::present_position>(box).y = 42.0f;
+        const float y0 = world.get<edyn::position>(box).y;
+        edyn::step_simulation(world, tw + 2.0);
+        edyn::step_simulation(world, tw + 2.0 + 1.0 / 60);
+        CHECK(world.get<edyn::position>(box).y > y0 + 0.01f);            // two steps were taken (asynchronous: the first one has arrived)
+        CHECK(world.get<edyn::present_position>(box).y == 42.0f);        // ... and the presentation was not touched
+        edyn::detach(world);
+    }
     std::printf(failures == 0 ? "LIFECYCLE_OK\n" : "LIFECYCLE_FAIL\n");
     return failures == 0 ? 0 : 1;
 }
