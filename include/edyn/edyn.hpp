@@ -306,8 +306,10 @@ public:
     unsigned size() const { return (unsigned)workers_.size() + 1; }
     void prewake() {
         if (workers_.empty()) return;
-        hint_.fetch_add(1, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
+        // (seq_cst on both sides of the sleepers_ / hint_ and sleepers_ / ticket_ pairs: "publish, then look for sleepers" against "register as a
+        //  sleeper, then look for work" is a store-load pattern - with release / acquire alone both sides may miss each other and a worker sleeps through a job)
+        hint_.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
     }
     /// f(begin, end, worker) for every chunk; worker in [0, size()); returns when every chunk is done
     template <typename F>
@@ -320,8 +322,8 @@ public:
         ctx_ = &f; count_ = count; grain_ = grain; chunks_.store(chunks, std::memory_order_relaxed);
         remaining_.store(chunks, std::memory_order_relaxed);
         const uint64_t seq = ++seq_;
-        ticket_.store(seq << 32, std::memory_order_release);   // opens the job: (sequence, next chunk)
-        if (sleepers_.load(std::memory_order_acquire)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
+        ticket_.store(seq << 32, std::memory_order_seq_cst);   // opens the job: (sequence, next chunk)
+        if (sleepers_.load(std::memory_order_seq_cst)) { { std::lock_guard<std::mutex> l(m_); } cv_.notify_all(); }
         take_chunks(seq, 0u);
         while (remaining_.load(std::memory_order_acquire) != 0) cpu_relax();
         ticket_.store((seq << 32) | 0xFFFFFFFFull, std::memory_order_release);   // closed: a straggler finds no chunk and no stale field is read
@@ -356,10 +358,10 @@ private:
             if (std::chrono::steady_clock::now() < spin_until) { for (int k = 0; k < 32; ++k) cpu_relax(); continue; }
             std::unique_lock<std::mutex> l(m_);
             if (stop_) return;
-            sleepers_.fetch_add(1, std::memory_order_acq_rel);
+            sleepers_.fetch_add(1, std::memory_order_seq_cst);
             cv_.wait(l, [&] {
-                const uint64_t now = ticket_.load(std::memory_order_acquire);
-                return stop_ || ((now >> 32) != seen && (uint32_t)now != 0xFFFFFFFFu) || hint_.load(std::memory_order_acquire) != seen_hint;
+                const uint64_t now = ticket_.load(std::memory_order_seq_cst);
+                return stop_ || ((now >> 32) != seen && (uint32_t)now != 0xFFFFFFFFu) || hint_.load(std::memory_order_seq_cst) != seen_hint;
             });
             sleepers_.fetch_sub(1, std::memory_order_acq_rel);
             if (stop_) return;
