@@ -268,6 +268,7 @@ struct Counters {
     uint32_t tree_found;         // forest-certificate manifolds (Manifolds::tree) of the previous array that this step's pair set keeps (k_bp_pairs)
     uint32_t tree_marks;         // manifolds marked by this step's island update
     uint32_t tree_total;         // marked manifolds in the current array (NOT reset per step): tree_found == tree_total <=> no island can have split
+    uint32_t col_wg_rounds;      // rounds k_col_rounds ran this step (edynhip_stats::colour_rounds counts them with the multi-block rounds)
     uint32_t bp_rebuilt;         // the candidate lists were rebuilt in this step on the device's own flag (k_bp_compact copies bp_rebuild here before clearing it): the host adapts the lists' look-ahead to it
     int32_t bounds_min[3], bounds_max[3];   // ordered-int encoded floats
     // sorted-order ranges per (colour, point count): key = colour*4 + (4 - num_points)
@@ -322,6 +323,7 @@ struct edynhip_ctx {
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
     uint32_t *cs_sup = nullptr;    // [16][256 keys] key counts of every 16 blocks (direct colour sort, solver.hip k_cs_*)
     uint32_t col_lds_edges = 0;   // listed edges k_col_rounds holds in LDS (set at the first colouring)
+    uint32_t col_lds_bytes = 0;   // dynamic LDS of that launch: the edges and the hashed mark table
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries
     uint64_t *used = nullptr;      // per body: colours in use
     uint2 *isl_top = nullptr;      // per island label: (highest colour carried into this step + 1, has an edge to colour) - k_col_tops; cleared like `used`

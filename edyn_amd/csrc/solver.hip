@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(1024) k_col_prepare(uint32_t M, uint32_t *__re
 // between rounds (round 5: the workgroup is bound by the memory requests one CU can issue - a restless heap of polyhedra lists 15 000
 // edges per step and still has two thirds of them after three rounds; the zeroing stores were two of six requests per edge and round).
 // Longer lists, and what is left after max_rounds, go to the multi-block rounds (the host sees cnt->uncoloured != 0).
-__global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+__global__ void __launch_bounds__(1024) k_col_rounds_global(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
                                                      const uint32_t *__restrict__ flags, uint64_t *best0, uint64_t *best1, uint64_t *used, Counters *cnt,
                                                      uint32_t *list, uint32_t cap, uint32_t max_rounds) {
     extern __shared__ uint32_t col_lds[];   // ea[cap], eb[cap]
@@ -519,6 +519,104 @@ __global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint3
         }
     }
     if (threadIdx.x == 0) cnt->uncoloured = left;
+}
+// Round 6: the same rounds with the endpoint marks in LDS. The kernel above spends its time on the memory requests one CU can issue - eight
+// scattered 8-byte requests per listed edge and round (two marks set, two read, the list read twice and rewritten), 15 000 edges and ~32
+// rounds on a restless heap. Here the list, the edges' endpoints and the marks live in LDS; global memory is touched once per edge, when it
+// takes its colour. The marks are a HASHED table (slot = hash(body), 4 bytes: the priority): two bodies may share a slot, and then an edge is
+// "best" only if it beats the uncoloured edges of every body in its two slots - a stricter test than the rule's, so an edge may take its
+// colour a round later, never earlier: it still takes it after all its higher-priority neighbours and before all lower ones, and the result
+// is the greedy colouring in priority order whatever the rounds were (winners of one round are never adjacent). Every thread owns the edges
+// t, t + 1024, ... and keeps its survivors packed at the front of that column: no list compaction across threads, three barriers per round.
+__global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+                                                     const uint32_t *__restrict__ flags, uint64_t *used, Counters *cnt,
+                                                     const uint32_t *__restrict__ list, uint32_t cap, uint32_t lds_words, uint32_t max_rounds) {
+    extern __shared__ uint32_t col_lds[];   // em[n0] manifold, es[n0] endpoint slots (slot A | dynamic A << 15 | slot B << 16 | dynamic B << 31), mark[T]
+    __shared__ uint32_t alive[2], left_sum;
+    const uint32_t n0 = cnt->unc_count;
+    if (n0 == 0 || n0 > cap) { if (threadIdx.x == 0) cnt->col_wg_rounds = 0; return; }
+    uint32_t *em = col_lds, *es = col_lds + n0, *mark = col_lds + 2 * n0;
+    uint32_t T = 1024, bits = 10;   // table size: what the workgroup's LDS leaves, at most 2^15 slots, no more than ~16 per edge (it is cleared once)
+    while (T < 32768u && 2 * T <= lds_words - 2 * n0 && T < 16u * n0) { T *= 2; ++bits; }
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < T; i += blockDim.x) mark[i] = 0;
+    uint32_t mine = 0;   // live edges of this thread: em[tid + k * 1024], k < mine (its share of the list, packed at the front of its column)
+    for (uint32_t e = tid; e < n0; e += blockDim.x) {
+        const uint32_t m = list[e], a = bA[m], b = bB[m];
+        const uint32_t sa = (a * 0x9E3779B1u) >> (32u - bits), sb = (b * 0x9E3779B1u) >> (32u - bits);
+        const uint32_t to = tid + mine++ * blockDim.x;
+        em[to] = m;
+        es[to] = sa | (is_dynamic(flags[a]) ? 0x8000u : 0u) | (sb << 16) | (is_dynamic(flags[b]) ? 0x80000000u : 0u);
+    }
+    if (tid < 2) alive[tid] = 0;
+    if (tid == 0) left_sum = 0;
+    __syncthreads();
+    auto ld = [](const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // other waves' atomics: not through a stale L1 line
+    auto ld32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    uint32_t round = 0;
+    for (; round < max_rounds; ++round) {
+        for (uint32_t k = 0; k < mine; ++k) {                                // phase 1: every slot learns the best uncoloured edge of its bodies
+            const uint32_t e = tid + k * blockDim.x, s = es[e], pr = (uint32_t)edge_prio(em[e]);
+            if (s & 0x8000u) atomicMax(&mark[s & 0x7FFFu], pr);
+            if (s >> 31) atomicMax(&mark[(s >> 16) & 0x7FFFu], pr);
+        }
+        __syncthreads();
+        if (tid == 0) alive[(round + 1) & 1] = 0;
+        // phase 2: an edge that is best in both its slots takes its colour. The winners of a thread are taken four at a time with their loads
+        // issued together - bodies and point count, then the bodies' colour masks: two dependent round trips per batch, where one winner after
+        // the other paid them per edge (a thread owns up to 16 listed edges; winners of a round are never adjacent, so their masks are independent)
+        for (uint32_t k = 0;;) {
+            uint32_t nw = 0, we[4];
+            for (; k < mine && nw < 4u; ++k) {
+                const uint32_t e = tid + k * blockDim.x, s = es[e], pr = (uint32_t)edge_prio(em[e]);
+                if (((s & 0x8000u) && mark[s & 0x7FFFu] != pr) || ((s >> 31) && mark[(s >> 16) & 0x7FFFu] != pr)) continue;
+                we[nw++] = e;
+            }
+            if (nw == 0) break;
+            uint32_t wm[4], ws[4], ia[4], ib[4], in[4];
+            uint64_t busy[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (j < nw) { wm[j] = em[we[j]]; ws[j] = es[we[j]]; ia[j] = bA[wm[j]]; ib[j] = bB[wm[j]]; in[j] = ld32(&info[wm[j]]); }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (j < nw) busy[j] = ((ws[j] & 0x8000u) ? ld(&used[ia[j]]) : 0ull) | ((ws[j] >> 31) ? ld(&used[ib[j]]) : 0ull);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (j < nw) {
+                    const uint64_t avail = ~busy[j] & ((1ull << kSerialColour) - 1ull);
+                    const uint32_t c = avail ? (uint32_t)__ffsll((long long)avail) - 1 : kSerialColour;   // nothing free: the serial bucket
+                    info[wm[j]] = (in[j] & 0xFF) | (c << 8);
+                    // its marks go at once (nobody else can equal them: the others in these slots read either this priority or zero and stay)
+                    if (ws[j] & 0x8000u) { atomicOr((unsigned long long *)&used[ia[j]], 1ull << c); mark[ws[j] & 0x7FFFu] = 0; }
+                    if (ws[j] >> 31) { atomicOr((unsigned long long *)&used[ib[j]], 1ull << c); mark[(ws[j] >> 16) & 0x7FFFu] = 0; }
+                    em[we[j]] = 0xFFFFFFFFu;
+                }
+        }
+        __threadfence_block(); __syncthreads();   // the marks have been read; the colours' atomics are at the L2 before the next round reads `used`
+        uint32_t kept = 0;
+        for (uint32_t k = 0; k < mine; ++k) {                                // the survivors clear their slots and move to the front of the column
+            const uint32_t e = tid + k * blockDim.x, m = em[e];
+            if (m == 0xFFFFFFFFu) continue;
+            const uint32_t s = es[e];
+            if (s & 0x8000u) mark[s & 0x7FFFu] = 0;
+            if (s >> 31) mark[(s >> 16) & 0x7FFFu] = 0;
+            const uint32_t to = tid + kept * blockDim.x;
+            if (to != e) { em[to] = m; es[to] = s; }
+            ++kept;
+        }
+        mine = kept;
+        if (__ballot(mine != 0) && (tid & 63u) == 0) alive[round & 1] = 1;
+        __syncthreads();
+        if (!alive[round & 1]) { ++round; break; }
+    }
+    // what max_rounds left over goes to the multi-block rounds (their marks were cleared by k_col_prepare and never touched here)
+    uint32_t left = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) left += __shfl_xor(left, off);
+    if ((tid & 63u) == 0 && left) atomicAdd(&left_sum, left);
+    __syncthreads();
+    if (tid == 0) { cnt->uncoloured = left_sum; cnt->col_wg_rounds = round; }
 }
 __global__ void k_col_best(uint32_t M, const uint32_t *__restrict__ info, const uint32_t *__restrict__ bA,
                            const uint32_t *__restrict__ bB, const uint32_t *__restrict__ flags, uint64_t *best_cur,
@@ -3434,18 +3532,26 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
     };
     // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
     // could not finish (a long list, or more rounds than it runs) is left to the multi-block rounds below.
-    if (c->col_lds_edges == 0) {   // endpoints of the listed edges live in LDS: as many as one workgroup may have (8 bytes each)
+    static const bool col_lds_env = !(getenv("EDYNHIP_COL_LDS") && getenv("EDYNHIP_COL_LDS")[0] == '0');   // developer knob (A/B): the rounds with their marks in global memory
+    constexpr uint32_t kColMinTable = 8192;   // mark slots the longest list still leaves room for
+    if (c->col_lds_edges == 0) {   // the listed edges and the mark table live in LDS: as much as one workgroup may have (8 bytes per edge + 4 per slot)
         int max_lds = 0;
         (void)hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
-        uint32_t edges = std::min<uint32_t>(kColUncCap, max_lds > 2048 ? (uint32_t)(max_lds - 1024) / 8u : 4096u);
-        if (edges * 8u > 48u * 1024u && hipFuncSetAttribute((const void *)k_col_rounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(edges * 8u)) != hipSuccess) {
+        uint32_t bytes = max_lds > 65536 ? (uint32_t)max_lds - 1024u : 48u * 1024u;
+        const void *fn = col_lds_env ? (const void *)k_col_rounds : (const void *)k_col_rounds_global;
+        if (bytes > 48u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             (void)hipGetLastError();
-            edges = 48u * 1024u / 8u;
+            bytes = 48u * 1024u;
         }
-        c->col_lds_edges = edges;
+        c->col_lds_bytes = bytes;
+        c->col_lds_edges = std::min<uint32_t>(kColUncCap, (bytes - (col_lds_env ? 4u * kColMinTable : 0u)) / 8u);
     }
-    hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
-                       c->col_unc, c->col_lds_edges, 256u);
+    if (col_lds_env)
+        hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_bytes, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->cnt,
+                           c->col_unc, c->col_lds_edges, c->col_lds_bytes / 4u, 256u);
+    else
+        hipLaunchKernelGGL(k_col_rounds_global, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
+                           c->col_unc, c->col_lds_edges, 256u);
     EH_TRY(sort_and_fetch());
     *first_final = c->cnt_host->uncoloured == 0;
     if (c->cnt_host->uncoloured != 0) {
@@ -3461,7 +3567,7 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
         EH_TRY(sort_and_fetch());
     }
     // (no contact count is an error any more: what does not fit the 62 parallel colours goes to the serial bucket, ctx.hpp)
-    c->stats.colour_rounds = total_rounds;
+    c->stats.colour_rounds = total_rounds + c->cnt_host->col_wg_rounds;
     uint32_t nc = 0, na = 0;
     for (uint32_t k = 0; k < kMaxColours; ++k) {
         uint32_t begin = 0xFFFFFFFFu, pos = 0, cnt4[4];
