@@ -256,8 +256,8 @@ struct Shard {
 
 class Pool {   // one persistent host thread per shard (a context is single-threaded; its step spins on its own counters)
 public:
-    explicit Pool(uint32_t n) : n_(n) {
-        for (uint32_t r = 0; r < n; ++r) threads_.emplace_back([this, r] { loop(r); });
+    explicit Pool(uint32_t n) : n_(n), serial_(getenv("EDYNHIP_WORLD_SERIAL") != nullptr) {   // (developer knob: every shard on the caller's thread)
+        if (!serial_) for (uint32_t r = 0; r < n; ++r) threads_.emplace_back([this, r] { loop(r); });
     }
     ~Pool() {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
@@ -266,6 +266,7 @@ public:
     }
     void run(const std::function<void(uint32_t)> &fn) {
         if (n_ == 1) { fn(0); return; }
+        if (serial_) { for (uint32_t r = 0; r < n_; ++r) fn(r); return; }
         { std::lock_guard<std::mutex> g(m_); fn_ = &fn; pending_ = n_; ++gen_; }
         cv_.notify_all();
         std::unique_lock<std::mutex> l(m_);
@@ -288,6 +289,7 @@ private:
         }
     }
     uint32_t n_;
+    bool serial_;
     std::vector<std::thread> threads_;
     std::mutex m_;
     std::condition_variable cv_, done_;

@@ -27,6 +27,7 @@
 //     body's previous manifold and hands it on to the next - no kernel boundary or barrier per colour;
 //   * per colour (scenes with joints, or when the resident-grid launch is refused): one launch per colour with one
 //     manifold per lane (k_contact_solve, k_joint_solve, k_pos_contacts, k_pos_joints).
+#include <mutex>
 #include "ctx.hpp"
 #include "dpolyhedron.hpp"
 
@@ -3409,7 +3410,17 @@ int refresh_derived(edynhip_ctx *c) {
 // the spin limit still turns a violated assumption into an error instead of a hang.
 static hipError_t launch_resident(edynhip_ctx *c, const void *kernel, uint32_t grid, uint32_t block, void **params) {
     if (c->cfg.flags & EDYNHIP_FLAG_EXCLUSIVE_DEVICE) return hipLaunchKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
-    return hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
+    // One cooperative launch at a time per device: contexts of several host threads on ONE device (the multi-GPU world on a single GPU,
+    // edynhip_world_create with a device listed more than once) otherwise enter the runtime's cooperative-launch path concurrently, and the
+    // process then dies in the runtime's exit handler (ROCm 7.2: hsa_shut_down, `scripts/exit_probe.py multi2`). Uncontended on a node with one context per GPU.
+    // A context's FIRST cooperative launch (whatever the runtime sets up lazily for it) is alone in the process.
+    static std::mutex coop_launch[64], coop_first;
+    std::unique_lock<std::mutex> first(coop_first, std::defer_lock);
+    if (!c->coop_launched) first.lock();
+    std::lock_guard<std::mutex> guard(coop_launch[(uint32_t)c->device & 63u]);
+    const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(block), params, 0, c->stream);
+    c->coop_launched = true;
+    return e;
 }
 static void rec(edynhip_ctx *c, int idx) {
     if (c->timer.e && ((c->timer.mask >> idx) & 1u)) (void)hipEventRecord(c->timer.e[idx], c->stream);

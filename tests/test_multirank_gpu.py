@@ -134,3 +134,15 @@ def test_island_boxes_reduced_on_the_device():
     order = np.argsort(lab[:n.value])
     assert np.array_equal(lab[:n.value][order], isl.astype(np.uint32))
     assert np.array_equal(bx[:n.value][order], boxes)
+
+
+def test_a_process_that_stepped_a_multi_world_exits_cleanly():
+    """Several shards of a world on ONE device step from one host thread each; their cooperative launches used to enter the runtime
+    concurrently and the process then died in the runtime's exit handler (SIGSEGV in hsa_shut_down after the script's last line).
+    solver.hip launch_resident serialises them per device: the process must end with status 0."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("multi2", "multi4_gloo"):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "exit_probe.py"), mode], cwd=root, capture_output=True, text=True, timeout=300)
+        assert "end of script" in r.stdout, r.stdout + r.stderr
+        assert r.returncode == 0, f"{mode}: exit status {r.returncode}\n{r.stdout[-500:]}\n{r.stderr[-500:]}"
