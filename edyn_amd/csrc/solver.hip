@@ -139,7 +139,9 @@ __global__ void k_cc_hook_bodies(uint32_t n, Manifolds mf, uint32_t M, const uin
             for (uint32_t s = s0; s < s1; ++s) {
                 if (((mf.info[s] & 0xFF) != 0) != (pass == 0)) continue;
                 const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
-                if (is_dynamic(flags[lo]) && cc_union(island, i, lo)) { mf.tree[s] = 1; ++marks; }
+                if (!is_dynamic(flags[lo])) continue;
+                if (island[i] == island[lo]) continue;   // both under the same node: one tree already (two loads instead of two walks; most edges of a pile end here)
+                if (cc_union(island, i, lo)) { mf.tree[s] = 1; ++marks; }
             }
     }
     cc_count_marks(marks, cnt);
@@ -447,14 +449,14 @@ __global__ void __launch_bounds__(1024) k_col_prepare(uint32_t M, uint32_t *__re
 // between rounds (round 5: the workgroup is bound by the memory requests one CU can issue - a restless heap of polyhedra lists 15 000
 // edges per step and still has two thirds of them after three rounds; the zeroing stores were two of six requests per edge and round).
 // Longer lists, and what is left after max_rounds, go to the multi-block rounds (the host sees cnt->uncoloured != 0).
-__global__ void __launch_bounds__(1024) k_col_rounds_global(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+__global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
                                                      const uint32_t *__restrict__ flags, uint64_t *best0, uint64_t *best1, uint64_t *used, Counters *cnt,
                                                      uint32_t *list, uint32_t cap, uint32_t max_rounds) {
     extern __shared__ uint32_t col_lds[];   // ea[cap], eb[cap]
     uint32_t *ea = col_lds, *eb = col_lds + cap;
     __shared__ uint32_t live, wr;
     const uint32_t n0 = cnt->unc_count;
-    if (n0 == 0 || n0 > cap) return;
+    if (n0 == 0 || n0 > cap) { if (threadIdx.x == 0) cnt->col_wg_rounds = 0; return; }
     for (uint32_t e = threadIdx.x; e < n0; e += blockDim.x) {
         const uint32_t m = list[e], a = bA[m], b = bB[m];
         ea[e] = a | (is_dynamic(flags[a]) ? 0x80000000u : 0u);
@@ -519,9 +521,11 @@ __global__ void __launch_bounds__(1024) k_col_rounds_global(uint32_t *info, cons
             if (b >> 31) { best0[b & 0x7FFFFFFFu] = 0; best1[b & 0x7FFFFFFFu] = 0; }
         }
     }
-    if (threadIdx.x == 0) cnt->uncoloured = left;
+    if (threadIdx.x == 0) { cnt->uncoloured = left; cnt->col_wg_rounds = round; }
 }
-// Round 6: the same rounds with the endpoint marks in LDS. The kernel above spends its time on the memory requests one CU can issue - eight
+// Round 6, an experiment kept behind EDYNHIP_COL_LDS=1 (measured: 3 % faster on the polyhedron heap, 1-2 us SLOWER per step on every pile - the
+// 159 KB of LDS it asks for and its clearing - so k_col_rounds above stays the default; the two are compared by
+// test_colouring_rounds_in_lds_and_in_global_memory_colour_alike): the same rounds with the endpoint marks in LDS. The kernel above spends its time on the memory requests one CU can issue - eight
 // scattered 8-byte requests per listed edge and round (two marks set, two read, the list read twice and rewritten), 15 000 edges and ~32
 // rounds on a restless heap. Here the list, the edges' endpoints and the marks live in LDS; global memory is touched once per edge, when it
 // takes its colour. The marks are a HASHED table (slot = hash(body), 4 bytes: the priority): two bodies may share a slot, and then an edge is
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(1024) k_col_rounds_global(uint32_t *info, cons
 // colour a round later, never earlier: it still takes it after all its higher-priority neighbours and before all lower ones, and the result
 // is the greedy colouring in priority order whatever the rounds were (winners of one round are never adjacent). Every thread owns the edges
 // t, t + 1024, ... and keeps its survivors packed at the front of that column: no list compaction across threads, three barriers per round.
-__global__ void __launch_bounds__(1024) k_col_rounds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
+__global__ void __launch_bounds__(1024) k_col_rounds_lds(uint32_t *info, const uint32_t *__restrict__ bA, const uint32_t *__restrict__ bB,
                                                      const uint32_t *__restrict__ flags, uint64_t *used, Counters *cnt,
                                                      const uint32_t *__restrict__ list, uint32_t cap, uint32_t lds_words, uint32_t max_rounds) {
     extern __shared__ uint32_t col_lds[];   // em[n0] manifold, es[n0] endpoint slots (slot A | dynamic A << 15 | slot B << 16 | dynamic B << 31), mark[T]
@@ -3543,13 +3547,13 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
     };
     // Steady state: the few new edges are coloured by one workgroup (k_col_rounds) and ONE fetch brings the offsets; what it
     // could not finish (a long list, or more rounds than it runs) is left to the multi-block rounds below.
-    static const bool col_lds_env = !(getenv("EDYNHIP_COL_LDS") && getenv("EDYNHIP_COL_LDS")[0] == '0');   // developer knob (A/B): the rounds with their marks in global memory
+    static const bool col_lds_env = getenv("EDYNHIP_COL_LDS") && getenv("EDYNHIP_COL_LDS")[0] == '1';   // developer knob (A/B): the rounds with their marks in a hashed LDS table (k_col_rounds)
     constexpr uint32_t kColMinTable = 8192;   // mark slots the longest list still leaves room for
     if (c->col_lds_edges == 0) {   // the listed edges and the mark table live in LDS: as much as one workgroup may have (8 bytes per edge + 4 per slot)
         int max_lds = 0;
         (void)hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
         uint32_t bytes = max_lds > 65536 ? (uint32_t)max_lds - 1024u : 48u * 1024u;
-        const void *fn = col_lds_env ? (const void *)k_col_rounds : (const void *)k_col_rounds_global;
+        const void *fn = col_lds_env ? (const void *)k_col_rounds_lds : (const void *)k_col_rounds;
         if (bytes > 48u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             (void)hipGetLastError();
             bytes = 48u * 1024u;
@@ -3558,10 +3562,10 @@ static int colour_contacts(edynhip_ctx *c, Between between, bool *first_final) {
         c->col_lds_edges = std::min<uint32_t>(kColUncCap, (bytes - (col_lds_env ? 4u * kColMinTable : 0u)) / 8u);
     }
     if (col_lds_env)
-        hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_bytes, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->cnt,
+        hipLaunchKernelGGL(k_col_rounds_lds, dim3(1), dim3(1024), (size_t)c->col_lds_bytes, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->used, c->cnt,
                            c->col_unc, c->col_lds_edges, c->col_lds_bytes / 4u, 256u);
     else
-        hipLaunchKernelGGL(k_col_rounds_global, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
+        hipLaunchKernelGGL(k_col_rounds, dim3(1), dim3(1024), (size_t)c->col_lds_edges * 8u, s, mf.info, mf.bodyA, mf.bodyB, c->b.flags, c->best[0], c->best[1], c->used, c->cnt,
                            c->col_unc, c->col_lds_edges, 256u);
     EH_TRY(sort_and_fetch());
     *first_final = c->cnt_host->uncoloured == 0;
