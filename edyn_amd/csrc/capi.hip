@@ -572,6 +572,8 @@ edynhip_ctx *edynhip_create(const edynhip_config *cfg, int *status_out) {
 
 void edynhip_destroy(edynhip_ctx *c) {
     if (!c) return;
+    if (getenv("EDYNHIP_TREE_STATS"))   // developer knob: how the island labels were kept up to date (solver.hip islands)
+        fprintf(stderr, "[edynhip] island labels: %llu steps relabelled in full, %llu incrementally\n", (unsigned long long)c->cc_full_steps, (unsigned long long)c->cc_incremental_steps);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);

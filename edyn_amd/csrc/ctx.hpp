@@ -323,6 +323,7 @@ struct edynhip_ctx {
     uint32_t *cs_hist = nullptr, *cs_start = nullptr;            // [256 keys][blocks of 1024 manifolds]
     uint32_t *cs_sup = nullptr;    // [16][256 keys] key counts of every 16 blocks (direct colour sort, solver.hip k_cs_*)
     uint32_t col_lds_edges = 0;   // listed edges k_col_rounds holds in LDS (set at the first colouring)
+    uint64_t cc_full_steps = 0, cc_incremental_steps = 0;   // how the island labels were brought up to date, step by step (EDYNHIP_TREE_STATS)
     bool coop_launched = false;   // this context has made a cooperative launch (solver.hip launch_resident)
     uint32_t col_lds_bytes = 0;   // dynamic LDS of that launch: the edges and the hashed mark table
     uint32_t *col_unc = nullptr;                                 // this step's uncoloured edges (k_col_rounds), kColUncCap entries

@@ -89,6 +89,11 @@ DI void cc_count_marks(uint32_t marks, Counters *cnt) {   // every lane of the w
 // CC_FULL only: every body starts at its smallest dynamic lower-index neighbour it has CONTACT POINTS with (its manifolds
 // with lower-index partners are the contiguous segment [seg_start, seg_end) of the sorted array). Links point to smaller
 // indices, so this is a valid forest and most unions below find their roots already merged. Clears the segment's marks.
+// (Round 6, built, measured and withdrawn - profiles/r06_tree_repair_experiment/, the patch is kept there: LOCAL REPAIR of the certificate. k_bp_pairs
+//  listed the marked manifolds the new pair set drops, an extra workgroup of k_bp_compact looked for a replacement path a - c - b over manifolds
+//  that exist in both arrays (c among a's lower-index partners) and marked it, the host then kept the incremental mode. Bit-exact, but a step
+//  drops SEVERAL certificate manifolds and every one needs its path: 8 of 135 relabelling steps repaired on the headline pile, 20 of 384 on
+//  mixed32k, 13 of 129 on islands256k, none on the polyhedron heap, which paid 4 % for the listing. EDYNHIP_TREE_STATS=1 prints the counts.)
 // (Round 6, measured and dropped: offering the edges in classes of decreasing STABILITY - manifolds whose oldest point has lived for 32 steps,
 //  then the other manifolds with points, then the pointless ones - so that the certificate consists of long-lived contacts. The number of
 //  steps that relabel in full did not move (mixed32k 372 against 373 of 440, pile32k 127 / 128, islands256k 277 / 277, the polyhedron heap
@@ -3453,6 +3458,7 @@ int islands(edynhip_ctx *c) {
     const int mode = force ? CC_FULL : inplace ? CC_SKIP
                      : (c->full_step && c->cnt_host->tree_found == c->cnt_host->tree_total) ? CC_INCREMENTAL : CC_FULL;
     (void)pm;
+    if (mode == CC_FULL) ++c->cc_full_steps; else if (mode == CC_INCREMENTAL) ++c->cc_incremental_steps;
     // island sleeping: last step's labels, before the hooks rewrite them (the merge rule of k_sleep_sizes / k_sleep_carry reads them)
     if (sleeping && mode != CC_SKIP && c->sleep_old_label)
         EH_HIP(c, hipMemcpyAsync(c->sleep_old_label, c->b.island, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
