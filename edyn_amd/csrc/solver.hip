@@ -139,15 +139,22 @@ __global__ void k_cc_hook_bodies(uint32_t n, Manifolds mf, uint32_t M, const uin
     uint32_t marks = 0;
     if (i < n && M != 0 && is_dynamic(flags[i])) {
         const uint32_t s0 = mf.seg_start[i], s1 = mf.seg_end[i];
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass)
-            for (uint32_t s = s0; s < s1; ++s) {
-                if (((mf.info[s] & 0xFF) != 0) != (pass == 0)) continue;
-                const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
-                if (!is_dynamic(flags[lo])) continue;
-                if (island[i] == island[lo]) continue;   // both under the same node: one tree already (two loads instead of two walks; most edges of a pile end here)
-                if (cc_union(island, i, lo)) { mf.tree[s] = 1; ++marks; }
-            }
+        auto hook = [&](uint32_t s) {
+            const uint32_t lo = (uint32_t)(mf.skey[s] >> 1);
+            if (!is_dynamic(flags[lo])) return;
+            if (island[i] == island[lo]) return;   // both under the same node: one tree already (two loads instead of two walks; most edges of a pile end here)
+            if (cc_union(island, i, lo)) { mf.tree[s] = 1; ++marks; }
+        };
+        // the manifolds with contact points first; the others are remembered (a bit each: an owner keeps at most kOwnCap = 64 in its segment,
+        // longer segments take the plain second pass) and visited afterwards without reading the point counts again
+        uint64_t later = 0;
+        const bool fits = s1 - s0 <= 64u;
+        for (uint32_t s = s0; s < s1; ++s) {
+            if ((mf.info[s] & 0xFF) != 0) hook(s);
+            else if (fits) later |= 1ull << (s - s0);
+        }
+        if (fits) for (; later; later &= later - 1) hook(s0 + (uint32_t)__ffsll((long long)later) - 1u);
+        else for (uint32_t s = s0; s < s1; ++s) if ((mf.info[s] & 0xFF) == 0) hook(s);
     }
     cc_count_marks(marks, cnt);
 }
