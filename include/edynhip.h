@@ -178,7 +178,7 @@ typedef struct {
 
 typedef struct {
     uint32_t num_bodies, num_manifolds, num_points, num_active_manifolds, num_islands, num_colours,
-             num_joint_colours, colour_rounds, num_joints, num_joint_rows;
+             num_joint_colours, colour_rounds, num_joints, num_joint_rows;   /* colour_rounds: rounds the last step's contact colouring took (the one-workgroup rounds + the multi-block ones) */
     uint32_t solve_schedule;         /* EDYNHIP_SCHEDULE_*: which velocity-solve kernels the last step launched */
     uint32_t colour_size[64];        /* manifolds per solver colour in the last step */
 } edynhip_stats;
