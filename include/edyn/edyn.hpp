@@ -482,6 +482,7 @@ struct gpu_stepper {
     bool removal_pending{true};                                     // an on_destroy hook fired (or nothing is known yet): sync_removed has work
     bool records_pending{false};                                    // a record snapshot of the previous update is in flight (asynchronous mode)
     float present_dt{0};                                            // update_presentation's interpolation_dt of the update in progress
+    bool prefetch_on{false};                                        // the context copies its contact events ahead of the step's state (edynhip_set_event_prefetch): what write_back reads
     bool present_this_call{true};                                   // edyn::update refreshes present_*; edyn::step_simulation does not (stepper_sequential.cpp:121-147 never calls update_presentation)
     bool hooks_connected{false};
     bool host_presentation{false};                                  // this update's presentation transforms were not part of a write-back: compute them on the host
@@ -801,9 +802,11 @@ inline void upload_scene(entt::registry &registry, gpu_stepper &s) {
         s.meshes.clear();   // meshes belong to the context
         if (!s.ctx) throw stepper_error(st, std::string("edynhip_create: ") + edynhip_last_error(nullptr));
         if (s.should_collide) check(s, edynhip_set_pair_filter(s.ctx, &pair_filter_trampoline, &s));   // a re-created context asks the same predicate
-        // contact entities follow the narrowphase, not the end of the step (edynhip.h "Contact-event prefetch"): the host builds them while the solve runs
-        // (also in asynchronous mode, whose step callbacks and edits take the synchronous write-back: the prefetch is 200 KB of copy per step call)
-        if (s.cfg.materialize_contacts) check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max));
+        // contact entities follow the narrowphase, not the end of the step (edynhip.h "Contact-event prefetch"): the host builds them while the solve runs.
+        // Asynchronous mode reads its events with the record snapshots and only takes the synchronous write-back for step callbacks: the
+        // prefetch (a pack kernel and up to 200 KB of copy per step call) is switched on there when a callback is first seen (run_steps)
+        s.prefetch_on = s.cfg.materialize_contacts && (s.cfg.execution_mode != execution_mode::asynchronous || s.pre_step || s.post_step);
+        if (s.prefetch_on) check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max));
         s.capacity = c.max_bodies; s.joint_capacity = c.max_joints;
         s.params_dirty = false;
     }
@@ -1253,6 +1256,7 @@ inline void run_steps(entt::registry &registry, gpu_stepper &s, unsigned steps, 
     if (s.pre_step || s.post_step) {
         // step callbacks (stepper_sequential.cpp:76-78,97-99) see the registry between steps: one step per launch, the state
         // written back after each, edits made by a callback (followed by edyn::refresh) uploaded before the next
+        if (s.cfg.materialize_contacts && !s.prefetch_on) { check(s, edynhip_set_event_prefetch(s.ctx, prefetch_events_max)); s.prefetch_on = true; }   // (callbacks set on a running asynchronous world)
         for (unsigned k = 0; k < steps; ++k) {
             if (s.pre_step) s.pre_step(registry);
             if (s.state_dirty) upload_state(registry, s);
